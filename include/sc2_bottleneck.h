@@ -1,0 +1,171 @@
+/*
+ * sc2_bottleneck.h -- C-ABI of libsc2amd.so, the MI355X (gfx950) implementation of the
+ * supervised-compression bottleneck hot path of sc2bench.
+ *
+ * The reference has no FFI of its own: the path sits behind Python nn.Modules
+ * (sc2bench/models/layer.py) that call CompressAI (Python + two pybind11
+ * extensions) and torch's conv kernels.  Each entry point below names the
+ * reference interface it replaces (file:line under the sc2bench tree, or the
+ * CompressAI symbol the reference calls at that line).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All device
+ *    work is enqueued on it; nothing synchronises, nothing allocates.
+ *  - every buffer is caller-allocated device memory unless marked HOST.
+ *  - return value: 0 = success, negative = error (SC2_ERR_*).  No exceptions cross
+ *    the boundary.  sc2_last_error() returns a thread-local message.
+ *  - stateless and re-entrant.
+ */
+#ifndef SC2_BOTTLENECK_H
+#define SC2_BOTTLENECK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC2_OK 0
+#define SC2_ERR_INVALID_ARG (-1)
+#define SC2_ERR_UNSUPPORTED (-2)
+#define SC2_ERR_DOMAIN (-3)      /* pmf has a negative / non-finite entry (std::domain_error upstream) */
+#define SC2_ERR_ZERO_PMF (-4)    /* pmf sums to zero */
+#define SC2_ERR_LAUNCH (-5)      /* hip launch error */
+#define SC2_ERR_NO_DEVICE (-6)
+#define SC2_ERR_INTERNAL (-7)
+
+/* ABI version: bumped on any signature change. */
+#define SC2_ABI_VERSION 3
+int sc2_abi_version(void);
+const char *sc2_last_error(void);
+/* number of visible HIP devices (0 on a CPU-only box); never throws. */
+int sc2_device_count(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Layout conversion                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+/* x: f32 NCHW [N,C,H,W]  ->  y: bf16 NHWC [N,H,W,Cpad] (channels c>=C zero-filled).
+ * Replaces the implicit layout of the tensor handed to nn.Conv2d at layer.py:475. */
+int sc2_nchw_f32_to_nhwc_bf16(const float *x, void *y, int N, int C, int H, int W, int Cpad, void *stream);
+/* x: bf16 NHWC [N,H,W,C] -> y: f32 NCHW [N,C,H,W] (what a reference caller sees). */
+int sc2_nhwc_bf16_to_nchw_f32(const void *x, float *y, int N, int C, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Implicit-GEMM convolution on the matrix cores (bf16 in, f32 accumulate)                    */
+/* Replaces nn.Conv2d(bias=False) at layer.py:475-476,479-480,482-483 (encoder) and            */
+/* 485-486,489-490,492-493 (decoder); with a_op/epilogue set, CompressAI GDN1.forward at       */
+/* layer.py:478,481,488,491 (norm = conv2d(|x|, gamma 1x1, beta); y = x/norm or x*norm).       */
+/* ------------------------------------------------------------------------------------------ */
+enum sc2_conv_aop { SC2_AOP_NONE = 0, SC2_AOP_ABS = 1 };
+enum sc2_conv_epilogue {
+    SC2_EPI_NONE = 0,
+    SC2_EPI_GDN = 1,  /* y = ep_x / (ep_beta[c] + acc)   (GDN1, inverse=False) */
+    SC2_EPI_IGDN = 2, /* y = ep_x * (ep_beta[c] + acc)   (GDN1, inverse=True)  */
+    SC2_EPI_BIAS = 3, /* y = acc + ep_beta[c]            (conv + bias / folded BN) */
+    SC2_EPI_BIAS_RELU = 4,     /* y = relu(acc + ep_beta[c]) */
+    SC2_EPI_BIAS_ADD_RELU = 5  /* y = relu(acc + ep_beta[c] + ep_x) (residual add) */
+};
+enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHWC = 2 };
+
+typedef struct sc2_conv_desc {
+    int32_t N, H, W, Cin;          /* input  : bf16 NHWC [N,H,W,Cin], Cin % 8 == 0              */
+    int32_t Cout;                  /* output channels, Cout % 8 == 0                             */
+    int32_t KH, KW;                /* filter taps                                                */
+    int32_t stride_h, stride_w;
+    int32_t pad_h, pad_w;
+    int32_t OH, OW;                /* output spatial size (caller computes, library validates)   */
+    int32_t a_op;                  /* enum sc2_conv_aop: transform applied to the input on load  */
+    int32_t epilogue;              /* enum sc2_conv_epilogue                                     */
+    int32_t out_format;            /* enum sc2_conv_out                                          */
+    int32_t Kpad;                  /* row pitch (elements) of the packed weights, % 64 == 0      */
+    int32_t Cout_pad;              /* rows of the packed weight matrix (>= Cout, % 128 == 0 or
+                                      == tile width; see sc2_conv_weight_rows)                   */
+} sc2_conv_desc;
+
+/* Rows the packed weight buffer must have for a given Cout (zero rows beyond Cout). */
+int sc2_conv_weight_rows(int Cout);
+/* Row pitch (elements) the packed weight buffer must have for K = KH*KW*Cin. */
+int sc2_conv_weight_pitch(int K);
+
+/* w_packed: bf16 [Cout_pad][Kpad], element (co, (kh*KW+kw)*Cin + ci); zero padded.
+ * ep_x   : bf16 NHWC [N,OH,OW,Cout] for GDN/IGDN/ADD epilogues (NULL otherwise)
+ * ep_beta: f32 [Cout] for GDN/IGDN/BIAS epilogues (NULL otherwise)
+ * y      : per out_format. */
+int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
+                   const void *ep_x, const float *ep_beta, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Entropy bottleneck (factorised prior), filters fixed to (3,3,3,3) as sc2bench uses them     */
+/* Replaces CompressAI EntropyBottleneck.forward called at layer.py:531 (and wrapper.py:238),  */
+/* EntropyModel.quantize/dequantize at layer.py:545-547.                                       */
+/* ------------------------------------------------------------------------------------------ */
+#define SC2_EB_PARAM_STRIDE 64
+/* Per-channel parameter block (f32[64]); "sp" = softplus(matrix), "th" = tanh(factor):
+ *  [0..2]   sp(M0)[3x1]  [3..5]   b0[3]  [6..8]   th(f0)[3]
+ *  [9..17]  sp(M1)[3x3]  [18..20] b1[3]  [21..23] th(f1)[3]
+ *  [24..32] sp(M2)[3x3]  [33..35] b2[3]  [36..38] th(f2)[3]
+ *  [39..47] sp(M3)[3x3]  [48..50] b3[3]  [51..53] th(f3)[3]
+ *  [54..56] sp(M4)[1x3]  [57]     b4     [58]     median (quantiles[c,0,1])   [59..63] 0 */
+enum sc2_eb_mode { SC2_EB_NOISE = 0, SC2_EB_DEQUANTIZE = 1 };
+
+/* y        : f32 NCHW [N,C,HW]
+ * noise    : f32 NCHW, same shape (mode NOISE: y_hat = y + noise; ignored otherwise; the caller
+ *            draws U(-1/2,1/2) as the reference does with torch.empty_like().uniform_())
+ * y_hat    : f32 NCHW out (nullable)
+ * y_hat_bf16_nhwc : bf16 NHWC out, the decoder's input (nullable)
+ * lik      : f32 NCHW out = max(sigmoid(L(y_hat+.5)) - sigmoid(L(y_hat-.5)), lik_bound) (nullable)
+ * bits_partial : f32 [N*C*gridDim.y] partial sums of -log2(lik) (nullable; n_partial receives count)
+ */
+int sc2_eb_forward(const float *y, const float *noise, const float *params, int N, int C, int HW,
+                   int mode, float lik_bound, float *y_hat, void *y_hat_bf16_nhwc, float *lik,
+                   float *bits_partial, int bits_partial_len, void *stream);
+/* number of partial sums sc2_eb_forward writes for this problem size */
+int sc2_eb_bits_partial_len(int N, int C, int HW);
+
+/* symbols = int32(round_half_even(y - median[c])) in NCHW order, one row of C*HW per image.
+ * Replaces EntropyModel.quantize(x, "symbols", means) reached from layer.py:506. */
+int sc2_eb_symbols(const float *y, const float *medians, int N, int C, int HW, int32_t *symbols, void *stream);
+/* y_hat = float(symbols) + median[c]   (EntropyModel.dequantize reached from layer.py:520). */
+int sc2_eb_dequantize(const int32_t *symbols, const float *medians, int N, int C, int HW, float *y_hat_f32_nchw,
+                      void *y_hat_bf16_nhwc, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* CDF quantisation (HOST function, bit-exact integer result)                                  */
+/* Replaces compressai._CXX.pmf_to_quantized_cdf reached from layer.py:431-441 (update()).     */
+/* pmf: HOST f32[n]; cdf: HOST u32[n+1].                                                       */
+/* ------------------------------------------------------------------------------------------ */
+int sc2_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf);
+
+/* ------------------------------------------------------------------------------------------ */
+/* rANS (64-bit state, 32-bit renormalisation, 16-bit precision, 4-bit bypass), one stream per */
+/* image, all streams of a batch in one launch.  Bit-exact to CompressAI's                     */
+/* RansEncoder.encode_with_indexes / RansDecoder.decode_with_indexes (layer.py:506,520).       */
+/* ------------------------------------------------------------------------------------------ */
+/* symbols : i32 [n_streams][n_sym]
+ * indexes : i32 [n_streams][n_sym] CDF row per symbol, or NULL -> row = position / index_div
+ *           (the entropy bottleneck's indexes[n,c,h,w] = c with index_div = H*W)
+ * cdfs    : i32 [n_cdfs][cdf_stride];  cdf_sizes, offsets : i32 [n_cdfs]
+ * out     : u8  [n_streams][out_stride]; stream i occupies
+ *           out[i*out_stride + out_offset[i] .. + out_nbytes[i])  (streams are END-aligned in
+ *           their rows because rANS emits its words back to front)
+ * out_stride must be >= sc2_rans_max_bytes(n_sym); out_stride % 4 == 0.
+ * status  : i32 [n_streams] 0 ok, 1 = row overflow (cannot happen with sc2_rans_max_bytes).
+ */
+int64_t sc2_rans_max_bytes(int64_t n_sym);
+int sc2_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, int64_t index_div, int n_streams,
+                          int64_t n_sym, const int32_t *cdfs, int n_cdfs, int cdf_stride,
+                          const int32_t *cdf_sizes, const int32_t *offsets, uint8_t *out, int64_t out_stride,
+                          int32_t *out_offset, int32_t *out_nbytes, int32_t *status, void *stream);
+/* in : u8 [n_streams][in_stride], stream i at in[i*in_stride + in_offset[i] ..+in_nbytes[i]),
+ *      in_offset[i] % 4 == 0.  symbols_out : i32 [n_streams][n_sym]. */
+int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const int32_t *in_offset, const int32_t *in_nbytes,
+                          const int32_t *indexes, int64_t index_div, int n_streams, int64_t n_sym,
+                          const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                          const int32_t *offsets, int32_t *symbols_out, int32_t *status, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC2_BOTTLENECK_H */

@@ -1,0 +1,16 @@
+"""sc2bench_amd: MI355X-native implementation of sc2bench's supervised-compression bottleneck path.
+
+The directory is named ``sc2-benchmark_amd`` (not an importable identifier); ``sc2bench_amd.py`` at the
+repository root loads it under the module name ``sc2bench_amd``.
+"""
+from . import hip  # noqa: F401
+from .analysis import ANALYZER_CLASS_DICT, AnalyzableModule, FileSizeAccumulator, FileSizeAnalyzer  # noqa: F401
+from .backbone import (BACKBONE_CLASS_DICT, BACKBONE_FUNC_DICT, MODEL_DICT, SplittableResNet,  # noqa: F401
+                       UpdatableBackbone, check_if_updatable, get_backbone, splittable_resnet)
+from .entropy import (CompressionModel, EntropyBottleneck, GDN1, HipConv2d, LowerBound,  # noqa: F401
+                      NonNegativeParametrizer)
+from .layer import (LAYER_CLASS_DICT, LAYER_FUNC_DICT, BaseBottleneck, EntropyBottleneckLayer,  # noqa: F401
+                    FPBasedResNetBottleneck, get_layer, register_layer_class, register_layer_func)
+from .loss import BppLoss  # noqa: F401
+
+__version__ = '0.1.0'

@@ -1,0 +1,188 @@
+"""Splittable backbones: host-side mirror of sc2bench/models/backbone.py for the ResNet path
+(UpdatableBackbone :47-75, SplittableResNet :175-276, splittable_resnet :658-698, registries :15-44,
+get_backbone :894-909).
+
+Forward order is the reference's: pre_transform -> bottleneck (encode/analyze/decode when updated and in
+eval mode, else bottleneck.forward) -> layer2 -> layer3 -> layer4 -> avgpool -> flatten -> fc
+(backbone.py:225-254).  ``compute_dtype='bf16'`` runs the task head in bf16 channels_last and takes the
+decoder's bf16 NHWC output without a copy.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .analysis import AnalyzableModule
+from .entropy import CompressionModel
+from .layer import get_layer
+from .resnet import RESNET_FUNC_DICT, FrozenBatchNorm2d
+
+BACKBONE_CLASS_DICT = dict()
+BACKBONE_FUNC_DICT = dict()
+MODEL_DICT = dict()  # the slice of torchdistill's model registry this package feeds
+
+
+def register_backbone_class(cls):
+    BACKBONE_CLASS_DICT[cls.__name__] = cls
+    MODEL_DICT[cls.__name__] = cls
+    return cls
+
+
+def register_backbone_func(func):
+    BACKBONE_FUNC_DICT[func.__name__] = func
+    MODEL_DICT[func.__name__] = func
+    return func
+
+
+class UpdatableBackbone(AnalyzableModule):
+    """Base class of backbones that carry an updatable (entropy-coded) bottleneck."""
+
+    def __init__(self, analyzer_configs=None):
+        super().__init__(analyzer_configs)
+        self.bottleneck_updated = False
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError()
+
+    def update(self, **kwargs):
+        raise NotImplementedError()
+
+    def get_aux_module(self, **kwargs):
+        raise NotImplementedError()
+
+
+def check_if_updatable(model):
+    return isinstance(model, UpdatableBackbone)
+
+
+class SplittableResNet(UpdatableBackbone):
+    """ResNet with its stem and layer1 replaced by a neural encoder / entropy bottleneck / decoder.
+
+    :param bottleneck_layer: bottleneck module (encoder + entropy bottleneck + decoder)
+    :param resnet_model: ResNet to take layer2..fc from
+    :param inplanes: ResNet inplanes or None
+    :param skips_avgpool: drop avgpool (and everything after)
+    :param skips_fc: drop fc
+    :param pre_transform: optional module applied to the input
+    :param analysis_config: {'analyzes_after_compress': bool, 'analyzer_configs': [...]}
+    :param short_module_names: which of layer2/3/4 to keep
+    """
+
+    def __init__(self, bottleneck_layer, resnet_model, inplanes=None, skips_avgpool=True, skips_fc=True,
+                 pre_transform=None, analysis_config=None, short_module_names=None):
+        if analysis_config is None:
+            analysis_config = dict()
+        if short_module_names is None:
+            short_module_name_set = {'layer2', 'layer3', 'layer4'}
+        else:
+            short_module_name_set = set(short_module_names)
+        super().__init__(analysis_config.get('analyzer_configs', list()))
+        self.pre_transform = pre_transform
+        self.analyzes_after_compress = analysis_config.get('analyzes_after_compress', False)
+        self.bottleneck_layer = bottleneck_layer
+        self.layer2 = resnet_model.layer2 if 'layer2' in short_module_name_set else None
+        self.layer3 = resnet_model.layer3 if 'layer3' in short_module_name_set else None
+        self.layer4 = resnet_model.layer4 if 'layer4' in short_module_name_set else None
+        self.avgpool = None if skips_avgpool \
+            else resnet_model.global_pool if hasattr(resnet_model, 'global_pool') else resnet_model.avgpool
+        self.fc = None if skips_fc else resnet_model.fc
+        self.inplanes = resnet_model.inplanes if inplanes is None else inplanes
+        self.compute_dtype = 'f32'
+
+    def set_compute_dtype(self, dtype):
+        """'f32' (reference dtype) or 'bf16' (task head in bf16 channels_last, decoder output zero-copy)."""
+        assert dtype in ('f32', 'bf16')
+        self.compute_dtype = dtype
+        head = [m for m in (self.layer2, self.layer3, self.layer4, self.avgpool, self.fc) if m is not None]
+        for m in head:
+            if dtype == 'bf16':
+                m.to(dtype=torch.bfloat16, memory_format=torch.channels_last)
+            else:
+                m.to(dtype=torch.float32)
+        if hasattr(self.bottleneck_layer, 'output_format'):
+            self.bottleneck_layer.output_format = 'bf16_nhwc' if dtype == 'bf16' else 'f32_nchw'
+        return self
+
+    def head(self, x):
+        if self.layer2 is not None:
+            x = self.layer2(x)
+        if self.layer3 is not None:
+            x = self.layer3(x)
+        if self.layer4 is not None:
+            x = self.layer4(x)
+        if self.avgpool is None:
+            return x
+        x = self.avgpool(x)
+        if self.fc is None:
+            return x
+        x = torch.flatten(x, 1)
+        return self.fc(x)
+
+    def forward(self, x):
+        if self.pre_transform is not None:
+            x = self.pre_transform(x)
+        if self.bottleneck_updated and not self.training:
+            x = self.bottleneck_layer.encode(x)
+            if self.analyzes_after_compress:
+                self.analyze(x)
+            x = self.bottleneck_layer.decode(**x)
+        else:
+            x = self.bottleneck_layer(x)
+        return self.head(x)
+
+    def forward_device(self, x):
+        """Eval-mode forward that keeps the entropy-coded streams on the device (no host round trip):
+        returns (head output, nbytes i32 [N]).  Same arithmetic as forward() in updated+eval mode."""
+        if self.pre_transform is not None:
+            x = self.pre_transform(x)
+        buf, off, nb, st, shape = self.bottleneck_layer.encode_device(x)
+        x = self.bottleneck_layer.decode_device(buf, off, nb, shape)
+        return self.head(x), nb, st
+
+    def update(self):
+        self.bottleneck_layer.update()
+        self.bottleneck_updated = True
+
+    def load_state_dict(self, state_dict, **kwargs):
+        """Loads everything but `bottleneck_layer.*` non-strictly, then the bottleneck through its own loader
+        (which resizes the CDF buffers).  Like the reference, this pops the bottleneck keys from the passed dict."""
+        entropy_bottleneck_state_dict = OrderedDict()
+        for key in list(state_dict.keys()):
+            if key.startswith('bottleneck_layer.'):
+                entropy_bottleneck_state_dict[key.replace('bottleneck_layer.', '', 1)] = state_dict.pop(key)
+        super().load_state_dict(state_dict, strict=False)
+        self.bottleneck_layer.load_state_dict(entropy_bottleneck_state_dict)
+
+    def get_aux_module(self, **kwargs):
+        return self.bottleneck_layer if isinstance(self.bottleneck_layer, CompressionModel) else None
+
+
+register_backbone_class(SplittableResNet)
+
+
+@register_backbone_func
+def splittable_resnet(bottleneck_config, resnet_name='resnet50', inplanes=None, skips_avgpool=True, skips_fc=True,
+                      pre_transform=None, analysis_config=None, org_model_ckpt_file_path_or_url=None,
+                      org_ckpt_strict=True, short_module_names=None, **resnet_kwargs):
+    """Builds a SplittableResNet from a bottleneck config {'key', 'kwargs'} and a ResNet name
+    (same signature as backbone.py:659-698)."""
+    bottleneck_layer = get_layer(bottleneck_config['key'], **bottleneck_config['kwargs'])
+    if resnet_name not in RESNET_FUNC_DICT:
+        raise KeyError('resnet_name `{}` is not available (have {})'.format(resnet_name, sorted(RESNET_FUNC_DICT)))
+    if resnet_kwargs.pop('norm_layer', '') == 'FrozenBatchNorm2d':
+        resnet_model = RESNET_FUNC_DICT[resnet_name](norm_layer=FrozenBatchNorm2d, **resnet_kwargs)
+    else:
+        resnet_model = RESNET_FUNC_DICT[resnet_name](**resnet_kwargs)
+    if org_model_ckpt_file_path_or_url is not None:
+        from .ckpt import load_ckpt
+        load_ckpt(org_model_ckpt_file_path_or_url, model=resnet_model, strict=org_ckpt_strict)
+    return SplittableResNet(bottleneck_layer, resnet_model, inplanes, skips_avgpool, skips_fc,
+                            pre_transform, analysis_config, short_module_names=short_module_names)
+
+
+def get_backbone(cls_or_func_name, **kwargs):
+    if cls_or_func_name in BACKBONE_CLASS_DICT:
+        return BACKBONE_CLASS_DICT[cls_or_func_name](**kwargs)
+    elif cls_or_func_name in BACKBONE_FUNC_DICT:
+        return BACKBONE_FUNC_DICT[cls_or_func_name](**kwargs)
+    return None

@@ -1,0 +1,54 @@
+"""Builds libsc2amd.so (HIP kernels + C-ABI, gfx950 only) in-tree with hipcc.
+
+The shared library is the product: ``sc2-benchmark_amd/libsc2amd.so`` travels with the source tree
+(git-ignored, not gpurun-ignored).  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
+LIB = os.path.join(HERE, 'libsc2amd.so')
+SOURCES = ['abi.cpp', 'cdf_host.cpp', 'layout.hip', 'conv_igemm.hip', 'entropy.hip', 'rans.hip']
+HEADERS = [os.path.join(CSRC, 'sc2_common.h'), os.path.join(HERE, '..', 'include', 'sc2_bottleneck.h')]
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
+         '-D__HIP_PLATFORM_AMD__=1']
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src + '.o')
+    if _stale(obj, [path] + HEADERS):
+        cmd = [HIPCC] + FLAGS + ['-x', 'hip', '-c', path, '-o', obj]
+        subprocess.check_call(cmd)
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if _stale(LIB, objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        subprocess.check_call(cmd)
+    if verbose:
+        print('built', LIB)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv, verbose=True)

@@ -1,0 +1,455 @@
+// Implicit-GEMM convolution for gfx950 (MI355X): bf16 NHWC activations, bf16 packed weights,
+// f32 accumulation on v_mfma_f32_16x16x32_bf16.
+//
+//   C[m, n] = sum_k A[m, k] * B[k, n]
+//   m = (img, oh, ow)            M = N*OH*OW
+//   n = output channel           (Cout)
+//   k = (kh, kw, ci)             K = KH*KW*Cin, gathered from the NHWC input on the fly
+//
+// One kernel covers every transform on the bottleneck path (reference: nn.Conv2d at
+// sc2bench/models/layer.py:475-493) and, as a 1x1 conv on |x| with a multiplicative epilogue,
+// CompressAI's GDN1 (layer.py:478,481,488,491).
+//
+// Structure (per 256-thread workgroup = 4 waves, one BM x BN output tile):
+//   * A and B k-slabs (BK = 32) are register-staged into a double-buffered, XOR-swizzled LDS
+//     image (conflict-free for the ds_read_b128 fragment reads, checked with the lane-group
+//     table of MI355X_MICROARCH.md section LDS); global loads of slab t+1 are issued before the
+//     MFMAs of slab t and written to LDS after them: one barrier per slab.
+//   * 16-byte chunks never straddle a filter tap (Cin % 8 == 0), so each chunk is one
+//     predicated global_load_dwordx4; out-of-image taps and the K tail load zeros.
+//   * the epilogue stages the f32 accumulators through LDS so that global stores are
+//     whole 16-byte channel runs (NHWC) or pixel runs (NCHW) and the fused element-wise
+//     epilogues (GDN / IGDN / bias / residual) read their operands coalesced.
+//   * workgroup ids are remapped so that workgroups sharing an XCD (id % 8) cover
+//     neighbouring tiles (shared input halo and the same weight panel stay in that XCD's L2).
+#include "sc2_common.h"
+
+namespace {
+
+struct ConvArgs {
+    const uint16_t *__restrict__ x;
+    const uint16_t *__restrict__ w;
+    void *__restrict__ y;
+    const uint16_t *__restrict__ ep_x;
+    const float *__restrict__ ep_beta;
+    int N, H, W, Cin, Cout;
+    int KH, KW, SH, SW, PH, PW;
+    int OH, OW, OHW, M;
+    int Kpad, KT;
+    int n_ntiles;
+    int aop, epi, out;
+};
+
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_,
+          int PH_, int PW_>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, BK = 32;
+    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+    static constexpr bool STATIC = STATIC_;
+    static constexpr int CIN = CIN_, KH = KH_, KW = KW_, SH = SH_, SW = SW_, PH = PH_, PW = PW_;
+    static constexpr int KC = BK / 8;  // 16-byte chunks per tile row
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int MT = WM / 16, NT = WN / 16;
+    static constexpr int A_CH = BM * KC / 256;
+    static constexpr int B_CH = (BN * KC + 255) / 256;
+    static constexpr int STAGE_ROWS = WAVES_M * 16;
+    static constexpr int MAIN_LDS = 2 * (BM + BN) * BK * 2;
+    static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
+    static constexpr int LDS_BYTES = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(BM % (WAVES_M * 16) == 0 && BN % (WAVES_N * 16) == 0, "wave tiling");
+    static_assert((BM * KC) % 256 == 0, "A chunks per thread");
+};
+
+// byte offset of 16-byte chunk `c` of row `r` in a [rows][BK] bf16 LDS tile (BK = 32 -> 64-byte rows).
+// chunk index XORed with (r >> 1) & 3: the 16 rows x 4 chunks one MFMA operand read touches
+// land on 16 distinct 16-byte slots of the 256-byte bank row in every ds_read_b128 lane group.
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 3)) << 4); }
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, KC = C::KC;
+    constexpr int MT = C::MT, NT = C::NT, A_CH = C::A_CH, B_CH = C::B_CH;
+    constexpr int A_ROW_STEP = 256 / KC;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *As = smem;                    // [2][BM*BK*2 bytes]
+    unsigned char *Bs = smem + 2 * BM * BK * 2;  // [2][BN*BK*2 bytes]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+
+    const int Cin = C::STATIC ? C::CIN : p.Cin;
+    const int KH = C::STATIC ? C::KH : p.KH;
+    const int KW = C::STATIC ? C::KW : p.KW;
+    const int SH = C::STATIC ? C::SH : p.SH;
+    const int SW = C::STATIC ? C::SW : p.SW;
+    const int PH = C::STATIC ? C::PH : p.PH;
+    const int PW = C::STATIC ? C::PW : p.PW;
+    const int CIN8 = Cin >> 3;
+    const int H = p.H, W = p.W;
+
+    // --- XCD-aware workgroup remap (bijective form) ---
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int ntile = bid % p.n_ntiles;
+    const int mtile = bid / p.n_ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+
+    // --- per-thread A gather state (rows are fixed for the whole K loop) ---
+    const int kc = tid % KC;
+    const int arow0 = tid / KC;
+    long long a_off[A_CH];
+    int a_ih0[A_CH], a_iw0[A_CH];
+    bool a_ok[A_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int m = m0 + arow0 + i * A_ROW_STEP;
+        a_ok[i] = m < p.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int img = mm / p.OHW;
+        const int rem = mm - img * p.OHW;
+        const int oh = rem / p.OW;
+        const int ow = rem - oh * p.OW;
+        a_ih0[i] = oh * SH - PH;
+        a_iw0[i] = ow * SW - PW;
+        a_off[i] = ((long long)(img * H + a_ih0[i]) * W + a_iw0[i]) * Cin;
+    }
+    // k state of this thread's chunk column: (kh, kw, c8)
+    int c8 = kc, kh = 0, kw = 0;
+    while (c8 >= CIN8) {
+        c8 -= CIN8;
+        if (++kw == KW) { kw = 0; ++kh; }
+    }
+    // B rows
+    const uint16_t *b_ptr[B_CH];
+    bool b_ok[B_CH];
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) {
+        const int q = tid + j * 256;
+        b_ok[j] = q < BN * KC;
+        const int rowb = b_ok[j] ? q / KC : 0;
+        b_ptr[j] = p.w + (long long)(n0 + rowb) * p.Kpad + kc * 8;
+    }
+
+    uint4 a_reg[A_CH], b_reg[B_CH];
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+
+    auto load_tile = [&](int kt) {
+        const long long tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
+        const bool tap_ok = kh < KH;
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+            const bool ok = a_ok[i] && tap_ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+            a_reg[i] = ok ? *reinterpret_cast<const uint4 *>(p.x + a_off[i] + tap_off) : zero4;
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) {
+            b_reg[j] = b_ok[j] ? *reinterpret_cast<const uint4 *>(b_ptr[j] + kt * BK) : zero4;
+        }
+        // advance the k state by one tile
+        c8 += KC;
+        while (c8 >= CIN8) {
+            c8 -= CIN8;
+            if (++kw == KW) { kw = 0; ++kh; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char *Ab = As + buf * (BM * BK * 2);
+        unsigned char *Bb = Bs + buf * (BN * BK * 2);
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) {
+            const int r = arow0 + i * A_ROW_STEP;
+            *reinterpret_cast<uint4 *>(Ab + lds_off(r, kc)) = a_reg[i];
+        }
+#pragma unroll
+        for (int j = 0; j < B_CH; ++j) {
+            if (b_ok[j]) {
+                const int r = (tid + j * 256) / KC;
+                *reinterpret_cast<uint4 *>(Bb + lds_off(r, kc)) = b_reg[j];
+            }
+        }
+    };
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t amask = p.aop == SC2_AOP_ABS ? 0x7FFF7FFFu : 0xFFFFFFFFu;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int KT = p.KT;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+
+        const unsigned char *Ab = As + buf * (BM * BK * 2);
+        const unsigned char *Bb = Bs + buf * (BN * BK * 2);
+        bf16x8_t af[MT], bfr[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            uint4 v = *reinterpret_cast<const uint4 *>(Ab + lds_off(wm * C::WM + i * 16 + frow, fq));
+            v.x &= amask; v.y &= amask; v.z &= amask; v.w &= amask;
+            af[i] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(Bb + lds_off(wn * C::WN + j * 16 + frow, fq));
+            bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // MT passes; pass i stages tile-row i of every wave (WAVES_M*16 rows x BN cols, f32).
+    float *stage = reinterpret_cast<float *>(smem);
+    const bool nchw = p.out == SC2_OUT_F32_NCHW;
+    const int RS = nchw ? BN + 1 : BN + 4;  // row stride in floats (bank spread for the read pattern)
+    const int Cout = p.Cout;
+    const int epi = p.epi;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (i > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sr = wm * 16 + fq * 4 + e;
+                const int sc = wn * C::WN + j * 16 + frow;
+                stage[sr * RS + sc] = acc[i][j][e];
+            }
+        }
+        __syncthreads();
+        if (!nchw) {
+            constexpr int CPR = BN / 8;  // 8-channel chunks per row
+            for (int q = tid; q < C::STAGE_ROWS * CPR; q += 256) {
+                const int sr = q / CPR, cc = q - sr * CPR;
+                const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
+                const int n = n0 + cc * 8;
+                if (m >= p.M || n >= Cout) continue;
+                float v[8];
+                {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(stage + sr * RS + cc * 8);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(stage + sr * RS + cc * 8 + 4);
+                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+                    v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                }
+                const long long o = (long long)m * Cout + n;
+                if (epi != SC2_EPI_NONE) {
+                    float b[8];
+                    {
+                        const float4 b0 = *reinterpret_cast<const float4 *>(p.ep_beta + n);
+                        const float4 b1 = *reinterpret_cast<const float4 *>(p.ep_beta + n + 4);
+                        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
+                        b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+                    }
+                    float xv[8];
+                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
+                        const uint4 xr = *reinterpret_cast<const uint4 *>(p.ep_x + o);
+                        const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            xv[2 * t] = __builtin_bit_cast(float, xw[t] << 16);
+                            xv[2 * t + 1] = __builtin_bit_cast(float, xw[t] & 0xFFFF0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) xv[t] = 0.f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float norm = b[t] + v[t];
+                        float r;
+                        if (epi == SC2_EPI_GDN) r = xv[t] * (1.0f / norm);
+                        else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
+                        else if (epi == SC2_EPI_BIAS) r = norm;
+                        else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
+                        else r = fmaxf(norm + xv[t], 0.f);
+                        v[t] = r;
+                    }
+                }
+                if (p.out == SC2_OUT_BF16_NHWC) {
+                    uint4 ov;
+                    ov.x = pack_bf16x2(v[0], v[1]);
+                    ov.y = pack_bf16x2(v[2], v[3]);
+                    ov.z = pack_bf16x2(v[4], v[5]);
+                    ov.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + o) = ov;
+                } else {
+                    float *yo = reinterpret_cast<float *>(p.y) + o;
+                    *reinterpret_cast<float4 *>(yo) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4 *>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+        } else {
+            // f32 NCHW: lanes run along pixels so each channel plane gets contiguous runs.
+            for (int q = tid; q < C::STAGE_ROWS * BN; q += 256) {
+                const int cidx = q / C::STAGE_ROWS, sr = q - cidx * C::STAGE_ROWS;
+                const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
+                const int n = n0 + cidx;
+                if (m >= p.M || n >= Cout) continue;
+                float v = stage[sr * RS + cidx];
+                if (epi != SC2_EPI_NONE) {
+                    const float norm = p.ep_beta[n] + v;
+                    float xv = 0.f;
+                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU)
+                        xv = bf16_bits_to_f32(p.ep_x[(long long)m * Cout + n]);
+                    if (epi == SC2_EPI_GDN) v = xv * (1.0f / norm);
+                    else if (epi == SC2_EPI_IGDN) v = xv * norm;
+                    else if (epi == SC2_EPI_BIAS) v = norm;
+                    else if (epi == SC2_EPI_BIAS_RELU) v = fmaxf(norm, 0.f);
+                    else v = fmaxf(norm + xv, 0.f);
+                }
+                const int img = m / p.OHW;
+                const int pix = m - img * p.OHW;
+                reinterpret_cast<float *>(p.y)[((long long)img * Cout + n) * p.OHW + pix] = v;
+            }
+        }
+    }
+}
+
+template <class C>
+int launch(const ConvArgs &a, hipStream_t s) {
+    ConvArgs p = a;
+    p.KT = (a.KH * a.KW * a.Cin + C::BK - 1) / C::BK;
+    p.n_ntiles = (a.Cout + C::BN - 1) / C::BN;
+    const int n_mtiles = (a.M + C::BM - 1) / C::BM;
+    const long long nwg = (long long)n_mtiles * p.n_ntiles;
+    if (nwg <= 0 || nwg > 0x7FFFFFFFLL) {
+        sc2_set_error("conv2d: grid of %lld workgroups out of range", nwg);
+        return SC2_ERR_INVALID_ARG;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_igemm_kernel<C>, dim3((unsigned)nwg), dim3(256), C::LDS_BYTES, s, p);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+// Static geometries of FPBasedResNetBottleneck(24, 256) (layer.py:464-494) -> folded address math.
+//                 BM   BN  WM WN  static Cin KH KW SH SW PH PW
+using C_conv0 = Cfg<128, 96, 2, 2, true, 8, 5, 3, 2, 1, 2, 1>;      // 3->96 k5 s2 p2 on the pixel-pair view
+using C_gdn96 = Cfg<128, 96, 2, 2, true, 96, 1, 1, 1, 1, 0, 0>;
+using C_conv2 = Cfg<128, 48, 4, 1, true, 96, 5, 5, 2, 2, 2, 2>;     // 96->48 k5 s2 p2
+using C_gdn48 = Cfg<128, 48, 4, 1, true, 48, 1, 1, 1, 1, 0, 0>;
+using C_conv4 = Cfg<128, 32, 4, 1, true, 48, 2, 2, 1, 1, 0, 0>;     // 48->24 k2
+using C_dec0 = Cfg<128, 128, 2, 2, true, 24, 2, 2, 1, 1, 1, 1>;     // 24->512 k2 p1
+using C_gdn512 = Cfg<128, 128, 2, 2, true, 512, 1, 1, 1, 1, 0, 0>;
+using C_dec2 = Cfg<128, 128, 2, 2, true, 512, 2, 2, 1, 1, 0, 0>;    // 512->256 k2
+using C_gdn256 = Cfg<128, 128, 2, 2, true, 256, 1, 1, 1, 1, 0, 0>;
+using C_dec4 = Cfg<128, 128, 2, 2, true, 256, 2, 2, 1, 1, 1, 1>;    // 256->256 k2 p1
+// Runtime-geometry fallbacks (other channel widths, the ResNet tail, other bottleneck sizes).
+using G_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
+using G_96 = Cfg<128, 96, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
+using G_64 = Cfg<128, 64, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
+using G_48 = Cfg<128, 48, 4, 1, false, 0, 0, 0, 0, 0, 0, 0>;
+using G_32 = Cfg<128, 32, 4, 1, false, 0, 0, 0, 0, 0, 0, 0>;
+
+template <class C>
+bool matches(const ConvArgs &a) {
+    return a.Cin == C::CIN && a.KH == C::KH && a.KW == C::KW && a.SH == C::SH && a.SW == C::SW && a.PH == C::PH &&
+           a.PW == C::PW;
+}
+
+}  // namespace
+
+extern "C" int sc2_conv_weight_rows(int Cout) {
+    if (Cout <= 0) return 0;
+    if (Cout <= 32) return 32;
+    if (Cout <= 48) return 48;
+    if (Cout <= 64) return 64;
+    if (Cout <= 96) return 96;
+    return (Cout + 127) / 128 * 128;
+}
+extern "C" int sc2_conv_weight_pitch(int K) { return K <= 0 ? 0 : (K + 63) / 64 * 64; }
+
+extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, const void *ep_x,
+                              const float *ep_beta, void *stream) {
+    SC2_REQUIRE(d && x && w_packed && y, SC2_ERR_INVALID_ARG, "conv2d: null argument");
+    SC2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, SC2_ERR_INVALID_ARG,
+                "conv2d: non-positive dimension");
+    SC2_REQUIRE(d->Cin % 8 == 0 && d->Cout % 8 == 0, SC2_ERR_INVALID_ARG,
+                "conv2d: Cin (%d) and Cout (%d) must be multiples of 8", d->Cin, d->Cout);
+    SC2_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_h >= 0 && d->pad_w >= 0,
+                SC2_ERR_INVALID_ARG, "conv2d: bad filter geometry");
+    const int OH = (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1;
+    const int OW = (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1;
+    SC2_REQUIRE(OH == d->OH && OW == d->OW && OH > 0 && OW > 0, SC2_ERR_INVALID_ARG,
+                "conv2d: output size %dx%d does not match geometry (%dx%d)", d->OH, d->OW, OH, OW);
+    const int K = d->KH * d->KW * d->Cin;
+    SC2_REQUIRE(d->Kpad == sc2_conv_weight_pitch(K), SC2_ERR_INVALID_ARG, "conv2d: Kpad %d != %d", d->Kpad,
+                sc2_conv_weight_pitch(K));
+    SC2_REQUIRE(d->Cout_pad == sc2_conv_weight_rows(d->Cout), SC2_ERR_INVALID_ARG, "conv2d: Cout_pad %d != %d",
+                d->Cout_pad, sc2_conv_weight_rows(d->Cout));
+    SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS, SC2_ERR_INVALID_ARG, "conv2d: bad a_op");
+    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_BIAS_ADD_RELU, SC2_ERR_INVALID_ARG,
+                "conv2d: bad epilogue");
+    SC2_REQUIRE(d->out_format >= SC2_OUT_BF16_NHWC && d->out_format <= SC2_OUT_F32_NHWC, SC2_ERR_INVALID_ARG,
+                "conv2d: bad out_format");
+    if (d->epilogue != SC2_EPI_NONE) SC2_REQUIRE(ep_beta, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_beta");
+    if (d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS_ADD_RELU)
+        SC2_REQUIRE(ep_x, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_x");
+    const long long M = (long long)d->N * OH * OW;
+    SC2_REQUIRE(M < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv2d: N*OH*OW = %lld exceeds 2^31", M);
+    SC2_REQUIRE((long long)d->N * d->H < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv2d: N*H too large");
+
+    ConvArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_packed);
+    a.y = y;
+    a.ep_x = static_cast<const uint16_t *>(ep_x);
+    a.ep_beta = ep_beta;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.SH = d->stride_h; a.SW = d->stride_w; a.PH = d->pad_h; a.PW = d->pad_w;
+    a.OH = OH; a.OW = OW; a.OHW = OH * OW; a.M = (int)M;
+    a.Kpad = d->Kpad; a.KT = 0; a.n_ntiles = 0;
+    a.aop = d->a_op; a.epi = d->epilogue; a.out = d->out_format;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    const int rows = d->Cout_pad;
+    // static geometries first (tile width must agree with the packed row count)
+    if (rows == 96 && matches<C_conv0>(a)) return launch<C_conv0>(a, s);
+    if (rows == 96 && matches<C_gdn96>(a)) return launch<C_gdn96>(a, s);
+    if (rows == 48 && matches<C_conv2>(a)) return launch<C_conv2>(a, s);
+    if (rows == 48 && matches<C_gdn48>(a)) return launch<C_gdn48>(a, s);
+    if (rows == 32 && matches<C_conv4>(a)) return launch<C_conv4>(a, s);
+    if (rows % 128 == 0) {
+        if (matches<C_dec0>(a)) return launch<C_dec0>(a, s);
+        if (matches<C_gdn512>(a)) return launch<C_gdn512>(a, s);
+        if (matches<C_dec2>(a)) return launch<C_dec2>(a, s);
+        if (matches<C_gdn256>(a)) return launch<C_gdn256>(a, s);
+        if (matches<C_dec4>(a)) return launch<C_dec4>(a, s);
+        return launch<G_128>(a, s);
+    }
+    if (rows == 96) return launch<G_96>(a, s);
+    if (rows == 64) return launch<G_64>(a, s);
+    if (rows == 48) return launch<G_48>(a, s);
+    if (rows == 32) return launch<G_32>(a, s);
+    sc2_set_error("conv2d: unsupported packed row count %d", rows);
+    return SC2_ERR_UNSUPPORTED;
+}

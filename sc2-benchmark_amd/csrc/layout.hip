@@ -1,0 +1,88 @@
+// Layout conversion kernels (HBM-bound, coalesced on the wide side).
+//   f32 NCHW (what reference callers hand to nn.Conv2d, sc2bench/models/layer.py:475)
+//   <-> bf16 NHWC (the layout every implicit-GEMM kernel of this library consumes/produces).
+#include "sc2_common.h"
+
+namespace {
+
+// one thread = one pixel x VEC channels.  Lanes run along pixels, so the per-plane f32 reads are
+// contiguous; each lane writes one VEC*2-byte vector.
+template <int VEC>
+__global__ __launch_bounds__(256) void nchw_f32_to_nhwc_bf16_kernel(const float *__restrict__ x,
+                                                                    uint16_t *__restrict__ y, int C, int HW, int Cpad,
+                                                                    long long total_pix) {
+    const int cg = blockIdx.y;  // channel group
+    const int c0 = cg * VEC;
+    for (long long gp = (long long)blockIdx.x * 256 + threadIdx.x; gp < total_pix; gp += (long long)gridDim.x * 256) {
+        const long long n = gp / HW;
+        const int pix = (int)(gp - n * HW);
+        uint16_t v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = c0 + j;
+            v[j] = c < C ? f32_to_bf16_bits(x[(n * C + c) * HW + pix]) : (uint16_t)0;
+        }
+        uint16_t *dst = y + gp * Cpad + c0;
+        if (VEC == 8) {
+            uint4 o;
+            o.x = v[0] | ((uint32_t)v[1] << 16);
+            o.y = v[2] | ((uint32_t)v[3] << 16);
+            o.z = v[4] | ((uint32_t)v[5] << 16);
+            o.w = v[6] | ((uint32_t)v[7] << 16);
+            *reinterpret_cast<uint4 *>(dst) = o;
+        } else {
+            uint2 o;
+            o.x = v[0] | ((uint32_t)v[1] << 16);
+            o.y = v[2] | ((uint32_t)v[3] << 16);
+            *reinterpret_cast<uint2 *>(dst) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_bf16_to_nchw_f32_kernel(const uint16_t *__restrict__ x,
+                                                                    float *__restrict__ y, int C, int HW,
+                                                                    long long total_pix) {
+    const int c0 = blockIdx.y * 8;
+    for (long long gp = (long long)blockIdx.x * 256 + threadIdx.x; gp < total_pix; gp += (long long)gridDim.x * 256) {
+        const long long n = gp / HW;
+        const int pix = (int)(gp - n * HW);
+        const uint4 r = *reinterpret_cast<const uint4 *>(x + gp * C + c0);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            y[(n * C + c0 + 2 * t) * HW + pix] = __builtin_bit_cast(float, w[t] << 16);
+            y[(n * C + c0 + 2 * t + 1) * HW + pix] = __builtin_bit_cast(float, w[t] & 0xFFFF0000u);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sc2_nchw_f32_to_nhwc_bf16(const float *x, void *y, int N, int C, int H, int W, int Cpad, void *stream) {
+    SC2_REQUIRE(x && y, SC2_ERR_INVALID_ARG, "nchw_to_nhwc: null argument");
+    SC2_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 4 == 0, SC2_ERR_INVALID_ARG,
+                "nchw_to_nhwc: bad dims N=%d C=%d H=%d W=%d Cpad=%d", N, C, H, W, Cpad);
+    const long long total = (long long)N * H * W;
+    const int gx = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cpad % 8 == 0)
+        hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<8>, dim3(gx, Cpad / 8), dim3(256), 0, s, x,
+                           static_cast<uint16_t *>(y), C, H * W, Cpad, total);
+    else
+        hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel<4>, dim3(gx, Cpad / 4), dim3(256), 0, s, x,
+                           static_cast<uint16_t *>(y), C, H * W, Cpad, total);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+extern "C" int sc2_nhwc_bf16_to_nchw_f32(const void *x, float *y, int N, int C, int H, int W, void *stream) {
+    SC2_REQUIRE(x && y, SC2_ERR_INVALID_ARG, "nhwc_to_nchw: null argument");
+    SC2_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && C % 8 == 0, SC2_ERR_INVALID_ARG,
+                "nhwc_to_nchw: bad dims N=%d C=%d H=%d W=%d (C %% 8 != 0)", N, C, H, W);
+    const long long total = (long long)N * H * W;
+    const int gx = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, dim3(gx, C / 8), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(x), y, C, H * W, total);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}

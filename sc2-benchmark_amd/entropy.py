@@ -1,0 +1,531 @@
+"""Host-side mirror of the CompressAI classes the reference's bottleneck is built from.
+
+sc2bench builds ``FPBasedResNetBottleneck`` out of ``compressai.layers.GDN1``,
+``compressai.entropy_models.EntropyBottleneck`` and ``compressai.models.CompressionModel``
+(sc2bench/models/layer.py:2-6, 401-494).  The classes here keep CompressAI's constructor arguments,
+parameter / buffer names (so released checkpoints load), method names and error
+behaviour, but every tensor-sized computation runs in the HIP library (``hip.py``); only
+per-channel scalar work (reparametrisation of beta/gamma, softplus/tanh of the 58 bottleneck
+parameters per channel, the once-per-model CDF table build) uses torch ops.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import hip
+
+
+# --------------------------------------------------------------------------------------------- #
+# compressai.ops restated on torch ops (parameter-sized tensors only)
+# --------------------------------------------------------------------------------------------- #
+class _LowerBoundFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, bound = ctx.saved_tensors
+        pass_through_if = (x >= bound) | (grad_output < 0)
+        return pass_through_if * grad_output, None
+
+
+class LowerBound(nn.Module):
+    """max(x, bound) whose gradient passes when x >= bound or the gradient pushes x up."""
+
+    def __init__(self, bound):
+        super().__init__()
+        self.register_buffer('bound', torch.Tensor([float(bound)]))
+
+    def forward(self, x):
+        return _LowerBoundFn.apply(x, self.bound)
+
+
+class NonNegativeParametrizer(nn.Module):
+    def __init__(self, minimum=0.0, reparam_offset=2 ** -18):
+        super().__init__()
+        self.minimum = float(minimum)
+        self.reparam_offset = float(reparam_offset)
+        pedestal = self.reparam_offset ** 2
+        self.register_buffer('pedestal', torch.Tensor([pedestal]))
+        bound = (self.minimum + self.reparam_offset ** 2) ** 0.5
+        self.lower_bound = LowerBound(bound)
+
+    def init(self, x):
+        return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
+
+    def forward(self, x):
+        out = self.lower_bound(x)
+        return out ** 2 - self.pedestal
+
+
+def _require_device(x, what):
+    if not x.is_cuda:
+        raise hip.Sc2Error('{}: input is on {}; sc2bench_amd computes on a HIP device only (no CPU fallback)'
+                           .format(what, x.device))
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d(bias=False) parameter holder whose forward is the implicit-GEMM MFMA kernel.
+
+    Module-by-module use (``encoder(x)``) converts f32 NCHW <-> bf16 NHWC around the kernel; the
+    bottleneck's own forward keeps activations in bf16 NHWC between layers (``bottleneck.py``).
+    """
+
+    def packed_weight(self):
+        key = (self.weight._version, self.weight.device, self.weight.data_ptr())
+        if getattr(self, '_packed_key', None) != key:
+            self._packed = hip.pack_conv_weight(self.weight)
+            self._packed_key = key
+        return self._packed
+
+    def forward_nhwc(self, x_nhwc, out_format=hip.OUT_BF16_NHWC):
+        assert self.bias is None and self.groups == 1 and self.dilation == (1, 1)
+        return hip.conv2d_fwd(x_nhwc, self.packed_weight(), self.out_channels, self.kernel_size[0],
+                              self.kernel_size[1], self.stride, self.padding, out_format=out_format)
+
+    def forward(self, x):
+        _require_device(x, 'HipConv2d')
+        cin = self.in_channels
+        x_nhwc = hip.nchw_f32_to_nhwc_bf16(x.float(), (cin + 7) // 8 * 8)
+        if cin % 8 != 0:
+            w = torch.zeros((self.out_channels, x_nhwc.shape[-1]) + tuple(self.kernel_size),
+                            dtype=self.weight.dtype, device=self.weight.device)
+            w[:, :cin] = self.weight.detach()
+            packed = hip.pack_conv_weight(w)
+            return hip.conv2d_fwd(x_nhwc, packed, self.out_channels, self.kernel_size[0], self.kernel_size[1],
+                                  self.stride, self.padding, out_format=hip.OUT_F32_NCHW)
+        return self.forward_nhwc(x_nhwc, out_format=hip.OUT_F32_NCHW)
+
+
+class GDN1(nn.Module):
+    """Simplified generalized divisive normalisation: y = x / (beta + gamma |x|); inverse: x * (...).
+
+    Same parameters, initialisation and state-dict keys as compressai.layers.GDN1 (used by the
+    reference at layer.py:478,481,488,491).  The channel reduction gamma |x| is a 1x1 implicit GEMM on
+    the matrix cores with |.| applied on operand load and the divide / multiply fused in the epilogue.
+    """
+
+    def __init__(self, in_channels, inverse=False, beta_min=1e-6, gamma_init=0.1):
+        super().__init__()
+        beta_min = float(beta_min)
+        gamma_init = float(gamma_init)
+        self.inverse = bool(inverse)
+        self.in_channels = int(in_channels)
+        self.beta_reparam = NonNegativeParametrizer(minimum=beta_min)
+        beta = torch.ones(in_channels)
+        beta = self.beta_reparam.init(beta)
+        self.beta = nn.Parameter(beta)
+        self.gamma_reparam = NonNegativeParametrizer()
+        gamma = gamma_init * torch.eye(in_channels)
+        gamma = self.gamma_reparam.init(gamma)
+        self.gamma = nn.Parameter(gamma)
+
+    def effective(self):
+        """(beta f32 [C], packed bf16 gamma [Cpad, Kpad]) on the parameter device; cached per parameter version."""
+        key = (self.beta._version, self.gamma._version, self.gamma.device, self.gamma.data_ptr())
+        if getattr(self, '_eff_key', None) != key:
+            with torch.no_grad():
+                beta = self.beta_reparam(self.beta).float().contiguous()
+                gamma = self.gamma_reparam(self.gamma)
+                C = self.in_channels
+                self._eff = (beta, hip.pack_conv_weight(gamma.reshape(C, C, 1, 1)))
+            self._eff_key = key
+        return self._eff
+
+    def forward_nhwc(self, x_nhwc, out_format=hip.OUT_BF16_NHWC):
+        beta, gamma_packed = self.effective()
+        return hip.conv2d_fwd(x_nhwc, gamma_packed, self.in_channels, 1, 1, 1, 0, a_op=hip.AOP_ABS,
+                              epilogue=hip.EPI_IGDN if self.inverse else hip.EPI_GDN, out_format=out_format,
+                              ep_x=x_nhwc, ep_beta=beta)
+
+    def forward(self, x):
+        _require_device(x, 'GDN1')
+        x_nhwc = hip.nchw_f32_to_nhwc_bf16(x.float())
+        return self.forward_nhwc(x_nhwc, out_format=hip.OUT_F32_NCHW)
+
+
+# --------------------------------------------------------------------------------------------- #
+# EntropyBottleneck
+# --------------------------------------------------------------------------------------------- #
+class EntropyBottleneck(nn.Module):
+    """Factorised-prior entropy model with CompressAI 1.2.x semantics.
+
+    forward / quantize / dequantize / compress / decompress run in the HIP library; ``update()``
+    builds the integer CDF tables once per model on the host (as the reference's C++ helper does).
+    """
+
+    def __init__(self, channels, *args, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3),
+                 likelihood_bound=1e-9, entropy_coder_precision=16, **kwargs):
+        super().__init__()
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        self.use_likelihood_bound = likelihood_bound > 0
+        self.likelihood_bound = float(likelihood_bound)
+        if self.use_likelihood_bound:
+            self.likelihood_lower_bound = LowerBound(likelihood_bound)
+        self.register_buffer('_offset', torch.IntTensor())
+        self.register_buffer('_quantized_cdf', torch.IntTensor())
+        self.register_buffer('_cdf_length', torch.IntTensor())
+
+        filters = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        channels = self.channels
+        self.matrices = nn.ParameterList()
+        self.biases = nn.ParameterList()
+        self.factors = nn.ParameterList()
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / filters[i + 1]))
+            matrix = torch.Tensor(channels, filters[i + 1], filters[i])
+            matrix.data.fill_(init)
+            self.matrices.append(nn.Parameter(matrix))
+            bias = torch.Tensor(channels, filters[i + 1], 1)
+            nn.init.uniform_(bias, -0.5, 0.5)
+            self.biases.append(nn.Parameter(bias))
+            if i < len(self.filters):
+                factor = torch.Tensor(channels, filters[i + 1], 1)
+                nn.init.zeros_(factor)
+                self.factors.append(nn.Parameter(factor))
+
+        self.quantiles = nn.Parameter(torch.Tensor(channels, 1, 3))
+        init = torch.Tensor([-self.init_scale, 0, self.init_scale])
+        self.quantiles.data = init.repeat(self.quantiles.size(0), 1, 1)
+        target = np.log(2 / self.tail_mass - 1)
+        self.register_buffer('target', torch.Tensor([-target, 0, target]))
+
+    # ---- small helpers (same names as upstream; the reference calls the first two, layer.py:524-526)
+    def _get_medians(self):
+        return self.quantiles[:, :, 1:2]
+
+    @staticmethod
+    def _extend_ndims(tensor, n):
+        return tensor.reshape(-1, *([1] * n)) if n > 0 else tensor.reshape(-1)
+
+    @staticmethod
+    def _build_indexes(size):
+        dims = len(size)
+        C = size[1]
+        view_dims = np.ones((dims,), dtype=np.int64)
+        view_dims[1] = -1
+        indexes = torch.arange(C).view(*view_dims)
+        indexes = indexes.int()
+        return indexes.repeat(size[0], 1, *size[2:])
+
+    def _logits_cumulative(self, inputs, stop_gradient):
+        """Parameter-sized use only (aux loss on [C,1,3] quantiles, CDF grid in update())."""
+        logits = inputs
+        for i in range(len(self.filters) + 1):
+            matrix = self.matrices[i]
+            if stop_gradient:
+                matrix = matrix.detach()
+            logits = torch.matmul(F.softplus(matrix), logits)
+            bias = self.biases[i]
+            if stop_gradient:
+                bias = bias.detach()
+            logits = logits + bias
+            if i < len(self.filters):
+                factor = self.factors[i]
+                if stop_gradient:
+                    factor = factor.detach()
+                logits = logits + torch.tanh(factor) * torch.tanh(logits)
+        return logits
+
+    def _check_filters(self):
+        if self.filters != (3, 3, 3, 3):
+            raise hip.Sc2Error('the HIP entropy-bottleneck kernels are built for filters=(3,3,3,3) '
+                               '(the only configuration sc2bench uses); got {}'.format(self.filters))
+
+    def effective_params(self):
+        """f32 [C, 64] block the kernels read (layout: include/sc2_bottleneck.h); differentiable."""
+        self._check_filters()
+        C = self.channels
+        parts = []
+        for i in range(5):
+            parts.append(F.softplus(self.matrices[i]).reshape(C, -1))
+            parts.append(self.biases[i].reshape(C, -1))
+            if i < 4:
+                parts.append(torch.tanh(self.factors[i]).reshape(C, -1))
+        parts.append(self._get_medians().reshape(C, 1))
+        p = torch.cat(parts, dim=1)
+        return F.pad(p, (0, hip.EB_PARAM_STRIDE - p.shape[1])).float().contiguous()
+
+    def _cached_params(self):
+        ps = list(self.matrices) + list(self.biases) + list(self.factors) + [self.quantiles]
+        key = tuple(p._version for p in ps) + (self.quantiles.device, self.quantiles.data_ptr())
+        if getattr(self, '_eff_key', None) != key:
+            with torch.no_grad():
+                self._eff = self.effective_params()
+            self._eff_key = key
+        return self._eff
+
+    # ---- quantisation (EntropyModel.quantize / dequantize; reference call layer.py:545-547)
+    def quantize(self, inputs, mode, means=None):
+        if mode not in ('noise', 'dequantize', 'symbols'):
+            raise ValueError('Invalid quantization mode: "{}"'.format(mode))
+        _require_device(inputs, 'EntropyBottleneck.quantize')
+        if mode == 'noise':
+            half = float(0.5)
+            noise = torch.empty_like(inputs).uniform_(-half, half)
+            return inputs + noise
+        x = inputs.float().contiguous()
+        C = x.shape[1]
+        if means is None:
+            med = torch.zeros(C, dtype=torch.float32, device=x.device)
+        else:
+            med = means.detach().float().reshape(means.shape[0], C, -1)[0, :, 0].contiguous()
+        sym = hip.eb_symbols(x, med)
+        if mode == 'symbols':
+            return sym
+        return hip.eb_dequantize(sym, med, want_f32=True)[0]
+
+    @staticmethod
+    def dequantize(inputs, means=None, dtype=torch.float):
+        if means is not None:
+            outputs = inputs.type_as(means)
+            outputs = outputs + means
+        else:
+            outputs = inputs.type(dtype)
+        return outputs
+
+    # ---- forward (reference call layer.py:531)
+    def forward(self, x, training=None, noise=None):
+        """Returns (y_hat, likelihoods), both f32 with x's shape.  ``noise`` overrides the U(-.5,.5) draw."""
+        if training is None:
+            training = self.training
+        _require_device(x, 'EntropyBottleneck.forward')
+        y = x.float().contiguous()
+        if torch.is_grad_enabled() and (y.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import eb_forward_autograd
+            return eb_forward_autograd(self, y, training, noise)
+        params = self._cached_params()
+        if training:
+            if noise is None:
+                half = float(0.5)
+                noise = torch.empty_like(y).uniform_(-half, half)
+            y_hat, _, lik, _ = hip.eb_forward(y, params, hip.EB_NOISE, noise=noise.float().contiguous(),
+                                              lik_bound=self.likelihood_bound if self.use_likelihood_bound else 0.0)
+        else:
+            y_hat, _, lik, _ = hip.eb_forward(y, params, hip.EB_DEQUANTIZE,
+                                              lik_bound=self.likelihood_bound if self.use_likelihood_bound else 0.0)
+        return y_hat, lik
+
+    def loss(self):
+        logits = self._logits_cumulative(self.quantiles, stop_gradient=True)
+        return torch.abs(logits - self.target).sum()
+
+    # ---- CDF tables (EntropyBottleneck.update; reached from layer.py:431-441)
+    @torch.no_grad()
+    def update(self, force=False, update_quantiles=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        dev = self.quantiles.device
+        # Host evaluation in f32 with torch CPU ops, in upstream's op order: the integer tables depend on
+        # p*65536 rounding, so they are built where the reference's CPU path builds them.
+        cpu = _CpuReplica(self)
+        quantiles = self.quantiles.detach().cpu()
+        medians = quantiles[:, 0, 1]
+        minima = medians - quantiles[:, 0, 0]
+        minima = torch.ceil(minima).int()
+        minima = torch.clamp(minima, min=0)
+        maxima = quantiles[:, 0, 2] - medians
+        maxima = torch.ceil(maxima).int()
+        maxima = torch.clamp(maxima, min=0)
+        offset = -minima
+        pmf_start = medians - minima
+        pmf_length = maxima + minima + 1
+        max_length = pmf_length.max().item()
+        samples = torch.arange(max_length)
+        samples = samples[None, :] + pmf_start[:, None, None]
+        half = float(0.5)
+        lower = cpu.logits_cumulative(samples - half)
+        upper = cpu.logits_cumulative(samples + half)
+        pmf = torch.sigmoid(upper) - torch.sigmoid(lower)
+        pmf = pmf[:, 0, :]
+        tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length)
+        self._offset = offset.to(dev)
+        self._quantized_cdf = quantized_cdf.to(dev)
+        self._cdf_length = (pmf_length + 2).to(dev)
+        return True
+
+    def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
+        cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
+        for i, p in enumerate(pmf):
+            prob = torch.cat((p[:pmf_length[i]], tail_mass[i]), dim=0)
+            _cdf = hip.pmf_to_quantized_cdf(prob, self.entropy_coder_precision)
+            cdf[i, :_cdf.size(0)] = _cdf
+        return cdf
+
+    def _check_cdf_size(self):
+        if self._quantized_cdf.numel() == 0:
+            raise ValueError('Uninitialized CDFs. Run update() first')
+        if len(self._quantized_cdf.size()) != 2:
+            raise ValueError('Invalid CDF size {}'.format(self._quantized_cdf.size()))
+
+    def _check_offsets_size(self):
+        if self._offset.numel() == 0:
+            raise ValueError('Uninitialized offsets. Run update() first')
+        if len(self._offset.size()) != 1:
+            raise ValueError('Invalid offsets size {}'.format(self._offset.size()))
+
+    def _check_cdf_length(self):
+        if self._cdf_length.numel() == 0:
+            raise ValueError('Uninitialized CDF lengths. Run update() first')
+        if len(self._cdf_length.size()) != 1:
+            raise ValueError('Invalid offsets size {}'.format(self._cdf_length.size()))
+
+    def _tables(self):
+        self._check_cdf_size()
+        self._check_cdf_length()
+        self._check_offsets_size()
+        return (self._quantized_cdf.contiguous(), self._cdf_length.reshape(-1).int().contiguous(),
+                self._offset.reshape(-1).int().contiguous())
+
+    def _median_vector(self):
+        return self._get_medians().detach().reshape(-1).float().contiguous()
+
+    # ---- entropy coding on the device
+    def compress_device(self, x):
+        """x: f32 [N,C,*spatial] on device -> (buf u8 [N,stride], offset i32 [N], nbytes i32 [N]) on device.
+
+        No host synchronisation unless a row overflowed its (generous) default stride.
+        """
+        if len(x.size()) < 2:
+            raise ValueError('Invalid `inputs` size. Expected a tensor with at least 2 dimensions.')
+        _require_device(x, 'EntropyBottleneck.compress')
+        cdf, cdf_len, offset = self._tables()
+        y = x.float().contiguous()
+        N, C = y.shape[0], y.shape[1]
+        if C != cdf.shape[0]:
+            raise ValueError('`inputs` has {} channels but the CDF table has {} rows'.format(C, cdf.shape[0]))
+        hw = y.numel() // (N * C)
+        sym = hip.eb_symbols(y, self._median_vector())
+        buf, off, nb, st = hip.rans_encode_batch(sym.view(N, C * hw), cdf, cdf_len, offset, index_div=hw)
+        return buf, off, nb, st
+
+    def compress(self, x):
+        """Returns list[bytes], one rANS stream per batch item (EntropyBottleneck.compress, layer.py:506)."""
+        buf, off, nb, st = self.compress_device(x)
+        if int(st.max().item()) != 0:  # a row overflowed 2 B/symbol: redo with the proven upper bound
+            cdf, cdf_len, offset = self._tables()
+            y = x.float().contiguous()
+            N, C = y.shape[0], y.shape[1]
+            hw = y.numel() // (N * C)
+            sym = hip.eb_symbols(y, self._median_vector())
+            buf, off, nb, st = hip.rans_encode_batch(sym.view(N, C * hw), cdf, cdf_len, offset, index_div=hw,
+                                                     out_stride=hip.rans_max_bytes(C * hw))
+        nb_h = nb.cpu().numpy()
+        stride = buf.shape[1]
+        width = int(nb_h.max())
+        tail = buf[:, stride - width:].contiguous().cpu().numpy()  # streams are end-aligned in their rows
+        return [tail[i, width - int(nb_h[i]):].tobytes() for i in range(tail.shape[0])]
+
+    def pack_strings(self, strings, device):
+        """list[bytes] -> (buf u8 [N,stride], offset i32 [N], nbytes i32 [N]) on device (start-aligned)."""
+        n = len(strings)
+        stride = (max(len(s) for s in strings) + 3) // 4 * 4 + 8
+        host = np.zeros((n, stride), dtype=np.uint8)
+        lens = np.zeros((n,), dtype=np.int32)
+        for i, s in enumerate(strings):
+            host[i, :len(s)] = np.frombuffer(s, dtype=np.uint8)
+            lens[i] = len(s)
+        buf = torch.from_numpy(host).to(device)
+        nb = torch.from_numpy(lens).to(device)
+        off = torch.zeros((n,), dtype=torch.int32, device=device)
+        return buf, off, nb
+
+    def decompress_device(self, buf, off, nb, size, want_f32=True, want_nhwc=False):
+        """Device buffers -> (y_hat f32 NCHW or None, y_hat bf16 NHWC or None)."""
+        cdf, cdf_len, offset = self._tables()
+        C = cdf.shape[0]
+        hw = int(np.prod(size))
+        N = buf.shape[0]
+        sym, _ = hip.rans_decode_batch(buf, off, nb, C * hw, cdf, cdf_len, offset, index_div=hw)
+        return hip.eb_dequantize(sym.view(N, C, *size), self._median_vector(), want_f32=want_f32,
+                                 want_nhwc=want_nhwc)
+
+    def decompress(self, strings, size):
+        """list[bytes], spatial size -> f32 [N,C,*size] (EntropyBottleneck.decompress, layer.py:520)."""
+        dev = self._quantized_cdf.device
+        if dev.type != 'cuda':
+            raise hip.Sc2Error('EntropyBottleneck.decompress: module is on {}; HIP device required'.format(dev))
+        buf, off, nb = self.pack_strings(strings, dev)
+        return self.decompress_device(buf, off, nb, tuple(size), want_f32=True)[0]
+
+
+class _CpuReplica(object):
+    """CPU copies of the bottleneck parameters for the once-per-model table build in update()."""
+
+    def __init__(self, eb):
+        self.matrices = [p.detach().cpu().float() for p in eb.matrices]
+        self.biases = [p.detach().cpu().float() for p in eb.biases]
+        self.factors = [p.detach().cpu().float() for p in eb.factors]
+
+    def logits_cumulative(self, inputs):
+        logits = inputs
+        n = len(self.matrices)
+        for i in range(n):
+            logits = torch.matmul(F.softplus(self.matrices[i]), logits)
+            logits = logits + self.biases[i]
+            if i < n - 1:
+                logits = logits + torch.tanh(self.factors[i]) * torch.tanh(logits)
+        return logits
+
+
+# --------------------------------------------------------------------------------------------- #
+# CompressionModel
+# --------------------------------------------------------------------------------------------- #
+def _remap_old_eb_keys(prefix, state_dict):
+    """compressai<=1.1 stored `_matrix{i}` / `_bias{i}` / `_factor{i}`; >=1.2 uses ParameterLists."""
+    for old, new in (('_matrix', 'matrices'), ('_bias', 'biases'), ('_factor', 'factors')):
+        for i in range(5):
+            ok = '{}{}{}'.format(prefix, old, i)
+            if ok in state_dict:
+                state_dict['{}{}.{}'.format(prefix, new, i)] = state_dict.pop(ok)
+
+
+def update_registered_buffers(module, module_name, buffer_names, state_dict):
+    """Resizes registered int buffers to the checkpoint's shapes before loading (compressai.models.utils)."""
+    for name in buffer_names:
+        key = '{}.{}'.format(module_name, name) if module_name else name
+        if key not in state_dict:
+            continue
+        new = state_dict[key]
+        cur = getattr(module, name)
+        if cur.shape != new.shape:
+            setattr(module, name, torch.empty(new.shape, dtype=cur.dtype, device=cur.device))
+
+
+class CompressionModel(nn.Module):
+    """Base class holding an ``entropy_bottleneck`` (compressai.models.CompressionModel, as used through
+    the deprecated ``entropy_bottleneck_channels`` argument at layer.py:409)."""
+
+    def __init__(self, entropy_bottleneck_channels=None, init_weights=None):
+        super().__init__()
+        if entropy_bottleneck_channels is not None:
+            self.entropy_bottleneck = EntropyBottleneck(entropy_bottleneck_channels)
+
+    def aux_loss(self):
+        """Sum of the quantile losses of all EntropyBottleneck children (image_classification.py:76)."""
+        loss = sum(m.loss() for m in self.modules() if isinstance(m, EntropyBottleneck))
+        return loss
+
+    def update(self, scale_table=None, force=False, update_quantiles=False):
+        updated = False
+        for m in self.modules():
+            if isinstance(m, EntropyBottleneck):
+                updated |= m.update(force=force, update_quantiles=update_quantiles)
+        return updated
+
+    def load_state_dict(self, state_dict, strict=True):
+        for name, module in self.named_modules():
+            if isinstance(module, EntropyBottleneck):
+                prefix = name + '.' if name else ''
+                _remap_old_eb_keys(prefix, state_dict)
+                update_registered_buffers(module, name, ['_quantized_cdf', '_offset', '_cdf_length'], state_dict)
+        return nn.Module.load_state_dict(self, state_dict, strict=strict)

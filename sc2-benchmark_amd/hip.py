@@ -1,0 +1,323 @@
+"""ctypes binding of libsc2amd.so (the C-ABI declared in include/sc2_bottleneck.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every compute call below goes through
+the C-ABI with raw pointers and the current HIP stream.  There is NO fallback: if the shared library
+is missing, or a tensor is not on a HIP device, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsc2amd.so')
+_lib = None
+
+AOP_NONE, AOP_ABS = 0, 1
+EPI_NONE, EPI_GDN, EPI_IGDN, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_ADD_RELU = 0, 1, 2, 3, 4, 5
+OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
+EB_NOISE, EB_DEQUANTIZE = 0, 1
+EB_PARAM_STRIDE = 64
+
+# symbols the header declares; tests check each is exported
+ABI_SYMBOLS = [
+    'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
+    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
+    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv2d_fwd',
+    'sc2_eb_forward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
+    'sc2_pmf_to_quantized_cdf',
+    'sc2_rans_max_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
+]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        'N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride_h', 'stride_w', 'pad_h', 'pad_w', 'OH', 'OW',
+        'a_op', 'epilogue', 'out_format', 'Kpad', 'Cout_pad')]
+
+
+class Sc2Error(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libsc2amd.so; raises if it has not been built (python sc2-benchmark_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Sc2Error('libsc2amd.so not found at {}: the HIP extension is not built '
+                       '(run `python -c "import __graft_entry__ as g; g.build()"`). '
+                       'There is no CPU fallback.'.format(LIB_PATH))
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+    L.sc2_abi_version.restype = i32
+    L.sc2_last_error.restype = ctypes.c_char_p
+    L.sc2_device_count.restype = i32
+    L.sc2_nchw_f32_to_nhwc_bf16.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.sc2_nhwc_bf16_to_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.sc2_conv_weight_rows.argtypes = [i32]
+    L.sc2_conv_weight_pitch.argtypes = [i32]
+    L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
+    L.sc2_eb_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
+    L.sc2_eb_bits_partial_len.argtypes = [i32, i32, i32]
+    L.sc2_eb_symbols.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.sc2_eb_dequantize.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.sc2_pmf_to_quantized_cdf.argtypes = [ctypes.POINTER(ctypes.c_float), i32, i32,
+                                           ctypes.POINTER(ctypes.c_uint32)]
+    L.sc2_rans_max_bytes.argtypes = [i64]
+    L.sc2_rans_max_bytes.restype = i64
+    L.sc2_rans_encode_batch.argtypes = [vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.sc2_rans_decode_batch.argtypes = [vp, i64, vp, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp]
+    for name in ABI_SYMBOLS:
+        getattr(L, name)  # raises AttributeError if the library lacks a declared symbol
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().sc2_last_error().decode('utf-8', 'replace')
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = last_error()
+        if rc in (-1, -3, -4):
+            raise ValueError('{}: {}'.format(what, msg))
+        raise Sc2Error('{} failed (code {}): {}'.format(what, rc, msg))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise Sc2Error('{} must be a tensor on a HIP device (got {}); there is no CPU fallback in this package'
+                       .format(name, 'device=' + str(t.device) if isinstance(t, torch.Tensor) else type(t)))
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+# --------------------------------------------------------------------------------------------- #
+# layout
+# --------------------------------------------------------------------------------------------- #
+def nchw_f32_to_nhwc_bf16(x, cpad=None):
+    """x: f32 [N,C,H,W] contiguous -> bf16 tensor of shape [N,H,W,Cpad] (NHWC memory)."""
+    _dev(x, 'x')
+    assert x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    cpad = C if cpad is None else cpad
+    y = torch.empty((N, H, W, cpad), dtype=torch.bfloat16, device=x.device)
+    _check(lib().sc2_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(y), N, C, H, W, cpad, _stream()), 'nchw_f32_to_nhwc_bf16')
+    return y
+
+
+def nhwc_bf16_to_nchw_f32(x):
+    """x: bf16 [N,H,W,C] -> f32 [N,C,H,W]."""
+    _dev(x, 'x')
+    assert x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous()
+    N, H, W, C = x.shape
+    y = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    _check(lib().sc2_nhwc_bf16_to_nchw_f32(_ptr(x), _ptr(y), N, C, H, W, _stream()), 'nhwc_bf16_to_nchw_f32')
+    return y
+
+
+# --------------------------------------------------------------------------------------------- #
+# conv
+# --------------------------------------------------------------------------------------------- #
+def weight_rows(cout):
+    return lib().sc2_conv_weight_rows(int(cout))
+
+
+def weight_pitch(k):
+    return lib().sc2_conv_weight_pitch(int(k))
+
+
+def pack_conv_weight(w):
+    """w: [Cout, Cin, KH, KW] (any float dtype, device) -> bf16 [Cout_pad, Kpad], k = (kh*KW+kw)*Cin+ci."""
+    cout, cin, kh, kw = w.shape
+    k = cin * kh * kw
+    rows, pitch = weight_rows(cout), weight_pitch(k)
+    packed = torch.zeros((rows, pitch), dtype=torch.bfloat16, device=w.device)
+    packed[:cout, :k] = w.detach().permute(0, 2, 3, 1).reshape(cout, k).to(torch.bfloat16)
+    return packed
+
+
+def pack_conv0_weight_pairs(w):
+    """First encoder conv (Cin=3, k5 s2 p2) on the pixel-pair view of the input.
+
+    The input is stored as bf16 NHWC with channels padded 3->4, viewed as [N, H, W/2, 8]
+    (8 = 2 pixels x 4 channels).  A 5-tap stride-2 row filter becomes a 3-tap stride-1 filter over
+    pixel pairs: pair tap t covers original taps kw = 2t, 2t+1 (kw = 5 and channel 3 are zero).
+    Returns bf16 [Cout_pad, Kpad] with k = (kh*3 + t)*8 + (dw*4 + c).
+    """
+    cout, cin, kh, kw = w.shape
+    assert cin <= 4 and kw == 5, 'pixel-pair packing is for the 3-channel 5x5 stride-2 first conv'
+    wp = torch.zeros((cout, kh, 3, 2, 4), dtype=torch.float32, device=w.device)
+    wd = w.detach().float()
+    for t in range(3):
+        for dw in range(2):
+            k = 2 * t + dw
+            if k < kw:
+                wp[:, :, t, dw, :cin] = wd[:, :, :, k].permute(0, 2, 1)
+    k_total = kh * 3 * 8
+    rows, pitch = weight_rows(cout), weight_pitch(k_total)
+    packed = torch.zeros((rows, pitch), dtype=torch.bfloat16, device=w.device)
+    packed[:cout, :k_total] = wp.reshape(cout, k_total).to(torch.bfloat16)
+    return packed
+
+
+def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilogue=EPI_NONE,
+               out_format=OUT_BF16_NHWC, ep_x=None, ep_beta=None, out=None):
+    """x_nhwc: bf16 [N,H,W,Cin]; returns the output tensor.
+
+    out_format OUT_BF16_NHWC -> bf16 [N,OH,OW,Cout]; OUT_F32_NCHW -> f32 [N,Cout,OH,OW];
+    OUT_F32_NHWC -> f32 [N,OH,OW,Cout].  stride / pad: int or (h, w).
+    """
+    _dev(x_nhwc, 'x')
+    _dev(w_packed, 'w_packed')
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    N, H, W, Cin = x_nhwc.shape
+    OH = (H + 2 * ph - kh) // sh + 1
+    OW = (W + 2 * pw - kw) // sw + 1
+    d = ConvDesc(N, H, W, Cin, cout, kh, kw, sh, sw, ph, pw, OH, OW, a_op, epilogue, out_format,
+                 w_packed.shape[1], w_packed.shape[0])
+    if out is None:
+        if out_format == OUT_BF16_NHWC:
+            out = torch.empty((N, OH, OW, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+        elif out_format == OUT_F32_NCHW:
+            out = torch.empty((N, cout, OH, OW), dtype=torch.float32, device=x_nhwc.device)
+        else:
+            out = torch.empty((N, OH, OW, cout), dtype=torch.float32, device=x_nhwc.device)
+    if ep_x is not None:
+        _dev(ep_x, 'ep_x')
+        assert ep_x.dtype == torch.bfloat16 and ep_x.is_contiguous() and ep_x.numel() == N * OH * OW * cout
+    if ep_beta is not None:
+        _dev(ep_beta, 'ep_beta')
+        assert ep_beta.dtype == torch.float32 and ep_beta.is_contiguous() and ep_beta.numel() == cout
+    _check(lib().sc2_conv2d_fwd(ctypes.byref(d), _ptr(x_nhwc), _ptr(w_packed), _ptr(out), _ptr(ep_x),
+                                _ptr(ep_beta), _stream()), 'conv2d_fwd')
+    return out
+
+
+# --------------------------------------------------------------------------------------------- #
+# entropy bottleneck
+# --------------------------------------------------------------------------------------------- #
+def eb_forward(y, params, mode, noise=None, lik_bound=1e-9, want_y_hat=True, want_nhwc=False, want_lik=True,
+               want_bits=False):
+    """y: f32 [N,C,*spatial] contiguous (NCHW). Returns (y_hat, y_hat_nhwc_bf16, lik, bits_partial)."""
+    _dev(y, 'y')
+    _dev(params, 'params')
+    assert y.dtype == torch.float32 and y.is_contiguous() and params.dtype == torch.float32
+    N, C = y.shape[0], y.shape[1]
+    HW = y.numel() // (N * C)
+    assert params.shape == (C, EB_PARAM_STRIDE) and params.is_contiguous()
+    if noise is not None:
+        _dev(noise, 'noise')
+        assert noise.shape == y.shape and noise.dtype == torch.float32 and noise.is_contiguous()
+    y_hat = torch.empty_like(y) if want_y_hat else None
+    nhwc = torch.empty((N,) + tuple(y.shape[2:]) + (C,), dtype=torch.bfloat16, device=y.device) if want_nhwc else None
+    lik = torch.empty_like(y) if want_lik else None
+    nb = lib().sc2_eb_bits_partial_len(N, C, HW) if want_bits else 0
+    bits = torch.empty((nb,), dtype=torch.float32, device=y.device) if want_bits else None
+    _check(lib().sc2_eb_forward(_ptr(y), _ptr(noise), _ptr(params), N, C, HW, int(mode), float(lik_bound),
+                                _ptr(y_hat), _ptr(nhwc), _ptr(lik), _ptr(bits), nb, _stream()), 'eb_forward')
+    return y_hat, nhwc, lik, bits
+
+
+def eb_symbols(y, medians):
+    _dev(y, 'y')
+    _dev(medians, 'medians')
+    assert y.dtype == torch.float32 and y.is_contiguous() and medians.dtype == torch.float32
+    N, C = y.shape[0], y.shape[1]
+    HW = y.numel() // (N * C)
+    assert medians.numel() == C and medians.is_contiguous()
+    sym = torch.empty(y.shape, dtype=torch.int32, device=y.device)
+    _check(lib().sc2_eb_symbols(_ptr(y), _ptr(medians), N, C, HW, _ptr(sym), _stream()), 'eb_symbols')
+    return sym
+
+
+def eb_dequantize(symbols, medians, want_f32=True, want_nhwc=False):
+    _dev(symbols, 'symbols')
+    _dev(medians, 'medians')
+    assert symbols.dtype == torch.int32 and symbols.is_contiguous()
+    N, C = symbols.shape[0], symbols.shape[1]
+    HW = symbols.numel() // (N * C)
+    f32 = torch.empty(symbols.shape, dtype=torch.float32, device=symbols.device) if want_f32 else None
+    nhwc = torch.empty((N,) + tuple(symbols.shape[2:]) + (C,), dtype=torch.bfloat16,
+                       device=symbols.device) if want_nhwc else None
+    _check(lib().sc2_eb_dequantize(_ptr(symbols), _ptr(medians), N, C, HW, _ptr(f32), _ptr(nhwc), _stream()),
+           'eb_dequantize')
+    return f32, nhwc
+
+
+# --------------------------------------------------------------------------------------------- #
+# CDF + rANS
+# --------------------------------------------------------------------------------------------- #
+def pmf_to_quantized_cdf(pmf, precision=16):
+    """Host function. pmf: sequence / 1-D CPU tensor of floats -> torch.IntTensor (len+1)."""
+    if isinstance(pmf, torch.Tensor):
+        pmf = pmf.detach().cpu().tolist()
+    n = len(pmf)
+    arr = (ctypes.c_float * n)(*pmf)
+    out = (ctypes.c_uint32 * (n + 1))()
+    _check(lib().sc2_pmf_to_quantized_cdf(arr, n, int(precision), out), 'pmf_to_quantized_cdf')
+    return torch.IntTensor(list(out))
+
+
+def rans_max_bytes(n_sym):
+    return int(lib().sc2_rans_max_bytes(int(n_sym)))
+
+
+def rans_encode_batch(symbols, cdfs, cdf_sizes, offsets, indexes=None, index_div=0, out_stride=None):
+    """symbols: i32 [n_streams, n_sym] (device).  Returns (buf u8 [n_streams, stride], offset, nbytes, status)."""
+    _dev(symbols, 'symbols')
+    for name, t in (('cdfs', cdfs), ('cdf_sizes', cdf_sizes), ('offsets', offsets)):
+        _dev(t, name)
+        assert t.dtype == torch.int32 and t.is_contiguous(), name
+    assert symbols.dtype == torch.int32 and symbols.dim() == 2 and symbols.is_contiguous()
+    n_streams, n_sym = symbols.shape
+    if indexes is not None:
+        _dev(indexes, 'indexes')
+        assert indexes.shape == symbols.shape and indexes.dtype == torch.int32 and indexes.is_contiguous()
+    if out_stride is None:
+        out_stride = 2 * n_sym + 64  # 16 bits / symbol + flush; overflow is reported via status
+    out_stride = (int(out_stride) + 3) // 4 * 4
+    dev = symbols.device
+    buf = torch.empty((n_streams, out_stride), dtype=torch.uint8, device=dev)
+    off = torch.empty((n_streams,), dtype=torch.int32, device=dev)
+    nb = torch.empty((n_streams,), dtype=torch.int32, device=dev)
+    st = torch.empty((n_streams,), dtype=torch.int32, device=dev)
+    _check(lib().sc2_rans_encode_batch(_ptr(symbols), _ptr(indexes), int(index_div), n_streams, n_sym, _ptr(cdfs),
+                                       cdfs.shape[0], cdfs.shape[1], _ptr(cdf_sizes), _ptr(offsets), _ptr(buf),
+                                       out_stride, _ptr(off), _ptr(nb), _ptr(st), _stream()), 'rans_encode_batch')
+    return buf, off, nb, st
+
+
+def rans_decode_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, indexes=None, index_div=0):
+    """buf: u8 [n_streams, stride] (device), stream i at buf[i, off[i]:off[i]+nb[i]].  Returns (symbols, status)."""
+    for name, t in (('buf', buf), ('off', off), ('nb', nb), ('cdfs', cdfs), ('cdf_sizes', cdf_sizes),
+                    ('offsets', offsets)):
+        _dev(t, name)
+        assert t.is_contiguous(), name
+    assert buf.dtype == torch.uint8 and buf.dim() == 2
+    n_streams, stride = buf.shape
+    dev = buf.device
+    sym = torch.empty((n_streams, n_sym), dtype=torch.int32, device=dev)
+    st = torch.empty((n_streams,), dtype=torch.int32, device=dev)
+    if indexes is not None:
+        _dev(indexes, 'indexes')
+        assert indexes.shape == sym.shape and indexes.dtype == torch.int32 and indexes.is_contiguous()
+    _check(lib().sc2_rans_decode_batch(_ptr(buf), stride, _ptr(off), _ptr(nb), _ptr(indexes), int(index_div),
+                                       n_streams, int(n_sym), _ptr(cdfs), cdfs.shape[0], cdfs.shape[1],
+                                       _ptr(cdf_sizes), _ptr(offsets), _ptr(sym), _ptr(st), _stream()),
+           'rans_decode_batch')
+    return sym, st

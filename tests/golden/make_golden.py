@@ -1,0 +1,105 @@
+"""Generates the committed golden fixtures from the ORACLE (oracle/), in this container.
+
+    python tests/golden/make_golden.py
+
+The reference itself cannot run here (compressai / torchdistill / torchvision are not installed and not
+installable), so these vectors pin the oracle against regressions and give the GPU tests fixed
+inputs/outputs; they are NOT outputs of a CompressAI binary (parity unpinned).  If a machine
+with compressai is available, regenerate the same keys there to upgrade the pin.
+"""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import cpu_ref as R  # noqa: E402
+from oracle import rans, rans_py  # noqa: E402
+sys.path.insert(0, HERE)
+from recipe import build_oracle_bottleneck, fingerprint  # noqa: E402
+
+
+def make_rans_kat():
+    kat = {'_provenance': 'self-derived from the restated algorithm (SURVEY.md 8(c)); C and pure-Python '
+                          'restatements agree; not from a CompressAI binary'}
+    pmf = [0.1, 0.2, 0.4, 0.2, 0.099, 0.001]
+    cdf = [int(v) for v in rans.pmf_to_quantized_cdf(pmf)]
+    assert cdf == rans_py.pmf_to_quantized_cdf(pmf)
+    kat['cdf_cases'] = [
+        {'pmf': pmf, 'cdf': cdf},
+        {'pmf': [1e-9, 0.5, 0.5 - 2e-9, 1e-9], 'cdf': [int(v) for v in rans.pmf_to_quantized_cdf([1e-9, 0.5, 0.5 - 2e-9, 1e-9])]},
+        {'pmf': [0.25] * 4, 'cdf': [int(v) for v in rans.pmf_to_quantized_cdf([0.25] * 4)]},
+        {'pmf': [1e-12] * 7 + [1.0], 'cdf': [int(v) for v in rans.pmf_to_quantized_cdf([1e-12] * 7 + [1.0])]},
+    ]
+    table = {'cdfs': [cdf], 'cdf_sizes': [7], 'offsets': [-2]}
+    cases = []
+    for syms in ([], [0, 1, -1, 2, -2, 0, 0, 1], [0, 3, -3, 40, -40, 1000, 0], [5] * 9, [-100000, 100000], [70000] * 3):
+        idx = [0] * len(syms)
+        enc = rans.encode_with_indexes(syms, idx, table['cdfs'], table['cdf_sizes'], table['offsets'])
+        assert enc == rans_py.encode_with_indexes(syms, idx, table['cdfs'], table['cdf_sizes'], table['offsets'])
+        assert list(rans.decode_with_indexes(enc, idx, table['cdfs'], table['cdf_sizes'], table['offsets'])) == syms
+        cases.append({'symbols': syms, 'indexes': idx, 'hex': enc.hex()})
+    # two-row table with different lengths and offsets, indexes alternate
+    cdf2 = [int(v) for v in rans.pmf_to_quantized_cdf([0.05, 0.9, 0.04, 0.01])]
+    width = max(len(cdf), len(cdf2))
+    t2 = {'cdfs': [cdf + [0] * (width - len(cdf)), cdf2 + [0] * (width - len(cdf2))], 'cdf_sizes': [7, 5],
+          'offsets': [-2, -1]}
+    rng = random.Random(0)
+    syms = [rng.randint(-6, 6) for _ in range(5000)]
+    idx = [i % 2 for i in range(5000)]
+    enc = rans.encode_with_indexes(syms, idx, t2['cdfs'], t2['cdf_sizes'], t2['offsets'])
+    assert enc == rans_py.encode_with_indexes(syms, idx, t2['cdfs'], t2['cdf_sizes'], t2['offsets'])
+    kat['table'] = table
+    kat['cases'] = cases
+    kat['table2'] = t2
+    kat['case2'] = {'seed': 0, 'n': 5000, 'nbytes': len(enc),
+                    'sha_prefix_hex': enc[:32].hex(), 'tail_hex': enc[-16:].hex()}
+    with open(os.path.join(HERE, 'rans_kat.json'), 'w') as f:
+        json.dump(kat, f, indent=1)
+
+
+def make_fp_golden():
+    m, x = build_oracle_bottleneck(R)
+    g = {'fingerprint': fingerprint(m), 'x': x}
+    with torch.no_grad():
+        latent = m.encoder(x)
+        y_hat, lik = m.entropy_bottleneck(latent)
+        g['latent'] = latent
+        g['y_hat_eval'] = y_hat
+        g['lik_eval'] = lik
+        noise = torch.rand_like(latent) - 0.5
+        y_noisy, lik_noisy = m.entropy_bottleneck(latent, training=True, noise=noise)
+        g['noise'] = noise
+        g['y_hat_noise'] = y_noisy
+        g['lik_noise'] = lik_noisy
+        g['bits_eval'] = R.bpp_loss(y_hat, lik, 'sum')
+        g['bpp_mean'] = R.bpp_loss(y_hat, lik, 'mean')
+        g['bpp_batchmean'] = R.bpp_loss(y_hat, lik, 'batchmean')
+        g['decoded'] = m.decoder(y_hat)
+        g['aux_loss'] = m.aux_loss()
+        g['gdn_in'] = torch.randn(2, 48, 7, 7)
+        g['gdn_out'] = m.encoder[3](g['gdn_in'])
+        g['igdn_out'] = R.GDN1(48, inverse=True)(g['gdn_in'])
+        m.update()
+        eb = m.entropy_bottleneck
+        g['quantized_cdf'] = eb._quantized_cdf.clone()
+        g['offset'] = eb._offset.clone()
+        g['cdf_length'] = eb._cdf_length.clone()
+        g['symbols'] = eb.symbols(latent)
+        enc = m.encode(x)
+        g['strings_hex'] = [s.hex() for s in enc['strings'][0]]
+        g['shape'] = list(enc['shape'])
+        g['file_size_kb'] = R.file_size(enc)
+        g['file_size_env'] = {'python': sys.version.split()[0], 'torch': torch.__version__}
+        g['decoded_from_strings'] = m.decode(**enc)
+    torch.save(g, os.path.join(HERE, 'fp_golden.pt'))
+
+
+if __name__ == '__main__':
+    make_rans_kat()
+    make_fp_golden()
+    print('golden fixtures written to', HERE)

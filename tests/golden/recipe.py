@@ -1,0 +1,25 @@
+"""Deterministic recipe for the golden bottleneck (shared by make_golden.py and the tests).
+
+The 1.3 M weights are NOT stored in the fixture (5 MB); they are rebuilt from torch.manual_seed(0) on the
+CPU generator and checked against the stored fingerprint.
+"""
+import torch
+
+
+def build_oracle_bottleneck(R):
+    torch.manual_seed(0)
+    m = R.FPBasedResNetBottleneck()
+    R.perturb_quantiles(m.entropy_bottleneck)
+    with torch.no_grad():
+        m.encoder[4].weight.mul_(40.0)   # spreads the latent over several quantisation bins
+        for g in (m.encoder[1], m.encoder[3], m.decoder[1], m.decoder[3]):
+            g.gamma.add_(0.02 * torch.rand_like(g.gamma))   # non-diagonal gamma
+        for f in m.entropy_bottleneck.factors:
+            f.add_(0.3 * torch.randn_like(f))               # exercise the tanh gates
+    m.eval()
+    x = torch.rand(2, 3, 32, 32)
+    return m, x
+
+
+def fingerprint(module):
+    return {k: float(v.double().abs().sum()) for k, v in module.state_dict().items() if v.numel() > 0}

@@ -1,0 +1,68 @@
+"""The C-ABI library loads, exports every symbol include/sc2_bottleneck.h declares, and its HOST function
+(CDF quantisation) is bit-exact against the oracle.  No device compute here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import rans as oracle_rans
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'sc2_bottleneck.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(sc2_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol(S):
+    lib = S.hip.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), 'libsc2amd.so does not export {}'.format(name)
+    assert sorted(S.hip.ABI_SYMBOLS) == declared
+    assert lib.sc2_abi_version() == 3
+
+
+def test_missing_library_fails_loudly(S, monkeypatch):
+    monkeypatch.setattr(S.hip, '_lib', None)
+    monkeypatch.setattr(S.hip, 'LIB_PATH', '/nonexistent/libsc2amd.so')
+    with pytest.raises(S.hip.Sc2Error, match='no CPU fallback'):
+        S.hip.lib()
+
+
+def test_cpu_tensor_is_rejected(S):
+    import torch
+    with pytest.raises(S.hip.Sc2Error, match='no CPU fallback'):
+        S.hip.nchw_f32_to_nhwc_bf16(torch.zeros(1, 3, 4, 4))
+    m = S.FPBasedResNetBottleneck()
+    with torch.no_grad(), pytest.raises(S.hip.Sc2Error):
+        m(torch.zeros(1, 3, 32, 32))
+
+
+def test_host_cdf_matches_oracle(S):
+    rng = np.random.RandomState(1)
+    for n in (1, 2, 5, 23, 64, 257):
+        for power in (1, 3, 8):
+            p = rng.rand(n).astype(np.float32) ** power
+            p /= max(p.sum(), 1e-30)
+            got = S.hip.pmf_to_quantized_cdf(p.tolist())
+            want = oracle_rans.pmf_to_quantized_cdf(p)
+            assert got.tolist() == [int(v) for v in want]
+    assert S.hip.pmf_to_quantized_cdf([1e-9, 0.5, 0.5 - 2e-9, 1e-9]).tolist() == [0, 1, 32767, 65535, 65536]
+    with pytest.raises(ValueError):
+        S.hip.pmf_to_quantized_cdf([0.3, -0.2])
+    with pytest.raises(ValueError):
+        S.hip.pmf_to_quantized_cdf([0.0, 0.0, 0.0])
+    with pytest.raises(ValueError):
+        S.hip.pmf_to_quantized_cdf([float('nan'), 0.5])
+
+
+def test_sizing_helpers(S):
+    lib = S.hip.lib()
+    assert [lib.sc2_conv_weight_rows(c) for c in (24, 48, 64, 96, 256, 512, 1000)] == [32, 48, 64, 96, 256, 512, 1024]
+    assert [lib.sc2_conv_weight_pitch(k) for k in (75, 96, 120, 2400)] == [128, 128, 128, 2432]
+    assert S.hip.rans_max_bytes(0) >= 8 and S.hip.rans_max_bytes(72600) >= 72600 * 52 // 8
