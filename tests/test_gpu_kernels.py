@@ -1,0 +1,289 @@
+"""-m gpu: per-kernel parity of the HIP path (through the C-ABI) against the CPU oracle.
+
+Tolerances: integer / byte work (symbols given y, CDF tables, rANS streams) is bit-exact.  The MFMA kernels
+take bf16 operands and accumulate in f32; they are compared with the f32 CPU op evaluated on the SAME
+bf16-rounded operands, so only accumulation order and the final bf16 store rounding differ:
+|err| <= 2^-8 |ref| + 1e-3 * scale for bf16 outputs, 2e-3 relative for f32 outputs.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import rans as oracle_rans
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def assert_close_bf16(got, ref, what, extra=0.0):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs()
+    tol = (2.0 ** -8 + extra) * ref.abs() + 2e-3 * scale
+    bad = err > tol
+    assert not bad.any(), '{}: {} / {} elements off, max err {} (scale {})'.format(
+        what, int(bad.sum()), bad.numel(), err.max().item(), scale)
+
+
+def test_layout_roundtrip(S, dev):
+    x = torch.randn(3, 5, 6, 10)
+    y = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev), 8)
+    assert y.shape == (3, 6, 10, 8) and y.dtype == torch.bfloat16
+    ref = torch.zeros(3, 6, 10, 8)
+    ref[..., :5] = bf16_round(x).permute(0, 2, 3, 1)
+    assert torch.equal(y.float().cpu(), ref)
+    y4 = S.hip.nchw_f32_to_nhwc_bf16(x[:, :3].contiguous().to(dev), 4)
+    assert torch.equal(y4.float().cpu()[..., :3], bf16_round(x[:, :3]).permute(0, 2, 3, 1)) and (y4[..., 3] == 0).all()
+    back = S.hip.nhwc_bf16_to_nchw_f32(y)
+    assert torch.equal(back.cpu()[:, :5], bf16_round(x))
+
+
+CONV_CASES = [
+    # (Cin, Cout, k, stride, pad, H, W, N)   static geometries of the FP bottleneck, then generic ones
+    (96, 48, 5, 2, 2, 20, 24, 2),
+    (48, 24, 2, 1, 0, 9, 11, 3),
+    (24, 512, 2, 1, 1, 7, 9, 2),
+    (512, 256, 2, 1, 0, 8, 8, 2),
+    (256, 256, 2, 1, 1, 7, 7, 3),
+    (16, 40, 3, 1, 1, 13, 9, 2),     # generic, Cout 40 -> 48-row tile
+    (64, 64, 3, 2, 1, 15, 15, 2),    # generic 64
+    (32, 136, 1, 1, 0, 5, 5, 7),     # generic 128-wide, Cout not a tile multiple
+    (8, 96, 3, 1, 1, 6, 6, 1),       # generic 96
+    (128, 8, 1, 2, 0, 9, 9, 2),      # tiny Cout
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,H,W,N', CONV_CASES)
+def test_conv_igemm(S, dev, cin, cout, k, stride, pad, H, W, N):
+    g = torch.Generator().manual_seed(cin * 1000 + cout)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ref = F.conv2d(bf16_round(x), bf16_round(w), stride=stride, padding=pad)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev), cin)
+    wp = S.hip.pack_conv_weight(w.to(dev))
+    out = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad)
+    assert out.shape == (N, ref.shape[2], ref.shape[3], cout)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'conv bf16 nhwc')
+    out32 = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW)
+    torch.testing.assert_close(out32.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+    out32h = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NHWC)
+    assert torch.equal(out32h.permute(0, 3, 1, 2).cpu(), out32.cpu())
+
+
+def test_conv_identity_asymmetric(S, dev):
+    """A = I style check: 1x1 conv with a permutation-like asymmetric weight must route channels exactly."""
+    cin = cout = 96
+    x = torch.arange(2 * cin * 4 * 5, dtype=torch.float32).reshape(2, cin, 4, 5) % 251 - 125
+    w = torch.zeros(cout, cin, 1, 1)
+    for o in range(cout):
+        w[o, (7 * o + 3) % cin, 0, 0] = 1.0 if o % 2 == 0 else -2.0
+    ref = F.conv2d(x, w)
+    out = S.hip.conv2d_fwd(S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)), S.hip.pack_conv_weight(w.to(dev)), cout, 1, 1, 1, 0,
+                           out_format=S.hip.OUT_F32_NCHW)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_conv0_pixel_pairs(S, dev):
+    """First encoder conv (3->96, k5 s2 p2) on the pixel-pair view equals the plain convolution."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 32, 48, generator=g)
+    w = torch.randn(96, 3, 5, 5, generator=g) / 75 ** 0.5
+    ref = F.conv2d(bf16_round(x), bf16_round(w), stride=2, padding=2)
+    x4 = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev), 4)
+    out = S.hip.conv2d_fwd(x4.view(2, 32, 24, 8), S.hip.pack_conv0_weight_pairs(w.to(dev)), 96, 5, 3, (2, 1), (2, 1),
+                           out_format=S.hip.OUT_F32_NCHW)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize('C,inverse', [(96, False), (48, False), (512, True), (256, True), (40, False)])
+def test_gdn1(S, R, dev, C, inverse):
+    torch.manual_seed(C)
+    ref_m = R.GDN1(C, inverse=inverse)
+    with torch.no_grad():
+        ref_m.gamma.add_(0.05 * torch.rand(C, C) / C ** 0.5)
+        ref_m.beta.add_(0.1 * torch.rand(C))
+    m = S.GDN1(C, inverse=inverse)
+    m.load_state_dict(ref_m.state_dict())
+    assert sorted(m.state_dict().keys()) == sorted(ref_m.state_dict().keys())
+    m.to(dev)
+    x = torch.randn(2, C, 9, 7)
+    with torch.no_grad():
+        # oracle on the bf16-rounded operands the kernel sees (x and gamma are bf16 on the device)
+        beta = ref_m.beta_reparam(ref_m.beta)
+        gamma = bf16_round(ref_m.gamma_reparam(ref_m.gamma)).reshape(C, C, 1, 1)
+        xb = bf16_round(x)
+        norm = F.conv2d(xb.abs(), gamma, beta)
+        ref = xb * norm if inverse else xb * (1.0 / norm)
+        out = m(x.to(dev))
+        out_b = m.forward_nhwc(S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)))
+        full = ref_m(x)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+    assert_close_bf16(out_b.permute(0, 3, 1, 2), ref, 'gdn bf16')
+    # and against the pure-f32 oracle with the bf16 operand tolerance
+    assert_close_bf16(out, full, 'gdn vs f32 oracle', extra=2.0 ** -6)
+
+
+def _golden():
+    return torch.load(os.path.join(HERE, 'golden', 'fp_golden.pt'), weights_only=False)
+
+
+def _device_bottleneck(S, R, dev):
+    import sys
+    sys.path.insert(0, os.path.join(HERE, 'golden'))
+    from recipe import build_oracle_bottleneck
+    ref, x = build_oracle_bottleneck(R)
+    m = S.FPBasedResNetBottleneck()
+    m.load_state_dict({k: v.clone() for k, v in ref.state_dict().items()})
+    m.eval().to(dev)
+    return m, ref, x
+
+
+def test_entropy_bottleneck_forward(S, R, dev):
+    g = _golden()
+    m, ref, _ = _device_bottleneck(S, R, dev)
+    eb = m.entropy_bottleneck
+    latent = g['latent'].to(dev)
+    with torch.no_grad():
+        y_hat, lik = eb(latent)  # eval: round(y - median) + median
+        assert torch.equal(y_hat.cpu(), g['y_hat_eval'])
+        torch.testing.assert_close(lik.cpu(), g['lik_eval'], rtol=2e-4, atol=2e-7)
+        y_n, lik_n = eb(latent, training=True, noise=g['noise'].to(dev))
+        torch.testing.assert_close(y_n.cpu(), g['y_hat_noise'], rtol=0, atol=1e-6)
+        torch.testing.assert_close(lik_n.cpu(), g['lik_noise'], rtol=2e-4, atol=2e-7)
+        # fused rate: sum of -log2 p partials == BppLoss('sum') of the oracle
+        _, nhwc, _, bits = S.hip.eb_forward(latent.contiguous(), eb._cached_params(), S.hip.EB_DEQUANTIZE,
+                                            want_y_hat=False, want_nhwc=True, want_lik=False, want_bits=True)
+        assert abs(bits.double().sum().item() - float(g['bits_eval'])) <= 1e-4 * float(g['bits_eval'])
+        assert torch.equal(nhwc.float().permute(0, 3, 1, 2).cpu(), bf16_round(g['y_hat_eval']))
+        # likelihood lower bound engages far in the tails
+        far = torch.full((1, 24, 2, 2), 500.0, device=dev)
+        _, lik_far = eb(far)
+        assert torch.all(lik_far == 1e-9)
+        loss = S.BppLoss('eb', 'sum')({'eb': {'output': (y_hat, lik)}})
+        assert abs(loss.item() - float(g['bits_eval'])) <= 1e-3 * float(g['bits_eval'])
+
+
+def test_symbols_and_dequantize_bit_exact(S, R, dev):
+    g = _golden()
+    m, ref, _ = _device_bottleneck(S, R, dev)
+    eb = m.entropy_bottleneck
+    latent = g['latent'].to(dev)
+    means = m._get_means(latent)
+    sym = eb.quantize(latent, 'symbols', means)
+    assert sym.dtype == torch.int32 and torch.equal(sym.cpu(), g['symbols'])
+    deq = eb.quantize(latent, 'dequantize', means)
+    assert torch.equal(deq.cpu(), g['y_hat_eval'])
+    assert torch.equal(eb.dequantize(sym, means).cpu(), g['y_hat_eval'])
+    # half-way cases round to even, like torch.round
+    y = torch.tensor([0.5, 1.5, 2.5, -0.5, -1.5, 3.4999, -2.5001]).reshape(1, 1, 7, 1).repeat(1, 24, 1, 1).to(dev)
+    s = S.hip.eb_symbols(y.contiguous(), torch.zeros(24, device=dev))
+    assert s[0, 0, :, 0].tolist() == [0, 2, 2, 0, -2, 3, -3]
+    noisy = eb.quantize(latent, 'noise')
+    assert (noisy - latent).abs().max().item() <= 0.5
+    with pytest.raises(ValueError):
+        eb.quantize(latent, 'nope')
+
+
+def _tables(dev, rows, sizes, offs):
+    width = max(len(r) for r in rows)
+    cdfs = torch.tensor([r + [0] * (width - len(r)) for r in rows], dtype=torch.int32, device=dev)
+    return cdfs, torch.tensor(sizes, dtype=torch.int32, device=dev), torch.tensor(offs, dtype=torch.int32, device=dev)
+
+
+def _streams(buf, off, nb):
+    b, o, n = buf.cpu().numpy(), off.cpu().numpy(), nb.cpu().numpy()
+    return [b[i, o[i]:o[i] + n[i]].tobytes() for i in range(b.shape[0])]
+
+
+def test_rans_known_answers(S, dev):
+    kat = json.load(open(os.path.join(HERE, 'golden', 'rans_kat.json')))
+    t = kat['table']
+    cdfs, sizes, offs = _tables(dev, t['cdfs'], t['cdf_sizes'], t['offsets'])
+    for case in kat['cases']:
+        n = len(case['symbols'])
+        sym = torch.tensor([case['symbols']], dtype=torch.int32, device=dev).reshape(1, n)
+        buf, off, nb, st = S.hip.rans_encode_batch(sym, cdfs, sizes, offs, index_div=max(n, 1), out_stride=256)
+        assert st.item() == 0
+        assert _streams(buf, off, nb)[0].hex() == case['hex']
+        dec, st2 = S.hip.rans_decode_batch(buf, off, nb, n, cdfs, sizes, offs, index_div=max(n, 1))
+        assert dec.cpu().tolist() == [case['symbols']]
+
+
+@pytest.mark.parametrize('n_streams,n_sym', [(1, 1), (3, 17), (64, 300), (70, 1000), (130, 257)])
+def test_rans_batch_bit_exact(S, dev, n_streams, n_sym):
+    rng = np.random.RandomState(n_streams * 7 + n_sym)
+    rows, sizes, offs = [], [], []
+    for r in range(5):
+        n = rng.randint(2, 30)
+        p = rng.rand(n).astype(np.float32) ** 3 + 1e-5
+        p /= p.sum()
+        cdf = [int(v) for v in oracle_rans.pmf_to_quantized_cdf(p)]
+        rows.append(cdf)
+        sizes.append(len(cdf))
+        offs.append(-int(rng.randint(0, n)))
+    cdfs, d_sizes, d_offs = _tables(dev, rows, sizes, offs)
+    sym = rng.randint(-12, 13, size=(n_streams, n_sym)).astype(np.int32)
+    sym[rng.rand(n_streams, n_sym) < 0.01] = 5000          # multi-nibble escapes
+    sym[rng.rand(n_streams, n_sym) < 0.01] = -70000
+    idx = rng.randint(0, 5, size=(n_streams, n_sym)).astype(np.int32)
+    d_sym, d_idx = torch.from_numpy(sym).to(dev), torch.from_numpy(idx).to(dev)
+    buf, off, nb, st = S.hip.rans_encode_batch(d_sym, cdfs, d_sizes, d_offs, indexes=d_idx,
+                                               out_stride=S.hip.rans_max_bytes(n_sym))
+    assert int(st.max()) == 0
+    got = _streams(buf, off, nb)
+    h_cdfs = cdfs.cpu().numpy()
+    for i in range(n_streams):
+        want = oracle_rans.encode_with_indexes(sym[i], idx[i], h_cdfs, sizes, offs)
+        assert got[i] == want, 'stream {} differs'.format(i)
+    dec, st2 = S.hip.rans_decode_batch(buf, off, nb, n_sym, cdfs, d_sizes, d_offs, indexes=d_idx)
+    assert int(st2.max()) == 0 and np.array_equal(dec.cpu().numpy(), sym)
+    # implicit indexes (entropy-bottleneck layout: row = position // index_div)
+    div = max(1, (n_sym + 4) // 5)
+    buf, off, nb, st = S.hip.rans_encode_batch(d_sym, cdfs, d_sizes, d_offs, index_div=div,
+                                               out_stride=S.hip.rans_max_bytes(n_sym))
+    imp = (np.arange(n_sym) // div).astype(np.int32)
+    got = _streams(buf, off, nb)
+    for i in range(0, n_streams, max(1, n_streams // 8)):
+        assert got[i] == oracle_rans.encode_with_indexes(sym[i], imp, h_cdfs, sizes, offs)
+    dec, _ = S.hip.rans_decode_batch(buf, off, nb, n_sym, cdfs, d_sizes, d_offs, index_div=div)
+    assert np.array_equal(dec.cpu().numpy(), sym)
+
+
+def test_rans_overflow_flag_and_large_table(S, dev):
+    rng = np.random.RandomState(3)
+    # a 400-row table does not fit the LDS path -> global-memory variant must give the same bytes
+    rows, sizes, offs = [], [], []
+    for r in range(400):
+        n = rng.randint(2, 24)
+        p = rng.rand(n).astype(np.float32) + 1e-3
+        p /= p.sum()
+        cdf = [int(v) for v in oracle_rans.pmf_to_quantized_cdf(p)]
+        rows.append(cdf)
+        sizes.append(len(cdf))
+        offs.append(-int(rng.randint(0, n)))
+    cdfs, d_sizes, d_offs = _tables(dev, rows, sizes, offs)
+    assert cdfs.numel() > 6144
+    sym = rng.randint(-5, 30, size=(9, 500)).astype(np.int32)
+    idx = rng.randint(0, 400, size=(9, 500)).astype(np.int32)
+    buf, off, nb, st = S.hip.rans_encode_batch(torch.from_numpy(sym).to(dev), cdfs, d_sizes, d_offs,
+                                               indexes=torch.from_numpy(idx).to(dev),
+                                               out_stride=S.hip.rans_max_bytes(500))
+    got = _streams(buf, off, nb)
+    h = cdfs.cpu().numpy()
+    for i in range(9):
+        assert got[i] == oracle_rans.encode_with_indexes(sym[i], idx[i], h, sizes, offs)
+    dec, _ = S.hip.rans_decode_batch(buf, off, nb, 500, cdfs, d_sizes, d_offs, indexes=torch.from_numpy(idx).to(dev))
+    assert np.array_equal(dec.cpu().numpy(), sym)
+    # too small a row: status flags the overflow instead of writing out of bounds
+    buf, off, nb, st = S.hip.rans_encode_batch(torch.from_numpy(sym).to(dev), cdfs, d_sizes, d_offs,
+                                               indexes=torch.from_numpy(idx).to(dev), out_stride=64)
+    assert int(st.min()) == 1
