@@ -1,0 +1,220 @@
+"""bench.py -- images/s + bpp of the Entropic-Student ResNet-50 (FP bottleneck 24ch) at 224x224 on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bs 256] [--inflight D]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of bs synthetic images resident in HBM, in the
+reference's evaluation mode after update() (sc2bench/models/backbone.py:229-233):
+    encoder (3 MFMA convs + 2 GDN1) -> symbols -> rANS encode (one stream per image) -> rANS decode ->
+    dequantise -> decoder (3 MFMA convs + 2 inverse GDN1) -> ResNet-50 layer2..fc -> logits.
+Nothing is skipped: the byte streams are really produced and really decoded; bpp is 8 * bytes / pixels.
+Steps are software-pipelined over D HIP streams (the serial range coder of batch i overlaps the MFMA
+kernels of batch i+1); exactly K steps complete inside the timed region, bracketed by barrier +
+synchronize; the wall time is the max over ranks.  One process per GPU; the path shards by image, so
+N GPUs = N independent shards, no data-path collective ("weak" scaling, bs per GPU fixed).
+
+Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant MFMA kernel, HIP events on
+its own stream, inside the timed region) and `cpu_baseline` (the oracle = CPU port of the same path, timed on
+the host cores of this box on a bounded sample; N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+BOTTLENECK_GFLOP_PER_IMG = 8.3418
+# algorithmic MFLOP per image of each tagged kernel (2 * MACs)
+KERNEL_MFLOP = {'enc.conv0': 180.6, 'enc.gdn1': 231.2, 'enc.conv2': 722.5, 'enc.gdn3': 14.5, 'enc.conv4': 27.9,
+                'dec.conv0': 308.3, 'dec.igdn1': 1644.2, 'dec.conv2': 3171.9, 'dec.igdn3': 396.5,
+                'dec.conv4': 1644.2}
+
+
+def build_model(dev, seed=0):
+    import sc2bench_amd as S
+    torch.manual_seed(seed)
+    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
+    model = S.splittable_resnet(cfg, resnet_name='resnet50', skips_avgpool=False, skips_fc=False, num_classes=1000)
+    eb = model.bottleneck_layer.entropy_bottleneck
+    with torch.no_grad():   # fixed quantile perturbation so the CDF tables are non-degenerate
+        C = eb.channels
+        q = torch.zeros(C, 1, 3)
+        for c in range(C):
+            q[c, 0, 0], q[c, 0, 1], q[c, 0, 2] = -(3 + c % 5), 0.25 * (c % 3), 4 + c % 7
+        eb.quantiles.copy_(q)
+    model.eval().to(dev)
+    model.update()
+    model.set_compute_dtype('bf16')
+    return model
+
+
+def synthetic_batch(bs, dev, seed=0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    x = torch.rand(bs, 3, 224, 224, generator=g)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return ((x - mean) / std).to(dev)
+
+
+def cpu_baseline(sample_images, state_dict):
+    """The oracle (CPU port of the reference path: torch CPU fp32 ops + single-threaded C rANS, as upstream)."""
+    from oracle import cpu_ref as R
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    ref = R.SplittableResNet50(R.FPBasedResNetBottleneck())
+    tables = ('_offset', '_quantized_cdf', '_cdf_length')   # rebuilt by the oracle's own update()
+    sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if not k.endswith(tables)}
+    ref.load_state_dict({k: v for k, v in sd.items() if not k.startswith('bottleneck_layer.')}, strict=False)
+    ref.bottleneck_layer.load_state_dict({k[len('bottleneck_layer.'):]: v for k, v in sd.items()
+                                          if k.startswith('bottleneck_layer.')}, strict=False)
+    ref.eval()
+    ref.update()
+    x = synthetic_batch(sample_images, torch.device('cpu'), seed=0)
+    with torch.no_grad():
+        ref(x[:2])  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            ref(x)
+            n += sample_images
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or n >= 8 * sample_images:
+                break
+    nbytes = sum(len(s) for s in ref.last_encoded['strings'][0])
+    return {'value': n / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': '{} images (batches of {}) of the same synthetic workload, full encode->decode->head, '
+                      '{:.1f} s of CPU work'.format(n, sample_images, dt),
+            'bpp': 8.0 * nbytes / (sample_images * 224 * 224)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
+    ap.add_argument('--inflight', type=int, default=4, help='steps in flight (HIP streams)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    if args.gpus != world and rank == 0 and distributed:
+        print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
+
+    import sc2bench_amd as S
+    from sc2bench_amd import hip
+    model = build_model(dev)
+    x = synthetic_batch(args.bs, dev, seed=rank)   # a different shard per rank, resident in HBM
+    D = max(1, min(args.inflight, args.steps))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(D)]
+    results = [None] * D
+
+    def step(i):
+        s = streams[i % D]
+        with torch.cuda.stream(s), torch.no_grad():
+            logits, nb, st = model.forward_device(x)
+            results[i % D] = (logits, nb, st)
+
+    def sync_all():
+        for s in streams:
+            s.synchronize()
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+
+    select = lambda tag: tag in KERNEL_MFLOP or tag.startswith('rans')  # noqa: E731
+    with hip.KernelTimer(select) as timer:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        sync_all()
+        t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    logits, nb, st = results[(args.steps - 1) % D]
+    assert int(st.max().item()) == 0, 'rANS row overflow'
+    assert torch.isfinite(logits.float()).all()
+    bytes_per_img = nb.float().mean().item()
+    bpp = 8.0 * bytes_per_img / (224 * 224)
+    images = args.bs * args.steps * world
+    value = images / elapsed
+
+    if rank == 0:
+        ksum = timer.summary()
+        conv = {k: v for k, v in ksum.items() if k in KERNEL_MFLOP}
+        dom = max(conv, key=lambda k: conv[k][0] * conv[k][1])
+        dom_ms = conv[dom][1]
+        achieved = KERNEL_MFLOP[dom] * 1e6 * args.bs / (dom_ms * 1e-3) / 1e12
+        fwd_ms = sum(v[1] for v in conv.values())
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'images/s + bpp, Entropic-Student ResNet-50 224^2',
+            'value': value, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'Entropic-Student ResNet-50 (FPBasedResNetBottleneck 24ch), ILSVRC2012 shape '
+                                   '224x224x3, eval after update(): encode -> rANS -> decode -> layer2..fc',
+                       'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'inflight_steps': D,
+                       'weights': 'random init seed 0 + fixed quantile perturbation', 'sharding': 'images, no collective'},
+            'bpp': bpp, 'bytes_per_image': bytes_per_img,
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS, 'traffic': traffic,
+                         'kernel_ms': dom_ms, 'launches_timed': conv[dom][0]},
+            'bottleneck_forward': {'ms_per_batch_sum_of_mfma_kernels': fwd_ms,
+                                   'tflops': BOTTLENECK_GFLOP_PER_IMG * args.bs / fwd_ms,
+                                   'frac_of_mfma_peak': BOTTLENECK_GFLOP_PER_IMG * args.bs / fwd_ms / PEAK_BF16_TFLOPS},
+            'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())},
+        }
+        if 'rans_encode' in ksum:
+            n_sym = 24 * 55 * 55
+            out['rans'] = {'encode_ms': ksum['rans_encode'][1], 'decode_ms': ksum['rans_decode'][1],
+                           'streams_in_flight': args.bs, 'symbols_per_stream': n_sym,
+                           'encode_Msym_per_s_per_stream': n_sym / ksum['rans_encode'][1] / 1e3,
+                           'decode_Msym_per_s_per_stream': n_sym / ksum['rans_decode'][1] / 1e3}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(8, model.state_dict())
+            except Exception as e:  # the baseline is a reported figure; never let it take the bench line down
+                out['cpu_baseline'] = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port',
+                                       'sample': 'failed: {}'.format(e)}
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

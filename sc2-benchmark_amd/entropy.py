@@ -84,7 +84,8 @@ class HipConv2d(nn.Conv2d):
     def forward_nhwc(self, x_nhwc, out_format=hip.OUT_BF16_NHWC):
         assert self.bias is None and self.groups == 1 and self.dilation == (1, 1)
         return hip.conv2d_fwd(x_nhwc, self.packed_weight(), self.out_channels, self.kernel_size[0],
-                              self.kernel_size[1], self.stride, self.padding, out_format=out_format)
+                              self.kernel_size[1], self.stride, self.padding, out_format=out_format,
+                              tag=getattr(self, '_tag', None))
 
     def forward(self, x):
         _require_device(x, 'HipConv2d')
@@ -139,7 +140,7 @@ class GDN1(nn.Module):
         beta, gamma_packed = self.effective()
         return hip.conv2d_fwd(x_nhwc, gamma_packed, self.in_channels, 1, 1, 1, 0, a_op=hip.AOP_ABS,
                               epilogue=hip.EPI_IGDN if self.inverse else hip.EPI_GDN, out_format=out_format,
-                              ep_x=x_nhwc, ep_beta=beta)
+                              ep_x=x_nhwc, ep_beta=beta, tag=getattr(self, '_tag', None))
 
     def forward(self, x):
         _require_device(x, 'GDN1')

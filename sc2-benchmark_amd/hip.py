@@ -91,6 +91,54 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer(object):
+    """Optional HIP-event timing of individual launches, on the stream they are launched on.
+
+    ``with hip.KernelTimer() as t: ...`` records an event pair around every launch made through this module
+    whose tag passes ``select``; ``t.summary()`` (after a synchronize) returns {tag: (count, mean_ms)}.
+    Used by bench.py to measure the dominant kernel live inside the timed region.
+    """
+    active = None
+
+    def __init__(self, select=None):
+        self.select = select
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+        return False
+
+    def summary(self):
+        out = {}
+        for tag, e0, e1 in self.records:
+            out.setdefault(tag, []).append(e0.elapsed_time(e1))
+        return {k: (len(v), sum(v) / len(v)) for k, v in out.items()}
+
+
+class _timed(object):
+    def __init__(self, tag):
+        t = KernelTimer.active
+        self.t = t if (t is not None and (t.select is None or t.select(tag))) else None
+        self.tag = tag
+
+    def __enter__(self):
+        if self.t is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.t.records.append((self.tag, self.e0, e1))
+        return False
+
+
 def _dev(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise Sc2Error('{} must be a tensor on a HIP device (got {}); there is no CPU fallback in this package'
@@ -173,7 +221,7 @@ def pack_conv0_weight_pairs(w):
 
 
 def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilogue=EPI_NONE,
-               out_format=OUT_BF16_NHWC, ep_x=None, ep_beta=None, out=None):
+               out_format=OUT_BF16_NHWC, ep_x=None, ep_beta=None, out=None, tag=None):
     """x_nhwc: bf16 [N,H,W,Cin]; returns the output tensor.
 
     out_format OUT_BF16_NHWC -> bf16 [N,OH,OW,Cout]; OUT_F32_NCHW -> f32 [N,Cout,OH,OW];
@@ -203,8 +251,9 @@ def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilo
     if ep_beta is not None:
         _dev(ep_beta, 'ep_beta')
         assert ep_beta.dtype == torch.float32 and ep_beta.is_contiguous() and ep_beta.numel() == cout
-    _check(lib().sc2_conv2d_fwd(ctypes.byref(d), _ptr(x_nhwc), _ptr(w_packed), _ptr(out), _ptr(ep_x),
-                                _ptr(ep_beta), _stream()), 'conv2d_fwd')
+    with _timed(tag or 'conv{}x{}_{}to{}'.format(kh, kw, Cin, cout)):
+        _check(lib().sc2_conv2d_fwd(ctypes.byref(d), _ptr(x_nhwc), _ptr(w_packed), _ptr(out), _ptr(ep_x),
+                                    _ptr(ep_beta), _stream()), 'conv2d_fwd')
     return out
 
 
@@ -296,9 +345,10 @@ def rans_encode_batch(symbols, cdfs, cdf_sizes, offsets, indexes=None, index_div
     off = torch.empty((n_streams,), dtype=torch.int32, device=dev)
     nb = torch.empty((n_streams,), dtype=torch.int32, device=dev)
     st = torch.empty((n_streams,), dtype=torch.int32, device=dev)
-    _check(lib().sc2_rans_encode_batch(_ptr(symbols), _ptr(indexes), int(index_div), n_streams, n_sym, _ptr(cdfs),
+    with _timed('rans_encode'):
+        _check(lib().sc2_rans_encode_batch(_ptr(symbols), _ptr(indexes), int(index_div), n_streams, n_sym, _ptr(cdfs),
                                        cdfs.shape[0], cdfs.shape[1], _ptr(cdf_sizes), _ptr(offsets), _ptr(buf),
-                                       out_stride, _ptr(off), _ptr(nb), _ptr(st), _stream()), 'rans_encode_batch')
+                                         out_stride, _ptr(off), _ptr(nb), _ptr(st), _stream()), 'rans_encode_batch')
     return buf, off, nb, st
 
 
@@ -316,7 +366,8 @@ def rans_decode_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, indexes=Non
     if indexes is not None:
         _dev(indexes, 'indexes')
         assert indexes.shape == sym.shape and indexes.dtype == torch.int32 and indexes.is_contiguous()
-    _check(lib().sc2_rans_decode_batch(_ptr(buf), stride, _ptr(off), _ptr(nb), _ptr(indexes), int(index_div),
+    with _timed('rans_decode'):
+        _check(lib().sc2_rans_decode_batch(_ptr(buf), stride, _ptr(off), _ptr(nb), _ptr(indexes), int(index_div),
                                        n_streams, int(n_sym), _ptr(cdfs), cdfs.shape[0], cdfs.shape[1],
                                        _ptr(cdf_sizes), _ptr(offsets), _ptr(sym), _ptr(st), _stream()),
            'rans_decode_batch')

@@ -111,6 +111,10 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             GDN1(d[2], inverse=True),
             HipConv2d(d[2], d[3], kernel_size=2, stride=1, padding=1, bias=False)
         )
+        for prefix, seq in (('enc', self.encoder), ('dec', self.decoder)):
+            for i, mod in enumerate(seq):
+                mod._tag = '{}.{}{}'.format(prefix, 'igdn' if getattr(mod, 'inverse', False) else
+                                            'gdn' if isinstance(mod, GDN1) else 'conv', i)
         self.output_format = 'f32_nchw'
         self._conv0_pack = None
         self._conv0_key = None
@@ -138,7 +142,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             N, _, H, W = x.shape
             x4 = hip.nchw_f32_to_nhwc_bf16(x, 4)                      # [N,H,W,4]
             xp = x4.view(N, H, W // 2, 8)                             # pixel pairs
-            h = hip.conv2d_fwd(xp, self._conv0_packed(), c0.out_channels, 5, 3, (2, 1), (2, 1))
+            h = hip.conv2d_fwd(xp, self._conv0_packed(), c0.out_channels, 5, 3, (2, 1), (2, 1), tag=c0._tag)
         else:
             cin = c0.in_channels
             xin = hip.nchw_f32_to_nhwc_bf16(x, (cin + 7) // 8 * 8)
