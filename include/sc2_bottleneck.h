@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 3
+#define SC2_ABI_VERSION 5
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -152,18 +152,24 @@ int sc2_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *c
  *           their rows because rANS emits its words back to front)
  * out_stride must be >= sc2_rans_max_bytes(n_sym); out_stride % 4 == 0.
  * status  : i32 [n_streams] 0 ok, 1 = row overflow (cannot happen with sc2_rans_max_bytes).
+ * workspace : device scratch of sc2_rans_workspace_bytes(n_streams, n_sym, n_cdfs, cdf_stride) bytes (the
+ *             [position][lane] transposed intermediate of the multi-pass coder and the per-entry reciprocal
+ *             table); contents undefined afterwards.
  */
 int64_t sc2_rans_max_bytes(int64_t n_sym);
+int64_t sc2_rans_workspace_bytes(int n_streams, int64_t n_sym, int n_cdfs, int cdf_stride);
 int sc2_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, int64_t index_div, int n_streams,
                           int64_t n_sym, const int32_t *cdfs, int n_cdfs, int cdf_stride,
                           const int32_t *cdf_sizes, const int32_t *offsets, uint8_t *out, int64_t out_stride,
-                          int32_t *out_offset, int32_t *out_nbytes, int32_t *status, void *stream);
+                          int32_t *out_offset, int32_t *out_nbytes, int32_t *status, void *workspace,
+                          int64_t workspace_bytes, void *stream);
 /* in : u8 [n_streams][in_stride], stream i at in[i*in_stride + in_offset[i] ..+in_nbytes[i]),
  *      in_offset[i] % 4 == 0.  symbols_out : i32 [n_streams][n_sym]. */
 int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const int32_t *in_offset, const int32_t *in_nbytes,
                           const int32_t *indexes, int64_t index_div, int n_streams, int64_t n_sym,
                           const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
-                          const int32_t *offsets, int32_t *symbols_out, int32_t *status, void *stream);
+                          const int32_t *offsets, int32_t *symbols_out, int32_t *status, void *workspace,
+                          int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

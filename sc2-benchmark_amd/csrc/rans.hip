@@ -3,16 +3,23 @@
 // 64-bit state, 32-bit word renormalisation, 16-bit probability precision, 4-bit bypass escape
 // for out-of-table values, one independent stream per image.
 //
-// rANS is a serial state machine per stream, so the parallel axis is the batch: one lane per
-// stream, 64 streams per wave.  All lanes of a wave sit at the same symbol position, so table
-// rows are (nearly) wave-uniform and the quantised CDFs live in LDS.
-//   * encoder: walks the symbols back to front (the order in which upstream's flush() pops its
-//     symbol stack), emits 32-bit words from the END of the stream's row towards its start, then
-//     the two state words; the stream is therefore end-aligned in its row (out_offset tells where).
-//     x / freq uses an exact double-precision reciprocal division (2 fma-corrected steps) instead
-//     of a 64-bit integer division.
-//   * decoder: mirrors Rans64DecGet/Advance; the symbol search is an upper-bound binary search
-//     over the (strictly increasing) CDF row, identical in result to upstream's linear find_if.
+// rANS is a serial state machine per stream, so the parallel axis is the batch: one lane per stream,
+// 64 streams per wave.  Everything that is NOT on the state's dependency chain is moved out of the serial
+// loop into fully parallel passes, and every access of the serial loop is made lane-contiguous:
+//
+//   encode  = table (parallel: per CDF entry the Alverson reciprocal of its frequency)  ->  prepare (parallel:
+//             symbol -> table entry index, transposed to [position][lane] through an LDS tile)  ->  serial (one
+//             wave per 64 streams: per 8 positions, 8 coalesced 256-byte loads and 8 LDS table reads are issued up
+//             front, then 8 branch-free integer state updates x += bias + (mulhi64(x, rcp) >> shift) * (2^16 - freq);
+//             emitted words are staged per lane in LDS and flushed in bursts).  Words are laid out from the END of
+//             the stream's row towards its start (the order in which upstream's flush() pops its symbol stack), so
+//             a stream is end-aligned in its row.  A conditional branch costs ~60 cycles on a lone wave
+//             (tools/micro/chain2.hip), hence the select-based hot path; escapes take a per-chunk slow path.
+//   decode  = serial (per CDF row, the wave builds an exact 65536-entry cum_freq -> symbol table in LDS: one
+//             ds_read_u16 replaces upstream's linear find_if; stream words come from a per-lane LDS ring; 8-symbol
+//             chunks are speculated branch-free and rolled back if they hit an escape symbol; outputs go to a
+//             [position][lane] buffer)  ->  finish (parallel transpose back to [stream][position]).
+//   Per-symbol explicit `indexes` (no common row per position) use the generic kernels at the bottom.
 #include "sc2_common.h"
 
 namespace {
@@ -21,10 +28,11 @@ constexpr int kPrecision = 16;
 constexpr int kBypassPrecision = 4;
 constexpr int kMaxBypassVal = (1 << kBypassPrecision) - 1;
 constexpr unsigned long long kRansL = 1ull << 31;
-constexpr int kMaxLdsEntries = 6144;  // cdf entries kept in LDS (24 KB i32 + 48 KB f64 reciprocals)
+constexpr int kEncLdsEntries = 4096;   // encoder table entries (16 B each) kept in LDS
+constexpr int kMaxRowLds = 4096;       // longest CDF row the LUT decoder keeps in LDS
 
 struct RansArgs {
-    const int32_t *symbols;   // encode: in   decode: out
+    const int32_t *symbols;   // encode: in
     const int32_t *indexes;   // nullable
     long long index_div;
     int n_streams;
@@ -38,148 +46,233 @@ struct RansArgs {
     int32_t *io_offset;       // encode: out  decode: in
     int32_t *io_nbytes;       // encode: out  decode: in
     int32_t *status;
-    int32_t *symbols_out;
+    int32_t *symbols_out;     // decode: out
+    uint32_t *ws;             // [n_blocks][n_sym][64]
 };
 
-// exact floor(x / f) and x mod f for x < 2^63, 1 <= f < 2^16, with rcp = 1.0 / f (correctly rounded).
-__device__ __forceinline__ void divmod_u64(unsigned long long x, unsigned f, double rcp, unsigned long long &q,
-                                           unsigned &r) {
-    const double df = (double)f;
-    const double dxh = (double)(unsigned)(x >> 32);
-    double q1 = floor(dxh * rcp);
-    double r1 = fma(-q1, df, dxh);
-    if (r1 >= df) { q1 += 1.0; r1 -= df; }
-    if (r1 < 0.0) { q1 -= 1.0; r1 += df; }
-    const double num = fma(r1, 4294967296.0, (double)(unsigned)x);  // < 2^48, exact
-    double q0 = floor(num * rcp);
-    double r0 = fma(-q0, df, num);
-    if (r0 >= df) { q0 += 1.0; r0 -= df; }
-    if (r0 < 0.0) { q0 -= 1.0; r0 += df; }
-    q = ((unsigned long long)(unsigned)q1 << 32) | (unsigned long long)(unsigned)q0;
-    r = (unsigned)r0;
-}
-
-struct EncState {
-    unsigned long long x;
-    uint32_t *ptr;    // next free word is ptr[-1]
-    uint32_t *limit;  // lowest address that still leaves room for the 2 flush words
-    int overflow;
+// ------------------------------------------------------------------------------------------------ encode
+// Per-entry encoder constants (Alverson reciprocal, as ryg_rans' Rans64EncSymbol): with
+//   q = mulhi64(x, rcp) >> shift   (exact floor(x / freq) for x < 2^63)
+// the rANS update ((x / freq) << 16) + (x % freq) + start equals x + bias + q * (65536 - freq):
+// no division and no remainder on the state's dependency chain.
+struct __attribute__((aligned(16))) EncEntry {
+    unsigned long long rcp;
+    uint32_t bias;   // start (freq >= 2) or start + 65535 (freq == 1)
+    uint32_t cs;     // (65536 - freq) | shift << 16
 };
 
-__device__ __forceinline__ void enc_emit(EncState &s) {
-    if (s.ptr > s.limit) {
-        s.ptr -= 1;
-        *s.ptr = (uint32_t)s.x;
-    } else {
-        s.overflow = 1;
+__global__ __launch_bounds__(256) void rans_build_enc_table_kernel(const int32_t *__restrict__ cdfs, int n_entries,
+                                                                   int cdf_stride, EncEntry *__restrict__ tab) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_entries) return;
+    EncEntry en;
+    en.rcp = ~0ull; en.bias = 65535u; en.cs = 65535u;   // harmless filler for the last column / empty cells
+    if (i % cdf_stride + 1 < cdf_stride) {
+        const uint32_t start = (uint32_t)cdfs[i] & 0xFFFFu;                                 // uint16_t upstream
+        const uint32_t freq = ((uint32_t)cdfs[i + 1] - (uint32_t)cdfs[i]) & 0xFFFFu;
+        if (freq >= 2) {
+            uint32_t shift = 0;
+            while (freq > (1u << shift)) ++shift;
+            // ((1 << (shift + 63)) + freq - 1) / freq by two 64-bit divides
+            unsigned long long x0 = freq - 1, x1 = 1ull << (shift + 31);
+            const unsigned long long t1 = x1 / freq;
+            x0 += (x1 % freq) << 32;
+            const unsigned long long t0 = x0 / freq;
+            en.rcp = t0 + (t1 << 32);
+            en.bias = start;
+            en.cs = (65536u - freq) | ((shift - 1) << 16);
+        } else if (freq == 1) {
+            en.rcp = ~0ull;
+            en.bias = start + 65535u;
+            en.cs = 65535u;
+        }
     }
-    s.x >>= 32;
+    tab[i] = en;
 }
 
-__device__ __forceinline__ void enc_put(EncState &s, unsigned start, unsigned freq, double rcp) {
-    // x_max = ((RANS64_L >> 16) << 32) * freq = freq << 47
-    if ((s.x >> 47) >= (unsigned long long)freq) enc_emit(s);
-    unsigned long long q;
-    unsigned r;
-    divmod_u64(s.x, freq, rcp, q, r);
-    s.x = (q << kPrecision) + r + start;
+// parallel pass: ws[blk][i][lane] = table entry index of symbol i of stream blk*64+lane, bit 31 = escape.
+__global__ __launch_bounds__(256) void rans_enc_prepare_kernel(const RansArgs a) {
+    __shared__ uint32_t tile[64][65];
+    const int blk = blockIdx.y;
+    const long long i0 = (long long)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int pl = t & 63;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int sl = r * 4 + (t >> 6);
+        const int s = blk * 64 + sl;
+        const long long i = i0 + pl;
+        uint32_t e = 0;
+        if (s < a.n_streams && i < a.n_sym) {
+            const long long g = (long long)s * a.n_sym + i;
+            const int idx = a.indexes ? a.indexes[g] : (int)(i / a.index_div);
+            const int max_value = a.cdf_sizes[idx] - 2;
+            int value = a.symbols[g] - a.offsets[idx];
+            uint32_t esc = 0;
+            if (value < 0 || value >= max_value) { value = max_value; esc = 0x80000000u; }
+            e = (uint32_t)(idx * a.cdf_stride + value) | esc;
+        }
+        tile[pl][sl] = e;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int p = r * 4 + (t >> 6);
+        const long long i = i0 + p;
+        if (i < a.n_sym) a.ws[((long long)blk * a.n_sym + i) * 64 + pl] = tile[p][pl];
+    }
 }
 
-__device__ __forceinline__ void enc_put_bits(EncState &s, unsigned val) {
-    // freq = 1 << (16 - 4); x_max = 2^59
-    if ((s.x >> 59) != 0ull) enc_emit(s);
-    s.x = (s.x << kBypassPrecision) | val;
-}
+constexpr int kStage = 48;   // emitted words staged per lane in LDS between flushes (+1 dummy slot)
 
 template <bool LDS_TABLES>
-__global__ __launch_bounds__(64) void rans_encode_kernel(const RansArgs a) {
+__global__ __launch_bounds__(64) void rans_enc_serial_kernel(const RansArgs a, const EncEntry *__restrict__ gtab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int32_t *l_cdf = reinterpret_cast<int32_t *>(smem);
+    uint32_t *stg = reinterpret_cast<uint32_t *>(smem);                                   // [kStage + 1][64]
+    EncEntry *ltab = reinterpret_cast<EncEntry *>(smem + (kStage + 1) * 64 * 4);
     const int n_entries = a.n_cdfs * a.cdf_stride;
-    double *l_rcp = reinterpret_cast<double *>(smem + ((n_entries * 4 + 15) / 16) * 16);
+    const int lane = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);   // a lone serial wave must not queue behind co-resident MFMA workgroups
     if (LDS_TABLES) {
-        for (int i = threadIdx.x; i < n_entries; i += 64) {
-            l_cdf[i] = a.cdfs[i];
-            const int row = i / a.cdf_stride, col = i - row * a.cdf_stride;
-            double rc = 0.0;
-            if (col + 1 < a.cdf_stride) {
-                const int f = a.cdfs[i + 1] - a.cdfs[i];
-                if (f > 0) rc = 1.0 / (double)f;
-            }
-            l_rcp[i] = rc;
-        }
+        for (int i = lane; i < n_entries; i += 64) ltab[i] = gtab[i];
         __syncthreads();
     }
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s >= a.n_streams) return;
-
-    const int32_t *sym = a.symbols + (long long)s * a.n_sym;
-    const int32_t *idxp = a.indexes ? a.indexes + (long long)s * a.n_sym : nullptr;
-    uint32_t *row = reinterpret_cast<uint32_t *>(a.buf + (long long)s * a.stride);
+    const EncEntry *tab = LDS_TABLES ? ltab : gtab;
+    const int blk = blockIdx.x;
+    const int s = blk * 64 + lane;
+    const bool active = s < a.n_streams;
+    const int sc = active ? s : a.n_streams - 1;  // inactive lanes shadow a real stream but never store
+    uint32_t *row = reinterpret_cast<uint32_t *>(a.buf + (long long)sc * a.stride);
     const long long row_words = a.stride / 4;
+    const uint32_t *wsb = a.ws + (long long)blk * a.n_sym * 64 + lane;
 
-    EncState st;
-    st.x = kRansL;
-    st.ptr = row + row_words;
-    st.limit = row + 2;
-    st.overflow = 0;
+    unsigned long long x = kRansL;
+    uint32_t *ptr = row + row_words;                 // next free word is ptr[-1]
+    uint32_t *const limit = active ? row + 2 : row + row_words;   // keeps room for the 2 flush words
+    int overflow = 0;
+    int cnt = 0;                                     // words staged in LDS for this lane
+    uint32_t *const stl = stg + lane;
 
-    for (long long i = a.n_sym - 1; i >= 0; --i) {
-        const int idx = idxp ? idxp[i] : (int)(i / a.index_div);
-        const int max_value = a.cdf_sizes[idx] - 2;
-        int value = sym[i] - a.offsets[idx];
-        unsigned raw_val = 0;
-        if (value < 0) {
-            raw_val = (unsigned)(-2 * value - 1);
-            value = max_value;
-        } else if (value >= max_value) {
-            raw_val = (unsigned)(2 * (value - max_value));
-            value = max_value;
-        }
-        if (value == max_value) {
-            // upstream pushes [symbol, count nibbles (15,..,15,rem), raw nibbles j=0..n-1]; flush pops in reverse.
+    auto flush = [&]() {
+        long long avail = ptr - limit;
+        int n_store = cnt;
+        if ((long long)cnt > avail) { n_store = (int)avail; overflow = 1; }
+        for (int j = 0; __any(j < n_store); ++j)
+            if (j < n_store) ptr[-1 - j] = stl[j * 64];
+        ptr -= n_store;
+        cnt = 0;
+    };
+    // branch-free table symbol (the common case): selects are written as mask arithmetic so that the compiler
+    // keeps them as VALU bit operations instead of exec-mask control flow (VALU->SALU round trips cost more
+    // than the arithmetic they guard on a lone wave).
+    auto put_fast = [&](const EncEntry en) {
+        const uint32_t cmpl = en.cs & 0xFFFFu, shift = en.cs >> 16, freq = 65536u - cmpl;
+        const uint32_t xh = (uint32_t)(x >> 32), xl = (uint32_t)x;
+        // emit <=> x >= freq << 47 <=> (xh >> 15) >= freq ; m = all-ones when emitting
+        const uint32_t m = (uint32_t)((int32_t)(freq - 1u - (xh >> 15)) >> 31);
+        const uint32_t slot = (uint32_t)kStage + (((uint32_t)cnt - (uint32_t)kStage) & m);
+        stl[slot * 64] = xl;
+        cnt -= (int)m;   // m is 0 or -1
+        const uint32_t nxl = xl ^ ((xl ^ xh) & m);
+        const uint32_t nxh = xh & ~m;
+        x = ((unsigned long long)nxh << 32) | nxl;
+        const unsigned long long q = __umul64hi(x, en.rcp) >> shift;
+        x = x + en.bias + q * cmpl;
+    };
+    auto emit_slow = [&]() {
+        stl[cnt * 64] = (uint32_t)x;
+        cnt += 1;
+        x >>= 32;
+    };
+    auto put_bits = [&](unsigned val) {              // bypass: freq = 1 << 12, x_max = 2^59
+        if ((x >> 59) != 0ull) emit_slow();
+        x = (x << kBypassPrecision) | val;
+    };
+    // one symbol with the out-of-table (bypass) path; upstream pushes [symbol, count nibbles (15,..,15,rem), raw
+    // nibbles j=0..n-1] and flush() pops them in reverse, so the bypass part is coded BEFORE the table symbol.
+    auto step_slow = [&](uint32_t e, long long i) {
+        if (__any(cnt > kStage - 14)) flush();
+        const uint32_t ei = e & 0x7FFFFFFFu;
+        if (e >> 31) {
+            const int idx = (int)(ei / (uint32_t)a.cdf_stride);
+            const int max_value = a.cdf_sizes[idx] - 2;
+            const int v = a.symbols[(long long)sc * a.n_sym + i] - a.offsets[idx];
+            const unsigned raw = v < 0 ? (unsigned)(-2 * v - 1) : (unsigned)(2 * (v - max_value));
             int n_bypass = 0;
-            while ((raw_val >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;
-            for (int j = n_bypass - 1; j >= 0; --j) enc_put_bits(st, (raw_val >> (j * kBypassPrecision)) & kMaxBypassVal);
+            while ((raw >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;
+            for (int j = n_bypass - 1; j >= 0; --j) put_bits((raw >> (j * kBypassPrecision)) & kMaxBypassVal);
             const int n15 = n_bypass / kMaxBypassVal, rem = n_bypass - n15 * kMaxBypassVal;
-            enc_put_bits(st, (unsigned)rem);
-            for (int t = 0; t < n15; ++t) enc_put_bits(st, kMaxBypassVal);
+            put_bits((unsigned)rem);
+            for (int t = 0; t < n15; ++t) put_bits(kMaxBypassVal);
         }
-        const int e = idx * a.cdf_stride + value;
-        unsigned start, freq;
-        double rcp;
-        if (LDS_TABLES) {
-            start = (unsigned)l_cdf[e];
-            freq = (unsigned)l_cdf[e + 1] - start;
-            rcp = l_rcp[e];
-        } else {
-            start = (unsigned)a.cdfs[e];
-            freq = (unsigned)a.cdfs[e + 1] - start;
-            rcp = 1.0 / (double)(freq & 0xFFFFu);
-        }
-        // upstream stores start and range as uint16_t
-        enc_put(st, start & 0xFFFFu, freq & 0xFFFFu, rcp);
+        put_fast(tab[ei]);
+    };
+
+    constexpr int U = 8;
+    long long i = a.n_sym - 1;
+    for (long long rem = a.n_sym % U; rem > 0; --rem, --i) step_slow(wsb[i * 64], i);   // ragged head
+    uint32_t e_cur[U], e_nxt[U];
+    if (i >= 0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) e_cur[u] = wsb[(i - u) * 64];
     }
-    // Rans64EncFlush
-    st.ptr -= 2;
-    st.ptr[0] = (uint32_t)(st.x);
-    st.ptr[1] = (uint32_t)(st.x >> 32);
-    a.io_offset[s] = (int32_t)((st.ptr - row) * 4);
-    a.io_nbytes[s] = (int32_t)((row + row_words - st.ptr) * 4);
-    a.status[s] = st.overflow;
+    for (; i >= 0; i -= U) {
+        if (i - U >= 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) e_nxt[u] = wsb[(i - U - u) * 64];
+        }
+        uint32_t esc = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) esc |= e_cur[u];
+        if (__any((esc >> 31) != 0)) {
+#pragma unroll 1
+            for (int u = 0; u < U; ++u) step_slow(e_cur[u], i - u);
+        } else {
+            if (__any(cnt > kStage - U)) flush();
+            EncEntry en[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) en[u] = tab[e_cur[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) put_fast(en[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) e_cur[u] = e_nxt[u];
+    }
+    flush();
+    if (active) {
+        // Rans64EncFlush
+        ptr -= 2;
+        ptr[0] = (uint32_t)(x);
+        ptr[1] = (uint32_t)(x >> 32);
+        a.io_offset[s] = (int32_t)((ptr - row) * 4);
+        a.io_nbytes[s] = (int32_t)((row + row_words - ptr) * 4);
+        a.status[s] = overflow;
+    }
 }
 
+// ------------------------------------------------------------------------------------------------ decode
 struct DecState {
     unsigned long long x;
-    const uint32_t *ptr;
+    const uint32_t *ptr;   // next word to prefetch
     const uint32_t *end;
+    uint32_t w0, w1;       // the next two words of the stream, already loaded
 };
 
+__device__ __forceinline__ uint32_t dec_fetch(const uint32_t *p, const uint32_t *end) { return p < end ? *p : 0u; }
+
+__device__ __forceinline__ void dec_init(DecState &d, const uint32_t *w, int n_words) {
+    d.end = w + n_words;
+    d.x = (unsigned long long)dec_fetch(w, d.end) | ((unsigned long long)dec_fetch(w + 1, d.end) << 32);
+    d.w0 = dec_fetch(w + 2, d.end);
+    d.w1 = dec_fetch(w + 3, d.end);
+    d.ptr = w + 4;
+}
 __device__ __forceinline__ void dec_renorm(DecState &d) {
     if (d.x < kRansL) {
-        const uint32_t w = d.ptr < d.end ? *d.ptr : 0u;
+        d.x = (d.x << 32) | d.w0;
+        d.w0 = d.w1;
+        d.w1 = dec_fetch(d.ptr, d.end);
         d.ptr += 1;
-        d.x = (d.x << 32) | w;
     }
 }
 __device__ __forceinline__ unsigned dec_get_bits(DecState &d) {
@@ -188,9 +281,196 @@ __device__ __forceinline__ unsigned dec_get_bits(DecState &d) {
     dec_renorm(d);
     return val;
 }
+__device__ __forceinline__ int dec_escape(DecState &d, int max_value) {
+    int val = (int)dec_get_bits(d);
+    int n_bypass = val;
+    while (val == kMaxBypassVal) {
+        val = (int)dec_get_bits(d);
+        n_bypass += val;
+    }
+    int raw_val = 0;
+    for (int j = 0; j < n_bypass; ++j) {
+        val = (int)dec_get_bits(d);
+        raw_val |= val << (j * kBypassPrecision);
+    }
+    int value = raw_val >> 1;
+    if (raw_val & 1) value = -value - 1;
+    else value += max_value;
+    return value;
+}
 
+constexpr int kWin = 32;   // stream words buffered per lane in LDS (ring)
+
+// LUT decoder for implicit indexes (row = position / index_div): all lanes share the CDF row of the current
+// position.  Per row the wave builds an exact 65536-entry u16 table cum_freq -> symbol in LDS; the symbol's
+// {start, freq} comes from a second small LDS table.  Stream words are staged per lane in an LDS ring that is
+// topped up 16 words at a time, so the common path (8 symbols) touches no global loads and has no branches;
+// chunks that contain an escape symbol are rolled back and redone on the exact per-symbol path.
+__global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *lut = reinterpret_cast<uint16_t *>(smem);                                     // [65536]
+    uint32_t *win = reinterpret_cast<uint32_t *>(smem + 65536 * 2);                         // [kWin][64]
+    uint32_t *rowtab = win + kWin * 64;                                                     // start | freq << 16
+    const int lane = threadIdx.x;
+    const int blk = blockIdx.x;
+    const int s = blk * 64 + lane;
+    const bool active = s < a.n_streams;
+    const int sc = active ? s : a.n_streams - 1;
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)sc * a.stride + a.io_offset[sc]);
+    const int n_words = a.io_nbytes[sc] / 4;
+    uint32_t *wsb = a.ws + (long long)blk * a.n_sym * 64 + lane;
+    uint32_t *const wl = win + lane;
+
+    int lp = 0;   // words [0, lp) of this lane's stream have been copied into the ring
+    int rp = 0;   // next unread word
+    auto top_up = [&]() {   // every lane whose ring has >= 16 free slots takes its next 16 words (0 past the end)
+        const bool want = lp - rp <= kWin - 16;
+#pragma unroll 4
+        for (int j = 0; j < 16; ++j) {
+            if (want) {
+                const int k = lp + j;
+                wl[(k & (kWin - 1)) * 64] = k < n_words ? w[k] : 0u;
+            }
+        }
+        if (want) lp += 16;
+    };
+    auto ring = [&](int k) { return wl[(k & (kWin - 1)) * 64]; };
+    top_up();
+    top_up();
+    unsigned long long x = (unsigned long long)ring(0) | ((unsigned long long)ring(1) << 32);
+    rp = 2;
+    uint32_t wq = ring(rp), wq1 = ring(rp + 1);   // the next two unread words, kept in registers
+
+    const long long n_rows = a.n_sym == 0 ? 0 : (a.n_sym - 1) / a.index_div + 1;
+    for (long long row = 0; row < n_rows; ++row) {
+        const int32_t *cdf = a.cdfs + row * a.cdf_stride;
+        // wave-uniform row constants, forced into scalar registers NOW: a vector load first used inside the symbol
+        // loop would put an s_waitcnt vmcnt(0) there and drain the output stores on every chunk
+        const int size = __builtin_amdgcn_readfirstlane(a.cdf_sizes[row]);
+        const int max_value = size - 2;
+        const int offset = __builtin_amdgcn_readfirstlane(a.offsets[row]);
+        __syncthreads();  // previous row's table reads are done
+        for (int k = lane; k + 1 < size; k += 64) {
+            const uint32_t lo = (uint32_t)cdf[k], hi = (uint32_t)cdf[k + 1];
+            rowtab[k] = (lo & 0xFFFFu) | ((hi - lo) << 16);
+        }
+        for (int k = 0; k + 1 < size; ++k) {
+            const uint32_t lo = (uint32_t)cdf[k], hi = (uint32_t)cdf[k + 1];
+            for (uint32_t c = lo + lane; c < hi && c < 65536u; c += 64) lut[c] = (uint16_t)k;
+        }
+        __syncthreads();
+        const long long i_end = (row + 1) * a.index_div < a.n_sym ? (row + 1) * a.index_div : a.n_sym;
+        long long i = row * a.index_div;
+
+        // exact per-symbol path (escapes, ragged tails, redo of rolled-back chunks); works on x, rp and the ring
+        auto renorm_slow = [&]() {
+            if (x < kRansL) {
+                x = (x << 32) | ring(rp);
+                rp += 1;
+            }
+        };
+        auto get_bits = [&]() {
+            const int val = (int)(x & kMaxBypassVal);
+            x >>= kBypassPrecision;
+            renorm_slow();
+            return val;
+        };
+        auto step_slow = [&](long long pos) {
+            if (__any(lp - rp < 14)) top_up();
+            const unsigned cum_freq = (unsigned)(x & 0xFFFFu);
+            const int sidx = lut[cum_freq];
+            const uint32_t sf = rowtab[sidx];
+            x = (unsigned long long)(sf >> 16) * (x >> kPrecision) + cum_freq - (sf & 0xFFFFu);
+            renorm_slow();
+            int value = sidx;
+            if (value == max_value) {
+                int val = get_bits();
+                int n_bypass = val;
+                while (val == kMaxBypassVal) {
+                    val = get_bits();
+                    n_bypass += val;
+                }
+                int raw_val = 0;
+                for (int j = 0; j < n_bypass; ++j) {
+                    val = get_bits();
+                    raw_val |= val << (j * kBypassPrecision);
+                }
+                value = raw_val >> 1;
+                if (raw_val & 1) value = -value - 1;
+                else value += max_value;
+            }
+            wsb[pos * 64] = (uint32_t)(value + offset);
+        };
+
+        constexpr int U = 8;
+        while (i < i_end) {
+            if (i + U > i_end) {   // ragged tail of the row
+                step_slow(i);
+                ++i;
+                wq = ring(rp);
+                wq1 = ring(rp + 1);
+                continue;
+            }
+            if (__any(lp - rp < 12)) top_up();
+            const unsigned long long x0 = x;
+            const int rp0 = rp;
+            uint32_t esc = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned cum_freq = (unsigned)(x & 0xFFFFu);
+                const uint32_t sidx = lut[cum_freq];
+                const uint32_t sf = rowtab[sidx];
+                x = (unsigned long long)(sf >> 16) * (x >> kPrecision) + cum_freq - (sf & 0xFFFFu);
+                const bool need = (x >> 31) == 0ull;
+                x = need ? ((x << 32) | wq) : x;
+                rp += need ? 1 : 0;
+                wq = need ? wq1 : wq;
+                wq1 = ring(rp + 1);
+                esc |= (sidx == (uint32_t)max_value) ? 1u : 0u;
+                wsb[(i + u) * 64] = (uint32_t)((int)sidx + offset);
+            }
+            if (__any(esc != 0)) {   // roll the chunk back and decode it exactly
+                x = x0;
+                rp = rp0;
+#pragma unroll 1
+                for (int u = 0; u < U; ++u) step_slow(i + u);
+                wq = ring(rp);
+                wq1 = ring(rp + 1);
+            }
+            i += U;
+        }
+    }
+    if (active) a.status[s] = 0;
+}
+
+// parallel pass: symbols_out[s][i] = ws[blk][i][lane]
+__global__ __launch_bounds__(256) void rans_dec_finish_kernel(const RansArgs a) {
+    __shared__ uint32_t tile[64][65];
+    const int blk = blockIdx.y;
+    const long long i0 = (long long)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int pl = t & 63;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int p = r * 4 + (t >> 6);
+        const long long i = i0 + p;
+        tile[p][pl] = i < a.n_sym ? a.ws[((long long)blk * a.n_sym + i) * 64 + pl] : 0u;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int sl = r * 4 + (t >> 6);
+        const int s = blk * 64 + sl;
+        const long long i = i0 + pl;
+        if (s < a.n_streams && i < a.n_sym) a.symbols_out[(long long)s * a.n_sym + i] = (int32_t)tile[pl][sl];
+    }
+}
+
+// generic decoder: explicit per-symbol indexes (or rows too long for the LUT path); upper-bound binary search,
+// identical in result to upstream's linear find_if over the strictly increasing CDF row.
 template <bool LDS_TABLES>
-__global__ __launch_bounds__(64) void rans_decode_kernel(const RansArgs a) {
+__global__ __launch_bounds__(64) void rans_dec_generic_kernel(const RansArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int32_t *l_cdf = reinterpret_cast<int32_t *>(smem);
     const int n_entries = a.n_cdfs * a.cdf_stride;
@@ -201,24 +481,17 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansArgs a) {
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= a.n_streams) return;
     const int32_t *tab = LDS_TABLES ? l_cdf : a.cdfs;
-
     const int32_t *idxp = a.indexes ? a.indexes + (long long)s * a.n_sym : nullptr;
     int32_t *out = a.symbols_out + (long long)s * a.n_sym;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)s * a.stride + a.io_offset[s]);
-    const int n_words = a.io_nbytes[s] / 4;
     DecState d;
-    d.end = w + n_words;
-    d.x = (unsigned long long)(n_words > 0 ? w[0] : 0u) | ((unsigned long long)(n_words > 1 ? w[1] : 0u) << 32);
-    d.ptr = w + 2;
-
+    dec_init(d, w, a.io_nbytes[s] / 4);
     for (long long i = 0; i < a.n_sym; ++i) {
         const int idx = idxp ? idxp[i] : (int)(i / a.index_div);
         const int32_t *cdf = tab + idx * a.cdf_stride;
         const int size = a.cdf_sizes[idx];
         const int max_value = size - 2;
-        const int offset = a.offsets[idx];
         const unsigned cum_freq = (unsigned)(d.x & 0xFFFFu);
-        // first k in [0, size) with cdf[k] > cum_freq  (upper bound); s = k - 1
         int lo = 0, hi = size;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -230,23 +503,8 @@ __global__ __launch_bounds__(64) void rans_decode_kernel(const RansArgs a) {
         d.x = (unsigned long long)freq * (d.x >> kPrecision) + cum_freq - start;
         dec_renorm(d);
         int value = sidx;
-        if (value == max_value) {
-            int val = (int)dec_get_bits(d);
-            int n_bypass = val;
-            while (val == kMaxBypassVal) {
-                val = (int)dec_get_bits(d);
-                n_bypass += val;
-            }
-            int raw_val = 0;
-            for (int j = 0; j < n_bypass; ++j) {
-                val = (int)dec_get_bits(d);
-                raw_val |= val << (j * kBypassPrecision);
-            }
-            value = raw_val >> 1;
-            if (raw_val & 1) value = -value - 1;
-            else value += max_value;
-        }
-        out[i] = value + offset;
+        if (value == max_value) value = dec_escape(d, max_value);
+        out[i] = value + a.offsets[idx];
     }
     a.status[s] = 0;
 }
@@ -257,11 +515,19 @@ int check_common(const int32_t *indexes, long long index_div, int n_streams, lon
     SC2_REQUIRE(n_streams > 0 && n_sym >= 0 && n_cdfs > 0 && cdf_stride >= 3, SC2_ERR_INVALID_ARG,
                 "rans: bad sizes n_streams=%d n_sym=%lld n_cdfs=%d cdf_stride=%d", n_streams, n_sym, n_cdfs,
                 cdf_stride);
+    SC2_REQUIRE((long long)n_cdfs * cdf_stride < (1ll << 31), SC2_ERR_UNSUPPORTED, "rans: CDF table too large");
     if (!indexes) SC2_REQUIRE(index_div > 0, SC2_ERR_INVALID_ARG, "rans: index_div must be positive");
     if (!indexes && n_sym > 0)
         SC2_REQUIRE((n_sym - 1) / index_div < n_cdfs, SC2_ERR_INVALID_ARG,
                     "rans: implicit index %lld out of range (%d CDF rows)", (n_sym - 1) / index_div, n_cdfs);
     return SC2_OK;
+}
+
+template <class K>
+void allow_big_lds(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
 }
 
 }  // namespace
@@ -273,31 +539,58 @@ extern "C" int64_t sc2_rans_max_bytes(int64_t n_sym) {
     return words * 4;
 }
 
+static int64_t ws_entries_bytes(int n_streams, int64_t n_sym) {
+    const int64_t n_blocks = (n_streams + 63) / 64;
+    const int64_t b = n_blocks * n_sym * 64 * 4;
+    return (b + 255) / 256 * 256 + 256;
+}
+
+extern "C" int64_t sc2_rans_workspace_bytes(int n_streams, int64_t n_sym, int n_cdfs, int cdf_stride) {
+    if (n_streams <= 0 || n_sym < 0 || n_cdfs <= 0 || cdf_stride <= 0) return 0;
+    return ws_entries_bytes(n_streams, n_sym) + (int64_t)n_cdfs * cdf_stride * (int64_t)sizeof(EncEntry);
+}
+
 extern "C" int sc2_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, int64_t index_div, int n_streams,
                                      int64_t n_sym, const int32_t *cdfs, int n_cdfs, int cdf_stride,
                                      const int32_t *cdf_sizes, const int32_t *offsets, uint8_t *out,
                                      int64_t out_stride, int32_t *out_offset, int32_t *out_nbytes, int32_t *status,
-                                     void *stream) {
+                                     void *workspace, int64_t workspace_bytes, void *stream) {
     int rc = check_common(indexes, index_div, n_streams, n_sym, cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets);
     if (rc != SC2_OK) return rc;
-    SC2_REQUIRE((symbols || n_sym == 0) && out && out_offset && out_nbytes && status, SC2_ERR_INVALID_ARG,
-                "rans_encode: null argument");
+    SC2_REQUIRE((symbols || n_sym == 0) && out && out_offset && out_nbytes && status && workspace,
+                SC2_ERR_INVALID_ARG, "rans_encode: null argument");
     SC2_REQUIRE(out_stride >= 16 && out_stride % 4 == 0 && out_stride < (1ll << 31), SC2_ERR_INVALID_ARG,
                 "rans_encode: out_stride %lld must be a multiple of 4 in [16, 2^31)", (long long)out_stride);
+    SC2_REQUIRE(workspace_bytes >= sc2_rans_workspace_bytes(n_streams, n_sym, n_cdfs, cdf_stride), SC2_ERR_INVALID_ARG,
+                "rans_encode: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)sc2_rans_workspace_bytes(n_streams, n_sym, n_cdfs, cdf_stride));
     RansArgs a;
     a.symbols = symbols; a.indexes = indexes; a.index_div = index_div > 0 ? index_div : 1;
     a.n_streams = n_streams; a.n_sym = n_sym;
     a.cdfs = cdfs; a.n_cdfs = n_cdfs; a.cdf_stride = cdf_stride; a.cdf_sizes = cdf_sizes; a.offsets = offsets;
     a.buf = out; a.stride = out_stride; a.io_offset = out_offset; a.io_nbytes = out_nbytes; a.status = status;
-    a.symbols_out = nullptr;
-    const int grid = (n_streams + 63) / 64;
+    a.symbols_out = nullptr; a.ws = static_cast<uint32_t *>(workspace);
+    const int n_blocks = (n_streams + 63) / 64;
     const int n_entries = n_cdfs * cdf_stride;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n_entries <= kMaxLdsEntries) {
-        const size_t lds = ((size_t)(n_entries * 4 + 15) / 16) * 16 + (size_t)n_entries * 8;
-        hipLaunchKernelGGL(rans_encode_kernel<true>, dim3(grid), dim3(64), lds, s, a);
+    if (n_sym > 0) {
+        const long long gx = (n_sym + 63) / 64;
+        SC2_REQUIRE(gx < (1ll << 31) && n_blocks <= 65535, SC2_ERR_UNSUPPORTED, "rans_encode: problem too large");
+        hipLaunchKernelGGL(rans_enc_prepare_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
+        SC2_CHECK_LAUNCH();
+    }
+    EncEntry *gtab = reinterpret_cast<EncEntry *>(static_cast<unsigned char *>(workspace) +
+                                                  ws_entries_bytes(n_streams, n_sym));
+    hipLaunchKernelGGL(rans_build_enc_table_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, cdfs, n_entries,
+                       cdf_stride, gtab);
+    SC2_CHECK_LAUNCH();
+    const size_t stage_lds = (size_t)(kStage + 1) * 64 * 4;
+    if (n_entries <= kEncLdsEntries) {
+        const size_t lds = stage_lds + (size_t)n_entries * sizeof(EncEntry);
+        allow_big_lds(rans_enc_serial_kernel<true>, lds);
+        hipLaunchKernelGGL(rans_enc_serial_kernel<true>, dim3(n_blocks), dim3(64), lds, s, a, gtab);
     } else {
-        hipLaunchKernelGGL(rans_encode_kernel<false>, dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(rans_enc_serial_kernel<false>, dim3(n_blocks), dim3(64), stage_lds, s, a, gtab);
     }
     SC2_CHECK_LAUNCH();
     return SC2_OK;
@@ -307,27 +600,43 @@ extern "C" int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const
                                      const int32_t *in_nbytes, const int32_t *indexes, int64_t index_div,
                                      int n_streams, int64_t n_sym, const int32_t *cdfs, int n_cdfs, int cdf_stride,
                                      const int32_t *cdf_sizes, const int32_t *offsets, int32_t *symbols_out,
-                                     int32_t *status, void *stream) {
+                                     int32_t *status, void *workspace, int64_t workspace_bytes, void *stream) {
     int rc = check_common(indexes, index_div, n_streams, n_sym, cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets);
     if (rc != SC2_OK) return rc;
-    SC2_REQUIRE(in && in_offset && in_nbytes && (symbols_out || n_sym == 0) && status, SC2_ERR_INVALID_ARG,
-                "rans_decode: null argument");
+    SC2_REQUIRE(in && in_offset && in_nbytes && (symbols_out || n_sym == 0) && status && workspace,
+                SC2_ERR_INVALID_ARG, "rans_decode: null argument");
     SC2_REQUIRE(in_stride >= 8 && in_stride % 4 == 0, SC2_ERR_INVALID_ARG,
                 "rans_decode: in_stride %lld must be a multiple of 4, >= 8", (long long)in_stride);
+    SC2_REQUIRE(workspace_bytes >= sc2_rans_workspace_bytes(n_streams, n_sym, n_cdfs, cdf_stride), SC2_ERR_INVALID_ARG,
+                "rans_decode: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)sc2_rans_workspace_bytes(n_streams, n_sym, n_cdfs, cdf_stride));
     RansArgs a;
     a.symbols = nullptr; a.indexes = indexes; a.index_div = index_div > 0 ? index_div : 1;
     a.n_streams = n_streams; a.n_sym = n_sym;
     a.cdfs = cdfs; a.n_cdfs = n_cdfs; a.cdf_stride = cdf_stride; a.cdf_sizes = cdf_sizes; a.offsets = offsets;
     a.buf = const_cast<uint8_t *>(in); a.stride = in_stride;
     a.io_offset = const_cast<int32_t *>(in_offset); a.io_nbytes = const_cast<int32_t *>(in_nbytes);
-    a.status = status; a.symbols_out = symbols_out;
-    const int grid = (n_streams + 63) / 64;
+    a.status = status; a.symbols_out = symbols_out; a.ws = static_cast<uint32_t *>(workspace);
+    const int n_blocks = (n_streams + 63) / 64;
     const int n_entries = n_cdfs * cdf_stride;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (n_entries <= kMaxLdsEntries) {
-        hipLaunchKernelGGL(rans_decode_kernel<true>, dim3(grid), dim3(64), (size_t)n_entries * 4, s, a);
+    if (!indexes && cdf_stride <= kMaxRowLds) {
+        const size_t lds = (size_t)65536 * 2 + (size_t)kWin * 64 * 4 + (size_t)cdf_stride * 4 + 16;
+        allow_big_lds(rans_dec_lut_kernel, lds);
+        hipLaunchKernelGGL(rans_dec_lut_kernel, dim3(n_blocks), dim3(64), lds, s, a);
+        SC2_CHECK_LAUNCH();
+        if (n_sym > 0) {
+            const long long gx = (n_sym + 63) / 64;
+            SC2_REQUIRE(gx < (1ll << 31) && n_blocks <= 65535, SC2_ERR_UNSUPPORTED, "rans_decode: problem too large");
+            hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
+            SC2_CHECK_LAUNCH();
+        }
+        return SC2_OK;
+    }
+    if (n_entries <= 12288) {
+        hipLaunchKernelGGL(rans_dec_generic_kernel<true>, dim3(n_blocks), dim3(64), (size_t)n_entries * 4, s, a);
     } else {
-        hipLaunchKernelGGL(rans_decode_kernel<false>, dim3(grid), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(rans_dec_generic_kernel<false>, dim3(n_blocks), dim3(64), 0, s, a);
     }
     SC2_CHECK_LAUNCH();
     return SC2_OK;

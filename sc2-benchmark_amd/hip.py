@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv2d_fwd',
     'sc2_eb_forward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_pmf_to_quantized_cdf',
-    'sc2_rans_max_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
+    'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
 ]
 
 
@@ -67,8 +67,11 @@ def lib():
                                            ctypes.POINTER(ctypes.c_uint32)]
     L.sc2_rans_max_bytes.argtypes = [i64]
     L.sc2_rans_max_bytes.restype = i64
-    L.sc2_rans_encode_batch.argtypes = [vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp]
-    L.sc2_rans_decode_batch.argtypes = [vp, i64, vp, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp]
+    L.sc2_rans_workspace_bytes.argtypes = [i32, i64, i32, i32]
+    L.sc2_rans_workspace_bytes.restype = i64
+    L.sc2_rans_encode_batch.argtypes = [vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
+    L.sc2_rans_decode_batch.argtypes = [vp, i64, vp, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, i64,
+                                        vp]
     for name in ABI_SYMBOLS:
         getattr(L, name)  # raises AttributeError if the library lacks a declared symbol
     _lib = L
@@ -345,10 +348,13 @@ def rans_encode_batch(symbols, cdfs, cdf_sizes, offsets, indexes=None, index_div
     off = torch.empty((n_streams,), dtype=torch.int32, device=dev)
     nb = torch.empty((n_streams,), dtype=torch.int32, device=dev)
     st = torch.empty((n_streams,), dtype=torch.int32, device=dev)
+    ws_bytes = int(lib().sc2_rans_workspace_bytes(n_streams, n_sym, cdfs.shape[0], cdfs.shape[1]))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     with _timed('rans_encode'):
         _check(lib().sc2_rans_encode_batch(_ptr(symbols), _ptr(indexes), int(index_div), n_streams, n_sym, _ptr(cdfs),
                                        cdfs.shape[0], cdfs.shape[1], _ptr(cdf_sizes), _ptr(offsets), _ptr(buf),
-                                         out_stride, _ptr(off), _ptr(nb), _ptr(st), _stream()), 'rans_encode_batch')
+                                         out_stride, _ptr(off), _ptr(nb), _ptr(st), _ptr(ws), ws_bytes, _stream()),
+               'rans_encode_batch')
     return buf, off, nb, st
 
 
@@ -366,9 +372,11 @@ def rans_decode_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, indexes=Non
     if indexes is not None:
         _dev(indexes, 'indexes')
         assert indexes.shape == sym.shape and indexes.dtype == torch.int32 and indexes.is_contiguous()
+    ws_bytes = int(lib().sc2_rans_workspace_bytes(n_streams, n_sym, cdfs.shape[0], cdfs.shape[1]))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     with _timed('rans_decode'):
         _check(lib().sc2_rans_decode_batch(_ptr(buf), stride, _ptr(off), _ptr(nb), _ptr(indexes), int(index_div),
                                        n_streams, int(n_sym), _ptr(cdfs), cdfs.shape[0], cdfs.shape[1],
-                                       _ptr(cdf_sizes), _ptr(offsets), _ptr(sym), _ptr(st), _stream()),
-           'rans_decode_batch')
+                                       _ptr(cdf_sizes), _ptr(offsets), _ptr(sym), _ptr(st), _ptr(ws), ws_bytes,
+                                           _stream()), 'rans_decode_batch')
     return sym, st

@@ -34,8 +34,6 @@ def main():
     m = S.FPBasedResNetBottleneck().eval().to(dev)
     from oracle import cpu_ref as R
     R.perturb_quantiles(m.entropy_bottleneck)
-    with torch.no_grad():
-        m.encoder[4].weight.mul_(40.0)
     m.update()
     N = args.bs
     x = torch.rand(N, 3, 224, 224, device=dev)
