@@ -11,12 +11,15 @@
 // CompressAI's GDN1 (layer.py:478,481,488,491).
 //
 // Structure (per 256-thread workgroup = 4 waves, one BM x BN output tile):
-//   * A and B k-slabs (BK = 32) are register-staged into a double-buffered, XOR-swizzled LDS
-//     image (conflict-free for the ds_read_b128 fragment reads, checked with the lane-group
-//     table of MI355X_MICROARCH.md section LDS); global loads of slab t+1 are issued before the
-//     MFMAs of slab t and written to LDS after them: one barrier per slab.
-//   * 16-byte chunks never straddle a filter tap (Cin % 8 == 0), so each chunk is one
-//     predicated global_load_dwordx4; out-of-image taps and the K tail load zeros.
+//   * A and B k-slabs (BK = 32) go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
+//     ds_write) into a 4-deep ring of XOR-swizzled LDS images; the LDS image is lane-linear per
+//     wave-instruction, so the swizzle is applied to each lane's SOURCE address (which chunk it fetches).
+//     Three slabs stay in flight across the single raw s_barrier per slab behind a counted
+//     s_waitcnt vmcnt(N); fragments are read with inline-asm ds_read_b128 (a compiler-visible LDS read
+//     would make hipcc drain vmcnt(0) in front of it) -- conflict-free per the lane-group table of
+//     MI355X_MICROARCH.md section LDS.
+//   * 16-byte chunks never straddle a filter tap (Cin % 8 == 0), so each chunk is one lane of a
+//     direct-to-LDS load; out-of-image taps and the K tail source a 16-byte zero block instead.
 //   * the epilogue stages the f32 accumulators through LDS so that global stores are
 //     whole 16-byte channel runs (NHWC) or pixel runs (NCHW) and the fused element-wise
 //     epilogues (GDN / IGDN / bias / residual) read their operands coalesced.
@@ -50,15 +53,19 @@ struct Cfg {
     static constexpr int KC = BK / 8;  // 16-byte chunks per tile row
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int MT = WM / 16, NT = WN / 16;
-    static constexpr int A_CH = BM * KC / 256;
-    static constexpr int B_CH = (BN * KC + 255) / 256;
+    static constexpr int STAGES = 4;                       // LDS ring depth (k-slabs)
+    static constexpr int BNP = (BN + 63) / 64 * 64;        // B rows staged (whole 1-KB wave-instructions per wave)
+    static constexpr int A_IPW = BM / 64;                  // direct-to-LDS instructions per wave per slab (A)
+    static constexpr int B_IPW = BNP / 64;                 //                                              (B)
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BNP * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int STAGE_ROWS = WAVES_M * 16;
-    static constexpr int MAIN_LDS = 2 * (BM + BN) * BK * 2;
+    static constexpr int MAIN_LDS = STAGES * STAGE_BYTES;
     static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
     static constexpr int LDS_BYTES = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(BM % (WAVES_M * 16) == 0 && BN % (WAVES_N * 16) == 0, "wave tiling");
-    static_assert((BM * KC) % 256 == 0, "A chunks per thread");
+    static_assert(BM % 64 == 0, "A rows per wave-instruction");
 };
 
 // byte offset of 16-byte chunk `c` of row `r` in a [rows][BK] bf16 LDS tile (BK = 32 -> 64-byte rows).
@@ -66,19 +73,29 @@ struct Cfg {
 // land on 16 distinct 16-byte slots of the 256-byte bank row in every ds_read_b128 lane group.
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 3)) << 4); }
 
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+__device__ uint4 g_zero16;   // 16 zero bytes: the source of every out-of-image / K-tail chunk
+
+__device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BM = C::BM, BN = C::BN, BK = C::BK, KC = C::KC;
-    constexpr int MT = C::MT, NT = C::NT, A_CH = C::A_CH, B_CH = C::B_CH;
-    constexpr int A_ROW_STEP = 256 / KC;
+    constexpr int MT = C::MT, NT = C::NT, S = C::STAGES;
+    constexpr int A_IPW = C::A_IPW, B_IPW = C::B_IPW, L = A_IPW + B_IPW;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *As = smem;                    // [2][BM*BK*2 bytes]
-    unsigned char *Bs = smem + 2 * BM * BK * 2;  // [2][BN*BK*2 bytes]
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
 
     const int Cin = C::STATIC ? C::CIN : p.Cin;
@@ -103,80 +120,76 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const int mtile = bid / p.n_ntiles;
     const int m0 = mtile * BM, n0 = ntile * BN;
 
-    // --- per-thread A gather state (rows are fixed for the whole K loop) ---
-    const int kc = tid % KC;
-    const int arow0 = tid / KC;
-    long long a_off[A_CH];
-    int a_ih0[A_CH], a_iw0[A_CH];
-    bool a_ok[A_CH];
+    // --- per-lane gather state.  Wave-instruction q = j*4 + wave fills LDS rows [16q, 16q+16) of a slab; lane l
+    //     owns 16-byte position 64q + l = row 16q + (l >> 2), stored chunk l & 3, which under the read swizzle
+    //     holds k-chunk (l & 3) ^ ((row >> 1) & 3) = (l & 3) ^ ((l >> 3) & 3): the same for every row of a lane.
+    const int kc = (lane & 3) ^ ((lane >> 3) & 3);
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16);
+    const long long zero_off = zero - p.x, zero_off_w = zero - p.w;   // element offsets of the zero block
+    long long a_off[A_IPW];
+    int a_ih0[A_IPW], a_iw0[A_IPW];
+    bool a_ok[A_IPW];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        const int m = m0 + arow0 + i * A_ROW_STEP;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
+    for (int j = 0; j < A_IPW; ++j) {
+        const int m = m0 + (j * 4 + wave) * 16 + (lane >> 2);
+        a_ok[j] = m < p.M;
+        const int mm = a_ok[j] ? m : 0;
         const int img = mm / p.OHW;
         const int rem = mm - img * p.OHW;
         const int oh = rem / p.OW;
         const int ow = rem - oh * p.OW;
-        a_ih0[i] = oh * SH - PH;
-        a_iw0[i] = ow * SW - PW;
-        a_off[i] = ((long long)(img * H + a_ih0[i]) * W + a_iw0[i]) * Cin;
+        a_ih0[j] = oh * SH - PH;
+        a_iw0[j] = ow * SW - PW;
+        a_off[j] = ((long long)(img * H + a_ih0[j]) * W + a_iw0[j]) * Cin;
     }
-    // k state of this thread's chunk column: (kh, kw, c8)
+    long long b_off[B_IPW];
+#pragma unroll
+    for (int j = 0; j < B_IPW; ++j) {
+        int rowb = (j * 4 + wave) * 16 + (lane >> 2);
+        if (rowb >= BN) rowb = 0;   // padding rows of the staged image: any valid source, never read back
+        b_off[j] = (long long)(n0 + rowb) * p.Kpad + kc * 8;
+    }
+    // k state of this lane's chunk column: (kh, kw, c8); advancing by one slab wraps at most WRAPS times
+    constexpr int WRAPS = C::STATIC ? (KC + (C::CIN / 8) - 1) / (C::CIN / 8 > 0 ? C::CIN / 8 : 1) : KC;
     int c8 = kc, kh = 0, kw = 0;
-    while (c8 >= CIN8) {
-        c8 -= CIN8;
-        if (++kw == KW) { kw = 0; ++kh; }
-    }
-    // B rows
-    const uint16_t *b_ptr[B_CH];
-    bool b_ok[B_CH];
+    auto wrap_k = [&]() {
 #pragma unroll
-    for (int j = 0; j < B_CH; ++j) {
-        const int q = tid + j * 256;
-        b_ok[j] = q < BN * KC;
-        const int rowb = b_ok[j] ? q / KC : 0;
-        b_ptr[j] = p.w + (long long)(n0 + rowb) * p.Kpad + kc * 8;
-    }
-
-    uint4 a_reg[A_CH], b_reg[B_CH];
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-
-    auto load_tile = [&](int kt) {
-        const long long tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
-        const bool tap_ok = kh < KH;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-            const bool ok = a_ok[i] && tap_ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-            a_reg[i] = ok ? *reinterpret_cast<const uint4 *>(p.x + a_off[i] + tap_off) : zero4;
-        }
-#pragma unroll
-        for (int j = 0; j < B_CH; ++j) {
-            b_reg[j] = b_ok[j] ? *reinterpret_cast<const uint4 *>(b_ptr[j] + kt * BK) : zero4;
-        }
-        // advance the k state by one tile
-        c8 += KC;
-        while (c8 >= CIN8) {
-            c8 -= CIN8;
-            if (++kw == KW) { kw = 0; ++kh; }
+        for (int rep = 0; rep < WRAPS; ++rep) {
+            const bool w1 = c8 >= CIN8;
+            c8 -= w1 ? CIN8 : 0;
+            kw += w1 ? 1 : 0;
+            const bool w2 = kw == KW;
+            kw = w2 ? 0 : kw;
+            kh += w2 ? 1 : 0;
         }
     };
-    auto store_tile = [&](int buf) {
-        unsigned char *Ab = As + buf * (BM * BK * 2);
-        unsigned char *Bb = Bs + buf * (BN * BK * 2);
+    wrap_k();
+    const int KT = p.KT;
+
+    auto issue_tile = [&](int kt, int buf) {
+        unsigned char *Ab = smem + buf * C::STAGE_BYTES;
+        unsigned char *Bb = Ab + C::A_BYTES;
+        const long long tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
+        const bool tap_ok = kh < KH;   // false for the K tail and for the dummy slabs past KT
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const int r = arow0 + i * A_ROW_STEP;
-            *reinterpret_cast<uint4 *>(Ab + lds_off(r, kc)) = a_reg[i];
+        for (int j = 0; j < A_IPW; ++j) {
+            const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+            // bitwise (not short-circuit) so this stays a chain of VALU compares + selects: a conditional branch
+            // costs more than the whole address computation (tools/micro/chain2.hip)
+            const bool ok = a_ok[j] & tap_ok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            const long long off = ok ? a_off[j] + tap_off : zero_off;
+            const uint16_t *src = p.x + off;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Ab + (j * 4 + wave) * 1024), 16, 0, 0);
         }
+        const bool kt_ok = kt < KT;
 #pragma unroll
-        for (int j = 0; j < B_CH; ++j) {
-            if (b_ok[j]) {
-                const int r = (tid + j * 256) / KC;
-                *reinterpret_cast<uint4 *>(Bb + lds_off(r, kc)) = b_reg[j];
-            }
+        for (int j = 0; j < B_IPW; ++j) {
+            const long long off = kt_ok ? b_off[j] + (long long)kt * BK : zero_off_w;
+            const uint16_t *src = p.w + off;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Bb + (j * 4 + wave) * 1024), 16, 0, 0);
         }
+        c8 += KC;
+        wrap_k();
     };
 
     f32x4_t acc[MT][NT];
@@ -187,39 +200,48 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 
     const uint32_t amask = p.aop == SC2_AOP_ABS ? 0x7FFF7FFFu : 0xFFFFFFFFu;
     const int frow = lane & 15, fq = lane >> 4;
+    uint32_t a_rd[MT], b_rd[NT];   // fragment read offsets inside a slab (fixed per lane)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_rd[i] = (uint32_t)lds_off(wm * C::WM + i * 16 + frow, fq);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b_rd[j] = (uint32_t)(C::A_BYTES + lds_off(wn * C::WN + j * 16 + frow, fq));
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < S - 1; ++st) issue_tile(st, st);
 
-    const int KT = p.KT;
     for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
+        // slab kt has landed once at most (S-2) younger slabs of this wave are outstanding ...
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");
+        // ... and, after the barrier, for every wave; the barrier also frees the slab computed last iteration
+        __builtin_amdgcn_s_barrier();
+        issue_tile(kt + S - 1, (kt + S - 1) % S);
 
-        const unsigned char *Ab = As + buf * (BM * BK * 2);
-        const unsigned char *Bb = Bs + buf * (BN * BK * 2);
+        const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
+        uint4 av[MT], bv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[i] = lds_read16(sb + a_rd[i]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = lds_read16(sb + b_rd[j]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
         bf16x8_t af[MT], bfr[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            uint4 v = *reinterpret_cast<const uint4 *>(Ab + lds_off(wm * C::WM + i * 16 + frow, fq));
+            uint4 v = av[i];
             v.x &= amask; v.y &= amask; v.z &= amask; v.w &= amask;
             af[i] = __builtin_bit_cast(bf16x8_t, v);
         }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(Bb + lds_off(wn * C::WN + j * 16 + frow, fq));
-            bfr[j] = __builtin_bit_cast(bf16x8_t, v);
-        }
+        for (int j = 0; j < NT; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, bv[j]);
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-
-        if (kt + 1 < KT) store_tile(buf ^ 1);
-        __syncthreads();
     }
+    // drain the dummy slabs and make sure every wave is done reading before the epilogue reuses the LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     // ------------------------------------------------------------------ epilogue
     // MT passes; pass i stages tile-row i of every wave (WAVES_M*16 rows x BN cols, f32).
