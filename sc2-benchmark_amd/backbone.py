@@ -88,6 +88,9 @@ class SplittableResNet(UpdatableBackbone):
         self.fc = None if skips_fc else resnet_model.fc
         self.inplanes = resnet_model.inplanes if inplanes is None else inplanes
         self.compute_dtype = 'f32'
+        self.use_hip_head = True     # bf16 eval: run layer2..fc on the library's fused conv kernel (head.py)
+        self._hip_head = None
+        self._hip_head_key = None
 
     def set_compute_dtype(self, dtype):
         """'f32' (reference dtype) or 'bf16' (task head in bf16 channels_last, decoder output zero-copy)."""
@@ -103,7 +106,23 @@ class SplittableResNet(UpdatableBackbone):
             self.bottleneck_layer.output_format = 'bf16_nhwc' if dtype == 'bf16' else 'f32_nchw'
         return self
 
+    def _hip_head_for_eval(self):
+        """Folded conv+BN(+ReLU)(+residual) head for bf16 eval; rebuilt when a parameter changes."""
+        mods = [m for m in (self.layer2, self.layer3, self.layer4, self.fc) if m is not None]
+        key = tuple(p._version for m in mods for p in m.parameters()) + \
+            tuple(b._version for m in mods for b in m.buffers()) + (str(next(mods[0].parameters()).device),)
+        if self._hip_head is None or self._hip_head_key != key:
+            from .head import HipHead
+            layers = [(i + 2, m) for i, m in enumerate((self.layer2, self.layer3, self.layer4)) if m is not None]
+            self._hip_head = HipHead(layers, self.fc if self.avgpool is not None else None)
+            self._hip_head_key = key
+        return self._hip_head
+
     def head(self, x):
+        if (self.compute_dtype == 'bf16' and self.use_hip_head and not self.training and x.is_cuda
+                and x.dtype == torch.bfloat16 and self.layer2 is not None):
+            x_nhwc = x.permute(0, 2, 3, 1).contiguous()   # a view when x is channels_last (the decoder's output)
+            return self._hip_head_for_eval().forward(x_nhwc, with_pool=self.avgpool is not None)
         if self.layer2 is not None:
             x = self.layer2(x)
         if self.layer3 is not None:
@@ -138,6 +157,28 @@ class SplittableResNet(UpdatableBackbone):
         buf, off, nb, st, shape = self.bottleneck_layer.encode_device(x)
         x = self.bottleneck_layer.decode_device(buf, off, nb, shape)
         return self.head(x), nb, st
+
+    # ---- the same eval forward cut into three stages, so that a caller can run the serial range coder on its
+    #      own HIP stream(s) while the MFMA stream works on neighbouring batches (bench.py)
+    def stage_front(self, x):
+        """encoder + quantisation: -> (symbols int32 [N, C*h*w], (h, w))."""
+        if self.pre_transform is not None:
+            x = self.pre_transform(x)
+        latent = self.bottleneck_layer.analysis(x)
+        return self.bottleneck_layer.entropy_bottleneck.symbols_device(latent), tuple(latent.shape[-2:])
+
+    def stage_coder(self, sym, hw_shape):
+        """rANS encode to byte streams, then decode them: -> (decoded symbols, nbytes [N], status [N])."""
+        eb = self.bottleneck_layer.entropy_bottleneck
+        hw = hw_shape[0] * hw_shape[1]
+        buf, off, nb, st = eb.encode_symbols_device(sym, hw)
+        dec = eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw)
+        return dec, nb, st
+
+    def stage_back(self, dec_sym, hw_shape):
+        """dequantise + decoder + task head."""
+        _, y_hat_nhwc = self.bottleneck_layer.entropy_bottleneck.dequantize_device(dec_sym, hw_shape)
+        return self.head(self.bottleneck_layer.synthesis_nhwc(y_hat_nhwc))
 
     def update(self):
         self.bottleneck_layer.update()

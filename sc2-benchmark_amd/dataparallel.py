@@ -1,0 +1,107 @@
+"""Data parallelism for the bottleneck path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" on CPU for tests).
+
+The path shards by image -- every image is an independent forward and an independent rANS stream -- so inference /
+evaluation needs no data-path collective; training adds ONE gradient all-reduce per step over the
+trainable set.  In stage 1 of the Entropic-Student recipe only `bottleneck_layer` trains (reference config
+`splitable_resnet50-fp-beta0.08_from_resnet50.yaml:135`): 1 304 168 f32 values = 5.2 MB, latency-bound on a ring
+(2*(7/8)*5.2 MB / 153 GB/s ~ 60 us of wire time), hence a single flat bucket and a single RCCL call instead of
+DDP's per-bucket hooks; larger trainable sets (stage 2, ~106 MB) are split into `bucket_mb` buckets launched as
+soon as each is full so they overlap what remains of backward.
+
+Replaces `torch.nn.parallel.DistributedDataParallel` as the reference wraps it
+(script/task/image_classification.py:110-111; configs `wrapper: 'DistributedDataParallel'`).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK (torchrun) -> (distributed, rank, world, device)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device('cuda', local_rank) if use_cuda else torch.device('cpu')
+    if use_cuda:
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        backend = backend or ('nccl' if use_cuda else 'gloo')
+        kwargs = {'device_id': device} if (use_cuda and backend == 'nccl') else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return world > 1, rank, world, device
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous [start, end) slice of n_items for this rank (remainder spread over the first ranks)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class FlatGradAllReducer(object):
+    """Keeps the gradients of the trainable parameters in flat f32 buckets (each p.grad is a view) and averages
+    them across ranks with one all-reduce per bucket."""
+
+    def __init__(self, params, bucket_mb=25.0, process_group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        cap = max(1, int(bucket_mb * 1024 * 1024 / 4))
+        self.buckets = []
+        cur, cur_n = [], 0
+        for p in self.params:
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(cur)
+        self.flats = []
+        for bucket in self.buckets:
+            dev, n = bucket[0].device, sum(p.numel() for p in bucket)
+            flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            o = 0
+            for p in bucket:
+                p.grad = flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.flats.append(flat)
+
+    def zero_grad(self):
+        for flat in self.flats:
+            flat.zero_()
+
+    def all_reduce(self):
+        """Average gradients over ranks.  Call after backward(); a no-op on a single process."""
+        if self.world == 1:
+            return
+        works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for flat in self.flats]
+        for w, flat in zip(works, self.flats):
+            w.wait()
+            flat.div_(self.world)
+
+    def nbytes(self):
+        return sum(f.numel() * 4 for f in self.flats)
+
+
+def broadcast_parameters(module, src=0, process_group=None):
+    """Makes every rank start from rank `src`'s parameters and buffers (what DDP does at construction)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        if t.numel() > 0:
+            dist.broadcast(t.data, src=src, group=process_group)
+
+
+def all_reduce_mean_scalars(values, device, process_group=None):
+    """Metric reduction (MetricLogger.synchronize_between_processes in the reference): mean over ranks."""
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.all_reduce(t, group=process_group)
+        t /= dist.get_world_size(process_group)
+    return t.tolist()

@@ -409,6 +409,30 @@ class EntropyBottleneck(nn.Module):
         buf, off, nb, st = hip.rans_encode_batch(sym.view(N, C * hw), cdf, cdf_len, offset, index_div=hw)
         return buf, off, nb, st
 
+    # ---- stage-wise device API (lets a caller put the serial coder on its own HIP stream)
+    def symbols_device(self, x):
+        """x: f32 [N,C,*spatial] -> int32 symbols [N, C*prod(spatial)] (round(x - median), NCHW order)."""
+        _require_device(x, 'EntropyBottleneck.symbols')
+        y = x.float().contiguous()
+        N, C = y.shape[0], y.shape[1]
+        return hip.eb_symbols(y, self._median_vector()).view(N, -1)
+
+    def encode_symbols_device(self, sym, hw, out_stride=None):
+        """sym: int32 [N, C*hw] -> (buf, offset, nbytes, status) on device."""
+        cdf, cdf_len, offset = self._tables()
+        return hip.rans_encode_batch(sym, cdf, cdf_len, offset, index_div=hw, out_stride=out_stride)
+
+    def decode_symbols_device(self, buf, off, nb, n_sym, hw):
+        """-> int32 symbols [N, n_sym] on device."""
+        cdf, cdf_len, offset = self._tables()
+        return hip.rans_decode_batch(buf, off, nb, n_sym, cdf, cdf_len, offset, index_div=hw)[0]
+
+    def dequantize_device(self, sym, size, want_f32=False, want_nhwc=True):
+        """int32 symbols [N, C*prod(size)] -> (y_hat f32 NCHW or None, y_hat bf16 NHWC or None)."""
+        C = self._quantized_cdf.shape[0]
+        return hip.eb_dequantize(sym.view(sym.shape[0], C, *size), self._median_vector(), want_f32=want_f32,
+                                 want_nhwc=want_nhwc)
+
     def compress(self, x):
         """Returns list[bytes], one rANS stream per batch item (EntropyBottleneck.compress, layer.py:506)."""
         buf, off, nb, st = self.compress_device(x)

@@ -1,0 +1,93 @@
+"""Inference-time ResNet task head (layer2..fc) on the library's implicit-GEMM kernel.
+
+The caller on the far side of the bottleneck path (reference: sc2bench/models/backbone.py:235-254, torchvision
+Bottleneck blocks).  In eval mode BatchNorm is an affine map, so each conv+BN(+ReLU)(+residual) is ONE
+`sc2_conv2d_fwd` launch: BN folded into the packed bf16 weights and a per-channel f32 bias, ReLU and the
+residual add fused in the epilogue (SC2_EPI_BIAS / BIAS_RELU / BIAS_ADD_RELU).  Activations stay bf16 NHWC from
+the decoder's output to the pooled features; the classifier is the same kernel as a 1x1 conv.
+
+Only used when the model is in eval mode; training keeps the torch modules (BatchNorm statistics).
+"""
+import torch
+from torch import nn
+
+from . import hip
+from .resnet import Bottleneck, FrozenBatchNorm2d
+
+
+def _fold(conv, bn):
+    """conv (no bias) followed by an eval-mode norm layer -> (packed bf16 weight, f32 bias)."""
+    w = conv.weight.detach().float()
+    if isinstance(bn, (nn.BatchNorm2d, FrozenBatchNorm2d)):
+        gamma = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(bn.running_mean)
+        beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(bn.running_mean)
+        scale = gamma * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
+        bias = beta - bn.running_mean.detach().float() * scale
+    else:
+        raise TypeError('cannot fold {}'.format(type(bn)))
+    w = w * scale.reshape(-1, 1, 1, 1)
+    return hip.pack_conv_weight(w), bias.contiguous()
+
+
+class _Conv(object):
+    def __init__(self, conv, bn, tag):
+        assert conv.bias is None and conv.groups == 1
+        self.w, self.b = _fold(conv, bn)
+        self.cout = conv.out_channels
+        self.k = conv.kernel_size
+        self.stride = conv.stride
+        self.pad = conv.padding
+        self.dilation = conv.dilation
+        self.tag = tag
+        if self.dilation != (1, 1):
+            raise hip.Sc2Error('dilated convolutions are not supported by the HIP head (got {})'.format(self.dilation))
+
+    def __call__(self, x, epilogue, ep_x=None):
+        return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,
+                              ep_x=ep_x, ep_beta=self.b, tag=self.tag)
+
+
+class HipHead(object):
+    """Folded, fused inference head built from (layer2, layer3, layer4, avgpool, fc) torch modules."""
+
+    def __init__(self, layers, fc):
+        self.blocks = []
+        for li, layer in layers:
+            for bi, blk in enumerate(layer):
+                if not isinstance(blk, Bottleneck):
+                    raise hip.Sc2Error('HipHead supports torchvision Bottleneck blocks, got {}'.format(type(blk)))
+                t = 'head.{}.{}'.format(li, bi)
+                ds = None
+                if blk.downsample is not None:
+                    ds = _Conv(blk.downsample[0], blk.downsample[1], t + '.ds')
+                self.blocks.append((_Conv(blk.conv1, blk.bn1, t + '.c1'), _Conv(blk.conv2, blk.bn2, t + '.c2'),
+                                    _Conv(blk.conv3, blk.bn3, t + '.c3'), ds))
+        self.fc = None
+        if fc is not None:
+            w = fc.weight.detach().float().reshape(fc.out_features, fc.in_features, 1, 1)
+            cout_pad = (fc.out_features + 7) // 8 * 8
+            if cout_pad != fc.out_features:
+                w = torch.cat([w, torch.zeros(cout_pad - fc.out_features, fc.in_features, 1, 1, device=w.device)])
+            b = torch.zeros(cout_pad, device=w.device)
+            if fc.bias is not None:
+                b[:fc.out_features] = fc.bias.detach().float()
+            self.fc = (hip.pack_conv_weight(w), b.contiguous(), cout_pad, fc.out_features)
+
+    def forward(self, x_nhwc, with_pool=True):
+        """x_nhwc: bf16 [N,H,W,C] -> logits f32 [N,classes] (or pooled / feature map if the model skips them)."""
+        h = x_nhwc
+        for c1, c2, c3, ds in self.blocks:
+            identity = h if ds is None else ds(h, hip.EPI_BIAS)
+            o = c1(h, hip.EPI_BIAS_RELU)
+            o = c2(o, hip.EPI_BIAS_RELU)
+            h = c3(o, hip.EPI_BIAS_ADD_RELU, ep_x=identity)
+        if not with_pool:
+            return h.permute(0, 3, 1, 2)
+        pooled = h.float().mean(dim=(1, 2))                       # [N, C] (AdaptiveAvgPool2d((1,1)) + flatten)
+        if self.fc is None:
+            return pooled
+        w, b, cout_pad, n_cls = self.fc
+        pin = pooled.to(torch.bfloat16).reshape(pooled.shape[0], 1, 1, pooled.shape[1]).contiguous()
+        out = hip.conv2d_fwd(pin, w, cout_pad, 1, 1, 1, 0, epilogue=hip.EPI_BIAS, ep_beta=b,
+                             out_format=hip.OUT_F32_NHWC, tag='head.fc')
+        return out.reshape(out.shape[0], cout_pad)[:, :n_cls]

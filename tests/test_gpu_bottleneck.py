@@ -173,4 +173,35 @@ def test_splittable_resnet_logits(S, R, dev):
     with torch.no_grad():
         post_bf16, nb, st = model.forward_device(x.to(dev))
     assert int(st.max()) == 0 and nb.shape == (2,)
+    assert model._hip_head is not None, 'bf16 eval must run the fused HIP head'
     assert (post_bf16.float().cpu() - ref_post).abs().max().item() <= 0.08 * scale + 0.08
+    # the same head through torch modules (MIOpen) agrees with the fused folded-BN head
+    model.use_hip_head = False
+    with torch.no_grad():
+        post_torch, _, _ = model.forward_device(x.to(dev))
+    assert (post_bf16.float() - post_torch.float()).abs().max().item() <= 0.05 * scale + 0.05
+
+
+def test_hip_head_folded_bn(S, R, dev):
+    """conv+BN(+ReLU)(+residual) fused launches vs the f32 torch modules with non-trivial BN statistics."""
+    torch.manual_seed(3)
+    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
+    model = S.splittable_resnet(cfg, skips_avgpool=False, skips_fc=False, num_classes=1000)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    model.eval()
+    x = torch.randn(3, 256, 14, 14)
+    with torch.no_grad():
+        ref = model.head(x)                       # f32 torch modules on CPU
+    model.to(dev).set_compute_dtype('bf16')
+    xb = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        out = model.head(xb)
+    assert out.shape == (3, 1000) and out.dtype == torch.float32
+    scale = ref.abs().max().item()
+    assert (out.cpu() - ref).abs().max().item() <= 0.05 * scale + 0.05

@@ -83,6 +83,15 @@ def main():
         rows.append(('analysis()', timeit(lambda: m.analysis(x), args.iters), 1177e6 * N, 0))
         m.output_format = 'bf16_nhwc'
         rows.append(('synthesis()', timeit(lambda: m.synthesis_nhwc(yh), args.iters), 7165e6 * N, 0))
+    # task head (layer2..fc): fused folded-BN HIP launches vs torch modules (MIOpen), bf16 NHWC
+    import bench as B
+    full = B.build_model(dev)
+    with torch.no_grad():
+        feat = torch.randn(N, 56, 56, 256, device=dev).to(torch.bfloat16)
+        xh = feat.permute(0, 3, 1, 2)
+        rows.append(('head(hip)()', timeit(lambda: full.head(xh), args.iters), 6.6e9 * N, 0))
+        full.use_hip_head = False
+        rows.append(('head(torch)()', timeit(lambda: full.head(xh), args.iters), 6.6e9 * N, 0))
     tot = 0.0
     print('{:<18}{:>10}{:>12}{:>12}'.format('kernel', 'ms', 'TFLOP/s', 'GB/s'))
     for name, ms, flops, byts in rows:
