@@ -44,7 +44,7 @@ struct ConvArgs {
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_,
-          int PH_, int PW_>
+          int PH_, int PW_, int STAGES_ = 2>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, BK = 32;
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
@@ -53,7 +53,15 @@ struct Cfg {
     static constexpr int KC = BK / 8;  // 16-byte chunks per tile row
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int MT = WM / 16, NT = WN / 16;
-    static constexpr int STAGES = 4;                       // LDS ring depth (k-slabs)
+#ifndef SC2_CONV_ORDER
+#define SC2_CONV_ORDER 1
+#endif
+#ifndef SC2_CONV_PRIO
+#define SC2_CONV_PRIO 0
+#endif
+    // LDS ring depth (k-slabs).  Measured on MI355X (tools/layer_times.py): short-K / HBM-bound layers want
+    // occupancy (2 slabs -> 4 workgroups per CU), long-K MFMA-bound layers want 3 slabs (3 workgroups per CU).
+    static constexpr int STAGES = STAGES_;
     static constexpr int BNP = (BN + 63) / 64 * 64;        // B rows staged (whole 1-KB wave-instructions per wave)
     static constexpr int A_IPW = BM / 64;                  // direct-to-LDS instructions per wave per slab (A)
     static constexpr int B_IPW = BNP / 64;                 //                                              (B)
@@ -214,16 +222,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");
         // ... and, after the barrier, for every wave; the barrier also frees the slab computed last iteration
         __builtin_amdgcn_s_barrier();
+#if SC2_CONV_ORDER == 0
         issue_tile(kt + S - 1, (kt + S - 1) % S);
-
+#endif
         const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
         uint4 av[MT], bv[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) av[i] = lds_read16(sb + a_rd[i]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) bv[j] = lds_read16(sb + b_rd[j]);
+#if SC2_CONV_ORDER == 1
+        // the next slab's address arithmetic and direct-to-LDS loads are issued under the fragment reads' latency
+        issue_tile(kt + S - 1, (kt + S - 1) % S);
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+#if SC2_CONV_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         bf16x8_t af[MT], bfr[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -238,6 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+#if SC2_CONV_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     // drain the dummy slabs and make sure every wave is done reading before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -377,16 +396,16 @@ int launch(const ConvArgs &a, hipStream_t s) {
 //                 BM   BN  WM WN  static Cin KH KW SH SW PH PW
 using C_conv0 = Cfg<128, 96, 2, 2, true, 8, 5, 3, 2, 1, 2, 1>;      // 3->96 k5 s2 p2 on the pixel-pair view
 using C_gdn96 = Cfg<128, 96, 2, 2, true, 96, 1, 1, 1, 1, 0, 0>;
-using C_conv2 = Cfg<128, 48, 4, 1, true, 96, 5, 5, 2, 2, 2, 2>;     // 96->48 k5 s2 p2
+using C_conv2 = Cfg<128, 48, 4, 1, true, 96, 5, 5, 2, 2, 2, 2, 3>;     // 96->48 k5 s2 p2
 using C_gdn48 = Cfg<128, 48, 4, 1, true, 48, 1, 1, 1, 1, 0, 0>;
 using C_conv4 = Cfg<128, 32, 4, 1, true, 48, 2, 2, 1, 1, 0, 0>;     // 48->24 k2
 using C_dec0 = Cfg<128, 128, 2, 2, true, 24, 2, 2, 1, 1, 1, 1>;     // 24->512 k2 p1
-using C_gdn512 = Cfg<128, 128, 2, 2, true, 512, 1, 1, 1, 1, 0, 0>;
-using C_dec2 = Cfg<128, 128, 2, 2, true, 512, 2, 2, 1, 1, 0, 0>;    // 512->256 k2
-using C_gdn256 = Cfg<128, 128, 2, 2, true, 256, 1, 1, 1, 1, 0, 0>;
-using C_dec4 = Cfg<128, 128, 2, 2, true, 256, 2, 2, 1, 1, 1, 1>;    // 256->256 k2 p1
+using C_gdn512 = Cfg<128, 128, 2, 2, true, 512, 1, 1, 1, 1, 0, 0, 3>;
+using C_dec2 = Cfg<128, 128, 2, 2, true, 512, 2, 2, 1, 1, 0, 0, 3>;    // 512->256 k2
+using C_gdn256 = Cfg<128, 128, 2, 2, true, 256, 1, 1, 1, 1, 0, 0, 3>;
+using C_dec4 = Cfg<128, 128, 2, 2, true, 256, 2, 2, 1, 1, 1, 1, 3>;    // 256->256 k2 p1
 // Runtime-geometry fallbacks (other channel widths, the ResNet tail, other bottleneck sizes).
-using G_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
+using G_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3>;
 using G_96 = Cfg<128, 96, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 using G_64 = Cfg<128, 64, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 using G_48 = Cfg<128, 48, 4, 1, false, 0, 0, 0, 0, 0, 0, 0>;

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsc2amd.so')
+LIB_PATH = os.environ.get('SC2_LIB') or os.path.join(_HERE, 'libsc2amd.so')   # SC2_LIB: A/B builds (tools/)
 _lib = None
 
 AOP_NONE, AOP_ABS = 0, 1
