@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 5
+#define SC2_ABI_VERSION 6
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -65,7 +65,12 @@ enum sc2_conv_epilogue {
     SC2_EPI_IGDN = 2, /* y = ep_x * (ep_beta[c] + acc)   (GDN1, inverse=True)  */
     SC2_EPI_BIAS = 3, /* y = acc + ep_beta[c]            (conv + bias / folded BN) */
     SC2_EPI_BIAS_RELU = 4,     /* y = relu(acc + ep_beta[c]) */
-    SC2_EPI_BIAS_ADD_RELU = 5  /* y = relu(acc + ep_beta[c] + ep_x) (residual add) */
+    SC2_EPI_BIAS_ADD_RELU = 5, /* y = relu(acc + ep_beta[c] + ep_x) (residual add) */
+    /* conv FOLLOWED BY GDN1 in one launch (Cout in {32,48,64,96}: one tile holds every channel of a pixel):
+     * x = acc; y = x / (ep_beta + gamma |x|)  resp.  x * (ep_beta + gamma |x|).  `ep_x` carries the packed bf16
+     * gamma matrix [sc2_conv_weight_rows(Cout)][sc2_conv_weight_pitch(Cout)] instead of an activation. */
+    SC2_EPI_FUSED_GDN = 6,
+    SC2_EPI_FUSED_IGDN = 7
 };
 enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHWC = 2 };
 

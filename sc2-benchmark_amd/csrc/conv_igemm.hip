@@ -41,6 +41,7 @@ struct ConvArgs {
     int Kpad, KT;
     int n_ntiles;
     int aop, epi, out;
+    int g_pitch;   // fused GDN: row pitch (elements) of the packed gamma matrix handed in through ep_x
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_,
@@ -70,7 +71,12 @@ struct Cfg {
     static constexpr int STAGE_ROWS = WAVES_M * 16;
     static constexpr int MAIN_LDS = STAGES * STAGE_BYTES;
     static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
-    static constexpr int LDS_BYTES = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
+    // fused GDN epilogue (tile covers every output channel): |x| image [BM][XC chunks] + gamma image [BN][XC chunks]
+    static constexpr int XC = (BN + 31) / 32 * 4;          // 16-byte chunks per row (K of the second GEMM, padded to 32)
+    static constexpr int XSW = (XC % 8 == 0) ? 7 : 3;      // chunk XOR mask: conflict-free ds_read_b128 for XC = 8 / 12
+    static constexpr int FUSE_LDS = (BM + BN) * XC * 16;
+    static constexpr int LDS0 = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
+    static constexpr int LDS_BYTES = LDS0 > FUSE_LDS ? LDS0 : FUSE_LDS;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(BM % (WAVES_M * 16) == 0 && BN % (WAVES_N * 16) == 0, "wave tiling");
     static_assert(BM % 64 == 0, "A rows per wave-instruction");
@@ -262,13 +268,89 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    // ------------------------------------------------------------------ fused GDN1 / inverse GDN1
+    // The tile holds every output channel of its pixels, so norm = beta + gamma |x| is a second, LDS-resident GEMM:
+    // |x| (bf16) is written to an LDS image straight from the accumulators, gamma is staged next to it, and
+    // y = x / norm (or x * norm) is applied to the f32 accumulators before the store: the GDN costs no HBM traffic.
+    if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
+        constexpr int XC = C::XC, XSW = C::XSW, ROWB = XC * 16;
+        unsigned char *Xi = smem;
+        unsigned char *Gi = smem + BM * ROWB;
+        if (XC * 8 > BN) {   // K padding of the second GEMM: zero the chunks past the last channel
+            constexpr int PADC = XC - BN / 8;
+            for (int q = tid; q < BM * PADC; q += 256) {
+                const int r = q / PADC, c = BN / 8 + (q - r * PADC);
+                *reinterpret_cast<uint4 *>(Xi + r * ROWB + ((c ^ ((r >> 1) & XSW)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = wm * C::WM + i * 16 + fq * 4 + e;
+                    const int col = wn * C::WN + j * 16 + frow;
+                    const uint16_t h = f32_to_bf16_bits(acc[i][j][e]) & 0x7FFFu;   // |x|
+                    *reinterpret_cast<uint16_t *>(Xi + r * ROWB + (((col >> 3) ^ ((r >> 1) & XSW)) << 4) +
+                                                  (col & 7) * 2) = h;
+                }
+        const uint16_t *gamma = p.ep_x;   // packed bf16 [rows >= BN][g_pitch], zero padded
+        for (int q = tid; q < BN * XC; q += 256) {
+            const int r = q / XC, c = q - r * XC;
+            const uint4 v = *reinterpret_cast<const uint4 *>(gamma + (long long)r * p.g_pitch + c * 8);
+            *reinterpret_cast<uint4 *>(Gi + r * ROWB + ((c ^ ((r >> 1) & XSW)) << 4)) = v;
+        }
+        __syncthreads();
+        f32x4_t nrm[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) nrm[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < XC / 4; ++ks) {
+            bf16x8_t xa[MT], gb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * C::WM + i * 16 + frow;
+                xa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(
+                                                         Xi + r * ROWB + (((4 * ks + fq) ^ ((r >> 1) & XSW)) << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * C::WN + j * 16 + frow;
+                gb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(
+                                                         Gi + r * ROWB + (((4 * ks + fq) ^ ((r >> 1) & XSW)) << 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    nrm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], gb[j], nrm[i][j], 0, 0, 0);
+        }
+        const bool inverse = p.epi == SC2_EPI_FUSED_IGDN;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * C::WN + j * 16 + frow;
+            const float b = col < p.Cout ? p.ep_beta[col] : 1.0f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float norm = b + nrm[i][j][e];
+                    acc[i][j][e] = inverse ? acc[i][j][e] * norm : acc[i][j][e] * (1.0f / norm);
+                }
+        }
+        __syncthreads();   // the images are dead; the staging buffer below reuses their LDS
+    }
+    const int epi = (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) ? (int)SC2_EPI_NONE : p.epi;
+
     // ------------------------------------------------------------------ epilogue
     // MT passes; pass i stages tile-row i of every wave (WAVES_M*16 rows x BN cols, f32).
     float *stage = reinterpret_cast<float *>(smem);
     const bool nchw = p.out == SC2_OUT_F32_NCHW;
     const int RS = nchw ? BN + 1 : BN + 4;  // row stride in floats (bank spread for the read pattern)
     const int Cout = p.Cout;
-    const int epi = p.epi;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         if (i > 0) __syncthreads();
@@ -448,12 +530,18 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     SC2_REQUIRE(d->Cout_pad == sc2_conv_weight_rows(d->Cout), SC2_ERR_INVALID_ARG, "conv2d: Cout_pad %d != %d",
                 d->Cout_pad, sc2_conv_weight_rows(d->Cout));
     SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS, SC2_ERR_INVALID_ARG, "conv2d: bad a_op");
-    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_BIAS_ADD_RELU, SC2_ERR_INVALID_ARG,
+    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_FUSED_IGDN, SC2_ERR_INVALID_ARG,
                 "conv2d: bad epilogue");
+    const bool fused = d->epilogue == SC2_EPI_FUSED_GDN || d->epilogue == SC2_EPI_FUSED_IGDN;
+    if (fused)
+        SC2_REQUIRE(d->Cout == d->Cout_pad && (d->Cout == 96 || d->Cout == 48 || d->Cout == 64 || d->Cout == 32),
+                    SC2_ERR_UNSUPPORTED,
+                    "conv2d: fused GDN needs one tile to cover all output channels (Cout in {32,48,64,96}), got %d",
+                    d->Cout);
     SC2_REQUIRE(d->out_format >= SC2_OUT_BF16_NHWC && d->out_format <= SC2_OUT_F32_NHWC, SC2_ERR_INVALID_ARG,
                 "conv2d: bad out_format");
     if (d->epilogue != SC2_EPI_NONE) SC2_REQUIRE(ep_beta, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_beta");
-    if (d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS_ADD_RELU)
+    if (d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS_ADD_RELU || fused)
         SC2_REQUIRE(ep_x, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_x");
     const long long M = (long long)d->N * OH * OW;
     SC2_REQUIRE(M < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv2d: N*OH*OW = %lld exceeds 2^31", M);
@@ -470,6 +558,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.OH = OH; a.OW = OW; a.OHW = OH * OW; a.M = (int)M;
     a.Kpad = d->Kpad; a.KT = 0; a.n_ntiles = 0;
     a.aop = d->a_op; a.epi = d->epilogue; a.out = d->out_format;
+    a.g_pitch = sc2_conv_weight_pitch(d->Cout);
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     const int rows = d->Cout_pad;

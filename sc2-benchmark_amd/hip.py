@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get('SC2_LIB') or os.path.join(_HERE, 'libsc2amd.so')   # 
 _lib = None
 
 AOP_NONE, AOP_ABS = 0, 1
-EPI_NONE, EPI_GDN, EPI_IGDN, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_ADD_RELU = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_GDN, EPI_IGDN, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_ADD_RELU, EPI_FUSED_GDN, EPI_FUSED_IGDN = range(8)
+FUSABLE_GDN_CHANNELS = (32, 48, 64, 96)   # conv + GDN1 in one launch: one tile must hold every output channel
 OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
 EB_NOISE, EB_DEQUANTIZE = 0, 1
 EB_PARAM_STRIDE = 64
@@ -250,7 +251,11 @@ def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilo
             out = torch.empty((N, OH, OW, cout), dtype=torch.float32, device=x_nhwc.device)
     if ep_x is not None:
         _dev(ep_x, 'ep_x')
-        assert ep_x.dtype == torch.bfloat16 and ep_x.is_contiguous() and ep_x.numel() == N * OH * OW * cout
+        assert ep_x.dtype == torch.bfloat16 and ep_x.is_contiguous()
+        if epilogue in (EPI_FUSED_GDN, EPI_FUSED_IGDN):   # ep_x carries the packed gamma matrix
+            assert tuple(ep_x.shape) == (weight_rows(cout), weight_pitch(cout))
+        else:
+            assert ep_x.numel() == N * OH * OW * cout
     if ep_beta is not None:
         _dev(ep_beta, 'ep_beta')
         assert ep_beta.dtype == torch.float32 and ep_beta.is_contiguous() and ep_beta.numel() == cout

@@ -116,6 +116,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                 mod._tag = '{}.{}{}'.format(prefix, 'igdn' if getattr(mod, 'inverse', False) else
                                             'gdn' if isinstance(mod, GDN1) else 'conv', i)
         self.output_format = 'f32_nchw'
+        self.fuse_gdn = True    # conv + GDN1 in one launch where one tile holds all output channels (encoder)
         self._conv0_pack = None
         self._conv0_key = None
 
@@ -138,12 +139,21 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         _require_device(x, 'FPBasedResNetBottleneck')
         c0, g1, c2, g3, c4 = self.encoder
         x = x.float()
+        fuse0 = self.fuse_gdn and c0.out_channels in hip.FUSABLE_GDN_CHANNELS
+        fuse2 = self.fuse_gdn and c2.out_channels in hip.FUSABLE_GDN_CHANNELS
         if self._uses_pair_conv0(x):
             N, _, H, W = x.shape
             x4 = hip.nchw_f32_to_nhwc_bf16(x, 4)                      # [N,H,W,4]
             xp = x4.view(N, H, W // 2, 8)                             # pixel pairs
-            h = hip.conv2d_fwd(xp, self._conv0_packed(), c0.out_channels, 5, 3, (2, 1), (2, 1), tag=c0._tag)
+            if fuse0:
+                beta, gamma = g1.effective()
+                h = hip.conv2d_fwd(xp, self._conv0_packed(), c0.out_channels, 5, 3, (2, 1), (2, 1),
+                                   epilogue=hip.EPI_FUSED_IGDN if g1.inverse else hip.EPI_FUSED_GDN, ep_x=gamma,
+                                   ep_beta=beta, tag=c0._tag)
+            else:
+                h = hip.conv2d_fwd(xp, self._conv0_packed(), c0.out_channels, 5, 3, (2, 1), (2, 1), tag=c0._tag)
         else:
+            fuse0 = False
             cin = c0.in_channels
             xin = hip.nchw_f32_to_nhwc_bf16(x, (cin + 7) // 8 * 8)
             if cin % 8 != 0:
@@ -154,9 +164,15 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                                    c0.kernel_size[1], c0.stride, c0.padding)
             else:
                 h = c0.forward_nhwc(xin)
-        h = g1.forward_nhwc(h)
-        h = c2.forward_nhwc(h)
-        h = g3.forward_nhwc(h)
+        if not fuse0:
+            h = g1.forward_nhwc(h)
+        if fuse2:
+            beta, gamma = g3.effective()
+            h = hip.conv2d_fwd(h, c2.packed_weight(), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
+                               c2.padding, epilogue=hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN,
+                               ep_x=gamma, ep_beta=beta, tag=c2._tag)
+        else:
+            h = g3.forward_nhwc(c2.forward_nhwc(h))
         return c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
 
     def synthesis_nhwc(self, y_hat_nhwc):

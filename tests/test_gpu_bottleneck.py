@@ -43,9 +43,14 @@ def test_analysis_synthesis_vs_oracle(S, R, dev):
         dec = m.synthesis(g['y_hat_eval'].to(dev))
         r, mx = rel_err(dec, g['decoded'])
         assert r < BF16_REL_L2, 'decoder rel L2 {} max {}'.format(r, mx)
-        # module-by-module path (nn.Sequential call, f32 NCHW between modules) == fused NHWC pipeline
+        # module-by-module path (nn.Sequential call, f32 NCHW between modules) == unfused NHWC pipeline, and the
+        # conv+GDN fused launches (GDN applied to the f32 accumulators) stay within bf16 rounding of both
         seq = m.encoder(x.to(dev))
-        assert torch.equal(seq.cpu(), latent.cpu())
+        m.fuse_gdn = False
+        assert torch.equal(seq.cpu(), m.analysis(x.to(dev)).cpu())
+        m.fuse_gdn = True
+        r, _ = rel_err(latent, seq)
+        assert r < 8e-3, 'fused vs unfused encoder rel L2 {}'.format(r)
         m.output_format = 'bf16_nhwc'
         dec_b = m.synthesis(g['y_hat_eval'].to(dev))
         assert dec_b.dtype == torch.bfloat16 and dec_b.shape == dec.shape

@@ -132,6 +132,38 @@ def test_gdn1(S, R, dev, C, inverse):
     assert_close_bf16(out, full, 'gdn vs f32 oracle', extra=2.0 ** -6)
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,pad,inverse', [(96, 48, 5, 2, 2, False), (16, 96, 3, 1, 1, False),
+                                                            (24, 64, 2, 1, 1, True), (8, 32, 1, 1, 0, False)])
+def test_conv_fused_gdn(S, R, dev, cin, cout, k, stride, pad, inverse):
+    """conv followed by GDN1 in ONE launch vs conv (f32) -> GDN1 of the oracle on the bf16-rounded operands."""
+    torch.manual_seed(cout)
+    gdn = R.GDN1(cout, inverse=inverse)
+    with torch.no_grad():
+        gdn.gamma.add_(0.05 * torch.rand(cout, cout) / cout ** 0.5)
+        gdn.beta.add_(0.1 * torch.rand(cout))
+    x = torch.randn(2, cin, 13, 10)
+    w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    with torch.no_grad():
+        conv = F.conv2d(bf16_round(x), bf16_round(w), stride=stride, padding=pad)
+        beta = gdn.beta_reparam(gdn.beta)
+        gamma = bf16_round(gdn.gamma_reparam(gdn.gamma))
+        norm = F.conv2d(bf16_round(conv).abs(), gamma.reshape(cout, cout, 1, 1), beta)   # |x| enters the MFMA as bf16
+        ref = conv * norm if inverse else conv / norm
+    m = S.GDN1(cout, inverse=inverse)
+    m.load_state_dict(gdn.state_dict())
+    m.to(dev)
+    beta_d, gamma_d = m.effective()
+    out = S.hip.conv2d_fwd(S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)), S.hip.pack_conv_weight(w.to(dev)), cout, k, k, stride,
+                           pad, epilogue=S.hip.EPI_FUSED_IGDN if inverse else S.hip.EPI_FUSED_GDN, ep_x=gamma_d,
+                           ep_beta=beta_d, out_format=S.hip.OUT_F32_NCHW)
+    torch.testing.assert_close(out.cpu(), ref, rtol=3e-3, atol=3e-3 * ref.abs().max().item())
+    with pytest.raises(S.hip.Sc2Error):   # a 256-channel GDN does not fit one tile: must be refused, not mis-computed
+        S.hip.conv2d_fwd(S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)), S.hip.pack_conv_weight(torch.randn(256, cin, 1, 1).to(dev)),
+                         256, 1, 1, 1, 0, epilogue=S.hip.EPI_FUSED_GDN,
+                         ep_x=S.hip.pack_conv_weight(torch.eye(256).reshape(256, 256, 1, 1).to(dev)),
+                         ep_beta=torch.ones(256, device=dev))
+
+
 def _golden():
     return torch.load(os.path.join(HERE, 'golden', 'fp_golden.pt'), weights_only=False)
 
