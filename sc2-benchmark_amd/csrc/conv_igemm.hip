@@ -25,6 +25,8 @@
 //     epilogues (GDN / IGDN / bias / residual) read their operands coalesced.
 //   * workgroup ids are remapped so that workgroups sharing an XCD (id % 8) cover
 //     neighbouring tiles (shared input halo and the same weight panel stay in that XCD's L2).
+#include <stdlib.h>
+
 #include "sc2_common.h"
 
 namespace {
@@ -96,6 +98,118 @@ __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
     uint4 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
+}
+
+// Stores a workgroup's accumulator tile: MT passes, pass i stages tile-row i of every wave (WAVES_M*16 rows x BN cols,
+// f32) through LDS so that global stores are whole 16-byte channel runs (NHWC) or pixel runs (NCHW), with the
+// element-wise epilogues (GDN / IGDN / bias / ReLU / residual) applied on the way out.  Call with the LDS idle.
+template <class C, int NTHREADS>
+__device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char *smem, f32x4_t (&acc)[C::MT][C::NT],
+                                                int tid, int wm, int wn, int frow, int fq, int m0, int n0, int epi) {
+    constexpr int BN = C::BN, MT = C::MT, NT = C::NT;
+    float *stage = reinterpret_cast<float *>(smem);
+    const bool nchw = p.out == SC2_OUT_F32_NCHW;
+    const int RS = nchw ? BN + 1 : BN + 4;  // row stride in floats (bank spread for the read pattern)
+    const int Cout = p.Cout;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        if (i > 0) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int sr = wm * 16 + fq * 4 + e;
+                const int sc = wn * C::WN + j * 16 + frow;
+                stage[sr * RS + sc] = acc[i][j][e];
+            }
+        }
+        __syncthreads();
+        if (!nchw) {
+            constexpr int CPR = BN / 8;  // 8-channel chunks per row
+            for (int q = tid; q < C::STAGE_ROWS * CPR; q += NTHREADS) {
+                const int sr = q / CPR, cc = q - sr * CPR;
+                const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
+                const int n = n0 + cc * 8;
+                if (m >= p.M || n >= Cout) continue;
+                float v[8];
+                {
+                    const float4 v0 = *reinterpret_cast<const float4 *>(stage + sr * RS + cc * 8);
+                    const float4 v1 = *reinterpret_cast<const float4 *>(stage + sr * RS + cc * 8 + 4);
+                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+                    v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+                }
+                const long long o = (long long)m * Cout + n;
+                if (epi != SC2_EPI_NONE) {
+                    float b[8];
+                    {
+                        const float4 b0 = *reinterpret_cast<const float4 *>(p.ep_beta + n);
+                        const float4 b1 = *reinterpret_cast<const float4 *>(p.ep_beta + n + 4);
+                        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
+                        b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+                    }
+                    float xv[8];
+                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
+                        const uint4 xr = *reinterpret_cast<const uint4 *>(p.ep_x + o);
+                        const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            xv[2 * t] = __builtin_bit_cast(float, xw[t] << 16);
+                            xv[2 * t + 1] = __builtin_bit_cast(float, xw[t] & 0xFFFF0000u);
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) xv[t] = 0.f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float norm = b[t] + v[t];
+                        float r;
+                        if (epi == SC2_EPI_GDN) r = xv[t] * (1.0f / norm);
+                        else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
+                        else if (epi == SC2_EPI_BIAS) r = norm;
+                        else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
+                        else r = fmaxf(norm + xv[t], 0.f);
+                        v[t] = r;
+                    }
+                }
+                if (p.out == SC2_OUT_BF16_NHWC) {
+                    uint4 ov;
+                    ov.x = pack_bf16x2(v[0], v[1]);
+                    ov.y = pack_bf16x2(v[2], v[3]);
+                    ov.z = pack_bf16x2(v[4], v[5]);
+                    ov.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + o) = ov;
+                } else {
+                    float *yo = reinterpret_cast<float *>(p.y) + o;
+                    *reinterpret_cast<float4 *>(yo) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4 *>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            }
+        } else {
+            // f32 NCHW: lanes run along pixels so each channel plane gets contiguous runs.
+            for (int q = tid; q < C::STAGE_ROWS * BN; q += NTHREADS) {
+                const int cidx = q / C::STAGE_ROWS, sr = q - cidx * C::STAGE_ROWS;
+                const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
+                const int n = n0 + cidx;
+                if (m >= p.M || n >= Cout) continue;
+                float v = stage[sr * RS + cidx];
+                if (epi != SC2_EPI_NONE) {
+                    const float norm = p.ep_beta[n] + v;
+                    float xv = 0.f;
+                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU)
+                        xv = bf16_bits_to_f32(p.ep_x[(long long)m * Cout + n]);
+                    if (epi == SC2_EPI_GDN) v = xv * (1.0f / norm);
+                    else if (epi == SC2_EPI_IGDN) v = xv * norm;
+                    else if (epi == SC2_EPI_BIAS) v = norm;
+                    else if (epi == SC2_EPI_BIAS_RELU) v = fmaxf(norm, 0.f);
+                    else v = fmaxf(norm + xv, 0.f);
+                }
+                const int img = m / p.OHW;
+                const int pix = m - img * p.OHW;
+                reinterpret_cast<float *>(p.y)[((long long)img * Cout + n) * p.OHW + pix] = v;
+            }
+        }
+    }
 }
 
 template <class C>
@@ -345,111 +459,254 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     }
     const int epi = (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) ? (int)SC2_EPI_NONE : p.epi;
 
-    // ------------------------------------------------------------------ epilogue
-    // MT passes; pass i stages tile-row i of every wave (WAVES_M*16 rows x BN cols, f32).
-    float *stage = reinterpret_cast<float *>(smem);
-    const bool nchw = p.out == SC2_OUT_F32_NCHW;
-    const int RS = nchw ? BN + 1 : BN + 4;  // row stride in floats (bank spread for the read pattern)
-    const int Cout = p.Cout;
+    conv_store_tile<C, 256>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi);
+}
+
+// ======================================================================================================
+// Big-tile variant for the MFMA-bound layers (Cout % 128 == 0, long K): 512 threads = 8 waves, 256 x BN tile,
+// BK = 32 slabs in a 4-deep direct-to-LDS ring.  The 8 waves form two groups of four (wave w and w + 4 share a
+// SIMD) that run ONE BARRIER OUT OF STEP: between two barriers one group issues its fragment reads and the next
+// slab's direct-to-LDS loads while the other group issues 16 MFMAs, then they swap.  The SIMD's matrix pipe is
+// therefore fed by one wave while its partner does the LDS / address work, instead of both stalling together.
+//   per wave and slab: PHASES phases of {4 A-fragment reads (+ NT B reads in phase 0), a share of slab t+3's
+//   loads, lgkmcnt(0) | barrier | 16 MFMAs | barrier}; a slab's loads are retired with a counted vmcnt one slab
+//   before its first read, by every wave, ahead of the barrier that opens that read (RAW); a stage is re-filled only
+//   after a barrier that follows the lgkmcnt(0) of its last readers (WAR).
+template <int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_, int PH_,
+          int PW_>
+struct Cfg8 {
+    static constexpr int BM = 256, BN = BN_, BK = 32, KC = 4;
+    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+    static constexpr bool STATIC = STATIC_;
+    static constexpr int CIN = CIN_, KH = KH_, KW = KW_, SH = SH_, SW = SW_, PH = PH_, PW = PW_;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int MT = WM / 16, NT = WN / 16;
+    static constexpr int PHASES = MT / 4;
+    static constexpr int STAGES = 4;
+    static constexpr int A_IPW = BM / 16 / 8, B_IPW = BN / 16 / 8;
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int STAGE_ROWS = WAVES_M * 16;
+    static constexpr int MAIN_LDS = STAGES * STAGE_BYTES;
+    static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
+    static constexpr int LDS_BYTES = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
+    static_assert(WAVES_M * WAVES_N == 8 && NT == 4 && MT % 4 == 0, "8 waves, 16 MFMAs per phase");
+    static_assert(BN % 128 == 0, "whole direct-to-LDS instructions per wave");
+};
+
+template <class C>
+__global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, KC = C::KC;
+    constexpr int MT = C::MT, NT = C::NT, S = C::STAGES, PHASES = C::PHASES;
+    constexpr int A_IPW = C::A_IPW, B_IPW = C::B_IPW, L = A_IPW + B_IPW;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2;   // waves w and w + 4 sit on the same SIMD and work out of step
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+
+    const int Cin = C::STATIC ? C::CIN : p.Cin;
+    const int KH = C::STATIC ? C::KH : p.KH;
+    const int KW = C::STATIC ? C::KW : p.KW;
+    const int SH = C::STATIC ? C::SH : p.SH;
+    const int SW = C::STATIC ? C::SW : p.SW;
+    const int PH = C::STATIC ? C::PH : p.PH;
+    const int PW = C::STATIC ? C::PW : p.PW;
+    const int CIN8 = Cin >> 3;
+    const int H = p.H, W = p.W;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int ntile = bid % p.n_ntiles;
+    const int mtile = bid / p.n_ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+
+    // gather state: wave-instruction q = j * 8 + wave fills rows [16q, 16q + 16) of a slab (see conv_igemm_kernel)
+    const int kc = (lane & 3) ^ ((lane >> 3) & 3);
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16);
+    const long long zero_off = zero - p.x, zero_off_w = zero - p.w;
+    long long a_off[A_IPW];
+    int a_ih0[A_IPW], a_iw0[A_IPW];
+    bool a_ok[A_IPW];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        if (i > 0) __syncthreads();
+    for (int j = 0; j < A_IPW; ++j) {
+        const int m = m0 + (j * 8 + wave) * 16 + (lane >> 2);
+        a_ok[j] = m < p.M;
+        const int mm = a_ok[j] ? m : 0;
+        const int img = mm / p.OHW;
+        const int rem = mm - img * p.OHW;
+        const int oh = rem / p.OW;
+        const int ow = rem - oh * p.OW;
+        a_ih0[j] = oh * SH - PH;
+        a_iw0[j] = ow * SW - PW;
+        a_off[j] = ((long long)(img * H + a_ih0[j]) * W + a_iw0[j]) * Cin;
+    }
+    long long b_off[B_IPW];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+    for (int j = 0; j < B_IPW; ++j) b_off[j] = (long long)(n0 + (j * 8 + wave) * 16 + (lane >> 2)) * p.Kpad + kc * 8;
+    // k position of slab t.  When Cin % 32 == 0 a slab never straddles a filter tap, so the tap (kh, kw) and the
+    // channel base are WAVE-UNIFORM functions of t: they live in scalar registers and cost no vector ALU; only
+    // the bounds test and the final add are per lane.  Otherwise a per-lane (kh, kw, c8) state machine is stepped.
+    const bool aligned = C::STATIC ? (C::CIN % 32 == 0) : (Cin % 32 == 0);
+    const int spt = aligned ? (CIN8 >> 2) : 1;     // slabs per tap
+    constexpr int WRAPS = C::STATIC ? (KC + (C::CIN / 8) - 1) / (C::CIN / 8 > 0 ? C::CIN / 8 : 1) : KC;
+    int c8 = kc, kh = 0, kw = 0;
+    auto wrap_k = [&]() {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int sr = wm * 16 + fq * 4 + e;
-                const int sc = wn * C::WN + j * 16 + frow;
-                stage[sr * RS + sc] = acc[i][j][e];
-            }
+        for (int rep = 0; rep < WRAPS; ++rep) {
+            const bool w1 = c8 >= CIN8;
+            c8 -= w1 ? CIN8 : 0;
+            kw += w1 ? 1 : 0;
+            const bool w2 = kw == KW;
+            kw = w2 ? 0 : kw;
+            kh += w2 ? 1 : 0;
         }
-        __syncthreads();
-        if (!nchw) {
-            constexpr int CPR = BN / 8;  // 8-channel chunks per row
-            for (int q = tid; q < C::STAGE_ROWS * CPR; q += 256) {
-                const int sr = q / CPR, cc = q - sr * CPR;
-                const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
-                const int n = n0 + cc * 8;
-                if (m >= p.M || n >= Cout) continue;
-                float v[8];
-                {
-                    const float4 v0 = *reinterpret_cast<const float4 *>(stage + sr * RS + cc * 8);
-                    const float4 v1 = *reinterpret_cast<const float4 *>(stage + sr * RS + cc * 8 + 4);
-                    v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-                    v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-                }
-                const long long o = (long long)m * Cout + n;
-                if (epi != SC2_EPI_NONE) {
-                    float b[8];
-                    {
-                        const float4 b0 = *reinterpret_cast<const float4 *>(p.ep_beta + n);
-                        const float4 b1 = *reinterpret_cast<const float4 *>(p.ep_beta + n + 4);
-                        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
-                        b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
-                    }
-                    float xv[8];
-                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
-                        const uint4 xr = *reinterpret_cast<const uint4 *>(p.ep_x + o);
-                        const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            xv[2 * t] = __builtin_bit_cast(float, xw[t] << 16);
-                            xv[2 * t + 1] = __builtin_bit_cast(float, xw[t] & 0xFFFF0000u);
-                        }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) xv[t] = 0.f;
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        const float norm = b[t] + v[t];
-                        float r;
-                        if (epi == SC2_EPI_GDN) r = xv[t] * (1.0f / norm);
-                        else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
-                        else if (epi == SC2_EPI_BIAS) r = norm;
-                        else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
-                        else r = fmaxf(norm + xv[t], 0.f);
-                        v[t] = r;
-                    }
-                }
-                if (p.out == SC2_OUT_BF16_NHWC) {
-                    uint4 ov;
-                    ov.x = pack_bf16x2(v[0], v[1]);
-                    ov.y = pack_bf16x2(v[2], v[3]);
-                    ov.z = pack_bf16x2(v[4], v[5]);
-                    ov.w = pack_bf16x2(v[6], v[7]);
-                    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + o) = ov;
-                } else {
-                    float *yo = reinterpret_cast<float *>(p.y) + o;
-                    *reinterpret_cast<float4 *>(yo) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4 *>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                }
-            }
+    };
+    if (!aligned) wrap_k();
+    const int KT = p.KT;
+    int next_a = 0;   // slab index the next issue_a() call fetches
+
+    auto issue_a = [&](int buf) {   // A rows of the next unissued slab
+        unsigned char *Ab = smem + buf * C::STAGE_BYTES;
+        int t_kh, t_kw;
+        long long tap_off;
+        if (aligned) {
+            const int tap = next_a / spt, cb = next_a - tap * spt;   // scalar
+            t_kh = tap / KW;
+            t_kw = tap - t_kh * KW;
+            tap_off = ((long long)t_kh * W + t_kw) * Cin + cb * 32 + kc * 8;
         } else {
-            // f32 NCHW: lanes run along pixels so each channel plane gets contiguous runs.
-            for (int q = tid; q < C::STAGE_ROWS * BN; q += 256) {
-                const int cidx = q / C::STAGE_ROWS, sr = q - cidx * C::STAGE_ROWS;
-                const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
-                const int n = n0 + cidx;
-                if (m >= p.M || n >= Cout) continue;
-                float v = stage[sr * RS + cidx];
-                if (epi != SC2_EPI_NONE) {
-                    const float norm = p.ep_beta[n] + v;
-                    float xv = 0.f;
-                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU)
-                        xv = bf16_bits_to_f32(p.ep_x[(long long)m * Cout + n]);
-                    if (epi == SC2_EPI_GDN) v = xv * (1.0f / norm);
-                    else if (epi == SC2_EPI_IGDN) v = xv * norm;
-                    else if (epi == SC2_EPI_BIAS) v = norm;
-                    else if (epi == SC2_EPI_BIAS_RELU) v = fmaxf(norm, 0.f);
-                    else v = fmaxf(norm + xv, 0.f);
-                }
-                const int img = m / p.OHW;
-                const int pix = m - img * p.OHW;
-                reinterpret_cast<float *>(p.y)[((long long)img * Cout + n) * p.OHW + pix] = v;
+            t_kh = kh;
+            t_kw = kw;
+            tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
+        }
+        const bool tap_ok = t_kh < KH;   // false for the K tail and the dummy slabs past KT
+#pragma unroll
+        for (int j = 0; j < A_IPW; ++j) {
+            const int ih = a_ih0[j] + t_kh, iw = a_iw0[j] + t_kw;
+            const bool ok = a_ok[j] & tap_ok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            const long long off = ok ? a_off[j] + tap_off : zero_off;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.x + off), (lds_ptr_t)(Ab + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+        ++next_a;
+        if (!aligned) {
+            c8 += KC;
+            wrap_k();
+        }
+    };
+    auto issue_b = [&](int kt, int buf) {
+        unsigned char *Bb = smem + buf * C::STAGE_BYTES + C::A_BYTES;
+        const bool kt_ok = kt < KT;
+#pragma unroll
+        for (int j = 0; j < B_IPW; ++j) {
+            const long long off = kt_ok ? b_off[j] + (long long)kt * BK : zero_off_w;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.w + off), (lds_ptr_t)(Bb + (j * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t amask = p.aop == SC2_AOP_ABS ? 0x7FFF7FFFu : 0xFFFFFFFFu;
+    const int frow = lane & 15, fq = lane >> 4;
+    uint32_t a_rd[MT], b_rd[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_rd[i] = (uint32_t)lds_off(wm * C::WM + i * 16 + frow, fq);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b_rd[j] = (uint32_t)(C::A_BYTES + lds_off(wn * C::WN + j * 16 + frow, fq));
+
+#pragma unroll
+    for (int st = 0; st < S - 1; ++st) {
+        issue_a(st);
+        issue_b(st, st);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");   // slab 0 has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    if (group == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+    uint4 bv[NT];
+    for (int kt = 0; kt < KT; ++kt) {
+        const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
+        const int nbuf = (kt + S - 1) % S;
+#pragma unroll
+        for (int ph = 0; ph < PHASES; ++ph) {
+            // ---- load interval: this phase's fragments, a share of slab kt+S-1's loads
+            uint4 av[4];
+            if (ph == 0) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = lds_read16(sb + b_rd[j]);
             }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = lds_read16(sb + a_rd[4 * ph + i]);
+            if (ph == 0) issue_a(nbuf);
+            if (ph == PHASES - 1) issue_b(kt + S - 1, nbuf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (ph == PHASES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");   // slab kt+1 landed
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- MFMA interval (the partner group is in its load interval)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            bf16x8_t af[4], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint4 v = av[i];
+                v.x &= amask; v.y &= amask; v.z &= amask; v.w &= amask;
+                af[i] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, bv[j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[4 * ph + i][j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[4 * ph + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (group == 0) __builtin_amdgcn_s_barrier();   // re-align the groups
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy slabs past KT
+    __builtin_amdgcn_s_barrier();
+
+    conv_store_tile<C, 512>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi);
+}
+
+template <class C>
+int launch8(const ConvArgs &a, hipStream_t s) {
+    ConvArgs p = a;
+    p.KT = (a.KH * a.KW * a.Cin + C::BK - 1) / C::BK;
+    p.n_ntiles = (a.Cout + C::BN - 1) / C::BN;
+    const int n_mtiles = (a.M + C::BM - 1) / C::BM;
+    const long long nwg = (long long)n_mtiles * p.n_ntiles;
+    if (nwg <= 0 || nwg > 0x7FFFFFFFLL) {
+        sc2_set_error("conv2d: grid of %lld workgroups out of range", nwg);
+        return SC2_ERR_INVALID_ARG;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_igemm8_kernel<C>, dim3((unsigned)nwg), dim3(512), C::LDS_BYTES, s, p);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
 }
 
 template <class C>
@@ -492,6 +749,14 @@ using G_96 = Cfg<128, 96, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 using G_64 = Cfg<128, 64, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 using G_48 = Cfg<128, 48, 4, 1, false, 0, 0, 0, 0, 0, 0, 0>;
 using G_32 = Cfg<128, 32, 4, 1, false, 0, 0, 0, 0, 0, 0, 0>;
+
+// big-tile (8-wave) geometries: the MFMA-bound decoder layers and the runtime-geometry fallback
+using B_gdn512 = Cfg8<256, 2, 4, true, 512, 1, 1, 1, 1, 0, 0>;
+using B_dec2 = Cfg8<256, 2, 4, true, 512, 2, 2, 1, 1, 0, 0>;
+using B_gdn256 = Cfg8<256, 2, 4, true, 256, 1, 1, 1, 1, 0, 0>;
+using B_dec4 = Cfg8<256, 2, 4, true, 256, 2, 2, 1, 1, 1, 1>;
+using BG_256 = Cfg8<256, 2, 4, false, 0, 0, 0, 0, 0, 0, 0>;
+using BG_128 = Cfg8<128, 4, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 
 template <class C>
 bool matches(const ConvArgs &a) {
@@ -568,6 +833,22 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     if (rows == 48 && matches<C_conv2>(a)) return launch<C_conv2>(a, s);
     if (rows == 48 && matches<C_gdn48>(a)) return launch<C_gdn48>(a, s);
     if (rows == 32 && matches<C_conv4>(a)) return launch<C_conv4>(a, s);
+    // big tiles pay when there is enough K to amortise the 256-row tile's prologue / epilogue and enough rows to
+    // fill the chip twice over
+    // (SC2_CONV_FORCE_BIG / SC2_CONV_NO_BIG: test and A/B switches)
+    // Measured (tools/ab_big.py, one process, MI355X): 256-wide big tile wins +27 % at K = 2048 and +13 % at K = 1024,
+    // ties or loses on the HBM-bound 1x1 GDN GEMMs and on short K; the 128-wide big tile never wins.
+    const bool forced = getenv("SC2_CONV_FORCE_BIG") != nullptr;
+    const bool big = rows % 128 == 0 && !getenv("SC2_CONV_NO_BIG") &&
+                     ((K >= 1024 && d->Cout % 256 == 0 && d->a_op == SC2_AOP_NONE && M >= 256LL * 512) || forced);
+    if (big && d->Cout % 256 == 0) {
+        if (matches<B_gdn512>(a)) return launch8<B_gdn512>(a, s);
+        if (matches<B_dec2>(a)) return launch8<B_dec2>(a, s);
+        if (matches<B_gdn256>(a)) return launch8<B_gdn256>(a, s);
+        if (matches<B_dec4>(a)) return launch8<B_dec4>(a, s);
+        return launch8<BG_256>(a, s);
+    }
+    if (big && d->Cout % 128 == 0) return launch8<BG_128>(a, s);
     if (rows % 128 == 0) {
         if (matches<C_dec0>(a)) return launch<C_dec0>(a, s);
         if (matches<C_gdn512>(a)) return launch<C_gdn512>(a, s);

@@ -79,6 +79,53 @@ def test_conv_igemm(S, dev, cin, cout, k, stride, pad, H, W, N):
     assert torch.equal(out32h.permute(0, 3, 1, 2).cpu(), out32.cpu())
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,pad,H,W,N', [
+    (512, 256, 2, 1, 0, 9, 9, 5),      # dec.conv2 geometry (static big tile), 320 rows: 2 tiles, ragged
+    (256, 256, 2, 1, 1, 8, 8, 3),      # dec.conv4 geometry
+    (64, 512, 1, 1, 0, 20, 20, 1),     # generic 256-wide, 2 n-tiles, K = 64 (2 slabs < ring depth)
+    (32, 128, 3, 1, 1, 17, 19, 2),     # generic 128-wide 8-wave tile
+    (24, 384, 3, 2, 1, 30, 30, 2),     # Cout 384: 128-wide tiles, K = 216 (tail slab)
+])
+def test_conv_big_tile(S, dev, monkeypatch, cin, cout, k, stride, pad, H, W, N):
+    """The 8-wave staggered 256-row kernel (forced here: its dispatch thresholds need >= 131072 rows)."""
+    monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ref = F.conv2d(bf16_round(x), bf16_round(w), stride=stride, padding=pad)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev), cin)
+    wp = S.hip.pack_conv_weight(w.to(dev))
+    out32 = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW)
+    torch.testing.assert_close(out32.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+    out = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'big-tile conv bf16 nhwc')
+    monkeypatch.delenv('SC2_CONV_FORCE_BIG')
+    monkeypatch.setenv('SC2_CONV_NO_BIG', '1')
+    small = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW)
+    torch.testing.assert_close(out32.cpu(), small.cpu(), rtol=1e-5, atol=1e-5 * ref.abs().max().item())
+
+
+def test_gdn_big_tile(S, R, dev, monkeypatch):
+    monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
+    for C, inverse in ((256, True), (512, True)):
+        torch.manual_seed(C)
+        ref_m = R.GDN1(C, inverse=inverse)
+        with torch.no_grad():
+            ref_m.gamma.add_(0.05 * torch.rand(C, C) / C ** 0.5)
+        m = S.GDN1(C, inverse=inverse)
+        m.load_state_dict(ref_m.state_dict())
+        m.to(dev)
+        x = torch.randn(3, C, 10, 9)
+        with torch.no_grad():
+            beta = ref_m.beta_reparam(ref_m.beta)
+            gamma = bf16_round(ref_m.gamma_reparam(ref_m.gamma)).reshape(C, C, 1, 1)
+            xb = bf16_round(x)
+            norm = F.conv2d(xb.abs(), gamma, beta)
+            ref = xb * norm if inverse else xb / norm
+            out = m(x.to(dev))
+        torch.testing.assert_close(out.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+
+
 def test_conv_identity_asymmetric(S, dev):
     """A = I style check: 1x1 conv with a permutation-like asymmetric weight must route channels exactly."""
     cin = cout = 96
