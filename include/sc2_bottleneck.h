@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 6
+#define SC2_ABI_VERSION 8
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -87,6 +87,11 @@ typedef struct sc2_conv_desc {
     int32_t Kpad;                  /* row pitch (elements) of the packed weights, % 64 == 0      */
     int32_t Cout_pad;              /* rows of the packed weight matrix (>= Cout, % 128 == 0 or
                                       == tile width; see sc2_conv_weight_rows)                   */
+    /* Output scatter, for the data gradient of a strided conv (one launch per stride-parity class).  out_H == 0:
+     * dense output [N,OH,OW,Cout].  Otherwise OH/OW are taken as given (rows past the symmetric-padding formula
+     * see implicit zeros) and output pixel (oh, ow) is written to (oh*out_stride_h + out_off_h,
+     * ow*out_stride_w + out_off_w) of an NHWC tensor [N,out_H,out_W,Cout]; pixels outside it are dropped. */
+    int32_t out_H, out_W, out_stride_h, out_stride_w, out_off_h, out_off_w;
 } sc2_conv_desc;
 
 /* Rows the packed weight buffer must have for a given Cout (zero rows beyond Cout). */
@@ -128,6 +133,16 @@ int sc2_eb_forward(const float *y, const float *noise, const float *params, int 
                    float *bits_partial, int bits_partial_len, void *stream);
 /* number of partial sums sc2_eb_forward writes for this problem size */
 int sc2_eb_bits_partial_len(int N, int C, int HW);
+
+/* Backward of sc2_eb_forward (CompressAI EntropyBottleneck.forward under autograd, reached from the training loop
+ * through layer.py:531) w.r.t. y and the effective parameter block.  Re-evaluates the forward from (y, noise).
+ *   g_yhat, g_lik : upstream gradients, f32 NCHW (nullable = zero)
+ *   g_y           : f32 NCHW out
+ *   g_params_partial : f32 [n_partial][64] out, n_partial = sc2_eb_bits_partial_len(N, C, HW) rows ordered
+ *                   (n, c, tile); the caller sums the rows of a channel.  Slot 58 is the median's gradient. */
+int sc2_eb_backward(const float *y, const float *noise, const float *params, int N, int C, int HW, int mode,
+                    float lik_bound, const float *g_yhat, const float *g_lik, float *g_y, float *g_params_partial,
+                    int n_partial, void *stream);
 
 /* symbols = int32(round_half_even(y - median[c])) in NCHW order, one row of C*HW per image.
  * Replaces EntropyModel.quantize(x, "symbols", means) reached from layer.py:506. */

@@ -161,27 +161,10 @@ class _EbFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_yhat, g_lik):
         y, params, noise = ctx.saved_tensors
-        N, C = y.shape[0], y.shape[1]
-        with torch.enable_grad():
-            y_ = y.detach().requires_grad_(True)
-            P = params.detach().requires_grad_(True)
-            v = y_.transpose(0, 1).reshape(C, 1, -1)
-            if ctx.training:
-                out = v + noise.transpose(0, 1).reshape(C, 1, -1)
-            else:
-                med = P[:, 58].reshape(C, 1, 1)
-                out = torch.round(v - med) + med
-            lik = torch.sigmoid(_eb_logits(out + 0.5, P)) - torch.sigmoid(_eb_logits(out - 0.5, P))
-            if ctx.lik_bound > 0:
-                lik = _LowerBoundFn.apply(lik, ctx.lik_bound)
-            shape = (C, N) + tuple(y.shape[2:])
-            out_b = out.reshape(shape).transpose(0, 1)
-            lik_b = lik.reshape(shape).transpose(0, 1)
-            gy, gp = torch.autograd.grad((out_b, lik_b), (y_, P), (g_yhat, g_lik), allow_unused=True)
-        if gy is None:
-            gy = torch.zeros_like(y)
-        if gp is None:
-            gp = torch.zeros_like(params)
+        mode = hip.EB_NOISE if ctx.training else hip.EB_DEQUANTIZE
+        gy, gp = hip.eb_backward(y, params.detach().contiguous(), mode, noise if ctx.training else None,
+                                 g_yhat.float().contiguous() if g_yhat is not None else None,
+                                 g_lik.float().contiguous() if g_lik is not None else None, lik_bound=ctx.lik_bound)
         return gy, gp, None, None, None
 
 

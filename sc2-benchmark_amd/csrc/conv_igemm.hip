@@ -44,6 +44,7 @@ struct ConvArgs {
     int n_ntiles;
     int aop, epi, out;
     int g_pitch;   // fused GDN: row pitch (elements) of the packed gamma matrix handed in through ep_x
+    int o_H, o_W, o_sh, o_sw, o_h0, o_w0;   // NHWC output scatter (o_H == 0: dense): pixel (oh, ow) -> (oh*o_sh+o_h0, ..)
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_,
@@ -138,7 +139,16 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
                     v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
                     v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
                 }
-                const long long o = (long long)m * Cout + n;
+                long long o = (long long)m * Cout + n;
+                const long long o_ep = o;   // epilogue operands (ep_x) are always dense
+                if (p.o_H > 0) {   // strided scatter (transposed-convolution parity classes of the data gradient)
+                    const int img = m / p.OHW;
+                    const int rem = m - img * p.OHW;
+                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    const int yh = oh * p.o_sh + p.o_h0, yw = ow * p.o_sw + p.o_w0;
+                    if (yh >= p.o_H || yw >= p.o_W) continue;
+                    o = (((long long)img * p.o_H + yh) * p.o_W + yw) * Cout + n;
+                }
                 if (epi != SC2_EPI_NONE) {
                     float b[8];
                     {
@@ -149,7 +159,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
                     }
                     float xv[8];
                     if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
-                        const uint4 xr = *reinterpret_cast<const uint4 *>(p.ep_x + o);
+                        const uint4 xr = *reinterpret_cast<const uint4 *>(p.ep_x + o_ep);
                         const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -785,8 +795,18 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
                 "conv2d: Cin (%d) and Cout (%d) must be multiples of 8", d->Cin, d->Cout);
     SC2_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_h >= 0 && d->pad_w >= 0,
                 SC2_ERR_INVALID_ARG, "conv2d: bad filter geometry");
-    const int OH = (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1;
-    const int OW = (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1;
+    int OH = (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1;
+    int OW = (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1;
+    const bool scatter = d->out_H > 0;
+    if (scatter) {
+        // transposed-convolution use: the caller fixes the number of output rows/cols (rows past the symmetric
+        // formula see implicit zero padding) and where each lands in a strided NHWC output
+        SC2_REQUIRE(d->OH > 0 && d->OW > 0 && d->out_W > 0 && d->out_stride_h > 0 && d->out_stride_w > 0 &&
+                        d->out_off_h >= 0 && d->out_off_w >= 0 && d->out_format != SC2_OUT_F32_NCHW,
+                    SC2_ERR_INVALID_ARG, "conv2d: bad output scatter");
+        OH = d->OH;
+        OW = d->OW;
+    }
     SC2_REQUIRE(OH == d->OH && OW == d->OW && OH > 0 && OW > 0, SC2_ERR_INVALID_ARG,
                 "conv2d: output size %dx%d does not match geometry (%dx%d)", d->OH, d->OW, OH, OW);
     const int K = d->KH * d->KW * d->Cin;
@@ -824,6 +844,8 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.Kpad = d->Kpad; a.KT = 0; a.n_ntiles = 0;
     a.aop = d->a_op; a.epi = d->epilogue; a.out = d->out_format;
     a.g_pitch = sc2_conv_weight_pitch(d->Cout);
+    a.o_H = scatter ? d->out_H : 0; a.o_W = d->out_W; a.o_sh = d->out_stride_h; a.o_sw = d->out_stride_w;
+    a.o_h0 = d->out_off_h; a.o_w0 = d->out_off_w;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     const int rows = d->Cout_pad;

@@ -86,6 +86,145 @@ __global__ __launch_bounds__(EB_THREADS) void eb_forward_kernel(
     }
 }
 
+// Backward of eb_forward_kernel.  Per element the 5-layer cumulative-logit MLP is re-evaluated at y_hat -/+ 1/2
+// (nothing but y_hat is saved by the forward) and differentiated by hand; the 58 per-channel parameter gradients are
+// accumulated in registers over the thread's elements, reduced over the workgroup (wave shuffles, then LDS) and written
+// as one partial row per workgroup; the caller sums the partial rows of a channel.
+//   g_lik passes the likelihood lower bound by CompressAI's LowerBound rule (x >= bound or the gradient pushes x up).
+struct EbGrad {
+    float g[SC2_EB_PARAM_STRIDE];
+};
+
+__device__ __forceinline__ float eb_logits_bwd(float v, const float *__restrict__ P, float d_out, float *__restrict__ G,
+                                               bool want) {
+    // forward, keeping pre-activations and tanh values
+    float g0[3], t0[3], h0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g0[k] = P[k] * v + P[3 + k];
+        t0[k] = tanhf(g0[k]);
+        h0[k] = g0[k] + P[6 + k] * t0[k];
+    }
+    float gl[3][3], tl[3][3], hl[3][3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const float *Q = P + 9 + 15 * l;
+        const float *hin = l == 0 ? h0 : hl[l - 1];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gl[l][k] = Q[3 * k] * hin[0] + Q[3 * k + 1] * hin[1] + Q[3 * k + 2] * hin[2] + Q[9 + k];
+            tl[l][k] = tanhf(gl[l][k]);
+            hl[l][k] = gl[l][k] + Q[12 + k] * tl[l][k];
+        }
+    }
+    const float out = P[54] * hl[2][0] + P[55] * hl[2][1] + P[56] * hl[2][2] + P[57];
+    if (!want) return out;
+    // backward
+    float dh[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        G[54 + j] += d_out * hl[2][j];
+        dh[j] = d_out * P[54 + j];
+    }
+    G[57] += d_out;
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+        const float *Q = P + 9 + 15 * l;
+        float *GQ = G + 9 + 15 * l;
+        const float *hin = l == 0 ? h0 : hl[l - 1];
+        float dg[3], dhin[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            GQ[12 + k] += dh[k] * tl[l][k];
+            dg[k] = dh[k] * (1.0f + Q[12 + k] * (1.0f - tl[l][k] * tl[l][k]));
+            GQ[9 + k] += dg[k];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                GQ[3 * k + j] += dg[k] * hin[j];
+                dhin[j] += Q[3 * k + j] * dg[k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dh[j] = dhin[j];
+    }
+    float dv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        G[6 + k] += dh[k] * t0[k];
+        const float dg = dh[k] * (1.0f + P[6 + k] * (1.0f - t0[k] * t0[k]));
+        G[3 + k] += dg;
+        G[k] += dg * v;
+        dv += P[k] * dg;
+    }
+    G[63] = dv;   // scratch slot: d out / d v of this evaluation
+    return out;
+}
+
+__global__ __launch_bounds__(EB_THREADS) void eb_backward_kernel(
+    const float *__restrict__ y, const float *__restrict__ noise, const float *__restrict__ params, int C, int HW,
+    int mode, float lik_bound, const float *__restrict__ g_yhat, const float *__restrict__ g_lik,
+    float *__restrict__ g_y, float *__restrict__ g_partial) {
+    const int plane = blockIdx.x;
+    const int c = plane % C;
+    const float *P = params + c * SC2_EB_PARAM_STRIDE;
+    const float med = P[58];
+    const long long base = (long long)plane * HW;
+    float G[SC2_EB_PARAM_STRIDE];
+#pragma unroll
+    for (int k = 0; k < SC2_EB_PARAM_STRIDE; ++k) G[k] = 0.f;
+    float g_med = 0.f;
+#pragma unroll 1
+    for (int e = 0; e < EB_EPT; ++e) {
+        const int pix = blockIdx.y * EB_TILE + e * EB_THREADS + threadIdx.x;
+        if (pix < HW) {
+            const float v = y[base + pix];
+            const float out = mode == SC2_EB_NOISE ? v + noise[base + pix] : rintf(v - med) + med;
+            float d_total = g_yhat ? g_yhat[base + pix] : 0.f;
+            if (g_lik) {
+                const float gl = g_lik[base + pix];
+                const float lower = eb_logits_bwd(out - 0.5f, P, 0.f, G, false);
+                const float upper = eb_logits_bwd(out + 0.5f, P, 0.f, G, false);
+                const float su = sigmoidf_(upper), sl = sigmoidf_(lower);
+                const float raw = su - sl;
+                const float g_raw = (raw >= lik_bound || gl < 0.f) ? gl : 0.f;
+                if (g_raw != 0.f) {
+                    (void)eb_logits_bwd(out + 0.5f, P, g_raw * su * (1.0f - su), G, true);
+                    d_total += G[63];
+                    (void)eb_logits_bwd(out - 0.5f, P, -g_raw * sl * (1.0f - sl), G, true);
+                    d_total += G[63];
+                }
+            }
+            // noise mode: y_hat = y + u -> dy = d y_hat ; dequantize mode: y_hat = round(y - m) + m -> dy = 0, dm = d y_hat
+            if (mode == SC2_EB_NOISE) {
+                g_y[base + pix] = d_total;
+            } else {
+                g_y[base + pix] = 0.f;
+                g_med += d_total;
+            }
+        }
+    }
+    G[58] = g_med;
+    G[63] = 0.f;
+    // workgroup reduction of the 59 sums
+    __shared__ float red[EB_THREADS / 64][SC2_EB_PARAM_STRIDE];
+#pragma unroll
+    for (int k = 0; k < 59; ++k) {
+        float s = G[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < SC2_EB_PARAM_STRIDE) {
+        float s = 0.f;
+        if (threadIdx.x < 59) {
+#pragma unroll
+            for (int w = 0; w < EB_THREADS / 64; ++w) s += red[w][threadIdx.x];
+        }
+        g_partial[((long long)plane * gridDim.y + blockIdx.y) * SC2_EB_PARAM_STRIDE + threadIdx.x] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void eb_symbols_kernel(const float *__restrict__ y, const float *__restrict__ medians,
                                                          int C, int HW, int32_t *__restrict__ symbols) {
     const int plane = blockIdx.x;
@@ -137,6 +276,23 @@ extern "C" int sc2_eb_forward(const float *y, const float *noise, const float *p
     hipLaunchKernelGGL(eb_forward_kernel, grid, dim3(EB_THREADS), 0, static_cast<hipStream_t>(stream), y, noise,
                        params, C, HW, mode, lik_bound, y_hat, static_cast<uint16_t *>(y_hat_bf16_nhwc), lik,
                        bits_partial);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+extern "C" int sc2_eb_backward(const float *y, const float *noise, const float *params, int N, int C, int HW, int mode,
+                               float lik_bound, const float *g_yhat, const float *g_lik, float *g_y,
+                               float *g_params_partial, int n_partial, void *stream) {
+    SC2_REQUIRE(y && params && g_y && g_params_partial, SC2_ERR_INVALID_ARG, "eb_backward: null argument");
+    SC2_REQUIRE(N > 0 && C > 0 && HW > 0, SC2_ERR_INVALID_ARG, "eb_backward: bad dims N=%d C=%d HW=%d", N, C, HW);
+    SC2_REQUIRE(mode == SC2_EB_NOISE || mode == SC2_EB_DEQUANTIZE, SC2_ERR_INVALID_ARG,
+                "Invalid quantization mode: \"%d\"", mode);
+    if (mode == SC2_EB_NOISE) SC2_REQUIRE(noise, SC2_ERR_INVALID_ARG, "eb_backward: noise mode needs the noise tensor");
+    SC2_REQUIRE(n_partial == sc2_eb_bits_partial_len(N, C, HW), SC2_ERR_INVALID_ARG,
+                "eb_backward: n_partial %d != %d", n_partial, sc2_eb_bits_partial_len(N, C, HW));
+    dim3 grid(N * C, plane_grid_x(HW, EB_TILE));
+    hipLaunchKernelGGL(eb_backward_kernel, grid, dim3(EB_THREADS), 0, static_cast<hipStream_t>(stream), y, noise,
+                       params, C, HW, mode, lik_bound, g_yhat, g_lik, g_y, g_params_partial);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }

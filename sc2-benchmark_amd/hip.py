@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv2d_fwd',
-    'sc2_eb_forward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
+    'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
 ]
@@ -34,7 +34,8 @@ ABI_SYMBOLS = [
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride_h', 'stride_w', 'pad_h', 'pad_w', 'OH', 'OW',
-        'a_op', 'epilogue', 'out_format', 'Kpad', 'Cout_pad')]
+        'a_op', 'epilogue', 'out_format', 'Kpad', 'Cout_pad', 'out_H', 'out_W', 'out_stride_h', 'out_stride_w',
+        'out_off_h', 'out_off_w')]
 
 
 class Sc2Error(RuntimeError):
@@ -61,6 +62,7 @@ def lib():
     L.sc2_conv_weight_pitch.argtypes = [i32]
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     L.sc2_eb_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
+    L.sc2_eb_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
     L.sc2_eb_bits_partial_len.argtypes = [i32, i32, i32]
     L.sc2_eb_symbols.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.sc2_eb_dequantize.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
@@ -224,8 +226,53 @@ def pack_conv0_weight_pairs(w):
     return packed
 
 
+def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16):
+    """Data gradient of y = conv2d(x, weight, stride, pad) on the forward implicit-GEMM kernel.
+
+    gy_nhwc: bf16 [N,OH,OW,Cout]; weight: [Cout,Cin,KH,KW]; returns NHWC [N,H,W,Cin] (H, W = in_hw).
+    A transposed convolution is, per stride-parity class (ih % s, iw % s), a stride-1 correlation of gy with the
+    sub-filter of taps kh = r + s*t (r = (ih + p) % s), flipped; each class is one launch that scatters its rows
+    to every s-th pixel of the gradient.  Stride 1 is the single-class case (full flip, pad k-1-p).
+    """
+    cout, cin, KH, KW = weight.shape
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    H, W = in_hw
+    N = gy_nhwc.shape[0]
+    fmt = OUT_BF16_NHWC if out_dtype == torch.bfloat16 else OUT_F32_NHWC
+    gx = torch.empty((N, H, W, cin), dtype=out_dtype, device=gy_nhwc.device)
+    covered_h = covered_w = 0
+    wt = weight.detach().permute(1, 0, 2, 3)   # [Cin, Cout, KH, KW]
+    for ch in range(sh):
+        rh = (ch + ph) % sh
+        khs = list(range(rh, KH, sh))
+        rows = (H - ch + sh - 1) // sh if H > ch else 0
+        for cw in range(sw):
+            rw = (cw + pw) % sw
+            kws = list(range(rw, KW, sw))
+            cols = (W - cw + sw - 1) // sw if W > cw else 0
+            if rows == 0 or cols == 0:
+                continue
+            if not khs or not kws:      # no tap reaches this parity class: its gradient is zero
+                gx[:, ch::sh, cw::sw] = 0
+                continue
+            qh, qw = (ch + ph - rh) // sh, (cw + pw - rw) // sw
+            pad_h, pad_w = len(khs) - 1 - qh, len(kws) - 1 - qw
+            if pad_h < 0 or pad_w < 0:
+                raise Sc2Error('conv2d_dgrad: unsupported geometry k={} s={} p={}'.format((KH, KW), (sh, sw), (ph, pw)))
+            sub = wt[:, :, khs][:, :, :, kws].flip(2, 3).contiguous()      # taps in correlation order
+            packed = pack_conv_weight(sub)
+            if sh == 1 and sw == 1:
+                conv2d_fwd(gy_nhwc, packed, cin, len(khs), len(kws), 1, (pad_h, pad_w), out_format=fmt, out=gx,
+                           tag='dgrad')
+            else:
+                conv2d_fwd(gy_nhwc, packed, cin, len(khs), len(kws), 1, (pad_h, pad_w), out_format=fmt, tag='dgrad',
+                           scatter=(rows, cols, gx, sh, sw, ch, cw))
+    return gx
+
+
 def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilogue=EPI_NONE,
-               out_format=OUT_BF16_NHWC, ep_x=None, ep_beta=None, out=None, tag=None):
+               out_format=OUT_BF16_NHWC, ep_x=None, ep_beta=None, out=None, tag=None, scatter=None):
     """x_nhwc: bf16 [N,H,W,Cin]; returns the output tensor.
 
     out_format OUT_BF16_NHWC -> bf16 [N,OH,OW,Cout]; OUT_F32_NCHW -> f32 [N,Cout,OH,OW];
@@ -240,8 +287,14 @@ def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilo
     N, H, W, Cin = x_nhwc.shape
     OH = (H + 2 * ph - kh) // sh + 1
     OW = (W + 2 * pw - kw) // sw + 1
+    sc = (0, 0, 0, 0, 0, 0)
+    if scatter is not None:   # (OH, OW, out tensor [N,out_H,out_W,cout], stride_h, stride_w, off_h, off_w)
+        OH, OW, out, s_h, s_w, o_h, o_w = scatter
+        assert out.dtype == (torch.bfloat16 if out_format == OUT_BF16_NHWC else torch.float32) and out.is_contiguous()
+        assert out.shape[0] == N and out.shape[3] == cout
+        sc = (out.shape[1], out.shape[2], s_h, s_w, o_h, o_w)
     d = ConvDesc(N, H, W, Cin, cout, kh, kw, sh, sw, ph, pw, OH, OW, a_op, epilogue, out_format,
-                 w_packed.shape[1], w_packed.shape[0])
+                 w_packed.shape[1], w_packed.shape[0], *sc)
     if out is None:
         if out_format == OUT_BF16_NHWC:
             out = torch.empty((N, OH, OW, cout), dtype=torch.bfloat16, device=x_nhwc.device)
@@ -288,6 +341,25 @@ def eb_forward(y, params, mode, noise=None, lik_bound=1e-9, want_y_hat=True, wan
     _check(lib().sc2_eb_forward(_ptr(y), _ptr(noise), _ptr(params), N, C, HW, int(mode), float(lik_bound),
                                 _ptr(y_hat), _ptr(nhwc), _ptr(lik), _ptr(bits), nb, _stream()), 'eb_forward')
     return y_hat, nhwc, lik, bits
+
+
+def eb_backward(y, params, mode, noise, g_yhat, g_lik, lik_bound=1e-9):
+    """Returns (g_y f32 like y, g_params f32 [C, 64]) -- the per-workgroup partial rows are summed here."""
+    _dev(y, 'y')
+    N, C = y.shape[0], y.shape[1]
+    HW = y.numel() // (N * C)
+    for t in (noise, g_yhat, g_lik):
+        if t is not None:
+            _dev(t, 'grad/noise')
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == y.numel()
+    g_y = torch.empty_like(y)
+    n_partial = lib().sc2_eb_bits_partial_len(N, C, HW)
+    part = torch.empty((n_partial, EB_PARAM_STRIDE), dtype=torch.float32, device=y.device)
+    _check(lib().sc2_eb_backward(_ptr(y), _ptr(noise), _ptr(params), N, C, HW, int(mode), float(lik_bound),
+                                 _ptr(g_yhat), _ptr(g_lik), _ptr(g_y), _ptr(part), n_partial, _stream()),
+           'eb_backward')
+    g_params = part.view(N, C, n_partial // (N * C), EB_PARAM_STRIDE).sum(dim=(0, 2))
+    return g_y, g_params
 
 
 def eb_symbols(y, medians):

@@ -366,3 +366,32 @@ def test_rans_overflow_flag_and_large_table(S, dev):
     buf, off, nb, st = S.hip.rans_encode_batch(torch.from_numpy(sym).to(dev), cdfs, d_sizes, d_offs,
                                                indexes=torch.from_numpy(idx).to(dev), out_stride=64)
     assert int(st.min()) == 1
+
+
+DGRAD_CASES = [
+    # (Cin, Cout, k, stride, pad, H, W, N)
+    (96, 48, 5, 2, 2, 20, 24, 2),      # enc.conv2 geometry: 4 stride-parity classes (3x3, 3x2, 2x3, 2x2 sub-filters)
+    (48, 24, 2, 1, 0, 9, 11, 3),
+    (24, 512, 2, 1, 1, 7, 9, 2),
+    (512, 256, 2, 1, 0, 8, 8, 2),
+    (256, 256, 2, 1, 1, 7, 7, 3),
+    (64, 64, 3, 2, 1, 15, 15, 2),      # odd input size with stride 2
+    (128, 32, 1, 2, 0, 9, 9, 2),       # 1x1 stride 2: three of four parity classes receive no tap
+    (16, 40, 3, 1, 1, 13, 9, 2),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,H,W,N', DGRAD_CASES)
+def test_conv_dgrad(S, dev, cin, cout, k, stride, pad, H, W, N):
+    """Data gradient on the forward implicit-GEMM kernel (flipped sub-filters per stride-parity class)."""
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    gy = torch.randn(N, cout, OH, OW, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cout * k * k) ** 0.5
+    ref = torch.nn.grad.conv2d_input((N, cin, H, W), bf16_round(w), bf16_round(gy), stride=stride, padding=pad)
+    gy_nhwc = S.hip.nchw_f32_to_nhwc_bf16(gy.to(dev))
+    gx = S.hip.conv2d_dgrad(gy_nhwc, w.to(dev), stride, pad, (H, W), out_dtype=torch.float32)
+    assert gx.shape == (N, H, W, cin)
+    torch.testing.assert_close(gx.permute(0, 3, 1, 2).cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+    gxb = S.hip.conv2d_dgrad(gy_nhwc, w.to(dev), stride, pad, (H, W))
+    assert_close_bf16(gxb.permute(0, 3, 1, 2), ref, 'dgrad bf16')
