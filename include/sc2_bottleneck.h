@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 8
+#define SC2_ABI_VERSION 10
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -105,6 +105,22 @@ int sc2_conv_weight_pitch(int K);
  * y      : per out_format. */
 int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
                    const void *ep_x, const float *ep_beta, void *stream);
+
+/* Weight gradient of sc2_conv2d_fwd: dw[co][(kh*KW+kw)*Cin+ci] = sum over output pixels of gy * im2col(x).
+ * Replaces the weight half of nn.Conv2d's backward (reached through loss.backward(), image_classification.py:79).
+ *   x  : bf16 NHWC [N,H,W,Cin]      gy : bf16 NHWC [N,OH,OW,Cout]
+ *   dw : f32 [Cout][KH*KW*Cin], overwritten (zeroed on the stream, then accumulated with f32 atomics)
+ * Uses N,H,W,Cin,Cout,KH,KW,stride,pad,OH,OW and a_op (SC2_AOP_ABS: |x| operand, for GDN1's gamma) of the
+ * descriptor; the other fields are ignored. */
+int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const void *gy, float *dw, void *stream);
+
+/* Element-wise halves of the GDN1 backward (norm = beta + gamma|x|, y = x/norm or x*norm; all tensors bf16 NHWC
+ * [M pixels][C], C % 8 == 0).  The channel-mixing halves are sc2_conv2d_fwd (gamma^T d_norm) and sc2_conv2d_wgrad.
+ *   pre : d_norm, dx_direct out; d_beta f32[C] out (zeroed on the stream, then atomically accumulated)
+ *   post: dx = dx_direct + sign(x) * t */
+int sc2_gdn_bwd_pre(const void *gy, const void *x, const void *norm, long long M, int C, int inverse, void *d_norm,
+                    void *dx_direct, float *d_beta, void *stream);
+int sc2_gdn_bwd_post(const void *dx_direct, const void *x, const void *t, long long n_elements, void *dx, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Entropy bottleneck (factorised prior), filters fixed to (3,3,3,3) as sc2bench uses them     */

@@ -1,17 +1,17 @@
 """Training path: autograd wiring of the HIP forward kernels.
 
-FORWARD runs on the hand-written kernels (same launches as inference).  BACKWARD in this round is INTERIM:
-gradients are computed on the device with PyTorch-ROCm ops (MIOpen `convolution_backward` for the convs,
-re-evaluation of the GDN / entropy-bottleneck formulas under torch autograd for the rest).  Hand-written
-dgrad / wgrad / GDN-bwd / bottleneck-bwd kernels are the next row of DESIGN.md section 8; nothing here touches the
-CPU or the oracle.
+FORWARD and BACKWARD both run on the hand-written kernels: data gradients of the convs on the forward
+implicit-GEMM kernel (flipped sub-filters per stride-parity class, `hip.conv2d_dgrad`), weight gradients on
+`conv_wgrad.hip` (transposing LDS reads), GDN1 backward as two element-wise kernels around a gamma^T GEMM and a
+wgrad, the entropy bottleneck on `eb_backward_kernel`.  torch autograd only stitches the pieces together and
+differentiates the parameter-sized reparametrisations (beta/gamma lower bounds, softplus/tanh of the 58
+bottleneck parameters per channel).  The frozen ResNet head's input gradient still goes through torch modules.
 
 Reference semantics reproduced: `_forward2train` (sc2bench/models/layer.py:529-533) before `update()`, and the
 round + detach path after it (layer.py:543-549); `LowerBound` gradient rule of CompressAI (gradient passes where
 x >= bound or where it pushes x up).
 """
 import torch
-import torch.nn.functional as F
 
 from . import hip
 
@@ -54,28 +54,29 @@ class _ConvFn(torch.autograd.Function):
         x_nhwc, weight = ctx.saved_tensors
         stride, pad, out_format, w_view = ctx.cfg
         if out_format == hip.OUT_BF16_NHWC:
-            g = _cl(gy.contiguous())
+            g = gy.contiguous()
         elif out_format == hip.OUT_F32_NCHW:
-            g = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            g = hip.nchw_f32_to_nhwc_bf16(gy.float().contiguous())
         else:
-            g = _cl(gy.to(torch.bfloat16).contiguous())
-        # the kernel may see the input through a different (Cin, KW) view than the parameter (first encoder conv)
-        x_log, w_log = w_view(x_nhwc, weight) if w_view is not None else (_cl(x_nhwc), weight)
-        sh, sw = (stride, stride) if isinstance(stride, int) else stride
-        ph, pw = (pad, pad) if isinstance(pad, int) else pad
-        if w_view is not None:
-            sh, sw, ph, pw = w_view.stride + w_view.pad
+            g = gy.to(torch.bfloat16).contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gi, gw, _ = torch.ops.aten.convolution_backward(
-            g, x_log, w_log.to(torch.bfloat16), None, (sh, sw), (ph, pw), (1, 1), False, (0, 0), 1,
-            (need_x, need_w, False))
-        if need_w:
-            gw = gw.float()
-            if w_view is not None:
-                gw = gw[:, :weight.shape[1]]
-        if need_x:
-            gi = gi.permute(0, 2, 3, 1).contiguous()
-        return gi if need_x else None, gw if need_w else None, None, None, None, None, None, None, None, None
+        gi = gw = None
+        if w_view is not None:
+            # first encoder conv on its pixel-pair view: K is ordered (kh, pair tap, pixel-in-pair * 4 + channel)
+            if need_w:
+                raw = hip.conv2d_wgrad(x_nhwc, g, 5, 3, (2, 1), (2, 1))            # [Cout, 8, 5, 3]
+                cout = raw.shape[0]
+                full = raw.permute(0, 2, 3, 1).reshape(cout, 5, 3, 2, 4)            # (kh, t, dw, c)
+                gw = full.reshape(cout, 5, 6, 4)[:, :, :5, :weight.shape[1]].permute(0, 3, 1, 2).contiguous()
+            if need_x:
+                raise hip.Sc2Error('the pixel-pair first conv has no data gradient (its input is the image)')
+        else:
+            kh, kw = weight.shape[2], weight.shape[3]
+            if need_w:
+                gw = hip.conv2d_wgrad(x_nhwc, g, kh, kw, stride, pad).contiguous()
+            if need_x:
+                gi = hip.conv2d_dgrad(g, weight, stride, pad, (x_nhwc.shape[1], x_nhwc.shape[2]))
+        return gi, gw, None, None, None, None, None, None, None, None
 
 
 class _PairView(object):
@@ -110,40 +111,8 @@ class _GdnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x_nhwc, beta, gamma = ctx.saved_tensors
-        C = beta.numel()
-        with torch.enable_grad():
-            x = _cl(x_nhwc).detach().requires_grad_(True)
-            b = beta.detach().to(torch.bfloat16).requires_grad_(True)
-            g = gamma.detach().to(torch.bfloat16).requires_grad_(True)
-            norm = F.conv2d(torch.abs(x), g.reshape(C, C, 1, 1), b)
-            y = x * norm if ctx.inverse else x / norm
-            gx, gb, gg = torch.autograd.grad(y, (x, b, g), _cl(gy.contiguous()))
-        return gx.permute(0, 2, 3, 1).contiguous(), gb.float(), gg.float(), None, None
-
-
-def _eb_logits(v, P):
-    """Cumulative logits from the packed effective-parameter block P [C,64]; v: [C,1,T]."""
-    C = P.shape[0]
-    h = P[:, 0:3].reshape(C, 3, 1) * v + P[:, 3:6].reshape(C, 3, 1)
-    h = h + P[:, 6:9].reshape(C, 3, 1) * torch.tanh(h)
-    for layer in range(3):
-        o = 9 + 15 * layer
-        h = torch.matmul(P[:, o:o + 9].reshape(C, 3, 3), h) + P[:, o + 9:o + 12].reshape(C, 3, 1)
-        h = h + P[:, o + 12:o + 15].reshape(C, 3, 1) * torch.tanh(h)
-    return torch.matmul(P[:, 54:57].reshape(C, 1, 3), h) + P[:, 57:58].reshape(C, 1, 1)
-
-
-class _LowerBoundFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, bound):
-        ctx.save_for_backward(x)
-        ctx.bound = bound
-        return torch.clamp(x, min=bound)
-
-    @staticmethod
-    def backward(ctx, g):
-        x, = ctx.saved_tensors
-        return ((x >= ctx.bound) | (g < 0)) * g, None
+        dx, d_beta, d_gamma = hip.gdn1_backward(gy, x_nhwc, beta, gamma, ctx.inverse)
+        return dx, d_beta, d_gamma, None, None
 
 
 class _EbFn(torch.autograd.Function):

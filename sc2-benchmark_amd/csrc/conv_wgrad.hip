@@ -1,0 +1,231 @@
+// Weight gradient of the implicit-GEMM convolution for gfx950:
+//
+//   dW[co][k] = sum_m gY[m][co] * A[m][k]      m = (img, oh, ow),  k = (kh, kw, ci),  A = im2col(x)
+//
+// i.e. the training-time counterpart of nn.Conv2d's backward w.r.t. its weight (the reference reaches it through
+// loss.backward() in script/task/image_classification.py:79 for the convs of sc2bench/models/layer.py:475-493, and
+// for GDN1's 1x1 gamma).  It is a GEMM whose REDUCTION index is the pixel index m, while both operands are stored
+// pixel-major (NHWC rows).  Instead of transposing on the way into LDS, the slabs keep their natural [m][channel]
+// layout (so they are filled by plain direct-to-LDS loads) and the MFMA fragments are read with the transposing LDS
+// read ds_read_b64_tr_b16 (4 rows x 16 columns -> column-major), two reads per 16x16x32 operand fragment.
+//
+// Tile: 128 output channels x 128 k-columns per workgroup (4 waves, 64 x 64 each), reduction in slabs of 32 pixels
+// through a 3-deep LDS ring (same counted-vmcnt / one-barrier-per-slab pipeline as conv_igemm.hip).  The pixel range
+// is split over workgroups; partial sums are combined with f32 atomic adds into the (small, pre-zeroed) dW.
+// Bank conflicts: a fragment read touches 8 different pixel rows at one 32-byte column offset; the 16-byte chunk
+// index is XORed with f(row) = 2*((row & 3) + 4*((row >> 3) & 1)) -- applied to the SOURCE address of the
+// direct-to-LDS load and again to the read address -- so the 8 rows land on 8 different 32-byte slots.
+#include "sc2_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+__device__ uint4 g_wzero16;
+
+struct WgradArgs {
+    const uint16_t *__restrict__ x;
+    const uint16_t *__restrict__ gy;
+    float *__restrict__ dw;
+    int N, H, W, Cin, Cout;
+    int KH, KW, SH, SW, PH, PW;
+    int OH, OW, OHW, M, K;
+    int rows_per_block;   // pixels reduced by one workgroup (multiple of 32)
+    int x_abs;            // use |x| as the im2col operand (d gamma of GDN1)
+    int n_ktiles, n_ctiles;
+};
+
+constexpr int WG_TILE = 128;              // channels / k-columns per tile
+constexpr int WG_ROWB = WG_TILE * 2;      // bytes per pixel row of a slab image
+constexpr int WG_SLAB = 32;               // pixels per slab
+constexpr int WG_IMG = WG_SLAB * WG_ROWB; // 8 KB
+constexpr int WG_STAGES = 3;
+
+__device__ __forceinline__ int wg_swz(int row) { return 2 * ((row & 3) + 4 * ((row >> 3) & 1)); }
+
+__device__ __forceinline__ uint2 lds_read_tr(uint32_t addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int bid = blockIdx.x;
+    const int tiles = p.n_ktiles * p.n_ctiles;
+    const int chunk = bid / tiles;
+    const int t = bid - chunk * tiles;
+    const int ctile = t / p.n_ktiles, ktile = t - ctile * p.n_ktiles;
+    const int co0 = ctile * WG_TILE, k0 = ktile * WG_TILE;
+    const int m_begin = chunk * p.rows_per_block;
+    const int m_end = min(p.M, m_begin + p.rows_per_block);
+    const int n_slabs = (m_end - m_begin + WG_SLAB - 1) / WG_SLAB;
+
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_wzero16);
+    const long long zoff_x = zero - p.x, zoff_g = zero - p.gy;
+
+    // direct-to-LDS assignment: wave-instruction q = j*4 + wave covers slab rows [4q, 4q+4); lane l -> row 4q + (l >> 4),
+    // stored chunk l & 15, which holds logical chunk (l & 15) ^ swz(row)
+    int row_j[2], gco_j[2], kh_j[2], kw_j[2], ci_j[2];
+    bool gok_j[2], kok_j[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (j * 4 + wave) * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ wg_swz(row);
+        row_j[j] = row;
+        gco_j[j] = co0 + 8 * c;
+        gok_j[j] = gco_j[j] < p.Cout;
+        const int k = k0 + 8 * c;
+        kok_j[j] = k < p.K;
+        const int kk = kok_j[j] ? k : 0;
+        const int tap = kk / p.Cin;
+        ci_j[j] = kk - tap * p.Cin;
+        kh_j[j] = tap / p.KW;
+        kw_j[j] = tap - kh_j[j] * p.KW;
+    }
+
+    auto issue_slab = [&](int s, int buf) {
+        unsigned char *Gi = smem + buf * (2 * WG_IMG);
+        unsigned char *Ai = Gi + WG_IMG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m_begin + s * WG_SLAB + row_j[j];
+            const bool mok = (s < n_slabs) & (m < m_end);
+            const int mm = mok ? m : 0;
+            // dY operand
+            const bool g_ok = mok & gok_j[j];
+            const long long goff = g_ok ? (long long)mm * p.Cout + gco_j[j] : zoff_g;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.gy + goff), (lds_ptr_t)(Gi + (j * 4 + wave) * 1024), 16, 0, 0);
+            // im2col operand
+            const int img = mm / p.OHW;
+            const int rem = mm - img * p.OHW;
+            const int oh = rem / p.OW;
+            const int ow = rem - oh * p.OW;
+            const int ih = oh * p.SH - p.PH + kh_j[j], iw = ow * p.SW - p.PW + kw_j[j];
+            const bool a_ok = mok & kok_j[j] & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
+            const long long aoff = a_ok ? ((long long)(img * p.H + ih) * p.W + iw) * p.Cin + ci_j[j] : zoff_x;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.x + aoff), (lds_ptr_t)(Ai + (j * 4 + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // transposing fragment reads: lane i16 of a 16-lane group addresses slab row 8*fq + (i16 >> 2) (+4 for the second
+    // half of the 8-deep k group) at columns 4*(i16 & 3) .. +3 of the 16-column tile and receives column i16
+    const int i16 = lane & 15, fq = lane >> 4;
+    const int rrow = 8 * fq + (i16 >> 2);
+    uint32_t g_rd[4][2], a_rd[4][2];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = rrow + 4 * h;
+            const int gc = wm * 64 + tt * 16 + 4 * (i16 & 3);   // column inside the 128-wide image
+            const int ac = wn * 64 + tt * 16 + 4 * (i16 & 3);
+            g_rd[tt][h] = (uint32_t)(r * WG_ROWB + (((gc >> 3) ^ wg_swz(r)) << 4) + ((gc >> 2) & 1) * 8);
+            a_rd[tt][h] = (uint32_t)(WG_IMG + r * WG_ROWB + (((ac >> 3) ^ wg_swz(r)) << 4) + ((ac >> 2) & 1) * 8);
+        }
+
+    const uint32_t xmask = p.x_abs ? 0x7FFF7FFFu : 0xFFFFFFFFu;
+    constexpr int S = WG_STAGES, L = 4;
+#pragma unroll
+    for (int st = 0; st < S - 1; ++st) issue_slab(st, st);
+
+    for (int s = 0; s < n_slabs; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const uint32_t sb = lds_base + (uint32_t)((s % S) * (2 * WG_IMG));
+        uint2 gv[4][2], av[4][2];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                gv[tt][h] = lds_read_tr(sb + g_rd[tt][h]);
+                av[tt][h] = lds_read_tr(sb + a_rd[tt][h]);
+            }
+        issue_slab(s + S - 1, (s + S - 1) % S);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8_t gf[4], af[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            gf[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(gv[tt][0].x, gv[tt][0].y, gv[tt][1].x, gv[tt][1].y));
+            af[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(av[tt][0].x & xmask, av[tt][0].y & xmask, av[tt][1].x & xmask,
+                                                             av[tt][1].y & xmask));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], af[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // combine the pixel-range partial sums: f32 atomic adds (dW is small; arrival order varies run to run)
+    const int frow = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + wm * 64 + i * 16 + fq * 4 + e;
+                const int k = k0 + wn * 64 + j * 16 + frow;
+                if (co < p.Cout && k < p.K) atomicAdd(p.dw + (long long)co * p.K + k, acc[i][j][e]);
+            }
+}
+
+}  // namespace
+
+extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const void *gy, float *dw, void *stream) {
+    SC2_REQUIRE(d && x && gy && dw, SC2_ERR_INVALID_ARG, "conv2d_wgrad: null argument");
+    SC2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->Cin % 8 == 0 && d->Cout % 8 == 0,
+                SC2_ERR_INVALID_ARG, "conv2d_wgrad: bad dims (Cin %d, Cout %d must be multiples of 8)", d->Cin, d->Cout);
+    SC2_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_h >= 0 && d->pad_w >= 0,
+                SC2_ERR_INVALID_ARG, "conv2d_wgrad: bad filter geometry");
+    const int OH = (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1;
+    const int OW = (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1;
+    SC2_REQUIRE(OH == d->OH && OW == d->OW && OH > 0 && OW > 0, SC2_ERR_INVALID_ARG,
+                "conv2d_wgrad: output size %dx%d does not match geometry (%dx%d)", d->OH, d->OW, OH, OW);
+    const long long M = (long long)d->N * OH * OW;
+    SC2_REQUIRE(M < 0x7FFFFFFFLL && (long long)d->N * d->H < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED,
+                "conv2d_wgrad: problem too large");
+    WgradArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.gy = static_cast<const uint16_t *>(gy);
+    a.dw = dw;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.SH = d->stride_h; a.SW = d->stride_w; a.PH = d->pad_h; a.PW = d->pad_w;
+    a.OH = OH; a.OW = OW; a.OHW = OH * OW; a.M = (int)M; a.K = d->KH * d->KW * d->Cin;
+    a.x_abs = d->a_op == SC2_AOP_ABS;
+    a.n_ktiles = (a.K + WG_TILE - 1) / WG_TILE;
+    a.n_ctiles = (a.Cout + WG_TILE - 1) / WG_TILE;
+    // enough pixel chunks to fill the chip several times over, at least 8 slabs each
+    const long long tiles = (long long)a.n_ktiles * a.n_ctiles;
+    long long chunks = (4096 + tiles - 1) / tiles;
+    long long rows = (M + chunks - 1) / chunks;
+    rows = (rows + WG_SLAB - 1) / WG_SLAB * WG_SLAB;
+    if (rows < 8 * WG_SLAB) rows = 8 * WG_SLAB;
+    chunks = (M + rows - 1) / rows;
+    a.rows_per_block = (int)rows;
+    const long long grid = tiles * chunks;
+    SC2_REQUIRE(grid > 0 && grid < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv2d_wgrad: grid out of range");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)a.Cout * a.K * sizeof(float), s);
+    SC2_REQUIRE(e == hipSuccess, SC2_ERR_LAUNCH, "conv2d_wgrad: memset failed: %s", hipGetErrorString(e));
+    const size_t lds = (size_t)WG_STAGES * 2 * WG_IMG;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}

@@ -24,7 +24,7 @@ EB_PARAM_STRIDE = 64
 ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
-    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv2d_fwd',
+    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv2d_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
@@ -61,6 +61,9 @@ def lib():
     L.sc2_conv_weight_rows.argtypes = [i32]
     L.sc2_conv_weight_pitch.argtypes = [i32]
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
+    L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
+    L.sc2_gdn_bwd_pre.argtypes = [vp, vp, vp, ctypes.c_longlong, i32, i32, vp, vp, vp, vp]
+    L.sc2_gdn_bwd_post.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
     L.sc2_eb_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
     L.sc2_eb_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
     L.sc2_eb_bits_partial_len.argtypes = [i32, i32, i32]
@@ -224,6 +227,51 @@ def pack_conv0_weight_pairs(w):
     packed = torch.zeros((rows, pitch), dtype=torch.bfloat16, device=w.device)
     packed[:cout, :k_total] = wp.reshape(cout, k_total).to(torch.bfloat16)
     return packed
+
+
+def gdn1_backward(gy_nhwc, x_nhwc, beta, gamma, inverse):
+    """Backward of GDN1 / inverse GDN1 on the HIP kernels: returns (dx bf16 NHWC, d_beta f32 [C], d_gamma f32 [C,C]).
+
+    beta [C] / gamma [C,C] are the effective (reparametrised) f32 tensors."""
+    C = beta.numel()
+    M = x_nhwc.numel() // C
+    gy_nhwc = gy_nhwc.contiguous()
+    beta = beta.detach().float().contiguous()
+    norm = conv2d_fwd(x_nhwc, pack_conv_weight(gamma.detach().reshape(C, C, 1, 1)), C, 1, 1, 1, 0, a_op=AOP_ABS,
+                      epilogue=EPI_BIAS, ep_beta=beta, tag='gdn.bwd.norm')
+    d_norm = torch.empty_like(x_nhwc)
+    dxd = torch.empty_like(x_nhwc)
+    d_beta = torch.empty((C,), dtype=torch.float32, device=x_nhwc.device)
+    _check(lib().sc2_gdn_bwd_pre(_ptr(gy_nhwc), _ptr(x_nhwc), _ptr(norm), M, C, 1 if inverse else 0, _ptr(d_norm),
+                                 _ptr(dxd), _ptr(d_beta), _stream()), 'gdn_bwd_pre')
+    t = conv2d_fwd(d_norm, pack_conv_weight(gamma.detach().t().reshape(C, C, 1, 1)), C, 1, 1, 1, 0, tag='gdn.bwd.gT')
+    dx = torch.empty_like(x_nhwc)
+    _check(lib().sc2_gdn_bwd_post(_ptr(dxd), _ptr(x_nhwc), _ptr(t), x_nhwc.numel(), _ptr(dx), _stream()),
+           'gdn_bwd_post')
+    d_gamma = conv2d_wgrad(x_nhwc, d_norm, 1, 1, 1, 0, x_abs=True).reshape(C, C)
+    return dx, d_beta, d_gamma
+
+
+def conv2d_wgrad(x_nhwc, gy_nhwc, kh, kw, stride, pad, x_abs=False):
+    """Weight gradient: x bf16 [N,H,W,Cin], gy bf16 [N,OH,OW,Cout] -> f32 [Cout, Cin, KH, KW]."""
+    _dev(x_nhwc, 'x')
+    _dev(gy_nhwc, 'gy')
+    assert x_nhwc.dtype == torch.bfloat16 and gy_nhwc.dtype == torch.bfloat16
+    assert x_nhwc.is_contiguous() and gy_nhwc.is_contiguous()
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    N, H, W, Cin = x_nhwc.shape
+    OH = (H + 2 * ph - kh) // sh + 1
+    OW = (W + 2 * pw - kw) // sw + 1
+    cout = gy_nhwc.shape[3]
+    assert tuple(gy_nhwc.shape) == (N, OH, OW, cout)
+    d = ConvDesc(N, H, W, Cin, cout, kh, kw, sh, sw, ph, pw, OH, OW, AOP_ABS if x_abs else AOP_NONE, 0, 0, 0, 0, 0, 0,
+                 0, 0, 0, 0)
+    dw = torch.empty((cout, kh * kw * Cin), dtype=torch.float32, device=x_nhwc.device)
+    with _timed('wgrad'):
+        _check(lib().sc2_conv2d_wgrad(ctypes.byref(d), _ptr(x_nhwc), _ptr(gy_nhwc), _ptr(dw), _stream()),
+               'conv2d_wgrad')
+    return dw.view(cout, kh, kw, Cin).permute(0, 3, 1, 2)
 
 
 def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16):

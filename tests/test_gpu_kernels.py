@@ -395,3 +395,43 @@ def test_conv_dgrad(S, dev, cin, cout, k, stride, pad, H, W, N):
     torch.testing.assert_close(gx.permute(0, 3, 1, 2).cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
     gxb = S.hip.conv2d_dgrad(gy_nhwc, w.to(dev), stride, pad, (H, W))
     assert_close_bf16(gxb.permute(0, 3, 1, 2), ref, 'dgrad bf16')
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,H,W,N', DGRAD_CASES + [(8, 96, 3, 1, 1, 30, 30, 4), (256, 136, 1, 1, 0, 40, 40, 3)])
+def test_conv_wgrad(S, dev, cin, cout, k, stride, pad, H, W, N):
+    """Weight gradient kernel (transposing LDS fragment reads, f32 atomic combine of pixel-range partials)."""
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = torch.randn(N, cin, H, W, generator=g)
+    gy = torch.randn(N, cout, OH, OW, generator=g)
+    ref = torch.nn.grad.conv2d_weight(bf16_round(x), (cout, cin, k, k), bf16_round(gy), stride=stride, padding=pad)
+    dw = S.hip.conv2d_wgrad(S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)), S.hip.nchw_f32_to_nhwc_bf16(gy.to(dev)), k, k,
+                            stride, pad)
+    assert dw.shape == (cout, cin, k, k)
+    torch.testing.assert_close(dw.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize('C,inverse', [(96, False), (48, False), (256, True), (40, True)])
+def test_gdn1_backward(S, R, dev, C, inverse):
+    """GDN1 backward on the HIP kernels (element-wise pre/post + gamma^T GEMM + wgrad) vs the oracle's autograd."""
+    torch.manual_seed(C + 1)
+    ref_m = R.GDN1(C, inverse=inverse)
+    with torch.no_grad():
+        ref_m.gamma.add_(0.05 * torch.rand(C, C) / C ** 0.5)
+        ref_m.beta.add_(0.1 * torch.rand(C))
+    x = bf16_round(torch.randn(2, C, 11, 9))
+    gy = bf16_round(torch.randn(2, C, 11, 9))
+    beta = ref_m.beta_reparam(ref_m.beta).detach().requires_grad_(True)
+    gamma = bf16_round(ref_m.gamma_reparam(ref_m.gamma).detach()).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    norm = F.conv2d(xr.abs(), gamma.reshape(C, C, 1, 1), beta)
+    y = xr * norm if inverse else xr / norm
+    y.backward(gy)
+    dx, d_beta, d_gamma = S.hip.gdn1_backward(S.hip.nchw_f32_to_nhwc_bf16(gy.to(dev)), S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)),
+                                              beta.detach().to(dev), gamma.detach().to(dev), inverse)
+
+    def rel(a, b):
+        return ((a.float().cpu() - b).norm() / (b.norm() + 1e-20)).item()
+    assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 1.5e-2      # norm, d_norm and t pass through bf16
+    assert rel(d_beta, beta.grad) < 1.5e-2
+    assert rel(d_gamma, gamma.grad) < 1.5e-2
