@@ -1,0 +1,176 @@
+"""Loads the reference's experiment YAML files unchanged.
+
+The reference's `configs/**.yaml` use four torchdistill YAML tags: `!join`, `!import_get`,
+`!import_call`, `!getattr`, evaluated eagerly at load time (script/task/image_classification.py:207), and dotted keys
+into packages that are not installed here (`torchvision`, `torchdistill`) or that this package replaces
+(`sc2bench`).  This loader resolves
+
+* `sc2bench.*`      -> the registries of this package (same keys: layers, backbones, losses, analyzers),
+* `torchvision.datasets.*` -> `SyntheticImageFolder` (no dataset directory is needed, nothing is downloaded),
+* `torchvision.models.resnet.*Weights` -> an inert enum (pretrained weights need the network),
+* `torchvision.transforms.*`, `torchdistill.*`, anything else that cannot be imported -> a recording placeholder,
+
+so every config parses, and `models.student_model` builds the HIP-backed model from the very same block.
+"""
+import importlib
+import os
+
+import torch
+import yaml
+
+
+class Placeholder(object):
+    """Stands in for an object of a package that is not available offline; records how it was built."""
+
+    def __init__(self, key, args=(), kwargs=None):
+        self.key = key
+        self.args = tuple(args)
+        self.kwargs = dict(kwargs or {})
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return Placeholder('{}.{}'.format(self.key, name))
+
+    def __call__(self, *args, **kwargs):
+        return Placeholder(self.key, args, kwargs)
+
+    def __repr__(self):
+        return 'Placeholder({})'.format(self.key)
+
+
+class SyntheticImageFolder(torch.utils.data.Dataset):
+    """`torchvision.datasets.ImageFolder(root, transform)` stand-in: seeded random images, ImageNet-normalised."""
+
+    def __init__(self, root=None, transform=None, num_samples=1024, num_classes=1000, image_size=224, **kwargs):
+        self.root = root
+        self.transform = transform
+        self.num_samples = num_samples
+        self.num_classes = num_classes
+        self.image_size = image_size
+        self.mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+        self.std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+
+    def __len__(self):
+        return self.num_samples
+
+    def __getitem__(self, index):
+        g = torch.Generator().manual_seed(index)
+        x = torch.rand(3, self.image_size, self.image_size, generator=g)
+        return (x - self.mean) / self.std, int(torch.randint(0, self.num_classes, (1,), generator=g))
+
+
+class _WeightsEnum(object):
+    """Inert stand-in for torchvision's `ResNet50_Weights` etc. (`!getattr [*, 'IMAGENET1K_V1']` must resolve)."""
+
+    def __init__(self, name):
+        self._name = name
+
+    def __getattr__(self, item):
+        if item.startswith('__'):
+            raise AttributeError(item)
+        return '{}.{}'.format(self._name, item)
+
+
+def _sc2bench_attr(key):
+    import sc2bench_amd as S
+    from . import loss as loss_mod
+    name = key.split('.')[-1]
+    for registry in (S.LAYER_CLASS_DICT, S.LAYER_FUNC_DICT, S.BACKBONE_CLASS_DICT, S.BACKBONE_FUNC_DICT,
+                     S.ANALYZER_CLASS_DICT, loss_mod.MIDDLE_LEVEL_LOSS_DICT):
+        if name in registry:
+            return registry[name]
+    if hasattr(S, name):
+        return getattr(S, name)
+    return Placeholder(key)
+
+
+def resolve(key):
+    """Dotted name -> object, with the substitutions listed in the module docstring."""
+    if key.startswith('sc2bench.'):
+        return _sc2bench_attr(key)
+    if key.startswith('torchvision.datasets.'):
+        return SyntheticImageFolder
+    if key.startswith('torchvision.models.') and key.endswith('_Weights'):
+        return _WeightsEnum(key)
+    module_name, _, attr = key.rpartition('.')
+    try:
+        return getattr(importlib.import_module(module_name), attr)
+    except Exception:
+        return Placeholder(key)
+
+
+class _Loader(yaml.SafeLoader):
+    pass
+
+
+def _join(loader, node):
+    return ''.join(str(v) for v in loader.construct_sequence(node, deep=True))
+
+
+def _import_get(loader, node):
+    entry = loader.construct_mapping(node, deep=True)
+    return resolve(entry['key'])
+
+
+def _import_call(loader, node):
+    entry = loader.construct_mapping(node, deep=True)
+    init = entry.get('init') or dict()
+    args = init.get('args') or list()
+    kwargs = init.get('kwargs') or dict()
+    target = resolve(entry['key'])
+    return target(*args, **kwargs)
+
+
+def _getattr(loader, node):
+    obj, name = loader.construct_sequence(node, deep=True)
+    return getattr(obj, name)
+
+
+_Loader.add_constructor('!join', _join)
+_Loader.add_constructor('!import_get', _import_get)
+_Loader.add_constructor('!import_call', _import_call)
+_Loader.add_constructor('!getattr', _getattr)
+
+
+def load_yaml_file(path):
+    """torchdistill.common.yaml_util.load_yaml_file: the config dict with every tag evaluated."""
+    with open(os.path.expanduser(path)) as f:
+        return yaml.load(f, Loader=_Loader)
+
+
+def overwrite_config(org_config, sub_config):
+    """`--json` deep overwrite (sc2bench/common/config_util.py:1-17)."""
+    for key, value in sub_config.items():
+        if key in org_config and isinstance(value, dict) and isinstance(org_config[key], dict):
+            overwrite_config(org_config[key], value)
+        else:
+            org_config[key] = value
+
+
+def import_dependencies(dependencies):
+    """`dependencies: [{name: sc2bench.models}, ...]` -- registration by import; sc2bench names map to this package."""
+    for dep in dependencies or list():
+        name = dep['name'] if isinstance(dep, dict) else dep
+        if name.startswith('sc2bench'):
+            importlib.import_module('sc2bench_amd')
+        else:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                pass
+
+
+def build_model(model_config):
+    """models.{teacher_model, student_model, model} block -> nn.Module (torchvision / sc2bench registries)."""
+    import sc2bench_amd as S
+    from .resnet import RESNET_FUNC_DICT
+    key = model_config['key']
+    kwargs = dict(model_config.get('kwargs') or {})
+    if key in S.MODEL_DICT:
+        kwargs.pop('weights', None)
+        return S.MODEL_DICT[key](**kwargs)
+    if key in RESNET_FUNC_DICT:
+        return RESNET_FUNC_DICT[key](**kwargs)
+    raise KeyError('model key `{}` is not available in this build (have {})'.format(
+        key, sorted(list(S.MODEL_DICT) + list(RESNET_FUNC_DICT))))

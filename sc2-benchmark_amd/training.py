@@ -1,0 +1,229 @@
+"""Training driver for the Entropic-Student recipe, driven by the reference's own YAML `train:` blocks.
+
+The reference hands this to torchdistill's `DistillationBox` (script/task/image_classification.py:153-193; behaviour
+restated in SURVEY.md appendix C).  What the hot path needs from it is small and is reproduced here with the same
+config keys: per-model `sequential` / `frozen_modules` / `forward_hook` / `requires_grad`, the forward-hook IO
+dict, `WeightedSumLoss` over `SimpleLossWrapper(MSELoss | ...)` and mid-level losses (`BppLoss`), optimizer /
+scheduler by key, the separate `aux_loss` backward (image_classification.py:74-77), and -- instead of DDP -- the
+flat-bucket gradient all-reduce of `dataparallel.py`.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .dataparallel import FlatGradAllReducer
+from .loss import MIDDLE_LEVEL_LOSS_DICT
+
+
+def get_module(root, path):
+    """'a.b.0' -> submodule ('.' = the model itself)."""
+    if path in ('.', ''):
+        return root
+    mod = root
+    for part in path.split('.'):
+        mod = mod[int(part)] if isinstance(mod, (nn.Sequential, nn.ModuleList)) and part.isdigit() \
+            else getattr(mod, part)
+    return mod
+
+
+def redesign_model(model, sequential):
+    """`sequential: [names]` -> nn.Sequential over the named children (torchdistill redesign_model); empty -> model."""
+    if not sequential:
+        return model
+    return nn.Sequential(OrderedDict((name.replace('.', '__'), get_module(model, name)) for name in sequential))
+
+
+def freeze(model, frozen_paths):
+    for path in frozen_paths or list():
+        for p in get_module(model, path).parameters():
+            p.requires_grad_(False)
+
+
+class ForwardHookManager(object):
+    """io_dict[module_path] = {'input': ..., 'output': ...}, refilled on every forward, cleared after the loss."""
+
+    def __init__(self, model, hook_config):
+        self.io_dict = dict()
+        self.handles = []
+        paths_in = (hook_config or {}).get('input') or []
+        paths_out = (hook_config or {}).get('output') or []
+        for path in sorted(set(paths_in) | set(paths_out)):
+            module = get_module(model, path)
+            self.handles.append(module.register_forward_hook(self._make(path, path in paths_in, path in paths_out)))
+
+    def _make(self, path, want_in, want_out):
+        def hook(module, inputs, output):
+            entry = self.io_dict.setdefault(path, dict())
+            if want_in:
+                entry['input'] = inputs[0] if len(inputs) == 1 else inputs
+            if want_out:
+                entry['output'] = output
+        return hook
+
+    def pop(self):
+        out, self.io_dict = self.io_dict, dict()
+        return out
+
+    def clear(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+
+class KDLoss(nn.Module):
+    """alpha * CE(student, labels) + (1 - alpha) * T^2 * KL(student / T || teacher / T)  (torchdistill KDLoss)."""
+
+    def __init__(self, student_module_path='.', student_module_io='output', teacher_module_path='.',
+                 teacher_module_io='output', temperature=1.0, alpha=0.5, reduction='batchmean', **kwargs):
+        super().__init__()
+        self.sp, self.sio, self.tp, self.tio = student_module_path, student_module_io, teacher_module_path, \
+            teacher_module_io
+        self.temperature, self.alpha, self.reduction = temperature, alpha, reduction
+
+    def forward(self, student_io_dict, teacher_io_dict, targets=None, *args, **kwargs):
+        s = student_io_dict[self.sp][self.sio].float()
+        t = teacher_io_dict[self.tp][self.tio].float()
+        T = self.temperature
+        soft = nn.functional.kl_div(torch.log_softmax(s / T, dim=1), torch.softmax(t / T, dim=1),
+                                    reduction=self.reduction)
+        if self.alpha is None or self.alpha == 0 or targets is None:
+            return soft
+        hard = nn.functional.cross_entropy(s, targets, reduction='mean' if self.reduction == 'batchmean' else self.reduction)
+        return self.alpha * hard + (1 - self.alpha) * (T ** 2) * soft
+
+
+class SimpleLossWrapper(nn.Module):
+    """low-level criterion(input, target) with both taken from the io dicts."""
+
+    def __init__(self, low_level_loss, input, target, **kwargs):
+        super().__init__()
+        self.low_level_loss = low_level_loss
+        self.input_cfg, self.target_cfg = input, target
+
+    @staticmethod
+    def _extract(cfg, student_io_dict, teacher_io_dict):
+        io = teacher_io_dict if cfg['is_from_teacher'] else student_io_dict
+        return io[cfg['module_path']][cfg['io']]
+
+    def forward(self, student_io_dict, teacher_io_dict, targets=None, *args, **kwargs):
+        x = self._extract(self.input_cfg, student_io_dict, teacher_io_dict)
+        y = self._extract(self.target_cfg, student_io_dict, teacher_io_dict)
+        return self.low_level_loss(x.float(), y.float())
+
+
+LOW_LEVEL_LOSSES = {'MSELoss': nn.MSELoss, 'L1Loss': nn.L1Loss, 'CrossEntropyLoss': nn.CrossEntropyLoss}
+
+
+class WeightedSumLoss(nn.Module):
+    """sum_i weight_i * term_i(student_io_dict, teacher_io_dict, targets)."""
+
+    def __init__(self, sub_terms=None, model_term=None, **kwargs):
+        super().__init__()
+        self.terms = nn.ModuleDict()
+        self.weights = dict()
+        for name, cfg in (sub_terms or {}).items():
+            crit_cfg = cfg['criterion']
+            key, ckw = crit_cfg['key'], dict(crit_cfg.get('kwargs') or {})
+            if 'criterion_wrapper' in cfg:
+                wkw = dict(cfg['criterion_wrapper'].get('kwargs') or {})
+                term = SimpleLossWrapper(LOW_LEVEL_LOSSES[key](**ckw), **wkw)
+            elif key in MIDDLE_LEVEL_LOSS_DICT:
+                term = MIDDLE_LEVEL_LOSS_DICT[key](**ckw)
+            elif key == 'KDLoss':
+                term = KDLoss(**ckw)
+            else:
+                raise KeyError('criterion `{}` is not available'.format(key))
+            self.terms[name] = term
+            self.weights[name] = float(cfg.get('weight', 1.0))
+
+    def forward(self, student_io_dict, teacher_io_dict, targets=None):
+        total = 0
+        for name, term in self.terms.items():
+            total = total + self.weights[name] * term(student_io_dict, teacher_io_dict, targets)
+        return total
+
+
+def build_criterion(cfg):
+    if cfg['key'] != 'WeightedSumLoss':
+        raise KeyError('criterion `{}` is not available'.format(cfg['key']))
+    return WeightedSumLoss(**(cfg.get('kwargs') or {}))
+
+
+class DistillationStage(object):
+    """One `train.stageN` block: teacher (frozen, no grad) + student with hooks, criterion, optimizer.
+
+    forward_process(batch, targets) -> loss ; post_forward_process(loss) -> backward, gradient all-reduce, step.
+    """
+
+    def __init__(self, teacher, student, stage_config, device, lr_factor=1, head_dtype=None):
+        self.device = device
+        t_cfg, s_cfg = stage_config.get('teacher') or {}, stage_config.get('student') or {}
+        self.student_full = student
+        self.aux_module = student.get_aux_module() if hasattr(student, 'get_aux_module') else None
+        freeze(student, s_cfg.get('frozen_modules'))
+        for p in teacher.parameters():
+            p.requires_grad_(False)
+        teacher.eval()
+        if head_dtype is not None:     # bf16 channels_last task-head modules (teacher and the frozen student tail)
+            teacher.to(dtype=head_dtype, memory_format=torch.channels_last)
+            for name in ('layer2', 'layer3', 'layer4', 'avgpool', 'fc'):
+                m = getattr(student, name, None)
+                if m is not None:
+                    m.to(dtype=head_dtype, memory_format=torch.channels_last)
+        self.head_dtype = head_dtype
+        self.teacher = redesign_model(teacher, t_cfg.get('sequential'))
+        self.student = redesign_model(student, s_cfg.get('sequential'))
+        self.t_hooks = ForwardHookManager(self.teacher, t_cfg.get('forward_hook'))
+        self.s_hooks = ForwardHookManager(self.student, s_cfg.get('forward_hook'))
+        self.criterion = build_criterion(stage_config['criterion'])
+        params = [p for p in student.parameters() if p.requires_grad]
+        self.reducer = FlatGradAllReducer(params)
+        o_cfg = stage_config['optimizer']
+        okw = dict(o_cfg.get('kwargs') or {})
+        if 'lr' in okw:
+            okw['lr'] = okw['lr'] * lr_factor
+        self.optimizer = getattr(torch.optim, o_cfg['key'])(params, **okw)
+        s = stage_config.get('scheduler')
+        self.lr_scheduler = getattr(torch.optim.lr_scheduler, s['key'])(self.optimizer, **(s.get('kwargs') or {})) \
+            if s else None
+        self.student_full.train()
+        for path in s_cfg.get('frozen_modules') or list():   # frozen BatchNorm layers keep their statistics
+            get_module(student, path).eval()
+
+    def forward_process(self, batch, targets=None):
+        tb = batch.to(self.head_dtype).contiguous(memory_format=torch.channels_last) if self.head_dtype else batch
+        with torch.no_grad():
+            t_out = self.teacher(tb)
+        t_io = self.t_hooks.pop()
+        t_io['.'] = {'output': t_out}
+        s_out = self._student_forward(batch)
+        s_io = self.s_hooks.pop()
+        s_io['.'] = {'output': s_out}
+        return self.criterion(s_io, t_io, targets)
+
+    def _student_forward(self, batch):
+        if self.head_dtype is None or not isinstance(self.student, nn.Sequential):
+            return self.student(batch)
+        x = batch
+        for i, module in enumerate(self.student):   # the bottleneck speaks f32 NCHW; the frozen tail runs in head_dtype
+            x = module(x)
+            if i == 0:
+                x = x.to(self.head_dtype).contiguous(memory_format=torch.channels_last)
+        return x
+
+    def post_forward_process(self, loss, bottleneck_updated=False):
+        if self.aux_module is not None and not bottleneck_updated:
+            self.aux_module.aux_loss().backward()
+        loss.backward()
+        self.reducer.all_reduce()
+        self.optimizer.step()
+        self.reducer.zero_grad()
+
+    def post_epoch_process(self):
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+
+    def clean_modules(self):
+        self.t_hooks.clear()
+        self.s_hooks.clear()

@@ -107,3 +107,47 @@ def test_frozen_parameters_get_no_gradient(S, R, dev):
     out.sum().backward()
     assert all(p.grad is None for p in m.encoder.parameters())
     assert m.decoder[0].weight.grad is not None
+
+
+STAGE1 = {   # the `train.stage1` block of the reference's Entropic-Student ResNet-50 config (beta = 0.08), as data
+    'teacher': {'sequential': ['conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4'],
+                'forward_hook': {'input': [], 'output': ['layer1', 'layer2', 'layer3', 'layer4']}, 'requires_grad': False},
+    'student': {'sequential': ['bottleneck_layer', 'layer2', 'layer3', 'layer4'],
+                'frozen_modules': ['layer2', 'layer3', 'layer4'],
+                'forward_hook': {'input': [], 'output': ['bottleneck_layer', 'layer2', 'layer3', 'layer4',
+                                                         'bottleneck_layer.entropy_bottleneck']}, 'requires_grad': True},
+    'optimizer': {'key': 'Adam', 'kwargs': {'lr': 0.001}},
+    'scheduler': {'key': 'MultiStepLR', 'kwargs': {'milestones': [5, 8], 'gamma': 0.1}},
+    'criterion': {'key': 'WeightedSumLoss', 'kwargs': {'sub_terms': dict(
+        [('layer{}'.format(i), {'criterion': {'key': 'MSELoss', 'kwargs': {'reduction': 'sum'}},
+                                'criterion_wrapper': {'key': 'SimpleLossWrapper', 'kwargs': {
+                                    'input': {'is_from_teacher': False, 'module_path': 'bottleneck_layer' if i == 1 else 'layer{}'.format(i), 'io': 'output'},
+                                    'target': {'is_from_teacher': True, 'module_path': 'layer{}'.format(i), 'io': 'output'}}},
+                                'weight': 1.0}) for i in (1, 2, 3, 4)] +
+        [('bpp', {'criterion': {'key': 'BppLoss', 'kwargs': {'entropy_module_path': 'bottleneck_layer.entropy_bottleneck',
+                                                             'reduction': 'sum'}}, 'weight': 0.08})])}},
+}
+
+
+def test_stage1_training_steps_reduce_the_loss(S, dev):
+    """Entropic-Student stage 1 driven by the reference's config keys: teacher/student hooks, MSE-sum + 0.08 * bits,
+    aux-loss backward, flat-bucket (single process) reducer, Adam.  A few steps on a fixed batch must lower the loss."""
+    from sc2bench_amd import training as T
+    from sc2bench_amd.resnet import resnet50
+    torch.manual_seed(0)
+    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
+    student = S.splittable_resnet(cfg, skips_avgpool=False, skips_fc=False).to(dev)
+    teacher = resnet50().to(dev)
+    stage = T.DistillationStage(teacher, student, STAGE1, dev)
+    assert all(not p.requires_grad for p in student.layer3.parameters())
+    assert stage.reducer.nbytes() == 4 * (1304168 + sum(p.numel() for p in student.fc.parameters()))
+    x = torch.rand(4, 3, 64, 64, device=dev)
+    losses = []
+    for _ in range(6):
+        loss = stage.forward_process(x)
+        losses.append(loss.item())
+        assert torch.isfinite(loss)
+        stage.post_forward_process(loss)
+    stage.clean_modules()
+    assert losses[-1] < losses[0], losses
+    assert float(student.bottleneck_layer.encoder[0].weight.grad.abs().sum()) == 0.0   # zeroed after the step
