@@ -103,6 +103,78 @@ def cpu_baseline(sample_images, state_dict):
             'bpp': 8.0 * nbytes / (sample_images * 224 * 224)}
 
 
+STAGE1 = {   # train.stage1 of configs/ilsvrc2012/supervised_compression/entropic_student/splitable_resnet50-fp-beta0.08_from_resnet50.yaml
+    'teacher': {'sequential': ['conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4'],
+                'forward_hook': {'input': [], 'output': ['layer1', 'layer2', 'layer3', 'layer4']}},
+    'student': {'sequential': ['bottleneck_layer', 'layer2', 'layer3', 'layer4'],
+                'frozen_modules': ['layer2', 'layer3', 'layer4'],
+                'forward_hook': {'input': [], 'output': ['bottleneck_layer', 'layer2', 'layer3', 'layer4',
+                                                         'bottleneck_layer.entropy_bottleneck']}},
+    'optimizer': {'key': 'Adam', 'kwargs': {'lr': 0.001}},
+    'criterion': {'key': 'WeightedSumLoss', 'kwargs': {'sub_terms': dict(
+        [('layer{}'.format(i), {'criterion': {'key': 'MSELoss', 'kwargs': {'reduction': 'sum'}},
+                                'criterion_wrapper': {'key': 'SimpleLossWrapper', 'kwargs': {
+                                    'input': {'is_from_teacher': False,
+                                              'module_path': 'bottleneck_layer' if i == 1 else 'layer{}'.format(i), 'io': 'output'},
+                                    'target': {'is_from_teacher': True, 'module_path': 'layer{}'.format(i), 'io': 'output'}}},
+                                'weight': 1.0}) for i in (1, 2, 3, 4)] +
+        [('bpp', {'criterion': {'key': 'BppLoss', 'kwargs': {'entropy_module_path': 'bottleneck_layer.entropy_bottleneck',
+                                                             'reduction': 'sum'}}, 'weight': 0.08})])}},
+}
+
+
+def train_bench(args, dev, rank, world, distributed):
+    """Stage-1 Entropic-Student training step: frozen teacher forward, student forward (HIP bottleneck + frozen tail),
+    MSE-sum + 0.08 * bits, aux loss, backward on the HIP kernels, ONE flat-bucket gradient all-reduce (RCCL), Adam."""
+    import sc2bench_amd as S
+    from sc2bench_amd import training as T, dataparallel as dp
+    from sc2bench_amd.resnet import resnet50
+    torch.manual_seed(0)
+    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
+    student = S.splittable_resnet(cfg, skips_avgpool=False, skips_fc=False).to(dev)
+    teacher = resnet50().to(dev)
+    if distributed:
+        dp.broadcast_parameters(student)
+    stage = T.DistillationStage(teacher, student, STAGE1, dev, head_dtype=torch.bfloat16)
+    x = synthetic_batch(args.bs, dev, seed=rank)
+
+    def step():
+        loss = stage.forward_process(x)
+        stage.post_forward_process(loss)
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert torch.isfinite(loss)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/s, Entropic-Student ResNet-50 stage-1 training step, 224^2', 'value': args.bs * args.steps * world / elapsed,
+            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'stage 1 of the Entropic-Student recipe (bottleneck trains, layer2-4 frozen, frozen teacher)',
+                       'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'gradient_all_reduce_bytes': stage.reducer.nbytes(),
+                       'sharding': 'images; one flat-bucket all-reduce per step'},
+            'final_loss': loss.item()}))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -111,6 +183,8 @@ def main():
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--inflight', type=int, default=3, help='range-coder chains in flight (coder HIP streams, <= 3)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
+                    help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -129,6 +203,8 @@ def main():
 
     import sc2bench_amd as S
     from sc2bench_amd import hip
+    if args.mode == 'train':
+        return train_bench(args, dev, rank, world, distributed)
     model = build_model(dev)
     x = synthetic_batch(args.bs, dev, seed=rank)   # a different shard per rank, resident in HBM
     # Software pipeline over HIP streams: ONE MFMA stream runs front(i) [encoder + quantise] and

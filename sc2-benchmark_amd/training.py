@@ -177,7 +177,9 @@ class DistillationStage(object):
         self.t_hooks = ForwardHookManager(self.teacher, t_cfg.get('forward_hook'))
         self.s_hooks = ForwardHookManager(self.student, s_cfg.get('forward_hook'))
         self.criterion = build_criterion(stage_config['criterion'])
-        params = [p for p in student.parameters() if p.requires_grad]
+        # as torchdistill does, the optimizer (and the gradient buckets) see the REDESIGNED student: modules left out
+        # of `sequential` (avgpool / fc in stage 1) take no part in the step
+        params = [p for p in self.student.parameters() if p.requires_grad]
         self.reducer = FlatGradAllReducer(params)
         o_cfg = stage_config['optimizer']
         okw = dict(o_cfg.get('kwargs') or {})
