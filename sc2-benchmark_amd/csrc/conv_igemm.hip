@@ -48,8 +48,11 @@ struct ConvArgs {
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_,
-          int PH_, int PW_, int STAGES_ = 2>
+          int PH_, int PW_, int STAGES_ = 2, bool EPX_ = false>
 struct Cfg {
+    // EPX: prefetch the epilogue operand (GDN's x / the residual) before the K loop (+32 VGPRs); instantiated only
+    // for the launches whose epilogue reads one
+    static constexpr bool EPX = EPX_;
     static constexpr int BM = BM_, BN = BN_, BK = 32;
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
     static constexpr bool STATIC = STATIC_;
@@ -104,9 +107,37 @@ __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
 // Stores a workgroup's accumulator tile: MT passes, pass i stages tile-row i of every wave (WAVES_M*16 rows x BN cols,
 // f32) through LDS so that global stores are whole 16-byte channel runs (NHWC) or pixel runs (NCHW), with the
 // element-wise epilogues (GDN / IGDN / bias / ReLU / residual) applied on the way out.  Call with the LDS idle.
+// chunk tasks of one store pass handled by one thread
 template <class C, int NTHREADS>
+struct EpiGeom {
+    static constexpr int CPR = C::BN / 8;
+    static constexpr int QPT = (C::STAGE_ROWS * CPR + NTHREADS - 1) / NTHREADS;
+};
+
+// Issues, before the main loop, the loads of the epilogue operand (GDN's x / the residual) this thread will need in
+// conv_store_tile: their latency hides behind the whole K loop instead of being exposed once per store pass.
+template <class C, int NTHREADS>
+__device__ __forceinline__ void conv_prefetch_epx(const ConvArgs &p, int tid, int m0, int n0,
+                                                  uint4 (&epx)[C::MT][EpiGeom<C, NTHREADS>::QPT]) {
+    constexpr int CPR = EpiGeom<C, NTHREADS>::CPR, QPT = EpiGeom<C, NTHREADS>::QPT;
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+        for (int r = 0; r < QPT; ++r) {
+            const int q = tid + r * NTHREADS;
+            const int sr = q / CPR, cc = q - sr * CPR;
+            const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
+            const int n = n0 + cc * 8;
+            const bool ok = (q < C::STAGE_ROWS * CPR) & (m < p.M) & (n < p.Cout);
+            epx[i][r] = ok ? *reinterpret_cast<const uint4 *>(p.ep_x + (long long)m * p.Cout + n)
+                           : make_uint4(0u, 0u, 0u, 0u);
+        }
+}
+
+template <class C, int NTHREADS, bool PREFETCHED = false>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char *smem, f32x4_t (&acc)[C::MT][C::NT],
-                                                int tid, int wm, int wn, int frow, int fq, int m0, int n0, int epi) {
+                                                int tid, int wm, int wn, int frow, int fq, int m0, int n0, int epi,
+                                                const uint4 (*epx)[EpiGeom<C, NTHREADS>::QPT] = nullptr) {
     constexpr int BN = C::BN, MT = C::MT, NT = C::NT;
     float *stage = reinterpret_cast<float *>(smem);
     const bool nchw = p.out == SC2_OUT_F32_NCHW;
@@ -127,7 +158,10 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
         __syncthreads();
         if (!nchw) {
             constexpr int CPR = BN / 8;  // 8-channel chunks per row
-            for (int q = tid; q < C::STAGE_ROWS * CPR; q += NTHREADS) {
+#pragma unroll
+            for (int rq = 0; rq < EpiGeom<C, NTHREADS>::QPT; ++rq) {
+                const int q = tid + rq * NTHREADS;
+                if (q >= C::STAGE_ROWS * CPR) continue;
                 const int sr = q / CPR, cc = q - sr * CPR;
                 const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
                 const int n = n0 + cc * 8;
@@ -159,7 +193,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
                     }
                     float xv[8];
                     if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
-                        const uint4 xr = *reinterpret_cast<const uint4 *>(p.ep_x + o_ep);
+                        const uint4 xr = PREFETCHED ? epx[i][rq] : *reinterpret_cast<const uint4 *>(p.ep_x + o_ep);
                         const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -344,6 +378,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) b_rd[j] = (uint32_t)(C::A_BYTES + lds_off(wn * C::WN + j * 16 + frow, fq));
 
+    // epilogue operand (GDN's x / residual), fetched now so that its latency hides behind the K loop
+    uint4 epx[C::EPX ? MT : 1][EpiGeom<C, 256>::QPT];
+    if constexpr (C::EPX) conv_prefetch_epx<C, 256>(p, tid, m0, n0, epx);
+
 #pragma unroll
     for (int st = 0; st < S - 1; ++st) issue_tile(st, st);
 
@@ -396,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     // The tile holds every output channel of its pixels, so norm = beta + gamma |x| is a second, LDS-resident GEMM:
     // |x| (bf16) is written to an LDS image straight from the accumulators, gamma is staged next to it, and
     // y = x / norm (or x * norm) is applied to the f32 accumulators before the store: the GDN costs no HBM traffic.
-    if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
+    if constexpr (BN <= 96) if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
         constexpr int XC = C::XC, XSW = C::XSW, ROWB = XC * 16;
         unsigned char *Xi = smem;
         unsigned char *Gi = smem + BM * ROWB;
@@ -469,7 +507,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     }
     const int epi = (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) ? (int)SC2_EPI_NONE : p.epi;
 
-    conv_store_tile<C, 256>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi);
+    if constexpr (C::EPX)
+        conv_store_tile<C, 256, true>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi, epx);
+    else
+        conv_store_tile<C, 256, false>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi);
 }
 
 // ======================================================================================================
@@ -760,6 +801,17 @@ using G_64 = Cfg<128, 64, 2, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 using G_48 = Cfg<128, 48, 4, 1, false, 0, 0, 0, 0, 0, 0, 0>;
 using G_32 = Cfg<128, 32, 4, 1, false, 0, 0, 0, 0, 0, 0, 0>;
 
+// twins that prefetch the epilogue operand (GDN / IGDN on x, residual add)
+using Cx_gdn96 = Cfg<128, 96, 2, 2, true, 96, 1, 1, 1, 1, 0, 0, 2, true>;
+using Cx_gdn48 = Cfg<128, 48, 4, 1, true, 48, 1, 1, 1, 1, 0, 0, 2, true>;
+using Cx_gdn512 = Cfg<128, 128, 2, 2, true, 512, 1, 1, 1, 1, 0, 0, 3, true>;
+using Cx_gdn256 = Cfg<128, 128, 2, 2, true, 256, 1, 1, 1, 1, 0, 0, 3, true>;
+using Gx_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, true>;
+using Gx_96 = Cfg<128, 96, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
+using Gx_64 = Cfg<128, 64, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
+using Gx_48 = Cfg<128, 48, 4, 1, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
+using Gx_32 = Cfg<128, 32, 4, 1, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
+
 // big-tile (8-wave) geometries: the MFMA-bound decoder layers and the runtime-geometry fallback
 using B_gdn512 = Cfg8<256, 2, 4, true, 512, 1, 1, 1, 1, 0, 0>;
 using B_dec2 = Cfg8<256, 2, 4, true, 512, 2, 2, 1, 1, 0, 0>;
@@ -871,6 +923,21 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         return launch8<BG_256>(a, s);
     }
     if (big && d->Cout % 128 == 0) return launch8<BG_128>(a, s);
+    const bool epx = (d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS_ADD_RELU) &&
+                     d->out_format != SC2_OUT_F32_NCHW && !scatter;
+    if (epx) {
+        if (rows == 96 && matches<Cx_gdn96>(a)) return launch<Cx_gdn96>(a, s);
+        if (rows == 48 && matches<Cx_gdn48>(a)) return launch<Cx_gdn48>(a, s);
+        if (rows % 128 == 0) {
+            if (matches<Cx_gdn512>(a)) return launch<Cx_gdn512>(a, s);
+            if (matches<Cx_gdn256>(a)) return launch<Cx_gdn256>(a, s);
+            return launch<Gx_128>(a, s);
+        }
+        if (rows == 96) return launch<Gx_96>(a, s);
+        if (rows == 64) return launch<Gx_64>(a, s);
+        if (rows == 48) return launch<Gx_48>(a, s);
+        if (rows == 32) return launch<Gx_32>(a, s);
+    }
     if (rows % 128 == 0) {
         if (matches<C_dec0>(a)) return launch<C_dec0>(a, s);
         if (matches<C_gdn512>(a)) return launch<C_gdn512>(a, s);
