@@ -37,9 +37,15 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 BOTTLENECK_GFLOP_PER_IMG = 8.3418
 # algorithmic MFLOP per image of each tagged kernel (2 * MACs)
-KERNEL_MFLOP = {'enc.conv0': 180.6, 'enc.gdn1': 231.2, 'enc.conv2': 722.5, 'enc.gdn3': 14.5, 'enc.conv4': 27.9,
-                'dec.conv0': 308.3, 'dec.igdn1': 1644.2, 'dec.conv2': 3171.9, 'dec.igdn3': 396.5,
-                'dec.conv4': 1644.2}
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy achieves
+KERNEL_MFLOP = {'enc.conv0': 180.6 + 231.2, 'enc.gdn1': 231.2, 'enc.conv2': 722.5 + 14.5, 'enc.gdn3': 14.5,
+                'enc.conv4': 27.9, 'dec.conv0': 308.3, 'dec.igdn1': 1644.2, 'dec.conv2': 3171.9, 'dec.igdn3': 396.5,
+                'dec.conv4': 1644.2}   # enc.conv0 / enc.conv2 launches include their fused GDN1
+# algorithmic HBM bytes per image of each launch: bf16 activations in + out (+ the epilogue operand of the unfused
+# IGDN launches, which read x twice); weights (< 2.6 MB in total, L2-resident) are not counted
+KERNEL_MBYTE = {'enc.conv0': 0.401 + 2.408, 'enc.gdn1': 3 * 2.408, 'enc.conv2': 2.408 + 0.301, 'enc.gdn3': 3 * 0.301,
+                'enc.conv4': 0.301 + 0.290, 'dec.conv0': 0.145 + 3.211, 'dec.igdn1': 3 * 3.211,
+                'dec.conv2': 3.211 + 1.549, 'dec.igdn3': 3 * 1.549, 'dec.conv4': 1.549 + 1.606}
 
 
 def build_model(dev, seed=0):
@@ -280,8 +286,20 @@ def main():
         conv = {k: v for k, v in ksum.items() if k in KERNEL_MFLOP}
         dom = max(conv, key=lambda k: conv[k][0] * conv[k][1])
         dom_ms = conv[dom][1]
-        achieved = KERNEL_MFLOP[dom] * 1e6 * args.bs / (dom_ms * 1e-3) / 1e12
         fwd_ms = sum(v[1] for v in conv.values())
+
+        def roof(k, ms):
+            """bound = whichever roof the launch's algorithmic intensity puts it under (ridge = 312.5 FLOP/B)"""
+            tf = KERNEL_MFLOP[k] * 1e6 * args.bs / (ms * 1e-3) / 1e12
+            gbs = KERNEL_MBYTE[k] * 1e6 * args.bs / (ms * 1e-3) / 1e9
+            hbm = KERNEL_MFLOP[k] / KERNEL_MBYTE[k] < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS
+            return {'bound': 'hbm' if hbm else 'mfma', 'achieved': gbs if hbm else tf,
+                    'peak': PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS, 'unit': 'GB/s' if hbm else 'TFLOP/s',
+                    'frac': (gbs / PEAK_HBM_GBS) if hbm else (tf / PEAK_BF16_TFLOPS), 'tflops': tf, 'gbs': gbs,
+                    'kernel_ms': ms}
+        per_kernel = {k: roof(k, v[1]) for k, v in conv.items()}
+        floor_ms = sum(max(KERNEL_MFLOP[k] * 1e6 * args.bs / (PEAK_BF16_TFLOPS * 1e12),
+                           KERNEL_MBYTE[k] * 1e6 * args.bs / (PEAK_HBM_GBS * 1e9)) * 1e3 for k in conv)
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
@@ -299,12 +317,15 @@ def main():
                        'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'inflight_steps': D,
                        'weights': 'random init seed 0 + fixed quantile perturbation', 'sharding': 'images, no collective'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
-            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': achieved, 'peak': PEAK_BF16_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_BF16_TFLOPS, 'traffic': traffic,
-                         'kernel_ms': dom_ms, 'launches_timed': conv[dom][0]},
+            'roofline': dict(per_kernel[dom], kernel=dom, traffic=traffic, launches_timed=conv[dom][0]),
             'bottleneck_forward': {'ms_per_batch_sum_of_mfma_kernels': fwd_ms,
                                    'tflops': BOTTLENECK_GFLOP_PER_IMG * args.bs / fwd_ms,
-                                   'frac_of_mfma_peak': BOTTLENECK_GFLOP_PER_IMG * args.bs / fwd_ms / PEAK_BF16_TFLOPS},
+                                   'frac_of_mfma_peak': BOTTLENECK_GFLOP_PER_IMG * args.bs / fwd_ms / PEAK_BF16_TFLOPS,
+                                   'roofline_floor_ms_of_this_launch_structure': floor_ms,
+                                   'frac_of_floor': floor_ms / fwd_ms},
+            'kernel_rooflines': {k: {'bound': v['bound'], 'frac': round(v['frac'], 4), 'tflops': round(v['tflops'], 1),
+                                     'gbs': round(v['gbs'], 1), 'ms': round(v['kernel_ms'], 4)}
+                                 for k, v in sorted(per_kernel.items())},
             'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())},
         }
         if 'rans_encode' in ksum:

@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 10
+#define SC2_ABI_VERSION 11
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -73,6 +73,12 @@ enum sc2_conv_epilogue {
     SC2_EPI_FUSED_IGDN = 7
 };
 enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHWC = 2 };
+/* Order of the K axis of the packed weights (and of the kernel's walk over the input):
+ *   TAP_MAJOR  k = (kh*KW + kw)*Cin + ci                       (default)
+ *   SLAB_MAJOR k = ((ci/32)*KH*KW + kh*KW + kw)*32 + ci%32     (Cin % 32 == 0): the taps of one 32-channel slab are
+ *              consecutive, so the overlapping pixels they re-read stay in L1/L2 (measured 4x fewer fabric reads on
+ *              the 2x2 decoder convs). */
+enum sc2_conv_k_order { SC2_K_TAP_MAJOR = 0, SC2_K_SLAB_MAJOR = 1 };
 
 typedef struct sc2_conv_desc {
     int32_t N, H, W, Cin;          /* input  : bf16 NHWC [N,H,W,Cin], Cin % 8 == 0              */
@@ -92,6 +98,7 @@ typedef struct sc2_conv_desc {
      * see implicit zeros) and output pixel (oh, ow) is written to (oh*out_stride_h + out_off_h,
      * ow*out_stride_w + out_off_w) of an NHWC tensor [N,out_H,out_W,Cout]; pixels outside it are dropped. */
     int32_t out_H, out_W, out_stride_h, out_stride_w, out_off_h, out_off_w;
+    int32_t k_order;               /* enum sc2_conv_k_order */
 } sc2_conv_desc;
 
 /* Rows the packed weight buffer must have for a given Cout (zero rows beyond Cout). */

@@ -43,8 +43,9 @@ class _ConvFn(torch.autograd.Function):
     """y = conv(x) on the implicit-GEMM kernel; x bf16 NHWC, weight the f32 OIHW parameter."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, weight, packed, kh, kw, stride, pad, out_format, tag, w_view):
-        y = hip.conv2d_fwd(x_nhwc, packed, weight.shape[0], kh, kw, stride, pad, out_format=out_format, tag=tag)
+    def forward(ctx, x_nhwc, weight, packed, kh, kw, stride, pad, out_format, tag, w_view, k_order=0):
+        y = hip.conv2d_fwd(x_nhwc, packed, weight.shape[0], kh, kw, stride, pad, out_format=out_format, tag=tag,
+                           k_order=k_order)
         ctx.save_for_backward(x_nhwc, weight)
         ctx.cfg = (stride, pad, out_format, w_view)
         return y
@@ -76,7 +77,7 @@ class _ConvFn(torch.autograd.Function):
                 gw = hip.conv2d_wgrad(x_nhwc, g, kh, kw, stride, pad).contiguous()
             if need_x:
                 gi = hip.conv2d_dgrad(g, weight, stride, pad, (x_nhwc.shape[1], x_nhwc.shape[2]))
-        return gi, gw, None, None, None, None, None, None, None, None
+        return gi, gw, None, None, None, None, None, None, None, None, None
 
 
 class _PairView(object):
@@ -149,7 +150,7 @@ def eb_forward_autograd(eb, y, training, noise=None):
 
 def _conv(mod, x_nhwc, out_format=hip.OUT_BF16_NHWC):
     return _ConvFn.apply(x_nhwc, mod.weight, mod.packed_weight(), mod.kernel_size[0], mod.kernel_size[1],
-                         mod.stride, mod.padding, out_format, getattr(mod, '_tag', None), None)
+                         mod.stride, mod.padding, out_format, getattr(mod, '_tag', None), None, mod.k_order())
 
 
 def _gdn(mod, x_nhwc):
@@ -167,7 +168,7 @@ def analysis_autograd(m, x):
         x4 = _ToNhwcBf16.apply(x, 4)
         xp = x4.view(N, H, W // 2, 8)
         h = _ConvFn.apply(xp, c0.weight, m._conv0_packed(), 5, 3, (2, 1), (2, 1), hip.OUT_BF16_NHWC, c0._tag,
-                          _PairView())
+                          _PairView(), hip.K_TAP_MAJOR)
     else:
         cin = c0.in_channels
         if cin % 8 != 0:

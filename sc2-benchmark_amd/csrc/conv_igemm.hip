@@ -44,6 +44,7 @@ struct ConvArgs {
     int n_ntiles;
     int aop, epi, out;
     int g_pitch;   // fused GDN: row pitch (elements) of the packed gamma matrix handed in through ep_x
+    int k_slab_major;   // K ordered (channel slab of 32, tap, channel) instead of (tap, channel): needs Cin % 32 == 0
     int o_H, o_W, o_sh, o_sw, o_h0, o_w0;   // NHWC output scatter (o_H == 0: dense): pixel (oh, ow) -> (oh*o_sh+o_h0, ..)
 };
 
@@ -335,17 +336,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             kh += w2 ? 1 : 0;
         }
     };
-    wrap_k();
+    if (!(C::STATIC ? (C::CIN % 32 == 0) : (Cin % 32 == 0))) wrap_k();
     const int KT = p.KT;
 
+    // When Cin % 32 == 0 a slab never straddles a filter tap: tap and channel base are wave-uniform closed forms of
+    // the slab index (scalar registers).  With k_slab_major the K axis runs (channel slab, tap, channel): the taps of
+    // one 32-channel slab are consecutive slabs, so the overlapping pixels they re-read are still in L1 / L2.
+    const bool aligned = C::STATIC ? (C::CIN % 32 == 0) : (Cin % 32 == 0);
+    const int spt = aligned ? (CIN8 >> 2) : 1;     // slabs per tap
+    const int ntaps = KH * KW;
     auto issue_tile = [&](int kt, int buf) {
         unsigned char *Ab = smem + buf * C::STAGE_BYTES;
         unsigned char *Bb = Ab + C::A_BYTES;
-        const long long tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
-        const bool tap_ok = kh < KH;   // false for the K tail and for the dummy slabs past KT
+        int t_kh, t_kw;
+        long long tap_off;
+        bool tap_ok;
+        if (aligned) {
+            int tap, cb;
+            if (p.k_slab_major) { cb = kt / ntaps; tap = kt - cb * ntaps; }
+            else { tap = kt / spt; cb = kt - tap * spt; }
+            t_kh = tap / KW;
+            t_kw = tap - t_kh * KW;
+            tap_off = ((long long)t_kh * W + t_kw) * Cin + cb * 32 + kc * 8;
+            tap_ok = kt < KT;
+        } else {
+            t_kh = kh;
+            t_kw = kw;
+            tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
+            tap_ok = kh < KH;   // false for the K tail and for the dummy slabs past KT
+        }
 #pragma unroll
         for (int j = 0; j < A_IPW; ++j) {
-            const int ih = a_ih0[j] + kh, iw = a_iw0[j] + kw;
+            const int ih = a_ih0[j] + t_kh, iw = a_iw0[j] + t_kw;
             // bitwise (not short-circuit) so this stays a chain of VALU compares + selects: a conditional branch
             // costs more than the whole address computation (tools/micro/chain2.hip)
             const bool ok = a_ok[j] & tap_ok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
@@ -360,8 +382,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             const uint16_t *src = p.w + off;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Bb + (j * 4 + wave) * 1024), 16, 0, 0);
         }
-        c8 += KC;
-        wrap_k();
+        if (!aligned) {
+            c8 += KC;
+            wrap_k();
+        }
     };
 
     f32x4_t acc[MT][NT];
@@ -631,7 +655,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
         int t_kh, t_kw;
         long long tap_off;
         if (aligned) {
-            const int tap = next_a / spt, cb = next_a - tap * spt;   // scalar
+            int tap, cb;   // scalar
+            if (p.k_slab_major) { cb = next_a / (KH * KW); tap = next_a - cb * (KH * KW); }
+            else { tap = next_a / spt; cb = next_a - tap * spt; }
             t_kh = tap / KW;
             t_kw = tap - t_kh * KW;
             tap_off = ((long long)t_kh * W + t_kw) * Cin + cb * 32 + kc * 8;
@@ -640,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
             t_kw = kw;
             tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
         }
-        const bool tap_ok = t_kh < KH;   // false for the K tail and the dummy slabs past KT
+        const bool tap_ok = aligned ? (next_a < KT) : (t_kh < KH);   // false for the K tail and the dummy slabs past KT
 #pragma unroll
         for (int j = 0; j < A_IPW; ++j) {
             const int ih = a_ih0[j] + t_kh, iw = a_iw0[j] + t_kw;
@@ -867,6 +893,8 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     SC2_REQUIRE(d->Cout_pad == sc2_conv_weight_rows(d->Cout), SC2_ERR_INVALID_ARG, "conv2d: Cout_pad %d != %d",
                 d->Cout_pad, sc2_conv_weight_rows(d->Cout));
     SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS, SC2_ERR_INVALID_ARG, "conv2d: bad a_op");
+    SC2_REQUIRE(d->k_order == SC2_K_TAP_MAJOR || (d->k_order == SC2_K_SLAB_MAJOR && d->Cin % 32 == 0),
+                SC2_ERR_INVALID_ARG, "conv2d: slab-major K order needs Cin %% 32 == 0 (Cin = %d)", d->Cin);
     SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_FUSED_IGDN, SC2_ERR_INVALID_ARG,
                 "conv2d: bad epilogue");
     const bool fused = d->epilogue == SC2_EPI_FUSED_GDN || d->epilogue == SC2_EPI_FUSED_IGDN;
@@ -896,6 +924,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.Kpad = d->Kpad; a.KT = 0; a.n_ntiles = 0;
     a.aop = d->a_op; a.epi = d->epilogue; a.out = d->out_format;
     a.g_pitch = sc2_conv_weight_pitch(d->Cout);
+    a.k_slab_major = d->k_order == SC2_K_SLAB_MAJOR;
     a.o_H = scatter ? d->out_H : 0; a.o_W = d->out_W; a.o_sh = d->out_stride_h; a.o_sw = d->out_stride_w;
     a.o_h0 = d->out_off_h; a.o_w0 = d->out_off_w;
     hipStream_t s = static_cast<hipStream_t>(stream);

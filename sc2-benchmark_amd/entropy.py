@@ -74,10 +74,13 @@ class HipConv2d(nn.Conv2d):
     bottleneck's own forward keeps activations in bf16 NHWC between layers (``bottleneck.py``).
     """
 
+    def k_order(self):
+        return hip.preferred_k_order(self.in_channels, self.kernel_size[0], self.kernel_size[1])
+
     def packed_weight(self):
         key = (self.weight._version, self.weight.device, self.weight.data_ptr())
         if getattr(self, '_packed_key', None) != key:
-            self._packed = hip.pack_conv_weight(self.weight)
+            self._packed = hip.pack_conv_weight(self.weight, self.k_order())
             self._packed_key = key
         return self._packed
 
@@ -85,7 +88,7 @@ class HipConv2d(nn.Conv2d):
         assert self.bias is None and self.groups == 1 and self.dilation == (1, 1)
         return hip.conv2d_fwd(x_nhwc, self.packed_weight(), self.out_channels, self.kernel_size[0],
                               self.kernel_size[1], self.stride, self.padding, out_format=out_format,
-                              tag=getattr(self, '_tag', None))
+                              tag=getattr(self, '_tag', None), k_order=self.k_order())
 
     def forward(self, x):
         _require_device(x, 'HipConv2d')

@@ -26,13 +26,14 @@ def _fold(conv, bn):
     else:
         raise TypeError('cannot fold {}'.format(type(bn)))
     w = w * scale.reshape(-1, 1, 1, 1)
-    return hip.pack_conv_weight(w), bias.contiguous()
+    order = hip.preferred_k_order(w.shape[1], w.shape[2], w.shape[3])
+    return hip.pack_conv_weight(w, order), bias.contiguous(), order
 
 
 class _Conv(object):
     def __init__(self, conv, bn, tag):
         assert conv.bias is None and conv.groups == 1
-        self.w, self.b = _fold(conv, bn)
+        self.w, self.b, self.k_order = _fold(conv, bn)
         self.cout = conv.out_channels
         self.k = conv.kernel_size
         self.stride = conv.stride
@@ -44,7 +45,7 @@ class _Conv(object):
 
     def __call__(self, x, epilogue, ep_x=None):
         return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,
-                              ep_x=ep_x, ep_beta=self.b, tag=self.tag)
+                              ep_x=ep_x, ep_beta=self.b, tag=self.tag, k_order=self.k_order)
 
 
 class HipHead(object):

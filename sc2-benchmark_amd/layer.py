@@ -170,7 +170,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             beta, gamma = g3.effective()
             h = hip.conv2d_fwd(h, c2.packed_weight(), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
                                c2.padding, epilogue=hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN,
-                               ep_x=gamma, ep_beta=beta, tag=c2._tag)
+                               ep_x=gamma, ep_beta=beta, tag=c2._tag, k_order=c2.k_order())
         else:
             h = g3.forward_nhwc(c2.forward_nhwc(h))
         return c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
