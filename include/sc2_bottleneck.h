@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 11
+#define SC2_ABI_VERSION 12
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -66,7 +66,8 @@ enum sc2_conv_epilogue {
     SC2_EPI_BIAS = 3, /* y = acc + ep_beta[c]            (conv + bias / folded BN) */
     SC2_EPI_BIAS_RELU = 4,     /* y = relu(acc + ep_beta[c]) */
     SC2_EPI_BIAS_ADD_RELU = 5, /* y = relu(acc + ep_beta[c] + ep_x) (residual add) */
-    /* conv FOLLOWED BY GDN1 in one launch (Cout in {32,48,64,96}: one tile holds every channel of a pixel):
+    /* conv FOLLOWED BY GDN1 in one launch where one tile holds every channel of a pixel: Cout in {32,48,64,96}, or
+     * Cout == 256 on the 256-wide big-tile path (sc2_conv_fused_gdn_supported tells):
      * x = acc; y = x / (ep_beta + gamma |x|)  resp.  x * (ep_beta + gamma |x|).  `ep_x` carries the packed bf16
      * gamma matrix [sc2_conv_weight_rows(Cout)][sc2_conv_weight_pitch(Cout)] instead of an activation. */
     SC2_EPI_FUSED_GDN = 6,
@@ -110,6 +111,8 @@ int sc2_conv_weight_pitch(int K);
  * ep_x   : bf16 NHWC [N,OH,OW,Cout] for GDN/IGDN/ADD epilogues (NULL otherwise)
  * ep_beta: f32 [Cout] for GDN/IGDN/BIAS epilogues (NULL otherwise)
  * y      : per out_format. */
+/* 1 if SC2_EPI_FUSED_GDN / _IGDN is available for this geometry (all of `d` filled in as for sc2_conv2d_fwd). */
+int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d);
 int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
                    const void *ep_x, const float *ep_beta, void *stream);
 

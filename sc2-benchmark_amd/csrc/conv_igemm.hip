@@ -135,14 +135,17 @@ __device__ __forceinline__ void conv_prefetch_epx(const ConvArgs &p, int tid, in
         }
 }
 
+// x_img != nullptr: the GDN operand x is an LDS-resident bf16 image [tile row][512 B], chunk XOR (row & 15) (the
+// fused conv + IGDN of the 256-wide big tile); `smem` is then the staging area, with unpadded rows (rs_override).
 template <class C, int NTHREADS, bool PREFETCHED = false>
 __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char *smem, f32x4_t (&acc)[C::MT][C::NT],
                                                 int tid, int wm, int wn, int frow, int fq, int m0, int n0, int epi,
-                                                const uint4 (*epx)[EpiGeom<C, NTHREADS>::QPT] = nullptr) {
+                                                const uint4 (*epx)[EpiGeom<C, NTHREADS>::QPT] = nullptr,
+                                                const unsigned char *x_img = nullptr, int rs_override = 0) {
     constexpr int BN = C::BN, MT = C::MT, NT = C::NT;
     float *stage = reinterpret_cast<float *>(smem);
     const bool nchw = p.out == SC2_OUT_F32_NCHW;
-    const int RS = nchw ? BN + 1 : BN + 4;  // row stride in floats (bank spread for the read pattern)
+    const int RS = rs_override ? rs_override : (nchw ? BN + 1 : BN + 4);  // row stride in floats (bank spread)
     const int Cout = p.Cout;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -194,7 +197,13 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
                     }
                     float xv[8];
                     if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
-                        const uint4 xr = PREFETCHED ? epx[i][rq] : *reinterpret_cast<const uint4 *>(p.ep_x + o_ep);
+                        uint4 xr;
+                        if (x_img) {
+                            const int trow = (sr >> 4) * C::WM + i * 16 + (sr & 15);
+                            xr = *reinterpret_cast<const uint4 *>(x_img + trow * 512 + ((cc ^ (trow & 15)) << 4));
+                        } else {
+                            xr = PREFETCHED ? epx[i][rq] : *reinterpret_cast<const uint4 *>(p.ep_x + o_ep);
+                        }
                         const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -564,7 +573,10 @@ struct Cfg8 {
     static constexpr int STAGE_ROWS = WAVES_M * 16;
     static constexpr int MAIN_LDS = STAGES * STAGE_BYTES;
     static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
-    static constexpr int LDS_BYTES = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
+    // fused conv + GDN1 (BN == 256 == Cout): x image 256 x 512 B + a 2 x 16 KB gamma-slab ring / store staging
+    static constexpr int FUSE_LDS = BN == 256 ? 256 * 512 + 32768 : 0;
+    static constexpr int LDS1 = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
+    static constexpr int LDS_BYTES = LDS1 > FUSE_LDS ? LDS1 : FUSE_LDS;
     static_assert(WAVES_M * WAVES_N == 8 && NT == 4 && MT % 4 == 0, "8 waves, 16 MFMAs per phase");
     static_assert(BN % 128 == 0, "whole direct-to-LDS instructions per wave");
 };
@@ -761,6 +773,71 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy slabs past KT
     __builtin_amdgcn_s_barrier();
 
+    // ---- conv followed by GDN1 / inverse GDN1 in the same launch (the tile holds all 256 channels of its pixels):
+    // x goes to an LDS image as bf16, norm = gamma |x| is a second MFMA GEMM whose A operand is that image (|.| on the
+    // fragment) and whose B operand, gamma, streams through a 2-slab direct-to-LDS ring; y = x * (beta + norm) (or
+    // x / ...) is applied in the store pass with x read back from the image.  No HBM traffic for the GDN.
+    if constexpr (BN == 256) {
+        if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
+            unsigned char *Xi = smem;
+            unsigned char *ring = smem + 256 * 512;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = wm * C::WM + i * 16 + fq * 4 + e;
+                        const int col = wn * C::WN + j * 16 + frow;
+                        *reinterpret_cast<uint16_t *>(Xi + r * 512 + (((col >> 3) ^ (r & 15)) << 4) + (col & 7) * 2) =
+                            f32_to_bf16_bits(acc[i][j][e]);
+                        acc[i][j][e] = 0.f;
+                    }
+            const uint16_t *gamma = p.ep_x;
+            const long long zero_off_g = zero - gamma;
+            (void)zero_off_g;
+            auto issue_g = [&](int ks2, int buf) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const long long off = (long long)((j * 8 + wave) * 16 + (lane >> 2)) * p.g_pitch + ks2 * 32 + kc * 8;
+                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gamma + off),
+                                                     (lds_ptr_t)(ring + buf * 16384 + (j * 8 + wave) * 1024), 16, 0, 0);
+                }
+            };
+            issue_g(0, 0);
+            const uint32_t xi_base = lds_base, ring_base = lds_base + 256 * 512;
+            for (int ks2 = 0; ks2 < 8; ++ks2) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // gamma slab ks2 landed everywhere; (ks2 == 0) the x image is complete
+                if (ks2 + 1 < 8) issue_g(ks2 + 1, (ks2 + 1) & 1);
+                uint4 xa[MT], gb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int r = wm * C::WM + i * 16 + frow;
+                    xa[i] = lds_read16(xi_base + (uint32_t)(r * 512 + (((4 * ks2 + fq) ^ (r & 15)) << 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    gb[j] = lds_read16(ring_base + (uint32_t)((ks2 & 1) * 16384 + lds_off(wn * C::WN + j * 16 + frow, fq)));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    uint4 v = xa[i];
+                    v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu;
+                    const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, gb[j]),
+                                                                            acc[i][j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_barrier();   // every wave is done with the gamma ring: it becomes the store staging area
+            conv_store_tile<C, 512>(p, ring, acc, tid, wm, wn, frow, fq, m0, n0,
+                                    p.epi == SC2_EPI_FUSED_IGDN ? (int)SC2_EPI_IGDN : (int)SC2_EPI_GDN, nullptr, Xi, BN);
+            return;
+        }
+    }
     conv_store_tile<C, 512>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi);
 }
 
@@ -864,6 +941,26 @@ extern "C" int sc2_conv_weight_rows(int Cout) {
 }
 extern "C" int sc2_conv_weight_pitch(int K) { return K <= 0 ? 0 : (K + 63) / 64 * 64; }
 
+namespace {
+// the 8-wave 256-row tile is used when ...
+bool big_tile_eligible(const sc2_conv_desc *d, long long M, int K) {
+    // Measured (tools/ab_big.py, one process, MI355X): 256-wide big tile wins +27 % at K = 2048 and +13 % at K = 1024,
+    // ties or loses on the HBM-bound 1x1 GDN GEMMs and on short K; the 128-wide big tile never wins.
+    // (SC2_CONV_FORCE_BIG / SC2_CONV_NO_BIG: test and A/B switches)
+    const bool forced = getenv("SC2_CONV_FORCE_BIG") != nullptr;
+    return sc2_conv_weight_rows(d->Cout) % 128 == 0 && !getenv("SC2_CONV_NO_BIG") &&
+           ((K >= 1024 && d->Cout % 256 == 0 && d->a_op == SC2_AOP_NONE && M >= 256LL * 512) || forced);
+}
+}  // namespace
+
+extern "C" int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d) {
+    if (!d || d->Cout <= 0) return 0;
+    if (d->Cout == 32 || d->Cout == 48 || d->Cout == 64 || d->Cout == 96) return 1;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    return d->Cout == 256 && d->out_format != SC2_OUT_F32_NCHW && d->out_H == 0 &&
+           big_tile_eligible(d, M, d->KH * d->KW * d->Cin) ? 1 : 0;
+}
+
 extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, const void *ep_x,
                               const float *ep_beta, void *stream) {
     SC2_REQUIRE(d && x && w_packed && y, SC2_ERR_INVALID_ARG, "conv2d: null argument");
@@ -899,10 +996,9 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
                 "conv2d: bad epilogue");
     const bool fused = d->epilogue == SC2_EPI_FUSED_GDN || d->epilogue == SC2_EPI_FUSED_IGDN;
     if (fused)
-        SC2_REQUIRE(d->Cout == d->Cout_pad && (d->Cout == 96 || d->Cout == 48 || d->Cout == 64 || d->Cout == 32),
-                    SC2_ERR_UNSUPPORTED,
-                    "conv2d: fused GDN needs one tile to cover all output channels (Cout in {32,48,64,96}), got %d",
-                    d->Cout);
+        SC2_REQUIRE(d->Cout == d->Cout_pad && sc2_conv_fused_gdn_supported(d), SC2_ERR_UNSUPPORTED,
+                    "conv2d: fused GDN needs one tile to cover all output channels (Cout in {32,48,64,96}, or 256 on "
+                    "the big-tile path: K >= 1024, >= 131072 output pixels, NHWC output); got Cout %d", d->Cout);
     SC2_REQUIRE(d->out_format >= SC2_OUT_BF16_NHWC && d->out_format <= SC2_OUT_F32_NHWC, SC2_ERR_INVALID_ARG,
                 "conv2d: bad out_format");
     if (d->epilogue != SC2_EPI_NONE) SC2_REQUIRE(ep_beta, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_beta");
@@ -936,14 +1032,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     if (rows == 48 && matches<C_conv2>(a)) return launch<C_conv2>(a, s);
     if (rows == 48 && matches<C_gdn48>(a)) return launch<C_gdn48>(a, s);
     if (rows == 32 && matches<C_conv4>(a)) return launch<C_conv4>(a, s);
-    // big tiles pay when there is enough K to amortise the 256-row tile's prologue / epilogue and enough rows to
-    // fill the chip twice over
-    // (SC2_CONV_FORCE_BIG / SC2_CONV_NO_BIG: test and A/B switches)
-    // Measured (tools/ab_big.py, one process, MI355X): 256-wide big tile wins +27 % at K = 2048 and +13 % at K = 1024,
-    // ties or loses on the HBM-bound 1x1 GDN GEMMs and on short K; the 128-wide big tile never wins.
-    const bool forced = getenv("SC2_CONV_FORCE_BIG") != nullptr;
-    const bool big = rows % 128 == 0 && !getenv("SC2_CONV_NO_BIG") &&
-                     ((K >= 1024 && d->Cout % 256 == 0 && d->a_op == SC2_AOP_NONE && M >= 256LL * 512) || forced);
+    const bool big = big_tile_eligible(d, M, K);
     if (big && d->Cout % 256 == 0) {
         if (matches<B_gdn512>(a)) return launch8<B_gdn512>(a, s);
         if (matches<B_dec2>(a)) return launch8<B_dec2>(a, s);

@@ -24,7 +24,7 @@ EB_PARAM_STRIDE = 64
 ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
-    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv2d_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv2d_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
@@ -60,6 +60,7 @@ def lib():
     L.sc2_nhwc_bf16_to_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv_weight_rows.argtypes = [i32]
     L.sc2_conv_weight_pitch.argtypes = [i32]
+    L.sc2_conv_fused_gdn_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
     L.sc2_gdn_bwd_pre.argtypes = [vp, vp, vp, ctypes.c_longlong, i32, i32, vp, vp, vp, vp]
@@ -335,6 +336,18 @@ def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16):
                 conv2d_fwd(gy_nhwc, packed, cin, len(khs), len(kws), 1, (pad_h, pad_w), out_format=fmt, tag='dgrad',
                            scatter=(rows, cols, gx, sh, sw, ch, cw))
     return gx
+
+
+def conv_fused_gdn_supported(x_shape, cout, kh, kw, stride, pad, out_format=OUT_BF16_NHWC):
+    """True if conv + GDN1 runs as ONE launch (EPI_FUSED_GDN / EPI_FUSED_IGDN) for this geometry; x_shape = [N,H,W,Cin]."""
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    N, H, W, Cin = x_shape
+    OH = (H + 2 * ph - kh) // sh + 1
+    OW = (W + 2 * pw - kw) // sw + 1
+    d = ConvDesc(N, H, W, Cin, cout, kh, kw, sh, sw, ph, pw, OH, OW, AOP_NONE, EPI_FUSED_GDN, out_format,
+                 weight_pitch(kh * kw * Cin), weight_rows(cout), 0, 0, 0, 0, 0, 0, K_TAP_MAJOR)
+    return bool(lib().sc2_conv_fused_gdn_supported(ctypes.byref(d)))
 
 
 def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilogue=EPI_NONE,

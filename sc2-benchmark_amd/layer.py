@@ -180,8 +180,15 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         c0, g1, c2, g3, c4 = self.decoder
         h = c0.forward_nhwc(y_hat_nhwc)
         h = g1.forward_nhwc(h)
-        h = c2.forward_nhwc(h)
-        h = g3.forward_nhwc(h)
+        if self.fuse_gdn and hip.conv_fused_gdn_supported(tuple(h.shape), c2.out_channels, c2.kernel_size[0],
+                                                          c2.kernel_size[1], c2.stride, c2.padding):
+            beta, gamma = g3.effective()   # conv + inverse GDN1 in one launch (256-wide big tile holds all channels)
+            h = hip.conv2d_fwd(h, c2.packed_weight(), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
+                               c2.padding, epilogue=hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN,
+                               ep_x=gamma, ep_beta=beta, tag=c2._tag, k_order=c2.k_order())
+        else:
+            h = c2.forward_nhwc(h)
+            h = g3.forward_nhwc(h)
         if self.output_format == 'bf16_nhwc':
             out = c4.forward_nhwc(h, out_format=hip.OUT_BF16_NHWC)
             return out.permute(0, 3, 1, 2)  # logical NCHW, channels_last memory

@@ -224,6 +224,43 @@ def test_conv_fused_gdn(S, R, dev, cin, cout, k, stride, pad, inverse):
                          ep_beta=torch.ones(256, device=dev))
 
 
+@pytest.mark.parametrize('cin,k,pad,inverse', [(512, 2, 0, True), (64, 1, 0, False)])
+def test_conv_fused_gdn_big_tile(S, R, dev, monkeypatch, cin, k, pad, inverse):
+    """conv + GDN1(256) in one launch of the 256-wide 8-wave tile (x image and gamma ring in LDS), ragged last tile."""
+    monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
+    cout = 256
+    torch.manual_seed(cin)
+    gdn = R.GDN1(cout, inverse=inverse)
+    with torch.no_grad():
+        gdn.gamma.add_(0.05 * torch.rand(cout, cout) / cout ** 0.5)
+        gdn.beta.add_(0.1 * torch.rand(cout))
+    x = torch.randn(3, cin, 11, 10)
+    w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+    with torch.no_grad():
+        conv = F.conv2d(bf16_round(x), bf16_round(w), padding=pad)
+        beta = gdn.beta_reparam(gdn.beta)
+        gamma = bf16_round(gdn.gamma_reparam(gdn.gamma))
+        xb = bf16_round(conv)   # x enters the second GEMM and the final multiply as bf16 (LDS image)
+        norm = F.conv2d(xb.abs(), gamma.reshape(cout, cout, 1, 1), beta)
+        ref = xb * norm if inverse else xb / norm
+    m = S.GDN1(cout, inverse=inverse)
+    m.load_state_dict(gdn.state_dict())
+    m.to(dev)
+    beta_d, gamma_d = m.effective()
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    assert S.hip.conv_fused_gdn_supported(tuple(x_nhwc.shape), cout, k, k, 1, pad)
+    for order in ((S.hip.K_TAP_MAJOR, S.hip.K_SLAB_MAJOR) if cin % 32 == 0 and k > 1 else (S.hip.K_TAP_MAJOR,)):
+        out = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev), order), cout, k, k, 1, pad,
+                               epilogue=S.hip.EPI_FUSED_IGDN if inverse else S.hip.EPI_FUSED_GDN, ep_x=gamma_d,
+                               ep_beta=beta_d, out_format=S.hip.OUT_F32_NHWC, k_order=order)
+        torch.testing.assert_close(out.permute(0, 3, 1, 2).cpu(), ref, rtol=3e-3, atol=3e-3 * ref.abs().max().item())
+    outb = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, k, k, 1, pad,
+                            epilogue=S.hip.EPI_FUSED_IGDN if inverse else S.hip.EPI_FUSED_GDN, ep_x=gamma_d, ep_beta=beta_d)
+    assert_close_bf16(outb.permute(0, 3, 1, 2), ref, 'big-tile fused conv+gdn bf16')
+    monkeypatch.delenv('SC2_CONV_FORCE_BIG')
+    assert not S.hip.conv_fused_gdn_supported(tuple(x_nhwc.shape), cout, k, k, 1, pad)   # too few rows un-forced
+
+
 def _golden():
     return torch.load(os.path.join(HERE, 'golden', 'fp_golden.pt'), weights_only=False)
 
