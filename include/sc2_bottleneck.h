@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 12
+#define SC2_ABI_VERSION 13
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -115,6 +115,17 @@ int sc2_conv_weight_pitch(int K);
 int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d);
 int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
                    const void *ep_x, const float *ep_beta, void *stream);
+
+/* First decoder stage in ONE launch: y = GDN1_512(Conv2d(Cin -> 512, k2, s1, p1, bias=False)(x)) with the inverse
+ * (multiplicative) or forward (divisive) normalisation: t = conv(x); y = t * (beta + gamma |t|) resp. t / (...).
+ * Replaces decoder[0] + decoder[1] of FPBasedResNetBottleneck (sc2bench/models/layer.py:486-488); the 512-channel
+ * intermediate never reaches HBM.
+ *   x : bf16 NHWC [N,H,W,Cin], Cin in {8,16,24,32};   w_packed : bf16 [512][Kpad], Kpad = sc2_conv_weight_pitch(4*Cin)
+ *   gamma_packed : bf16 [512][512] (effective gamma, row = output channel);   beta : f32 [512] (effective beta)
+ *   y : bf16 NHWC [N,H+1,W+1,512] */
+int sc2_conv2x2_gdn512_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
+int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const void *gamma_packed, const float *beta,
+                           void *y, int N, int H, int W, int Cin, int inverse, void *stream);
 
 /* Weight gradient of sc2_conv2d_fwd: dw[co][(kh*KW+kw)*Cin+ci] = sum over output pixels of gy * im2col(x).
  * Replaces the weight half of nn.Conv2d's backward (reached through loss.backward(), image_classification.py:79).

@@ -1,0 +1,307 @@
+// First decoder stage of the FP bottleneck in ONE launch (gfx950):
+//     y = IGDN1_512( Conv2d(Cin -> 512, k2, s1, p1, bias=False)(x) )          (sc2bench/models/layer.py:486-488)
+// i.e.  t = conv(x);  y = t * (beta + gamma |t|)   (or t / (...) for the non-inverse GDN1).
+//
+// Why a dedicated kernel: as two launches the 512-channel intermediate t (822 MB at 256 x 56 x 56) is written once and
+// read twice, and the K = 96 conv is all prologue/epilogue.  Here t never leaves the CU.
+//
+// Structure: persistent 512-thread workgroups (one per CU), each looping over tiles of 128 consecutive output pixels x
+// all 512 channels.  Eight waves, wave w owns channels [64w, 64w+64) of every pixel of the tile (8 x 4 accumulator
+// tiles of v_mfma_f32_16x16x32_bf16, weights as the A operand so a lane holds 4 consecutive channels of a pixel).
+//   phase 1  t = W0 * patch:  the tile's im2col patch [128 px][4 taps x Cin] (<= 32 KB) sits in LDS (loaded one tile
+//            ahead, during phase 2 of the previous tile); W0 fragments come straight from L2 into registers.
+//            t is rounded to bf16 into the LDS IMAGE [128 px][512 ch] (128 KB, 16-byte chunks XOR-swizzled by row).
+//   phase 2  norm = gamma * |t|:  K = 512; |t| fragments are read from the image (every wave reads all 128 rows),
+//            gamma fragments stream from L2 into registers, two 16-byte halves of a 128-byte line per lane per
+//            64-deep step (the k order inside a step is permuted identically for both operands so that the four
+//            lanes of a row fetch one whole line).  No barrier inside the phase: the two waves of a SIMD drift
+//            apart and one issues MFMAs while the other waits for its loads.
+//   epilogue y = t * (beta + norm) in f32, written back IN PLACE into the image (each 8-byte slot belongs to one
+//            lane), then the 128 KB tile - contiguous in the NHWC output - is streamed out in 16-byte stores.
+// HBM traffic per tile: 128 x Cin x 2 B in (x taps overlap in L2), 128 KB out.
+#include "sc2_common.h"
+
+namespace {
+
+struct DecArgs {
+    const uint16_t *__restrict__ x;      // bf16 NHWC [N,H,W,CIN]
+    const uint16_t *__restrict__ w;      // packed bf16 [512][Kpad], k = (kh*2+kw)*CIN + ci
+    const uint16_t *__restrict__ g;      // packed bf16 gamma [512][512]
+    const float *__restrict__ beta;      // f32 [512]
+    uint16_t *__restrict__ y;            // bf16 NHWC [N,OH,OW,512]
+    int N, H, W, OH, OW, OHW, M, Kpad, n_tiles, inverse;
+};
+
+constexpr int BM = 128, CH = 512, WN = 64, MT = 8, NT = 4;
+constexpr int IMG_BYTES = BM * CH * 2;
+
+__device__ __forceinline__ int slab_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 3)) << 4); }
+__device__ __forceinline__ int img_off(int row, int c16) { return row * (CH * 2) + ((c16 ^ (row & 15)) << 4); }
+
+template <int CIN, bool INVERSE>
+__global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p) {
+    constexpr int CIN8 = CIN / 8;
+    constexpr int KS1 = (4 * CIN + 31) / 32;     // 32-deep k-steps of the conv (K = 4 taps x CIN)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *img = smem;
+    unsigned char *patch = smem + IMG_BYTES;     // KS1 slabs of [128 rows][64 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int H = p.H, W = p.W;
+    // LDS addresses as (per-lane base) + (compile-time constant), so that they fold into the ds instructions'
+    // immediate offsets instead of occupying registers: row = i*16 + frow, so row & 15 = frow everywhere.
+    // (ds offsets are 16 bits: bases above 64 KB are made opaque so that the constant part stays an immediate)
+    int patch_lane = IMG_BYTES + frow * 64 + ((fq ^ ((frow >> 1) & 3)) << 4);   // + s*8192 + i*1024
+    asm volatile("" : "+v"(patch_lane));
+    int slot_lane[NT];   // image slot of this lane's 4 channels of accumulator tile (i, j):  + i*16384
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+        slot_lane[j] = frow * (CH * 2) + (((wn * 8 + j * 2 + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8;
+    auto hi = [](int base) {   // base + 65536 as a value the compiler cannot fold back into a 17-bit offset
+        int v = base + 65536;
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+
+    // this thread's share of a tile's patch: chunk (row = tid >> 2, c = tid & 3) of each of the KS1 slabs
+    const int prow = tid >> 2, pc = tid & 3;
+    auto load_patch = [&](int tile, uint4 (&pv)[KS1]) {
+        const int m = tile * BM + prow;
+        const bool m_ok = (tile < p.n_tiles) & (m < p.M);
+        const int mm = m_ok ? m : 0;
+        const int im = mm / p.OHW;
+        const int rem = mm - im * p.OHW;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            const int kc = s * 4 + pc;               // 16-byte k chunk: (tap, 8-channel group)
+            const int tap = kc / CIN8, c8 = kc - tap * CIN8;
+            const int ih = oh - 1 + (tap >> 1), iw = ow - 1 + (tap & 1);
+            const bool ok = m_ok & (tap < 4) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            const long long off = (((long long)im * H + ih) * W + iw) * CIN + c8 * 8;
+            pv[s] = ok ? *reinterpret_cast<const uint4 *>(p.x + off) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_patch = [&](const uint4 (&pv)[KS1]) {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) *reinterpret_cast<uint4 *>(patch + s * 8192 + slab_off(prow, pc)) = pv[s];
+    };
+
+    int tile = blockIdx.x;
+    {
+        uint4 pv[KS1];
+        load_patch(tile, pv);
+        store_patch(pv);
+    }
+    __syncthreads();
+
+    const uint16_t *wrow[NT], *grow[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int ch = wn * WN + j * 16 + frow;
+        wrow[j] = p.w + (long long)ch * p.Kpad + fq * 8;
+        grow[j] = p.g + (long long)ch * CH;
+    }
+
+    // W0 fragments of this wave (its 64 channels x K): the same for every tile, but 48 registers are too many to
+    // hold through phase 2, so they are re-fetched (L2) per tile - issued BEFORE the previous tile's output stores so
+    // that waiting for them never waits for those stores (vmcnt retires in issue order).
+    uint4 wv[KS1][NT];
+    auto load_w = [&]() {
+#pragma unroll
+        for (int s = 0; s < KS1; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wv[s][j] = *reinterpret_cast<const uint4 *>(wrow[j] + s * 32);
+    };
+    load_w();
+
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        const int m0 = tile * BM;
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        int slot_hi[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) slot_hi[j] = hi(slot_lane[j]);
+
+        // ---------------------------------------------------------------- phase 1: t = conv(x)
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            bf16x8_t wf[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wf[j] = __builtin_bit_cast(bf16x8_t, wv[s][j]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const bf16x8_t xf = __builtin_bit_cast(
+                    bf16x8_t, *reinterpret_cast<const uint4 *>(smem + patch_lane + s * 8192 + i * 1024));
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, acc[i][j], 0, 0, 0);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's read-ahead (registers)
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                uint2 h;
+                h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                *reinterpret_cast<uint2 *>(img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384) = h;
+                acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();   // the image holds all 512 channels of the tile; the patch has been consumed
+
+        // ---------------------------------------------------------------- phase 2: norm = gamma |t|
+        uint4 pv[KS1];
+        load_patch(tile + gridDim.x, pv);   // next tile's patch: in flight for the whole phase
+        uint4 gb[2][NT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) gb[h][j] = *reinterpret_cast<const uint4 *>(grow[j] + (2 * fq + h) * 8);
+#pragma unroll 1
+        for (int d = 0; d < CH / 64; ++d) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kc = d * 8 + 2 * fq + h;   // this lane's 16-byte k chunk of the 64-deep step
+                const int rd_lane = frow * (CH * 2) + ((kc ^ frow) << 4);   // + i*16384
+                const int rd_hi = hi(rd_lane);
+                bf16x8_t gf[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) gf[j] = __builtin_bit_cast(bf16x8_t, gb[h][j]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    uint4 v = *reinterpret_cast<const uint4 *>(img + (i < 4 ? rd_lane : rd_hi) + (i & 3) * 16384);
+                    v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu;   // |t|
+                    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[j], xf, acc[i][j], 0, 0, 0);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (d + 1 < CH / 64) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        gb[h][j] = *reinterpret_cast<const uint4 *>(grow[j] + ((d + 1) * 8 + 2 * fq + h) * 8);
+                }
+            }
+        }
+        store_patch(pv);   // nobody reads the patch region until the barriers below have been passed
+
+        // ---------------------------------------------------------------- epilogue: y = t * (beta + norm), in place
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = wn * WN + j * 16 + fq * 4;
+            const float4 b4 = *reinterpret_cast<const float4 *>(p.beta + col);
+            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384;
+                const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
+                const float t[4] = {__builtin_bit_cast(float, xr.x << 16), __builtin_bit_cast(float, xr.x & 0xFFFF0000u),
+                                    __builtin_bit_cast(float, xr.y << 16), __builtin_bit_cast(float, xr.y & 0xFFFF0000u)};
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float norm = b[e] + acc[i][j][e];
+                    r[e] = INVERSE ? t[e] * norm : t[e] * (1.0f / norm);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(r[0], r[1]);
+                o.y = pack_bf16x2(r[2], r[3]);
+                *reinterpret_cast<uint2 *>(slot) = o;
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        load_w();          // next tile's W0 fragments, ahead of the stores
+        __syncthreads();
+        {
+            // thread (wave wn, lane) streams chunk `lane` of rows wn, wn + 8, ...: row & 15 = wn or wn + 8
+            uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)m0 * CH) + tid;   // the tile is contiguous in y
+            int rd_base[2];   // rows wn + 16k and wn + 8 + 16k
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                rd_base[par] = (wn + 8 * par) * (CH * 2) + ((lane ^ (wn + 8 * par)) << 4);
+                asm volatile("" : "+v"(rd_base[par]));
+            }
+#pragma unroll
+            for (int r = 0; r < BM / 8; ++r) {
+                const int row = wn + r * 8;
+                if (m0 + row < p.M)   // wave-uniform
+                    yo[r * 512] = *reinterpret_cast<const uint4 *>(img + rd_base[r & 1] + (r >> 1) * 16384);
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();   // image free for the next tile's phase 1; next patch visible to every wave
+    }
+}
+
+int g_num_cus = 0;
+
+template <int CIN, bool INVERSE>
+int launch_dec(const DecArgs &a, hipStream_t s) {
+    constexpr int KS1 = (4 * CIN + 31) / 32;
+    constexpr int lds = IMG_BYTES + KS1 * 8192;
+    static_assert(lds <= 160 * 1024, "image + patch must fit the CU's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2x2_gdn512_kernel<CIN, INVERSE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    if (g_num_cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        g_num_cus = n;
+    }
+    const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
+    hipLaunchKernelGGL((conv2x2_gdn512_kernel<CIN, INVERSE>), dim3(grid), dim3(512), lds, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+}  // namespace
+
+extern "C" int sc2_conv2x2_gdn512_supported(int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    return (Cin == 8 || Cin == 16 || Cin == 24 || Cin == 32) && Cout == 512 && KH == 2 && KW == 2 && stride == 1 &&
+                   pad == 1 ? 1 : 0;
+}
+
+extern "C" int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const void *gamma_packed,
+                                      const float *beta, void *y, int N, int H, int W, int Cin, int inverse,
+                                      void *stream) {
+    SC2_REQUIRE(x && w_packed && gamma_packed && beta && y, SC2_ERR_INVALID_ARG, "conv2x2_gdn512: null argument");
+    SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv2x2_gdn512: non-positive dimension");
+    SC2_REQUIRE(sc2_conv2x2_gdn512_supported(Cin, 512, 2, 2, 1, 1), SC2_ERR_UNSUPPORTED,
+                "conv2x2_gdn512: Cin %d not in {8,16,24,32}", Cin);
+    SC2_REQUIRE(Kpad == sc2_conv_weight_pitch(4 * Cin), SC2_ERR_INVALID_ARG, "conv2x2_gdn512: Kpad %d != %d", Kpad,
+                sc2_conv_weight_pitch(4 * Cin));
+    const long long M = (long long)N * (H + 1) * (W + 1);
+    SC2_REQUIRE(M < 0x7FFFFFFFLL - 256, SC2_ERR_UNSUPPORTED, "conv2x2_gdn512: N*OH*OW = %lld exceeds 2^31", M);
+    DecArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_packed);
+    a.g = static_cast<const uint16_t *>(gamma_packed);
+    a.beta = beta;
+    a.y = static_cast<uint16_t *>(y);
+    a.N = N; a.H = H; a.W = W; a.OH = H + 1; a.OW = W + 1; a.OHW = a.OH * a.OW; a.M = (int)M;
+    a.Kpad = Kpad; a.n_tiles = (int)((M + BM - 1) / BM); a.inverse = inverse ? 1 : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (Cin) {
+        case 8: return inverse ? launch_dec<8, true>(a, s) : launch_dec<8, false>(a, s);
+        case 16: return inverse ? launch_dec<16, true>(a, s) : launch_dec<16, false>(a, s);
+        case 24: return inverse ? launch_dec<24, true>(a, s) : launch_dec<24, false>(a, s);
+        default: return inverse ? launch_dec<32, true>(a, s) : launch_dec<32, false>(a, s);
+    }
+}

@@ -45,6 +45,8 @@ struct ConvArgs {
     int aop, epi, out;
     int g_pitch;   // fused GDN: row pitch (elements) of the packed gamma matrix handed in through ep_x
     int k_slab_major;   // K ordered (channel slab of 32, tap, channel) instead of (tap, channel): needs Cin % 32 == 0
+    int touch; // 1: pull the epilogue operand's lines into L2 with one dword load per 128-byte line before the K loop
+    int dbg;   // development switches (SC2_CONV_DEBUG): bit 0 skips the store epilogue, bit 1 the K loop
     int o_H, o_W, o_sh, o_sw, o_h0, o_w0;   // NHWC output scatter (o_H == 0: dense): pixel (oh, ow) -> (oh*o_sh+o_h0, ..)
 };
 
@@ -82,8 +84,10 @@ struct Cfg {
     static constexpr int XC = (BN + 31) / 32 * 4;          // 16-byte chunks per row (K of the second GEMM, padded to 32)
     static constexpr int XSW = (XC % 8 == 0) ? 7 : 3;      // chunk XOR mask: conflict-free ds_read_b128 for XC = 8 / 12
     static constexpr int FUSE_LDS = (BM + BN) * XC * 16;
+    static constexpr int IMG_LDS = BM * (BN * 2 + 16);     // bf16 store image (ImgPad)
     static constexpr int LDS0 = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
-    static constexpr int LDS_BYTES = LDS0 > FUSE_LDS ? LDS0 : FUSE_LDS;
+    static constexpr int LDS1 = LDS0 > FUSE_LDS ? LDS0 : FUSE_LDS;
+    static constexpr int LDS_BYTES = LDS1 > IMG_LDS ? LDS1 : IMG_LDS;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(BM % (WAVES_M * 16) == 0 && BN % (WAVES_N * 16) == 0, "wave tiling");
     static_assert(BM % 64 == 0, "A rows per wave-instruction");
@@ -105,43 +109,196 @@ __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
     return v;
 }
 
-// Stores a workgroup's accumulator tile: MT passes, pass i stages tile-row i of every wave (WAVES_M*16 rows x BN cols,
-// f32) through LDS so that global stores are whole 16-byte channel runs (NHWC) or pixel runs (NCHW), with the
-// element-wise epilogues (GDN / IGDN / bias / ReLU / residual) applied on the way out.  Call with the LDS idle.
-// chunk tasks of one store pass handled by one thread
-template <class C, int NTHREADS>
-struct EpiGeom {
-    static constexpr int CPR = C::BN / 8;
-    static constexpr int QPT = (C::STAGE_ROWS * CPR + NTHREADS - 1) / NTHREADS;
+// ------------------------------------------------------------------------------------------------ store epilogue
+// Accumulator layout.  The MFMAs are issued with the WEIGHT fragment as the A operand and the activation fragment as
+// the B operand, so D = W X^T and lane (frow, fq) of accumulator tile (i, j) holds FOUR CONSECUTIVE CHANNELS
+//     out[pixel = wm*WM + i*16 + frow][channel = wn*WN + j*16 + fq*4 + e],  e = 0..3
+// i.e. 8 contiguous bytes of the bf16 NHWC output: one ds_write_b64 per accumulator tile instead of four scalar
+// writes, and the element-wise epilogues see their per-channel operands as float4.
+//
+// bf16 NHWC (the format between kernels): ONE pass.  The whole BM x BN tile is transposed through a bf16 LDS image
+// (rows padded by 16 B, or chunk-XOR-swizzled for the 8-wave tiles): the epilogue operand x (GDN / residual) is
+// parked in the image with coalesced 16-byte accesses, every lane updates its 8-byte slots in place in f32
+// (x -> y), and the image is streamed out in whole 16-byte channel runs.  Measured before this layout
+// (tools/epi_share.sh): the 4-pass f32 staging cost as much as the whole K loop on the K <= 512 layers.
+// f32 outputs (latent, module-level API, fc): MT passes through an f32 staging buffer, as before.
+template <class C>
+struct ImgPad {   // 4-wave tiles: row pitch BN*2 + 16 bytes (ds_write_b64 of 16 rows: 2-way conflicts at worst)
+    static constexpr int PITCH = C::BN * 2 + 16;
+    static constexpr int BYTES = C::BM * PITCH;
+    static __device__ __forceinline__ int off(int row, int c16) { return row * PITCH + (c16 << 4); }
+};
+template <class C>
+struct ImgXor {   // 8-wave tiles (BN*2/16 >= 16 chunks per row): power-of-two pitch, chunk index XOR (row & 15)
+    static constexpr int PITCH = C::BN * 2;
+    static constexpr int BYTES = C::BM * PITCH;
+    static __device__ __forceinline__ int off(int row, int c16) { return row * PITCH + ((c16 ^ (row & 15)) << 4); }
 };
 
-// Issues, before the main loop, the loads of the epilogue operand (GDN's x / the residual) this thread will need in
-// conv_store_tile: their latency hides behind the whole K loop instead of being exposed once per store pass.
+template <class C, int NTHREADS>
+struct EpiGeom {
+    static constexpr int CPR = C::BN / 8;                                  // 16-byte chunks per tile row
+    static constexpr int Q = C::BM * CPR;                                  // chunks per tile
+    static constexpr int QPT = (Q + NTHREADS - 1) / NTHREADS;              // chunks per thread
+    static constexpr int QPT_PASS = (C::STAGE_ROWS * CPR + NTHREADS - 1) / NTHREADS;   // f32 staging passes
+};
+
+// Issues, before the main loop, the loads of the epilogue operand (GDN's x / the residual) this thread will park in
+// the LDS image: their latency hides behind the whole K loop.
 template <class C, int NTHREADS>
 __device__ __forceinline__ void conv_prefetch_epx(const ConvArgs &p, int tid, int m0, int n0,
-                                                  uint4 (&epx)[C::MT][EpiGeom<C, NTHREADS>::QPT]) {
-    constexpr int CPR = EpiGeom<C, NTHREADS>::CPR, QPT = EpiGeom<C, NTHREADS>::QPT;
+                                                  uint4 (&epx)[EpiGeom<C, NTHREADS>::QPT]) {
+    constexpr int CPR = EpiGeom<C, NTHREADS>::CPR, QPT = EpiGeom<C, NTHREADS>::QPT, Q = EpiGeom<C, NTHREADS>::Q;
 #pragma unroll
-    for (int i = 0; i < C::MT; ++i)
+    for (int r = 0; r < QPT; ++r) {
+        const int q = tid + r * NTHREADS;
+        const int row = q / CPR, cc = q - row * CPR;
+        const int m = m0 + row, n = n0 + cc * 8;
+        const bool ok = (q < Q) & (m < p.M) & (n < p.Cout);
+        epx[r] = ok ? *reinterpret_cast<const uint4 *>(p.ep_x + (long long)m * p.Cout + n) : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// L2 prefetch of the epilogue operand tile (gfx950 has no prefetch instruction): one dword load per 128-byte line into
+// a scratch register that nothing reads; the load is the oldest entry of the wave's vmcnt queue, so the counted waits of
+// the K loop retire it with the first slab.  Costs one VGPR instead of the 32 of the register prefetch.
+template <class C, int NTHREADS>
+struct TouchGeom {
+    static constexpr int LPR = (C::BN * 2 + 127) / 128;            // lines per tile row
+    static constexpr int NL = C::BM * LPR;
+    static constexpr int TPT = (NL + NTHREADS - 1) / NTHREADS;     // touches per thread
+};
+// The destination registers must stay reserved until the loads have returned (the compiler cannot see the pending
+// writes of an asm load): the caller passes `sink` to conv_touch_done() after a vmcnt wait that covers them.
+template <class C, int NTHREADS>
+__device__ __forceinline__ void conv_touch_epx(const ConvArgs &p, int tid, int m0, int n0,
+                                               uint32_t (&sink)[TouchGeom<C, NTHREADS>::TPT]) {
+    constexpr int LPR = TouchGeom<C, NTHREADS>::LPR, NL = TouchGeom<C, NTHREADS>::NL;
+#pragma unroll
+    for (int r = 0; r < TouchGeom<C, NTHREADS>::TPT; ++r) {
+        const int q = tid + r * NTHREADS;
+        const int row = q / LPR, cl = q - row * LPR;
+        const int m = m0 + row, n = n0 + cl * 64;
+        const bool ok = (q < NL) & (m < p.M) & (n < p.Cout);
+        const uint16_t *src = ok ? p.ep_x + (long long)m * p.Cout + n : p.ep_x;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(sink[r]) : "v"(src) : "memory");
+    }
+}
+template <int N>
+__device__ __forceinline__ void conv_touch_done(uint32_t (&sink)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm volatile("" ::"v"(sink[r]));
+}
+
+__device__ __forceinline__ long long conv_out_offset(const ConvArgs &p, int m, int n, bool &ok) {
+    ok = true;
+    if (p.o_H > 0) {   // strided scatter (transposed-convolution parity classes of the data gradient)
+        const int img = m / p.OHW;
+        const int rem = m - img * p.OHW;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int yh = oh * p.o_sh + p.o_h0, yw = ow * p.o_sw + p.o_w0;
+        ok = (yh < p.o_H) & (yw < p.o_W);
+        return (((long long)img * p.o_H + yh) * p.o_W + yw) * p.Cout + n;
+    }
+    return (long long)m * p.Cout + n;
+}
+
+// bf16 NHWC store through the LDS image `img` (Img::BYTES, idle LDS).  x_in_image: the image already holds the
+// epilogue operand x (the fused conv + GDN1 of the 256-wide tile leaves it there).
+template <class C, class Img, int NTHREADS, bool PREFETCHED>
+__device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned char *img, f32x4_t (&acc)[C::MT][C::NT],
+                                                     int tid, int wm, int wn, int frow, int fq, int m0, int n0, int epi,
+                                                     const uint4 *epx, bool x_in_image) {
+    constexpr int MT = C::MT, NT = C::NT;
+    constexpr int CPR = EpiGeom<C, NTHREADS>::CPR, QPT = EpiGeom<C, NTHREADS>::QPT, Q = EpiGeom<C, NTHREADS>::Q;
+    const int Cout = p.Cout;
+    const bool needs_x = epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU;
+    if (needs_x && !x_in_image) {
 #pragma unroll
         for (int r = 0; r < QPT; ++r) {
             const int q = tid + r * NTHREADS;
-            const int sr = q / CPR, cc = q - sr * CPR;
-            const int m = m0 + (sr >> 4) * C::WM + i * 16 + (sr & 15);
-            const int n = n0 + cc * 8;
-            const bool ok = (q < C::STAGE_ROWS * CPR) & (m < p.M) & (n < p.Cout);
-            epx[i][r] = ok ? *reinterpret_cast<const uint4 *>(p.ep_x + (long long)m * p.Cout + n)
-                           : make_uint4(0u, 0u, 0u, 0u);
+            const int row = q / CPR, cc = q - row * CPR;
+            if (q < Q) {
+                uint4 v;
+                if (PREFETCHED) {
+                    v = epx[r];
+                } else {
+                    const int m = m0 + row, n = n0 + cc * 8;
+                    v = ((m < p.M) & (n < Cout)) ? *reinterpret_cast<const uint4 *>(p.ep_x + (long long)m * Cout + n)
+                                                 : make_uint4(0u, 0u, 0u, 0u);
+                }
+                *reinterpret_cast<uint4 *>(img + Img::off(row, cc)) = v;
+            }
         }
+        __syncthreads();
+    }
+    float4 bj[NT];
+    if (epi != SC2_EPI_NONE) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * C::WN + j * 16 + fq * 4;
+            bj[j] = n < Cout ? *reinterpret_cast<const float4 *>(p.ep_beta + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = wm * C::WM + i * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = wn * C::WN + j * 16 + fq * 4;
+            unsigned char *slot = img + Img::off(row, col >> 3) + (col & 7) * 2;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (epi != SC2_EPI_NONE) {
+                float xv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (needs_x) {
+                    const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
+                    xv[0] = __builtin_bit_cast(float, xr.x << 16);
+                    xv[1] = __builtin_bit_cast(float, xr.x & 0xFFFF0000u);
+                    xv[2] = __builtin_bit_cast(float, xr.y << 16);
+                    xv[3] = __builtin_bit_cast(float, xr.y & 0xFFFF0000u);
+                }
+                const float b[4] = {bj[j].x, bj[j].y, bj[j].z, bj[j].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float norm = b[t] + v[t];
+                    float r;
+                    if (epi == SC2_EPI_GDN) r = xv[t] * (1.0f / norm);
+                    else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
+                    else if (epi == SC2_EPI_BIAS) r = norm;
+                    else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
+                    else r = fmaxf(norm + xv[t], 0.f);
+                    v[t] = r;
+                }
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2 *>(slot) = o;
+        }
+    }
+    __syncthreads();
+    uint16_t *y = reinterpret_cast<uint16_t *>(p.y);
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int q = tid + r * NTHREADS;
+        const int row = q / CPR, cc = q - row * CPR;
+        const int m = m0 + row, n = n0 + cc * 8;
+        if ((q < Q) & (m < p.M) & (n < Cout)) {
+            bool ok;
+            const long long o = conv_out_offset(p, m, n, ok);
+            if (ok) *reinterpret_cast<uint4 *>(y + o) = *reinterpret_cast<const uint4 *>(img + Img::off(row, cc));
+        }
+    }
 }
 
-// x_img != nullptr: the GDN operand x is an LDS-resident bf16 image [tile row][512 B], chunk XOR (row & 15) (the
-// fused conv + IGDN of the 256-wide big tile); `smem` is then the staging area, with unpadded rows (rs_override).
-template <class C, int NTHREADS, bool PREFETCHED = false>
-__device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char *smem, f32x4_t (&acc)[C::MT][C::NT],
-                                                int tid, int wm, int wn, int frow, int fq, int m0, int n0, int epi,
-                                                const uint4 (*epx)[EpiGeom<C, NTHREADS>::QPT] = nullptr,
-                                                const unsigned char *x_img = nullptr, int rs_override = 0) {
+// f32 outputs: MT passes, pass i stages tile-row i of every wave (WAVES_M*16 rows x BN cols, f32) through LDS so
+// that global stores are whole channel runs (NHWC) or pixel runs (NCHW), element-wise epilogue applied on the way
+// out.  x_img != nullptr: the GDN operand x is an LDS-resident bf16 image [tile row][512 B], chunk XOR (row & 15)
+// (fused conv + IGDN of the 256-wide tile); `smem` is then the staging area with unpadded rows (rs_override).
+template <class C, int NTHREADS>
+__device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned char *smem, f32x4_t (&acc)[C::MT][C::NT],
+                                                    int tid, int wm, int wn, int frow, int fq, int m0, int n0, int epi,
+                                                    const unsigned char *x_img = nullptr, int rs_override = 0) {
     constexpr int BN = C::BN, MT = C::MT, NT = C::NT;
     float *stage = reinterpret_cast<float *>(smem);
     const bool nchw = p.out == SC2_OUT_F32_NCHW;
@@ -154,8 +311,8 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
         for (int j = 0; j < NT; ++j) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int sr = wm * 16 + fq * 4 + e;
-                const int sc = wn * C::WN + j * 16 + frow;
+                const int sr = wm * 16 + frow;
+                const int sc = wn * C::WN + j * 16 + fq * 4 + e;
                 stage[sr * RS + sc] = acc[i][j][e];
             }
         }
@@ -163,7 +320,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
         if (!nchw) {
             constexpr int CPR = BN / 8;  // 8-channel chunks per row
 #pragma unroll
-            for (int rq = 0; rq < EpiGeom<C, NTHREADS>::QPT; ++rq) {
+            for (int rq = 0; rq < EpiGeom<C, NTHREADS>::QPT_PASS; ++rq) {
                 const int q = tid + rq * NTHREADS;
                 if (q >= C::STAGE_ROWS * CPR) continue;
                 const int sr = q / CPR, cc = q - sr * CPR;
@@ -177,16 +334,9 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
                     v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
                     v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
                 }
-                long long o = (long long)m * Cout + n;
-                const long long o_ep = o;   // epilogue operands (ep_x) are always dense
-                if (p.o_H > 0) {   // strided scatter (transposed-convolution parity classes of the data gradient)
-                    const int img = m / p.OHW;
-                    const int rem = m - img * p.OHW;
-                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                    const int yh = oh * p.o_sh + p.o_h0, yw = ow * p.o_sw + p.o_w0;
-                    if (yh >= p.o_H || yw >= p.o_W) continue;
-                    o = (((long long)img * p.o_H + yh) * p.o_W + yw) * Cout + n;
-                }
+                bool ok;
+                const long long o = conv_out_offset(p, m, n, ok);
+                if (!ok) continue;
                 if (epi != SC2_EPI_NONE) {
                     float b[8];
                     {
@@ -202,7 +352,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
                             const int trow = (sr >> 4) * C::WM + i * 16 + (sr & 15);
                             xr = *reinterpret_cast<const uint4 *>(x_img + trow * 512 + ((cc ^ (trow & 15)) << 4));
                         } else {
-                            xr = PREFETCHED ? epx[i][rq] : *reinterpret_cast<const uint4 *>(p.ep_x + o_ep);
+                            xr = *reinterpret_cast<const uint4 *>(p.ep_x + (long long)m * Cout + n);   // always dense
                         }
                         const uint32_t xw[4] = {xr.x, xr.y, xr.z, xr.w};
 #pragma unroll
@@ -226,18 +376,9 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
                         v[t] = r;
                     }
                 }
-                if (p.out == SC2_OUT_BF16_NHWC) {
-                    uint4 ov;
-                    ov.x = pack_bf16x2(v[0], v[1]);
-                    ov.y = pack_bf16x2(v[2], v[3]);
-                    ov.z = pack_bf16x2(v[4], v[5]);
-                    ov.w = pack_bf16x2(v[6], v[7]);
-                    *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(p.y) + o) = ov;
-                } else {
-                    float *yo = reinterpret_cast<float *>(p.y) + o;
-                    *reinterpret_cast<float4 *>(yo) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4 *>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                }
+                float *yo = reinterpret_cast<float *>(p.y) + o;
+                *reinterpret_cast<float4 *>(yo) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4 *>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
             }
         } else {
             // f32 NCHW: lanes run along pixels so each channel plane gets contiguous runs.
@@ -250,8 +391,15 @@ __device__ __forceinline__ void conv_store_tile(const ConvArgs &p, unsigned char
                 if (epi != SC2_EPI_NONE) {
                     const float norm = p.ep_beta[n] + v;
                     float xv = 0.f;
-                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU)
-                        xv = bf16_bits_to_f32(p.ep_x[(long long)m * Cout + n]);
+                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
+                        if (x_img) {
+                            const int trow = (sr >> 4) * C::WM + i * 16 + (sr & 15);
+                            xv = bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(
+                                x_img + trow * 512 + (((cidx >> 3) ^ (trow & 15)) << 4) + (cidx & 7) * 2));
+                        } else {
+                            xv = bf16_bits_to_f32(p.ep_x[(long long)m * Cout + n]);
+                        }
+                    }
                     if (epi == SC2_EPI_GDN) v = xv * (1.0f / norm);
                     else if (epi == SC2_EPI_IGDN) v = xv * norm;
                     else if (epi == SC2_EPI_BIAS) v = norm;
@@ -346,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         }
     };
     if (!(C::STATIC ? (C::CIN % 32 == 0) : (Cin % 32 == 0))) wrap_k();
-    const int KT = p.KT;
+    const int KT = (p.dbg & 2) ? 0 : p.KT;
 
     // When Cin % 32 == 0 a slab never straddles a filter tap: tap and channel base are wave-uniform closed forms of
     // the slab index (scalar registers).  With k_slab_major the K axis runs (channel slab, tap, channel): the taps of
@@ -412,8 +560,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     for (int j = 0; j < NT; ++j) b_rd[j] = (uint32_t)(C::A_BYTES + lds_off(wn * C::WN + j * 16 + frow, fq));
 
     // epilogue operand (GDN's x / residual), fetched now so that its latency hides behind the K loop
-    uint4 epx[C::EPX ? MT : 1][EpiGeom<C, 256>::QPT];
+    uint4 epx[C::EPX ? EpiGeom<C, 256>::QPT : 1];
     if constexpr (C::EPX) conv_prefetch_epx<C, 256>(p, tid, m0, n0, epx);
+    uint32_t touch_sink[TouchGeom<C, 256>::TPT] = {};
+    if (!C::EPX && p.touch) conv_touch_epx<C, 256>(p, tid, m0, n0, touch_sink);
 
 #pragma unroll
     for (int st = 0; st < S - 1; ++st) issue_tile(st, st);
@@ -454,13 +604,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // D = W X^T
 #if SC2_CONV_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
     }
     // drain the dummy slabs and make sure every wave is done reading before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    conv_touch_done(touch_sink);
     __builtin_amdgcn_s_barrier();
 
     // ------------------------------------------------------------------ fused GDN1 / inverse GDN1
@@ -481,15 +632,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = wm * C::WM + i * 16 + fq * 4 + e;
-                    const int col = wn * C::WN + j * 16 + frow;
-                    const uint16_t h = f32_to_bf16_bits(acc[i][j][e]) & 0x7FFFu;   // |x|
-                    *reinterpret_cast<uint16_t *>(Xi + r * ROWB + (((col >> 3) ^ ((r >> 1) & XSW)) << 4) +
-                                                  (col & 7) * 2) = h;
-                }
+            for (int j = 0; j < NT; ++j) {
+                const int r = wm * C::WM + i * 16 + frow;
+                const int col = wn * C::WN + j * 16 + fq * 4;   // 4 consecutive channels of pixel r
+                uint2 h;                                        // |x| as bf16
+                h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]) & 0x7FFF7FFFu;
+                h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]) & 0x7FFF7FFFu;
+                *reinterpret_cast<uint2 *>(Xi + r * ROWB + (((col >> 3) ^ ((r >> 1) & XSW)) << 4) + (col & 7) * 2) = h;
+            }
         const uint16_t *gamma = p.ep_x;   // packed bf16 [rows >= BN][g_pitch], zero padded
         for (int q = tid; q < BN * XC; q += 256) {
             const int r = q / XC, c = q - r * XC;
@@ -521,29 +671,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    nrm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[i], gb[j], nrm[i][j], 0, 0, 0);
+                    nrm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb[j], xa[i], nrm[i][j], 0, 0, 0);
         }
         const bool inverse = p.epi == SC2_EPI_FUSED_IGDN;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn * C::WN + j * 16 + frow;
-            const float b = col < p.Cout ? p.ep_beta[col] : 1.0f;
+            const int col = n0 + wn * C::WN + j * 16 + fq * 4;
+            const float4 b4 = col < p.Cout ? *reinterpret_cast<const float4 *>(p.ep_beta + col)
+                                           : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float norm = b + nrm[i][j][e];
+                    const float norm = b[e] + nrm[i][j][e];
                     acc[i][j][e] = inverse ? acc[i][j][e] * norm : acc[i][j][e] * (1.0f / norm);
                 }
         }
         __syncthreads();   // the images are dead; the staging buffer below reuses their LDS
     }
     const int epi = (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) ? (int)SC2_EPI_NONE : p.epi;
+    if (p.dbg & 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
 
-    if constexpr (C::EPX)
-        conv_store_tile<C, 256, true>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi, epx);
+    if (p.out == SC2_OUT_BF16_NHWC)
+        conv_store_tile_bf16<C, ImgPad<C>, 256, C::EPX>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi, epx, false);
     else
-        conv_store_tile<C, 256, false>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi);
+        conv_store_tile_f32<C, 256>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi);
 }
 
 // ======================================================================================================
@@ -575,8 +734,10 @@ struct Cfg8 {
     static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
     // fused conv + GDN1 (BN == 256 == Cout): x image 256 x 512 B + a 2 x 16 KB gamma-slab ring / store staging
     static constexpr int FUSE_LDS = BN == 256 ? 256 * 512 + 32768 : 0;
+    static constexpr int IMG_LDS = BM * BN * 2;            // bf16 store image (ImgXor)
     static constexpr int LDS1 = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
-    static constexpr int LDS_BYTES = LDS1 > FUSE_LDS ? LDS1 : FUSE_LDS;
+    static constexpr int LDS2 = LDS1 > FUSE_LDS ? LDS1 : FUSE_LDS;
+    static constexpr int LDS_BYTES = LDS2 > IMG_LDS ? LDS2 : IMG_LDS;
     static_assert(WAVES_M * WAVES_N == 8 && NT == 4 && MT % 4 == 0, "8 waves, 16 MFMAs per phase");
     static_assert(BN % 128 == 0, "whole direct-to-LDS instructions per wave");
 };
@@ -659,7 +820,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
         }
     };
     if (!aligned) wrap_k();
-    const int KT = p.KT;
+    const int KT = (p.dbg & 2) ? 0 : p.KT;
     int next_a = 0;   // slab index the next issue_a() call fetches
 
     auto issue_a = [&](int buf) {   // A rows of the next unissued slab
@@ -762,7 +923,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[4 * ph + i][j] =
-                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[4 * ph + i][j], 0, 0, 0);
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[4 * ph + i][j], 0, 0, 0);   // D = W X^T
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -773,6 +934,13 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy slabs past KT
     __builtin_amdgcn_s_barrier();
 
+    if (p.dbg & 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
     // ---- conv followed by GDN1 / inverse GDN1 in the same launch (the tile holds all 256 channels of its pixels):
     // x goes to an LDS image as bf16, norm = gamma |x| is a second MFMA GEMM whose A operand is that image (|.| on the
     // fragment) and whose B operand, gamma, streams through a 2-slab direct-to-LDS ring; y = x * (beta + norm) (or
@@ -784,15 +952,15 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = wm * C::WM + i * 16 + fq * 4 + e;
-                        const int col = wn * C::WN + j * 16 + frow;
-                        *reinterpret_cast<uint16_t *>(Xi + r * 512 + (((col >> 3) ^ (r & 15)) << 4) + (col & 7) * 2) =
-                            f32_to_bf16_bits(acc[i][j][e]);
-                        acc[i][j][e] = 0.f;
-                    }
+                for (int j = 0; j < NT; ++j) {
+                    const int r = wm * C::WM + i * 16 + frow;
+                    const int col = wn * C::WN + j * 16 + fq * 4;
+                    uint2 h;
+                    h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                    h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                    *reinterpret_cast<uint2 *>(Xi + r * 512 + (((col >> 3) ^ (r & 15)) << 4) + (col & 7) * 2) = h;
+                    acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
             const uint16_t *gamma = p.ep_x;
             const long long zero_off_g = zero - gamma;
             (void)zero_off_g;
@@ -828,17 +996,24 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
                     const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8_t, gb[j]),
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, gb[j]), af,
                                                                             acc[i][j], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_s_barrier();   // every wave is done with the gamma ring: it becomes the store staging area
-            conv_store_tile<C, 512>(p, ring, acc, tid, wm, wn, frow, fq, m0, n0,
-                                    p.epi == SC2_EPI_FUSED_IGDN ? (int)SC2_EPI_IGDN : (int)SC2_EPI_GDN, nullptr, Xi, BN);
+            __builtin_amdgcn_s_barrier();   // every wave is done with the gamma ring and with its x-image fragments
+            const int epi2 = p.epi == SC2_EPI_FUSED_IGDN ? (int)SC2_EPI_IGDN : (int)SC2_EPI_GDN;
+            if (p.out == SC2_OUT_BF16_NHWC)   // x -> y in place in the image, then streamed out
+                conv_store_tile_bf16<C, ImgXor<C>, 512, false>(p, Xi, acc, tid, wm, wn, frow, fq, m0, n0, epi2, nullptr,
+                                                               true);
+            else                              // the ring becomes the f32 staging area, x read back from the image
+                conv_store_tile_f32<C, 512>(p, ring, acc, tid, wm, wn, frow, fq, m0, n0, epi2, Xi, BN);
             return;
         }
     }
-    conv_store_tile<C, 512>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi);
+    if (p.out == SC2_OUT_BF16_NHWC)
+        conv_store_tile_bf16<C, ImgXor<C>, 512, false>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi, nullptr, false);
+    else
+        conv_store_tile_f32<C, 512>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi);
 }
 
 template <class C>
@@ -1021,6 +1196,16 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.aop = d->a_op; a.epi = d->epilogue; a.out = d->out_format;
     a.g_pitch = sc2_conv_weight_pitch(d->Cout);
     a.k_slab_major = d->k_order == SC2_K_SLAB_MAJOR;
+    {
+        const char *dbg = getenv("SC2_CONV_DEBUG");
+        a.dbg = dbg ? atoi(dbg) : 0;
+    }
+    const bool needs_x_operand =
+        d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS_ADD_RELU;
+    {
+        const char *t = getenv("SC2_CONV_TOUCH");
+        a.touch = (needs_x_operand && d->out_format == SC2_OUT_BF16_NHWC && !scatter && t && atoi(t)) ? 1 : 0;
+    }
     a.o_H = scatter ? d->out_H : 0; a.o_W = d->out_W; a.o_sh = d->out_stride_h; a.o_sw = d->out_stride_w;
     a.o_h0 = d->out_off_h; a.o_w0 = d->out_off_w;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1041,8 +1226,9 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         return launch8<BG_256>(a, s);
     }
     if (big && d->Cout % 128 == 0) return launch8<BG_128>(a, s);
-    const bool epx = (d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS_ADD_RELU) &&
-                     d->out_format != SC2_OUT_F32_NCHW && !scatter;
+    bool epx = needs_x_operand &&
+                     d->out_format == SC2_OUT_BF16_NHWC && !scatter && !getenv("SC2_CONV_NO_EPX");
+    if (a.touch) epx = false;
     if (epx) {
         if (rows == 96 && matches<Cx_gdn96>(a)) return launch<Cx_gdn96>(a, s);
         if (rows == 48 && matches<Cx_gdn48>(a)) return launch<Cx_gdn48>(a, s);

@@ -24,7 +24,8 @@ EB_PARAM_STRIDE = 64
 ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
-    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv2d_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv2d_fwd',
+    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
@@ -62,6 +63,8 @@ def lib():
     L.sc2_conv_weight_pitch.argtypes = [i32]
     L.sc2_conv_fused_gdn_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
+    L.sc2_conv2x2_gdn512_supported.argtypes = [i32] * 6
+    L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
     L.sc2_gdn_bwd_pre.argtypes = [vp, vp, vp, ctypes.c_longlong, i32, i32, vp, vp, vp, vp]
     L.sc2_gdn_bwd_post.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
@@ -395,6 +398,29 @@ def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilo
     with _timed(tag or 'conv{}x{}_{}to{}'.format(kh, kw, Cin, cout)):
         _check(lib().sc2_conv2d_fwd(ctypes.byref(d), _ptr(x_nhwc), _ptr(w_packed), _ptr(out), _ptr(ep_x),
                                     _ptr(ep_beta), _stream()), 'conv2d_fwd')
+    return out
+
+
+def conv2x2_gdn512_supported(cin, cout, kh, kw, stride, pad):
+    """True if Conv2d(cin -> 512, k2, s1, p1) followed by a 512-channel GDN1 runs as the single fused launch."""
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    return sh == sw and ph == pw and bool(lib().sc2_conv2x2_gdn512_supported(cin, cout, kh, kw, sh, ph))
+
+
+def conv2x2_gdn512_fwd(x_nhwc, w_packed, gamma_packed, beta, inverse, tag=None):
+    """y = GDN1_512(conv2x2(x)) (s1, p1) in one launch; x bf16 [N,H,W,Cin] -> bf16 [N,H+1,W+1,512]."""
+    for t, name in ((x_nhwc, 'x'), (w_packed, 'w_packed'), (gamma_packed, 'gamma_packed'), (beta, 'beta')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, Cin = x_nhwc.shape
+    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous() and w_packed.shape[0] == 512
+    assert gamma_packed.dtype == torch.bfloat16 and gamma_packed.is_contiguous() and tuple(gamma_packed.shape) == (512, 512)
+    assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 512
+    out = torch.empty((N, H + 1, W + 1, 512), dtype=torch.bfloat16, device=x_nhwc.device)
+    with _timed(tag or 'conv2x2_gdn512'):
+        _check(lib().sc2_conv2x2_gdn512_fwd(_ptr(x_nhwc), _ptr(w_packed), w_packed.shape[1], _ptr(gamma_packed), _ptr(beta),
+                                            _ptr(out), N, H, W, Cin, 1 if inverse else 0, _stream()), 'conv2x2_gdn512_fwd')
     return out
 
 

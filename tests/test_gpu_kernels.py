@@ -261,6 +261,42 @@ def test_conv_fused_gdn_big_tile(S, R, dev, monkeypatch, cin, k, pad, inverse):
     assert not S.hip.conv_fused_gdn_supported(tuple(x_nhwc.shape), cout, k, k, 1, pad)   # too few rows un-forced
 
 
+@pytest.mark.parametrize('cin,inverse,N,H,W', [(24, True, 3, 7, 9), (24, False, 2, 5, 5), (16, True, 1, 12, 11),
+                                               (32, True, 2, 6, 6), (8, True, 5, 9, 9)])
+def test_conv2x2_gdn512_fused(S, R, dev, cin, inverse, N, H, W):
+    """decoder[0] + decoder[1] (Conv k2 p1 -> 512, GDN1(512)) in one persistent launch vs the oracle ops on the
+    bf16-rounded operands; several tiles per workgroup, ragged last tile, image borders."""
+    cout = 512
+    torch.manual_seed(cin + N)
+    gdn = R.GDN1(cout, inverse=inverse)
+    with torch.no_grad():
+        gdn.gamma.add_(0.05 * torch.rand(cout, cout) / cout ** 0.5)
+        gdn.beta.add_(0.1 * torch.rand(cout))
+    x = torch.randn(N, cin, H, W)
+    w = torch.randn(cout, cin, 2, 2) / (cin * 4) ** 0.5
+    with torch.no_grad():
+        conv = F.conv2d(bf16_round(x), bf16_round(w), padding=1)
+        beta = gdn.beta_reparam(gdn.beta)
+        gamma = bf16_round(gdn.gamma_reparam(gdn.gamma))
+        tb = bf16_round(conv)   # t enters the second GEMM and the final product as bf16 (LDS image)
+        norm = F.conv2d(tb.abs(), gamma.reshape(cout, cout, 1, 1), beta)
+        ref = tb * norm if inverse else tb / norm
+    m = S.GDN1(cout, inverse=inverse)
+    m.load_state_dict(gdn.state_dict())
+    m.to(dev)
+    beta_d, gamma_d = m.effective()
+    assert S.hip.conv2x2_gdn512_supported(cin, cout, 2, 2, 1, 1)
+    assert not S.hip.conv2x2_gdn512_supported(cin, 256, 2, 2, 1, 1)
+    assert not S.hip.conv2x2_gdn512_supported(cin, cout, 2, 2, 1, 0)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    out = S.hip.conv2x2_gdn512_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), gamma_d, beta_d, inverse)
+    assert out.shape == (N, H + 1, W + 1, cout)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'fused conv2x2 + gdn512', extra=2.0 ** -8)
+    # and the same result as the two-launch path (conv -> GDN1) up to the bf16 rounding of its intermediate
+    two = m.forward_nhwc(S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 2, 2, 1, 1))
+    assert_close_bf16(out, two, 'fused vs two launches', extra=2.0 ** -7)
+
+
 def _golden():
     return torch.load(os.path.join(HERE, 'golden', 'fp_golden.pt'), weights_only=False)
 

@@ -74,8 +74,17 @@ def main():
         rows.append(('dec.conv0', timeit(lambda: d0.forward_nhwc(yh), args.iters), 308.3e6 * N, yh.numel() * 2 + b0.numel() * 2))
         b1 = h1.forward_nhwc(b0)
         rows.append(('dec.igdn512', timeit(lambda: h1.forward_nhwc(b0), args.iters), 1644.2e6 * N, b0.numel() * 4 + b1.numel() * 2))
+        if hip.conv2x2_gdn512_supported(24, 512, 2, 2, 1, 1):
+            beta1, gamma1 = h1.effective()
+            rows.append(('dec.conv0+igdn512', timeit(lambda: hip.conv2x2_gdn512_fwd(yh, d0.packed_weight(), gamma1, beta1, True), args.iters),
+                         (308.3e6 + 1644.2e6) * N, yh.numel() * 2 + b1.numel() * 2))
         b2 = d2.forward_nhwc(b1)
         rows.append(('dec.conv2', timeit(lambda: d2.forward_nhwc(b1), args.iters), 3171.9e6 * N, b1.numel() * 2 + b2.numel() * 2))
+        if hip.conv_fused_gdn_supported(tuple(b1.shape), 256, 2, 2, 1, 0):
+            beta3, gamma3 = h3.effective()
+            rows.append(('dec.conv2+igdn256', timeit(lambda: hip.conv2d_fwd(b1, d2.packed_weight(), 256, 2, 2, 1, 0, epilogue=hip.EPI_FUSED_IGDN,
+                                                                              ep_x=gamma3, ep_beta=beta3, k_order=d2.k_order()), args.iters),
+                         (3171.9e6 + 396.5e6) * N, b1.numel() * 2 + b2.numel() * 2))
         b3 = h3.forward_nhwc(b2)
         rows.append(('dec.igdn256', timeit(lambda: h3.forward_nhwc(b2), args.iters), 396.5e6 * N, b2.numel() * 4 + b3.numel() * 2))
         b4 = d4.forward_nhwc(b3)
