@@ -36,16 +36,24 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 BOTTLENECK_GFLOP_PER_IMG = 8.3418
-# algorithmic MFLOP per image of each tagged kernel (2 * MACs)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy achieves
-KERNEL_MFLOP = {'enc.conv0': 180.6 + 231.2, 'enc.gdn1': 231.2, 'enc.conv2': 722.5 + 14.5, 'enc.gdn3': 14.5,
-                'enc.conv4': 27.9, 'dec.conv0': 308.3, 'dec.igdn1': 1644.2, 'dec.conv2': 3171.9, 'dec.igdn3': 396.5,
-                'dec.conv4': 1644.2}   # enc.conv0 / enc.conv2 launches include their fused GDN1
-# algorithmic HBM bytes per image of each launch: bf16 activations in + out (+ the epilogue operand of the unfused
-# IGDN launches, which read x twice); weights (< 2.6 MB in total, L2-resident) are not counted
-KERNEL_MBYTE = {'enc.conv0': 0.401 + 2.408, 'enc.gdn1': 3 * 2.408, 'enc.conv2': 2.408 + 0.301, 'enc.gdn3': 3 * 0.301,
-                'enc.conv4': 0.301 + 0.290, 'dec.conv0': 0.145 + 3.211, 'dec.igdn1': 3 * 3.211,
-                'dec.conv2': 3.211 + 1.549, 'dec.igdn3': 3 * 1.549, 'dec.conv4': 1.549 + 1.606}
+# per image, 224x224: algorithmic MFLOP (2 * MACs), bf16 activation MB read, MB written.  Weights
+# (< 2.6 MB in total, L2-resident) are not counted.
+OPS = {'enc.conv0': (180.6, 0.401, 2.408), 'enc.gdn1': (231.2, 2.408, 2.408), 'enc.conv2': (722.5, 2.408, 0.301),
+       'enc.gdn3': (14.5, 0.301, 0.301), 'enc.conv4': (27.9, 0.301, 0.290), 'dec.conv0': (308.3, 0.145, 3.211),
+       'dec.igdn1': (1644.2, 3.211, 3.211), 'dec.conv2': (3171.9, 3.211, 1.549), 'dec.igdn3': (396.5, 1.549, 1.549),
+       'dec.conv4': (1644.2, 1.549, 1.606)}
+
+
+def launch_work(tag):
+    """(MFLOP, MB) per image of one tagged launch; 'a+b' = ops a and b fused in one launch (reads a's input, writes
+    b's output); an unfused GDN launch reads its input twice (GEMM operand + element-wise operand)."""
+    parts = tag.split('+')
+    if any(q not in OPS for q in parts):
+        return None
+    mflop = sum(OPS[q][0] for q in parts)
+    rd = OPS[parts[0]][1] * (2 if len(parts) == 1 and 'gdn' in parts[0] else 1)
+    return mflop, rd + OPS[parts[-1]][2]
 
 
 def build_model(dev, seed=0):
@@ -187,7 +195,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--inflight', type=int, default=3, help='range-coder chains in flight (coder HIP streams, <= 3)')
+    ap.add_argument('--inflight', type=int, default=6, help='range-coder chains in flight (coder HIP streams, <= 7)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
@@ -216,8 +224,9 @@ def main():
     # Software pipeline over HIP streams: ONE MFMA stream runs front(i) [encoder + quantise] and
     # back(i - depth) [dequantise + decoder + head] back to back; the serial range coder of step i
     # (encode -> bytes -> decode) runs on one of `n_coder` coder streams, so `n_coder` coder chains are in
-    # flight while the matrix cores never wait for them.  1 + n_coder streams <= the 4 hardware queues.
-    n_coder = max(1, min(args.inflight, 6))
+    # flight while the matrix cores never wait for them.  1 + n_coder streams <= the 8 hardware queues
+    # (GPU_MAX_HW_QUEUES above).  A coder chain is 4 waves (256 lanes = 256 streams) for ~20 ms: latency, not work.
+    n_coder = max(1, min(args.inflight, 7))
     depth = n_coder
     mfma_stream = torch.cuda.Stream(device=dev)
     coder_streams = [torch.cuda.Stream(device=dev) for _ in range(n_coder)]
@@ -261,10 +270,11 @@ def main():
     run_steps(args.warmup)
     sync_all()
 
-    select = lambda tag: tag in KERNEL_MFLOP or tag.startswith('rans')  # noqa: E731
+    select = lambda tag: launch_work(tag) is not None or tag.startswith('rans')  # noqa: E731
     with hip.KernelTimer(select) as timer:
         t0 = time.perf_counter()
         run_steps(args.steps)
+        t_issued = time.perf_counter()
         sync_all()
         t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -283,23 +293,24 @@ def main():
 
     if rank == 0:
         ksum = timer.summary()
-        conv = {k: v for k, v in ksum.items() if k in KERNEL_MFLOP}
+        conv = {k: v for k, v in ksum.items() if launch_work(k) is not None}
         dom = max(conv, key=lambda k: conv[k][0] * conv[k][1])
         dom_ms = conv[dom][1]
         fwd_ms = sum(v[1] for v in conv.values())
 
         def roof(k, ms):
             """bound = whichever roof the launch's algorithmic intensity puts it under (ridge = 312.5 FLOP/B)"""
-            tf = KERNEL_MFLOP[k] * 1e6 * args.bs / (ms * 1e-3) / 1e12
-            gbs = KERNEL_MBYTE[k] * 1e6 * args.bs / (ms * 1e-3) / 1e9
-            hbm = KERNEL_MFLOP[k] / KERNEL_MBYTE[k] < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS
+            mflop, mbyte = launch_work(k)
+            tf = mflop * 1e6 * args.bs / (ms * 1e-3) / 1e12
+            gbs = mbyte * 1e6 * args.bs / (ms * 1e-3) / 1e9
+            hbm = mflop / mbyte < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS
             return {'bound': 'hbm' if hbm else 'mfma', 'achieved': gbs if hbm else tf,
                     'peak': PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS, 'unit': 'GB/s' if hbm else 'TFLOP/s',
                     'frac': (gbs / PEAK_HBM_GBS) if hbm else (tf / PEAK_BF16_TFLOPS), 'tflops': tf, 'gbs': gbs,
                     'kernel_ms': ms}
         per_kernel = {k: roof(k, v[1]) for k, v in conv.items()}
-        floor_ms = sum(max(KERNEL_MFLOP[k] * 1e6 * args.bs / (PEAK_BF16_TFLOPS * 1e12),
-                           KERNEL_MBYTE[k] * 1e6 * args.bs / (PEAK_HBM_GBS * 1e9)) * 1e3 for k in conv)
+        floor_ms = sum(max(launch_work(k)[0] * 1e6 * args.bs / (PEAK_BF16_TFLOPS * 1e12),
+                           launch_work(k)[1] * 1e6 * args.bs / (PEAK_HBM_GBS * 1e9)) * 1e3 for k in conv)
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
@@ -317,6 +328,7 @@ def main():
                        'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'inflight_steps': D,
                        'weights': 'random init seed 0 + fixed quantile perturbation', 'sharding': 'images, no collective'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
+            'host_issue_ms_per_step': 1e3 * (t_issued - t0) / args.steps,
             'roofline': dict(per_kernel[dom], kernel=dom, traffic=traffic, launches_timed=conv[dom][0]),
             'bottleneck_forward': {'ms_per_batch_sum_of_mfma_kernels': fwd_ms,
                                    'tflops': BOTTLENECK_GFLOP_PER_IMG * args.bs / fwd_ms,

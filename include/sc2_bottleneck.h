@@ -120,11 +120,13 @@ int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, 
  * (multiplicative) or forward (divisive) normalisation: t = conv(x); y = t * (beta + gamma |t|) resp. t / (...).
  * Replaces decoder[0] + decoder[1] of FPBasedResNetBottleneck (sc2bench/models/layer.py:486-488); the 512-channel
  * intermediate never reaches HBM.
- *   x : bf16 NHWC [N,H,W,Cin], Cin in {8,16,24,32};   w_packed : bf16 [512][Kpad], Kpad = sc2_conv_weight_pitch(4*Cin)
- *   gamma_packed : bf16 [512][512] (effective gamma, row = output channel);   beta : f32 [512] (effective beta)
+ *   x : bf16 NHWC [N,H,W,Cin], Cin in {8,16,24};   w_packed : bf16 [512][Kpad], Kpad = sc2_conv_weight_pitch(4*Cin)
+ *   gamma_frag : effective gamma as bf16 MFMA-fragment blocks [32 channel tiles][16 k steps][64 lanes][8]: entry
+ *                (jt, ks, lane = fq*16 + frow, e) = gamma[jt*16 + frow][ks*32 + fq*8 + e] (one operand fragment =
+ *                1 KB contiguous);   beta : f32 [512] (effective beta)
  *   y : bf16 NHWC [N,H+1,W+1,512] */
 int sc2_conv2x2_gdn512_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
-int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const void *gamma_packed, const float *beta,
+int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const void *gamma_frag, const float *beta,
                            void *y, int N, int H, int W, int Cin, int inverse, void *stream);
 
 /* Weight gradient of sc2_conv2d_fwd: dw[co][(kh*KW+kw)*Cin+ci] = sum over output pixels of gy * im2col(x).

@@ -19,17 +19,36 @@
 //   epilogue y = t * (beta + norm) in f32, written back IN PLACE into the image (each 8-byte slot belongs to one
 //            lane), then the 128 KB tile - contiguous in the NHWC output - is streamed out in 16-byte stores.
 // HBM traffic per tile: 128 x Cin x 2 B in (x taps overlap in L2), 128 KB out.
+#include <stdlib.h>
+
+#include <atomic>
+
 #include "sc2_common.h"
+
+#ifndef SC2_DEC_STAMPS
+#define SC2_DEC_STAMPS 0   // 1: diagnostic build that records s_memtime at the phase boundaries (tools/dec_stamps.py)
+#endif
+#if SC2_DEC_STAMPS
+#define STAMP(k)                                                                                      \
+    do {                                                                                              \
+        if (p.stamps && lane == 0 && blockIdx.x < 8 && n_done < 16)                                   \
+            p.stamps[((blockIdx.x * 8 + wn) * 16 + n_done) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
 
 namespace {
 
 struct DecArgs {
     const uint16_t *__restrict__ x;      // bf16 NHWC [N,H,W,CIN]
     const uint16_t *__restrict__ w;      // packed bf16 [512][Kpad], k = (kh*2+kw)*CIN + ci
-    const uint16_t *__restrict__ g;      // packed bf16 gamma [512][512]
+    const uint16_t *__restrict__ g;      // bf16 gamma, fragment-major [32 channel tiles][16 k steps][64 lanes][8]
     const float *__restrict__ beta;      // f32 [512]
     uint16_t *__restrict__ y;            // bf16 NHWC [N,OH,OW,512]
     int N, H, W, OH, OW, OHW, M, Kpad, n_tiles, inverse;
+    unsigned long long *stamps;          // diagnostic build only (SC2_DEC_STAMPS)
+    unsigned *tile_ctr;                  // next unclaimed tile; preset to 2 * gridDim.x on the stream before the launch
 };
 
 constexpr int BM = 128, CH = 512, WN = 64, MT = 8, NT = 4;
@@ -45,6 +64,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *img = smem;
     unsigned char *patch = smem + IMG_BYTES;     // KS1 slabs of [128 rows][64 B]
+    volatile int *next_slot = reinterpret_cast<volatile int *>(smem + IMG_BYTES + KS1 * 8192);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -98,13 +118,11 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
     }
     __syncthreads();
 
-    const uint16_t *wrow[NT], *grow[NT];
+    const uint16_t *wrow[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int ch = wn * WN + j * 16 + frow;
-        wrow[j] = p.w + (long long)ch * p.Kpad + fq * 8;
-        grow[j] = p.g + (long long)ch * CH;
-    }
+    for (int j = 0; j < NT; ++j) wrow[j] = p.w + (long long)(wn * WN + j * 16 + frow) * p.Kpad + fq * 8;
+    // this lane's 16 bytes of fragment (channel tile wn*4 + j, step ks): gfrag[(j * 16 + ks) * 64]
+    const uint4 *gfrag = reinterpret_cast<const uint4 *>(p.g) + (long long)(wn * NT) * (CH / 32) * 64 + lane;
 
     // W0 fragments of this wave (its 64 channels x K): the same for every tile, but 48 registers are too many to
     // hold through phase 2, so they are re-fetched (L2) per tile - issued BEFORE the previous tile's output stores so
@@ -118,8 +136,15 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
     };
     load_w();
 
-    for (; tile < p.n_tiles; tile += gridDim.x) {
+    // Tiles are claimed dynamically, one atomic per tile: a workgroup whose CU is shared with other kernels (the range
+    // coder's serial waves), or that starts late because its CU's LDS was taken, simply processes fewer tiles.
+    // (claimed one tile ahead of use, so that the next patch can be fetched without waiting for the claim)
+    int next_tile = tile + gridDim.x;
+    int n_done = 0;
+    (void)n_done;
+    while (tile < p.n_tiles) {
         const int m0 = tile * BM;
+        STAMP(0);
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -158,21 +183,31 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(1);
         __syncthreads();   // the image holds all 512 channels of the tile; the patch has been consumed
+        STAMP(2);
 
         // ---------------------------------------------------------------- phase 2: norm = gamma |t|
-        uint4 pv[KS1];
-        load_patch(tile + gridDim.x, pv);   // next tile's patch: in flight for the whole phase
+        // gamma fragments come FRAGMENT-MAJOR from memory ([16-channel tile][32-deep step][lane][8 k], packed on the
+        // host): one wave-instruction reads 1 KB contiguous = 8 whole 128-byte lines.  (Row-major gamma made every
+        // such load touch 16 lines for 64 bytes each, and the phase ran at the vector L1's request rate: 2.7k cycles
+        // per 32-deep step against 1k of MFMA issue - tools/dec_stamps.py.)  gb[h] holds step 2d + h and is
+        // re-filled for step 2d + 2 + h as soon as its MFMAs have been issued.
+        constexpr int NS = CH / 32;
         uint4 gb[2][NT];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) gb[h][j] = *reinterpret_cast<const uint4 *>(grow[j] + (2 * fq + h) * 8);
+            for (int j = 0; j < NT; ++j) gb[h][j] = gfrag[(j * NS + h) * 64];
 #pragma unroll 1
-        for (int d = 0; d < CH / 64; ++d) {
+        for (int d = 0; d < NS / 2; ++d) {
+            // the two waves of a SIMD (w and w + 4) take turns at priority: with a fixed priority (or none: age decides)
+            // one of them runs the phase at full speed and the other finishes what is left alone, at half speed
+            if (((d >> 1) ^ (wn >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int kc = d * 8 + 2 * fq + h;   // this lane's 16-byte k chunk of the 64-deep step
+                const int kc = (2 * d + h) * 4 + fq;   // this lane's 16-byte k chunk of step 2d + h
                 const int rd_lane = frow * (CH * 2) + ((kc ^ frow) << 4);   // + i*16384
                 const int rd_hi = hi(rd_lane);
                 bf16x8_t gf[NT];
@@ -188,21 +223,28 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[j], xf, acc[i][j], 0, 0, 0);
                     if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (d + 1 < CH / 64) {
+                if (d + 1 < NS / 2) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        gb[h][j] = *reinterpret_cast<const uint4 *>(grow[j] + ((d + 1) * 8 + 2 * fq + h) * 8);
+                    for (int j = 0; j < NT; ++j) gb[h][j] = gfrag[(j * NS + 2 * d + 2 + h) * 64];
                 }
             }
         }
-        store_patch(pv);   // nobody reads the patch region until the barriers below have been passed
+        __builtin_amdgcn_s_setprio(0);
+        STAMP(3);
+        // Loads issued here, in this order (vmcnt retires in issue order): beta for the epilogue below, then this
+        // thread's share of the NEXT tile's patch (consumed only after the output stores), then the claim of the tile
+        // after next (lane 0 of wave 0; every wave learns it behind the next barrier).
+        float4 b4v[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b4v[j] = *reinterpret_cast<const float4 *>(p.beta + wn * WN + j * 16 + fq * 4);
+        uint4 pv[KS1];
+        load_patch(next_tile, pv);
+        if (tid == 0) *next_slot = (int)atomicAdd(p.tile_ctr, 1u);
 
         // ---------------------------------------------------------------- epilogue: y = t * (beta + norm), in place
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int col = wn * WN + j * 16 + fq * 4;
-            const float4 b4 = *reinterpret_cast<const float4 *>(p.beta + col);
-            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+            const float b[4] = {b4v[j].x, b4v[j].y, b4v[j].z, b4v[j].w};
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384;
@@ -222,8 +264,11 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        load_w();          // next tile's W0 fragments, ahead of the stores
+        STAMP(4);
         __syncthreads();
+        STAMP(5);
+        const int tile_after_next = __builtin_amdgcn_readfirstlane(*next_slot);
+        load_w();          // next tile's W0 fragments, issued ahead of the output stores
         {
             // thread (wave wn, lane) streams chunk `lane` of rows wn, wn + 8, ...: row & 15 = wn or wn + 8
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)m0 * CH) + tid;   // the tile is contiguous in y
@@ -241,16 +286,25 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
                 if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        store_patch(pv);   // (the patch region was last read in phase 1)
+        STAMP(6);
         __syncthreads();   // image free for the next tile's phase 1; next patch visible to every wave
+        STAMP(7);
+        ++n_done;
+        tile = next_tile;
+        next_tile = tile_after_next;
     }
 }
 
 int g_num_cus = 0;
+constexpr int kMaxDevices = 16, kCtrRing = 256;
+unsigned *g_ctr_ring[kMaxDevices] = {};
+std::atomic<unsigned> g_ctr_seq{0};
 
 template <int CIN, bool INVERSE>
 int launch_dec(const DecArgs &a, hipStream_t s) {
     constexpr int KS1 = (4 * CIN + 31) / 32;
-    constexpr int lds = IMG_BYTES + KS1 * 8192;
+    constexpr int lds = IMG_BYTES + KS1 * 8192 + 16;   // + the next-tile slot
     static_assert(lds <= 160 * 1024, "image + patch must fit the CU's LDS");
     static bool attr_set = false;
     if (!attr_set) {
@@ -266,7 +320,52 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
         g_num_cus = n;
     }
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
-    hipLaunchKernelGGL((conv2x2_gdn512_kernel<CIN, INVERSE>), dim3(grid), dim3(512), lds, s, a);
+    // tile counter: one of a ring of device words (launches in flight on different streams must not share one),
+    // preset on the stream to the first unclaimed tile
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) {
+        sc2_set_error("conv2x2_gdn512: device ordinal %d out of range", dev);
+        return SC2_ERR_UNSUPPORTED;
+    }
+    if (!g_ctr_ring[dev]) {
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, kCtrRing * sizeof(unsigned)) != hipSuccess) {
+            sc2_set_error("conv2x2_gdn512: cannot allocate the tile counters");
+            return SC2_ERR_INTERNAL;
+        }
+        g_ctr_ring[dev] = static_cast<unsigned *>(ptr);
+    }
+    DecArgs b = a;
+    b.tile_ctr = g_ctr_ring[dev] + (g_ctr_seq.fetch_add(1) % kCtrRing);
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.tile_ctr), 2 * grid, 1, s) != hipSuccess) {
+        sc2_set_error("conv2x2_gdn512: cannot preset the tile counter");
+        return SC2_ERR_LAUNCH;
+    }
+    b.stamps = nullptr;
+#if SC2_DEC_STAMPS
+    const char *stamp_path = getenv("SC2_DEC_STAMPS");
+    const size_t stamp_bytes = 8 * 8 * 16 * 8 * sizeof(unsigned long long);
+    if (stamp_path) {
+        void *sp = nullptr;
+        (void)hipMalloc(&sp, stamp_bytes);
+        (void)hipMemsetAsync(sp, 0, stamp_bytes, s);
+        b.stamps = static_cast<unsigned long long *>(sp);
+    }
+#endif
+    hipLaunchKernelGGL((conv2x2_gdn512_kernel<CIN, INVERSE>), dim3(grid), dim3(512), lds, s, b);
+#if SC2_DEC_STAMPS
+    if (b.stamps) {
+        static unsigned long long host[8 * 8 * 16 * 8];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(host, b.stamps, stamp_bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(b.stamps);
+        if (FILE *f = fopen(stamp_path, "wb")) {
+            fwrite(host, 1, stamp_bytes, f);
+            fclose(f);
+        }
+    }
+#endif
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -274,7 +373,7 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
 }  // namespace
 
 extern "C" int sc2_conv2x2_gdn512_supported(int Cin, int Cout, int KH, int KW, int stride, int pad) {
-    return (Cin == 8 || Cin == 16 || Cin == 24 || Cin == 32) && Cout == 512 && KH == 2 && KW == 2 && stride == 1 &&
+    return (Cin == 8 || Cin == 16 || Cin == 24) && Cout == 512 && KH == 2 && KW == 2 && stride == 1 &&
                    pad == 1 ? 1 : 0;
 }
 
@@ -284,7 +383,7 @@ extern "C" int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int K
     SC2_REQUIRE(x && w_packed && gamma_packed && beta && y, SC2_ERR_INVALID_ARG, "conv2x2_gdn512: null argument");
     SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv2x2_gdn512: non-positive dimension");
     SC2_REQUIRE(sc2_conv2x2_gdn512_supported(Cin, 512, 2, 2, 1, 1), SC2_ERR_UNSUPPORTED,
-                "conv2x2_gdn512: Cin %d not in {8,16,24,32}", Cin);
+                "conv2x2_gdn512: Cin %d not in {8,16,24}", Cin);
     SC2_REQUIRE(Kpad == sc2_conv_weight_pitch(4 * Cin), SC2_ERR_INVALID_ARG, "conv2x2_gdn512: Kpad %d != %d", Kpad,
                 sc2_conv_weight_pitch(4 * Cin));
     const long long M = (long long)N * (H + 1) * (W + 1);
@@ -296,12 +395,11 @@ extern "C" int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int K
     a.beta = beta;
     a.y = static_cast<uint16_t *>(y);
     a.N = N; a.H = H; a.W = W; a.OH = H + 1; a.OW = W + 1; a.OHW = a.OH * a.OW; a.M = (int)M;
-    a.Kpad = Kpad; a.n_tiles = (int)((M + BM - 1) / BM); a.inverse = inverse ? 1 : 0;
+    a.Kpad = Kpad; a.n_tiles = (int)((M + BM - 1) / BM); a.inverse = inverse ? 1 : 0; a.tile_ctr = nullptr; a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (Cin) {
         case 8: return inverse ? launch_dec<8, true>(a, s) : launch_dec<8, false>(a, s);
         case 16: return inverse ? launch_dec<16, true>(a, s) : launch_dec<16, false>(a, s);
-        case 24: return inverse ? launch_dec<24, true>(a, s) : launch_dec<24, false>(a, s);
-        default: return inverse ? launch_dec<32, true>(a, s) : launch_dec<32, false>(a, s);
+        default: return inverse ? launch_dec<24, true>(a, s) : launch_dec<24, false>(a, s);
     }
 }

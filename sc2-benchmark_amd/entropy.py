@@ -139,6 +139,16 @@ class GDN1(nn.Module):
             self._eff_key = key
         return self._eff
 
+    def effective_fragments(self):
+        """(beta f32 [C], gamma as bf16 MFMA-fragment-major blocks: hip.pack_gamma_fragments); cached like effective()."""
+        key = (self.beta._version, self.gamma._version, self.gamma.device, self.gamma.data_ptr())
+        if getattr(self, '_frag_key', None) != key:
+            with torch.no_grad():
+                beta = self.beta_reparam(self.beta).float().contiguous()
+                self._frag = (beta, hip.pack_gamma_fragments(self.gamma_reparam(self.gamma)))
+            self._frag_key = key
+        return self._frag
+
     def forward_nhwc(self, x_nhwc, out_format=hip.OUT_BF16_NHWC):
         beta, gamma_packed = self.effective()
         return hip.conv2d_fwd(x_nhwc, gamma_packed, self.in_channels, 1, 1, 1, 0, a_op=hip.AOP_ABS,

@@ -408,14 +408,26 @@ def conv2x2_gdn512_supported(cin, cout, kh, kw, stride, pad):
     return sh == sw and ph == pw and bool(lib().sc2_conv2x2_gdn512_supported(cin, cout, kh, kw, sh, ph))
 
 
+def pack_gamma_fragments(gamma):
+    """Effective gamma [C, C] (row = output channel) -> bf16 fragment-major [C/16][C/32][64][8]: entry
+    (jt, ks, lane = fq*16 + frow, e) = gamma[jt*16 + frow, ks*32 + fq*8 + e], so that one MFMA operand fragment
+    (16 channels x 32 k) is 1 KB contiguous.  Layout of the `gamma_frag` argument of sc2_conv2x2_gdn512_fwd."""
+    _dev(gamma, 'gamma')
+    C = gamma.shape[0]
+    assert gamma.dim() == 2 and gamma.shape[1] == C and C % 32 == 0
+    g = gamma.detach().to(torch.bfloat16).reshape(C // 16, 16, C // 32, 4, 8)      # jt, frow, ks, fq, e
+    return g.permute(0, 2, 3, 1, 4).contiguous().reshape(C // 16, C // 32, 64, 8)
+
+
 def conv2x2_gdn512_fwd(x_nhwc, w_packed, gamma_packed, beta, inverse, tag=None):
-    """y = GDN1_512(conv2x2(x)) (s1, p1) in one launch; x bf16 [N,H,W,Cin] -> bf16 [N,H+1,W+1,512]."""
+    """y = GDN1_512(conv2x2(x)) (s1, p1) in one launch; x bf16 [N,H,W,Cin] -> bf16 [N,H+1,W+1,512].
+    gamma_packed: pack_gamma_fragments(effective gamma)."""
     for t, name in ((x_nhwc, 'x'), (w_packed, 'w_packed'), (gamma_packed, 'gamma_packed'), (beta, 'beta')):
         _dev(t, name)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
     N, H, W, Cin = x_nhwc.shape
     assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous() and w_packed.shape[0] == 512
-    assert gamma_packed.dtype == torch.bfloat16 and gamma_packed.is_contiguous() and tuple(gamma_packed.shape) == (512, 512)
+    assert gamma_packed.dtype == torch.bfloat16 and gamma_packed.is_contiguous() and tuple(gamma_packed.shape) == (32, 16, 64, 8)
     assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 512
     out = torch.empty((N, H + 1, W + 1, 512), dtype=torch.bfloat16, device=x_nhwc.device)
     with _timed(tag or 'conv2x2_gdn512'):

@@ -149,7 +149,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                 beta, gamma = g1.effective()
                 h = hip.conv2d_fwd(xp, self._conv0_packed(), c0.out_channels, 5, 3, (2, 1), (2, 1),
                                    epilogue=hip.EPI_FUSED_IGDN if g1.inverse else hip.EPI_FUSED_GDN, ep_x=gamma,
-                                   ep_beta=beta, tag=c0._tag)
+                                   ep_beta=beta, tag=c0._tag + '+' + g1._tag)
             else:
                 h = hip.conv2d_fwd(xp, self._conv0_packed(), c0.out_channels, 5, 3, (2, 1), (2, 1), tag=c0._tag)
         else:
@@ -170,7 +170,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             beta, gamma = g3.effective()
             h = hip.conv2d_fwd(h, c2.packed_weight(), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
                                c2.padding, epilogue=hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN,
-                               ep_x=gamma, ep_beta=beta, tag=c2._tag, k_order=c2.k_order())
+                               ep_x=gamma, ep_beta=beta, tag=c2._tag + '+' + g3._tag, k_order=c2.k_order())
         else:
             h = g3.forward_nhwc(c2.forward_nhwc(h))
         return c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
@@ -181,8 +181,8 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         if (self.fuse_gdn and g1.in_channels == c0.out_channels and c0.k_order() == hip.K_TAP_MAJOR and
                 hip.conv2x2_gdn512_supported(c0.in_channels, c0.out_channels, c0.kernel_size[0], c0.kernel_size[1],
                                              c0.stride, c0.padding)):
-            beta, gamma = g1.effective()   # conv + (inverse) GDN1(512) in one persistent launch; t never reaches HBM
-            h = hip.conv2x2_gdn512_fwd(y_hat_nhwc, c0.packed_weight(), gamma, beta, g1.inverse, tag=c0._tag)
+            beta, gamma = g1.effective_fragments()   # conv + (inverse) GDN1(512) in one persistent launch
+            h = hip.conv2x2_gdn512_fwd(y_hat_nhwc, c0.packed_weight(), gamma, beta, g1.inverse, tag=c0._tag + '+' + g1._tag)
         else:
             h = c0.forward_nhwc(y_hat_nhwc)
             h = g1.forward_nhwc(h)
@@ -191,7 +191,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             beta, gamma = g3.effective()   # conv + inverse GDN1 in one launch (256-wide big tile holds all channels)
             h = hip.conv2d_fwd(h, c2.packed_weight(), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
                                c2.padding, epilogue=hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN,
-                               ep_x=gamma, ep_beta=beta, tag=c2._tag, k_order=c2.k_order())
+                               ep_x=gamma, ep_beta=beta, tag=c2._tag + '+' + g3._tag, k_order=c2.k_order())
         else:
             h = c2.forward_nhwc(h)
             h = g3.forward_nhwc(h)

@@ -262,7 +262,7 @@ def test_conv_fused_gdn_big_tile(S, R, dev, monkeypatch, cin, k, pad, inverse):
 
 
 @pytest.mark.parametrize('cin,inverse,N,H,W', [(24, True, 3, 7, 9), (24, False, 2, 5, 5), (16, True, 1, 12, 11),
-                                               (32, True, 2, 6, 6), (8, True, 5, 9, 9)])
+                                               (8, True, 5, 9, 9), (24, True, 80, 27, 27)])
 def test_conv2x2_gdn512_fused(S, R, dev, cin, inverse, N, H, W):
     """decoder[0] + decoder[1] (Conv k2 p1 -> 512, GDN1(512)) in one persistent launch vs the oracle ops on the
     bf16-rounded operands; several tiles per workgroup, ragged last tile, image borders."""
@@ -288,8 +288,12 @@ def test_conv2x2_gdn512_fused(S, R, dev, cin, inverse, N, H, W):
     assert S.hip.conv2x2_gdn512_supported(cin, cout, 2, 2, 1, 1)
     assert not S.hip.conv2x2_gdn512_supported(cin, 256, 2, 2, 1, 1)
     assert not S.hip.conv2x2_gdn512_supported(cin, cout, 2, 2, 1, 0)
+    assert not S.hip.conv2x2_gdn512_supported(32, cout, 2, 2, 1, 1)
+    assert not S.hip.conv2x2_gdn512_supported(32, cout, 2, 2, 1, 1)
     x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
-    out = S.hip.conv2x2_gdn512_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), gamma_d, beta_d, inverse)
+    _, gamma_f = m.effective_fragments()
+    assert torch.equal(gamma_f[3, 5, 2 * 16 + 7].cpu(), gamma_d[3 * 16 + 7, 5 * 32 + 2 * 8:5 * 32 + 2 * 8 + 8].cpu())
+    out = S.hip.conv2x2_gdn512_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), gamma_f, beta_d, inverse)
     assert out.shape == (N, H + 1, W + 1, cout)
     assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'fused conv2x2 + gdn512', extra=2.0 ** -8)
     # and the same result as the two-launch path (conv -> GDN1) up to the bf16 rounding of its intermediate
