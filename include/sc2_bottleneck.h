@@ -79,7 +79,10 @@ enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHW
  *   SLAB_MAJOR k = ((ci/32)*KH*KW + kh*KW + kw)*32 + ci%32     (Cin % 32 == 0): the taps of one 32-channel slab are
  *              consecutive, so the overlapping pixels they re-read stay in L1/L2 (measured 4x fewer fabric reads on
  *              the 2x2 decoder convs). */
-enum sc2_conv_k_order { SC2_K_TAP_MAJOR = 0, SC2_K_SLAB_MAJOR = 1 };
+enum sc2_conv_k_order { SC2_K_TAP_MAJOR = 0, SC2_K_SLAB_MAJOR = 1,
+                        /* flag, OR-ed in: w_packed is [Kpad/32][Cout_pad][32] (the B tile of one 32-deep k-slab is
+                         * contiguous) instead of [Cout_pad][Kpad] */
+                        SC2_K_B_TILE_MAJOR = 2 };
 
 typedef struct sc2_conv_desc {
     int32_t N, H, W, Cin;          /* input  : bf16 NHWC [N,H,W,Cin], Cin % 8 == 0              */

@@ -44,6 +44,9 @@ struct ConvArgs {
     int n_ntiles;
     int aop, epi, out;
     int g_pitch;   // fused GDN: row pitch (elements) of the packed gamma matrix handed in through ep_x
+    int b_kt_stride;    // element stride of the packed weights between k-slabs: 32 (row-major rows of Kpad) or Cout_pad*32
+                        // (SC2_K_B_TILE_MAJOR: [k-slab][row][32], a slab's B tile is contiguous: whole 128-byte lines per load)
+    int b_row_stride;   // element stride between weight rows: Kpad or 32
     int k_slab_major;   // K ordered (channel slab of 32, tap, channel) instead of (tap, channel): needs Cin % 32 == 0
     int touch; // 1: pull the epilogue operand's lines into L2 with one dword load per 128-byte line before the K loop
     int dbg;   // development switches (SC2_CONV_DEBUG): bit 0 skips the store epilogue, bit 1 the K loop
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     for (int j = 0; j < B_IPW; ++j) {
         int rowb = (j * 4 + wave) * 16 + (lane >> 2);
         if (rowb >= BN) rowb = 0;   // padding rows of the staged image: any valid source, never read back
-        b_off[j] = (long long)(n0 + rowb) * p.Kpad + kc * 8;
+        b_off[j] = (long long)(n0 + rowb) * p.b_row_stride + kc * 8;
     }
     // k state of this lane's chunk column: (kh, kw, c8); advancing by one slab wraps at most WRAPS times
     constexpr int WRAPS = C::STATIC ? (KC + (C::CIN / 8) - 1) / (C::CIN / 8 > 0 ? C::CIN / 8 : 1) : KC;
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         const bool kt_ok = kt < KT;
 #pragma unroll
         for (int j = 0; j < B_IPW; ++j) {
-            const long long off = kt_ok ? b_off[j] + (long long)kt * BK : zero_off_w;
+            const long long off = kt_ok ? b_off[j] + (long long)kt * p.b_kt_stride : zero_off_w;
             const uint16_t *src = p.w + off;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(Bb + (j * 4 + wave) * 1024), 16, 0, 0);
         }
@@ -800,7 +803,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
     }
     long long b_off[B_IPW];
 #pragma unroll
-    for (int j = 0; j < B_IPW; ++j) b_off[j] = (long long)(n0 + (j * 8 + wave) * 16 + (lane >> 2)) * p.Kpad + kc * 8;
+    for (int j = 0; j < B_IPW; ++j)
+        b_off[j] = (long long)(n0 + (j * 8 + wave) * 16 + (lane >> 2)) * p.b_row_stride + kc * 8;
     // k position of slab t.  When Cin % 32 == 0 a slab never straddles a filter tap, so the tap (kh, kw) and the
     // channel base are WAVE-UNIFORM functions of t: they live in scalar registers and cost no vector ALU; only
     // the bounds test and the final add are per lane.  Otherwise a per-lane (kh, kw, c8) state machine is stepped.
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
         const bool kt_ok = kt < KT;
 #pragma unroll
         for (int j = 0; j < B_IPW; ++j) {
-            const long long off = kt_ok ? b_off[j] + (long long)kt * BK : zero_off_w;
+            const long long off = kt_ok ? b_off[j] + (long long)kt * p.b_kt_stride : zero_off_w;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.w + off), (lds_ptr_t)(Bb + (j * 8 + wave) * 1024), 16, 0, 0);
         }
     };
@@ -1165,7 +1169,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     SC2_REQUIRE(d->Cout_pad == sc2_conv_weight_rows(d->Cout), SC2_ERR_INVALID_ARG, "conv2d: Cout_pad %d != %d",
                 d->Cout_pad, sc2_conv_weight_rows(d->Cout));
     SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS, SC2_ERR_INVALID_ARG, "conv2d: bad a_op");
-    SC2_REQUIRE(d->k_order == SC2_K_TAP_MAJOR || (d->k_order == SC2_K_SLAB_MAJOR && d->Cin % 32 == 0),
+    SC2_REQUIRE(d->k_order >= 0 && d->k_order <= 3 && (!(d->k_order & SC2_K_SLAB_MAJOR) || d->Cin % 32 == 0),
                 SC2_ERR_INVALID_ARG, "conv2d: slab-major K order needs Cin %% 32 == 0 (Cin = %d)", d->Cin);
     SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_FUSED_IGDN, SC2_ERR_INVALID_ARG,
                 "conv2d: bad epilogue");
@@ -1195,7 +1199,9 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.Kpad = d->Kpad; a.KT = 0; a.n_ntiles = 0;
     a.aop = d->a_op; a.epi = d->epilogue; a.out = d->out_format;
     a.g_pitch = sc2_conv_weight_pitch(d->Cout);
-    a.k_slab_major = d->k_order == SC2_K_SLAB_MAJOR;
+    a.k_slab_major = (d->k_order & SC2_K_SLAB_MAJOR) ? 1 : 0;
+    a.b_kt_stride = (d->k_order & SC2_K_B_TILE_MAJOR) ? d->Cout_pad * 32 : 32;
+    a.b_row_stride = (d->k_order & SC2_K_B_TILE_MAJOR) ? 32 : d->Kpad;
     {
         const char *dbg = getenv("SC2_CONV_DEBUG");
         a.dbg = dbg ? atoi(dbg) : 0;

@@ -77,12 +77,17 @@ class HipConv2d(nn.Conv2d):
     def k_order(self):
         return hip.preferred_k_order(self.in_channels, self.kernel_size[0], self.kernel_size[1])
 
-    def packed_weight(self):
-        key = (self.weight._version, self.weight.device, self.weight.data_ptr())
-        if getattr(self, '_packed_key', None) != key:
-            self._packed = hip.pack_conv_weight(self.weight, self.k_order())
-            self._packed_key = key
-        return self._packed
+    def packed_weight(self, k_order=None):
+        """Packed bf16 weights in this layer's preferred k order (or the one asked for); cached per parameter version."""
+        order = self.k_order() if k_order is None else k_order
+        key = (self.weight._version, self.weight.device, self.weight.data_ptr(), order)
+        cache = self.__dict__.setdefault('_packed_cache', {})
+        if cache.get('key') != key[:3]:
+            cache.clear()
+            cache['key'] = key[:3]
+        if order not in cache:
+            cache[order] = hip.pack_conv_weight(self.weight, order)
+        return cache[order]
 
     def forward_nhwc(self, x_nhwc, out_format=hip.OUT_BF16_NHWC):
         assert self.bias is None and self.groups == 1 and self.dilation == (1, 1)

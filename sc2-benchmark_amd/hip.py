@@ -199,7 +199,7 @@ def weight_pitch(k):
     return lib().sc2_conv_weight_pitch(int(k))
 
 
-K_TAP_MAJOR, K_SLAB_MAJOR = 0, 1
+K_TAP_MAJOR, K_SLAB_MAJOR, K_B_TILE_MAJOR = 0, 1, 2   # K_B_TILE_MAJOR: flag OR-ed into the k order
 
 
 def pack_conv_weight(w, k_order=K_TAP_MAJOR):
@@ -210,21 +210,27 @@ def pack_conv_weight(w, k_order=K_TAP_MAJOR):
     k = cin * kh * kw
     rows, pitch = weight_rows(cout), weight_pitch(k)
     packed = torch.zeros((rows, pitch), dtype=torch.bfloat16, device=w.device)
+    tile_major = bool(k_order & K_B_TILE_MAJOR)
+    k_order = k_order & 1
     if k_order == K_SLAB_MAJOR:
         assert cin % 32 == 0
         flat = w.detach().reshape(cout, cin // 32, 32, kh * kw).permute(0, 1, 3, 2).reshape(cout, k)
     else:
         flat = w.detach().permute(0, 2, 3, 1).reshape(cout, k)
     packed[:cout, :k] = flat.to(torch.bfloat16)
+    if tile_major:   # [k-slab][row][32]: same bytes, the B tile of a k-slab contiguous; kept 2-D for the shape checks
+        rows, kpad = packed.shape
+        packed = packed.reshape(rows, kpad // 32, 32).permute(1, 0, 2).contiguous().reshape(rows, kpad)
     return packed
 
 
 def preferred_k_order(cin, kh, kw):
     """Slab-major pays when several taps re-read overlapping pixels and the channel count allows it."""
     if os.environ.get('SC2_K_ORDER') == 'tap':      # A/B switch (tools/)
-        return K_TAP_MAJOR
+        return K_TAP_MAJOR | (K_B_TILE_MAJOR if os.environ.get('SC2_B_TILE', '1') != '0' else 0)
     # measured (same box, tools/layer_times.py): +1.5 % on the 2x2 decoder convs, -4 % on the 25-tap stride-2 conv
-    return K_SLAB_MAJOR if (cin % 32 == 0 and 1 < kh * kw <= 9) else K_TAP_MAJOR
+    base = K_SLAB_MAJOR if (cin % 32 == 0 and 1 < kh * kw <= 9) else K_TAP_MAJOR
+    return base | (K_B_TILE_MAJOR if os.environ.get('SC2_B_TILE', '1') != '0' else 0)
 
 
 def pack_conv0_weight_pairs(w):

@@ -178,11 +178,11 @@ class FPBasedResNetBottleneck(BaseBottleneck):
     def synthesis_nhwc(self, y_hat_nhwc):
         """decoder on a bf16 NHWC latent (layer.py:485-493); output per ``self.output_format``."""
         c0, g1, c2, g3, c4 = self.decoder
-        if (self.fuse_gdn and g1.in_channels == c0.out_channels and c0.k_order() == hip.K_TAP_MAJOR and
+        if (self.fuse_gdn and g1.in_channels == c0.out_channels and
                 hip.conv2x2_gdn512_supported(c0.in_channels, c0.out_channels, c0.kernel_size[0], c0.kernel_size[1],
                                              c0.stride, c0.padding)):
             beta, gamma = g1.effective_fragments()   # conv + (inverse) GDN1(512) in one persistent launch
-            h = hip.conv2x2_gdn512_fwd(y_hat_nhwc, c0.packed_weight(), gamma, beta, g1.inverse, tag=c0._tag + '+' + g1._tag)
+            h = hip.conv2x2_gdn512_fwd(y_hat_nhwc, c0.packed_weight(hip.K_TAP_MAJOR), gamma, beta, g1.inverse, tag=c0._tag + '+' + g1._tag)
         else:
             h = c0.forward_nhwc(y_hat_nhwc)
             h = g1.forward_nhwc(h)

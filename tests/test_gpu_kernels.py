@@ -77,6 +77,10 @@ def test_conv_igemm(S, dev, cin, cout, k, stride, pad, H, W, N):
     torch.testing.assert_close(out32.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
     out32h = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NHWC)
     assert torch.equal(out32h.permute(0, 3, 1, 2).cpu(), out32.cpu())
+    # weights packed [k-slab][row][32] (B tile of a slab contiguous): same result bit for bit
+    wpt = S.hip.pack_conv_weight(w.to(dev), S.hip.K_B_TILE_MAJOR)
+    outt = S.hip.conv2d_fwd(x_nhwc, wpt, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW, k_order=S.hip.K_B_TILE_MAJOR)
+    assert torch.equal(outt.cpu(), out32.cpu())
     if cin % 32 == 0:   # slab-major K order: (channel slab, tap, channel) walk with matching weight packing
         wps = S.hip.pack_conv_weight(w.to(dev), S.hip.K_SLAB_MAJOR)
         outs = S.hip.conv2d_fwd(x_nhwc, wps, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW,
@@ -85,6 +89,8 @@ def test_conv_igemm(S, dev, cin, cout, k, stride, pad, H, W, N):
     else:
         with pytest.raises(ValueError):
             S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad, k_order=S.hip.K_SLAB_MAJOR)
+    with pytest.raises(ValueError):
+        S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad, k_order=4)
 
 
 @pytest.mark.parametrize('cin,cout,k,stride,pad,H,W,N', [
@@ -108,10 +114,13 @@ def test_conv_big_tile(S, dev, monkeypatch, cin, cout, k, stride, pad, H, W, N):
     out = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad)
     assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'big-tile conv bf16 nhwc')
     if cin % 32 == 0:
-        wps = S.hip.pack_conv_weight(w.to(dev), S.hip.K_SLAB_MAJOR)
-        outs = S.hip.conv2d_fwd(x_nhwc, wps, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW,
-                                k_order=S.hip.K_SLAB_MAJOR)
+        order = S.hip.K_SLAB_MAJOR | S.hip.K_B_TILE_MAJOR
+        wps = S.hip.pack_conv_weight(w.to(dev), order)
+        outs = S.hip.conv2d_fwd(x_nhwc, wps, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW, k_order=order)
         torch.testing.assert_close(outs.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+    wpt = S.hip.pack_conv_weight(w.to(dev), S.hip.K_B_TILE_MAJOR)
+    outt = S.hip.conv2d_fwd(x_nhwc, wpt, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW, k_order=S.hip.K_B_TILE_MAJOR)
+    assert torch.equal(outt.cpu(), out32.cpu())
     monkeypatch.delenv('SC2_CONV_FORCE_BIG')
     monkeypatch.setenv('SC2_CONV_NO_BIG', '1')
     small = S.hip.conv2d_fwd(x_nhwc, wp, cout, k, k, stride, pad, out_format=S.hip.OUT_F32_NCHW)

@@ -15,7 +15,7 @@ beta, gamma = h1.effective_fragments()
 path = os.environ['SC2_DEC_STAMPS']
 with torch.no_grad():
     for _ in range(3):
-        hip.conv2x2_gdn512_fwd(yh, d0.packed_weight(), gamma, beta, True)
+        hip.conv2x2_gdn512_fwd(yh, d0.packed_weight(hip.K_TAP_MAJOR), gamma, beta, True)
     torch.cuda.synchronize()
 st = np.fromfile(path, dtype=np.uint64).reshape(8, 8, 16, 8).astype(np.int64)   # [wg][wave][tile][stamp]
 names = ['phase1+imgwrite', 'barrier1', 'phase2', 'patch st+epilogue', 'load_w+barrier2', 'readout', 'barrier3', 'loop']

@@ -1,4 +1,3 @@
 #!/bin/bash
-timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -k "gdn512" 2>&1 | tail -4
-timeout 300 python tools/layer_times.py --bs 256 2>&1 | grep -E "conv0\+igdn512|synthesis"
-SC2_LIB=tools/variants/lib_stamps.so SC2_DEC_STAMPS=/tmp/st.bin timeout 200 python tools/dec_stamps.py 2>&1 | tail -3
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+for r in 1 2; do for V in 0 1; do echo "== SC2_B_TILE=$V"; SC2_B_TILE=$V timeout 300 python tools/layer_times.py --bs 256 2>&1 | grep -E "enc\.conv|dec\.conv2|dec.conv4|igdn256|analysis|synthesis|head\(hip"; done; done

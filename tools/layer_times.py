@@ -76,7 +76,7 @@ def main():
         rows.append(('dec.igdn512', timeit(lambda: h1.forward_nhwc(b0), args.iters), 1644.2e6 * N, b0.numel() * 4 + b1.numel() * 2))
         if hip.conv2x2_gdn512_supported(24, 512, 2, 2, 1, 1):
             beta1, gamma1 = h1.effective_fragments()
-            rows.append(('dec.conv0+igdn512', timeit(lambda: hip.conv2x2_gdn512_fwd(yh, d0.packed_weight(), gamma1, beta1, True), args.iters),
+            rows.append(('dec.conv0+igdn512', timeit(lambda: hip.conv2x2_gdn512_fwd(yh, d0.packed_weight(hip.K_TAP_MAJOR), gamma1, beta1, True), args.iters),
                          (308.3e6 + 1644.2e6) * N, yh.numel() * 2 + b1.numel() * 2))
         b2 = d2.forward_nhwc(b1)
         rows.append(('dec.conv2', timeit(lambda: d2.forward_nhwc(b1), args.iters), 3171.9e6 * N, b1.numel() * 2 + b2.numel() * 2))
