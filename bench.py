@@ -195,7 +195,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--inflight', type=int, default=6, help='range-coder chains in flight (coder HIP streams, <= 7)')
+    ap.add_argument('--inflight', type=int, default=3, help='range-coder chains in flight (coder HIP streams, <= 7)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
@@ -315,7 +315,10 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                # measured at bs 256 per GPU; HBM-side bytes per launch (FETCH_SIZE doubled as the microarch guide
+                # prescribes for gfx950 + WRITE_SIZE), scaled to this run's batch
+                rec = json.load(open(tpath)).get(dom)
+                traffic = rec['hbm_bytes_per_launch'] * args.bs / 256.0 if rec else None
             except Exception:
                 traffic = None
         out = {
