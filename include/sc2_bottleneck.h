@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 13
+#define SC2_ABI_VERSION 14
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -71,7 +71,8 @@ enum sc2_conv_epilogue {
      * x = acc; y = x / (ep_beta + gamma |x|)  resp.  x * (ep_beta + gamma |x|).  `ep_x` carries the packed bf16
      * gamma matrix [sc2_conv_weight_rows(Cout)][sc2_conv_weight_pitch(Cout)] instead of an activation. */
     SC2_EPI_FUSED_GDN = 6,
-    SC2_EPI_FUSED_IGDN = 7
+    SC2_EPI_FUSED_IGDN = 7,
+    SC2_EPI_BIAS_LEAKY_RELU = 8 /* y = leaky_relu(acc + ep_beta[c], 0.01) (nn.LeakyReLU() default slope; h_a / h_s) */
 };
 enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHWC = 2 };
 /* Order of the K axis of the packed weights (and of the kernel's walk over the input):
@@ -192,6 +193,28 @@ int sc2_eb_symbols(const float *y, const float *medians, int N, int C, int HW, i
 /* y_hat = float(symbols) + median[c]   (EntropyModel.dequantize reached from layer.py:520). */
 int sc2_eb_dequantize(const int32_t *symbols, const float *medians, int N, int C, int HW, float *y_hat_f32_nchw,
                       void *y_hat_bf16_nhwc, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* GaussianConditional (hyperprior bottlenecks, sc2bench/models/layer.py:553-817)              */
+/* Replaces CompressAI GaussianConditional.forward / quantize / dequantize / build_indexes     */
+/* reached from layer.py:646-647,665,679,691-693,776,785,794,811-813.                          */
+/* All tensors f32 NCHW with `chw` elements per image; `scales` / `means` may be channel       */
+/* slices of a wider tensor and carry their own per-image element stride.                      */
+/* ------------------------------------------------------------------------------------------ */
+/* mode SC2_EB_NOISE: y_hat = y + noise (means ignored, as upstream); SC2_EB_DEQUANTIZE: y_hat = round(y - means) +
+ * means.  lik = max(Phi((.5 - |v|)/s) - Phi((-.5 - |v|)/s), lik_bound), v = y_hat - means, s = max(scales,
+ * scale_bound), Phi(t) = .5 erfc(-t / sqrt 2).  means, noise, y_hat, lik nullable. */
+int sc2_gc_forward(const float *y, const float *scales, int64_t scales_img_stride, const float *means,
+                   int64_t means_img_stride, const float *noise, int64_t n_img, int64_t chw, int mode,
+                   float scale_bound, float lik_bound, float *y_hat, float *lik, void *stream);
+/* symbols = int32(round_half_even(y - means)); indexes = (n_table - 1) - #{t < n_table - 1 : max(scales,
+ * scale_bound) <= scale_table[t]} (GaussianConditional.build_indexes).  Either output may be NULL. */
+int sc2_gc_symbols_indexes(const float *y, const float *scales, int64_t scales_img_stride, const float *means,
+                           int64_t means_img_stride, int64_t n_img, int64_t chw, const float *scale_table, int n_table,
+                           float scale_bound, int32_t *symbols, int32_t *indexes, void *stream);
+/* y_hat = float(symbols) + means (means nullable), f32 NCHW and / or bf16 NHWC [n_img, HW, C]. */
+int sc2_gc_dequantize(const int32_t *symbols, const float *means, int64_t means_img_stride, int64_t n_img, int C,
+                      int HW, float *y_hat_f32_nchw, void *y_hat_bf16_nhwc, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* CDF quantisation (HOST function, bit-exact integer result)                                  */

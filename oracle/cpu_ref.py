@@ -13,6 +13,8 @@ execute them) of the floating-point half of the hot path:
 * ``FPBasedResNetBottleneck`` -- follows sc2bench/models/layer.py:444-550 line by
   line in behaviour (structure 464-494, encode 496-507, decode 509-521,
   _get_means 523-527, _forward2train 529-533, forward 535-550).
+* ``GaussianConditional``, ``get_scale_table`` -- CompressAI 1.2.x entropy_models.py / models/google.py;
+  ``SHPBasedResNetBottleneck`` / ``MSHPBasedResNetBottleneck`` -- sc2bench/models/layer.py:553-817.
 * ``SplittableResNet`` forward order -- sc2bench/models/backbone.py:225-258.
 * ``BppLoss`` -- sc2bench/loss.py:20-37.  ``file_size`` -- sc2bench/analysis.py:126-134
   (torchdistill ``get_binary_object_size`` = ``sys.getsizeof(pickle.dumps(obj))/unit``).
@@ -386,6 +388,307 @@ class FPBasedResNetBottleneck(nn.Module):
             decoder_input = decoder_input.detach()
             return self.decoder(decoder_input)
         return self._forward2train(x, noise=noise)
+
+
+# --------------------------------------------------------------------------- #
+# GaussianConditional + hyperprior bottlenecks (layer.py:553-817)
+# --------------------------------------------------------------------------- #
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
+
+
+def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
+    """compressai.models.google.get_scale_table (imported by the reference at layer.py:5, used at :700)."""
+    return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
+
+
+class GaussianConditional(nn.Module):
+    """CompressAI 1.2.x ``GaussianConditional`` (entropy_models.py) as the reference uses it: constructed with
+    ``GaussianConditional(None)`` (layer.py:627), ``build_indexes`` / ``compress(y, indexes, means=)`` /
+    ``decompress(strings, indexes, dtype | means=)`` (layer.py:646-647,665,776,785), ``forward(y, scales, means=)``
+    (:679,794), ``quantize`` / ``dequantize`` (:691-693,811-813), ``update_scale_table`` (:702)."""
+
+    def __init__(self, scale_table=None, scale_bound=0.11, tail_mass=1e-9, likelihood_bound=1e-9,
+                 entropy_coder_precision=16):
+        super().__init__()
+        if scale_table is not None and (len(scale_table) < 1 or list(scale_table) != sorted(scale_table) or
+                                        any(s <= 0 for s in scale_table)):
+            raise ValueError('Invalid scale_table "({})"'.format(scale_table))
+        self.tail_mass = float(tail_mass)
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        self.use_likelihood_bound = likelihood_bound > 0
+        if self.use_likelihood_bound:
+            self.likelihood_lower_bound = LowerBound(likelihood_bound)
+        if scale_bound is None and scale_table:
+            scale_bound = scale_table[0]
+        if scale_bound <= 0:
+            raise ValueError('Invalid parameters')
+        self.lower_bound_scale = LowerBound(scale_bound)
+        self.register_buffer('_offset', torch.IntTensor())
+        self.register_buffer('_quantized_cdf', torch.IntTensor())
+        self.register_buffer('_cdf_length', torch.IntTensor())
+        self.register_buffer('scale_table', self._prepare_scale_table(scale_table) if scale_table else torch.Tensor())
+        self.register_buffer('scale_bound', torch.Tensor([float(scale_bound)]) if scale_bound is not None else None)
+
+    @staticmethod
+    def _prepare_scale_table(scale_table):
+        return torch.Tensor(tuple(float(s) for s in scale_table))
+
+    @staticmethod
+    def _standardized_cumulative(inputs):
+        half = float(0.5)
+        const = float(-(2 ** -0.5))
+        return half * torch.erfc(const * inputs)
+
+    @staticmethod
+    def _standardized_quantile(quantile):
+        import scipy.stats
+        return scipy.stats.norm.ppf(quantile)
+
+    quantize = EntropyBottleneck.quantize
+    dequantize = staticmethod(EntropyBottleneck.dequantize)
+    _pmf_to_cdf = EntropyBottleneck._pmf_to_cdf
+    _check_tables = EntropyBottleneck._check_tables
+
+    def update_scale_table(self, scale_table, force=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        device = self.scale_table.device
+        self.scale_table = self._prepare_scale_table(scale_table).to(device)
+        self.update()
+        return True
+
+    def update(self):
+        multiplier = -self._standardized_quantile(self.tail_mass / 2)
+        pmf_center = torch.ceil(self.scale_table * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = torch.max(pmf_length).item()
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None])
+        samples_scale = self.scale_table.unsqueeze(1)
+        samples = samples.float()
+        samples_scale = samples_scale.float()
+        upper = self._standardized_cumulative((0.5 - samples) / samples_scale)
+        lower = self._standardized_cumulative((-0.5 - samples) / samples_scale)
+        pmf = upper - lower
+        tail_mass = 2 * lower[:, :1]
+        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length)
+        self._offset = -pmf_center
+        self._cdf_length = pmf_length + 2
+
+    def _likelihood(self, inputs, scales, means=None):
+        half = float(0.5)
+        values = inputs - means if means is not None else inputs
+        scales = self.lower_bound_scale(scales)
+        values = torch.abs(values)
+        upper = self._standardized_cumulative((half - values) / scales)
+        lower = self._standardized_cumulative((-half - values) / scales)
+        return upper - lower
+
+    def forward(self, inputs, scales, means=None, training=None, noise=None):
+        if training is None:
+            training = self.training
+        outputs = self.quantize(inputs, 'noise' if training else 'dequantize', means, noise=noise)
+        likelihood = self._likelihood(outputs, scales, means)
+        if self.use_likelihood_bound:
+            likelihood = self.likelihood_lower_bound(likelihood)
+        return outputs, likelihood
+
+    def build_indexes(self, scales):
+        scales = self.lower_bound_scale(scales)
+        indexes = scales.new_full(scales.size(), len(self.scale_table) - 1).int()
+        for s in self.scale_table[:-1]:
+            indexes -= (scales <= s).int()
+        return indexes
+
+    def compress(self, inputs, indexes, means=None):
+        symbols = self.quantize(inputs, 'symbols', means)
+        if len(inputs.size()) < 2:
+            raise ValueError('Invalid `inputs` size. Expected a tensor with at least 2 dimensions.')
+        if inputs.size() != indexes.size():
+            raise ValueError('`inputs` and `indexes` should have the same size.')
+        self._check_tables()
+        strings = []
+        for i in range(symbols.size(0)):
+            strings.append(_rans.encode_with_indexes(
+                symbols[i].reshape(-1).int().numpy(), indexes[i].reshape(-1).int().numpy(),
+                self._quantized_cdf.numpy(), self._cdf_length.reshape(-1).int().numpy(),
+                self._offset.reshape(-1).int().numpy()))
+        return strings
+
+    def decompress(self, strings, indexes, dtype=torch.float, means=None):
+        if not isinstance(strings, (tuple, list)):
+            raise ValueError('Invalid `strings` parameter type.')
+        if not len(strings) == indexes.size(0):
+            raise ValueError('Invalid strings or indexes parameters')
+        self._check_tables()
+        if means is not None and means.size()[:2] != indexes.size()[:2]:
+            raise ValueError('Invalid means or indexes parameters')
+        outputs = torch.empty(indexes.size(), dtype=torch.int32)
+        for i, s in enumerate(strings):
+            values = _rans.decode_with_indexes(
+                s, indexes[i].reshape(-1).int().numpy(), self._quantized_cdf.numpy(),
+                self._cdf_length.reshape(-1).int().numpy(), self._offset.reshape(-1).int().numpy())
+            outputs[i] = torch.from_numpy(values).reshape(outputs[i].size())
+        return self.dequantize(outputs, means, dtype)
+
+
+class SHPBasedResNetBottleneck(nn.Module):
+    """sc2bench/models/layer.py:553-720 restated (scale hyperprior)."""
+
+    def __init__(self, num_input_channels=3, num_latent_channels=16, num_bottleneck_channels=24,
+                 num_target_channels=256, h_a=None, h_s=None, g_a_channel_sizes=None, g_s_channel_sizes=None):
+        super().__init__()
+        if g_a_channel_sizes is None:
+            g_a_channel_sizes = [num_input_channels, num_bottleneck_channels * 4, num_bottleneck_channels * 2,
+                                 num_bottleneck_channels]
+        else:
+            num_bottleneck_channels = g_a_channel_sizes[3]
+        if g_s_channel_sizes is None:
+            g_s_channel_sizes = [g_a_channel_sizes[-1], num_target_channels * 2, num_target_channels,
+                                 num_target_channels]
+        self.entropy_bottleneck = EntropyBottleneck(num_latent_channels)
+        self.updated = False
+        a, g = g_a_channel_sizes, g_s_channel_sizes
+        self.g_a = nn.Sequential(
+            nn.Conv2d(a[0], a[1], kernel_size=5, stride=2, padding=2, bias=False), GDN1(a[1]),
+            nn.Conv2d(a[1], a[2], kernel_size=5, stride=2, padding=2, bias=False), GDN1(a[2]),
+            nn.Conv2d(a[2], a[3], kernel_size=2, stride=1, padding=0, bias=False))
+        self.g_s = nn.Sequential(
+            nn.Conv2d(g[0], g[1], kernel_size=2, stride=1, padding=1, bias=False), GDN1(g[1], inverse=True),
+            nn.Conv2d(g[1], g[2], kernel_size=2, stride=1, padding=0, bias=False), GDN1(g[2], inverse=True),
+            nn.Conv2d(g[2], g[3], kernel_size=2, stride=1, padding=1, bias=False))
+        L, B = num_latent_channels, num_bottleneck_channels
+        self.h_a = nn.Sequential(
+            nn.Conv2d(B, L, kernel_size=5, stride=2, padding=1, bias=False), nn.ReLU(inplace=True),
+            nn.Conv2d(L, L, kernel_size=5, stride=2, padding=2, bias=False)) if h_a is None else h_a
+        self.h_s = nn.Sequential(
+            nn.ConvTranspose2d(L, L, kernel_size=5, stride=2, padding=1, bias=False), nn.LeakyReLU(inplace=True),
+            nn.ConvTranspose2d(L, L, kernel_size=5, stride=2, padding=1, bias=False), nn.LeakyReLU(inplace=True),
+            nn.Conv2d(L, B, kernel_size=5, stride=1, padding=0, bias=False)) if h_s is None else h_s
+        self.gaussian_conditional = GaussianConditional(None)
+        self.num_latent_channels = num_latent_channels
+        self.num_bottleneck_channels = num_bottleneck_channels
+
+    def aux_loss(self):
+        return self.entropy_bottleneck.loss()
+
+    def encode(self, x, **kwargs):
+        y = self.g_a(x)
+        z = self.h_a(torch.abs(y))
+        z_shape = z.size()[-2:]
+        z_strings = self.entropy_bottleneck.compress(z)
+        z_hat = self.entropy_bottleneck.decompress(z_strings, z_shape)
+        scales_hat = self.h_s(z_hat)
+        indices = self.gaussian_conditional.build_indexes(scales_hat)
+        y_strings = self.gaussian_conditional.compress(y, indices)
+        return {'strings': [y_strings, z_strings], 'shape': z_shape}
+
+    def decode(self, strings, shape):
+        assert isinstance(strings, list) and len(strings) == 2
+        z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
+        scales_hat = self.h_s(z_hat)
+        indices = self.gaussian_conditional.build_indexes(scales_hat)
+        y_hat = self.gaussian_conditional.decompress(strings[0], indices, z_hat.dtype)
+        return self.g_s(y_hat)
+
+    def _get_means(self, x):
+        medians = self.entropy_bottleneck._get_medians().detach()
+        spatial_dims = len(x.size()) - 2
+        medians = self.entropy_bottleneck._extend_ndims(medians, spatial_dims)
+        return medians.expand(x.size(0), *([-1] * (spatial_dims + 1)))
+
+    def _forward2train(self, x, noise_z=None, noise_y=None):
+        y = self.g_a(x)
+        z = self.h_a(torch.abs(y))
+        z_hat, z_likelihoods = self.entropy_bottleneck(z, noise=noise_z)
+        scales_hat = self.h_s(z_hat)
+        y_hat, y_likelihoods = self.gaussian_conditional(y, scales_hat, noise=noise_y)
+        self.last_likelihoods = (y_likelihoods, z_likelihoods)
+        return self.g_s(y_hat)
+
+    def forward(self, x, **kw):
+        if self.updated:
+            if not self.training:
+                return self.decode(**self.encode(x))
+            y = self.g_a(x)
+            y_hat = self.gaussian_conditional.dequantize(
+                self.gaussian_conditional.quantize(y, 'dequantize', self._get_means(y)))
+            y_hat = y_hat.detach()
+            return self.g_s(y_hat)
+        return self._forward2train(x, **kw)
+
+    def update(self, scale_table=None, force=False):
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= self.entropy_bottleneck.update(force=force)
+        self.updated = True
+        return updated
+
+
+class MSHPBasedResNetBottleneck(SHPBasedResNetBottleneck):
+    """sc2bench/models/layer.py:723-817 restated (mean-scale hyperprior)."""
+
+    def __init__(self, num_input_channels=3, num_latent_channels=16, num_bottleneck_channels=24,
+                 num_target_channels=256, g_a_channel_sizes=None, g_s_channel_sizes=None):
+        L, B = num_latent_channels, num_bottleneck_channels
+        h_a = nn.Sequential(
+            nn.Conv2d(B, L, kernel_size=5, stride=2, padding=1, bias=False), nn.LeakyReLU(inplace=True),
+            nn.Conv2d(L, L, kernel_size=5, stride=2, padding=2, bias=False))
+        h_s = nn.Sequential(
+            nn.ConvTranspose2d(L, L, kernel_size=5, stride=2, padding=1, bias=False), nn.LeakyReLU(inplace=True),
+            nn.ConvTranspose2d(L, L * 3 // 2, kernel_size=5, stride=2, padding=1, bias=False),
+            nn.LeakyReLU(inplace=True),
+            nn.Conv2d(L * 3 // 2, B * 2, kernel_size=5, stride=1, padding=0, bias=False))
+        super().__init__(num_input_channels=num_input_channels, num_latent_channels=num_latent_channels,
+                         num_bottleneck_channels=num_bottleneck_channels, num_target_channels=num_target_channels,
+                         h_a=h_a, h_s=h_s, g_a_channel_sizes=g_a_channel_sizes, g_s_channel_sizes=g_s_channel_sizes)
+
+    def encode(self, x, **kwargs):
+        y = self.g_a(x)
+        z = self.h_a(y)
+        z_strings = self.entropy_bottleneck.compress(z)
+        z_shape = z.size()[-2:]
+        z_hat = self.entropy_bottleneck.decompress(z_strings, z_shape)
+        gaussian_params = self.h_s(z_hat)
+        scales_hat, means_hat = gaussian_params.chunk(2, 1)
+        indices = self.gaussian_conditional.build_indexes(scales_hat)
+        y_strings = self.gaussian_conditional.compress(y, indices, means=means_hat)
+        return {'strings': [y_strings, z_strings], 'shape': z_shape}
+
+    def decode(self, strings, shape):
+        assert isinstance(strings, list) and len(strings) == 2
+        z_hat = self.entropy_bottleneck.decompress(strings[1], shape)
+        gaussian_params = self.h_s(z_hat)
+        scales_hat, means_hat = gaussian_params.chunk(2, 1)
+        indices = self.gaussian_conditional.build_indexes(scales_hat)
+        y_hat = self.gaussian_conditional.decompress(strings[0], indices, means=means_hat)
+        return self.g_s(y_hat)
+
+    def _forward2train(self, x, noise_z=None, noise_y=None):
+        y = self.g_a(x)
+        z = self.h_a(y)
+        z_hat, z_likelihoods = self.entropy_bottleneck(z, noise=noise_z)
+        gaussian_params = self.h_s(z_hat)
+        scales_hat, means_hat = gaussian_params.chunk(2, 1)
+        y_hat, y_likelihoods = self.gaussian_conditional(y, scales_hat, means=means_hat, noise=noise_y)
+        self.last_likelihoods = (y_likelihoods, z_likelihoods)
+        return self.g_s(y_hat)
+
+    def forward(self, x, **kw):
+        if self.updated:
+            if not self.training:
+                return self.decode(**self.encode(x))
+            y = self.g_a(x)
+            z = self.h_a(y)
+            z_hat = self.entropy_bottleneck.dequantize(
+                self.entropy_bottleneck.quantize(z, 'dequantize', self._get_means(z)))
+            gaussian_params = self.h_s(z_hat)
+            scales_hat, means_hat = gaussian_params.chunk(2, 1)
+            y_hat = self.gaussian_conditional.dequantize(
+                self.gaussian_conditional.quantize(y, 'dequantize', means_hat))
+            y_hat = y_hat.detach()
+            return self.g_s(y_hat)
+        return self._forward2train(x, **kw)
 
 
 # --------------------------------------------------------------------------- #

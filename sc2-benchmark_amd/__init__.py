@@ -7,10 +7,11 @@ from . import hip  # noqa: F401
 from .analysis import ANALYZER_CLASS_DICT, AnalyzableModule, FileSizeAccumulator, FileSizeAnalyzer  # noqa: F401
 from .backbone import (BACKBONE_CLASS_DICT, BACKBONE_FUNC_DICT, MODEL_DICT, SplittableResNet,  # noqa: F401
                        UpdatableBackbone, check_if_updatable, get_backbone, splittable_resnet)
-from .entropy import (CompressionModel, EntropyBottleneck, GDN1, HipConv2d, LowerBound,  # noqa: F401
-                      NonNegativeParametrizer)
+from .entropy import (CompressionModel, EntropyBottleneck, GDN1, GaussianConditional, HipConv2d,  # noqa: F401
+                      HipConvTranspose2d, LowerBound, NonNegativeParametrizer, get_scale_table)
 from .layer import (LAYER_CLASS_DICT, LAYER_FUNC_DICT, BaseBottleneck, EntropyBottleneckLayer,  # noqa: F401
-                    FPBasedResNetBottleneck, get_layer, register_layer_class, register_layer_func)
+                    FPBasedResNetBottleneck, MSHPBasedResNetBottleneck, SHPBasedResNetBottleneck, get_layer,
+                    register_layer_class, register_layer_func)
 from .loss import BppLoss  # noqa: F401
 
 __version__ = '0.1.0'

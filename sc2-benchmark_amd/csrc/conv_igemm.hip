@@ -269,6 +269,7 @@ __device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned
                     else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
                     else if (epi == SC2_EPI_BIAS) r = norm;
                     else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
+                    else if (epi == SC2_EPI_BIAS_LEAKY_RELU) r = norm > 0.f ? norm : 0.01f * norm;
                     else r = fmaxf(norm + xv[t], 0.f);
                     v[t] = r;
                 }
@@ -375,6 +376,7 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                         else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
                         else if (epi == SC2_EPI_BIAS) r = norm;
                         else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
+                    else if (epi == SC2_EPI_BIAS_LEAKY_RELU) r = norm > 0.f ? norm : 0.01f * norm;
                         else r = fmaxf(norm + xv[t], 0.f);
                         v[t] = r;
                     }
@@ -407,6 +409,7 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                     else if (epi == SC2_EPI_IGDN) v = xv * norm;
                     else if (epi == SC2_EPI_BIAS) v = norm;
                     else if (epi == SC2_EPI_BIAS_RELU) v = fmaxf(norm, 0.f);
+                    else if (epi == SC2_EPI_BIAS_LEAKY_RELU) v = norm > 0.f ? norm : 0.01f * norm;
                     else v = fmaxf(norm + xv, 0.f);
                 }
                 const int img = m / p.OHW;
@@ -1171,7 +1174,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS, SC2_ERR_INVALID_ARG, "conv2d: bad a_op");
     SC2_REQUIRE(d->k_order >= 0 && d->k_order <= 3 && (!(d->k_order & SC2_K_SLAB_MAJOR) || d->Cin % 32 == 0),
                 SC2_ERR_INVALID_ARG, "conv2d: slab-major K order needs Cin %% 32 == 0 (Cin = %d)", d->Cin);
-    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_FUSED_IGDN, SC2_ERR_INVALID_ARG,
+    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_BIAS_LEAKY_RELU, SC2_ERR_INVALID_ARG,
                 "conv2d: bad epilogue");
     const bool fused = d->epilogue == SC2_EPI_FUSED_GDN || d->epilogue == SC2_EPI_FUSED_IGDN;
     if (fused)

@@ -8,6 +8,8 @@ behaviour, but every tensor-sized computation runs in the HIP library (``hip.py`
 per-channel scalar work (reparametrisation of beta/gamma, softplus/tanh of the 58 bottleneck
 parameters per channel, the once-per-model CDF table build) uses torch ops.
 """
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -107,6 +109,118 @@ class HipConv2d(nn.Conv2d):
             return hip.conv2d_fwd(x_nhwc, packed, self.out_channels, self.kernel_size[0], self.kernel_size[1],
                                   self.stride, self.padding, out_format=hip.OUT_F32_NCHW)
         return self.forward_nhwc(x_nhwc, out_format=hip.OUT_F32_NCHW)
+
+
+class HipConvTranspose2d(nn.ConvTranspose2d):
+    """nn.ConvTranspose2d(bias=False) parameter holder (h_s of the hyperprior bottlenecks, layer.py:612-621) whose
+    forward runs on the implicit-GEMM kernel: a transposed convolution is, per stride-parity class of the output, a
+    stride-1 correlation with the flipped sub-filter of the taps that reach that class; each class is one launch that
+    scatters its rows to every s-th output pixel (the data-gradient path of the training code, `hip.conv2d_dgrad`).
+    The packed sub-filters are cached per parameter version."""
+
+    def _classes(self):
+        key = (self.weight._version, self.weight.device, self.weight.data_ptr())
+        if getattr(self, '_cls_key', None) != key:
+            assert self.bias is None and self.groups == 1 and self.dilation == (1, 1) and self.output_padding == (0, 0)
+            cin, cout, KH, KW = self.weight.shape          # ConvTranspose2d weight: [in, out, kh, kw]
+            sh, sw = self.stride
+            ph, pw = self.padding
+            wt = self.weight.detach().permute(1, 0, 2, 3)   # [out, in, kh, kw]: rows = output channels
+            classes = []
+            for ch in range(sh):
+                rh = (ch + ph) % sh
+                khs = list(range(rh, KH, sh))
+                for cw in range(sw):
+                    rw = (cw + pw) % sw
+                    kws = list(range(rw, KW, sw))
+                    if not khs or not kws:
+                        raise hip.Sc2Error('HipConvTranspose2d: a stride-parity class without taps (k={} s={} p={})'
+                                           .format((KH, KW), (sh, sw), (ph, pw)))
+                    qh, qw = (ch + ph - rh) // sh, (cw + pw - rw) // sw
+                    pad_h, pad_w = len(khs) - 1 - qh, len(kws) - 1 - qw
+                    if pad_h < 0 or pad_w < 0:
+                        raise hip.Sc2Error('HipConvTranspose2d: unsupported geometry k={} s={} p={}'
+                                           .format((KH, KW), (sh, sw), (ph, pw)))
+                    sub = wt[:, :, khs][:, :, :, kws].flip(2, 3).contiguous()
+                    classes.append((ch, cw, len(khs), len(kws), pad_h, pad_w, hip.pack_conv_weight(sub)))
+            self._cls = classes
+            self._cls_key = key
+        return self._cls
+
+    def forward_nhwc(self, x_nhwc, epilogue=hip.EPI_NONE, ep_beta=None, out_format=hip.OUT_BF16_NHWC):
+        """x bf16 [N,H,W,Cin] -> [N,(H-1)s-2p+k,(W-1)s-2p+k,Cout] (bf16, or f32 NHWC)."""
+        N, H, W, _ = x_nhwc.shape
+        sh, sw = self.stride
+        OH = (H - 1) * sh - 2 * self.padding[0] + self.kernel_size[0]
+        OW = (W - 1) * sw - 2 * self.padding[1] + self.kernel_size[1]
+        cout = self.out_channels
+        out = torch.empty((N, OH, OW, cout), dtype=torch.bfloat16 if out_format == hip.OUT_BF16_NHWC else torch.float32,
+                          device=x_nhwc.device)
+        for ch, cw, nkh, nkw, pad_h, pad_w, packed in self._classes():
+            rows = (OH - ch + sh - 1) // sh if OH > ch else 0
+            cols = (OW - cw + sw - 1) // sw if OW > cw else 0
+            if rows == 0 or cols == 0:
+                continue
+            if sh == 1 and sw == 1:
+                hip.conv2d_fwd(x_nhwc, packed, cout, nkh, nkw, 1, (pad_h, pad_w), epilogue=epilogue, ep_beta=ep_beta,
+                               out_format=out_format, out=out, tag=getattr(self, '_tag', None))
+            else:
+                hip.conv2d_fwd(x_nhwc, packed, cout, nkh, nkw, 1, (pad_h, pad_w), epilogue=epilogue, ep_beta=ep_beta,
+                               out_format=out_format, tag=getattr(self, '_tag', None),
+                               scatter=(rows, cols, out, sh, sw, ch, cw))
+        return out
+
+    def forward(self, x, output_size=None):
+        _require_device(x, 'HipConvTranspose2d')
+        out = self.forward_nhwc(hip.nchw_f32_to_nhwc_bf16(x.float()), out_format=hip.OUT_F32_NHWC)
+        return out.permute(0, 3, 1, 2).contiguous()
+
+
+def run_hip_sequence(seq, x_nhwc, a_op=hip.AOP_NONE, last_out_format=hip.OUT_F32_NCHW):
+    """Runs an nn.Sequential of HipConv2d / HipConvTranspose2d / ReLU / LeakyReLU (the h_a / h_s transforms of the
+    hyperprior bottlenecks) on bf16 NHWC activations; an activation is fused into the preceding conv's epilogue.
+    `a_op` applies to the first conv's input (|y| of the scale hyperprior).  Any other module runs as a torch
+    module on the device, on an f32 NCHW copy.  Returns the last layer's output in `last_out_format`."""
+    mods = list(seq)
+    h = x_nhwc
+    i = 0
+    first = True
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        last = (i + 1 >= len(mods)) or (isinstance(nxt, (nn.ReLU, nn.LeakyReLU)) and i + 2 >= len(mods))
+        fmt = last_out_format if last else hip.OUT_BF16_NHWC
+        if isinstance(m, (HipConv2d, HipConvTranspose2d)):
+            epi, beta = hip.EPI_NONE, None
+            if isinstance(nxt, nn.ReLU):
+                epi = hip.EPI_BIAS_RELU
+            elif isinstance(nxt, nn.LeakyReLU) and abs(nxt.negative_slope - 0.01) < 1e-12:
+                epi = hip.EPI_BIAS_LEAKY_RELU
+            if epi != hip.EPI_NONE:
+                beta = torch.zeros(m.out_channels, dtype=torch.float32, device=h.device)
+                i += 1
+            if isinstance(m, HipConv2d):
+                assert m.bias is None
+                h = hip.conv2d_fwd(h, m.packed_weight(), m.out_channels, m.kernel_size[0], m.kernel_size[1], m.stride,
+                                   m.padding, a_op=a_op if first else hip.AOP_NONE, epilogue=epi, ep_beta=beta,
+                                   out_format=fmt, tag=getattr(m, '_tag', None), k_order=m.k_order())
+            else:
+                if first and a_op != hip.AOP_NONE:
+                    h = h.abs()
+                if fmt == hip.OUT_F32_NCHW:
+                    h = m.forward_nhwc(h, epi, beta, out_format=hip.OUT_F32_NHWC).permute(0, 3, 1, 2).contiguous()
+                else:
+                    h = m.forward_nhwc(h, epi, beta, out_format=fmt)
+        else:
+            x32 = h.float().permute(0, 3, 1, 2)
+            if first and a_op != hip.AOP_NONE:
+                x32 = x32.abs()
+            y32 = m(x32.contiguous())
+            h = y32.contiguous() if last and last_out_format == hip.OUT_F32_NCHW else \
+                hip.nchw_f32_to_nhwc_bf16(y32.float().contiguous())
+        first = False
+        i += 1
+    return h
 
 
 class GDN1(nn.Module):
@@ -451,6 +565,14 @@ class EntropyBottleneck(nn.Module):
         return hip.eb_dequantize(sym.view(sym.shape[0], C, *size), self._median_vector(), want_f32=want_f32,
                                  want_nhwc=want_nhwc)
 
+    @staticmethod
+    def unpack_strings(buf, off, nb):
+        """Device streams (end-aligned rows of an encode) -> list[bytes]."""
+        nb_h = nb.cpu().numpy()
+        off_h = off.cpu().numpy()
+        host = buf.cpu().numpy()
+        return [host[i, int(off_h[i]):int(off_h[i]) + int(nb_h[i])].tobytes() for i in range(host.shape[0])]
+
     def compress(self, x):
         """Returns list[bytes], one rANS stream per batch item (EntropyBottleneck.compress, layer.py:506)."""
         buf, off, nb, st = self.compress_device(x)
@@ -499,6 +621,190 @@ class EntropyBottleneck(nn.Module):
             raise hip.Sc2Error('EntropyBottleneck.decompress: module is on {}; HIP device required'.format(dev))
         buf, off, nb = self.pack_strings(strings, dev)
         return self.decompress_device(buf, off, nb, tuple(size), want_f32=True)[0]
+
+
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
+
+
+def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
+    """compressai.models.google.get_scale_table (imported by the reference at layer.py:5)."""
+    return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
+
+
+class GaussianConditional(nn.Module):
+    """Gaussian conditional entropy model with CompressAI 1.2.x semantics, as the hyperprior
+    bottlenecks use it (layer.py:627,646-647,665,679,691-693,702,776,785,794,811-813).  forward / quantize /
+    dequantize / build_indexes / compress / decompress run in the HIP library (per-symbol CDF rows through the
+    explicit-`indexes` path of the batched rANS coder); ``update_scale_table()`` builds the integer tables once
+    per model on the host, as the reference does (scipy's normal quantile + the C++ CDF quantiser)."""
+
+    def __init__(self, scale_table=None, *args, scale_bound=0.11, tail_mass=1e-9, likelihood_bound=1e-9,
+                 entropy_coder_precision=16, **kwargs):
+        super().__init__()
+        if not isinstance(scale_table, (type(None), list, tuple)):
+            raise ValueError('Invalid type for scale_table "{}"'.format(type(scale_table)))
+        if isinstance(scale_table, (list, tuple)) and len(scale_table) < 1:
+            raise ValueError('Invalid scale_table length "{}"'.format(len(scale_table)))
+        if scale_table and (scale_table != sorted(scale_table) or any(s <= 0 for s in scale_table)):
+            raise ValueError('Invalid scale_table "({})"'.format(scale_table))
+        self.tail_mass = float(tail_mass)
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        self.use_likelihood_bound = likelihood_bound > 0
+        self.likelihood_bound = float(likelihood_bound)
+        if self.use_likelihood_bound:
+            self.likelihood_lower_bound = LowerBound(likelihood_bound)
+        if scale_bound is None and scale_table:
+            scale_bound = scale_table[0]
+        if scale_bound <= 0:
+            raise ValueError('Invalid parameters')
+        self.lower_bound_scale = LowerBound(scale_bound)
+        self.register_buffer('_offset', torch.IntTensor())
+        self.register_buffer('_quantized_cdf', torch.IntTensor())
+        self.register_buffer('_cdf_length', torch.IntTensor())
+        self.register_buffer('scale_table', self._prepare_scale_table(scale_table) if scale_table else torch.Tensor())
+        self.register_buffer('scale_bound', torch.Tensor([float(scale_bound)]) if scale_bound is not None else None)
+        self._scale_bound = float(scale_bound)
+
+    @staticmethod
+    def _prepare_scale_table(scale_table):
+        return torch.Tensor(tuple(float(s) for s in scale_table))
+
+    @staticmethod
+    def _standardized_cumulative(inputs):
+        half = float(0.5)
+        const = float(-(2 ** -0.5))
+        return half * torch.erfc(const * inputs)
+
+    @staticmethod
+    def _standardized_quantile(quantile):
+        import scipy.stats
+        return scipy.stats.norm.ppf(quantile)
+
+    _pmf_to_cdf = EntropyBottleneck._pmf_to_cdf
+    _check_cdf_size = EntropyBottleneck._check_cdf_size
+    _check_offsets_size = EntropyBottleneck._check_offsets_size
+    _check_cdf_length = EntropyBottleneck._check_cdf_length
+    _tables = EntropyBottleneck._tables
+    pack_strings = EntropyBottleneck.pack_strings
+    dequantize = staticmethod(EntropyBottleneck.dequantize)
+
+    def update_scale_table(self, scale_table, force=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        device = self.scale_table.device
+        self.scale_table = self._prepare_scale_table(scale_table).to(device)
+        self.update()
+        return True
+
+    @torch.no_grad()
+    def update(self):
+        dev = self.scale_table.device
+        table = self.scale_table.detach().cpu()          # host build in f32 torch CPU ops, upstream's op order
+        multiplier = -self._standardized_quantile(self.tail_mass / 2)
+        pmf_center = torch.ceil(table * multiplier).int()
+        pmf_length = 2 * pmf_center + 1
+        max_length = torch.max(pmf_length).item()
+        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None])
+        samples_scale = table.unsqueeze(1)
+        samples = samples.float()
+        samples_scale = samples_scale.float()
+        upper = self._standardized_cumulative((0.5 - samples) / samples_scale)
+        lower = self._standardized_cumulative((-0.5 - samples) / samples_scale)
+        pmf = upper - lower
+        tail_mass = 2 * lower[:, :1]
+        quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length)
+        self._quantized_cdf = quantized_cdf.to(dev)
+        self._offset = (-pmf_center).to(dev)
+        self._cdf_length = (pmf_length + 2).to(dev)
+
+    # ---- quantisation (EntropyModel.quantize; reference calls layer.py:691-693,811-813)
+    def quantize(self, inputs, mode, means=None):
+        if mode not in ('noise', 'dequantize', 'symbols'):
+            raise ValueError('Invalid quantization mode: "{}"'.format(mode))
+        _require_device(inputs, 'GaussianConditional.quantize')
+        if mode == 'noise':
+            half = float(0.5)
+            noise = torch.empty_like(inputs).uniform_(-half, half)
+            return inputs + noise
+        x = inputs.float().contiguous()
+        if means is not None:
+            means = means.detach().float().expand_as(x)    # raises like upstream's broadcast if the shapes clash
+        if mode == 'symbols':
+            return hip.gc_symbols_indexes(x, None, means, None, want_indexes=False)[0]
+        return hip.gc_forward(x, None, means, mode=hip.EB_DEQUANTIZE, scale_bound=self._scale_bound, want_lik=False)[0]
+
+    def forward(self, inputs, scales, means=None, training=None, noise=None):
+        """Returns (outputs, likelihoods), f32 with the input's shape.  ``noise`` overrides the U(-.5,.5) draw."""
+        if training is None:
+            training = self.training
+        _require_device(inputs, 'GaussianConditional.forward')
+        x = inputs.float().contiguous()
+        bound = self.likelihood_bound if self.use_likelihood_bound else 0.0
+        if training:
+            if noise is None:
+                half = float(0.5)
+                noise = torch.empty_like(x).uniform_(-half, half)
+            return hip.gc_forward(x, scales.float(), None if means is None else means.float(),
+                                  noise=noise.float().contiguous(), mode=hip.EB_NOISE, scale_bound=self._scale_bound,
+                                  lik_bound=bound)
+        return hip.gc_forward(x, scales.float(), None if means is None else means.float(), mode=hip.EB_DEQUANTIZE,
+                              scale_bound=self._scale_bound, lik_bound=bound)
+
+    def build_indexes(self, scales):
+        _require_device(scales, 'GaussianConditional.build_indexes')
+        if self.scale_table.numel() == 0:
+            raise ValueError('Uninitialized scale table. Run update() first')
+        return hip.gc_symbols_indexes(None, scales.float(), None, self.scale_table.float().contiguous(),
+                                      scale_bound=self._scale_bound, want_symbols=False)[1]
+
+    # ---- entropy coding on the device
+    def compress_device(self, inputs, indexes, means=None, out_stride=None):
+        """f32 [N,C,*spatial], int32 indexes -> (buf, offset, nbytes, status) on the device."""
+        if len(inputs.size()) < 2:
+            raise ValueError('Invalid `inputs` size. Expected a tensor with at least 2 dimensions.')
+        if inputs.size() != indexes.size():
+            raise ValueError('`inputs` and `indexes` should have the same size.')
+        cdf, cdf_len, offset = self._tables()
+        x = inputs.float().contiguous()
+        sym = hip.gc_symbols_indexes(x, None, None if means is None else means.float(), None, want_indexes=False)[0]
+        N = x.shape[0]
+        return hip.rans_encode_batch(sym.view(N, -1), cdf, cdf_len, offset,
+                                     indexes=indexes.int().contiguous().view(N, -1), out_stride=out_stride)
+
+    def compress(self, inputs, indexes, means=None):
+        """-> list[bytes], one rANS stream per batch item (EntropyModel.compress, layer.py:647,776)."""
+        buf, off, nb, st = self.compress_device(inputs, indexes, means)
+        if int(st.max().item()) != 0:
+            buf, off, nb, st = self.compress_device(inputs, indexes, means,
+                                                    out_stride=hip.rans_max_bytes(inputs[0].numel()))
+        nb_h = nb.cpu().numpy()
+        stride = buf.shape[1]
+        width = int(nb_h.max())
+        tail = buf[:, stride - width:].contiguous().cpu().numpy()
+        return [tail[i, width - int(nb_h[i]):].tobytes() for i in range(tail.shape[0])]
+
+    def decompress_device(self, buf, off, nb, indexes, means=None, want_f32=True, want_nhwc=False):
+        cdf, cdf_len, offset = self._tables()
+        N = indexes.shape[0]
+        sym, _ = hip.rans_decode_batch(buf, off, nb, indexes[0].numel(), cdf, cdf_len, offset,
+                                       indexes=indexes.int().contiguous().view(N, -1))
+        return hip.gc_dequantize(sym.view(indexes.shape), None if means is None else means.float(), want_f32=want_f32,
+                                 want_nhwc=want_nhwc)
+
+    def decompress(self, strings, indexes, dtype=torch.float, means=None):
+        """list[bytes], indexes -> f32 tensor shaped like indexes (EntropyModel.decompress, layer.py:665,785)."""
+        if not isinstance(strings, (tuple, list)):
+            raise ValueError('Invalid `strings` parameter type.')
+        if not len(strings) == indexes.size(0):
+            raise ValueError('Invalid strings or indexes parameters')
+        if means is not None and (means.size()[:2] != indexes.size()[:2]):
+            raise ValueError('Invalid means or indexes parameters')
+        dev = indexes.device
+        if dev.type != 'cuda':
+            raise hip.Sc2Error('GaussianConditional.decompress: indexes are on {}; HIP device required'.format(dev))
+        buf, off, nb = self.pack_strings(strings, dev)
+        out = self.decompress_device(buf, off, nb, indexes, means)[0]
+        return out if means is not None else out.type(dtype)
 
 
 class _CpuReplica(object):
@@ -559,10 +865,14 @@ class CompressionModel(nn.Module):
         return loss
 
     def update(self, scale_table=None, force=False, update_quantiles=False):
+        if scale_table is None:
+            scale_table = get_scale_table()
         updated = False
         for m in self.modules():
             if isinstance(m, EntropyBottleneck):
                 updated |= m.update(force=force, update_quantiles=update_quantiles)
+            if isinstance(m, GaussianConditional):
+                updated |= m.update_scale_table(scale_table, force=force)
         return updated
 
     def load_state_dict(self, state_dict, strict=True):

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get('SC2_LIB') or os.path.join(_HERE, 'libsc2amd.so')   # 
 _lib = None
 
 AOP_NONE, AOP_ABS = 0, 1
-EPI_NONE, EPI_GDN, EPI_IGDN, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_ADD_RELU, EPI_FUSED_GDN, EPI_FUSED_IGDN = range(8)
+EPI_NONE, EPI_GDN, EPI_IGDN, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_ADD_RELU, EPI_FUSED_GDN, EPI_FUSED_IGDN, \
+    EPI_BIAS_LEAKY_RELU = range(9)
 FUSABLE_GDN_CHANNELS = (32, 48, 64, 96)   # conv + GDN1 in one launch: one tile must hold every output channel
 OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
 EB_NOISE, EB_DEQUANTIZE = 0, 1
@@ -27,6 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
+    'sc2_gc_forward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
 ]
@@ -71,6 +73,9 @@ def lib():
     L.sc2_eb_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
     L.sc2_eb_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
     L.sc2_eb_bits_partial_len.argtypes = [i32, i32, i32]
+    L.sc2_gc_forward.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, i32, f32, f32, vp, vp, vp]
+    L.sc2_gc_symbols_indexes.argtypes = [vp, vp, i64, vp, i64, i64, i64, vp, i32, f32, vp, vp, vp]
+    L.sc2_gc_dequantize.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp]
     L.sc2_eb_symbols.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.sc2_eb_dequantize.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     L.sc2_pmf_to_quantized_cdf.argtypes = [ctypes.POINTER(ctypes.c_float), i32, i32,
@@ -510,6 +515,86 @@ def eb_dequantize(symbols, medians, want_f32=True, want_nhwc=False):
     _check(lib().sc2_eb_dequantize(_ptr(symbols), _ptr(medians), N, C, HW, _ptr(f32), _ptr(nhwc), _stream()),
            'eb_dequantize')
     return f32, nhwc
+
+
+# --------------------------------------------------------------------------------------------- #
+# GaussianConditional (hyperprior bottlenecks)
+# --------------------------------------------------------------------------------------------- #
+def _img_slice(t, ref, name):
+    """f32 tensor with ref's shape that is dense inside each batch item (possibly a channel slice of a wider
+    tensor, e.g. gaussian_params.chunk(2, 1)) -> (tensor, per-image element stride)."""
+    _dev(t, name)
+    assert t.dtype == torch.float32 and tuple(t.shape) == tuple(ref.shape), name
+    if t.dim() < 2 or not t[0].is_contiguous():
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else t[0].numel())
+
+
+def gc_forward(y, scales, means=None, noise=None, mode=EB_DEQUANTIZE, scale_bound=0.11, lik_bound=1e-9,
+               want_y_hat=True, want_lik=True):
+    """GaussianConditional.forward: y f32 [N,C,*spatial] contiguous -> (y_hat, likelihoods)."""
+    _dev(y, 'y')
+    assert y.dtype == torch.float32 and y.is_contiguous()
+    N, chw = y.shape[0], y[0].numel()
+    s_stride = m_stride = 0
+    if scales is not None:
+        scales, s_stride = _img_slice(scales, y, 'scales')
+    if means is not None:
+        means, m_stride = _img_slice(means, y, 'means')
+    if noise is not None:
+        _dev(noise, 'noise')
+        assert noise.shape == y.shape and noise.dtype == torch.float32 and noise.is_contiguous()
+    y_hat = torch.empty_like(y) if want_y_hat else None
+    lik = torch.empty_like(y) if want_lik else None
+    _check(lib().sc2_gc_forward(_ptr(y), _ptr(scales), s_stride, _ptr(means), m_stride, _ptr(noise), N, chw, int(mode),
+                                float(scale_bound), float(lik_bound), _ptr(y_hat), _ptr(lik), _stream()), 'gc_forward')
+    return y_hat, lik
+
+
+def gc_symbols_indexes(y, scales, means, scale_table, scale_bound=0.11, want_symbols=True, want_indexes=True):
+    """-> (symbols int32 like y or None, indexes int32 like scales or None)."""
+    ref = y if y is not None else scales
+    _dev(ref, 'y')
+    N, chw = ref.shape[0], ref[0].numel()
+    s_stride = m_stride = 0
+    if y is not None:
+        assert y.dtype == torch.float32 and y.is_contiguous()
+    if scales is not None:
+        scales, s_stride = _img_slice(scales, ref, 'scales')
+    if means is not None:
+        means, m_stride = _img_slice(means, ref, 'means')
+    n_table = 0
+    if want_indexes:
+        _dev(scale_table, 'scale_table')
+        assert scale_table.dtype == torch.float32 and scale_table.is_contiguous()
+        n_table = scale_table.numel()
+    sym = torch.empty(ref.shape, dtype=torch.int32, device=ref.device) if want_symbols else None
+    idx = torch.empty(ref.shape, dtype=torch.int32, device=ref.device) if want_indexes else None
+    _check(lib().sc2_gc_symbols_indexes(_ptr(y), _ptr(scales), s_stride, _ptr(means), m_stride, N, chw,
+                                        _ptr(scale_table) if want_indexes else None, n_table, float(scale_bound),
+                                        _ptr(sym), _ptr(idx), _stream()), 'gc_symbols_indexes')
+    return sym, idx
+
+
+def gc_dequantize(symbols, means=None, want_f32=True, want_nhwc=False):
+    """symbols int32 [N,C,*spatial] -> (y_hat f32 NCHW or None, y_hat bf16 NHWC or None); y_hat = symbols + means."""
+    _dev(symbols, 'symbols')
+    assert symbols.dtype == torch.int32 and symbols.is_contiguous() and symbols.dim() >= 3
+    N, C = symbols.shape[0], symbols.shape[1]
+    HW = symbols[0, 0].numel()
+    m_stride = 0
+    if means is not None:
+        _dev(means, 'means')
+        assert means.dtype == torch.float32 and tuple(means.shape) == tuple(symbols.shape)
+        if not means[0].is_contiguous():
+            means = means.contiguous()
+        m_stride = means.stride(0) if N > 1 else means[0].numel()
+    y_hat = torch.empty(symbols.shape, dtype=torch.float32, device=symbols.device) if want_f32 else None
+    nhwc = torch.empty((N,) + tuple(symbols.shape[2:]) + (C,), dtype=torch.bfloat16, device=symbols.device) \
+        if want_nhwc else None
+    _check(lib().sc2_gc_dequantize(_ptr(symbols), _ptr(means), m_stride, N, C, HW, _ptr(y_hat), _ptr(nhwc), _stream()),
+           'gc_dequantize')
+    return y_hat, nhwc
 
 
 # --------------------------------------------------------------------------------------------- #

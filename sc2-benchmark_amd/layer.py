@@ -11,7 +11,8 @@ import torch
 from torch import nn
 
 from . import hip
-from .entropy import CompressionModel, GDN1, HipConv2d, _require_device
+from .entropy import (CompressionModel, GDN1, GaussianConditional, HipConv2d, HipConvTranspose2d, _require_device,
+                      get_scale_table, run_hip_sequence, update_registered_buffers)
 
 LAYER_CLASS_DICT = dict()
 LAYER_FUNC_DICT = dict()
@@ -111,18 +112,28 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             GDN1(d[2], inverse=True),
             HipConv2d(d[2], d[3], kernel_size=2, stride=1, padding=1, bias=False)
         )
-        for prefix, seq in (('enc', self.encoder), ('dec', self.decoder)):
+        self._init_transforms()
+
+    def _g_a(self):
+        return self.encoder
+
+    def _g_s(self):
+        return self.decoder
+
+    def _init_transforms(self):
+        """Launch tags + pipeline switches shared by every bottleneck built on the FP analysis / synthesis stacks."""
+        for prefix, seq in (('enc', self._g_a()), ('dec', self._g_s())):
             for i, mod in enumerate(seq):
                 mod._tag = '{}.{}{}'.format(prefix, 'igdn' if getattr(mod, 'inverse', False) else
                                             'gdn' if isinstance(mod, GDN1) else 'conv', i)
         self.output_format = 'f32_nchw'
-        self.fuse_gdn = True    # conv + GDN1 in one launch where one tile holds all output channels (encoder)
+        self.fuse_gdn = True    # conv + GDN1 in one launch where one tile holds all output channels
         self._conv0_pack = None
         self._conv0_key = None
 
     # ---- fused pipelines on bf16 NHWC ---------------------------------------------------------- #
     def _conv0_packed(self):
-        w = self.encoder[0].weight
+        w = self._g_a()[0].weight
         key = (w._version, w.device, w.data_ptr())
         if self._conv0_key != key:
             self._conv0_pack = hip.pack_conv0_weight_pairs(w)
@@ -130,14 +141,14 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         return self._conv0_pack
 
     def _uses_pair_conv0(self, x):
-        c0 = self.encoder[0]
+        c0 = self._g_a()[0]
         return (c0.in_channels <= 4 and c0.kernel_size == (5, 5) and c0.stride == (2, 2) and c0.padding == (2, 2)
                 and x.shape[-1] % 2 == 0 and c0.out_channels % 8 == 0)
 
     def analysis(self, x):
         """encoder(x): f32 NCHW image batch -> f32 NCHW latent (layer.py:475-483)."""
         _require_device(x, 'FPBasedResNetBottleneck')
-        c0, g1, c2, g3, c4 = self.encoder
+        c0, g1, c2, g3, c4 = self._g_a()
         x = x.float()
         fuse0 = self.fuse_gdn and c0.out_channels in hip.FUSABLE_GDN_CHANNELS
         fuse2 = self.fuse_gdn and c2.out_channels in hip.FUSABLE_GDN_CHANNELS
@@ -177,7 +188,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
 
     def synthesis_nhwc(self, y_hat_nhwc):
         """decoder on a bf16 NHWC latent (layer.py:485-493); output per ``self.output_format``."""
-        c0, g1, c2, g3, c4 = self.decoder
+        c0, g1, c2, g3, c4 = self._g_s()
         if (self.fuse_gdn and g1.in_channels == c0.out_channels and
                 hip.conv2x2_gdn512_supported(c0.in_channels, c0.out_channels, c0.kernel_size[0], c0.kernel_size[1],
                                              c0.stride, c0.padding)):
@@ -265,6 +276,246 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                 self.entropy_bottleneck.quantize(encoded_output, 'dequantize', self._get_means(encoded_output)))
             decoder_input = decoder_input.detach()
             return self.synthesis(decoder_input)
+        return self._forward2train(x)
+
+
+def _hyper_transform(seq):
+    """nn.Conv2d / nn.ConvTranspose2d (bias-free) of a user-supplied h_a / h_s -> their HIP-backed subclasses in place
+    (same parameters, same state-dict keys)."""
+    for i, m in enumerate(seq):
+        if type(m) is nn.Conv2d and m.bias is None and m.groups == 1 and m.dilation == (1, 1):
+            c = HipConv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, bias=False)
+            c.weight = m.weight
+            seq[i] = c
+        elif type(m) is nn.ConvTranspose2d and m.bias is None and m.groups == 1 and m.dilation == (1, 1) and \
+                m.output_padding == (0, 0):
+            c = HipConvTranspose2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, bias=False)
+            c.weight = m.weight
+            seq[i] = c
+    return seq
+
+
+@register_layer_class
+class SHPBasedResNetBottleneck(BaseBottleneck):
+    """Scale-hyperprior encoder / hyper-codec / decoder for ResNet (layer.py:553-720).
+
+    g_a / g_s are the FP bottleneck's analysis / synthesis stacks (same fused kernels); h_a / h_s run on the
+    implicit-GEMM kernel (transposed convolutions as stride-parity classes); the latent y is coded with the
+    Gaussian conditional model whose per-element CDF rows come from h_s(z_hat), z with the factorised prior.
+
+    :param num_input_channels: number of input channels
+    :param num_latent_channels: number of latent (hyper) channels
+    :param num_bottleneck_channels: number of bottleneck channels
+    :param num_target_channels: number of output channels of the decoder
+    :param h_a: parametric transform h_a or None
+    :param h_s: parametric transform h_s or None
+    :param g_a_channel_sizes: 4 channel counts of g_a or None
+    :param g_s_channel_sizes: 4 channel counts of g_s or None
+    """
+
+    def __init__(self, num_input_channels=3, num_latent_channels=16, num_bottleneck_channels=24,
+                 num_target_channels=256, h_a=None, h_s=None, g_a_channel_sizes=None, g_s_channel_sizes=None):
+        if g_a_channel_sizes is None:
+            g_a_channel_sizes = \
+                [num_input_channels, num_bottleneck_channels * 4, num_bottleneck_channels * 2, num_bottleneck_channels]
+        else:
+            num_bottleneck_channels = g_a_channel_sizes[3]
+        if g_s_channel_sizes is None:
+            g_s_channel_sizes = \
+                [g_a_channel_sizes[-1], num_target_channels * 2, num_target_channels, num_target_channels]
+        super().__init__(entropy_bottleneck_channels=num_latent_channels)
+        a, g = g_a_channel_sizes, g_s_channel_sizes
+        self.g_a = nn.Sequential(
+            HipConv2d(a[0], a[1], kernel_size=5, stride=2, padding=2, bias=False),
+            GDN1(a[1]),
+            HipConv2d(a[1], a[2], kernel_size=5, stride=2, padding=2, bias=False),
+            GDN1(a[2]),
+            HipConv2d(a[2], a[3], kernel_size=2, stride=1, padding=0, bias=False)
+        )
+        self.g_s = nn.Sequential(
+            HipConv2d(g[0], g[1], kernel_size=2, stride=1, padding=1, bias=False),
+            GDN1(g[1], inverse=True),
+            HipConv2d(g[1], g[2], kernel_size=2, stride=1, padding=0, bias=False),
+            GDN1(g[2], inverse=True),
+            HipConv2d(g[2], g[3], kernel_size=2, stride=1, padding=1, bias=False)
+        )
+        L, B = num_latent_channels, num_bottleneck_channels
+        self.h_a = nn.Sequential(
+            HipConv2d(B, L, kernel_size=5, stride=2, padding=1, bias=False),
+            nn.ReLU(inplace=True),
+            HipConv2d(L, L, kernel_size=5, stride=2, padding=2, bias=False)
+        ) if h_a is None else _hyper_transform(h_a)
+        self.h_s = nn.Sequential(
+            HipConvTranspose2d(L, L, kernel_size=5, stride=2, padding=1, bias=False),
+            nn.LeakyReLU(inplace=True),
+            HipConvTranspose2d(L, L, kernel_size=5, stride=2, padding=1, bias=False),
+            nn.LeakyReLU(inplace=True),
+            HipConv2d(L, B, kernel_size=5, stride=1, padding=0, bias=False)
+        ) if h_s is None else _hyper_transform(h_s)
+        self.gaussian_conditional = GaussianConditional(None)
+        self.num_latent_channels = num_latent_channels
+        self.num_bottleneck_channels = num_bottleneck_channels
+        self._init_transforms()
+        for prefix, seq in (('h_a', self.h_a), ('h_s', self.h_s)):
+            for i, mod in enumerate(seq):
+                mod._tag = '{}.{}'.format(prefix, i)
+
+    # the FP bottleneck's fused analysis / synthesis pipelines, on g_a / g_s
+    _g_a = lambda self: self.g_a        # noqa: E731
+    _g_s = lambda self: self.g_s        # noqa: E731
+    _init_transforms = FPBasedResNetBottleneck._init_transforms
+    _conv0_packed = FPBasedResNetBottleneck._conv0_packed
+    _uses_pair_conv0 = FPBasedResNetBottleneck._uses_pair_conv0
+    analysis = FPBasedResNetBottleneck.analysis
+    synthesis_nhwc = FPBasedResNetBottleneck.synthesis_nhwc
+    synthesis = FPBasedResNetBottleneck.synthesis
+    _hyper_abs = True       # h_a sees |y| (layer.py:641,675)
+
+    # ---- hyper transforms on the device --------------------------------------------------------- #
+    def hyper_analysis(self, y):
+        """z = h_a(|y|) (SHP) or h_a(y) (MSHP): f32 NCHW latent -> f32 NCHW hyper-latent."""
+        y_nhwc = hip.nchw_f32_to_nhwc_bf16(y.float().contiguous(), y.shape[1])
+        return run_hip_sequence(self.h_a, y_nhwc, a_op=hip.AOP_ABS if self._hyper_abs else hip.AOP_NONE)
+
+    def hyper_synthesis(self, z_hat_nhwc):
+        """h_s(z_hat) on a bf16 NHWC hyper-latent -> f32 NCHW Gaussian parameters."""
+        return run_hip_sequence(self.h_s, z_hat_nhwc)
+
+    def _z_hat_nhwc(self, z_hat):
+        return hip.nchw_f32_to_nhwc_bf16(z_hat.float().contiguous(), z_hat.shape[1])
+
+    def _params(self, gaussian_params):
+        """-> (scales_hat, means_hat or None)"""
+        return gaussian_params, None
+
+    # ---- reference API -------------------------------------------------------------------------- #
+    def encode(self, x, **kwargs):
+        """-> {'strings': [y_strings, z_strings], 'shape': z spatial size} (layer.py:630-648 / 765-777)."""
+        y = self.analysis(x)
+        z = self.hyper_analysis(y)
+        z_shape = z.size()[-2:]
+        eb = self.entropy_bottleneck
+        zbuf, zoff, znb, zst = eb.compress_device(z)
+        if int(zst.max().item()) != 0:
+            raise hip.Sc2Error('rANS row overflow in the hyper-latent stream')
+        _, z_hat_nhwc = eb.decompress_device(zbuf, zoff, znb, tuple(z_shape), want_f32=False, want_nhwc=True)
+        scales_hat, means_hat = self._params(self.hyper_synthesis(z_hat_nhwc))
+        indices = self.gaussian_conditional.build_indexes(scales_hat)
+        y_strings = self.gaussian_conditional.compress(y, indices, means=means_hat)
+        z_strings = eb.unpack_strings(zbuf, zoff, znb)
+        return {'strings': [y_strings, z_strings], 'shape': z_shape}
+
+    def decode(self, strings, shape):
+        """strings [y_strings, z_strings], z shape -> decoder output (layer.py:650-666 / 779-786)."""
+        assert isinstance(strings, list) and len(strings) == 2
+        eb = self.entropy_bottleneck
+        dev = eb._quantized_cdf.device
+        if dev.type != 'cuda':
+            raise hip.Sc2Error('{}.decode: module is on {}; HIP device required'.format(type(self).__name__, dev))
+        zbuf, zoff, znb = eb.pack_strings(strings[1], dev)
+        _, z_hat_nhwc = eb.decompress_device(zbuf, zoff, znb, tuple(shape), want_f32=False, want_nhwc=True)
+        scales_hat, means_hat = self._params(self.hyper_synthesis(z_hat_nhwc))
+        indices = self.gaussian_conditional.build_indexes(scales_hat)
+        gc = self.gaussian_conditional
+        ybuf, yoff, ynb = gc.pack_strings(strings[0], dev)
+        _, y_hat_nhwc = gc.decompress_device(ybuf, yoff, ynb, indices, means_hat, want_f32=False, want_nhwc=True)
+        return self.synthesis_nhwc(y_hat_nhwc)
+
+    def _get_means(self, x):
+        medians = self.entropy_bottleneck._get_medians().detach()
+        spatial_dims = len(x.size()) - 2
+        medians = self.entropy_bottleneck._extend_ndims(medians, spatial_dims)
+        return medians.expand(x.size(0), *([-1] * (spatial_dims + 1)))
+
+    def _forward2train(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise hip.Sc2Error('{}: the training (autograd) path of the hyperprior bottlenecks is not built yet; '
+                               'run under torch.no_grad()'.format(type(self).__name__))
+        y = self.analysis(x)
+        z = self.hyper_analysis(y)
+        z_hat, z_likelihoods = self.entropy_bottleneck(z)
+        scales_hat, means_hat = self._params(self.hyper_synthesis(self._z_hat_nhwc(z_hat)))
+        y_hat, y_likelihoods = self.gaussian_conditional(y, scales_hat, means=means_hat)
+        self.last_likelihoods = (y_likelihoods, z_likelihoods)
+        return self.synthesis(y_hat)
+
+    def forward(self, x):
+        # if fine-tune or evaluate after "update"
+        if self.updated:
+            if not self.training:
+                encoded_obj = self.encode(x)
+                decoded_obj = self.decode(**encoded_obj)
+                return decoded_obj
+            y = self.analysis(x)
+            y_hat = self.gaussian_conditional.dequantize(
+                self.gaussian_conditional.quantize(y, 'dequantize', self._get_means(y))
+            )
+            y_hat = y_hat.detach()
+            return self.synthesis(y_hat)
+        return self._forward2train(x)
+
+    def update(self, scale_table=None, force=False):
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= super().update(force=force)
+        self.updated = True
+        return updated
+
+    def load_state_dict(self, state_dict, **kwargs):
+        """Resizes the registered buffers of the Gaussian model to the checkpoint's shapes, then loads
+        (layer.py:706-720)."""
+        update_registered_buffers(self.gaussian_conditional, 'gaussian_conditional',
+                                  ['_quantized_cdf', '_offset', '_cdf_length', 'scale_table'], state_dict)
+        return super().load_state_dict(state_dict, **kwargs)
+
+
+@register_layer_class
+class MSHPBasedResNetBottleneck(SHPBasedResNetBottleneck):
+    """Mean-scale-hyperprior encoder / hyper-codec / decoder for ResNet (layer.py:723-817)."""
+    _hyper_abs = False      # h_a sees y itself (layer.py:767,789)
+
+    def __init__(self, num_input_channels=3, num_latent_channels=16, num_bottleneck_channels=24,
+                 num_target_channels=256, g_a_channel_sizes=None, g_s_channel_sizes=None):
+        L, B = num_latent_channels, num_bottleneck_channels
+        h_a = nn.Sequential(
+            HipConv2d(B, L, kernel_size=5, stride=2, padding=1, bias=False),
+            nn.LeakyReLU(inplace=True),
+            HipConv2d(L, L, kernel_size=5, stride=2, padding=2, bias=False)
+        )
+        h_s = nn.Sequential(
+            HipConvTranspose2d(L, L, kernel_size=5, stride=2, padding=1, bias=False),
+            nn.LeakyReLU(inplace=True),
+            HipConvTranspose2d(L, L * 3 // 2, kernel_size=5, stride=2, padding=1, bias=False),
+            nn.LeakyReLU(inplace=True),
+            HipConv2d(L * 3 // 2, B * 2, kernel_size=5, stride=1, padding=0, bias=False)
+        )
+        super().__init__(num_input_channels=num_input_channels, num_latent_channels=num_latent_channels,
+                         num_bottleneck_channels=num_bottleneck_channels, num_target_channels=num_target_channels,
+                         h_a=h_a, h_s=h_s, g_a_channel_sizes=g_a_channel_sizes, g_s_channel_sizes=g_s_channel_sizes)
+
+    def _params(self, gaussian_params):
+        scales_hat, means_hat = gaussian_params.chunk(2, 1)
+        return scales_hat, means_hat
+
+    def forward(self, x):
+        # if fine-tune or evaluate after "update"
+        if self.updated:
+            if not self.training:
+                encoded_obj = self.encode(x)
+                decoded_obj = self.decode(**encoded_obj)
+                return decoded_obj
+            y = self.analysis(x)
+            z = self.hyper_analysis(y)
+            z_hat = self.entropy_bottleneck.dequantize(
+                self.entropy_bottleneck.quantize(z, 'dequantize', self._get_means(z))
+            )
+            scales_hat, means_hat = self._params(self.hyper_synthesis(self._z_hat_nhwc(z_hat)))
+            y_hat = self.gaussian_conditional.dequantize(
+                self.gaussian_conditional.quantize(y, 'dequantize', means_hat)
+            )
+            y_hat = y_hat.detach()
+            return self.synthesis(y_hat)
         return self._forward2train(x)
 
 

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import cpu_ref as R  # noqa: E402
 from oracle import rans, rans_py  # noqa: E402
 sys.path.insert(0, HERE)
-from recipe import build_oracle_bottleneck, fingerprint  # noqa: E402
+from recipe import build_oracle_bottleneck, build_oracle_hyperprior, fingerprint  # noqa: E402
 
 
 def make_rans_kat():
@@ -99,7 +99,46 @@ def make_fp_golden():
     torch.save(g, os.path.join(HERE, 'fp_golden.pt'))
 
 
+def make_hyperprior_golden():
+    """Scale / mean-scale hyperprior bottlenecks (layer.py:553-817): Gaussian-conditional tables, likelihoods, indexes,
+    both byte streams and the decoded output of the seeded oracle models."""
+    import hashlib
+    out = {}
+    for name in ('SHPBasedResNetBottleneck', 'MSHPBasedResNetBottleneck'):
+        m, x = build_oracle_hyperprior(R, name)
+        g = {'fingerprint': fingerprint(m), 'x': x}
+        with torch.no_grad():
+            y = m.g_a(x)
+            z = m.h_a(torch.abs(y) if name.startswith('SHP') else y)
+            z_hat, z_lik = m.entropy_bottleneck(z)
+            params = m.h_s(z_hat)
+            scales, means = (params, None) if name.startswith('SHP') else params.chunk(2, 1)
+            y_hat, y_lik = m.gaussian_conditional(y, scales, means=means)
+            g.update(y=y, z=z, z_hat=z_hat, z_lik=z_lik, gaussian_params=params, y_hat=y_hat, y_lik=y_lik)
+            noise = torch.rand_like(y) - 0.5
+            g['noise_y'] = noise
+            g['y_hat_noise'], g['y_lik_noise'] = m.gaussian_conditional(y, scales, means=means, training=True, noise=noise)
+            m.update()
+            gc = m.gaussian_conditional
+            g['gc_cdf_sha256'] = hashlib.sha256(gc._quantized_cdf.numpy().tobytes()).hexdigest()
+            g['gc_cdf_shape'] = list(gc._quantized_cdf.shape)
+            g['gc_offset'] = gc._offset.clone()
+            g['gc_cdf_length'] = gc._cdf_length.clone()
+            g['gc_cdf_rows'] = {i: gc._quantized_cdf[i, :int(gc._cdf_length[i])].clone() for i in (0, 1, 17, 63)}
+            g['scale_table'] = gc.scale_table.clone()
+            g['indexes'] = gc.build_indexes(scales)
+            enc = m.encode(x)
+            g['y_strings_hex'] = [s.hex() for s in enc['strings'][0]]
+            g['z_strings_hex'] = [s.hex() for s in enc['strings'][1]]
+            g['shape'] = list(enc['shape'])
+            g['decoded'] = m.decode(**enc)
+            g['file_size_kb'] = R.file_size(enc)
+        out[name] = g
+    torch.save(out, os.path.join(HERE, 'hyperprior_golden.pt'))
+
+
 if __name__ == '__main__':
     make_rans_kat()
     make_fp_golden()
+    make_hyperprior_golden()
     print('golden fixtures written to', HERE)

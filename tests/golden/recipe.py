@@ -23,3 +23,19 @@ def build_oracle_bottleneck(R):
 
 def fingerprint(module):
     return {k: float(v.double().abs().sum()) for k, v in module.state_dict().items() if v.numel() > 0}
+
+
+def build_oracle_hyperprior(R, name):
+    """Seeded SHP / MSHP oracle bottleneck (name = class name) with non-trivial tables, and its input."""
+    torch.manual_seed(1)
+    m = getattr(R, name)()
+    R.perturb_quantiles(m.entropy_bottleneck)
+    with torch.no_grad():
+        m.g_a[4].weight.mul_(40.0)              # spreads the latent over several quantisation bins
+        m.h_a[2].weight.mul_(12.0)              # ... and the hyper-latent
+        m.h_s[4].weight.mul_(6.0)               # scales / means well away from the 0.11 floor
+        for g in (m.g_a[1], m.g_a[3], m.g_s[1], m.g_s[3]):
+            g.gamma.add_(0.02 * torch.rand_like(g.gamma))
+    m.eval()
+    x = torch.rand(2, 3, 32, 32)
+    return m, x

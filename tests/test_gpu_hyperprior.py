@@ -1,0 +1,183 @@
+"""-m gpu: hyperprior bottlenecks on the HIP path against the CPU oracle.
+
+Integer work is bit-exact: symbols and CDF-row indexes given the same floats, byte streams given the same symbols
+and indexes (explicit-`indexes` path of the batched rANS coder over the 64 x 3133 Gaussian table).  Floating point:
+likelihoods within 2e-5 relative (erfc in f32 on both sides), bf16 MFMA transforms as in test_gpu_kernels.py."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+from recipe import build_oracle_hyperprior  # noqa: E402
+
+NAMES = ('SHPBasedResNetBottleneck', 'MSHPBasedResNetBottleneck')
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.fixture(scope='module')
+def golden():
+    return torch.load(os.path.join(HERE, 'golden', 'hyperprior_golden.pt'), weights_only=False)
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_gaussian_conditional_kernels(S, R, dev, golden, name):
+    g = golden[name]
+    params = g['gaussian_params']
+    scales, means = (params, None) if name.startswith('SHP') else params.chunk(2, 1)
+    y = g['y']
+    gc = S.GaussianConditional(None).to(dev).eval()
+    gc.update_scale_table(S.get_scale_table())
+    yd, sd = y.to(dev), scales.to(dev)            # `scales` / `means` stay channel slices of the wider tensor (MSHP)
+    md = None if means is None else params.to(dev).chunk(2, 1)[1]
+    if means is not None:
+        sd = params.to(dev).chunk(2, 1)[0]
+        assert not sd.is_contiguous()
+    y_hat, lik = gc(yd, sd, means=md)
+    assert torch.equal(y_hat.cpu(), g['y_hat'])
+    torch.testing.assert_close(lik.cpu(), g['y_lik'], rtol=2e-5, atol=1e-9)
+    yn, ln = gc(yd, sd, means=md, training=True, noise=g['noise_y'].to(dev))
+    assert torch.equal(yn.cpu(), g['y_hat_noise'])
+    torch.testing.assert_close(ln.cpu(), g['y_lik_noise'], rtol=2e-5, atol=1e-9)
+    assert torch.equal(gc.build_indexes(sd).cpu(), g['indexes'])
+    ref_gc = R.GaussianConditional(None)
+    sym = gc.quantize(yd, 'symbols', md)
+    assert sym.dtype == torch.int32 and torch.equal(sym.cpu(), ref_gc.quantize(y, 'symbols', means))
+    deq = gc.quantize(yd, 'dequantize', md)
+    assert torch.equal(deq.cpu(), ref_gc.quantize(y, 'dequantize', means))
+    assert torch.equal(gc.dequantize(sym, md).cpu(), ref_gc.dequantize(sym.cpu(), means))
+    # edge values: ties round to even, scales at / below the bound and beyond the table
+    e_y = torch.tensor([[[0.5, 1.5, -0.5, -1.5, 2.5, 1e4, -1e4, 0.0]]])
+    e_s = torch.tensor([[[0.0, 0.11, 0.110001, 1.0, 255.0, 256.0, 300.0, 1e9]]])
+    ref_gc.update_scale_table(R.get_scale_table())
+    assert torch.equal(gc.quantize(e_y.to(dev), 'symbols').cpu(), ref_gc.quantize(e_y, 'symbols'))
+    assert torch.equal(gc.build_indexes(e_s.to(dev)).cpu(), ref_gc.build_indexes(e_s))
+    _, e_l = gc(e_y.to(dev), e_s.to(dev))
+    torch.testing.assert_close(e_l.cpu(), ref_gc.eval()(e_y, e_s)[1], rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('cin,cout,H,W,act', [(16, 16, 14, 14, 'leaky'), (16, 24, 29, 27, 'leaky'), (8, 16, 5, 6, None),
+                                              (16, 16, 7, 7, 'relu')])
+def test_conv_transpose_and_activation_epilogues(S, dev, cin, cout, H, W, act):
+    """HipConvTranspose2d (k5 s2 p1, stride-parity classes with output scatter) with the fused activation vs
+    F.conv_transpose2d on the bf16-rounded operands."""
+    torch.manual_seed(cin * 10 + cout)
+    m = S.HipConvTranspose2d(cin, cout, kernel_size=5, stride=2, padding=1, bias=False)
+    x = torch.randn(2, cin, H, W)
+    with torch.no_grad():
+        ref = F.conv_transpose2d(bf16_round(x), bf16_round(m.weight), stride=2, padding=1)
+        if act == 'leaky':
+            ref = F.leaky_relu(ref)
+        elif act == 'relu':
+            ref = F.relu(ref)
+    m.to(dev)
+    epi = {None: S.hip.EPI_NONE, 'leaky': S.hip.EPI_BIAS_LEAKY_RELU, 'relu': S.hip.EPI_BIAS_RELU}[act]
+    beta = None if act is None else torch.zeros(cout, device=dev)
+    with torch.no_grad():
+        out = m.forward_nhwc(S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)), epi, beta, out_format=S.hip.OUT_F32_NHWC)
+        assert out.shape == (2, (H - 1) * 2 - 2 + 5, (W - 1) * 2 - 2 + 5, cout)
+        torch.testing.assert_close(out.permute(0, 3, 1, 2).cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+        if act is None:
+            mod = m(x.to(dev))      # module-level call: f32 NCHW in / out
+            torch.testing.assert_close(mod.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_hyperprior_bottleneck_on_device(S, R, dev, golden, name):
+    g = golden[name]
+    ref, x = build_oracle_hyperprior(R, name)
+    m = S.get_layer(name)
+    m.load_state_dict({k: v.clone() for k, v in ref.state_dict().items()})
+    m.eval().to(dev)
+    ref.update()
+    assert m.update() is True
+    gc, eb = m.gaussian_conditional, m.entropy_bottleneck
+    assert torch.equal(gc._quantized_cdf.cpu(), ref.gaussian_conditional._quantized_cdf)
+    assert torch.equal(eb._quantized_cdf.cpu(), ref.entropy_bottleneck._quantized_cdf)
+    xd = x.to(dev)
+    with torch.no_grad():
+        # the transforms: bf16 MFMA path vs the f32 oracle (tolerances of test_gpu_kernels.py)
+        y = m.analysis(xd)
+        z = m.hyper_analysis(y)
+        rel = lambda a, b: ((a.cpu() - b).norm() / b.norm()).item()   # noqa: E731
+        assert rel(y, g['y']) < 1.5e-2 and rel(z, g['z']) < 2.5e-2
+        params = m.hyper_synthesis(S.hip.nchw_f32_to_nhwc_bf16(g['z_hat'].to(dev), g['z_hat'].shape[1]))
+        assert params.shape == g['gaussian_params'].shape and rel(params, g['gaussian_params']) < 1.5e-2
+
+        enc = m.encode(xd)
+        assert list(enc['shape']) == g['shape'] and len(enc['strings']) == 2
+        # bit-exact coding GIVEN the device floats: replay the integer half on the oracle
+        z_strings = ref.entropy_bottleneck.compress(z.cpu())
+        assert enc['strings'][1] == z_strings
+        z_hat = ref.entropy_bottleneck.decompress(z_strings, enc['shape'])
+        scales_hat, means_hat = m._params(m.hyper_synthesis(S.hip.nchw_f32_to_nhwc_bf16(z_hat.to(dev), z_hat.shape[1])))
+        indexes = gc.build_indexes(scales_hat)
+        assert torch.equal(indexes.cpu(), ref.gaussian_conditional.build_indexes(scales_hat.cpu()))
+        means_cpu = None if means_hat is None else means_hat.cpu()
+        y_strings = ref.gaussian_conditional.compress(y.cpu(), indexes.cpu(), means=means_cpu)
+        assert enc['strings'][0] == y_strings, 'latent streams differ from the oracle coder on the same symbols'
+        # decode: the same streams decode on the oracle to the same integers; device decode + synthesis is
+        # deterministic and equals the synthesis of the dequantised latent
+        y_hat_ref = ref.gaussian_conditional.decompress(enc['strings'][0], indexes.cpu(), means=means_cpu)
+        y_hat_dev = gc.decompress(enc['strings'][0], indexes, means=means_hat)
+        assert torch.equal(y_hat_dev.cpu(), y_hat_ref)
+        assert torch.equal(y_hat_dev.cpu(), ref.gaussian_conditional.quantize(y.cpu(), 'dequantize', means_cpu))
+        out = m.decode(**enc)
+        assert torch.equal(out, m.synthesis(y_hat_dev))
+        assert torch.equal(m(xd), out)                                     # forward() in updated-eval mode
+        # against the f32 oracle end to end: symbol flips at .5 boundaries are inherent below f32; report + bound
+        sym_dev = gc.quantize(y, 'symbols', means_hat).cpu()
+        sym_ref = ref.gaussian_conditional.quantize(g['y'], 'symbols', None if name.startswith('SHP') else
+                                                    g['gaussian_params'].chunk(2, 1)[1])
+        mismatch = (sym_dev != sym_ref).float().mean().item()
+        assert mismatch < 0.03, 'latent symbol mismatch rate {}'.format(mismatch)
+        assert rel(out, g['decoded']) < 8e-2
+        # byte counts close to the oracle's (same model, nearly the same symbols)
+        nb_dev = sum(len(s) for s in enc['strings'][0])
+        nb_ref = sum(len(s) // 2 for s in g['y_strings_hex'])
+        assert abs(nb_dev - nb_ref) < 0.05 * nb_ref
+        # FileSizeAnalyzer on the two-stream object
+        an = S.FileSizeAnalyzer(unit='KB')
+        an.analyze(enc)
+        assert an.file_size_list[0] == R.file_size(enc)
+        if name.startswith('MSHP'):
+            m.train()
+            assert torch.equal(m(xd), out)                                 # updated-train path dequantises the same way
+            m.eval()
+        else:
+            m.train()
+            with pytest.raises(RuntimeError):                              # the reference's own shape clash (layer.py:691)
+                m(xd)
+            m.eval()
+        # not-updated path (likelihood mode)
+        m.updated = False
+        o2 = m(xd)
+        y_lik, z_lik = m.last_likelihoods
+        assert o2.shape == out.shape and y_lik.shape == y.shape and z_lik.shape == z.shape
+        assert float(y_lik.min()) >= float(torch.tensor(1e-9)) and float(y_lik.max()) <= 1.0
+        m.updated = True
+    with pytest.raises(S.hip.Sc2Error):
+        m.updated = False
+        m(xd.requires_grad_(True))     # the hyperprior training path is not built: must refuse, not mis-train
+
+
+def test_hyperprior_through_the_yaml_registry(S, dev):
+    """`bottleneck_config: {key: MSHPBasedResNetBottleneck, ...}` of the reference's mshp configs builds and runs."""
+    torch.manual_seed(0)
+    model = S.splittable_resnet({'key': 'MSHPBasedResNetBottleneck',
+                                 'kwargs': {'num_latent_channels': 16, 'num_bottleneck_channels': 24,
+                                            'num_target_channels': 256}},
+                                skips_avgpool=False, skips_fc=False, num_classes=10)
+    model.eval().to(dev)
+    model.update()
+    assert model.bottleneck_updated and model.bottleneck_layer.updated
+    with torch.no_grad():
+        logits = model(torch.rand(2, 3, 64, 64, device=dev))
+    assert logits.shape == (2, 10) and torch.isfinite(logits.float()).all()
