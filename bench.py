@@ -197,6 +197,7 @@ def main():
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--inflight', type=int, default=3, help='range-coder chains in flight (coder HIP streams, <= 7)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--split-mfma', type=int, default=1, help='K > 0: decoder+head stages round-robin on K HIP streams of their own (0: one MFMA stream for everything)')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
     args = ap.parse_args()
@@ -229,6 +230,9 @@ def main():
     n_coder = max(1, min(args.inflight, 7))
     depth = n_coder
     mfma_stream = torch.cuda.Stream(device=dev)
+    # --split-mfma: front(i) [encoder] and back(i - depth) [decoder + head] on two streams, so that the tails of one
+    # stage's short launches overlap the other's (both still feed the same matrix cores)
+    back_streams = [torch.cuda.Stream(device=dev) for _ in range(args.split_mfma)] if args.split_mfma else [mfma_stream]
     coder_streams = [torch.cuda.Stream(device=dev) for _ in range(n_coder)]
     D = n_coder + 1
     results = [None]
@@ -253,14 +257,17 @@ def main():
                 j = i - depth
                 if j >= 0:
                     dec, nb, st, hw, ev2 = pending.pop(j)
-                    with torch.cuda.stream(mfma_stream):
-                        mfma_stream.wait_event(ev2)
-                        dec.record_stream(mfma_stream)
+                    back_stream = back_streams[j % len(back_streams)]
+                    with torch.cuda.stream(back_stream):
+                        back_stream.wait_event(ev2)
+                        dec.record_stream(back_stream)
                         logits = model.stage_back(dec, hw)
                         results[0] = (logits, nb, st)
 
     def sync_all():
         mfma_stream.synchronize()
+        for bstream in back_streams:
+            bstream.synchronize()
         for cstream in coder_streams:
             cstream.synchronize()
         torch.cuda.synchronize(dev)
@@ -329,6 +336,7 @@ def main():
             'config': {'workload': 'Entropic-Student ResNet-50 (FPBasedResNetBottleneck 24ch), ILSVRC2012 shape '
                                    '224x224x3, eval after update(): encode -> rANS -> decode -> layer2..fc',
                        'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'inflight_steps': D,
+                       'hip_streams': {'encoder': 1, 'decoder+head': len(back_streams), 'range_coder': n_coder},
                        'weights': 'random init seed 0 + fixed quantile perturbation', 'sharding': 'images, no collective'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
             'host_issue_ms_per_step': 1e3 * (t_issued - t0) / args.steps,
