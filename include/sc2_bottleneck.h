@@ -69,7 +69,7 @@ enum sc2_conv_epilogue {
     /* conv FOLLOWED BY GDN1 in one launch where one tile holds every channel of a pixel: Cout in {32,48,64,96}, or
      * Cout == 256 on the 256-wide big-tile path (sc2_conv_fused_gdn_supported tells):
      * x = acc; y = x / (ep_beta + gamma |x|)  resp.  x * (ep_beta + gamma |x|).  `ep_x` carries the packed bf16
-     * gamma matrix [sc2_conv_weight_rows(Cout)][sc2_conv_weight_pitch(Cout)] instead of an activation. */
+     * gamma matrix instead of an activation, in the layout sc2_conv_fused_gdn_supported reports. */
     SC2_EPI_FUSED_GDN = 6,
     SC2_EPI_FUSED_IGDN = 7,
     SC2_EPI_BIAS_LEAKY_RELU = 8 /* y = leaky_relu(acc + ep_beta[c], 0.01) (nn.LeakyReLU() default slope; h_a / h_s) */
@@ -115,7 +115,10 @@ int sc2_conv_weight_pitch(int K);
  * ep_x   : bf16 NHWC [N,OH,OW,Cout] for GDN/IGDN/ADD epilogues (NULL otherwise)
  * ep_beta: f32 [Cout] for GDN/IGDN/BIAS epilogues (NULL otherwise)
  * y      : per out_format. */
-/* 1 if SC2_EPI_FUSED_GDN / _IGDN is available for this geometry (all of `d` filled in as for sc2_conv2d_fwd). */
+/* Non-zero if SC2_EPI_FUSED_GDN / _IGDN is available for this geometry (all of `d` filled in as for sc2_conv2d_fwd):
+ * 1 = `ep_x` carries gamma as packed rows [sc2_conv_weight_rows(Cout)][sc2_conv_weight_pitch(Cout)] (tiles of
+ * 32..96 channels); 2 = `ep_x` carries gamma as MFMA-fragment blocks [Cout/16][Cout/32][64][8], entry (jt, ks,
+ * lane = fq*16 + frow, e) = gamma[jt*16 + frow][ks*32 + fq*8 + e] (the 256-wide 8-wave tile). */
 int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d);
 int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
                    const void *ep_x, const float *ep_beta, void *stream);

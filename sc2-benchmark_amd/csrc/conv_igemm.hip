@@ -950,8 +950,8 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
     }
     // ---- conv followed by GDN1 / inverse GDN1 in the same launch (the tile holds all 256 channels of its pixels):
     // x goes to an LDS image as bf16, norm = gamma |x| is a second MFMA GEMM whose A operand is that image (|.| on the
-    // fragment) and whose B operand, gamma, streams through a 2-slab direct-to-LDS ring; y = x * (beta + norm) (or
-    // x / ...) is applied in the store pass with x read back from the image.  No HBM traffic for the GDN.
+    // fragment) and whose B operand, gamma, comes fragment-major from L2; y = x * (beta + norm) (or x / ...) is applied
+    // in the store pass with x read back from the image.  No HBM traffic for the GDN.
     if constexpr (BN == 256) {
         if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
             unsigned char *Xi = smem;
@@ -968,46 +968,36 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
                     *reinterpret_cast<uint2 *>(Xi + r * 512 + (((col >> 3) ^ (r & 15)) << 4) + (col & 7) * 2) = h;
                     acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 }
-            const uint16_t *gamma = p.ep_x;
-            const long long zero_off_g = zero - gamma;
-            (void)zero_off_g;
-            auto issue_g = [&](int ks2, int buf) {
+            // gamma comes FRAGMENT-MAJOR ([16-channel tile][32-deep step][lane][8 k]: one operand fragment = 1 KB
+            // contiguous, hip.pack_gamma_fragments) straight from L2 into registers, one step ahead: no LDS ring and no
+            // barrier inside the loop, the two waves of a SIMD drift apart and hide each other's waits.
+            const uint4 *gfrag = reinterpret_cast<const uint4 *>(p.ep_x) + (long long)(wn * NT) * (BN / 32) * 64 + lane;
+            constexpr int NS = BN / 32;
+            uint4 gbuf[2][NT];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const long long off = (long long)((j * 8 + wave) * 16 + (lane >> 2)) * p.g_pitch + ks2 * 32 + kc * 8;
-                    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gamma + off),
-                                                     (lds_ptr_t)(ring + buf * 16384 + (j * 8 + wave) * 1024), 16, 0, 0);
+            for (int j = 0; j < NT; ++j) gbuf[0][j] = gfrag[(j * NS + 0) * 64];
+            __builtin_amdgcn_s_barrier();   // the x image is complete
+            const unsigned char *xrow = Xi + (wm * C::WM + frow) * 512;
+#pragma unroll
+            for (int ks2 = 0; ks2 < NS; ++ks2) {
+                if (ks2 + 1 < NS) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) gbuf[(ks2 + 1) & 1][j] = gfrag[(j * NS + ks2 + 1) * 64];
                 }
-            };
-            issue_g(0, 0);
-            const uint32_t xi_base = lds_base, ring_base = lds_base + 256 * 512;
-            for (int ks2 = 0; ks2 < 8; ++ks2) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();   // gamma slab ks2 landed everywhere; (ks2 == 0) the x image is complete
-                if (ks2 + 1 < 8) issue_g(ks2 + 1, (ks2 + 1) & 1);
-                uint4 xa[MT], gb[NT];
+                const int xc = ((4 * ks2 + fq) ^ frow) << 4;   // row & 15 == frow for every fragment row of this lane
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int r = wm * C::WM + i * 16 + frow;
-                    xa[i] = lds_read16(xi_base + (uint32_t)(r * 512 + (((4 * ks2 + fq) ^ (r & 15)) << 4)));
-                }
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    gb[j] = lds_read16(ring_base + (uint32_t)((ks2 & 1) * 16384 + lds_off(wn * C::WN + j * 16 + frow, fq)));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    uint4 v = xa[i];
+                    uint4 v = *reinterpret_cast<const uint4 *>(xrow + i * 16 * 512 + xc);
                     v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu;
                     const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, gb[j]), af,
-                                                                            acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, gbuf[ks2 & 1][j]), af, acc[i][j], 0, 0, 0);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            __builtin_amdgcn_s_barrier();   // every wave is done with the gamma ring and with its x-image fragments
+            __builtin_amdgcn_s_barrier();   // every wave is done with its x-image fragments
             const int epi2 = p.epi == SC2_EPI_FUSED_IGDN ? (int)SC2_EPI_IGDN : (int)SC2_EPI_GDN;
             if (p.out == SC2_OUT_BF16_NHWC)   // x -> y in place in the image, then streamed out
                 conv_store_tile_bf16<C, ImgXor<C>, 512, false>(p, Xi, acc, tid, wm, wn, frow, fq, m0, n0, epi2, nullptr,
@@ -1140,7 +1130,7 @@ extern "C" int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d) {
     if (d->Cout == 32 || d->Cout == 48 || d->Cout == 64 || d->Cout == 96) return 1;
     const long long M = (long long)d->N * d->OH * d->OW;
     return d->Cout == 256 && d->out_format != SC2_OUT_F32_NCHW && d->out_H == 0 &&
-           big_tile_eligible(d, M, d->KH * d->KW * d->Cin) ? 1 : 0;
+           big_tile_eligible(d, M, d->KH * d->KW * d->Cin) ? 2 : 0;
 }
 
 extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, const void *ep_x,

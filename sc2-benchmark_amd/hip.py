@@ -353,7 +353,8 @@ def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16):
 
 
 def conv_fused_gdn_supported(x_shape, cout, kh, kw, stride, pad, out_format=OUT_BF16_NHWC):
-    """True if conv + GDN1 runs as ONE launch (EPI_FUSED_GDN / EPI_FUSED_IGDN) for this geometry; x_shape = [N,H,W,Cin]."""
+    """Non-zero if conv + GDN1 runs as ONE launch (EPI_FUSED_GDN / EPI_FUSED_IGDN) for this geometry (x_shape =
+    [N,H,W,Cin]): 1 = ep_x takes GDN1.effective()'s packed-row gamma, 2 = GDN1.effective_fragments()'s."""
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
     N, H, W, Cin = x_shape
@@ -361,7 +362,7 @@ def conv_fused_gdn_supported(x_shape, cout, kh, kw, stride, pad, out_format=OUT_
     OW = (W + 2 * pw - kw) // sw + 1
     d = ConvDesc(N, H, W, Cin, cout, kh, kw, sh, sw, ph, pw, OH, OW, AOP_NONE, EPI_FUSED_GDN, out_format,
                  weight_pitch(kh * kw * Cin), weight_rows(cout), 0, 0, 0, 0, 0, 0, K_TAP_MAJOR)
-    return bool(lib().sc2_conv_fused_gdn_supported(ctypes.byref(d)))
+    return int(lib().sc2_conv_fused_gdn_supported(ctypes.byref(d)))   # 0 no, 1 packed-row gamma, 2 fragment-major gamma
 
 
 def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilogue=EPI_NONE,
@@ -399,8 +400,8 @@ def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilo
     if ep_x is not None:
         _dev(ep_x, 'ep_x')
         assert ep_x.dtype == torch.bfloat16 and ep_x.is_contiguous()
-        if epilogue in (EPI_FUSED_GDN, EPI_FUSED_IGDN):   # ep_x carries the packed gamma matrix
-            assert tuple(ep_x.shape) == (weight_rows(cout), weight_pitch(cout))
+        if epilogue in (EPI_FUSED_GDN, EPI_FUSED_IGDN):   # ep_x carries the gamma matrix (packed rows or fragments)
+            assert tuple(ep_x.shape) in ((weight_rows(cout), weight_pitch(cout)), (cout // 16, cout // 32, 64, 8))
         else:
             assert ep_x.numel() == N * OH * OW * cout
     if ep_beta is not None:

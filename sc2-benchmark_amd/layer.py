@@ -197,9 +197,11 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         else:
             h = c0.forward_nhwc(y_hat_nhwc)
             h = g1.forward_nhwc(h)
-        if self.fuse_gdn and hip.conv_fused_gdn_supported(tuple(h.shape), c2.out_channels, c2.kernel_size[0],
-                                                          c2.kernel_size[1], c2.stride, c2.padding):
-            beta, gamma = g3.effective()   # conv + inverse GDN1 in one launch (256-wide big tile holds all channels)
+        fused = hip.conv_fused_gdn_supported(tuple(h.shape), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1],
+                                             c2.stride, c2.padding) if self.fuse_gdn else 0
+        if fused:
+            # conv + inverse GDN1 in one launch (256-wide big tile holds all channels)
+            beta, gamma = g3.effective_fragments() if fused == 2 else g3.effective()
             h = hip.conv2d_fwd(h, c2.packed_weight(), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
                                c2.padding, epilogue=hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN,
                                ep_x=gamma, ep_beta=beta, tag=c2._tag + '+' + g3._tag, k_order=c2.k_order())

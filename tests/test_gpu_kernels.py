@@ -255,9 +255,9 @@ def test_conv_fused_gdn_big_tile(S, R, dev, monkeypatch, cin, k, pad, inverse):
     m = S.GDN1(cout, inverse=inverse)
     m.load_state_dict(gdn.state_dict())
     m.to(dev)
-    beta_d, gamma_d = m.effective()
+    beta_d, gamma_d = m.effective_fragments()      # the 256-wide tile takes gamma as MFMA-fragment blocks
     x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
-    assert S.hip.conv_fused_gdn_supported(tuple(x_nhwc.shape), cout, k, k, 1, pad)
+    assert S.hip.conv_fused_gdn_supported(tuple(x_nhwc.shape), cout, k, k, 1, pad) == 2
     for order in ((S.hip.K_TAP_MAJOR, S.hip.K_SLAB_MAJOR) if cin % 32 == 0 and k > 1 else (S.hip.K_TAP_MAJOR,)):
         out = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev), order), cout, k, k, 1, pad,
                                epilogue=S.hip.EPI_FUSED_IGDN if inverse else S.hip.EPI_FUSED_GDN, ep_x=gamma_d,

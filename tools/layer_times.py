@@ -81,7 +81,7 @@ def main():
         b2 = d2.forward_nhwc(b1)
         rows.append(('dec.conv2', timeit(lambda: d2.forward_nhwc(b1), args.iters), 3171.9e6 * N, b1.numel() * 2 + b2.numel() * 2))
         if hip.conv_fused_gdn_supported(tuple(b1.shape), 256, 2, 2, 1, 0):
-            beta3, gamma3 = h3.effective()
+            beta3, gamma3 = h3.effective_fragments()
             rows.append(('dec.conv2+igdn256', timeit(lambda: hip.conv2d_fwd(b1, d2.packed_weight(), 256, 2, 2, 1, 0, epilogue=hip.EPI_FUSED_IGDN,
                                                                               ep_x=gamma3, ep_beta=beta3, k_order=d2.k_order()), args.iters),
                          (3171.9e6 + 396.5e6) * N, b1.numel() * 2 + b2.numel() * 2))
