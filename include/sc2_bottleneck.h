@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 14
+#define SC2_ABI_VERSION 15
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -83,7 +83,11 @@ enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHW
 enum sc2_conv_k_order { SC2_K_TAP_MAJOR = 0, SC2_K_SLAB_MAJOR = 1,
                         /* flag, OR-ed in: w_packed is [Kpad/32][Cout_pad][32] (the B tile of one 32-deep k-slab is
                          * contiguous) instead of [Cout_pad][Kpad] */
-                        SC2_K_B_TILE_MAJOR = 2 };
+                        SC2_K_B_TILE_MAJOR = 2,
+                        /* flag, with SLAB_MAJOR only: w_packed is MFMA-fragment-major [Kpad/32][Cout_pad/16][64][8], entry
+                         * (kt, jt, lane = fq*16 + frow, e) = W[jt*16 + frow][kt*32 + fq*8 + e]; taken by the LDS-patch
+                         * kernel of the 5x5 stride-2 geometry (sc2_conv_patch_supported) */
+                        SC2_K_B_FRAG_MAJOR = 4 };
 
 typedef struct sc2_conv_desc {
     int32_t N, H, W, Cin;          /* input  : bf16 NHWC [N,H,W,Cin], Cin % 8 == 0              */
@@ -120,6 +124,9 @@ int sc2_conv_weight_pitch(int K);
  * 32..96 channels); 2 = `ep_x` carries gamma as MFMA-fragment blocks [Cout/16][Cout/32][64][8], entry (jt, ks,
  * lane = fq*16 + frow, e) = gamma[jt*16 + frow][ks*32 + fq*8 + e] (the 256-wide 8-wave tile). */
 int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d);
+/* 1 if this geometry runs on the LDS-resident-patch kernel (5x5 stride 2 pad 2, Cin 96 -> Cout 48, OW <= 64, bf16 NHWC
+ * output: the second encoder conv, layer.py:479-480), which takes SC2_K_SLAB_MAJOR | SC2_K_B_FRAG_MAJOR weights. */
+int sc2_conv_patch_supported(const sc2_conv_desc *d);
 int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
                    const void *ep_x, const float *ep_beta, void *stream);
 

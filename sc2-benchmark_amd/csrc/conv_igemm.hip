@@ -211,7 +211,7 @@ __device__ __forceinline__ long long conv_out_offset(const ConvArgs &p, int m, i
 template <class C, class Img, int NTHREADS, bool PREFETCHED>
 __device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned char *img, f32x4_t (&acc)[C::MT][C::NT],
                                                      int tid, int wm, int wn, int frow, int fq, int m0, int n0, int epi,
-                                                     const uint4 *epx, bool x_in_image) {
+                                                     const uint4 *epx, bool x_in_image, int valid_rows = C::BM) {
     constexpr int MT = C::MT, NT = C::NT;
     constexpr int CPR = EpiGeom<C, NTHREADS>::CPR, QPT = EpiGeom<C, NTHREADS>::QPT, Q = EpiGeom<C, NTHREADS>::Q;
     const int Cout = p.Cout;
@@ -287,7 +287,7 @@ __device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned
         const int q = tid + r * NTHREADS;
         const int row = q / CPR, cc = q - row * CPR;
         const int m = m0 + row, n = n0 + cc * 8;
-        if ((q < Q) & (m < p.M) & (n < Cout)) {
+        if ((q < Q) & (m < p.M) & (n < Cout) & (row < valid_rows)) {
             bool ok;
             const long long o = conv_out_offset(p, m, n, ok);
             if (ok) *reinterpret_cast<uint4 *>(y + o) = *reinterpret_cast<const uint4 *>(img + Img::off(row, cc));
@@ -419,6 +419,87 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
         }
     }
 }
+
+// Fused GDN1 / inverse GDN1 of a tile that holds every output channel of its pixels (BN <= 96): norm = beta + gamma |x|
+// is a second, LDS-resident GEMM - |x| (bf16) is written to an LDS image straight from the accumulators, gamma is staged
+// next to it, and y = x / norm (or x * norm) is applied to the f32 accumulators: the GDN costs no HBM traffic.
+// Call with the LDS idle; returns with the LDS idle.
+template <class C>
+__device__ __forceinline__ void conv_fused_gdn_small(const ConvArgs &p, unsigned char *smem, f32x4_t (&acc)[C::MT][C::NT],
+                                                     int tid, int wm, int wn, int frow, int fq, int n0) {
+    constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
+
+        constexpr int XC = C::XC, XSW = C::XSW, ROWB = XC * 16;
+        unsigned char *Xi = smem;
+        unsigned char *Gi = smem + BM * ROWB;
+        if (XC * 8 > BN) {   // K padding of the second GEMM: zero the chunks past the last channel
+            constexpr int PADC = XC - BN / 8;
+            for (int q = tid; q < BM * PADC; q += 256) {
+                const int r = q / PADC, c = BN / 8 + (q - r * PADC);
+                *reinterpret_cast<uint4 *>(Xi + r * ROWB + ((c ^ ((r >> 1) & XSW)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wm * C::WM + i * 16 + frow;
+                const int col = wn * C::WN + j * 16 + fq * 4;   // 4 consecutive channels of pixel r
+                uint2 h;                                        // |x| as bf16
+                h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]) & 0x7FFF7FFFu;
+                h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]) & 0x7FFF7FFFu;
+                *reinterpret_cast<uint2 *>(Xi + r * ROWB + (((col >> 3) ^ ((r >> 1) & XSW)) << 4) + (col & 7) * 2) = h;
+            }
+        const uint16_t *gamma = p.ep_x;   // packed bf16 [rows >= BN][g_pitch], zero padded
+        for (int q = tid; q < BN * XC; q += 256) {
+            const int r = q / XC, c = q - r * XC;
+            const uint4 v = *reinterpret_cast<const uint4 *>(gamma + (long long)r * p.g_pitch + c * 8);
+            *reinterpret_cast<uint4 *>(Gi + r * ROWB + ((c ^ ((r >> 1) & XSW)) << 4)) = v;
+        }
+        __syncthreads();
+        f32x4_t nrm[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) nrm[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < XC / 4; ++ks) {
+            bf16x8_t xa[MT], gb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * C::WM + i * 16 + frow;
+                xa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(
+                                                         Xi + r * ROWB + (((4 * ks + fq) ^ ((r >> 1) & XSW)) << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * C::WN + j * 16 + frow;
+                gb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(
+                                                         Gi + r * ROWB + (((4 * ks + fq) ^ ((r >> 1) & XSW)) << 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    nrm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb[j], xa[i], nrm[i][j], 0, 0, 0);
+        }
+        const bool inverse = p.epi == SC2_EPI_FUSED_IGDN;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * C::WN + j * 16 + fq * 4;
+            const float4 b4 = col < p.Cout ? *reinterpret_cast<const float4 *>(p.ep_beta + col)
+                                           : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float norm = b[e] + nrm[i][j][e];
+                    acc[i][j][e] = inverse ? acc[i][j][e] * norm : acc[i][j][e] * (1.0f / norm);
+                }
+        }
+        __syncthreads();   // the images are dead; the staging buffer below reuses their LDS
+    }
 
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
@@ -621,81 +702,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     __builtin_amdgcn_s_barrier();
 
     // ------------------------------------------------------------------ fused GDN1 / inverse GDN1
-    // The tile holds every output channel of its pixels, so norm = beta + gamma |x| is a second, LDS-resident GEMM:
-    // |x| (bf16) is written to an LDS image straight from the accumulators, gamma is staged next to it, and
-    // y = x / norm (or x * norm) is applied to the f32 accumulators before the store: the GDN costs no HBM traffic.
-    if constexpr (BN <= 96) if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
-        constexpr int XC = C::XC, XSW = C::XSW, ROWB = XC * 16;
-        unsigned char *Xi = smem;
-        unsigned char *Gi = smem + BM * ROWB;
-        if (XC * 8 > BN) {   // K padding of the second GEMM: zero the chunks past the last channel
-            constexpr int PADC = XC - BN / 8;
-            for (int q = tid; q < BM * PADC; q += 256) {
-                const int r = q / PADC, c = BN / 8 + (q - r * PADC);
-                *reinterpret_cast<uint4 *>(Xi + r * ROWB + ((c ^ ((r >> 1) & XSW)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int r = wm * C::WM + i * 16 + frow;
-                const int col = wn * C::WN + j * 16 + fq * 4;   // 4 consecutive channels of pixel r
-                uint2 h;                                        // |x| as bf16
-                h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]) & 0x7FFF7FFFu;
-                h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]) & 0x7FFF7FFFu;
-                *reinterpret_cast<uint2 *>(Xi + r * ROWB + (((col >> 3) ^ ((r >> 1) & XSW)) << 4) + (col & 7) * 2) = h;
-            }
-        const uint16_t *gamma = p.ep_x;   // packed bf16 [rows >= BN][g_pitch], zero padded
-        for (int q = tid; q < BN * XC; q += 256) {
-            const int r = q / XC, c = q - r * XC;
-            const uint4 v = *reinterpret_cast<const uint4 *>(gamma + (long long)r * p.g_pitch + c * 8);
-            *reinterpret_cast<uint4 *>(Gi + r * ROWB + ((c ^ ((r >> 1) & XSW)) << 4)) = v;
-        }
-        __syncthreads();
-        f32x4_t nrm[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) nrm[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < XC / 4; ++ks) {
-            bf16x8_t xa[MT], gb[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int r = wm * C::WM + i * 16 + frow;
-                xa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(
-                                                         Xi + r * ROWB + (((4 * ks + fq) ^ ((r >> 1) & XSW)) << 4)));
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int r = wn * C::WN + j * 16 + frow;
-                gb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(
-                                                         Gi + r * ROWB + (((4 * ks + fq) ^ ((r >> 1) & XSW)) << 4)));
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    nrm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gb[j], xa[i], nrm[i][j], 0, 0, 0);
-        }
-        const bool inverse = p.epi == SC2_EPI_FUSED_IGDN;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn * C::WN + j * 16 + fq * 4;
-            const float4 b4 = col < p.Cout ? *reinterpret_cast<const float4 *>(p.ep_beta + col)
-                                           : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float norm = b[e] + nrm[i][j][e];
-                    acc[i][j][e] = inverse ? acc[i][j][e] * norm : acc[i][j][e] * (1.0f / norm);
-                }
-        }
-        __syncthreads();   // the images are dead; the staging buffer below reuses their LDS
-    }
+    if constexpr (BN <= 96)
+        if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN)
+            conv_fused_gdn_small<C>(p, smem, acc, tid, wm, wn, frow, fq, n0);
     const int epi = (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) ? (int)SC2_EPI_NONE : p.epi;
     if (p.dbg & 1) {
 #pragma unroll
@@ -712,6 +721,153 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 }
 
 // ======================================================================================================
+// 5x5 stride-2 convolution from an LDS-resident input PATCH (second encoder conv, 96 -> 48, layer.py:479-480).
+// The generic kernel gathers every (tap, channel-slab) A tile from L2 again: 25 taps re-read each input pixel 6.25
+// times, the re-reads miss the 4 MB L2 (PMC: 3.5 GB fetched for 0.62 GB of input) and the launch runs at the
+// Infinity Cache's rate.  Here a workgroup owns TWO output rows of one image (<= 128 pixels); per 32-channel slab it
+// loads the 7 input rows it needs ONCE (direct-to-LDS, 1.75x the input instead of 6.25x) and builds all 25 taps'
+// A fragments from LDS with per-lane addresses.  Patch layout: [column parity][input row][half column j][64 B]: a
+// tap reads one parity plane at consecutive j for consecutive output pixels, so the 16-byte-chunk XOR swizzle of the
+// slab tiles ((j >> 1) & 3) keeps the fragment reads conflict-free.  Weights come FRAGMENT-MAJOR
+// (SC2_K_B_FRAG_MAJOR: [k-step][16-row tile][lane][8 k], 1 KB contiguous per operand fragment) straight from L2 into
+// registers, two steps ahead: no barrier inside a channel slab.  52 KB of LDS -> three workgroups per CU, one's
+// patch load overlaps the others' MFMAs.  Epilogue (fused GDN1, bf16 store) shared with conv_igemm_kernel.
+template <class C>
+__global__ __launch_bounds__(256, 3) void conv5s2_patch_kernel(const ConvArgs p) {
+    constexpr int BN = C::BN, MT = C::MT, NT = C::NT;
+    constexpr int CIN = C::CIN, NCB = CIN / 32, NTAP = 25;
+    static_assert(C::STATIC && C::WAVES_N == 1 && C::KH == 5 && C::KW == 5 && C::SH == 2 && CIN % 32 == 0, "geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave, wn = 0;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int H = p.H, W = p.W, OW = p.OW, J = OW + 2;
+    const int rp_per_img = (p.OH + 1) >> 1;
+    const int img = blockIdx.x / rp_per_img;
+    const int oh0 = (blockIdx.x - img * rp_per_img) * 2;
+    const int valid = (p.OH - oh0 >= 2 ? 2 : 1) * OW;   // real output pixels of this tile (rows beyond are dummies)
+    const int m0 = (img * p.OH + oh0) * OW;
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16);
+
+    // ---- this thread's share of the patch fill: LDS chunk P = tid + 256 k  <->  (plane, row r, half column j, chunk)
+    const int n_chunks = 2 * 7 * J * 4;
+    constexpr int MAXQ = (2 * 7 * 66 * 4 + 255) / 256;   // J <= 66
+    const int nq = (n_chunks + 255) >> 8;
+    auto patch_src = [&](int k) {   // element offset inside the image of LDS chunk tid + 256 k, -1: zero block
+        const int P = tid + 256 * k;
+        const int cphys = P & 3, t = P >> 2;
+        const int t2 = t / J, j = t - t2 * J;
+        const int plane = t2 / 7, r = t2 - plane * 7;
+        const int chunk = cphys ^ ((j >> 1) & 3);
+        const int ih = 2 * oh0 - C::PH + r, iw = 2 * j + plane - C::PW;
+        const bool ok = (P < n_chunks) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+        return ok ? (ih * W + iw) * CIN + chunk * 8 : -1;
+    };
+    const uint16_t *ximg = p.x + (long long)img * H * W * CIN;
+
+    // ---- K is split over the four waves BY TAP (wave w takes taps w, w + 4, ...): every wave then streams only its
+    //      own quarter of the weights (an M split made each wave stream all 225 KB per tile: 6.5 GB through the vector
+    //      L1 per launch, and the kernel ran at that rate), while all waves read the same A fragments from the patch.
+    //      Each wave accumulates partial sums for the WHOLE 128 x 48 tile; they are added up through LDS at the end.
+    constexpr int MA = C::BM / 16;   // 8 m-tiles
+    const uint4 *bfrag = reinterpret_cast<const uint4 *>(p.w) + lane;   // [(step * NT + j) * 64]
+
+    f32x4_t part[MA][NT];
+#pragma unroll
+    for (int i = 0; i < MA; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) part[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NQ = (NTAP + 3) / 4;   // taps per wave (the last one only for wave 0)
+#pragma unroll 1
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (cb > 0) __syncthreads();   // every wave is done with the previous slab's patch
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            if (k < nq) {
+                const int so = patch_src(k);
+                const uint16_t *src = so >= 0 ? ximg + so + cb * 32 : zero;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(smem + (wave * 64 + 256 * k) * 16), 16, 0, 0);
+            }
+        }
+        uint4 bq[2][NT];   // this wave's weight fragments, one tap ahead
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[0][j] = bfrag[((cb * NTAP + wave) * NT + j) * 64];
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");   // the patch share has landed (the weights may still fly)
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int tap = wave + 4 * q;
+            if (tap < NTAP) {   // wave-uniform
+                if (tap + 4 < NTAP) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bq[(q + 1) & 1][j] = bfrag[((cb * NTAP + tap + 4) * NT + j) * 64];
+                }
+                const int kh = tap / 5, kw = tap - kh * 5;
+                const int d = kw >> 1;
+                const int tap_off = (((kw & 1) * 7 + kh) * J + d) * 64;
+                int fr = frow;
+                asm volatile("" : "+v"(fr));   // keeps the address arithmetic below INSIDE the tap loop
+#pragma unroll
+                for (int i = 0; i < MA; ++i) {
+                    // pixel of (m-tile i, lane row) -> patch offset (recomputed: registers are what limits occupancy)
+                    const int pix = i * 16 + fr;
+                    const bool real = pix < 2 * OW;
+                    const int orow = real ? (pix >= OW ? 1 : 0) : 1;
+                    const int ocol = real ? pix - orow * OW : OW - 1;
+                    const int swz = (fq ^ (((ocol + d) >> 1) & 3)) << 4;
+                    const bf16x8_t af = __builtin_bit_cast(
+                        bf16x8_t, *reinterpret_cast<const uint4 *>(smem + ((2 * orow) * J + ocol) * 64 + tap_off + swz));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bq[q & 1][j]), af,
+                                                                             part[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- add the four waves' partial tiles through an f32 LDS buffer [128][BN]; every wave then takes back the rows
+    //      it owns in the epilogue's tiling (wave w: rows 32w .. 32w + 31)
+    __syncthreads();   // the patch is dead
+    // (one wave at a time: three waves adding concurrently with ds_add_f32 into the same slots ran 2x slower)
+    float *red = reinterpret_cast<float *>(smem);
+#pragma unroll 1
+    for (int turn = 0; turn < 4; ++turn) {
+        if (wave == turn) {
+#pragma unroll
+            for (int i = 0; i < MA; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float4 *slot = reinterpret_cast<float4 *>(red + (i * 16 + frow) * BN + j * 16 + fq * 4);
+                    float4 v = make_float4(part[i][j][0], part[i][j][1], part[i][j][2], part[i][j][3]);
+                    if (turn > 0) {
+                        const float4 o = *slot;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *slot = v;
+                }
+        }
+        __syncthreads();
+    }
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const float4 v = *reinterpret_cast<const float4 *>(red + (wm * C::WM + i * 16 + frow) * BN + j * 16 + fq * 4);
+            acc[i][j] = f32x4_t{v.x, v.y, v.z, v.w};
+        }
+    __syncthreads();   // the reduction buffer is dead: its LDS becomes the GDN images / the store image
+    if constexpr (BN <= 96)
+        if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN)
+            conv_fused_gdn_small<C>(p, smem, acc, tid, wm, wn, frow, fq, 0);
+    const int epi = (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) ? (int)SC2_EPI_NONE : p.epi;
+    conv_store_tile_bf16<C, ImgPad<C>, 256, false>(p, smem, acc, tid, wm, wn, frow, fq, m0, 0, epi, nullptr, false, valid);
+}
+
+// ======================================================================================================
 // Big-tile variant for the MFMA-bound layers (Cout % 128 == 0, long K): 512 threads = 8 waves, 256 x BN tile,
 // BK = 32 slabs in a 4-deep direct-to-LDS ring.  The 8 waves form two groups of four (wave w and w + 4 share a
 // SIMD) that run ONE BARRIER OUT OF STEP: between two barriers one group issues its fragment reads and the next
@@ -722,16 +878,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 //   before its first read, by every wave, ahead of the barrier that opens that read (RAW); a stage is re-filled only
 //   after a barrier that follows the lgkmcnt(0) of its last readers (WAR).
 template <int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_, int PH_,
-          int PW_>
+          int PW_, int BM_ = 256, int STAGES_ = 4>
 struct Cfg8 {
-    static constexpr int BM = 256, BN = BN_, BK = 32, KC = 4;
+    // BM = 128 with a 3-deep ring: 72 KB of LDS and <= 128 registers, so TWO workgroups share a CU and one's store
+    // epilogue (x image, second GEMM, read-out: ~20 % of a fused conv + IGDN tile) overlaps the other's K loop
+    static constexpr int BM = BM_, BN = BN_, BK = 32, KC = 4;
+    static constexpr int MIN_WAVES = BM_ == 128 ? 4 : 2;   // waves per SIMD the register allocation must allow
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
     static constexpr bool STATIC = STATIC_;
     static constexpr int CIN = CIN_, KH = KH_, KW = KW_, SH = SH_, SW = SW_, PH = PH_, PW = PW_;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int MT = WM / 16, NT = WN / 16;
     static constexpr int PHASES = MT / 4;
-    static constexpr int STAGES = 4;
+    static constexpr int STAGES = STAGES_;
     static constexpr int A_IPW = BM / 16 / 8, B_IPW = BN / 16 / 8;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
@@ -739,7 +898,8 @@ struct Cfg8 {
     static constexpr int MAIN_LDS = STAGES * STAGE_BYTES;
     static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
     // fused conv + GDN1 (BN == 256 == Cout): x image 256 x 512 B + a 2 x 16 KB gamma-slab ring / store staging
-    static constexpr int FUSE_LDS = BN == 256 ? 256 * 512 + 32768 : 0;
+    // (the f32-output form of the fused epilogue stages through 32 KB behind the image: full-height tile only)
+    static constexpr int FUSE_LDS = BN == 256 ? BM * 512 + (BM == 256 ? 32768 : 0) : 0;
     static constexpr int IMG_LDS = BM * BN * 2;            // bf16 store image (ImgXor)
     static constexpr int LDS1 = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
     static constexpr int LDS2 = LDS1 > FUSE_LDS ? LDS1 : FUSE_LDS;
@@ -749,7 +909,7 @@ struct Cfg8 {
 };
 
 template <class C>
-__global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const ConvArgs p) {
     constexpr int BM = C::BM, BN = C::BN, BK = C::BK, KC = C::KC;
     constexpr int MT = C::MT, NT = C::NT, S = C::STAGES, PHASES = C::PHASES;
     constexpr int A_IPW = C::A_IPW, B_IPW = C::B_IPW, L = A_IPW + B_IPW;
@@ -955,7 +1115,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8_kernel(const ConvArgs p) {
     if constexpr (BN == 256) {
         if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
             unsigned char *Xi = smem;
-            unsigned char *ring = smem + 256 * 512;
+            unsigned char *ring = smem + BM * 512;   // f32-output staging (BM == 256 only)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1057,6 +1217,30 @@ int launch(const ConvArgs &a, hipStream_t s) {
     return SC2_OK;
 }
 
+template <class C>
+int launch_patch(const ConvArgs &a, hipStream_t s) {
+    ConvArgs p = a;
+    p.KT = 0;
+    p.n_ntiles = 1;
+    const int J = a.OW + 2;
+    const int patch = 2 * 7 * J * 64;
+    const int lds = patch > C::LDS_BYTES ? patch : C::LDS_BYTES;
+    const long long nwg = (long long)a.N * ((a.OH + 1) / 2);
+    if (nwg <= 0 || nwg > 0x7FFFFFFFLL) {
+        sc2_set_error("conv2d: grid of %lld workgroups out of range", nwg);
+        return SC2_ERR_INVALID_ARG;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv5s2_patch_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * 66 * 64);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv5s2_patch_kernel<C>, dim3((unsigned)nwg), dim3(256), lds, s, p);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
 // Static geometries of FPBasedResNetBottleneck(24, 256) (layer.py:464-494) -> folded address math.
 //                 BM   BN  WM WN  static Cin KH KW SH SW PH PW
 using C_conv0 = Cfg<128, 96, 2, 2, true, 8, 5, 3, 2, 1, 2, 1>;      // 3->96 k5 s2 p2 on the pixel-pair view
@@ -1092,6 +1276,8 @@ using B_gdn512 = Cfg8<256, 2, 4, true, 512, 1, 1, 1, 1, 0, 0>;
 using B_dec2 = Cfg8<256, 2, 4, true, 512, 2, 2, 1, 1, 0, 0>;
 using B_gdn256 = Cfg8<256, 2, 4, true, 256, 1, 1, 1, 1, 0, 0>;
 using B_dec4 = Cfg8<256, 2, 4, true, 256, 2, 2, 1, 1, 1, 1>;
+using H_dec2 = Cfg8<256, 2, 4, true, 512, 2, 2, 1, 1, 0, 0, 128, 3>;   // half-height twins: 2 workgroups per CU
+using H_dec4 = Cfg8<256, 2, 4, true, 256, 2, 2, 1, 1, 1, 1, 128, 3>;
 using BG_256 = Cfg8<256, 2, 4, false, 0, 0, 0, 0, 0, 0, 0>;
 using BG_128 = Cfg8<128, 4, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 
@@ -1124,6 +1310,15 @@ bool big_tile_eligible(const sc2_conv_desc *d, long long M, int K) {
            ((K >= 1024 && d->Cout % 256 == 0 && d->a_op == SC2_AOP_NONE && M >= 256LL * 512) || forced);
 }
 }  // namespace
+
+extern "C" int sc2_conv_patch_supported(const sc2_conv_desc *d) {
+    if (!d) return 0;
+    return d->Cin == 96 && d->Cout == 48 && d->KH == 5 && d->KW == 5 && d->stride_h == 2 && d->stride_w == 2 &&
+                   d->pad_h == 2 && d->pad_w == 2 && d->OW > 0 && d->OW <= 64 && d->out_format == SC2_OUT_BF16_NHWC &&
+                   d->out_H == 0 && d->a_op == SC2_AOP_NONE && d->epilogue != SC2_EPI_GDN && d->epilogue != SC2_EPI_IGDN &&
+                   d->epilogue != SC2_EPI_BIAS_ADD_RELU
+               ? 1 : 0;
+}
 
 extern "C" int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d) {
     if (!d || d->Cout <= 0) return 0;
@@ -1162,7 +1357,9 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     SC2_REQUIRE(d->Cout_pad == sc2_conv_weight_rows(d->Cout), SC2_ERR_INVALID_ARG, "conv2d: Cout_pad %d != %d",
                 d->Cout_pad, sc2_conv_weight_rows(d->Cout));
     SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS, SC2_ERR_INVALID_ARG, "conv2d: bad a_op");
-    SC2_REQUIRE(d->k_order >= 0 && d->k_order <= 3 && (!(d->k_order & SC2_K_SLAB_MAJOR) || d->Cin % 32 == 0),
+    SC2_REQUIRE(d->k_order >= 0 && d->k_order <= 7 && (!(d->k_order & SC2_K_SLAB_MAJOR) || d->Cin % 32 == 0) &&
+                    (!(d->k_order & SC2_K_B_FRAG_MAJOR) ||
+                     ((d->k_order & SC2_K_SLAB_MAJOR) && !(d->k_order & SC2_K_B_TILE_MAJOR))),
                 SC2_ERR_INVALID_ARG, "conv2d: slab-major K order needs Cin %% 32 == 0 (Cin = %d)", d->Cin);
     SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_BIAS_LEAKY_RELU, SC2_ERR_INVALID_ARG,
                 "conv2d: bad epilogue");
@@ -1210,6 +1407,13 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     const int rows = d->Cout_pad;
+    if (d->k_order & SC2_K_B_FRAG_MAJOR) {
+        // fragment-major weights are understood by the LDS-patch kernel only (sc2_conv_patch_supported tells)
+        SC2_REQUIRE(sc2_conv_patch_supported(d), SC2_ERR_UNSUPPORTED,
+                    "conv2d: SC2_K_B_FRAG_MAJOR weights need the 5x5 stride-2 patch geometry (Cin 96, Cout 48, OW <= 64, "
+                    "bf16 NHWC output, slab-major K)");
+        return launch_patch<C_conv2>(a, s);
+    }
     // static geometries first (tile width must agree with the packed row count)
     if (rows == 96 && matches<C_conv0>(a)) return launch<C_conv0>(a, s);
     if (rows == 96 && matches<C_gdn96>(a)) return launch<C_gdn96>(a, s);
@@ -1218,6 +1422,11 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     if (rows == 32 && matches<C_conv4>(a)) return launch<C_conv4>(a, s);
     const bool big = big_tile_eligible(d, M, K);
     if (big && d->Cout % 256 == 0) {
+        const char *half = getenv("SC2_CONV_HALF");
+        if ((half ? atoi(half) : 0) && d->out_format == SC2_OUT_BF16_NHWC) {
+            if (matches<H_dec2>(a)) return launch8<H_dec2>(a, s);
+            if (matches<H_dec4>(a)) return launch8<H_dec4>(a, s);
+        }
         if (matches<B_gdn512>(a)) return launch8<B_gdn512>(a, s);
         if (matches<B_dec2>(a)) return launch8<B_dec2>(a, s);
         if (matches<B_gdn256>(a)) return launch8<B_gdn256>(a, s);

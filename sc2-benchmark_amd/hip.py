@@ -25,7 +25,8 @@ EB_PARAM_STRIDE = 64
 ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
-    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv2d_fwd',
+    'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
+    'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
@@ -64,6 +65,7 @@ def lib():
     L.sc2_conv_weight_rows.argtypes = [i32]
     L.sc2_conv_weight_pitch.argtypes = [i32]
     L.sc2_conv_fused_gdn_supported.argtypes = [ctypes.POINTER(ConvDesc)]
+    L.sc2_conv_patch_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     L.sc2_conv2x2_gdn512_supported.argtypes = [i32] * 6
     L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
@@ -204,7 +206,7 @@ def weight_pitch(k):
     return lib().sc2_conv_weight_pitch(int(k))
 
 
-K_TAP_MAJOR, K_SLAB_MAJOR, K_B_TILE_MAJOR = 0, 1, 2   # K_B_TILE_MAJOR: flag OR-ed into the k order
+K_TAP_MAJOR, K_SLAB_MAJOR, K_B_TILE_MAJOR, K_B_FRAG_MAJOR = 0, 1, 2, 4   # the last two: flags OR-ed into the k order
 
 
 def pack_conv_weight(w, k_order=K_TAP_MAJOR):
@@ -216,6 +218,7 @@ def pack_conv_weight(w, k_order=K_TAP_MAJOR):
     rows, pitch = weight_rows(cout), weight_pitch(k)
     packed = torch.zeros((rows, pitch), dtype=torch.bfloat16, device=w.device)
     tile_major = bool(k_order & K_B_TILE_MAJOR)
+    frag_major = bool(k_order & K_B_FRAG_MAJOR)
     k_order = k_order & 1
     if k_order == K_SLAB_MAJOR:
         assert cin % 32 == 0
@@ -223,10 +226,28 @@ def pack_conv_weight(w, k_order=K_TAP_MAJOR):
     else:
         flat = w.detach().permute(0, 2, 3, 1).reshape(cout, k)
     packed[:cout, :k] = flat.to(torch.bfloat16)
+    if frag_major:   # [k-step][16-row tile][lane = fq*16 + frow][8]: one MFMA operand fragment = 1 KB contiguous
+        rows, kpad = packed.shape
+        assert rows % 16 == 0 and not tile_major
+        packed = packed.reshape(rows // 16, 16, kpad // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous().reshape(rows, kpad)
     if tile_major:   # [k-slab][row][32]: same bytes, the B tile of a k-slab contiguous; kept 2-D for the shape checks
         rows, kpad = packed.shape
         packed = packed.reshape(rows, kpad // 32, 32).permute(1, 0, 2).contiguous().reshape(rows, kpad)
     return packed
+
+
+def conv_patch_supported(x_shape, cout, kh, kw, stride, pad, out_format=OUT_BF16_NHWC, epilogue=EPI_NONE):
+    """True if this conv runs on the LDS-resident-patch kernel (weights then packed K_SLAB_MAJOR | K_B_FRAG_MAJOR)."""
+    if os.environ.get('SC2_CONV_PATCH', '1') == '0':      # A/B switch (tools/)
+        return False
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    N, H, W, Cin = x_shape
+    OH = (H + 2 * ph - kh) // sh + 1
+    OW = (W + 2 * pw - kw) // sw + 1
+    d = ConvDesc(N, H, W, Cin, cout, kh, kw, sh, sw, ph, pw, OH, OW, AOP_NONE, epilogue, out_format,
+                 weight_pitch(kh * kw * Cin), weight_rows(cout), 0, 0, 0, 0, 0, 0, K_SLAB_MAJOR | K_B_FRAG_MAJOR)
+    return bool(lib().sc2_conv_patch_supported(ctypes.byref(d)))
 
 
 def preferred_k_order(cin, kh, kw):

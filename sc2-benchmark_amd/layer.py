@@ -179,9 +179,14 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             h = g1.forward_nhwc(h)
         if fuse2:
             beta, gamma = g3.effective()
-            h = hip.conv2d_fwd(h, c2.packed_weight(), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
-                               c2.padding, epilogue=hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN,
-                               ep_x=gamma, ep_beta=beta, tag=c2._tag + '+' + g3._tag, k_order=c2.k_order())
+            epi = hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN
+            order = c2.k_order()
+            if hip.conv_patch_supported(tuple(h.shape), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
+                                        c2.padding, epilogue=epi):
+                order = hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR   # input patch staged in LDS once (conv5s2_patch_kernel)
+            h = hip.conv2d_fwd(h, c2.packed_weight(order), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1],
+                               c2.stride, c2.padding, epilogue=epi, ep_x=gamma, ep_beta=beta,
+                               tag=c2._tag + '+' + g3._tag, k_order=order)
         else:
             h = g3.forward_nhwc(c2.forward_nhwc(h))
         return c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)

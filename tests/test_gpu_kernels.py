@@ -100,9 +100,12 @@ def test_conv_igemm(S, dev, cin, cout, k, stride, pad, H, W, N):
     (32, 128, 3, 1, 1, 17, 19, 2),     # generic 128-wide 8-wave tile
     (24, 384, 3, 2, 1, 30, 30, 2),     # Cout 384: 128-wide tiles, K = 216 (tail slab)
 ])
-def test_conv_big_tile(S, dev, monkeypatch, cin, cout, k, stride, pad, H, W, N):
-    """The 8-wave staggered 256-row kernel (forced here: its dispatch thresholds need >= 131072 rows)."""
+@pytest.mark.parametrize('half', ['0', '1'])
+def test_conv_big_tile(S, dev, monkeypatch, cin, cout, k, stride, pad, H, W, N, half):
+    """The 8-wave staggered 256-row kernel (forced here: its dispatch thresholds need >= 131072 rows); half = '1':
+    the 128-row twins of the two decoder geometries (two workgroups per CU)."""
     monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
+    monkeypatch.setenv('SC2_CONV_HALF', half)
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.randn(N, cin, H, W, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
@@ -233,10 +236,13 @@ def test_conv_fused_gdn(S, R, dev, cin, cout, k, stride, pad, inverse):
                          ep_beta=torch.ones(256, device=dev))
 
 
+@pytest.mark.parametrize('half', ['0', '1'])
 @pytest.mark.parametrize('cin,k,pad,inverse', [(512, 2, 0, True), (64, 1, 0, False)])
-def test_conv_fused_gdn_big_tile(S, R, dev, monkeypatch, cin, k, pad, inverse):
-    """conv + GDN1(256) in one launch of the 256-wide 8-wave tile (x image and gamma ring in LDS), ragged last tile."""
+def test_conv_fused_gdn_big_tile(S, R, dev, monkeypatch, cin, k, pad, inverse, half):
+    """conv + GDN1(256) in one launch of the 256-wide 8-wave tile (x image in LDS, gamma fragments from L2), ragged
+    last tile; half = '1': the 128-row twin of the dec.conv2 geometry."""
     monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
+    monkeypatch.setenv('SC2_CONV_HALF', half)
     cout = 256
     torch.manual_seed(cin)
     gdn = R.GDN1(cout, inverse=inverse)
@@ -308,6 +314,46 @@ def test_conv2x2_gdn512_fused(S, R, dev, cin, inverse, N, H, W):
     # and the same result as the two-launch path (conv -> GDN1) up to the bf16 rounding of its intermediate
     two = m.forward_nhwc(S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 2, 2, 1, 1))
     assert_close_bf16(out, two, 'fused vs two launches', extra=2.0 ** -7)
+
+
+@pytest.mark.parametrize('N,H,W,fused', [(2, 24, 20, True), (3, 22, 36, False), (1, 112, 112, True), (2, 10, 128, True)])
+def test_conv5s2_patch_kernel(S, R, dev, N, H, W, fused):
+    """Second encoder conv (96 -> 48, k5 s2 p2) from the LDS-resident input patch (+ fused GDN1(48)): against the f32
+    op on the bf16-rounded operands, and bit-for-bit-close to the generic gather kernel; odd output heights, image
+    borders, the widest supported rows (OW = 64)."""
+    cin, cout = 96, 48
+    torch.manual_seed(H * W)
+    x = torch.randn(N, cin, H, W)
+    w = torch.randn(cout, cin, 5, 5) / (cin * 25) ** 0.5
+    gdn = R.GDN1(cout)
+    with torch.no_grad():
+        gdn.gamma.add_(0.05 * torch.rand(cout, cout) / cout ** 0.5)
+        gdn.beta.add_(0.1 * torch.rand(cout))
+        conv = F.conv2d(bf16_round(x), bf16_round(w), stride=2, padding=2)
+        ref = conv
+        if fused:
+            beta = gdn.beta_reparam(gdn.beta)
+            gamma = bf16_round(gdn.gamma_reparam(gdn.gamma))
+            ref = conv / F.conv2d(bf16_round(conv).abs(), gamma.reshape(cout, cout, 1, 1), beta)
+    m = S.GDN1(cout)
+    m.load_state_dict(gdn.state_dict())
+    m.to(dev)
+    beta_d, gamma_d = m.effective()
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    epi = S.hip.EPI_FUSED_GDN if fused else S.hip.EPI_NONE
+    assert S.hip.conv_patch_supported(tuple(x_nhwc.shape), cout, 5, 5, 2, 2, epilogue=epi)
+    assert not S.hip.conv_patch_supported(tuple(x_nhwc.shape), cout, 5, 5, 2, 2, out_format=S.hip.OUT_F32_NCHW)
+    assert not S.hip.conv_patch_supported((N, H, 2 * 70, cin), cout, 5, 5, 2, 2)          # rows wider than a tile
+    order = S.hip.K_SLAB_MAJOR | S.hip.K_B_FRAG_MAJOR
+    kw = dict(epilogue=epi, ep_x=gamma_d if fused else None, ep_beta=beta_d if fused else None)
+    out = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev), order), cout, 5, 5, 2, 2, k_order=order, **kw)
+    assert out.shape == (N, ref.shape[2], ref.shape[3], cout)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'patch conv', extra=2.0 ** -8 if fused else 0.0)
+    gen = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 5, 5, 2, 2, **kw)
+    assert_close_bf16(out, gen, 'patch vs gather kernel', extra=2.0 ** -7)
+    with pytest.raises(S.hip.Sc2Error):     # fragment-major weights outside the patch geometry must be refused
+        S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev), order), cout, 5, 5, 2, 2, k_order=order,
+                         out_format=S.hip.OUT_F32_NCHW)
 
 
 def _golden():

@@ -51,6 +51,12 @@ def main():
         rows.append(('enc.gdn96', timeit(lambda: g1.forward_nhwc(a0), args.iters), 231.2e6 * N, a0.numel() * 4 + a1.numel() * 2))
         a2 = e2.forward_nhwc(a1)
         rows.append(('enc.conv2', timeit(lambda: e2.forward_nhwc(a1), args.iters), 722.5e6 * N, a1.numel() * 2 + a2.numel() * 2))
+        beta_g3, gamma_g3 = g3.effective()
+        for nm, order in (('enc.conv2+gdn48 (gather)', e2.k_order()), ('enc.conv2+gdn48 (patch)', hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR)):
+            wq = e2.packed_weight(order)
+            rows.append((nm, timeit(lambda: hip.conv2d_fwd(a1, wq, 48, 5, 5, 2, 2, epilogue=hip.EPI_FUSED_GDN, ep_x=gamma_g3,
+                                                            ep_beta=beta_g3, k_order=order), args.iters),
+                         (722.5e6 + 14.5e6) * N, a1.numel() * 2 + a2.numel() * 2))
         a3 = g3.forward_nhwc(a2)
         rows.append(('enc.gdn48', timeit(lambda: g3.forward_nhwc(a2), args.iters), 14.5e6 * N, a2.numel() * 4 + a3.numel() * 2))
         y = e4.forward_nhwc(a3, out_format=hip.OUT_F32_NCHW)
