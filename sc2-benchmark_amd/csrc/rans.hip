@@ -509,6 +509,153 @@ __global__ __launch_bounds__(64) void rans_dec_generic_kernel(const RansArgs a) 
     a.status[s] = 0;
 }
 
+// parallel pass: dst[blk][i][lane] = src[blk*64 + lane][i] (per-symbol indexes into the serial decoder's lane-contiguous
+// order; `dst` = the workspace, n_blocks * n_sym * 64 words)
+__global__ __launch_bounds__(256) void rans_transpose_in_kernel(const int32_t *__restrict__ src, int n_streams,
+                                                                long long n_sym, uint32_t *__restrict__ dst) {
+    __shared__ uint32_t tile[64][65];
+    const int blk = blockIdx.y;
+    const long long i0 = (long long)blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const int pl = t & 63;
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int sl = r * 4 + (t >> 6);
+        const int s = blk * 64 + sl;
+        const long long i = i0 + pl;
+        tile[pl][sl] = (s < n_streams && i < n_sym) ? (uint32_t)src[(long long)s * n_sym + i] : 0u;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < 16; ++r) {
+        const int p = r * 4 + (t >> 6);
+        const long long i = i0 + p;
+        if (i < n_sym) dst[((long long)blk * n_sym + i) * 64 + pl] = tile[p][pl];
+    }
+}
+
+// Decoder for explicit per-symbol indexes over a RAGGED table (the Gaussian conditional model: 64 rows of 5 .. 3133
+// entries, 27 k entries in all although the rectangular table has 200 k): the rows are packed back to back into LDS as
+// u16 (the closing 65536 of a row is implied by its position), so the upper-bound search - identical in result to
+// upstream's linear find_if - runs on LDS instead of global memory.  Falls back to the global table inside the same
+// kernel when the packed rows do not fit.  Indexes are fetched eight symbols ahead (they do not depend on the state).
+constexpr int kRaggedCap = 61440;    // u16 entries of packed CDF rows kept in LDS (120 KB)
+constexpr int kRaggedRows = 256;
+
+template <int kBucketBits>
+__global__ __launch_bounds__(64) void rans_dec_ragged_kernel(const RansArgs a) {
+    constexpr int kBuckets = 1 << kBucketBits;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *l_cdf = reinterpret_cast<uint16_t *>(smem);                       // [kRaggedCap]
+    int *row_start = reinterpret_cast<int *>(smem + kRaggedCap * 2);            // [n_cdfs + 1]
+    int *l_size = row_start + a.n_cdfs + 1;                                     // [n_cdfs]
+    int *l_off = l_size + a.n_cdfs;                                             // [n_cdfs]
+    // bucket[row][b] = first k with cdf[k] >= b << (16 - bits): the search for cum_freq starts inside the bucket
+    // of its top `bits` bits - a Gaussian row has most of its entries in the tails, most of its mass in a few buckets
+    uint16_t *bucket = reinterpret_cast<uint16_t *>(l_off + a.n_cdfs);          // [n_cdfs][kBuckets + 1]
+    const int lane = threadIdx.x;
+    for (int r = lane; r < a.n_cdfs; r += 64) {
+        l_size[r] = a.cdf_sizes[r];
+        l_off[r] = a.offsets[r];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int tot = 0;
+        for (int r = 0; r < a.n_cdfs; ++r) {
+            row_start[r] = tot;
+            tot += l_size[r];
+        }
+        row_start[a.n_cdfs] = tot;
+    }
+    __syncthreads();
+    const bool in_lds = row_start[a.n_cdfs] <= kRaggedCap;
+    if (in_lds) {
+        for (int r = 0; r < a.n_cdfs; ++r) {
+            const int size = l_size[r], st = row_start[r];
+            for (int k = lane; k < size; k += 64) l_cdf[st + k] = (uint16_t)a.cdfs[(long long)r * a.cdf_stride + k];
+        }
+    }
+    __syncthreads();
+    if (in_lds) {
+        for (int t = lane; t < a.n_cdfs * (kBuckets + 1); t += 64) {
+            const int r = t / (kBuckets + 1), b = t - r * (kBuckets + 1);
+            const int size = l_size[r];
+            const uint16_t *row = l_cdf + row_start[r];
+            const unsigned target = (unsigned)b << (16 - kBucketBits);   // first k with cdf[k] > target - 1, i.e. >= target
+            int lo = 0, hi = size;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const unsigned v = mid == size - 1 ? 65536u : (unsigned)row[mid];
+                if (v >= target && !(b == 0 && v == 0u)) hi = mid; else lo = mid + 1;
+            }
+            bucket[t] = (uint16_t)lo;
+        }
+    }
+    __syncthreads();
+    const int s = blockIdx.x * 64 + lane;
+    if (s >= a.n_streams) return;
+    __builtin_amdgcn_s_setprio(3);
+    // indexes arrive transposed to [position][lane] in the workspace; each slot is overwritten IN PLACE by the decoded
+    // value of its position (an index is fetched >= 8 positions before its slot is written), and the finish pass
+    // transposes the workspace into symbols_out
+    uint32_t *out = a.ws + (long long)blockIdx.x * a.n_sym * 64 + lane;
+    const uint32_t *idxp = out;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)s * a.stride + a.io_offset[s]);
+    DecState d;
+    dec_init(d, w, a.io_nbytes[s] / 4);
+    constexpr int U = 8;
+    int nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nxt[u] = u < a.n_sym ? (int)idxp[(long long)u * 64] : 0;
+    for (long long i0 = 0; i0 < a.n_sym; i0 += U) {
+        int cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cur[u] = nxt[u];
+            nxt[u] = i0 + U + u < a.n_sym ? (int)idxp[(i0 + U + u) * 64] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u < a.n_sym) {
+                const int idx = cur[u];
+                const int size = l_size[idx];
+                const int max_value = size - 2;
+                const unsigned cum_freq = (unsigned)(d.x & 0xFFFFu);
+                int lo = 0, hi = size;
+                unsigned start, next;
+                if (in_lds) {
+                    const uint16_t *row = l_cdf + row_start[idx];
+                    const uint16_t *bk = bucket + idx * (kBuckets + 1) + (cum_freq >> (16 - kBucketBits));
+                    lo = bk[0];                                   // first k with cdf[k] >= bucket floor (<= answer)
+                    hi = min((int)bk[1] + 1, size);               // the answer is <= first k with cdf[k] >= next floor
+                    while (lo < hi) {   // first k with cdf[k] > cum_freq; the last entry of a row is 65536
+                        const int mid = (lo + hi) >> 1;
+                        const unsigned v = mid == size - 1 ? 65536u : (unsigned)row[mid];
+                        if (v > cum_freq) hi = mid; else lo = mid + 1;
+                    }
+                    start = (unsigned)row[lo - 1];
+                    next = lo == size - 1 ? 65536u : (unsigned)row[lo];
+                } else {
+                    const int32_t *row = a.cdfs + (long long)idx * a.cdf_stride;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if ((unsigned)row[mid] > cum_freq) hi = mid; else lo = mid + 1;
+                    }
+                    start = (unsigned)row[lo - 1];
+                    next = (unsigned)row[lo];
+                }
+                const int sidx = lo - 1;
+                d.x = (unsigned long long)(next - start) * (d.x >> kPrecision) + cum_freq - start;
+                dec_renorm(d);
+                int value = sidx;
+                if (value == max_value) value = dec_escape(d, max_value);
+                out[(i0 + u) * 64] = (uint32_t)(value + l_off[idx]);
+            }
+        }
+    }
+    a.status[s] = 0;
+}
+
 int check_common(const int32_t *indexes, long long index_div, int n_streams, long long n_sym, const int32_t *cdfs,
                  int n_cdfs, int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets) {
     SC2_REQUIRE(cdfs && cdf_sizes && offsets, SC2_ERR_INVALID_ARG, "rans: Uninitialized CDFs. Run update() first");
@@ -633,7 +780,29 @@ extern "C" int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const
         }
         return SC2_OK;
     }
-    if (n_entries <= 12288) {
+    if (indexes && n_entries > 12288 && n_cdfs <= kRaggedRows) {
+        const int bits = n_cdfs <= 64 ? 8 : 5;   // 257 / 33 bucket bounds per row: 33 KB / 17 KB at the largest row count
+        const size_t lds = (size_t)kRaggedCap * 2 + (size_t)(3 * n_cdfs + 1) * 4 +
+                           (size_t)n_cdfs * ((1 << bits) + 1) * 2 + 16;
+        if (bits == 8) allow_big_lds(rans_dec_ragged_kernel<8>, lds);
+        else allow_big_lds(rans_dec_ragged_kernel<5>, lds);
+        if (n_sym > 0) {
+            const long long gx = (n_sym + 63) / 64;
+            SC2_REQUIRE(gx < (1ll << 31) && n_blocks <= 65535, SC2_ERR_UNSUPPORTED, "rans_decode: problem too large");
+            hipLaunchKernelGGL(rans_transpose_in_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, indexes, n_streams,
+                               (long long)n_sym, a.ws);
+            SC2_CHECK_LAUNCH();
+        }
+        if (bits == 8) hipLaunchKernelGGL(rans_dec_ragged_kernel<8>, dim3(n_blocks), dim3(64), lds, s, a);
+        else hipLaunchKernelGGL(rans_dec_ragged_kernel<5>, dim3(n_blocks), dim3(64), lds, s, a);
+        SC2_CHECK_LAUNCH();
+        if (n_sym > 0) {
+            const long long gx = (n_sym + 63) / 64;
+            hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
+            SC2_CHECK_LAUNCH();
+        }
+        return SC2_OK;
+    } else if (n_entries <= 12288) {
         hipLaunchKernelGGL(rans_dec_generic_kernel<true>, dim3(n_blocks), dim3(64), (size_t)n_entries * 4, s, a);
     } else {
         hipLaunchKernelGGL(rans_dec_generic_kernel<false>, dim3(n_blocks), dim3(64), 0, s, a);

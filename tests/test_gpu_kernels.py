@@ -513,6 +513,38 @@ def test_rans_overflow_flag_and_large_table(S, dev):
     assert int(st.min()) == 1
 
 
+@pytest.mark.parametrize('n_rows,max_len,label', [(200, 90, 'ragged rows packed in LDS'), (60, 1400, 'packed rows exceed LDS: global')])
+def test_rans_ragged_tables_explicit_indexes(S, dev, n_rows, max_len, label):
+    """Per-symbol CDF rows over a wide ragged table (the shape of the Gaussian conditional model): encoder with the
+    global entry table, decoder with the rows packed into LDS as u16 (or its in-kernel global fallback)."""
+    rng = np.random.RandomState(n_rows)
+    rows, sizes, offs = [], [], []
+    for r in range(n_rows):
+        n = int(rng.randint(3, max_len)) if r else max_len      # row 0 pins the table width
+        p = rng.rand(n).astype(np.float32) ** 3 + 1e-4
+        p /= p.sum()
+        cdf = [int(v) for v in oracle_rans.pmf_to_quantized_cdf(p)]
+        rows.append(cdf)
+        sizes.append(len(cdf))
+        offs.append(-int(rng.randint(0, n)))
+    cdfs, d_sizes, d_offs = _tables(dev, rows, sizes, offs)
+    assert cdfs.numel() > 12288
+    n_streams, n_sym = 70, 333
+    idx = rng.randint(0, n_rows, size=(n_streams, n_sym)).astype(np.int32)
+    span = np.array(sizes)[idx]
+    sym = ((rng.rand(n_streams, n_sym) * (span + 6) - 3).astype(np.int64) + np.array(offs)[idx]).astype(np.int32)   # in-table and escapes
+    d_idx = torch.from_numpy(idx).to(dev)
+    buf, off, nb, st = S.hip.rans_encode_batch(torch.from_numpy(sym).to(dev), cdfs, d_sizes, d_offs, indexes=d_idx,
+                                               out_stride=S.hip.rans_max_bytes(n_sym))
+    assert int(st.max()) == 0
+    got = _streams(buf, off, nb)
+    h = cdfs.cpu().numpy()
+    for i in (0, 1, 33, 69):
+        assert got[i] == oracle_rans.encode_with_indexes(sym[i], idx[i], h, sizes, offs), label
+    dec, dst = S.hip.rans_decode_batch(buf, off, nb, n_sym, cdfs, d_sizes, d_offs, indexes=d_idx)
+    assert int(dst.max()) == 0 and np.array_equal(dec.cpu().numpy(), sym), label
+
+
 DGRAD_CASES = [
     # (Cin, Cout, k, stride, pad, H, W, N)
     (96, 48, 5, 2, 2, 20, 24, 2),      # enc.conv2 geometry: 4 stride-parity classes (3x3, 3x2, 2x3, 2x2 sub-filters)

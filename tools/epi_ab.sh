@@ -1,4 +1,3 @@
 #!/bin/bash
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-timeout 300 python tools/layer_times.py --bs 256 2>&1 | grep -E "enc\.|analysis"
-timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), d['bpp'], d['roofline'], d['bottleneck_forward'], d['kernels_ms'])"
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_hyperprior.py -x -q -k "rans or hyperprior or gaussian" 2>&1 | tail -6
+timeout 600 python tools/hyper_times.py --bs 256 2>&1 | tail -10

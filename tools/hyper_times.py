@@ -10,7 +10,10 @@ dev = torch.device('cuda:0')
 torch.manual_seed(0)
 m = S.get_layer(args.name).eval().to(dev)
 with torch.no_grad():
-    m.g_a[4].weight.mul_(40.0); m.h_a[2].weight.mul_(12.0); m.h_s[4].weight.mul_(6.0)
+    # latent of a few units, scales spread over the table (an untrained h_s would pin every scale at the 0.11 floor
+    # and turn every symbol into a bypass-coded escape)
+    m.g_a[4].weight.mul_(12.0); m.h_a[2].weight.mul_(12.0); m.h_s[4].weight.mul_(40.0)
+    m.h_s[4].weight.abs_()
 m.update()
 x = torch.rand(args.bs, 3, 224, 224, device=dev)
 def timeit(fn, iters=3):
