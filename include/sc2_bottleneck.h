@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 15
+#define SC2_ABI_VERSION 16
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -217,6 +217,13 @@ int sc2_eb_dequantize(const int32_t *symbols, const float *medians, int N, int C
 int sc2_gc_forward(const float *y, const float *scales, int64_t scales_img_stride, const float *means,
                    int64_t means_img_stride, const float *noise, int64_t n_img, int64_t chw, int mode,
                    float scale_bound, float lik_bound, float *y_hat, float *lik, void *stream);
+/* Backward of sc2_gc_forward in SC2_EB_NOISE mode (GaussianConditional.forward under autograd in training, reached
+ * from layer.py:679,794 through loss.backward()): g_yhat / g_lik upstream gradients (nullable = zero); g_y, g_scales,
+ * g_means dense f32 [n_img][chw] outputs (each nullable).  noise nullable = zero. */
+int sc2_gc_backward(const float *y, const float *scales, int64_t scales_img_stride, const float *means,
+                    int64_t means_img_stride, const float *noise, int64_t n_img, int64_t chw, float scale_bound,
+                    float lik_bound, const float *g_yhat, const float *g_lik, float *g_y, float *g_scales,
+                    float *g_means, void *stream);
 /* symbols = int32(round_half_even(y - means)); indexes = (n_table - 1) - #{t < n_table - 1 : max(scales,
  * scale_bound) <= scale_table[t]} (GaussianConditional.build_indexes).  Either output may be NULL. */
 int sc2_gc_symbols_indexes(const float *y, const float *scales, int64_t scales_img_stride, const float *means,

@@ -161,7 +161,7 @@ def _gdn(mod, x_nhwc):
 
 def analysis_autograd(m, x):
     """encoder(x) with gradients: f32 NCHW image -> f32 NCHW latent."""
-    c0, g1, c2, g3, c4 = m.encoder
+    c0, g1, c2, g3, c4 = m._g_a()
     x = x.float()
     if m._uses_pair_conv0(x):
         N, _, H, W = x.shape
@@ -183,7 +183,7 @@ def analysis_autograd(m, x):
 
 def synthesis_autograd(m, y_hat):
     """decoder(y_hat) with gradients: f32 NCHW latent -> f32 NCHW features."""
-    c0, g1, c2, g3, c4 = m.decoder
+    c0, g1, c2, g3, c4 = m._g_s()
     h = _ToNhwcBf16.apply(y_hat, y_hat.shape[1])
     h = _conv(c0, h)
     h = _gdn(g1, h)
@@ -205,3 +205,153 @@ def bottleneck_forward_updated_autograd(m, x):
         y = m.analysis(x)
         y_hat = m.entropy_bottleneck.quantize(y, 'dequantize', m._get_means(y))
     return synthesis_autograd(m, y_hat.detach())
+
+
+# --------------------------------------------------------------------------------------------- #
+# hyperprior bottlenecks (layer.py:553-817) under autograd
+# --------------------------------------------------------------------------------------------- #
+_ACT_SLOPE = {0: None, 1: 0.0, 2: 0.01}     # none / ReLU / LeakyReLU(0.01)
+
+
+def _act_backward(g, out, act):
+    """Gradient through the activation fused into a conv epilogue; ReLU and LeakyReLU keep the sign, so the mask
+    comes from the saved OUTPUT."""
+    if act == 0:
+        return g
+    slope = _ACT_SLOPE[act]
+    return torch.where(out > 0, g, g * slope) if slope else torch.where(out > 0, g, torch.zeros_like(g))
+
+
+class _ConvActFn(torch.autograd.Function):
+    """conv (+ fused ReLU / LeakyReLU) of h_a / h_s on the implicit-GEMM kernel; x bf16 NHWC, bf16 NHWC or f32 NCHW out."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight, mod, act, out_format):
+        epi = {0: hip.EPI_NONE, 1: hip.EPI_BIAS_RELU, 2: hip.EPI_BIAS_LEAKY_RELU}[act]
+        beta = torch.zeros(mod.out_channels, dtype=torch.float32, device=x_nhwc.device) if act else None
+        y = hip.conv2d_fwd(x_nhwc, mod.packed_weight(), mod.out_channels, mod.kernel_size[0], mod.kernel_size[1],
+                           mod.stride, mod.padding, epilogue=epi, ep_beta=beta, out_format=out_format,
+                           tag=getattr(mod, '_tag', None), k_order=mod.k_order())
+        ctx.save_for_backward(x_nhwc, weight, y if act else x_nhwc.new_zeros(1))
+        ctx.cfg = (mod.stride, mod.padding, act, out_format)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_nhwc, weight, y = ctx.saved_tensors
+        stride, pad, act, out_format = ctx.cfg
+        gy = _act_backward(gy, y, act)
+        if out_format == hip.OUT_BF16_NHWC:
+            g = gy.contiguous()
+        elif out_format == hip.OUT_F32_NCHW:
+            g = hip.nchw_f32_to_nhwc_bf16(gy.float().contiguous())
+        else:
+            g = gy.to(torch.bfloat16).contiguous()
+        kh, kw = weight.shape[2], weight.shape[3]
+        gw = hip.conv2d_wgrad(x_nhwc, g, kh, kw, stride, pad).contiguous() if ctx.needs_input_grad[1] else None
+        gi = hip.conv2d_dgrad(g, weight, stride, pad, (x_nhwc.shape[1], x_nhwc.shape[2])) \
+            if ctx.needs_input_grad[0] else None
+        return gi, gw, None, None, None
+
+
+class _ConvTransposeActFn(torch.autograd.Function):
+    """ConvTranspose2d (+ fused activation) of h_s: forward as stride-parity classes with output scatter; backward:
+    the data gradient is the plain strided convolution with the same weights, the weight gradient the conv weight
+    gradient with the roles of input and output gradient exchanged."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight, mod, act):
+        epi = {0: hip.EPI_NONE, 1: hip.EPI_BIAS_RELU, 2: hip.EPI_BIAS_LEAKY_RELU}[act]
+        beta = torch.zeros(mod.out_channels, dtype=torch.float32, device=x_nhwc.device) if act else None
+        y = mod.forward_nhwc(x_nhwc, epi, beta)
+        ctx.save_for_backward(x_nhwc, weight, y if act else x_nhwc.new_zeros(1))
+        ctx.cfg = (mod.stride, mod.padding, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_nhwc, weight, y = ctx.saved_tensors
+        stride, pad, act = ctx.cfg
+        g = _act_backward(gy, y, act).contiguous()
+        cin, cout, kh, kw = weight.shape                      # [in, out, kh, kw] = a conv weight [Cout'=in, Cin'=out]
+        gi = gw = None
+        if ctx.needs_input_grad[0]:
+            gi = hip.conv2d_fwd(g, hip.pack_conv_weight(weight.detach()), cin, kh, kw, stride, pad, tag='convT.dgrad')
+        if ctx.needs_input_grad[1]:
+            gw = hip.conv2d_wgrad(g, x_nhwc, kh, kw, stride, pad).contiguous()
+        return gi, gw, None, None
+
+
+def hyper_sequence_autograd(seq, x_nhwc):
+    """h_a / h_s (HipConv2d / HipConvTranspose2d / ReLU / LeakyReLU) with gradients: bf16 NHWC in, f32 NCHW out."""
+    from .entropy import HipConv2d, HipConvTranspose2d
+    mods = list(seq)
+    h = x_nhwc
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        act = 0
+        if isinstance(nxt, torch.nn.ReLU):
+            act = 1
+        elif isinstance(nxt, torch.nn.LeakyReLU) and abs(nxt.negative_slope - 0.01) < 1e-12:
+            act = 2
+        last = i + (2 if act else 1) >= len(mods)
+        if isinstance(m, HipConv2d):
+            h = _ConvActFn.apply(h, m.weight, m, act, hip.OUT_F32_NCHW if last else hip.OUT_BF16_NHWC)
+        elif isinstance(m, HipConvTranspose2d):
+            h = _ConvTransposeActFn.apply(h, m.weight, m, act)
+            if last:
+                h = h.float().permute(0, 3, 1, 2).contiguous()
+        else:
+            raise hip.Sc2Error('training path of the hyperprior bottlenecks: unsupported module {} in h_a / h_s'
+                               .format(type(m).__name__))
+        i += 2 if act else 1
+    return h
+
+
+class _GcFn(torch.autograd.Function):
+    """(y_hat, likelihood) of the Gaussian conditional model in training (noise) mode on the fused kernels."""
+
+    @staticmethod
+    def forward(ctx, y, scales, means, noise, scale_bound, lik_bound):
+        y_hat, lik = hip.gc_forward(y, scales, means, noise=noise, mode=hip.EB_NOISE, scale_bound=scale_bound,
+                                    lik_bound=lik_bound)
+        ctx.save_for_backward(y, scales, means if means is not None else y.new_zeros(1), noise)
+        ctx.has_means = means is not None
+        ctx.bounds = (scale_bound, lik_bound)
+        return y_hat, lik
+
+    @staticmethod
+    def backward(ctx, g_yhat, g_lik):
+        y, scales, means, noise = ctx.saved_tensors
+        g_y, g_s, g_m = hip.gc_backward(y, scales, means if ctx.has_means else None, noise,
+                                        g_yhat.float().contiguous() if g_yhat is not None else None,
+                                        g_lik.float().contiguous() if g_lik is not None else None,
+                                        scale_bound=ctx.bounds[0], lik_bound=ctx.bounds[1])
+        return g_y, g_s, g_m, None, None, None
+
+
+def gc_forward_autograd(gc, y, scales, means, noise=None):
+    """GaussianConditional.forward with gradients, training (noise) mode."""
+    y = y.float().contiguous()
+    if noise is None:
+        half = float(0.5)
+        noise = torch.empty_like(y).uniform_(-half, half)
+    bound = gc.likelihood_bound if gc.use_likelihood_bound else 0.0
+    return _GcFn.apply(y, scales.float().contiguous(), None if means is None else means.float().contiguous(),
+                       noise.float().contiguous(), gc._scale_bound, bound)
+
+
+def hyperprior_forward2train_autograd(m, x, noise_z=None, noise_y=None):
+    """layer.py:673-680 / 788-795: g_a -> h_a -> entropy_bottleneck -> h_s -> gaussian_conditional -> g_s; both entropy
+    modules are called as modules so that their forward hooks see (outputs, likelihoods) for the rate terms."""
+    y = analysis_autograd(m, x)
+    hin = torch.abs(y) if m._hyper_abs else y
+    z = hyper_sequence_autograd(m.h_a, _ToNhwcBf16.apply(hin, hin.shape[1]))
+    z_hat, z_lik = m.entropy_bottleneck(z, noise=noise_z)
+    params = hyper_sequence_autograd(m.h_s, _ToNhwcBf16.apply(z_hat, z_hat.shape[1]))
+    scales_hat, means_hat = m._params(params)
+    y_hat, y_lik = m.gaussian_conditional(y, scales_hat, means=means_hat, noise=noise_y)
+    m.last_likelihoods = (y_lik, z_lik)
+    return synthesis_autograd(m, y_hat)

@@ -91,6 +91,43 @@ __global__ __launch_bounds__(256) void gc_dequantize_kernel(const int32_t *__res
     }
 }
 
+// Backward of gc_forward_kernel in NOISE mode (the training mode: y_hat = y + noise, so d y_hat / d y = 1 and the means
+// enter only through v = |y_hat - mean|).  With u = (.5 - v)/s, l = (-.5 - v)/s, p = Phi(u) - Phi(l):
+//   dp/dv = (phi(l) - phi(u)) / s        dp/ds = (l phi(l) - u phi(u)) / s        phi = standard normal density
+// LowerBound gradients as upstream: through the likelihood bound where p >= bound or the gradient is negative, through
+// the scale bound where scales >= bound or the gradient is negative.
+__global__ __launch_bounds__(256) void gc_backward_kernel(const GcArgs a, const float *__restrict__ g_yhat,
+                                                          const float *__restrict__ g_lik, float *__restrict__ g_y,
+                                                          float *__restrict__ g_scales, float *__restrict__ g_means) {
+    const long long total = a.n_img * a.chw;
+    const float inv_sqrt_2pi = 0.39894228040143267794f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long n = i / a.chw, r = i - n * a.chw;
+        const float mean = a.means ? a.means[n * a.m_stride + r] : 0.f;
+        const float out = a.y[i] + (a.noise ? a.noise[i] : 0.f);
+        const float s_raw = a.scales[n * a.s_stride + r];
+        const float s = fmaxf(s_raw, a.scale_bound);
+        const float dlt = out - mean;
+        const float v = fabsf(dlt);
+        const float u = (0.5f - v) / s, l = (-0.5f - v) / s;
+        const float p = std_cumulative(u) - std_cumulative(l);
+        float gp = g_lik ? g_lik[i] : 0.f;
+        if (a.lik_bound > 0.f && !(p >= a.lik_bound || gp < 0.f)) gp = 0.f;
+        const float phi_u = inv_sqrt_2pi * expf(-0.5f * u * u), phi_l = inv_sqrt_2pi * expf(-0.5f * l * l);
+        const float dp_dv = (phi_l - phi_u) / s;
+        const float dp_ds = (l * phi_l - u * phi_u) / s;
+        const float sgn = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+        const float g_from_lik = gp * dp_dv * sgn;
+        if (g_y) g_y[i] = (g_yhat ? g_yhat[i] : 0.f) + g_from_lik;
+        if (g_means) g_means[i] = -g_from_lik;
+        if (g_scales) {
+            float gs = gp * dp_ds;
+            if (!(s_raw >= a.scale_bound || gs < 0.f)) gs = 0.f;
+            g_scales[i] = gs;
+        }
+    }
+}
+
 int grid_for(long long total) {
     long long g = (total + 255) / 256;
     if (g > 8192) g = 8192;
@@ -146,6 +183,23 @@ extern "C" int sc2_gc_dequantize(const int32_t *symbols, const float *means, int
     hipLaunchKernelGGL(gc_dequantize_kernel, dim3(grid_for(n_img * chw)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        symbols, means, (long long)n_img, chw, (long long)means_img_stride, C, HW, y_hat_f32_nchw,
                        static_cast<uint16_t *>(y_hat_bf16_nhwc));
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+extern "C" int sc2_gc_backward(const float *y, const float *scales, int64_t scales_img_stride, const float *means,
+                               int64_t means_img_stride, const float *noise, int64_t n_img, int64_t chw,
+                               float scale_bound, float lik_bound, const float *g_yhat, const float *g_lik, float *g_y,
+                               float *g_scales, float *g_means, void *stream) {
+    SC2_REQUIRE(y && scales && (g_y || g_scales || g_means), SC2_ERR_INVALID_ARG, "gc_backward: null argument");
+    SC2_REQUIRE(n_img > 0 && chw > 0 && scale_bound > 0.f, SC2_ERR_INVALID_ARG, "gc_backward: bad arguments");
+    SC2_REQUIRE(!g_means || means, SC2_ERR_INVALID_ARG, "gc_backward: a means gradient needs means");
+    GcArgs a;
+    a.y = y; a.scales = scales; a.means = means; a.noise = noise;
+    a.n_img = n_img; a.chw = chw; a.s_stride = scales_img_stride; a.m_stride = means_img_stride;
+    a.scale_bound = scale_bound; a.lik_bound = lik_bound; a.mode = SC2_EB_NOISE;
+    hipLaunchKernelGGL(gc_backward_kernel, dim3(grid_for(n_img * chw)), dim3(256), 0, static_cast<hipStream_t>(stream), a,
+                       g_yhat, g_lik, g_y, g_scales, g_means);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }

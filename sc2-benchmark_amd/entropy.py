@@ -740,6 +740,10 @@ class GaussianConditional(nn.Module):
         _require_device(inputs, 'GaussianConditional.forward')
         x = inputs.float().contiguous()
         bound = self.likelihood_bound if self.use_likelihood_bound else 0.0
+        if training and torch.is_grad_enabled() and (x.requires_grad or scales.requires_grad or
+                                                      (means is not None and means.requires_grad)):
+            from .autograd import gc_forward_autograd
+            return gc_forward_autograd(self, x, scales, means, noise)
         if training:
             if noise is None:
                 half = float(0.5)

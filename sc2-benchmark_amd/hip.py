@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
-    'sc2_gc_forward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
+    'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
 ]
@@ -76,6 +76,7 @@ def lib():
     L.sc2_eb_backward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
     L.sc2_eb_bits_partial_len.argtypes = [i32, i32, i32]
     L.sc2_gc_forward.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, i32, f32, f32, vp, vp, vp]
+    L.sc2_gc_backward.argtypes = [vp, vp, i64, vp, i64, vp, i64, i64, f32, f32, vp, vp, vp, vp, vp, vp]
     L.sc2_gc_symbols_indexes.argtypes = [vp, vp, i64, vp, i64, i64, i64, vp, i32, f32, vp, vp, vp]
     L.sc2_gc_dequantize.argtypes = [vp, vp, i64, i64, i32, i32, vp, vp, vp]
     L.sc2_eb_symbols.argtypes = [vp, vp, i32, i32, i32, vp, vp]
@@ -571,6 +572,27 @@ def gc_forward(y, scales, means=None, noise=None, mode=EB_DEQUANTIZE, scale_boun
     _check(lib().sc2_gc_forward(_ptr(y), _ptr(scales), s_stride, _ptr(means), m_stride, _ptr(noise), N, chw, int(mode),
                                 float(scale_bound), float(lik_bound), _ptr(y_hat), _ptr(lik), _stream()), 'gc_forward')
     return y_hat, lik
+
+
+def gc_backward(y, scales, means, noise, g_yhat, g_lik, scale_bound=0.11, lik_bound=1e-9):
+    """Backward of gc_forward in noise mode -> (g_y, g_scales, g_means or None), dense f32 like y."""
+    _dev(y, 'y')
+    assert y.dtype == torch.float32 and y.is_contiguous()
+    N, chw = y.shape[0], y[0].numel()
+    scales, s_stride = _img_slice(scales, y, 'scales')
+    m_stride = 0
+    if means is not None:
+        means, m_stride = _img_slice(means, y, 'means')
+    for t in (noise, g_yhat, g_lik):
+        if t is not None:
+            _dev(t, 'grad/noise')
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == y.shape
+    g_y, g_s = torch.empty_like(y), torch.empty_like(y)
+    g_m = torch.empty_like(y) if means is not None else None
+    _check(lib().sc2_gc_backward(_ptr(y), _ptr(scales), s_stride, _ptr(means), m_stride, _ptr(noise), N, chw,
+                                 float(scale_bound), float(lik_bound), _ptr(g_yhat), _ptr(g_lik), _ptr(g_y), _ptr(g_s),
+                                 _ptr(g_m), _stream()), 'gc_backward')
+    return g_y, g_s, g_m
 
 
 def gc_symbols_indexes(y, scales, means, scale_table, scale_bound=0.11, want_symbols=True, want_indexes=True):

@@ -434,10 +434,12 @@ class SHPBasedResNetBottleneck(BaseBottleneck):
         medians = self.entropy_bottleneck._extend_ndims(medians, spatial_dims)
         return medians.expand(x.size(0), *([-1] * (spatial_dims + 1)))
 
+    _needs_grad = FPBasedResNetBottleneck._needs_grad
+
     def _forward2train(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise hip.Sc2Error('{}: the training (autograd) path of the hyperprior bottlenecks is not built yet; '
-                               'run under torch.no_grad()'.format(type(self).__name__))
+        if self._needs_grad(x):
+            from .autograd import hyperprior_forward2train_autograd
+            return hyperprior_forward2train_autograd(self, x)
         y = self.analysis(x)
         z = self.hyper_analysis(y)
         z_hat, z_likelihoods = self.entropy_bottleneck(z)
@@ -453,13 +455,20 @@ class SHPBasedResNetBottleneck(BaseBottleneck):
                 encoded_obj = self.encode(x)
                 decoded_obj = self.decode(**encoded_obj)
                 return decoded_obj
-            y = self.analysis(x)
-            y_hat = self.gaussian_conditional.dequantize(
-                self.gaussian_conditional.quantize(y, 'dequantize', self._get_means(y))
-            )
+            with torch.no_grad():
+                y = self.analysis(x)
+                y_hat = self.gaussian_conditional.dequantize(
+                    self.gaussian_conditional.quantize(y, 'dequantize', self._get_means(y))
+                )
             y_hat = y_hat.detach()
-            return self.synthesis(y_hat)
+            return self._synthesis_maybe_grad(x, y_hat)
         return self._forward2train(x)
+
+    def _synthesis_maybe_grad(self, x, y_hat):
+        if self._needs_grad(x):
+            from .autograd import synthesis_autograd
+            return synthesis_autograd(self, y_hat)
+        return self.synthesis(y_hat)
 
     def update(self, scale_table=None, force=False):
         if scale_table is None:
@@ -512,17 +521,18 @@ class MSHPBasedResNetBottleneck(SHPBasedResNetBottleneck):
                 encoded_obj = self.encode(x)
                 decoded_obj = self.decode(**encoded_obj)
                 return decoded_obj
-            y = self.analysis(x)
-            z = self.hyper_analysis(y)
-            z_hat = self.entropy_bottleneck.dequantize(
-                self.entropy_bottleneck.quantize(z, 'dequantize', self._get_means(z))
-            )
-            scales_hat, means_hat = self._params(self.hyper_synthesis(self._z_hat_nhwc(z_hat)))
-            y_hat = self.gaussian_conditional.dequantize(
-                self.gaussian_conditional.quantize(y, 'dequantize', means_hat)
-            )
+            with torch.no_grad():
+                y = self.analysis(x)
+                z = self.hyper_analysis(y)
+                z_hat = self.entropy_bottleneck.dequantize(
+                    self.entropy_bottleneck.quantize(z, 'dequantize', self._get_means(z))
+                )
+                scales_hat, means_hat = self._params(self.hyper_synthesis(self._z_hat_nhwc(z_hat)))
+                y_hat = self.gaussian_conditional.dequantize(
+                    self.gaussian_conditional.quantize(y, 'dequantize', means_hat)
+                )
             y_hat = y_hat.detach()
-            return self.synthesis(y_hat)
+            return self._synthesis_maybe_grad(x, y_hat)
         return self._forward2train(x)
 
 
