@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 16
+#define SC2_ABI_VERSION 17
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -142,6 +142,16 @@ int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, 
 int sc2_conv2x2_gdn512_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const void *gamma_frag, const float *beta,
                            void *y, int N, int H, int W, int Cin, int inverse, void *stream);
+
+/* Streaming 1x1 convolution with a short K and a wide N: y = act(x W^T + bias [+ residual]) in one persistent launch
+ * (the HBM-bound 1x1 layers of the ResNet-50 tail behind the bottleneck, backbone.py:235-254: third conv of a
+ * Bottleneck block with its residual add + ReLU, stride-2 downsample).
+ *   x : bf16 NHWC [N,H,W,Cin], Cin in {128, 256};  w_frag : bf16 MFMA-fragment blocks [Cout/16][Cin/32][64][8], entry
+ *   (jt, ks, lane = fq*16 + frow, e) = W[jt*16 + frow][ks*32 + fq*8 + e];  bias : f32 [Cout];  residual : bf16 NHWC
+ *   [N,OH,OW,Cout] or NULL;  y : bf16 NHWC [N,OH,OW,Cout], OH = (H-1)/stride + 1;  Cout % 256 == 0; stride 1 or 2. */
+int sc2_conv1x1_stream_supported(int Cin, int Cout, int stride);
+int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y, int N,
+                           int H, int W, int Cin, int Cout, int stride, int relu, void *stream);
 
 /* Weight gradient of sc2_conv2d_fwd: dw[co][(kh*KW+kw)*Cin+ci] = sum over output pixels of gy * im2col(x).
  * Replaces the weight half of nn.Conv2d's backward (reached through loss.backward(), image_classification.py:79).

@@ -27,23 +27,32 @@ def _fold(conv, bn):
         raise TypeError('cannot fold {}'.format(type(bn)))
     w = w * scale.reshape(-1, 1, 1, 1)
     order = hip.preferred_k_order(w.shape[1], w.shape[2], w.shape[3])
-    return hip.pack_conv_weight(w, order), bias.contiguous(), order
+    return hip.pack_conv_weight(w, order), bias.contiguous(), order, w
 
 
 class _Conv(object):
     def __init__(self, conv, bn, tag):
         assert conv.bias is None and conv.groups == 1
-        self.w, self.b, self.k_order = _fold(conv, bn)
+        self.w, self.b, self.k_order, w_folded = _fold(conv, bn)
         self.cout = conv.out_channels
         self.k = conv.kernel_size
         self.stride = conv.stride
         self.pad = conv.padding
         self.dilation = conv.dilation
         self.tag = tag
+        # HBM-bound 1x1 layers with a short K and a wide N run on the persistent streaming kernel
+        self.stream = hip.conv1x1_stream_supported(conv.in_channels, conv.out_channels, self.k[0], self.k[1],
+                                                   self.stride, self.pad) and conv.dilation == (1, 1)
+        if self.stream:
+            self.w_frag = hip.pack_weight_fragments(w_folded.reshape(w_folded.shape[0], w_folded.shape[1]))
         if self.dilation != (1, 1):
             raise hip.Sc2Error('dilated convolutions are not supported by the HIP head (got {})'.format(self.dilation))
 
     def __call__(self, x, epilogue, ep_x=None):
+        if self.stream and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU, hip.EPI_BIAS_ADD_RELU):
+            return hip.conv1x1_stream_fwd(x, self.w_frag, self.b, stride=self.stride[0],
+                                          residual=ep_x if epilogue == hip.EPI_BIAS_ADD_RELU else None,
+                                          relu=epilogue != hip.EPI_BIAS, tag=self.tag)
         return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,
                               ep_x=ep_x, ep_beta=self.b, tag=self.tag, k_order=self.k_order)
 

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
-    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -69,6 +69,8 @@ def lib():
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     L.sc2_conv2x2_gdn512_supported.argtypes = [i32] * 6
     L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
+    L.sc2_conv1x1_stream_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
     L.sc2_gdn_bwd_pre.argtypes = [vp, vp, vp, ctypes.c_longlong, i32, i32, vp, vp, vp, vp]
     L.sc2_gdn_bwd_post.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
@@ -440,6 +442,45 @@ def conv2x2_gdn512_supported(cin, cout, kh, kw, stride, pad):
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
     return sh == sw and ph == pw and bool(lib().sc2_conv2x2_gdn512_supported(cin, cout, kh, kw, sh, ph))
+
+
+def pack_weight_fragments(w2d):
+    """[N, K] matrix (row = output channel) -> bf16 MFMA-fragment blocks [N/16][K/32][64][8]: entry (jt, ks, lane =
+    fq*16 + frow, e) = w2d[jt*16 + frow, ks*32 + fq*8 + e], one operand fragment = 1 KB contiguous."""
+    _dev(w2d, 'w2d')
+    n, k = w2d.shape
+    assert n % 16 == 0 and k % 32 == 0
+    g = w2d.detach().to(torch.bfloat16).reshape(n // 16, 16, k // 32, 4, 8)      # jt, frow, ks, fq, e
+    return g.permute(0, 2, 3, 1, 4).contiguous().reshape(n // 16, k // 32, 64, 8)
+
+
+def conv1x1_stream_supported(cin, cout, kh, kw, stride, pad):
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    if os.environ.get('SC2_CONV_STREAM', '1') == '0':      # A/B switch (tools/)
+        return False
+    return kh == 1 and kw == 1 and sh == sw and ph == 0 and pw == 0 and \
+        bool(lib().sc2_conv1x1_stream_supported(cin, cout, sh))
+
+
+def conv1x1_stream_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False, tag=None):
+    """y = act(conv1x1(x) + bias [+ residual]) on the persistent streaming kernel; bf16 NHWC in / out."""
+    for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, Cin = x_nhwc.shape
+    cout = w_frag.shape[0] * 16
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (cout // 16, Cin // 32, 64, 8)
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    out = torch.empty((N, OH, OW, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    if residual is not None:
+        _dev(residual, 'residual')
+        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and tuple(residual.shape) == tuple(out.shape)
+    with _timed(tag or 'conv1x1_stream'):
+        _check(lib().sc2_conv1x1_stream_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(out), N, H, W,
+                                            Cin, cout, int(stride), 1 if relu else 0, _stream()), 'conv1x1_stream_fwd')
+    return out
 
 
 def pack_gamma_fragments(gamma):

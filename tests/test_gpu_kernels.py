@@ -356,6 +356,36 @@ def test_conv5s2_patch_kernel(S, R, dev, N, H, W, fused):
                          out_format=S.hip.OUT_F32_NCHW)
 
 
+@pytest.mark.parametrize('cin,cout,stride,N,H,W,res,relu', [(128, 512, 1, 3, 9, 11, True, True), (256, 1024, 1, 2, 14, 14, True, True),
+                                                           (256, 512, 2, 2, 13, 10, False, False), (128, 256, 1, 40, 20, 20, False, True)])
+def test_conv1x1_stream(S, dev, cin, cout, stride, N, H, W, res, relu):
+    """Persistent streaming 1x1 conv (+ bias, residual, ReLU) against the f32 op on the bf16-rounded operands and
+    against the generic tile kernel; several units per workgroup, ragged last pixel tile, stride-2 gather."""
+    g = torch.Generator().manual_seed(cin + cout + N)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(bf16_round(x), bf16_round(w), stride=stride) + bias.view(1, -1, 1, 1)
+    r = bf16_round(torch.randn(ref.shape, generator=g)) if res else None
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    assert S.hip.conv1x1_stream_supported(cin, cout, 1, 1, stride, 0)
+    assert not S.hip.conv1x1_stream_supported(64, cout, 1, 1, stride, 0)
+    assert not S.hip.conv1x1_stream_supported(cin, cout, 3, 3, stride, 1)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    r_nhwc = S.hip.nchw_f32_to_nhwc_bf16(r.to(dev)) if res else None
+    out = S.hip.conv1x1_stream_fwd(x_nhwc, S.hip.pack_weight_fragments(w.reshape(cout, cin).to(dev)), bias.to(dev),
+                                   stride=stride, residual=r_nhwc, relu=relu)
+    assert out.shape == (N, ref.shape[2], ref.shape[3], cout)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'streaming 1x1 conv')
+    epi = S.hip.EPI_BIAS_ADD_RELU if (res and relu) else S.hip.EPI_BIAS_RELU if relu else S.hip.EPI_BIAS
+    gen = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 1, 1, stride, 0, epilogue=epi, ep_x=r_nhwc,
+                           ep_beta=bias.to(dev))
+    assert_close_bf16(out, gen, 'streaming vs tile kernel', extra=2.0 ** -8)
+
+
 def _golden():
     return torch.load(os.path.join(HERE, 'golden', 'fp_golden.pt'), weights_only=False)
 
