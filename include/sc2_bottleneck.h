@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 17
+#define SC2_ABI_VERSION 18
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -142,6 +142,16 @@ int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, 
 int sc2_conv2x2_gdn512_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const void *gamma_frag, const float *beta,
                            void *y, int N, int H, int W, int Cin, int inverse, void *stream);
+
+/* First encoder stage in ONE persistent launch: y = GDN1_96(Conv2d(3 -> 96, k5, s2, p2, bias=False)(x)) on the
+ * pixel-pair view of the image (replaces encoder[0] + encoder[1], sc2bench/models/layer.py:476-478).
+ *   x_pairs : bf16 [N, H, W/2, 8] (two pixels x four channels, channel 3 zero: sc2_nchw_f32_to_nhwc_bf16 with c_pad 4)
+ *   w_frag  : bf16 MFMA-fragment blocks [6][4][64][8] of the pair-packed weights W'[96][128], k = (kh*3 + t)*8 + dw*4 + c
+ *   gamma_frag : bf16 fragment blocks [6][3][64][8] of the effective gamma;  beta : f32 [96]
+ *   y : bf16 NHWC [N, OH, W/2, 96], OH = (H - 1)/2 + 1.   W/2 must be 112 (224-pixel-wide images). */
+int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs);
+int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N,
+                        int H, int W_pairs, int inverse, void *stream);
 
 /* Streaming 1x1 convolution with a short K and a wide N: y = act(x W^T + bias [+ residual]) in one persistent launch
  * (the HBM-bound 1x1 layers of the ResNet-50 tail behind the bottleneck, backbone.py:235-254: third conv of a

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libsc2amd.so')
-SOURCES = ['abi.cpp', 'cdf_host.cpp', 'layout.hip', 'conv_igemm.hip', 'conv_gdn512.hip', 'conv1x1_stream.hip', 'conv_wgrad.hip', 'gdn_bwd.hip', 'entropy.hip', 'gaussian.hip', 'rans.hip']
+SOURCES = ['abi.cpp', 'cdf_host.cpp', 'layout.hip', 'conv_igemm.hip', 'conv_gdn512.hip', 'conv0_gdn96.hip', 'conv1x1_stream.hip', 'conv_wgrad.hip', 'gdn_bwd.hip', 'entropy.hip', 'gaussian.hip', 'rans.hip']
 HEADERS = [os.path.join(CSRC, 'sc2_common.h'), os.path.join(HERE, '..', 'include', 'sc2_bottleneck.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',

@@ -1,0 +1,297 @@
+// First encoder stage of the FP / SHP / MSHP bottlenecks in ONE persistent launch (gfx950):
+//     y = GDN1_96( Conv2d(3 -> 96, k5, s2, p2, bias=False)(x) )               (sc2bench/models/layer.py:476-478)
+// on the pixel-pair view of the image (bf16 [N, H, W/2, 8]: 2 pixels x 4 channels per 16 bytes; the 5-tap stride-2
+// row filter is a 3-tap stride-1 filter over pairs, K = 5 x 3 x 8 = 120).
+//
+// The launch is a stream: 0.4 MB in, 2.4 MB out per image against 0.4 GFLOP.  On the generic tile kernel a workgroup
+// does four k-slabs, the fused GDN and a 24 KB store, then waits for the acks: 2.5 TB/s.  Here 256-thread workgroups
+// (two per CU, so one's epilogue overlaps the other's MFMAs) loop over UNITS of two output rows of one image
+// (2 x 112 pixels x 96 channels = 43 KB out):
+//   input   the 7 image rows a unit needs (12.5 KB) are staged in LDS, prefetched one unit ahead into registers
+//           before the current unit's output stores are issued (vmcnt retires in issue order);
+//   conv    A fragments straight from the staged rows (consecutive pixels = consecutive 16-byte pairs), W0 fragments
+//           FRAGMENT-MAJOR from L2 into registers; wave (wm, wn) owns output row wm x channels [48 wn, 48 wn + 48);
+//   GDN1    |t| (bf16) goes to an LDS image [224 px][96 ch] (rows padded to 208 B: conflict-free fragment reads),
+//           norm = beta + gamma |t| is a second GEMM with gamma fragment-major from L2, y = t / norm on the f32
+//           accumulators, written to the image and streamed out as one contiguous 43 KB block.
+// Units are claimed with one atomic each, one unit ahead.  Geometry: OW = 112 (224-pixel-wide input) only; other sizes
+// use the generic kernel.
+#include <stdlib.h>
+
+#include <atomic>
+
+#include "sc2_common.h"
+
+namespace {
+
+struct EncArgs {
+    const uint16_t *__restrict__ x;      // bf16 [N, H, WP, 8] pixel pairs
+    const uint16_t *__restrict__ w;      // bf16 fragment-major [6][4][64][8]  (rows = 96 channels, K = 120 -> 128)
+    const uint16_t *__restrict__ g;      // bf16 fragment-major gamma [6][3][64][8]
+    const float *__restrict__ beta;      // f32 [96]
+    uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, OW, 96]
+    int H, WP, OH, n_units, units_per_img;
+    unsigned *unit_ctr;
+};
+
+constexpr int OW = 112, CH = 96, MT = OW / 16, NT = 3, KS1 = 4, KS2 = 3;
+constexpr int IN_ROWS = 7, IN_PITCH = (OW + 2) * 16;               // staged input rows: pair columns -1 .. OW
+constexpr int IN_BYTES = IN_ROWS * IN_PITCH;                        // 12 768
+constexpr int IMG_PITCH = 208, IMG_BYTES = 2 * OW * IMG_PITCH;      // 46 592
+constexpr int GAM_BYTES = 6 * KS2 * 64 * 16;                        // 18 432
+constexpr int Y_Q = (2 * OW * (CH / 8) + 255) / 256;                     // output 16-byte chunks per thread (11)
+constexpr int IN_Q = (IN_ROWS * (OW + 2) + 255) / 256;              // staged 16-byte chunks per thread (4)
+
+template <bool INVERSE>
+__global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *rows = smem;
+    unsigned char *img = smem + IN_BYTES;
+    unsigned char *gam = smem + IN_BYTES + IMG_BYTES;   // gamma fragments [6][3][64] x 16 B, loaded once
+    float *beta_s = reinterpret_cast<float *>(smem + IN_BYTES + IMG_BYTES + GAM_BYTES);   // [96]
+    __shared__ int next_slot;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;       // output row of the unit, channel half
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // Global loads of the tail are written branch-free (clamped address + select) so that the compiler counts vmcnt
+    // exactly: its wait for the rows is then vmcnt(<stores issued after them>) and never waits for a store.
+    uint4 in_next[IN_Q];
+    bool in_ok[IN_Q];
+    auto load_rows = [&](int unit, int tid) {   // the 7 input rows of `unit`, zero outside the image
+        const bool live = unit < p.n_units;
+        const int im = live ? unit / p.units_per_img : 0;
+        const int oh0 = live ? (unit - im * p.units_per_img) * 2 : 0;
+#pragma unroll
+        for (int k = 0; k < IN_Q; ++k) {
+            const int q = tid + 256 * k;
+            const int r = q / (OW + 2), c = q - r * (OW + 2);
+            const int ih = 2 * oh0 - 2 + r, pc = c - 1;
+            in_ok[k] = live & (q < IN_ROWS * (OW + 2)) & ((unsigned)ih < (unsigned)p.H) & ((unsigned)pc < (unsigned)p.WP);
+            const long long off = in_ok[k] ? (((long long)im * p.H + ih) * p.WP + pc) * 8 : 0;
+            in_next[k] = *reinterpret_cast<const uint4 *>(p.x + off);
+        }
+    };
+    auto store_rows = [&](int tid) {
+#pragma unroll
+        for (int k = 0; k < IN_Q; ++k) {
+            const int q = tid + 256 * k;
+            const bool inside = q < IN_ROWS * (OW + 2);       // k == IN_Q - 1: the others rewrite their previous chunk
+            const int kk = k > 0 ? k - 1 : 0;
+            const uint4 v = inside ? in_next[k] : in_next[kk];
+            const bool ok = inside ? in_ok[k] : in_ok[kk];
+            *reinterpret_cast<uint4 *>(rows + (inside ? q : q - 256) * 16) = ok ? v : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    const uint4 *wfrag = reinterpret_cast<const uint4 *>(p.w) + (long long)(wn * NT) * KS1 * 64;   // [(j*KS1 + ks)*64 + lane]
+
+    // W0 fragments stay in registers for the life of the workgroup (48 VGPRs), gamma's and beta in LDS: no load is
+    // issued behind the output stores
+    uint4 wv[KS1][NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) wv[ks][j] = wfrag[(j * KS1 + ks) * 64 + lane];
+    if (tid < CH) beta_s[tid] = p.beta[tid];
+    for (int q = tid; q < GAM_BYTES / 16; q += 256)
+        reinterpret_cast<uint4 *>(gam)[q] = reinterpret_cast<const uint4 *>(p.g)[q];
+    const unsigned char *gfrag = gam + (wn * NT) * KS2 * 1024 + lane * 16;   // + (j*KS2 + ks) * 1024
+
+    int unit = blockIdx.x;
+    int next_unit = unit + gridDim.x;
+    load_rows(unit, tid);
+    store_rows(tid);
+    __syncthreads();
+
+    while (unit < p.n_units) {
+        const int im = unit / p.units_per_img;
+        const int oh0 = (unit - im * p.units_per_img) * 2;
+        const int n_rows = p.OH - oh0 >= 2 ? 2 : 1;
+
+        // ---------------------------------------------------------------- conv: t = W0 * patch
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            const int c = ks * 4 + fq;                 // 16-byte k chunk = (kh, pair tap t); chunk 15 is K padding
+            const int kh = c / 3, t = c - kh * 3;
+            const bool pad = c >= 15;
+            const int a_lane = ((2 * wm + (pad ? 0 : kh)) * (OW + 2) + (pad ? 0 : t) + frow) * 16;   // + i * 256
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                uint4 v = *reinterpret_cast<const uint4 *>(rows + a_lane + i * 256);
+                if (pad) v = make_uint4(0u, 0u, 0u, 0u);
+                const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[ks][j]), af,
+                                                                        acc[i][j], 0, 0, 0);
+            }
+        }
+        // |t| (bf16) of this lane's 4 channels of each accumulator tile -> image
+        const int px_lane = wm * OW + frow;            // + i * 16
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = wn * 48 + j * 16 + fq * 4;
+                uint2 h;
+                h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]) & 0x7FFF7FFFu;
+                h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]) & 0x7FFF7FFFu;
+                *reinterpret_cast<uint2 *>(img + (px_lane + i * 16) * IMG_PITCH + col * 2) = h;
+            }
+        __syncthreads();   // staged rows consumed; |t| image complete (a pixel's 96 channels come from two waves)
+
+        // ---------------------------------------------------------------- GDN1: norm = beta + gamma |t|
+        // two passes over the pixel tiles (4 + 3): half the norm accumulators live at a time, and a pass's results may
+        // overwrite its |t| rows as soon as both channel-half waves of the row have read them
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            constexpr int MH = 4;
+            const int i0 = half * MH;
+            f32x4_t nrm[MH][NT];
+#pragma unroll
+            for (int i = 0; i < MH; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) nrm[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                uint4 gv[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) gv[j] = *reinterpret_cast<const uint4 *>(gfrag + (j * KS2 + ks) * 1024);
+#pragma unroll
+                for (int i = 0; i < MH; ++i) {
+                    if (i0 + i >= MT) continue;
+                    const bf16x8_t xf = __builtin_bit_cast(
+                        bf16x8_t,
+                        *reinterpret_cast<const uint4 *>(img + (px_lane + (i0 + i) * 16) * IMG_PITCH + (ks * 4 + fq) * 16));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        nrm[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, gv[j]), xf,
+                                                                            nrm[i][j], 0, 0, 0);
+                }
+            }
+            __syncthreads();   // every wave has read this pass's |t| fragments: those rows may now take the results
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int col = wn * 48 + j * 16 + fq * 4;
+                const float4 b4 = *reinterpret_cast<const float4 *>(beta_s + col);
+                const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int i = 0; i < MH; ++i) {
+                    if (i0 + i >= MT) continue;
+                    float r[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float norm = b[e] + nrm[i][j][e];
+                        r[e] = INVERSE ? acc[i0 + i][j][e] * norm : acc[i0 + i][j][e] * __builtin_amdgcn_rcpf(norm);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(r[0], r[1]);
+                    o.y = pack_bf16x2(r[2], r[3]);
+                    *reinterpret_cast<uint2 *>(img + (px_lane + (i0 + i) * 16) * IMG_PITCH + col * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------------------------------------------------------- next unit's rows, then stream this unit out
+        // (the claim and the row loads are issued BEFORE the output stores: vmcnt retires in issue order, so waiting
+        //  for them does not wait for the store acknowledgements)
+        int tq = tid;   // opaque: the per-thread offsets below are recomputed, not kept (spilled) across the unit
+        asm volatile("" : "+v"(tq));
+        unsigned claimed = 0;
+        if (tid == 0) {   // raw instruction: the compiler's atomicAdd waits for the result (vmcnt(0)) on the spot
+            const unsigned one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
+        }
+        load_rows(next_unit, tq);
+        {
+            uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * CH);   // contiguous 2 rows
+            const int n_chunks = n_rows * OW * (CH / 8);
+#pragma unroll
+            for (int k = 0; k < Y_Q; ++k) {
+                const int q0 = tq + 256 * k;
+                const int q = q0 < n_chunks ? q0 : tq;      // past the end: store the thread's first chunk again
+                const int px = q / (CH / 8), c = q - px * (CH / 8);
+                yo[q] = *reinterpret_cast<const uint4 *>(img + px * IMG_PITCH + c * 16);
+            }
+        }
+        store_rows(tq);    // the staged rows were last read before the first barrier of this unit
+        if (tid == 0) {    // the claim is older than the row loads store_rows() has just waited for
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(claimed) : "n"(Y_Q) : "memory");
+            next_slot = (int)claimed;
+        }
+        __syncthreads();   // next rows visible; image free
+        unit = next_unit;
+        next_unit = __builtin_amdgcn_readfirstlane(next_slot);
+    }
+}
+
+int g_cus0 = 0;
+constexpr int kMaxDev0 = 16, kRing0 = 256;
+unsigned *g_ring0[kMaxDev0] = {};
+std::atomic<unsigned> g_seq0{0};
+
+}  // namespace
+
+extern "C" int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs) {
+    return Cin_pairs == 8 && Cout == 96 && W_pairs == OW ? 1 : 0;
+}
+
+extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta,
+                                   void *y, int N, int H, int W_pairs, int inverse, void *stream) {
+    SC2_REQUIRE(x_pairs && w_frag && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "conv0_gdn96: null argument");
+    SC2_REQUIRE(N > 0 && H > 0, SC2_ERR_INVALID_ARG, "conv0_gdn96: non-positive dimension");
+    SC2_REQUIRE(sc2_conv0_gdn96_supported(8, 96, W_pairs), SC2_ERR_UNSUPPORTED,
+                "conv0_gdn96: needs %d pixel pairs per row (a 224-pixel-wide image), got %d", OW, W_pairs);
+    EncArgs a;
+    a.x = static_cast<const uint16_t *>(x_pairs);
+    a.w = static_cast<const uint16_t *>(w_frag);
+    a.g = static_cast<const uint16_t *>(gamma_frag);
+    a.beta = beta;
+    a.y = static_cast<uint16_t *>(y);
+    a.H = H; a.WP = W_pairs;
+    a.OH = (H + 4 - 5) / 2 + 1;
+    a.units_per_img = (a.OH + 1) / 2;
+    const long long units = (long long)N * a.units_per_img;
+    SC2_REQUIRE(units < 0x7FFFFFFFLL - 1024, SC2_ERR_UNSUPPORTED, "conv0_gdn96: too many units");
+    a.n_units = (int)units;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    constexpr int lds = IN_BYTES + IMG_BYTES + GAM_BYTES + CH * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    SC2_REQUIRE(dev >= 0 && dev < kMaxDev0, SC2_ERR_UNSUPPORTED, "conv0_gdn96: device ordinal %d out of range", dev);
+    if (g_cus0 == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cus0 = n;
+    }
+    if (!g_ring0[dev]) {
+        void *ptr = nullptr;
+        SC2_REQUIRE(hipMalloc(&ptr, kRing0 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
+                    "conv0_gdn96: cannot allocate the unit counters");
+        g_ring0[dev] = static_cast<unsigned *>(ptr);
+    }
+    const int grid = a.n_units < 2 * g_cus0 ? a.n_units : 2 * g_cus0;   // two workgroups per CU
+    a.unit_ctr = g_ring0[dev] + (g_seq0.fetch_add(1) % kRing0);
+    SC2_REQUIRE(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.unit_ctr), 2 * grid, 1, s) == hipSuccess, SC2_ERR_LAUNCH,
+                "conv0_gdn96: cannot preset the unit counter");
+    if (inverse) hipLaunchKernelGGL(conv0_gdn96_kernel<true>, dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(conv0_gdn96_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}

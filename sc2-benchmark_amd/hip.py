@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
-    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -69,6 +70,8 @@ def lib():
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     L.sc2_conv2x2_gdn512_supported.argtypes = [i32] * 6
     L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv0_gdn96_supported.argtypes = [i32, i32, i32]
+    L.sc2_conv0_gdn96_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_stream_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
@@ -442,6 +445,30 @@ def conv2x2_gdn512_supported(cin, cout, kh, kw, stride, pad):
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
     return sh == sw and ph == pw and bool(lib().sc2_conv2x2_gdn512_supported(cin, cout, kh, kw, sh, ph))
+
+
+def conv0_gdn96_supported(x_pairs_shape, cout):
+    """True if the pixel-pair first conv + GDN1(96) runs as the single persistent launch (224-pixel-wide images)."""
+    if os.environ.get('SC2_CONV0_FUSED', '1') == '0':      # A/B switch (tools/)
+        return False
+    return len(x_pairs_shape) == 4 and bool(lib().sc2_conv0_gdn96_supported(x_pairs_shape[3], cout, x_pairs_shape[2]))
+
+
+def conv0_gdn96_fwd(x_pairs, w_frag, gamma_frag, beta, inverse=False, tag=None):
+    """x_pairs bf16 [N,H,W/2,8] -> bf16 NHWC [N,(H-1)//2+1,W/2,96]; w_frag / gamma_frag: pack_weight_fragments of the
+    pair-packed weights [96,128] and of the effective gamma [96,96]."""
+    for t, name in ((x_pairs, 'x_pairs'), (w_frag, 'w_frag'), (gamma_frag, 'gamma_frag'), (beta, 'beta')):
+        _dev(t, name)
+    assert x_pairs.dtype == torch.bfloat16 and x_pairs.dim() == 4 and x_pairs.is_contiguous() and x_pairs.shape[3] == 8
+    N, H, WP, _ = x_pairs.shape
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (6, 4, 64, 8)
+    assert gamma_frag.dtype == torch.bfloat16 and gamma_frag.is_contiguous() and tuple(gamma_frag.shape) == (6, 3, 64, 8)
+    assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 96
+    out = torch.empty((N, (H - 1) // 2 + 1, WP, 96), dtype=torch.bfloat16, device=x_pairs.device)
+    with _timed(tag or 'conv0_gdn96'):
+        _check(lib().sc2_conv0_gdn96_fwd(_ptr(x_pairs), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, WP,
+                                         1 if inverse else 0, _stream()), 'conv0_gdn96_fwd')
+    return out
 
 
 def pack_weight_fragments(w2d):

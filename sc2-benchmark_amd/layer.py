@@ -140,6 +140,13 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             self._conv0_key = key
         return self._conv0_pack
 
+    def _conv0_fragments(self):
+        packed = self._conv0_packed()
+        if getattr(self, '_conv0_frag_src', None) is not packed:
+            self._conv0_frag = hip.pack_weight_fragments(packed[:self._g_a()[0].out_channels])
+            self._conv0_frag_src = packed
+        return self._conv0_frag
+
     def _uses_pair_conv0(self, x):
         c0 = self._g_a()[0]
         return (c0.in_channels <= 4 and c0.kernel_size == (5, 5) and c0.stride == (2, 2) and c0.padding == (2, 2)
@@ -156,7 +163,11 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             N, _, H, W = x.shape
             x4 = hip.nchw_f32_to_nhwc_bf16(x, 4)                      # [N,H,W,4]
             xp = x4.view(N, H, W // 2, 8)                             # pixel pairs
-            if fuse0:
+            if fuse0 and g1.in_channels == 96 and hip.conv0_gdn96_supported(tuple(xp.shape), c0.out_channels):
+                beta, gamma_f = g1.effective_fragments()   # conv + GDN1(96) as one persistent streaming launch
+                h = hip.conv0_gdn96_fwd(xp, self._conv0_fragments(), gamma_f, beta, g1.inverse,
+                                        tag=c0._tag + '+' + g1._tag)
+            elif fuse0:
                 beta, gamma = g1.effective()
                 h = hip.conv2d_fwd(xp, self._conv0_packed(), c0.out_channels, 5, 3, (2, 1), (2, 1),
                                    epilogue=hip.EPI_FUSED_IGDN if g1.inverse else hip.EPI_FUSED_GDN, ep_x=gamma,
@@ -372,6 +383,7 @@ class SHPBasedResNetBottleneck(BaseBottleneck):
     _g_s = lambda self: self.g_s        # noqa: E731
     _init_transforms = FPBasedResNetBottleneck._init_transforms
     _conv0_packed = FPBasedResNetBottleneck._conv0_packed
+    _conv0_fragments = FPBasedResNetBottleneck._conv0_fragments
     _uses_pair_conv0 = FPBasedResNetBottleneck._uses_pair_conv0
     analysis = FPBasedResNetBottleneck.analysis
     synthesis_nhwc = FPBasedResNetBottleneck.synthesis_nhwc

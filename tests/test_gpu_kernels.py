@@ -386,6 +386,41 @@ def test_conv1x1_stream(S, dev, cin, cout, stride, N, H, W, res, relu):
     assert_close_bf16(out, gen, 'streaming vs tile kernel', extra=2.0 ** -8)
 
 
+@pytest.mark.parametrize('N,H,inverse', [(3, 224, False), (2, 30, False), (5, 11, True)])
+def test_conv0_gdn96_fused(S, R, dev, N, H, inverse):
+    """First encoder conv on pixel pairs + GDN1(96) as one persistent launch vs the f32 ops on the bf16-rounded
+    operands and vs the tile kernel's fused path; image borders, odd output height, several units per workgroup."""
+    W = 224
+    torch.manual_seed(H)
+    x = torch.rand(N, 3, H, W) * 2 - 1
+    w = torch.randn(96, 3, 5, 5) / 75 ** 0.5
+    gdn = R.GDN1(96, inverse=inverse)
+    with torch.no_grad():
+        gdn.gamma.add_(0.05 * torch.rand(96, 96) / 96 ** 0.5)
+        gdn.beta.add_(0.1 * torch.rand(96))
+        conv = F.conv2d(bf16_round(x), bf16_round(w), stride=2, padding=2)
+        beta = gdn.beta_reparam(gdn.beta)
+        gamma = bf16_round(gdn.gamma_reparam(gdn.gamma))
+        norm = F.conv2d(bf16_round(conv).abs(), gamma.reshape(96, 96, 1, 1), beta)
+        ref = conv * norm if inverse else conv / norm
+    m = S.GDN1(96, inverse=inverse)
+    m.load_state_dict(gdn.state_dict())
+    m.to(dev)
+    beta_d, gamma_f = m.effective_fragments()
+    x4 = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev), 4)
+    xp = x4.view(N, H, W // 2, 8)
+    assert S.hip.conv0_gdn96_supported(tuple(xp.shape), 96)
+    assert not S.hip.conv0_gdn96_supported((N, H, 100, 8), 96)
+    packed = S.hip.pack_conv0_weight_pairs(w.to(dev))
+    out = S.hip.conv0_gdn96_fwd(xp, S.hip.pack_weight_fragments(packed[:96]), gamma_f, beta_d, inverse)
+    assert out.shape == (N, ref.shape[2], ref.shape[3], 96)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'fused conv0 + gdn96', extra=2.0 ** -8)
+    _, gamma_d = m.effective()
+    tile = S.hip.conv2d_fwd(xp, packed, 96, 5, 3, (2, 1), (2, 1), epilogue=S.hip.EPI_FUSED_IGDN if inverse else
+                            S.hip.EPI_FUSED_GDN, ep_x=gamma_d, ep_beta=beta_d)
+    assert_close_bf16(out, tile, 'persistent vs tile kernel', extra=2.0 ** -7)
+
+
 def _golden():
     return torch.load(os.path.join(HERE, 'golden', 'fp_golden.pt'), weights_only=False)
 

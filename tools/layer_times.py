@@ -47,6 +47,15 @@ def main():
         w0 = m._conv0_packed()
         a0 = hip.conv2d_fwd(xp, w0, 96, 5, 3, (2, 1), (2, 1))
         rows.append(('enc.conv0', timeit(lambda: hip.conv2d_fwd(xp, w0, 96, 5, 3, (2, 1), (2, 1)), args.iters), 180.6e6 * N, x4.numel() * 2 + a0.numel() * 2))
+        if hip.conv0_gdn96_supported(tuple(xp.shape), 96):
+            beta_g1, gamma_g1 = g1.effective_fragments()
+            wf0 = m._conv0_fragments()
+            rows.append(('enc.conv0+gdn96 (stream)', timeit(lambda: hip.conv0_gdn96_fwd(xp, wf0, gamma_g1, beta_g1), args.iters),
+                         (180.6e6 + 231.2e6) * N, x4.numel() * 2 + a0.numel() * 2))
+        _, gamma_g1r = g1.effective()
+        rows.append(('enc.conv0+gdn96 (tile)', timeit(lambda: hip.conv2d_fwd(xp, w0, 96, 5, 3, (2, 1), (2, 1), epilogue=hip.EPI_FUSED_GDN,
+                                                                                ep_x=gamma_g1r, ep_beta=g1.effective()[0]), args.iters),
+                     (180.6e6 + 231.2e6) * N, x4.numel() * 2 + a0.numel() * 2))
         a1 = g1.forward_nhwc(a0)
         rows.append(('enc.gdn96', timeit(lambda: g1.forward_nhwc(a0), args.iters), 231.2e6 * N, a0.numel() * 4 + a1.numel() * 2))
         a2 = e2.forward_nhwc(a1)
