@@ -42,6 +42,12 @@ constexpr int GAM_BYTES = 6 * KS2 * 64 * 16;                        // 18 432
 constexpr int Y_Q = (2 * OW * (CH / 8) + 255) / 256;                     // output 16-byte chunks per thread (11)
 constexpr int IN_Q = (IN_ROWS * (OW + 2) + 255) / 256;              // staged 16-byte chunks per thread (4)
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 template <bool INVERSE>
 __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -65,14 +71,15 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
         const bool live = unit < p.n_units;
         const int im = live ? unit / p.units_per_img : 0;
         const int oh0 = live ? (unit - im * p.units_per_img) * 2 : 0;
+        const uint16_t *ximg = p.x + (long long)im * p.H * p.WP * 8;
 #pragma unroll
         for (int k = 0; k < IN_Q; ++k) {
-            const int q = tid + 256 * k;
-            const int r = q / (OW + 2), c = q - r * (OW + 2);
-            const int ih = 2 * oh0 - 2 + r, pc = c - 1;
+            const unsigned q = tid + 256 * k;
+            const unsigned r = (q * 575u) >> 16, c = q - r * (OW + 2);      // q / 114 for q < 1100
+            const int ih = 2 * oh0 - 2 + (int)r, pc = (int)c - 1;
             in_ok[k] = live & (q < IN_ROWS * (OW + 2)) & ((unsigned)ih < (unsigned)p.H) & ((unsigned)pc < (unsigned)p.WP);
-            const long long off = in_ok[k] ? (((long long)im * p.H + ih) * p.WP + pc) * 8 : 0;
-            in_next[k] = *reinterpret_cast<const uint4 *>(p.x + off);
+            const unsigned off = in_ok[k] ? (unsigned)(ih * p.WP + pc) * 16u : 0u;   // bytes within the image (< 2^31)
+            in_next[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(ximg) + off);
         }
     };
     auto store_rows = [&](int tid) {
@@ -125,9 +132,8 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
             const int a_lane = ((2 * wm + (pad ? 0 : kh)) * (OW + 2) + (pad ? 0 : t) + frow) * 16;   // + i * 256
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                uint4 v = *reinterpret_cast<const uint4 *>(rows + a_lane + i * 256);
-                if (pad) v = make_uint4(0u, 0u, 0u, 0u);
-                const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+                // (the padding chunk reads tap (0, 0): finite image data against W0's zero K-padding columns)
+                const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(rows + a_lane + i * 256));
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[ks][j]), af,
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
             for (int j = 0; j < NT; ++j) {
                 const int col = wn * 48 + j * 16 + fq * 4;
                 uint2 h;
-                h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]) & 0x7FFF7FFFu;
-                h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]) & 0x7FFF7FFFu;
+                h.x = pack2(f32x2_t{acc[i][j][0], acc[i][j][1]}) & 0x7FFF7FFFu;
+                h.y = pack2(f32x2_t{acc[i][j][2], acc[i][j][3]}) & 0x7FFF7FFFu;
                 *reinterpret_cast<uint2 *>(img + (px_lane + i * 16) * IMG_PITCH + col * 2) = h;
             }
         __syncthreads();   // staged rows consumed; |t| image complete (a pixel's 96 channels come from two waves)
@@ -182,19 +188,22 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
             for (int j = 0; j < NT; ++j) {
                 const int col = wn * 48 + j * 16 + fq * 4;
                 const float4 b4 = *reinterpret_cast<const float4 *>(beta_s + col);
-                const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+                const f32x2_t b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
 #pragma unroll
                 for (int i = 0; i < MH; ++i) {
                     if (i0 + i >= MT) continue;
-                    float r[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float norm = b[e] + nrm[i][j][e];
-                        r[e] = INVERSE ? acc[i0 + i][j][e] * norm : acc[i0 + i][j][e] * __builtin_amdgcn_rcpf(norm);
-                    }
+                    // explicit (e0,e1) / (e2,e3) pairs: packed add / mul / convert, no lane shuffles
+                    const f32x2_t n01 = b01 + f32x2_t{nrm[i][j][0], nrm[i][j][1]};
+                    const f32x2_t n23 = b23 + f32x2_t{nrm[i][j][2], nrm[i][j][3]};
+                    const f32x2_t t01 = {acc[i0 + i][j][0], acc[i0 + i][j][1]}, t23 = {acc[i0 + i][j][2], acc[i0 + i][j][3]};
                     uint2 o;
-                    o.x = pack_bf16x2(r[0], r[1]);
-                    o.y = pack_bf16x2(r[2], r[3]);
+                    if (INVERSE) {
+                        o.x = pack2(t01 * n01);
+                        o.y = pack2(t23 * n23);
+                    } else {
+                        o.x = pack2(t01 * f32x2_t{__builtin_amdgcn_rcpf(n01[0]), __builtin_amdgcn_rcpf(n01[1])});
+                        o.y = pack2(t23 * f32x2_t{__builtin_amdgcn_rcpf(n23[0]), __builtin_amdgcn_rcpf(n23[1])});
+                    }
                     *reinterpret_cast<uint2 *>(img + (px_lane + (i0 + i) * 16) * IMG_PITCH + col * 2) = o;
                 }
             }
@@ -216,10 +225,10 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
             const int n_chunks = n_rows * OW * (CH / 8);
 #pragma unroll
             for (int k = 0; k < Y_Q; ++k) {
-                const int q0 = tq + 256 * k;
-                const int q = q0 < n_chunks ? q0 : tq;      // past the end: store the thread's first chunk again
-                const int px = q / (CH / 8), c = q - px * (CH / 8);
-                yo[q] = *reinterpret_cast<const uint4 *>(img + px * IMG_PITCH + c * 16);
+                const unsigned q0 = tq + 256 * k;
+                const unsigned q = q0 < (unsigned)n_chunks ? q0 : (unsigned)tq;   // past the end: the thread's first chunk again
+                const unsigned px = (q * 43691u) >> 19;                           // q / 12 for q < 4096
+                yo[q] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
             }
         }
         store_rows(tq);    // the staged rows were last read before the first barrier of this unit

@@ -36,7 +36,17 @@ struct StreamArgs {
 
 constexpr int BM = 128, BNC = 256, MT = 8, NT = 2;
 
-template <int K>
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+// The tail of a unit (next unit's loads, this unit's stores) is straight-line code: addresses are clamped instead of
+// guarded, so the compiler's vmcnt bookkeeping stays exact and its wait for the loads is vmcnt(<stores issued after
+// them>) -- never a wait for a store acknowledgement.
+template <int K, bool RES>
 __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs p) {
     constexpr int KS = K / 32;                 // k-steps
     constexpr int A_BYTES = BM * K * 2;        // A tile
@@ -44,9 +54,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
     constexpr int A_Q = BM * CPR / 512;        // A chunks per thread
     constexpr int IMG_Q = BM * (BNC / 8) / 512;   // image chunks per thread (8)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int next_slot;
     unsigned char *At = smem;
     unsigned char *img = smem + A_BYTES;
-    volatile int *next_slot = reinterpret_cast<volatile int *>(smem + A_BYTES + BM * BNC * 2);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -55,70 +65,68 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
     const int Cout = p.Cout;
 
     // register sets of the NEXT unit, filled while the current one is being stored
-    uint4 a_next[A_Q], r_next[IMG_Q], w_regs[KS][NT];
+    u32x4_t a_next[A_Q], r_next[RES ? IMG_Q : 1];   // native vectors: a struct copy becomes a memcpy SROA will not split
+    uint4 w_regs[KS][NT];
+    float4 b_next[NT];
 
-    auto load_unit = [&](int unit) {
-        const bool live = unit < p.n_units;
+    auto load_unit = [&](int unit, int tid) {
+        const bool live = unit < p.n_units;     // a dead unit loads unit 0's operands and never uses them
         const int tile = live ? unit / p.n_chunks : 0;
         const int chunk = live ? unit - tile * p.n_chunks : 0;
         const int m0 = tile * BM;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            b_next[j] = *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + wn * (NT * 16) + j * 16 + ((tid & 63) >> 4) * 4);
         // weights of this wave's 32 channels of the chunk: all k-steps
-        const uint4 *wf = reinterpret_cast<const uint4 *>(p.w) + ((long long)(chunk * (BNC / 16) + wn * NT) * KS) * 64 + lane;
+        const uint4 *wf = reinterpret_cast<const uint4 *>(p.w) + ((long long)(chunk * (BNC / 16) + wn * NT) * KS) * 64 + (tid & 63);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) w_regs[ks][j] = wf[(j * KS + ks) * 64];
-        // A tile: chunk q = tid + 512 k  ->  (row, 16-byte chunk)
-#pragma unroll
-        for (int k = 0; k < A_Q; ++k) {
-            const int q = tid + 512 * k;
-            const int row = q / CPR, c = q - row * CPR;
-            const int m = m0 + row;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (live && m < p.M) {
-                long long pix = m;
-                if (p.stride != 1) {
-                    const int im = m / p.OHW, rem = m - im * p.OHW;
-                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                    pix = ((long long)im * p.H + oh * p.stride) * p.W + ow * p.stride;
-                }
-                v = *reinterpret_cast<const uint4 *>(p.x + pix * K + c * 8);
-            }
-            a_next[k] = v;
-        }
-        // residual tile
-        if (p.res) {
+        // residual tile (rows past M: clamped, their results are never stored)
+        if (RES) {
 #pragma unroll
             for (int k = 0; k < IMG_Q; ++k) {
                 const int q = tid + 512 * k;
                 const int row = q >> 5, c = q & 31;
-                const int m = m0 + row;
-                r_next[k] = (live && m < p.M)
-                                ? *reinterpret_cast<const uint4 *>(p.res + (long long)m * Cout + chunk * BNC + c * 8)
-                                : make_uint4(0u, 0u, 0u, 0u);
+                const int m = min(m0 + row, p.M - 1);
+                r_next[k] = *reinterpret_cast<const u32x4_t *>(p.res + (long long)m * Cout + chunk * BNC + c * 8);
             }
         }
-    };
-    auto store_a = [&]() {
+        // A tile: chunk q = tid + 512 k  ->  (row, 16-byte chunk); the youngest loads: waiting for them covers the rest
 #pragma unroll
         for (int k = 0; k < A_Q; ++k) {
             const int q = tid + 512 * k;
             const int row = q / CPR, c = q - row * CPR;
-            *reinterpret_cast<uint4 *>(At + row * (K * 2) + ((c ^ (row & 15)) << 4)) = a_next[k];
+            const int m = min(m0 + row, p.M - 1);
+            long long pix = m;
+            if (p.stride != 1) {
+                const int im = m / p.OHW, rem = m - im * p.OHW;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                pix = ((long long)im * p.H + oh * p.stride) * p.W + ow * p.stride;
+            }
+            a_next[k] = *reinterpret_cast<const u32x4_t *>(p.x + pix * K + c * 8);
+        }
+    };
+    auto store_a = [&](int tid) {
+#pragma unroll
+        for (int k = 0; k < A_Q; ++k) {
+            const int q = tid + 512 * k;
+            const int row = q / CPR, c = q - row * CPR;
+            *reinterpret_cast<u32x4_t *>(At + row * (K * 2) + ((c ^ (row & 15)) << 4)) = a_next[k];
         }
     };
 
     int unit = blockIdx.x;
     int next_unit = unit + gridDim.x;
-    load_unit(unit);
-    store_a();
+    load_unit(unit, tid);
+    store_a(tid);
     __syncthreads();
 
     while (unit < p.n_units) {
         const int tile = unit / p.n_chunks;
         const int chunk = unit - tile * p.n_chunks;
         const int m0 = tile * BM;
-        if (tid == 0) *next_slot = (int)atomicAdd(p.unit_ctr, 1u);
 
         // ---- K loop: A fragments from LDS, weights from the registers loaded one unit ago
         f32x4_t acc[MT][NT];
@@ -139,63 +147,72 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
             }
         }
         // ---- residual of this unit (fetched one unit ago) into the image
-        if (p.res) {
+        if (RES) {
 #pragma unroll
             for (int k = 0; k < IMG_Q; ++k) {
                 const int q = tid + 512 * k;
                 const int row = q >> 5, c = q & 31;
-                *reinterpret_cast<uint4 *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4)) = r_next[k];
+                *reinterpret_cast<u32x4_t *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4)) = r_next[k];
             }
         }
         __syncthreads();   // the A tile has been consumed by every wave; the residual image is complete
-        // ---- y = act(acc + bias [+ residual]) in place in the image
+        // ---- y = act(acc + bias [+ residual]) in place in the image; explicit (e0,e1)/(e2,e3) pairs: packed ops
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = wn * (NT * 16) + j * 16 + fq * 4;            // channel inside the chunk
-            const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + col);
-            const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+            const float4 b4 = b_next[j];
+            const f32x2_t b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = i * 16 + frow;
                 unsigned char *slot = img + row * (BNC * 2) + (((col >> 3) ^ frow) << 4) + (col & 7) * 2;
-                float v[4] = {acc[i][j][0] + b[0], acc[i][j][1] + b[1], acc[i][j][2] + b[2], acc[i][j][3] + b[3]};
-                if (p.res) {
+                f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]} + b01;
+                f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]} + b23;
+                if (RES) {
                     const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
-                    v[0] += __builtin_bit_cast(float, xr.x << 16);
-                    v[1] += __builtin_bit_cast(float, xr.x & 0xFFFF0000u);
-                    v[2] += __builtin_bit_cast(float, xr.y << 16);
-                    v[3] += __builtin_bit_cast(float, xr.y & 0xFFFF0000u);
+                    v01 += f32x2_t{__builtin_bit_cast(float, xr.x << 16), __builtin_bit_cast(float, xr.x & 0xFFFF0000u)};
+                    v23 += f32x2_t{__builtin_bit_cast(float, xr.y << 16), __builtin_bit_cast(float, xr.y & 0xFFFF0000u)};
                 }
                 if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
+                    v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
                 }
                 uint2 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
+                o.x = pack2(v01);
+                o.y = pack2(v23);
                 *reinterpret_cast<uint2 *>(slot) = o;
             }
         }
         __syncthreads();
-        // ---- the accumulators are dead: fetch the next unit's operands, THEN stream this unit out
-        const int unit_after_next = __builtin_amdgcn_readfirstlane(*next_slot);
-        load_unit(next_unit);
+        // ---- the accumulators are dead: claim a unit and fetch the next unit's operands, THEN stream this unit out
+        int tq = tid;   // opaque: per-thread offsets are recomputed here, not carried (spilled) across the unit
+        asm volatile("" : "+v"(tq));
+        unsigned claimed = 0;
+        if (tid == 0) {   // raw instruction: the compiler's atomicAdd waits for the result (vmcnt(0)) on the spot
+            const unsigned one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
+        }
+        load_unit(next_unit, tq);
         {
-            uint4 *yo = reinterpret_cast<uint4 *>(p.y);
+            uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)chunk * BNC);
 #pragma unroll
             for (int k = 0; k < IMG_Q; ++k) {
-                const int q = tid + 512 * k;
-                const int row = q >> 5, c = q & 31;
-                const int m = m0 + row;
-                if (m < p.M)
-                    yo[((long long)m * Cout + chunk * BNC) / 8 + c] =
-                        *reinterpret_cast<const uint4 *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4));
+                const int q = tq + 512 * k;
+                int row = q >> 5;
+                const int c = q & 31;
+                row = m0 + row < p.M ? row : 0;      // past the end: row 0 of the tile again (same data, same address)
+                yo[(long long)(m0 + row) * (Cout / 8) + c] =
+                    *reinterpret_cast<const uint4 *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4));
             }
         }
-        store_a();         // the A tile region was last read before the first barrier of this unit
+        store_a(tq);       // the A tile region was last read before the first barrier of this unit
+        if (tid == 0) {    // the claim is older than the loads store_a() has just waited for
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(claimed) : "n"(IMG_Q) : "memory");
+            next_slot = (int)claimed;
+        }
         __syncthreads();   // next A tile visible; image free
         unit = next_unit;
-        next_unit = unit_after_next;
+        next_unit = __builtin_amdgcn_readfirstlane(next_slot);
     }
 }
 
@@ -204,12 +221,12 @@ constexpr int kMaxDev = 16, kRing = 256;
 unsigned *g_ring[kMaxDev] = {};
 std::atomic<unsigned> g_seq{0};
 
-template <int K>
+template <int K, bool RES>
 int launch_stream(const StreamArgs &a, hipStream_t s) {
-    constexpr int lds = BM * K * 2 + BM * BNC * 2 + 16;
+    constexpr int lds = BM * K * 2 + BM * BNC * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_stream_kernel<K>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -239,7 +256,7 @@ int launch_stream(const StreamArgs &a, hipStream_t s) {
         sc2_set_error("conv1x1_stream: cannot preset the unit counter");
         return SC2_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(conv1x1_stream_kernel<K>, dim3(grid), dim3(512), lds, s, b);
+    hipLaunchKernelGGL((conv1x1_stream_kernel<K, RES>), dim3(grid), dim3(512), lds, s, b);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -276,5 +293,6 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
     a.n_units = (int)units;
     a.unit_ctr = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return Cin == 128 ? launch_stream<128>(a, s) : launch_stream<256>(a, s);
+    if (a.res) return Cin == 128 ? launch_stream<128, true>(a, s) : launch_stream<256, true>(a, s);
+    return Cin == 128 ? launch_stream<128, false>(a, s) : launch_stream<256, false>(a, s);
 }
