@@ -14,7 +14,8 @@
 //   GDN1    |t| (bf16) goes to an LDS image [224 px][96 ch] (rows padded to 208 B: conflict-free fragment reads),
 //           norm = beta + gamma |t| is a second GEMM with gamma fragment-major from L2, y = t / norm on the f32
 //           accumulators, written to the image and streamed out as one contiguous 43 KB block.
-// Units are claimed with one atomic each, one unit ahead.  Geometry: OW = 112 (224-pixel-wide input) only; other sizes
+// Units are claimed with one atomic each, one unit ahead (claim c means unit c + 2 * gridDim.x; a launch makes exactly
+// n_units claims, and the one that draws n_units - 1 writes the counter back to zero: no preset launch).  Geometry: OW = 112 (224-pixel-wide input) only; other sizes
 // use the generic kernel.
 #include <stdlib.h>
 
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
         store_rows(tq);    // the staged rows were last read before the first barrier of this unit
         if (tid == 0) {    // the claim is older than the row loads store_rows() has just waited for
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(claimed) : "n"(Y_Q) : "memory");
-            next_slot = (int)claimed;
+            next_slot = (int)(claimed + 2 * gridDim.x);
+            if (claimed == (unsigned)(p.n_units - 1)) *p.unit_ctr = 0u;   // the launch's last claim re-arms the counter
         }
         __syncthreads();   // next rows visible; image free
         unit = next_unit;
@@ -293,12 +295,12 @@ extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, cons
         void *ptr = nullptr;
         SC2_REQUIRE(hipMalloc(&ptr, kRing0 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
                     "conv0_gdn96: cannot allocate the unit counters");
+        SC2_REQUIRE(hipMemset(ptr, 0, kRing0 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
+                    "conv0_gdn96: cannot clear the unit counters");
         g_ring0[dev] = static_cast<unsigned *>(ptr);
     }
     const int grid = a.n_units < 2 * g_cus0 ? a.n_units : 2 * g_cus0;   // two workgroups per CU
     a.unit_ctr = g_ring0[dev] + (g_seq0.fetch_add(1) % kRing0);
-    SC2_REQUIRE(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.unit_ctr), 2 * grid, 1, s) == hipSuccess, SC2_ERR_LAUNCH,
-                "conv0_gdn96: cannot preset the unit counter");
     if (inverse) hipLaunchKernelGGL(conv0_gdn96_kernel<true>, dim3(grid), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(conv0_gdn96_kernel<false>, dim3(grid), dim3(256), lds, s, a);
     SC2_CHECK_LAUNCH();

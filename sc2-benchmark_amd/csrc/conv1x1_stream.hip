@@ -31,7 +31,7 @@ struct StreamArgs {
     uint16_t *__restrict__ y;             // bf16 NHWC [N,OH,OW,Cout]
     int H, W, OH, OW, OHW, M, Cout, stride, relu;
     int n_chunks, n_units;                // 256-channel chunks per pixel tile; units = pixel tiles x chunks
-    unsigned *unit_ctr;                   // next unclaimed unit; preset to 2 * gridDim.x on the stream
+    unsigned *unit_ctr;                   // claims so far (claim c = unit c + 2 * gridDim.x); zero between launches
 };
 
 constexpr int BM = 128, BNC = 256, MT = 8, NT = 2;
@@ -208,7 +208,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
         store_a(tq);       // the A tile region was last read before the first barrier of this unit
         if (tid == 0) {    // the claim is older than the loads store_a() has just waited for
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(claimed) : "n"(IMG_Q) : "memory");
-            next_slot = (int)claimed;
+            next_slot = (int)(claimed + 2 * gridDim.x);
+            if (claimed == (unsigned)(p.n_units - 1)) *p.unit_ctr = 0u;   // the launch's last claim re-arms the counter
         }
         __syncthreads();   // next A tile visible; image free
         unit = next_unit;
@@ -247,15 +248,15 @@ int launch_stream(const StreamArgs &a, hipStream_t s) {
             sc2_set_error("conv1x1_stream: cannot allocate the unit counters");
             return SC2_ERR_INTERNAL;
         }
+        if (hipMemset(ptr, 0, kRing * sizeof(unsigned)) != hipSuccess) {
+            sc2_set_error("conv1x1_stream: cannot clear the unit counters");
+            return SC2_ERR_INTERNAL;
+        }
         g_ring[dev] = static_cast<unsigned *>(ptr);
     }
     const int grid = a.n_units < g_cus ? a.n_units : g_cus;
     StreamArgs b = a;
     b.unit_ctr = g_ring[dev] + (g_seq.fetch_add(1) % kRing);
-    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.unit_ctr), 2 * grid, 1, s) != hipSuccess) {
-        sc2_set_error("conv1x1_stream: cannot preset the unit counter");
-        return SC2_ERR_LAUNCH;
-    }
     hipLaunchKernelGGL((conv1x1_stream_kernel<K, RES>), dim3(grid), dim3(512), lds, s, b);
     SC2_CHECK_LAUNCH();
     return SC2_OK;

@@ -48,7 +48,7 @@ struct DecArgs {
     uint16_t *__restrict__ y;            // bf16 NHWC [N,OH,OW,512]
     int N, H, W, OH, OW, OHW, M, Kpad, n_tiles, inverse;
     unsigned long long *stamps;          // diagnostic build only (SC2_DEC_STAMPS)
-    unsigned *tile_ctr;                  // next unclaimed tile; preset to 2 * gridDim.x on the stream before the launch
+    unsigned *tile_ctr;                  // claims so far (claim c = tile c + 2 * gridDim.x); zero between launches
 };
 
 constexpr int BM = 128, CH = 512, WN = 64, MT = 8, NT = 4;
@@ -239,7 +239,11 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
         for (int j = 0; j < NT; ++j) b4v[j] = *reinterpret_cast<const float4 *>(p.beta + wn * WN + j * 16 + fq * 4);
         uint4 pv[KS1];
         load_patch(next_tile, pv);
-        if (tid == 0) *next_slot = (int)atomicAdd(p.tile_ctr, 1u);
+        if (tid == 0) {
+            const unsigned c = atomicAdd(p.tile_ctr, 1u);
+            *next_slot = (int)(c + 2 * gridDim.x);
+            if (c == (unsigned)(p.n_tiles - 1)) *p.tile_ctr = 0u;   // the launch's last claim re-arms the counter
+        }
 
         // ---------------------------------------------------------------- epilogue: y = t * (beta + norm), in place
 #pragma unroll
@@ -334,14 +338,14 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
             sc2_set_error("conv2x2_gdn512: cannot allocate the tile counters");
             return SC2_ERR_INTERNAL;
         }
+        if (hipMemset(ptr, 0, kCtrRing * sizeof(unsigned)) != hipSuccess) {
+            sc2_set_error("conv2x2_gdn512: cannot clear the tile counters");
+            return SC2_ERR_INTERNAL;
+        }
         g_ctr_ring[dev] = static_cast<unsigned *>(ptr);
     }
     DecArgs b = a;
     b.tile_ctr = g_ctr_ring[dev] + (g_ctr_seq.fetch_add(1) % kCtrRing);
-    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.tile_ctr), 2 * grid, 1, s) != hipSuccess) {
-        sc2_set_error("conv2x2_gdn512: cannot preset the tile counter");
-        return SC2_ERR_LAUNCH;
-    }
     b.stamps = nullptr;
 #if SC2_DEC_STAMPS
     const char *stamp_path = getenv("SC2_DEC_STAMPS");

@@ -867,6 +867,77 @@ __global__ __launch_bounds__(256, 3) void conv5s2_patch_kernel(const ConvArgs p)
     conv_store_tile_bf16<C, ImgPad<C>, 256, false>(p, smem, acc, tid, wm, wn, frow, fq, m0, 0, epi, nullptr, false, valid);
 }
 
+// Everything behind the K loop of the big-tile kernels: the fused conv + (I)GDN1 second GEMM of the 256-wide tile,
+// then the store epilogue.  Shared by the 8-wave and the 4-wave kernels (NTHREADS = 512 / 256).
+template <class C, int NTHREADS>
+__device__ __forceinline__ void conv_big_epilogue(const ConvArgs &p, unsigned char *smem, f32x4_t (&acc)[C::MT][C::NT], int tid,
+                                                  int lane, int wm, int wn, int frow, int fq, int m0, int n0) {
+    constexpr int BM = C::BM, BN = C::BN, MT = C::MT, NT = C::NT;
+    // ---- conv followed by GDN1 / inverse GDN1 in the same launch (the tile holds all 256 channels of its pixels):
+    // x goes to an LDS image as bf16, norm = gamma |x| is a second MFMA GEMM whose A operand is that image (|.| on the
+    // fragment) and whose B operand, gamma, comes fragment-major from L2; y = x * (beta + norm) (or x / ...) is applied
+    // in the store pass with x read back from the image.  No HBM traffic for the GDN.
+    if constexpr (BN == 256) {
+        if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
+            unsigned char *Xi = smem;
+            unsigned char *ring = smem + BM * 512;   // f32-output staging (BM == 256 only)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int r = wm * C::WM + i * 16 + frow;
+                    const int col = wn * C::WN + j * 16 + fq * 4;
+                    uint2 h;
+                    h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                    h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                    *reinterpret_cast<uint2 *>(Xi + r * 512 + (((col >> 3) ^ (r & 15)) << 4) + (col & 7) * 2) = h;
+                    acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+            // gamma comes FRAGMENT-MAJOR ([16-channel tile][32-deep step][lane][8 k]: one operand fragment = 1 KB
+            // contiguous, hip.pack_gamma_fragments) straight from L2 into registers, one step ahead: no LDS ring and no
+            // barrier inside the loop, the two waves of a SIMD drift apart and hide each other's waits.
+            const uint4 *gfrag = reinterpret_cast<const uint4 *>(p.ep_x) + (long long)(wn * NT) * (BN / 32) * 64 + lane;
+            constexpr int NS = BN / 32;
+            uint4 gbuf[2][NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) gbuf[0][j] = gfrag[(j * NS + 0) * 64];
+            __builtin_amdgcn_s_barrier();   // the x image is complete
+            const unsigned char *xrow = Xi + (wm * C::WM + frow) * 512;
+#pragma unroll
+            for (int ks2 = 0; ks2 < NS; ++ks2) {
+                if (ks2 + 1 < NS) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) gbuf[(ks2 + 1) & 1][j] = gfrag[(j * NS + ks2 + 1) * 64];
+                }
+                const int xc = ((4 * ks2 + fq) ^ frow) << 4;   // row & 15 == frow for every fragment row of this lane
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    uint4 v = *reinterpret_cast<const uint4 *>(xrow + i * 16 * 512 + xc);
+                    v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu;
+                    const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, gbuf[ks2 & 1][j]), af, acc[i][j], 0, 0, 0);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_s_barrier();   // every wave is done with its x-image fragments
+            const int epi2 = p.epi == SC2_EPI_FUSED_IGDN ? (int)SC2_EPI_IGDN : (int)SC2_EPI_GDN;
+            if (p.out == SC2_OUT_BF16_NHWC)   // x -> y in place in the image, then streamed out
+                conv_store_tile_bf16<C, ImgXor<C>, NTHREADS, false>(p, Xi, acc, tid, wm, wn, frow, fq, m0, n0, epi2, nullptr,
+                                                               true);
+            else if (NTHREADS != 256)         // the ring becomes the f32 staging area, x read back from the image
+                conv_store_tile_f32<C, NTHREADS>(p, ring, acc, tid, wm, wn, frow, fq, m0, n0, epi2, Xi, BN);
+            return;
+        }
+    }
+    if (p.out == SC2_OUT_BF16_NHWC)
+        conv_store_tile_bf16<C, ImgXor<C>, NTHREADS, false>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi, nullptr, false);
+    else if (NTHREADS != 256)   // (the 4-wave kernel is dispatched for bf16 NHWC outputs only: 256 accumulators + staging spill)
+        conv_store_tile_f32<C, NTHREADS>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi);
+}
+
 // ======================================================================================================
 // Big-tile variant for the MFMA-bound layers (Cout % 128 == 0, long K): 512 threads = 8 waves, 256 x BN tile,
 // BK = 32 slabs in a 4-deep direct-to-LDS ring.  The 8 waves form two groups of four (wave w and w + 4 share a
@@ -1108,69 +1179,262 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
             for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
         return;
     }
-    // ---- conv followed by GDN1 / inverse GDN1 in the same launch (the tile holds all 256 channels of its pixels):
-    // x goes to an LDS image as bf16, norm = gamma |x| is a second MFMA GEMM whose A operand is that image (|.| on the
-    // fragment) and whose B operand, gamma, comes fragment-major from L2; y = x * (beta + norm) (or x / ...) is applied
-    // in the store pass with x read back from the image.  No HBM traffic for the GDN.
-    if constexpr (BN == 256) {
-        if (p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN) {
-            unsigned char *Xi = smem;
-            unsigned char *ring = smem + BM * 512;   // f32-output staging (BM == 256 only)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int r = wm * C::WM + i * 16 + frow;
-                    const int col = wn * C::WN + j * 16 + fq * 4;
-                    uint2 h;
-                    h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                    h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
-                    *reinterpret_cast<uint2 *>(Xi + r * 512 + (((col >> 3) ^ (r & 15)) << 4) + (col & 7) * 2) = h;
-                    acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                }
-            // gamma comes FRAGMENT-MAJOR ([16-channel tile][32-deep step][lane][8 k]: one operand fragment = 1 KB
-            // contiguous, hip.pack_gamma_fragments) straight from L2 into registers, one step ahead: no LDS ring and no
-            // barrier inside the loop, the two waves of a SIMD drift apart and hide each other's waits.
-            const uint4 *gfrag = reinterpret_cast<const uint4 *>(p.ep_x) + (long long)(wn * NT) * (BN / 32) * 64 + lane;
-            constexpr int NS = BN / 32;
-            uint4 gbuf[2][NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) gbuf[0][j] = gfrag[(j * NS + 0) * 64];
-            __builtin_amdgcn_s_barrier();   // the x image is complete
-            const unsigned char *xrow = Xi + (wm * C::WM + frow) * 512;
-#pragma unroll
-            for (int ks2 = 0; ks2 < NS; ++ks2) {
-                if (ks2 + 1 < NS) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) gbuf[(ks2 + 1) & 1][j] = gfrag[(j * NS + ks2 + 1) * 64];
-                }
-                const int xc = ((4 * ks2 + fq) ^ frow) << 4;   // row & 15 == frow for every fragment row of this lane
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    uint4 v = *reinterpret_cast<const uint4 *>(xrow + i * 16 * 512 + xc);
-                    v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu;
-                    const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8_t, gbuf[ks2 & 1][j]), af, acc[i][j], 0, 0, 0);
-                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_s_barrier();   // every wave is done with its x-image fragments
-            const int epi2 = p.epi == SC2_EPI_FUSED_IGDN ? (int)SC2_EPI_IGDN : (int)SC2_EPI_GDN;
-            if (p.out == SC2_OUT_BF16_NHWC)   // x -> y in place in the image, then streamed out
-                conv_store_tile_bf16<C, ImgXor<C>, 512, false>(p, Xi, acc, tid, wm, wn, frow, fq, m0, n0, epi2, nullptr,
-                                                               true);
-            else                              // the ring becomes the f32 staging area, x read back from the image
-                conv_store_tile_f32<C, 512>(p, ring, acc, tid, wm, wn, frow, fq, m0, n0, epi2, Xi, BN);
-            return;
-        }
+    conv_big_epilogue<C, 512>(p, smem, acc, tid, lane, wm, wn, frow, fq, m0, n0);
+}
+
+// ======================================================================================================
+// Register-tile variant of the big tile: 256 threads = 4 waves, ONE per SIMD with the whole 512-entry register file,
+// each owning a 128 x 128 quarter of the 256 x 256 tile (64 accumulator tiles = 256 registers).  Per 32-deep slab a
+// wave issues 64 MFMAs against 16 fragment reads (8 pixel + 8 weight fragments): a quarter of the LDS bytes per MFMA
+// of the 8-wave tiling (128 x 64 per wave: 12 reads per 32 MFMAs), which is what bounds that kernel - its reads plus
+// the direct-to-LDS writes need more LDS cycles per slab than its MFMAs need matrix-pipe cycles.  No partner wave
+// hides latency here, so the slab loop is software-pipelined inside the wave: the fragments of slab t + 1 are read
+// into a second register set BETWEEN the MFMAs of slab t (one read per four MFMAs), the direct-to-LDS loads of slab
+// t + 3 are issued at the top of slab t, and there is ONE barrier per slab (1024 matrix-pipe cycles).
+//   RAW: every wave retires its share of slab t + 1 (counted vmcnt) before the barrier at the top of slab t, and
+//        reads that slab only behind it.
+//   WAR: slab t + 3 lands in the stage slab t - 1 lived in; its fragments were read during slab t - 2 and waited
+//        for (lgkmcnt(0)) before the barrier at the top of slab t - 1.
+template <bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_, int PH_, int PW_>
+struct Cfg4 {
+    static constexpr int BM = 256, BN = 256, BK = 32, KC = 4;
+    static constexpr int WAVES_M = 2, WAVES_N = 2;
+    static constexpr bool STATIC = STATIC_;
+    static constexpr int CIN = CIN_, KH = KH_, KW = KW_, SH = SH_, SW = SW_, PH = PH_, PW = PW_;
+    static constexpr int WM = 128, WN = 128, MT = 8, NT = 8;
+    static constexpr int STAGES = 4;
+    static constexpr int A_IPW = BM / 16 / 4, B_IPW = BN / 16 / 4;
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int STAGE_ROWS = WAVES_M * 16;
+    static constexpr int MAIN_LDS = STAGES * STAGE_BYTES;
+    static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
+    static constexpr int FUSE_LDS = BM * 512 + 32768;
+    static constexpr int IMG_LDS = BM * BN * 2;
+    static constexpr int LDS_BYTES = FUSE_LDS;   // the largest of the four
+    static_assert(FUSE_LDS >= MAIN_LDS && FUSE_LDS >= EPI_LDS && FUSE_LDS >= IMG_LDS, "LDS plan");
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 1) void conv_igemm4_kernel(const ConvArgs p) {
+    constexpr int BM = C::BM, BN = C::BN, KC = C::KC;
+    constexpr int MT = C::MT, NT = C::NT, S = C::STAGES;
+    constexpr int A_IPW = C::A_IPW, B_IPW = C::B_IPW, L = A_IPW + B_IPW;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int Cin = C::STATIC ? C::CIN : p.Cin;
+    const int KH = C::STATIC ? C::KH : p.KH;
+    const int KW = C::STATIC ? C::KW : p.KW;
+    const int SH = C::STATIC ? C::SH : p.SH;
+    const int SW = C::STATIC ? C::SW : p.SW;
+    const int PH = C::STATIC ? C::PH : p.PH;
+    const int PW = C::STATIC ? C::PW : p.PW;
+    const int CIN8 = Cin >> 3;
+    const int H = p.H, W = p.W;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
     }
-    if (p.out == SC2_OUT_BF16_NHWC)
-        conv_store_tile_bf16<C, ImgXor<C>, 512, false>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi, nullptr, false);
-    else
-        conv_store_tile_f32<C, 512>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, p.epi);
+    const int ntile = bid % p.n_ntiles;
+    const int mtile = bid / p.n_ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+
+    // gather state: wave-instruction q = j * 4 + wave fills rows [16q, 16q + 16) of a slab (see conv_igemm_kernel)
+    const int kc = (lane & 3) ^ ((lane >> 3) & 3);
+    const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16);
+    const long long zero_off = zero - p.x, zero_off_w = zero - p.w;
+    long long a_off[A_IPW];
+    int a_ih0[A_IPW], a_iw0[A_IPW];
+    bool a_ok[A_IPW];
+#pragma unroll
+    for (int j = 0; j < A_IPW; ++j) {
+        const int m = m0 + (j * 4 + wave) * 16 + (lane >> 2);
+        a_ok[j] = m < p.M;
+        const int mm = a_ok[j] ? m : 0;
+        const int img = mm / p.OHW;
+        const int rem = mm - img * p.OHW;
+        const int oh = rem / p.OW;
+        const int ow = rem - oh * p.OW;
+        a_ih0[j] = oh * SH - PH;
+        a_iw0[j] = ow * SW - PW;
+        a_off[j] = ((long long)(img * H + a_ih0[j]) * W + a_iw0[j]) * Cin;
+    }
+    long long b_off[B_IPW];
+#pragma unroll
+    for (int j = 0; j < B_IPW; ++j)
+        b_off[j] = (long long)(n0 + (j * 4 + wave) * 16 + (lane >> 2)) * p.b_row_stride + kc * 8;
+    const bool aligned = C::STATIC ? (C::CIN % 32 == 0) : (Cin % 32 == 0);
+    const int spt = aligned ? (CIN8 >> 2) : 1;     // slabs per tap
+    constexpr int WRAPS = C::STATIC ? (KC + (C::CIN / 8) - 1) / (C::CIN / 8 > 0 ? C::CIN / 8 : 1) : KC;
+    int c8 = kc, kh = 0, kw = 0;
+    auto wrap_k = [&]() {
+#pragma unroll
+        for (int rep = 0; rep < WRAPS; ++rep) {
+            const bool w1 = c8 >= CIN8;
+            c8 -= w1 ? CIN8 : 0;
+            kw += w1 ? 1 : 0;
+            const bool w2 = kw == KW;
+            kw = w2 ? 0 : kw;
+            kh += w2 ? 1 : 0;
+        }
+    };
+    if (!aligned) wrap_k();
+    const int KT = (p.dbg & 2) ? 0 : p.KT;
+    int next_a = 0;   // slab index the next issue_a() call fetches
+
+    auto issue_a = [&](int buf) {   // A rows of the next unissued slab
+        unsigned char *Ab = smem + buf * C::STAGE_BYTES;
+        int t_kh, t_kw;
+        long long tap_off;
+        if (aligned) {
+            int tap, cb;   // scalar
+            if (p.k_slab_major) { cb = next_a / (KH * KW); tap = next_a - cb * (KH * KW); }
+            else { tap = next_a / spt; cb = next_a - tap * spt; }
+            t_kh = tap / KW;
+            t_kw = tap - t_kh * KW;
+            tap_off = ((long long)t_kh * W + t_kw) * Cin + cb * 32 + kc * 8;
+        } else {
+            t_kh = kh;
+            t_kw = kw;
+            tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
+        }
+        const bool tap_ok = aligned ? (next_a < KT) : (t_kh < KH);   // false for the K tail and the dummy slabs past KT
+#pragma unroll
+        for (int j = 0; j < A_IPW; ++j) {
+            const int ih = a_ih0[j] + t_kh, iw = a_iw0[j] + t_kw;
+            const bool ok = a_ok[j] & tap_ok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            const long long off = ok ? a_off[j] + tap_off : zero_off;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.x + off), (lds_ptr_t)(Ab + (j * 4 + wave) * 1024), 16, 0, 0);
+        }
+        ++next_a;
+        if (!aligned) {
+            c8 += KC;
+            wrap_k();
+        }
+    };
+    auto issue_b = [&](int kt, int buf) {
+        unsigned char *Bb = smem + buf * C::STAGE_BYTES + C::A_BYTES;
+        const bool kt_ok = kt < KT;
+#pragma unroll
+        for (int j = 0; j < B_IPW; ++j) {
+            const long long off = kt_ok ? b_off[j] + (long long)kt * p.b_kt_stride : zero_off_w;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.w + off), (lds_ptr_t)(Bb + (j * 4 + wave) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const uint32_t amask = p.aop == SC2_AOP_ABS ? 0x7FFF7FFFu : 0xFFFFFFFFu;
+    const int frow = lane & 15, fq = lane >> 4;
+    // fragment (i, lane) of the wave's rows sits 1024 B after fragment (i - 1, lane): one base + immediates
+    const uint32_t a_rd = lds_base + (uint32_t)lds_off(wm * C::WM + frow, fq);
+    const uint32_t b_rd = lds_base + (uint32_t)(C::A_BYTES + lds_off(wn * C::WN + frow, fq));
+    auto read_frag = [](uint32_t addr, int imm) {   // ds_read_b128 with the tile offset as an immediate
+        uint4 v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(0) : "memory");
+        (void)imm;
+        return v;
+    };
+    (void)read_frag;
+
+#pragma unroll
+    for (int st = 0; st < S - 1; ++st) {
+        issue_a(st);
+        issue_b(st, st);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");   // slab 0 has landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+
+    uint4 fa[2][MT], fb[2][NT];   // fragment register sets: slab t in set t & 1
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[0][i] = lds_read16(a_rd + i * 1024);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[0][j] = lds_read16(b_rd + j * 1024);
+
+    auto slab = [&](int kt, uint4 (&ca)[MT], uint4 (&cb)[NT], uint4 (&na)[MT], uint4 (&nb)[NT]) {
+        // slab kt + 1 landed (this wave's share), this wave's reads of slab kt are back: then everybody's are
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((S - 3) * L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int nbuf = (kt + S - 1) % S;
+        issue_a(nbuf);
+        issue_b(kt + S - 1, nbuf);
+        const uint32_t so = (uint32_t)(((kt + 1) % S) * C::STAGE_BYTES);
+        bf16x8_t bw[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bw[j] = __builtin_bit_cast(bf16x8_t, cb[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            uint4 v = ca[i];
+            v.x &= amask; v.y &= amask; v.z &= amask; v.w &= amask;
+            const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+            // two fragment reads of the next slab per row of eight MFMAs
+            na[i] = lds_read16(a_rd + so + i * 1024);
+#pragma unroll
+            for (int j = 0; j < NT / 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af, acc[i][j], 0, 0, 0);   // D = W X^T
+            __builtin_amdgcn_sched_barrier(0);
+            nb[i] = lds_read16(b_rd + so + i * 1024);
+#pragma unroll
+            for (int j = NT / 2; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], af, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    static_assert(MT == NT, "one B read per A row");
+    for (int kt = 0; kt < KT; kt += 2) {
+        slab(kt, fa[0], fb[0], fa[1], fb[1]);
+        if (kt + 1 < KT) slab(kt + 1, fa[1], fb[1], fa[0], fb[0]);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // dummy slabs past KT, the last prefetched fragments
+    __builtin_amdgcn_s_barrier();
+
+    if (p.dbg & 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+    conv_big_epilogue<C, 256>(p, smem, acc, tid, lane, wm, wn, frow, fq, m0, n0);
+}
+
+template <class C>
+int launch4(const ConvArgs &a, hipStream_t s) {
+    ConvArgs p = a;
+    p.KT = (a.KH * a.KW * a.Cin + C::BK - 1) / C::BK;
+    p.n_ntiles = (a.Cout + C::BN - 1) / C::BN;
+    const int n_mtiles = (a.M + C::BM - 1) / C::BM;
+    const long long nwg = (long long)n_mtiles * p.n_ntiles;
+    if (nwg <= 0 || nwg > 0x7FFFFFFFLL) {
+        sc2_set_error("conv2d: grid of %lld workgroups out of range", nwg);
+        return SC2_ERR_INVALID_ARG;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm4_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_igemm4_kernel<C>, dim3((unsigned)nwg), dim3(256), C::LDS_BYTES, s, p);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
 }
 
 template <class C>
@@ -1279,6 +1543,10 @@ using B_dec4 = Cfg8<256, 2, 4, true, 256, 2, 2, 1, 1, 1, 1>;
 using H_dec2 = Cfg8<256, 2, 4, true, 512, 2, 2, 1, 1, 0, 0, 128, 3>;   // half-height twins: 2 workgroups per CU
 using H_dec4 = Cfg8<256, 2, 4, true, 256, 2, 2, 1, 1, 1, 1, 128, 3>;
 using BG_256 = Cfg8<256, 2, 4, false, 0, 0, 0, 0, 0, 0, 0>;
+// register-tile (4-wave, 128 x 128 per wave) geometries
+using R_dec2 = Cfg4<true, 512, 2, 2, 1, 1, 0, 0>;
+using R_dec4 = Cfg4<true, 256, 2, 2, 1, 1, 1, 1>;
+using RG_256 = Cfg4<false, 0, 0, 0, 0, 0, 0, 0>;
 using BG_128 = Cfg8<128, 4, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 
 template <class C>
@@ -1307,7 +1575,7 @@ bool big_tile_eligible(const sc2_conv_desc *d, long long M, int K) {
     // (SC2_CONV_FORCE_BIG / SC2_CONV_NO_BIG: test and A/B switches)
     const bool forced = getenv("SC2_CONV_FORCE_BIG") != nullptr;
     return sc2_conv_weight_rows(d->Cout) % 128 == 0 && !getenv("SC2_CONV_NO_BIG") &&
-           ((K >= 1024 && d->Cout % 256 == 0 && d->a_op == SC2_AOP_NONE && M >= 256LL * 512) || forced);
+           ((K >= 1024 && d->Cout % 256 == 0 && d->a_op == SC2_AOP_NONE && M >= 256LL * 192) || forced);
 }
 }  // namespace
 
@@ -1426,6 +1694,14 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         if ((half ? atoi(half) : 0) && d->out_format == SC2_OUT_BF16_NHWC) {
             if (matches<H_dec2>(a)) return launch8<H_dec2>(a, s);
             if (matches<H_dec4>(a)) return launch8<H_dec4>(a, s);
+        }
+        {
+            const char *r4 = getenv("SC2_CONV_BIG4");   // A/B switch: the 4-wave register-tile kernel
+            if (r4 && atoi(r4) && d->out_format == SC2_OUT_BF16_NHWC) {
+                if (matches<R_dec2>(a)) return launch4<R_dec2>(a, s);
+                if (matches<R_dec4>(a)) return launch4<R_dec4>(a, s);
+                return launch4<RG_256>(a, s);
+            }
         }
         if (matches<B_gdn512>(a)) return launch8<B_gdn512>(a, s);
         if (matches<B_dec2>(a)) return launch8<B_dec2>(a, s);

@@ -100,12 +100,14 @@ def test_conv_igemm(S, dev, cin, cout, k, stride, pad, H, W, N):
     (32, 128, 3, 1, 1, 17, 19, 2),     # generic 128-wide 8-wave tile
     (24, 384, 3, 2, 1, 30, 30, 2),     # Cout 384: 128-wide tiles, K = 216 (tail slab)
 ])
-@pytest.mark.parametrize('half', ['0', '1'])
+@pytest.mark.parametrize('half', ['0', '1', 'r4'])
 def test_conv_big_tile(S, dev, monkeypatch, cin, cout, k, stride, pad, H, W, N, half):
-    """The 8-wave staggered 256-row kernel (forced here: its dispatch thresholds need >= 131072 rows); half = '1':
-    the 128-row twins of the two decoder geometries (two workgroups per CU)."""
+    """The 8-wave staggered 256-row kernel (forced here: its dispatch thresholds need >= 49152 rows); half = '1':
+    the 128-row twins of the two decoder geometries (two workgroups per CU); 'r4': the 4-wave register-tile kernel
+    (128 x 128 per wave, bf16 NHWC outputs of 256-wide tiles; SC2_CONV_BIG4 A/B variant)."""
     monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
-    monkeypatch.setenv('SC2_CONV_HALF', half)
+    monkeypatch.setenv('SC2_CONV_HALF', '0' if half == 'r4' else half)
+    monkeypatch.setenv('SC2_CONV_BIG4', '1' if half == 'r4' else '0')
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.randn(N, cin, H, W, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
@@ -236,13 +238,14 @@ def test_conv_fused_gdn(S, R, dev, cin, cout, k, stride, pad, inverse):
                          ep_beta=torch.ones(256, device=dev))
 
 
-@pytest.mark.parametrize('half', ['0', '1'])
+@pytest.mark.parametrize('half', ['0', '1', 'r4'])
 @pytest.mark.parametrize('cin,k,pad,inverse', [(512, 2, 0, True), (64, 1, 0, False)])
 def test_conv_fused_gdn_big_tile(S, R, dev, monkeypatch, cin, k, pad, inverse, half):
     """conv + GDN1(256) in one launch of the 256-wide 8-wave tile (x image in LDS, gamma fragments from L2), ragged
     last tile; half = '1': the 128-row twin of the dec.conv2 geometry."""
     monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
-    monkeypatch.setenv('SC2_CONV_HALF', half)
+    monkeypatch.setenv('SC2_CONV_HALF', '0' if half == 'r4' else half)
+    monkeypatch.setenv('SC2_CONV_BIG4', '1' if half == 'r4' else '0')
     cout = 256
     torch.manual_seed(cin)
     gdn = R.GDN1(cout, inverse=inverse)
