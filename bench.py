@@ -195,7 +195,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--inflight', type=int, default=3, help='range-coder chains in flight (coder HIP streams, <= 7)')
+    ap.add_argument('--inflight', type=int, default=5, help='range-coder chains in flight (coder HIP streams, <= 7)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--split-mfma', type=int, default=1, help='K > 0: decoder+head stages round-robin on K HIP streams of their own (0: one MFMA stream for everything)')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',

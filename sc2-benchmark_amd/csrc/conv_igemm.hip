@@ -949,12 +949,24 @@ __device__ __forceinline__ void conv_big_epilogue(const ConvArgs &p, unsigned ch
 //   before its first read, by every wave, ahead of the barrier that opens that read (RAW); a stage is re-filled only
 //   after a barrier that follows the lgkmcnt(0) of its last readers (WAR).
 template <int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_, int PH_,
-          int PW_, int BM_ = 256, int STAGES_ = 4>
+          int PW_, int BM_ = 256, int STAGES_ = 4, bool PATCH3_ = false, int PATCH_EXTRA_ = 64>
 struct Cfg8 {
+    // PATCH3 (window staging): stride-1 convolutions with static KH x KW and padding, runtime Cin % 32 == 0, slab-major
+    // K.  Along the flattened NHW pixel index the input pixel of output pixel m at tap (kh, kw) is
+    //     g(m) + kh W + kw,   g(m) = img HW + (oh - PH) W + (ow - PW),
+    // and g(m) - m changes only at output-row and image boundaries (not at all when OH x OW == H x W).  The pixel
+    // operand of all KH KW taps of a 32-channel slab is therefore one window of BM + PATCH_EXTRA consecutive input
+    // pixels: it is staged ONCE per slab (20-28 KB instead of KH KW im2col slabs of 16 KB through the L2 -> LDS
+    // path, which is what bounds these layers) and every tap reads it at a row shift of kh W + kw, out-of-image taps
+    // redirected to a zero row.  The dispatcher checks that the window of every tile fits (sc2_conv2d_fwd).
+    static constexpr bool PATCH3 = PATCH3_;
+    static constexpr int PATCH_ROWS = BM_ + PATCH_EXTRA_, PATCH_BYTES = PATCH_ROWS * 64;
+    static constexpr int PATCH_ZERO = 2 * PATCH_BYTES;          // 64 zero bytes behind the two patch buffers
+    static constexpr int PATCH_B0 = PATCH_ZERO + 64;            // weight-slab ring
     // BM = 128 with a 3-deep ring: 72 KB of LDS and <= 128 registers, so TWO workgroups share a CU and one's store
     // epilogue (x image, second GEMM, read-out: ~20 % of a fused conv + IGDN tile) overlaps the other's K loop
     static constexpr int BM = BM_, BN = BN_, BK = 32, KC = 4;
-    static constexpr int MIN_WAVES = BM_ == 128 ? 4 : 2;   // waves per SIMD the register allocation must allow
+    static constexpr int MIN_WAVES = (BM_ == 128 || (PATCH3_ && BN_ == 128)) ? 4 : 2;   // waves per SIMD the register allocation must allow
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
     static constexpr bool STATIC = STATIC_;
     static constexpr int CIN = CIN_, KH = KH_, KW = KW_, SH = SH_, SW = SW_, PH = PH_, PW = PW_;
@@ -966,7 +978,7 @@ struct Cfg8 {
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int STAGE_ROWS = WAVES_M * 16;
-    static constexpr int MAIN_LDS = STAGES * STAGE_BYTES;
+    static constexpr int MAIN_LDS = PATCH3_ ? PATCH_B0 + STAGES * B_BYTES : STAGES * STAGE_BYTES;
     static constexpr int EPI_LDS = STAGE_ROWS * (BN + 4) * 4;
     // fused conv + GDN1 (BN == 256 == Cout): x image 256 x 512 B + a 2 x 16 KB gamma-slab ring / store staging
     // (the f32-output form of the fused epilogue stages through 32 KB behind the image: full-height tile only)
@@ -994,7 +1006,7 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
     const int group = wave >> 2;   // waves w and w + 4 sit on the same SIMD and work out of step
     const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
 
-    const int Cin = C::STATIC ? C::CIN : p.Cin;
+    const int Cin = (C::STATIC && C::CIN > 0) ? C::CIN : p.Cin;   // (CIN 0: static filter geometry, runtime channels)
     const int KH = C::STATIC ? C::KH : p.KH;
     const int KW = C::STATIC ? C::KW : p.KW;
     const int SH = C::STATIC ? C::SH : p.SH;
@@ -1091,8 +1103,57 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
             wrap_k();
         }
     };
+    // ---- PATCH3: per-lane state of the shifted-window reads and the window fill
+    [[maybe_unused]] int pr_row[MT];        // window row of (m-tile i, this lane's fragment row) at the centre tap
+    [[maybe_unused]] uint32_t pr_mask[MT];  // bit (kh * 3 + kw): that tap's input pixel lies inside the image
+    [[maybe_unused]] const int frow_p = lane & 15, fq_p = lane >> 4;
+    [[maybe_unused]] long long g_base = 0;   // flattened NHW index of window row 0
+    if constexpr (C::PATCH3) {
+        if (tid < 16) reinterpret_cast<uint32_t *>(smem + C::PATCH_ZERO)[tid] = 0u;
+        const int HW = H * W;
+        const int m_last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+        {   // the smallest g of the tile: its first pixel, or the first pixel of a later image of the tile
+            const int img0 = m0 / p.OHW, rem0 = m0 - img0 * p.OHW;
+            const int oh0 = rem0 / p.OW, ow0 = rem0 - oh0 * p.OW;
+            g_base = (long long)img0 * HW + (oh0 - PH) * W + (ow0 - PW);
+            const int img1 = m_last / p.OHW;
+            for (int im = img0 + 1; im <= img1; ++im) {
+                const long long gi = (long long)im * HW - PH * W - PW;
+                g_base = gi < g_base ? gi : g_base;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = wm * C::WM + i * 16 + frow_p;
+            const int m = m0 + row < p.M ? m0 + row : m_last;   // (tail rows: any valid pixel, results discarded)
+            const int img = m / p.OHW, rem = m - img * p.OHW;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            uint32_t mk = 0;
+#pragma unroll
+            for (int t = 0; t < KH * KW; ++t) {
+                const int ih = oh - PH + t / KW, iw = ow - PW + t % KW;
+                mk |= (((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W)) ? (1u << t) : 0u;
+            }
+            pr_mask[i] = mk;
+            pr_row[i] = (int)((long long)img * HW + (oh - PH) * W + (ow - PW) - g_base);
+        }
+    }
+    auto issue_patch = [&](int cb) {   // window of channel slab cb -> patch buffer cb & 1 (this wave's rows)
+        unsigned char *Pb = smem + (cb & 1) * C::PATCH_BYTES;
+        const bool cb_ok = cb * 32 < Cin;
+#pragma unroll
+        for (int j = 0; j < (C::PATCH_ROWS / 16 + 7) / 8; ++j) {
+            const int q = j * 8 + wave;
+            if (q < C::PATCH_ROWS / 16) {   // wave-uniform
+                const long long g = g_base + q * 16 + (lane >> 2);   // flattened NHW input pixel
+                const bool ok = cb_ok & (g >= 0) & (g < (long long)p.N * H * W);
+                const long long off = ok ? g * Cin + cb * 32 + kc * 8 : zero_off;
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.x + off), (lds_ptr_t)(Pb + q * 1024), 16, 0, 0);
+            }
+        }
+    };
     auto issue_b = [&](int kt, int buf) {
-        unsigned char *Bb = smem + buf * C::STAGE_BYTES + C::A_BYTES;
+        unsigned char *Bb = C::PATCH3 ? smem + C::PATCH_B0 + buf * C::B_BYTES : smem + buf * C::STAGE_BYTES + C::A_BYTES;
         const bool kt_ok = kt < KT;
 #pragma unroll
         for (int j = 0; j < B_IPW; ++j) {
@@ -1113,21 +1174,27 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
 #pragma unroll
     for (int i = 0; i < MT; ++i) a_rd[i] = (uint32_t)lds_off(wm * C::WM + i * 16 + frow, fq);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b_rd[j] = (uint32_t)(C::A_BYTES + lds_off(wn * C::WN + j * 16 + frow, fq));
+    for (int j = 0; j < NT; ++j)
+        b_rd[j] = (uint32_t)((C::PATCH3 ? C::PATCH_B0 : C::A_BYTES) + lds_off(wn * C::WN + j * 16 + frow, fq));
 
+    if constexpr (C::PATCH3) issue_patch(0);
 #pragma unroll
     for (int st = 0; st < S - 1; ++st) {
-        issue_a(st);
+        if constexpr (!C::PATCH3) issue_a(st);
         issue_b(st, st);
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");   // slab 0 has landed (this wave's share)
+    constexpr int LW = C::PATCH3 ? B_IPW : L;   // counted loads per slab (the window loads are older than any slab waited for)
+    [[maybe_unused]] int p_cb = 0, p_tap = 0;   // PATCH3: channel slab and tap of k-step kt
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LW) : "memory");   // slab 0 has landed (this wave's share)
     __builtin_amdgcn_s_barrier();
     if (group == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
     uint4 bv[NT];
     for (int kt = 0; kt < KT; ++kt) {
-        const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
+        const uint32_t sb = lds_base + (uint32_t)((kt % S) * (C::PATCH3 ? C::B_BYTES : C::STAGE_BYTES));
         const int nbuf = (kt + S - 1) % S;
+        [[maybe_unused]] const uint32_t pbase = lds_base + (uint32_t)((p_cb & 1) * C::PATCH_BYTES);
+        [[maybe_unused]] const int p_shift = (p_tap / KW) * W + p_tap % KW;
 #pragma unroll
         for (int ph = 0; ph < PHASES; ++ph) {
             // ---- load interval: this phase's fragments, a share of slab kt+S-1's loads
@@ -1137,11 +1204,24 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
                 for (int j = 0; j < NT; ++j) bv[j] = lds_read16(sb + b_rd[j]);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = lds_read16(sb + a_rd[4 * ph + i]);
-            if (ph == 0) issue_a(nbuf);
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (C::PATCH3) {
+                    const int r = pr_row[4 * ph + i] + p_shift;
+                    const uint32_t in_img = (pr_mask[4 * ph + i] >> p_tap) & 1u;
+                    const uint32_t addr = in_img ? pbase + (uint32_t)lds_off(r, fq_p) : lds_base + C::PATCH_ZERO + fq_p * 16;
+                    av[i] = lds_read16(addr);
+                } else {
+                    av[i] = lds_read16(sb + a_rd[4 * ph + i]);
+                }
+            }
+            if constexpr (C::PATCH3) {
+                if (ph == 0 && p_tap == 0) issue_patch(p_cb + 1);   // next slab's window (its buffer was last read a slab ago)
+            } else {
+                if (ph == 0) issue_a(nbuf);
+            }
             if (ph == PHASES - 1) issue_b(kt + S - 1, nbuf);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (ph == PHASES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");   // slab kt+1 landed
+            if (ph == PHASES - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * LW) : "memory");   // slab kt+1 landed
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             // ---- MFMA interval (the partner group is in its load interval)
@@ -1166,6 +1246,9 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (C::PATCH3) {
+            if (++p_tap == KH * KW) { p_tap = 0; ++p_cb; }
         }
     }
     if (group == 0) __builtin_amdgcn_s_barrier();   // re-align the groups
@@ -1548,6 +1631,12 @@ using R_dec2 = Cfg4<true, 512, 2, 2, 1, 1, 0, 0>;
 using R_dec4 = Cfg4<true, 256, 2, 2, 1, 1, 1, 1>;
 using RG_256 = Cfg4<false, 0, 0, 0, 0, 0, 0, 0>;
 using BG_128 = Cfg8<128, 4, 2, false, 0, 0, 0, 0, 0, 0, 0>;
+// 3x3 stride-1 pad-1 layers of the ResNet tail: the nine taps read one staged window (Cfg8::PATCH3)
+using P3_256 = Cfg8<256, 2, 4, true, 0, 3, 3, 1, 1, 1, 1, 256, 4, true>;
+using P3_128 = Cfg8<128, 4, 2, true, 0, 3, 3, 1, 1, 1, 1, 256, 4, true>;
+// 2x2 stride-1 decoder layers (dec.conv2: pad 0, dec.conv4: pad 1): windows of up to 448 pixels (tiles that cross an image)
+using P2_dec2 = Cfg8<256, 2, 4, true, 0, 2, 2, 1, 1, 0, 0, 256, 4, true, 192>;
+using P2_dec4 = Cfg8<256, 2, 4, true, 0, 2, 2, 1, 1, 1, 1, 256, 4, true, 192>;
 
 template <class C>
 bool matches(const ConvArgs &a) {
@@ -1688,6 +1777,34 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     if (rows == 48 && matches<C_conv2>(a)) return launch<C_conv2>(a, s);
     if (rows == 48 && matches<C_gdn48>(a)) return launch<C_gdn48>(a, s);
     if (rows == 32 && matches<C_conv4>(a)) return launch<C_conv4>(a, s);
+    {
+        // stride-1 layers with slab-major K: one staged window per 32-channel slab serves all taps (Cfg8::PATCH3).
+        // Measured (MI355X, bs 256): 3x3 layers of the ResNet tail -24 % (layer2) / -22 % (layer3) with the 128-wide
+        // tile; the 2x2 decoder layers +25 % SLOWER (their four taps re-read through L2 cheaply, the shifted reads cost
+        // address arithmetic and LDS bank conflicts), so those stay on the im2col gather unless asked for.
+        // SC2_CONV_PATCH3: 0 = off, 256 = the 256-wide tile for the 3x3 layers too, 2 = also the 2x2 decoder layers
+        const char *p3 = getenv("SC2_CONV_PATCH3");
+        const int mode = p3 ? atoi(p3) : 1;
+        const bool base_ok = mode != 0 && d->stride_h == 1 && d->stride_w == 1 && d->Cin % 32 == 0 &&
+                             (d->k_order & SC2_K_SLAB_MAJOR) && !scatter && d->a_op == SC2_AOP_NONE;
+        // rows of the window a 256-pixel tile can need: its own pixels, the taps' reach, and the drift of g(m) - m over
+        // the output rows and image boundaries the tile crosses
+        const long long drift_row = OW > d->W ? OW - d->W : d->W - OW;
+        const long long hw = (long long)d->H * d->W, ohw = (long long)OH * OW;
+        const long long drift_img = hw > ohw ? hw - ohw : ohw - hw;
+        const long long window = 256 + (long long)(d->KH - 1) * d->W + d->KW + (256 / OW + 2) * drift_row +
+                                 (256 / ohw + 1) * drift_img;
+        if (base_ok && d->KH == 3 && d->KW == 3 && d->pad_h == 1 && d->pad_w == 1 && d->Cout % 128 == 0 &&
+            d->out_format == SC2_OUT_BF16_NHWC && !fused && window <= P3_128::PATCH_ROWS) {
+            if (d->Cout % 256 == 0 && mode == 256) return launch8<P3_256>(a, s);
+            return launch8<P3_128>(a, s);
+        }
+        if (base_ok && mode == 2 && d->KH == 2 && d->KW == 2 && d->Cout == 256 && window <= P2_dec2::PATCH_ROWS &&
+            big_tile_eligible(d, M, K)) {
+            if (d->pad_h == 0 && d->pad_w == 0) return launch8<P2_dec2>(a, s);
+            if (d->pad_h == 1 && d->pad_w == 1) return launch8<P2_dec4>(a, s);
+        }
+    }
     const bool big = big_tile_eligible(d, M, K);
     if (big && d->Cout % 256 == 0) {
         const char *half = getenv("SC2_CONV_HALF");

@@ -100,14 +100,16 @@ def test_conv_igemm(S, dev, cin, cout, k, stride, pad, H, W, N):
     (32, 128, 3, 1, 1, 17, 19, 2),     # generic 128-wide 8-wave tile
     (24, 384, 3, 2, 1, 30, 30, 2),     # Cout 384: 128-wide tiles, K = 216 (tail slab)
 ])
-@pytest.mark.parametrize('half', ['0', '1', 'r4'])
+@pytest.mark.parametrize('half', ['0', '1', 'r4', 'w2'])
 def test_conv_big_tile(S, dev, monkeypatch, cin, cout, k, stride, pad, H, W, N, half):
     """The 8-wave staggered 256-row kernel (forced here: its dispatch thresholds need >= 49152 rows); half = '1':
     the 128-row twins of the two decoder geometries (two workgroups per CU); 'r4': the 4-wave register-tile kernel
-    (128 x 128 per wave, bf16 NHWC outputs of 256-wide tiles; SC2_CONV_BIG4 A/B variant)."""
+    (128 x 128 per wave, bf16 NHWC outputs of 256-wide tiles; SC2_CONV_BIG4 A/B variant); 'w2': one staged input
+    window per channel slab for the 2x2 decoder geometries (SC2_CONV_PATCH3=2)."""
     monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
-    monkeypatch.setenv('SC2_CONV_HALF', '0' if half == 'r4' else half)
+    monkeypatch.setenv('SC2_CONV_HALF', half if half in ('0', '1') else '0')
     monkeypatch.setenv('SC2_CONV_BIG4', '1' if half == 'r4' else '0')
+    monkeypatch.setenv('SC2_CONV_PATCH3', '2' if half == 'w2' else '0')   # 'w2': window-staged 2x2 decoder geometries
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.randn(N, cin, H, W, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
@@ -236,6 +238,35 @@ def test_conv_fused_gdn(S, R, dev, cin, cout, k, stride, pad, inverse):
                          256, 1, 1, 1, 0, epilogue=S.hip.EPI_FUSED_GDN,
                          ep_x=S.hip.pack_conv_weight(torch.eye(256).reshape(256, 256, 1, 1).to(dev)),
                          ep_beta=torch.ones(256, device=dev))
+
+
+@pytest.mark.parametrize('cin,cout,H,W,N', [
+    (128, 128, 28, 28, 3),     # layer2 geometry: tiles cross image rows, ragged last tile
+    (64, 256, 14, 14, 9),      # layer3 geometry: a 256-pixel tile spans two images
+    (32, 256, 7, 7, 11),       # layer4 geometry: five images per tile, a single channel slab
+    (96, 384, 5, 31, 2),       # widest supported row, Cout 384 (128-wide tiles), three channel slabs
+])
+def test_conv3x3_window_kernel(S, dev, monkeypatch, cin, cout, H, W, N):
+    """3x3 stride-1 pad-1 convolution with ONE staged input window per 32-channel slab serving all nine taps
+    (Cfg8::PATCH3) against the f32 op on the bf16-rounded operands and against the im2col-gather kernels; image
+    borders, tiles spanning images, bias + ReLU epilogue."""
+    g = torch.Generator().manual_seed(cin + cout + W)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(bf16_round(x), bf16_round(w), padding=1) + bias.reshape(1, -1, 1, 1))
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev), cin)
+    order = S.hip.preferred_k_order(cin, 3, 3)
+    assert order & S.hip.K_SLAB_MAJOR
+    wp = S.hip.pack_conv_weight(w.to(dev), order)
+    outs = {}
+    for flag in ('1', '0', '256'):     # window kernel (128-wide tiles), im2col gather, window kernel (256-wide if it divides)
+        monkeypatch.setenv('SC2_CONV_PATCH3', flag)
+        outs[flag] = S.hip.conv2d_fwd(x_nhwc, wp, cout, 3, 3, 1, 1, epilogue=S.hip.EPI_BIAS_RELU, ep_beta=bias.to(dev),
+                                      k_order=order)
+    assert_close_bf16(outs['1'].permute(0, 3, 1, 2), ref, '3x3 window kernel')
+    assert_close_bf16(outs['1'], outs['0'], 'window vs gather kernel', extra=2.0 ** -7)
+    assert_close_bf16(outs['256'], outs['0'], 'window (256-wide) vs gather kernel', extra=2.0 ** -7)
 
 
 @pytest.mark.parametrize('half', ['0', '1', 'r4'])
