@@ -50,6 +50,7 @@ struct ConvArgs {
     int k_slab_major;   // K ordered (channel slab of 32, tap, channel) instead of (tap, channel): needs Cin % 32 == 0
     int touch; // 1: pull the epilogue operand's lines into L2 with one dword load per 128-byte line before the K loop
     int dbg;   // development switches (SC2_CONV_DEBUG): bit 0 skips the store epilogue, bit 1 the K loop
+    unsigned x_bytes, w_bytes;   // sizes of x and of the packed weights when both are < 2 GB (buffer-addressed loads), else 0
     int o_H, o_W, o_sh, o_sw, o_h0, o_w0;   // NHWC output scatter (o_H == 0: dense): pixel (oh, ow) -> (oh*o_sh+o_h0, ..)
 };
 
@@ -105,6 +106,23 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
 __device__ uint4 g_zero16;   // 16 zero bytes: the source of every out-of-image / K-tail chunk
+
+// Buffer descriptors and buffer-addressed direct-to-LDS loads.  The host pass of hipcc parses kernel bodies too and has
+// neither the type nor the builtins: it gets stand-ins (a kernel whose body fails to parse silently loses its host stub).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)bytes, 0x00020000);
+}
+// 16 bytes per lane from base + voff + soff (voff per lane, out of range -> zeros; soff scalar) to LDS at dst + 16 * lane
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, (int)voff, (int)soff, 0, 0);
+}
+#else
+typedef int buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *, uint32_t) { return 0; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, uint32_t) {}
+#endif
 
 __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
     uint4 v;
@@ -1031,6 +1049,47 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
     const int kc = (lane & 3) ^ ((lane >> 3) & 3);
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_zero16);
     const long long zero_off = zero - p.x, zero_off_w = zero - p.w;
+    // BUF: static slab-aligned geometries issue their direct-to-LDS loads through buffer descriptors: the per-lane
+    // offset is a 32-bit constant of the tile, the slab's position (tap, channel block / k-slab) a scalar offset, and an
+    // out-of-image or tail lane is sent out of range (the load returns zeros) - two or three vector instructions per
+    // load instead of the ~15 of the 64-bit address arithmetic, which made the load interval the longer half of the
+    // two-group schedule.  (Needs x and w below 2 GB: ConvArgs::x_bytes, checked by the launcher.)
+#ifndef SC2_CONV_NO_BUF
+    constexpr bool BUF = C::STATIC && (C::CIN % 32 == 0) && C::KH * C::KW <= 32;
+#else
+    constexpr bool BUF = false;   // A/B build (tools/build_variant.sh nobuf -DSC2_CONV_NO_BUF)
+#endif
+    constexpr uint32_t OOB = 0x80000000u;
+    [[maybe_unused]] buf_rsrc_t rs_x, rs_w;
+    [[maybe_unused]] uint32_t a_vo[A_IPW], a_tapmask[A_IPW], b_vo[B_IPW], pw_vo[(C::PATCH_ROWS / 16 + 7) / 8];
+    if constexpr (BUF) {
+        const long long shift = ((long long)PH * W + PW) * Cin;   // elements: the descriptor starts at tap (0, 0) of pixel (0, 0)
+        rs_x = make_rsrc(p.x - (C::PATCH3 ? 0 : shift), p.x_bytes + (C::PATCH3 ? 0u : (uint32_t)(shift * 2)));
+        rs_w = make_rsrc(p.w, p.w_bytes);
+        if constexpr (!C::PATCH3) {
+#pragma unroll
+            for (int j = 0; j < A_IPW; ++j) {
+                const int m = m0 + (j * 8 + wave) * 16 + (lane >> 2);
+                const bool ok = m < p.M;
+                const int mm = ok ? m : 0;
+                const int img = mm / p.OHW;
+                const int rem = mm - img * p.OHW;
+                const int oh = rem / p.OW;
+                const int ow = rem - oh * p.OW;
+                a_vo[j] = (uint32_t)((((long long)img * H + oh * SH) * W + ow * SW) * Cin * 2 + kc * 16);
+                uint32_t mk = 0;
+#pragma unroll
+                for (int t = 0; t < KH * KW; ++t) {
+                    const int ih = oh * SH - PH + t / KW, iw = ow * SW - PW + t % KW;
+                    mk |= (ok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W)) ? (1u << t) : 0u;
+                }
+                a_tapmask[j] = mk;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_IPW; ++j)
+            b_vo[j] = (uint32_t)(((long long)(n0 + (j * 8 + wave) * 16 + (lane >> 2)) * p.b_row_stride + kc * 8) * 2);
+    }
     long long a_off[A_IPW];
     int a_ih0[A_IPW], a_iw0[A_IPW];
     bool a_ok[A_IPW];
@@ -1090,6 +1149,19 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
             tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
         }
         const bool tap_ok = aligned ? (next_a < KT) : (t_kh < KH);   // false for the K tail and the dummy slabs past KT
+        if constexpr (BUF) {
+            int tap, cb;   // scalar: (tap, channel block) of the slab
+            if (p.k_slab_major) { cb = next_a / (KH * KW); tap = next_a - cb * (KH * KW); }
+            else { tap = next_a / spt; cb = next_a - tap * spt; }
+            const uint32_t soff = (uint32_t)(((tap / KW) * W + tap % KW) * Cin + cb * 32) * 2u;
+#pragma unroll
+            for (int j = 0; j < A_IPW; ++j) {
+                const uint32_t vo = (tap_ok && ((a_tapmask[j] >> tap) & 1u)) ? a_vo[j] : OOB;
+                buf_load_lds16(rs_x, (lds_ptr_t)(Ab + (j * 8 + wave) * 1024), vo, soff);
+            }
+            ++next_a;
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < A_IPW; ++j) {
             const int ih = a_ih0[j] + t_kh, iw = a_iw0[j] + t_kw;
@@ -1138,9 +1210,25 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
             pr_row[i] = (int)((long long)img * HW + (oh - PH) * W + (ow - PW) - g_base);
         }
     }
+    if constexpr (BUF && C::PATCH3) {
+#pragma unroll
+        for (int j = 0; j < (C::PATCH_ROWS / 16 + 7) / 8; ++j) {
+            const long long g = g_base + (j * 8 + wave) * 16 + (lane >> 2);
+            pw_vo[j] = ((g >= 0) & (g < (long long)p.N * H * W)) ? (uint32_t)(g * Cin * 2 + kc * 16) : OOB;
+        }
+    }
     auto issue_patch = [&](int cb) {   // window of channel slab cb -> patch buffer cb & 1 (this wave's rows)
         unsigned char *Pb = smem + (cb & 1) * C::PATCH_BYTES;
         const bool cb_ok = cb * 32 < Cin;
+        if constexpr (BUF) {
+#pragma unroll
+            for (int j = 0; j < (C::PATCH_ROWS / 16 + 7) / 8; ++j) {
+                const int q = j * 8 + wave;
+                if (q < C::PATCH_ROWS / 16)   // wave-uniform
+                    buf_load_lds16(rs_x, (lds_ptr_t)(Pb + q * 1024), cb_ok ? pw_vo[j] : OOB, (uint32_t)cb * 64u);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < (C::PATCH_ROWS / 16 + 7) / 8; ++j) {
             const int q = j * 8 + wave;
@@ -1155,6 +1243,13 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
     auto issue_b = [&](int kt, int buf) {
         unsigned char *Bb = C::PATCH3 ? smem + C::PATCH_B0 + buf * C::B_BYTES : smem + buf * C::STAGE_BYTES + C::A_BYTES;
         const bool kt_ok = kt < KT;
+        if constexpr (BUF) {
+            const uint32_t soff = (uint32_t)(kt_ok ? kt : KT - 1) * (uint32_t)p.b_kt_stride * 2u;   // (slabs past KT are never read)
+#pragma unroll
+            for (int j = 0; j < B_IPW; ++j)
+                buf_load_lds16(rs_w, (lds_ptr_t)(Bb + (j * 8 + wave) * 1024), b_vo[j], soff);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < B_IPW; ++j) {
             const long long off = kt_ok ? b_off[j] + (long long)kt * p.b_kt_stride : zero_off_w;
@@ -1231,7 +1326,9 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 uint4 v = av[i];
-                v.x &= amask; v.y &= amask; v.z &= amask; v.w &= amask;
+                if (p.aop == SC2_AOP_ABS) {   // uniform: only the GDN GEMMs take |x|
+                    v.x &= amask; v.y &= amask; v.z &= amask; v.w &= amask;
+                }
                 af[i] = __builtin_bit_cast(bf16x8_t, v);
             }
 #pragma unroll
@@ -1746,6 +1843,13 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.Kpad = d->Kpad; a.KT = 0; a.n_ntiles = 0;
     a.aop = d->a_op; a.epi = d->epilogue; a.out = d->out_format;
     a.g_pitch = sc2_conv_weight_pitch(d->Cout);
+    {
+        const unsigned long long xb = (unsigned long long)d->N * d->H * d->W * d->Cin * 2ull;
+        const unsigned long long wb = (unsigned long long)d->Cout_pad * d->Kpad * 2ull;
+        const bool fits = xb < 0x7FF00000ull && wb < 0x7FF00000ull;
+        a.x_bytes = fits ? (unsigned)xb : 0u;
+        a.w_bytes = fits ? (unsigned)wb : 0u;
+    }
     a.k_slab_major = (d->k_order & SC2_K_SLAB_MAJOR) ? 1 : 0;
     a.b_kt_stride = (d->k_order & SC2_K_B_TILE_MAJOR) ? d->Cout_pad * 32 : 32;
     a.b_row_stride = (d->k_order & SC2_K_B_TILE_MAJOR) ? 32 : d->Kpad;
@@ -1785,7 +1889,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         // SC2_CONV_PATCH3: 0 = off, 256 = the 256-wide tile for the 3x3 layers too, 2 = also the 2x2 decoder layers
         const char *p3 = getenv("SC2_CONV_PATCH3");
         const int mode = p3 ? atoi(p3) : 1;
-        const bool base_ok = mode != 0 && d->stride_h == 1 && d->stride_w == 1 && d->Cin % 32 == 0 &&
+        const bool base_ok = mode != 0 && a.x_bytes != 0 && d->stride_h == 1 && d->stride_w == 1 && d->Cin % 32 == 0 &&
                              (d->k_order & SC2_K_SLAB_MAJOR) && !scatter && d->a_op == SC2_AOP_NONE;
         // rows of the window a 256-pixel tile can need: its own pixels, the taps' reach, and the drift of g(m) - m over
         // the output rows and image boundaries the tile crosses
@@ -1806,6 +1910,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         }
     }
     const bool big = big_tile_eligible(d, M, K);
+    if (big && d->Cout % 256 == 0 && a.x_bytes == 0) return launch8<BG_256>(a, s);   // >= 2 GB: 64-bit addressing only
     if (big && d->Cout % 256 == 0) {
         const char *half = getenv("SC2_CONV_HALF");
         if ((half ? atoi(half) : 0) && d->out_format == SC2_OUT_BF16_NHWC) {
