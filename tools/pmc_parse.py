@@ -15,7 +15,7 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
                 res[name][counter].append(val)
 table = {}
 for name, d in res.items():
-    if not any(q in name for q in ('conv_igemm', 'conv2x2', 'eb_', 'rans', 'nhwc')):
+    if not any(q in name for q in ('conv_igemm', 'conv2x2', 'conv0_gdn96', 'conv5s2', 'conv1x1_stream', 'eb_', 'rans', 'nhwc')):
         continue
     fetch = sorted(d.get('FETCH_SIZE', [0]))
     write = sorted(d.get('WRITE_SIZE', [0]))
@@ -23,13 +23,15 @@ for name, d in res.items():
     f = fetch[len(fetch) // 2] * 1024 * 2
     w = write[len(write) // 2] * 1024
     short = name.split('Cfg')[-1][:60] if 'Cfg' in name else name.replace('void ', '').replace('(anonymous namespace)::', '')[:60]
+    if 'conv5s2_patch' in name:
+        short = 'conv5s2_patch_kernel' + short[:40]
     table[short] = {'fetch_bytes_corrected': f, 'write_bytes': w, 'hbm_bytes': f + w, 'launches': len(fetch)}
 for k, v in sorted(table.items(), key=lambda kv: -kv[1]['hbm_bytes']):
     print('{:<62} fetch {:9.1f} MB  write {:9.1f} MB  total {:9.1f} MB  (n={})'.format(k, v['fetch_bytes_corrected'] / 1e6, v['write_bytes'] / 1e6, v['hbm_bytes'] / 1e6, v['launches']))
 json.dump(table, open(os.path.join(out, 'traffic_raw.json'), 'w'), indent=1)
 
 # bench.py tags of the bottleneck launches -> HBM-side bytes per launch at the profiled batch (profiles/traffic.json)
-TAGS = {'enc.conv0+enc.gdn1': '<128, 96, 2, 2, true, 8, 5, 3', 'enc.conv2+enc.gdn3': '<128, 48, 4, 1, true, 96, 5, 5',
+TAGS = {'enc.conv0+enc.gdn1': 'conv0_gdn96_kernel', 'enc.conv2+enc.gdn3': 'conv5s2_patch_kernel',
         'enc.conv4': '<128, 32, 4, 1, true, 48, 2, 2', 'dec.conv0+dec.igdn1': 'conv2x2_gdn512_kernel',
         'dec.conv2+dec.igdn3': '8<256, 2, 4, true, 512, 2, 2', 'dec.conv4': '8<256, 2, 4, true, 256, 2, 2'}
 tags = {}
