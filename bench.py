@@ -9,9 +9,11 @@ reference's evaluation mode after update() (sc2bench/models/backbone.py:229-233)
     encoder (3 MFMA convs + 2 GDN1) -> symbols -> rANS encode (one stream per image) -> rANS decode ->
     dequantise -> decoder (3 MFMA convs + 2 inverse GDN1) -> ResNet-50 layer2..fc -> logits.
 Nothing is skipped: the byte streams are really produced and really decoded; bpp is 8 * bytes / pixels.
-Steps are software-pipelined over HIP streams (one MFMA stream; the serial range coder of batch i runs on one of
-three coder streams and overlaps the MFMA kernels of the neighbouring batches); exactly K steps start and
-complete inside the timed region, bracketed by barrier + synchronize; the wall time is the max over ranks.  One process per GPU; the path shards by image, so
+Steps are software-pipelined over HIP streams (the encoder stage on one stream, decoder + head on a second; the serial
+range coder of batch i runs on one of five coder streams and overlaps the MFMA kernels of the neighbouring batches);
+exactly K steps start and complete inside the timed region, bracketed by barrier + synchronize, so the region carries
+one fill and drain of that pipeline (one coder latency, ~24 ms: 5 % of the default K = 100 steps, 13 % of K = 20); the
+wall time is the max over ranks.  One process per GPU; the path shards by image, so
 N GPUs = N independent shards, no data-path collective ("weak" scaling, bs per GPU fixed).
 
 Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant MFMA kernel, HIP events on
@@ -192,8 +194,8 @@ def train_bench(args, dev, rank, world, distributed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--inflight', type=int, default=5, help='range-coder chains in flight (coder HIP streams, <= 7)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

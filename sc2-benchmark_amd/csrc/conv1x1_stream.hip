@@ -34,7 +34,8 @@ struct StreamArgs {
     unsigned *unit_ctr;                   // claims so far (claim c = unit c + 2 * gridDim.x); zero between launches
 };
 
-constexpr int BM = 128, BNC = 256, MT = 8, NT = 2;
+// Unit shapes (pixels x channels): 128 x 256 for K in {128, 256} when Cout % 256 == 0, 128 x 128 for the narrow layers,
+// 64 x 128 for K = 512 (its weights - 16 channels x 512 per wave - still fit the registers: 64 VGPRs).
 
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -46,13 +47,15 @@ __device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f3
 // The tail of a unit (next unit's loads, this unit's stores) is straight-line code: addresses are clamped instead of
 // guarded, so the compiler's vmcnt bookkeeping stays exact and its wait for the loads is vmcnt(<stores issued after
 // them>) -- never a wait for a store acknowledgement.
-template <int K, bool RES>
+template <int K, int BM, int BNC, bool RES>
 __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs p) {
+    constexpr int MT = BM / 16, NT = BNC / 16 / 8;   // per wave: all pixel tiles x its 16 NT channels
+    constexpr int CPI = BNC / 8;               // 16-byte chunks per image row
     constexpr int KS = K / 32;                 // k-steps
     constexpr int A_BYTES = BM * K * 2;        // A tile
     constexpr int CPR = K / 8;                 // 16-byte chunks per A row
     constexpr int A_Q = BM * CPR / 512;        // A chunks per thread
-    constexpr int IMG_Q = BM * (BNC / 8) / 512;   // image chunks per thread (8)
+    constexpr int IMG_Q = BM * CPI / 512;      // image chunks per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int next_slot;
     unsigned char *At = smem;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
 #pragma unroll
             for (int k = 0; k < IMG_Q; ++k) {
                 const int q = tid + 512 * k;
-                const int row = q >> 5, c = q & 31;
+                const int row = q / CPI, c = q % CPI;
                 const int m = min(m0 + row, p.M - 1);
                 r_next[k] = *reinterpret_cast<const u32x4_t *>(p.res + (long long)m * Cout + chunk * BNC + c * 8);
             }
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
 #pragma unroll
             for (int k = 0; k < IMG_Q; ++k) {
                 const int q = tid + 512 * k;
-                const int row = q >> 5, c = q & 31;
+                const int row = q / CPI, c = q % CPI;
                 *reinterpret_cast<u32x4_t *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4)) = r_next[k];
             }
         }
@@ -198,8 +201,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
 #pragma unroll
             for (int k = 0; k < IMG_Q; ++k) {
                 const int q = tq + 512 * k;
-                int row = q >> 5;
-                const int c = q & 31;
+                int row = q / CPI;
+                const int c = q % CPI;
                 row = m0 + row < p.M ? row : 0;      // past the end: row 0 of the tile again (same data, same address)
                 yo[(long long)(m0 + row) * (Cout / 8) + c] =
                     *reinterpret_cast<const uint4 *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4));
@@ -222,12 +225,20 @@ constexpr int kMaxDev = 16, kRing = 256;
 unsigned *g_ring[kMaxDev] = {};
 std::atomic<unsigned> g_seq{0};
 
-template <int K, bool RES>
-int launch_stream(const StreamArgs &a, hipStream_t s) {
+template <int K, int BM, int BNC, bool RES>
+int launch_stream(const StreamArgs &a0, hipStream_t s) {
     constexpr int lds = BM * K * 2 + BM * BNC * 2;
+    StreamArgs a = a0;
+    a.n_chunks = a.Cout / BNC;
+    const long long units = (((long long)a.M + BM - 1) / BM) * a.n_chunks;
+    if (units >= 0x7FFFFFFFLL - 1024) {
+        sc2_set_error("conv1x1_stream: too many units");
+        return SC2_ERR_UNSUPPORTED;
+    }
+    a.n_units = (int)units;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, RES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, BM, BNC, RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -257,7 +268,7 @@ int launch_stream(const StreamArgs &a, hipStream_t s) {
     const int grid = a.n_units < g_cus ? a.n_units : g_cus;
     StreamArgs b = a;
     b.unit_ctr = g_ring[dev] + (g_seq.fetch_add(1) % kRing);
-    hipLaunchKernelGGL((conv1x1_stream_kernel<K, RES>), dim3(grid), dim3(512), lds, s, b);
+    hipLaunchKernelGGL((conv1x1_stream_kernel<K, BM, BNC, RES>), dim3(grid), dim3(512), lds, s, b);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -265,7 +276,7 @@ int launch_stream(const StreamArgs &a, hipStream_t s) {
 }  // namespace
 
 extern "C" int sc2_conv1x1_stream_supported(int Cin, int Cout, int stride) {
-    return (Cin == 128 || Cin == 256) && Cout >= 256 && Cout % 256 == 0 && (stride == 1 || stride == 2) ? 1 : 0;
+    return (Cin == 128 || Cin == 256 || Cin == 512) && Cout >= 128 && Cout % 128 == 0 && (stride == 1 || stride == 2) ? 1 : 0;
 }
 
 extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y,
@@ -273,7 +284,7 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
     SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv1x1_stream: null argument");
     SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv1x1_stream: non-positive dimension");
     SC2_REQUIRE(sc2_conv1x1_stream_supported(Cin, Cout, stride), SC2_ERR_UNSUPPORTED,
-                "conv1x1_stream: needs Cin in {128, 256}, Cout %% 256 == 0, stride 1 or 2 (got %d -> %d, stride %d)", Cin,
+                "conv1x1_stream: needs Cin in {128, 256, 512}, Cout %% 128 == 0, stride 1 or 2 (got %d -> %d, stride %d)", Cin,
                 Cout, stride);
     StreamArgs a;
     a.x = static_cast<const uint16_t *>(x);
@@ -288,12 +299,17 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
     const long long M = (long long)N * a.OHW;
     SC2_REQUIRE(M < 0x7FFFFFFFLL - 256, SC2_ERR_UNSUPPORTED, "conv1x1_stream: N*OH*OW = %lld exceeds 2^31", M);
     a.M = (int)M; a.Cout = Cout; a.stride = stride; a.relu = relu ? 1 : 0;
-    a.n_chunks = Cout / BNC;
-    const long long units = ((M + BM - 1) / BM) * a.n_chunks;
-    SC2_REQUIRE(units < 0x7FFFFFFFLL - 1024, SC2_ERR_UNSUPPORTED, "conv1x1_stream: too many units");
-    a.n_units = (int)units;
+    a.n_chunks = 0; a.n_units = 0;   // set per unit shape by the launcher
     a.unit_ctr = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a.res) return Cin == 128 ? launch_stream<128, true>(a, s) : launch_stream<256, true>(a, s);
-    return Cin == 128 ? launch_stream<128, false>(a, s) : launch_stream<256, false>(a, s);
+    // unit shape: K = 512 -> 64 x 128; otherwise 128 x 256 if it divides Cout, else 128 x 128
+#define SC2_STREAM_GO(KK, BMM, BNN) return a.res ? launch_stream<KK, BMM, BNN, true>(a, s) : launch_stream<KK, BMM, BNN, false>(a, s)
+    if (Cin == 512) SC2_STREAM_GO(512, 64, 128);
+    if (Cout % 256 == 0) {
+        if (Cin == 128) SC2_STREAM_GO(128, 128, 256);
+        SC2_STREAM_GO(256, 128, 256);
+    }
+    if (Cin == 128) SC2_STREAM_GO(128, 128, 128);
+    SC2_STREAM_GO(256, 128, 128);
+#undef SC2_STREAM_GO
 }

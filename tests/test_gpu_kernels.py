@@ -391,7 +391,11 @@ def test_conv5s2_patch_kernel(S, R, dev, N, H, W, fused):
 
 
 @pytest.mark.parametrize('cin,cout,stride,N,H,W,res,relu', [(128, 512, 1, 3, 9, 11, True, True), (256, 1024, 1, 2, 14, 14, True, True),
-                                                           (256, 512, 2, 2, 13, 10, False, False), (128, 256, 1, 40, 20, 20, False, True)])
+                                                           (256, 512, 2, 2, 13, 10, False, False), (128, 256, 1, 40, 20, 20, False, True),
+                                                           (512, 128, 1, 5, 17, 9, False, True),      # 64 x 128 units, K = 512
+                                                           (512, 256, 2, 3, 15, 15, True, True),      # two 128-channel chunks
+                                                           (256, 128, 1, 7, 12, 12, False, True),     # 128 x 128 units
+                                                           (128, 384, 1, 2, 10, 10, True, True)])     # Cout % 256 != 0
 def test_conv1x1_stream(S, dev, cin, cout, stride, N, H, W, res, relu):
     """Persistent streaming 1x1 conv (+ bias, residual, ReLU) against the f32 op on the bf16-rounded operands and
     against the generic tile kernel; several units per workgroup, ragged last pixel tile, stride-2 gather."""

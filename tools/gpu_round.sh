@@ -7,7 +7,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
-python bench.py --steps 20 --warmup 3 "$@" > $OUT/bench.json 2> $OUT/bench.err
+python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 python tools/layer_times.py --bs 256 > $OUT/layer_times.log 2>&1
 ROOT=$(pwd)
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof_bench.err)
