@@ -12,8 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libsc2amd.so')
-SOURCES = ['abi.cpp', 'cdf_host.cpp', 'layout.hip', 'conv_igemm.hip', 'conv_gdn512.hip', 'conv0_gdn96.hip', 'conv1x1_stream.hip', 'conv_wgrad.hip', 'gdn_bwd.hip', 'entropy.hip', 'gaussian.hip', 'rans.hip']
-HEADERS = [os.path.join(CSRC, 'sc2_common.h'), os.path.join(HERE, '..', 'include', 'sc2_bottleneck.h')]
+# (the implicit-GEMM templates of conv_igemm_impl.h are instantiated in eight translation units so that they compile in
+#  parallel: the slowest ones first)
+SOURCES = ['conv_inst_e.hip', 'conv_inst_f.hip', 'conv_inst_g.hip', 'conv_inst_h.hip', 'conv_inst_a.hip', 'conv_inst_b.hip',
+           'conv_inst_c.hip', 'conv_inst_d.hip', 'conv_igemm.hip', 'conv_gdn512.hip', 'conv0_gdn96.hip', 'conv1x1_stream.hip',
+           'conv_wgrad.hip', 'gdn_bwd.hip', 'entropy.hip', 'gaussian.hip', 'rans.hip', 'layout.hip', 'abi.cpp', 'cdf_host.cpp']
+HEADERS = [os.path.join(CSRC, 'sc2_common.h'), os.path.join(CSRC, 'conv_igemm_impl.h'),
+           os.path.join(HERE, '..', 'include', 'sc2_bottleneck.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-D__HIP_PLATFORM_AMD__=1']
@@ -40,7 +45,7 @@ def build(force=False, verbose=False):
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(_compile, SOURCES))
     if _stale(LIB, objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
