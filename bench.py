@@ -200,6 +200,8 @@ def main():
     ap.add_argument('--inflight', type=int, default=5, help='range-coder chains in flight (coder HIP streams, <= 7)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--split-mfma', type=int, default=1, help='K > 0: decoder+head stages round-robin on K HIP streams of their own (0: one MFMA stream for everything)')
+    ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
+    ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
     args = ap.parse_args()
@@ -234,8 +236,9 @@ def main():
     mfma_stream = torch.cuda.Stream(device=dev)
     # --split-mfma: front(i) [encoder] and back(i - depth) [decoder + head] on two streams, so that the tails of one
     # stage's short launches overlap the other's (both still feed the same matrix cores)
-    back_streams = [torch.cuda.Stream(device=dev) for _ in range(args.split_mfma)] if args.split_mfma else [mfma_stream]
-    coder_streams = [torch.cuda.Stream(device=dev) for _ in range(n_coder)]
+    back_streams = [torch.cuda.Stream(device=dev, priority=args.back_priority) for _ in range(args.split_mfma)] \
+        if args.split_mfma else [mfma_stream]
+    coder_streams = [torch.cuda.Stream(device=dev, priority=args.coder_priority) for _ in range(n_coder)]
     D = n_coder + 1
     results = [None]
 

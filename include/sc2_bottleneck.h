@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 18
+#define SC2_ABI_VERSION 19
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -152,6 +152,15 @@ int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const 
 int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs);
 int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N,
                         int H, int W_pairs, int inverse, void *stream);
+
+/* Second encoder stage in ONE persistent launch: y = GDN1_48(Conv2d(96 -> 48, k5, s2, p2, bias=False)(x)) for
+ * 112-pixel-wide inputs (replaces encoder[2] + encoder[3], sc2bench/models/layer.py:479-481; inverse != 0: inverse GDN1).
+ *   x : bf16 NHWC [N, H, 112, 96];   y : bf16 NHWC [N, (H - 1)/2 + 1, 56, 48]
+ *   w_frag : the conv weights packed SC2_K_SLAB_MAJOR | SC2_K_B_FRAG_MAJOR ([k-step = slab*25 + tap][3][64][8] bf16)
+ *   gamma_frag : bf16 fragment blocks [3][2][64][8] of the effective gamma [48][48 -> 64 zero-padded];  beta : f32 [48] */
+int sc2_conv2_gdn48_supported(int Cin, int Cout, int W);
+int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N, int H,
+                        int W, int inverse, void *stream);
 
 /* Streaming 1x1 convolution with a short K and a wide N: y = act(x W^T + bias [+ residual]) in one persistent launch
  * (the HBM-bound 1x1 layers of the ResNet-50 tail behind the bottleneck, backbone.py:235-254: third conv of a

@@ -1,0 +1,388 @@
+// Second encoder stage of the FP / SHP / MSHP bottlenecks in ONE persistent launch (gfx950):
+//     y = GDN1_48( Conv2d(96 -> 48, k5, s2, p2, bias=False)(x) )                (sc2bench/models/layer.py:479-481)
+// for 112-pixel-wide inputs (the 224 x 224 path).  185 GFLOP per 256-image batch over 0.62 GB of input.
+//
+// Why its own kernel: K = 2400 against N = 48.  Every formulation that streams the weights per tile moves 230 KB of them
+// for 112 output pixels (the LDS-patch tile kernel: 2.7 GB through L2 per batch, 0.36 ms in its K loop alone).  Here the
+// weights never move again after the prologue:
+//   * a workgroup is 4 waves - one per SIMD, each with the whole 512-entry register file - one workgroup per CU,
+//     persistent; K is split over the waves BY (slab, tap): wave w owns taps ((w + cb) & 3) + 4q of channel slab cb -
+//     18 or 19 of the 75 k-steps - and keeps their fragments in REGISTERS (54 resident fragments = 216 VGPRs; the one
+//     wave per slab that has a seventh tap fetches that fragment per unit); no partner wave hides latency, so the
+//     fragments of the next tap are read between the MFMAs of the current one;
+//   * a unit = two output rows of one image (112 pixels = exactly seven 16-row MFMA tiles x three channel tiles); its
+//     input patch (7 rows x 116 columns) is staged per 32-channel slab by direct-to-LDS loads into a double buffer,
+//     slab g + 1 in flight while slab g is multiplied (buffer descriptors: per-lane offsets are constants of the
+//     kernel, the row / slab position is the scalar offset, out-of-image lanes read zeros);
+//   * every wave accumulates partial sums for the WHOLE 112 x 48 tile; they are added up through LDS in two rounds of
+//     four pixel tiles (48 KB), pixel tile 4 r + w summed by wave w, which then owns all 48 channels of its 16 pixels;
+//   * GDN1(48) is therefore wave-local: |t| (bf16) to the wave's own rows of an LDS image (no barrier), norm = beta +
+//     gamma |t| as six more MFMAs per owned tile (gamma fragments in LDS), y = t / norm, bf16 to a 10.5 KB output image
+//     that is one contiguous block of the NHWC output.
+// Units are claimed dynamically, two ahead (claim c = unit c + 2 gridDim.x; the last claim re-arms the counter).
+#include <stdlib.h>
+
+#include <atomic>
+
+#include "sc2_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, (int)voff, (int)soff, 0, 0);
+}
+#else   // host pass: stand-ins (see conv_igemm_impl.h)
+typedef int buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *, uint32_t) { return 0; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, uint32_t) {}
+#endif
+
+__device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+struct Enc2Args {
+    const uint16_t *__restrict__ x;      // bf16 NHWC [N, H, 112, 96]
+    const uint16_t *__restrict__ w;      // bf16 fragment-major, slab-major K: [k-step = cb*25 + tap][3][64][8]
+    const uint16_t *__restrict__ g;      // bf16 fragment-major gamma [3][2][64][8] (K 48 zero-padded to 64)
+    const float *__restrict__ beta;      // f32 [48]
+    uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, 56, 48]
+    int H, OH, n_units, units_per_img;
+    unsigned *unit_ctr;
+};
+
+constexpr int W_IN = 112, OW = 56, CIN = 96, COUT = 48, J = OW + 2, NTAP = 25, NCB = 3;
+constexpr int MT = 7, NT = 3;
+constexpr int N_CHUNKS = 2 * 7 * J * 4;                 // 16-byte chunks of one slab's patch (3248)
+constexpr int N_PIECES = (N_CHUNKS + 63) / 64;          // 1 KB direct-to-LDS pieces (51)
+constexpr int PATCH_STRIDE = N_PIECES * 1024;           // 52 224
+constexpr int NW = 4, NQ = 6;                           // waves; resident taps per wave and slab
+constexpr int PIECES_PER_WAVE = (N_PIECES + NW - 1) / NW;   // 13
+constexpr int RED_OFF = 2 * PATCH_STRIDE;               // reduction rounds: [4 waves][12 blocks][64 lanes][16 B] = 48 KB
+constexpr int RED_BYTES = NW * 12 * 1024;
+constexpr int TIMG_OFF = RED_OFF;                       // |t| image [112][128 B] (chunks 6, 7 stay zero), over the dead rounds
+constexpr int OIMG_OFF = RED_OFF + 112 * 128;           // output image [112][96 B]
+constexpr int GAM_OFF = RED_OFF + RED_BYTES;            // gamma fragments [3][2][64] x 16 B, then beta [48] f32: loaded once
+constexpr int BETA_OFF = GAM_OFF + 6 * 1024;
+constexpr int LDS_BYTES = BETA_OFF + COUT * 4;
+static_assert(OIMG_OFF + 112 * 96 <= GAM_OFF, "images fit the reduction area");
+static_assert(LDS_BYTES + 64 <= 160 * 1024, "one workgroup per CU");
+
+template <bool INVERSE>
+__global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int next_slot;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int H = p.H;
+
+    // ---- resident weight fragments: taps ((wave + cb) & 3) + 4 q, q < 6, of every slab (54 fragments = 216 VGPRs)
+    const uint4 *wfrag = reinterpret_cast<const uint4 *>(p.w) + lane;   // [(kstep * 3 + j) * 64]
+    uint4 wreg[NCB][NQ][NT];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int tap = ((wave + cb) & 3) + 4 * q;   // < 24
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wreg[cb][q][j] = wfrag[((cb * NTAP + tap) * NT + j) * 64];
+        }
+    if (tid < 384 - 256) reinterpret_cast<uint4 *>(smem + GAM_OFF)[tid + 256] = reinterpret_cast<const uint4 *>(p.g)[tid + 256];
+    reinterpret_cast<uint4 *>(smem + GAM_OFF)[tid] = reinterpret_cast<const uint4 *>(p.g)[tid];
+    if (tid < COUT) reinterpret_cast<float *>(smem + BETA_OFF)[tid] = p.beta[tid];
+
+    // ---- patch fill: piece pc = wave + 4 k of a slab = LDS chunks [64 pc, 64 pc + 64); chunk P <-> (plane, row r, half
+    //      column j, physical chunk): source = input row 2 oh0 - 2 + r, column 2 j + plane - 2, logical chunk = phys ^ swz
+    uint32_t pv[PIECES_PER_WAVE];     // byte offset inside the image relative to row 2 oh0 - 2; low bits: r
+#pragma unroll
+    for (int k = 0; k < PIECES_PER_WAVE; ++k) {
+        const int P = (wave + NW * k) * 64 + lane;
+        const int cphys = P & 3, t = P >> 2;
+        const int t2 = t / J, j = t - t2 * J;
+        const int plane = t2 / 7, r = t2 - plane * 7;
+        const int chunk = cphys ^ ((j >> 1) & 3);
+        const int iw = 2 * j + plane - 2;
+        const bool ok = (P < N_CHUNKS) & ((unsigned)iw < (unsigned)W_IN);
+        pv[k] = ok ? (uint32_t)(((r * W_IN + iw) * CIN + chunk * 8) * 2) | (uint32_t)r : 0x80000000u;
+    }
+    auto issue_patch = [&](int unit, int cb, int buf) {
+        const bool live = unit < p.n_units;
+        const int im = live ? unit / p.units_per_img : 0;
+        const int oh0 = live ? (unit - im * p.units_per_img) * 2 : 0;
+        // descriptor base two rows above the image: row offsets are then non-negative for oh0 = 0
+        const uint16_t *base = p.x + ((long long)im * H - 2) * W_IN * CIN;
+        const buf_rsrc_t rs = make_rsrc(base, (uint32_t)(H + 2) * W_IN * CIN * 2);
+        const uint32_t soff = (uint32_t)((2 * oh0) * W_IN * CIN + cb * 32) * 2u;
+        unsigned char *Pb = smem + buf * PATCH_STRIDE;
+#pragma unroll
+        for (int k = 0; k < PIECES_PER_WAVE; ++k) {
+            const int pc = wave + NW * k;
+            if (pc < N_PIECES) {   // wave-uniform
+                const int ih = 2 * oh0 - 2 + (int)(pv[k] & 7u);   // patch row r rides in the offset's free low bits
+                const uint32_t vo = (live & ((unsigned)ih < (unsigned)H)) ? (pv[k] & ~15u) : 0x80000000u;
+                buf_load_lds16(rs, (lds_ptr_t)(Pb + pc * 1024), vo, soff);
+            }
+        }
+    };
+    // fragment address of (pixel tile i, this lane) at tap offset tap_off / half-column shift d inside patch buffer pb
+    auto frag_addr = [&](uint32_t pb, int i, int tap_off, int d, int fr) {   // fr: an opaque copy of frow (no hoisting)
+        const int pix = i * 16 + fr;
+        const int orow = pix >= OW ? 1 : 0;
+        const int ocol = pix - orow * OW;
+        const int swz = (fq ^ (((ocol + d) >> 1) & 3)) << 4;
+        return pb + (uint32_t)(((2 * orow) * J + ocol) * 64 + tap_off + swz);
+    };
+
+    int unit = blockIdx.x;
+    int next_unit = unit + gridDim.x;
+    issue_patch(unit, 0, 0);
+    int g = 0;   // global slab counter of this workgroup: slab g lives in patch buffer g & 1
+
+    while (unit < p.n_units) {
+        const int im = unit / p.units_per_img;
+        const int oh0 = (unit - im * p.units_per_img) * 2;
+        const int n_rows = p.OH - oh0 >= 2 ? 2 : 1;
+        unsigned claimed = 0;
+        if (tid == 0) {   // raw instruction (the compiler's atomicAdd waits for the result on the spot); read in the tail
+            const unsigned one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
+        }
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            // slab g has landed (this wave's pieces), then everybody's; the barrier also says every wave is done reading
+            // slab g - 1, whose buffer slab g + 1 now overwrites.  (First slab of a unit: only the three output stores of
+            // the previous unit were issued after this slab's loads, so vmcnt(3) does not wait for their acknowledgements.)
+            if (cb == 0 && g != 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            // the wave with a seventh tap in this slab fetches that fragment now (L2; older than the patch loads below)
+            const int tap6 = ((wave + cb) & 3) + 4 * NQ;
+            uint4 w6[NT];
+            if (tap6 < NTAP) {
+                int ln = lane;
+                asm volatile("" : "+v"(ln));   // (address rebuilt here, not carried across the unit)
+                const uint4 *w6p = reinterpret_cast<const uint4 *>(p.w) + ((cb * NTAP + tap6) * NT) * 64 + ln;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) w6[j] = w6p[j * 64];
+            }
+            if (cb + 1 < NCB) issue_patch(unit, cb + 1, (g + 1) & 1);
+            else issue_patch(next_unit, 0, (g + 1) & 1);
+            const uint32_t pb = lds_base + (uint32_t)((g & 1) * PATCH_STRIDE);
+            // one wave per SIMD: the fragments of tap q + 1 are read between the MFMAs of tap q
+            uint4 av[2][MT];
+            {
+                const int tap = (wave + cb) & 3;
+                const int kh = tap / 5, kw = tap - kh * 5;
+                int fr = frow;
+                asm volatile("" : "+v"(fr));
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    av[0][i] = lds_read16(frag_addr(pb, i, (((kw & 1) * 7 + kh) * J + (kw >> 1)) * 64, kw >> 1, fr));
+            }
+#pragma unroll
+            for (int q = 0; q <= NQ; ++q) {
+                const int tap = ((wave + cb) & 3) + 4 * q;
+                if (tap < NTAP) {   // wave-uniform (q < NQ: always)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tap q's fragments
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ntap = tap + 4;
+                    const int nkh = ntap / 5, nkw = ntap - nkh * 5;
+                    const int noff = (((nkw & 1) * 7 + nkh) * J + (nkw >> 1)) * 64;
+                    int fr = frow;
+                    asm volatile("" : "+v"(fr));   // the 7 x 25 fragment addresses are rebuilt per tap, not kept (spilled)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        if (q < NQ && ntap < NTAP) av[(q + 1) & 1][i] = lds_read16(frag_addr(pb, i, noff, nkw >> 1, fr));
+                        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[q & 1][i]);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const uint4 wv = q < NQ ? wreg[cb][q < NQ ? q : 0][j] : w6[j];
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), af, acc[i][j],
+                                                                                0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            ++g;
+        }
+        // ---------------------------------------------------------------- sum of the four partial tiles, two rounds
+        f32x4_t own[2][NT];   // owned pixel tiles 4 r + wave, all three channel tiles
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            __syncthreads();   // round r - 1 has been read
+#pragma unroll
+            for (int b = 0; b < 12; ++b) {
+                const int i = 4 * r + b / 3, j = b % 3;
+                if (i < MT)
+                    *reinterpret_cast<f32x4_t *>(smem + RED_OFF + ((wave * 12 + b) * 64 + lane) * 16) = acc[i][j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (4 * r + wave < MT) {
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; ++w2)
+                        s += *reinterpret_cast<const f32x4_t *>(smem + RED_OFF + ((w2 * 12 + wave * 3 + j) * 64 + lane) * 16);
+                }
+                own[r][j] = s;
+            }
+        }
+        __syncthreads();   // the rounds are dead: their area becomes the |t| image and the output image
+        // ---------------------------------------------------------------- GDN1(48) on the owned pixel tiles (wave-private rows)
+        unsigned char *timg = smem + TIMG_OFF;
+        unsigned char *oimg = smem + OIMG_OFF;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = 4 * r + wave;
+            if (i < MT) {   // wave-uniform
+                const int px = i * 16 + frow;
+                if (fq < 2) *reinterpret_cast<uint4 *>(timg + px * 128 + (((6 + fq) ^ (px & 7)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int c = j * 2 + (fq >> 1);
+                    uint2 h;
+                    h.x = pack2(f32x2_t{own[r][j][0], own[r][j][1]}) & 0x7FFF7FFFu;
+                    h.y = pack2(f32x2_t{own[r][j][2], own[r][j][3]}) & 0x7FFF7FFFu;
+                    *reinterpret_cast<uint2 *>(timg + px * 128 + ((c ^ (px & 7)) << 4) + (fq & 1) * 8) = h;
+                }
+                // (the rows are this wave's own: its LDS operations complete in order, no barrier)
+                uint4 xv[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    xv[ks] = *reinterpret_cast<const uint4 *>(timg + px * 128 + (((ks * 4 + fq) ^ (px & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const float4 beta4 = *reinterpret_cast<const float4 *>(smem + BETA_OFF + (j * 16 + fq * 4) * 4);
+                    f32x4_t nrm = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const uint4 gv = *reinterpret_cast<const uint4 *>(smem + GAM_OFF + ((j * 2 + ks) * 64 + lane) * 16);
+                        nrm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, gv),
+                                                                      __builtin_bit_cast(bf16x8_t, xv[ks]), nrm, 0, 0, 0);
+                    }
+                    const f32x2_t n01 = f32x2_t{beta4.x, beta4.y} + f32x2_t{nrm[0], nrm[1]};
+                    const f32x2_t n23 = f32x2_t{beta4.z, beta4.w} + f32x2_t{nrm[2], nrm[3]};
+                    const f32x2_t t01 = {own[r][j][0], own[r][j][1]}, t23 = {own[r][j][2], own[r][j][3]};
+                    uint2 o;
+                    if (INVERSE) {
+                        o.x = pack2(t01 * n01);
+                        o.y = pack2(t23 * n23);
+                    } else {
+                        o.x = pack2(t01 * f32x2_t{__builtin_amdgcn_rcpf(n01[0]), __builtin_amdgcn_rcpf(n01[1])});
+                        o.y = pack2(t23 * f32x2_t{__builtin_amdgcn_rcpf(n23[0]), __builtin_amdgcn_rcpf(n23[1])});
+                    }
+                    *reinterpret_cast<uint2 *>(oimg + px * (COUT * 2) + (j * 16 + fq * 4) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---------------------------------------------------------------- stream the unit out (one contiguous block of y)
+        {
+            uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * COUT);
+            const unsigned n_out = (unsigned)(n_rows * OW * (COUT / 8));   // 672 or 336 chunks
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned q0 = tid + 256 * k;
+                const unsigned q = q0 < n_out ? q0 : (unsigned)tid;   // past the end: the thread's first chunk again (same data)
+                yo[q] = *reinterpret_cast<const uint4 *>(oimg + q * 16);
+            }
+        }
+        if (tid == 0) {   // the claim was issued at the top of the unit: older than every wait since
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(claimed)::"memory");
+            next_slot = (int)(claimed + 2 * gridDim.x);
+            if (claimed == (unsigned)(p.n_units - 1)) *p.unit_ctr = 0u;   // the launch's last claim re-arms the counter
+        }
+        __syncthreads();   // also: the images are free for the next unit's rounds
+        unit = next_unit;
+        next_unit = __builtin_amdgcn_readfirstlane(next_slot);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the patch prefetched for a unit that does not exist
+}
+
+int g_cus2 = 0;
+constexpr int kMaxDev2 = 16, kRing2 = 256;
+unsigned *g_ring2[kMaxDev2] = {};
+std::atomic<unsigned> g_seq2{0};
+
+}  // namespace
+
+extern "C" int sc2_conv2_gdn48_supported(int Cin, int Cout, int W) {
+    return Cin == CIN && Cout == COUT && W == W_IN ? 1 : 0;
+}
+
+extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y,
+                                   int N, int H, int W, int inverse, void *stream) {
+    SC2_REQUIRE(x && w_frag && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "conv2_gdn48: null argument");
+    SC2_REQUIRE(N > 0 && H > 0, SC2_ERR_INVALID_ARG, "conv2_gdn48: non-positive dimension");
+    SC2_REQUIRE(sc2_conv2_gdn48_supported(CIN, COUT, W), SC2_ERR_UNSUPPORTED,
+                "conv2_gdn48: needs a %d-pixel-wide input (got %d)", W_IN, W);
+    SC2_REQUIRE((long long)(H + 2) * W_IN * CIN * 2 < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv2_gdn48: image too tall");
+    Enc2Args a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_frag);
+    a.g = static_cast<const uint16_t *>(gamma_frag);
+    a.beta = beta;
+    a.y = static_cast<uint16_t *>(y);
+    a.H = H;
+    a.OH = (H + 4 - 5) / 2 + 1;
+    a.units_per_img = (a.OH + 1) / 2;
+    const long long units = (long long)N * a.units_per_img;
+    SC2_REQUIRE(units < 0x7FFFFFFFLL - 1024, SC2_ERR_UNSUPPORTED, "conv2_gdn48: too many units");
+    a.n_units = (int)units;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    SC2_REQUIRE(dev >= 0 && dev < kMaxDev2, SC2_ERR_UNSUPPORTED, "conv2_gdn48: device ordinal %d out of range", dev);
+    if (g_cus2 == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cus2 = n;
+    }
+    if (!g_ring2[dev]) {
+        void *ptr = nullptr;
+        SC2_REQUIRE(hipMalloc(&ptr, kRing2 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
+                    "conv2_gdn48: cannot allocate the unit counters");
+        SC2_REQUIRE(hipMemset(ptr, 0, kRing2 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
+                    "conv2_gdn48: cannot clear the unit counters");
+        g_ring2[dev] = static_cast<unsigned *>(ptr);
+    }
+    const int grid = a.n_units < g_cus2 ? a.n_units : g_cus2;   // one 4-wave workgroup per CU
+    a.unit_ctr = g_ring2[dev] + (g_seq2.fetch_add(1) % kRing2);
+    if (inverse) hipLaunchKernelGGL(conv2_gdn48_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(conv2_gdn48_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}

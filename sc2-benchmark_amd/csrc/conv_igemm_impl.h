@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256, 3) void conv5s2_patch_kernel(const ConvArgs p)
 
     constexpr int NQ = (NTAP + 3) / 4;   // taps per wave (the last one only for wave 0)
 #pragma unroll 1
-    for (int cb = 0; cb < NCB; ++cb) {
+    for (int cb = 0; cb < ((p.dbg & 2) ? 0 : NCB); ++cb) {   // (SC2_CONV_DEBUG bit 1: no K loop)
         if (cb > 0) __syncthreads();   // every wave is done with the previous slab's patch
 #pragma unroll
         for (int k = 0; k < MAXQ; ++k) {
@@ -851,6 +851,13 @@ __global__ __launch_bounds__(256, 3) void conv5s2_patch_kernel(const ConvArgs p)
                 }
             }
         }
+    }
+    if (p.dbg & 1) {   // SC2_CONV_DEBUG bit 0: no reduction / epilogue
+#pragma unroll
+        for (int i = 0; i < MA; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(part[i][j]));
+        return;
     }
     // ---- add the four waves' partial tiles through an f32 LDS buffer [128][BN]; every wave then takes back the rows
     //      it owns in the epilogue's tiling (wave w: rows 32w .. 32w + 31)

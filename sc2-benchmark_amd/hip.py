@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -72,6 +72,8 @@ def lib():
     L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_conv0_gdn96_supported.argtypes = [i32, i32, i32]
     L.sc2_conv0_gdn96_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
+    L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_stream_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
@@ -468,6 +470,33 @@ def conv0_gdn96_fwd(x_pairs, w_frag, gamma_frag, beta, inverse=False, tag=None):
     with _timed(tag or 'conv0_gdn96'):
         _check(lib().sc2_conv0_gdn96_fwd(_ptr(x_pairs), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, WP,
                                          1 if inverse else 0, _stream()), 'conv0_gdn96_fwd')
+    return out
+
+
+def conv2_gdn48_supported(x_shape, cout, kh, kw, stride, pad):
+    """True if this conv + GDN1(48) runs as the persistent weights-in-registers launch (96 -> 48, k5 s2 p2, W = 112)."""
+    if os.environ.get('SC2_CONV2_FUSED', '1') == '0':      # A/B switch (tools/)
+        return False
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    return (len(x_shape) == 4 and (kh, kw, sh, sw, ph, pw) == (5, 5, 2, 2, 2, 2) and
+            bool(lib().sc2_conv2_gdn48_supported(x_shape[3], cout, x_shape[2])))
+
+
+def conv2_gdn48_fwd(x_nhwc, w_frag, gamma_frag, beta, inverse=False, tag=None):
+    """x bf16 [N,H,112,96] -> bf16 NHWC [N,(H-1)//2+1,56,48]; w_frag: pack_conv_weight(w, K_SLAB_MAJOR | K_B_FRAG_MAJOR);
+    gamma_frag: pack_weight_fragments of the effective gamma zero-padded to [48, 64]."""
+    for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (gamma_frag, 'gamma_frag'), (beta, 'beta')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous() and x_nhwc.shape[3] == 96
+    N, H, W, _ = x_nhwc.shape
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (48, weight_pitch(2400))
+    assert gamma_frag.dtype == torch.bfloat16 and gamma_frag.is_contiguous() and tuple(gamma_frag.shape) == (3, 2, 64, 8)
+    assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 48
+    out = torch.empty((N, (H - 1) // 2 + 1, 56, 48), dtype=torch.bfloat16, device=x_nhwc.device)
+    with _timed(tag or 'conv2_gdn48'):
+        _check(lib().sc2_conv2_gdn48_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, W,
+                                         1 if inverse else 0, _stream()), 'conv2_gdn48_fwd')
     return out
 
 

@@ -140,6 +140,13 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             self._conv0_key = key
         return self._conv0_pack
 
+    def _gdn48_fragments(self, gamma_packed):
+        """fragment-major form of the packed effective gamma [48][64] (cached per packed tensor)."""
+        if getattr(self, '_g48_src', None) is not gamma_packed:
+            self._g48_frag = hip.pack_weight_fragments(gamma_packed)
+            self._g48_src = gamma_packed
+        return self._g48_frag
+
     def _conv0_fragments(self):
         packed = self._conv0_packed()
         if getattr(self, '_conv0_frag_src', None) is not packed:
@@ -188,7 +195,12 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                 h = c0.forward_nhwc(xin)
         if not fuse0:
             h = g1.forward_nhwc(h)
-        if fuse2:
+        if fuse2 and g3.in_channels == 48 and hip.conv2_gdn48_supported(tuple(h.shape), c2.out_channels, c2.kernel_size[0],
+                                                                        c2.kernel_size[1], c2.stride, c2.padding):
+            beta, gamma = g3.effective()   # conv + GDN1(48) as one persistent launch, weights resident in registers
+            h = hip.conv2_gdn48_fwd(h, c2.packed_weight(hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR), self._gdn48_fragments(gamma),
+                                    beta, g3.inverse, tag=c2._tag + '+' + g3._tag)
+        elif fuse2:
             beta, gamma = g3.effective()
             epi = hip.EPI_FUSED_IGDN if g3.inverse else hip.EPI_FUSED_GDN
             order = c2.k_order()
@@ -384,6 +396,7 @@ class SHPBasedResNetBottleneck(BaseBottleneck):
     _init_transforms = FPBasedResNetBottleneck._init_transforms
     _conv0_packed = FPBasedResNetBottleneck._conv0_packed
     _conv0_fragments = FPBasedResNetBottleneck._conv0_fragments
+    _gdn48_fragments = FPBasedResNetBottleneck._gdn48_fragments
     _uses_pair_conv0 = FPBasedResNetBottleneck._uses_pair_conv0
     analysis = FPBasedResNetBottleneck.analysis
     synthesis_nhwc = FPBasedResNetBottleneck.synthesis_nhwc

@@ -459,6 +459,41 @@ def test_conv0_gdn96_fused(S, R, dev, N, H, inverse):
     assert_close_bf16(out, tile, 'persistent vs tile kernel', extra=2.0 ** -7)
 
 
+@pytest.mark.parametrize('N,H,inverse', [(3, 112, False), (2, 30, False), (300, 3, False), (5, 9, True)])
+def test_conv2_gdn48_fused(S, R, dev, N, H, inverse):
+    """Second encoder conv (96 -> 48, k5 s2 p2) + GDN1(48) as one persistent launch with the weights resident in
+    registers vs the f32 ops on the bf16-rounded operands and vs the LDS-patch tile kernel; image borders, odd output
+    height, more units than workgroups."""
+    W = 112
+    torch.manual_seed(H + N)
+    x = torch.randn(N, 96, H, W)
+    w = torch.randn(48, 96, 5, 5) / 2400 ** 0.5
+    gdn = R.GDN1(48, inverse=inverse)
+    with torch.no_grad():
+        gdn.gamma.add_(0.05 * torch.rand(48, 48) / 48 ** 0.5)
+        gdn.beta.add_(0.1 * torch.rand(48))
+        conv = F.conv2d(bf16_round(x), bf16_round(w), stride=2, padding=2)
+        beta = gdn.beta_reparam(gdn.beta)
+        gamma = bf16_round(gdn.gamma_reparam(gdn.gamma))
+        norm = F.conv2d(bf16_round(conv).abs(), gamma.reshape(48, 48, 1, 1), beta)
+        ref = conv * norm if inverse else conv / norm
+    m = S.GDN1(48, inverse=inverse)
+    m.load_state_dict(gdn.state_dict())
+    m.to(dev)
+    beta_d, gamma_d = m.effective()
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    assert S.hip.conv2_gdn48_supported(tuple(x_nhwc.shape), 48, 5, 5, 2, 2)
+    assert not S.hip.conv2_gdn48_supported((N, H, 100, 96), 48, 5, 5, 2, 2)
+    order = S.hip.K_SLAB_MAJOR | S.hip.K_B_FRAG_MAJOR
+    wp = S.hip.pack_conv_weight(w.to(dev), order)
+    out = S.hip.conv2_gdn48_fwd(x_nhwc, wp, S.hip.pack_weight_fragments(gamma_d), beta_d, inverse)
+    assert out.shape == (N, ref.shape[2], ref.shape[3], 48)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'fused conv2 + gdn48', extra=2.0 ** -8)
+    tile = S.hip.conv2d_fwd(x_nhwc, wp, 48, 5, 5, 2, 2, epilogue=S.hip.EPI_FUSED_IGDN if inverse else S.hip.EPI_FUSED_GDN,
+                            ep_x=gamma_d, ep_beta=beta_d, k_order=order)
+    assert_close_bf16(out, tile, 'persistent vs patch kernel', extra=2.0 ** -7)
+
+
 def _golden():
     return torch.load(os.path.join(HERE, 'golden', 'fp_golden.pt'), weights_only=False)
 

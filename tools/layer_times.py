@@ -61,6 +61,11 @@ def main():
         a2 = e2.forward_nhwc(a1)
         rows.append(('enc.conv2', timeit(lambda: e2.forward_nhwc(a1), args.iters), 722.5e6 * N, a1.numel() * 2 + a2.numel() * 2))
         beta_g3, gamma_g3 = g3.effective()
+        if hip.conv2_gdn48_supported(tuple(a1.shape), 48, 5, 5, 2, 2):
+            wq48 = e2.packed_weight(hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR)
+            gf48 = hip.pack_weight_fragments(gamma_g3)
+            rows.append(('enc.conv2+gdn48 (resident)', timeit(lambda: hip.conv2_gdn48_fwd(a1, wq48, gf48, beta_g3), args.iters),
+                         (722.5e6 + 14.5e6) * N, a1.numel() * 2 + a2.numel() * 2))
         for nm, order in (('enc.conv2+gdn48 (gather)', e2.k_order()), ('enc.conv2+gdn48 (patch)', hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR)):
             wq = e2.packed_weight(order)
             rows.append((nm, timeit(lambda: hip.conv2d_fwd(a1, wq, 48, 5, 5, 2, 2, epilogue=hip.EPI_FUSED_GDN, ep_x=gamma_g3,
