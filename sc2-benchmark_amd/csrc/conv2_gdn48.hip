@@ -122,24 +122,34 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         const bool ok = (P < N_CHUNKS) & ((unsigned)iw < (unsigned)W_IN);
         pv[k] = ok ? (uint32_t)(((r * W_IN + iw) * CIN + chunk * 8) * 2) | (uint32_t)r : 0x80000000u;
     }
-    auto issue_patch = [&](int unit, int cb, int buf) {
-        const bool live = unit < p.n_units;
-        const int im = live ? unit / p.units_per_img : 0;
-        const int oh0 = live ? (unit - im * p.units_per_img) * 2 : 0;
+    // direct-to-LDS pieces of one slab: the descriptor / scalar offset / destination are set up once (patch_setup), the
+    // pieces are then issued one or two at a time BETWEEN the taps of the slab being multiplied (a burst of 13 at the
+    // top of a slab cost ~2 000 cycles of this wave's only instruction stream)
+    struct PatchJob { buf_rsrc_t rs; uint32_t soff; unsigned char *dst; int row0; bool live; };
+    auto patch_setup = [&](int unit, int cb, int buf) {
+        PatchJob jb;
+        jb.live = unit < p.n_units;
+        const int im = jb.live ? unit / p.units_per_img : 0;
+        const int oh0 = jb.live ? (unit - im * p.units_per_img) * 2 : 0;
         // descriptor base two rows above the image: row offsets are then non-negative for oh0 = 0
-        const uint16_t *base = p.x + ((long long)im * H - 2) * W_IN * CIN;
-        const buf_rsrc_t rs = make_rsrc(base, (uint32_t)(H + 2) * W_IN * CIN * 2);
-        const uint32_t soff = (uint32_t)((2 * oh0) * W_IN * CIN + cb * 32) * 2u;
-        unsigned char *Pb = smem + buf * PATCH_STRIDE;
-#pragma unroll
-        for (int k = 0; k < PIECES_PER_WAVE; ++k) {
-            const int pc = wave + NW * k;
-            if (pc < N_PIECES) {   // wave-uniform
-                const int ih = 2 * oh0 - 2 + (int)(pv[k] & 7u);   // patch row r rides in the offset's free low bits
-                const uint32_t vo = (live & ((unsigned)ih < (unsigned)H)) ? (pv[k] & ~15u) : 0x80000000u;
-                buf_load_lds16(rs, (lds_ptr_t)(Pb + pc * 1024), vo, soff);
-            }
+        jb.rs = make_rsrc(p.x + ((long long)im * H - 2) * W_IN * CIN, (uint32_t)(H + 2) * W_IN * CIN * 2);
+        jb.soff = (uint32_t)((2 * oh0) * W_IN * CIN + cb * 32) * 2u;
+        jb.dst = smem + buf * PATCH_STRIDE;
+        jb.row0 = 2 * oh0 - 2;
+        return jb;
+    };
+    auto issue_piece = [&](const PatchJob &jb, int k) {
+        const int pc = wave + NW * k;
+        if (pc < N_PIECES) {   // wave-uniform
+            const int ih = jb.row0 + (int)(pv[k] & 7u);   // patch row r rides in the offset's free low bits
+            const uint32_t vo = (jb.live & ((unsigned)ih < (unsigned)H)) ? (pv[k] & ~15u) : 0x80000000u;
+            buf_load_lds16(jb.rs, (lds_ptr_t)(jb.dst + pc * 1024), vo, jb.soff);
         }
+    };
+    auto issue_patch = [&](int unit, int cb, int buf) {
+        const PatchJob jb = patch_setup(unit, cb, buf);
+#pragma unroll
+        for (int k = 0; k < PIECES_PER_WAVE; ++k) issue_piece(jb, k);
     };
     // fragment address of (pixel tile i, this lane) at tap offset tap_off / half-column shift d inside patch buffer pb
     auto frag_addr = [&](uint32_t pb, int i, int tap_off, int d, int fr) {   // fr: an opaque copy of frow (no hoisting)
@@ -159,11 +169,6 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         const int im = unit / p.units_per_img;
         const int oh0 = (unit - im * p.units_per_img) * 2;
         const int n_rows = p.OH - oh0 >= 2 ? 2 : 1;
-        unsigned claimed = 0;
-        if (tid == 0) {   // raw instruction (the compiler's atomicAdd waits for the result on the spot); read in the tail
-            const unsigned one = 1u;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
-        }
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -178,6 +183,19 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             if (cb == 0 && g != 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (cb == 1 && tid == 0) {
+                // Claim of the unit after next.  Issue AND wait in one statement: the compiler may copy or spill an asm
+                // load's destination before the data lands (it did, once the register pressure changed: stale claims,
+                // an endless unit loop).  Here nothing else of wave 0 is in flight (slab 1's loads have just been waited
+                // for, slab 2's are not issued yet) and wave 0 has six taps in this slab where wave 3 has seven, so the
+                // atomic's round trip is mostly slack.
+                unsigned claimed;
+                const unsigned one = 1u;
+                asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
+                next_slot = (int)(claimed + 2 * gridDim.x);
+                if (claimed == (unsigned)(p.n_units - 1)) *p.unit_ctr = 0u;   // the launch's last claim re-arms the counter
+            }
             // the wave with a seventh tap in this slab fetches that fragment now (L2; older than the patch loads below)
             const int tap6 = ((wave + cb) & 3) + 4 * NQ;
             uint4 w6[NT];
@@ -188,8 +206,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) w6[j] = w6p[j * 64];
             }
-            if (cb + 1 < NCB) issue_patch(unit, cb + 1, (g + 1) & 1);
-            else issue_patch(next_unit, 0, (g + 1) & 1);
+            const PatchJob jb = cb + 1 < NCB ? patch_setup(unit, cb + 1, (g + 1) & 1) : patch_setup(next_unit, 0, (g + 1) & 1);
             const uint32_t pb = lds_base + (uint32_t)((g & 1) * PATCH_STRIDE);
             // one wave per SIMD: the fragments of tap q + 1 are read between the MFMAs of tap q
             uint4 av[2][MT];
@@ -225,6 +242,12 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                }
+                // two pieces of the next slab per tap (13 pieces over the 6 taps every wave has, the last one carries three)
+                if (q < NQ) {
+                    issue_piece(jb, 2 * q);
+                    issue_piece(jb, 2 * q + 1);
+                    if (q == NQ - 1) issue_piece(jb, 2 * NQ);
                 }
             }
             ++g;
@@ -311,11 +334,6 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                 const unsigned q = q0 < n_out ? q0 : (unsigned)tid;   // past the end: the thread's first chunk again (same data)
                 yo[q] = *reinterpret_cast<const uint4 *>(oimg + q * 16);
             }
-        }
-        if (tid == 0) {   // the claim was issued at the top of the unit: older than every wait since
-            asm volatile("s_waitcnt vmcnt(3)" : "+v"(claimed)::"memory");
-            next_slot = (int)(claimed + 2 * gridDim.x);
-            if (claimed == (unsigned)(p.n_units - 1)) *p.unit_ctr = 0u;   // the launch's last claim re-arms the counter
         }
         __syncthreads();   // also: the images are free for the next unit's rounds
         unit = next_unit;

@@ -494,6 +494,35 @@ def test_conv2_gdn48_fused(S, R, dev, N, H, inverse):
     assert_close_bf16(out, tile, 'persistent vs patch kernel', extra=2.0 ** -7)
 
 
+def test_persistent_encoder_kernels_many_units(S, R, dev):
+    """More units than resident workgroups can take statically: every workgroup of the two persistent encoder kernels
+    goes through several dynamic claims (a stale claim register once made this an endless loop).  Device-only check
+    against the tile kernels on the same operands."""
+    N = 40
+    torch.manual_seed(5)
+    # first stage: 40 x 56 = 2240 units over <= 512 workgroups
+    x = (torch.rand(N, 3, 224, 224) * 2 - 1).to(dev)
+    w0 = (torch.randn(96, 3, 5, 5) / 75 ** 0.5).to(dev)
+    g1 = S.GDN1(96).to(dev)
+    beta1, gamma1_f = g1.effective_fragments()
+    _, gamma1 = g1.effective()
+    xp = S.hip.nchw_f32_to_nhwc_bf16(x, 4).view(N, 224, 112, 8)
+    packed0 = S.hip.pack_conv0_weight_pairs(w0)
+    a = S.hip.conv0_gdn96_fwd(xp, S.hip.pack_weight_fragments(packed0[:96]), gamma1_f, beta1)
+    a_tile = S.hip.conv2d_fwd(xp, packed0, 96, 5, 3, (2, 1), (2, 1), epilogue=S.hip.EPI_FUSED_GDN, ep_x=gamma1, ep_beta=beta1)
+    assert_close_bf16(a, a_tile, 'conv0+gdn96 persistent vs tile, 2240 units', extra=2.0 ** -7)
+    # second stage: 40 x 28 = 1120 units over <= 256 workgroups
+    w2 = (torch.randn(48, 96, 5, 5) / 2400 ** 0.5).to(dev)
+    g3 = S.GDN1(48).to(dev)
+    beta3, gamma3 = g3.effective()
+    order = S.hip.K_SLAB_MAJOR | S.hip.K_B_FRAG_MAJOR
+    wp = S.hip.pack_conv_weight(w2, order)
+    b = S.hip.conv2_gdn48_fwd(a, wp, S.hip.pack_weight_fragments(gamma3), beta3)
+    b_tile = S.hip.conv2d_fwd(a, wp, 48, 5, 5, 2, 2, epilogue=S.hip.EPI_FUSED_GDN, ep_x=gamma3, ep_beta=beta3, k_order=order)
+    assert_close_bf16(b, b_tile, 'conv2+gdn48 persistent vs patch kernel, 1120 units', extra=2.0 ** -7)
+    torch.cuda.synchronize()
+
+
 def _golden():
     return torch.load(os.path.join(HERE, 'golden', 'fp_golden.pt'), weights_only=False)
 
