@@ -151,13 +151,20 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
 #pragma unroll
         for (int k = 0; k < PIECES_PER_WAVE; ++k) issue_piece(jb, k);
     };
-    // fragment address of (pixel tile i, this lane) at tap offset tap_off / half-column shift d inside patch buffer pb
-    auto frag_addr = [&](uint32_t pb, int i, int tap_off, int d, int fr) {   // fr: an opaque copy of frow (no hoisting)
-        const int pix = i * 16 + fr;
+    // fragment address of (pixel tile i, this lane) at tap offset tap_off / half-column shift d inside patch buffer pb:
+    // the pixel part is a constant of the lane (14 registers); per read only the shift's swizzle is rebuilt - the ~10
+    // instructions of the full form per read did not fit beside the MFMAs of this wave's only instruction stream
+    uint32_t fa_base[MT];
+    int fa_col[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int pix = i * 16 + frow;
         const int orow = pix >= OW ? 1 : 0;
-        const int ocol = pix - orow * OW;
-        const int swz = (fq ^ (((ocol + d) >> 1) & 3)) << 4;
-        return pb + (uint32_t)(((2 * orow) * J + ocol) * 64 + tap_off + swz);
+        fa_col[i] = pix - orow * OW;
+        fa_base[i] = (uint32_t)(((2 * orow) * J + fa_col[i]) * 64);
+    }
+    auto frag_addr = [&](uint32_t pb_tap, int i, int d, int fqo) {   // pb_tap = patch buffer + tap offset (scalar)
+        return pb_tap + fa_base[i] + (uint32_t)((fqo ^ (((fa_col[i] + d) >> 1) & 3)) << 4);   // fqo: opaque copy of fq
     };
 
     int unit = blockIdx.x;
@@ -213,11 +220,11 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             {
                 const int tap = (wave + cb) & 3;
                 const int kh = tap / 5, kw = tap - kh * 5;
-                int fr = frow;
-                asm volatile("" : "+v"(fr));
+                int fqo = fq;
+                asm volatile("" : "+v"(fqo));   // (keeps the 7 x 25 complete addresses from being hoisted and spilled)
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
-                    av[0][i] = lds_read16(frag_addr(pb, i, (((kw & 1) * 7 + kh) * J + (kw >> 1)) * 64, kw >> 1, fr));
+                    av[0][i] = lds_read16(frag_addr(pb + (uint32_t)((((kw & 1) * 7 + kh) * J + (kw >> 1)) * 64), i, kw >> 1, fqo));
             }
 #pragma unroll
             for (int q = 0; q <= NQ; ++q) {
@@ -228,11 +235,12 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                     const int ntap = tap + 4;
                     const int nkh = ntap / 5, nkw = ntap - nkh * 5;
                     const int noff = (((nkw & 1) * 7 + nkh) * J + (nkw >> 1)) * 64;
-                    int fr = frow;
-                    asm volatile("" : "+v"(fr));   // the 7 x 25 fragment addresses are rebuilt per tap, not kept (spilled)
+                    int fqo = fq;
+                    asm volatile("" : "+v"(fqo));
+
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        if (q < NQ && ntap < NTAP) av[(q + 1) & 1][i] = lds_read16(frag_addr(pb, i, noff, nkw >> 1, fr));
+                        if (q < NQ && ntap < NTAP) av[(q + 1) & 1][i] = lds_read16(frag_addr(pb + (uint32_t)noff, i, nkw >> 1, fqo));
                         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[q & 1][i]);
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
@@ -243,11 +251,14 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                // two pieces of the next slab per tap (13 pieces over the 6 taps every wave has, the last one carries three)
-                if (q < NQ) {
-                    issue_piece(jb, 2 * q);
-                    issue_piece(jb, 2 * q + 1);
-                    if (q == NQ - 1) issue_piece(jb, 2 * NQ);
+                // three pieces of the next slab behind each of the first taps (13 pieces over taps 0 .. 4): spread, but
+                // early enough to have landed when the slab ends
+                if (q < 4) {
+                    issue_piece(jb, 3 * q);
+                    issue_piece(jb, 3 * q + 1);
+                    issue_piece(jb, 3 * q + 2);
+                } else if (q == 4) {
+                    issue_piece(jb, 12);
                 }
             }
             ++g;
