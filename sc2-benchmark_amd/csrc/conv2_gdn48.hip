@@ -19,7 +19,8 @@
 //   * GDN1(48) is therefore wave-local: |t| (bf16) to the wave's own rows of an LDS image (no barrier), norm = beta +
 //     gamma |t| as six more MFMAs per owned tile (gamma fragments in LDS), y = t / norm, bf16 to a 10.5 KB output image
 //     that is one contiguous block of the NHWC output.
-// Units are claimed dynamically, two ahead (claim c = unit c + 2 gridDim.x; the last claim re-arms the counter).
+// Units are claimed dynamically, two ahead, from one counter per XCD (claim c = local unit c + 2 x workgroups of the
+// XCD; an XCD makes exactly as many claims as it has units, and the last one re-arms its counter).
 #include <stdlib.h>
 
 #include <atomic>
@@ -61,8 +62,8 @@ struct Enc2Args {
     const uint16_t *__restrict__ g;      // bf16 fragment-major gamma [3][2][64][8] (K 48 zero-padded to 64)
     const float *__restrict__ beta;      // f32 [48]
     uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, 56, 48]
-    int H, OH, n_units, units_per_img;
-    unsigned *unit_ctr;
+    int N, H, OH, n_units, units_per_img;
+    unsigned *unit_ctr;   // eight counters: one per XCD
 };
 
 constexpr int W_IN = 112, OW = 56, CIN = 96, COUT = 48, J = OW + 2, NTAP = 25, NCB = 3;
@@ -126,11 +127,20 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     // pieces are then issued one or two at a time BETWEEN the taps of the slab being multiplied (a burst of 13 at the
     // top of a slab cost ~2 000 cycles of this wave's only instruction stream)
     struct PatchJob { buf_rsrc_t rs; uint32_t soff; unsigned char *dst; int row0; bool live; };
+    // Units are XCD-local: workgroup b runs on XCD b & 7 (round-robin dispatch) and only takes units of the images
+    // im = xcd (mod 8), in order - neighbouring row pairs of an image (3 of their 7 input rows are shared) and the three
+    // slab passes over the same 128-byte lines then meet in ONE 4 MB L2 instead of eight.
+    const int xcd = blockIdx.x & 7;
+    const int wg_l = blockIdx.x >> 3;                                   // index of this workgroup on its XCD
+    const int wgs_x = ((int)gridDim.x - xcd + 7) >> 3;                  // workgroups on this XCD
+    const int n_local = xcd < p.N ? ((p.N - xcd + 7) >> 3) * p.units_per_img : 0;   // units of this XCD
+    unsigned *const my_ctr = p.unit_ctr + xcd;
     auto patch_setup = [&](int unit, int cb, int buf) {
         PatchJob jb;
-        jb.live = unit < p.n_units;
-        const int im = jb.live ? unit / p.units_per_img : 0;
-        const int oh0 = jb.live ? (unit - im * p.units_per_img) * 2 : 0;
+        jb.live = unit < n_local;
+        const int im_l = jb.live ? unit / p.units_per_img : 0;
+        const int im = xcd + 8 * im_l;
+        const int oh0 = jb.live ? (unit - im_l * p.units_per_img) * 2 : 0;
         // descriptor base two rows above the image: row offsets are then non-negative for oh0 = 0
         jb.rs = make_rsrc(p.x + ((long long)im * H - 2) * W_IN * CIN, (uint32_t)(H + 2) * W_IN * CIN * 2);
         jb.soff = (uint32_t)((2 * oh0) * W_IN * CIN + cb * 32) * 2u;
@@ -167,14 +177,15 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         return pb_tap + fa_base[i] + (uint32_t)((fqo ^ (((fa_col[i] + d) >> 1) & 3)) << 4);   // fqo: opaque copy of fq
     };
 
-    int unit = blockIdx.x;
-    int next_unit = unit + gridDim.x;
+    int unit = wg_l;
+    int next_unit = unit + wgs_x;
     issue_patch(unit, 0, 0);
     int g = 0;   // global slab counter of this workgroup: slab g lives in patch buffer g & 1
 
-    while (unit < p.n_units) {
-        const int im = unit / p.units_per_img;
-        const int oh0 = (unit - im * p.units_per_img) * 2;
+    while (unit < n_local) {
+        const int im_l = unit / p.units_per_img;
+        const int im = xcd + 8 * im_l;
+        const int oh0 = (unit - im_l * p.units_per_img) * 2;
         const int n_rows = p.OH - oh0 >= 2 ? 2 : 1;
         f32x4_t acc[MT][NT];
 #pragma unroll
@@ -199,9 +210,9 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                 unsigned claimed;
                 const unsigned one = 1u;
                 asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
-                next_slot = (int)(claimed + 2 * gridDim.x);
-                if (claimed == (unsigned)(p.n_units - 1)) *p.unit_ctr = 0u;   // the launch's last claim re-arms the counter
+                             : "=&v"(claimed) : "v"(my_ctr), "v"(one) : "memory");
+                next_slot = (int)(claimed + 2 * wgs_x);
+                if (claimed == (unsigned)(n_local - 1)) *my_ctr = 0u;   // this XCD's last claim re-arms its counter
             }
             // the wave with a seventh tap in this slab fetches that fragment now (L2; older than the patch loads below)
             const int tap6 = ((wave + cb) & 3) + 4 * NQ;
@@ -377,7 +388,7 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
     a.g = static_cast<const uint16_t *>(gamma_frag);
     a.beta = beta;
     a.y = static_cast<uint16_t *>(y);
-    a.H = H;
+    a.N = N; a.H = H;
     a.OH = (H + 4 - 5) / 2 + 1;
     a.units_per_img = (a.OH + 1) / 2;
     const long long units = (long long)N * a.units_per_img;
@@ -409,7 +420,7 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
         g_ring2[dev] = static_cast<unsigned *>(ptr);
     }
     const int grid = a.n_units < g_cus2 ? a.n_units : g_cus2;   // one 4-wave workgroup per CU
-    a.unit_ctr = g_ring2[dev] + (g_seq2.fetch_add(1) % kRing2);
+    a.unit_ctr = g_ring2[dev] + 8 * (g_seq2.fetch_add(1) % (kRing2 / 8));   // eight counters per launch
     if (inverse) hipLaunchKernelGGL(conv2_gdn48_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, s, a);
     else hipLaunchKernelGGL(conv2_gdn48_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, s, a);
     SC2_CHECK_LAUNCH();

@@ -10,7 +10,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err
 python tools/layer_times.py --bs 256 > $OUT/layer_times.log 2>&1
 ROOT=$(pwd)
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline "$@" > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof_bench.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o bench -- python3 $ROOT/bench.py --no-cpu-baseline "$@" > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof_bench.err)
 find $OUT/prof -name "*kernel_stats*" | head -3
 for f in $(find $OUT/prof -name "*kernel_stats.csv"); do cp $f $OUT/kernel_stats.csv; done
 ls -la $OUT $OUT/prof 2>/dev/null | head -30
