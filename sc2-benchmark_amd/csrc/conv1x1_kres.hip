@@ -1,0 +1,293 @@
+// 1x1 convolution with a LONG K and the weights resident in registers (gfx950): the conv1 layers of the ResNet tail's
+// layer3 / layer4.0 (1024 -> 256 / 512, torchvision Bottleneck.conv1 + bn1 + ReLU in eval mode, backbone.py:235-254):
+//     y[m, n] = act( sum_k x[m, k] w[n, k] + bias[n] ),  K = 1024, bf16 NHWC in and out.
+//
+// M is small there (50 176 pixels at bs 256) and the weights are 0.5 - 1 MB: a tile kernel re-reads them per 128-pixel
+// tile (205 MB through L2 per launch, 355 TFLOP/s).  Here a workgroup is bound to ONE 128-channel chunk of the output
+// for its whole life and keeps that chunk's weights in registers:
+//   * 4 waves, one per SIMD, 512 registers each; wave (kh, nh) holds K half kh x 64 channels nh of the chunk:
+//     16 k-steps x 4 channel tiles = 64 fragments = 256 VGPRs, loaded once;
+//   * a unit = 32 pixels: its A tile (64 KB) arrives by buffer-addressed LDS-DMA into a double buffer (next unit's
+//     pieces are issued behind the first k-steps of the current one), each wave multiplies its K half for both 16-pixel
+//     tiles (128 MFMAs) reading the A fragments of k-step s + 1 between the MFMAs of k-step s;
+//   * the two K halves are exchanged through 16 KB of LDS: wave (kh, nh) sends the pixel tile it does not own and adds
+//     its partner's partial for pixel tile kh; bias + ReLU, bf16, 8 KB output image, streamed out;
+//   * units are claimed dynamically, two ahead, from one counter per (XCD, chunk): an XCD owns the pixel tiles
+//     t = xcd (mod 8) for every chunk, so the chunks' workgroups read a tile's A rows through the same L2 at about the
+//     same time (A from HBM once, not once per chunk); a workgroup whose CU is held by another kernel takes fewer.
+#include <stdlib.h>
+
+#include <atomic>
+
+#include "sc2_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, (int)voff, (int)soff, 0, 0);
+}
+#else   // host pass: stand-ins (see conv_igemm_impl.h)
+typedef int buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *, uint32_t) { return 0; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, uint32_t) {}
+#endif
+
+__device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+struct KresArgs {
+    const uint16_t *__restrict__ x;      // bf16 [M, 1024]
+    const uint16_t *__restrict__ w;      // bf16 fragment-major [Cout/16][32][64][8]
+    const float *__restrict__ bias;      // f32 [Cout]
+    uint16_t *__restrict__ y;            // bf16 [M, Cout]
+    int M, Cout, relu, n_chunks, n_tiles;
+    unsigned *unit_ctr;                  // 64 counters: [XCD][chunk]
+};
+
+constexpr int K = 1024, KS = K / 32, BM = 32, BNC = 128;
+constexpr int A_BYTES = BM * K * 2;                       // 65 536
+constexpr int PIECES = A_BYTES / 1024, PIECES_PER_WAVE = PIECES / 4;   // 64, 16
+constexpr int XCH_OFF = 2 * A_BYTES;                      // exchange area [4 waves][4 blocks][64 lanes][16 B] = 16 KB
+constexpr int OIMG_OFF = XCH_OFF;                         // output image [32][256 B], over the dead exchange area
+constexpr int LDS_BYTES = XCH_OFF + 16 * 1024;
+static_assert(LDS_BYTES + 64 <= 160 * 1024, "one workgroup per CU");
+
+__global__ __launch_bounds__(256, 1) void conv1x1_kres_kernel(const KresArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int next_slot;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 1, nh = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // Workgroup b runs on XCD b & 7 (round-robin dispatch).  Each XCD takes the pixel tiles t = xcd (mod 8) for EVERY
+    // chunk, and its workgroups are dealt to the chunks in turn: the workgroups of the different chunks walk the same
+    // tile sequence at the same pace inside one L2, so a tile's A rows come from HBM once, not once per chunk.
+    const int xcd = blockIdx.x & 7;
+    const int j_x = blockIdx.x >> 3;                          // index of this workgroup on its XCD
+    const int chunk = j_x % p.n_chunks;                       // its 128 output channels, for its whole life
+    const int wg_l = j_x / p.n_chunks;                        // index among the XCD's workgroups of that chunk
+    const int wgs_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int wgs_c = (wgs_x - chunk + p.n_chunks - 1) / p.n_chunks;
+    const int n_local = (p.n_tiles - xcd + 7) >> 3;           // tiles of this XCD: local tile u = global tile xcd + 8 u
+    unsigned *const my_ctr = p.unit_ctr + xcd * 8 + chunk;
+
+    // ---- resident weights: k-steps [16 kh, 16 kh + 16) x channel tiles [4 nh, 4 nh + 4) of the chunk
+    uint4 wreg[KS / 2][4];
+    {
+        const uint4 *wf = reinterpret_cast<const uint4 *>(p.w) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < KS / 2; ++s)
+                wreg[s][j] = wf[((long long)(chunk * 8 + nh * 4 + j) * KS + kh * (KS / 2) + s) * 64];
+    }
+    const float4 bias4[4] = {
+        *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + nh * 64 + 0 * 16 + fq * 4),
+        *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + nh * 64 + 1 * 16 + fq * 4),
+        *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + nh * 64 + 2 * 16 + fq * 4),
+        *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + nh * 64 + 3 * 16 + fq * 4)};
+
+    // ---- A tile fill: piece pc = wave + 4 k = (row pc >> 1, half pc & 1) = physical chunks [64 half, 64 half + 64) of the
+    //      row; physical chunk c holds logical chunk c ^ (row & 15) (conflict-free fragment reads)
+    const buf_rsrc_t rs = make_rsrc(p.x, (uint32_t)((long long)p.M * K * 2 < 0x7FF00000LL ? (long long)p.M * K * 2 : 0));
+    auto issue_piece = [&](int tile, int buf, int k) {
+        const int pc = wave + 4 * k;
+        const int row = pc >> 1, half = pc & 1;
+        const int m = (xcd + 8 * tile) * BM + row;           // tile: XCD-local index
+        const bool ok = tile < n_local && m < p.M;   // (scalar)
+        const uint32_t vo = ok ? (uint32_t)(((64 * half + lane) ^ (row & 15)) * 16) : 0x80000000u;
+        buf_load_lds16(rs, (lds_ptr_t)(smem + buf * A_BYTES + pc * 1024), vo, ok ? (uint32_t)m * (K * 2) : 0u);
+    };
+
+    int unit = wg_l;
+    int next_unit = unit + wgs_c;
+#pragma unroll
+    for (int k = 0; k < PIECES_PER_WAVE; ++k) issue_piece(unit, 0, k);
+    int g = 0;   // units done by this workgroup: unit g's A tile lives in buffer g & 1
+
+    while (unit < n_local) {
+        const int m0 = (xcd + 8 * unit) * BM;
+        // this unit's A tile has landed (this wave's pieces), then everybody's.  (Behind the first unit only the two
+        // output stores of the previous unit - and wave 0's claim - were issued after these pieces.)
+        if (g != 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned claimed = 0;
+        if (tid == 0) {   // raw instruction: the compiler's atomicAdd waits for the result on the spot (tools/audit_asm_atomic.py)
+            const unsigned one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(my_ctr), "v"(one) : "memory");
+        }
+        const uint32_t ab = lds_base + (uint32_t)((g & 1) * A_BYTES);
+        // fragment of pixel tile i at k-step ks: row i * 16 + frow, logical chunk ks * 4 + fq
+        const uint32_t a_lane = ab + (uint32_t)(frow * (K * 2));
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint4 av[2][2];
+        {
+            int fqo = fq;
+            asm volatile("" : "+v"(fqo));
+            const int ks = kh * (KS / 2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                av[0][i] = lds_read16(a_lane + (uint32_t)(i * 16 * K * 2) + (uint32_t)((((ks * 4 + fqo) ^ frow)) << 4));
+        }
+#pragma unroll
+        for (int s = 0; s < KS / 2; ++s) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < KS / 2) {
+                int fqo = fq;
+                asm volatile("" : "+v"(fqo));   // (addresses rebuilt per step, not hoisted and spilled)
+                const int ks = kh * (KS / 2) + s + 1;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    av[(s + 1) & 1][i] = lds_read16(a_lane + (uint32_t)(i * 16 * K * 2) + (uint32_t)((((ks * 4 + fqo) ^ frow)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[s & 1][i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[s][j]), af, acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next unit's A tile: two pieces behind each of the first eight k-steps
+            if (s < 8) {
+                issue_piece(next_unit, (g + 1) & 1, 2 * s);
+                issue_piece(next_unit, (g + 1) & 1, 2 * s + 1);
+            }
+        }
+        // ---------------------------------------------------------------- exchange of the K halves
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4_t *>(smem + XCH_OFF + ((wave * 4 + j) * 64 + lane) * 16) = acc[1 - kh][j];
+        __syncthreads();
+        f32x4_t own[4];   // pixel tile kh, channel tiles 4 nh + j
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            own[j] = acc[kh][j] + *reinterpret_cast<const f32x4_t *>(smem + XCH_OFF + (((wave ^ 2) * 4 + j) * 64 + lane) * 16);
+        __syncthreads();   // the exchange area becomes the output image
+        // ---------------------------------------------------------------- bias (+ ReLU), bf16, output image [32][256 B]
+        {
+            unsigned char *oimg = smem + OIMG_OFF;
+            const int px = kh * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x2_t v01 = f32x2_t{own[j][0], own[j][1]} + f32x2_t{bias4[j].x, bias4[j].y};
+                f32x2_t v23 = f32x2_t{own[j][2], own[j][3]} + f32x2_t{bias4[j].z, bias4[j].w};
+                if (p.relu) {
+                    v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
+                    v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
+                }
+                uint2 o;
+                o.x = pack2(v01);
+                o.y = pack2(v23);
+                const int c = nh * 8 + j * 2 + (fq >> 1);   // 16-byte chunk of the row; swizzled by the row
+                *reinterpret_cast<uint2 *>(oimg + px * 256 + ((c ^ (px & 15)) << 4) + (fq & 1) * 8) = o;
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned char *oimg = smem + OIMG_OFF;
+            uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)chunk * BNC);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int q = tid + 256 * k;
+                int row = q >> 4;
+                const int c = q & 15;
+                row = m0 + row < p.M ? row : 0;      // past the end: row 0 of the tile again (same data, same address)
+                yo[(long long)(m0 + row) * (p.Cout / 8) + c] = *reinterpret_cast<const uint4 *>(oimg + row * 256 + ((c ^ (row & 15)) << 4));
+            }
+        }
+        if (tid == 0) {   // the claim is older than the A pieces whose wait opens the next unit - and than these stores
+            asm volatile("s_waitcnt vmcnt(2)" : "+v"(claimed)::"memory");
+            next_slot = (int)(claimed + 2 * wgs_c);
+            if (claimed == (unsigned)(n_local - 1)) *my_ctr = 0u;   // the last claim of this (XCD, chunk) re-arms its counter
+        }
+        __syncthreads();
+        ++g;
+        unit = next_unit;
+        next_unit = __builtin_amdgcn_readfirstlane(next_slot);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile prefetched for a unit that does not exist
+}
+
+int g_cus_k = 0;
+constexpr int kMaxDevK = 16, kRingK = 1024;
+unsigned *g_ring_k[kMaxDevK] = {};
+std::atomic<unsigned> g_seq_k{0};
+
+}  // namespace
+
+extern "C" int sc2_conv1x1_kres_supported(int Cin, int Cout, int stride) {
+    return Cin == K && Cout >= BNC && Cout % BNC == 0 && Cout <= 8 * BNC && stride == 1 ? 1 : 0;
+}
+
+extern "C" int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin,
+                                    int Cout, int relu, void *stream) {
+    SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv1x1_kres: null argument");
+    SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv1x1_kres: non-positive dimension");
+    SC2_REQUIRE(sc2_conv1x1_kres_supported(Cin, Cout, 1), SC2_ERR_UNSUPPORTED,
+                "conv1x1_kres: needs Cin == %d, Cout %% %d == 0, Cout <= %d (got %d -> %d)", K, BNC, 8 * BNC, Cin, Cout);
+    const long long M = (long long)N * H * W;
+    SC2_REQUIRE(M * K * 2 < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv1x1_kres: input of %lld pixels exceeds 2 GB", M);
+    KresArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_frag);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.M = (int)M; a.Cout = Cout; a.relu = relu ? 1 : 0;
+    a.n_chunks = Cout / BNC;
+    a.n_tiles = (int)((M + BM - 1) / BM);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_kres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
+        attr_set = true;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    SC2_REQUIRE(dev >= 0 && dev < kMaxDevK, SC2_ERR_UNSUPPORTED, "conv1x1_kres: device ordinal %d out of range", dev);
+    if (g_cus_k == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cus_k = n;
+    }
+    if (!g_ring_k[dev]) {
+        void *ptr = nullptr;
+        SC2_REQUIRE(hipMalloc(&ptr, kRingK * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
+                    "conv1x1_kres: cannot allocate the unit counters");
+        SC2_REQUIRE(hipMemset(ptr, 0, kRingK * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
+                    "conv1x1_kres: cannot clear the unit counters");
+        g_ring_k[dev] = static_cast<unsigned *>(ptr);
+    }
+    const long long units = (long long)a.n_tiles * a.n_chunks;
+    int grid = units < g_cus_k ? (int)units : g_cus_k;          // one 4-wave workgroup per CU
+    if (grid < 8 * a.n_chunks) grid = 8 * a.n_chunks;           // every (XCD, chunk) needs a workgroup
+    a.unit_ctr = g_ring_k[dev] + 64 * (g_seq_k.fetch_add(1) % (kRingK / 64));   // [8 XCDs][<= 8 chunks] counters per launch
+    hipLaunchKernelGGL(conv1x1_kres_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -72,6 +72,8 @@ def lib():
     L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_conv0_gdn96_supported.argtypes = [i32, i32, i32]
     L.sc2_conv0_gdn96_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.sc2_conv1x1_kres_supported.argtypes = [i32, i32, i32]
+    L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
@@ -508,6 +510,31 @@ def pack_weight_fragments(w2d):
     assert n % 16 == 0 and k % 32 == 0
     g = w2d.detach().to(torch.bfloat16).reshape(n // 16, 16, k // 32, 4, 8)      # jt, frow, ks, fq, e
     return g.permute(0, 2, 3, 1, 4).contiguous().reshape(n // 16, k // 32, 64, 8)
+
+
+def conv1x1_kres_supported(cin, cout, kh, kw, stride, pad):
+    """True if this 1x1 conv runs on the weights-in-registers kernel (K = 1024, stride 1, Cout % 128 == 0)."""
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    if os.environ.get('SC2_CONV_KRES', '1') == '0':      # A/B switch (tools/)
+        return False
+    return (kh, kw, ph, pw) == (1, 1, 0, 0) and sh == sw and bool(lib().sc2_conv1x1_kres_supported(cin, cout, sh))
+
+
+def conv1x1_kres_fwd(x_nhwc, w_frag, bias, relu=False, tag=None):
+    """x bf16 [N,H,W,1024] -> bf16 [N,H,W,Cout]; w_frag = pack_weight_fragments(w[Cout, 1024])."""
+    for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, Cin = x_nhwc.shape
+    cout = w_frag.shape[0] * 16
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (cout // 16, Cin // 32, 64, 8)
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
+    out = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    with _timed(tag or 'conv1x1_kres'):
+        _check(lib().sc2_conv1x1_kres_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(out), N, H, W, Cin, cout,
+                                          1 if relu else 0, _stream()), 'conv1x1_kres_fwd')
+    return out
 
 
 def conv1x1_stream_supported(cin, cout, kh, kw, stride, pad):
