@@ -302,8 +302,9 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
     a.n_chunks = 0; a.n_units = 0;   // set per unit shape by the launcher
     a.unit_ctr = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // unit shape: K = 512 -> 64 x 128; otherwise 128 x 256 if it divides Cout, else 128 x 128
+    // unit shape: K = 512 -> 64 x 256 (or 64 x 128); otherwise 128 x 256 if it divides Cout, else 128 x 128
 #define SC2_STREAM_GO(KK, BMM, BNN) return a.res ? launch_stream<KK, BMM, BNN, true>(a, s) : launch_stream<KK, BMM, BNN, false>(a, s)
+    if (Cin == 512 && Cout % 256 == 0) SC2_STREAM_GO(512, 64, 256);   // (half the A re-reads of the 128-wide unit)
     if (Cin == 512) SC2_STREAM_GO(512, 64, 128);
     if (Cout % 256 == 0) {
         if (Cin == 128) SC2_STREAM_GO(128, 128, 256);
