@@ -66,3 +66,20 @@ def test_sizing_helpers(S):
     assert [lib.sc2_conv_weight_rows(c) for c in (24, 48, 64, 96, 256, 512, 1000)] == [32, 48, 64, 96, 256, 512, 1024]
     assert [lib.sc2_conv_weight_pitch(k) for k in (75, 96, 120, 2400)] == [128, 128, 128, 2432]
     assert S.hip.rans_max_bytes(0) >= 8 and S.hip.rans_max_bytes(72600) >= 72600 * 52 // 8
+
+
+def test_raw_claim_atomics_are_read_behind_their_wait():
+    """The persistent kernels claim work with a raw `global_atomic_add` whose destination register hipcc believes is
+    written at the asm statement; if the compiler copies or spills it before the counted wait, claims go stale and the
+    unit loop never ends (seen once).  tools/audit_asm_atomic.py compiles the kernels to ISA and checks the first
+    reader of every such register."""
+    import os
+    import subprocess
+    import sys
+    if not os.path.exists('/opt/rocm/bin/hipcc'):
+        import pytest
+        pytest.skip('hipcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_asm_atomic.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count('ok ') >= 14 and 'BAD' not in r.stdout, r.stdout
