@@ -21,6 +21,7 @@
 //     that is one contiguous block of the NHWC output.
 // Units are claimed dynamically, two ahead, from one counter per XCD (claim c = local unit c + 2 x workgroups of the
 // XCD; an XCD makes exactly as many claims as it has units, and the last one re-arms its counter).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <atomic>
@@ -56,6 +57,19 @@ __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
     return v;
 }
 
+#ifndef SC2_ENC2_STAMPS
+#define SC2_ENC2_STAMPS 0   // 1: diagnostic build that records s_memtime at the phase boundaries (tools/enc2_stamps.py)
+#endif
+#if SC2_ENC2_STAMPS
+#define STAMP(k)                                                                                                \
+    do {                                                                                                        \
+        if (p.stamps && lane == 0 && blockIdx.x < 8 && g_units < 16)                                            \
+            p.stamps[((blockIdx.x * 4 + wave) * 16 + g_units) * 12 + (k)] = __builtin_amdgcn_s_memtime();       \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 struct Enc2Args {
     const uint16_t *__restrict__ x;      // bf16 NHWC [N, H, 112, 96]
     const uint16_t *__restrict__ w;      // bf16 fragment-major, slab-major K: [k-step = cb*25 + tap][3][64][8]
@@ -64,6 +78,7 @@ struct Enc2Args {
     uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, 56, 48]
     int N, H, OH, n_units, units_per_img;
     unsigned *unit_ctr;   // eight counters: one per XCD
+    unsigned long long *stamps;   // diagnostic build only (SC2_ENC2_STAMPS)
 };
 
 constexpr int W_IN = 112, OW = 56, CIN = 96, COUT = 48, J = OW + 2, NTAP = 25, NCB = 3;
@@ -181,12 +196,14 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     int next_unit = unit + wgs_x;
     issue_patch(unit, 0, 0);
     int g = 0;   // global slab counter of this workgroup: slab g lives in patch buffer g & 1
+    [[maybe_unused]] int g_units = 0;
 
     while (unit < n_local) {
         const int im_l = unit / p.units_per_img;
         const int im = xcd + 8 * im_l;
         const int oh0 = (unit - im_l * p.units_per_img) * 2;
         const int n_rows = p.OH - oh0 >= 2 ? 2 : 1;
+        STAMP(0);
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             if (cb == 0 && g != 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            STAMP(1 + 2 * cb);
             if (cb == 1 && tid == 0) {
                 // Claim of the unit after next.  Issue AND wait in one statement: the compiler may copy or spill an asm
                 // load's destination before the data lands (it did, once the register pressure changed: stale claims,
@@ -272,6 +290,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                     issue_piece(jb, 12);
                 }
             }
+            STAMP(2 + 2 * cb);
             ++g;
         }
         // ---------------------------------------------------------------- sum of the four partial tiles, two rounds
@@ -298,6 +317,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             }
         }
         __syncthreads();   // the rounds are dead: their area becomes the |t| image and the output image
+        STAMP(7);
         // ---------------------------------------------------------------- GDN1(48) on the owned pixel tiles (wave-private rows)
         unsigned char *timg = smem + TIMG_OFF;
         unsigned char *oimg = smem + OIMG_OFF;
@@ -346,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             }
         }
         __syncthreads();
+        STAMP(8);
         // ---------------------------------------------------------------- stream the unit out (one contiguous block of y)
         {
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * COUT);
@@ -358,6 +379,8 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             }
         }
         __syncthreads();   // also: the images are free for the next unit's rounds
+        STAMP(9);
+        ++g_units;
         unit = next_unit;
         next_unit = __builtin_amdgcn_readfirstlane(next_slot);
     }
@@ -421,8 +444,30 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
     }
     const int grid = a.n_units < g_cus2 ? a.n_units : g_cus2;   // one 4-wave workgroup per CU
     a.unit_ctr = g_ring2[dev] + 8 * (g_seq2.fetch_add(1) % (kRing2 / 8));   // eight counters per launch
+    a.stamps = nullptr;
+#if SC2_ENC2_STAMPS
+    const char *stamp_path = getenv("SC2_ENC2_STAMPS");
+    const size_t stamp_bytes = 8 * 4 * 16 * 12 * sizeof(unsigned long long);
+    if (stamp_path) {
+        void *sp = nullptr;
+        (void)hipMalloc(&sp, stamp_bytes);
+        (void)hipMemset(sp, 0, stamp_bytes);
+        a.stamps = static_cast<unsigned long long *>(sp);
+    }
+#endif
     if (inverse) hipLaunchKernelGGL(conv2_gdn48_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, s, a);
     else hipLaunchKernelGGL(conv2_gdn48_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, s, a);
+#if SC2_ENC2_STAMPS
+    if (a.stamps) {
+        (void)hipStreamSynchronize(s);
+        unsigned long long *host = static_cast<unsigned long long *>(malloc(stamp_bytes));
+        (void)hipMemcpy(host, a.stamps, stamp_bytes, hipMemcpyDeviceToHost);
+        (void)hipFree(a.stamps);
+        FILE *f = fopen(stamp_path, "wb");
+        if (f) { fwrite(host, 1, stamp_bytes, f); fclose(f); }
+        free(host);
+    }
+#endif
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
