@@ -37,6 +37,8 @@ extern template int launch8<BG_256>(const ConvArgs &, hipStream_t);
 extern template int launch8<BG_128>(const ConvArgs &, hipStream_t);
 extern template int launch8<P3_256>(const ConvArgs &, hipStream_t);
 extern template int launch8<P3_128>(const ConvArgs &, hipStream_t);
+extern template int launch8<S2_128>(const ConvArgs &, hipStream_t);
+extern template int launch8<S2_256>(const ConvArgs &, hipStream_t);
 extern template int launch8<P2_dec2>(const ConvArgs &, hipStream_t);
 extern template int launch8<P2_dec4>(const ConvArgs &, hipStream_t);
 extern template int launch4<R_dec2>(const ConvArgs &, hipStream_t);
@@ -209,6 +211,18 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
             big_tile_eligible(d, M, K)) {
             if (d->pad_h == 0 && d->pad_w == 0) return launch8<P2_dec2>(a, s);
             if (d->pad_h == 1 && d->pad_w == 1) return launch8<P2_dec4>(a, s);
+        }
+    }
+    {
+        // 3x3 stride-2 pad-1 layers: static-geometry 8-wave tile with buffer-addressed gather.  Measured (bs 256): the
+        // 256-wide tile wins where the runtime-geometry big tile was already in use (layer3.0 conv2: 0.127 -> 0.107 ms); the
+        // 128-wide one loses to the 4-wave kernel (layer2.0 0.143 -> 0.168 ms) and is only reachable with SC2_CONV_S2=128.
+        const char *s2 = getenv("SC2_CONV_S2");
+        const int mode = s2 ? atoi(s2) : 1;
+        if (mode != 0 && a.x_bytes != 0 && d->KH == 3 && d->KW == 3 && d->stride_h == 2 && d->stride_w == 2 && d->pad_h == 1 &&
+            d->pad_w == 1 && d->Cin % 32 == 0 && !scatter && d->a_op == SC2_AOP_NONE && d->Cout % 128 == 0 && !fused) {
+            if (mode == 128) return launch8<S2_128>(a, s);
+            if (d->Cout % 256 == 0 && (M >= 256LL * 192 || mode == 256)) return launch8<S2_256>(a, s);
         }
     }
     const bool big = big_tile_eligible(d, M, K);

@@ -1744,6 +1744,9 @@ using BG_128 = Cfg8<128, 4, 2, false, 0, 0, 0, 0, 0, 0, 0>;
 // 3x3 stride-1 pad-1 layers of the ResNet tail: the nine taps read one staged window (Cfg8::PATCH3)
 using P3_256 = Cfg8<256, 2, 4, true, 0, 3, 3, 1, 1, 1, 1, 256, 4, true>;
 using P3_128 = Cfg8<128, 4, 2, true, 0, 3, 3, 1, 1, 1, 1, 256, 4, true>;
+// 3x3 stride-2 pad-1 layers (first block of each stage of the tail): im2col gather with buffer-addressed loads
+using S2_128 = Cfg8<128, 4, 2, true, 0, 3, 3, 2, 2, 1, 1>;
+using S2_256 = Cfg8<256, 2, 4, true, 0, 3, 3, 2, 2, 1, 1>;
 // 2x2 stride-1 decoder layers (dec.conv2: pad 0, dec.conv4: pad 1): windows of up to 448 pixels (tiles that cross an image)
 using P2_dec2 = Cfg8<256, 2, 4, true, 0, 2, 2, 1, 1, 0, 0, 256, 4, true, 192>;
 using P2_dec4 = Cfg8<256, 2, 4, true, 0, 2, 2, 1, 1, 1, 1, 256, 4, true, 192>;

@@ -269,6 +269,27 @@ def test_conv3x3_window_kernel(S, dev, monkeypatch, cin, cout, H, W, N):
     assert_close_bf16(outs['256'], outs['0'], 'window (256-wide) vs gather kernel', extra=2.0 ** -7)
 
 
+@pytest.mark.parametrize('cin,cout,H,W,N', [(128, 128, 56, 56, 3), (64, 256, 29, 27, 4), (32, 512, 14, 14, 12)])
+def test_conv3x3_stride2_static_tile(S, dev, monkeypatch, cin, cout, H, W, N):
+    """3x3 stride-2 pad-1 convolution on the static-geometry 8-wave tile with buffer-addressed gather (out-of-image taps
+    and tail rows are sent out of range and read zeros) vs the f32 op and vs the 4-wave gather kernel; odd sizes."""
+    g = torch.Generator().manual_seed(cin + cout + W)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(bf16_round(x), bf16_round(w), stride=2, padding=1) + bias.reshape(1, -1, 1, 1))
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev), cin)
+    order = S.hip.preferred_k_order(cin, 3, 3)
+    wp = S.hip.pack_conv_weight(w.to(dev), order)
+    outs = {}
+    for flag in ('128', '256', '0'):
+        monkeypatch.setenv('SC2_CONV_S2', flag)
+        outs[flag] = S.hip.conv2d_fwd(x_nhwc, wp, cout, 3, 3, 2, 1, epilogue=S.hip.EPI_BIAS_RELU, ep_beta=bias.to(dev), k_order=order)
+    assert_close_bf16(outs['128'].permute(0, 3, 1, 2), ref, '3x3 stride-2 static tile')
+    assert_close_bf16(outs['128'], outs['0'], 'static tile vs 4-wave gather', extra=2.0 ** -7)
+    assert_close_bf16(outs['256'], outs['0'], 'static 256-wide tile vs 4-wave gather', extra=2.0 ** -7)
+
+
 @pytest.mark.parametrize('half', ['0', '1', 'r4'])
 @pytest.mark.parametrize('cin,k,pad,inverse', [(512, 2, 0, True), (64, 1, 0, False)])
 def test_conv_fused_gdn_big_tile(S, R, dev, monkeypatch, cin, k, pad, inverse, half):
