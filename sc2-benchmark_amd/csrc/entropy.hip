@@ -249,6 +249,40 @@ __global__ __launch_bounds__(256) void eb_dequantize_kernel(const int32_t *__res
     }
 }
 
+// Same, through an LDS tile so that the bf16 NHWC copy leaves as whole 16-byte runs: a block owns 256 pixels of one image
+// for ALL channels (symbols read per channel plane, coalesced), C even.  The plane-per-block form above scatters two bytes
+// per lane at a stride of 2 C bytes: 328 MB of HBM writes for a 37 MB tensor (PMC WRITE_SIZE, profiles/r01f_pmc_traffic.txt).
+constexpr int DQ_TILE = 256;
+__global__ __launch_bounds__(256) void eb_dequantize_tile_kernel(const int32_t *__restrict__ symbols,
+                                                                 const float *__restrict__ medians, int C, int HW,
+                                                                 float *__restrict__ y_hat,
+                                                                 uint16_t *__restrict__ y_hat_nhwc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dq_smem[];
+    uint16_t *tile = reinterpret_cast<uint16_t *>(dq_smem);     // [DQ_TILE][C]
+    const int n = blockIdx.y;
+    const int pix0 = blockIdx.x * DQ_TILE;
+    const int npix = HW - pix0 < DQ_TILE ? HW - pix0 : DQ_TILE;
+    const int t = threadIdx.x;
+    for (int c = 0; c < C; ++c) {
+        const long long base = ((long long)n * C + c) * HW + pix0;
+        if (t < npix) {
+            const float v = (float)symbols[base + t] + medians[c];
+            if (y_hat) y_hat[base + t] = v;
+            tile[t * C + c] = f32_to_bf16_bits(v);
+        }
+    }
+    __syncthreads();
+    const int bytes = npix * C * 2;                              // contiguous in the NHWC output
+    unsigned char *dst = reinterpret_cast<unsigned char *>(y_hat_nhwc + ((long long)n * HW + pix0) * C);
+    // (pix0 * C * 2 is a multiple of 16 for DQ_TILE = 256 and even C; the image base is when HW * C * 2 is)
+    if (((uintptr_t)dst & 15) == 0) {
+        for (int q = t; q < bytes / 16; q += 256) reinterpret_cast<uint4 *>(dst)[q] = reinterpret_cast<const uint4 *>(dq_smem)[q];
+        for (int q = (bytes / 16) * 16 + t; q < bytes; q += 256) dst[q] = dq_smem[q];
+    } else {
+        for (int q = t; q < bytes / 4; q += 256) reinterpret_cast<uint32_t *>(dst)[q] = reinterpret_cast<const uint32_t *>(dq_smem)[q];
+    }
+}
+
 int plane_grid_x(int HW, int per_block) {
     int g = (HW + per_block - 1) / per_block;
     return g < 1 ? 1 : g;
@@ -313,6 +347,13 @@ extern "C" int sc2_eb_dequantize(const int32_t *symbols, const float *medians, i
     SC2_REQUIRE(symbols && medians && (y_hat_f32_nchw || y_hat_bf16_nhwc), SC2_ERR_INVALID_ARG,
                 "eb_dequantize: null argument");
     SC2_REQUIRE(N > 0 && C > 0 && HW > 0, SC2_ERR_INVALID_ARG, "eb_dequantize: bad dims");
+    if (y_hat_bf16_nhwc && C % 2 == 0 && C <= 128 && N <= 65535) {   // tile form: coalesced NHWC stores
+        dim3 grid(plane_grid_x(HW, DQ_TILE), N);
+        hipLaunchKernelGGL(eb_dequantize_tile_kernel, grid, dim3(256), (size_t)DQ_TILE * C * 2, static_cast<hipStream_t>(stream),
+                           symbols, medians, C, HW, y_hat_f32_nchw, static_cast<uint16_t *>(y_hat_bf16_nhwc));
+        SC2_CHECK_LAUNCH();
+        return SC2_OK;
+    }
     dim3 grid(N * C, plane_grid_x(HW, 1024));
     hipLaunchKernelGGL(eb_dequantize_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), symbols, medians,
                        C, HW, y_hat_f32_nchw, static_cast<uint16_t *>(y_hat_bf16_nhwc));

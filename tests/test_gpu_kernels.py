@@ -609,6 +609,21 @@ def test_entropy_bottleneck_forward(S, R, dev):
         assert abs(loss.item() - float(g['bits_eval'])) <= 1e-3 * float(g['bits_eval'])
 
 
+@pytest.mark.parametrize('N,C,H,W', [(3, 24, 55, 55), (2, 24, 7, 9), (5, 6, 16, 16), (2, 25, 10, 10)])
+def test_dequantize_layouts(S, dev, N, C, H, W):
+    """symbols + medians -> f32 NCHW and bf16 NHWC in one launch: both exact (tile-transposed form for even C, ragged last
+    pixel tile, a row base that is not 16-byte aligned; plane form for odd C)."""
+    g = torch.Generator().manual_seed(N * C + W)
+    sym = torch.randint(-40, 40, (N, C, H, W), generator=g, dtype=torch.int32).to(dev)
+    med = torch.randn(C, generator=g).to(dev)
+    f32, nhwc = S.hip.eb_dequantize(sym, med, want_f32=True, want_nhwc=True)
+    ref = sym.float() + med.view(1, C, 1, 1)
+    assert torch.equal(f32, ref)
+    assert torch.equal(nhwc, ref.permute(0, 2, 3, 1).to(torch.bfloat16))
+    _, only = S.hip.eb_dequantize(sym, med, want_f32=False, want_nhwc=True)
+    assert torch.equal(only, nhwc)
+
+
 def test_symbols_and_dequantize_bit_exact(S, R, dev):
     g = _golden()
     m, ref, _ = _device_bottleneck(S, R, dev)
