@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 20
+#define SC2_ABI_VERSION 21
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -51,6 +51,10 @@ int sc2_device_count(void);
 int sc2_nchw_f32_to_nhwc_bf16(const float *x, void *y, int N, int C, int H, int W, int Cpad, void *stream);
 /* x: bf16 NHWC [N,H,W,C] -> y: f32 NCHW [N,C,H,W] (what a reference caller sees). */
 int sc2_nhwc_bf16_to_nchw_f32(const void *x, float *y, int N, int C, int H, int W, void *stream);
+
+/* AdaptiveAvgPool2d((1,1)) + flatten of a bf16 NHWC feature map [N, HW, C] (torchvision ResNet.avgpool,
+ * sc2bench/models/backbone.py:250-252): mean over HW in f32 -> y_f32 [N, C] and / or y_bf16 [N, C] (either may be NULL). */
+int sc2_avgpool_nhwc(const void *x, float *y_f32, void *y_bf16, int N, int HW, int C, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Implicit-GEMM convolution on the matrix cores (bf16 in, f32 accumulate)                    */

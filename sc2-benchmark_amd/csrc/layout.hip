@@ -75,6 +75,52 @@ extern "C" int sc2_nchw_f32_to_nhwc_bf16(const float *x, void *y, int N, int C, 
     return SC2_OK;
 }
 
+namespace {
+// AdaptiveAvgPool2d((1, 1)) + flatten on a bf16 NHWC feature map: one thread per 8 channels of one image walks the HW
+// pixels (each load a 16-byte channel run, a wave reads 1 KB contiguous), f32 accumulation, mean rounded once.
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const uint16_t *__restrict__ x, float *__restrict__ y_f32,
+                                                           uint16_t *__restrict__ y_bf16, int HW, int C) {
+    const int n = blockIdx.y;
+    const int c8 = blockIdx.x * 256 + threadIdx.x;
+    if (c8 * 8 >= C) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(x + (long long)n * HW * C) + c8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < HW; ++p) {
+        const uint4 v = src[(long long)p * (C / 8)];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[2 * k] += __builtin_bit_cast(float, w[k] << 16);
+            acc[2 * k + 1] += __builtin_bit_cast(float, w[k] & 0xFFFF0000u);
+        }
+    }
+    const float inv = 1.0f / (float)HW;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] *= inv;
+    if (y_f32) {
+        float4 *o = reinterpret_cast<float4 *>(y_f32 + (long long)n * C + c8 * 8);
+        o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    if (y_bf16) {
+        uint4 o;
+        o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+        o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+        *reinterpret_cast<uint4 *>(y_bf16 + (long long)n * C + c8 * 8) = o;
+    }
+}
+}  // namespace
+
+extern "C" int sc2_avgpool_nhwc(const void *x, float *y_f32, void *y_bf16, int N, int HW, int C, void *stream) {
+    SC2_REQUIRE(x && (y_f32 || y_bf16), SC2_ERR_INVALID_ARG, "avgpool_nhwc: null argument");
+    SC2_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 8 == 0 && N <= 65535, SC2_ERR_INVALID_ARG,
+                "avgpool_nhwc: bad dims N=%d HW=%d C=%d (C %% 8 == 0, N <= 65535)", N, HW, C);
+    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3((C / 8 + 255) / 256, N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(x), y_f32, static_cast<uint16_t *>(y_bf16), HW, C);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
 extern "C" int sc2_nhwc_bf16_to_nchw_f32(const void *x, float *y, int N, int C, int H, int W, void *stream) {
     SC2_REQUIRE(x && y, SC2_ERR_INVALID_ARG, "nhwc_to_nchw: null argument");
     SC2_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && C % 8 == 0, SC2_ERR_INVALID_ARG,

@@ -98,11 +98,11 @@ class HipHead(object):
             h = c3(o, hip.EPI_BIAS_ADD_RELU, ep_x=identity)
         if not with_pool:
             return h.permute(0, 3, 1, 2)
-        pooled = h.float().mean(dim=(1, 2))                       # [N, C] (AdaptiveAvgPool2d((1,1)) + flatten)
-        if self.fc is None:
-            return pooled
+        if self.fc is None:                                       # [N, C] (AdaptiveAvgPool2d((1,1)) + flatten)
+            return hip.avgpool_nhwc(h.contiguous(), want_f32=True)[0]
         w, b, cout_pad, n_cls = self.fc
-        pin = pooled.to(torch.bfloat16).reshape(pooled.shape[0], 1, 1, pooled.shape[1]).contiguous()
+        pooled = hip.avgpool_nhwc(h.contiguous(), want_f32=False, want_bf16=True)[1]   # f32 mean, rounded once
+        pin = pooled.reshape(pooled.shape[0], 1, 1, pooled.shape[1])
         out = hip.conv2d_fwd(pin, w, cout_pad, 1, 1, 1, 0, epilogue=hip.EPI_BIAS, ep_beta=b,
                              out_format=hip.OUT_F32_NHWC, tag='head.fc')
         return out.reshape(out.shape[0], cout_pad)[:, :n_cls]

@@ -24,7 +24,7 @@ EB_PARAM_STRIDE = 64
 # symbols the header declares; tests check each is exported
 ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
-    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32',
+    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
@@ -63,6 +63,7 @@ def lib():
     L.sc2_device_count.restype = i32
     L.sc2_nchw_f32_to_nhwc_bf16.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_nhwc_bf16_to_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.sc2_avgpool_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.sc2_conv_weight_rows.argtypes = [i32]
     L.sc2_conv_weight_pitch.argtypes = [i32]
     L.sc2_conv_fused_gdn_supported.argtypes = [ctypes.POINTER(ConvDesc)]
@@ -500,6 +501,18 @@ def conv2_gdn48_fwd(x_nhwc, w_frag, gamma_frag, beta, inverse=False, tag=None):
         _check(lib().sc2_conv2_gdn48_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, W,
                                          1 if inverse else 0, _stream()), 'conv2_gdn48_fwd')
     return out
+
+
+def avgpool_nhwc(x_nhwc, want_f32=True, want_bf16=False):
+    """bf16 NHWC [N,H,W,C] -> (mean over H,W as f32 [N,C] or None, the same rounded to bf16 [N,C] or None)."""
+    _dev(x_nhwc, 'x')
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, C = x_nhwc.shape
+    f32 = torch.empty((N, C), dtype=torch.float32, device=x_nhwc.device) if want_f32 else None
+    b16 = torch.empty((N, C), dtype=torch.bfloat16, device=x_nhwc.device) if want_bf16 else None
+    with _timed('avgpool'):
+        _check(lib().sc2_avgpool_nhwc(_ptr(x_nhwc), _ptr(f32), _ptr(b16), N, H * W, C, _stream()), 'avgpool_nhwc')
+    return f32, b16
 
 
 def pack_weight_fragments(w2d):

@@ -609,6 +609,16 @@ def test_entropy_bottleneck_forward(S, R, dev):
         assert abs(loss.item() - float(g['bits_eval'])) <= 1e-3 * float(g['bits_eval'])
 
 
+@pytest.mark.parametrize('N,H,W,C', [(5, 7, 7, 2048), (3, 3, 5, 24), (2, 1, 1, 4096)])
+def test_avgpool_nhwc(S, dev, N, H, W, C):
+    g = torch.Generator().manual_seed(C + N)
+    x = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16).to(dev)
+    f32, b16 = S.hip.avgpool_nhwc(x, want_f32=True, want_bf16=True)
+    ref = x.float().mean(dim=(1, 2))
+    torch.testing.assert_close(f32, ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(b16, f32.to(torch.bfloat16))
+
+
 @pytest.mark.parametrize('N,C,H,W', [(3, 24, 55, 55), (2, 24, 7, 9), (5, 6, 16, 16), (2, 25, 10, 10)])
 def test_dequantize_layouts(S, dev, N, C, H, W):
     """symbols + medians -> f32 NCHW and bf16 NHWC in one launch: both exact (tile-transposed form for even C, ragged last
