@@ -282,17 +282,22 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                 }
                 // three pieces of the next slab behind each of the first taps (13 pieces over taps 0 .. 4): spread, but
                 // early enough to have landed when the slab ends
-                if (q < 4) {
-                    issue_piece(jb, 3 * q);
-                    issue_piece(jb, 3 * q + 1);
-                    issue_piece(jb, 3 * q + 2);
-                } else if (q == 4) {
-                    issue_piece(jb, 12);
+                // (the last slab issues nothing here: the next unit's first slab is fetched from the reduction rounds
+                //  below, where this wave mostly waits)
+                if (cb + 1 < NCB) {
+                    if (q < 4) {
+                        issue_piece(jb, 3 * q);
+                        issue_piece(jb, 3 * q + 1);
+                        issue_piece(jb, 3 * q + 2);
+                    } else if (q == 4) {
+                        issue_piece(jb, 12);
+                    }
                 }
             }
             STAMP(2 + 2 * cb);
             ++g;
         }
+        const PatchJob jb_next = patch_setup(next_unit, 0, g & 1);   // g = first slab of the next unit: its buffer is free
         // ---------------------------------------------------------------- sum of the four partial tiles, two rounds
         f32x4_t own[2][NT];   // owned pixel tiles 4 r + wave, all three channel tiles
 #pragma unroll
@@ -305,6 +310,10 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                     *reinterpret_cast<f32x4_t *>(smem + RED_OFF + ((wave * 12 + b) * 64 + lane) * 16) = acc[i][j];
             }
             __syncthreads();
+            // the next unit's first slab: 7 + 6 pieces, issued while the partial tiles are being read
+#pragma unroll
+            for (int k = 0; k < PIECES_PER_WAVE; ++k)
+                if ((k < 7) == (r == 0)) issue_piece(jb_next, k);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -321,37 +330,59 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         // ---------------------------------------------------------------- GDN1(48) on the owned pixel tiles (wave-private rows)
         unsigned char *timg = smem + TIMG_OFF;
         unsigned char *oimg = smem + OIMG_OFF;
+        {
+            // both owned pixel tiles side by side (their LDS round trips and MFMA chains overlap); the rows are this wave's
+            // own, its LDS operations complete in order: no barrier
+            const bool has1 = 4 + wave < MT;   // wave-uniform: wave 3 owns one tile only
+            int px[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = 4 * r + wave;
-            if (i < MT) {   // wave-uniform
-                const int px = i * 16 + frow;
-                if (fq < 2) *reinterpret_cast<uint4 *>(timg + px * 128 + (((6 + fq) ^ (px & 7)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+            for (int r = 0; r < 2; ++r) px[r] = (4 * r + wave) * 16 + frow;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1 && !has1) continue;
+                if (fq < 2) *reinterpret_cast<uint4 *>(timg + px[r] * 128 + (((6 + fq) ^ (px[r] & 7)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int c = j * 2 + (fq >> 1);
                     uint2 h;
                     h.x = pack2(f32x2_t{own[r][j][0], own[r][j][1]}) & 0x7FFF7FFFu;
                     h.y = pack2(f32x2_t{own[r][j][2], own[r][j][3]}) & 0x7FFF7FFFu;
-                    *reinterpret_cast<uint2 *>(timg + px * 128 + ((c ^ (px & 7)) << 4) + (fq & 1) * 8) = h;
+                    *reinterpret_cast<uint2 *>(timg + px[r] * 128 + ((c ^ (px[r] & 7)) << 4) + (fq & 1) * 8) = h;
                 }
-                // (the rows are this wave's own: its LDS operations complete in order, no barrier)
-                uint4 xv[2];
+            }
+            uint4 gv[NT][2];
+            float4 beta4[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                beta4[j] = *reinterpret_cast<const float4 *>(smem + BETA_OFF + (j * 16 + fq * 4) * 4);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    xv[ks] = *reinterpret_cast<const uint4 *>(timg + px * 128 + (((ks * 4 + fq) ^ (px & 7)) << 4));
+                    gv[j][ks] = *reinterpret_cast<const uint4 *>(smem + GAM_OFF + ((j * 2 + ks) * 64 + lane) * 16);
+            }
+            uint4 xv[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    xv[r][ks] = *reinterpret_cast<const uint4 *>(timg + px[r] * 128 + (((ks * 4 + fq) ^ (px[r] & 7)) << 4));
+            f32x4_t nrm[2][NT];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const float4 beta4 = *reinterpret_cast<const float4 *>(smem + BETA_OFF + (j * 16 + fq * 4) * 4);
-                    f32x4_t nrm = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    nrm[r][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const uint4 gv = *reinterpret_cast<const uint4 *>(smem + GAM_OFF + ((j * 2 + ks) * 64 + lane) * 16);
-                        nrm = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, gv),
-                                                                      __builtin_bit_cast(bf16x8_t, xv[ks]), nrm, 0, 0, 0);
-                    }
-                    const f32x2_t n01 = f32x2_t{beta4.x, beta4.y} + f32x2_t{nrm[0], nrm[1]};
-                    const f32x2_t n23 = f32x2_t{beta4.z, beta4.w} + f32x2_t{nrm[2], nrm[3]};
+                    for (int ks = 0; ks < 2; ++ks)
+                        nrm[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, gv[j][ks]),
+                                                                            __builtin_bit_cast(bf16x8_t, xv[r][ks]), nrm[r][j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r == 1 && !has1) continue;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const f32x2_t n01 = f32x2_t{beta4[j].x, beta4[j].y} + f32x2_t{nrm[r][j][0], nrm[r][j][1]};
+                    const f32x2_t n23 = f32x2_t{beta4[j].z, beta4[j].w} + f32x2_t{nrm[r][j][2], nrm[r][j][3]};
                     const f32x2_t t01 = {own[r][j][0], own[r][j][1]}, t23 = {own[r][j][2], own[r][j][3]};
                     uint2 o;
                     if (INVERSE) {
@@ -361,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                         o.x = pack2(t01 * f32x2_t{__builtin_amdgcn_rcpf(n01[0]), __builtin_amdgcn_rcpf(n01[1])});
                         o.y = pack2(t23 * f32x2_t{__builtin_amdgcn_rcpf(n23[0]), __builtin_amdgcn_rcpf(n23[1])});
                     }
-                    *reinterpret_cast<uint2 *>(oimg + px * (COUT * 2) + (j * 16 + fq * 4) * 2) = o;
+                    *reinterpret_cast<uint2 *>(oimg + px[r] * (COUT * 2) + (j * 16 + fq * 4) * 2) = o;
                 }
             }
         }
