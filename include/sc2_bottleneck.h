@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 21
+#define SC2_ABI_VERSION 22
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -157,13 +157,14 @@ int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs);
 int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N,
                         int H, int W_pairs, int inverse, void *stream);
 
-/* 1x1 convolution with K = 1024 and the weights resident in registers (conv1 + bn1 + ReLU of the ResNet tail's layer3 and
- * layer4.0 in eval mode, sc2bench/models/backbone.py:235-254): y = act(x W^T + bias), stride 1, Cout % 128 == 0, Cout <= 1024.
- *   x : bf16 NHWC [N,H,W,1024];  w_frag : bf16 fragment blocks [Cout/16][32][64][8] (BN folded);  bias : f32 [Cout];
- *   y : bf16 NHWC [N,H,W,Cout];  relu != 0: ReLU. */
+/* 1x1 convolution with a long K and the weights resident in registers (conv1 + bn1 + ReLU and the stride-2 downsample of
+ * the ResNet tail's layer3 / layer4 in eval mode, sc2bench/models/backbone.py:235-254): y = act(x W^T + bias).
+ * Cin = 1024: Cout % 128 == 0, Cout <= 2048;  Cin = 2048: Cout % 64 == 0, Cout <= 1024;  stride 1 or 2 (no padding).
+ *   x : bf16 NHWC [N,H,W,Cin];  w_frag : bf16 fragment blocks [Cout/16][Cin/32][64][8] (BN folded);  bias : f32 [Cout];
+ *   y : bf16 NHWC [N,OH,OW,Cout], OH = (H-1)/stride + 1;  relu != 0: ReLU. */
 int sc2_conv1x1_kres_supported(int Cin, int Cout, int stride);
 int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
-                         int relu, void *stream);
+                         int stride, int relu, void *stream);
 
 /* Second encoder stage in ONE persistent launch: y = GDN1_48(Conv2d(96 -> 48, k5, s2, p2, bias=False)(x)) for
  * 112-pixel-wide inputs (replaces encoder[2] + encoder[3], sc2bench/models/layer.py:479-481; inverse != 0: inverse GDN1).

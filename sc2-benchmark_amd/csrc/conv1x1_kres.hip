@@ -51,23 +51,40 @@ __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
 }
 
 struct KresArgs {
-    const uint16_t *__restrict__ x;      // bf16 [M, 1024]
-    const uint16_t *__restrict__ w;      // bf16 fragment-major [Cout/16][32][64][8]
+    const uint16_t *__restrict__ x;      // bf16 NHWC [N, H, W, K]
+    const uint16_t *__restrict__ w;      // bf16 fragment-major [Cout/16][K/32][64][8]
     const float *__restrict__ bias;      // f32 [Cout]
-    uint16_t *__restrict__ y;            // bf16 [M, Cout]
+    uint16_t *__restrict__ y;            // bf16 [M, Cout],  M = N * OH * OW
     int M, Cout, relu, n_chunks, n_tiles;
-    unsigned *unit_ctr;                  // 64 counters: [XCD][chunk]
+    int H, W, OW, OHW, stride;           // stride 2: output pixel (im, oh, ow) reads input pixel (im, 2 oh, 2 ow)
+    unsigned in_bytes;                   // size of x
+    unsigned *unit_ctr;                  // counters [8 XCDs][16 chunks]
 };
 
-constexpr int K = 1024, KS = K / 32, BM = 32, BNC = 128;
-constexpr int A_BYTES = BM * K * 2;                       // 65 536
-constexpr int PIECES = A_BYTES / 1024, PIECES_PER_WAVE = PIECES / 4;   // 64, 16
-constexpr int XCH_OFF = 2 * A_BYTES;                      // exchange area [4 waves][4 blocks][64 lanes][16 B] = 16 KB
-constexpr int OIMG_OFF = XCH_OFF;                         // output image [32][256 B], over the dead exchange area
-constexpr int LDS_BYTES = XCH_OFF + 16 * 1024;
-static_assert(LDS_BYTES + 64 <= 160 * 1024, "one workgroup per CU");
+// Shapes: K = 1024 -> units of 32 pixels x 128 channels; K = 2048 -> 16 pixels x 64 channels.  Either way a wave holds
+// K / 2 x BNC / 2 weights = 256 VGPRs and an A tile is 64 KB.
+template <int K_, int BM_, int BNC_>
+struct KresShape {
+    static constexpr int K = K_, BM = BM_, BNC = BNC_;
+    static constexpr int KS = K / 32, KSH = KS / 2;          // k-steps, per K half
+    static constexpr int MT = BM / 16, NTW = BNC / 32;       // pixel tiles, channel tiles per wave (its half of the chunk)
+    static constexpr int NB = MT * NTW, NOWN = NB / 2;       // accumulator blocks per wave, owned after the exchange
+    static constexpr int A_BYTES = BM * K * 2;               // 65 536
+    static constexpr int PPR = K * 2 / 1024;                 // 1 KB pieces per A row
+    static constexpr int PIECES = A_BYTES / 1024, PIECES_PER_WAVE = PIECES / 4;   // 64, 16
+    static constexpr int XCH_OFF = 2 * A_BYTES;              // exchange area [4 waves][NOWN blocks][64 lanes][16 B]
+    static constexpr int OIMG_OFF = XCH_OFF;                 // output image [BM][BNC * 2 B], over the dead exchange area
+    static constexpr int LDS_BYTES = XCH_OFF + 16 * 1024;
+    static constexpr int OUT_CHUNKS = BM * BNC * 2 / 16;     // 16-byte chunks of a unit's output
+    static constexpr int STORES = OUT_CHUNKS >= 256 ? OUT_CHUNKS / 256 : 1;   // store instructions per thread and unit
+    static_assert(A_BYTES == 65536 && (K / 64) * (BNC / 32) * 4 == 256, "64 KB A tile, 256 weight registers per wave");
+    static_assert(4 * NOWN * 1024 <= 16 * 1024 && BM * BNC * 2 <= 16 * 1024 && STORES >= 1, "exchange / image area");
+    static_assert(LDS_BYTES + 64 <= 160 * 1024, "one workgroup per CU");
+};
 
+template <class S>
 __global__ __launch_bounds__(256, 1) void conv1x1_kres_kernel(const KresArgs p) {
+    constexpr int K = S::K, BM = S::BM, BNC = S::BNC, KS = S::KS, KSH = S::KSH, MT = S::MT, NTW = S::NTW, NOWN = S::NOWN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int next_slot;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
@@ -82,52 +99,64 @@ __global__ __launch_bounds__(256, 1) void conv1x1_kres_kernel(const KresArgs p) 
     // tile sequence at the same pace inside one L2, so a tile's A rows come from HBM once, not once per chunk.
     const int xcd = blockIdx.x & 7;
     const int j_x = blockIdx.x >> 3;                          // index of this workgroup on its XCD
-    const int chunk = j_x % p.n_chunks;                       // its 128 output channels, for its whole life
+    const int chunk = j_x % p.n_chunks;                       // its BNC output channels, for its whole life
     const int wg_l = j_x / p.n_chunks;                        // index among the XCD's workgroups of that chunk
     const int wgs_x = ((int)gridDim.x - xcd + 7) >> 3;
     const int wgs_c = (wgs_x - chunk + p.n_chunks - 1) / p.n_chunks;
     const int n_local = (p.n_tiles - xcd + 7) >> 3;           // tiles of this XCD: local tile u = global tile xcd + 8 u
-    unsigned *const my_ctr = p.unit_ctr + xcd * 8 + chunk;
+    unsigned *const my_ctr = p.unit_ctr + xcd * 16 + chunk;
 
-    // ---- resident weights: k-steps [16 kh, 16 kh + 16) x channel tiles [4 nh, 4 nh + 4) of the chunk
-    uint4 wreg[KS / 2][4];
+    // ---- resident weights: k-steps [KSH kh, KSH kh + KSH) x channel tiles [NTW nh, NTW nh + NTW) of the chunk
+    uint4 wreg[KSH][NTW];
     {
         const uint4 *wf = reinterpret_cast<const uint4 *>(p.w) + lane;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NTW; ++j)
 #pragma unroll
-            for (int s = 0; s < KS / 2; ++s)
-                wreg[s][j] = wf[((long long)(chunk * 8 + nh * 4 + j) * KS + kh * (KS / 2) + s) * 64];
+            for (int s = 0; s < KSH; ++s)
+                wreg[s][j] = wf[((long long)(chunk * (BNC / 16) + nh * NTW + j) * KS + kh * KSH + s) * 64];
     }
-    const float4 bias4[4] = {
-        *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + nh * 64 + 0 * 16 + fq * 4),
-        *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + nh * 64 + 1 * 16 + fq * 4),
-        *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + nh * 64 + 2 * 16 + fq * 4),
-        *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + nh * 64 + 3 * 16 + fq * 4)};
 
-    // ---- A tile fill: piece pc = wave + 4 k = (row pc >> 1, half pc & 1) = physical chunks [64 half, 64 half + 64) of the
-    //      row; physical chunk c holds logical chunk c ^ (row & 15) (conflict-free fragment reads)
-    const buf_rsrc_t rs = make_rsrc(p.x, (uint32_t)((long long)p.M * K * 2 < 0x7FF00000LL ? (long long)p.M * K * 2 : 0));
-    auto issue_piece = [&](int tile, int buf, int k) {
+    // ---- A tile fill: piece pc = wave + 4 k = (row pc / PPR, part pc % PPR) = physical chunks [64 part, 64 part + 64) of
+    //      the row; physical chunk c holds logical chunk c ^ (row & 15) (conflict-free fragment reads)
+    const buf_rsrc_t rs = make_rsrc(p.x, p.in_bytes);
+    // input pixel of output pixel m (stride 2: every other pixel of every other row), as a byte offset; lane r < BM of
+    // every wave computes row r of a tile, the pieces pick theirs with v_readlane
+    auto row_offsets = [&](int tile) -> uint32_t {
+        const int m = (xcd + 8 * tile) * BM + (lane & (BM - 1));
+        const bool ok = tile < n_local && m < p.M;
+        long long pix = m;
+        if (p.stride == 2) {
+            const int mm = ok ? m : 0;
+            const int im = mm / p.OHW, rem = mm - im * p.OHW;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            pix = ((long long)im * p.H + 2 * oh) * p.W + 2 * ow;
+        }
+        return ok ? (uint32_t)(pix * (K * 2)) : 0xFFFFFFFFu;
+    };
+    auto issue_piece = [&](uint32_t rowoff_v, int buf, int k) {
         const int pc = wave + 4 * k;
-        const int row = pc >> 1, half = pc & 1;
-        const int m = (xcd + 8 * tile) * BM + row;           // tile: XCD-local index
-        const bool ok = tile < n_local && m < p.M;   // (scalar)
-        const uint32_t vo = ok ? (uint32_t)(((64 * half + lane) ^ (row & 15)) * 16) : 0x80000000u;
-        buf_load_lds16(rs, (lds_ptr_t)(smem + buf * A_BYTES + pc * 1024), vo, ok ? (uint32_t)m * (K * 2) : 0u);
+        const int row = pc / S::PPR, part = pc % S::PPR;
+        const uint32_t ro = (uint32_t)__builtin_amdgcn_readlane((int)rowoff_v, row);   // scalar
+        const bool ok = ro != 0xFFFFFFFFu;
+        const uint32_t vo = ok ? (uint32_t)(((64 * part + lane) ^ (row & 15)) * 16) : 0x80000000u;
+        buf_load_lds16(rs, (lds_ptr_t)(smem + buf * S::A_BYTES + pc * 1024), vo, ok ? ro : 0u);
     };
 
     int unit = wg_l;
     int next_unit = unit + wgs_c;
+    {
+        const uint32_t ro = row_offsets(unit);
 #pragma unroll
-    for (int k = 0; k < PIECES_PER_WAVE; ++k) issue_piece(unit, 0, k);
+        for (int k = 0; k < S::PIECES_PER_WAVE; ++k) issue_piece(ro, 0, k);
+    }
     int g = 0;   // units done by this workgroup: unit g's A tile lives in buffer g & 1
 
     while (unit < n_local) {
         const int m0 = (xcd + 8 * unit) * BM;
-        // this unit's A tile has landed (this wave's pieces), then everybody's.  (Behind the first unit only the two
-        // output stores of the previous unit - and wave 0's claim - were issued after these pieces.)
-        if (g != 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        // this unit's A tile has landed (this wave's pieces), then everybody's.  (Behind the first unit only the output
+        // stores of the previous unit were issued after these pieces.)
+        if (g != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S::STORES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned claimed = 0;
@@ -135,67 +164,80 @@ __global__ __launch_bounds__(256, 1) void conv1x1_kres_kernel(const KresArgs p) 
             const unsigned one = 1u;
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(my_ctr), "v"(one) : "memory");
         }
-        const uint32_t ab = lds_base + (uint32_t)((g & 1) * A_BYTES);
+        const uint32_t ro_next = row_offsets(next_unit);
+        const uint32_t ab = lds_base + (uint32_t)((g & 1) * S::A_BYTES);
         // fragment of pixel tile i at k-step ks: row i * 16 + frow, logical chunk ks * 4 + fq
         const uint32_t a_lane = ab + (uint32_t)(frow * (K * 2));
-        f32x4_t acc[2][4];
+        f32x4_t acc[MT][NTW];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        uint4 av[2][2];
+            for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint4 av[2][MT];
         {
             int fqo = fq;
             asm volatile("" : "+v"(fqo));
-            const int ks = kh * (KS / 2);
+            const int ks = kh * KSH;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
                 av[0][i] = lds_read16(a_lane + (uint32_t)(i * 16 * K * 2) + (uint32_t)((((ks * 4 + fqo) ^ frow)) << 4));
         }
+        constexpr int PIECE_STEPS = 8;                                     // k-steps that carry the next unit's pieces
+        constexpr int PER_STEP = S::PIECES_PER_WAVE / PIECE_STEPS;
 #pragma unroll
-        for (int s = 0; s < KS / 2; ++s) {
+        for (int s = 0; s < KSH; ++s) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < KS / 2) {
+            if (s + 1 < KSH) {
                 int fqo = fq;
                 asm volatile("" : "+v"(fqo));   // (addresses rebuilt per step, not hoisted and spilled)
-                const int ks = kh * (KS / 2) + s + 1;
+                const int ks = kh * KSH + s + 1;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
                     av[(s + 1) & 1][i] = lds_read16(a_lane + (uint32_t)(i * 16 * K * 2) + (uint32_t)((((ks * 4 + fqo) ^ frow)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MT; ++i) {
                 const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[s & 1][i]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NTW; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wreg[s][j]), af, acc[i][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             // the next unit's A tile: two pieces behind each of the first eight k-steps
-            if (s < 8) {
-                issue_piece(next_unit, (g + 1) & 1, 2 * s);
-                issue_piece(next_unit, (g + 1) & 1, 2 * s + 1);
+            if (s < PIECE_STEPS) {
+#pragma unroll
+                for (int q = 0; q < PER_STEP; ++q) issue_piece(ro_next, (g + 1) & 1, PER_STEP * s + q);
             }
         }
-        // ---------------------------------------------------------------- exchange of the K halves
+        // ---------------------------------------------------------------- exchange of the K halves: block b = i NTW + j;
+        // wave (kh, nh) keeps blocks [NOWN kh, NOWN kh + NOWN) and sends the others to its partner (1 - kh, nh)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<f32x4_t *>(smem + XCH_OFF + ((wave * 4 + j) * 64 + lane) * 16) = acc[1 - kh][j];
+        for (int b = 0; b < NOWN; ++b) {
+            const f32x4_t v = kh ? acc[b / NTW][b % NTW] : acc[(NOWN + b) / NTW][(NOWN + b) % NTW];   // the block I do not own
+            *reinterpret_cast<f32x4_t *>(smem + S::XCH_OFF + ((wave * NOWN + b) * 64 + lane) * 16) = v;
+        }
         __syncthreads();
-        f32x4_t own[4];   // pixel tile kh, channel tiles 4 nh + j
+        f32x4_t own[NOWN];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            own[j] = acc[kh][j] + *reinterpret_cast<const f32x4_t *>(smem + XCH_OFF + (((wave ^ 2) * 4 + j) * 64 + lane) * 16);
+        for (int b = 0; b < NOWN; ++b) {
+            const f32x4_t mine = kh ? acc[(NOWN + b) / NTW][(NOWN + b) % NTW] : acc[b / NTW][b % NTW];
+            own[b] = mine + *reinterpret_cast<const f32x4_t *>(smem + S::XCH_OFF + (((wave ^ 2) * NOWN + b) * 64 + lane) * 16);
+        }
         __syncthreads();   // the exchange area becomes the output image
-        // ---------------------------------------------------------------- bias (+ ReLU), bf16, output image [32][256 B]
+        // ---------------------------------------------------------------- bias (+ ReLU), bf16, output image [BM][BNC * 2 B]
         {
-            unsigned char *oimg = smem + OIMG_OFF;
-            const int px = kh * 16 + frow;
+            unsigned char *oimg = smem + S::OIMG_OFF;
+            constexpr int CPI = BNC / 8;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f32x2_t v01 = f32x2_t{own[j][0], own[j][1]} + f32x2_t{bias4[j].x, bias4[j].y};
-                f32x2_t v23 = f32x2_t{own[j][2], own[j][3]} + f32x2_t{bias4[j].z, bias4[j].w};
+            for (int b = 0; b < NOWN; ++b) {
+                const int bb = kh * NOWN + b;
+                const int i = bb / NTW, j = bb % NTW;             // (scalar)
+                const int px = i * 16 + frow;
+                const int ch = nh * (BNC / 2) + j * 16 + fq * 4;  // channel inside the chunk
+                const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + ch);
+                f32x2_t v01 = f32x2_t{own[b][0], own[b][1]} + f32x2_t{bias4.x, bias4.y};
+                f32x2_t v23 = f32x2_t{own[b][2], own[b][3]} + f32x2_t{bias4.z, bias4.w};
                 if (p.relu) {
                     v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
                     v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
@@ -203,25 +245,27 @@ __global__ __launch_bounds__(256, 1) void conv1x1_kres_kernel(const KresArgs p) 
                 uint2 o;
                 o.x = pack2(v01);
                 o.y = pack2(v23);
-                const int c = nh * 8 + j * 2 + (fq >> 1);   // 16-byte chunk of the row; swizzled by the row
-                *reinterpret_cast<uint2 *>(oimg + px * 256 + ((c ^ (px & 15)) << 4) + (fq & 1) * 8) = o;
+                const int c = ch >> 3;                            // 16-byte chunk of the row; swizzled by the row
+                *reinterpret_cast<uint2 *>(oimg + px * (BNC * 2) + ((c ^ (px & (CPI - 1))) << 4) + (ch & 7) * 2) = o;
             }
         }
         __syncthreads();
         {
-            const unsigned char *oimg = smem + OIMG_OFF;
+            const unsigned char *oimg = smem + S::OIMG_OFF;
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)chunk * BNC);
+            constexpr int CPI = BNC / 8;                          // 16-byte chunks per image row
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int q = tid + 256 * k;
-                int row = q >> 4;
-                const int c = q & 15;
+            for (int k = 0; k < S::STORES; ++k) {
+                const int q = (tid + 256 * k) % S::OUT_CHUNKS;   // (a 2 KB image: both halves of the workgroup store it)
+                int row = q / CPI;
+                const int c = q % CPI;
                 row = m0 + row < p.M ? row : 0;      // past the end: row 0 of the tile again (same data, same address)
-                yo[(long long)(m0 + row) * (p.Cout / 8) + c] = *reinterpret_cast<const uint4 *>(oimg + row * 256 + ((c ^ (row & 15)) << 4));
+                yo[(long long)(m0 + row) * (p.Cout / 8) + c] =
+                    *reinterpret_cast<const uint4 *>(oimg + row * (BNC * 2) + ((c ^ (row & (CPI - 1))) << 4));
             }
         }
         if (tid == 0) {   // the claim is older than the A pieces whose wait opens the next unit - and than these stores
-            asm volatile("s_waitcnt vmcnt(2)" : "+v"(claimed)::"memory");
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(claimed) : "n"(S::STORES) : "memory");
             next_slot = (int)(claimed + 2 * wgs_c);
             if (claimed == (unsigned)(n_local - 1)) *my_ctr = 0u;   // the last claim of this (XCD, chunk) re-arms its counter
         }
@@ -238,38 +282,22 @@ constexpr int kMaxDevK = 16, kRingK = 1024;
 unsigned *g_ring_k[kMaxDevK] = {};
 std::atomic<unsigned> g_seq_k{0};
 
-}  // namespace
-
-extern "C" int sc2_conv1x1_kres_supported(int Cin, int Cout, int stride) {
-    return Cin == K && Cout >= BNC && Cout % BNC == 0 && Cout <= 8 * BNC && stride == 1 ? 1 : 0;
-}
-
-extern "C" int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin,
-                                    int Cout, int relu, void *stream) {
-    SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv1x1_kres: null argument");
-    SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv1x1_kres: non-positive dimension");
-    SC2_REQUIRE(sc2_conv1x1_kres_supported(Cin, Cout, 1), SC2_ERR_UNSUPPORTED,
-                "conv1x1_kres: needs Cin == %d, Cout %% %d == 0, Cout <= %d (got %d -> %d)", K, BNC, 8 * BNC, Cin, Cout);
-    const long long M = (long long)N * H * W;
-    SC2_REQUIRE(M * K * 2 < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv1x1_kres: input of %lld pixels exceeds 2 GB", M);
-    KresArgs a;
-    a.x = static_cast<const uint16_t *>(x);
-    a.w = static_cast<const uint16_t *>(w_frag);
-    a.bias = bias;
-    a.y = static_cast<uint16_t *>(y);
-    a.M = (int)M; a.Cout = Cout; a.relu = relu ? 1 : 0;
-    a.n_chunks = Cout / BNC;
-    a.n_tiles = (int)((M + BM - 1) / BM);
-    hipStream_t s = static_cast<hipStream_t>(stream);
+template <class S>
+int launch_kres(KresArgs a, hipStream_t s) {
+    a.n_chunks = a.Cout / S::BNC;
+    a.n_tiles = (a.M + S::BM - 1) / S::BM;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_kres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_kres_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  S::LDS_BYTES);
         attr_set = true;
     }
     int dev = 0;
     (void)hipGetDevice(&dev);
-    SC2_REQUIRE(dev >= 0 && dev < kMaxDevK, SC2_ERR_UNSUPPORTED, "conv1x1_kres: device ordinal %d out of range", dev);
+    if (dev < 0 || dev >= kMaxDevK) {
+        sc2_set_error("conv1x1_kres: device ordinal %d out of range", dev);
+        return SC2_ERR_UNSUPPORTED;
+    }
     if (g_cus_k == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -277,17 +305,52 @@ extern "C" int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const flo
     }
     if (!g_ring_k[dev]) {
         void *ptr = nullptr;
-        SC2_REQUIRE(hipMalloc(&ptr, kRingK * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
-                    "conv1x1_kres: cannot allocate the unit counters");
-        SC2_REQUIRE(hipMemset(ptr, 0, kRingK * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
-                    "conv1x1_kres: cannot clear the unit counters");
+        if (hipMalloc(&ptr, kRingK * sizeof(unsigned)) != hipSuccess || hipMemset(ptr, 0, kRingK * sizeof(unsigned)) != hipSuccess) {
+            sc2_set_error("conv1x1_kres: cannot allocate the unit counters");
+            return SC2_ERR_INTERNAL;
+        }
         g_ring_k[dev] = static_cast<unsigned *>(ptr);
     }
     const long long units = (long long)a.n_tiles * a.n_chunks;
     int grid = units < g_cus_k ? (int)units : g_cus_k;          // one 4-wave workgroup per CU
     if (grid < 8 * a.n_chunks) grid = 8 * a.n_chunks;           // every (XCD, chunk) needs a workgroup
-    a.unit_ctr = g_ring_k[dev] + 64 * (g_seq_k.fetch_add(1) % (kRingK / 64));   // [8 XCDs][<= 8 chunks] counters per launch
-    hipLaunchKernelGGL(conv1x1_kres_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a);
+    a.unit_ctr = g_ring_k[dev] + 128 * (g_seq_k.fetch_add(1) % (kRingK / 128));   // [8 XCDs][16 chunks] counters per launch
+    hipLaunchKernelGGL(conv1x1_kres_kernel<S>, dim3(grid), dim3(256), S::LDS_BYTES, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
+}
+
+}  // namespace
+
+extern "C" int sc2_conv1x1_kres_supported(int Cin, int Cout, int stride) {
+    if (stride != 1 && stride != 2) return 0;
+    if (Cin == 1024) return Cout >= 128 && Cout % 128 == 0 && Cout <= 16 * 128 ? 1 : 0;
+    if (Cin == 2048) return Cout >= 64 && Cout % 64 == 0 && Cout <= 16 * 64 ? 1 : 0;
+    return 0;
+}
+
+extern "C" int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin,
+                                    int Cout, int stride, int relu, void *stream) {
+    SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv1x1_kres: null argument");
+    SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv1x1_kres: non-positive dimension");
+    SC2_REQUIRE(sc2_conv1x1_kres_supported(Cin, Cout, stride), SC2_ERR_UNSUPPORTED,
+                "conv1x1_kres: needs Cin 1024 (Cout %% 128 == 0, <= 2048) or 2048 (Cout %% 64 == 0, <= 1024), stride 1 or 2 "
+                "(got %d -> %d, stride %d)", Cin, Cout, stride);
+    const long long in_bytes = (long long)N * H * W * Cin * 2;
+    SC2_REQUIRE(in_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv1x1_kres: input of %lld bytes exceeds 2 GB", in_bytes);
+    KresArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_frag);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.H = H; a.W = W; a.stride = stride;
+    const int OH = (H - 1) / stride + 1;
+    a.OW = (W - 1) / stride + 1;
+    a.OHW = OH * a.OW;
+    a.M = N * a.OHW; a.Cout = Cout; a.relu = relu ? 1 : 0;
+    a.in_bytes = (unsigned)in_bytes;
+    a.n_chunks = 0; a.n_tiles = 0; a.unit_ctr = nullptr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (Cin == 1024) return launch_kres<KresShape<1024, 32, 128>>(a, s);
+    return launch_kres<KresShape<2048, 16, 64>>(a, s);
 }

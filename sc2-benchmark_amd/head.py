@@ -43,7 +43,8 @@ class _Conv(object):
         # HBM-bound 1x1 layers with a short K and a wide N run on the persistent streaming kernel
         self.stream = hip.conv1x1_stream_supported(conv.in_channels, conv.out_channels, self.k[0], self.k[1],
                                                    self.stride, self.pad) and conv.dilation == (1, 1)
-        # K = 1024 1x1 layers (conv1 of layer3 / layer4.0): weights resident in registers, one 128-channel chunk per workgroup
+        # K = 1024 / 2048 1x1 layers (conv1 of layer3 / layer4, layer4's downsample): weights resident in registers, one
+        # channel chunk per workgroup
         self.kres = (not self.stream) and conv.dilation == (1, 1) and hip.conv1x1_kres_supported(
             conv.in_channels, conv.out_channels, self.k[0], self.k[1], self.stride, self.pad)
         if self.stream or self.kres:
@@ -57,7 +58,8 @@ class _Conv(object):
                                           residual=ep_x if epilogue == hip.EPI_BIAS_ADD_RELU else None,
                                           relu=epilogue != hip.EPI_BIAS, tag=self.tag)
         if self.kres and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU):
-            return hip.conv1x1_kres_fwd(x, self.w_frag, self.b, relu=epilogue == hip.EPI_BIAS_RELU, tag=self.tag)
+            return hip.conv1x1_kres_fwd(x, self.w_frag, self.b, stride=self.stride[0], relu=epilogue == hip.EPI_BIAS_RELU,
+                                        tag=self.tag)
         return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,
                               ep_x=ep_x, ep_beta=self.b, tag=self.tag, k_order=self.k_order)
 

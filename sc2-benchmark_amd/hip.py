@@ -74,7 +74,7 @@ def lib():
     L.sc2_conv0_gdn96_supported.argtypes = [i32, i32, i32]
     L.sc2_conv0_gdn96_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_kres_supported.argtypes = [i32, i32, i32]
-    L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
@@ -526,16 +526,19 @@ def pack_weight_fragments(w2d):
 
 
 def conv1x1_kres_supported(cin, cout, kh, kw, stride, pad):
-    """True if this 1x1 conv runs on the weights-in-registers kernel (K = 1024, stride 1, Cout % 128 == 0)."""
+    """True if this 1x1 conv runs on the weights-in-registers kernel (K = 1024 or 2048, stride 1 or 2)."""
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    if os.environ.get('SC2_CONV_KRES', '1') == '0':      # A/B switch (tools/)
+    mode = os.environ.get('SC2_CONV_KRES', '1')          # A/B switch (tools/): 0 off, 2 = also the K = 2048 layers
+    if mode == '0':
+        return False
+    if cin == 2048 and mode != '2':   # measured: layer4 conv1 (2048 -> 512, 12 544 pixels) 0.065 ms vs 0.063 ms on the tile kernel
         return False
     return (kh, kw, ph, pw) == (1, 1, 0, 0) and sh == sw and bool(lib().sc2_conv1x1_kres_supported(cin, cout, sh))
 
 
-def conv1x1_kres_fwd(x_nhwc, w_frag, bias, relu=False, tag=None):
-    """x bf16 [N,H,W,1024] -> bf16 [N,H,W,Cout]; w_frag = pack_weight_fragments(w[Cout, 1024])."""
+def conv1x1_kres_fwd(x_nhwc, w_frag, bias, stride=1, relu=False, tag=None):
+    """x bf16 [N,H,W,Cin] -> bf16 [N,OH,OW,Cout]; w_frag = pack_weight_fragments(w[Cout, Cin]); Cin 1024 or 2048."""
     for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
         _dev(t, name)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
@@ -543,9 +546,10 @@ def conv1x1_kres_fwd(x_nhwc, w_frag, bias, relu=False, tag=None):
     cout = w_frag.shape[0] * 16
     assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (cout // 16, Cin // 32, 64, 8)
     assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
-    out = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    stride = int(stride)
+    out = torch.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, cout), dtype=torch.bfloat16, device=x_nhwc.device)
     with _timed(tag or 'conv1x1_kres'):
-        _check(lib().sc2_conv1x1_kres_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(out), N, H, W, Cin, cout,
+        _check(lib().sc2_conv1x1_kres_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(out), N, H, W, Cin, cout, stride,
                                           1 if relu else 0, _stream()), 'conv1x1_kres_fwd')
     return out
 

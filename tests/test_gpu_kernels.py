@@ -515,27 +515,31 @@ def test_conv2_gdn48_fused(S, R, dev, N, H, inverse):
     assert_close_bf16(out, tile, 'persistent vs patch kernel', extra=2.0 ** -7)
 
 
-@pytest.mark.parametrize('cout,N,H,W,relu', [(256, 3, 14, 14, True), (512, 2, 9, 7, False), (128, 70, 14, 14, True),
-                                             (1024, 1, 5, 5, True)])
-def test_conv1x1_kres(S, dev, cout, N, H, W, relu):
-    """1x1 conv with K = 1024 and the weights resident in registers (+ bias, ReLU) against the f32 op on the bf16-rounded
-    operands and against the tile kernel; ragged last pixel tile, one to eight channel chunks, more units than
-    workgroups (dynamic claims per chunk)."""
+@pytest.mark.parametrize('cin,cout,stride,N,H,W,relu', [(1024, 256, 1, 3, 14, 14, True), (1024, 512, 1, 2, 9, 7, False),
+                                                        (1024, 128, 1, 70, 14, 14, True), (1024, 2048, 2, 3, 14, 14, False),
+                                                        (2048, 512, 1, 5, 7, 7, True), (2048, 64, 2, 9, 5, 6, True),
+                                                        (2048, 1024, 1, 40, 7, 7, False)])
+def test_conv1x1_kres(S, dev, cin, cout, stride, N, H, W, relu):
+    """1x1 conv with K = 1024 / 2048 and the weights resident in registers (+ bias, ReLU, stride 2) against the f32 op on
+    the bf16-rounded operands and against the tile kernel; ragged last pixel tile, one to sixteen channel chunks, more
+    units than workgroups (dynamic claims per XCD and chunk)."""
     g = torch.Generator().manual_seed(cout + N)
-    x = torch.randn(N, 1024, H, W, generator=g)
-    w = torch.randn(cout, 1024, 1, 1, generator=g) / 32
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
     bias = torch.randn(cout, generator=g)
-    ref = F.conv2d(bf16_round(x), bf16_round(w)) + bias.view(1, -1, 1, 1)
+    ref = F.conv2d(bf16_round(x), bf16_round(w), stride=stride) + bias.view(1, -1, 1, 1)
     if relu:
         ref = F.relu(ref)
-    assert S.hip.conv1x1_kres_supported(1024, cout, 1, 1, 1, 0)
+    assert bool(S.hip.lib().sc2_conv1x1_kres_supported(cin, cout, stride))
+    assert S.hip.conv1x1_kres_supported(cin, cout, 1, 1, stride, 0) == (cin == 1024)   # K = 2048: opt-in (no gain measured)
     assert not S.hip.conv1x1_kres_supported(512, cout, 1, 1, 1, 0)
-    assert not S.hip.conv1x1_kres_supported(1024, cout, 1, 1, 2, 0)
+    assert not S.hip.conv1x1_kres_supported(cin, cout, 1, 1, 3, 0)
     x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
-    out = S.hip.conv1x1_kres_fwd(x_nhwc, S.hip.pack_weight_fragments(w.reshape(cout, 1024).to(dev)), bias.to(dev), relu=relu)
-    assert out.shape == (N, H, W, cout)
+    out = S.hip.conv1x1_kres_fwd(x_nhwc, S.hip.pack_weight_fragments(w.reshape(cout, cin).to(dev)), bias.to(dev), stride=stride,
+                                 relu=relu)
+    assert out.shape == (N, ref.shape[2], ref.shape[3], cout)
     assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'weights-in-registers 1x1 conv')
-    gen = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 1, 1, 1, 0,
+    gen = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 1, 1, stride, 0,
                            epilogue=S.hip.EPI_BIAS_RELU if relu else S.hip.EPI_BIAS, ep_beta=bias.to(dev))
     assert_close_bf16(out, gen, 'kres vs tile kernel', extra=2.0 ** -8)
 
