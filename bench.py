@@ -9,11 +9,14 @@ reference's evaluation mode after update() (sc2bench/models/backbone.py:229-233)
     encoder (3 MFMA convs + 2 GDN1) -> symbols -> rANS encode (one stream per image) -> rANS decode ->
     dequantise -> decoder (3 MFMA convs + 2 inverse GDN1) -> ResNet-50 layer2..fc -> logits.
 Nothing is skipped: the byte streams are really produced and really decoded; bpp is 8 * bytes / pixels.
-Steps are software-pipelined over HIP streams (the encoder stage on one stream, decoder + head on a second; the serial
-range coder of batch i runs on one of five coder streams and overlaps the MFMA kernels of the neighbouring batches);
-exactly K steps start and complete inside the timed region, bracketed by barrier + synchronize, so the region carries
-one fill and drain of that pipeline (one coder latency, ~24 ms: 5 % of the default K = 100 steps, 13 % of K = 20); the
-wall time is the max over ranks.  One process per GPU; the path shards by image, so
+Steps are software-pipelined over HIP streams: the encoder stage on one stream, decoder + head on a second, and the serial
+range coder on two coder streams, ONE coder launch per 8 steps (8 x 256 image streams encoded, then decoded, by the same
+two serial kernels: their ~25 ms are per-stream latency, not work, and do not grow with the number of streams).  Measured:
+a long-running kernel on another hardware queue slows every MFMA launch of the pipeline, even a single-thread spin
+kernel (6.3 ms per step without the coder, 7.1 ms with spin kernels in its place, 7.9 ms with one coder chain per step,
+6.7 ms with one per 8 steps; `--diag-skip-coder`, tools/diag_coder.sh), so fewer, wider coder launches win.  Exactly K
+steps start and complete inside the timed region, bracketed by barrier + synchronize, so the region carries one fill and
+drain of that pipeline; the wall time is the max over ranks.  One process per GPU; the path shards by image, so
 N GPUs = N independent shards, no data-path collective ("weak" scaling, bs per GPU fixed).
 
 Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant MFMA kernel, HIP events on
@@ -197,9 +200,11 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--inflight', type=int, default=5, help='range-coder chains in flight (coder HIP streams, <= 7)')
+    ap.add_argument('--inflight', type=int, default=2, help='range-coder chains in flight (coder HIP streams, <= 7)')
+    ap.add_argument('--coder-group', type=int, default=8, help='steps whose symbols share one range-coder launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--split-mfma', type=int, default=1, help='K > 0: decoder+head stages round-robin on K HIP streams of their own (0: one MFMA stream for everything)')
+    ap.add_argument('--diag-skip-coder', type=int, default=0, help='DIAGNOSTIC (invalid as a result): 1 = reuse the first step\'s coder output, 2 = same but still run the coder')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
@@ -231,19 +236,53 @@ def main():
     # (encode -> bytes -> decode) runs on one of `n_coder` coder streams, so `n_coder` coder chains are in
     # flight while the matrix cores never wait for them.  1 + n_coder streams <= the 8 hardware queues
     # (GPU_MAX_HW_QUEUES above).  A coder chain is 4 waves (256 lanes = 256 streams) for ~20 ms: latency, not work.
-    n_coder = max(1, min(args.inflight, 7))
-    depth = n_coder
+    n_coder = max(1, min(args.inflight, 13))
+    depth = n_coder * max(1, args.coder_group)
     mfma_stream = torch.cuda.Stream(device=dev)
     # --split-mfma: front(i) [encoder] and back(i - depth) [decoder + head] on two streams, so that the tails of one
     # stage's short launches overlap the other's (both still feed the same matrix cores)
     back_streams = [torch.cuda.Stream(device=dev, priority=args.back_priority) for _ in range(args.split_mfma)] \
         if args.split_mfma else [mfma_stream]
     coder_streams = [torch.cuda.Stream(device=dev, priority=args.coder_priority) for _ in range(n_coder)]
-    D = n_coder + 1
+    D = depth + 1
     results = [None]
+    cached = []
+
+    G = max(1, args.coder_group)   # steps whose symbols share ONE coder launch (G * bs streams per launch)
 
     def run_steps(n_steps):
         pending = {}
+        group = []   # (step, symbols, (h, w), event) of the steps waiting for their coder launch
+
+        def flush():
+            cs = coder_streams[(group[0][0] // G) % n_coder]
+            with torch.cuda.stream(cs):
+                for _, g_sym, _, g_ev in group:
+                    cs.wait_event(g_ev)
+                    g_sym.record_stream(cs)
+                sym = group[0][1] if len(group) == 1 else torch.cat([g[1] for g in group])
+                hw = group[0][2]
+                if args.diag_skip_coder and cached:   # diagnostic only: how much the coder chains cost the MFMA stages
+                    dec, nb, st = cached[0]
+                    ev2 = torch.cuda.Event()
+                    ev2.record(cs)
+                    if args.diag_skip_coder == 2:     # the coder still runs (resources), nobody waits for it
+                        model.stage_coder(sym, hw)
+                    elif args.diag_skip_coder == 3:   # two long single-thread spin kernels in its place
+                        torch.cuda._sleep(int(12e-3 * 2.0e9))
+                        torch.cuda._sleep(int(11e-3 * 2.0e9))
+                else:
+                    dec, nb, st = model.stage_coder(sym, hw)
+                    if args.diag_skip_coder:
+                        cached.append((dec, nb, st))
+                    ev2 = torch.cuda.Event()
+                    ev2.record(cs)
+            n = group[0][1].shape[0]
+            for k, (step, _, _, _) in enumerate(group):
+                sl = slice(k * n, (k + 1) * n) if dec.shape[0] == n * len(group) else slice(0, n)
+                pending[step] = (dec[sl], nb[sl], st[sl], hw, ev2, dec)
+            group.clear()
+
         with torch.no_grad():
             for i in range(n_steps + depth):
                 if i < n_steps:
@@ -251,21 +290,16 @@ def main():
                         sym, hw = model.stage_front(x)
                         ev = torch.cuda.Event()
                         ev.record(mfma_stream)
-                    cs = coder_streams[i % n_coder]
-                    with torch.cuda.stream(cs):
-                        cs.wait_event(ev)
-                        sym.record_stream(cs)
-                        dec, nb, st = model.stage_coder(sym, hw)
-                        ev2 = torch.cuda.Event()
-                        ev2.record(cs)
-                    pending[i] = (dec, nb, st, hw, ev2)
+                    group.append((i, sym, hw, ev))
+                    if len(group) == G or i == n_steps - 1:
+                        flush()
                 j = i - depth
                 if j >= 0:
-                    dec, nb, st, hw, ev2 = pending.pop(j)
+                    dec, nb, st, hw, ev2, whole = pending.pop(j)
                     back_stream = back_streams[j % len(back_streams)]
                     with torch.cuda.stream(back_stream):
                         back_stream.wait_event(ev2)
-                        dec.record_stream(back_stream)
+                        whole.record_stream(back_stream)
                         logits = model.stage_back(dec, hw)
                         results[0] = (logits, nb, st)
 
@@ -279,7 +313,9 @@ def main():
         if distributed:
             dist.barrier()
 
-    run_steps(args.warmup)
+    # whole coder groups, so that the timed region meets warm allocator pools and LDS attributes (W = 0 stays 0)
+    warm_steps = (args.warmup + G - 1) // G * G
+    run_steps(warm_steps)
     sync_all()
 
     select = lambda tag: launch_work(tag) is not None or tag.startswith('rans')  # noqa: E731
@@ -342,6 +378,7 @@ def main():
                                    '224x224x3, eval after update(): encode -> rANS -> decode -> layer2..fc',
                        'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'inflight_steps': D,
                        'hip_streams': {'encoder': 1, 'decoder+head': len(back_streams), 'range_coder': n_coder},
+                       'steps_per_coder_launch': G, 'warmup_steps_run': warm_steps,
                        'weights': 'random init seed 0 + fixed quantile perturbation', 'sharding': 'images, no collective'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
             'host_issue_ms_per_step': 1e3 * (t_issued - t0) / args.steps,
