@@ -200,7 +200,7 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--inflight', type=int, default=2, help='range-coder chains in flight (coder HIP streams, <= 7)')
+    ap.add_argument('--inflight', type=int, default=2, help='coder HIP streams (coder launches in flight)')
     ap.add_argument('--coder-group', type=int, default=8, help='steps whose symbols share one range-coder launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--split-mfma', type=int, default=1, help='K > 0: decoder+head stages round-robin on K HIP streams of their own (0: one MFMA stream for everything)')
@@ -231,11 +231,10 @@ def main():
         return train_bench(args, dev, rank, world, distributed)
     model = build_model(dev)
     x = synthetic_batch(args.bs, dev, seed=rank)   # a different shard per rank, resident in HBM
-    # Software pipeline over HIP streams: ONE MFMA stream runs front(i) [encoder + quantise] and
-    # back(i - depth) [dequantise + decoder + head] back to back; the serial range coder of step i
-    # (encode -> bytes -> decode) runs on one of `n_coder` coder streams, so `n_coder` coder chains are in
-    # flight while the matrix cores never wait for them.  1 + n_coder streams <= the 8 hardware queues
-    # (GPU_MAX_HW_QUEUES above).  A coder chain is 4 waves (256 lanes = 256 streams) for ~20 ms: latency, not work.
+    # Software pipeline over HIP streams: front(i) [encoder + quantise] and back(i - depth) [dequantise + decoder +
+    # head] are issued back to back; the serial range coder (encode -> bytes -> decode) of `coder_group` consecutive
+    # steps runs as ONE launch on one of `n_coder` coder streams (module docstring: why grouped).  A coder launch is
+    # one wave per 64 image streams for ~25 ms: latency, not work.
     n_coder = max(1, min(args.inflight, 13))
     depth = n_coder * max(1, args.coder_group)
     mfma_stream = torch.cuda.Stream(device=dev)
