@@ -20,11 +20,30 @@ def save_ckpt(model, optimizer, lr_scheduler, best_value, args, output_file_path
     torch.save(ckpt, output_file_path)
 
 
-def load_ckpt(ckpt_file_path, model=None, optimizer=None, lr_scheduler=None, strict=True):
+def _torch_load(path, unsafe=False):
+    """weights_only load (tensors, containers, argparse.Namespace for the 'args' entry).  A checkpoint that needs
+    arbitrary unpickling is refused unless `unsafe` (or SC2_UNSAFE_CKPT=1) says the file is trusted."""
+    import argparse
+    if unsafe or os.environ.get('SC2_UNSAFE_CKPT') == '1':
+        return torch.load(path, map_location='cpu', weights_only=False)
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as e:
+        raise RuntimeError('checkpoint {} does not load with weights_only=True ({}); if the file is trusted, set '
+                           'SC2_UNSAFE_CKPT=1 or pass unsafe=True'.format(path, e))
+
+
+def load_ckpt(ckpt_file_path, model=None, optimizer=None, lr_scheduler=None, strict=True, unsafe=False):
+    if isinstance(ckpt_file_path, str) and ckpt_file_path.startswith(('http://', 'https://')):
+        # torchdistill downloads here; this build runs offline, and returning (None, None) would silently leave the
+        # model at its random initialisation
+        raise RuntimeError('load_ckpt: {} is a URL; download it and pass the local path (no network access here)'
+                           .format(ckpt_file_path))
     if ckpt_file_path is None or not os.path.isfile(ckpt_file_path):
-        logger.info('ckpt file path is None or does not exist: {}'.format(ckpt_file_path))
+        logger.warning('ckpt file path is None or does not exist: {} -- nothing loaded'.format(ckpt_file_path))
         return None, None
-    ckpt = torch.load(ckpt_file_path, map_location='cpu', weights_only=False)
+    ckpt = _torch_load(ckpt_file_path, unsafe=unsafe)
     if model is not None:
         state = ckpt['model'] if 'model' in ckpt else ckpt
         if strict is None:

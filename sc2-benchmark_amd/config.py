@@ -6,7 +6,8 @@ into packages that are not installed here (`torchvision`, `torchdistill`) or tha
 (`sc2bench`).  This loader resolves
 
 * `sc2bench.*`      -> the registries of this package (same keys: layers, backbones, losses, analyzers),
-* `torchvision.datasets.*` -> `SyntheticImageFolder` (no dataset directory is needed, nothing is downloaded),
+* `torchvision.datasets.*` -> this module's `ImageFolder` (root/<class>/<image>; a missing directory raises on first
+  use unless SC2_SYNTHETIC_DATA=1 opts in to random images),
 * `torchvision.models.resnet.*Weights` -> an inert enum (pretrained weights need the network),
 * `torchvision.transforms.*`, `torchdistill.*`, anything else that cannot be imported -> a recording placeholder,
 
@@ -40,7 +41,7 @@ class Placeholder(object):
 
 
 class SyntheticImageFolder(torch.utils.data.Dataset):
-    """`torchvision.datasets.ImageFolder(root, transform)` stand-in: seeded random images, ImageNet-normalised."""
+    """Seeded random images with random labels, ImageNet-normalised: plumbing / throughput runs only."""
 
     def __init__(self, root=None, transform=None, num_samples=1024, num_classes=1000, image_size=224, **kwargs):
         self.root = root
@@ -58,6 +59,67 @@ class SyntheticImageFolder(torch.utils.data.Dataset):
         g = torch.Generator().manual_seed(index)
         x = torch.rand(3, self.image_size, self.image_size, generator=g)
         return (x - self.mean) / self.std, int(torch.randint(0, self.num_classes, (1,), generator=g))
+
+
+IMG_EXTENSIONS = ('.jpg', '.jpeg', '.png', '.ppm', '.bmp', '.pgm', '.tif', '.tiff', '.webp')
+
+
+class ImageFolder(torch.utils.data.Dataset):
+    """`torchvision.datasets.ImageFolder(root, transform)`: root/<class>/<image>, classes sorted by name, label = class
+    index, images opened with PIL and converted to RGB.  The directory is scanned on first use, so a config whose
+    dataset directory does not exist still PARSES; using such a dataset raises, unless SC2_SYNTHETIC_DATA=1 opts in to
+    `SyntheticImageFolder` (random pixels, random labels -- never silently)."""
+
+    def __init__(self, root=None, transform=None, target_transform=None, **kwargs):
+        self.root = None if root is None else os.path.expanduser(str(root))
+        self.transform = transform
+        self.target_transform = target_transform
+        self.kwargs = kwargs
+        self._samples = None
+        self._synthetic = None
+
+    def _scan(self):
+        if self._samples is not None or self._synthetic is not None:
+            return
+        if self.root is not None and os.path.isdir(self.root):
+            classes = sorted(d for d in os.listdir(self.root) if os.path.isdir(os.path.join(self.root, d)))
+            samples = []
+            for ci, c in enumerate(classes):
+                for dirpath, _, files in sorted(os.walk(os.path.join(self.root, c), followlinks=True)):
+                    for f in sorted(files):
+                        if f.lower().endswith(IMG_EXTENSIONS):
+                            samples.append((os.path.join(dirpath, f), ci))
+            if not samples:
+                raise FileNotFoundError('ImageFolder: no images under {}'.format(self.root))
+            self.classes, self._samples = classes, samples
+            return
+        if os.environ.get('SC2_SYNTHETIC_DATA') == '1':
+            import logging
+            logging.getLogger(__name__).warning('dataset directory {} not found: SC2_SYNTHETIC_DATA=1 -> random pixels, '
+                                                'random labels'.format(self.root))
+            self._synthetic = SyntheticImageFolder(self.root, **{k: v for k, v in self.kwargs.items()
+                                                                 if k in ('num_samples', 'num_classes', 'image_size')})
+            return
+        raise FileNotFoundError('ImageFolder: dataset directory {} does not exist (set SC2_SYNTHETIC_DATA=1 to run on '
+                                'random images with random labels instead)'.format(self.root))
+
+    def __len__(self):
+        self._scan()
+        return len(self._synthetic) if self._synthetic is not None else len(self._samples)
+
+    def __getitem__(self, index):
+        self._scan()
+        if self._synthetic is not None:
+            return self._synthetic[index]
+        from PIL import Image
+        path, target = self._samples[index]
+        with open(path, 'rb') as f:
+            img = Image.open(f).convert('RGB')
+        if self.transform is not None and not isinstance(self.transform, Placeholder):
+            img = self.transform(img)
+        if self.target_transform is not None and not isinstance(self.target_transform, Placeholder):
+            target = self.target_transform(target)
+        return img, target
 
 
 class _WeightsEnum(object):
@@ -90,7 +152,7 @@ def resolve(key):
     if key.startswith('sc2bench.'):
         return _sc2bench_attr(key)
     if key.startswith('torchvision.datasets.'):
-        return SyntheticImageFolder
+        return ImageFolder
     if key.startswith('torchvision.models.') and key.endswith('_Weights'):
         return _WeightsEnum(key)
     module_name, _, attr = key.rpartition('.')
@@ -168,7 +230,10 @@ def build_model(model_config):
     key = model_config['key']
     kwargs = dict(model_config.get('kwargs') or {})
     if key in S.MODEL_DICT:
-        kwargs.pop('weights', None)
+        if kwargs.get('weights') is not None:   # splittable_resnet & co. forward **kwargs to the torchvision builder
+            import logging
+            logging.getLogger(__name__).warning('model `{}`: weights={!r} is passed on to the ResNet builder, which loads '
+                                                '$SC2_PRETRAINED_DIR/<name>.pth or warns'.format(key, kwargs['weights']))
         return S.MODEL_DICT[key](**kwargs)
     if key in RESNET_FUNC_DICT:
         return RESNET_FUNC_DICT[key](**kwargs)

@@ -197,9 +197,15 @@ __global__ __launch_bounds__(64) void rans_enc_serial_kernel(const RansArgs a, c
             const int idx = (int)(ei / (uint32_t)a.cdf_stride);
             const int max_value = a.cdf_sizes[idx] - 2;
             const int v = a.symbols[(long long)sc * a.n_sym + i] - a.offsets[idx];
-            const unsigned raw = v < 0 ? (unsigned)(-2 * v - 1) : (unsigned)(2 * (v - max_value));
+            // |v| >= 2^30 would wrap the 32-bit raw value (a diverged latent saturated by eb_symbols): code the
+            // clamped value and report status 2 instead of spinning (a shift by 32 is masked to 0 on gfx950, so
+            // upstream's unbounded nibble count would never terminate here)
+            int vc = v;
+            if (vc < -(1 << 30)) { vc = -(1 << 30); overflow |= 2; }
+            if (vc - max_value > (1 << 30)) { vc = max_value + (1 << 30); overflow |= 2; }
+            const unsigned raw = vc < 0 ? (unsigned)(-2 * vc - 1) : (unsigned)(2 * (vc - max_value));
             int n_bypass = 0;
-            while ((raw >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;
+            while (n_bypass < 8 && (raw >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;
             for (int j = n_bypass - 1; j >= 0; --j) put_bits((raw >> (j * kBypassPrecision)) & kMaxBypassVal);
             const int n15 = n_bypass / kMaxBypassVal, rem = n_bypass - n15 * kMaxBypassVal;
             put_bits((unsigned)rem);
@@ -291,7 +297,7 @@ __device__ __forceinline__ int dec_escape(DecState &d, int max_value) {
     int raw_val = 0;
     for (int j = 0; j < n_bypass; ++j) {
         val = (int)dec_get_bits(d);
-        raw_val |= val << (j * kBypassPrecision);
+        if (j < 8) raw_val |= val << (j * kBypassPrecision);   // a corrupt stream may announce more than 8 nibbles
     }
     int value = raw_val >> 1;
     if (raw_val & 1) value = -value - 1;
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
                 int raw_val = 0;
                 for (int j = 0; j < n_bypass; ++j) {
                     val = get_bits();
-                    raw_val |= val << (j * kBypassPrecision);
+                    if (j < 8) raw_val |= val << (j * kBypassPrecision);   // corrupt stream: more than 8 nibbles
                 }
                 value = raw_val >> 1;
                 if (raw_val & 1) value = -value - 1;

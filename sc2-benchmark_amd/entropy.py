@@ -69,6 +69,16 @@ def _require_device(x, what):
                            .format(what, x.device))
 
 
+def _raise_on_status(st, what):
+    """rANS status per stream: bit 0 = the row overflowed its stride, bit 1 = a symbol lies outside the codable range
+    (|symbol - offset| >= 2^30: a non-finite or diverged latent; upstream's nibble loop never terminates there)."""
+    code = int(st.max().item())
+    if code & 2:
+        raise ValueError('{}: a symbol is outside the codable range (non-finite or diverged latent)'.format(what))
+    if code:
+        raise hip.Sc2Error('{}: rANS stream overflowed its maximum size'.format(what))
+
+
 class HipConv2d(nn.Conv2d):
     """nn.Conv2d(bias=False) parameter holder whose forward is the implicit-GEMM MFMA kernel.
 
@@ -584,6 +594,7 @@ class EntropyBottleneck(nn.Module):
             sym = hip.eb_symbols(y, self._median_vector())
             buf, off, nb, st = hip.rans_encode_batch(sym.view(N, C * hw), cdf, cdf_len, offset, index_div=hw,
                                                      out_stride=hip.rans_max_bytes(C * hw))
+            _raise_on_status(st, 'EntropyBottleneck.compress')
         nb_h = nb.cpu().numpy()
         stride = buf.shape[1]
         width = int(nb_h.max())
@@ -781,6 +792,7 @@ class GaussianConditional(nn.Module):
         if int(st.max().item()) != 0:
             buf, off, nb, st = self.compress_device(inputs, indexes, means,
                                                     out_stride=hip.rans_max_bytes(inputs[0].numel()))
+            _raise_on_status(st, 'GaussianConditional.compress')
         nb_h = nb.cpu().numpy()
         stride = buf.shape[1]
         width = int(nb_h.max())

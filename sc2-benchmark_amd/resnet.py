@@ -7,8 +7,14 @@ avgpool, fc`` (backbone.py:217-223).  This file re-declares that architecture so
 channels_last at inference: it is the caller of the bottleneck path, not part of the hand-written path
 (SURVEY.md 2.2 row N9).
 """
+import logging
+import os
+import warnings
+
 import torch
 from torch import nn
+
+logger = logging.getLogger(__name__)
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -119,20 +125,39 @@ class ResNet(nn.Module):
         return self.fc(x)
 
 
+def _build(name, blocks, weights, kwargs):
+    """`weights` / `pretrained` name torchvision's downloadable ImageNet weights.  There is no network here: the
+    weights are taken from $SC2_PRETRAINED_DIR/<name>.pth (a torchvision state dict) when that file exists; otherwise
+    the model keeps its random initialisation and says so with a warning (SC2_STRICT_WEIGHTS=1 turns it into an error)."""
+    pretrained = kwargs.pop('pretrained', None)
+    model = ResNet(blocks, **kwargs)
+    if weights is not None or pretrained:
+        root = os.environ.get('SC2_PRETRAINED_DIR')
+        path = os.path.join(root, name + '.pth') if root else None
+        if path and os.path.isfile(path):
+            from .ckpt import load_ckpt
+            load_ckpt(path, model=model, strict=True)
+        else:
+            msg = ('{}(weights={!r}): pretrained weights requested but no local file found ({}); the model is RANDOMLY '
+                   'INITIALISED. Put a torchvision state dict at $SC2_PRETRAINED_DIR/{}.pth'
+                   .format(name, weights if weights is not None else 'pretrained', path or 'SC2_PRETRAINED_DIR unset', name))
+            if os.environ.get('SC2_STRICT_WEIGHTS') == '1':
+                raise FileNotFoundError(msg)
+            warnings.warn(msg)
+            logger.warning(msg)
+    return model
+
+
 def resnet50(weights=None, progress=True, **kwargs):
-    """``weights`` is accepted for config compatibility; pretrained weights need network access (absent)."""
-    kwargs.pop('pretrained', None)
-    return ResNet((3, 4, 6, 3), **kwargs)
+    return _build('resnet50', (3, 4, 6, 3), weights, kwargs)
 
 
 def resnet101(weights=None, progress=True, **kwargs):
-    kwargs.pop('pretrained', None)
-    return ResNet((3, 4, 23, 3), **kwargs)
+    return _build('resnet101', (3, 4, 23, 3), weights, kwargs)
 
 
 def resnet152(weights=None, progress=True, **kwargs):
-    kwargs.pop('pretrained', None)
-    return ResNet((3, 8, 36, 3), **kwargs)
+    return _build('resnet152', (3, 8, 36, 3), weights, kwargs)
 
 
 RESNET_FUNC_DICT = {'resnet50': resnet50, 'resnet101': resnet101, 'resnet152': resnet152}

@@ -1,0 +1,126 @@
+"""-m gpu: the path bench.py times -- SplittableResNet.stage_front / stage_coder / stage_back at bs 256, 224x224,
+eight steps' symbols concatenated into ONE coder launch (2 048 streams x 72 600 symbols) -- against the oracle's
+range coder on the device symbols, against the coder's own round trip, and against forward_device (the un-staged
+eval forward).  Also the status codes the coder returns for symbols outside the codable range."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def bench_model(dev):
+    import bench
+    model = bench.build_model(dev)
+    return bench, model
+
+
+def test_bench_workload_is_not_degenerate(bench_model, dev):
+    """bench.shape_workload: byte counts depend on the image and escape symbols are coded."""
+    bench, model = bench_model
+    x = bench.synthetic_batch(64, dev, seed=0)
+    with torch.no_grad():
+        sym, hw = model.stage_front(x)
+        eb = model.bottleneck_layer.entropy_bottleneck
+        buf, off, nb, st = eb.encode_symbols_device(sym, hw[0] * hw[1])
+    assert int(st.max()) == 0
+    nbh = nb.cpu().numpy()
+    assert nbh.max() - nbh.min() > 1000, 'stream lengths do not vary: {}'.format(nbh[:8])
+    v = sym.view(64, 24, -1) - eb._offset.view(1, 24, 1)
+    esc = ((v < 0) | (v >= (eb._cdf_length - 2).view(1, 24, 1))).float().mean().item()
+    assert 1e-4 < esc < 0.05, 'escape fraction {}'.format(esc)
+    assert sym.min().item() < -4 and sym.max().item() > 4
+
+
+def test_bench_path_2048_streams(bench_model, dev):
+    bench, model = bench_model
+    bs, groups = 256, 8
+    eb = model.bottleneck_layer.entropy_bottleneck
+    xs, syms = [], []
+    with torch.no_grad():
+        for g in range(groups):
+            x = bench.synthetic_batch(bs, dev, seed=g)
+            sym, hw = model.stage_front(x)
+            if g in (0, 5):
+                xs.append((g, x))
+            syms.append(sym)
+        assert hw == (55, 55) and syms[0].shape == (bs, 24 * 55 * 55)
+        sym_all = torch.cat(syms)                                   # [2048, 72600]
+        n_hw = hw[0] * hw[1]
+        # the coder exactly as bench.py launches it
+        dec, nb, st = model.stage_coder(sym_all, hw)
+        assert int(st.max()) == 0
+        assert torch.equal(dec, sym_all), 'decode(encode(symbols)) != symbols'
+        # byte identity against the oracle's coder on the same device symbols, 32 sampled streams
+        buf, off, nb2, st2 = eb.encode_symbols_device(sym_all, n_hw)
+        assert torch.equal(nb, nb2) and int(st2.max()) == 0
+        rng = np.random.RandomState(0)
+        pick = sorted(set([0, 1, 255, 256, 1023, 2047] + rng.randint(0, bs * groups, size=26).tolist()))
+        ref = bench.oracle_model(model.state_dict())
+        reb = ref.bottleneck_layer.entropy_bottleneck
+        assert torch.equal(eb._quantized_cdf.cpu(), reb._quantized_cdf)
+        assert torch.equal(eb._offset.cpu(), reb._offset) and torch.equal(eb._cdf_length.cpu(), reb._cdf_length)
+        idx = torch.tensor(pick, device=dev)
+        got = eb.unpack_strings(buf[idx], off[idx], nb2[idx])
+        want = bench.oracle_streams(ref, sym_all[idx].cpu(), n_hw)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a == b, 'stream {} differs from the oracle coder ({} vs {} bytes)'.format(pick[i], len(a), len(b))
+        assert len(set(len(s) for s in got)) > 8, 'stream lengths do not vary'
+        # the staged forward == the un-staged eval forward, bit for bit (same kernels, same operands)
+        for g, x in xs:
+            logits = model.stage_back(dec[g * bs:(g + 1) * bs], hw)
+            ref_logits, nb_ref, st_ref = model.forward_device(x)
+            assert torch.equal(nb_ref, nb[g * bs:(g + 1) * bs])
+            assert torch.equal(logits, ref_logits), 'stage_back(stage_coder(stage_front(x))) != forward_device(x)'
+            assert torch.isfinite(logits.float()).all()
+
+
+def test_bench_digest_matches_oracle(bench_model, dev):
+    """The two digests bench.py prints (device streams / oracle coder on the device symbols) are equal."""
+    bench, model = bench_model
+    x = bench.synthetic_batch(16, dev, seed=3)
+    with torch.no_grad():
+        sym, hw = model.stage_front(x)
+        eb = model.bottleneck_layer.entropy_bottleneck
+        buf, off, nb, st = eb.encode_symbols_device(sym, hw[0] * hw[1])
+    dev_streams = eb.unpack_strings(buf[:8], off[:8], nb[:8])
+    ref = bench.oracle_model(model.state_dict())
+    assert bench.sha256_of(dev_streams) == bench.sha256_of(bench.oracle_streams(ref, sym[:8].cpu(), hw[0] * hw[1]))
+
+
+def test_rans_symbol_out_of_range_sets_status(S, dev):
+    """|symbol - offset| >= 2^30 (a saturated, non-finite latent): status bit 1, the launch terminates, the other streams
+    are intact; values up to 2^27 and beyond (8 raw nibbles) still round-trip exactly."""
+    from oracle import rans as oracle_rans
+    p = np.array([0.1, 0.2, 0.4, 0.2, 0.099, 0.001], dtype=np.float32)
+    cdf = [int(v) for v in oracle_rans.pmf_to_quantized_cdf(p)]
+    cdfs = torch.tensor([cdf], dtype=torch.int32, device=dev)
+    sizes = torch.tensor([len(cdf)], dtype=torch.int32, device=dev)
+    offs = torch.tensor([-2], dtype=torch.int32, device=dev)
+    sym = np.zeros((4, 40), dtype=np.int32)
+    sym[0, 5] = 2 ** 31 - 1           # INT_MAX as eb_symbols saturates +inf
+    sym[0, 9] = -2 ** 31              # INT_MIN
+    sym[1, 7] = 2 ** 26 + 12345       # 7 raw nibbles: the range upstream's nibble loop still terminates on
+    sym[1, 8] = -(2 ** 26)
+    sym[2, :] = np.arange(40) % 5 - 2
+    sym[3, 3] = 2 ** 28 + 5           # 8 raw nibbles (upstream's `raw >> 32` is undefined there): device round trip only
+    sym[3, 4] = -(2 ** 29)
+    d_sym = torch.from_numpy(sym).to(dev)
+    buf, off, nb, st = S.hip.rans_encode_batch(d_sym, cdfs, sizes, offs, index_div=40, out_stride=S.hip.rans_max_bytes(40))
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [2, 0, 0, 0]
+    got = [b for b in S.EntropyBottleneck.unpack_strings(buf, off, nb)]
+    idx = np.zeros(40, dtype=np.int32)
+    for i in (1, 2):
+        assert got[i] == oracle_rans.encode_with_indexes(sym[i], idx, cdfs.cpu().numpy(), [len(cdf)], [-2])
+    dec, _ = S.hip.rans_decode_batch(buf, off, nb, 40, cdfs, sizes, offs, index_div=40)
+    assert np.array_equal(dec.cpu().numpy()[1:], sym[1:])
+    # the module API raises instead of returning a stream that does not decode to its input
+    eb = S.EntropyBottleneck(1)
+    eb._quantized_cdf, eb._cdf_length, eb._offset = cdfs, sizes, offs
+    eb.to(dev)
+    y = torch.zeros(1, 1, 4, 4, device=dev)
+    y[0, 0, 1, 1] = float('inf')
+    with pytest.raises(ValueError):
+        eb.compress(y)

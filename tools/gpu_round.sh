@@ -4,6 +4,7 @@
 TAG=${1:-r01}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
+export GPU_MAX_HW_QUEUES=8   # bench.py sets it in-process, but under rocprofv3 the runtime may initialise before Python runs
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
