@@ -68,7 +68,8 @@ def shape_workload(model):
       * quantiles [-(3+c%5), 0.25*(c%3), 4+c%7] per channel c (SURVEY.md 8(d)) -> ragged tables of 10-19 entries;
       * the first matrix of the cumulative-logit MLP is sharpened per channel (softplus(M0) * 5*(1+0.25*(c%4))): a peaked
         prior, as a trained model has;
-      * the last encoder conv is scaled x10: latent std ~1.7, symbols in about [-10, 9], ~0.7 % escape (bypass) symbols.
+      * the last encoder conv is scaled x7: latent std ~1, symbols in about [-6, 6], ~1e-4 escape (bypass) symbols: a
+        few per image (0 - 50), as an operating point whose tables fit the latent has (x10 gives 0.7 %).
     Byte counts then depend on the image (synthetic_batch gives every image its own contrast)."""
     import torch.nn.functional as F
     bl = model.bottleneck_layer
@@ -83,7 +84,7 @@ def shape_workload(model):
         eb.quantiles.copy_(q.to(eb.quantiles.device))
         m0 = eb.matrices[0]
         m0.copy_(torch.log(torch.expm1(k.to(m0.device) * F.softplus(m0))))
-        bl.encoder[4].weight.mul_(10.0)
+        bl.encoder[4].weight.mul_(7.0)
     return model
 
 
@@ -278,6 +279,40 @@ def train_bench(args, dev, rank, world, distributed):
         dist.destroy_process_group()
 
 
+def dry_run(args, world, rank, local_rank):
+    """The launch contract without a device: process group (gloo), per-rank shard seed, barrier-bracketed timed region,
+    max over ranks, ONE JSON line from rank 0.  No HIP call is made (torch.cuda is not touched)."""
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))      # stands in for a step; ranks differ so that MAX is exercised
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    info = {'rank': rank, 'local_rank': local_rank, 'seed': rank}
+    ranks = [info]
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+        ranks = [None] * world
+        dist.all_gather_object(ranks, info)
+    if rank == 0:
+        print(json.dumps({'metric': 'images/s + bpp, Entropic-Student ResNet-50 224^2', 'dry_run': True,
+                          'value': args.bs * args.steps * world / elapsed, 'unit': 'images/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'none',
+                          'config': {'workload': 'dry run: launch / rank / reduction plumbing only',
+                                     'batch_per_gpu': args.bs, 'global_batch': args.bs * world}, 'ranks': ranks}))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -286,6 +321,7 @@ def main():
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--inflight', type=int, default=4, help='coder HIP streams (coder launches that may be in flight)')
     ap.add_argument('--max-inflight', type=int, default=24, help='encoder stage i waits for decoder+head stage i - this')
+    ap.add_argument('--ramp', type=int, default=1, help='1: the first coder groups of a run hold 1, 2, 4, ... steps')
     ap.add_argument('--coder-group', type=int, default=8, help='steps whose symbols share one range-coder launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bs1', action='store_true', help='skip the bs-1 evaluation-mode row')
@@ -293,6 +329,7 @@ def main():
     ap.add_argument('--diag-skip-coder', type=int, default=0, help='DIAGNOSTIC (invalid as a result): 1 = reuse the first step\'s coder output, 2 = same but still run the coder')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
+    ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
     args = ap.parse_args()
@@ -300,6 +337,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.dry_run:
+        return dry_run(args, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -341,7 +380,7 @@ def main():
 
     def group_plan(n_steps):
         """sizes of the coder groups of a run: 1, 2, 4, ... up to G, then G."""
-        sizes, g = [], 1
+        sizes, g = [], (1 if args.ramp else G)
         while sum(sizes) < n_steps:
             sizes.append(min(g, G, n_steps - sum(sizes)))
             g *= 2
@@ -390,8 +429,10 @@ def main():
             issued_back = 0
             for i in range(n_steps):
                 with torch.cuda.stream(mfma_stream):
-                    if i - args.max_inflight in back_done:   # bound the run-ahead of the encoder stream (memory, latency)
-                        mfma_stream.wait_event(back_done.pop(i - args.max_inflight))
+                    if i - args.max_inflight in back_done:
+                        # bound the run-ahead of the host and of the encoder stream: memory in flight, latency per batch,
+                        # and the caching allocator keeps recycling cross-stream blocks instead of calling hipMalloc
+                        back_done.pop(i - args.max_inflight).synchronize()
                     if record and i % 8 == 0:
                         e0 = torch.cuda.Event(enable_timing=True)
                         e0.record(mfma_stream)
@@ -510,7 +551,7 @@ def main():
                        'hip_streams': {'encoder': 1, 'decoder+head': len(back_streams), 'range_coder': n_coder},
                        'steps_per_coder_launch': G, 'max_inflight_steps': args.max_inflight, 'coder_group_plan': group_plan(args.steps)[:6], 'warmup_steps_run': warm_steps,
                        'weights': 'random init seed 0, operating point shaped by bench.shape_workload (ragged tables, '
-                                  'peaked prior, latent std ~1.7, ~0.7 % escape symbols)',
+                                  'peaked prior, latent std ~1, ~1e-4 escape symbols)',
                        'images': 'torch.rand, per-image contrast 0.25-1, ImageNet normalisation',
                        'sharding': 'images, no collective'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,

@@ -6,8 +6,9 @@ evaluation needs no data-path collective; training adds ONE gra
 trainable set.  In stage 1 of the Entropic-Student recipe only `bottleneck_layer` trains (reference config
 `splitable_resnet50-fp-beta0.08_from_resnet50.yaml:135`): 1 304 168 f32 values = 5.2 MB, latency-bound on a ring
 (2*(7/8)*5.2 MB / 153 GB/s ~ 60 us of wire time), hence a single flat bucket and a single RCCL call instead of
-DDP's per-bucket hooks; larger trainable sets (stage 2, ~106 MB) are split into `bucket_mb` buckets launched as
-soon as each is full so they overlap what remains of backward.
+DDP's per-bucket hooks; larger trainable sets (stage 2, ~106 MB) are split into `bucket_mb` buckets, each launched
+from a post-accumulate-grad hook when its last gradient lands, so they overlap what remains of backward
+(`FlatGradAllReducer.overlap`).
 
 Replaces `torch.nn.parallel.DistributedDataParallel` as the reference wraps it
 (script/task/image_classification.py:110-111; configs `wrapper: 'DistributedDataParallel'`).
@@ -44,8 +45,17 @@ def shard_range(n_items, rank, world):
 
 
 class FlatGradAllReducer(object):
-    """Keeps the gradients of the trainable parameters in flat f32 buckets (each p.grad is a view) and averages
-    them across ranks with one all-reduce per bucket."""
+    """Keeps the gradients of the trainable parameters in flat f32 buckets (each p.grad is a view) and averages them
+    across ranks with one all-reduce per bucket.
+
+    Buckets are filled in REVERSE parameter order (the order in which backward produces gradients).  Inside
+    ``with reducer.overlap(): loss.backward()`` a post-accumulate-grad hook counts the gradients that have landed in
+    each bucket and launches the bucket's all-reduce (async, on the collective's own stream) the moment its last
+    gradient is written, so the first buckets travel while backward is still producing the rest (stage 2 of the
+    recipe: ~106 MB).  ``all_reduce()`` launches whatever was not launched by a hook -- every bucket when overlap()
+    was not used, and buckets holding a parameter that received no gradient in this backward (e.g. `quantiles`, whose
+    gradient comes from the separate aux-loss backward) -- then waits for all of them and divides by the world size.
+    Gradients accumulated by earlier backward passes of the same step (aux loss) are part of what is reduced."""
 
     def __init__(self, params, bucket_mb=25.0, process_group=None):
         self.params = [p for p in params if p.requires_grad]
@@ -54,7 +64,7 @@ class FlatGradAllReducer(object):
         cap = max(1, int(bucket_mb * 1024 * 1024 / 4))
         self.buckets = []
         cur, cur_n = [], 0
-        for p in self.params:
+        for p in reversed(self.params):
             if cur and cur_n + p.numel() > cap:
                 self.buckets.append(cur)
                 cur, cur_n = [], 0
@@ -63,14 +73,51 @@ class FlatGradAllReducer(object):
         if cur:
             self.buckets.append(cur)
         self.flats = []
-        for bucket in self.buckets:
+        self._bucket_of = {}
+        for b, bucket in enumerate(self.buckets):
             dev, n = bucket[0].device, sum(p.numel() for p in bucket)
             flat = torch.zeros(n, dtype=torch.float32, device=dev)
             o = 0
             for p in bucket:
                 p.grad = flat[o:o + p.numel()].view_as(p)
                 o += p.numel()
+                self._bucket_of[p] = b
             self.flats.append(flat)
+        self._armed = False
+        self._pending = [0] * len(self.buckets)
+        self._works = [None] * len(self.buckets)
+        self.launched_by_hook = 0      # buckets whose all-reduce started inside backward (last step)
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] \
+            if self.world > 1 else []
+
+    def _launch(self, b):
+        self._works[b] = dist.all_reduce(self.flats[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b = self._bucket_of[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self._works[b] is None:
+            self._launch(b)
+            self.launched_by_hook += 1
+
+    def overlap(self):
+        """Context manager around the LAST backward of a step: buckets launch as they fill."""
+        reducer = self
+
+        class _Armed(object):
+            def __enter__(self_inner):
+                reducer._pending = [len(b) for b in reducer.buckets]
+                reducer._works = [None] * len(reducer.buckets)
+                reducer.launched_by_hook = 0
+                reducer._armed = reducer.world > 1
+                return reducer
+
+            def __exit__(self_inner, *exc):
+                reducer._armed = False
+                return False
+        return _Armed()
 
     def zero_grad(self):
         for flat in self.flats:
@@ -80,10 +127,13 @@ class FlatGradAllReducer(object):
         """Average gradients over ranks.  Call after backward(); a no-op on a single process."""
         if self.world == 1:
             return
-        works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for flat in self.flats]
-        for w, flat in zip(works, self.flats):
-            w.wait()
+        for b in range(len(self.buckets)):
+            if self._works[b] is None:
+                self._launch(b)
+        for b, flat in enumerate(self.flats):
+            self._works[b].wait()
             flat.div_(self.world)
+        self._works = [None] * len(self.buckets)
 
     def nbytes(self):
         return sum(f.numel() * 4 for f in self.flats)

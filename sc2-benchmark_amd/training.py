@@ -156,7 +156,7 @@ class DistillationStage(object):
     forward_process(batch, targets) -> loss ; post_forward_process(loss) -> backward, gradient all-reduce, step.
     """
 
-    def __init__(self, teacher, student, stage_config, device, lr_factor=1, head_dtype=None):
+    def __init__(self, teacher, student, stage_config, device, lr_factor=1, head_dtype=None, bucket_mb=25.0):
         self.device = device
         t_cfg, s_cfg = stage_config.get('teacher') or {}, stage_config.get('student') or {}
         self.student_full = student
@@ -180,7 +180,7 @@ class DistillationStage(object):
         # as torchdistill does, the optimizer (and the gradient buckets) see the REDESIGNED student: modules left out
         # of `sequential` (avgpool / fc in stage 1) take no part in the step
         params = [p for p in self.student.parameters() if p.requires_grad]
-        self.reducer = FlatGradAllReducer(params)
+        self.reducer = FlatGradAllReducer(params, bucket_mb=bucket_mb)
         o_cfg = stage_config['optimizer']
         okw = dict(o_cfg.get('kwargs') or {})
         if 'lr' in okw:
@@ -217,7 +217,8 @@ class DistillationStage(object):
     def post_forward_process(self, loss, bottleneck_updated=False):
         if self.aux_module is not None and not bottleneck_updated:
             self.aux_module.aux_loss().backward()
-        loss.backward()
+        with self.reducer.overlap():     # buckets start their all-reduce as backward fills them
+            loss.backward()
         self.reducer.all_reduce()
         self.optimizer.step()
         self.reducer.zero_grad()

@@ -77,3 +77,145 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [e - s for s, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# DP == single process on the concatenated batch, through DistillationStage
+STAGE = {
+    'teacher': {'sequential': ['layer1', 'layer2'], 'forward_hook': {'input': [], 'output': ['layer1', 'layer2']}},
+    'student': {'sequential': ['bottleneck_layer', 'layer2'], 'frozen_modules': ['layer2'],
+                'forward_hook': {'input': [], 'output': ['bottleneck_layer', 'layer2', 'bottleneck_layer.entropy_bottleneck']}},
+    'optimizer': {'key': 'SGD', 'kwargs': {'lr': 0.0}},
+    'criterion': {'key': 'WeightedSumLoss', 'kwargs': {'sub_terms': {
+        'layer1': {'criterion': {'key': 'MSELoss', 'kwargs': {'reduction': 'sum'}},
+                   'criterion_wrapper': {'key': 'SimpleLossWrapper', 'kwargs': {
+                       'input': {'is_from_teacher': False, 'module_path': 'bottleneck_layer', 'io': 'output'},
+                       'target': {'is_from_teacher': True, 'module_path': 'layer1', 'io': 'output'}}}, 'weight': 1.0},
+        'layer2': {'criterion': {'key': 'MSELoss', 'kwargs': {'reduction': 'sum'}},
+                   'criterion_wrapper': {'key': 'SimpleLossWrapper', 'kwargs': {
+                       'input': {'is_from_teacher': False, 'module_path': 'layer2', 'io': 'output'},
+                       'target': {'is_from_teacher': True, 'module_path': 'layer2', 'io': 'output'}}}, 'weight': 1.0},
+        'bpp': {'criterion': {'key': 'BppLoss', 'kwargs': {'entropy_module_path': 'bottleneck_layer.entropy_bottleneck',
+                                                           'reduction': 'sum'}}, 'weight': 0.08}}}},
+}
+
+
+def _build_pair():
+    """CPU-safe student (the oracle's FP bottleneck with a per-image deterministic noise draw + a frozen conv tail) and
+    teacher, identical on every rank."""
+    import torch.nn as nn
+    from oracle import cpu_ref as R
+
+    class DetEB(R.EntropyBottleneck):
+        def forward(self, x, training=None, noise=None):
+            g = torch.Generator().manual_seed(99)
+            base = torch.rand(x.shape[1:], generator=g) - 0.5          # the same noise field for every image
+            return super().forward(x, training, noise=base.unsqueeze(0).expand_as(x))
+
+    class Student(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bottleneck_layer = R.FPBasedResNetBottleneck(num_bottleneck_channels=8, num_target_channels=16)
+            eb = DetEB(8)
+            eb.load_state_dict(self.bottleneck_layer.entropy_bottleneck.state_dict())
+            self.bottleneck_layer.entropy_bottleneck = eb
+            self.layer2 = nn.Conv2d(16, 8, 3, padding=1)
+
+        def get_aux_module(self):
+            return self.bottleneck_layer
+
+    class Teacher(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer1 = nn.Conv2d(3, 16, 5, stride=4, padding=2)
+            self.layer2 = nn.Conv2d(16, 8, 3, padding=1)
+
+    torch.manual_seed(5)
+    return Teacher(), Student()
+
+
+def _grads_after_step(batch, distributed):
+    from sc2bench_amd import training as T
+    teacher, student = _build_pair()
+    stage = T.DistillationStage(teacher, student, STAGE, torch.device('cpu'), bucket_mb=0.02)
+    if distributed:
+        assert stage.reducer.world == 2 and len(stage.reducer.flats) >= 3
+    loss = stage.forward_process(batch)
+    # post_forward_process without the optimizer step / zero_grad, so that the reduced gradients can be read
+    stage.aux_module.aux_loss().backward()
+    with stage.reducer.overlap():
+        loss.backward()
+    hooked = stage.reducer.launched_by_hook
+    stage.reducer.all_reduce()
+    return [p.grad.clone() for p in stage.reducer.params], float(loss.detach()), hooked
+
+
+def _dp_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank)})
+    from sc2bench_amd import dataparallel as dp
+    dp.init_distributed(backend='gloo')
+    torch.set_num_threads(2)
+    x = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(11))
+    s, e = dp.shard_range(4, rank, world)
+    grads, loss, hooked = _grads_after_step(x[s:e], True)
+    out[rank] = ([g.numpy() for g in grads], loss, hooked)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_gradients_equal_single_process_on_concatenated_batch():
+    """Losses are sums over the local batch (MSE sum, bits sum, as in the ES recipe), so the rank-averaged DP gradient
+    times the world size is the gradient of the single-process loss on the concatenated batch; the aux-loss gradient
+    (batch-independent, identical on every rank) survives the average unchanged."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_dp_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=240)
+            assert p.exitcode == 0
+        res = dict(out)
+    torch.set_num_threads(2)
+    x = torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(11))
+    single, loss, _ = _grads_after_step(x, False)
+    # the same step with the aux-loss gradient alone (batch-independent part)
+    from sc2bench_amd import training as T
+    teacher, student = _build_pair()
+    stage = T.DistillationStage(teacher, student, STAGE, torch.device('cpu'))
+    stage.aux_module.aux_loss().backward()
+    aux = [p.grad.clone() for p in stage.reducer.params]
+    assert abs(res[0][1] + res[1][1] - loss) <= 1e-4 * abs(loss)
+    assert res[0][2] >= 1, 'no bucket was launched from a gradient hook during backward'
+    for g0, g1, gs, ga in zip(res[0][0], res[1][0], single, aux):
+        g0, g1 = torch.from_numpy(g0), torch.from_numpy(g1)
+        assert torch.equal(g0, g1), 'ranks disagree after the all-reduce'
+        want = (gs - ga) / world + ga
+        tol = 1e-4 * float(want.abs().max()) + 1e-6
+        assert float((g0 - want).abs().max()) <= tol
+
+
+def test_bench_torchrun_dry_run_world2():
+    """bench.py under torch.distributed.run with 2 ranks, as the driver launches it: rank/shard/seed plumbing, the
+    barrier and the max-over-ranks reduction, on gloo; --dry-run exits before any GPU call."""
+    import json
+    import subprocess
+    port = _free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--dry-run']
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line from rank 0: {}'.format(r.stdout)
+    rec = json.loads(lines[0])
+    assert rec['dry_run'] and rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['warmup'] == 1
+    assert rec['config']['global_batch'] == 2 * rec['config']['batch_per_gpu']
+    assert rec['ranks'] == [{'rank': 0, 'local_rank': 0, 'seed': 0}, {'rank': 1, 'local_rank': 1, 'seed': 1}]
+    assert rec['scaling'] == 'weak' and rec['value'] > 0
