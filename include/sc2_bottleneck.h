@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 22
+#define SC2_ABI_VERSION 23
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -62,7 +62,8 @@ int sc2_avgpool_nhwc(const void *x, float *y_f32, void *y_bf16, int N, int HW, i
 /* 485-486,489-490,492-493 (decoder); with a_op/epilogue set, CompressAI GDN1.forward at       */
 /* layer.py:478,481,488,491 (norm = conv2d(|x|, gamma 1x1, beta); y = x/norm or x*norm).       */
 /* ------------------------------------------------------------------------------------------ */
-enum sc2_conv_aop { SC2_AOP_NONE = 0, SC2_AOP_ABS = 1 };
+enum sc2_conv_aop { SC2_AOP_NONE = 0, SC2_AOP_ABS = 1,
+                    SC2_AOP_SQUARE = 2 /* x^2: the operand of CompressAI GDN (squared form), compressai.layers.GDN.forward */ };
 enum sc2_conv_epilogue {
     SC2_EPI_NONE = 0,
     SC2_EPI_GDN = 1,  /* y = ep_x / (ep_beta[c] + acc)   (GDN1, inverse=False) */
@@ -76,7 +77,11 @@ enum sc2_conv_epilogue {
      * gamma matrix instead of an activation, in the layout sc2_conv_fused_gdn_supported reports. */
     SC2_EPI_FUSED_GDN = 6,
     SC2_EPI_FUSED_IGDN = 7,
-    SC2_EPI_BIAS_LEAKY_RELU = 8 /* y = leaky_relu(acc + ep_beta[c], 0.01) (nn.LeakyReLU() default slope; h_a / h_s) */
+    SC2_EPI_BIAS_LEAKY_RELU = 8, /* y = leaky_relu(acc + ep_beta[c], 0.01) (nn.LeakyReLU() default slope; h_a / h_s) */
+    /* CompressAI GDN (squared form; bmshj2018_factorized g_a / g_s, reached from sc2bench/models/registry.py:73-80): with
+     * a_op = SC2_AOP_SQUARE and the 1x1 gamma GEMM, acc = gamma x^2 */
+    SC2_EPI_GDN2 = 9,  /* y = ep_x * rsqrt(ep_beta[c] + acc)   (GDN, inverse=False) */
+    SC2_EPI_IGDN2 = 10 /* y = ep_x * sqrt(ep_beta[c] + acc)    (GDN, inverse=True)  */
 };
 enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHWC = 2 };
 /* Order of the K axis of the packed weights (and of the kernel's walk over the input):

@@ -13,5 +13,11 @@ from .layer import (LAYER_CLASS_DICT, LAYER_FUNC_DICT, BaseBottleneck, EntropyBo
                     FPBasedResNetBottleneck, MSHPBasedResNetBottleneck, SHPBasedResNetBottleneck, get_layer,
                     register_layer_class, register_layer_func)
 from .loss import BppLoss  # noqa: F401
+from .compression import (COMPRESSION_MODEL_CLASS_DICT, COMPRESSION_MODEL_FUNC_DICT, FactorizedPrior,  # noqa: F401
+                          bmshj2018_factorized, get_compression_model)
+from .entropy import GDN  # noqa: F401
+from .transforms import AdaptivePad, PILImageModule, PILTensorModule  # noqa: F401
+from .wrapper import (WRAPPER_CLASS_DICT, CodecFeatureCompressionClassifier, CodecInputCompressionClassifier,  # noqa: F401
+                      EntropicClassifier, NeuralInputCompressionClassifier, SplitClassifier, wrap_model)
 
 __version__ = '0.1.0'

@@ -9,7 +9,9 @@ into packages that are not installed here (`torchvision`, `torchdistill`) or tha
 * `torchvision.datasets.*` -> this module's `ImageFolder` (root/<class>/<image>; a missing directory raises on first
   use unless SC2_SYNTHETIC_DATA=1 opts in to random images),
 * `torchvision.models.resnet.*Weights` -> an inert enum (pretrained weights need the network),
-* `torchvision.transforms.*`, `torchdistill.*`, anything else that cannot be imported -> a recording placeholder,
+* `torchvision.transforms.{Compose,Resize,CenterCrop,ToTensor,Normalize,RandomResizedCrop,RandomHorizontalFlip}` ->
+  `sc2bench_amd.transforms` (PIL + torch),
+* other `torchvision.*`, `torchdistill.*`, anything else that cannot be imported -> a recording placeholder,
 
 so every config parses, and `models.student_model` builds the HIP-backed model from the very same block.
 """
@@ -144,6 +146,11 @@ def _sc2bench_attr(key):
             return registry[name]
     if hasattr(S, name):
         return getattr(S, name)
+    from . import transforms as tr, wrapper as wr, compression as cm
+    for registry in (tr.CODEC_TRANSFORM_MODULE_DICT, tr.MISC_TRANSFORM_MODULE_DICT, wr.WRAPPER_CLASS_DICT,
+                     cm.COMPRESSION_MODEL_CLASS_DICT, cm.COMPRESSION_MODEL_FUNC_DICT):
+        if name in registry:
+            return registry[name]
     return Placeholder(key)
 
 
@@ -155,6 +162,11 @@ def resolve(key):
         return ImageFolder
     if key.startswith('torchvision.models.') and key.endswith('_Weights'):
         return _WeightsEnum(key)
+    if key.startswith('torchvision.transforms.'):
+        from . import transforms as tr
+        name = key.split('.')[-1]
+        if name in tr.TORCHVISION_TRANSFORM_DICT:
+            return tr.TORCHVISION_TRANSFORM_DICT[name]
     module_name, _, attr = key.rpartition('.')
     try:
         return getattr(importlib.import_module(module_name), attr)
@@ -223,10 +235,14 @@ def import_dependencies(dependencies):
                 pass
 
 
-def build_model(model_config):
-    """models.{teacher_model, student_model, model} block -> nn.Module (torchvision / sc2bench registries)."""
+def build_model(model_config, device='cpu'):
+    """models.{teacher_model, student_model, model} block -> nn.Module (torchvision / sc2bench registries); a block with a
+    `classification_model` entry is a wrapped baseline (sc2bench/models/wrapper.py:343-370)."""
     import sc2bench_amd as S
     from .resnet import RESNET_FUNC_DICT
+    if 'classification_model' in model_config:
+        from .wrapper import get_wrapped_classification_model
+        return get_wrapped_classification_model(model_config, device)
     key = model_config['key']
     kwargs = dict(model_config.get('kwargs') or {})
     if key in S.MODEL_DICT:

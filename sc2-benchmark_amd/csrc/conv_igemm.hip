@@ -73,8 +73,7 @@ extern "C" int sc2_conv_patch_supported(const sc2_conv_desc *d) {
     if (!d) return 0;
     return d->Cin == 96 && d->Cout == 48 && d->KH == 5 && d->KW == 5 && d->stride_h == 2 && d->stride_w == 2 &&
                    d->pad_h == 2 && d->pad_w == 2 && d->OW > 0 && d->OW <= 64 && d->out_format == SC2_OUT_BF16_NHWC &&
-                   d->out_H == 0 && d->a_op == SC2_AOP_NONE && d->epilogue != SC2_EPI_GDN && d->epilogue != SC2_EPI_IGDN &&
-                   d->epilogue != SC2_EPI_BIAS_ADD_RELU
+                   d->out_H == 0 && d->a_op == SC2_AOP_NONE && !epi_needs_x(d->epilogue)
                ? 1 : 0;
 }
 
@@ -114,12 +113,12 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
                 sc2_conv_weight_pitch(K));
     SC2_REQUIRE(d->Cout_pad == sc2_conv_weight_rows(d->Cout), SC2_ERR_INVALID_ARG, "conv2d: Cout_pad %d != %d",
                 d->Cout_pad, sc2_conv_weight_rows(d->Cout));
-    SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS, SC2_ERR_INVALID_ARG, "conv2d: bad a_op");
+    SC2_REQUIRE(d->a_op >= SC2_AOP_NONE && d->a_op <= SC2_AOP_SQUARE, SC2_ERR_INVALID_ARG, "conv2d: bad a_op");
     SC2_REQUIRE(d->k_order >= 0 && d->k_order <= 7 && (!(d->k_order & SC2_K_SLAB_MAJOR) || d->Cin % 32 == 0) &&
                     (!(d->k_order & SC2_K_B_FRAG_MAJOR) ||
                      ((d->k_order & SC2_K_SLAB_MAJOR) && !(d->k_order & SC2_K_B_TILE_MAJOR))),
                 SC2_ERR_INVALID_ARG, "conv2d: slab-major K order needs Cin %% 32 == 0 (Cin = %d)", d->Cin);
-    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_BIAS_LEAKY_RELU, SC2_ERR_INVALID_ARG,
+    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_IGDN2, SC2_ERR_INVALID_ARG,
                 "conv2d: bad epilogue");
     const bool fused = d->epilogue == SC2_EPI_FUSED_GDN || d->epilogue == SC2_EPI_FUSED_IGDN;
     if (fused)
@@ -129,7 +128,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     SC2_REQUIRE(d->out_format >= SC2_OUT_BF16_NHWC && d->out_format <= SC2_OUT_F32_NHWC, SC2_ERR_INVALID_ARG,
                 "conv2d: bad out_format");
     if (d->epilogue != SC2_EPI_NONE) SC2_REQUIRE(ep_beta, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_beta");
-    if (d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS_ADD_RELU || fused)
+    if (epi_needs_x(d->epilogue) || fused)
         SC2_REQUIRE(ep_x, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_x");
     const long long M = (long long)d->N * OH * OW;
     SC2_REQUIRE(M < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv2d: N*OH*OW = %lld exceeds 2^31", M);
@@ -161,8 +160,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         const char *dbg = getenv("SC2_CONV_DEBUG");
         a.dbg = dbg ? atoi(dbg) : 0;
     }
-    const bool needs_x_operand =
-        d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS_ADD_RELU;
+    const bool needs_x_operand = epi_needs_x(d->epilogue);
     {
         const char *t = getenv("SC2_CONV_TOUCH");
         a.touch = (needs_x_operand && d->out_format == SC2_OUT_BF16_NHWC && !scatter && t && atoi(t)) ? 1 : 0;

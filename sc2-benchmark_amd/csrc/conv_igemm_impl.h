@@ -36,6 +36,27 @@
 
 namespace sc2conv {
 
+// epilogues that read an activation operand x through ep_x (GDN forms: y = x * f(beta + acc); residual add)
+__host__ __device__ __forceinline__ constexpr bool epi_needs_x(int epi) {
+    return epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU || epi == SC2_EPI_GDN2 ||
+           epi == SC2_EPI_IGDN2;
+}
+
+// eight bf16 values squared (f32 product, rounded to nearest even by the pack): the A operand of the squared-form GDN
+// GEMM norm^2 = beta + gamma x^2 (CompressAI GDN, bmshj2018_factorized)
+__device__ __forceinline__ uint4 bf16x8_square(uint4 v) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float lo = __builtin_bit_cast(float, w[t] << 16), hi = __builtin_bit_cast(float, w[t] & 0xFFFF0000u);
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t sq = {lo * lo, hi * hi};
+        w[t] = __builtin_bit_cast(uint32_t, __builtin_convertvector(sq, bf16x2_t));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 
 struct ConvArgs {
     const uint16_t *__restrict__ x;
@@ -239,7 +260,7 @@ __device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned
     constexpr int MT = C::MT, NT = C::NT;
     constexpr int CPR = EpiGeom<C, NTHREADS>::CPR, QPT = EpiGeom<C, NTHREADS>::QPT, Q = EpiGeom<C, NTHREADS>::Q;
     const int Cout = p.Cout;
-    const bool needs_x = epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU;
+    const bool needs_x = epi_needs_x(epi);
     if (needs_x && !x_in_image) {
 #pragma unroll
         for (int r = 0; r < QPT; ++r) {
@@ -291,6 +312,8 @@ __device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned
                     float r;
                     if (epi == SC2_EPI_GDN) r = xv[t] * (1.0f / norm);
                     else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
+                    else if (epi == SC2_EPI_GDN2) r = xv[t] * rsqrtf(norm);
+                    else if (epi == SC2_EPI_IGDN2) r = xv[t] * sqrtf(norm);
                     else if (epi == SC2_EPI_BIAS) r = norm;
                     else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
                     else if (epi == SC2_EPI_BIAS_LEAKY_RELU) r = norm > 0.f ? norm : 0.01f * norm;
@@ -374,7 +397,7 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                         b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
                     }
                     float xv[8];
-                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
+                    if (epi_needs_x(epi)) {
                         uint4 xr;
                         if (x_img) {
                             const int trow = (sr >> 4) * C::WM + i * 16 + (sr & 15);
@@ -398,6 +421,8 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                         float r;
                         if (epi == SC2_EPI_GDN) r = xv[t] * (1.0f / norm);
                         else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
+                        else if (epi == SC2_EPI_GDN2) r = xv[t] * rsqrtf(norm);
+                        else if (epi == SC2_EPI_IGDN2) r = xv[t] * sqrtf(norm);
                         else if (epi == SC2_EPI_BIAS) r = norm;
                         else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
                     else if (epi == SC2_EPI_BIAS_LEAKY_RELU) r = norm > 0.f ? norm : 0.01f * norm;
@@ -420,7 +445,7 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                 if (epi != SC2_EPI_NONE) {
                     const float norm = p.ep_beta[n] + v;
                     float xv = 0.f;
-                    if (epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU) {
+                    if (epi_needs_x(epi)) {
                         if (x_img) {
                             const int trow = (sr >> 4) * C::WM + i * 16 + (sr & 15);
                             xv = bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(
@@ -431,6 +456,8 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                     }
                     if (epi == SC2_EPI_GDN) v = xv * (1.0f / norm);
                     else if (epi == SC2_EPI_IGDN) v = xv * norm;
+                    else if (epi == SC2_EPI_GDN2) v = xv * rsqrtf(norm);
+                    else if (epi == SC2_EPI_IGDN2) v = xv * sqrtf(norm);
                     else if (epi == SC2_EPI_BIAS) v = norm;
                     else if (epi == SC2_EPI_BIAS_RELU) v = fmaxf(norm, 0.f);
                     else if (epi == SC2_EPI_BIAS_LEAKY_RELU) v = norm > 0.f ? norm : 0.01f * norm;
@@ -707,6 +734,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         for (int i = 0; i < MT; ++i) {
             uint4 v = av[i];
             v.x &= amask; v.y &= amask; v.z &= amask; v.w &= amask;
+            if (p.aop == SC2_AOP_SQUARE) v = bf16x8_square(v);   // wave-uniform: only the squared-form GDN GEMMs
             af[i] = __builtin_bit_cast(bf16x8_t, v);
         }
 #pragma unroll

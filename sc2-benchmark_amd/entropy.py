@@ -101,41 +101,60 @@ class HipConv2d(nn.Conv2d):
             cache[order] = hip.pack_conv_weight(self.weight, order)
         return cache[order]
 
+    def bias_f32(self):
+        return None if self.bias is None else self.bias.detach().float().contiguous()
+
+    def padded_weight(self, cin_pad):
+        """Packed weights with the input channels zero-padded to `cin_pad` (a 3-channel image enters the kernels as
+        8-channel NHWC); cached per parameter version."""
+        key = (self.weight._version, self.weight.device, self.weight.data_ptr(), cin_pad)
+        if getattr(self, '_padw_key', None) != key:
+            w = torch.zeros((self.out_channels, cin_pad) + tuple(self.kernel_size), dtype=self.weight.dtype,
+                            device=self.weight.device)
+            w[:, :self.in_channels] = self.weight.detach()
+            self._padw = hip.pack_conv_weight(w)
+            self._padw_key = key
+        return self._padw
+
     def forward_nhwc(self, x_nhwc, out_format=hip.OUT_BF16_NHWC):
-        assert self.bias is None and self.groups == 1 and self.dilation == (1, 1)
+        """x bf16 NHWC (channels possibly zero-padded beyond in_channels to a multiple of 8); a bias rides in the epilogue."""
+        assert self.groups == 1 and self.dilation == (1, 1)
+        epi, beta = (hip.EPI_NONE, None) if self.bias is None else (hip.EPI_BIAS, self.bias_f32())
+        if x_nhwc.shape[-1] != self.in_channels:
+            return hip.conv2d_fwd(x_nhwc, self.padded_weight(x_nhwc.shape[-1]), self.out_channels, self.kernel_size[0],
+                                  self.kernel_size[1], self.stride, self.padding, epilogue=epi, ep_beta=beta,
+                                  out_format=out_format, tag=getattr(self, '_tag', None))
         return hip.conv2d_fwd(x_nhwc, self.packed_weight(), self.out_channels, self.kernel_size[0],
-                              self.kernel_size[1], self.stride, self.padding, out_format=out_format,
-                              tag=getattr(self, '_tag', None), k_order=self.k_order())
+                              self.kernel_size[1], self.stride, self.padding, epilogue=epi, ep_beta=beta,
+                              out_format=out_format, tag=getattr(self, '_tag', None), k_order=self.k_order())
 
     def forward(self, x):
         _require_device(x, 'HipConv2d')
-        cin = self.in_channels
-        x_nhwc = hip.nchw_f32_to_nhwc_bf16(x.float(), (cin + 7) // 8 * 8)
-        if cin % 8 != 0:
-            w = torch.zeros((self.out_channels, x_nhwc.shape[-1]) + tuple(self.kernel_size),
-                            dtype=self.weight.dtype, device=self.weight.device)
-            w[:, :cin] = self.weight.detach()
-            packed = hip.pack_conv_weight(w)
-            return hip.conv2d_fwd(x_nhwc, packed, self.out_channels, self.kernel_size[0], self.kernel_size[1],
-                                  self.stride, self.padding, out_format=hip.OUT_F32_NCHW)
+        x_nhwc = hip.nchw_f32_to_nhwc_bf16(x.float(), (self.in_channels + 7) // 8 * 8)
         return self.forward_nhwc(x_nhwc, out_format=hip.OUT_F32_NCHW)
 
 
 class HipConvTranspose2d(nn.ConvTranspose2d):
-    """nn.ConvTranspose2d(bias=False) parameter holder (h_s of the hyperprior bottlenecks, layer.py:612-621) whose
+    """nn.ConvTranspose2d parameter holder (h_s of the hyperprior bottlenecks, layer.py:612-621; with bias and
+    output_padding, the `deconv` of CompressAI's bmshj2018_factorized synthesis transform) whose
     forward runs on the implicit-GEMM kernel: a transposed convolution is, per stride-parity class of the output, a
     stride-1 correlation with the flipped sub-filter of the taps that reach that class; each class is one launch that
     scatters its rows to every s-th output pixel (the data-gradient path of the training code, `hip.conv2d_dgrad`).
     The packed sub-filters are cached per parameter version."""
 
+    def _cout_pad(self):
+        return (self.out_channels + 7) // 8 * 8     # the kernels write whole 16-byte channel runs
+
     def _classes(self):
         key = (self.weight._version, self.weight.device, self.weight.data_ptr())
         if getattr(self, '_cls_key', None) != key:
-            assert self.bias is None and self.groups == 1 and self.dilation == (1, 1) and self.output_padding == (0, 0)
+            assert self.groups == 1 and self.dilation == (1, 1)
             cin, cout, KH, KW = self.weight.shape          # ConvTranspose2d weight: [in, out, kh, kw]
             sh, sw = self.stride
             ph, pw = self.padding
             wt = self.weight.detach().permute(1, 0, 2, 3)   # [out, in, kh, kw]: rows = output channels
+            if self._cout_pad() != cout:
+                wt = torch.cat([wt, wt.new_zeros((self._cout_pad() - cout,) + tuple(wt.shape[1:]))])
             classes = []
             for ch in range(sh):
                 rh = (ch + ph) % sh
@@ -158,13 +177,19 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
         return self._cls
 
     def forward_nhwc(self, x_nhwc, epilogue=hip.EPI_NONE, ep_beta=None, out_format=hip.OUT_BF16_NHWC):
-        """x bf16 [N,H,W,Cin] -> [N,(H-1)s-2p+k,(W-1)s-2p+k,Cout] (bf16, or f32 NHWC)."""
+        """x bf16 [N,H,W,Cin] -> [N,(H-1)s-2p+k+op,(W-1)s-2p+k+op,Cout] (bf16, or f32 NHWC)."""
         N, H, W, _ = x_nhwc.shape
         sh, sw = self.stride
-        OH = (H - 1) * sh - 2 * self.padding[0] + self.kernel_size[0]
-        OW = (W - 1) * sw - 2 * self.padding[1] + self.kernel_size[1]
-        cout = self.out_channels
-        out = torch.empty((N, OH, OW, cout), dtype=torch.bfloat16 if out_format == hip.OUT_BF16_NHWC else torch.float32,
+        OH = (H - 1) * sh - 2 * self.padding[0] + self.kernel_size[0] + self.output_padding[0]
+        OW = (W - 1) * sw - 2 * self.padding[1] + self.kernel_size[1] + self.output_padding[1]
+        cout, cpad = self.out_channels, self._cout_pad()
+        if self.bias is not None:      # the bias rides in each parity class's epilogue
+            if epilogue != hip.EPI_NONE:
+                raise hip.Sc2Error('HipConvTranspose2d: a bias and a fused activation epilogue together are not supported')
+            epilogue, ep_beta = hip.EPI_BIAS, self.bias.detach().float().contiguous()
+        if ep_beta is not None and cpad != cout:
+            ep_beta = torch.cat([ep_beta, ep_beta.new_zeros(cpad - cout)])
+        out = torch.empty((N, OH, OW, cpad), dtype=torch.bfloat16 if out_format == hip.OUT_BF16_NHWC else torch.float32,
                           device=x_nhwc.device)
         for ch, cw, nkh, nkw, pad_h, pad_w, packed in self._classes():
             rows = (OH - ch + sh - 1) // sh if OH > ch else 0
@@ -172,13 +197,13 @@ class HipConvTranspose2d(nn.ConvTranspose2d):
             if rows == 0 or cols == 0:
                 continue
             if sh == 1 and sw == 1:
-                hip.conv2d_fwd(x_nhwc, packed, cout, nkh, nkw, 1, (pad_h, pad_w), epilogue=epilogue, ep_beta=ep_beta,
+                hip.conv2d_fwd(x_nhwc, packed, cpad, nkh, nkw, 1, (pad_h, pad_w), epilogue=epilogue, ep_beta=ep_beta,
                                out_format=out_format, out=out, tag=getattr(self, '_tag', None))
             else:
-                hip.conv2d_fwd(x_nhwc, packed, cout, nkh, nkw, 1, (pad_h, pad_w), epilogue=epilogue, ep_beta=ep_beta,
+                hip.conv2d_fwd(x_nhwc, packed, cpad, nkh, nkw, 1, (pad_h, pad_w), epilogue=epilogue, ep_beta=ep_beta,
                                out_format=out_format, tag=getattr(self, '_tag', None),
                                scatter=(rows, cols, out, sh, sw, ch, cw))
-        return out
+        return out if cpad == cout else out[..., :cout]
 
     def forward(self, x, output_size=None):
         _require_device(x, 'HipConvTranspose2d')
@@ -288,6 +313,21 @@ class GDN1(nn.Module):
         _require_device(x, 'GDN1')
         x_nhwc = hip.nchw_f32_to_nhwc_bf16(x.float())
         return self.forward_nhwc(x_nhwc, out_format=hip.OUT_F32_NCHW)
+
+
+class GDN(GDN1):
+    """Generalized divisive normalisation, squared form: y = x / sqrt(beta + gamma x^2); inverse: x * sqrt(...).
+
+    Same parameters, initialisation and state-dict keys as compressai.layers.GDN (the analysis / synthesis transforms
+    of `bmshj2018_factorized`, which the reference builds at sc2bench/models/registry.py:73-80 for the neural input
+    compression configs).  gamma x^2 is a 1x1 implicit GEMM on the matrix cores with the square applied to the
+    operand fragments and rsqrt / sqrt fused in the epilogue."""
+
+    def forward_nhwc(self, x_nhwc, out_format=hip.OUT_BF16_NHWC):
+        beta, gamma_packed = self.effective()
+        return hip.conv2d_fwd(x_nhwc, gamma_packed, self.in_channels, 1, 1, 1, 0, a_op=hip.AOP_SQUARE,
+                              epilogue=hip.EPI_IGDN2 if self.inverse else hip.EPI_GDN2, out_format=out_format,
+                              ep_x=x_nhwc, ep_beta=beta, tag=getattr(self, '_tag', None))
 
 
 # --------------------------------------------------------------------------------------------- #

@@ -1,0 +1,140 @@
+"""Evaluation loop of the image-classification task (script/task/image_classification.py:106-145) and the
+`-test_only` entry for the BASELINE plumbing configs:
+
+    python -m sc2bench_amd.evaluation --config <yaml> [--device cpu|cuda] [--json '{...}'] [--max_samples 100]
+
+It builds `models.model` (or `models.student_model`) from the reference's YAML file unchanged, loads `test.test_data_loader`
+(dataset, sampler, batch size, `collate_fn`), runs the model in eval mode under `torch.inference_mode()`, reports top-1 /
+top-5 accuracy and lets every analyzer summarise (data size in KB, as the reference logs it).  Metrics are averaged over
+ranks when a process group is up (`MetricLogger.synchronize_between_processes`: SURVEY.md C5).
+"""
+import argparse
+import json
+import logging
+import time
+
+import torch
+
+from . import config as C
+from .analysis import AnalyzableModule
+from .dataparallel import all_reduce_mean_scalars
+
+logger = logging.getLogger(__name__)
+
+
+def compute_accuracy(outputs, targets, topk=(1,)):
+    """-> [accuracy@k in percent] (image_classification.py:91-103)."""
+    with torch.no_grad():
+        maxk = max(topk)
+        batch_size = targets.size(0)
+        _, preds = outputs.topk(maxk, 1, True, True)
+        corrects = preds.t().eq(targets[None])
+        return [corrects[:k].flatten().sum(dtype=torch.float32) * (100.0 / batch_size) for k in topk]
+
+
+class Meter(object):
+    def __init__(self):
+        self.total, self.count = 0.0, 0
+
+    def update(self, value, n=1):
+        self.total += float(value) * n
+        self.count += n
+
+    @property
+    def global_avg(self):
+        return self.total / max(1, self.count)
+
+
+@torch.inference_mode()
+def evaluate(model, data_loader, device, max_samples=None, log_freq=1000, title=None):
+    """-> {'acc1', 'acc5', 'samples', 'seconds', 'analysis': [summaries]}."""
+    model = model.to(device) if device.type == 'cuda' else model
+    if hasattr(model, 'use_cpu4compression') and device.type != 'cuda':
+        model.use_cpu4compression()
+    if title is not None:
+        logger.info(title)
+    model.eval()
+    analyzable = isinstance(model, AnalyzableModule)
+    if analyzable:
+        model.activate_analysis()
+    acc1, acc5 = Meter(), Meter()
+    t0 = time.perf_counter()
+    seen = 0
+    for i, (image, target) in enumerate(data_loader):
+        if isinstance(image, torch.Tensor):
+            image = image.to(device, non_blocking=True)
+        if isinstance(target, torch.Tensor):
+            target = target.to(device, non_blocking=True)
+        output = model(image)
+        a1, a5 = compute_accuracy(output.float(), target.to(output.device), topk=(1, 5))
+        batch_size = len(image)
+        acc1.update(a1.item(), n=batch_size)
+        acc5.update(a5.item(), n=batch_size)
+        seen += batch_size
+        if log_freq and (i + 1) % log_freq == 0:
+            logger.info('Test: [{}] acc1 {:.3f} acc5 {:.3f}'.format(i + 1, acc1.global_avg, acc5.global_avg))
+        if max_samples is not None and seen >= max_samples:
+            break
+    top1, top5 = all_reduce_mean_scalars([acc1.global_avg, acc5.global_avg], torch.device('cpu'))
+    logger.info(' * Acc@1 {:.4f}\tAcc@5 {:.4f}\n'.format(top1, top5))
+    analysis = []
+    if analyzable and model.activated_analysis:
+        model.summarize()
+        analysis = [a.summary() for a in model.analyzers if hasattr(a, 'summary') and getattr(a, 'file_size_list', None)]
+    return {'acc1': top1, 'acc5': top5, 'samples': seen, 'seconds': time.perf_counter() - t0, 'analysis': analysis}
+
+
+def build_data_loader(dataset_dict, loader_config):
+    """`test.test_data_loader` block -> DataLoader (dataset by id, sampler class, kwargs, `collate_fn` by name)."""
+    from .transforms import default_collate_w_pil
+    dataset = dataset_dict[loader_config['dataset_id']]
+    kwargs = dict(loader_config.get('kwargs') or {})
+    sampler_cfg = loader_config.get('sampler') or {}
+    sampler_cls = sampler_cfg.get('class_or_func')
+    sampler = None
+    if sampler_cls is not None and not isinstance(sampler_cls, C.Placeholder):
+        sampler = sampler_cls(dataset, **(sampler_cfg.get('kwargs') or {}))
+    collate = {'default_collate_w_pil': default_collate_w_pil}.get(loader_config.get('collate_fn'))
+    kwargs.setdefault('batch_size', 1)
+    return torch.utils.data.DataLoader(dataset, sampler=sampler, collate_fn=collate, **kwargs)
+
+
+def test_only(config, device, max_samples=None, num_workers=None):
+    """The `-test_only` branch of main() (image_classification.py:236-250) for a config dict: -> evaluate()'s result."""
+    C.import_dependencies(config.get('dependencies'))
+    models = config['models']
+    model_config = models['student_model'] if 'student_model' in models else models['model']
+    model = C.build_model(model_config, device)
+    from .ckpt import load_ckpt
+    if model_config.get('dst_ckpt') is not None or model_config.get('src_ckpt') is not None:
+        load_ckpt(model_config.get('dst_ckpt') or model_config.get('src_ckpt'), model=model, strict=False)
+    if hasattr(model, 'update') and not isinstance(model, torch.nn.parallel.DistributedDataParallel):
+        from .backbone import check_if_updatable
+        if check_if_updatable(model):
+            model.update()
+    loader_config = dict(config['test']['test_data_loader'])
+    if num_workers is not None:
+        loader_config['kwargs'] = dict(loader_config.get('kwargs') or {}, num_workers=num_workers)
+    loader = build_data_loader(config['datasets'], loader_config)
+    return evaluate(model, loader, device, max_samples=max_samples, title='[Student/model]')
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='test-only evaluation of a reference config on this build')
+    ap.add_argument('--config', required=True)
+    ap.add_argument('--json', help='json string to overwrite config')
+    ap.add_argument('--device', default='cuda' if torch.cuda.is_available() else 'cpu')
+    ap.add_argument('--max_samples', type=int)
+    ap.add_argument('--num_workers', type=int)
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO)
+    config = C.load_yaml_file(args.config)
+    if args.json:
+        C.overwrite_config(config, json.loads(args.json))
+    result = test_only(config, torch.device(args.device), args.max_samples, args.num_workers)
+    print(json.dumps(result))
+    return result
+
+
+if __name__ == '__main__':
+    main()

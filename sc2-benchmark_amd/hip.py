@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SC2_LIB') or os.path.join(_HERE, 'libsc2amd.so')   # SC2_LIB: A/B builds (tools/)
 _lib = None
 
-AOP_NONE, AOP_ABS = 0, 1
+AOP_NONE, AOP_ABS, AOP_SQUARE = 0, 1, 2
 EPI_NONE, EPI_GDN, EPI_IGDN, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_ADD_RELU, EPI_FUSED_GDN, EPI_FUSED_IGDN, \
-    EPI_BIAS_LEAKY_RELU = range(9)
+    EPI_BIAS_LEAKY_RELU, EPI_GDN2, EPI_IGDN2 = range(11)
 FUSABLE_GDN_CHANNELS = (32, 48, 64, 96)   # conv + GDN1 in one launch: one tile must hold every output channel
 OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
 EB_NOISE, EB_DEQUANTIZE = 0, 1

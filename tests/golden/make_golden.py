@@ -137,7 +137,49 @@ def make_hyperprior_golden():
     torch.save(out, os.path.join(HERE, 'hyperprior_golden.pt'))
 
 
+def make_input_golden():
+    """the seeded factorized-prior codec (latent, tables, byte streams, reconstruction) and
+    the codec feature-compression transform (PILTensorModule sizes / reconstruction digests, Pillow version recorded)."""
+    import hashlib
+    import PIL
+    from oracle import cpu_ref_input as RI
+    from recipe import build_oracle_factorized_prior
+    m, x = build_oracle_factorized_prior(RI, R)
+    g = {'fingerprint': fingerprint(m), 'x': x}
+    with torch.no_grad():
+        y = m.g_a(x)
+        g['y'] = y
+        g['gdn_in'] = torch.randn(2, 192, 5, 7)
+        g['gdn_out'] = m.g_a[1](g['gdn_in'])
+        g['igdn_out'] = m.g_s[1](g['gdn_in'])
+        out = m(x)                                  # eval mode: dequantised latent, no noise
+        g['x_hat_forward'] = out['x_hat']
+        g['bits'] = float(-torch.log2(out['likelihoods']['y']).sum())
+        m.update()
+        eb = m.entropy_bottleneck
+        g['cdf_sha256'] = hashlib.sha256(eb._quantized_cdf.numpy().tobytes()).hexdigest()
+        g['cdf_shape'] = list(eb._quantized_cdf.shape)
+        g['offset'], g['cdf_length'] = eb._offset.clone(), eb._cdf_length.clone()
+        enc = m.compress(x)
+        g['strings_hex'] = [s.hex() for s in enc['strings'][0]]
+        g['shape'] = list(enc['shape'])
+        g['file_size_kb'] = R.file_size(enc)
+        g['x_hat'] = m.decompress(**enc)['x_hat']
+    torch.manual_seed(3)
+    feats = {'f512': torch.randn(512, 7, 7).abs() * 2 + 0.05, 'f5': torch.randn(5, 12, 10) + 3.0}
+    g['pil'] = {'pillow': PIL.__version__, 'cases': {}}
+    for name, t in feats.items():
+        rec, size = RI.pil_tensor_module(t, format='JPEG', quality=90)
+        g['pil']['cases'][name] = {'x': t, 'file_size': size, 'recon_sha256': hashlib.sha256(rec.numpy().tobytes()).hexdigest()}
+    g['pad'] = {'in_shape': [3, 224, 224], 'factor': 64, 'out_shape': list(RI.adaptive_pad(torch.zeros(3, 224, 224), factor=64).shape)}
+    torch.save(g, os.path.join(HERE, 'input_golden.pt'))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'input':     # only the input-compression fixture
+        make_input_golden()
+        sys.exit(0)
+    make_input_golden()
     make_rans_kat()
     make_fp_golden()
     make_hyperprior_golden()

@@ -39,3 +39,26 @@ def build_oracle_hyperprior(R, name):
     m.eval()
     x = torch.rand(2, 3, 32, 32)
     return m, x
+
+
+def build_oracle_factorized_prior(RI, R, quality=8):
+    """Seeded bmshj2018-factorized oracle model (quality 8: N = 192, M = 320, the BASELINE config) with non-trivial
+    GDN matrices, biases, tables and latent spread, and its input (already a multiple of 64 on both sides)."""
+    torch.manual_seed(2)
+    m = RI.bmshj2018_factorized(quality)
+    eb = m.entropy_bottleneck
+    with torch.no_grad():
+        C = eb.channels
+        q = torch.zeros(C, 1, 3)
+        for c in range(C):
+            q[c, 0, 0], q[c, 0, 1], q[c, 0, 2] = -(3 + c % 5), 0.25 * (c % 3), 4 + c % 7
+        eb.quantiles.copy_(q)
+        for mod in list(m.g_a) + list(m.g_s):
+            if isinstance(mod, RI.GDN):
+                mod.gamma.add_(0.01 * torch.rand_like(mod.gamma))
+            elif mod.bias is not None:
+                mod.bias.add_(0.05 * torch.randn_like(mod.bias))
+        m.g_a[6].weight.mul_(60.0)      # spreads the latent over several quantisation bins
+    m.eval()
+    x = torch.rand(2, 3, 64, 128)
+    return m, x
