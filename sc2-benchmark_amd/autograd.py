@@ -164,6 +164,8 @@ def analysis_autograd(m, x):
     c0, g1, c2, g3, c4 = m._g_a()
     x = x.float()
     if m._uses_pair_conv0(x):
+        if x.shape[-1] % 2:     # odd width: one zero column (what the conv's own padding reads)
+            x = torch.nn.functional.pad(x, (0, 1))
         N, _, H, W = x.shape
         x4 = _ToNhwcBf16.apply(x, 4)
         xp = x4.view(N, H, W // 2, 8)

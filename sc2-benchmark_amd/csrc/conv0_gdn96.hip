@@ -15,8 +15,10 @@
 //           norm = beta + gamma |t| is a second GEMM with gamma fragment-major from L2, y = t / norm on the f32
 //           accumulators, written to the image and streamed out as one contiguous 43 KB block.
 // Units are claimed with one atomic each, one unit ahead (claim c means unit c + 2 * gridDim.x; a launch makes exactly
-// n_units claims, and the one that draws n_units - 1 writes the counter back to zero: no preset launch).  Geometry: OW = 112 (224-pixel-wide input) only; other sizes
-// use the generic kernel.
+// n_units claims, and the one that draws n_units - 1 writes the counter back to zero: no preset launch).  Geometry: any
+// width -- an output row is cut into segments of OW = 112 pixels (one segment for the 224-pixel-wide input; 513 x 513 ->
+// 257 = 112 + 112 + 33, 1216 -> 608 = 5 x 112 + 48), a unit is two output rows of one segment; an odd image width is
+// zero-padded to even by the caller (the zero column is what the convolution's own padding would read).
 #include <stdlib.h>
 
 #include <atomic>
@@ -32,6 +34,7 @@ struct EncArgs {
     const float *__restrict__ beta;      // f32 [96]
     uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, OW, 96]
     int H, WP, OH, n_units, units_per_img;
+    int n_seg;                           // column segments of OW output pixels per output row (WP = total output width)
     unsigned *unit_ctr;
 };
 
@@ -71,13 +74,15 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
     auto load_rows = [&](int unit, int tid) {   // the 7 input rows of `unit`, zero outside the image
         const bool live = unit < p.n_units;
         const int im = live ? unit / p.units_per_img : 0;
-        const int oh0 = live ? (unit - im * p.units_per_img) * 2 : 0;
+        const int u_in = live ? unit - im * p.units_per_img : 0;
+        const int rp = u_in / p.n_seg, seg = u_in - rp * p.n_seg;
+        const int oh0 = rp * 2;
         const uint16_t *ximg = p.x + (long long)im * p.H * p.WP * 8;
 #pragma unroll
         for (int k = 0; k < IN_Q; ++k) {
             const unsigned q = tid + 256 * k;
             const unsigned r = (q * 575u) >> 16, c = q - r * (OW + 2);      // q / 114 for q < 1100
-            const int ih = 2 * oh0 - 2 + (int)r, pc = (int)c - 1;
+            const int ih = 2 * oh0 - 2 + (int)r, pc = seg * OW + (int)c - 1;
             in_ok[k] = live & (q < IN_ROWS * (OW + 2)) & ((unsigned)ih < (unsigned)p.H) & ((unsigned)pc < (unsigned)p.WP);
             const unsigned off = in_ok[k] ? (unsigned)(ih * p.WP + pc) * 16u : 0u;   // bytes within the image (< 2^31)
             in_next[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(ximg) + off);
@@ -116,8 +121,11 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
 
     while (unit < p.n_units) {
         const int im = unit / p.units_per_img;
-        const int oh0 = (unit - im * p.units_per_img) * 2;
+        const int u_in = unit - im * p.units_per_img;
+        const int rp = u_in / p.n_seg, seg = u_in - rp * p.n_seg;
+        const int oh0 = rp * 2;
         const int n_rows = p.OH - oh0 >= 2 ? 2 : 1;
+        const int n_cols = p.WP - seg * OW >= OW ? OW : p.WP - seg * OW;   // valid output columns of this segment
 
         // ---------------------------------------------------------------- conv: t = W0 * patch
         f32x4_t acc[MT][NT];
@@ -222,14 +230,20 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
         }
         load_rows(next_unit, tq);
         {
-            uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * CH);   // contiguous 2 rows
-            const int n_chunks = n_rows * OW * (CH / 8);
+            // the unit's two output rows x n_cols pixels: runs of n_cols * 192 bytes at (oh0 + row, seg * OW); for the
+            // 224-pixel-wide geometry (one segment, n_cols = OW) the two runs are one contiguous 43 KB block
+            uint4 *yo = reinterpret_cast<uint4 *>(p.y + (((long long)im * p.OH + oh0) * p.WP + seg * OW) * CH);
+            const unsigned q_safe = (unsigned)tq % (unsigned)(12 * n_cols);   // a chunk of row 0 that is always valid
 #pragma unroll
             for (int k = 0; k < Y_Q; ++k) {
                 const unsigned q0 = tq + 256 * k;
-                const unsigned q = q0 < (unsigned)n_chunks ? q0 : (unsigned)tq;   // past the end: the thread's first chunk again
-                const unsigned px = (q * 43691u) >> 19;                           // q / 12 for q < 4096
-                yo[q] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
+                const unsigned px0 = (q0 * 43691u) >> 19;                          // q0 / 12 for q0 < 4096
+                const unsigned row0 = px0 >= (unsigned)OW ? 1u : 0u, col0 = px0 - row0 * OW;
+                const bool ok = (row0 < (unsigned)n_rows) & (col0 < (unsigned)n_cols) & (q0 < (unsigned)(2 * OW * 12));
+                const unsigned q = ok ? q0 : q_safe;                               // invalid: a valid chunk again (same data)
+                const unsigned px = (q * 43691u) >> 19;
+                const unsigned row = px >= (unsigned)OW ? 1u : 0u, col = px - row * OW;
+                yo[(row * p.WP + col) * 12 + (q - px * 12)] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
             }
         }
         store_rows(tq);    // the staged rows were last read before the first barrier of this unit
@@ -252,7 +266,7 @@ std::atomic<unsigned> g_seq0{0};
 }  // namespace
 
 extern "C" int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs) {
-    return Cin_pairs == 8 && Cout == 96 && W_pairs == OW ? 1 : 0;
+    return Cin_pairs == 8 && Cout == 96 && W_pairs >= 1 ? 1 : 0;
 }
 
 extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta,
@@ -260,7 +274,8 @@ extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, cons
     SC2_REQUIRE(x_pairs && w_frag && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "conv0_gdn96: null argument");
     SC2_REQUIRE(N > 0 && H > 0, SC2_ERR_INVALID_ARG, "conv0_gdn96: non-positive dimension");
     SC2_REQUIRE(sc2_conv0_gdn96_supported(8, 96, W_pairs), SC2_ERR_UNSUPPORTED,
-                "conv0_gdn96: needs %d pixel pairs per row (a 224-pixel-wide image), got %d", OW, W_pairs);
+                "conv0_gdn96: needs at least one pixel pair per row, got %d", W_pairs);
+    SC2_REQUIRE((long long)H * W_pairs * 16 < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv0_gdn96: image too large");
     EncArgs a;
     a.x = static_cast<const uint16_t *>(x_pairs);
     a.w = static_cast<const uint16_t *>(w_frag);
@@ -269,7 +284,8 @@ extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, cons
     a.y = static_cast<uint16_t *>(y);
     a.H = H; a.WP = W_pairs;
     a.OH = (H + 4 - 5) / 2 + 1;
-    a.units_per_img = (a.OH + 1) / 2;
+    a.n_seg = (W_pairs + OW - 1) / OW;
+    a.units_per_img = ((a.OH + 1) / 2) * a.n_seg;
     const long long units = (long long)N * a.units_per_img;
     SC2_REQUIRE(units < 0x7FFFFFFFLL - 1024, SC2_ERR_UNSUPPORTED, "conv0_gdn96: too many units");
     a.n_units = (int)units;

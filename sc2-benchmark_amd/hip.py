@@ -453,7 +453,8 @@ def conv2x2_gdn512_supported(cin, cout, kh, kw, stride, pad):
 
 
 def conv0_gdn96_supported(x_pairs_shape, cout):
-    """True if the pixel-pair first conv + GDN1(96) runs as the single persistent launch (224-pixel-wide images)."""
+    """True if the pixel-pair first conv + GDN1(96) runs as the single persistent launch (any width: 112-pixel output
+    segments)."""
     if os.environ.get('SC2_CONV0_FUSED', '1') == '0':      # A/B switch (tools/)
         return False
     return len(x_pairs_shape) == 4 and bool(lib().sc2_conv0_gdn96_supported(x_pairs_shape[3], cout, x_pairs_shape[2]))

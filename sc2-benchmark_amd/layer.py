@@ -157,7 +157,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
     def _uses_pair_conv0(self, x):
         c0 = self._g_a()[0]
         return (c0.in_channels <= 4 and c0.kernel_size == (5, 5) and c0.stride == (2, 2) and c0.padding == (2, 2)
-                and x.shape[-1] % 2 == 0 and c0.out_channels % 8 == 0)
+                and c0.out_channels % 8 == 0)
 
     def analysis(self, x):
         """encoder(x): f32 NCHW image batch -> f32 NCHW latent (layer.py:475-483)."""
@@ -167,6 +167,8 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         fuse0 = self.fuse_gdn and c0.out_channels in hip.FUSABLE_GDN_CHANNELS
         fuse2 = self.fuse_gdn and c2.out_channels in hip.FUSABLE_GDN_CHANNELS
         if self._uses_pair_conv0(x):
+            if x.shape[-1] % 2:      # odd width (513): one zero column, exactly what the conv's own padding would read
+                x = torch.nn.functional.pad(x, (0, 1))
             N, _, H, W = x.shape
             x4 = hip.nchw_f32_to_nhwc_bf16(x, 4)                      # [N,H,W,4]
             xp = x4.view(N, H, W // 2, 8)                             # pixel pairs

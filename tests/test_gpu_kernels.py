@@ -445,11 +445,14 @@ def test_conv1x1_stream(S, dev, cin, cout, stride, N, H, W, res, relu):
     assert_close_bf16(out, gen, 'streaming vs tile kernel', extra=2.0 ** -8)
 
 
-@pytest.mark.parametrize('N,H,inverse', [(3, 224, False), (2, 30, False), (5, 11, True)])
-def test_conv0_gdn96_fused(S, R, dev, N, H, inverse):
+@pytest.mark.parametrize('N,H,W,inverse', [(3, 224, 224, False), (2, 30, 224, False), (5, 11, 224, True),
+                                           (2, 9, 514, False), (1, 7, 1216, False), (2, 5, 226, True), (2, 6, 40, False),
+                                           (3, 4, 2, False)])
+def test_conv0_gdn96_fused(S, R, dev, N, H, W, inverse):
     """First encoder conv on pixel pairs + GDN1(96) as one persistent launch vs the f32 ops on the bf16-rounded
-    operands and vs the tile kernel's fused path; image borders, odd output height, several units per workgroup."""
-    W = 224
+    operands and vs the tile kernel's fused path; image borders, odd output height, several units per workgroup; widths
+    other than 224: 112-pixel output segments (513 + 1 -> 112 + 112 + 33; 1216 -> 5 x 112 + 48; 226 -> 112 + 1;
+    40 -> one partial segment of 20; a single pixel pair)."""
     torch.manual_seed(H)
     x = torch.rand(N, 3, H, W) * 2 - 1
     w = torch.randn(96, 3, 5, 5) / 75 ** 0.5
@@ -469,7 +472,7 @@ def test_conv0_gdn96_fused(S, R, dev, N, H, inverse):
     x4 = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev), 4)
     xp = x4.view(N, H, W // 2, 8)
     assert S.hip.conv0_gdn96_supported(tuple(xp.shape), 96)
-    assert not S.hip.conv0_gdn96_supported((N, H, 100, 8), 96)
+    assert not S.hip.conv0_gdn96_supported((N, H, W // 2, 8), 48)
     packed = S.hip.pack_conv0_weight_pairs(w.to(dev))
     out = S.hip.conv0_gdn96_fwd(xp, S.hip.pack_weight_fragments(packed[:96]), gamma_f, beta_d, inverse)
     assert out.shape == (N, ref.shape[2], ref.shape[3], 96)
