@@ -5,8 +5,8 @@ repository root loads it under the module name ``sc2bench_amd``.
 """
 from . import hip  # noqa: F401
 from .analysis import ANALYZER_CLASS_DICT, AnalyzableModule, FileSizeAccumulator, FileSizeAnalyzer  # noqa: F401
-from .backbone import (BACKBONE_CLASS_DICT, BACKBONE_FUNC_DICT, MODEL_DICT, SplittableResNet,  # noqa: F401
-                       UpdatableBackbone, check_if_updatable, get_backbone, splittable_resnet)
+from .backbone import (BACKBONE_CLASS_DICT, BACKBONE_FUNC_DICT, MODEL_DICT, FeatureExtractionBackbone,  # noqa: F401
+                       SplittableResNet, UpdatableBackbone, check_if_updatable, get_backbone, splittable_resnet)
 from .entropy import (CompressionModel, EntropyBottleneck, GDN1, GaussianConditional, HipConv2d,  # noqa: F401
                       HipConvTranspose2d, LowerBound, NonNegativeParametrizer, get_scale_table)
 from .layer import (LAYER_CLASS_DICT, LAYER_FUNC_DICT, BaseBottleneck, EntropyBottleneckLayer,  # noqa: F401
@@ -20,4 +20,7 @@ from .transforms import AdaptivePad, PILImageModule, PILTensorModule  # noqa: F4
 from .wrapper import (WRAPPER_CLASS_DICT, CodecFeatureCompressionClassifier, CodecInputCompressionClassifier,  # noqa: F401
                       EntropicClassifier, NeuralInputCompressionClassifier, SplitClassifier, wrap_model)
 
-__version__ = '0.1.0'
+from .dense import (DETECTION_MODEL_FUNC_DICT, SEGMENTATION_MODEL_FUNC_DICT, BaseRCNN, BaseSegmentationModel,  # noqa: F401
+                    SegEvaluator, UpdatableBackboneWithFPN, backbone_with_fpn, deeplabv3_model, faster_rcnn_model)
+
+__version__ = '0.2.0'

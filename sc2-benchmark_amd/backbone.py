@@ -1,5 +1,5 @@
 """Splittable backbones: host-side mirror of sc2bench/models/backbone.py for the ResNet path
-(UpdatableBackbone :47-75, SplittableResNet :175-276, splittable_resnet :658-698, registries :15-44,
+(UpdatableBackbone :47-75, FeatureExtractionBackbone :90-172, SplittableResNet :175-276, splittable_resnet :658-698, registries :15-44,
 get_backbone :894-909).
 
 Forward order is the reference's: pre_transform -> bottleneck (encode/analyze/decode when updated and in
@@ -53,6 +53,104 @@ class UpdatableBackbone(AnalyzableModule):
 
 def check_if_updatable(model):
     return isinstance(model, UpdatableBackbone)
+
+
+class FeatureExtractionBackbone(UpdatableBackbone):
+    """Runs the named children of `model` in order and returns the outputs of the ones listed in `return_layer_dict`
+    (sc2bench/models/backbone.py:90-172; the body of the detection and segmentation models).  The child named by
+    `analyzable_layer_key` (the bottleneck) goes through encode -> analyze -> decode once the model is updated and in
+    eval mode; children after the last returned layer are dropped.
+
+    `set_compute_dtype('bf16')` (eval): the bottleneck hands bf16 NHWC features on, and every following child that is a
+    stack of torchvision Bottleneck blocks without dilation runs on the fused conv+norm kernels of `head.HipHead`
+    (FrozenBatchNorm2d and BatchNorm2d both fold); dilated stacks (DeepLab's layer3 / layer4) stay torch modules in
+    bf16 channels_last.
+    """
+
+    def __init__(self, model, return_layer_dict, analyzer_configs, analyzes_after_compress=False,
+                 analyzable_layer_key=None):
+        children = OrderedDict(model.named_children())
+        if not set(return_layer_dict).issubset(children.keys()):
+            raise ValueError('return_layer_dict are not present in model')
+        super().__init__(analyzer_configs)
+        wanted = {str(k) for k in return_layer_dict}
+        for name, module in children.items():
+            self.add_module(name, module)
+            wanted.discard(name)
+            if not wanted:        # everything to be returned has been produced: the rest of the model is not needed
+                break
+        self.return_layer_dict = return_layer_dict
+        self.analyzable_layer_key = analyzable_layer_key
+        self.analyzes_after_compress = analyzes_after_compress
+        self.compute_dtype = 'f32'
+        self._hip_layers = dict()
+
+    def set_compute_dtype(self, dtype):
+        assert dtype in ('f32', 'bf16')
+        self.compute_dtype = dtype
+        for name, module in self.named_children():
+            if name == self.analyzable_layer_key:
+                if hasattr(module, 'output_format'):
+                    module.output_format = 'bf16_nhwc' if dtype == 'bf16' else 'f32_nchw'
+            elif dtype == 'bf16':
+                module.to(dtype=torch.bfloat16, memory_format=torch.channels_last)
+            else:
+                module.to(dtype=torch.float32)
+        return self
+
+    def _hip_layer(self, name, module):
+        """HipHead of one child, or None if the child is not a stack of undilated Bottleneck blocks."""
+        from .head import HipHead
+        from .resnet import Bottleneck
+        if not (isinstance(module, nn.Sequential) and len(module) > 0 and all(isinstance(b, Bottleneck) for b in module)):
+            return None
+        if any(c.dilation != (1, 1) for b in module for c in (b.conv1, b.conv2, b.conv3)):
+            return None
+        key = tuple(t._version for t in list(module.parameters()) + list(module.buffers()))
+        cached = self._hip_layers.get(name)
+        if cached is None or cached[0] != key:
+            cached = (key, HipHead([(name, module)], None))
+            self._hip_layers[name] = cached
+        return cached[1]
+
+    def _run_child(self, name, module, x):
+        if self.compute_dtype == 'bf16' and not self.training and x.is_cuda and x.dtype == torch.bfloat16:
+            head = self._hip_layer(name, module)
+            if head is not None:
+                return head.forward(x.permute(0, 2, 3, 1).contiguous(), with_pool=False)
+        return module(x)
+
+    def forward(self, x):
+        out = OrderedDict()
+        for name, module in self.named_children():
+            if name == self.analyzable_layer_key and self.bottleneck_updated and not self.training:
+                compressed = module.encode(x)
+                if self.analyzes_after_compress:
+                    self.analyze(compressed)
+                x = module.decode(**compressed)
+            else:
+                x = self._run_child(name, module, x)
+            if name in self.return_layer_dict:
+                out[self.return_layer_dict[name]] = x
+        return out
+
+    def check_if_updatable(self):
+        key = self.analyzable_layer_key
+        return key is not None and key in self._modules and isinstance(self._modules[key], CompressionModel)
+
+    def update(self):
+        if self.analyzable_layer_key is None:
+            return
+        if self.analyzable_layer_key not in self._modules:
+            raise KeyError('`analyzable_layer_key` ({}) does not exist in {}'.format(self.analyzable_layer_key, self))
+        self._modules[self.analyzable_layer_key].update()
+        self.bottleneck_updated = True
+
+    def get_aux_module(self, **kwargs):
+        return self._modules[self.analyzable_layer_key] if self.check_if_updatable() else None
+
+
+register_backbone_class(FeatureExtractionBackbone)
 
 
 class SplittableResNet(UpdatableBackbone):

@@ -36,10 +36,21 @@ def _torch_load(path, unsafe=False):
 
 def load_ckpt(ckpt_file_path, model=None, optimizer=None, lr_scheduler=None, strict=True, unsafe=False):
     if isinstance(ckpt_file_path, str) and ckpt_file_path.startswith(('http://', 'https://')):
-        # torchdistill downloads here; this build runs offline, and returning (None, None) would silently leave the
-        # model at its random initialisation
-        raise RuntimeError('load_ckpt: {} is a URL; download it and pass the local path (no network access here)'
-                           .format(ckpt_file_path))
+        # torchdistill downloads here; this build runs offline.  The file is looked up by its basename in
+        # $SC2_PRETRAINED_DIR; if it is not there, returning (None, None) would silently leave the model at its random
+        # initialisation, so that needs an explicit opt-in (SC2_ALLOW_RANDOM_INIT=1) and still warns.
+        root = os.environ.get('SC2_PRETRAINED_DIR')
+        local = os.path.join(root, os.path.basename(ckpt_file_path)) if root else None
+        if local and os.path.isfile(local):
+            ckpt_file_path = local
+        elif os.environ.get('SC2_ALLOW_RANDOM_INIT') == '1':
+            logger.warning('load_ckpt: {} is a URL and no local copy exists ({}): NOTHING LOADED, the model keeps its '
+                           'current (random) parameters'.format(ckpt_file_path, local or 'SC2_PRETRAINED_DIR unset'))
+            return None, None
+        else:
+            raise RuntimeError('load_ckpt: {} is a URL; there is no network here. Put the file at $SC2_PRETRAINED_DIR/{} '
+                               'or set SC2_ALLOW_RANDOM_INIT=1 to continue without it'
+                               .format(ckpt_file_path, os.path.basename(ckpt_file_path)))
     if ckpt_file_path is None or not os.path.isfile(ckpt_file_path):
         logger.warning('ckpt file path is None or does not exist: {} -- nothing loaded'.format(ckpt_file_path))
         return None, None

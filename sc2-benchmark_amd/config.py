@@ -146,9 +146,10 @@ def _sc2bench_attr(key):
             return registry[name]
     if hasattr(S, name):
         return getattr(S, name)
-    from . import transforms as tr, wrapper as wr, compression as cm
+    from . import transforms as tr, wrapper as wr, compression as cm, dense as dn
     for registry in (tr.CODEC_TRANSFORM_MODULE_DICT, tr.MISC_TRANSFORM_MODULE_DICT, wr.WRAPPER_CLASS_DICT,
-                     cm.COMPRESSION_MODEL_CLASS_DICT, cm.COMPRESSION_MODEL_FUNC_DICT):
+                     cm.COMPRESSION_MODEL_CLASS_DICT, cm.COMPRESSION_MODEL_FUNC_DICT, dn.DETECTION_MODEL_FUNC_DICT,
+                     dn.SEGMENTATION_MODEL_FUNC_DICT):
         if name in registry:
             return registry[name]
     return Placeholder(key)
@@ -245,6 +246,10 @@ def build_model(model_config, device='cpu'):
         return get_wrapped_classification_model(model_config, device)
     key = model_config['key']
     kwargs = dict(model_config.get('kwargs') or {})
+    from . import dense as dn
+    for registry in (dn.DETECTION_MODEL_FUNC_DICT, dn.SEGMENTATION_MODEL_FUNC_DICT):
+        if key in registry:
+            return registry[key](**kwargs)
     if key in S.MODEL_DICT:
         if kwargs.get('weights') is not None:   # splittable_resnet & co. forward **kwargs to the torchvision builder
             import logging

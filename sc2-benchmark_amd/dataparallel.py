@@ -155,3 +155,26 @@ def all_reduce_mean_scalars(values, device, process_group=None):
         dist.all_reduce(t, group=process_group)
         t /= dist.get_world_size(process_group)
     return t.tolist()
+
+
+def all_gather_picklable(data, process_group=None):
+    """Every rank's picklable object, in rank order (script/task/coco/eval.py:161-200, the C3 collective of SURVEY.md 2.3:
+    variable-size pickled buffers, sizes exchanged first, payloads padded to the longest).  `torch.distributed`'s object
+    collective does exactly that on the backend's device (RCCL: the current HIP device; gloo: host)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return [data]
+    out = [None] * dist.get_world_size(process_group)
+    dist.all_gather_object(out, data, group=process_group)
+    return out
+
+
+def merge_coco_eval(img_ids, eval_imgs, process_group=None):
+    """Per-rank (image ids, evalImgs array [K, A, I_rank]) -> the merged, id-sorted, de-duplicated pair every rank
+    needs before COCOeval.accumulate (script/task/coco/eval.py:203-223)."""
+    import numpy as np
+    all_ids = all_gather_picklable(list(img_ids), process_group)
+    all_eval = all_gather_picklable(eval_imgs, process_group)
+    merged_ids = np.array([i for part in all_ids for i in part])
+    merged_eval = np.concatenate(list(all_eval), 2)
+    merged_ids, idx = np.unique(merged_ids, return_index=True)
+    return merged_ids, merged_eval[..., idx]

@@ -1,0 +1,123 @@
+"""-m gpu: the detection / segmentation callers driving the HIP bottleneck (BASELINE configs 4 and 5): the
+feature-extraction body (FrozenBatchNorm2d backbone + FPN; dilated backbone + DeepLabv3 head) in f32 and in bf16 (HIP
+ResNet stacks), before and after update(), against the oracle bottleneck composed with the same torch tail modules."""
+import copy
+from collections import OrderedDict
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_features(R, model_body, ref_bn, x, keys, updated):
+    """The oracle's bottleneck (decode(encode(x)) once updated), then CPU f32 copies of the body's tail modules."""
+    with torch.no_grad():
+        h = ref_bn.decode(**ref_bn.encode(x)) if updated else ref_bn(x)
+        out = OrderedDict()
+        for name, module in model_body.named_children():
+            if name != 'bottleneck_layer':
+                h = copy.deepcopy(module).cpu().float()(h)
+            if name in keys:
+                out[keys[name]] = h
+    return out
+
+
+def _build(S, R, dev, **resnet_kwargs):
+    torch.manual_seed(7)
+    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
+    backbone = S.splittable_resnet(cfg, skips_avgpool=True, skips_fc=True, **resnet_kwargs)
+    R.perturb_quantiles(backbone.bottleneck_layer.entropy_bottleneck)
+    with torch.no_grad():
+        backbone.bottleneck_layer.encoder[4].weight.mul_(30.0)
+        for m in backbone.modules():
+            if isinstance(m, (torch.nn.BatchNorm2d, S.resnet.FrozenBatchNorm2d)):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    ref_bn = R.FPBasedResNetBottleneck()
+    ref_bn.load_state_dict({k: v.clone() for k, v in backbone.bottleneck_layer.state_dict().items()}, strict=False)
+    ref_bn.eval()
+    return backbone, ref_bn
+
+
+def _close(got, ref, tol):
+    got, ref = got.float().cpu(), ref.float()
+    assert got.shape == ref.shape
+    r = ((got - ref).norm() / (ref.norm() + 1e-12)).item()
+    assert r < tol, 'rel L2 {}'.format(r)
+
+
+def test_backbone_with_fpn_frozen_bn(S, R, dev):
+    from sc2bench_amd import dense
+    backbone, ref_bn = _build(S, R, dev, norm_layer='FrozenBatchNorm2d')
+    keys = {'bottleneck_layer': '1', 'layer2': '2', 'layer3': '3', 'layer4': '4'}
+    bf = dense.backbone_with_fpn(backbone, return_layer_dict=keys, in_channels_list=[256, 512, 1024, 2048], out_channels=256,
+                                 analyzable_layer_key='bottleneck_layer',
+                                 analysis_config={'analyzes_after_compress': True,
+                                                  'analyzer_configs': [{'key': 'FileSizeAnalyzer', 'kwargs': {'unit': 'KB'}}]})
+    assert isinstance(bf.body.layer2[0].bn1, S.resnet.FrozenBatchNorm2d)
+    bf.eval().to(dev)
+    x = torch.rand(1, 3, 320, 416)                  # a (small) variable-size detection input: H, W multiples of 32
+    with torch.no_grad():
+        feats = bf.body(x.to(dev))
+        ref = _oracle_features(R, bf.body, ref_bn, x, keys, updated=False)
+        assert [tuple(v.shape) for v in feats.values()] == [(1, 256, 80, 104), (1, 512, 40, 52), (1, 1024, 20, 26), (1, 2048, 10, 13)]
+        for k in ref:
+            _close(feats[k], ref[k], 2e-2)
+        pyramid = bf(x.to(dev))
+        assert list(pyramid.keys()) == ['1', '2', '3', '4', 'pool'] and pyramid['pool'].shape == (1, 256, 5, 7)
+        # updated: encode -> size -> decode inside the body; bf16: the undilated stacks on the HIP head
+        bf.update()
+        ref_bn.update(force=True)
+        bf.activate_analysis()
+        feats_u = bf.body(x.to(dev))
+        ref_u = _oracle_features(R, bf.body, ref_bn, x, keys, updated=True)
+        for k in ref_u:
+            _close(feats_u[k], ref_u[k], 0.12)     # symbols may flip where bf16 moves a latent across a rounding boundary
+        assert len(bf.body.analyzers[0].file_size_list) == 1 and bf.body.analyzers[0].file_size_list[0] > 0
+        bf.body.set_compute_dtype('bf16')
+        feats_b = bf.body(x.to(dev))
+        assert feats_b['4'].dtype == torch.bfloat16 and set(bf.body._hip_layers) == {'layer2', 'layer3', 'layer4'}
+        for k in feats_u:
+            _close(feats_b[k], feats_u[k], 3e-2)
+        pyr_b = bf(x.to(dev))
+        _close(pyr_b['1'], bf.fpn(OrderedDict((k, v.float()) for k, v in feats_b.items()))['1'].cpu(), 1e-3)
+
+
+def test_deeplabv3_dilated_backbone(S, R, dev):
+    from sc2bench_amd import dense
+    backbone, ref_bn = _build(S, R, dev, replace_stride_with_dilation=[False, True, True])
+    keys = {'layer3': 'aux', 'layer4': 'out'}
+    body = S.FeatureExtractionBackbone(backbone, keys, [{'key': 'FileSizeAnalyzer', 'kwargs': {'unit': 'KB'}}], True,
+                                       analyzable_layer_key='bottleneck_layer')
+    model = dense.create_deeplabv3(body, num_input_channels=2048, uses_aux=True, num_aux_channels=1024, num_classes=21)
+    assert body.layer3[1].conv2.dilation == (2, 2) and body.layer4[1].conv2.dilation == (4, 4)
+    model.eval().to(dev)
+    x = torch.rand(1, 3, 257, 257)
+    with torch.no_grad():
+        feats = body(x.to(dev))
+        ref = _oracle_features(R, body, ref_bn, x, keys, updated=False)
+        assert feats['out'].shape == (1, 2048, 33, 33) and feats['aux'].shape == (1, 1024, 33, 33)
+        for k in ref:
+            _close(feats[k], ref[k], 2e-2)
+        out = model(x.to(dev))
+        cls_ref = torch.nn.functional.interpolate(copy.deepcopy(model.classifier).cpu()(ref['out']), size=(257, 257),
+                                                  mode='bilinear', align_corners=False)
+        _close(out['out'], cls_ref, 3e-2)
+        # the VOC shape of the config (513 x 513, odd width), updated, bf16: layer2 on the HIP head, dilated stacks on torch
+        model.update()
+        model.activate_analysis()
+        body.set_compute_dtype('bf16')
+        model.classifier.to(torch.bfloat16)
+        model.aux_classifier.to(torch.bfloat16)
+        x2 = torch.rand(2, 3, 513, 513)
+        out2 = model(x2.to(dev))
+        assert out2['out'].shape == (2, 21, 513, 513) and out2['aux'].shape == (2, 21, 513, 513)
+        assert torch.isfinite(out2['out'].float()).all()
+        assert set(body._hip_layers) == {'layer2'}
+        assert len(body.analyzers[0].file_size_list) == 1
+        ev = S.SegEvaluator(21)
+        ev.update(torch.randint(0, 21, (2, 513, 513), device=dev).flatten(), out2['out'].argmax(1).flatten())
+        assert int(ev.mat.sum()) == 2 * 513 * 513
