@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 23
+#define SC2_ABI_VERSION 24
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -83,7 +83,11 @@ enum sc2_conv_epilogue {
     SC2_EPI_GDN2 = 9,  /* y = ep_x * rsqrt(ep_beta[c] + acc)   (GDN, inverse=False) */
     SC2_EPI_IGDN2 = 10 /* y = ep_x * sqrt(ep_beta[c] + acc)    (GDN, inverse=True)  */
 };
-enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHWC = 2 };
+enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHWC = 2,
+                    /* int32 NCHW symbols round_half_even(acc - ep_beta[c]) (ep_beta = the entropy bottleneck's medians,
+                     * epilogue NONE): the last encoder conv followed by EntropyModel.quantize(.., 'symbols') in one
+                     * launch (layer.py:482-483 + :506), bit-identical to sc2_conv2d_fwd(F32_NCHW) + sc2_eb_symbols */
+                    SC2_OUT_I32_NCHW_SYM = 3 };
 /* Order of the K axis of the packed weights (and of the kernel's walk over the input):
  *   TAP_MAJOR  k = (kh*KW + kw)*Cin + ci                       (default)
  *   SLAB_MAJOR k = ((ci/32)*KH*KW + kh*KW + kw)*32 + ci%32     (Cin % 32 == 0): the taps of one 32-channel slab are

@@ -262,8 +262,12 @@ class SplittableResNet(UpdatableBackbone):
         """encoder + quantisation: -> (symbols int32 [N, C*h*w], (h, w))."""
         if self.pre_transform is not None:
             x = self.pre_transform(x)
-        latent = self.bottleneck_layer.analysis(x)
-        return self.bottleneck_layer.entropy_bottleneck.symbols_device(latent), tuple(latent.shape[-2:])
+        bl = self.bottleneck_layer
+        if type(bl).__name__ == 'FPBasedResNetBottleneck':      # last conv + quantisation in one launch
+            sym = bl.analysis(x, symbols_for=bl.entropy_bottleneck)
+            return sym.view(sym.shape[0], -1), tuple(sym.shape[-2:])
+        latent = bl.analysis(x)
+        return bl.entropy_bottleneck.symbols_device(latent), tuple(latent.shape[-2:])
 
     def stage_coder(self, sym, hw_shape):
         """rANS encode to byte streams, then decode them: -> (decoded symbols, nbytes [N], status [N])."""

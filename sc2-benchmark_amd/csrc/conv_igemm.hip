@@ -101,7 +101,8 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         // transposed-convolution use: the caller fixes the number of output rows/cols (rows past the symmetric
         // formula see implicit zero padding) and where each lands in a strided NHWC output
         SC2_REQUIRE(d->OH > 0 && d->OW > 0 && d->out_W > 0 && d->out_stride_h > 0 && d->out_stride_w > 0 &&
-                        d->out_off_h >= 0 && d->out_off_w >= 0 && d->out_format != SC2_OUT_F32_NCHW,
+                        d->out_off_h >= 0 && d->out_off_w >= 0 && d->out_format != SC2_OUT_F32_NCHW &&
+                        d->out_format != SC2_OUT_I32_NCHW_SYM,
                     SC2_ERR_INVALID_ARG, "conv2d: bad output scatter");
         OH = d->OH;
         OW = d->OW;
@@ -125,8 +126,11 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         SC2_REQUIRE(d->Cout == d->Cout_pad && sc2_conv_fused_gdn_supported(d), SC2_ERR_UNSUPPORTED,
                     "conv2d: fused GDN needs one tile to cover all output channels (Cout in {32,48,64,96}, or 256 on "
                     "the big-tile path: K >= 1024, >= 131072 output pixels, NHWC output); got Cout %d", d->Cout);
-    SC2_REQUIRE(d->out_format >= SC2_OUT_BF16_NHWC && d->out_format <= SC2_OUT_F32_NHWC, SC2_ERR_INVALID_ARG,
+    SC2_REQUIRE(d->out_format >= SC2_OUT_BF16_NHWC && d->out_format <= SC2_OUT_I32_NCHW_SYM, SC2_ERR_INVALID_ARG,
                 "conv2d: bad out_format");
+    if (d->out_format == SC2_OUT_I32_NCHW_SYM)
+        SC2_REQUIRE(d->epilogue == SC2_EPI_NONE && ep_beta && !scatter && sc2_conv_weight_rows(d->Cout) % 128 != 0,
+                    SC2_ERR_INVALID_ARG, "conv2d: symbol output needs no epilogue, the medians in ep_beta and Cout <= 96");
     if (d->epilogue != SC2_EPI_NONE) SC2_REQUIRE(ep_beta, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_beta");
     if (epi_needs_x(d->epilogue) || fused)
         SC2_REQUIRE(ep_x, SC2_ERR_INVALID_ARG, "conv2d: epilogue needs ep_x");

@@ -17,7 +17,7 @@ AOP_NONE, AOP_ABS, AOP_SQUARE = 0, 1, 2
 EPI_NONE, EPI_GDN, EPI_IGDN, EPI_BIAS, EPI_BIAS_RELU, EPI_BIAS_ADD_RELU, EPI_FUSED_GDN, EPI_FUSED_IGDN, \
     EPI_BIAS_LEAKY_RELU, EPI_GDN2, EPI_IGDN2 = range(11)
 FUSABLE_GDN_CHANNELS = (32, 48, 64, 96)   # conv + GDN1 in one launch: one tile must hold every output channel
-OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC = 0, 1, 2
+OUT_BF16_NHWC, OUT_F32_NCHW, OUT_F32_NHWC, OUT_I32_NCHW_SYM = 0, 1, 2, 3
 EB_NOISE, EB_DEQUANTIZE = 0, 1
 EB_PARAM_STRIDE = 64
 
@@ -427,6 +427,8 @@ def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilo
             out = torch.empty((N, OH, OW, cout), dtype=torch.bfloat16, device=x_nhwc.device)
         elif out_format == OUT_F32_NCHW:
             out = torch.empty((N, cout, OH, OW), dtype=torch.float32, device=x_nhwc.device)
+        elif out_format == OUT_I32_NCHW_SYM:
+            out = torch.empty((N, cout, OH, OW), dtype=torch.int32, device=x_nhwc.device)
         else:
             out = torch.empty((N, OH, OW, cout), dtype=torch.float32, device=x_nhwc.device)
     if ep_x is not None:

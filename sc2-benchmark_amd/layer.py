@@ -159,8 +159,10 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         return (c0.in_channels <= 4 and c0.kernel_size == (5, 5) and c0.stride == (2, 2) and c0.padding == (2, 2)
                 and c0.out_channels % 8 == 0)
 
-    def analysis(self, x):
-        """encoder(x): f32 NCHW image batch -> f32 NCHW latent (layer.py:475-483)."""
+    def analysis(self, x, symbols_for=None):
+        """encoder(x): f32 NCHW image batch -> f32 NCHW latent (layer.py:475-483).  `symbols_for` = an entropy model:
+        the last conv then writes int32 symbols round(latent - median) directly (its epilogue quantises the f32
+        accumulators; bit-identical to latent -> EntropyModel.quantize(.., 'symbols')) and the latent is never stored."""
         _require_device(x, 'FPBasedResNetBottleneck')
         c0, g1, c2, g3, c4 = self._g_a()
         x = x.float()
@@ -214,7 +216,12 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                                tag=c2._tag + '+' + g3._tag, k_order=order)
         else:
             h = g3.forward_nhwc(c2.forward_nhwc(h))
-        return c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
+        if symbols_for is not None and c4.bias is None and c4.out_channels <= 96 and c4.out_channels % 8 == 0:
+            return hip.conv2d_fwd(h, c4.packed_weight(), c4.out_channels, c4.kernel_size[0], c4.kernel_size[1], c4.stride,
+                                  c4.padding, out_format=hip.OUT_I32_NCHW_SYM, ep_beta=symbols_for._median_vector(),
+                                  tag=c4._tag, k_order=c4.k_order())
+        latent = c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
+        return latent if symbols_for is None else symbols_for.quantize(latent, 'symbols', self._get_means(latent))
 
     def synthesis_nhwc(self, y_hat_nhwc):
         """decoder on a bf16 NHWC latent (layer.py:485-493); output per ``self.output_format``."""

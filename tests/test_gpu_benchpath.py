@@ -33,6 +33,19 @@ def test_bench_workload_is_not_degenerate(bench_model, dev):
     assert sym.min().item() < -4 and sym.max().item() > 4
 
 
+def test_fused_last_conv_symbols_equal_unfused(bench_model, dev):
+    """stage_front's fused conv4 + quantisation == latent -> eb_symbols, bit for bit, at 224 and on a ragged shape."""
+    bench, model = bench_model
+    bl = model.bottleneck_layer
+    for x in (bench.synthetic_batch(64, dev, seed=9), torch.rand(3, 3, 97, 161, device=dev) * 4 - 2):
+        with torch.no_grad():
+            sym, hw = model.stage_front(x)
+            latent = bl.analysis(x)
+            want = bl.entropy_bottleneck.symbols_device(latent)
+        assert sym.dtype == torch.int32 and hw == tuple(latent.shape[-2:])
+        assert torch.equal(sym, want)
+
+
 def test_bench_path_2048_streams(bench_model, dev):
     bench, model = bench_model
     bs, groups = 256, 8
