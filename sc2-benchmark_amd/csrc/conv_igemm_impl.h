@@ -352,7 +352,11 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                                                     const unsigned char *x_img = nullptr, int rs_override = 0) {
     constexpr int BN = C::BN, MT = C::MT, NT = C::NT;
     float *stage = reinterpret_cast<float *>(smem);
-    const bool nchw = p.out == SC2_OUT_F32_NCHW || p.out == SC2_OUT_I32_NCHW_SYM;
+    // symbol output: tiles narrower than 128 channels only (the last encoder conv), decided at compile time so that the
+    // wide kernels' code is what it was (a runtime test here sent the 256-wide kernel's accumulators to scratch)
+    constexpr bool SYM_OK = C::BN < 128;
+    const bool sym = SYM_OK && p.out == SC2_OUT_I32_NCHW_SYM;
+    const bool nchw = SYM_OK ? (p.out == SC2_OUT_F32_NCHW || sym) : (p.out == SC2_OUT_F32_NCHW);
     const int RS = rs_override ? rs_override : (nchw ? BN + 1 : BN + 4);  // row stride in floats (bank spread)
     const int Cout = p.Cout;
 #pragma unroll
@@ -465,10 +469,13 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                 }
                 const int img = m / p.OHW;
                 const int pix = m - img * p.OHW;
-                if (p.out == SC2_OUT_I32_NCHW_SYM)   // quantised straight from the accumulator: round-half-even(v - median), as eb_symbols
-                    reinterpret_cast<int32_t *>(p.y)[((long long)img * Cout + n) * p.OHW + pix] = (int32_t)rintf(v - p.ep_beta[n]);
-                else
-                    reinterpret_cast<float *>(p.y)[((long long)img * Cout + n) * p.OHW + pix] = v;
+                if constexpr (SYM_OK) {
+                    if (sym) {   // quantised straight from the accumulator: round-half-even(v - median), as eb_symbols
+                        reinterpret_cast<int32_t *>(p.y)[((long long)img * Cout + n) * p.OHW + pix] = (int32_t)rintf(v - p.ep_beta[n]);
+                        continue;
+                    }
+                }
+                reinterpret_cast<float *>(p.y)[((long long)img * Cout + n) * p.OHW + pix] = v;
             }
         }
     }

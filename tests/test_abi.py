@@ -83,3 +83,23 @@ def test_raw_claim_atomics_are_read_behind_their_wait():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_asm_atomic.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count('ok ') >= 14 and 'BAD' not in r.stdout, r.stdout
+
+
+def test_hot_path_kernels_use_no_scratch():
+    """Read from the built library's code objects (tools/kernel_resources.py): no kernel of the default path may spill
+    to scratch.  (A shared-header edit once demoted the 256-wide decoder kernels' accumulators to 528 B / lane of
+    scratch: +20 % on dec.conv2 with every parity test green.)  Known exceptions: the opt-in experiment kernels."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('kernel_resources', os.path.join(root, 'tools', 'kernel_resources.py'))
+    kr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kr)
+    ks = kr.kernels(os.path.join(root, 'sc2-benchmark_amd', 'libsc2amd.so'))
+    assert len(ks) > 60
+    opt_in = ('conv_igemm4_kernel',                   # SC2_CONV_BIG4 experiment (4-wave register tile)
+              'ELi128ELi3ELb0ELi64EEEEEvNS_8ConvArgsE')   # SC2_CONV_HALF experiment (128-row tile, 128-register cap)
+    bad = [(k['name'], k['scratch']) for k in ks if k['scratch'] and not any(o in k['name'] for o in opt_in)]
+    assert not bad, 'kernels with scratch: {}'.format(bad)
+    big = [k for k in ks if 'conv_igemm8_kernel' in k['name'] and 'ELi256ELi4ELb0ELi64' in k['name']]
+    assert big and all(k['vgpr'] <= 256 for k in big)          # two waves per SIMD (the two-group schedule)
