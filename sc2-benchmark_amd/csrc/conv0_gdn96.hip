@@ -52,7 +52,8 @@ __device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f3
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
-template <bool INVERSE>
+// SEG = false: one 112-pixel segment per row (the 224-pixel-wide geometry), the unit's output is one contiguous block
+template <bool INVERSE, bool SEG>
 __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *rows = smem;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
         const bool live = unit < p.n_units;
         const int im = live ? unit / p.units_per_img : 0;
         const int u_in = live ? unit - im * p.units_per_img : 0;
-        const int rp = u_in / p.n_seg, seg = u_in - rp * p.n_seg;
+        const int rp = SEG ? u_in / p.n_seg : u_in, seg = SEG ? u_in - rp * p.n_seg : 0;
         const int oh0 = rp * 2;
         const uint16_t *ximg = p.x + (long long)im * p.H * p.WP * 8;
 #pragma unroll
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
     while (unit < p.n_units) {
         const int im = unit / p.units_per_img;
         const int u_in = unit - im * p.units_per_img;
-        const int rp = u_in / p.n_seg, seg = u_in - rp * p.n_seg;
+        const int rp = SEG ? u_in / p.n_seg : u_in, seg = SEG ? u_in - rp * p.n_seg : 0;
         const int oh0 = rp * 2;
         const int n_rows = p.OH - oh0 >= 2 ? 2 : 1;
         const int n_cols = p.WP - seg * OW >= OW ? OW : p.WP - seg * OW;   // valid output columns of this segment
@@ -230,20 +231,32 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
         }
         load_rows(next_unit, tq);
         {
-            // the unit's two output rows x n_cols pixels: runs of n_cols * 192 bytes at (oh0 + row, seg * OW); for the
-            // 224-pixel-wide geometry (one segment, n_cols = OW) the two runs are one contiguous 43 KB block
-            uint4 *yo = reinterpret_cast<uint4 *>(p.y + (((long long)im * p.OH + oh0) * p.WP + seg * OW) * CH);
-            const unsigned q_safe = (unsigned)tq % (unsigned)(12 * n_cols);   // a chunk of row 0 that is always valid
+            if constexpr (!SEG) {
+                uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * CH);   // contiguous 2 rows
+                const int n_chunks = n_rows * OW * (CH / 8);
 #pragma unroll
-            for (int k = 0; k < Y_Q; ++k) {
-                const unsigned q0 = tq + 256 * k;
-                const unsigned px0 = (q0 * 43691u) >> 19;                          // q0 / 12 for q0 < 4096
-                const unsigned row0 = px0 >= (unsigned)OW ? 1u : 0u, col0 = px0 - row0 * OW;
-                const bool ok = (row0 < (unsigned)n_rows) & (col0 < (unsigned)n_cols) & (q0 < (unsigned)(2 * OW * 12));
-                const unsigned q = ok ? q0 : q_safe;                               // invalid: a valid chunk again (same data)
-                const unsigned px = (q * 43691u) >> 19;
-                const unsigned row = px >= (unsigned)OW ? 1u : 0u, col = px - row * OW;
-                yo[(row * p.WP + col) * 12 + (q - px * 12)] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
+                for (int k = 0; k < Y_Q; ++k) {
+                    const unsigned q0 = tq + 256 * k;
+                    const unsigned q = q0 < (unsigned)n_chunks ? q0 : (unsigned)tq;   // past the end: the thread's first chunk again
+                    const unsigned px = (q * 43691u) >> 19;                           // q / 12 for q < 4096
+                    yo[q] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
+                }
+            } else {
+                // the unit's two output rows x n_cols pixels: runs of n_cols * 192 bytes at (oh0 + row, seg * OW); for the
+                // 224-pixel-wide geometry (one segment, n_cols = OW) the two runs are one contiguous 43 KB block
+                uint4 *yo = reinterpret_cast<uint4 *>(p.y + (((long long)im * p.OH + oh0) * p.WP + seg * OW) * CH);
+                const unsigned q_safe = (unsigned)tq % (unsigned)(12 * n_cols);   // a chunk of row 0 that is always valid
+#pragma unroll
+                for (int k = 0; k < Y_Q; ++k) {
+                    const unsigned q0 = tq + 256 * k;
+                    const unsigned px0 = (q0 * 43691u) >> 19;                          // q0 / 12 for q0 < 4096
+                    const unsigned row0 = px0 >= (unsigned)OW ? 1u : 0u, col0 = px0 - row0 * OW;
+                    const bool ok = (row0 < (unsigned)n_rows) & (col0 < (unsigned)n_cols) & (q0 < (unsigned)(2 * OW * 12));
+                    const unsigned q = ok ? q0 : q_safe;                               // invalid: a valid chunk again (same data)
+                    const unsigned px = (q * 43691u) >> 19;
+                    const unsigned row = px >= (unsigned)OW ? 1u : 0u, col = px - row * OW;
+                    yo[(row * p.WP + col) * 12 + (q - px * 12)] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
+                }
             }
         }
         store_rows(tq);    // the staged rows were last read before the first barrier of this unit
@@ -293,9 +306,13 @@ extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, cons
     constexpr int lds = IN_BYTES + IMG_BYTES + GAM_BYTES + CH * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -317,8 +334,11 @@ extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, cons
     }
     const int grid = a.n_units < 2 * g_cus0 ? a.n_units : 2 * g_cus0;   // two workgroups per CU
     a.unit_ctr = g_ring0[dev] + (g_seq0.fetch_add(1) % kRing0);
-    if (inverse) hipLaunchKernelGGL(conv0_gdn96_kernel<true>, dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(conv0_gdn96_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+    const bool seg = W_pairs != OW;
+    if (inverse && seg) hipLaunchKernelGGL((conv0_gdn96_kernel<true, true>), dim3(grid), dim3(256), lds, s, a);
+    else if (inverse) hipLaunchKernelGGL((conv0_gdn96_kernel<true, false>), dim3(grid), dim3(256), lds, s, a);
+    else if (seg) hipLaunchKernelGGL((conv0_gdn96_kernel<false, true>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv0_gdn96_kernel<false, false>), dim3(grid), dim3(256), lds, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }

@@ -27,6 +27,8 @@ extern template int launch<Gx_96>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_64>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_48>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_32>(const ConvArgs &, hipStream_t);
+extern template int launch<Gq_128>(const ConvArgs &, hipStream_t);
+extern template int launch<Gqx_128>(const ConvArgs &, hipStream_t);
 extern template int launch8<B_gdn512>(const ConvArgs &, hipStream_t);
 extern template int launch8<B_dec2>(const ConvArgs &, hipStream_t);
 extern template int launch8<B_gdn256>(const ConvArgs &, hipStream_t);
@@ -226,6 +228,13 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
             if (mode == 128) return launch8<S2_128>(a, s);
             if (d->Cout % 256 == 0 && (M >= 256LL * 192 || mode == 256)) return launch8<S2_256>(a, s);
         }
+    }
+    if (d->a_op == SC2_AOP_SQUARE || d->epilogue == SC2_EPI_GDN2 || d->epilogue == SC2_EPI_IGDN2) {
+        // squared-form GDN: its own two instantiations (Cfg::SQ)
+        SC2_REQUIRE(rows % 128 == 0 && !scatter, SC2_ERR_UNSUPPORTED,
+                    "conv2d: the squared-form GDN path needs Cout > 96 (packed rows %% 128 == 0), got %d rows", rows);
+        if (needs_x_operand && d->out_format == SC2_OUT_BF16_NHWC) return launch<Gqx_128>(a, s);
+        return launch<Gq_128>(a, s);
     }
     const bool big = big_tile_eligible(d, M, K);
     if (big && d->Cout % 256 == 0 && a.x_bytes == 0) return launch8<BG_256>(a, s);   // >= 2 GB: 64-bit addressing only

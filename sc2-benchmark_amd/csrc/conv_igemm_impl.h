@@ -37,9 +37,10 @@
 namespace sc2conv {
 
 // epilogues that read an activation operand x through ep_x (GDN forms: y = x * f(beta + acc); residual add)
+template <bool SQ = true>
 __host__ __device__ __forceinline__ constexpr bool epi_needs_x(int epi) {
-    return epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU || epi == SC2_EPI_GDN2 ||
-           epi == SC2_EPI_IGDN2;
+    return epi == SC2_EPI_GDN || epi == SC2_EPI_IGDN || epi == SC2_EPI_BIAS_ADD_RELU ||
+           (SQ && (epi == SC2_EPI_GDN2 || epi == SC2_EPI_IGDN2));
 }
 
 // eight bf16 values squared (f32 product, rounded to nearest even by the pack): the A operand of the squared-form GDN
@@ -82,8 +83,12 @@ struct ConvArgs {
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_,
-          int PH_, int PW_, int STAGES_ = 2, bool EPX_ = false>
+          int PH_, int PW_, int STAGES_ = 2, bool EPX_ = false, bool SQ_ = false>
 struct Cfg {
+    // SQ: the squared-form GDN build (CompressAI GDN: SC2_AOP_SQUARE operand, SC2_EPI_GDN2 / _IGDN2 epilogues).  Its code
+    // exists only in the instantiations that set it: in the shared epilogues a runtime case costs every kernel two
+    // transcendental ops per element (measured +3 % on the decoder layers), so it is a compile-time property.
+    static constexpr bool SQ = SQ_;
     // EPX: prefetch the epilogue operand (GDN's x / the residual) before the K loop (+32 VGPRs); instantiated only
     // for the launches whose epilogue reads one
     static constexpr bool EPX = EPX_;
@@ -260,7 +265,7 @@ __device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned
     constexpr int MT = C::MT, NT = C::NT;
     constexpr int CPR = EpiGeom<C, NTHREADS>::CPR, QPT = EpiGeom<C, NTHREADS>::QPT, Q = EpiGeom<C, NTHREADS>::Q;
     const int Cout = p.Cout;
-    const bool needs_x = epi_needs_x(epi);
+    const bool needs_x = epi_needs_x<C::SQ>(epi);
     if (needs_x && !x_in_image) {
 #pragma unroll
         for (int r = 0; r < QPT; ++r) {
@@ -312,8 +317,8 @@ __device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned
                     float r;
                     if (epi == SC2_EPI_GDN) r = xv[t] * (1.0f / norm);
                     else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
-                    else if (epi == SC2_EPI_GDN2) r = xv[t] * rsqrtf(norm);
-                    else if (epi == SC2_EPI_IGDN2) r = xv[t] * sqrtf(norm);
+                    else if (C::SQ && epi == SC2_EPI_GDN2) r = xv[t] * rsqrtf(norm);
+                    else if (C::SQ && epi == SC2_EPI_IGDN2) r = xv[t] * sqrtf(norm);
                     else if (epi == SC2_EPI_BIAS) r = norm;
                     else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
                     else if (epi == SC2_EPI_BIAS_LEAKY_RELU) r = norm > 0.f ? norm : 0.01f * norm;
@@ -401,7 +406,7 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                         b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
                     }
                     float xv[8];
-                    if (epi_needs_x(epi)) {
+                    if (epi_needs_x<C::SQ>(epi)) {
                         uint4 xr;
                         if (x_img) {
                             const int trow = (sr >> 4) * C::WM + i * 16 + (sr & 15);
@@ -425,8 +430,8 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                         float r;
                         if (epi == SC2_EPI_GDN) r = xv[t] * (1.0f / norm);
                         else if (epi == SC2_EPI_IGDN) r = xv[t] * norm;
-                        else if (epi == SC2_EPI_GDN2) r = xv[t] * rsqrtf(norm);
-                        else if (epi == SC2_EPI_IGDN2) r = xv[t] * sqrtf(norm);
+                        else if (C::SQ && epi == SC2_EPI_GDN2) r = xv[t] * rsqrtf(norm);
+                        else if (C::SQ && epi == SC2_EPI_IGDN2) r = xv[t] * sqrtf(norm);
                         else if (epi == SC2_EPI_BIAS) r = norm;
                         else if (epi == SC2_EPI_BIAS_RELU) r = fmaxf(norm, 0.f);
                     else if (epi == SC2_EPI_BIAS_LEAKY_RELU) r = norm > 0.f ? norm : 0.01f * norm;
@@ -449,7 +454,7 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                 if (epi != SC2_EPI_NONE) {
                     const float norm = p.ep_beta[n] + v;
                     float xv = 0.f;
-                    if (epi_needs_x(epi)) {
+                    if (epi_needs_x<C::SQ>(epi)) {
                         if (x_img) {
                             const int trow = (sr >> 4) * C::WM + i * 16 + (sr & 15);
                             xv = bf16_bits_to_f32(*reinterpret_cast<const uint16_t *>(
@@ -460,8 +465,8 @@ __device__ __forceinline__ void conv_store_tile_f32(const ConvArgs &p, unsigned 
                     }
                     if (epi == SC2_EPI_GDN) v = xv * (1.0f / norm);
                     else if (epi == SC2_EPI_IGDN) v = xv * norm;
-                    else if (epi == SC2_EPI_GDN2) v = xv * rsqrtf(norm);
-                    else if (epi == SC2_EPI_IGDN2) v = xv * sqrtf(norm);
+                    else if (C::SQ && epi == SC2_EPI_GDN2) v = xv * rsqrtf(norm);
+                    else if (C::SQ && epi == SC2_EPI_IGDN2) v = xv * sqrtf(norm);
                     else if (epi == SC2_EPI_BIAS) v = norm;
                     else if (epi == SC2_EPI_BIAS_RELU) v = fmaxf(norm, 0.f);
                     else if (epi == SC2_EPI_BIAS_LEAKY_RELU) v = norm > 0.f ? norm : 0.01f * norm;
@@ -744,7 +749,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         for (int i = 0; i < MT; ++i) {
             uint4 v = av[i];
             v.x &= amask; v.y &= amask; v.z &= amask; v.w &= amask;
-            if (p.aop == SC2_AOP_SQUARE) v = bf16x8_square(v);   // wave-uniform: only the squared-form GDN GEMMs
+            if constexpr (C::SQ) {
+                if (p.aop == SC2_AOP_SQUARE) v = bf16x8_square(v);   // wave-uniform
+            }
             af[i] = __builtin_bit_cast(bf16x8_t, v);
         }
 #pragma unroll
@@ -1029,6 +1036,7 @@ struct Cfg8 {
     // path, which is what bounds these layers) and every tap reads it at a row shift of kh W + kw, out-of-image taps
     // redirected to a zero row.  The dispatcher checks that the window of every tile fits (sc2_conv2d_fwd).
     static constexpr bool PATCH3 = PATCH3_;
+    static constexpr bool SQ = false;
     static constexpr int PATCH_ROWS = BM_ + PATCH_EXTRA_, PATCH_BYTES = PATCH_ROWS * 64;
     static constexpr int PATCH_ZERO = 2 * PATCH_BYTES;          // 64 zero bytes behind the two patch buffers
     static constexpr int PATCH_B0 = PATCH_ZERO + 64;            // weight-slab ring
@@ -1428,6 +1436,7 @@ __global__ __launch_bounds__(512, C::MIN_WAVES) void conv_igemm8_kernel(const Co
 //        for (lgkmcnt(0)) before the barrier at the top of slab t - 1.
 template <bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_, int PH_, int PW_>
 struct Cfg4 {
+    static constexpr bool SQ = false;
     static constexpr int BM = 256, BN = 256, BK = 32, KC = 4;
     static constexpr int WAVES_M = 2, WAVES_N = 2;
     static constexpr bool STATIC = STATIC_;
@@ -1762,6 +1771,9 @@ using Cx_gdn512 = Cfg<128, 128, 2, 2, true, 512, 1, 1, 1, 1, 0, 0, 3, true>;
 using Cx_gdn256 = Cfg<128, 128, 2, 2, true, 256, 1, 1, 1, 1, 0, 0, 3, true>;
 using Gx_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, true>;
 using Gx_96 = Cfg<128, 96, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
+// squared-form GDN GEMMs (1x1 on x^2, rsqrt / sqrt epilogue): bmshj2018_factorized, N = 128 / 192 (rows 128 / 256)
+using Gq_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, false, true>;
+using Gqx_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, true, true>;
 using Gx_64 = Cfg<128, 64, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
 using Gx_48 = Cfg<128, 48, 4, 1, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
 using Gx_32 = Cfg<128, 32, 4, 1, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;

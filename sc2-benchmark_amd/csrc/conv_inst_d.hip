@@ -7,4 +7,6 @@ template int launch<Gx_96>(const ConvArgs &, hipStream_t);
 template int launch<Gx_64>(const ConvArgs &, hipStream_t);
 template int launch<Gx_48>(const ConvArgs &, hipStream_t);
 template int launch<Gx_32>(const ConvArgs &, hipStream_t);
+template int launch<Gq_128>(const ConvArgs &, hipStream_t);
+template int launch<Gqx_128>(const ConvArgs &, hipStream_t);
 }  // namespace sc2conv
