@@ -1,0 +1,359 @@
+// Persistent form of the 256 x 256 big-tile kernel for the two MFMA-bound decoder layers of the FP / SHP / MSHP
+// bottlenecks (gfx950):
+//     dec.conv2 (512 -> 256, k2, p0) + inverse GDN1(256)   (sc2bench/models/layer.py:489-491)
+//     dec.conv4 (256 -> 256, k2, p1)                        (layer.py:492-493)
+//
+// The K loop is the one of conv_igemm8_kernel (conv_igemm_impl.h: 8 waves in two groups one barrier out of step, BK = 32
+// slabs in a 4-deep direct-to-LDS ring, buffer-addressed loads).  What changes is everything AROUND it.  As one workgroup
+// per tile, a CU spends per tile: ~2 us until the first slab lands, the K loop, the store epilogue (accumulators -> bf16
+// LDS image -> 128 KB of global stores) and its drain -- and with one 160 KB workgroup per CU nothing overlaps any of it
+// (measured, tools/epi_share.sh: dec.conv2 0.915 ms in all, 0.72 - 0.77 ms with the store epilogue switched off).
+// Here a workgroup walks the tiles of its XCD's share of the output and
+//   * parks the finished tile's 128 KB in REGISTERS (16 x 16 bytes per thread) once the image is complete,
+//   * computes the next tile's gather state and issues its first three slabs,
+//   * THEN issues the 16 output stores of the finished tile: they are younger than those slabs, so the counted vmcnt
+//     waits of the first K-loop iterations (+16) do not wait for store acknowledgements; by the third iteration
+//     (~1 us later) they have retired,
+// so the stores drain and the first slabs arrive while the matrix pipes already work on the next tile.
+#include "conv_igemm_impl.h"
+
+namespace sc2conv {
+
+template <class C>
+__global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, const int n_tiles) {
+    constexpr int BM = C::BM, BN = C::BN;
+    constexpr int MT = C::MT, NT = C::NT, S = C::STAGES, PHASES = C::PHASES;
+    constexpr int A_IPW = C::A_IPW, B_IPW = C::B_IPW, L = A_IPW + B_IPW;
+    constexpr int KH = C::KH, KW = C::KW, SH = C::SH, SW = C::SW, PH = C::PH, PW = C::PW, Cin = C::CIN;
+    static_assert(C::STATIC && Cin % 32 == 0 && !C::PATCH3 && BN == 256 && BM == 256 && S == 4 && KH * KW <= 32, "geometry");
+    constexpr int CPR = BN / 8, QPT = BM * CPR / 512;   // 16-byte chunks per tile row (32), per thread (16)
+    constexpr uint32_t OOB = 0x80000000u;
+    constexpr int WAIT_LOOP = (S - 2) * L, WAIT_PEND = WAIT_LOOP + QPT;
+    static_assert(WAIT_PEND < 64, "vmcnt is a 6-bit count");
+    typedef ImgXor<C> Img;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2;   // waves w and w + 4 sit on the same SIMD and work out of step
+    const int wm = wave / C::WAVES_N, wn = wave % C::WAVES_N;
+    const int H = p.H, W = p.W;
+    const int kc = (lane & 3) ^ ((lane >> 3) & 3);
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // descriptors: x starts at tap (0, 0) of pixel (0, 0); out-of-image lanes are sent out of range (zeros)
+    const long long shift = ((long long)PH * W + PW) * Cin;
+    const buf_rsrc_t rs_x = make_rsrc(p.x - shift, p.x_bytes + (uint32_t)(shift * 2));
+    const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    uint32_t b_vo[B_IPW];
+#pragma unroll
+    for (int j = 0; j < B_IPW; ++j)
+        b_vo[j] = (uint32_t)(((long long)((j * 8 + wave) * 16 + (lane >> 2)) * p.b_row_stride + kc * 8) * 2);
+    uint32_t a_rd[MT], b_rd[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_rd[i] = (uint32_t)lds_off(wm * C::WM + i * 16 + frow, fq);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b_rd[j] = (uint32_t)(C::A_BYTES + lds_off(wn * C::WN + j * 16 + frow, fq));
+    const int KT = p.KT;
+    constexpr int spt = Cin / 32;   // slabs per tap
+    const bool fused = p.epi == SC2_EPI_FUSED_GDN || p.epi == SC2_EPI_FUSED_IGDN;
+    uint16_t *const y = reinterpret_cast<uint16_t *>(p.y);
+
+    // this workgroup's tiles: XCD x owns a contiguous range of the output (halo rows and the weight panel stay in ONE
+    // L2), walked in order by the workgroups dispatched to it (round-robin: blockIdx & 7)
+    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
+    const int wgs_x = ((int)gridDim.x - xcd + 7) >> 3;
+    const int tq = n_tiles >> 3, tr = n_tiles & 7;
+    const int t_base = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int t_cnt = tq + (xcd < tr ? 1 : 0);
+
+    // the previous tile's output, parked until the next tile's first slabs are issued: SIXTEEN NAMED registers quads (as
+    // an array carried around the tile loop it stayed in scratch memory: 256 B / lane of scratch traffic whose reloads
+    // wait vmcnt(0) in the middle of the counted DMA schedule)
+    static_assert(QPT == 16, "sixteen parked chunks per thread");
+#define SC2_PEND_LIST(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+#define SC2_PEND_DECL(r) uint4 pend##r = make_uint4(0u, 0u, 0u, 0u);
+    SC2_PEND_LIST(SC2_PEND_DECL)
+    bool has_pend = false;
+    int pend_m0 = 0;
+    // (tq: an opaque copy of tid made where it is used -- the per-chunk offsets are then recomputed per tile instead of being
+    //  hoisted out of the tile loop and spilled around the K loop, whose reloads would wait vmcnt(0))
+#define SC2_PEND_STORE(r)                                                                          \
+    {                                                                                              \
+        const int q = tq + (r) * 512;                                                              \
+        const int row = q / CPR, cc = q - row * CPR;                                               \
+        const int m = pend_m0 + row;                                                               \
+        if (m < p.M) *reinterpret_cast<uint4 *>(y + (long long)m * BN + cc * 8) = pend##r;         \
+    }
+#define SC2_PEND_LOAD(r)                                                                           \
+    {                                                                                              \
+        const int q = tq + (r) * 512;                                                              \
+        const int row = q / CPR, cc = q - row * CPR;                                               \
+        pend##r = *reinterpret_cast<const uint4 *>(img + Img::off(row, cc));                       \
+    }
+
+    for (int t = wl; t < t_cnt; t += wgs_x) {
+        const int m0 = (t_base + t) * BM;
+        // ---- gather state of this tile: per-lane byte offset of its pixel, taps that fall inside the image
+        uint32_t a_vo[A_IPW], a_tapmask[A_IPW];
+#pragma unroll
+        for (int j = 0; j < A_IPW; ++j) {
+            const int m = m0 + (j * 8 + wave) * 16 + (lane >> 2);
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int img = mm / p.OHW;
+            const int rem = mm - img * p.OHW;
+            const int oh = rem / p.OW;
+            const int ow = rem - oh * p.OW;
+            a_vo[j] = (uint32_t)((((long long)img * H + oh * SH) * W + ow * SW) * Cin * 2 + kc * 16);
+            uint32_t mk = 0;
+#pragma unroll
+            for (int tp = 0; tp < KH * KW; ++tp) {
+                const int ih = oh * SH - PH + tp / KW, iw = ow * SW - PW + tp % KW;
+                mk |= (ok & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W)) ? (1u << tp) : 0u;
+            }
+            a_tapmask[j] = mk;
+        }
+        int next_a = 0;
+        auto issue_a = [&](int buf) {
+            unsigned char *Ab = smem + buf * C::STAGE_BYTES;
+            int tap, cb;   // scalar: (tap, channel block) of the slab
+            if (p.k_slab_major) { cb = next_a / (KH * KW); tap = next_a - cb * (KH * KW); }
+            else { tap = next_a / spt; cb = next_a - tap * spt; }
+            const bool tap_ok = next_a < KT;   // false for the dummy slabs past KT
+            const uint32_t soff = (uint32_t)(((tap / KW) * W + tap % KW) * Cin + cb * 32) * 2u;
+#pragma unroll
+            for (int j = 0; j < A_IPW; ++j) {
+                const uint32_t vo = (tap_ok && ((a_tapmask[j] >> tap) & 1u)) ? a_vo[j] : OOB;
+                buf_load_lds16(rs_x, (lds_ptr_t)(Ab + (j * 8 + wave) * 1024), vo, soff);
+            }
+            ++next_a;
+        };
+        auto issue_b = [&](int kt, int buf) {
+            unsigned char *Bb = smem + buf * C::STAGE_BYTES + C::A_BYTES;
+            const uint32_t soff = (uint32_t)(kt < KT ? kt : KT - 1) * (uint32_t)p.b_kt_stride * 2u;   // (slabs past KT are never read)
+#pragma unroll
+            for (int j = 0; j < B_IPW; ++j) buf_load_lds16(rs_w, (lds_ptr_t)(Bb + (j * 8 + wave) * 1024), b_vo[j], soff);
+        };
+
+#pragma unroll
+        for (int st = 0; st < S - 1; ++st) {
+            issue_a(st);
+            issue_b(st, st);
+        }
+        // the finished tile leaves now: its stores are younger than the three slabs above
+        asm volatile("" ::: "memory");
+        if (has_pend) {
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            SC2_PEND_LIST(SC2_PEND_STORE)
+        }
+        asm volatile("" ::: "memory");
+
+        // (zeroed by volatile asm: plain initialisers are hoisted above the stores, where the 64 parked registers and the
+        //  128 accumulators do not fit together)
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float z0, z1, z2, z3;
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
+                             : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
+                acc[i][j] = f32x4_t{z0, z1, z2, z3};
+            }
+
+        // slab 0 has landed (this wave's share); with stores pending, they and two slabs may still be in flight
+        if (has_pend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PEND) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_LOOP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        if (group == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
+
+        uint4 bv[NT];
+        for (int kt = 0; kt < KT; ++kt) {
+            const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
+            const int nbuf = (kt + S - 1) % S;
+            // the stores sit between slab 2 and slab 3 in issue order: the waits of iterations 0 and 1 (for slabs 1 and 2)
+            // leave them in flight, from iteration 2 on (slab 3) they are older than what is waited for
+            const bool pend_in_flight = has_pend && kt < 2;
+#pragma unroll
+            for (int ph = 0; ph < PHASES; ++ph) {
+                uint4 av[4];
+                if (ph == 0) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) bv[j] = lds_read16(sb + b_rd[j]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[i] = lds_read16(sb + a_rd[4 * ph + i]);
+                if (ph == 0) issue_a(nbuf);
+                if (ph == PHASES - 1) issue_b(kt + S - 1, nbuf);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ph == PHASES - 1) {   // slab kt + 1 has landed
+                    if (pend_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PEND) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_LOOP) : "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                bf16x8_t af[4], bfr[NT];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, av[i]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, bv[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[4 * ph + i][j] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[4 * ph + i][j], 0, 0, 0);   // D = W X^T
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (group == 0) __builtin_amdgcn_s_barrier();   // re-align the groups
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy slabs past KT have landed (in the ring, not in the image)
+        __builtin_amdgcn_s_barrier();
+
+        // ---------------------------------------------------------------- epilogue: accumulators -> bf16 image
+        unsigned char *img = smem;
+        if (fused) {
+            // conv followed by GDN1 / inverse GDN1: x -> image, norm = gamma |x| as a second GEMM (gamma fragment-major
+            // from L2 into registers, one step ahead), y = x * (beta + norm) or x / (...) in place in the image
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int r = wm * C::WM + i * 16 + frow;
+                    const int col = wn * C::WN + j * 16 + fq * 4;
+                    uint2 h;
+                    h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                    h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                    *reinterpret_cast<uint2 *>(img + Img::off(r, col >> 3) + (col & 7) * 2) = h;
+                    acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+            int ln = lane;
+            asm volatile("" : "+v"(ln));   // (addresses rebuilt per tile, not hoisted out of the tile loop and spilled)
+            const uint4 *gfrag = reinterpret_cast<const uint4 *>(p.ep_x) + (long long)(wn * NT) * (BN / 32) * 64 + ln;
+            constexpr int NS = BN / 32;
+            uint4 gbuf[2][NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) gbuf[0][j] = gfrag[(j * NS + 0) * 64];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // the x image is complete
+            const unsigned char *xrow = img + (wm * C::WM + frow) * 512;
+#pragma unroll
+            for (int ks2 = 0; ks2 < NS; ++ks2) {
+                if (ks2 + 1 < NS) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) gbuf[(ks2 + 1) & 1][j] = gfrag[(j * NS + ks2 + 1) * 64];
+                }
+                const int xc = ((4 * ks2 + fq) ^ frow) << 4;   // row & 15 == frow for every fragment row of this lane
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    uint4 v = *reinterpret_cast<const uint4 *>(xrow + i * 16 * 512 + xc);
+                    v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu;
+                    const bf16x8_t af = __builtin_bit_cast(bf16x8_t, v);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, gbuf[ks2 & 1][j]), af,
+                                                                            acc[i][j], 0, 0, 0);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // every wave is done with its x-image fragments
+            const bool inverse = p.epi == SC2_EPI_FUSED_IGDN;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float4 bj = *reinterpret_cast<const float4 *>(p.ep_beta + wn * C::WN + j * 16 + fq * 4);
+                const float b[4] = {bj.x, bj.y, bj.z, bj.w};
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = wm * C::WM + i * 16 + frow;
+                    const int col = wn * C::WN + j * 16 + fq * 4;
+                    unsigned char *slot = img + Img::off(row, col >> 3) + (col & 7) * 2;
+                    const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
+                    const float xv[4] = {__builtin_bit_cast(float, xr.x << 16), __builtin_bit_cast(float, xr.x & 0xFFFF0000u),
+                                         __builtin_bit_cast(float, xr.y << 16), __builtin_bit_cast(float, xr.y & 0xFFFF0000u)};
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float norm = b[e] + acc[i][j][e];
+                        v[e] = inverse ? xv[e] * norm : xv[e] * (1.0f / norm);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2 *>(slot) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int row = wm * C::WM + i * 16 + frow;
+                    const int col = wn * C::WN + j * 16 + fq * 4;
+                    uint2 o;
+                    o.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
+                    o.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                    *reinterpret_cast<uint2 *>(img + Img::off(row, col >> 3) + (col & 7) * 2) = o;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // the image is complete
+        // ---- image -> registers (whole 16-byte channel runs, as they will be stored)
+        {
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            SC2_PEND_LIST(SC2_PEND_LOAD)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave has read its part: the LDS is free for the next tile's ring
+        has_pend = true;
+        pend_m0 = m0;
+    }
+    if (has_pend) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        SC2_PEND_LIST(SC2_PEND_STORE)
+    }
+#undef SC2_PEND_LIST
+#undef SC2_PEND_DECL
+#undef SC2_PEND_STORE
+#undef SC2_PEND_LOAD
+}
+
+template <class C>
+int launch8p(const ConvArgs &a, hipStream_t s) {
+    ConvArgs p = a;
+    p.KT = (a.KH * a.KW * a.Cin + C::BK - 1) / C::BK;
+    p.n_ntiles = 1;
+    const int n_tiles = (a.M + C::BM - 1) / C::BM;
+    static bool attr_set = false;
+    static int n_cus = 0;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8p_kernel<C>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        n_cus = n;
+        attr_set = true;
+    }
+    const int grid = n_tiles < n_cus ? n_tiles : n_cus;   // one 160 KB workgroup per CU
+    hipLaunchKernelGGL(conv_igemm8p_kernel<C>, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, s, p, n_tiles);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+template int launch8p<B_dec2>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec4>(const ConvArgs &, hipStream_t);
+
+}  // namespace sc2conv

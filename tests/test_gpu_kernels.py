@@ -857,3 +857,58 @@ def test_gdn1_backward(S, R, dev, C, inverse):
     assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 1.5e-2      # norm, d_norm and t pass through bf16
     assert rel(d_beta, beta.grad) < 1.5e-2
     assert rel(d_gamma, gamma.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize('N', [3, 40, 131])
+def test_persistent_decoder_kernels_equal_per_tile_kernels(S, R, dev, N, monkeypatch):
+    """conv_dec_persist.hip (deferred output stores, workgroups that walk several tiles) against the one-workgroup-per-
+    tile kernel: dec.conv2 + inverse GDN1(256) and dec.conv4 are the same arithmetic in the same order -> bit-identical;
+    and against the f32 ops on the bf16-rounded operands.  N = 3: fewer tiles than CUs and a partial last tile (big tile
+    forced); 40 / 131: 1.9 / 6.2 tiles per workgroup."""
+    torch.manual_seed(N)
+    if N < 17:
+        monkeypatch.setenv('SC2_CONV_FORCE_BIG', '1')
+    h = (torch.randn(N, 56, 56, 512) * 0.5).to(torch.bfloat16).to(dev)
+    w2 = torch.randn(256, 512, 2, 2) / 2048 ** 0.5
+    gdn = R.GDN1(256, inverse=True)
+    with torch.no_grad():
+        gdn.gamma.add_(0.05 * torch.rand(256, 256) / 256 ** 0.5)
+        gdn.beta.add_(0.1 * torch.rand(256))
+    g = S.GDN1(256, inverse=True)
+    g.load_state_dict(gdn.state_dict())
+    g.to(dev)
+    c2 = S.HipConv2d(512, 256, 2, 1, 0, bias=False)
+    c4 = S.HipConv2d(256, 256, 2, 1, 1, bias=False)
+    with torch.no_grad():
+        c2.weight.copy_(w2)
+        c4.weight.copy_(torch.randn(256, 256, 2, 2) / 1024 ** 0.5)
+    c2.to(dev)
+    c4.to(dev)
+
+    def run():
+        fused = S.hip.conv_fused_gdn_supported(tuple(h.shape), 256, 2, 2, 1, 0)
+        assert fused == 2
+        beta, gamma = g.effective_fragments()
+        a = S.hip.conv2d_fwd(h, c2.packed_weight(), 256, 2, 2, 1, 0, epilogue=S.hip.EPI_FUSED_IGDN, ep_x=gamma, ep_beta=beta,
+                             k_order=c2.k_order())
+        b = c4.forward_nhwc(a)
+        plain = c2.forward_nhwc(h)
+        return a, b, plain
+
+    monkeypatch.setenv('SC2_CONV_PERSIST', '0')
+    a0, b0, p0 = run()
+    monkeypatch.setenv('SC2_CONV_PERSIST', '1')
+    a1, b1, p1 = run()
+    torch.cuda.synchronize()
+    assert a1.shape == (N, 55, 55, 256) and b1.shape == (N, 56, 56, 256)
+    assert torch.equal(a1, a0) and torch.equal(b1, b0) and torch.equal(p1, p0)
+    if N > 40:
+        return          # (the f32 reference of 131 images is minutes of CPU time; equality with the per-tile kernel stands)
+    with torch.no_grad():
+        hf = h.float().cpu().permute(0, 3, 1, 2)
+        conv = F.conv2d(hf, bf16_round(w2))
+        norm = F.conv2d(bf16_round(conv).abs(), bf16_round(gdn.gamma_reparam(gdn.gamma)).reshape(256, 256, 1, 1),
+                        gdn.beta_reparam(gdn.beta))
+        ref = conv * norm
+    assert_close_bf16(a1.permute(0, 3, 1, 2), ref, 'persistent dec.conv2 + igdn256', extra=2.0 ** -8)
+    assert_close_bf16(p1.permute(0, 3, 1, 2), conv, 'persistent dec.conv2')
