@@ -19,7 +19,20 @@
 
 namespace sc2conv {
 
-template <class C>
+// ds_read_b128 at addr + OFF (immediate): the fragment rows of a lane are 1 KB apart (16 tile rows x 64 B, same swizzle),
+// so ONE address register serves all eight pixel fragments and one the four weight fragments
+template <int OFF>
+__device__ __forceinline__ uint4 lds_read16_imm(uint32_t addr) {
+    uint4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
+// PIPE: the fragment reads of a phase are issued one phase EARLY, at the top of the previous phase's MFMA interval (second
+// register sets for the pixel and weight fragments), so that a wave's load interval holds only its two direct-to-LDS loads
+// and the wait for reads issued ~300 cycles before; the wait that retires slab kt + 1 moves from the last to the first
+// phase of slab kt so that BOTH wave groups have retired it before either reads it (the groups run one barrier apart).
+template <class C, bool PIPE>
 __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, const int n_tiles) {
     constexpr int BM = C::BM, BN = C::BN;
     constexpr int MT = C::MT, NT = C::NT, S = C::STAGES, PHASES = C::PHASES;
@@ -28,7 +41,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
     static_assert(C::STATIC && Cin % 32 == 0 && !C::PATCH3 && BN == 256 && BM == 256 && S == 4 && KH * KW <= 32, "geometry");
     constexpr int CPR = BN / 8, QPT = BM * CPR / 512;   // 16-byte chunks per tile row (32), per thread (16)
     constexpr uint32_t OOB = 0x80000000u;
-    constexpr int WAIT_LOOP = (S - 2) * L, WAIT_PEND = WAIT_LOOP + QPT;
+    constexpr int WAIT_LOOP = PIPE ? (S - 3) * L + A_IPW : (S - 2) * L, WAIT_PEND = WAIT_LOOP + QPT;
+    constexpr int WAIT_PRO = (S - 2) * L, WAIT_PRO_PEND = WAIT_PRO + QPT;
+    static_assert(!PIPE || PHASES == 2, "two phases per slab");
     static_assert(WAIT_PEND < 64, "vmcnt is a 6-bit count");
     typedef ImgXor<C> Img;
 
@@ -167,11 +182,88 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
             }
 
         // slab 0 has landed (this wave's share); with stores pending, they and two slabs may still be in flight
-        if (has_pend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PEND) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_LOOP) : "memory");
+        if (has_pend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PRO_PEND) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PRO) : "memory");
         __builtin_amdgcn_s_barrier();
         if (group == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0
 
+        if constexpr (PIPE) {
+            // fragments: two pixel sets (av0: tile rows 0-3 of a slab, phase 0; av1: rows 4-7, phase 1) and two weight sets
+            // (bvA: even slabs, bvB: odd slabs); each is read during the MFMA interval of the phase before its use
+            uint4 av0[4], av1[4], bvA[NT], bvB[NT];
+            static_assert(NT == 4, "four weight fragments per wave");
+            const uint32_t a_rd0 = a_rd[0], b_rd0 = b_rd[0];   // a_rd[i] = a_rd0 + 1024 i, b_rd[j] = b_rd0 + 1024 j
+            auto read_b = [&](uint32_t base, uint4 (&b)[NT]) {
+                b[0] = lds_read16_imm<0>(base + b_rd0);
+                b[1] = lds_read16_imm<1024>(base + b_rd0);
+                b[2] = lds_read16_imm<2048>(base + b_rd0);
+                b[3] = lds_read16_imm<3072>(base + b_rd0);
+            };
+            auto read_a_lo = [&](uint32_t base, uint4 (&a)[4]) {
+                a[0] = lds_read16_imm<0>(base + a_rd0);
+                a[1] = lds_read16_imm<1024>(base + a_rd0);
+                a[2] = lds_read16_imm<2048>(base + a_rd0);
+                a[3] = lds_read16_imm<3072>(base + a_rd0);
+            };
+            auto read_a_hi = [&](uint32_t base, uint4 (&a)[4]) {
+                a[0] = lds_read16_imm<4096>(base + a_rd0);
+                a[1] = lds_read16_imm<5120>(base + a_rd0);
+                a[2] = lds_read16_imm<6144>(base + a_rd0);
+                a[3] = lds_read16_imm<7168>(base + a_rd0);
+            };
+            read_b(lds_base, bvA);
+            read_a_lo(lds_base, av0);
+            auto mfma16 = [&](int half, const uint4 (&a)[4], const uint4 (&b)[NT]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[4 * half + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8_t, b[j]), __builtin_bit_cast(bf16x8_t, a[i]), acc[4 * half + i][j], 0, 0, 0);
+            };
+            auto slab = [&](int kt, const uint4 (&bc)[NT], uint4 (&bn)[NT]) {
+                const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
+                const uint32_t sb1 = lds_base + (uint32_t)(((kt + 1) % S) * C::STAGE_BYTES);
+                const int nbuf = (kt + S - 1) % S;
+                // ---- phase 0
+                issue_a(nbuf);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // av0, bc
+                // slab kt + 1 has landed (this wave's share); the stores of the previous tile sit between slab 2 and slab 3
+                if (has_pend && kt < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PEND) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_LOOP) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                read_a_hi(sb, av1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(0, av0, bc);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- phase 1
+                issue_b(kt + S - 1, nbuf);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // av1
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                read_b(sb1, bn);   // slab kt + 1: retired by both groups a phase ago
+                read_a_lo(sb1, av0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma16(1, av1, bc);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (int kt = 0; kt < KT; kt += 2) {   // (KT is even: Cin % 64 == 0 with four taps)
+                slab(kt, bvA, bvB);
+                slab(kt + 1, bvB, bvA);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments read ahead for the slab past the end
+        } else {
         uint4 bv[NT];
         for (int kt = 0; kt < KT; ++kt) {
             const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
@@ -215,6 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         if (group == 0) __builtin_amdgcn_s_barrier();   // re-align the groups
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the dummy slabs past KT have landed (in the ring, not in the image)
@@ -330,16 +423,20 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
 #undef SC2_PEND_LOAD
 }
 
-template <class C>
+template <class C, bool PIPE>
 int launch8p(const ConvArgs &a, hipStream_t s) {
     ConvArgs p = a;
     p.KT = (a.KH * a.KW * a.Cin + C::BK - 1) / C::BK;
+    if (PIPE && (p.KT & 1)) {
+        sc2_set_error("conv2d: the pipelined persistent kernel needs an even number of k-slabs");
+        return SC2_ERR_UNSUPPORTED;
+    }
     p.n_ntiles = 1;
     const int n_tiles = (a.M + C::BM - 1) / C::BM;
     static bool attr_set = false;
     static int n_cus = 0;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8p_kernel<C>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8p_kernel<C, PIPE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
@@ -348,12 +445,14 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
         attr_set = true;
     }
     const int grid = n_tiles < n_cus ? n_tiles : n_cus;   // one 160 KB workgroup per CU
-    hipLaunchKernelGGL(conv_igemm8p_kernel<C>, dim3((unsigned)grid), dim3(512), C::LDS_BYTES, s, p, n_tiles);
+    hipLaunchKernelGGL((conv_igemm8p_kernel<C, PIPE>), dim3((unsigned)grid), dim3(512), C::LDS_BYTES, s, p, n_tiles);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
 
-template int launch8p<B_dec2>(const ConvArgs &, hipStream_t);
-template int launch8p<B_dec4>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec2, false>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec4, false>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec2, true>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec4, true>(const ConvArgs &, hipStream_t);
 
 }  // namespace sc2conv
