@@ -32,8 +32,11 @@ __device__ __forceinline__ uint4 lds_read16_imm(uint32_t addr) {
 // register sets for the pixel and weight fragments), so that a wave's load interval holds only its two direct-to-LDS loads
 // and the wait for reads issued ~300 cycles before; the wait that retires slab kt + 1 moves from the last to the first
 // phase of slab kt so that BOTH wave groups have retired it before either reads it (the groups run one barrier apart).
-template <class C, bool PIPE>
+// MODE 2: ONE phase per slab -- 32 MFMAs between two barriers instead of 16 (eight pixel fragments + four weight fragments
+// read and both direct-to-LDS halves issued in the one load interval): half the barriers per MFMA.
+template <class C, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, const int n_tiles) {
+    constexpr bool PIPE = MODE == 1, ONE = MODE == 2;
     constexpr int BM = C::BM, BN = C::BN;
     constexpr int MT = C::MT, NT = C::NT, S = C::STAGES, PHASES = C::PHASES;
     constexpr int A_IPW = C::A_IPW, B_IPW = C::B_IPW, L = A_IPW + B_IPW;
@@ -263,6 +266,39 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
                 slab(kt + 1, bvB, bvA);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments read ahead for the slab past the end
+        } else if constexpr (ONE) {
+            const uint32_t a_rd0 = a_rd[0], b_rd0 = b_rd[0];
+            for (int kt = 0; kt < KT; ++kt) {
+                const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
+                const int nbuf = (kt + S - 1) % S;
+                uint4 bv[NT], av[MT];
+                static_assert(NT == 4 && MT == 8, "fragment counts");
+                bv[0] = lds_read16_imm<0>(sb + b_rd0); bv[1] = lds_read16_imm<1024>(sb + b_rd0);
+                bv[2] = lds_read16_imm<2048>(sb + b_rd0); bv[3] = lds_read16_imm<3072>(sb + b_rd0);
+                av[0] = lds_read16_imm<0>(sb + a_rd0); av[1] = lds_read16_imm<1024>(sb + a_rd0);
+                av[2] = lds_read16_imm<2048>(sb + a_rd0); av[3] = lds_read16_imm<3072>(sb + a_rd0);
+                av[4] = lds_read16_imm<4096>(sb + a_rd0); av[5] = lds_read16_imm<5120>(sb + a_rd0);
+                av[6] = lds_read16_imm<6144>(sb + a_rd0); av[7] = lds_read16_imm<7168>(sb + a_rd0);
+                issue_a(nbuf);
+                issue_b(kt + S - 1, nbuf);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (has_pend && kt < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PEND) : "memory");   // slab kt + 1 has landed
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_LOOP) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv[j]),
+                                                                            __builtin_bit_cast(bf16x8_t, av[i]), acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
         uint4 bv[NT];
         for (int kt = 0; kt < KT; ++kt) {
@@ -423,8 +459,9 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
 #undef SC2_PEND_LOAD
 }
 
-template <class C, bool PIPE>
+template <class C, int MODE>
 int launch8p(const ConvArgs &a, hipStream_t s) {
+    constexpr bool PIPE = MODE == 1;
     ConvArgs p = a;
     p.KT = (a.KH * a.KW * a.Cin + C::BK - 1) / C::BK;
     if (PIPE && (p.KT & 1)) {
@@ -436,7 +473,7 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
     static bool attr_set = false;
     static int n_cus = 0;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8p_kernel<C, PIPE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8p_kernel<C, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
@@ -445,14 +482,16 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
         attr_set = true;
     }
     const int grid = n_tiles < n_cus ? n_tiles : n_cus;   // one 160 KB workgroup per CU
-    hipLaunchKernelGGL((conv_igemm8p_kernel<C, PIPE>), dim3((unsigned)grid), dim3(512), C::LDS_BYTES, s, p, n_tiles);
+    hipLaunchKernelGGL((conv_igemm8p_kernel<C, MODE>), dim3((unsigned)grid), dim3(512), C::LDS_BYTES, s, p, n_tiles);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
 
-template int launch8p<B_dec2, false>(const ConvArgs &, hipStream_t);
-template int launch8p<B_dec4, false>(const ConvArgs &, hipStream_t);
-template int launch8p<B_dec2, true>(const ConvArgs &, hipStream_t);
-template int launch8p<B_dec4, true>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec2, 0>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec4, 0>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec2, 1>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec4, 1>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec2, 2>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec4, 2>(const ConvArgs &, hipStream_t);
 
 }  // namespace sc2conv

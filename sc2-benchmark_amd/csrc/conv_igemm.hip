@@ -46,11 +46,13 @@ extern template int launch8<P2_dec4>(const ConvArgs &, hipStream_t);
 extern template int launch4<R_dec2>(const ConvArgs &, hipStream_t);
 extern template int launch4<R_dec4>(const ConvArgs &, hipStream_t);
 extern template int launch4<RG_256>(const ConvArgs &, hipStream_t);
-template <class C, bool PIPE> int launch8p(const ConvArgs &, hipStream_t);   // conv_dec_persist.hip
-extern template int launch8p<B_dec2, false>(const ConvArgs &, hipStream_t);
-extern template int launch8p<B_dec4, false>(const ConvArgs &, hipStream_t);
-extern template int launch8p<B_dec2, true>(const ConvArgs &, hipStream_t);
-extern template int launch8p<B_dec4, true>(const ConvArgs &, hipStream_t);
+template <class C, int MODE> int launch8p(const ConvArgs &, hipStream_t);   // conv_dec_persist.hip
+extern template int launch8p<B_dec2, 0>(const ConvArgs &, hipStream_t);
+extern template int launch8p<B_dec4, 0>(const ConvArgs &, hipStream_t);
+extern template int launch8p<B_dec2, 1>(const ConvArgs &, hipStream_t);
+extern template int launch8p<B_dec4, 1>(const ConvArgs &, hipStream_t);
+extern template int launch8p<B_dec2, 2>(const ConvArgs &, hipStream_t);
+extern template int launch8p<B_dec4, 2>(const ConvArgs &, hipStream_t);
 }  // namespace sc2conv
 using namespace sc2conv;
 
@@ -260,13 +262,15 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         {
             // persistent form of the two decoder layers (deferred output stores, conv_dec_persist.hip); SC2_CONV_PERSIST=0/1: A/B
             const char *pe = getenv("SC2_CONV_PERSIST");
-            const int pmode = pe ? atoi(pe) : 1;   // 0: one workgroup per tile; 1: persistent; 2: persistent + fragment reads a phase early
+            const int pmode = pe ? atoi(pe) : 1;   // 0: one workgroup per tile; 1: persistent; 2: + fragment reads a phase early; 3: one phase (32 MFMAs) per slab
             const bool persist = pmode && a.x_bytes != 0 && d->out_format == SC2_OUT_BF16_NHWC && !scatter &&
                                  d->Cout == 256 && d->a_op == SC2_AOP_NONE && (d->epilogue == SC2_EPI_NONE || fused);
-            if (persist && pmode == 2 && matches<B_dec2>(a)) return launch8p<B_dec2, true>(a, s);
-            if (persist && pmode == 2 && matches<B_dec4>(a)) return launch8p<B_dec4, true>(a, s);
-            if (persist && matches<B_dec2>(a)) return launch8p<B_dec2, false>(a, s);
-            if (persist && matches<B_dec4>(a)) return launch8p<B_dec4, false>(a, s);
+            if (persist && pmode == 3 && matches<B_dec2>(a)) return launch8p<B_dec2, 2>(a, s);
+            if (persist && pmode == 3 && matches<B_dec4>(a)) return launch8p<B_dec4, 2>(a, s);
+            if (persist && pmode == 2 && matches<B_dec2>(a)) return launch8p<B_dec2, 1>(a, s);
+            if (persist && pmode == 2 && matches<B_dec4>(a)) return launch8p<B_dec4, 1>(a, s);
+            if (persist && matches<B_dec2>(a)) return launch8p<B_dec2, 0>(a, s);
+            if (persist && matches<B_dec4>(a)) return launch8p<B_dec4, 0>(a, s);
         }
         if (matches<B_gdn512>(a)) return launch8<B_gdn512>(a, s);
         if (matches<B_dec2>(a)) return launch8<B_dec2>(a, s);

@@ -897,9 +897,9 @@ def test_persistent_decoder_kernels_equal_per_tile_kernels(S, R, dev, N, monkeyp
 
     monkeypatch.setenv('SC2_CONV_PERSIST', '0')
     a0, b0, p0 = run()
-    for mode in ('2', '1'):     # 2: + fragment reads issued a phase early; 1: persistent, deferred stores
+    for mode in ('3', '2', '1'):     # 3: one phase per slab; 2: fragment reads issued a phase early; 1: persistent, deferred stores
         monkeypatch.setenv('SC2_CONV_PERSIST', mode)
-        for rep in range(3 if mode == '2' else 1):     # (a race in the read-ahead schedule would come and go)
+        for rep in range(3 if mode != '1' else 1):     # (a race in the read-ahead schedule would come and go)
             a1, b1, p1 = run()
             torch.cuda.synchronize()
             assert a1.shape == (N, 55, 55, 256) and b1.shape == (N, 56, 56, 256)
