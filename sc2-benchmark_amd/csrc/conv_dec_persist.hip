@@ -15,6 +15,20 @@
 //     waits of the first K-loop iterations (+16) do not wait for store acknowledgements; by the third iteration
 //     (~1 us later) they have retired,
 // so the stores drain and the first slabs arrive while the matrix pipes already work on the next tile.
+//
+// Measured on one MI355X, bs 256, same process (tools/ab_env.sh SC2_CONV_PERSIST "0 1 2 3"):
+//                                     dec.conv2   dec.conv2 + IGDN256   dec.conv4
+//   0  one workgroup per tile           0.92 ms        1.02 ms           0.52 ms
+//   1  persistent, deferred stores      0.79           0.90              0.45
+//   2  + fragment reads a phase early   0.75           0.85              0.43
+//   3  ONE phase per slab (default)     0.71           0.81              0.41
+// What bounds mode 3 (timing experiments with the operand loads switched off, outputs garbage): no loads at all 0.40 ms
+// (2.0 PFLOP/s: the MFMA / fragment-read / barrier structure alone), pixel operand only or weight operand only 0.52 - 0.53,
+// both 0.72: the 6 GB a launch moves L2 -> LDS (1 MB of pixels + 1 MB of weights per tile) arrive at ~19 TB/s, the
+// direct-to-LDS gather rate of the chip (MI355X_MICROARCH.md, indexed rows: 16.8 - 18.8 TB/s from L2), and an issuing
+// wave that is held back by that queue holds its barrier partner back.  Cache-policy bits on the loads change nothing.
+// Fewer bytes would need the four taps to share one staged window; with the XOR-swizzled 64-byte rows the shifted reads
+// then pay address arithmetic inside the load interval, which is the critical path (tried in round 1: 25 % slower).
 #include "conv_igemm_impl.h"
 
 namespace sc2conv {

@@ -262,7 +262,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         {
             // persistent form of the two decoder layers (deferred output stores, conv_dec_persist.hip); SC2_CONV_PERSIST=0/1: A/B
             const char *pe = getenv("SC2_CONV_PERSIST");
-            const int pmode = pe ? atoi(pe) : 1;   // 0: one workgroup per tile; 1: persistent; 2: + fragment reads a phase early; 3: one phase (32 MFMAs) per slab
+            const int pmode = pe ? atoi(pe) : 3;   // 0: one workgroup per tile; 1: persistent; 2: + fragment reads a phase early; 3: one phase (32 MFMAs) per slab
             const bool persist = pmode && a.x_bytes != 0 && d->out_format == SC2_OUT_BF16_NHWC && !scatter &&
                                  d->Cout == 256 && d->a_op == SC2_AOP_NONE && (d->epilogue == SC2_EPI_NONE || fused);
             if (persist && pmode == 3 && matches<B_dec2>(a)) return launch8p<B_dec2, 2>(a, s);
