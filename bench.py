@@ -321,6 +321,7 @@ def main():
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--inflight', type=int, default=4, help='coder HIP streams (coder launches that may be in flight)')
     ap.add_argument('--max-inflight', type=int, default=24, help='encoder stage i waits for decoder+head stage i - this')
+    ap.add_argument('--front-beside-head', type=int, default=1, help='1: encoder stage i waits for the decoder of the batch in flight (runs beside its head)')
     ap.add_argument('--ramp', type=int, default=1, help='1: the first coder groups of a run hold 1, 2, 4, ... steps')
     ap.add_argument('--coder-group', type=int, default=8, help='steps whose symbols share one range-coder launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -391,6 +392,7 @@ def main():
         group = []   # (step, symbols, (h, w), event) of the steps waiting for their coder launch
         plan = group_plan(n_steps)
         back_done = {}
+        dec_done = [None]
         launches = [0]
 
         def flush():
@@ -429,6 +431,9 @@ def main():
             issued_back = 0
             for i in range(n_steps):
                 with torch.cuda.stream(mfma_stream):
+                    if args.front_beside_head and dec_done[0] is not None:
+                        # the encoder stage runs beside the task head of the batch in flight, not beside its decoder
+                        mfma_stream.wait_event(dec_done[0])
                     if i - args.max_inflight in back_done:
                         # bound the run-ahead of the host and of the encoder stream: memory in flight, latency per batch,
                         # and the caching allocator keeps recycling cross-stream blocks instead of calling hipMalloc
@@ -453,7 +458,11 @@ def main():
                     with torch.cuda.stream(back_stream):
                         back_stream.wait_event(ev2)
                         whole.record_stream(back_stream)
-                        logits = model.stage_back(dec, hw)
+                        def mark():
+                            ev_d = torch.cuda.Event()
+                            ev_d.record(back_stream)
+                            dec_done[0] = ev_d
+                        logits = model.stage_back(dec, hw, after_decoder=mark if args.front_beside_head else None)
                         results[0] = (logits, nb, st)
                         back_done[j] = torch.cuda.Event()
                         back_done[j].record(back_stream)

@@ -277,10 +277,19 @@ class SplittableResNet(UpdatableBackbone):
         dec = eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw)
         return dec, nb, st
 
-    def stage_back(self, dec_sym, hw_shape):
-        """dequantise + decoder + task head."""
+    def stage_decoder(self, dec_sym, hw_shape):
+        """dequantise + decoder: decoded symbols -> features (the MFMA-bound half of the back stage)."""
         _, y_hat_nhwc = self.bottleneck_layer.entropy_bottleneck.dequantize_device(dec_sym, hw_shape)
-        return self.head(self.bottleneck_layer.synthesis_nhwc(y_hat_nhwc))
+        return self.bottleneck_layer.synthesis_nhwc(y_hat_nhwc)
+
+    def stage_back(self, dec_sym, hw_shape, after_decoder=None):
+        """dequantise + decoder + task head.  `after_decoder()` is called between the two (bench.py records an event
+        there: the encoder stage of a later batch is scheduled beside the head's HBM-bound kernels, not beside the
+        decoder's MFMA-bound ones)."""
+        feats = self.stage_decoder(dec_sym, hw_shape)
+        if after_decoder is not None:
+            after_decoder()
+        return self.head(feats)
 
     def update(self):
         self.bottleneck_layer.update()

@@ -49,7 +49,7 @@ __device__ __forceinline__ uint4 lds_read16_imm(uint32_t addr) {
 // MODE 2: ONE phase per slab -- 32 MFMAs between two barriers instead of 16 (eight pixel fragments + four weight fragments
 // read and both direct-to-LDS halves issued in the one load interval): half the barriers per MFMA.
 template <class C, int MODE>
-__global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, const int n_tiles) {
+__global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, const int n_tiles, const int chunk) {
     constexpr bool PIPE = MODE == 1, ONE = MODE == 2;
     constexpr int BM = C::BM, BN = C::BN;
     constexpr int MT = C::MT, NT = C::NT, S = C::STAGES, PHASES = C::PHASES;
@@ -96,11 +96,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
 
     // this workgroup's tiles: XCD x owns a contiguous range of the output (halo rows and the weight panel stay in ONE
     // L2), walked in order by the workgroups dispatched to it (round-robin: blockIdx & 7)
+    // and cut into runs of `chunk` consecutive tiles, one run per workgroup.  chunk = the whole share of a CU: fully
+    // persistent; smaller: more workgroups than CUs, which the hardware dispatcher spreads over whatever CUs are free
+    // (the serial coder's 136 KB workgroups and the encoder stage of a neighbouring batch take CUs away for milliseconds:
+    // with one static share per CU the launch then waits for the workgroups that could not start)
     const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3;
-    const int wgs_x = ((int)gridDim.x - xcd + 7) >> 3;
     const int tq = n_tiles >> 3, tr = n_tiles & 7;
     const int t_base = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int t_cnt = tq + (xcd < tr ? 1 : 0);
+    const int t_first = wl * chunk;
+    const int t_last = t_first + chunk < t_cnt ? t_first + chunk : t_cnt;
 
     // the previous tile's output, parked until the next tile's first slabs are issued: SIXTEEN NAMED registers quads (as
     // an array carried around the tile loop it stayed in scratch memory: 256 B / lane of scratch traffic whose reloads
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
         pend##r = *reinterpret_cast<const uint4 *>(img + Img::off(row, cc));                       \
     }
 
-    for (int t = wl; t < t_cnt; t += wgs_x) {
+    for (int t = t_first; t < t_last; ++t) {
         const int m0 = (t_base + t) * BM;
         // ---- gather state of this tile: per-lane byte offset of its pixel, taps that fall inside the image
         uint32_t a_vo[A_IPW], a_tapmask[A_IPW];
@@ -495,8 +500,14 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
         n_cus = n;
         attr_set = true;
     }
-    const int grid = n_tiles < n_cus ? n_tiles : n_cus;   // one 160 KB workgroup per CU
-    hipLaunchKernelGGL((conv_igemm8p_kernel<C, MODE>), dim3((unsigned)grid), dim3(512), C::LDS_BYTES, s, p, n_tiles);
+    // tiles per workgroup: SC2_CONV_CHUNK (0 / unset: the default below; large: one static share per CU)
+    const char *ce = getenv("SC2_CONV_CHUNK");
+    const int per_xcd = (n_tiles + 7) / 8, cus_x = n_cus / 8 > 0 ? n_cus / 8 : 1;
+    int chunk = ce && atoi(ce) > 0 ? atoi(ce) : 2;   // measured inside the pipelined bench (tools/chunk_ab.sh): 2 - 3 best, 1 static share per CU worst
+    const int full = (per_xcd + cus_x - 1) / cus_x;          // the share of one CU
+    if (chunk > full) chunk = full;
+    const int grid = 8 * ((per_xcd + chunk - 1) / chunk);
+    hipLaunchKernelGGL((conv_igemm8p_kernel<C, MODE>), dim3((unsigned)grid), dim3(512), C::LDS_BYTES, s, p, n_tiles, chunk);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
