@@ -321,7 +321,8 @@ def main():
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
     ap.add_argument('--inflight', type=int, default=4, help='coder HIP streams (coder launches that may be in flight)')
     ap.add_argument('--max-inflight', type=int, default=24, help='encoder stage i waits for decoder+head stage i - this')
-    ap.add_argument('--front-beside-head', type=int, default=1, help='1: encoder stage i waits for the decoder of the batch in flight (runs beside its head)')
+    ap.add_argument('--lag', type=int, default=-1, help='steps between issuing encoder stage i and decoder+head stage i - lag (-1: 0 with --split-mfma, 2 coder groups without)')
+    ap.add_argument('--front-beside-head', type=int, default=0, help='1: encoder stage i waits for the decoder of the batch in flight (runs beside its head)')
     ap.add_argument('--ramp', type=int, default=1, help='1: the first coder groups of a run hold 1, 2, 4, ... steps')
     ap.add_argument('--coder-group', type=int, default=8, help='steps whose symbols share one range-coder launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -393,6 +394,10 @@ def main():
         plan = group_plan(n_steps)
         back_done = {}
         dec_done = [None]
+        # host-order lag of the decoder+head stages.  With their own stream (default) they are issued as soon as their
+        # coder launch is and wait for it ON that stream; on a single MFMA stream a waiting stage would block the encoder
+        # stages queued behind it, so it is issued only when its coder launch has had time to finish (two groups later)
+        lag = args.lag if args.lag >= 0 else (0 if args.split_mfma else 2 * G)
         launches = [0]
 
         def flush():
@@ -450,7 +455,7 @@ def main():
                     flush()
                 # back stages of every step whose coder launch has been issued, oldest first: they wait for the
                 # coder's event on their own stream, the encoder stream runs ahead
-                while issued_back in pending:
+                while issued_back in pending and (i - issued_back >= lag or i == n_steps - 1):
                     j = issued_back
                     issued_back += 1
                     dec, nb, st, hw, ev2, whole = pending.pop(j)

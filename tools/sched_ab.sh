@@ -1,8 +1,8 @@
 #!/bin/bash
 export GPU_MAX_HW_QUEUES=8
-for r in 1 2; do for f in 0 1; do for K in 20 100; do
-  timeout 300 python bench.py --no-cpu-baseline --no-bs1 --steps $K --warmup 5 --front-beside-head $f 2>/dev/null | python -c "
+for r in 1 2; do for cfg in "1 -1" "0 -1" "0 8" "0 24"; do set -- $cfg; for K in 20 100; do
+  timeout 300 python bench.py --no-cpu-baseline --no-bs1 --steps $K --warmup 5 --split-mfma $1 --lag $2 2>/dev/null | python -c "
 import json,sys
 r=json.loads(sys.stdin.read()); k=r['kernels_ms']
-print('front_beside_head $f K=$K: %.0f img/s  %.3f ms/step  dec.conv2+igdn %.3f dec.conv4 %.3f dec0 %.3f enc %.3f/%.3f/%.3f  fwd %.3f frac %.3f lat %.0f' % (r['value'], r['ms_per_step'], k['dec.conv2+dec.igdn3'], k['dec.conv4'], k['dec.conv0+dec.igdn1'], k['enc.conv0+enc.gdn1'], k['enc.conv2+enc.gdn3'], k['enc.conv4'], r['bottleneck_forward']['ms_per_batch_sum_of_mfma_kernels'], r['bottleneck_forward']['frac_of_mfma_peak'], r['latency_ms_per_batch']['mean']))"
+print('split $1 lag $2 K=$K: %.0f img/s  %.3f ms/step  dec.conv2+igdn %.3f dec.conv4 %.3f dec0 %.3f enc %.3f/%.3f/%.3f  fwd %.3f frac %.3f lat %.0f' % (r['value'], r['ms_per_step'], k['dec.conv2+dec.igdn3'], k['dec.conv4'], k['dec.conv0+dec.igdn1'], k['enc.conv0+enc.gdn1'], k['enc.conv2+enc.gdn3'], k['enc.conv4'], r['bottleneck_forward']['ms_per_batch_sum_of_mfma_kernels'], r['bottleneck_forward']['frac_of_mfma_peak'], r['latency_ms_per_batch']['mean']))"
 done; done; done
