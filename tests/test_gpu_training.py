@@ -1,8 +1,8 @@
-"""-m gpu: training path (HIP forward kernels under autograd) against the f32 CPU oracle's autograd.
+"""-m gpu: training path (HIP forward AND backward kernels under autograd: conv data / weight gradients on the
+implicit-GEMM and wgrad kernels, GDN1 and entropy-bottleneck backward kernels) against the f32 CPU oracle's autograd.
 
-Tolerance: activations and weights pass through bf16 on the device (forward) and the interim backward runs in bf16
-on MIOpen, so parameter gradients are compared by relative L2 error per tensor (<= 6e-2) and the loss by 2e-2
-relative."""
+Tolerance: activations, weights and gradients pass through bf16 operands with f32 accumulation on the device, so
+parameter gradients are compared by relative L2 error per tensor (<= 6e-2) and the loss by 2e-2 relative."""
 import os
 import sys
 
