@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
     static_assert(!PIPE || PHASES == 2, "two phases per slab");
     static_assert(WAIT_PEND < 64, "vmcnt is a 6-bit count");
     typedef ImgXor<C> Img;
+    static_assert(Img::BYTES <= S * C::STAGE_BYTES, "the output image fits the ring");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
@@ -489,11 +490,14 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
     }
     p.n_ntiles = 1;
     const int n_tiles = (a.M + C::BM - 1) / C::BM;
+    // 128 KB: the ring, reused as the output image.  (The per-tile kernel asks for 160 KB -- its f32-output staging -- which
+    // no other workgroup fits beside; with 128 KB an encode wave of the range coder (20 KB) can share the CU.)
+    constexpr int LDS_P = C::STAGES * C::STAGE_BYTES;
     static bool attr_set = false;
     static int n_cus = 0;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8p_kernel<C, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
         int dev = 0, n = 0;
         (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -507,7 +511,7 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
     const int full = (per_xcd + cus_x - 1) / cus_x;          // the share of one CU
     if (chunk > full) chunk = full;
     const int grid = 8 * ((per_xcd + chunk - 1) / chunk);
-    hipLaunchKernelGGL((conv_igemm8p_kernel<C, MODE>), dim3((unsigned)grid), dim3(512), C::LDS_BYTES, s, p, n_tiles, chunk);
+    hipLaunchKernelGGL((conv_igemm8p_kernel<C, MODE>), dim3((unsigned)grid), dim3(512), LDS_P, s, p, n_tiles, chunk);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }

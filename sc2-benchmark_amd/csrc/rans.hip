@@ -312,10 +312,14 @@ constexpr int kWin = 32;   // stream words buffered per lane in LDS (ring)
 // {start, freq} comes from a second small LDS table.  Stream words are staged per lane in an LDS ring that is
 // topped up 16 words at a time, so the common path (8 symbols) touches no global loads and has no branches;
 // chunks that contain an escape symbol are rolled back and redone on the exact per-symbol path.
+// LutT = uint8_t when every CDF row has at most 256 symbols (the entropy bottleneck's tables: 10 - 100): the table is then
+// 64 KB instead of 128 KB and TWO decode workgroups share a CU -- a 2 048-stream launch holds 16 CUs for its ~15 ms instead of
+// 32 (a CU that hosts a decode wave cannot host a 128 KB workgroup of the MFMA kernels running beside it).
+template <typename LutT>
 __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint16_t *lut = reinterpret_cast<uint16_t *>(smem);                                     // [65536]
-    uint32_t *win = reinterpret_cast<uint32_t *>(smem + 65536 * 2);                         // [kWin][64]
+    LutT *lut = reinterpret_cast<LutT *>(smem);                                             // [65536]
+    uint32_t *win = reinterpret_cast<uint32_t *>(smem + 65536 * sizeof(LutT));              // [kWin][64]
     uint32_t *rowtab = win + kWin * 64;                                                     // start | freq << 16
     const int lane = threadIdx.x;
     const int blk = blockIdx.x;
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
         }
         for (int k = 0; k + 1 < size; ++k) {
             const uint32_t lo = (uint32_t)cdf[k], hi = (uint32_t)cdf[k + 1];
-            for (uint32_t c = lo + lane; c < hi && c < 65536u; c += 64) lut[c] = (uint16_t)k;
+            for (uint32_t c = lo + lane; c < hi && c < 65536u; c += 64) lut[c] = (LutT)k;
         }
         __syncthreads();
         const long long i_end = (row + 1) * a.index_div < a.n_sym ? (row + 1) * a.index_div : a.n_sym;
@@ -774,9 +778,15 @@ extern "C" int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const
     const int n_entries = n_cdfs * cdf_stride;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!indexes && cdf_stride <= kMaxRowLds) {
-        const size_t lds = (size_t)65536 * 2 + (size_t)kWin * 64 * 4 + (size_t)cdf_stride * 4 + 16;
-        allow_big_lds(rans_dec_lut_kernel, lds);
-        hipLaunchKernelGGL(rans_dec_lut_kernel, dim3(n_blocks), dim3(64), lds, s, a);
+        const bool small = cdf_stride <= 257;   // symbol indexes fit a byte
+        const size_t lds = (size_t)65536 * (small ? 1 : 2) + (size_t)kWin * 64 * 4 + (size_t)cdf_stride * 4 + 16;
+        if (small) {
+            allow_big_lds(rans_dec_lut_kernel<uint8_t>, lds);
+            hipLaunchKernelGGL(rans_dec_lut_kernel<uint8_t>, dim3(n_blocks), dim3(64), lds, s, a);
+        } else {
+            allow_big_lds(rans_dec_lut_kernel<uint16_t>, lds);
+            hipLaunchKernelGGL(rans_dec_lut_kernel<uint16_t>, dim3(n_blocks), dim3(64), lds, s, a);
+        }
         SC2_CHECK_LAUNCH();
         if (n_sym > 0) {
             const long long gx = (n_sym + 63) / 64;

@@ -914,3 +914,37 @@ def test_persistent_decoder_kernels_equal_per_tile_kernels(S, R, dev, N, monkeyp
         ref = conv * norm
     assert_close_bf16(a1.permute(0, 3, 1, 2), ref, 'persistent dec.conv2 + igdn256', extra=2.0 ** -8)
     assert_close_bf16(p1.permute(0, 3, 1, 2), conv, 'persistent dec.conv2')
+
+
+@pytest.mark.parametrize('n_symbols_in_row', [200, 256, 257, 700])
+def test_rans_lut_decoder_row_widths(S, dev, n_symbols_in_row):
+    """Implicit-index (entropy-bottleneck layout) decoder on both sides of the byte-sized lookup table: rows of up to 256
+    symbols take the 64 KB uint8 table, longer rows the 128 KB uint16 one; streams equal the oracle's, decode == input."""
+    rng = np.random.RandomState(n_symbols_in_row)
+    rows, sizes, offs = [], [], []
+    for r in range(3):
+        n = n_symbols_in_row if r == 1 else int(rng.randint(5, 40))
+        p = rng.rand(n).astype(np.float32) ** 2 + 1e-4
+        p /= p.sum()
+        cdf = [int(v) for v in oracle_rans.pmf_to_quantized_cdf(p)]
+        rows.append(cdf)
+        sizes.append(len(cdf))
+        offs.append(-(n // 2))
+    cdfs, d_sizes, d_offs = _tables(dev, rows, sizes, offs)
+    n_streams, div = 67, 150
+    n_sym = 3 * div
+    sym = np.zeros((n_streams, n_sym), dtype=np.int32)
+    for r in range(3):
+        n = sizes[r] - 2
+        sym[:, r * div:(r + 1) * div] = rng.randint(offs[r] - 2, offs[r] + n + 2, size=(n_streams, div))   # a few escapes
+    d_sym = torch.from_numpy(sym).to(dev)
+    buf, off, nb, st = S.hip.rans_encode_batch(d_sym, cdfs, d_sizes, d_offs, index_div=div,
+                                               out_stride=S.hip.rans_max_bytes(n_sym))
+    assert int(st.max()) == 0
+    got = _streams(buf, off, nb)
+    imp = (np.arange(n_sym) // div).astype(np.int32)
+    h = cdfs.cpu().numpy()
+    for i in (0, 1, 33, 66):
+        assert got[i] == oracle_rans.encode_with_indexes(sym[i], imp, h, sizes, offs)
+    dec, dst = S.hip.rans_decode_batch(buf, off, nb, n_sym, cdfs, d_sizes, d_offs, index_div=div)
+    assert int(dst.max()) == 0 and np.array_equal(dec.cpu().numpy(), sym)
