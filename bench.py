@@ -328,6 +328,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bs1', action='store_true', help='skip the bs-1 evaluation-mode row')
     ap.add_argument('--split-mfma', type=int, default=1, help='K > 0: decoder+head stages round-robin on K HIP streams of their own (0: one MFMA stream for everything)')
+    ap.add_argument('--head-streams', type=int, default=0, help='H > 0: the task head of step j runs on head stream j %% H (the next decoder does not wait for it)')
+    ap.add_argument('--head-halves', type=int, default=0, help='P > 1: the task head runs as P batch slices on P streams, the next decoder waits for all of them')
     ap.add_argument('--diag-skip-coder', type=int, default=0, help='DIAGNOSTIC (invalid as a result): 1 = reuse the first step\'s coder output, 2 = same but still run the coder')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
@@ -372,6 +374,7 @@ def main():
     back_streams = [torch.cuda.Stream(device=dev, priority=args.back_priority) for _ in range(args.split_mfma)] \
         if args.split_mfma else [mfma_stream]
     coder_streams = [torch.cuda.Stream(device=dev, priority=args.coder_priority) for _ in range(n_coder)]
+    head_streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.head_streams, args.head_halves))]
     with torch.no_grad():   # fold / pack every cached weight once, before the side streams use them
         model.forward_device(x[:2])
     torch.cuda.synchronize(dev)
@@ -394,6 +397,7 @@ def main():
         plan = group_plan(n_steps)
         back_done = {}
         dec_done = [None]
+        end_events = []
         # host-order lag of the decoder+head stages.  With their own stream (default) they are issued as soon as their
         # coder launch is and wait for it ON that stream; on a single MFMA stream a waiting stage would block the encoder
         # stages queued behind it, so it is issued only when its coder launch has had time to finish (two groups later)
@@ -467,13 +471,52 @@ def main():
                             ev_d = torch.cuda.Event()
                             ev_d.record(back_stream)
                             dec_done[0] = ev_d
-                        logits = model.stage_back(dec, hw, after_decoder=mark if args.front_beside_head else None)
+                        if args.head_halves > 1:
+                            # the head as P batch slices on P streams (their launch tails overlap); the decoder of the
+                            # next step waits for all of them, so decoder launches never share the CUs with a head
+                            feats = model.stage_decoder(dec, hw)
+                            ev_f = torch.cuda.Event()
+                            ev_f.record(back_stream)
+                            P = args.head_halves
+                            n_sl = (feats.shape[0] + P - 1) // P
+                            outs = []
+                            for hs_i in range(P):
+                                hs = head_streams[hs_i]
+                                with torch.cuda.stream(hs):
+                                    hs.wait_event(ev_f)
+                                    feats.record_stream(hs)
+                                    outs.append(model.head(feats[hs_i * n_sl:(hs_i + 1) * n_sl]))
+                                    ev_h = torch.cuda.Event()
+                                    ev_h.record(hs)
+                                back_stream.wait_event(ev_h)
+                            for o in outs:
+                                o.record_stream(back_stream)
+                            logits = torch.cat(outs)
+                        elif args.head_streams > 0:
+                            feats = model.stage_decoder(dec, hw)
+                            ev_f = torch.cuda.Event()
+                            ev_f.record(back_stream)
+                            hs = head_streams[j % args.head_streams]
+                            with torch.cuda.stream(hs):
+                                hs.wait_event(ev_f)
+                                feats.record_stream(hs)
+                                logits = model.head(feats)
+                                ev_h = torch.cuda.Event()
+                                ev_h.record(hs)
+                            end_events.append(ev_h)
+                            logits.record_stream(back_stream)
+                        else:
+                            logits = model.stage_back(dec, hw, after_decoder=mark if args.front_beside_head else None)
                         results[0] = (logits, nb, st)
                         back_done[j] = torch.cuda.Event()
-                        back_done[j].record(back_stream)
+                        if args.head_streams > 0 and args.head_halves <= 1:
+                            back_stream.wait_event(end_events[-args.head_streams]) if len(end_events) >= args.head_streams else None
+                            back_done[j] = end_events[-1]
+                        else:
+                            back_done[j].record(back_stream)
                         if record and j % 8 == 0:
                             e1 = torch.cuda.Event(enable_timing=True)
-                            e1.record(back_stream)
+                            e1.record(head_streams[j % args.head_streams] if (args.head_streams > 0 and args.head_halves <= 1) else back_stream)
                             [r for r in latency if r[0] == j][0][2] = e1
             assert issued_back == n_steps and not pending and not group
 
@@ -481,7 +524,7 @@ def main():
         mfma_stream.synchronize()
         for bstream in back_streams:
             bstream.synchronize()
-        for cstream in coder_streams:
+        for cstream in coder_streams + head_streams:
             cstream.synchronize()
         torch.cuda.synchronize(dev)
         if distributed:

@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 24
+#define SC2_ABI_VERSION 25
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -174,6 +174,18 @@ int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gam
 int sc2_conv1x1_kres_supported(int Cin, int Cout, int stride);
 int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
                          int stride, int relu, void *stream);
+
+/* 3x3 stride-1 pad-1 convolution + bias (+ ReLU) on 28 x 28 / 14 x 14 / 7 x 7 maps: conv2 + bn2 + ReLU of the torchvision
+ * Bottleneck blocks of layer2 / layer3 / layer4 behind the bottleneck (sc2bench/models/backbone.py:235-254 runs them) at the
+ * 224 x 224 operating point.  Tiles of 196 output pixels x 128 channels, zero-padded window planes in LDS, weights straight
+ * into registers (conv3x3_win.hip).
+ *   x : bf16 NHWC [N,H,W,Cin], H == W in {28, 14, 7}, Cin % 64 == 0;   y : bf16 NHWC [N,H,W,Cout], Cout % 128 == 0
+ *   w_frag : bf16 [Cin/32 * 9][Cout/16][64][8] (BN folded): entry (kt = slab*9 + kh*3 + kw, tile t = 2 g + j, lane = fq*16 +
+ *            frow, e) = W[32 g + 8 (frow / 4) + 4 j + frow % 4][slab*32 + fq*8 + e][kh][kw]   (the row permutation leaves
+ *            every lane with eight consecutive output channels of a pixel);   bias : f32 [Cout];   relu != 0: ReLU. */
+int sc2_conv3x3_win_supported(int H, int W, int Cin, int Cout);
+int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
+                        int relu, void *stream);
 
 /* Second encoder stage in ONE persistent launch: y = GDN1_48(Conv2d(96 -> 48, k5, s2, p2, bias=False)(x)) for
  * 112-pixel-wide inputs (replaces encoder[2] + encoder[3], sc2bench/models/layer.py:479-481; inverse != 0: inverse GDN1).

@@ -1,0 +1,298 @@
+// 3x3 stride-1 pad-1 convolution + bias (+ ReLU) for the ResNet tail's conv2 layers (gfx950): torchvision
+// Bottleneck.conv2 + bn2 + ReLU of layer2 / layer3 / layer4 in eval mode, the callers on the far side of the bottleneck
+// path (sc2bench/models/backbone.py:235-254), at the 28 / 14 / 7 pixel maps a 224 x 224 input reaches them with.
+//     y[n, oh, ow, co] = act( sum_{kh, kw, ci} x[n, oh + kh - 1, ow + kw - 1, ci] w[co, ci, kh, kw] + bias[co] ),  bf16 NHWC.
+//
+// Why a dedicated kernel.  On the window-staged tile kernel (conv_igemm_impl.h, Cfg8::PATCH3) these ten launches ran at
+// 480 - 620 TFLOP/s: 256-pixel tiles quantise 196-pixel images badly (392 tiles on 512 slots), every fragment read pays
+// ~8 vector instructions of swizzled, image-clipped address arithmetic, and every 16 MFMAs pay a barrier pair.  Here
+//   * a tile is 196 output pixels (one 14 x 14 image, seven rows of a 28 x 28 image, four 7 x 7 images = 13 MFMA row tiles)
+//     x 128 output channels: 512 or 1024 equal workgroups for bs 256, two per CU;
+//   * per 32-channel slab the tile's input window is staged ONCE, ZERO-PADDED (the halo is physically in LDS: no clipping
+//     in the loop), as four 16-byte-chunk PLANES [chunk][window row][16 B].  In that layout the fragment rows of a lane
+//     for tap (kh, kw) sit at a constant byte distance (kh (W + 2) + kw) * 16 from those of tap (0, 0): the nine taps of a
+//     slab read through ONE address register per row tile and nine immediate offsets - no vector ALU in the K loop;
+//   * wave w owns output channels [32 w, 32 w + 32) of the tile for all 13 row tiles (26 accumulator tiles).  Its weight
+//     fragments are nobody else's, so they never touch LDS: two buffer_load_dwordx4 per 26 MFMAs, straight from L2 into
+//     registers, three k-steps ahead (fragment-major packing: one operand = 1 KB contiguous);
+//   * the only shared operand is the window, so the waves meet at ONE barrier per slab = per 234 MFMAs per wave;
+//   * the weight rows are permuted at packing time so that a lane ends up with EIGHT consecutive output channels of a
+//     pixel: 13 sixteen-byte stores per lane, bias + ReLU in registers, no LDS staging.
+// The two workgroups of a CU are independent: while one wave of a SIMD reads its 13 pixel fragments the other issues MFMAs.
+#include <stdlib.h>
+
+#include "sc2_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack2(float a, float b) {   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, (int)voff, (int)soff, 0, 0);
+}
+__device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+#else   // host pass: stand-ins (see conv_igemm_impl.h)
+typedef int buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *, uint32_t) { return 0; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, uint32_t) {}
+__device__ __forceinline__ uint4 buf_load16(buf_rsrc_t, uint32_t, uint32_t) { return make_uint4(0, 0, 0, 0); }
+#endif
+
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_read16_imm(uint32_t addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// wait until at most N of this wave's LDS reads are outstanding; `v` (the destination of the read being waited for) is
+// threaded through so that its consumers cannot be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void wait_lgkm(u32x4_t &v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+
+struct WinArgs {
+    const uint16_t *__restrict__ x;      // bf16 NHWC [N, H, W, Cin]
+    const uint16_t *__restrict__ w;      // bf16 [Cin/32 * 9][Cout/16][64][8]  (sc2_conv3x3_win_fwd's packing)
+    const float *__restrict__ bias;      // f32 [Cout]
+    uint16_t *__restrict__ y;            // bf16 NHWC [N, H, W, Cout]
+    int N, Cin, Cout, relu;
+    int n_chunks;                        // Cout / 128
+    int n_mtiles;
+    unsigned x_bytes, w_bytes;
+};
+
+// W: map width = height; ROWS: output rows of one image per tile; IMGS: images per tile (ROWS == W when > 1)
+template <int W_, int ROWS_, int IMGS_>
+struct Geo {
+    static constexpr int W = W_, H = W_, ROWS = ROWS_, IMGS = IMGS_;
+    static constexpr int TILES_PER_IMG = H / ROWS;               // (IMGS == 1)
+    static constexpr int PWD = W + 2;                            // padded window width
+    static constexpr int IMGP = (ROWS + 2) * PWD;                // window rows per image
+    static constexpr int WROWS = IMGS * IMGP;
+    static constexpr int NRG = (WROWS + 63) / 64;                // 64-row direct-to-LDS pieces per plane
+    static constexpr int PLANE = NRG * 64 * 16;                  // bytes per chunk plane (a multiple of 256: bank-aligned planes)
+    static constexpr int WIN_BYTES = 4 * PLANE;
+    static constexpr int PX = IMGS * ROWS * W;                   // output pixels per tile
+    static constexpr int MT = (PX + 15) / 16;
+    static constexpr int LDS_BYTES = 2 * WIN_BYTES;
+    static_assert(H % ROWS == 0 && (IMGS == 1 || ROWS == H), "whole rows of one image, or whole images");
+    static_assert(PLANE % 256 == 0 && MT == 13, "13 row tiles, bank-aligned planes");
+    static_assert(WIN_BYTES + (2 * PWD + 2) * 16 < 65536, "tap offsets are 16-bit immediates");
+};
+
+constexpr int PF = 3;   // weight fragments are fetched this many k-steps ahead (18 k-steps per loop trip: 18 % PF == 0)
+
+template <class G, int PAR, int TAP>
+__device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t (&a_base)[G::MT], const uint4 &b0, const uint4 &b1) {
+    constexpr int MT = G::MT;
+    constexpr int OFF = PAR * G::WIN_BYTES + ((TAP / 3) * G::PWD + TAP % 3) * 16;
+    u32x4_t av[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) av[i] = lds_read16_imm<OFF>(a_base[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
+#define SC2_WIN_MMA(i)                                                                          \
+    {                                                                                           \
+        wait_lgkm<MT - 1 - (i)>(av[i]);                                                         \
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[i]);                                \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+    SC2_WIN_MMA(0) SC2_WIN_MMA(1) SC2_WIN_MMA(2) SC2_WIN_MMA(3) SC2_WIN_MMA(4) SC2_WIN_MMA(5) SC2_WIN_MMA(6)
+    SC2_WIN_MMA(7) SC2_WIN_MMA(8) SC2_WIN_MMA(9) SC2_WIN_MMA(10) SC2_WIN_MMA(11) SC2_WIN_MMA(12)
+#undef SC2_WIN_MMA
+}
+
+template <class G>
+__global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const WinArgs p) {
+    constexpr int MT = G::MT, W = G::W, H = G::H;
+    constexpr uint32_t OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int Cin = p.Cin, Cout = p.Cout;
+    const int NS = Cin >> 5;   // 32-channel slabs
+
+    // XCD x gets a contiguous range of (row tile, channel chunk) pairs, chunk fastest: the chunks of one row tile read
+    // their window through the same L2
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int chunk = bid % p.n_chunks, mtile = bid / p.n_chunks;
+    const int n0 = chunk * 128 + wave * 32;
+    // first image / first output row of the tile
+    const int img0 = G::IMGS > 1 ? mtile * G::IMGS : mtile / G::TILES_PER_IMG;
+    const int row0 = G::IMGS > 1 ? 0 : (mtile % G::TILES_PER_IMG) * G::ROWS;
+
+    const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
+    const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+
+    // window fill: wave w fills plane w (chunk w of every row); piece j = window rows [64 j, 64 j + 64)
+    uint32_t pw_vo[G::NRG];
+#pragma unroll
+    for (int j = 0; j < G::NRG; ++j) {
+        const int wr = j * 64 + lane;
+        const int il = wr / G::IMGP, rem = wr - il * G::IMGP;
+        const int ihp = rem / G::PWD, iwp = rem - ihp * G::PWD;
+        const int img = img0 + il, ih = row0 + ihp - 1, iw = iwp - 1;
+        const bool ok = (wr < G::WROWS) & (img < p.N) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+        pw_vo[j] = ok ? (uint32_t)((((img * H + ih) * W + iw) * Cin) * 2 + wave * 16) : OOB;
+    }
+    auto issue_window = [&](int cb, int par) {
+#pragma unroll
+        for (int j = 0; j < G::NRG; ++j)
+            buf_load_lds16(rs_x, (lds_ptr_t)(smem + par * G::WIN_BYTES + wave * G::PLANE + j * 1024), pw_vo[j], (uint32_t)cb * 64u);
+    };
+
+    // fragment rows of this lane at tap (0, 0)
+    uint32_t a_base[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = i * 16 + frow;
+        m = m < G::PX ? m : G::PX - 1;   // (rows past the tile: any valid address, results discarded)
+        const int il = m / (G::ROWS * W), rem = m - il * (G::ROWS * W);
+        const int ohl = rem / W, ow = rem - ohl * W;
+        a_base[i] = lds_base + (uint32_t)(fq * G::PLANE + (il * G::IMGP + ohl * G::PWD + ow) * 16);
+    }
+
+    // weights: k-step kt, 16-channel tile t -> 1 KB at ((kt * Cout/16) + t) * 1024; this wave's tiles are n0/16, n0/16 + 1
+    const uint32_t b_vo = (uint32_t)(lane * 16);
+    const uint32_t b_step = (uint32_t)(Cout >> 4) * 1024u;
+    const uint32_t KT = (uint32_t)NS * 9u;
+    const uint32_t b_so0 = (uint32_t)(n0 >> 4) * 1024u;
+    auto fetch_b = [&](uint32_t kt, uint4 &b0, uint4 &b1) {   // (past the end: the last k-step again, never used)
+        const uint32_t so = b_so0 + (kt < KT - 1u ? kt : KT - 1u) * b_step;
+        b0 = buf_load16(rs_w, b_vo, so);
+        b1 = buf_load16(rs_w, b_vo, so + 1024u);
+    };
+
+    f32x4_t acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    issue_window(0, 0);
+    uint4 bq[PF][2];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch_b((uint32_t)s, bq[s][0], bq[s][1]);
+
+#define SC2_WIN_STEP(PAR, cb, TAP, SLOT)                                              \
+    {                                                                                 \
+        const uint4 b0 = bq[SLOT][0], b1 = bq[SLOT][1];                               \
+        fetch_b((uint32_t)(cb) * 9u + (TAP + PF), bq[SLOT][0], bq[SLOT][1]);           \
+        k_step<G, PAR, TAP>(acc, a_base, b0, b1);                                     \
+    }
+#define SC2_WIN_SLAB(PAR, cb)                                                                           \
+    {                                                                                                   \
+        /* this wave's share of window cb has landed: it is older than the 2 PF weight loads in flight */ \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF) : "memory");                                    \
+        __builtin_amdgcn_s_barrier();   /* window cb complete; everybody is done with window cb - 1 */   \
+        if ((cb) + 1 < NS) issue_window((cb) + 1, 1 - PAR);                                              \
+        SC2_WIN_STEP(PAR, cb, 0, 0) SC2_WIN_STEP(PAR, cb, 1, 1) SC2_WIN_STEP(PAR, cb, 2, 2)              \
+        SC2_WIN_STEP(PAR, cb, 3, 0) SC2_WIN_STEP(PAR, cb, 4, 1) SC2_WIN_STEP(PAR, cb, 5, 2)              \
+        SC2_WIN_STEP(PAR, cb, 6, 0) SC2_WIN_STEP(PAR, cb, 7, 1) SC2_WIN_STEP(PAR, cb, 8, 2)              \
+    }
+    for (int cb = 0; cb < NS; cb += 2) {
+        SC2_WIN_SLAB(0, cb)
+        SC2_WIN_SLAB(1, cb + 1)
+    }
+#undef SC2_WIN_SLAB
+#undef SC2_WIN_STEP
+
+    // epilogue: lane (frow, fq) holds, for row tile i, output channels n0 + 8 fq + [0, 4) in acc[i][0] and + [4, 8) in acc[i][1]
+    // (the packing permutes the weight rows that way) of pixel i * 16 + frow
+    const float4 bias_lo = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq);
+    const float4 bias_hi = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq + 4);
+    const long long m_base = G::IMGS > 1 ? (long long)img0 * (H * W) : ((long long)img0 * H + row0) * W;
+    const long long M = (long long)p.N * H * W;
+    const bool relu = p.relu != 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ml = i * 16 + frow;
+        const long long m = m_base + ml;
+        float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
+                      acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        if (ml < G::PX && m < M) *reinterpret_cast<uint4 *>(p.y + m * Cout + n0 + 8 * fq) = o;
+    }
+}
+
+template <class G>
+int launch_win(WinArgs a, hipStream_t s) {
+    constexpr int HW = G::H * G::W;
+    a.n_mtiles = G::IMGS > 1 ? (a.N + G::IMGS - 1) / G::IMGS : a.N * G::TILES_PER_IMG;
+    (void)HW;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_win_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  G::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv3x3_win_kernel<G>, dim3(a.n_mtiles * a.n_chunks), dim3(256), G::LDS_BYTES, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+typedef Geo<28, 7, 1> G28;
+typedef Geo<14, 14, 1> G14;
+typedef Geo<7, 7, 4> G7;
+
+}  // namespace
+
+extern "C" int sc2_conv3x3_win_supported(int H, int W, int Cin, int Cout) {
+    if (H != W || (W != 28 && W != 14 && W != 7)) return 0;
+    return Cin >= 64 && Cin % 64 == 0 && Cout >= 128 && Cout % 128 == 0 ? 1 : 0;
+}
+
+extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin,
+                                   int Cout, int relu, void *stream) {
+    SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv3x3_win: null argument");
+    SC2_REQUIRE(N > 0, SC2_ERR_INVALID_ARG, "conv3x3_win: non-positive batch");
+    SC2_REQUIRE(sc2_conv3x3_win_supported(H, W, Cin, Cout), SC2_ERR_UNSUPPORTED,
+                "conv3x3_win: needs a 28 x 28, 14 x 14 or 7 x 7 map, Cin %% 64 == 0, Cout %% 128 == 0 (got %d x %d, %d -> %d)", H, W, Cin,
+                Cout);
+    const long long x_bytes = (long long)N * H * W * Cin * 2, w_bytes = (long long)Cin * 9 * Cout * 2;
+    SC2_REQUIRE(x_bytes < 0x7FF00000LL && w_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv3x3_win: operand of %lld bytes exceeds 2 GB",
+                x_bytes > w_bytes ? x_bytes : w_bytes);
+    WinArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_frag);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
+    a.n_chunks = Cout / 128; a.n_mtiles = 0;
+    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (W == 28) return launch_win<G28>(a, s);
+    if (W == 14) return launch_win<G14>(a, s);
+    return launch_win<G7>(a, s);
+}

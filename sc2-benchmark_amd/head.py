@@ -49,6 +49,12 @@ class _Conv(object):
             conv.in_channels, conv.out_channels, self.k[0], self.k[1], self.stride, self.pad)
         if self.stream or self.kres:
             self.w_frag = hip.pack_weight_fragments(w_folded.reshape(w_folded.shape[0], w_folded.shape[1]))
+        # 3x3 stride-1 layers on 28 / 14 / 7 pixel maps (conv2 of every block at the 224 x 224 operating point): the
+        # window-plane kernel; other map sizes stay on the implicit-GEMM tile kernel (decided per call, by the map size)
+        self.w_win = None
+        if hip.conv3x3_win_supported(14, 14, conv.in_channels, conv.out_channels, self.k[0], self.k[1], self.stride, self.pad,
+                                     conv.dilation):
+            self.w_win = hip.pack_conv3x3_win(w_folded)
         if self.dilation != (1, 1):
             raise hip.Sc2Error('dilated convolutions are not supported by the HIP head (got {})'.format(self.dilation))
 
@@ -60,6 +66,9 @@ class _Conv(object):
         if self.kres and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU):
             return hip.conv1x1_kres_fwd(x, self.w_frag, self.b, stride=self.stride[0], relu=epilogue == hip.EPI_BIAS_RELU,
                                         tag=self.tag)
+        if self.w_win is not None and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU) and \
+                hip.conv3x3_win_supported(x.shape[1], x.shape[2], x.shape[3], self.cout, self.k[0], self.k[1], self.stride, self.pad):
+            return hip.conv3x3_win_fwd(x, self.w_win, self.b, relu=epilogue == hip.EPI_BIAS_RELU, tag=self.tag)
         return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,
                               ep_x=ep_x, ep_beta=self.b, tag=self.tag, k_order=self.k_order)
 

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -75,6 +75,8 @@ def lib():
     L.sc2_conv0_gdn96_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_kres_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv3x3_win_supported.argtypes = [i32, i32, i32, i32]
+    L.sc2_conv3x3_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
@@ -554,6 +556,43 @@ def conv1x1_kres_fwd(x_nhwc, w_frag, bias, stride=1, relu=False, tag=None):
     with _timed(tag or 'conv1x1_kres'):
         _check(lib().sc2_conv1x1_kres_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(out), N, H, W, Cin, cout, stride,
                                           1 if relu else 0, _stream()), 'conv1x1_kres_fwd')
+    return out
+
+
+def conv3x3_win_supported(h, w, cin, cout, kh, kw, stride, pad, dilation=(1, 1)):
+    """True if this conv runs on the window-plane 3x3 kernel (28 / 14 / 7 pixel maps, stride 1, pad 1)."""
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    if os.environ.get('SC2_CONV_WIN', '1') == '0':      # A/B switch (tools/)
+        return False
+    return (kh, kw, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and tuple(dilation) == (1, 1) and \
+        bool(lib().sc2_conv3x3_win_supported(h, w, cin, cout))
+
+
+def pack_conv3x3_win(w):
+    """[Cout, Cin, 3, 3] -> bf16 [Cin/32 * 9][Cout/16][64][8] for sc2_conv3x3_win_fwd (layout: include/sc2_bottleneck.h)."""
+    _dev(w, 'w')
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and cout % 32 == 0 and cin % 32 == 0
+    # cout = 32 g + 8 a + 4 j + b   (frow = 4 a + b);   cin = 32 cb + 8 fq + e
+    g = w.detach().to(torch.bfloat16).reshape(cout // 32, 4, 2, 4, cin // 32, 4, 8, 9)   # g, a, j, b, cb, fq, e, tap
+    g = g.permute(4, 7, 0, 2, 5, 1, 3, 6)                                             # cb, tap, g, j, fq, a, b, e
+    return g.contiguous().reshape(cin // 32 * 9, cout // 16, 64, 8)
+
+
+def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None):
+    """y = act(conv3x3(x, stride 1, pad 1) + bias); bf16 NHWC in / out; w_frag = pack_conv3x3_win(w)."""
+    for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, Cin = x_nhwc.shape
+    cout = w_frag.shape[1] * 16
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (Cin // 32 * 9, cout // 16, 64, 8)
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
+    out = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    with _timed(tag or 'conv3x3_win'):
+        _check(lib().sc2_conv3x3_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(out), N, H, W, Cin, cout,
+                                         1 if relu else 0, _stream()), 'conv3x3_win_fwd')
     return out
 
 

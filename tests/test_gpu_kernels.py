@@ -547,6 +547,37 @@ def test_conv1x1_kres(S, dev, cin, cout, stride, N, H, W, relu):
     assert_close_bf16(out, gen, 'kres vs tile kernel', extra=2.0 ** -8)
 
 
+@pytest.mark.parametrize('cin,cout,N,HW,relu', [
+    (128, 128, 3, 28, True),      # layer2 conv2: four 7-row tiles per image
+    (256, 256, 5, 14, True),      # layer3 conv2: one image per tile, two channel chunks
+    (512, 512, 6, 7, True),       # layer4 conv2: four images per tile, ragged last tile (6 = 4 + 2)
+    (64, 128, 2, 14, False),      # two slabs only, no ReLU
+    (128, 384, 1, 7, True),       # a lone image in a four-image tile, three channel chunks
+])
+def test_conv3x3_win(S, dev, cin, cout, N, HW, relu):
+    """3x3 stride-1 pad-1 conv + bias (+ ReLU) on the window-plane kernel (conv3x3_win.hip) against the f32 op on the
+    bf16-rounded operands and against the implicit-GEMM tile kernel; the zero halo of every image border, tiles that end
+    inside the batch, the permuted weight rows."""
+    g = torch.Generator().manual_seed(cout + N + HW)
+    x = torch.randn(N, cin, HW, HW, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(bf16_round(x), bf16_round(w), padding=1) + bias.view(1, -1, 1, 1)
+    if relu:
+        ref = F.relu(ref)
+    assert S.hip.conv3x3_win_supported(HW, HW, cin, cout, 3, 3, 1, 1)
+    assert not S.hip.conv3x3_win_supported(HW, HW, cin, cout, 3, 3, 2, 1)
+    assert not S.hip.conv3x3_win_supported(16, 16, cin, cout, 3, 3, 1, 1)
+    assert not S.hip.conv3x3_win_supported(HW, HW, 96, cout, 3, 3, 1, 1)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    out = S.hip.conv3x3_win_fwd(x_nhwc, S.hip.pack_conv3x3_win(w.to(dev)), bias.to(dev), relu=relu)
+    assert out.shape == (N, HW, HW, cout)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'window-plane 3x3 conv')
+    gen = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 3, 3, 1, 1,
+                           epilogue=S.hip.EPI_BIAS_RELU if relu else S.hip.EPI_BIAS, ep_beta=bias.to(dev))
+    assert_close_bf16(out, gen, 'window-plane vs tile kernel', extra=2.0 ** -8)
+
+
 def test_persistent_encoder_kernels_many_units(S, R, dev):
     """More units than resident workgroups can take statically: every workgroup of the two persistent encoder kernels
     goes through several dynamic claims (a stale claim register once made this an endless loop).  Device-only check
