@@ -73,14 +73,15 @@ struct WinArgs {
     int n_chunks;                        // Cout / 128
     int n_mtiles;
     unsigned x_bytes, w_bytes;
+    unsigned long long *stamps;          // DEBUG (SC2_WIN_STAMPS=1): [workgroup][start, end] of the 100 MHz wall clock, or null
 };
 
 // W: map width = height; ROWS: output rows of one image per tile; IMGS: images per tile (ROWS == W when > 1)
-template <int W_, int ROWS_, int IMGS_>
+template <int W_, int ROWS_, int IMGS_, int PWD_ = W_ + 2>
 struct Geo {
     static constexpr int W = W_, H = W_, ROWS = ROWS_, IMGS = IMGS_;
     static constexpr int TILES_PER_IMG = H / ROWS;               // (IMGS == 1)
-    static constexpr int PWD = W + 2;                            // padded window width
+    static constexpr int PWD = PWD_;                             // window row pitch (>= W + 2)
     static constexpr int IMGP = (ROWS + 2) * PWD;                // window rows per image
     static constexpr int WROWS = IMGS * IMGP;
     static constexpr int NRG = (WROWS + 63) / 64;                // 64-row direct-to-LDS pieces per plane
@@ -96,18 +97,21 @@ struct Geo {
 
 constexpr int PF = 3;   // weight fragments are fetched this many k-steps ahead (18 k-steps per loop trip: 18 % PF == 0)
 
-template <class G, int PAR, int TAP>
+template <class G, int PAR, int TAP, int DBG>
 __device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t (&a_base)[G::MT], const uint4 &b0, const uint4 &b1) {
     constexpr int MT = G::MT;
     constexpr int OFF = PAR * G::WIN_BYTES + ((TAP / 3) * G::PWD + TAP % 3) * 16;
     u32x4_t av[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) av[i] = lds_read16_imm<OFF>(a_base[i]);
+    for (int i = 0; i < MT; ++i) {
+        if constexpr (DBG & 4) av[i] = u32x4_t{a_base[i], a_base[i], a_base[i], a_base[i]};   // timing experiment: no fragment reads
+        else av[i] = lds_read16_imm<OFF>(a_base[i]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
 #define SC2_WIN_MMA(i)                                                                          \
     {                                                                                           \
-        wait_lgkm<MT - 1 - (i)>(av[i]);                                                         \
+        if constexpr (!(DBG & 4)) wait_lgkm<MT - 1 - (i)>(av[i]);                               \
         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[i]);                                \
         acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
         acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
@@ -118,7 +122,8 @@ __device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t 
 #undef SC2_WIN_MMA
 }
 
-template <class G>
+// DBG (timing experiments, results garbage): 1 no window refills, 2 no weight fetches in the loop, 4 no fragment reads, 8 no barriers
+template <class G, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const WinArgs p) {
     constexpr int MT = G::MT, W = G::W, H = G::H;
     constexpr uint32_t OOB = 0x80000000u;
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const WinArgs p) {
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
 
     const int tid = threadIdx.x;
+    if (p.stamps && tid == 0) p.stamps[2 * blockIdx.x] = wall_clock64();
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const WinArgs p) {
     const int NS = Cin >> 5;   // 32-channel slabs
 
     // XCD x gets a contiguous range of (row tile, channel chunk) pairs, chunk fastest: the chunks of one row tile read
-    // their window through the same L2
+    // their window through the same L2.  (One chunk per XCD, which keeps layer4's 4.7 MB of weights within every 4 MB L2,
+    // measured the same.)
     int bid = blockIdx.x;
     {
         const int nwg = gridDim.x;
@@ -150,7 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const WinArgs p) {
     const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
     const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
 
-    // window fill: wave w fills plane w (chunk w of every row); piece j = window rows [64 j, 64 j + 64)
+    // window fill: wave w fills plane w (chunk w of every row); piece j = window rows [64 j, 64 j + 64).  The per-lane
+    // source offsets stay in registers: recomputing them per slab (~25 vector instructions per piece) cost 10 - 20 % of
+    // the kernel -- every vector instruction competes with the MFMAs for the SIMD's issue port
     uint32_t pw_vo[G::NRG];
 #pragma unroll
     for (int j = 0; j < G::NRG; ++j) {
@@ -204,15 +213,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const WinArgs p) {
 #define SC2_WIN_STEP(PAR, cb, TAP, SLOT)                                              \
     {                                                                                 \
         const uint4 b0 = bq[SLOT][0], b1 = bq[SLOT][1];                               \
-        fetch_b((uint32_t)(cb) * 9u + (TAP + PF), bq[SLOT][0], bq[SLOT][1]);           \
-        k_step<G, PAR, TAP>(acc, a_base, b0, b1);                                     \
+        if constexpr (!(DBG & 2)) fetch_b((uint32_t)(cb) * 9u + (TAP + PF), bq[SLOT][0], bq[SLOT][1]); \
+        k_step<G, PAR, TAP, DBG>(acc, a_base, b0, b1);                                \
     }
 #define SC2_WIN_SLAB(PAR, cb)                                                                           \
     {                                                                                                   \
         /* this wave's share of window cb has landed: it is older than the 2 PF weight loads in flight */ \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF) : "memory");                                    \
-        __builtin_amdgcn_s_barrier();   /* window cb complete; everybody is done with window cb - 1 */   \
-        if ((cb) + 1 < NS) issue_window((cb) + 1, 1 - PAR);                                              \
+        if constexpr (!(DBG & 8)) __builtin_amdgcn_s_barrier();   /* window cb complete; everybody is done with window cb - 1 */ \
+        if constexpr (!(DBG & 1)) { if ((cb) + 1 < NS) issue_window((cb) + 1, 1 - PAR); }                \
         SC2_WIN_STEP(PAR, cb, 0, 0) SC2_WIN_STEP(PAR, cb, 1, 1) SC2_WIN_STEP(PAR, cb, 2, 2)              \
         SC2_WIN_STEP(PAR, cb, 3, 0) SC2_WIN_STEP(PAR, cb, 4, 1) SC2_WIN_STEP(PAR, cb, 5, 2)              \
         SC2_WIN_STEP(PAR, cb, 6, 0) SC2_WIN_STEP(PAR, cb, 7, 1) SC2_WIN_STEP(PAR, cb, 8, 2)              \
@@ -244,20 +253,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const WinArgs p) {
         const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
         if (ml < G::PX && m < M) *reinterpret_cast<uint4 *>(p.y + m * Cout + n0 + 8 * fq) = o;
     }
+    if (p.stamps && tid == 0) p.stamps[2 * blockIdx.x + 1] = wall_clock64();
 }
 
-template <class G>
+template <class G, int DBG = 0>
 int launch_win(WinArgs a, hipStream_t s) {
     constexpr int HW = G::H * G::W;
     a.n_mtiles = G::IMGS > 1 ? (a.N + G::IMGS - 1) / G::IMGS : a.N * G::TILES_PER_IMG;
     (void)HW;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_win_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_win_kernel<G, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   G::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv3x3_win_kernel<G>, dim3(a.n_mtiles * a.n_chunks), dim3(256), G::LDS_BYTES, s, a);
+    const int n_wg = a.n_mtiles * a.n_chunks;
+    const char *st = getenv("SC2_WIN_STAMPS");   // DEBUG: per-workgroup start / end times of this launch, summarised on stderr
+    if (st && atoi(st)) {
+        unsigned long long *d = nullptr;
+        if (hipMalloc(reinterpret_cast<void **>(&d), (size_t)n_wg * 16) != hipSuccess) return SC2_ERR_INTERNAL;
+        a.stamps = d;
+        hipLaunchKernelGGL((conv3x3_win_kernel<G, DBG>), dim3(n_wg), dim3(256), G::LDS_BYTES, s, a);
+        (void)hipStreamSynchronize(s);
+        unsigned long long *h = static_cast<unsigned long long *>(malloc((size_t)n_wg * 16));
+        (void)hipMemcpy(h, d, (size_t)n_wg * 16, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < n_wg; ++i) { if (h[2 * i] < t0) t0 = h[2 * i]; if (h[2 * i + 1] > t1) t1 = h[2 * i + 1]; }
+        double s_sum = 0, d_sum = 0, s_max = 0, d_max = 0, d_min = 1e30;
+        for (int i = 0; i < n_wg; ++i) {
+            const double so = (h[2 * i] - t0) * 0.01, du = (h[2 * i + 1] - h[2 * i]) * 0.01;   // us
+            s_sum += so; d_sum += du; if (so > s_max) s_max = so; if (du > d_max) d_max = du; if (du < d_min) d_min = du;
+        }
+        fprintf(stderr, "conv3x3_win W=%d: %d workgroups, span %.2f us; start offset mean %.2f max %.2f us; duration min %.2f mean %.2f max %.2f us\n",
+                G::W, n_wg, (t1 - t0) * 0.01, s_sum / n_wg, s_max, d_min, d_sum / n_wg, d_max);
+        free(h);
+        (void)hipFree(d);
+        SC2_CHECK_LAUNCH();
+        return SC2_OK;
+    }
+    hipLaunchKernelGGL((conv3x3_win_kernel<G, DBG>), dim3(n_wg), dim3(256), G::LDS_BYTES, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -291,8 +325,21 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
     a.n_chunks = Cout / 128; a.n_mtiles = 0;
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (W == 28) return launch_win<G28>(a, s);
-    if (W == 14) return launch_win<G14>(a, s);
+    if (W == 14) {
+        const char *dbg = getenv("SC2_WIN_DBG");   // timing experiments on the 14 x 14 geometry (results garbage)
+        switch (dbg ? atoi(dbg) : 0) {
+            case 1: return launch_win<G14, 1>(a, s);
+            case 2: return launch_win<G14, 2>(a, s);
+            case 4: return launch_win<G14, 4>(a, s);
+            case 8: return launch_win<G14, 8>(a, s);
+            case 3: return launch_win<G14, 3>(a, s);
+            case 7: return launch_win<G14, 7>(a, s);
+            case 15: return launch_win<G14, 15>(a, s);
+            default: return launch_win<G14>(a, s);
+        }
+    }
     return launch_win<G7>(a, s);
 }

@@ -50,7 +50,8 @@ __device__ __forceinline__ uint4 lds_read16_imm(uint32_t addr) {
 // read and both direct-to-LDS halves issued in the one load interval): half the barriers per MFMA.
 template <class C, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, const int n_tiles, const int chunk) {
-    constexpr bool PIPE = MODE == 1, ONE = MODE == 2;
+    constexpr bool PIPE = MODE == 1, ONE = MODE == 2 || MODE == 3;
+    constexpr bool X32 = MODE == 3;   // TIMING EXPERIMENT (results garbage): the slab as 16 32x32x16 MFMAs on the same fragments
     constexpr int BM = C::BM, BN = C::BN;
     constexpr int MT = C::MT, NT = C::NT, S = C::STAGES, PHASES = C::PHASES;
     constexpr int A_IPW = C::A_IPW, B_IPW = C::B_IPW, L = A_IPW + B_IPW;
@@ -288,6 +289,16 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the fragments read ahead for the slab past the end
         } else if constexpr (ONE) {
             const uint32_t a_rd0 = a_rd[0], b_rd0 = b_rd[0];
+            typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+            [[maybe_unused]] f32x16_t acc32[4][2];
+            if constexpr (X32) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc32[a][b][e] = 0.f;
+            }
             for (int kt = 0; kt < KT; ++kt) {
                 const uint32_t sb = lds_base + (uint32_t)((kt % S) * C::STAGE_BYTES);
                 const int nbuf = (kt + S - 1) % S;
@@ -308,16 +319,37 @@ __global__ __launch_bounds__(512, 2) void conv_igemm8p_kernel(const ConvArgs p, 
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (X32) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                acc32[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, bv[2 * b + h]),
+                                                                                      __builtin_bit_cast(bf16x8_t, av[2 * a + h]), acc32[a][b], 0, 0, 0);
+                } else {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv[j]),
                                                                             __builtin_bit_cast(bf16x8_t, av[i]), acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (X32) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int q = 4 * ((i & 1) * 2 + (j & 1));
+                        acc[i][j] = f32x4_t{acc32[i >> 1][j >> 1][q], acc32[i >> 1][j >> 1][q + 1], acc32[i >> 1][j >> 1][q + 2],
+                                            acc32[i >> 1][j >> 1][q + 3]};
+                    }
             }
         } else {
         uint4 bv[NT];
@@ -522,5 +554,7 @@ template int launch8p<B_dec2, 1>(const ConvArgs &, hipStream_t);
 template int launch8p<B_dec4, 1>(const ConvArgs &, hipStream_t);
 template int launch8p<B_dec2, 2>(const ConvArgs &, hipStream_t);
 template int launch8p<B_dec4, 2>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec2, 3>(const ConvArgs &, hipStream_t);
+template int launch8p<B_dec4, 3>(const ConvArgs &, hipStream_t);
 
 }  // namespace sc2conv
