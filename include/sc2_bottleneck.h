@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 25
+#define SC2_ABI_VERSION 26
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -186,6 +186,18 @@ int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, v
 int sc2_conv3x3_win_supported(int H, int W, int Cin, int Cout);
 int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
                         int relu, void *stream);
+
+/* The two MFMA-bound decoder convolutions of the FP / SHP / MSHP bottlenecks on the window-plane structure, with the
+ * inverse GDN1 that follows the first one fused in (sc2bench/models/layer.py:489-493: Conv2d(512 -> 256, k2, p0) + GDN1(256,
+ * inverse) and Conv2d(256 -> 256, k2, p1)); conv2x2_win.hip.  Results bit-identical to sc2_conv2d_fwd's.
+ *   x : bf16 NHWC [N,H,W,Cin], W == 56 (pad 0) or 55 (pad 1), Cin % 64 == 0;   y : bf16 NHWC [N,H+2pad-1,W+2pad-1,256]
+ *   w_frag : bf16 [Cin/32 * 4 (+ 8 when fused)][16][64][8]: conv k-step kt = slab*4 + kh*2 + kw, then (fused) the 8 k-steps of
+ *            the effective gamma [256][256] as a 1x1 layer; entry (kt, tile t = 2 g + j, lane = fq*16 + frow, e) =
+ *            W[32 g + 8 (frow / 4) + 4 j + frow % 4][slab*32 + fq*8 + e][kh][kw]  (row permutation as sc2_conv3x3_win_fwd)
+ *   fused != 0: y = GDN1(conv(x)) with beta f32 [256]; inverse != 0: x * (beta + gamma |x|), else x / (...). */
+int sc2_conv2x2_win_supported(int H, int W, int Cin, int Cout, int pad);
+int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const float *beta, void *y, int N, int H, int W, int Cin, int pad,
+                        int fused, int inverse, void *stream);
 
 /* Second encoder stage in ONE persistent launch: y = GDN1_48(Conv2d(96 -> 48, k5, s2, p2, bias=False)(x)) for
  * 112-pixel-wide inputs (replaces encoder[2] + encoder[3], sc2bench/models/layer.py:479-481; inverse != 0: inverse GDN1).

@@ -1,0 +1,447 @@
+// The two MFMA-bound decoder layers of the FP / SHP / MSHP bottlenecks on the window-plane structure (gfx950):
+//     dec.conv2 (512 -> 256, k2, p0: 56 -> 55) + inverse GDN1(256)   (sc2bench/models/layer.py:489-491)
+//     dec.conv4 (256 -> 256, k2, p1: 55 -> 56)                        (layer.py:492-493)
+// Successor of conv_dec_persist.hip, whose K loop is bound by what it moves L2 -> LDS (a 256 x 256 tile stages 16 KB of
+// gathered pixels + 16 KB of weights per 32-deep slab; measured: 0.72 ms, 0.52 with either operand's loads switched off,
+// 0.40 with both).  Here (the structure of conv3x3_win.hip, which see):
+//   * a tile = 4 output rows x all 55 / 56 columns (14 MFMA row tiles) x all 256 channels; 8 waves, wave w owns channels
+//     [32 w, 32 w + 32) for every row tile (28 accumulator tiles);
+//   * per 32-channel slab the tile's 5-row input window is staged ONCE, zero-padded, as four 16-byte-chunk planes
+//     [chunk][window row][16 B]: the four taps read it at immediate offsets (kh PWD + kw) * 16 -- 4.5 KB per k-step through
+//     the L2 -> LDS path instead of 32 KB;
+//   * the weights never touch LDS: two buffer_load_dwordx4 per wave and k-step, four k-steps ahead, fragment-major;
+//   * one barrier per slab (112 MFMAs per wave); the window of the next slab -- or of the NEXT TILE's first slab -- is in
+//     flight during the current one, so the K loops of successive tiles join without a bubble (persistent workgroups,
+//     one per CU, XCD-contiguous tile ranges);
+//   * fused inverse GDN1: the tile's conv output goes to a bf16 image in LDS (32 channel-chunk planes of 224 rows),
+//     norm = gamma |x| is a second GEMM over the image (8 k-steps, gamma fragments through the same register ring),
+//     y = x * (beta + norm) with x read back from the lane's own image slots; 14 sixteen-byte stores per lane.
+//     Same operation order per output element as the tile kernels: results are bit-identical to theirs.
+#include <stdlib.h>
+
+#include "sc2_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack2(float a, float b) {   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, (int)voff, (int)soff, 0, 0);
+}
+__device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+// A 16-byte buffer store reads its data registers for several cycles after issue (the last quarter of the lanes last).  hipcc
+// (ROCm 7.2) placed a VALU write to those registers directly behind the store: lanes 12-15 of every 16 then stored the NEW
+// value (seen as garbage in the first dword of a few outputs, only from the second wave of a SIMD).  The nops keep the data
+// registers untouched until the store has read them.
+__device__ __forceinline__ void buf_store16(buf_rsrc_t r, uint32_t voff, uint32_t soff, u32x4_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+#else   // host pass: stand-ins (see conv_igemm_impl.h)
+typedef int buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *, uint32_t) { return 0; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, uint32_t) {}
+__device__ __forceinline__ uint4 buf_load16(buf_rsrc_t, uint32_t, uint32_t) { return make_uint4(0, 0, 0, 0); }
+__device__ __forceinline__ void buf_store16(buf_rsrc_t, uint32_t, uint32_t, u32x4_t) {}
+#endif
+
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_read16_imm(uint32_t addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write16_imm(uint32_t addr, u32x4_t v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// wait until at most N of this wave's LDS operations are outstanding; `v` (the destination of the read being waited for)
+// is threaded through so that its consumers cannot be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void wait_lgkm(u32x4_t &v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+
+struct W2Args {
+    const uint16_t *__restrict__ x;      // bf16 NHWC [N, H, W, Cin]
+    const uint16_t *__restrict__ w;      // bf16 [Cin/32 * 4 (+ 8)][16][64][8]: conv k-steps, then (fused) the 8 gamma k-steps
+    const float *__restrict__ beta;      // f32 [256] (fused) or null
+    uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, OW, 256]
+    int N, H, Cin, OH;
+    int n_tiles, tiles_per_img, tiles_per_wg;
+    int dbg;                             // DEBUG (SC2_W2_DBG): 1 = store x instead of y, 2 = store beta + norm
+    unsigned x_bytes, w_bytes, y_bytes;
+};
+
+// OW: output width (static: the tap offsets are immediates); PAD: 0 (W = OW + 1) or 1 (W = OW - 1)
+template <int OW_, int PAD_>
+struct Geo2 {
+    static constexpr int OW = OW_, PAD = PAD_, W = OW_ + 1 - 2 * PAD_;
+    static constexpr int ROWS = 4;                               // output rows per tile
+    static constexpr int PWD = W + 2 * PAD;                      // window row pitch
+    static constexpr int WROWS = (ROWS + 1) * PWD;
+    static constexpr int NRG = (WROWS + 63) / 64;                // 64-row direct-to-LDS pieces per plane
+    static constexpr int PLANE = NRG * 64 * 16;
+    static constexpr int WIN_BYTES = 4 * PLANE;
+    static constexpr int PX = ROWS * OW;
+    static constexpr int MT = (PX + 15) / 16;
+    static constexpr int IMG0 = 2 * WIN_BYTES;                   // fused: bf16 image of the conv output, 32 planes
+    static constexpr int IMG_PLANE = MT * 16 * 16;               // [224 rows][16 B]
+    static constexpr int LDS_PLAIN = 2 * WIN_BYTES, LDS_FUSED = IMG0 + 32 * IMG_PLANE;
+    static_assert(MT == 14 && NRG == 5 && PLANE % 256 == 0 && IMG_PLANE % 256 == 0, "14 row tiles, 5 pieces per plane");
+    static_assert(WIN_BYTES + (PWD + 1) * 16 < 65536 && 16 * IMG_PLANE + 13 * 256 < 65536, "16-bit immediates");
+    static_assert(LDS_FUSED <= 160 * 1024, "LDS");
+};
+
+constexpr int PF = 4;   // weight fragments are fetched this many k-steps ahead (= taps per slab: the ring slot of a k-step is its tap)
+
+// One k-step: 14 pixel fragments x 2 weight fragments.  The fragment reads run seven row tiles ahead of the MFMAs through
+// seven register quads: fragment i + 7 is read into the quad of fragment i as soon as its two MFMAs have been issued (28
+// registers instead of 56: with all fourteen in flight the kernel spilled).  lgkmcnt retires in order: the wait before row
+// tile i leaves min(13 - i, 6) younger reads outstanding.
+#define SC2_W2_MMA_SEQ                                                                             \
+    SC2_W2_MMA(0, 6) SC2_W2_MMA(1, 6) SC2_W2_MMA(2, 6) SC2_W2_MMA(3, 6) SC2_W2_MMA(4, 6) SC2_W2_MMA(5, 6) SC2_W2_MMA(6, 6) \
+    SC2_W2_MMA(7, 6) SC2_W2_MMA(8, 5) SC2_W2_MMA(9, 4) SC2_W2_MMA(10, 3) SC2_W2_MMA(11, 2) SC2_W2_MMA(12, 1) SC2_W2_MMA(13, 0)
+
+template <class G, int OFF>
+__device__ __forceinline__ void mma_step(f32x4_t (&acc)[G::MT][2], const uint32_t (&a_base)[G::MT], const uint4 &b0, const uint4 &b1) {
+    static_assert(G::MT == 14, "fourteen row tiles");
+    u32x4_t av[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) av[i] = lds_read16_imm<OFF>(a_base[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
+#define SC2_W2_MMA(i, NWAIT)                                                                    \
+    {                                                                                           \
+        wait_lgkm<NWAIT>(av[(i) % 7]);                                                          \
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[(i) % 7]);                          \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if constexpr ((i) + 7 < 14) av[(i) % 7] = lds_read16_imm<OFF>(a_base[(i) + 7 < 14 ? (i) + 7 : 0]); \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+    SC2_W2_MMA_SEQ
+#undef SC2_W2_MMA
+}
+
+// k-step of the norm GEMM: pixel fragments from the image planes [4 s, 4 s + 4) (this lane: plane 4 s + fq), |.| on the fragment
+template <class G, int OFF>
+__device__ __forceinline__ void norm_step(f32x4_t (&acc)[G::MT][2], uint32_t g_base, const uint4 &b0, const uint4 &b1) {
+    u32x4_t av[7];
+#define SC2_W2_RD(i) av[i] = lds_read16_imm<OFF + (i) * 256>(g_base);
+    SC2_W2_RD(0) SC2_W2_RD(1) SC2_W2_RD(2) SC2_W2_RD(3) SC2_W2_RD(4) SC2_W2_RD(5) SC2_W2_RD(6)
+#undef SC2_W2_RD
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
+#define SC2_W2_MMA(i, NWAIT)                                                                    \
+    {                                                                                           \
+        wait_lgkm<NWAIT>(av[(i) % 7]);                                                          \
+        const u32x4_t m = av[(i) % 7] & 0x7FFF7FFFu;                                            \
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, m);                                    \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if constexpr ((i) + 7 < 14) av[(i) % 7] = lds_read16_imm<OFF + ((i) + 7 < 14 ? (i) + 7 : 0) * 256>(g_base); \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+    SC2_W2_MMA_SEQ
+#undef SC2_W2_MMA
+}
+#undef SC2_W2_MMA_SEQ
+
+template <class G, bool FUSE, bool INVERSE>
+__global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
+    constexpr int MT = G::MT, W = G::W, OW = G::OW, PAD = G::PAD;
+    constexpr uint32_t OOB = 0x80000000u;
+    constexpr int NSTORE = MT;   // output stores per lane and tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int Cin = p.Cin, H = p.H, OH = p.OH;
+    const int NS = Cin >> 5;                 // 32-channel slabs (even)
+    const uint32_t KT = (uint32_t)NS * 4u;   // conv k-steps
+    const uint32_t KTT = KT + (FUSE ? 8u : 0u);
+
+    // this workgroup's tiles: XCD x (blockIdx & 7) owns a contiguous range of the output, cut into runs of tiles_per_wg
+    const int slot = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int t_first = slot * p.tiles_per_wg;
+    const int t_last = t_first + p.tiles_per_wg < p.n_tiles ? t_first + p.tiles_per_wg : p.n_tiles;
+    if (t_first >= t_last) return;
+
+    const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
+    const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    const buf_rsrc_t rs_y = make_rsrc(p.y, p.y_bytes);
+
+    // window fill: 20 pieces per slab (4 chunk planes x 5 row groups of 64): wave w fills plane w & 3, row groups {0, 1, 2}
+    // (waves 0-3) or {3, 4} (waves 4-7)
+    const int pq = wave & 3, pj0 = wave < 4 ? 0 : 3, pn = wave < 4 ? 3 : 2;
+    uint32_t pw_vo[3];
+    auto window_offsets = [&](int tile) {
+        const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * G::ROWS;
+        int ln = lane;   // opaque: recomputed per tile (hoisted out of the tile loop these values were spilled)
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int wr = (pj0 + j) * 64 + ln;
+            const int ihp = wr / G::PWD, iwp = wr - ihp * G::PWD;
+            const int ih = oh0 - PAD + ihp, iw = iwp - PAD;
+            const bool ok = (j < pn) & (wr < G::WROWS) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            pw_vo[j] = ok ? (uint32_t)((((img * H + ih) * W + iw) * Cin) * 2 + pq * 16) : OOB;
+        }
+    };
+    auto issue_window = [&](int cb, int par) {
+        unsigned char *dst = smem + par * G::WIN_BYTES + pq * G::PLANE + pj0 * 1024;
+        buf_load_lds16(rs_x, (lds_ptr_t)(dst), pw_vo[0], (uint32_t)cb * 64u);
+        buf_load_lds16(rs_x, (lds_ptr_t)(dst + 1024), pw_vo[1], (uint32_t)cb * 64u);
+        if (pn == 3) buf_load_lds16(rs_x, (lds_ptr_t)(dst + 2048), pw_vo[2], (uint32_t)cb * 64u);
+    };
+
+    // fragment rows of this lane at tap (0, 0)
+    uint32_t a_base[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = i * 16 + frow;
+        m = m < G::PX ? m : G::PX - 1;   // (rows past the tile: any valid address, results discarded)
+        const int ohl = m / OW, ow = m - ohl * OW;
+        a_base[i] = lds_base + (uint32_t)(fq * G::PLANE + (ohl * G::PWD + ow) * 16);
+    }
+    // fused: image slots.  Writer / read-back: plane 4 wave + fq, row 16 i + frow; norm GEMM reader: plane 4 s + fq
+    [[maybe_unused]] const uint32_t img_wr = lds_base + (uint32_t)(G::IMG0 + (4 * wave + fq) * G::IMG_PLANE + frow * 16);
+    [[maybe_unused]] const uint32_t g_base0 = lds_base + (uint32_t)(G::IMG0 + fq * G::IMG_PLANE + frow * 16);
+    [[maybe_unused]] const uint32_t g_base1 = g_base0 + 16u * G::IMG_PLANE;
+
+    // weights: k-step k, 16-channel tile t -> 1 KB at (k * 16 + t) * 1024; this wave's tiles are 2 w, 2 w + 1
+    const uint32_t b_vo = (uint32_t)(lane * 16);
+    const uint32_t b_so0 = (uint32_t)(2 * wave) * 1024u;
+    uint4 bq[PF][2];
+    auto fetch_b = [&](uint32_t k, uint4 &b0, uint4 &b1) {   // k in [0, 2 KTT): wraps to the next tile's first k-steps
+        const uint32_t kk = k >= KTT ? k - KTT : k;
+        const uint32_t so = b_so0 + kk * 16384u;
+        b0 = buf_load16(rs_w, b_vo, so);
+        b1 = buf_load16(rs_w, b_vo, so + 1024u);
+    };
+
+    f32x4_t acc[MT][2];
+
+    window_offsets(t_first);
+    issue_window(0, 0);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch_b((uint32_t)s, bq[s][0], bq[s][1]);
+
+    for (int tile = t_first; tile < t_last; ++tile) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        const bool first = tile == t_first;
+
+#define SC2_W2_STEP(PAR, cb, TAP)                                                                                   \
+    {                                                                                                               \
+        const uint4 b0 = bq[TAP][0], b1 = bq[TAP][1];                                                               \
+        fetch_b((uint32_t)(cb) * 4u + (TAP + PF), bq[TAP][0], bq[TAP][1]);                                           \
+        mma_step<G, PAR * G::WIN_BYTES + ((TAP / 2) * G::PWD + TAP % 2) * 16>(acc, a_base, b0, b1);                  \
+    }
+#define SC2_W2_SLAB(PAR, cb)                                                                                        \
+    {                                                                                                               \
+        /* this wave's share of the slab's window has landed: it is older than the 2 PF weight loads in flight and, in \
+           the first slab of a later tile, than the previous tile's output stores */                                \
+        if ((cb) == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF + NSTORE) : "memory");             \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF) : "memory");                                          \
+        __builtin_amdgcn_s_barrier();   /* window complete; everybody is done with the previous slab's window */    \
+        if ((cb) + 1 < NS) {                                                                                        \
+            issue_window((cb) + 1, 1 - PAR);                                                                        \
+        } else if (tile + 1 < t_last) {   /* the next tile's first window (buffer 0: NS is even) */                 \
+            window_offsets(tile + 1);                                                                               \
+            issue_window(0, 0);                                                                                     \
+        }                                                                                                           \
+        SC2_W2_STEP(PAR, cb, 0) SC2_W2_STEP(PAR, cb, 1) SC2_W2_STEP(PAR, cb, 2) SC2_W2_STEP(PAR, cb, 3)             \
+    }
+        for (int cb = 0; cb < NS; cb += 2) {
+            SC2_W2_SLAB(0, cb)
+            SC2_W2_SLAB(1, cb + 1)
+        }
+#undef SC2_W2_SLAB
+#undef SC2_W2_STEP
+
+        // ---- output.  Lane (frow, fq) holds, for row tile i, channels 32 w + 8 fq + [0, 4) in acc[i][0] and + [4, 8) in
+        // acc[i][1] (the packing permutes the weight rows that way) of tile pixel 16 i + frow
+        // Stores go through a buffer descriptor with invalid lanes sent out of range: ALWAYS 14 store instructions per tile,
+        // which the counted vmcnt wait of the next tile's first slab relies on.
+        const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * G::ROWS;
+        const int rows_valid = OH - oh0 < G::ROWS ? OH - oh0 : G::ROWS;
+        const int px_valid = rows_valid * OW;
+        const uint32_t y_so = (uint32_t)((img * OH + oh0) * OW) * 512u;            // tile base (bytes), scalar
+        int fr = frow, fqo = fq;   // opaque copies: the per-row-tile offsets and masks are recomputed per tile, not hoisted and spilled
+        asm volatile("" : "+v"(fr), "+v"(fqo));
+        const uint32_t y_vo = (uint32_t)(fr * 512 + (32 * wave + 8 * fqo) * 2);   // + i * 8192
+        if constexpr (FUSE) {
+            // x -> bf16 image
+#define SC2_W2_WR(i)                                                                                                        \
+    lds_write16_imm<(i) * 256>(img_wr, u32x4_t{pack2(acc[i][0][0], acc[i][0][1]), pack2(acc[i][0][2], acc[i][0][3]),      \
+                                               pack2(acc[i][1][0], acc[i][1][1]), pack2(acc[i][1][2], acc[i][1][3])});
+            SC2_W2_WR(0) SC2_W2_WR(1) SC2_W2_WR(2) SC2_W2_WR(3) SC2_W2_WR(4) SC2_W2_WR(5) SC2_W2_WR(6)
+            SC2_W2_WR(7) SC2_W2_WR(8) SC2_W2_WR(9) SC2_W2_WR(10) SC2_W2_WR(11) SC2_W2_WR(12) SC2_W2_WR(13)
+#undef SC2_W2_WR
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // the image is complete
+            // norm = gamma |x|: k-steps KT .. KT + 7 of the weight stream, ring slot = step & 3
+#define SC2_W2_NSTEP(S, BASE, OFF)                                                         \
+    {                                                                                      \
+        const uint4 b0 = bq[(S) & 3][0], b1 = bq[(S) & 3][1];                              \
+        fetch_b(KT + (S) + PF, bq[(S) & 3][0], bq[(S) & 3][1]);                            \
+        norm_step<G, OFF>(acc, BASE, b0, b1);                                              \
+    }
+            SC2_W2_NSTEP(0, g_base0, 0 * G::IMG_PLANE) SC2_W2_NSTEP(1, g_base0, 4 * G::IMG_PLANE)
+            SC2_W2_NSTEP(2, g_base0, 8 * G::IMG_PLANE) SC2_W2_NSTEP(3, g_base0, 12 * G::IMG_PLANE)
+            SC2_W2_NSTEP(4, g_base1, 0 * G::IMG_PLANE) SC2_W2_NSTEP(5, g_base1, 4 * G::IMG_PLANE)
+            SC2_W2_NSTEP(6, g_base1, 8 * G::IMG_PLANE) SC2_W2_NSTEP(7, g_base1, 12 * G::IMG_PLANE)
+#undef SC2_W2_NSTEP
+            // y = x * (beta + norm)  (inverse)  or  x / (beta + norm); x from this lane's own image slots.  (beta is fetched per
+            // tile: 32 bytes per lane out of L2; kept in registers across the K loop it was spilled to scratch)
+            const float4 beta_lo = *reinterpret_cast<const float4 *>(p.beta + 32 * wave + 8 * fqo);
+            const float4 beta_hi = *reinterpret_cast<const float4 *>(p.beta + 32 * wave + 8 * fqo + 4);
+            u32x4_t xr[MT];
+#define SC2_W2_RD(i) xr[i] = lds_read16_imm<(i) * 256>(img_wr);
+            SC2_W2_RD(0) SC2_W2_RD(1) SC2_W2_RD(2) SC2_W2_RD(3) SC2_W2_RD(4) SC2_W2_RD(5) SC2_W2_RD(6)
+            SC2_W2_RD(7) SC2_W2_RD(8) SC2_W2_RD(9) SC2_W2_RD(10) SC2_W2_RD(11) SC2_W2_RD(12) SC2_W2_RD(13)
+#undef SC2_W2_RD
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]),
+                         "+v"(xr[7]), "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13])::"memory");
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const float xv[8] = {__builtin_bit_cast(float, xr[i][0] << 16), __builtin_bit_cast(float, xr[i][0] & 0xFFFF0000u),
+                                     __builtin_bit_cast(float, xr[i][1] << 16), __builtin_bit_cast(float, xr[i][1] & 0xFFFF0000u),
+                                     __builtin_bit_cast(float, xr[i][2] << 16), __builtin_bit_cast(float, xr[i][2] & 0xFFFF0000u),
+                                     __builtin_bit_cast(float, xr[i][3] << 16), __builtin_bit_cast(float, xr[i][3] & 0xFFFF0000u)};
+                const float nm[8] = {beta_lo.x + acc[i][0][0], beta_lo.y + acc[i][0][1], beta_lo.z + acc[i][0][2], beta_lo.w + acc[i][0][3],
+                                     beta_hi.x + acc[i][1][0], beta_hi.y + acc[i][1][1], beta_hi.z + acc[i][1][2], beta_hi.w + acc[i][1][3]};
+                float r[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = INVERSE ? xv[e] * nm[e] : xv[e] * (1.0f / nm[e]);
+                if (p.dbg == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = xv[e];
+                } else if (p.dbg == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = nm[e];
+                }
+                const int ml = i * 16 + fr;
+                buf_store16(rs_y, ml < px_valid ? y_vo + (uint32_t)i * 8192u : OOB, y_so,
+                            u32x4_t{pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7])});
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int ml = i * 16 + fr;
+                buf_store16(rs_y, ml < px_valid ? y_vo + (uint32_t)i * 8192u : OOB, y_so,
+                            u32x4_t{pack2(acc[i][0][0], acc[i][0][1]), pack2(acc[i][0][2], acc[i][0][3]),
+                                    pack2(acc[i][1][0], acc[i][1][1]), pack2(acc[i][1][2], acc[i][1][3])});
+            }
+        }
+    }
+}
+
+int g_cus_w2 = 0;
+
+template <class G, bool FUSE, bool INVERSE = true>
+int launch_w2(W2Args a, hipStream_t s) {
+    constexpr int LDS = FUSE ? G::LDS_FUSED : G::LDS_PLAIN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2x2_win_kernel<G, FUSE, INVERSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS);
+        attr_set = true;
+    }
+    if (g_cus_w2 == 0) {
+        int dev = 0, n = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_cus_w2 = n;
+    }
+    a.tiles_per_img = (a.OH + G::ROWS - 1) / G::ROWS;
+    a.n_tiles = a.N * a.tiles_per_img;
+    // runs of `tiles_per_wg` consecutive tiles per workgroup.  Default 2: many short workgroups that the dispatcher places on
+    // whatever CUs are free -- inside the pipelined bench the serial coder's workgroups and the encoder stage of a later batch
+    // hold CUs for milliseconds, and with one static share per CU (14 tiles at bs 256) the launch waited for the workgroups
+    // that could not start (measured in the pipeline, K = 20: 0.85 ms with the whole share, 0.79 ms with runs of 2 or 1;
+    // stand-alone the same).  SC2_W2_RUN=<tiles> overrides (tools/w2_run_ab.sh).
+    const int cus8 = (g_cus_w2 / 8) * 8 > 0 ? (g_cus_w2 / 8) * 8 : 8;
+    const int share = (a.n_tiles + cus8 - 1) / cus8;
+    int run = share < 2 ? share : 2;
+    const char *rn = getenv("SC2_W2_RUN");
+    if (rn && atoi(rn) > 0) run = atoi(rn);
+    a.tiles_per_wg = run;
+    int grid = (a.n_tiles + run - 1) / run;
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL((conv2x2_win_kernel<G, FUSE, INVERSE>), dim3(grid), dim3(512), LDS, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+typedef Geo2<55, 0> Gd2;   // dec.conv2: 56 -> 55
+typedef Geo2<56, 1> Gd4;   // dec.conv4: 55 -> 56
+
+}  // namespace
+
+extern "C" int sc2_conv2x2_win_supported(int H, int W, int Cin, int Cout, int pad) {
+    if (Cout != 256 || Cin < 64 || Cin % 64 != 0) return 0;
+    if (pad == 0) return W == 56 && H >= 2 ? 1 : 0;
+    if (pad == 1) return W == 55 && H >= 1 ? 1 : 0;
+    return 0;
+}
+
+extern "C" int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const float *beta, void *y, int N, int H, int W, int Cin,
+                                   int pad, int fused, int inverse, void *stream) {
+    SC2_REQUIRE(x && w_frag && y, SC2_ERR_INVALID_ARG, "conv2x2_win: null argument");
+    SC2_REQUIRE(N > 0, SC2_ERR_INVALID_ARG, "conv2x2_win: non-positive batch");
+    SC2_REQUIRE(sc2_conv2x2_win_supported(H, W, Cin, 256, pad), SC2_ERR_UNSUPPORTED,
+                "conv2x2_win: needs Cout 256, Cin %% 64 == 0 and width 56 (pad 0) or 55 (pad 1); got %d x %d, Cin %d, pad %d", H, W, Cin,
+                pad);
+    SC2_REQUIRE(!fused || beta, SC2_ERR_INVALID_ARG, "conv2x2_win: the fused GDN1 needs beta");
+    const int ksteps = Cin / 32 * 4 + (fused ? 8 : 0);
+    const long long x_bytes = (long long)N * H * W * Cin * 2, w_bytes = (long long)ksteps * 16384;
+    const long long y_bytes = (long long)N * (H + 2 * pad - 1) * (W + 2 * pad - 1) * 512;
+    SC2_REQUIRE(x_bytes < 0x7FF00000LL && y_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv2x2_win: tensor of %lld bytes exceeds 2 GB",
+                x_bytes > y_bytes ? x_bytes : y_bytes);
+    W2Args a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_frag);
+    a.beta = beta;
+    a.y = static_cast<uint16_t *>(y);
+    a.N = N; a.H = H; a.Cin = Cin; a.OH = H + 2 * pad - 1;
+    a.n_tiles = 0; a.tiles_per_img = 0; a.tiles_per_wg = 0;
+    {
+        const char *dbg = getenv("SC2_W2_DBG");
+        a.dbg = dbg ? atoi(dbg) : 0;
+    }
+    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pad == 0) return !fused ? launch_w2<Gd2, false>(a, s) : inverse ? launch_w2<Gd2, true, true>(a, s) : launch_w2<Gd2, true, false>(a, s);
+    return !fused ? launch_w2<Gd4, false>(a, s) : inverse ? launch_w2<Gd4, true, true>(a, s) : launch_w2<Gd4, true, false>(a, s);
+}

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -77,6 +77,8 @@ def lib():
     L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3_win_supported.argtypes = [i32, i32, i32, i32]
     L.sc2_conv3x3_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv2x2_win_supported.argtypes = [i32, i32, i32, i32, i32]
+    L.sc2_conv2x2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
@@ -569,15 +571,63 @@ def conv3x3_win_supported(h, w, cin, cout, kh, kw, stride, pad, dilation=(1, 1))
         bool(lib().sc2_conv3x3_win_supported(h, w, cin, cout))
 
 
-def pack_conv3x3_win(w):
-    """[Cout, Cin, 3, 3] -> bf16 [Cin/32 * 9][Cout/16][64][8] for sc2_conv3x3_win_fwd (layout: include/sc2_bottleneck.h)."""
+def pack_conv_win(w):
+    """[Cout, Cin, KH, KW] -> bf16 [Cin/32 * KH*KW][Cout/16][64][8], the weight stream of the window-plane kernels
+    (sc2_conv3x3_win_fwd / sc2_conv2x2_win_fwd; layout: include/sc2_bottleneck.h): k-step = slab * KH*KW + tap, one MFMA
+    operand fragment = 1 KB contiguous, output rows permuted so that a lane ends up with eight consecutive channels."""
     _dev(w, 'w')
     cout, cin, kh, kw = w.shape
-    assert (kh, kw) == (3, 3) and cout % 32 == 0 and cin % 32 == 0
+    assert cout % 32 == 0 and cin % 32 == 0
     # cout = 32 g + 8 a + 4 j + b   (frow = 4 a + b);   cin = 32 cb + 8 fq + e
-    g = w.detach().to(torch.bfloat16).reshape(cout // 32, 4, 2, 4, cin // 32, 4, 8, 9)   # g, a, j, b, cb, fq, e, tap
-    g = g.permute(4, 7, 0, 2, 5, 1, 3, 6)                                             # cb, tap, g, j, fq, a, b, e
-    return g.contiguous().reshape(cin // 32 * 9, cout // 16, 64, 8)
+    g = w.detach().to(torch.bfloat16).reshape(cout // 32, 4, 2, 4, cin // 32, 4, 8, kh * kw)   # g, a, j, b, cb, fq, e, tap
+    g = g.permute(4, 7, 0, 2, 5, 1, 3, 6)                                                   # cb, tap, g, j, fq, a, b, e
+    return g.contiguous().reshape(cin // 32 * kh * kw, cout // 16, 64, 8)
+
+
+def pack_conv3x3_win(w):
+    """[Cout, Cin, 3, 3] -> bf16 [Cin/32 * 9][Cout/16][64][8] for sc2_conv3x3_win_fwd."""
+    assert tuple(w.shape[2:]) == (3, 3)
+    return pack_conv_win(w)
+
+
+def conv2x2_win_supported(x_shape, cout, kh, kw, stride, pad):
+    """True if this conv runs on the window-plane decoder kernel (k2, s1, Cout 256, width 56 / pad 0 or 55 / pad 1)."""
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    if os.environ.get('SC2_CONV2X2_WIN', '1') == '0':      # A/B switch (tools/)
+        return False
+    N, H, W, Cin = x_shape
+    return (kh, kw, sh, sw) == (2, 2, 1, 1) and ph == pw and bool(lib().sc2_conv2x2_win_supported(H, W, Cin, cout, ph))
+
+
+def pack_conv2x2_win(w, gamma=None):
+    """Weight stream of sc2_conv2x2_win_fwd: the conv's k-steps, then (fused GDN1) the effective gamma [256, 256] as a 1x1
+    layer."""
+    parts = [pack_conv_win(w)]
+    if gamma is not None:
+        assert tuple(gamma.shape) == (w.shape[0], w.shape[0])
+        parts.append(pack_conv_win(gamma.reshape(gamma.shape[0], gamma.shape[1], 1, 1)))
+    return torch.cat(parts).contiguous()
+
+
+def conv2x2_win_fwd(x_nhwc, w_frag, pad, beta=None, inverse=True, tag=None):
+    """y = conv2x2(x, stride 1, pad) [-> GDN1 / inverse GDN1 when beta is given]; bf16 NHWC in / out, Cout 256."""
+    for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, Cin = x_nhwc.shape
+    fused = beta is not None
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and \
+        tuple(w_frag.shape) == (Cin // 32 * 4 + (8 if fused else 0), 16, 64, 8)
+    if fused:
+        _dev(beta, 'beta')
+        assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 256
+    pad = int(pad)
+    out = torch.empty((N, H + 2 * pad - 1, W + 2 * pad - 1, 256), dtype=torch.bfloat16, device=x_nhwc.device)
+    with _timed(tag or 'conv2x2_win'):
+        _check(lib().sc2_conv2x2_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(beta) if fused else None, _ptr(out), N, H, W, Cin, pad,
+                                         1 if fused else 0, 1 if inverse else 0, _stream()), 'conv2x2_win_fwd')
+    return out
 
 
 def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None):

@@ -236,7 +236,14 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             h = g1.forward_nhwc(h)
         fused = hip.conv_fused_gdn_supported(tuple(h.shape), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1],
                                              c2.stride, c2.padding) if self.fuse_gdn else 0
-        if fused:
+        win2 = (self.fuse_gdn and type(g3) is GDN1 and g3.in_channels == c2.out_channels == 256 and c2.bias is None and
+                hip.conv2x2_win_supported(tuple(h.shape), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
+                                          c2.padding))
+        if win2:
+            # conv + inverse GDN1 on the window-plane kernel (bit-identical to the tile kernel's fused launch)
+            beta, w_frag = self._win_weights(c2, g3)
+            h = hip.conv2x2_win_fwd(h, w_frag, c2.padding[0], beta=beta, inverse=g3.inverse, tag=c2._tag + '+' + g3._tag)
+        elif fused:
             # conv + inverse GDN1 in one launch (256-wide big tile holds all channels)
             beta, gamma = g3.effective_fragments() if fused == 2 else g3.effective()
             h = hip.conv2d_fwd(h, c2.packed_weight(), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride,
@@ -246,9 +253,29 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             h = c2.forward_nhwc(h)
             h = g3.forward_nhwc(h)
         if self.output_format == 'bf16_nhwc':
-            out = c4.forward_nhwc(h, out_format=hip.OUT_BF16_NHWC)
+            if c4.bias is None and hip.conv2x2_win_supported(tuple(h.shape), c4.out_channels, c4.kernel_size[0], c4.kernel_size[1],
+                                                             c4.stride, c4.padding):
+                out = hip.conv2x2_win_fwd(h, self._win_weights(c4, None)[1], c4.padding[0], tag=c4._tag)
+            else:
+                out = c4.forward_nhwc(h, out_format=hip.OUT_BF16_NHWC)
             return out.permute(0, 3, 1, 2)  # logical NCHW, channels_last memory
         return c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
+
+    def _win_weights(self, conv, gdn):
+        """(beta, weight stream) of sc2_conv2x2_win_fwd for `conv` [+ the GDN1 behind it]; cached per parameter version."""
+        key = (conv.weight._version, conv.weight.device, conv.weight.data_ptr()) + \
+            (() if gdn is None else (gdn.beta._version, gdn.gamma._version, gdn.gamma.data_ptr()))
+        cache = self.__dict__.setdefault('_win_cache', {})
+        ent = cache.get(id(conv))
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                if gdn is None:
+                    ent = (key, None, hip.pack_conv2x2_win(conv.weight))
+                else:
+                    beta = gdn.beta_reparam(gdn.beta).float().contiguous()
+                    ent = (key, beta, hip.pack_conv2x2_win(conv.weight, gdn.gamma_reparam(gdn.gamma)))
+            cache[id(conv)] = ent
+        return ent[1], ent[2]
 
     def synthesis(self, y_hat):
         """decoder(y_hat) for an f32 NCHW latent."""

@@ -578,6 +578,52 @@ def test_conv3x3_win(S, dev, cin, cout, N, HW, relu):
     assert_close_bf16(out, gen, 'window-plane vs tile kernel', extra=2.0 ** -8)
 
 
+@pytest.mark.parametrize('cin,pad,N,H,fused,inverse,run', [
+    (512, 0, 3, 56, True, True, 0),       # dec.conv2 + inverse GDN1: one tile per workgroup, last row tile of an image 3 rows
+    (512, 0, 3, 56, True, True, 5),       # runs of 5 tiles: the K loops of successive tiles (and images) joined
+    (256, 1, 2, 55, False, True, 0),      # dec.conv4
+    (256, 1, 5, 55, False, True, 7),
+    (64, 0, 2, 9, False, True, 3),        # two slabs, a map that is not square (9 x 56 -> 8 x 55: two row tiles per image)
+    (128, 1, 3, 6, True, False, 2),       # forward GDN1, 6 x 55 -> 7 x 56
+])
+def test_conv2x2_win(S, dev, monkeypatch, cin, pad, N, H, fused, inverse, run):
+    """The window-plane decoder kernel (conv2x2_win.hip), plain and with the GDN1 behind it fused in, against the tile
+    kernels' launches of the same layer: BIT-IDENTICAL (same operation order per output element), and against the f32 op."""
+    if run:
+        monkeypatch.setenv('SC2_W2_RUN', str(run))
+    W = 56 if pad == 0 else 55
+    g = torch.Generator().manual_seed(cin + N + H)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(256, cin, 2, 2, generator=g) / (4 * cin) ** 0.5
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    assert S.hip.conv2x2_win_supported(tuple(x_nhwc.shape), 256, 2, 2, 1, pad)
+    assert not S.hip.conv2x2_win_supported(tuple(x_nhwc.shape), 128, 2, 2, 1, pad)
+    assert not S.hip.conv2x2_win_supported((N, H, W + 1, cin), 256, 2, 2, 1, pad)
+    order = S.hip.preferred_k_order(cin, 2, 2)
+    wp = S.hip.pack_conv_weight(w.to(dev), order)
+    if fused:
+        gdn = S.GDN1(256, inverse=inverse).to(dev)
+        with torch.no_grad():
+            gdn.gamma.add_(0.02 * torch.rand(256, 256, generator=g).to(dev))
+        mode = S.hip.conv_fused_gdn_supported(tuple(x_nhwc.shape), 256, 2, 2, 1, pad)
+        if mode:     # the tile kernel's fused launch (large batches only)
+            beta, gamma = gdn.effective_fragments() if mode == 2 else gdn.effective()
+            ref = S.hip.conv2d_fwd(x_nhwc, wp, 256, 2, 2, 1, pad, epilogue=S.hip.EPI_FUSED_IGDN if inverse else S.hip.EPI_FUSED_GDN,
+                                   ep_x=gamma, ep_beta=beta, k_order=order)
+        else:        # two launches: conv -> bf16 -> GDN1
+            ref = gdn.forward_nhwc(S.hip.conv2d_fwd(x_nhwc, wp, 256, 2, 2, 1, pad, k_order=order))
+        wf = S.hip.pack_conv2x2_win(w.to(dev), gdn.gamma_reparam(gdn.gamma).detach())
+        out = S.hip.conv2x2_win_fwd(x_nhwc, wf, pad, beta=gdn.beta_reparam(gdn.beta).detach().float().contiguous(), inverse=inverse)
+    else:
+        ref = S.hip.conv2d_fwd(x_nhwc, wp, 256, 2, 2, 1, pad, k_order=order)
+        out = S.hip.conv2x2_win_fwd(x_nhwc, S.hip.pack_conv2x2_win(w.to(dev)), pad)
+        f32 = F.conv2d(bf16_round(x), bf16_round(w), padding=pad)
+        assert_close_bf16(out.permute(0, 3, 1, 2), f32, 'window-plane 2x2 conv')
+    assert out.shape == ref.shape
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), \
+        'window-plane decoder kernel differs from the tile kernel in {} elements'.format(int((out != ref).sum()))
+
+
 def test_persistent_encoder_kernels_many_units(S, R, dev):
     """More units than resident workgroups can take statically: every workgroup of the two persistent encoder kernels
     goes through several dynamic claims (a stale claim register once made this an endless loop).  Device-only check

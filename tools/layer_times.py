@@ -105,10 +105,19 @@ def main():
             rows.append(('dec.conv2+igdn256', timeit(lambda: hip.conv2d_fwd(b1, d2.packed_weight(), 256, 2, 2, 1, 0, epilogue=hip.EPI_FUSED_IGDN,
                                                                               ep_x=gamma3, ep_beta=beta3, k_order=d2.k_order()), args.iters),
                          (3171.9e6 + 396.5e6) * N, b1.numel() * 2 + b2.numel() * 2))
+        if hip.conv2x2_win_supported(tuple(b1.shape), 256, 2, 2, 1, 0):   # the window-plane kernels (conv2x2_win.hip)
+            beta3w, w2f = m._win_weights(d2, h3)
+            w2p = hip.pack_conv2x2_win(d2.weight)
+            rows.append(('dec.conv2 (win)', timeit(lambda: hip.conv2x2_win_fwd(b1, w2p, 0), args.iters), 3171.9e6 * N, b1.numel() * 2 + b2.numel() * 2))
+            rows.append(('dec.conv2+igdn256 (win)', timeit(lambda: hip.conv2x2_win_fwd(b1, w2f, 0, beta=beta3w, inverse=True), args.iters),
+                         (3171.9e6 + 396.5e6) * N, b1.numel() * 2 + b2.numel() * 2))
         b3 = h3.forward_nhwc(b2)
         rows.append(('dec.igdn256', timeit(lambda: h3.forward_nhwc(b2), args.iters), 396.5e6 * N, b2.numel() * 4 + b3.numel() * 2))
         b4 = d4.forward_nhwc(b3)
         rows.append(('dec.conv4', timeit(lambda: d4.forward_nhwc(b3), args.iters), 1644.2e6 * N, b3.numel() * 2 + b4.numel() * 2))
+        if hip.conv2x2_win_supported(tuple(b3.shape), 256, 2, 2, 1, 1):
+            w4p = m._win_weights(d4, None)[1]
+            rows.append(('dec.conv4 (win)', timeit(lambda: hip.conv2x2_win_fwd(b3, w4p, 1), args.iters), 1644.2e6 * N, b3.numel() * 2 + b4.numel() * 2))
         rows.append(('analysis()', timeit(lambda: m.analysis(x), args.iters), 1177e6 * N, 0))
         m.output_format = 'bf16_nhwc'
         rows.append(('synthesis()', timeit(lambda: m.synthesis_nhwc(yh), args.iters), 7165e6 * N, 0))
