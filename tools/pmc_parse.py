@@ -15,7 +15,7 @@ for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
                 res[name][counter].append(val)
 table = {}
 for name, d in res.items():
-    if not any(q in name for q in ('conv_igemm', 'conv2x2', 'conv0_gdn96', 'conv2_gdn48', 'conv5s2', 'conv1x1_stream', 'eb_', 'rans', 'nhwc')):
+    if not any(q in name for q in ('conv_igemm', 'conv2x2', 'conv3x3_win', 'conv1x1_kres', 'conv0_gdn96', 'conv2_gdn48', 'conv5s2', 'conv1x1_stream', 'eb_', 'rans', 'nhwc')):
         continue
     fetch = sorted(d.get('FETCH_SIZE', [0]))
     write = sorted(d.get('WRITE_SIZE', [0]))
@@ -33,7 +33,7 @@ json.dump(table, open(os.path.join(out, 'traffic_raw.json'), 'w'), indent=1)
 # bench.py tags of the bottleneck launches -> HBM-side bytes per launch at the profiled batch (profiles/traffic.json)
 TAGS = {'enc.conv0+enc.gdn1': 'conv0_gdn96_kernel', 'enc.conv2+enc.gdn3': 'conv2_gdn48_kernel',
         'enc.conv4': '<128, 32, 4, 1, true, 48, 2, 2', 'dec.conv0+dec.igdn1': 'conv2x2_gdn512_kernel',
-        'dec.conv2+dec.igdn3': '8<256, 2, 4, true, 512, 2, 2', 'dec.conv4': '8<256, 2, 4, true, 256, 2, 2'}
+        'dec.conv2+dec.igdn3': 'conv2x2_win_kernel<Geo2<55, 0>, true', 'dec.conv4': 'conv2x2_win_kernel<Geo2<56, 1>, false'}
 tags = {}
 for tag, pat in TAGS.items():
     for k, v in table.items():
