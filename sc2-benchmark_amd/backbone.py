@@ -99,12 +99,15 @@ class FeatureExtractionBackbone(UpdatableBackbone):
         return self
 
     def _hip_layer(self, name, module):
-        """HipHead of one child, or None if the child is not a stack of undilated Bottleneck blocks."""
+        """HipHead of one child, or None if the child is not a stack of Bottleneck blocks (dilated 3x3 layers -- DeepLab's
+        layer3 / layer4 -- run as d * d undilated launches on the phase grids, `head._Conv._dilated`)."""
         from .head import HipHead
         from .resnet import Bottleneck
         if not (isinstance(module, nn.Sequential) and len(module) > 0 and all(isinstance(b, Bottleneck) for b in module)):
             return None
-        if any(c.dilation != (1, 1) for b in module for c in (b.conv1, b.conv2, b.conv3)):
+        if any(c.dilation != (1, 1) and not (c.kernel_size == (1, 1) or (c.kernel_size == (3, 3) and c.stride == (1, 1) and
+                                                                         c.padding == c.dilation and c.dilation[0] == c.dilation[1]))
+               for b in module for c in (b.conv1, b.conv2, b.conv3)):
             return None
         key = tuple(t._version for t in list(module.parameters()) + list(module.buffers()))
         cached = self._hip_layers.get(name)

@@ -42,10 +42,10 @@ class _Conv(object):
         self.tag = tag
         # HBM-bound 1x1 layers with a short K and a wide N run on the persistent streaming kernel
         self.stream = hip.conv1x1_stream_supported(conv.in_channels, conv.out_channels, self.k[0], self.k[1],
-                                                   self.stride, self.pad) and conv.dilation == (1, 1)
+                                                   self.stride, self.pad) and (conv.dilation == (1, 1) or self.k == (1, 1))
         # K = 1024 / 2048 1x1 layers (conv1 of layer3 / layer4, layer4's downsample): weights resident in registers, one
         # channel chunk per workgroup
-        self.kres = (not self.stream) and conv.dilation == (1, 1) and hip.conv1x1_kres_supported(
+        self.kres = (not self.stream) and (conv.dilation == (1, 1) or self.k == (1, 1)) and hip.conv1x1_kres_supported(
             conv.in_channels, conv.out_channels, self.k[0], self.k[1], self.stride, self.pad)
         if self.stream or self.kres:
             self.w_frag = hip.pack_weight_fragments(w_folded.reshape(w_folded.shape[0], w_folded.shape[1]))
@@ -55,10 +55,32 @@ class _Conv(object):
         if hip.conv3x3_win_supported(14, 14, conv.in_channels, conv.out_channels, self.k[0], self.k[1], self.stride, self.pad,
                                      conv.dilation):
             self.w_win = hip.pack_conv3x3_win(w_folded)
+        # Dilated 3x3 layers (DeepLab's layer3 / layer4, torchvision `replace_stride_with_dilation`): a stride-1 conv with
+        # dilation d and padding d is d*d independent UNDILATED pad-1 convs on the phase grids x[a::d, b::d] -- the same
+        # weights, the same kernels, outputs scattered back to y[a::d, b::d]
         if self.dilation != (1, 1):
-            raise hip.Sc2Error('dilated convolutions are not supported by the HIP head (got {})'.format(self.dilation))
+            d = self.dilation[0]
+            ok = (self.k == (3, 3) and self.stride == (1, 1) and self.dilation == (d, d) and self.pad == (d, d)) or self.k == (1, 1)
+            if not ok:
+                raise hip.Sc2Error('the HIP head supports dilation only on 3x3 stride-1 layers with padding == dilation '
+                                   '(got kernel {}, stride {}, padding {}, dilation {})'.format(self.k, self.stride, self.pad,
+                                                                                               self.dilation))
+
+    def _dilated(self, x, epilogue):
+        d = self.dilation[0]
+        N, H, W, _ = x.shape
+        y = torch.empty((N, H, W, self.cout), dtype=torch.bfloat16, device=x.device)
+        for a in range(min(d, H)):
+            for b in range(min(d, W)):
+                ys = hip.conv2d_fwd(x[:, a::d, b::d, :].contiguous(), self.w, self.cout, 3, 3, 1, 1, epilogue=epilogue,
+                                    ep_beta=self.b, tag=self.tag, k_order=self.k_order)
+                y[:, a::d, b::d, :] = ys
+        return y
 
     def __call__(self, x, epilogue, ep_x=None):
+        if self.dilation != (1, 1) and self.k == (3, 3):
+            assert ep_x is None
+            return self._dilated(x, epilogue)
         if self.stream and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU, hip.EPI_BIAS_ADD_RELU):
             return hip.conv1x1_stream_fwd(x, self.w_frag, self.b, stride=self.stride[0],
                                           residual=ep_x if epilogue == hip.EPI_BIAS_ADD_RELU else None,

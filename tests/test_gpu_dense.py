@@ -106,7 +106,7 @@ def test_deeplabv3_dilated_backbone(S, R, dev):
         cls_ref = torch.nn.functional.interpolate(copy.deepcopy(model.classifier).cpu()(ref['out']), size=(257, 257),
                                                   mode='bilinear', align_corners=False)
         _close(out['out'], cls_ref, 0.15)
-        # the VOC shape of the config (513 x 513, odd width), updated, bf16: layer2 on the HIP head, dilated stacks on torch
+        # the VOC shape of the config (513 x 513, odd width), updated, bf16: layer2 AND the dilated stacks on the HIP head
         model.update()
         model.activate_analysis()
         body.set_compute_dtype('bf16')
@@ -116,8 +116,33 @@ def test_deeplabv3_dilated_backbone(S, R, dev):
         out2 = model(x2.to(dev))
         assert out2['out'].shape == (2, 21, 513, 513) and out2['aux'].shape == (2, 21, 513, 513)
         assert torch.isfinite(out2['out'].float()).all()
-        assert set(body._hip_layers) == {'layer2'}
+        assert set(body._hip_layers) == {'layer2', 'layer3', 'layer4'}
         assert len(body.analyzers[0].file_size_list) == 1
         ev = S.SegEvaluator(21)
         ev.update(torch.randint(0, 21, (2, 513, 513), device=dev).flatten(), out2['out'].argmax(1).flatten())
         assert int(ev.mat.sum()) == 2 * 513 * 513
+
+
+@pytest.mark.parametrize('d,H,W', [(2, 33, 33), (4, 33, 35), (2, 5, 3), (4, 3, 2)])
+def test_dilated_conv3x3_on_phase_grids(S, dev, d, H, W):
+    """head._Conv on a dilated 3x3 layer (dilation d, padding d, stride 1: DeepLab's layer3 / layer4) = d * d undilated
+    launches on the phase grids x[a::d, b::d]; against torch's dilated conv + folded BN + ReLU on the bf16-rounded operands
+    (maps smaller than the dilation included)."""
+    from sc2bench_amd import head, hip
+    torch.manual_seed(d * 100 + H)
+    conv = torch.nn.Conv2d(64, 128, 3, padding=d, dilation=d, bias=False)
+    bn = torch.nn.BatchNorm2d(128).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.1)
+        bn.running_var.uniform_(0.5, 1.5)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.1)
+    x = torch.randn(2, 64, H, W)
+    c = head._Conv(conv.to(dev), bn.to(dev), 'test.dilated')
+    with torch.no_grad():
+        out = c(hip.nchw_f32_to_nhwc_bf16(x.to(dev)), hip.EPI_BIAS_RELU)
+        w_f, b_f = head._fold(conv, bn)[3].cpu(), head._fold(conv, bn)[1].cpu()
+        xr = x.to(torch.bfloat16).float()
+        ref = torch.relu(torch.nn.functional.conv2d(xr, w_f.to(torch.bfloat16).float(), padding=d, dilation=d) + b_f.view(1, -1, 1, 1))
+    assert out.shape == (2, H, W, 128)
+    _close(out.permute(0, 3, 1, 2).float(), ref, 2e-2)
