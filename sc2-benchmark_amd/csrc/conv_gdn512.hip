@@ -135,18 +135,6 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
             for (int j = 0; j < NT; ++j) wv[s][j] = *reinterpret_cast<const uint4 *>(wrow[j] + s * 32);
     };
     load_w();
-    // the first two gamma steps of a tile's phase 2 are fetched a tile AHEAD, together with W0 and before the previous tile's
-    // output stores: fetched at the top of phase 2 they sat behind those 16 stores in the vmcnt queue, and the phase began by
-    // waiting for their acknowledgements
-    constexpr int NS = CH / 32;
-    uint4 gb[2][NT];
-    auto load_g01 = [&]() {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) gb[h][j] = gfrag[(j * NS + h) * 64];
-    };
-    load_g01();
 
     // Tiles are claimed dynamically, one atomic per tile: a workgroup whose CU is shared with other kernels (the range
     // coder's serial waves), or that starts late because its CU's LDS was taken, simply processes fewer tiles.
@@ -205,6 +193,12 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
         // such load touch 16 lines for 64 bytes each, and the phase ran at the vector L1's request rate: 2.7k cycles
         // per 32-deep step against 1k of MFMA issue - tools/dec_stamps.py.)  gb[h] holds step 2d + h and is
         // re-filled for step 2d + 2 + h as soon as its MFMAs have been issued.
+        constexpr int NS = CH / 32;
+        uint4 gb[2][NT];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) gb[h][j] = gfrag[(j * NS + h) * 64];
 #pragma unroll 1
         for (int d = 0; d < NS / 2; ++d) {
             // the two waves of a SIMD (w and w + 4) take turns at priority: with a fixed priority (or none: age decides)
@@ -279,7 +273,6 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
         STAMP(5);
         const int tile_after_next = __builtin_amdgcn_readfirstlane(*next_slot);
         load_w();          // next tile's W0 fragments, issued ahead of the output stores
-        load_g01();        // and its first two gamma steps
         {
             // thread (wave wn, lane) streams chunk `lane` of rows wn, wn + 8, ...: row & 15 = wn or wn + 8
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)m0 * CH) + tid;   // the tile is contiguous in y
