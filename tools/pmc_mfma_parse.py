@@ -26,8 +26,10 @@ N = 256
 KERNELS = [   # (label, name pattern, algorithmic GFLOP per launch at bs 256)
     ('enc.conv0+gdn96', 'conv0_gdn96_kernel', 0.4118 * N), ('enc.conv2+gdn48', 'conv2_gdn48_kernel', 0.737 * N),
     ('dec.conv0+igdn512', 'conv2x2_gdn512_kernel', 1.9525 * N),
-    ('dec.conv2+igdn256 / dec.conv2', 'Cfg8<256, 2, 4, true, 512, 2, 2', 3.5684 * N),
-    ('dec.conv4', 'Cfg8<256, 2, 4, true, 256, 2, 2', 1.6442 * N)]
+    ('dec.conv2+igdn256 (tile kernel)', 'Cfg8<256, 2, 4, true, 512, 2, 2', 3.5684 * N),
+    ('dec.conv4 (tile kernel)', 'Cfg8<256, 2, 4, true, 256, 2, 2', 1.6442 * N),
+    ('dec.conv2+igdn256 (win)', 'Geo2<55, 0>, true', 3.5684 * N), ('dec.conv2 (win)', 'Geo2<55, 0>, false', 3.1719 * N),
+    ('dec.conv4 (win)', 'Geo2<56, 1>, false', 1.6442 * N)]
 if len(sys.argv) > 2:   # label:pattern:gflop triples replace the default list (tools/pmc_head.sh)
     KERNELS = [(a.split('|')[0], a.split('|')[1], float(a.split('|')[2])) for a in sys.argv[2:]]
 
