@@ -265,7 +265,16 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
         }
         g_ring[dev] = static_cast<unsigned *>(ptr);
     }
-    const int grid = a.n_units < g_cus ? a.n_units : g_cus;
+    static int per_cu = 0;   // resident workgroups per CU of this instantiation (LDS and registers decide)
+    if (per_cu == 0) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, BM, BNC, RES>), 512,
+                                                         lds) != hipSuccess || n < 1)
+            n = 1;
+        per_cu = n > 2 ? 2 : n;
+    }
+    const int slots = g_cus * per_cu;
+    const int grid = a.n_units < slots ? a.n_units : slots;
     StreamArgs b = a;
     b.unit_ctr = g_ring[dev] + (g_seq.fetch_add(1) % kRing);
     hipLaunchKernelGGL((conv1x1_stream_kernel<K, BM, BNC, RES>), dim3(grid), dim3(512), lds, s, b);
@@ -307,7 +316,13 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
     if (Cin == 512 && Cout % 256 == 0) SC2_STREAM_GO(512, 64, 256);   // (half the A re-reads of the 128-wide unit)
     if (Cin == 512) SC2_STREAM_GO(512, 64, 128);
     if (Cout % 256 == 0) {
-        if (Cin == 128) SC2_STREAM_GO(128, 128, 256);
+        const char *h = getenv("SC2_STREAM_BM64");   // A/B: 64-pixel units (64 / 48 KB of LDS: two / three workgroups per CU)
+        const int half = h ? atoi(h) : 0;
+        if (Cin == 128) {
+            if (half & 1) SC2_STREAM_GO(128, 64, 256);
+            SC2_STREAM_GO(128, 128, 256);
+        }
+        if (half & 2) SC2_STREAM_GO(256, 64, 256);
         SC2_STREAM_GO(256, 128, 256);
     }
     if (Cin == 128) SC2_STREAM_GO(128, 128, 128);
