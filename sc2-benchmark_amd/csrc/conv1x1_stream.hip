@@ -315,14 +315,8 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
 #define SC2_STREAM_GO(KK, BMM, BNN) return a.res ? launch_stream<KK, BMM, BNN, true>(a, s) : launch_stream<KK, BMM, BNN, false>(a, s)
     if (Cin == 512 && Cout % 256 == 0) SC2_STREAM_GO(512, 64, 256);   // (half the A re-reads of the 128-wide unit)
     if (Cin == 512) SC2_STREAM_GO(512, 64, 128);
-    if (Cout % 256 == 0) {
-        const char *h = getenv("SC2_STREAM_BM64");   // A/B: 64-pixel units (64 / 48 KB of LDS: two / three workgroups per CU)
-        const int half = h ? atoi(h) : 0;
-        if (Cin == 128) {
-            if (half & 1) SC2_STREAM_GO(128, 64, 256);
-            SC2_STREAM_GO(128, 128, 256);
-        }
-        if (half & 2) SC2_STREAM_GO(256, 64, 256);
+    if (Cout % 256 == 0) {   // (64-pixel units, two workgroups per CU: measured the same for K = 128, 5 - 15 % slower for K = 256)
+        if (Cin == 128) SC2_STREAM_GO(128, 128, 256);
         SC2_STREAM_GO(256, 128, 256);
     }
     if (Cin == 128) SC2_STREAM_GO(128, 128, 128);
