@@ -88,7 +88,7 @@ class _Conv(object):
         if self.kres and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU):
             return hip.conv1x1_kres_fwd(x, self.w_frag, self.b, stride=self.stride[0], relu=epilogue == hip.EPI_BIAS_RELU,
                                         tag=self.tag)
-        if self.w_win is not None and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU) and \
+        if self.w_win is not None and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU) and x.numel() * 2 < 0x7FF00000 and \
                 hip.conv3x3_win_supported(x.shape[1], x.shape[2], x.shape[3], self.cout, self.k[0], self.k[1], self.stride, self.pad):
             return hip.conv3x3_win_fwd(x, self.w_win, self.b, relu=epilogue == hip.EPI_BIAS_RELU, tag=self.tag)
         return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,

@@ -568,7 +568,7 @@ def conv3x3_win_supported(h, w, cin, cout, kh, kw, stride, pad, dilation=(1, 1))
     if os.environ.get('SC2_CONV_WIN', '1') == '0':      # A/B switch (tools/)
         return False
     return (kh, kw, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and tuple(dilation) == (1, 1) and \
-        bool(lib().sc2_conv3x3_win_supported(h, w, cin, cout))
+        bool(lib().sc2_conv3x3_win_supported(h, w, cin, cout))   # (the caller checks the 2 GB operand bound: head._Conv)
 
 
 def pack_conv_win(w):
@@ -597,6 +597,8 @@ def conv2x2_win_supported(x_shape, cout, kh, kw, stride, pad):
     if os.environ.get('SC2_CONV2X2_WIN', '1') == '0':      # A/B switch (tools/)
         return False
     N, H, W, Cin = x_shape
+    if max(N * H * W * Cin, N * (H + 2 * ph - 1) * (W + 2 * pw - 1) * cout) * 2 >= 0x7FF00000:   # 32-bit buffer offsets
+        return False
     return (kh, kw, sh, sw) == (2, 2, 1, 1) and ph == pw and bool(lib().sc2_conv2x2_win_supported(H, W, Cin, cout, ph))
 
 
