@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 26
+#define SC2_ABI_VERSION 27
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -198,6 +198,19 @@ int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, vo
 int sc2_conv2x2_win_supported(int H, int W, int Cin, int Cout, int pad);
 int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const float *beta, void *y, int N, int H, int W, int Cin, int pad,
                         int fused, int inverse, void *stream);
+
+/* The last decoder convolution (256 -> 256, k2, p1: 55 -> 56) with the two 1x1 layers of the caller that consume its output
+ * fused behind it: conv1 + bn1 + ReLU (256 -> 128) and downsample conv + bn (256 -> 512, stride 2) of layer2.0 of the ResNet
+ * tail (sc2bench/models/backbone.py:235-254 runs decoder then layer2; torchvision Bottleneck.forward).  The 411 MB
+ * feature map between the bottleneck and the head is then never written (y == NULL) or written once and not read back.
+ *   x : bf16 NHWC [N,55,55,Cin];   w_stream : bf16 [Cin/32*4 + 24][16][64][8] = the conv's k-steps, 8 k-steps of W1 (BN folded,
+ *   rows 128..255 zero), 8 k-steps of Wds rows 0..255, 8 k-steps of Wds rows 256..511 (packing as sc2_conv2x2_win_fwd);
+ *   bias1 f32 [128], bias_ds f32 [512] (folded BN);   y : bf16 NHWC [N,56,56,256] or NULL;
+ *   o1 : bf16 NHWC [N,56,56,128] = relu(W1 y + bias1);   ods : bf16 NHWC [N,28,28,512] = Wds y[::2, ::2] + bias_ds.
+ * Same operation order per element as the separate launches: bit-identical results. */
+int sc2_conv2x2_win_tail_supported(int H, int W, int Cin);
+int sc2_conv2x2_win_tail_fwd(const void *x, const void *w_stream, const float *bias1, const float *bias_ds, void *y, void *o1,
+                             void *ods, int N, int H, int W, int Cin, void *stream);
 
 /* Second encoder stage in ONE persistent launch: y = GDN1_48(Conv2d(96 -> 48, k5, s2, p2, bias=False)(x)) for
  * 112-pixel-wide inputs (replaces encoder[2] + encoder[3], sc2bench/models/layer.py:479-481; inverse != 0: inverse GDN1).

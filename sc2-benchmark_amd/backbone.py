@@ -280,6 +280,22 @@ class SplittableResNet(UpdatableBackbone):
         dec = eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw)
         return dec, nb, st
 
+    def decode_head(self, y_hat_nhwc):
+        """decoder + task head on a dequantised bf16 NHWC latent.  In bf16 eval with the HIP head, the decoder's last conv takes
+        layer2.0's conv1 and downsample with it (one launch, `FPBasedResNetBottleneck.synthesis_nhwc_tail`): the 256-channel
+        56 x 56 map between bottleneck and head is never written."""
+        bl = self.bottleneck_layer
+        if (self.compute_dtype == 'bf16' and self.use_hip_head and not self.training and self.layer2 is not None
+                and hasattr(bl, 'synthesis_nhwc_tail') and getattr(bl, 'output_format', '') == 'bf16_nhwc'):
+            head = self._hip_head_for_eval()
+            res = bl.synthesis_nhwc_tail(y_hat_nhwc, head)
+            if res is not None:
+                feats, pre = res
+                if pre is not None:
+                    return head.forward(None, with_pool=self.avgpool is not None, pre=pre)
+                return self.head(feats)
+        return self.head(bl.synthesis_nhwc(y_hat_nhwc))
+
     def stage_decoder(self, dec_sym, hw_shape):
         """dequantise + decoder: decoded symbols -> features (the MFMA-bound half of the back stage)."""
         _, y_hat_nhwc = self.bottleneck_layer.entropy_bottleneck.dequantize_device(dec_sym, hw_shape)
@@ -289,9 +305,11 @@ class SplittableResNet(UpdatableBackbone):
         """dequantise + decoder + task head.  `after_decoder()` is called between the two (bench.py records an event
         there: the encoder stage of a later batch is scheduled beside the head's HBM-bound kernels, not beside the
         decoder's MFMA-bound ones)."""
+        if after_decoder is None:
+            _, y_hat_nhwc = self.bottleneck_layer.entropy_bottleneck.dequantize_device(dec_sym, hw_shape)
+            return self.decode_head(y_hat_nhwc)
         feats = self.stage_decoder(dec_sym, hw_shape)
-        if after_decoder is not None:
-            after_decoder()
+        after_decoder()
         return self.head(feats)
 
     def update(self):

@@ -81,11 +81,16 @@ struct W2Args {
     const uint16_t *__restrict__ x;      // bf16 NHWC [N, H, W, Cin]
     const uint16_t *__restrict__ w;      // bf16 [Cin/32 * 4 (+ 8)][16][64][8]: conv k-steps, then (fused) the 8 gamma k-steps
     const float *__restrict__ beta;      // f32 [256] (fused) or null
-    uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, OW, 256]
+    uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, OW, 256]  (tail mode: may be null)
+    // tail mode (MODE 2): the two 1x1 layers that consume y in the caller (layer2.0 of the ResNet tail) fused behind the conv
+    const float *__restrict__ bias1;     // f32 [128]
+    const float *__restrict__ bias_ds;   // f32 [512]
+    uint16_t *__restrict__ o1;           // bf16 NHWC [N, OH, OW, 128]     = relu(W1 y + bias1)
+    uint16_t *__restrict__ ods;          // bf16 NHWC [N, OH/2, OW/2, 512] = Wds y[::2, ::2] + bias_ds
     int N, H, Cin, OH;
     int n_tiles, tiles_per_img, tiles_per_wg;
     int dbg;                             // DEBUG (SC2_W2_DBG): 1 = store x instead of y, 2 = store beta + norm
-    unsigned x_bytes, w_bytes, y_bytes;
+    unsigned x_bytes, w_bytes, y_bytes, o1_bytes, ods_bytes;
 };
 
 // OW: output width (static: the tap offsets are immediates); PAD: 0 (W = OW + 1) or 1 (W = OW - 1)
@@ -141,7 +146,7 @@ __device__ __forceinline__ void mma_step(f32x4_t (&acc)[G::MT][2], const uint32_
 }
 
 // k-step of the norm GEMM: pixel fragments from the image planes [4 s, 4 s + 4) (this lane: plane 4 s + fq), |.| on the fragment
-template <class G, int OFF>
+template <class G, int OFF, bool ABS>
 __device__ __forceinline__ void norm_step(f32x4_t (&acc)[G::MT][2], uint32_t g_base, const uint4 &b0, const uint4 &b1) {
     u32x4_t av[7];
 #define SC2_W2_RD(i) av[i] = lds_read16_imm<OFF + (i) * 256>(g_base);
@@ -152,7 +157,7 @@ __device__ __forceinline__ void norm_step(f32x4_t (&acc)[G::MT][2], uint32_t g_b
 #define SC2_W2_MMA(i, NWAIT)                                                                    \
     {                                                                                           \
         wait_lgkm<NWAIT>(av[(i) % 7]);                                                          \
-        const u32x4_t m = av[(i) % 7] & 0x7FFF7FFFu;                                            \
+        const u32x4_t m = ABS ? av[(i) % 7] & 0x7FFF7FFFu : av[(i) % 7];                        \
         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, m);                                    \
         acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
         acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
@@ -165,11 +170,33 @@ __device__ __forceinline__ void norm_step(f32x4_t (&acc)[G::MT][2], uint32_t g_b
 }
 #undef SC2_W2_MMA_SEQ
 
-template <class G, bool FUSE, bool INVERSE>
+// MODE 0: conv;  1: conv + (inverse) GDN1;  2: conv + the two 1x1 layers of the caller that read its output ("tail")
+// k-step of the tail's stride-2 1x1 layer: 4 row tiles = the tile's 56 pixels with even row and column (per-lane image rows)
+template <int OFF>
+__device__ __forceinline__ void ds_step(f32x4_t (&acc)[14][2], const uint32_t (&base)[4], const uint4 &b0, const uint4 &b1) {
+    u32x4_t av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = lds_read16_imm<OFF>(base[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
+#define SC2_W2_DS(i)                                                                            \
+    {                                                                                           \
+        wait_lgkm<3 - (i)>(av[i]);                                                              \
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[i]);                                \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+    SC2_W2_DS(0) SC2_W2_DS(1) SC2_W2_DS(2) SC2_W2_DS(3)
+#undef SC2_W2_DS
+}
+
+template <class G, int MODE, bool INVERSE>
 __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     constexpr int MT = G::MT, W = G::W, OW = G::OW, PAD = G::PAD;
+    constexpr bool FUSE = MODE == 1, TAIL = MODE == 2;
     constexpr uint32_t OOB = 0x80000000u;
-    constexpr int NSTORE = MT;   // output stores per lane and tile
+    constexpr int NSTORE = TAIL ? 2 * MT + 8 : MT;   // output stores per lane and tile (tail: o1, y, 2 x 4 ods; an upper bound when y is null)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
 
@@ -180,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     const int Cin = p.Cin, H = p.H, OH = p.OH;
     const int NS = Cin >> 5;                 // 32-channel slabs (even)
     const uint32_t KT = (uint32_t)NS * 4u;   // conv k-steps
-    const uint32_t KTT = KT + (FUSE ? 8u : 0u);
+    const uint32_t KTT = KT + (FUSE ? 8u : TAIL ? 24u : 0u);
 
     // this workgroup's tiles: XCD x (blockIdx & 7) owns a contiguous range of the output, cut into runs of tiles_per_wg
     const int slot = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -191,6 +218,8 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
     const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
     const buf_rsrc_t rs_y = make_rsrc(p.y, p.y_bytes);
+    [[maybe_unused]] const buf_rsrc_t rs_o1 = make_rsrc(TAIL ? p.o1 : p.y, TAIL ? p.o1_bytes : 0u);
+    [[maybe_unused]] const buf_rsrc_t rs_ods = make_rsrc(TAIL ? p.ods : p.y, TAIL ? p.ods_bytes : 0u);
 
     // window fill: 20 pieces per slab (4 chunk planes x 5 row groups of 64): wave w fills plane w & 3, row groups {0, 1, 2}
     // (waves 0-3) or {3, 4} (waves 4-7)
@@ -198,8 +227,9 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     uint32_t pw_vo[3];
     auto window_offsets = [&](int tile) {
         const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * G::ROWS;
-        int ln = lane;   // opaque: recomputed per tile (hoisted out of the tile loop these values were spilled)
-        asm volatile("" : "+v"(ln));
+        // (the lane index is re-derived here and the values below recomputed per tile: hoisted out of the tile loop they were spilled)
+        int ln;   // (volatile: computed where it is used)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int wr = (pj0 + j) * 64 + ln;
@@ -225,11 +255,6 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
         const int ohl = m / OW, ow = m - ohl * OW;
         a_base[i] = lds_base + (uint32_t)(fq * G::PLANE + (ohl * G::PWD + ow) * 16);
     }
-    // fused: image slots.  Writer / read-back: plane 4 wave + fq, row 16 i + frow; norm GEMM reader: plane 4 s + fq
-    [[maybe_unused]] const uint32_t img_wr = lds_base + (uint32_t)(G::IMG0 + (4 * wave + fq) * G::IMG_PLANE + frow * 16);
-    [[maybe_unused]] const uint32_t g_base0 = lds_base + (uint32_t)(G::IMG0 + fq * G::IMG_PLANE + frow * 16);
-    [[maybe_unused]] const uint32_t g_base1 = g_base0 + 16u * G::IMG_PLANE;
-
     // weights: k-step k, 16-channel tile t -> 1 KB at (k * 16 + t) * 1024; this wave's tiles are 2 w, 2 w + 1
     const uint32_t b_vo = (uint32_t)(lane * 16);
     const uint32_t b_so0 = (uint32_t)(2 * wave) * 1024u;
@@ -292,10 +317,16 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
         const int rows_valid = OH - oh0 < G::ROWS ? OH - oh0 : G::ROWS;
         const int px_valid = rows_valid * OW;
         const uint32_t y_so = (uint32_t)((img * OH + oh0) * OW) * 512u;            // tile base (bytes), scalar
-        int fr = frow, fqo = fq;   // opaque copies: the per-row-tile offsets and masks are recomputed per tile, not hoisted and spilled
-        asm volatile("" : "+v"(fr), "+v"(fqo));
+        int ln_o;   // the lane index, computed HERE (volatile): the per-row-tile offsets and masks derived from it are then recomputed per
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln_o));   // tile, not hoisted and spilled
+        const int fr = ln_o & 15, fqo = ln_o >> 4;
         const uint32_t y_vo = (uint32_t)(fr * 512 + (32 * wave + 8 * fqo) * 2);   // + i * 8192
-        if constexpr (FUSE) {
+        if constexpr (FUSE || TAIL) {
+            // image slots (computed here, per tile, from the re-derived lane index: held across the K loop they were spilled).
+            // Writer / read-back: plane 4 wave + fq, row 16 i + frow; second-GEMM reader: plane 4 s + fq
+            const uint32_t img_wr = lds_base + (uint32_t)(G::IMG0 + (4 * wave + fqo) * G::IMG_PLANE + fr * 16);
+            const uint32_t g_base0 = lds_base + (uint32_t)(G::IMG0 + fqo * G::IMG_PLANE + fr * 16);
+            const uint32_t g_base1 = g_base0 + 16u * G::IMG_PLANE;
             // x -> bf16 image
 #define SC2_W2_WR(i)                                                                                                        \
     lds_write16_imm<(i) * 256>(img_wr, u32x4_t{pack2(acc[i][0][0], acc[i][0][1]), pack2(acc[i][0][2], acc[i][0][3]),      \
@@ -315,45 +346,129 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     {                                                                                      \
         const uint4 b0 = bq[(S) & 3][0], b1 = bq[(S) & 3][1];                              \
         fetch_b(KT + (S) + PF, bq[(S) & 3][0], bq[(S) & 3][1]);                            \
-        norm_step<G, OFF>(acc, BASE, b0, b1);                                              \
+        norm_step<G, OFF, !TAIL>(acc, BASE, b0, b1);                                       \
     }
             SC2_W2_NSTEP(0, g_base0, 0 * G::IMG_PLANE) SC2_W2_NSTEP(1, g_base0, 4 * G::IMG_PLANE)
             SC2_W2_NSTEP(2, g_base0, 8 * G::IMG_PLANE) SC2_W2_NSTEP(3, g_base0, 12 * G::IMG_PLANE)
             SC2_W2_NSTEP(4, g_base1, 0 * G::IMG_PLANE) SC2_W2_NSTEP(5, g_base1, 4 * G::IMG_PLANE)
             SC2_W2_NSTEP(6, g_base1, 8 * G::IMG_PLANE) SC2_W2_NSTEP(7, g_base1, 12 * G::IMG_PLANE)
 #undef SC2_W2_NSTEP
-            // y = x * (beta + norm)  (inverse)  or  x / (beta + norm); x from this lane's own image slots.  (beta is fetched per
-            // tile: 32 bytes per lane out of L2; kept in registers across the K loop it was spilled to scratch)
-            const float4 beta_lo = *reinterpret_cast<const float4 *>(p.beta + 32 * wave + 8 * fqo);
-            const float4 beta_hi = *reinterpret_cast<const float4 *>(p.beta + 32 * wave + 8 * fqo + 4);
-            u32x4_t xr[MT];
-#define SC2_W2_RD(i) xr[i] = lds_read16_imm<(i) * 256>(img_wr);
-            SC2_W2_RD(0) SC2_W2_RD(1) SC2_W2_RD(2) SC2_W2_RD(3) SC2_W2_RD(4) SC2_W2_RD(5) SC2_W2_RD(6)
-            SC2_W2_RD(7) SC2_W2_RD(8) SC2_W2_RD(9) SC2_W2_RD(10) SC2_W2_RD(11) SC2_W2_RD(12) SC2_W2_RD(13)
-#undef SC2_W2_RD
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]),
-                         "+v"(xr[7]), "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13])::"memory");
+            if constexpr (TAIL) {
+                // ---- o1 = relu(W1 y + bias1): waves 0-3 hold channels 32 w + 8 fq + [0, 8) (the stream's rows 128-255 are zero);
+                // waves 4-7 issue the same 14 stores out of range (a fixed number of stores per wave and tile)
+                {
+                    const bool mine = wave < 4;
+                    const float4 b_lo = *reinterpret_cast<const float4 *>(p.bias1 + (mine ? 32 * wave : 0) + 8 * fqo);
+                    const float4 b_hi = *reinterpret_cast<const float4 *>(p.bias1 + (mine ? 32 * wave : 0) + 8 * fqo + 4);
+                    const uint32_t o_so = (uint32_t)((img * OH + oh0) * OW) * 256u;
+                    const uint32_t o_vo = (uint32_t)(fr * 256 + (32 * wave + 8 * fqo) * 2);   // + i * 4096
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const float xv[8] = {__builtin_bit_cast(float, xr[i][0] << 16), __builtin_bit_cast(float, xr[i][0] & 0xFFFF0000u),
-                                     __builtin_bit_cast(float, xr[i][1] << 16), __builtin_bit_cast(float, xr[i][1] & 0xFFFF0000u),
-                                     __builtin_bit_cast(float, xr[i][2] << 16), __builtin_bit_cast(float, xr[i][2] & 0xFFFF0000u),
-                                     __builtin_bit_cast(float, xr[i][3] << 16), __builtin_bit_cast(float, xr[i][3] & 0xFFFF0000u)};
-                const float nm[8] = {beta_lo.x + acc[i][0][0], beta_lo.y + acc[i][0][1], beta_lo.z + acc[i][0][2], beta_lo.w + acc[i][0][3],
-                                     beta_hi.x + acc[i][1][0], beta_hi.y + acc[i][1][1], beta_hi.z + acc[i][1][2], beta_hi.w + acc[i][1][3]};
-                float r[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) r[e] = INVERSE ? xv[e] * nm[e] : xv[e] * (1.0f / nm[e]);
-                if (p.dbg == 1) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = xv[e];
-                } else if (p.dbg == 2) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) r[e] = nm[e];
+                    for (int i = 0; i < MT; ++i) {
+                        const float r[8] = {fmaxf(acc[i][0][0] + b_lo.x, 0.f), fmaxf(acc[i][0][1] + b_lo.y, 0.f), fmaxf(acc[i][0][2] + b_lo.z, 0.f),
+                                            fmaxf(acc[i][0][3] + b_lo.w, 0.f), fmaxf(acc[i][1][0] + b_hi.x, 0.f), fmaxf(acc[i][1][1] + b_hi.y, 0.f),
+                                            fmaxf(acc[i][1][2] + b_hi.z, 0.f), fmaxf(acc[i][1][3] + b_hi.w, 0.f)};
+                        const int ml = i * 16 + fr;
+                        buf_store16(rs_o1, (mine & (ml < px_valid)) ? o_vo + (uint32_t)i * 4096u : OOB, o_so,
+                                    u32x4_t{pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7])});
+                    }
                 }
-                const int ml = i * 16 + fr;
-                buf_store16(rs_y, ml < px_valid ? y_vo + (uint32_t)i * 8192u : OOB, y_so,
-                            u32x4_t{pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7])});
+                // ---- y itself, if the caller wants it (read back from the image: the accumulators are gone)
+                if (p.y != nullptr) {
+                    u32x4_t xr[MT];
+#define SC2_W2_RD(i) xr[i] = lds_read16_imm<(i) * 256>(img_wr);
+                    SC2_W2_RD(0) SC2_W2_RD(1) SC2_W2_RD(2) SC2_W2_RD(3) SC2_W2_RD(4) SC2_W2_RD(5) SC2_W2_RD(6)
+                    SC2_W2_RD(7) SC2_W2_RD(8) SC2_W2_RD(9) SC2_W2_RD(10) SC2_W2_RD(11) SC2_W2_RD(12) SC2_W2_RD(13)
+#undef SC2_W2_RD
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]),
+                                 "+v"(xr[7]), "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13])::"memory");
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const int ml = i * 16 + fr;
+                        buf_store16(rs_y, ml < px_valid ? y_vo + (uint32_t)i * 8192u : OOB, y_so, xr[i]);
+                    }
+                }
+                // ---- ods = Wds y[::2, ::2] + bias_ds: two passes of 256 output channels over the tile's 56 even pixels
+                const uint32_t d_so = (uint32_t)((img * (OH / 2) + oh0 / 2) * (OW / 2)) * 1024u;
+                uint32_t ds_lo[4], ds_hi[4];   // image rows of the even pixels (row 2 r', column 2 c'); computed here, per tile: held
+#pragma unroll                                 // across the K loop they were spilled
+                for (int i = 0; i < 4; ++i) {
+                    int m = i * 16 + fr;
+                    m = m < 2 * (OW / 2) ? m : 0;
+                    const int r2 = m / (OW / 2), c2 = m - r2 * (OW / 2);
+                    ds_lo[i] = lds_base + (uint32_t)(G::IMG0 + fqo * G::IMG_PLANE + (2 * r2 * OW + 2 * c2) * 16);
+                    ds_hi[i] = ds_lo[i] + 16u * G::IMG_PLANE;
+                }
+#define SC2_W2_DSTEP(S, BASE, OFF)                                                         \
+    {                                                                                      \
+        const uint4 b0 = bq[(S) & 3][0], b1 = bq[(S) & 3][1];                              \
+        fetch_b(KT + (S) + PF, bq[(S) & 3][0], bq[(S) & 3][1]);                            \
+        ds_step<OFF>(acc, BASE, b0, b1);                                                   \
+    }
+#define SC2_W2_DPASS(PASS)                                                                                                   \
+    {                                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
+            acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};                                                                         \
+            acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};                                                                         \
+        }                                                                                                                    \
+        SC2_W2_DSTEP(8 + 8 * PASS + 0, ds_lo, 0 * G::IMG_PLANE) SC2_W2_DSTEP(8 + 8 * PASS + 1, ds_lo, 4 * G::IMG_PLANE)      \
+        SC2_W2_DSTEP(8 + 8 * PASS + 2, ds_lo, 8 * G::IMG_PLANE) SC2_W2_DSTEP(8 + 8 * PASS + 3, ds_lo, 12 * G::IMG_PLANE)     \
+        SC2_W2_DSTEP(8 + 8 * PASS + 4, ds_hi, 0 * G::IMG_PLANE) SC2_W2_DSTEP(8 + 8 * PASS + 5, ds_hi, 4 * G::IMG_PLANE)      \
+        SC2_W2_DSTEP(8 + 8 * PASS + 6, ds_hi, 8 * G::IMG_PLANE) SC2_W2_DSTEP(8 + 8 * PASS + 7, ds_hi, 12 * G::IMG_PLANE)     \
+        const float4 b_lo = *reinterpret_cast<const float4 *>(p.bias_ds + 256 * PASS + 32 * wave + 8 * fqo);                 \
+        const float4 b_hi = *reinterpret_cast<const float4 *>(p.bias_ds + 256 * PASS + 32 * wave + 8 * fqo + 4);             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
+            const int m2 = i * 16 + fr;                                                                                      \
+            const int r2 = m2 / (OW / 2), c2 = m2 - r2 * (OW / 2);                                                           \
+            const bool ok = (m2 < 2 * (OW / 2)) & (2 * r2 < rows_valid);                                                     \
+            const uint32_t vo = (uint32_t)((r2 * (OW / 2) + c2) * 1024 + (256 * PASS + 32 * wave + 8 * fqo) * 2);            \
+            buf_store16(rs_ods, ok ? vo : OOB, d_so,                                                                         \
+                        u32x4_t{pack2(acc[i][0][0] + b_lo.x, acc[i][0][1] + b_lo.y), pack2(acc[i][0][2] + b_lo.z, acc[i][0][3] + b_lo.w), \
+                                pack2(acc[i][1][0] + b_hi.x, acc[i][1][1] + b_hi.y), pack2(acc[i][1][2] + b_hi.z, acc[i][1][3] + b_hi.w)}); \
+        }                                                                                                                    \
+    }
+                SC2_W2_DPASS(0)
+                SC2_W2_DPASS(1)
+#undef SC2_W2_DPASS
+#undef SC2_W2_DSTEP
+            } else {
+                // y = x * (beta + norm)  (inverse)  or  x / (beta + norm); x from this lane's own image slots.  (beta is fetched per
+                // tile: 32 bytes per lane out of L2; kept in registers across the K loop it was spilled to scratch)
+                const float4 beta_lo = *reinterpret_cast<const float4 *>(p.beta + 32 * wave + 8 * fqo);
+                const float4 beta_hi = *reinterpret_cast<const float4 *>(p.beta + 32 * wave + 8 * fqo + 4);
+                // (two batches of seven row tiles: with all fourteen read-backs live the forward-GDN form, whose divisions need more
+                //  temporaries, spilled)
+#define SC2_W2_FIN(i0)                                                                                                              \
+    {                                                                                                                               \
+        u32x4_t xr[7];                                                                                                              \
+        xr[0] = lds_read16_imm<((i0) + 0) * 256>(img_wr); xr[1] = lds_read16_imm<((i0) + 1) * 256>(img_wr);                         \
+        xr[2] = lds_read16_imm<((i0) + 2) * 256>(img_wr); xr[3] = lds_read16_imm<((i0) + 3) * 256>(img_wr);                         \
+        xr[4] = lds_read16_imm<((i0) + 4) * 256>(img_wr); xr[5] = lds_read16_imm<((i0) + 5) * 256>(img_wr);                         \
+        xr[6] = lds_read16_imm<((i0) + 6) * 256>(img_wr);                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                         \
+                     : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6])::"memory");         \
+        _Pragma("unroll") for (int k = 0; k < 7; ++k) {                                                                             \
+            const int i = (i0) + k;                                                                                                 \
+            const float xv[8] = {__builtin_bit_cast(float, xr[k][0] << 16), __builtin_bit_cast(float, xr[k][0] & 0xFFFF0000u),      \
+                                 __builtin_bit_cast(float, xr[k][1] << 16), __builtin_bit_cast(float, xr[k][1] & 0xFFFF0000u),      \
+                                 __builtin_bit_cast(float, xr[k][2] << 16), __builtin_bit_cast(float, xr[k][2] & 0xFFFF0000u),      \
+                                 __builtin_bit_cast(float, xr[k][3] << 16), __builtin_bit_cast(float, xr[k][3] & 0xFFFF0000u)};     \
+            const float nm[8] = {beta_lo.x + acc[i][0][0], beta_lo.y + acc[i][0][1], beta_lo.z + acc[i][0][2], beta_lo.w + acc[i][0][3], \
+                                 beta_hi.x + acc[i][1][0], beta_hi.y + acc[i][1][1], beta_hi.z + acc[i][1][2], beta_hi.w + acc[i][1][3]}; \
+            float r[8];                                                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) r[e] = INVERSE ? xv[e] * nm[e] : xv[e] * (1.0f / nm[e]);                  \
+            if (p.dbg == 1) {                                                                                                       \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) r[e] = xv[e];                                                         \
+            } else if (p.dbg == 2) {                                                                                                \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) r[e] = nm[e];                                                         \
+            }                                                                                                                       \
+            const int ml = i * 16 + fr;                                                                                             \
+            buf_store16(rs_y, ml < px_valid ? y_vo + (uint32_t)i * 8192u : OOB, y_so,                                               \
+                        u32x4_t{pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7])});                       \
+        }                                                                                                                           \
+    }
+                SC2_W2_FIN(0)
+                SC2_W2_FIN(7)
+#undef SC2_W2_FIN
             }
         } else {
 #pragma unroll
@@ -369,12 +484,12 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
 
 int g_cus_w2 = 0;
 
-template <class G, bool FUSE, bool INVERSE = true>
+template <class G, int MODE, bool INVERSE = true>
 int launch_w2(W2Args a, hipStream_t s) {
-    constexpr int LDS = FUSE ? G::LDS_FUSED : G::LDS_PLAIN;
+    constexpr int LDS = MODE != 0 ? G::LDS_FUSED : G::LDS_PLAIN;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2x2_win_kernel<G, FUSE, INVERSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2x2_win_kernel<G, MODE, INVERSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS);
         attr_set = true;
     }
@@ -399,7 +514,7 @@ int launch_w2(W2Args a, hipStream_t s) {
     a.tiles_per_wg = run;
     int grid = (a.n_tiles + run - 1) / run;
     grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL((conv2x2_win_kernel<G, FUSE, INVERSE>), dim3(grid), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((conv2x2_win_kernel<G, MODE, INVERSE>), dim3(grid), dim3(512), LDS, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -441,7 +556,36 @@ extern "C" int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const floa
         a.dbg = dbg ? atoi(dbg) : 0;
     }
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
+    a.bias1 = nullptr; a.bias_ds = nullptr; a.o1 = nullptr; a.ods = nullptr; a.o1_bytes = 0; a.ods_bytes = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (pad == 0) return !fused ? launch_w2<Gd2, false>(a, s) : inverse ? launch_w2<Gd2, true, true>(a, s) : launch_w2<Gd2, true, false>(a, s);
-    return !fused ? launch_w2<Gd4, false>(a, s) : inverse ? launch_w2<Gd4, true, true>(a, s) : launch_w2<Gd4, true, false>(a, s);
+    if (pad == 0) return !fused ? launch_w2<Gd2, 0>(a, s) : inverse ? launch_w2<Gd2, 1, true>(a, s) : launch_w2<Gd2, 1, false>(a, s);
+    return !fused ? launch_w2<Gd4, 0>(a, s) : inverse ? launch_w2<Gd4, 1, true>(a, s) : launch_w2<Gd4, 1, false>(a, s);
+}
+
+extern "C" int sc2_conv2x2_win_tail_supported(int H, int W, int Cin) {
+    return sc2_conv2x2_win_supported(H, W, Cin, 256, 1) && H == 55 && W == 55 ? 1 : 0;
+}
+
+extern "C" int sc2_conv2x2_win_tail_fwd(const void *x, const void *w_stream, const float *bias1, const float *bias_ds, void *y,
+                                        void *o1, void *ods, int N, int H, int W, int Cin, void *stream) {
+    SC2_REQUIRE(x && w_stream && bias1 && bias_ds && o1 && ods, SC2_ERR_INVALID_ARG, "conv2x2_win_tail: null argument");
+    SC2_REQUIRE(N > 0, SC2_ERR_INVALID_ARG, "conv2x2_win_tail: non-positive batch");
+    SC2_REQUIRE(sc2_conv2x2_win_tail_supported(H, W, Cin), SC2_ERR_UNSUPPORTED,
+                "conv2x2_win_tail: needs a 55 x 55 input (56 x 56 output), Cin %% 64 == 0 (got %d x %d, Cin %d)", H, W, Cin);
+    const long long x_bytes = (long long)N * H * W * Cin * 2, y_bytes = (long long)N * 56 * 56 * 512;
+    SC2_REQUIRE(x_bytes < 0x7FF00000LL && y_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv2x2_win_tail: tensor of %lld bytes exceeds 2 GB",
+                x_bytes > y_bytes ? x_bytes : y_bytes);
+    W2Args a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_stream);
+    a.beta = nullptr;
+    a.y = static_cast<uint16_t *>(y);
+    a.bias1 = bias1; a.bias_ds = bias_ds;
+    a.o1 = static_cast<uint16_t *>(o1);
+    a.ods = static_cast<uint16_t *>(ods);
+    a.N = N; a.H = H; a.Cin = Cin; a.OH = 56;
+    a.n_tiles = 0; a.tiles_per_img = 0; a.tiles_per_wg = 0; a.dbg = 0;
+    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)((Cin / 32 * 4 + 24) * 16384); a.y_bytes = y ? (unsigned)y_bytes : 0u;
+    a.o1_bytes = (unsigned)((long long)N * 56 * 56 * 256); a.ods_bytes = (unsigned)((long long)N * 28 * 28 * 1024);
+    return launch_w2<Gd4, 2>(a, static_cast<hipStream_t>(stream));
 }

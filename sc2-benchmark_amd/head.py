@@ -51,6 +51,7 @@ class _Conv(object):
             self.w_frag = hip.pack_weight_fragments(w_folded.reshape(w_folded.shape[0], w_folded.shape[1]))
         # 3x3 stride-1 layers on 28 / 14 / 7 pixel maps (conv2 of every block at the 224 x 224 operating point): the
         # window-plane kernel; other map sizes stay on the implicit-GEMM tile kernel (decided per call, by the map size)
+        self.w2d = w_folded.reshape(w_folded.shape[0], w_folded.shape[1]).to(torch.bfloat16) if self.k == (1, 1) else None
         self.w_win = None
         if hip.conv3x3_win_supported(14, 14, conv.in_channels, conv.out_channels, self.k[0], self.k[1], self.stride, self.pad,
                                      conv.dilation):
@@ -121,10 +122,27 @@ class HipHead(object):
                 b[:fc.out_features] = fc.bias.detach().float()
             self.fc = (hip.pack_conv_weight(w), b.contiguous(), cout_pad, fc.out_features)
 
-    def forward(self, x_nhwc, with_pool=True):
-        """x_nhwc: bf16 [N,H,W,C] -> logits f32 [N,classes] (or pooled / feature map if the model skips them)."""
+    def tail_spec(self):
+        """(W1 [128, 256], bias1, Wds [512, 256], bias_ds) of the first block when it is layer2.0 of a ResNet-50 tail (conv1 1x1
+        256 -> 128 stride 1, downsample 1x1 256 -> 512 stride 2) -- the two layers `sc2_conv2x2_win_tail_fwd` can take along
+        with the last decoder conv; else None."""
+        c1, _, _, ds = self.blocks[0]
+        if ds is None or c1.w2d is None or ds.w2d is None:
+            return None
+        if tuple(c1.w2d.shape) != (128, 256) or c1.stride != (1, 1) or tuple(ds.w2d.shape) != (512, 256) or ds.stride != (2, 2):
+            return None
+        return c1.w2d, c1.b, ds.w2d, ds.b
+
+    def forward(self, x_nhwc, with_pool=True, pre=None):
+        """x_nhwc: bf16 [N,H,W,C] -> logits f32 [N,classes] (or pooled / feature map if the model skips them).
+        pre = (conv1 output, downsample output) of the first block when the decoder's last launch produced them."""
         h = x_nhwc
-        for c1, c2, c3, ds in self.blocks:
+        for bi, (c1, c2, c3, ds) in enumerate(self.blocks):
+            if bi == 0 and pre is not None:
+                o, identity = pre
+                o = c2(o, hip.EPI_BIAS_RELU)
+                h = c3(o, hip.EPI_BIAS_ADD_RELU, ep_x=identity)
+                continue
             identity = h if ds is None else ds(h, hip.EPI_BIAS)
             o = c1(h, hip.EPI_BIAS_RELU)
             o = c2(o, hip.EPI_BIAS_RELU)

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -79,6 +79,8 @@ def lib():
     L.sc2_conv3x3_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2x2_win_supported.argtypes = [i32, i32, i32, i32, i32]
     L.sc2_conv2x2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv2x2_win_tail_supported.argtypes = [i32, i32, i32]
+    L.sc2_conv2x2_win_tail_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
@@ -610,6 +612,44 @@ def pack_conv2x2_win(w, gamma=None):
         assert tuple(gamma.shape) == (w.shape[0], w.shape[0])
         parts.append(pack_conv_win(gamma.reshape(gamma.shape[0], gamma.shape[1], 1, 1)))
     return torch.cat(parts).contiguous()
+
+
+def conv2x2_win_tail_supported(x_shape):
+    """True if the last decoder conv can take the head's first two 1x1 layers with it (55 x 55 input, sc2_conv2x2_win_tail_fwd)."""
+    if os.environ.get('SC2_CONV2X2_WIN', '1') == '0' or os.environ.get('SC2_W2_TAIL', '1') == '0':      # A/B switches (tools/)
+        return False
+    N, H, W, Cin = x_shape
+    if N * 56 * 56 * 256 * 2 >= 0x7FF00000 or N * H * W * Cin * 2 >= 0x7FF00000:
+        return False
+    return bool(lib().sc2_conv2x2_win_tail_supported(H, W, Cin))
+
+
+def pack_conv2x2_win_tail(w, w1, wds):
+    """Weight stream of sc2_conv2x2_win_tail_fwd: conv [256, Cin, 2, 2], then W1 [128, 256] (zero rows 128..255), then the two
+    256-row halves of Wds [512, 256] as 1x1 layers."""
+    assert tuple(w1.shape) == (128, 256) and tuple(wds.shape) == (512, 256) and w.shape[0] == 256
+    w1p = torch.cat([w1, torch.zeros_like(w1)]).reshape(256, 256, 1, 1)
+    parts = [pack_conv_win(w), pack_conv_win(w1p), pack_conv_win(wds[:256].reshape(256, 256, 1, 1)),
+             pack_conv_win(wds[256:].reshape(256, 256, 1, 1))]
+    return torch.cat(parts).contiguous()
+
+
+def conv2x2_win_tail_fwd(x_nhwc, w_stream, bias1, bias_ds, want_y=False, tag=None):
+    """-> (o1 [N,56,56,128], ods [N,28,28,512], y [N,56,56,256] or None); see include/sc2_bottleneck.h."""
+    for t, name in ((x_nhwc, 'x'), (w_stream, 'w_stream'), (bias1, 'bias1'), (bias_ds, 'bias_ds')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, Cin = x_nhwc.shape
+    assert w_stream.dtype == torch.bfloat16 and w_stream.is_contiguous() and tuple(w_stream.shape) == (Cin // 32 * 4 + 24, 16, 64, 8)
+    assert bias1.dtype == torch.float32 and bias1.numel() == 128 and bias_ds.dtype == torch.float32 and bias_ds.numel() == 512
+    dev = x_nhwc.device
+    o1 = torch.empty((N, 56, 56, 128), dtype=torch.bfloat16, device=dev)
+    ods = torch.empty((N, 28, 28, 512), dtype=torch.bfloat16, device=dev)
+    y = torch.empty((N, 56, 56, 256), dtype=torch.bfloat16, device=dev) if want_y else None
+    with _timed(tag or 'conv2x2_win_tail'):
+        _check(lib().sc2_conv2x2_win_tail_fwd(_ptr(x_nhwc), _ptr(w_stream), _ptr(bias1), _ptr(bias_ds), _ptr(y) if want_y else None,
+                                              _ptr(o1), _ptr(ods), N, H, W, Cin, _stream()), 'conv2x2_win_tail_fwd')
+    return o1, ods, y
 
 
 def conv2x2_win_fwd(x_nhwc, w_frag, pad, beta=None, inverse=True, tag=None):

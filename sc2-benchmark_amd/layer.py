@@ -223,7 +223,41 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         latent = c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
         return latent if symbols_for is None else symbols_for.quantize(latent, 'symbols', self._get_means(latent))
 
-    def synthesis_nhwc(self, y_hat_nhwc):
+    def synthesis_nhwc_tail(self, y_hat_nhwc, head):
+        """decoder on a bf16 NHWC latent WITH the first two 1x1 layers of the HIP task head `head` (layer2.0's conv1 and
+        downsample) fused behind its last conv: -> (None, (conv1 output, downsample output)) for `HipHead.forward(pre=...)`, or
+        (decoder output, None) when the geometry is not the 224 x 224 operating point, or None when `head` has no such
+        block.  In the fused case the decoder's own output is never materialised."""
+        spec = head.tail_spec()
+        c4 = self._g_s()[4]
+        if spec is None or c4.bias is not None or tuple(c4.kernel_size) != (2, 2) or c4.out_channels != 256:
+            return None
+        h = self.synthesis_nhwc(y_hat_nhwc, upto_last=True)
+        if not hip.conv2x2_win_tail_supported(tuple(h.shape)) or tuple(c4.padding) != (1, 1):
+            return self._last_conv(h), None
+        key = (c4.weight._version, c4.weight.data_ptr(), id(head))
+        cache = self.__dict__.setdefault('_tail_cache', {})
+        if cache.get('key') != key:
+            w1, b1, wds, bds = spec
+            with torch.no_grad():
+                cache['val'] = (hip.pack_conv2x2_win_tail(c4.weight.detach(), w1, wds), b1, bds)
+            cache['key'] = key
+        stream, b1, bds = cache['val']
+        o1, ods, _ = hip.conv2x2_win_tail_fwd(h, stream, b1, bds, tag=c4._tag + '+head.2.0')
+        return None, (o1, ods)
+
+    def _last_conv(self, h):
+        c4 = self._g_s()[4]
+        if self.output_format == 'bf16_nhwc':
+            if c4.bias is None and hip.conv2x2_win_supported(tuple(h.shape), c4.out_channels, c4.kernel_size[0], c4.kernel_size[1],
+                                                             c4.stride, c4.padding):
+                out = hip.conv2x2_win_fwd(h, self._win_weights(c4, None)[1], c4.padding[0], tag=c4._tag)
+            else:
+                out = c4.forward_nhwc(h, out_format=hip.OUT_BF16_NHWC)
+            return out.permute(0, 3, 1, 2)  # logical NCHW, channels_last memory
+        return c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
+
+    def synthesis_nhwc(self, y_hat_nhwc, upto_last=False):
         """decoder on a bf16 NHWC latent (layer.py:485-493); output per ``self.output_format``."""
         c0, g1, c2, g3, c4 = self._g_s()
         if (self.fuse_gdn and g1.in_channels == c0.out_channels and
@@ -252,14 +286,9 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         else:
             h = c2.forward_nhwc(h)
             h = g3.forward_nhwc(h)
-        if self.output_format == 'bf16_nhwc':
-            if c4.bias is None and hip.conv2x2_win_supported(tuple(h.shape), c4.out_channels, c4.kernel_size[0], c4.kernel_size[1],
-                                                             c4.stride, c4.padding):
-                out = hip.conv2x2_win_fwd(h, self._win_weights(c4, None)[1], c4.padding[0], tag=c4._tag)
-            else:
-                out = c4.forward_nhwc(h, out_format=hip.OUT_BF16_NHWC)
-            return out.permute(0, 3, 1, 2)  # logical NCHW, channels_last memory
-        return c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
+        if upto_last:
+            return h
+        return self._last_conv(h)
 
     def _win_weights(self, conv, gdn):
         """(beta, weight stream) of sc2_conv2x2_win_fwd for `conv` [+ the GDN1 behind it]; cached per parameter version."""
@@ -436,6 +465,9 @@ class SHPBasedResNetBottleneck(BaseBottleneck):
     _uses_pair_conv0 = FPBasedResNetBottleneck._uses_pair_conv0
     analysis = FPBasedResNetBottleneck.analysis
     synthesis_nhwc = FPBasedResNetBottleneck.synthesis_nhwc
+    _win_weights = FPBasedResNetBottleneck._win_weights
+    synthesis_nhwc_tail = FPBasedResNetBottleneck.synthesis_nhwc_tail
+    _last_conv = FPBasedResNetBottleneck._last_conv
     synthesis = FPBasedResNetBottleneck.synthesis
     _hyper_abs = True       # h_a sees |y| (layer.py:641,675)
 

@@ -624,6 +624,36 @@ def test_conv2x2_win(S, dev, monkeypatch, cin, pad, N, H, fused, inverse, run):
         'window-plane decoder kernel differs from the tile kernel in {} elements'.format(int((out != ref).sum()))
 
 
+@pytest.mark.parametrize('N,run,want_y', [(3, 0, True), (2, 5, False), (5, 3, True)])
+def test_conv2x2_win_tail(S, dev, monkeypatch, N, run, want_y):
+    """The last decoder conv with layer2.0's conv1 (+ folded BN + ReLU) and downsample (+ folded BN, stride 2) fused behind it
+    (sc2_conv2x2_win_tail_fwd) against the three separate launches: BIT-IDENTICAL, over run lengths and repeated launches."""
+    if run:
+        monkeypatch.setenv('SC2_W2_RUN', str(run))
+    g = torch.Generator().manual_seed(N * 7 + run)
+    x = torch.randn(N, 256, 55, 55, generator=g)
+    w4 = torch.randn(256, 256, 2, 2, generator=g) / 32.0
+    w1 = (torch.randn(128, 256, generator=g) / 16.0)
+    wds = (torch.randn(512, 256, generator=g) / 16.0)
+    b1, bds = torch.randn(128, generator=g), torch.randn(512, generator=g)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    assert S.hip.conv2x2_win_tail_supported(tuple(x_nhwc.shape))
+    assert not S.hip.conv2x2_win_tail_supported((N, 56, 56, 256))
+    h = S.hip.conv2x2_win_fwd(x_nhwc, S.hip.pack_conv2x2_win(w4.to(dev)), 1)
+    ref1 = S.hip.conv1x1_stream_fwd(h, S.hip.pack_weight_fragments(w1.to(dev)), b1.to(dev), stride=1, relu=True)
+    refd = S.hip.conv1x1_stream_fwd(h, S.hip.pack_weight_fragments(wds.to(dev)), bds.to(dev), stride=2, relu=False)
+    stream = S.hip.pack_conv2x2_win_tail(w4.to(dev), w1.to(dev).to(torch.bfloat16), wds.to(dev).to(torch.bfloat16))
+    for _ in range(3):
+        o1, ods, y = S.hip.conv2x2_win_tail_fwd(x_nhwc, stream, b1.to(dev), bds.to(dev), want_y=want_y)
+        assert o1.shape == ref1.shape and ods.shape == refd.shape
+        assert torch.equal(o1.view(torch.int16), ref1.view(torch.int16)), 'conv1: {} elements differ'.format(int((o1 != ref1).sum()))
+        assert torch.equal(ods.view(torch.int16), refd.view(torch.int16)), 'downsample: {} elements differ'.format(int((ods != refd).sum()))
+        if want_y:
+            assert torch.equal(y.view(torch.int16), h.view(torch.int16))
+        else:
+            assert y is None
+
+
 def test_persistent_encoder_kernels_many_units(S, R, dev):
     """More units than resident workgroups can take statically: every workgroup of the two persistent encoder kernels
     goes through several dynamic claims (a stale claim register once made this an endless loop).  Device-only check
