@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 27
+#define SC2_ABI_VERSION 28
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -186,6 +186,15 @@ int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, v
 int sc2_conv3x3_win_supported(int H, int W, int Cin, int Cout);
 int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
                         int relu, void *stream);
+
+/* The stride-2 form of the same kernel: conv2 + bn2 + ReLU of layer2.0 / layer3.0 / layer4.0 (3x3, stride 2, pad 1; torchvision
+ * puts the stride on conv2), 56 -> 28, 28 -> 14, 14 -> 7 at the 224 x 224 operating point (sc2bench/models/backbone.py:235-254).
+ * The window is stored in four parity classes so that the nine taps stay immediate offsets (conv3x3_win.hip, GeoS2).
+ *   x : bf16 NHWC [N,H,W,Cin], H == W in {56, 28, 14}, Cin % 32 == 0;   y : bf16 NHWC [N,H/2,W/2,Cout], Cout % 128 == 0
+ *   w_frag, bias, relu : as sc2_conv3x3_win_fwd. */
+int sc2_conv3x3s2_win_supported(int H, int W, int Cin, int Cout);
+int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
+                          int relu, void *stream);
 
 /* The two MFMA-bound decoder convolutions of the FP / SHP / MSHP bottlenecks on the window-plane structure, with the
  * inverse GDN1 that follows the first one fused in (sc2bench/models/layer.py:489-493: Conv2d(512 -> 256, k2, p0) + GDN1(256,

@@ -93,6 +93,36 @@ struct Geo {
     static_assert(H % ROWS == 0 && (IMGS == 1 || ROWS == H), "whole rows of one image, or whole images");
     static_assert(PLANE % 256 == 0 && MT == 13, "13 row tiles, bank-aligned planes");
     static_assert(WIN_BYTES + (2 * PWD + 2) * 16 < 65536, "tap offsets are 16-bit immediates");
+    static constexpr int tap_off(int tap) { return ((tap / 3) * PWD + tap % 3) * 16; }   // bytes from tap (0, 0)'s fragment row
+};
+
+// Stride 2 (pad 1): the input pixel of output (oh, ow) at tap (kh, kw) is (2 oh + kh - 1, 2 ow + kw - 1).  In padded window
+// coordinates (ihp, iwp) = (2 ohl + kh, 2 ow + kw) the PARITY of a position is a property of the tap alone, so the window is
+// stored as four parity classes [(ihp & 1, iwp & 1)][ihp >> 1][iwp >> 1]: inside a class, neighbouring output pixels are
+// neighbouring window rows again and tap (kh, kw) is the constant distance
+//     ((kh & 1) * 2 + (kw & 1)) * CLS + (kh >> 1) * PWD + (kw >> 1)      window rows
+// from tap (0, 0) -- immediates, as for stride 1.  OW: OUTPUT map width = height (the input map is 2 OW wide).
+template <int OW_, int ROWS_, int IMGS_>
+struct GeoS2 {
+    static constexpr int OW = OW_, OH = OW_, W = 2 * OW_, H = 2 * OW_, ROWS = ROWS_, IMGS = IMGS_;
+    static constexpr int TILES_PER_IMG = OH / ROWS;
+    static constexpr int PWD = OW + 1;                           // class row pitch (iwp >> 1 in [0, OW])
+    static constexpr int CLS = (ROWS + 1) * PWD;                 // window rows per parity class (ihp >> 1 in [0, ROWS])
+    static constexpr int IMGP = 4 * CLS;
+    static constexpr int WROWS = IMGS * IMGP;
+    static constexpr int NRG = (WROWS + 63) / 64;
+    static constexpr int PLANE = NRG * 64 * 16;
+    static constexpr int WIN_BYTES = 4 * PLANE;
+    static constexpr int PX = IMGS * ROWS * OW;
+    static constexpr int MT = (PX + 15) / 16;
+    static constexpr int LDS_BYTES = WIN_BYTES;                  // ONE window (60 - 64 KB): two workgroups per CU
+    static_assert(OH % ROWS == 0 && (IMGS == 1 || ROWS == OH), "whole rows of one image, or whole images");
+    static_assert(PLANE % 256 == 0 && MT == 13, "13 row tiles, bank-aligned planes");
+    static_assert(4 * CLS * 16 < 65536, "tap offsets are 16-bit immediates");
+    static constexpr int tap_off(int tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        return (((kh & 1) * 2 + (kw & 1)) * CLS + (kh >> 1) * PWD + (kw >> 1)) * 16;
+    }
 };
 
 constexpr int PF = 3;   // weight fragments are fetched this many k-steps ahead (18 k-steps per loop trip: 18 % PF == 0)
@@ -100,7 +130,7 @@ constexpr int PF = 3;   // weight fragments are fetched this many k-steps ahead 
 template <class G, int PAR, int TAP, int DBG>
 __device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t (&a_base)[G::MT], const uint4 &b0, const uint4 &b1) {
     constexpr int MT = G::MT;
-    constexpr int OFF = PAR * G::WIN_BYTES + ((TAP / 3) * G::PWD + TAP % 3) * 16;
+    constexpr int OFF = PAR * G::WIN_BYTES + G::tap_off(TAP);
     u32x4_t av[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -296,11 +326,179 @@ int launch_win(WinArgs a, hipStream_t s) {
     return SC2_OK;
 }
 
+// Stride-2 form (conv2 of layer2.0 / layer3.0 / layer4.0: 56 -> 28, 28 -> 14, 14 -> 7): the same tile (196 output pixels x 128
+// channels, wave w = 32 channels x 13 row tiles), the same k_step, the window in parity classes (GeoS2).  A stride-2 window
+// holds 4x the pixels of its output tile (60 - 64 KB per 32-channel slab), so it is SINGLE-buffered and two workgroups share a
+// CU: while one waits for its next window the other has the matrix pipes (a slab is 234 MFMAs per wave = 3.7 k cycles against
+// ~2 k cycles to land 60 KB).  Two barriers per slab: everybody done with window cb - 1 / window cb complete.
+template <class G>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_win_kernel(const WinArgs p) {
+    constexpr int MT = G::MT, W = G::W, H = G::H, OW = G::OW, OH = G::OH;
+    constexpr uint32_t OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int Cin = p.Cin, Cout = p.Cout;
+    const int NS = Cin >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int chunk = bid % p.n_chunks, mtile = bid / p.n_chunks;
+    const int n0 = chunk * 128 + wave * 32;
+    const int img0 = G::IMGS > 1 ? mtile * G::IMGS : mtile / G::TILES_PER_IMG;
+    const int row0 = G::IMGS > 1 ? 0 : (mtile % G::TILES_PER_IMG) * G::ROWS;   // first OUTPUT row of the tile
+
+    const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
+    const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+
+    // window fill: wave w fills chunk plane w; window row wr = (image, parity class, ihp >> 1, iwp >> 1)
+    uint32_t pw_vo[G::NRG];
+#pragma unroll
+    for (int j = 0; j < G::NRG; ++j) {
+        const int wr = j * 64 + lane;
+        const int il = wr / G::IMGP, rem = wr - il * G::IMGP;
+        const int cls = rem / G::CLS, rem2 = rem - cls * G::CLS;
+        const int r = rem2 / G::PWD, c = rem2 - r * G::PWD;
+        const int img = img0 + il, ih = 2 * (row0 + r) + (cls >> 1) - 1, iw = 2 * c + (cls & 1) - 1;
+        const bool ok = (wr < G::WROWS) & (img < p.N) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+        pw_vo[j] = ok ? (uint32_t)((((img * H + ih) * W + iw) * Cin) * 2 + wave * 16) : OOB;
+    }
+    auto issue_window = [&](int cb) {
+#pragma unroll
+        for (int j = 0; j < G::NRG; ++j)
+            buf_load_lds16(rs_x, (lds_ptr_t)(smem + wave * G::PLANE + j * 1024), pw_vo[j], (uint32_t)cb * 64u);
+    };
+
+    // fragment rows of this lane at tap (0, 0): class (0, 0), (ohl, ow)
+    uint32_t a_base[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = i * 16 + frow;
+        m = m < G::PX ? m : G::PX - 1;
+        const int il = m / (G::ROWS * OW), rem = m - il * (G::ROWS * OW);
+        const int ohl = rem / OW, ow = rem - ohl * OW;
+        a_base[i] = lds_base + (uint32_t)(fq * G::PLANE + (il * G::IMGP + ohl * G::PWD + ow) * 16);
+    }
+
+    const uint32_t b_vo = (uint32_t)(lane * 16);
+    const uint32_t b_step = (uint32_t)(Cout >> 4) * 1024u;
+    const uint32_t KT = (uint32_t)NS * 9u;
+    const uint32_t b_so0 = (uint32_t)(n0 >> 4) * 1024u;
+    auto fetch_b = [&](uint32_t kt, uint4 &b0, uint4 &b1) {
+        const uint32_t so = b_so0 + (kt < KT - 1u ? kt : KT - 1u) * b_step;
+        b0 = buf_load16(rs_w, b_vo, so);
+        b1 = buf_load16(rs_w, b_vo, so + 1024u);
+    };
+
+    f32x4_t acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    uint4 bq[PF][2];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch_b((uint32_t)s, bq[s][0], bq[s][1]);
+
+#define SC2_S2_STEP(cb, TAP, SLOT)                                                     \
+    {                                                                                 \
+        const uint4 b0 = bq[SLOT][0], b1 = bq[SLOT][1];                               \
+        fetch_b((uint32_t)(cb) * 9u + (TAP + PF), bq[SLOT][0], bq[SLOT][1]);          \
+        k_step<G, 0, TAP, 0>(acc, a_base, b0, b1);                                    \
+    }
+    for (int cb = 0; cb < NS; ++cb) {
+        if (cb > 0) __builtin_amdgcn_s_barrier();   // everybody is done with window cb - 1
+        issue_window(cb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();               // window cb complete
+        SC2_S2_STEP(cb, 0, 0) SC2_S2_STEP(cb, 1, 1) SC2_S2_STEP(cb, 2, 2)
+        SC2_S2_STEP(cb, 3, 0) SC2_S2_STEP(cb, 4, 1) SC2_S2_STEP(cb, 5, 2)
+        SC2_S2_STEP(cb, 6, 0) SC2_S2_STEP(cb, 7, 1) SC2_S2_STEP(cb, 8, 2)
+    }
+#undef SC2_S2_STEP
+
+    const float4 bias_lo = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq);
+    const float4 bias_hi = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq + 4);
+    const long long m_base = G::IMGS > 1 ? (long long)img0 * (OH * OW) : ((long long)img0 * OH + row0) * OW;
+    const long long M = (long long)p.N * OH * OW;
+    const bool relu = p.relu != 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int ml = i * 16 + frow;
+        const long long m = m_base + ml;
+        float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
+                      acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        if (ml < G::PX && m < M) *reinterpret_cast<uint4 *>(p.y + m * Cout + n0 + 8 * fq) = o;
+    }
+}
+
+template <class G>
+int launch_win_s2(WinArgs a, hipStream_t s) {
+    a.n_mtiles = G::IMGS > 1 ? (a.N + G::IMGS - 1) / G::IMGS : a.N * G::TILES_PER_IMG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3s2_win_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  G::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3s2_win_kernel<G>), dim3(a.n_mtiles * a.n_chunks), dim3(256), G::LDS_BYTES, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
 typedef Geo<28, 7, 1> G28;
 typedef Geo<14, 14, 1> G14;
 typedef Geo<7, 7, 4> G7;
+typedef GeoS2<28, 7, 1> S28;   // 56 x 56 -> 28 x 28
+typedef GeoS2<14, 14, 1> S14;  // 28 x 28 -> 14 x 14
+typedef GeoS2<7, 7, 4> S7;     // 14 x 14 -> 7 x 7
 
 }  // namespace
+
+extern "C" int sc2_conv3x3s2_win_supported(int H, int W, int Cin, int Cout) {
+    if (H != W || (W != 56 && W != 28 && W != 14)) return 0;
+    return Cin >= 32 && Cin % 32 == 0 && Cout >= 128 && Cout % 128 == 0 ? 1 : 0;
+}
+
+extern "C" int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin,
+                                     int Cout, int relu, void *stream) {
+    SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv3x3s2_win: null argument");
+    SC2_REQUIRE(N > 0, SC2_ERR_INVALID_ARG, "conv3x3s2_win: non-positive batch");
+    SC2_REQUIRE(sc2_conv3x3s2_win_supported(H, W, Cin, Cout), SC2_ERR_UNSUPPORTED,
+                "conv3x3s2_win: needs a 56 x 56, 28 x 28 or 14 x 14 input map, Cin %% 32 == 0, Cout %% 128 == 0 (got %d x %d, %d -> %d)", H,
+                W, Cin, Cout);
+    const long long x_bytes = (long long)N * H * W * Cin * 2, w_bytes = (long long)Cin * 9 * Cout * 2;
+    SC2_REQUIRE(x_bytes < 0x7FF00000LL && w_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv3x3s2_win: operand of %lld bytes exceeds 2 GB",
+                x_bytes > w_bytes ? x_bytes : w_bytes);
+    WinArgs a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_frag);
+    a.bias = bias;
+    a.y = static_cast<uint16_t *>(y);
+    a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
+    a.n_chunks = Cout / 128; a.n_mtiles = 0;
+    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.stamps = nullptr;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (W == 56) return launch_win_s2<S28>(a, s);
+    if (W == 28) return launch_win_s2<S14>(a, s);
+    return launch_win_s2<S7>(a, s);
+}
 
 extern "C" int sc2_conv3x3_win_supported(int H, int W, int Cin, int Cout) {
     if (H != W || (W != 28 && W != 14 && W != 7)) return 0;

@@ -54,7 +54,7 @@ class _Conv(object):
         self.w2d = w_folded.reshape(w_folded.shape[0], w_folded.shape[1]).to(torch.bfloat16) if self.k == (1, 1) else None
         self.w_win = None
         if hip.conv3x3_win_supported(14, 14, conv.in_channels, conv.out_channels, self.k[0], self.k[1], self.stride, self.pad,
-                                     conv.dilation):
+                                     conv.dilation):   # (14 x 14 is a supported map of both the stride-1 and the stride-2 form)
             self.w_win = hip.pack_conv3x3_win(w_folded)
         # Dilated 3x3 layers (DeepLab's layer3 / layer4, torchvision `replace_stride_with_dilation`): a stride-1 conv with
         # dilation d and padding d is d*d independent UNDILATED pad-1 convs on the phase grids x[a::d, b::d] -- the same
@@ -91,7 +91,7 @@ class _Conv(object):
                                         tag=self.tag)
         if self.w_win is not None and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU) and x.numel() * 2 < 0x7FF00000 and \
                 hip.conv3x3_win_supported(x.shape[1], x.shape[2], x.shape[3], self.cout, self.k[0], self.k[1], self.stride, self.pad):
-            return hip.conv3x3_win_fwd(x, self.w_win, self.b, relu=epilogue == hip.EPI_BIAS_RELU, tag=self.tag)
+            return hip.conv3x3_win_fwd(x, self.w_win, self.b, relu=epilogue == hip.EPI_BIAS_RELU, tag=self.tag, stride=self.stride[0])
         return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,
                               ep_x=ep_x, ep_beta=self.b, tag=self.tag, k_order=self.k_order)
 

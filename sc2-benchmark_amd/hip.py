@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -77,6 +77,8 @@ def lib():
     L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3_win_supported.argtypes = [i32, i32, i32, i32]
     L.sc2_conv3x3_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv3x3s2_win_supported.argtypes = [i32, i32, i32, i32]
+    L.sc2_conv3x3s2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2x2_win_supported.argtypes = [i32, i32, i32, i32, i32]
     L.sc2_conv2x2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2x2_win_tail_supported.argtypes = [i32, i32, i32]
@@ -564,12 +566,17 @@ def conv1x1_kres_fwd(x_nhwc, w_frag, bias, stride=1, relu=False, tag=None):
 
 
 def conv3x3_win_supported(h, w, cin, cout, kh, kw, stride, pad, dilation=(1, 1)):
-    """True if this conv runs on the window-plane 3x3 kernel (28 / 14 / 7 pixel maps, stride 1, pad 1)."""
+    """True if this conv runs on the window-plane 3x3 kernel: stride 1, pad 1 on 28 / 14 / 7 pixel maps, or stride 2, pad 1 on
+    56 / 28 / 14 pixel maps (h, w = the INPUT map)."""
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
     if os.environ.get('SC2_CONV_WIN', '1') == '0':      # A/B switch (tools/)
         return False
-    return (kh, kw, sh, sw, ph, pw) == (3, 3, 1, 1, 1, 1) and tuple(dilation) == (1, 1) and \
+    if (kh, kw, ph, pw) != (3, 3, 1, 1) or tuple(dilation) != (1, 1):
+        return False
+    if (sh, sw) == (2, 2):
+        return os.environ.get('SC2_CONV_WIN_S2', '1') != '0' and bool(lib().sc2_conv3x3s2_win_supported(h, w, cin, cout))
+    return (sh, sw) == (1, 1) and \
         bool(lib().sc2_conv3x3_win_supported(h, w, cin, cout))   # (the caller checks the 2 GB operand bound: head._Conv)
 
 
@@ -672,8 +679,8 @@ def conv2x2_win_fwd(x_nhwc, w_frag, pad, beta=None, inverse=True, tag=None):
     return out
 
 
-def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None):
-    """y = act(conv3x3(x, stride 1, pad 1) + bias); bf16 NHWC in / out; w_frag = pack_conv3x3_win(w)."""
+def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None, stride=1):
+    """y = act(conv3x3(x, stride 1 or 2, pad 1) + bias); bf16 NHWC in / out; w_frag = pack_conv3x3_win(w)."""
     for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
         _dev(t, name)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
@@ -681,6 +688,14 @@ def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None):
     cout = w_frag.shape[1] * 16
     assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (Cin // 32 * 9, cout // 16, 64, 8)
     assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
+    stride = int(stride)
+    if stride == 2:
+        out = torch.empty((N, H // 2, W // 2, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+        with _timed(tag or 'conv3x3s2_win'):
+            _check(lib().sc2_conv3x3s2_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(out), N, H, W, Cin, cout,
+                                               1 if relu else 0, _stream()), 'conv3x3s2_win_fwd')
+        return out
+    assert stride == 1
     out = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=x_nhwc.device)
     with _timed(tag or 'conv3x3_win'):
         _check(lib().sc2_conv3x3_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(out), N, H, W, Cin, cout,

@@ -566,7 +566,7 @@ def test_conv3x3_win(S, dev, cin, cout, N, HW, relu):
     if relu:
         ref = F.relu(ref)
     assert S.hip.conv3x3_win_supported(HW, HW, cin, cout, 3, 3, 1, 1)
-    assert not S.hip.conv3x3_win_supported(HW, HW, cin, cout, 3, 3, 2, 1)
+    assert not S.hip.conv3x3_win_supported(7, 7, cin, cout, 3, 3, 2, 1)
     assert not S.hip.conv3x3_win_supported(16, 16, cin, cout, 3, 3, 1, 1)
     assert not S.hip.conv3x3_win_supported(HW, HW, 96, cout, 3, 3, 1, 1)
     x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
@@ -576,6 +576,36 @@ def test_conv3x3_win(S, dev, cin, cout, N, HW, relu):
     gen = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 3, 3, 1, 1,
                            epilogue=S.hip.EPI_BIAS_RELU if relu else S.hip.EPI_BIAS, ep_beta=bias.to(dev))
     assert_close_bf16(out, gen, 'window-plane vs tile kernel', extra=2.0 ** -8)
+
+
+@pytest.mark.parametrize('cin,cout,N,HW,relu', [
+    (128, 128, 3, 56, True),      # layer2.0 conv2: 56 -> 28, four 7-row tiles per image
+    (256, 256, 5, 28, True),      # layer3.0 conv2: 28 -> 14, one image per tile, two channel chunks
+    (512, 512, 6, 14, True),      # layer4.0 conv2: 14 -> 7, four images per tile, ragged last tile (6 = 4 + 2)
+    (32, 128, 2, 28, False),      # a single slab, no ReLU
+    (96, 384, 1, 14, True),       # a lone image in a four-image tile, three slabs, three channel chunks
+])
+def test_conv3x3s2_win(S, dev, cin, cout, N, HW, relu):
+    """3x3 stride-2 pad-1 conv + bias (+ ReLU) on the window-plane kernel's parity-class form (conv3x3_win.hip, GeoS2) against
+    the f32 op on the bf16-rounded operands and against the implicit-GEMM tile kernel: the zero halo (top / left only at stride
+    2), the four parity classes of the window, tiles that end inside the batch."""
+    g = torch.Generator().manual_seed(cout + N + HW)
+    x = torch.randn(N, cin, HW, HW, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(bf16_round(x), bf16_round(w), stride=2, padding=1) + bias.view(1, -1, 1, 1)
+    if relu:
+        ref = F.relu(ref)
+    assert S.hip.conv3x3_win_supported(HW, HW, cin, cout, 3, 3, 2, 1)
+    assert not S.hip.conv3x3_win_supported(HW + 2, HW + 2, cin, cout, 3, 3, 2, 1)
+    assert not S.hip.conv3x3_win_supported(HW, HW, cin, 64, 3, 3, 2, 1)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    out = S.hip.conv3x3_win_fwd(x_nhwc, S.hip.pack_conv3x3_win(w.to(dev)), bias.to(dev), relu=relu, stride=2)
+    assert out.shape == (N, HW // 2, HW // 2, cout)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'window-plane 3x3 stride-2 conv')
+    gen = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 3, 3, 2, 1,
+                           epilogue=S.hip.EPI_BIAS_RELU if relu else S.hip.EPI_BIAS, ep_beta=bias.to(dev))
+    assert_close_bf16(out, gen, 'window-plane stride 2 vs tile kernel', extra=2.0 ** -8)
 
 
 @pytest.mark.parametrize('cin,pad,N,H,fused,inverse,run', [

@@ -1,0 +1,10 @@
+"""Prints the fields of a bench.py JSON line that matter during tuning."""
+import json
+import sys
+
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r, b = d['roofline'], d['bottleneck_forward']
+print('K={} value={:.0f} img/s  ms/step={:.3f}  roofline.frac={:.3f} ({} {:.3f} ms)  bottleneck {:.3f} ms frac {:.3f}  match={}'.format(
+    d['steps'], d['value'], d['ms_per_step'], r['frac'], r['kernel'], r['kernel_ms'], b['ms_per_batch_sum_of_mfma_kernels'],
+    b['frac_of_mfma_peak'], d.get('bitstream_match')))
+print('  kernels_ms', json.dumps(d.get('kernels_ms')))
