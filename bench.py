@@ -336,6 +336,8 @@ def main():
     ap.add_argument('--diag-skip-coder', type=int, default=0, help='DIAGNOSTIC (invalid as a result): 1 = reuse the first step\'s coder output, 2 = same but still run the coder')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
+    ap.add_argument('--no-prealloc', action='store_true', help='A/B: skip the coder-buffer pre-allocation pass after the warm-up steps')
+    ap.add_argument('--diag-repeat', type=int, default=0, help='DIAGNOSTIC: after the timed region, time R more runs of K steps and print their wall times to stderr')
     ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
@@ -538,6 +540,25 @@ def main():
     run_steps(warm_steps)
     sync_all()
 
+    def prealloc_coder(n_steps):
+        """Resource warm-up, not a step: one range-coder launch per coder group of the timed plan, on the coder stream that group
+        will use, so that the timed region makes no first-time device allocation.  W warm-up steps only reach the group sizes
+        1, 2, 4 (W = 5: plan 1 + 2 + 4 + 1); the 8-step groups of the timed run then allocate ~2 GB of workspace, streams and
+        symbol buffers inside the timed region, and the FIRST process on a freshly booted box pays ~45 ms for that (measured:
+        174 ms vs 128 ms for the same 20 steps, tools/cold_diag.sh) -- the driver's situation."""
+        with torch.no_grad():
+            with torch.cuda.stream(mfma_stream):
+                sym1, hw = model.stage_front(x)
+            mfma_stream.synchronize()
+            for li, g in enumerate(group_plan(n_steps)):
+                cs = coder_streams[li % n_coder]
+                with torch.cuda.stream(cs):
+                    model.stage_coder(sym1 if g == 1 else torch.cat([sym1] * g), hw)
+        sync_all()
+
+    if args.warmup > 0 and not args.no_prealloc:
+        prealloc_coder(args.steps)
+
     select = lambda tag: launch_work(tag) is not None or tag.startswith('rans')  # noqa: E731
     with hip.KernelTimer(select) as timer:
         t0 = time.perf_counter()
@@ -546,6 +567,12 @@ def main():
         sync_all()
         t1 = time.perf_counter()
     elapsed = t1 - t0
+    for rep in range(args.diag_repeat):
+        tr0 = time.perf_counter()
+        run_steps(args.steps)
+        sync_all()
+        print('diag-repeat {}: first timed region {:.2f} ms, this one {:.2f} ms'.format(rep, elapsed * 1e3, (time.perf_counter() - tr0) * 1e3),
+              file=sys.stderr)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -612,6 +639,7 @@ def main():
                        'pipeline': 'event-driven: encoder stages run ahead, decoder+head stages wait for their coder launch',
                        'hip_streams': {'encoder': 1, 'decoder+head': len(back_streams), 'range_coder': n_coder},
                        'steps_per_coder_launch': G, 'max_inflight_steps': args.max_inflight, 'coder_group_plan': group_plan(args.steps)[:6], 'warmup_steps_run': warm_steps,
+                       'prealloc': 'none' if (args.no_prealloc or args.warmup == 0) else 'one untimed range-coder launch per coder group of the timed plan (device buffers only, not a step)',
                        'weights': 'random init seed 0, operating point shaped by bench.shape_workload (ragged tables, '
                                   'peaked prior, latent std ~1, ~1e-4 escape symbols)',
                        'images': 'torch.rand, per-image contrast 0.25-1, ImageNet normalisation',
