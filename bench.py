@@ -337,6 +337,7 @@ def main():
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
     ap.add_argument('--no-prealloc', action='store_true', help='A/B: skip the coder-buffer pre-allocation pass after the warm-up steps')
+    ap.add_argument('--diag-timeline', action='store_true', help='DIAGNOSTIC: HIP events around every stage of the timed run, printed to stderr (adds ~100 event records)')
     ap.add_argument('--diag-repeat', type=int, default=0, help='DIAGNOSTIC: after the timed region, time R more runs of K steps and print their wall times to stderr')
     ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
@@ -387,6 +388,12 @@ def main():
     cached = []
     statuses = []     # status vectors of EVERY coder launch of the timed run (checked after the final sync)
     latency = []      # (event at front(i) start, event at back(i) end) for a few steps
+    timeline = []     # --diag-timeline: (stage, step, start event, end event)
+
+    def tl_event(stream):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
 
     def group_plan(n_steps):
         """sizes of the coder groups of a run: 1, 2, 4, ... up to G, then G."""
@@ -428,7 +435,10 @@ def main():
                         torch.cuda._sleep(int(12e-3 * 2.0e9))
                         torch.cuda._sleep(int(11e-3 * 2.0e9))
                 else:
+                    tl0 = tl_event(cs) if (record and args.diag_timeline) else None
                     dec, nb, st = model.stage_coder(sym, hw)
+                    if tl0 is not None:
+                        timeline.append(('coder', group[0][0], tl0, tl_event(cs)))
                     if args.diag_skip_coder:
                         cached.append((dec, nb, st))
                     ev2 = torch.cuda.Event()
@@ -456,7 +466,11 @@ def main():
                         e0 = torch.cuda.Event(enable_timing=True)
                         e0.record(mfma_stream)
                         latency.append([i, e0, None])
+                    if record and args.diag_timeline:
+                        timeline.append(('front', i, tl_event(mfma_stream), None))
                     sym, hw = model.stage_front(x)
+                    if record and args.diag_timeline:
+                        timeline[-1] = timeline[-1][:3] + (tl_event(mfma_stream),)
                     ev = torch.cuda.Event()
                     ev.record(mfma_stream)
                 group.append((i, sym, hw, ev))
@@ -511,7 +525,10 @@ def main():
                             end_events.append(ev_h)
                             logits.record_stream(back_stream)
                         else:
+                            tl0 = tl_event(back_stream) if (record and args.diag_timeline) else None
                             logits = model.stage_back(dec, hw, after_decoder=mark if args.front_beside_head else None)
+                            if tl0 is not None:
+                                timeline.append(('back', j, tl0, tl_event(back_stream)))
                         results[0] = (logits, nb, st)
                         back_done[j] = torch.cuda.Event()
                         if args.head_streams > 0 and args.head_halves <= 1:
@@ -567,6 +584,11 @@ def main():
         sync_all()
         t1 = time.perf_counter()
     elapsed = t1 - t0
+    if timeline:
+        base = timeline[0][2]
+        for kind, step, e_a, e_b in sorted(timeline, key=lambda r: base.elapsed_time(r[2])):
+            print('timeline {:<6} step {:3d}  start {:8.2f} ms  end {:8.2f} ms  ({:.2f} ms)'.format(
+                kind, step, base.elapsed_time(e_a), base.elapsed_time(e_b), e_a.elapsed_time(e_b)), file=sys.stderr)
     for rep in range(args.diag_repeat):
         tr0 = time.perf_counter()
         run_steps(args.steps)
