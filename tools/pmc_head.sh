@@ -14,5 +14,5 @@ done
 python3 tools/pmc_mfma_parse.py $OUT "win28|Geo<28|59.2" "win14|Geo<14|59.2" "win7|Geo<7|59.2" "kres1024|KresShape<1024|26.3" \
   "stream512x64x256res|conv1x1_stream_kernel<512, 64, 256, true|26.3" "stream256x128x256res|conv1x1_stream_kernel<256, 128, 256, true|26.3" \
   "stream128res|conv1x1_stream_kernel<128, 128, 256, true|26.3" "stream512x64x128|conv1x1_stream_kernel<512, 64, 128, false|26.3" \
-  "generic128|Cfg<128, 128, 2, 2, false|55" "s2_256|Cfg8<256, 2, 4, true, 0, 3, 3, 2, 2|59.2" > $OUT/head_mfma_busy.txt 2>&1
+  "generic128|Cfg<128, 128, 2, 2, false|55" "s2win28|GeoS2<28|59.2" "s2win14|GeoS2<14|59.2" "s2win7|GeoS2<7|59.2" > $OUT/head_mfma_busy.txt 2>&1
 cat $OUT/head_mfma_busy.txt
