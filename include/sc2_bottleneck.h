@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 28
+#define SC2_ABI_VERSION 29
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -174,6 +174,17 @@ int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gam
 int sc2_conv1x1_kres_supported(int Cin, int Cout, int stride);
 int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
                          int stride, int relu, void *stream);
+
+/* 1x1 convolution + bias (+ residual) (+ ReLU) in the window-plane structure (conv1x1_win.hip): conv1 + bn1 + ReLU, conv3 + bn3 +
+ * identity + ReLU and the downsample layers of the torchvision Bottleneck blocks behind the bottleneck
+ * (sc2bench/models/backbone.py:235-254) where K is long and the layer is not HBM-bound.  Tiles of 208 output pixels x 128
+ * channels, 64-channel slabs of the pixel operand as chunk planes in LDS, weights straight into registers.
+ *   x : bf16 NHWC [N,H,W,Cin], Cin % 128 == 0;   y : bf16 NHWC [N,OH,OW,Cout], OH = (H-1)/stride + 1, Cout % 128 == 0, stride 1 | 2
+ *   w_frag : bf16 [Cin/32][Cout/16][64][8] (BN folded), the k-step stream of sc2_conv3x3_win_fwd for a 1 x 1 kernel (same row
+ *            permutation);   bias : f32 [Cout];   residual : bf16 [N,OH,OW,Cout] or NULL (added before the ReLU);   relu != 0: ReLU. */
+int sc2_conv1x1_win_supported(int Cin, int Cout, int stride);
+int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y, int N, int H, int W,
+                        int Cin, int Cout, int stride, int relu, void *stream);
 
 /* 3x3 stride-1 pad-1 convolution + bias (+ ReLU) on 28 x 28 / 14 x 14 / 7 x 7 maps: conv2 + bn2 + ReLU of the torchvision
  * Bottleneck blocks of layer2 / layer3 / layer4 behind the bottleneck (sc2bench/models/backbone.py:235-254 runs them) at the

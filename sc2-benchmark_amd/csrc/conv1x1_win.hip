@@ -1,0 +1,323 @@
+// 1x1 convolution + bias (+ residual) (+ ReLU) for the ResNet tail's conv1 / conv3 / downsample layers (gfx950), in the
+// structure of the window-plane 3x3 kernel (conv3x3_win.hip): torchvision Bottleneck.conv1 + bn1 + ReLU, conv3 + bn3 + identity
+// + ReLU and downsample[0] + downsample[1] of layer2 / layer3 / layer4 in eval mode, the callers on the far side of the
+// bottleneck path (sc2bench/models/backbone.py:235-254).
+//     y[m, co] = act( sum_ci x[pix(m), ci] w[co, ci] + bias[co] (+ res[m, co]) ),   bf16 NHWC, m = flat output pixel.
+//
+// Why another 1x1 kernel.  The weights-in-registers kernels (conv1x1_stream.hip, conv1x1_kres.hip) win where a layer is
+// HBM-bound with a short K.  The K >= 512 layers at 12 544 - 50 176 pixels (conv1 of layer3 / layer4, layer4's conv3) are not:
+// 26 - 53 GFLOP per launch ran at 400 - 630 TFLOP/s with the matrix pipes 15 - 20 % busy (profiles/r02j_pmc_head_mfma_busy.txt),
+// their time going into the resident-weight prologue (0.5 - 2 MB per workgroup), the K-half exchange and tile quantisation.
+// Here, as in conv3x3_win.hip:
+//   * a tile is 208 consecutive output pixels (13 MFMA row tiles, no image structure needed for a 1x1 layer) x 128 channels,
+//     wave w = 32 channels x 13 row tiles (26 accumulator tiles), two workgroups per CU;
+//   * the pixel operand is staged per 64-channel slab as eight 16-byte-chunk planes [chunk][pixel][16 B], double-buffered
+//     (2 x 32 KB): fragment rows are one address register per row tile + immediates, no vector ALU in the K loop;
+//   * weights go L2 -> registers, fragment-major, four k-steps ahead; ONE barrier per slab (52 MFMAs per wave);
+//   * the weight rows are permuted at packing time so that a lane holds eight consecutive channels of a pixel: 13 sixteen-byte
+//     stores (and residual loads) per lane, bias / residual / ReLU in registers.
+// Stride 2 (the downsample layers) only changes which input pixel a window row is filled from.
+#include <stdlib.h>
+
+#include "sc2_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack2(float a, float b) {   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xFFFF0000u); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, (int)voff, (int)soff, 0, 0);
+}
+__device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+#else   // host pass: stand-ins (see conv_igemm_impl.h)
+typedef int buf_rsrc_t;
+__device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *, uint32_t) { return 0; }
+__device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, uint32_t) {}
+__device__ __forceinline__ uint4 buf_load16(buf_rsrc_t, uint32_t, uint32_t) { return make_uint4(0, 0, 0, 0); }
+#endif
+
+template <int OFF>
+__device__ __forceinline__ u32x4_t lds_read16_imm(uint32_t addr) {
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm(u32x4_t &v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+
+struct P1Args {
+    const uint16_t *__restrict__ x;      // bf16 NHWC [N, H, W, Cin]
+    const uint16_t *__restrict__ w;      // bf16 [Cin/32][Cout/16][64][8]  (hip.pack_conv_win of the [Cout, Cin, 1, 1] weight)
+    const float *__restrict__ bias;      // f32 [Cout]
+    const uint16_t *__restrict__ res;    // bf16 [M, Cout] or null
+    uint16_t *__restrict__ y;            // bf16 [M, Cout], M = N * OH * OW
+    int N, H, W, OH, OW, stride, Cin, Cout, relu;
+    int n_chunks;                        // Cout / 128
+    long long M;
+    unsigned x_bytes, w_bytes;
+};
+
+constexpr int MT = 13;                   // MFMA row tiles per tile
+constexpr int PX = MT * 16;              // 208 output pixels per tile
+constexpr int NRG = 4;                   // 64-row direct-to-LDS pieces per plane (256 rows >= 208)
+constexpr int PLANE = NRG * 1024;        // bytes per 16-byte-chunk plane
+constexpr int SLAB_PLANES = 8;           // 64 channels per slab
+constexpr int WIN_BYTES = SLAB_PLANES * PLANE;   // 32 KB; NBUF of them form the ring (NBUF - 1 slabs in flight)
+constexpr int PF = 4;                    // weight fragments are fetched this many k-steps ahead (4 k-steps per loop trip)
+
+// one k-step: 32 channels = chunk planes 4 KS .. 4 KS + 3 of window PAR
+template <int PAR, int KS>
+__device__ __forceinline__ void k_step(f32x4_t (&acc)[MT][2], const uint32_t (&a_base)[MT], const uint4 &b0, const uint4 &b1) {
+    constexpr int OFF = (PAR & 1) * WIN_BYTES + KS * 4 * PLANE;   // (a_base points at window PAR & ~1: 16-bit immediates)
+    u32x4_t av[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) av[i] = lds_read16_imm<OFF>(a_base[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
+#define SC2_P1_MMA(i)                                                                           \
+    {                                                                                           \
+        wait_lgkm<MT - 1 - (i)>(av[i]);                                                         \
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[i]);                                \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+    SC2_P1_MMA(0) SC2_P1_MMA(1) SC2_P1_MMA(2) SC2_P1_MMA(3) SC2_P1_MMA(4) SC2_P1_MMA(5) SC2_P1_MMA(6)
+    SC2_P1_MMA(7) SC2_P1_MMA(8) SC2_P1_MMA(9) SC2_P1_MMA(10) SC2_P1_MMA(11) SC2_P1_MMA(12)
+#undef SC2_P1_MMA
+}
+
+// NBUF = 2: 64 KB of LDS, two workgroups per CU (the partner covers the slab that is not yet there): layers with many tiles.
+// NBUF = 4: 128 KB, one workgroup per CU, three slabs (1.5 us of MFMA work) in flight: the 12 544-pixel layers of layer4, whose
+// 244 - 976 workgroups would otherwise wait for every slab (one slab ahead = 0.5 us against ~2 us of loaded HBM latency).
+template <int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv1x1_win_kernel(const P1Args p) {
+    constexpr uint32_t OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int Cin = p.Cin, Cout = p.Cout;
+    const int NS = Cin >> 6;   // 64-channel slabs
+
+    // XCD x gets a contiguous range of (pixel tile, channel chunk) pairs, chunk fastest: the chunks of one pixel tile read
+    // their window through the same L2
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    }
+    const int chunk = bid % p.n_chunks, mtile = bid / p.n_chunks;
+    const int n0 = chunk * 128 + wave * 32;
+    const long long m0 = (long long)mtile * PX;
+
+    const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
+    const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+
+    // window fill: wave w fills chunk planes 2 w and 2 w + 1 (chunk c = channels [8 c, 8 c + 8) of the slab); piece j = rows
+    // [64 j, 64 j + 64) = output pixels m0 + 64 j + lane.  The per-lane source offsets stay in registers.
+    uint32_t pw_vo[NRG];
+#pragma unroll
+    for (int j = 0; j < NRG; ++j) {
+        const long long m = m0 + j * 64 + lane;
+        uint32_t vo = OOB;
+        if (j * 64 + lane < PX && m < p.M) {
+            long long pix = m;
+            if (p.stride != 1) {
+                const int ohw = p.OH * p.OW;
+                const int n = (int)(m / ohw), rem = (int)(m - (long long)n * ohw);
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                pix = ((long long)n * p.H + oh * p.stride) * p.W + ow * p.stride;
+            }
+            vo = (uint32_t)(pix * Cin * 2);
+        }
+        pw_vo[j] = vo;
+    }
+    auto issue_window = [&](int cb, int par) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int j = 0; j < NRG; ++j)
+                buf_load_lds16(rs_x, (lds_ptr_t)(smem + par * WIN_BYTES + (wave * 2 + c) * PLANE + j * 1024), pw_vo[j],
+                               (uint32_t)cb * 128u + (uint32_t)(wave * 2 + c) * 16u);
+        }
+    };
+
+    // fragment rows of this lane: k-lanes fq = chunk fq of the k-step's four planes
+    uint32_t a_base[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_base[i] = lds_base + (uint32_t)(fq * PLANE + (i * 16 + frow) * 16);
+    uint32_t a_base2[MT];   // windows 2, 3 of the four-deep ring
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a_base2[i] = a_base[i] + 2u * WIN_BYTES;
+
+    // weights: k-step kt, 16-channel tile t -> 1 KB at ((kt * Cout/16) + t) * 1024; this wave's tiles are n0/16, n0/16 + 1
+    const uint32_t b_vo = (uint32_t)(lane * 16);
+    const uint32_t b_step = (uint32_t)(Cout >> 4) * 1024u;
+    const uint32_t KT = (uint32_t)NS * 2u;
+    const uint32_t b_so0 = (uint32_t)(n0 >> 4) * 1024u;
+    auto fetch_b = [&](uint32_t kt, uint4 &b0, uint4 &b1) {   // (past the end: the last k-step again, never used)
+        const uint32_t so = b_so0 + (kt < KT - 1u ? kt : KT - 1u) * b_step;
+        b0 = buf_load16(rs_w, b_vo, so);
+        b1 = buf_load16(rs_w, b_vo, so + 1024u);
+    };
+
+    f32x4_t acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll
+    for (int d = 0; d < NBUF - 1; ++d)
+        if (d < NS) issue_window(d, d);
+    uint4 bq[PF][2];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch_b((uint32_t)s, bq[s][0], bq[s][1]);
+
+#define SC2_P1_STEP(PAR, cb, KS, SLOT)                                                 \
+    {                                                                                 \
+        const uint4 b0 = bq[SLOT][0], b1 = bq[SLOT][1];                               \
+        fetch_b((uint32_t)(cb) * 2u + (KS + PF), bq[SLOT][0], bq[SLOT][1]);           \
+        if constexpr ((PAR) < 2) k_step<PAR, KS>(acc, a_base, b0, b1);                \
+        else k_step<PAR, KS>(acc, a_base2, b0, b1);                                   \
+    }
+    // this wave's share of window cb has landed when at most the loads issued after it are outstanding: the NBUF - 2 younger
+    // windows (8 pieces each) and the 2 x 2 weight fetches of each of the NBUF - 1 slabs since (fewer near the ends: a
+    // conservative wait)
+    constexpr int YOUNGER = (NBUF - 2) * 8 + (NBUF - 1) * 4;
+#define SC2_P1_SLAB(PAR, cb, SLOT0)                                                                     \
+    {                                                                                                   \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");                                   \
+        __builtin_amdgcn_s_barrier();   /* window cb complete; everybody is done with window cb - 1 */   \
+        if ((cb) + NBUF - 1 < NS) issue_window((cb) + NBUF - 1, (PAR + NBUF - 1) % NBUF);               \
+        SC2_P1_STEP(PAR, cb, 0, SLOT0) SC2_P1_STEP(PAR, cb, 1, SLOT0 + 1)                                \
+    }
+    // (the windows of the prologue have fewer weight fetches behind them than YOUNGER assumes: drain everything once)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NBUF == 2) {
+        for (int cb = 0; cb < NS; cb += 2) {
+            SC2_P1_SLAB(0, cb, 0)
+            SC2_P1_SLAB(1, cb + 1, 2)
+        }
+    } else {
+        for (int cb = 0; cb < NS; cb += 4) {
+            SC2_P1_SLAB(0, cb, 0)
+            SC2_P1_SLAB(1, cb + 1, 2)
+            SC2_P1_SLAB(2, cb + 2, 0)
+            SC2_P1_SLAB(3, cb + 3, 2)
+        }
+    }
+#undef SC2_P1_SLAB
+#undef SC2_P1_STEP
+
+    // epilogue: lane (frow, fq) holds, for row tile i, output channels n0 + 8 fq + [0, 4) in acc[i][0] and + [4, 8) in acc[i][1]
+    // of pixel m0 + i * 16 + frow
+    const float4 bias_lo = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq);
+    const float4 bias_hi = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq + 4);
+    const bool relu = p.relu != 0;
+    const bool has_res = p.res != nullptr;
+    uint4 rv[MT];
+    if (has_res) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const long long m = m0 + i * 16 + frow;
+            rv[i] = m < p.M ? *reinterpret_cast<const uint4 *>(p.res + m * Cout + n0 + 8 * fq) : make_uint4(0, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const long long m = m0 + i * 16 + frow;
+        float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
+                      acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
+        if (has_res) {
+            v[0] += bf_lo(rv[i].x); v[1] += bf_hi(rv[i].x); v[2] += bf_lo(rv[i].y); v[3] += bf_hi(rv[i].y);
+            v[4] += bf_lo(rv[i].z); v[5] += bf_hi(rv[i].z); v[6] += bf_lo(rv[i].w); v[7] += bf_hi(rv[i].w);
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        if (m < p.M) *reinterpret_cast<uint4 *>(p.y + m * Cout + n0 + 8 * fq) = o;
+    }
+}
+
+template <int NBUF>
+int launch_p1(const P1Args &a, long long n_wg, hipStream_t s) {
+    constexpr int LDS_BYTES = NBUF * WIN_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_win_kernel<NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv1x1_win_kernel<NBUF>, dim3((unsigned)n_wg), dim3(256), LDS_BYTES, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+}  // namespace
+
+extern "C" int sc2_conv1x1_win_supported(int Cin, int Cout, int stride) {
+    return (stride == 1 || stride == 2) && Cin >= 128 && Cin % 128 == 0 && Cout >= 128 && Cout % 128 == 0 ? 1 : 0;
+}
+
+extern "C" int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y, int N, int H,
+                                   int W, int Cin, int Cout, int stride, int relu, void *stream) {
+    SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv1x1_win: null argument");
+    SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv1x1_win: non-positive shape");
+    SC2_REQUIRE(sc2_conv1x1_win_supported(Cin, Cout, stride), SC2_ERR_UNSUPPORTED,
+                "conv1x1_win: needs Cin %% 128 == 0, Cout %% 128 == 0, stride 1 or 2 (got %d -> %d, stride %d)", Cin, Cout, stride);
+    const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    const long long M = (long long)N * OH * OW;
+    const long long x_bytes = (long long)N * H * W * Cin * 2, w_bytes = (long long)Cin * Cout * 2, y_bytes = M * Cout * 2;
+    SC2_REQUIRE(x_bytes < 0x7FF00000LL && w_bytes < 0x7FF00000LL && y_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED,
+                "conv1x1_win: operand of %lld bytes exceeds 2 GB", x_bytes > y_bytes ? x_bytes : y_bytes);
+    P1Args a;
+    a.x = static_cast<const uint16_t *>(x);
+    a.w = static_cast<const uint16_t *>(w_frag);
+    a.bias = bias;
+    a.res = static_cast<const uint16_t *>(residual);
+    a.y = static_cast<uint16_t *>(y);
+    a.N = N; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.stride = stride; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
+    a.n_chunks = Cout / 128;
+    a.M = M;
+    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
+    const long long n_mtiles = (M + PX - 1) / PX;
+    const long long n_wg = n_mtiles * a.n_chunks;
+    SC2_REQUIRE(n_wg < (1ll << 31), SC2_ERR_UNSUPPORTED, "conv1x1_win: grid too large");
+    // ring depth: four buffers (one workgroup per CU) when the launch has about one workgroup per CU anyway (layer4's conv1 at
+    // bs 256: 244 workgroups, 0.050 -> 0.045 ms; every launch with more workgroups measured slower that way) and K is a
+    // multiple of 256; SC2_P1_NBUF = 2 | 4 overrides (A/B)
+    int nbuf = (Cin % 256 == 0 && n_wg <= 320) ? 4 : 2;
+    if (const char *e = getenv("SC2_P1_NBUF")) {
+        const int v = atoi(e);
+        if (v == 2 || (v == 4 && Cin % 256 == 0)) nbuf = v;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return nbuf == 4 ? launch_p1<4>(a, n_wg, s) : launch_p1<2>(a, n_wg, s);
+}

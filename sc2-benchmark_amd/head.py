@@ -8,6 +8,8 @@ the decoder's output to the pooled features; the classifier is the same kernel a
 
 Only used when the model is in eval mode; training keeps the torch modules (BatchNorm statistics).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -30,6 +32,23 @@ def _fold(conv, bn):
     return hip.pack_conv_weight(w, order), bias.contiguous(), order, w
 
 
+def _win1_policy(cin, cout, stride):
+    """Which 1x1 layers go to the window-plane 1x1 kernel (conv1x1_win.hip).  SC2_CONV1X1_WIN: '0' none, 'all' every supported
+    layer (A/B, tools/head_times.py), default = the layers it measured faster on."""
+    mode = os.environ.get('SC2_CONV1X1_WIN', '1')
+    if mode == '0':
+        return False
+    if mode == 'all':
+        return True
+    # measured at bs 256, 224 x 224 (tools/head_times.py, SC2_CONV1X1_WIN=all against the default):
+    #   conv1 of layer2.1-3 (512 -> 128)      0.075 -> 0.065 ms (streaming kernel)
+    #   conv1 of layer4.1-2 (2048 -> 512)     0.064 -> 0.045 ms (tile kernel)
+    #   conv3 of layer4     (512 -> 2048)     0.062 -> 0.054 ms (streaming kernel)
+    #   downsample of layer3 (512 -> 1024 s2) 0.111 -> 0.101 ms (streaming kernel)
+    # every other 1x1 layer was as fast or faster where it is (conv3 of layer2 / layer3 are HBM-bound: 0.104 -> 0.125 ms here)
+    return (cin, cout, stride) in ((512, 128, 1), (2048, 512, 1), (512, 2048, 1), (512, 1024, 2))
+
+
 class _Conv(object):
     def __init__(self, conv, bn, tag):
         assert conv.bias is None and conv.groups == 1
@@ -49,6 +68,11 @@ class _Conv(object):
             conv.in_channels, conv.out_channels, self.k[0], self.k[1], self.stride, self.pad)
         if self.stream or self.kres:
             self.w_frag = hip.pack_weight_fragments(w_folded.reshape(w_folded.shape[0], w_folded.shape[1]))
+        # long-K 1x1 layers that are not HBM-bound: the window-plane 1x1 kernel (which layers: _win1_policy, by measurement)
+        self.w_win1 = None
+        if self.k == (1, 1) and _win1_policy(conv.in_channels, conv.out_channels, self.stride[0]) and \
+                hip.conv1x1_win_supported(conv.in_channels, conv.out_channels, 1, 1, self.stride, self.pad):
+            self.w_win1 = hip.pack_conv_win(w_folded)
         # 3x3 stride-1 layers on 28 / 14 / 7 pixel maps (conv2 of every block at the 224 x 224 operating point): the
         # window-plane kernel; other map sizes stay on the implicit-GEMM tile kernel (decided per call, by the map size)
         self.w2d = w_folded.reshape(w_folded.shape[0], w_folded.shape[1]).to(torch.bfloat16) if self.k == (1, 1) else None
@@ -82,6 +106,11 @@ class _Conv(object):
         if self.dilation != (1, 1) and self.k == (3, 3):
             assert ep_x is None
             return self._dilated(x, epilogue)
+        if self.w_win1 is not None and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU, hip.EPI_BIAS_ADD_RELU) and \
+                max(x.numel(), x.shape[0] * x.shape[1] * x.shape[2] * self.cout) * 2 < 0x7FF00000:
+            return hip.conv1x1_win_fwd(x, self.w_win1, self.b, stride=self.stride[0],
+                                       residual=ep_x if epilogue == hip.EPI_BIAS_ADD_RELU else None,
+                                       relu=epilogue != hip.EPI_BIAS, tag=self.tag)
         if self.stream and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU, hip.EPI_BIAS_ADD_RELU):
             return hip.conv1x1_stream_fwd(x, self.w_frag, self.b, stride=self.stride[0],
                                           residual=ep_x if epilogue == hip.EPI_BIAS_ADD_RELU else None,

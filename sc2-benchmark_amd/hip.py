@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -78,6 +78,8 @@ def lib():
     L.sc2_conv3x3_win_supported.argtypes = [i32, i32, i32, i32]
     L.sc2_conv3x3_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3s2_win_supported.argtypes = [i32, i32, i32, i32]
+    L.sc2_conv1x1_win_supported.argtypes = [i32, i32, i32]
+    L.sc2_conv1x1_win_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3s2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2x2_win_supported.argtypes = [i32, i32, i32, i32, i32]
     L.sc2_conv2x2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -729,6 +731,34 @@ def conv1x1_stream_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False
     with _timed(tag or 'conv1x1_stream'):
         _check(lib().sc2_conv1x1_stream_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(out), N, H, W,
                                             Cin, cout, int(stride), 1 if relu else 0, _stream()), 'conv1x1_stream_fwd')
+    return out
+
+
+def conv1x1_win_supported(cin, cout, kh, kw, stride, pad):
+    """True if this 1x1 conv can run on the window-plane 1x1 kernel (Cin, Cout multiples of 128, stride 1 or 2)."""
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    return (kh, kw, ph, pw) == (1, 1, 0, 0) and sh == sw and bool(lib().sc2_conv1x1_win_supported(cin, cout, sh))
+
+
+def conv1x1_win_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False, tag=None):
+    """y = act(conv1x1(x) + bias [+ residual]) on the window-plane 1x1 kernel; bf16 NHWC in / out;
+    w_frag = pack_conv_win(w.reshape(Cout, Cin, 1, 1))."""
+    for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, Cin = x_nhwc.shape
+    cout = w_frag.shape[1] * 16
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (Cin // 32, cout // 16, 64, 8)
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
+    stride = int(stride)
+    out = torch.empty((N, (H - 1) // stride + 1, (W - 1) // stride + 1, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    if residual is not None:
+        _dev(residual, 'residual')
+        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and tuple(residual.shape) == tuple(out.shape)
+    with _timed(tag or 'conv1x1_win'):
+        _check(lib().sc2_conv1x1_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin, cout,
+                                         stride, 1 if relu else 0, _stream()), 'conv1x1_win_fwd')
     return out
 
 

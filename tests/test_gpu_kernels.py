@@ -578,6 +578,45 @@ def test_conv3x3_win(S, dev, cin, cout, N, HW, relu):
     assert_close_bf16(out, gen, 'window-plane vs tile kernel', extra=2.0 ** -8)
 
 
+@pytest.mark.parametrize('cin,cout,N,HW,stride,res,relu', [
+    (1024, 256, 3, 14, 1, False, True),    # layer3 conv1: 588 pixels = 2 full tiles + a ragged one, two channel chunks
+    (2048, 512, 5, 7, 1, False, True),     # layer4 conv1: K = 2048, 245 pixels
+    (512, 2048, 2, 7, 1, True, True),      # layer4 conv3 + identity + ReLU: 16 channel chunks, a single ragged tile
+    (256, 1024, 1, 14, 1, True, True),     # layer3 conv3
+    (1024, 2048, 3, 14, 2, False, False),  # layer4 downsample: stride 2, no ReLU
+    (128, 128, 2, 28, 2, False, False),    # one loop trip (K = 128), stride 2 on an even map
+    (256, 128, 1, 5, 2, False, True),      # odd map at stride 2 (5 -> 3)
+])
+def test_conv1x1_win(S, dev, cin, cout, N, HW, stride, res, relu):
+    """1x1 conv + bias (+ residual) (+ ReLU) on the window-plane 1x1 kernel (conv1x1_win.hip) against the f32 op on the
+    bf16-rounded operands and against the implicit-GEMM tile kernel: ragged last pixel tile, stride 2, the permuted weight
+    rows, the residual read in the kernel's own output layout."""
+    g = torch.Generator().manual_seed(cin + cout + N + HW)
+    x = torch.randn(N, cin, HW, HW, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bias = torch.randn(cout, generator=g)
+    OH = (HW - 1) // stride + 1
+    r = bf16_round(torch.randn(N, cout, OH, OH, generator=g)) if res else None
+    ref = F.conv2d(bf16_round(x), bf16_round(w), stride=stride) + bias.view(1, -1, 1, 1)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    assert S.hip.conv1x1_win_supported(cin, cout, 1, 1, stride, 0)
+    assert not S.hip.conv1x1_win_supported(cin, cout, 1, 1, 3, 0)
+    assert not S.hip.conv1x1_win_supported(cin + 64, cout, 1, 1, stride, 0)
+    assert not S.hip.conv1x1_win_supported(cin, cout, 3, 3, stride, 1)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    r_nhwc = S.hip.nchw_f32_to_nhwc_bf16(r.to(dev)) if res else None
+    out = S.hip.conv1x1_win_fwd(x_nhwc, S.hip.pack_conv_win(w.to(dev)), bias.to(dev), stride=stride, residual=r_nhwc, relu=relu)
+    assert out.shape == (N, OH, OH, cout)
+    assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'window-plane 1x1 conv')
+    epi = S.hip.EPI_BIAS_ADD_RELU if res else (S.hip.EPI_BIAS_RELU if relu else S.hip.EPI_BIAS)
+    gen = S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 1, 1, stride, 0, epilogue=epi, ep_x=r_nhwc,
+                           ep_beta=bias.to(dev))
+    assert_close_bf16(out, gen, 'window-plane 1x1 vs tile kernel', extra=2.0 ** -8)
+
+
 @pytest.mark.parametrize('cin,cout,N,HW,relu', [
     (128, 128, 3, 56, True),      # layer2.0 conv2: 56 -> 28, four 7-row tiles per image
     (256, 256, 5, 28, True),      # layer3.0 conv2: 28 -> 14, one image per tile, two channel chunks
