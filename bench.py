@@ -414,6 +414,9 @@ def main():
         # coder launch is and wait for it ON that stream; on a single MFMA stream a waiting stage would block the encoder
         # stages queued behind it, so it is issued only when its coder launch has had time to finish (two groups later)
         lag = args.lag if args.lag >= 0 else (0 if args.split_mfma else 2 * G)
+        # (stage i waits for back_done[i - max_inflight], which exists only once that decoder+head stage has been issued: a lag
+        #  of max_inflight or more would switch the throttle off and let the host run the encoder stages ahead without bound)
+        lag = min(lag, max(args.max_inflight - 1, 0))
         launches = [0]
 
         def flush():

@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 29
+#define SC2_ABI_VERSION 30
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -174,6 +174,17 @@ int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gam
 int sc2_conv1x1_kres_supported(int Cin, int Cout, int stride);
 int sc2_conv1x1_kres_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
                          int stride, int relu, void *stream);
+
+/* The last encoder convolution of the FP bottleneck, Conv2d(48 -> Cout <= 32, k2, s1, p0, bias=False) (sc2bench/models/layer.py:482
+ * `encoder[4]`; 48 -> 24 in every released configuration), as a streaming kernel without LDS (conv2x2_c48.hip): the two column
+ * taps of a pixel are 96 contiguous NHWC channels, so the MFMA operand fragments are plain 16-byte loads; weights resident in
+ * registers.  Results bit-identical to sc2_conv2d_fwd's.
+ *   x : bf16 NHWC [N,H,W,48];   w_frag : bf16 fragment blocks [2][6][64][8] of the [32][192] matrix W[co][kh*96 + kw*48 + ci]
+ *       (rows >= Cout zero; hip.pack_conv2x2_c48);   y : NCHW [N,Cout,H-1,W-1], f32 latent (symbols == 0) or int32 symbols
+ *       round-half-even(acc - medians[co]) (symbols != 0: EntropyModel.quantize(..., 'symbols') fused, as SC2_OUT_I32_NCHW_SYM). */
+int sc2_conv2x2_c48_supported(int H, int W, int Cin, int Cout);
+int sc2_conv2x2_c48_fwd(const void *x, const void *w_frag, const float *medians, void *y, int N, int H, int W, int Cin, int Cout,
+                        int symbols, void *stream);
 
 /* 1x1 convolution + bias (+ residual) (+ ReLU) in the window-plane structure (conv1x1_win.hip): conv1 + bn1 + ReLU, conv3 + bn3 +
  * identity + ReLU and the downsample layers of the torchvision Bottleneck blocks behind the bottleneck

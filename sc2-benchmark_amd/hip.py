@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -79,6 +79,8 @@ def lib():
     L.sc2_conv3x3_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3s2_win_supported.argtypes = [i32, i32, i32, i32]
     L.sc2_conv1x1_win_supported.argtypes = [i32, i32, i32]
+    L.sc2_conv2x2_c48_supported.argtypes = [i32, i32, i32, i32]
+    L.sc2_conv2x2_c48_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_win_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3s2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2x2_win_supported.argtypes = [i32, i32, i32, i32, i32]
@@ -731,6 +733,46 @@ def conv1x1_stream_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False
     with _timed(tag or 'conv1x1_stream'):
         _check(lib().sc2_conv1x1_stream_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(out), N, H, W,
                                             Cin, cout, int(stride), 1 if relu else 0, _stream()), 'conv1x1_stream_fwd')
+    return out
+
+
+def conv2x2_c48_supported(x_shape, cout, kh, kw, stride, pad):
+    """True if this conv runs on the streaming kernel of the FP encoder's last layer (Cin 48, k2, s1, p0, Cout <= 32)."""
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    if os.environ.get('SC2_CONV_C48', '1') == '0':      # A/B switch (tools/)
+        return False
+    N, H, W, Cin = x_shape
+    if N * H * W * Cin * 2 >= 0x7FF00000:
+        return False
+    return (kh, kw, sh, sw, ph, pw) == (2, 2, 1, 1, 0, 0) and bool(lib().sc2_conv2x2_c48_supported(H, W, Cin, cout))
+
+
+def pack_conv2x2_c48(w):
+    """[Cout <= 32, 48, 2, 2] -> bf16 fragment blocks [2][6][64][8] of W[co][kh*96 + kw*48 + ci] (rows >= Cout zero)."""
+    _dev(w, 'w')
+    cout = w.shape[0]
+    assert tuple(w.shape[1:]) == (48, 2, 2) and cout <= 32
+    w2d = torch.zeros((32, 192), dtype=torch.float32, device=w.device)
+    w2d[:cout] = w.detach().float().permute(0, 2, 3, 1).reshape(cout, 192)
+    return pack_weight_fragments(w2d)
+
+
+def conv2x2_c48_fwd(x_nhwc, w_frag, cout, medians=None, tag=None):
+    """x bf16 [N,H,W,48] -> f32 latent [N,cout,H-1,W-1], or (medians given) the int32 symbols round(y - median)."""
+    for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag')):
+        _dev(t, name)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, Cin = x_nhwc.shape
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (2, 6, 64, 8)
+    sym = medians is not None
+    if sym:
+        _dev(medians, 'medians')
+        assert medians.dtype == torch.float32 and medians.is_contiguous() and medians.numel() == cout
+    out = torch.empty((N, cout, H - 1, W - 1), dtype=torch.int32 if sym else torch.float32, device=x_nhwc.device)
+    with _timed(tag or 'conv2x2_c48'):
+        _check(lib().sc2_conv2x2_c48_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(medians) if sym else None, _ptr(out), N, H, W, Cin, cout,
+                                         1 if sym else 0, _stream()), 'conv2x2_c48_fwd')
     return out
 
 

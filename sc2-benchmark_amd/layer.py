@@ -216,6 +216,16 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                                tag=c2._tag + '+' + g3._tag, k_order=order)
         else:
             h = g3.forward_nhwc(c2.forward_nhwc(h))
+        if c4.bias is None and hip.conv2x2_c48_supported(tuple(h.shape), c4.out_channels, c4.kernel_size[0], c4.kernel_size[1],
+                                                         c4.stride, c4.padding):
+            # the streaming form of encoder[4] (48 -> 24, k2): f32 latent, or the coder's symbols straight from the accumulators
+            key = (c4.weight._version, c4.weight.device, c4.weight.data_ptr())
+            if getattr(self, '_c48_key', None) != key:
+                with torch.no_grad():
+                    self._c48_frag = hip.pack_conv2x2_c48(c4.weight)
+                self._c48_key = key
+            med = symbols_for._median_vector() if symbols_for is not None else None
+            return hip.conv2x2_c48_fwd(h, self._c48_frag, c4.out_channels, medians=med, tag=c4._tag)
         if symbols_for is not None and c4.bias is None and c4.out_channels <= 96 and c4.out_channels % 8 == 0:
             return hip.conv2d_fwd(h, c4.packed_weight(), c4.out_channels, c4.kernel_size[0], c4.kernel_size[1], c4.stride,
                                   c4.padding, out_format=hip.OUT_I32_NCHW_SYM, ep_beta=symbols_for._median_vector(),

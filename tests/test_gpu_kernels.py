@@ -578,6 +578,40 @@ def test_conv3x3_win(S, dev, cin, cout, N, HW, relu):
     assert_close_bf16(out, gen, 'window-plane vs tile kernel', extra=2.0 ** -8)
 
 
+@pytest.mark.parametrize('cout,N,H,W', [
+    (24, 3, 56, 56),      # encoder[4] of the FP bottleneck at 224 x 224: 3 x 3025 pixels, ragged last 16-pixel tile
+    (24, 2, 9, 7),        # a small non-square map
+    (32, 1, 5, 5),        # every padded weight row in use
+    (16, 5, 2, 2),        # one output pixel per image, one channel tile
+])
+def test_conv2x2_c48(S, dev, cout, N, H, W):
+    """The streaming form of the last encoder conv (conv2x2_c48.hip): f32 latent and int32 symbols BIT-IDENTICAL to the
+    implicit-GEMM tile kernel's two output formats (same k order, same MFMA operand roles), and within tolerance of the f32 op."""
+    g = torch.Generator().manual_seed(cout + N + H)
+    x = torch.randn(N, 48, H, W, generator=g)
+    w = torch.randn(cout, 48, 2, 2, generator=g) / 192 ** 0.5 * 3.0
+    med = torch.randn(cout, generator=g)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    assert S.hip.conv2x2_c48_supported(tuple(x_nhwc.shape), cout, 2, 2, 1, 0)
+    assert not S.hip.conv2x2_c48_supported(tuple(x_nhwc.shape), cout, 2, 2, 1, 1)
+    assert not S.hip.conv2x2_c48_supported(tuple(x_nhwc.shape), 40, 2, 2, 1, 0)
+    assert not S.hip.conv2x2_c48_supported((N, H, W, 64), cout, 2, 2, 1, 0)
+    wf = S.hip.pack_conv2x2_c48(w.to(dev))
+    lat = S.hip.conv2x2_c48_fwd(x_nhwc, wf, cout)
+    sym = S.hip.conv2x2_c48_fwd(x_nhwc, wf, cout, medians=med.to(dev))
+    assert lat.shape == (N, cout, H - 1, W - 1) and lat.dtype == torch.float32 and sym.dtype == torch.int32
+    ref = F.conv2d(bf16_round(x), bf16_round(w))
+    assert (lat.cpu() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-4
+    wp = S.hip.pack_conv_weight(w.to(dev))
+    if cout % 8 == 0:
+        gen = S.hip.conv2d_fwd(x_nhwc, wp, cout, 2, 2, 1, 0, out_format=S.hip.OUT_F32_NCHW)
+        assert torch.equal(lat, gen), 'latent differs from the tile kernel'
+        gsym = S.hip.conv2d_fwd(x_nhwc, wp, cout, 2, 2, 1, 0, out_format=S.hip.OUT_I32_NCHW_SYM, ep_beta=med.to(dev))
+        assert torch.equal(sym, gsym), 'symbols differ from the tile kernel'
+    assert torch.equal(sym, torch.round(lat - med.to(dev).view(1, -1, 1, 1)).to(torch.int32))
+    assert sym.abs().max().item() >= 2   # (the comparison is not vacuous)
+
+
 @pytest.mark.parametrize('cin,cout,N,HW,stride,res,relu', [
     (1024, 256, 3, 14, 1, False, True),    # layer3 conv1: 588 pixels = 2 full tiles + a ragged one, two channel chunks
     (2048, 512, 5, 7, 1, False, True),     # layer4 conv1: K = 2048, 245 pixels
