@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 30
+#define SC2_ABI_VERSION 31
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -55,6 +55,12 @@ int sc2_nhwc_bf16_to_nchw_f32(const void *x, float *y, int N, int C, int H, int 
 /* AdaptiveAvgPool2d((1,1)) + flatten of a bf16 NHWC feature map [N, HW, C] (torchvision ResNet.avgpool,
  * sc2bench/models/backbone.py:250-252): mean over HW in f32 -> y_f32 [N, C] and / or y_bf16 [N, C] (either may be NULL). */
 int sc2_avgpool_nhwc(const void *x, float *y_f32, void *y_bf16, int N, int HW, int C, void *stream);
+
+/* Classifier on the pooled features: out[m][n] = sum_k a[m][k] w[n][k] + bias[n] (torchvision ResNet.fc behind the pool,
+ * sc2bench/models/backbone.py:247-253).  K split over the four waves of a workgroup, operands straight from L2.
+ *   a : bf16 [M,K] (sc2_avgpool_nhwc's y_bf16), K % 128 == 0;   w_frag : bf16 fragment blocks [Npad/16][K/32][64][8] of the
+ *   [Npad,K] weight (rows >= N zero; hip.pack_weight_fragments);   bias : f32 [Npad];   out : f32 [M,Npad], Npad % 16 == 0. */
+int sc2_fc_fwd(const void *a, const void *w_frag, const float *bias, float *out, int M, int K, int Npad, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Implicit-GEMM convolution on the matrix cores (bf16 in, f32 accumulate)                    */

@@ -150,6 +150,16 @@ class HipHead(object):
             if fc.bias is not None:
                 b[:fc.out_features] = fc.bias.detach().float()
             self.fc = (hip.pack_conv_weight(w), b.contiguous(), cout_pad, fc.out_features)
+            # the dedicated classifier kernel (K split over the waves of a workgroup): rows padded to a multiple of 16
+            self.fc_frag = None
+            if fc.in_features % 128 == 0 and os.environ.get('SC2_FC_KERNEL', '1') != '0':
+                n16 = (fc.out_features + 15) // 16 * 16
+                w16 = torch.zeros(n16, fc.in_features, device=w.device)
+                w16[:fc.out_features] = fc.weight.detach().float()
+                b16 = torch.zeros(n16, device=w.device)
+                if fc.bias is not None:
+                    b16[:fc.out_features] = fc.bias.detach().float()
+                self.fc_frag = (hip.pack_weight_fragments(w16), b16.contiguous())
 
     def tail_spec(self):
         """(W1 [128, 256], bias1, Wds [512, 256], bias_ds) of the first block when it is layer2.0 of a ResNet-50 tail (conv1 1x1
@@ -182,6 +192,8 @@ class HipHead(object):
             return hip.avgpool_nhwc(h.contiguous(), want_f32=True)[0]
         w, b, cout_pad, n_cls = self.fc
         pooled = hip.avgpool_nhwc(h.contiguous(), want_f32=False, want_bf16=True)[1]   # f32 mean, rounded once
+        if self.fc_frag is not None:
+            return hip.fc_fwd(pooled, self.fc_frag[0], self.fc_frag[1], tag='head.fc')[:, :n_cls]
         pin = pooled.reshape(pooled.shape[0], 1, 1, pooled.shape[1])
         out = hip.conv2d_fwd(pin, w, cout_pad, 1, 1, 1, 0, epilogue=hip.EPI_BIAS, ep_beta=b,
                              out_format=hip.OUT_F32_NHWC, tag='head.fc')

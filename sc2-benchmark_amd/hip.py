@@ -24,7 +24,7 @@ EB_PARAM_STRIDE = 64
 # symbols the header declares; tests check each is exported
 ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
-    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc',
+    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_fc_fwd',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
@@ -64,6 +64,7 @@ def lib():
     L.sc2_nchw_f32_to_nhwc_bf16.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_nhwc_bf16_to_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.sc2_avgpool_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.sc2_fc_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.sc2_conv_weight_rows.argtypes = [i32]
     L.sc2_conv_weight_pitch.argtypes = [i32]
     L.sc2_conv_fused_gdn_supported.argtypes = [ctypes.POINTER(ConvDesc)]
@@ -528,6 +529,21 @@ def avgpool_nhwc(x_nhwc, want_f32=True, want_bf16=False):
     with _timed('avgpool'):
         _check(lib().sc2_avgpool_nhwc(_ptr(x_nhwc), _ptr(f32), _ptr(b16), N, H * W, C, _stream()), 'avgpool_nhwc')
     return f32, b16
+
+
+def fc_fwd(a, w_frag, bias, tag=None):
+    """out f32 [M, Npad] = a [M, K] (bf16) @ W^T + bias; w_frag = pack_weight_fragments(W [Npad, K]), Npad % 16 == 0."""
+    for t, name in ((a, 'a'), (w_frag, 'w_frag'), (bias, 'bias')):
+        _dev(t, name)
+    assert a.dtype == torch.bfloat16 and a.dim() == 2 and a.is_contiguous()
+    M, K = a.shape
+    npad = w_frag.shape[0] * 16
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (npad // 16, K // 32, 64, 8)
+    assert bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == npad
+    out = torch.empty((M, npad), dtype=torch.float32, device=a.device)
+    with _timed(tag or 'fc'):
+        _check(lib().sc2_fc_fwd(_ptr(a), _ptr(w_frag), _ptr(bias), _ptr(out), M, K, npad, _stream()), 'fc_fwd')
+    return out
 
 
 def pack_weight_fragments(w2d):

@@ -578,6 +578,31 @@ def test_conv3x3_win(S, dev, cin, cout, N, HW, relu):
     assert_close_bf16(out, gen, 'window-plane vs tile kernel', extra=2.0 ** -8)
 
 
+@pytest.mark.parametrize('M,K,N', [(256, 2048, 1000), (5, 512, 21), (130, 128, 16)])
+def test_fc_and_avgpool(S, dev, M, K, N):
+    """AdaptiveAvgPool2d((1,1)) + flatten + Linear on the pooled-feature kernels (layout.hip: avgpool_nhwc_kernel, fc_kernel)
+    against the f32 ops on the bf16-rounded operands; ragged batch, padded output columns."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, 7, 7, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    f32, b16 = S.hip.avgpool_nhwc(x_nhwc, want_f32=True, want_bf16=True)
+    ref_pool = bf16_round(x).mean(dim=(2, 3))
+    assert (f32.cpu() - ref_pool).abs().max().item() <= 1e-5 + 1e-5 * ref_pool.abs().max().item()
+    assert torch.equal(b16.float().cpu(), bf16_round(f32.cpu()))
+    n16 = (N + 15) // 16 * 16
+    w16 = torch.zeros(n16, K)
+    w16[:N] = w
+    b16v = torch.zeros(n16)
+    b16v[:N] = b
+    out = S.hip.fc_fwd(b16, S.hip.pack_weight_fragments(w16.to(dev)), b16v.to(dev))
+    assert out.shape == (M, n16)
+    ref = b16.float().cpu() @ bf16_round(w).t() + b
+    assert (out[:, :N].cpu() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-4
+    assert out[:, N:].abs().max().item() == 0.0 if n16 > N else True
+
+
 @pytest.mark.parametrize('cout,N,H,W', [
     (24, 3, 56, 56),      # encoder[4] of the FP bottleneck at 224 x 224: 3 x 3025 pixels, ragged last 16-pixel tile
     (24, 2, 9, 7),        # a small non-square map
