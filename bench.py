@@ -336,6 +336,7 @@ def main():
     ap.add_argument('--diag-skip-coder', type=int, default=0, help='DIAGNOSTIC (invalid as a result): 1 = reuse the first step\'s coder output, 2 = same but still run the coder')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
+    ap.add_argument('--cat-symbols', action='store_true', help='A/B: the symbols of a coder group are concatenated (torch.cat) instead of being written into one buffer by the encoder stages')
     ap.add_argument('--no-prealloc', action='store_true', help='A/B: skip the coder-buffer pre-allocation pass after the warm-up steps')
     ap.add_argument('--diag-timeline', action='store_true', help='DIAGNOSTIC: HIP events around every stage of the timed run, printed to stderr (adds ~100 event records)')
     ap.add_argument('--diag-repeat', type=int, default=0, help='DIAGNOSTIC: after the timed region, time R more runs of K steps and print their wall times to stderr')
@@ -403,8 +404,11 @@ def main():
             g *= 2
         return sizes
 
+    sym_cols = [None]   # symbols per image, known after the first encoder stage
+
     def run_steps(n_steps, record=False):
         pending = {}
+        gbuf = [None]
         group = []   # (step, symbols, (h, w), event) of the steps waiting for their coder launch
         plan = group_plan(n_steps)
         back_done = {}
@@ -426,7 +430,14 @@ def main():
                 for _, g_sym, _, g_ev in group:
                     cs.wait_event(g_ev)
                     g_sym.record_stream(cs)
-                sym = group[0][1] if len(group) == 1 else torch.cat([g[1] for g in group])
+                if len(group) == 1:
+                    sym = group[0][1]
+                elif gbuf[0] is not None:        # the encoder stages wrote their symbols into one buffer: nothing to copy
+                    sym = gbuf[0]
+                    sym.record_stream(cs)
+                else:
+                    sym = torch.cat([g[1] for g in group])
+                gbuf[0] = None
                 hw = group[0][2]
                 if args.diag_skip_coder and cached:   # diagnostic only: how much the coder chains cost the MFMA stages
                     dec, nb, st = cached[0]
@@ -471,7 +482,14 @@ def main():
                         latency.append([i, e0, None])
                     if record and args.diag_timeline:
                         timeline.append(('front', i, tl_event(mfma_stream), None))
-                    sym, hw = model.stage_front(x)
+                    g_size = plan[launches[0]]
+                    out = None
+                    if g_size > 1 and sym_cols[0] is not None and not args.cat_symbols:
+                        if gbuf[0] is None:      # one buffer per coder group; encoder stage k writes row block k
+                            gbuf[0] = torch.empty((g_size * args.bs, sym_cols[0]), dtype=torch.int32, device=dev)
+                        out = gbuf[0][len(group) * args.bs:(len(group) + 1) * args.bs]
+                    sym, hw = model.stage_front(x, out=out)
+                    sym_cols[0] = sym.shape[1]
                     if record and args.diag_timeline:
                         timeline[-1] = timeline[-1][:3] + (tl_event(mfma_stream),)
                     ev = torch.cuda.Event()

@@ -261,16 +261,21 @@ class SplittableResNet(UpdatableBackbone):
 
     # ---- the same eval forward cut into three stages, so that a caller can run the serial range coder on its
     #      own HIP stream(s) while the MFMA stream works on neighbouring batches (bench.py)
-    def stage_front(self, x):
-        """encoder + quantisation: -> (symbols int32 [N, C*h*w], (h, w))."""
+    def stage_front(self, x, out=None):
+        """encoder + quantisation: -> (symbols int32 [N, C*h*w], (h, w)).  `out`: a contiguous int32 [N, C*h*w] tensor to write
+        the symbols into (a row block of the buffer one range-coder launch will read: no concatenation afterwards)."""
         if self.pre_transform is not None:
             x = self.pre_transform(x)
         bl = self.bottleneck_layer
         if type(bl).__name__ == 'FPBasedResNetBottleneck':      # last conv + quantisation in one launch
-            sym = bl.analysis(x, symbols_for=bl.entropy_bottleneck)
+            sym = bl.analysis(x, symbols_for=bl.entropy_bottleneck, out=out)
             return sym.view(sym.shape[0], -1), tuple(sym.shape[-2:])
         latent = bl.analysis(x)
-        return bl.entropy_bottleneck.symbols_device(latent), tuple(latent.shape[-2:])
+        sym = bl.entropy_bottleneck.symbols_device(latent)
+        if out is not None:
+            out.copy_(sym)
+            sym = out
+        return sym, tuple(latent.shape[-2:])
 
     def stage_coder(self, sym, hw_shape):
         """rANS encode to byte streams, then decode them: -> (decoded symbols, nbytes [N], status [N])."""

@@ -774,8 +774,9 @@ def pack_conv2x2_c48(w):
     return pack_weight_fragments(w2d)
 
 
-def conv2x2_c48_fwd(x_nhwc, w_frag, cout, medians=None, tag=None):
-    """x bf16 [N,H,W,48] -> f32 latent [N,cout,H-1,W-1], or (medians given) the int32 symbols round(y - median)."""
+def conv2x2_c48_fwd(x_nhwc, w_frag, cout, medians=None, tag=None, out=None):
+    """x bf16 [N,H,W,48] -> f32 latent [N,cout,H-1,W-1], or (medians given) the int32 symbols round(y - median).
+    `out`: a contiguous tensor of that dtype and element count to write into (e.g. a row block of a coder-group buffer)."""
     for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag')):
         _dev(t, name)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
@@ -785,7 +786,13 @@ def conv2x2_c48_fwd(x_nhwc, w_frag, cout, medians=None, tag=None):
     if sym:
         _dev(medians, 'medians')
         assert medians.dtype == torch.float32 and medians.is_contiguous() and medians.numel() == cout
-    out = torch.empty((N, cout, H - 1, W - 1), dtype=torch.int32 if sym else torch.float32, device=x_nhwc.device)
+    dt = torch.int32 if sym else torch.float32
+    if out is None:
+        out = torch.empty((N, cout, H - 1, W - 1), dtype=dt, device=x_nhwc.device)
+    else:
+        _dev(out, 'out')
+        assert out.dtype == dt and out.is_contiguous() and out.numel() == N * cout * (H - 1) * (W - 1)
+        out = out.view(N, cout, H - 1, W - 1)
     with _timed(tag or 'conv2x2_c48'):
         _check(lib().sc2_conv2x2_c48_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(medians) if sym else None, _ptr(out), N, H, W, Cin, cout,
                                          1 if sym else 0, _stream()), 'conv2x2_c48_fwd')

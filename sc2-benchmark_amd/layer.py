@@ -159,10 +159,11 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         return (c0.in_channels <= 4 and c0.kernel_size == (5, 5) and c0.stride == (2, 2) and c0.padding == (2, 2)
                 and c0.out_channels % 8 == 0)
 
-    def analysis(self, x, symbols_for=None):
+    def analysis(self, x, symbols_for=None, out=None):
         """encoder(x): f32 NCHW image batch -> f32 NCHW latent (layer.py:475-483).  `symbols_for` = an entropy model:
         the last conv then writes int32 symbols round(latent - median) directly (its epilogue quantises the f32
-        accumulators; bit-identical to latent -> EntropyModel.quantize(.., 'symbols')) and the latent is never stored."""
+        accumulators; bit-identical to latent -> EntropyModel.quantize(.., 'symbols')) and the latent is never stored.
+        `out` (with `symbols_for`): a contiguous int32 tensor of the symbols' element count to write them into."""
         _require_device(x, 'FPBasedResNetBottleneck')
         c0, g1, c2, g3, c4 = self._g_a()
         x = x.float()
@@ -225,13 +226,21 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                     self._c48_frag = hip.pack_conv2x2_c48(c4.weight)
                 self._c48_key = key
             med = symbols_for._median_vector() if symbols_for is not None else None
-            return hip.conv2x2_c48_fwd(h, self._c48_frag, c4.out_channels, medians=med, tag=c4._tag)
+            return hip.conv2x2_c48_fwd(h, self._c48_frag, c4.out_channels, medians=med, tag=c4._tag,
+                                       out=out if symbols_for is not None else None)
         if symbols_for is not None and c4.bias is None and c4.out_channels <= 96 and c4.out_channels % 8 == 0:
-            return hip.conv2d_fwd(h, c4.packed_weight(), c4.out_channels, c4.kernel_size[0], c4.kernel_size[1], c4.stride,
-                                  c4.padding, out_format=hip.OUT_I32_NCHW_SYM, ep_beta=symbols_for._median_vector(),
-                                  tag=c4._tag, k_order=c4.k_order())
-        latent = c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
-        return latent if symbols_for is None else symbols_for.quantize(latent, 'symbols', self._get_means(latent))
+            sym = hip.conv2d_fwd(h, c4.packed_weight(), c4.out_channels, c4.kernel_size[0], c4.kernel_size[1], c4.stride,
+                                 c4.padding, out_format=hip.OUT_I32_NCHW_SYM, ep_beta=symbols_for._median_vector(),
+                                 tag=c4._tag, k_order=c4.k_order())
+        else:
+            latent = c4.forward_nhwc(h, out_format=hip.OUT_F32_NCHW)
+            if symbols_for is None:
+                return latent
+            sym = symbols_for.quantize(latent, 'symbols', self._get_means(latent))
+        if out is not None:
+            out.view(sym.shape).copy_(sym)
+            return out.view(sym.shape)
+        return sym
 
     def synthesis_nhwc_tail(self, y_hat_nhwc, head):
         """decoder on a bf16 NHWC latent WITH the first two 1x1 layers of the HIP task head `head` (layer2.0's conv1 and

@@ -46,6 +46,21 @@ def test_fused_last_conv_symbols_equal_unfused(bench_model, dev):
         assert torch.equal(sym, want)
 
 
+def test_stage_front_writes_into_group_buffer(bench_model, dev):
+    """stage_front(x, out=row block of a coder-group buffer) == stage_front(x), and touches nothing but its rows."""
+    bench, model = bench_model
+    xs = [bench.synthetic_batch(8, dev, seed=s) for s in (3, 4, 5)]
+    with torch.no_grad():
+        ref = [model.stage_front(x)[0] for x in xs]
+        cols = ref[0].shape[1]
+        buf = torch.full((3 * 8 + 2, cols), -12345, dtype=torch.int32, device=dev)
+        for k, x in enumerate(xs):
+            sym, hw = model.stage_front(x, out=buf[k * 8:(k + 1) * 8])
+            assert sym.data_ptr() == buf[k * 8:(k + 1) * 8].data_ptr() and tuple(sym.shape) == (8, cols)
+    assert torch.equal(buf[:24], torch.cat(ref))
+    assert (buf[24:] == -12345).all()
+
+
 def test_bench_path_2048_streams(bench_model, dev):
     bench, model = bench_model
     bs, groups = 256, 8
