@@ -336,6 +336,7 @@ def main():
     ap.add_argument('--diag-skip-coder', type=int, default=0, help='DIAGNOSTIC (invalid as a result): 1 = reuse the first step\'s coder output, 2 = same but still run the coder')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
+    ap.add_argument('--unfused-dequantize', action='store_true', help='A/B: the coder writes int32 symbols and the decoder+head stage dequantises them (two launches more traffic)')
     ap.add_argument('--cat-symbols', action='store_true', help='A/B: the symbols of a coder group are concatenated (torch.cat) instead of being written into one buffer by the encoder stages')
     ap.add_argument('--no-prealloc', action='store_true', help='A/B: skip the coder-buffer pre-allocation pass after the warm-up steps')
     ap.add_argument('--diag-timeline', action='store_true', help='DIAGNOSTIC: HIP events around every stage of the timed run, printed to stderr (adds ~100 event records)')
@@ -450,7 +451,7 @@ def main():
                         torch.cuda._sleep(int(11e-3 * 2.0e9))
                 else:
                     tl0 = tl_event(cs) if (record and args.diag_timeline) else None
-                    dec, nb, st = model.stage_coder(sym, hw)
+                    dec, nb, st = model.stage_coder(sym, hw, dequantized=not args.unfused_dequantize)
                     if tl0 is not None:
                         timeline.append(('coder', group[0][0], tl0, tl_event(cs)))
                     if args.diag_skip_coder:

@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 31
+#define SC2_ABI_VERSION 32
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -397,6 +397,16 @@ int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const int32_t *i
                           const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
                           const int32_t *offsets, int32_t *symbols_out, int32_t *status, void *workspace,
                           int64_t workspace_bytes, void *stream);
+/* sc2_rans_decode_batch for implicit indexes (row = position / index_div, n_sym == n_cdfs * index_div) with
+ * EntropyModel.dequantize fused into its last pass (sc2bench/models/layer.py:520 `entropy_bottleneck.decompress` ->
+ * dequantize(values, medians)): y_hat_bf16_nhwc[s][pix][c] = bf16(symbol[s][c * index_div + pix] + medians[c]), the layout the
+ * synthesis kernels read (as sc2_eb_dequantize's y_hat_bf16_nhwc, same rounding).  symbols_out may be NULL (the int32 symbols
+ * are then never written).  n_cdfs % 8 == 0, n_cdfs <= 64. */
+int sc2_rans_decode_dequantize_batch(const uint8_t *in, int64_t in_stride, const int32_t *in_offset, const int32_t *in_nbytes,
+                                     int64_t index_div, int n_streams, int64_t n_sym, const int32_t *cdfs, int n_cdfs,
+                                     int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets, const float *medians,
+                                     int32_t *symbols_out, void *y_hat_bf16_nhwc, int32_t *status, void *workspace,
+                                     int64_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

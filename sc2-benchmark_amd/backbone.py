@@ -277,11 +277,17 @@ class SplittableResNet(UpdatableBackbone):
             sym = out
         return sym, tuple(latent.shape[-2:])
 
-    def stage_coder(self, sym, hw_shape):
-        """rANS encode to byte streams, then decode them: -> (decoded symbols, nbytes [N], status [N])."""
+    def stage_coder(self, sym, hw_shape, dequantized=False):
+        """rANS encode to byte streams, then decode them: -> (decoded symbols, nbytes [N], status [N]).  `dequantized`: the
+        first item is the dequantised latent as bf16 NHWC [N, h, w, C] (decode + EntropyModel.dequantize in one coder launch,
+        the int32 symbols are never written) when the tables allow it; `stage_back` takes either."""
         eb = self.bottleneck_layer.entropy_bottleneck
         hw = hw_shape[0] * hw_shape[1]
         buf, off, nb, st = eb.encode_symbols_device(sym, hw)
+        if dequantized:
+            y_hat = eb.decode_dequantize_device(buf, off, nb, sym.shape[1], hw_shape)
+            if y_hat is not None:
+                return y_hat, nb, st
         dec = eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw)
         return dec, nb, st
 
@@ -303,6 +309,8 @@ class SplittableResNet(UpdatableBackbone):
 
     def stage_decoder(self, dec_sym, hw_shape):
         """dequantise + decoder: decoded symbols -> features (the MFMA-bound half of the back stage)."""
+        if dec_sym.dtype == torch.bfloat16:
+            return self.bottleneck_layer.synthesis_nhwc(dec_sym)
         _, y_hat_nhwc = self.bottleneck_layer.entropy_bottleneck.dequantize_device(dec_sym, hw_shape)
         return self.bottleneck_layer.synthesis_nhwc(y_hat_nhwc)
 
@@ -311,6 +319,8 @@ class SplittableResNet(UpdatableBackbone):
         there: the encoder stage of a later batch is scheduled beside the head's HBM-bound kernels, not beside the
         decoder's MFMA-bound ones)."""
         if after_decoder is None:
+            if dec_sym.dtype == torch.bfloat16:      # stage_coder(..., dequantized=True): already the NHWC latent
+                return self.decode_head(dec_sym)
             _, y_hat_nhwc = self.bottleneck_layer.entropy_bottleneck.dequantize_device(dec_sym, hw_shape)
             return self.decode_head(y_hat_nhwc)
         feats = self.stage_decoder(dec_sym, hw_shape)

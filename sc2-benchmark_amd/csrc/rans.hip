@@ -477,6 +477,39 @@ __global__ __launch_bounds__(256) void rans_dec_finish_kernel(const RansArgs a) 
     }
 }
 
+// parallel pass of the fused form: the decoded symbols leave as the DEQUANTISED latent the synthesis transform reads,
+// y_hat[s][pix][c] = bf16(symbol + median[c]) (EntropyModel.dequantize of sc2bench/models/layer.py:520 + the bf16 NHWC copy of
+// eb_dequantize_tile_kernel, same rounding), straight from the [position][lane] intermediate: the int32 symbols (8 x 74 MB per
+// coder launch of the bench) are never written and the dequantise launch of the decoder + head stage disappears.
+// Block = 64 streams x P pixels x all C channels; position i = c * HW + pix (implicit indexes, index_div = HW).
+constexpr int kDqP = 16;
+__global__ __launch_bounds__(256) void rans_dec_finish_dq_kernel(const RansArgs a, const float *__restrict__ medians,
+                                                                 uint16_t *__restrict__ y_hat, int C, int HW) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dq[];   // [64][LS]: stream-major, (pixel, channel) bf16 inside
+    const int LS = kDqP * C * 2 + 16;                                    // (C % 8 == 0: rows stay 16-byte aligned)
+    const int blk = blockIdx.y;
+    const int pix0 = blockIdx.x * kDqP;
+    const int np = HW - pix0 < kDqP ? HW - pix0 : kDqP;
+    const int t = threadIdx.x, pl = t & 63;
+    for (int row = t >> 6; row < C * kDqP; row += 4) {
+        const int c = row / kDqP, p = row - c * kDqP;
+        if (p < np) {
+            const long long i = (long long)c * HW + pix0 + p;
+            const int32_t v = (int32_t)a.ws[((long long)blk * a.n_sym + i) * 64 + pl];
+            *reinterpret_cast<uint16_t *>(dq + pl * LS + (p * C + c) * 2) = f32_to_bf16_bits((float)v + medians[c]);
+        }
+    }
+    __syncthreads();
+    const int chunks = np * C * 2 / 16;   // 16-byte chunks per stream, contiguous in the NHWC output
+    for (int q = t; q < 64 * chunks; q += 256) {
+        const int sl = q / chunks, k = q - sl * chunks;
+        const int s = blk * 64 + sl;
+        if (s < a.n_streams)
+            *reinterpret_cast<uint4 *>(reinterpret_cast<unsigned char *>(y_hat) + ((long long)s * HW + pix0) * C * 2 + k * 16) =
+                *reinterpret_cast<const uint4 *>(dq + sl * LS + k * 16);
+    }
+}
+
 // generic decoder: explicit per-symbol indexes (or rows too long for the LUT path); upper-bound binary search,
 // identical in result to upstream's linear find_if over the strictly increasing CDF row.
 template <bool LDS_TABLES>
@@ -753,15 +786,25 @@ extern "C" int sc2_rans_encode_batch(const int32_t *symbols, const int32_t *inde
     return SC2_OK;
 }
 
-extern "C" int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const int32_t *in_offset,
-                                     const int32_t *in_nbytes, const int32_t *indexes, int64_t index_div,
-                                     int n_streams, int64_t n_sym, const int32_t *cdfs, int n_cdfs, int cdf_stride,
-                                     const int32_t *cdf_sizes, const int32_t *offsets, int32_t *symbols_out,
-                                     int32_t *status, void *workspace, int64_t workspace_bytes, void *stream) {
+// medians / y_hat: the fused dequantised output of sc2_rans_decode_dequantize_batch (symbols_out may then be null)
+static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_offset,
+                       const int32_t *in_nbytes, const int32_t *indexes, int64_t index_div,
+                       int n_streams, int64_t n_sym, const int32_t *cdfs, int n_cdfs, int cdf_stride,
+                       const int32_t *cdf_sizes, const int32_t *offsets, int32_t *symbols_out,
+                       int32_t *status, void *workspace, int64_t workspace_bytes, void *stream, const float *medians,
+                       void *y_hat) {
     int rc = check_common(indexes, index_div, n_streams, n_sym, cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets);
     if (rc != SC2_OK) return rc;
-    SC2_REQUIRE(in && in_offset && in_nbytes && (symbols_out || n_sym == 0) && status && workspace,
+    SC2_REQUIRE(in && in_offset && in_nbytes && (symbols_out || y_hat || n_sym == 0) && status && workspace,
                 SC2_ERR_INVALID_ARG, "rans_decode: null argument");
+    if (y_hat) {
+        SC2_REQUIRE(medians, SC2_ERR_INVALID_ARG, "rans_decode_dequantize: null medians");
+        SC2_REQUIRE(!indexes && cdf_stride <= kMaxRowLds && n_cdfs % 8 == 0 && n_cdfs <= 64 && n_sym == (int64_t)n_cdfs * index_div &&
+                        index_div < (1ll << 31),
+                    SC2_ERR_UNSUPPORTED,
+                    "rans_decode_dequantize: needs implicit indexes, n_sym == n_cdfs * index_div and a channel count that is a "
+                    "multiple of 8, <= 64 (got %d rows, %lld symbols, index_div %lld)", n_cdfs, (long long)n_sym, (long long)index_div);
+    }
     SC2_REQUIRE(in_stride >= 8 && in_stride % 4 == 0, SC2_ERR_INVALID_ARG,
                 "rans_decode: in_stride %lld must be a multiple of 4, >= 8", (long long)in_stride);
     SC2_REQUIRE(workspace_bytes >= sc2_rans_workspace_bytes(n_streams, n_sym, n_cdfs, cdf_stride), SC2_ERR_INVALID_ARG,
@@ -791,8 +834,18 @@ extern "C" int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const
         if (n_sym > 0) {
             const long long gx = (n_sym + 63) / 64;
             SC2_REQUIRE(gx < (1ll << 31) && n_blocks <= 65535, SC2_ERR_UNSUPPORTED, "rans_decode: problem too large");
-            hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
-            SC2_CHECK_LAUNCH();
+            if (y_hat) {
+                const int HW = (int)index_div;
+                const size_t dq_lds = (size_t)64 * (kDqP * n_cdfs * 2 + 16);
+                allow_big_lds(rans_dec_finish_dq_kernel, dq_lds);
+                hipLaunchKernelGGL(rans_dec_finish_dq_kernel, dim3((HW + kDqP - 1) / kDqP, n_blocks), dim3(256), dq_lds, s, a, medians,
+                                   static_cast<uint16_t *>(y_hat), n_cdfs, HW);
+                SC2_CHECK_LAUNCH();
+            }
+            if (symbols_out) {
+                hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
+                SC2_CHECK_LAUNCH();
+            }
         }
         return SC2_OK;
     }
@@ -825,4 +878,24 @@ extern "C" int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const
     }
     SC2_CHECK_LAUNCH();
     return SC2_OK;
+}
+
+extern "C" int sc2_rans_decode_batch(const uint8_t *in, int64_t in_stride, const int32_t *in_offset,
+                                     const int32_t *in_nbytes, const int32_t *indexes, int64_t index_div,
+                                     int n_streams, int64_t n_sym, const int32_t *cdfs, int n_cdfs, int cdf_stride,
+                                     const int32_t *cdf_sizes, const int32_t *offsets, int32_t *symbols_out,
+                                     int32_t *status, void *workspace, int64_t workspace_bytes, void *stream) {
+    return decode_impl(in, in_stride, in_offset, in_nbytes, indexes, index_div, n_streams, n_sym, cdfs, n_cdfs, cdf_stride, cdf_sizes,
+                       offsets, symbols_out, status, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int sc2_rans_decode_dequantize_batch(const uint8_t *in, int64_t in_stride, const int32_t *in_offset,
+                                                const int32_t *in_nbytes, int64_t index_div, int n_streams, int64_t n_sym,
+                                                const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                                const int32_t *offsets, const float *medians, int32_t *symbols_out,
+                                                void *y_hat_bf16_nhwc, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                                void *stream) {
+    SC2_REQUIRE(y_hat_bf16_nhwc, SC2_ERR_INVALID_ARG, "rans_decode_dequantize: null output");
+    return decode_impl(in, in_stride, in_offset, in_nbytes, nullptr, index_div, n_streams, n_sym, cdfs, n_cdfs, cdf_stride, cdf_sizes,
+                       offsets, symbols_out, status, workspace, workspace_bytes, stream, medians, y_hat_bf16_nhwc);
 }

@@ -609,6 +609,16 @@ class EntropyBottleneck(nn.Module):
         cdf, cdf_len, offset = self._tables()
         return hip.rans_decode_batch(buf, off, nb, n_sym, cdf, cdf_len, offset, index_div=hw)[0]
 
+    def decode_dequantize_device(self, buf, off, nb, n_sym, size):
+        """decompress + dequantize in one coder launch: -> y_hat bf16 NHWC [N, h, w, C] on device, or None when the tables
+        do not fit the fused pass (the caller then uses decode_symbols_device + dequantize_device)."""
+        cdf, cdf_len, offset = self._tables()
+        hw = size[0] * size[1]
+        if not hip.rans_decode_dequantize_supported(cdf.shape[0], cdf.shape[1]) or n_sym != cdf.shape[0] * hw:
+            return None
+        y_hat, _, _ = hip.rans_decode_dequantize_batch(buf, off, nb, n_sym, cdf, cdf_len, offset, hw, self._median_vector())
+        return y_hat.view(y_hat.shape[0], size[0], size[1], cdf.shape[0])
+
     def dequantize_device(self, sym, size, want_f32=False, want_nhwc=True):
         """int32 symbols [N, C*prod(size)] -> (y_hat f32 NCHW or None, y_hat bf16 NHWC or None)."""
         C = self._quantized_cdf.shape[0]

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
-    'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch',
+    'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch',
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
     L.sc2_rans_encode_batch.argtypes = [vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]
     L.sc2_rans_decode_batch.argtypes = [vp, i64, vp, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, i64,
                                         vp]
+    L.sc2_rans_decode_dequantize_batch.argtypes = [vp, i64, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     for name in ABI_SYMBOLS:
         getattr(L, name)  # raises AttributeError if the library lacks a declared symbol
     _lib = L
@@ -1071,6 +1072,36 @@ def rans_encode_batch(symbols, cdfs, cdf_sizes, offsets, indexes=None, index_div
                                          out_stride, _ptr(off), _ptr(nb), _ptr(st), _ptr(ws), ws_bytes, _stream()),
                'rans_encode_batch')
     return buf, off, nb, st
+
+
+def rans_decode_dequantize_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, index_div, medians, want_symbols=False):
+    """Decode (implicit indexes: row = position // index_div) with the dequantisation fused into the last pass:
+    -> (y_hat bf16 NHWC [n_streams, index_div, C] flat pixels, status, symbols or None)."""
+    for name, t in (('buf', buf), ('off', off), ('nb', nb), ('cdfs', cdfs), ('cdf_sizes', cdf_sizes), ('offsets', offsets),
+                    ('medians', medians)):
+        _dev(t, name)
+        assert t.is_contiguous(), name
+    assert buf.dtype == torch.uint8 and buf.dim() == 2 and medians.dtype == torch.float32
+    n_streams, stride = buf.shape
+    C = cdfs.shape[0]
+    assert medians.numel() == C and n_sym == C * int(index_div)
+    dev = buf.device
+    y_hat = torch.empty((n_streams, int(index_div), C), dtype=torch.bfloat16, device=dev)
+    sym = torch.empty((n_streams, n_sym), dtype=torch.int32, device=dev) if want_symbols else None
+    st = torch.empty((n_streams,), dtype=torch.int32, device=dev)
+    ws_bytes = int(lib().sc2_rans_workspace_bytes(n_streams, n_sym, cdfs.shape[0], cdfs.shape[1]))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with _timed('rans_decode'):
+        _check(lib().sc2_rans_decode_dequantize_batch(_ptr(buf), stride, _ptr(off), _ptr(nb), int(index_div), n_streams, int(n_sym),
+                                                      _ptr(cdfs), cdfs.shape[0], cdfs.shape[1], _ptr(cdf_sizes), _ptr(offsets),
+                                                      _ptr(medians), _ptr(sym) if want_symbols else None, _ptr(y_hat), _ptr(st),
+                                                      _ptr(ws), ws_bytes, _stream()), 'rans_decode_dequantize_batch')
+    return y_hat, st, sym
+
+
+def rans_decode_dequantize_supported(n_cdfs, cdf_stride):
+    """True if sc2_rans_decode_dequantize_batch takes these tables (channel count % 8 == 0, <= 64, rows within the LUT decoder)."""
+    return n_cdfs % 8 == 0 and n_cdfs <= 64 and cdf_stride <= 4096 and os.environ.get('SC2_RANS_FUSED_DQ', '1') != '0'
 
 
 def rans_decode_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, indexes=None, index_div=0):

@@ -9,6 +9,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _hip():
+    import sc2bench_amd
+    return sc2bench_amd.hip
+
+
 @pytest.fixture(scope='module')
 def bench_model(dev):
     import bench
@@ -59,6 +64,30 @@ def test_stage_front_writes_into_group_buffer(bench_model, dev):
             assert sym.data_ptr() == buf[k * 8:(k + 1) * 8].data_ptr() and tuple(sym.shape) == (8, cols)
     assert torch.equal(buf[:24], torch.cat(ref))
     assert (buf[24:] == -12345).all()
+
+
+def test_fused_decode_dequantize_equals_two_launches(bench_model, dev):
+    """stage_coder(dequantized=True): the coder's last pass writes the bf16 NHWC latent == decode -> dequantize_device, bit for
+    bit (ragged last pixel block: 3025 = 189 * 16 + 1; a stream count that is not a multiple of 64), and stage_back accepts it."""
+    bench, model = bench_model
+    eb = model.bottleneck_layer.entropy_bottleneck
+    x = bench.synthetic_batch(70, dev, seed=11)
+    with torch.no_grad():
+        sym, hw = model.stage_front(x)
+        dec, nb, st = model.stage_coder(sym, hw)
+        y2, nb2, st2 = model.stage_coder(sym, hw, dequantized=True)
+        assert dec.dtype == torch.int32 and y2.dtype == torch.bfloat16 and tuple(y2.shape) == (70, hw[0], hw[1], 24)
+        assert torch.equal(dec, sym) and int(st.max()) == 0 and int(st2.max()) == 0 and torch.equal(nb, nb2)
+        _, ref = eb.dequantize_device(dec, hw)
+        assert torch.equal(y2.view(torch.int16), ref.view(torch.int16))
+        assert torch.equal(model.stage_back(y2, hw), model.stage_back(dec, hw))
+        # symbols alongside
+        cdf, cdf_len, offset = eb._tables()
+        buf, off, nbb, _ = eb.encode_symbols_device(sym, hw[0] * hw[1])
+        y3, st3, sym3 = _hip().rans_decode_dequantize_batch(buf, off, nbb, sym.shape[1], cdf, cdf_len, offset, hw[0] * hw[1],
+                                                               eb._median_vector(), want_symbols=True)
+    if y3 is not None:
+        assert torch.equal(sym3, sym) and torch.equal(y3.view(torch.int16).view(-1), ref.view(torch.int16).view(-1))
 
 
 def test_bench_path_2048_streams(bench_model, dev):
