@@ -74,41 +74,49 @@ struct P1Args {
     unsigned x_bytes, w_bytes;
 };
 
-constexpr int MT = 13;                   // MFMA row tiles per tile
-constexpr int PX = MT * 16;              // 208 output pixels per tile
-constexpr int NRG = 4;                   // 64-row direct-to-LDS pieces per plane (256 rows >= 208)
-constexpr int PLANE = NRG * 1024;        // bytes per 16-byte-chunk plane
-constexpr int SLAB_PLANES = 8;           // 64 channels per slab
-constexpr int WIN_BYTES = SLAB_PLANES * PLANE;   // 32 KB; NBUF of them form the ring (NBUF - 1 slabs in flight)
+// MT_ MFMA row tiles per tile: 13 (208 pixels, two workgroups per CU or one with the 4-deep ring) or 7 (112 pixels, ~150 VGPRs,
+// three workgroups per CU: twice as many, smaller workgroups, which lose less when slots are taken by kernels running beside them)
+template <int MT_>
+struct Tile {
+    static constexpr int MT = MT_;
+    static constexpr int PX = MT * 16;                    // output pixels per tile
+    static constexpr int NRG = (PX + 63) / 64;            // 64-row direct-to-LDS pieces per plane
+    static constexpr int PLANE = NRG * 1024;              // bytes per 16-byte-chunk plane
+    static constexpr int WIN_BYTES = 8 * PLANE;           // one 64-channel slab = eight planes; NBUF of them form the ring
+};
 constexpr int PF = 4;                    // weight fragments are fetched this many k-steps ahead (4 k-steps per loop trip)
 
 // one k-step: 32 channels = chunk planes 4 KS .. 4 KS + 3 of window PAR
-template <int PAR, int KS>
-__device__ __forceinline__ void k_step(f32x4_t (&acc)[MT][2], const uint32_t (&a_base)[MT], const uint4 &b0, const uint4 &b1) {
-    constexpr int OFF = (PAR & 1) * WIN_BYTES + KS * 4 * PLANE;   // (a_base points at window PAR & ~1: 16-bit immediates)
+template <class T, int I>
+__device__ __forceinline__ void mma_chain(f32x4_t (&acc)[T::MT][2], u32x4_t (&av)[T::MT], const bf16x8_t &bf0, const bf16x8_t &bf1) {
+    if constexpr (I < T::MT) {
+        wait_lgkm<T::MT - 1 - I>(av[I]);
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[I]);
+        acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[I][0], 0, 0, 0);
+        acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[I][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chain<T, I + 1>(acc, av, bf0, bf1);
+    }
+}
+
+template <class T, int PAR, int KS>
+__device__ __forceinline__ void k_step(f32x4_t (&acc)[T::MT][2], const uint32_t (&a_base)[T::MT], const uint4 &b0, const uint4 &b1) {
+    constexpr int MT = T::MT;
+    constexpr int OFF = (PAR & 1) * T::WIN_BYTES + KS * 4 * T::PLANE;   // (a_base points at window PAR & ~1: 16-bit immediates)
     u32x4_t av[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) av[i] = lds_read16_imm<OFF>(a_base[i]);
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
-#define SC2_P1_MMA(i)                                                                           \
-    {                                                                                           \
-        wait_lgkm<MT - 1 - (i)>(av[i]);                                                         \
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[i]);                                \
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-    }
-    SC2_P1_MMA(0) SC2_P1_MMA(1) SC2_P1_MMA(2) SC2_P1_MMA(3) SC2_P1_MMA(4) SC2_P1_MMA(5) SC2_P1_MMA(6)
-    SC2_P1_MMA(7) SC2_P1_MMA(8) SC2_P1_MMA(9) SC2_P1_MMA(10) SC2_P1_MMA(11) SC2_P1_MMA(12)
-#undef SC2_P1_MMA
+    mma_chain<T, 0>(acc, av, bf0, bf1);
 }
 
 // NBUF = 2: 64 KB of LDS, two workgroups per CU (the partner covers the slab that is not yet there): layers with many tiles.
 // NBUF = 4: 128 KB, one workgroup per CU, three slabs (1.5 us of MFMA work) in flight: the 12 544-pixel layers of layer4, whose
 // 244 - 976 workgroups would otherwise wait for every slab (one slab ahead = 0.5 us against ~2 us of loaded HBM latency).
-template <int NBUF>
-__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv1x1_win_kernel(const P1Args p) {
+template <int NBUF, class T>
+__global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void conv1x1_win_kernel(const P1Args p) {
+    constexpr int MT = T::MT, PX = T::PX, NRG = T::NRG, PLANE = T::PLANE, WIN_BYTES = T::WIN_BYTES;
     constexpr uint32_t OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
@@ -202,8 +210,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv1x1_win_kernel(con
     {                                                                                 \
         const uint4 b0 = bq[SLOT][0], b1 = bq[SLOT][1];                               \
         fetch_b((uint32_t)(cb) * 2u + (KS + PF), bq[SLOT][0], bq[SLOT][1]);           \
-        if constexpr ((PAR) < 2) k_step<PAR, KS>(acc, a_base, b0, b1);                \
-        else k_step<PAR, KS>(acc, a_base2, b0, b1);                                   \
+        if constexpr ((PAR) < 2) k_step<T, PAR, KS>(acc, a_base, b0, b1);             \
+        else k_step<T, PAR, KS>(acc, a_base2, b0, b1);                                \
     }
     // this wave's share of window cb has landed when at most the loads issued after it are outstanding: the NBUF - 2 younger
     // windows (8 pieces each) and the 2 x 2 weight fetches of each of the NBUF - 1 slabs since (fewer near the ends: a
@@ -266,16 +274,18 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void conv1x1_win_kernel(con
     }
 }
 
-template <int NBUF>
-int launch_p1(const P1Args &a, long long n_wg, hipStream_t s) {
-    constexpr int LDS_BYTES = NBUF * WIN_BYTES;
+template <int NBUF, class T>
+int launch_p1(const P1Args &a, hipStream_t s) {
+    constexpr int LDS_BYTES = NBUF * T::WIN_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_win_kernel<NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_win_kernel<NBUF, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv1x1_win_kernel<NBUF>, dim3((unsigned)n_wg), dim3(256), LDS_BYTES, s, a);
+    const long long n_wg = (a.M + T::PX - 1) / T::PX * a.n_chunks;
+    SC2_REQUIRE(n_wg < (1ll << 31), SC2_ERR_UNSUPPORTED, "conv1x1_win: grid too large");
+    hipLaunchKernelGGL((conv1x1_win_kernel<NBUF, T>), dim3((unsigned)n_wg), dim3(256), LDS_BYTES, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -307,9 +317,7 @@ extern "C" int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const floa
     a.n_chunks = Cout / 128;
     a.M = M;
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
-    const long long n_mtiles = (M + PX - 1) / PX;
-    const long long n_wg = n_mtiles * a.n_chunks;
-    SC2_REQUIRE(n_wg < (1ll << 31), SC2_ERR_UNSUPPORTED, "conv1x1_win: grid too large");
+    const long long n_wg = (M + 207) / 208 * a.n_chunks;   // (workgroups of the 208-pixel tiling)
     // ring depth: four buffers (one workgroup per CU) when the launch has about one workgroup per CU anyway (layer4's conv1 at
     // bs 256: 244 workgroups, 0.050 -> 0.045 ms; every launch with more workgroups measured slower that way) and K is a
     // multiple of 256; SC2_P1_NBUF = 2 | 4 overrides (A/B)
@@ -319,5 +327,9 @@ extern "C" int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const floa
         if (v == 2 || (v == 4 && Cin % 256 == 0)) nbuf = v;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return nbuf == 4 ? launch_p1<4>(a, n_wg, s) : launch_p1<2>(a, n_wg, s);
+    if (nbuf == 4) return launch_p1<4, Tile<13>>(a, s);
+    // half tiles (SC2_P1_HALF=1; off by default): 112-pixel tiles, three workgroups per CU.  Unlike the 3x3 kernels (conv3x3_win.hip)
+    // this one loses with them -- conv1 of layer2 0.068 -> 0.076 ms, bench - 0.3 %: per pixel a 1x1 layer streams twice the weights
+    static const int half = [] { const char *e = getenv("SC2_P1_HALF"); return e ? atoi(e) : 0; }();
+    return half ? launch_p1<2, Tile<7>>(a, s) : launch_p1<2, Tile<13>>(a, s);
 }

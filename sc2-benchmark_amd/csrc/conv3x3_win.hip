@@ -91,7 +91,7 @@ struct Geo {
     static constexpr int MT = (PX + 15) / 16;
     static constexpr int LDS_BYTES = 2 * WIN_BYTES;
     static_assert(H % ROWS == 0 && (IMGS == 1 || ROWS == H), "whole rows of one image, or whole images");
-    static_assert(PLANE % 256 == 0 && MT == 13, "13 row tiles, bank-aligned planes");
+    static_assert(PLANE % 256 == 0 && (MT == 13 || MT == 7), "13 (or, half tiles, 7) row tiles, bank-aligned planes");
     static_assert(WIN_BYTES + (2 * PWD + 2) * 16 < 65536, "tap offsets are 16-bit immediates");
     static constexpr int tap_off(int tap) { return ((tap / 3) * PWD + tap % 3) * 16; }   // bytes from tap (0, 0)'s fragment row
 };
@@ -117,7 +117,7 @@ struct GeoS2 {
     static constexpr int MT = (PX + 15) / 16;
     static constexpr int LDS_BYTES = WIN_BYTES;                  // ONE window (60 - 64 KB): two workgroups per CU
     static_assert(OH % ROWS == 0 && (IMGS == 1 || ROWS == OH), "whole rows of one image, or whole images");
-    static_assert(PLANE % 256 == 0 && MT == 13, "13 row tiles, bank-aligned planes");
+    static_assert(PLANE % 256 == 0 && (MT == 13 || MT == 7), "13 (or, half tiles, 7) row tiles, bank-aligned planes");
     static_assert(4 * CLS * 16 < 65536, "tap offsets are 16-bit immediates");
     static constexpr int tap_off(int tap) {
         const int kh = tap / 3, kw = tap % 3;
@@ -126,6 +126,19 @@ struct GeoS2 {
 };
 
 constexpr int PF = 3;   // weight fragments are fetched this many k-steps ahead (18 k-steps per loop trip: 18 % PF == 0)
+
+// MFMAs of one k-step, row tile I onwards: each waits for its own fragment read only (MT - 1 - I younger reads may be in flight)
+template <class G, int DBG, int I>
+__device__ __forceinline__ void mma_chain(f32x4_t (&acc)[G::MT][2], u32x4_t (&av)[G::MT], const bf16x8_t &bf0, const bf16x8_t &bf1) {
+    if constexpr (I < G::MT) {
+        if constexpr (!(DBG & 4)) wait_lgkm<G::MT - 1 - I>(av[I]);
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[I]);
+        acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[I][0], 0, 0, 0);
+        acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[I][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chain<G, DBG, I + 1>(acc, av, bf0, bf1);
+    }
+}
 
 template <class G, int PAR, int TAP, int DBG>
 __device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t (&a_base)[G::MT], const uint4 &b0, const uint4 &b1) {
@@ -139,22 +152,12 @@ __device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t 
     }
     __builtin_amdgcn_sched_barrier(0);
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
-#define SC2_WIN_MMA(i)                                                                          \
-    {                                                                                           \
-        if constexpr (!(DBG & 4)) wait_lgkm<MT - 1 - (i)>(av[i]);                               \
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[i]);                                \
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-    }
-    SC2_WIN_MMA(0) SC2_WIN_MMA(1) SC2_WIN_MMA(2) SC2_WIN_MMA(3) SC2_WIN_MMA(4) SC2_WIN_MMA(5) SC2_WIN_MMA(6)
-    SC2_WIN_MMA(7) SC2_WIN_MMA(8) SC2_WIN_MMA(9) SC2_WIN_MMA(10) SC2_WIN_MMA(11) SC2_WIN_MMA(12)
-#undef SC2_WIN_MMA
+    mma_chain<G, DBG, 0>(acc, av, bf0, bf1);
 }
 
 // DBG (timing experiments, results garbage): 1 no window refills, 2 no weight fetches in the loop, 4 no fragment reads, 8 no barriers
 template <class G, int DBG = 0>
-__global__ __launch_bounds__(256, 2) void conv3x3_win_kernel(const WinArgs p) {
+__global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(const WinArgs p) {
     constexpr int MT = G::MT, W = G::W, H = G::H;
     constexpr uint32_t OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -332,7 +335,7 @@ int launch_win(WinArgs a, hipStream_t s) {
 // CU: while one waits for its next window the other has the matrix pipes (a slab is 234 MFMAs per wave = 3.7 k cycles against
 // ~2 k cycles to land 60 KB).  Two barriers per slab: everybody done with window cb - 1 / window cb complete.
 template <class G>
-__global__ __launch_bounds__(256, 2) void conv3x3s2_win_kernel(const WinArgs p) {
+__global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3s2_win_kernel(const WinArgs p) {
     constexpr int MT = G::MT, W = G::W, H = G::H, OW = G::OW, OH = G::OH;
     constexpr uint32_t OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -464,9 +467,19 @@ int launch_win_s2(WinArgs a, hipStream_t s) {
 typedef Geo<28, 7, 1> G28;
 typedef Geo<14, 14, 1> G14;
 typedef Geo<7, 7, 4> G7;
+// half tiles (7 row tiles, ~156 VGPRs, three workgroups per CU), the default: as fast alone (0.053 / 0.053 / 0.052 ms against
+// 0.053 / 0.049 / 0.054), and launches of twice as many, smaller workgroups lose less when workgroup slots are taken by the
+// kernels running beside them in the pipeline (bench + 0.5 % at K = 20, + 0.9 % at K = 100; SC2_WIN_HALF=0 = whole tiles;
+// DESIGN.md section 6)
+typedef Geo<28, 4, 1> H28;
+typedef Geo<14, 7, 1> H14;
+typedef Geo<7, 7, 2> H7;
 typedef GeoS2<28, 7, 1> S28;   // 56 x 56 -> 28 x 28
 typedef GeoS2<14, 14, 1> S14;  // 28 x 28 -> 14 x 14
 typedef GeoS2<7, 7, 4> S7;     // 14 x 14 -> 7 x 7
+typedef GeoS2<28, 4, 1> HS28;  // half tiles (SC2_WIN_HALF): 32 - 40 KB windows, three workgroups per CU
+typedef GeoS2<14, 7, 1> HS14;
+typedef GeoS2<7, 7, 2> HS7;
 
 }  // namespace
 
@@ -495,6 +508,12 @@ extern "C" int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const fl
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
     a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int half = [] { const char *e = getenv("SC2_WIN_HALF"); return e ? atoi(e) : 1; }();
+    if (half) {
+        if (W == 56) return launch_win_s2<HS28>(a, s);
+        if (W == 28) return launch_win_s2<HS14>(a, s);
+        return launch_win_s2<HS7>(a, s);
+    }
     if (W == 56) return launch_win_s2<S28>(a, s);
     if (W == 28) return launch_win_s2<S14>(a, s);
     return launch_win_s2<S7>(a, s);
@@ -525,6 +544,12 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
     a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const int half = [] { const char *e = getenv("SC2_WIN_HALF"); return e ? atoi(e) : 1; }();
+    if (half) {
+        if (W == 28) return launch_win<H28>(a, s);
+        if (W == 14) return launch_win<H14>(a, s);
+        return launch_win<H7>(a, s);
+    }
     if (W == 28) return launch_win<G28>(a, s);
     if (W == 14) {
         const char *dbg = getenv("SC2_WIN_DBG");   // timing experiments on the 14 x 14 geometry (results garbage)
