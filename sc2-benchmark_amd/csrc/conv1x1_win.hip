@@ -10,9 +10,10 @@
 // their time going into the resident-weight prologue (0.5 - 2 MB per workgroup), the K-half exchange and tile quantisation.
 // Here, as in conv3x3_win.hip:
 //   * a tile is 208 consecutive output pixels (13 MFMA row tiles, no image structure needed for a 1x1 layer) x 128 channels,
-//     wave w = 32 channels x 13 row tiles (26 accumulator tiles), two workgroups per CU;
-//   * the pixel operand is staged per 64-channel slab as eight 16-byte-chunk planes [chunk][pixel][16 B], double-buffered
-//     (2 x 32 KB): fragment rows are one address register per row tile + immediates, no vector ALU in the K loop;
+//     wave w = 32 channels x 13 row tiles (26 accumulator tiles), two workgroups per CU (Tile<13>; Tile<7> = 112 pixels,
+//     three workgroups per CU, is an option that measured slower here);
+//   * the pixel operand is staged per 64-channel slab as eight 16-byte-chunk planes [chunk][pixel][16 B] in a ring of two
+//     (2 x 32 KB) or four slabs: fragment rows are one address register per row tile + immediates, no vector ALU in the K loop;
 //   * weights go L2 -> registers, fragment-major, four k-steps ahead; ONE barrier per slab (52 MFMAs per wave);
 //   * the weight rows are permuted at packing time so that a lane holds eight consecutive channels of a pixel: 13 sixteen-byte
 //     stores (and residual loads) per lane, bias / residual / ReLU in registers.
