@@ -713,6 +713,18 @@ int check_common(const int32_t *indexes, long long index_div, int n_streams, lon
     return SC2_OK;
 }
 
+// Small launches (<= 16 serial waves: up to 1 024 streams) ask for 159 KB of LDS per wave, so that no LDS-using workgroup of
+// another kernel shares their CU: the serial chain is latency-bound, every MFMA wave on its SIMD stretches it, and a launch this
+// small is what the FIRST decoder stage of a pipeline run waits for (bench K = 20: first coder launch 28.0 -> 27.3 ms, + 0.7 %
+// images/s, 3 of 3 runs; 16 CUs at most).  Larger launches keep their footprint: giving 32 - 64 CUs away costs more than it
+// gains.  SC2_RANS_LDS_PAD (KB, 0 = off) / SC2_RANS_PAD_WAVES override (A/B).
+static size_t lds_pad(size_t need, int n_wave_blocks) {
+    static const int pad_kb = [] { const char *e = getenv("SC2_RANS_LDS_PAD"); return e ? atoi(e) : 159; }();
+    static const int max_waves = [] { const char *e = getenv("SC2_RANS_PAD_WAVES"); return e ? atoi(e) : 16; }();
+    const size_t want = (size_t)pad_kb * 1024;
+    return (n_wave_blocks <= max_waves && want > need) ? want : need;
+}
+
 template <class K>
 void allow_big_lds(K kernel, size_t bytes) {
     if (bytes > 48 * 1024)
@@ -776,7 +788,7 @@ extern "C" int sc2_rans_encode_batch(const int32_t *symbols, const int32_t *inde
     SC2_CHECK_LAUNCH();
     const size_t stage_lds = (size_t)(kStage + 1) * 64 * 4;
     if (n_entries <= kEncLdsEntries) {
-        const size_t lds = stage_lds + (size_t)n_entries * sizeof(EncEntry);
+        const size_t lds = lds_pad(stage_lds + (size_t)n_entries * sizeof(EncEntry), n_blocks);
         allow_big_lds(rans_enc_serial_kernel<true>, lds);
         hipLaunchKernelGGL(rans_enc_serial_kernel<true>, dim3(n_blocks), dim3(64), lds, s, a, gtab);
     } else {
@@ -822,7 +834,7 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!indexes && cdf_stride <= kMaxRowLds) {
         const bool small = cdf_stride <= 257;   // symbol indexes fit a byte
-        const size_t lds = (size_t)65536 * (small ? 1 : 2) + (size_t)kWin * 64 * 4 + (size_t)cdf_stride * 4 + 16;
+        const size_t lds = lds_pad((size_t)65536 * (small ? 1 : 2) + (size_t)kWin * 64 * 4 + (size_t)cdf_stride * 4 + 16, n_blocks);
         if (small) {
             allow_big_lds(rans_dec_lut_kernel<uint8_t>, lds);
             hipLaunchKernelGGL(rans_dec_lut_kernel<uint8_t>, dim3(n_blocks), dim3(64), lds, s, a);
