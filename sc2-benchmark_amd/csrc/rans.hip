@@ -157,8 +157,20 @@ __global__ __launch_bounds__(64) void rans_enc_serial_kernel(const RansArgs a, c
         long long avail = ptr - limit;
         int n_store = cnt;
         if ((long long)cnt > avail) { n_store = (int)avail; overflow = 1; }
-        for (int j = 0; __any(j < n_store); ++j)
-            if (j < n_store) ptr[-1 - j] = stl[j * 64];
+        // four words per store where a lane has them (every lane writes ITS row: a 4-byte store per lane is 64 separate
+        // requests per wave-instruction); dword-aligned dwordx4, words in descending address order as emitted
+        struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
+        const int n4 = n_store & ~3;
+        for (int j = 0; __any(j < n4); j += 4) {
+            if (j < n4) {
+                Words4 t;
+                t.v[3] = stl[j * 64]; t.v[2] = stl[(j + 1) * 64]; t.v[1] = stl[(j + 2) * 64]; t.v[0] = stl[(j + 3) * 64];
+                *reinterpret_cast<Words4 *>(ptr - 4 - j) = t;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (n4 + r < n_store) ptr[-1 - (n4 + r)] = stl[(n4 + r) * 64];
         ptr -= n_store;
         cnt = 0;
     };
@@ -334,16 +346,28 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
 
     int lp = 0;   // words [0, lp) of this lane's stream have been copied into the ring
     int rp = 0;   // next unread word
-    auto top_up = [&]() {   // every lane whose ring has >= 16 free slots takes its next 16 words (0 past the end)
+    // every lane whose ring has >= 16 free slots takes its next 16 words (0 past the end) as four 16-byte loads: a lane's words
+    // are consecutive in ITS stream and every lane reads another row, so a 4-byte load per lane is 64 separate 4-byte requests
+    // per wave-instruction -- four times the requests of the same bytes as dwordx4 (dword-aligned, which gfx950 allows)
+    struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
+    auto top_up = [&]() {
         const bool want = lp - rp <= kWin - 16;
-#pragma unroll 4
-        for (int j = 0; j < 16; ++j) {
-            if (want) {
-                const int k = lp + j;
-                wl[(k & (kWin - 1)) * 64] = k < n_words ? w[k] : 0u;
+        if (want) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = lp + 4 * q;
+                Words4 t;
+                if (k + 3 < n_words) {
+                    t = *reinterpret_cast<const Words4 *>(w + k);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t.v[e] = k + e < n_words ? w[k + e] : 0u;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wl[((k + e) & (kWin - 1)) * 64] = t.v[e];
             }
+            lp += 16;
         }
-        if (want) lp += 16;
     };
     auto ring = [&](int k) { return wl[(k & (kWin - 1)) * 64]; };
     top_up();
