@@ -349,24 +349,33 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
     // every lane whose ring has >= 16 free slots takes its next 16 words (0 past the end) as four 16-byte loads: a lane's words
     // are consecutive in ITS stream and every lane reads another row, so a 4-byte load per lane is 64 separate 4-byte requests
     // per wave-instruction -- four times the requests of the same bytes as dwordx4 (dword-aligned, which gfx950 allows)
+    // ... and one top-up AHEAD: pre[] holds words [lp, lp + 16) of the lane's stream, loaded when the previous top-up ran, so a
+    // top-up writes registers to the ring and issues the next loads without waiting for memory
     struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
+    uint32_t pre[16];
+    auto prefetch = [&]() {   // pre[] <- words [lp, lp + 16)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lp + 4 * q;
+            Words4 t;
+            if (k + 3 < n_words) {
+                t = *reinterpret_cast<const Words4 *>(w + k);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t.v[e] = k + e < n_words ? w[k + e] : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pre[4 * q + e] = t.v[e];
+        }
+    };
+    prefetch();
     auto top_up = [&]() {
         const bool want = lp - rp <= kWin - 16;
         if (want) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = lp + 4 * q;
-                Words4 t;
-                if (k + 3 < n_words) {
-                    t = *reinterpret_cast<const Words4 *>(w + k);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t.v[e] = k + e < n_words ? w[k + e] : 0u;
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wl[((k + e) & (kWin - 1)) * 64] = t.v[e];
-            }
+            for (int j = 0; j < 16; ++j) wl[((lp + j) & (kWin - 1)) * 64] = pre[j];
             lp += 16;
+            prefetch();
         }
     };
     auto ring = [&](int k) { return wl[(k & (kWin - 1)) * 64]; };
