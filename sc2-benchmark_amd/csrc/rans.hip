@@ -229,32 +229,46 @@ __global__ __launch_bounds__(64) void rans_enc_serial_kernel(const RansArgs a, c
     constexpr int U = 8;
     long long i = a.n_sym - 1;
     for (long long rem = a.n_sym % U; rem > 0; --rem, --i) step_slow(wsb[i * 64], i);   // ragged head
-    uint32_t e_cur[U], e_nxt[U];
-    if (i >= 0) {
+    // The entries of a chunk are loaded TWO chunks ahead, in three register sets that rotate by name (copying one set into
+    // another would make the wave wait for it a chunk early): the [position][lane] intermediate of a 2 048-stream launch is
+    // 600 MB, it comes from HBM, and one chunk of symbols (~1 us) is shorter than a loaded HBM round trip.
+    auto load_chunk = [&](uint32_t (&e)[U], long long i0) {
+        if (i0 >= 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) e_cur[u] = wsb[(i - u) * 64];
-    }
-    for (; i >= 0; i -= U) {
-        if (i - U >= 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) e_nxt[u] = wsb[(i - U - u) * 64];
+            for (int u = 0; u < U; ++u) e[u] = wsb[(i0 - u) * 64];
         }
+    };
+    auto code_chunk = [&](const uint32_t (&e)[U], long long i0) {
         uint32_t esc = 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) esc |= e_cur[u];
+        for (int u = 0; u < U; ++u) esc |= e[u];
         if (__any((esc >> 31) != 0)) {
 #pragma unroll 1
-            for (int u = 0; u < U; ++u) step_slow(e_cur[u], i - u);
+            for (int u = 0; u < U; ++u) step_slow(e[u], i0 - u);
         } else {
             if (__any(cnt > kStage - U)) flush();
             EncEntry en[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) en[u] = tab[e_cur[u]];
+            for (int u = 0; u < U; ++u) en[u] = tab[e[u]];
 #pragma unroll
             for (int u = 0; u < U; ++u) put_fast(en[u]);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) e_cur[u] = e_nxt[u];
+    };
+    uint32_t e0[U], e1[U], e2[U];
+    load_chunk(e0, i);
+    load_chunk(e1, i - U);
+    while (i >= 0) {
+        load_chunk(e2, i - 2 * U);
+        code_chunk(e0, i);
+        i -= U;
+        if (i < 0) break;
+        load_chunk(e0, i - 2 * U);
+        code_chunk(e1, i);
+        i -= U;
+        if (i < 0) break;
+        load_chunk(e1, i - 2 * U);
+        code_chunk(e2, i);
+        i -= U;
     }
     flush();
     if (active) {
