@@ -10,8 +10,8 @@ reference's evaluation mode after update() (sc2bench/models/backbone.py:229-233)
     dequantise -> decoder (3 MFMA convs + 2 inverse GDN1) -> ResNet-50 layer2..fc -> logits.
 Nothing is skipped: the byte streams are really produced and really decoded; bpp is 8 * bytes / pixels.
 Steps are software-pipelined over HIP streams: the encoder stage on one stream, decoder + head on a second, and the serial
-range coder on two coder streams, ONE coder launch per 8 steps (8 x 256 image streams encoded, then decoded, by the same
-two serial kernels: their ~25 ms are per-stream latency, not work, and do not grow with the number of streams).  Measured:
+range coder on four coder streams, ONE coder launch per 8 steps (8 x 256 image streams encoded, then decoded, by the same
+two serial kernels: their ~20 ms are per-stream latency, not work, and do not grow with the number of streams).  Measured:
 a long-running kernel on another hardware queue slows every MFMA launch of the pipeline, even a single-thread spin
 kernel (6.3 ms per step without the coder, 7.1 ms with spin kernels in its place, 7.9 ms with one coder chain per step,
 6.7 ms with one per 8 steps; `--diag-skip-coder`, tools/diag_coder.sh), so fewer, wider coder launches win.  Exactly K
