@@ -316,6 +316,26 @@ def dry_run(args, world, rank, local_rank):
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <the same arguments>` as a child process (one rank per
+    GPU over RCCL, rendezvous on 127.0.0.1 and a free port), relays its output and exits with its return code.  A process
+    that has initialised the GPU must never be replaced or forked into ranks: this one has not touched it."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print('bench.py: the {}-rank launch failed with return code {}'.format(n, rc), file=sys.stderr)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -346,10 +366,16 @@ def main():
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `bench.py --gpus N` on its own: this process becomes the launcher.  It has made no HIP call (importing torch makes
+        # none) and makes none: the N ranks are CHILD processes, one per GPU, and this one only relays rank 0's line.
+        return self_launch(args.gpus)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.dry_run:
+        if args.gpus != world:
+            raise SystemExit('bench.py: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
         return dry_run(args, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
@@ -359,8 +385,9 @@ def main():
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
-    if args.gpus != world and rank == 0 and distributed:
-        print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus {} but WORLD_SIZE {}: the line would not describe the run that was asked for'
+                         .format(args.gpus, world))
 
     import sc2bench_amd as S
     from sc2bench_amd import hip
@@ -383,8 +410,18 @@ def main():
         if args.split_mfma else [mfma_stream]
     coder_streams = [torch.cuda.Stream(device=dev, priority=args.coder_priority) for _ in range(n_coder)]
     head_streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.head_streams, args.head_halves))]
-    with torch.no_grad():   # fold / pack every cached weight once, before the side streams use them
-        model.forward_device(x[:2])
+    sym_cols = [None]   # symbols per image
+    with torch.no_grad():
+        # fold / pack every cached weight once on the null stream, before the side streams use them, THROUGH THE THREE STAGES the
+        # pipeline runs (the staged form packs more than forward_device does: the symbol-writing last encoder conv and the
+        # decoder tail that carries layer2.0's two 1x1 layers), and learn the symbol count per image so that the very first
+        # coder group of a run already writes into its shared buffer
+        sym0, hw0 = model.stage_front(x[:2])
+        dec0, _, st0 = model.stage_coder(sym0, hw0, dequantized=not args.unfused_dequantize)
+        model.stage_back(dec0, hw0)
+        sym_cols[0] = sym0.shape[1]
+        assert int(st0.max().item()) == 0
+        del sym0, dec0, st0
     torch.cuda.synchronize(dev)
     results = [None]
     cached = []
@@ -405,12 +442,10 @@ def main():
             g *= 2
         return sizes
 
-    sym_cols = [None]   # symbols per image, known after the first encoder stage
-
     def run_steps(n_steps, record=False):
         pending = {}
         gbuf = [None]
-        group = []   # (step, symbols, (h, w), event) of the steps waiting for their coder launch
+        group = []   # (step, symbols, (h, w), event, in the shared buffer?) of the steps waiting for their coder launch
         plan = group_plan(n_steps)
         back_done = {}
         dec_done = [None]
@@ -428,13 +463,13 @@ def main():
             cs = coder_streams[launches[0] % n_coder]
             launches[0] += 1
             with torch.cuda.stream(cs):
-                for _, g_sym, _, g_ev in group:
+                for _, g_sym, _, g_ev, _ in group:
                     cs.wait_event(g_ev)
                     g_sym.record_stream(cs)
                 if len(group) == 1:
                     sym = group[0][1]
-                elif gbuf[0] is not None:        # the encoder stages wrote their symbols into one buffer: nothing to copy
-                    sym = gbuf[0]
+                elif gbuf[0] is not None and all(g[4] for g in group):
+                    sym = gbuf[0]                # every encoder stage wrote its row block of the one buffer: nothing to copy
                     sym.record_stream(cs)
                 else:
                     sym = torch.cat([g[1] for g in group])
@@ -461,7 +496,7 @@ def main():
                 if record:
                     statuses.append(st)
             n = group[0][1].shape[0]
-            for k, (step, _, _, _) in enumerate(group):
+            for k, (step, _, _, _, _) in enumerate(group):
                 sl = slice(k * n, (k + 1) * n) if dec.shape[0] == n * len(group) else slice(0, n)
                 pending[step] = (dec[sl], nb[sl], st[sl], hw, ev2, dec)
             group.clear()
@@ -495,7 +530,7 @@ def main():
                         timeline[-1] = timeline[-1][:3] + (tl_event(mfma_stream),)
                     ev = torch.cuda.Event()
                     ev.record(mfma_stream)
-                group.append((i, sym, hw, ev))
+                group.append((i, sym, hw, ev, out is not None))
                 if len(group) == plan[launches[0]]:
                     flush()
                 # back stages of every step whose coder launch has been issued, oldest first: they wait for the
@@ -687,6 +722,8 @@ def main():
                        'weights': 'random init seed 0, operating point shaped by bench.shape_workload (ragged tables, '
                                   'peaked prior, latent std ~1, ~1e-4 escape symbols)',
                        'images': 'torch.rand, per-image contrast 0.25-1, ImageNet normalisation',
+                       'streams': 'device-resident in the timed region (u8 rows in HBM with offset / nbytes vectors, no Python '
+                                  'bytes objects); the host-bytes encode()/decode() API of the reference is timed in bs1_eval',
                        'sharding': 'images, no collective'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
             'bytes_per_image_min_mean_max': [nb_f.min().item(), bytes_per_img, nb_f.max().item()],
@@ -713,16 +750,21 @@ def main():
                            'streams_in_flight': G * args.bs * n_coder, 'symbols_per_stream': n_sym,
                            'encode_Msym_per_s_per_stream': n_sym / ksum['rans_encode'][1] / 1e3,
                            'decode_Msym_per_s_per_stream': n_sym / ksum['rans_decode'][1] / 1e3}
+        failed = None
         if world == 1 and not args.no_bs1:
             out['bs1_eval'] = bs1_eval(model, x, dev)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(8, model.state_dict(), dev_symbols=sym8, hw=hw[0] * hw[1])
                 out['bitstream_match'] = out['cpu_baseline'].get('bitstream_sha256_first8') == out['bitstream_sha256_first8']
-            except Exception as e:  # the baseline is a reported figure; never let it take the bench line down
+            except Exception as e:  # the GPU figures are still printed, but a line without its baseline is not a result: rc != 0
                 out['cpu_baseline'] = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port',
-                                       'sample': 'failed: {}'.format(e)}
+                                       'sample': 'failed: {!r}'.format(e)}
+                failed = 'cpu_baseline failed: {!r}'.format(e)
         print(json.dumps(out))
+        if failed:
+            sys.stdout.flush()
+            raise SystemExit('bench.py: ' + failed)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 32
+#define SC2_ABI_VERSION 33
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -378,7 +378,8 @@ int sc2_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *c
  *           out[i*out_stride + out_offset[i] .. + out_nbytes[i])  (streams are END-aligned in
  *           their rows because rANS emits its words back to front)
  * out_stride must be >= sc2_rans_max_bytes(n_sym); out_stride % 4 == 0.
- * status  : i32 [n_streams] 0 ok, 1 = row overflow (cannot happen with sc2_rans_max_bytes).
+ * status  : i32 [n_streams] 0 ok; bit 0 = row overflow (cannot happen with sc2_rans_max_bytes); bit 1 = a symbol with
+ *           |symbol - offset| >= 2^30 was clamped (non-finite / diverged latent).
  * workspace : device scratch of sc2_rans_workspace_bytes(n_streams, n_sym, n_cdfs, cdf_stride) bytes (the
  *             [position][lane] transposed intermediate of the multi-pass coder and the per-entry reciprocal
  *             table); contents undefined afterwards.
@@ -407,6 +408,31 @@ int sc2_rans_decode_dequantize_batch(const uint8_t *in, int64_t in_stride, const
                                      int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets, const float *medians,
                                      int32_t *symbols_out, void *y_hat_bf16_nhwc, int32_t *status, void *workspace,
                                      int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* HOST range coder (same bit-exact format; every pointer is HOST memory, no HIP call is made).  */
+/* For the reference's evaluation mode -- test batch size 1, ONE stream per forward               */
+/* (script/task/image_classification.py:106-145 -> layer.py:506,520): a single rANS stream is a   */
+/* serial chain that one CPU core steps ~30x faster than one GPU lane, so below a stream-count    */
+/* threshold EntropyBottleneck / GaussianConditional .compress / .decompress call these instead   */
+/* of the batched device coder.  Product code (csrc/rans_host.cpp), not the test oracle.          */
+/* ------------------------------------------------------------------------------------------ */
+/* Opaque prepared tables: per CDF row the cumulative frequencies and a 256-bucket index for the decoder's symbol
+ * search.  cdfs : i32 [n_cdfs][cdf_stride], cdf_sizes / offsets : i32 [n_cdfs] as above.  SC2_ERR_INVALID_ARG if a row is
+ * not a strictly increasing table from 0 to 65 536 with at least two entries. */
+typedef struct sc2_rans_host_tables sc2_rans_host_tables;
+int sc2_rans_host_tables_create(const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                const int32_t *offsets, sc2_rans_host_tables **out);
+void sc2_rans_host_tables_destroy(sc2_rans_host_tables *tables);
+/* Same arguments, row layout (END-aligned streams, out_offset / out_nbytes) and status bits as sc2_rans_encode_batch /
+ * sc2_rans_decode_batch (additionally bit 2 = a CDF-row index outside the table); `out` / `in` 4-byte aligned;
+ * streams are spread over n_threads host threads (<= 1: the calling thread). */
+int sc2_rans_encode_host(const sc2_rans_host_tables *tables, const int32_t *symbols, const int32_t *indexes,
+                         int64_t index_div, int n_streams, int64_t n_sym, uint8_t *out, int64_t out_stride,
+                         int32_t *out_offset, int32_t *out_nbytes, int32_t *status, int n_threads);
+int sc2_rans_decode_host(const sc2_rans_host_tables *tables, const uint8_t *in, int64_t in_stride,
+                         const int32_t *in_offset, const int32_t *in_nbytes, const int32_t *indexes, int64_t index_div,
+                         int n_streams, int64_t n_sym, int32_t *symbols_out, int32_t *status, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -110,12 +110,7 @@ class FactorizedPrior(CompressionModel):
 
     def decompress(self, strings, shape):
         assert isinstance(strings, list) and len(strings) == 1
-        eb = self.entropy_bottleneck
-        dev = eb._quantized_cdf.device
-        if dev.type != 'cuda':
-            raise hip.Sc2Error('FactorizedPrior.decompress: module is on {}; HIP device required'.format(dev))
-        buf, off, nb = eb.pack_strings(strings[0], dev)
-        _, y_hat_nhwc = eb.decompress_device(buf, off, nb, tuple(shape), want_f32=False, want_nhwc=True)
+        _, y_hat_nhwc = self.entropy_bottleneck.decompress_to_device(strings[0], tuple(shape), want_f32=False, want_nhwc=True)
         x_hat = self.synthesis_nhwc(y_hat_nhwc).clamp_(0, 1)
         return {'x_hat': x_hat}
 

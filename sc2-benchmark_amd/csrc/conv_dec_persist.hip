@@ -554,7 +554,9 @@ template int launch8p<B_dec2, 1>(const ConvArgs &, hipStream_t);
 template int launch8p<B_dec4, 1>(const ConvArgs &, hipStream_t);
 template int launch8p<B_dec2, 2>(const ConvArgs &, hipStream_t);
 template int launch8p<B_dec4, 2>(const ConvArgs &, hipStream_t);
+#ifdef SC2_EXPERIMENTS   // MODE 3 = timing experiment with garbage results: not in the shipped library
 template int launch8p<B_dec2, 3>(const ConvArgs &, hipStream_t);
 template int launch8p<B_dec4, 3>(const ConvArgs &, hipStream_t);
+#endif
 
 }  // namespace sc2conv

@@ -267,8 +267,12 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
             const int pmode = pe ? atoi(pe) : 3;   // 0: one workgroup per tile; 1: persistent; 2: + fragment reads a phase early; 3: one phase (32 MFMAs) per slab
             const bool persist = pmode && a.x_bytes != 0 && d->out_format == SC2_OUT_BF16_NHWC && !scatter &&
                                  d->Cout == 256 && d->a_op == SC2_AOP_NONE && (d->epilogue == SC2_EPI_NONE || fused);
-            if (persist && pmode == 32 && matches<B_dec2>(a)) return launch8p<B_dec2, 3>(a, s);   // timing experiment, garbage results
+#ifdef SC2_EXPERIMENTS   // timing experiment with garbage results: never in the shipped library
+            if (persist && pmode == 32 && matches<B_dec2>(a)) return launch8p<B_dec2, 3>(a, s);
             if (persist && pmode == 32 && matches<B_dec4>(a)) return launch8p<B_dec4, 3>(a, s);
+#else
+            if (pmode == 32) return SC2_ERR_UNSUPPORTED;
+#endif
             if (persist && pmode == 3 && matches<B_dec2>(a)) return launch8p<B_dec2, 2>(a, s);
             if (persist && pmode == 3 && matches<B_dec4>(a)) return launch8p<B_dec4, 2>(a, s);
             if (persist && pmode == 2 && matches<B_dec2>(a)) return launch8p<B_dec2, 1>(a, s);

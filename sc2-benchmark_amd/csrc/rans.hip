@@ -156,7 +156,7 @@ __global__ __launch_bounds__(64) void rans_enc_serial_kernel(const RansArgs a, c
     auto flush = [&]() {
         long long avail = ptr - limit;
         int n_store = cnt;
-        if ((long long)cnt > avail) { n_store = (int)avail; overflow = 1; }
+        if ((long long)cnt > avail) { n_store = (int)avail; overflow |= 1; }   // (keeps bit 1 = clamped symbol)
         // four words per store where a lane has them (every lane writes ITS row: a 4-byte store per lane is 64 separate
         // requests per wave-instruction); dword-aligned dwordx4, words in descending address order as emitted
         struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
@@ -208,13 +208,13 @@ __global__ __launch_bounds__(64) void rans_enc_serial_kernel(const RansArgs a, c
         if (e >> 31) {
             const int idx = (int)(ei / (uint32_t)a.cdf_stride);
             const int max_value = a.cdf_sizes[idx] - 2;
-            const int v = a.symbols[(long long)sc * a.n_sym + i] - a.offsets[idx];
+            // symbol - offset in 64 bits: a latent saturated by eb_symbols (INT_MIN / INT_MAX) must not wrap before the clamp
+            const long long v = (long long)a.symbols[(long long)sc * a.n_sym + i] - (long long)a.offsets[idx];
             // |v| >= 2^30 would wrap the 32-bit raw value (a diverged latent saturated by eb_symbols): code the
             // clamped value and report status 2 instead of spinning (a shift by 32 is masked to 0 on gfx950, so
             // upstream's unbounded nibble count would never terminate here)
-            int vc = v;
-            if (vc < -(1 << 30)) { vc = -(1 << 30); overflow |= 2; }
-            if (vc - max_value > (1 << 30)) { vc = max_value + (1 << 30); overflow |= 2; }
+            int vc = (int)(v < -(1ll << 30) ? -(1ll << 30) : (v > (long long)max_value + (1ll << 30) ? (long long)max_value + (1ll << 30) : v));
+            if (v != (long long)vc) overflow |= 2;
             const unsigned raw = vc < 0 ? (unsigned)(-2 * vc - 1) : (unsigned)(2 * (vc - max_value));
             int n_bypass = 0;
             while (n_bypass < 8 && (raw >> (n_bypass * kBypassPrecision)) != 0) ++n_bypass;

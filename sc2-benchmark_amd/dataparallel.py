@@ -148,12 +148,30 @@ def broadcast_parameters(module, src=0, process_group=None):
             dist.broadcast(t.data, src=src, group=process_group)
 
 
-def all_reduce_mean_scalars(values, device, process_group=None):
-    """Metric reduction (MetricLogger.synchronize_between_processes in the reference): mean over ranks."""
-    t = torch.tensor(values, dtype=torch.float64, device=device)
+def collective_device(process_group=None):
+    """The device a collective's tensors must live on for the backend of this process group: the current HIP device under
+    RCCL ("nccl" cannot reduce host tensors), the host under gloo."""
+    if dist.is_initialized() and 'nccl' in str(dist.get_backend(process_group)).lower():
+        return torch.device('cuda', torch.cuda.current_device())
+    return torch.device('cpu')
+
+
+def all_reduce_mean_scalars(values, device=None, process_group=None):
+    """Mean over ranks of per-rank scalars (every rank weighs the same).  `device` None = the backend's device."""
+    t = torch.tensor(values, dtype=torch.float64, device=collective_device(process_group) if device is None else device)
     if dist.is_initialized() and dist.get_world_size(process_group) > 1:
         dist.all_reduce(t, group=process_group)
         t /= dist.get_world_size(process_group)
+    return t.tolist()
+
+
+def all_reduce_sum_scalars(values, device=None, process_group=None):
+    """Sum over ranks, on the backend's device.  Metric reduction as the reference's MetricLogger does it
+    (`synchronize_between_processes`: every meter's [count, total] are summed, the global average is total / count
+    afterwards), so ranks that saw different numbers of samples weigh by their samples."""
+    t = torch.tensor(values, dtype=torch.float64, device=collective_device(process_group) if device is None else device)
+    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.all_reduce(t, group=process_group)
     return t.tolist()
 
 

@@ -633,23 +633,58 @@ class EntropyBottleneck(nn.Module):
         host = buf.cpu().numpy()
         return [host[i, int(off_h[i]):int(off_h[i]) + int(nb_h[i])].tobytes() for i in range(host.shape[0])]
 
-    def compress(self, x):
-        """Returns list[bytes], one rANS stream per batch item (EntropyBottleneck.compress, layer.py:506)."""
-        buf, off, nb, st = self.compress_device(x)
-        if int(st.max().item()) != 0:  # a row overflowed 2 B/symbol: redo with the proven upper bound
+    def _host_tables(self):
+        """Prepared tables of the library's host coder (csrc/rans_host.cpp), rebuilt when update() / load_state_dict() changed
+        the integer tables."""
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self._quantized_cdf, self._cdf_length, self._offset))
+        cached = self.__dict__.get('_host_tables_cache')
+        if cached is None or cached[0] != key:
             cdf, cdf_len, offset = self._tables()
-            y = x.float().contiguous()
-            N, C = y.shape[0], y.shape[1]
-            hw = y.numel() // (N * C)
-            sym = hip.eb_symbols(y, self._median_vector())
-            buf, off, nb, st = hip.rans_encode_batch(sym.view(N, C * hw), cdf, cdf_len, offset, index_div=hw,
-                                                     out_stride=hip.rans_max_bytes(C * hw))
+            cached = (key, hip.HostRansTables(cdf, cdf_len, offset))
+            self.__dict__['_host_tables_cache'] = cached
+        return cached[1]
+
+    def compress_symbols(self, sym, hw):
+        """int32 symbols [N, C*hw] on the device -> list[bytes], one rANS stream per row.  Up to
+        `hip.host_coder_max_streams()` streams (the reference's evaluation mode codes ONE per forward) go through the
+        library's HOST coder: a single stream is a serial chain that a CPU core steps ~10x faster than a GPU lane; larger
+        batches through the batched device coder.  Same bytes either way (tests/test_gpu_host_coder.py)."""
+        N, n_sym = sym.shape
+        if 0 < N <= hip.host_coder_max_streams():
+            tables = self._host_tables()
+            sym_h = sym.cpu().numpy()
+            strings, st = hip.rans_encode_host(tables, sym_h, index_div=hw)
+            if int(st.max()) & 1:      # a row overflowed 2 B/symbol: redo with the proven upper bound
+                strings, st = hip.rans_encode_host(tables, sym_h, index_div=hw, out_stride=hip.rans_max_bytes(n_sym))
+            _raise_on_status(torch.from_numpy(st), 'EntropyBottleneck.compress')
+            return strings
+        cdf, cdf_len, offset = self._tables()
+        buf, off, nb, st = hip.rans_encode_batch(sym, cdf, cdf_len, offset, index_div=hw)
+        if int(st.max().item()) != 0:
+            buf, off, nb, st = hip.rans_encode_batch(sym, cdf, cdf_len, offset, index_div=hw,
+                                                     out_stride=hip.rans_max_bytes(n_sym))
             _raise_on_status(st, 'EntropyBottleneck.compress')
         nb_h = nb.cpu().numpy()
         stride = buf.shape[1]
         width = int(nb_h.max())
         tail = buf[:, stride - width:].contiguous().cpu().numpy()  # streams are end-aligned in their rows
         return [tail[i, width - int(nb_h[i]):].tobytes() for i in range(tail.shape[0])]
+
+    def compress(self, x):
+        """Returns list[bytes], one rANS stream per batch item (EntropyBottleneck.compress, layer.py:506)."""
+        if len(x.size()) < 2:
+            raise ValueError('Invalid `inputs` size. Expected a tensor with at least 2 dimensions.')
+        _require_device(x, 'EntropyBottleneck.compress')
+        cdf = self._tables()[0]
+        y = x.float().contiguous()
+        N, C = y.shape[0], y.shape[1]
+        if C != cdf.shape[0]:
+            raise ValueError('`inputs` has {} channels but the CDF table has {} rows'.format(C, cdf.shape[0]))
+        if N == 0:
+            return []
+        hw = y.numel() // (N * C)
+        sym = hip.eb_symbols(y, self._median_vector())
+        return self.compress_symbols(sym.view(N, C * hw), hw)
 
     def pack_strings(self, strings, device):
         """list[bytes] -> (buf u8 [N,stride], offset i32 [N], nbytes i32 [N]) on device (start-aligned)."""
@@ -675,13 +710,26 @@ class EntropyBottleneck(nn.Module):
         return hip.eb_dequantize(sym.view(N, C, *size), self._median_vector(), want_f32=want_f32,
                                  want_nhwc=want_nhwc)
 
-    def decompress(self, strings, size):
-        """list[bytes], spatial size -> f32 [N,C,*size] (EntropyBottleneck.decompress, layer.py:520)."""
+    def decompress_to_device(self, strings, size, want_f32=True, want_nhwc=False):
+        """list[bytes], spatial size -> (y_hat f32 NCHW or None, y_hat bf16 NHWC or None) on the module's device; the host
+        coder for a few streams, the batched device coder otherwise (see compress_symbols)."""
         dev = self._quantized_cdf.device
         if dev.type != 'cuda':
             raise hip.Sc2Error('EntropyBottleneck.decompress: module is on {}; HIP device required'.format(dev))
+        size = tuple(size)
+        if 0 < len(strings) <= hip.host_coder_max_streams():
+            C = self._quantized_cdf.shape[0]
+            hw = int(np.prod(size))
+            sym_h, _ = hip.rans_decode_host(self._host_tables(), strings, C * hw, index_div=hw)
+            sym = torch.from_numpy(sym_h).to(dev)
+            return hip.eb_dequantize(sym.view(len(strings), C, *size), self._median_vector(), want_f32=want_f32,
+                                     want_nhwc=want_nhwc)
         buf, off, nb = self.pack_strings(strings, dev)
-        return self.decompress_device(buf, off, nb, tuple(size), want_f32=True)[0]
+        return self.decompress_device(buf, off, nb, size, want_f32=want_f32, want_nhwc=want_nhwc)
+
+    def decompress(self, strings, size):
+        """list[bytes], spatial size -> f32 [N,C,*size] (EntropyBottleneck.decompress, layer.py:520)."""
+        return self.decompress_to_device(strings, size, want_f32=True)[0]
 
 
 SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256, 64
@@ -836,8 +884,34 @@ class GaussianConditional(nn.Module):
         return hip.rans_encode_batch(sym.view(N, -1), cdf, cdf_len, offset,
                                      indexes=indexes.int().contiguous().view(N, -1), out_stride=out_stride)
 
+    def _host_tables(self):
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self._quantized_cdf, self._cdf_length, self._offset))
+        cached = self.__dict__.get('_host_tables_cache')
+        if cached is None or cached[0] != key:
+            cdf, cdf_len, offset = self._tables()
+            cached = (key, hip.HostRansTables(cdf, cdf_len, offset))
+            self.__dict__['_host_tables_cache'] = cached
+        return cached[1]
+
     def compress(self, inputs, indexes, means=None):
-        """-> list[bytes], one rANS stream per batch item (EntropyModel.compress, layer.py:647,776)."""
+        """-> list[bytes], one rANS stream per batch item (EntropyModel.compress, layer.py:647,776).  A few streams go
+        through the library's host coder (EntropyBottleneck.compress_symbols: why)."""
+        if 0 < inputs.shape[0] <= hip.host_coder_max_streams():
+            if len(inputs.size()) < 2:
+                raise ValueError('Invalid `inputs` size. Expected a tensor with at least 2 dimensions.')
+            if inputs.size() != indexes.size():
+                raise ValueError('`inputs` and `indexes` should have the same size.')
+            x = inputs.float().contiguous()
+            N = x.shape[0]
+            sym = hip.gc_symbols_indexes(x, None, None if means is None else means.float(), None, want_indexes=False)[0]
+            sym_h = sym.view(N, -1).cpu().numpy()
+            idx_h = indexes.int().contiguous().view(N, -1).cpu().numpy()
+            tables = self._host_tables()
+            strings, st = hip.rans_encode_host(tables, sym_h, indexes=idx_h)
+            if int(st.max()) & 1:
+                strings, st = hip.rans_encode_host(tables, sym_h, indexes=idx_h, out_stride=hip.rans_max_bytes(sym_h.shape[1]))
+            _raise_on_status(torch.from_numpy(st), 'GaussianConditional.compress')
+            return strings
         buf, off, nb, st = self.compress_device(inputs, indexes, means)
         if int(st.max().item()) != 0:
             buf, off, nb, st = self.compress_device(inputs, indexes, means,
@@ -865,12 +939,24 @@ class GaussianConditional(nn.Module):
             raise ValueError('Invalid strings or indexes parameters')
         if means is not None and (means.size()[:2] != indexes.size()[:2]):
             raise ValueError('Invalid means or indexes parameters')
+        out = self.decompress_to_device(strings, indexes, means, want_f32=True, want_nhwc=False)[0]
+        return out if means is not None else out.type(dtype)
+
+    def decompress_to_device(self, strings, indexes, means=None, want_f32=True, want_nhwc=False):
+        """list[bytes], device indexes -> (y_hat f32 NCHW or None, y_hat bf16 NHWC or None); the host coder for a few streams,
+        the batched device coder otherwise."""
         dev = indexes.device
         if dev.type != 'cuda':
             raise hip.Sc2Error('GaussianConditional.decompress: indexes are on {}; HIP device required'.format(dev))
+        if 0 < len(strings) <= hip.host_coder_max_streams():
+            N = indexes.shape[0]
+            idx_h = indexes.int().contiguous().view(N, -1).cpu().numpy()
+            sym_h, _ = hip.rans_decode_host(self._host_tables(), list(strings), idx_h.shape[1], indexes=idx_h)
+            sym = torch.from_numpy(sym_h).to(dev)
+            return hip.gc_dequantize(sym.view(indexes.shape), None if means is None else means.float(), want_f32=want_f32,
+                                     want_nhwc=want_nhwc)
         buf, off, nb = self.pack_strings(strings, dev)
-        out = self.decompress_device(buf, off, nb, indexes, means)[0]
-        return out if means is not None else out.type(dtype)
+        return self.decompress_device(buf, off, nb, indexes, means, want_f32=want_f32, want_nhwc=want_nhwc)
 
 
 class _CpuReplica(object):

@@ -5,8 +5,8 @@
 
 It builds `models.model` (or `models.student_model`) from the reference's YAML file unchanged, loads `test.test_data_loader`
 (dataset, sampler, batch size, `collate_fn`), runs the model in eval mode under `torch.inference_mode()`, reports top-1 /
-top-5 accuracy and lets every analyzer summarise (data size in KB, as the reference logs it).  Metrics are averaged over
-ranks when a process group is up (`MetricLogger.synchronize_between_processes`: SURVEY.md C5).
+top-5 accuracy and lets every analyzer summarise (data size in KB, as the reference logs it).  Metric totals and counts are
+summed over ranks when a process group is up (`MetricLogger.synchronize_between_processes`: SURVEY.md C5).
 """
 import argparse
 import json
@@ -17,7 +17,7 @@ import torch
 
 from . import config as C
 from .analysis import AnalyzableModule
-from .dataparallel import all_reduce_mean_scalars
+from .dataparallel import all_reduce_sum_scalars
 
 logger = logging.getLogger(__name__)
 
@@ -75,13 +75,16 @@ def evaluate(model, data_loader, device, max_samples=None, log_freq=1000, title=
             logger.info('Test: [{}] acc1 {:.3f} acc5 {:.3f}'.format(i + 1, acc1.global_avg, acc5.global_avg))
         if max_samples is not None and seen >= max_samples:
             break
-    top1, top5 = all_reduce_mean_scalars([acc1.global_avg, acc5.global_avg], torch.device('cpu'))
+    # totals and counts are summed over ranks and divided afterwards (MetricLogger.synchronize_between_processes), on the
+    # backend's device: an RCCL-only process group cannot reduce a host tensor
+    t1, c1, t5, c5, seen_all = all_reduce_sum_scalars([acc1.total, acc1.count, acc5.total, acc5.count, seen])
+    top1, top5 = t1 / max(1.0, c1), t5 / max(1.0, c5)
     logger.info(' * Acc@1 {:.4f}\tAcc@5 {:.4f}\n'.format(top1, top5))
     analysis = []
     if analyzable and model.activated_analysis:
         model.summarize()
         analysis = [a.summary() for a in model.analyzers if hasattr(a, 'summary') and getattr(a, 'file_size_list', None)]
-    return {'acc1': top1, 'acc5': top5, 'samples': seen, 'seconds': time.perf_counter() - t0, 'analysis': analysis}
+    return {'acc1': top1, 'acc5': top5, 'samples': seen, 'samples_all_ranks': int(seen_all), 'seconds': time.perf_counter() - t0, 'analysis': analysis}
 
 
 def build_data_loader(dataset_dict, loader_config):

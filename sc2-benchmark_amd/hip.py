@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch',
+    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
 ]
 
 
@@ -114,6 +115,11 @@ def lib():
     L.sc2_rans_decode_batch.argtypes = [vp, i64, vp, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, i64,
                                         vp]
     L.sc2_rans_decode_dequantize_batch.argtypes = [vp, i64, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.sc2_rans_host_tables_create.argtypes = [vp, i32, i32, vp, vp, ctypes.POINTER(vp)]
+    L.sc2_rans_host_tables_destroy.argtypes = [vp]
+    L.sc2_rans_host_tables_destroy.restype = None
+    L.sc2_rans_encode_host.argtypes = [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp, i32]
+    L.sc2_rans_decode_host.argtypes = [vp, vp, i64, vp, vp, vp, i64, i32, i64, vp, vp, i32]
     for name in ABI_SYMBOLS:
         getattr(L, name)  # raises AttributeError if the library lacks a declared symbol
     _lib = L
@@ -1043,6 +1049,81 @@ def pmf_to_quantized_cdf(pmf, precision=16):
 
 def rans_max_bytes(n_sym):
     return int(lib().sc2_rans_max_bytes(int(n_sym)))
+
+
+# ---- host range coder (csrc/rans_host.cpp): a few streams are coded faster by CPU cores than by GPU lanes ----------------
+def host_coder_max_streams():
+    """Stream count up to which compress() / decompress() use the library's HOST coder (0 = always the device coder)."""
+    return int(os.environ.get('SC2_HOST_CODER_MAX_STREAMS', '8'))
+
+
+class HostRansTables(object):
+    """Prepared CDF tables of the host coder (opaque handle of sc2_rans_host_tables_create), built from int32 tensors /
+    arrays `cdfs` [n_cdfs, stride], `cdf_sizes` [n_cdfs], `offsets` [n_cdfs] wherever they live."""
+
+    def __init__(self, cdfs, cdf_sizes, offsets):
+        import numpy as np
+        to_np = lambda t: np.ascontiguousarray((t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)), dtype=np.int32)  # noqa: E731
+        c, z, o = to_np(cdfs), to_np(cdf_sizes).reshape(-1), to_np(offsets).reshape(-1)
+        assert c.ndim == 2 and z.shape[0] == c.shape[0] == o.shape[0]
+        self.n_cdfs = int(c.shape[0])
+        self._h = ctypes.c_void_p(0)
+        _check(lib().sc2_rans_host_tables_create(c.ctypes.data, c.shape[0], c.shape[1], z.ctypes.data, o.ctypes.data,
+                                                 ctypes.byref(self._h)), 'rans_host_tables_create')
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h and _lib is not None:
+            _lib.sc2_rans_host_tables_destroy(h)
+
+
+def _host_threads(n_streams):
+    return max(1, min(int(n_streams), len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16))
+
+
+def rans_encode_host(tables, symbols, indexes=None, index_div=0, out_stride=None):
+    """symbols: int32 numpy [n_streams, n_sym] (HOST) -> (list[bytes], status int32 numpy [n_streams])."""
+    import numpy as np
+    symbols = np.ascontiguousarray(symbols, dtype=np.int32)
+    n_streams, n_sym = symbols.shape
+    if indexes is not None:
+        indexes = np.ascontiguousarray(indexes, dtype=np.int32)
+        assert indexes.shape == symbols.shape
+    if out_stride is None:
+        out_stride = 2 * n_sym + 64
+    out_stride = (int(out_stride) + 3) // 4 * 4
+    buf = np.empty((n_streams, out_stride // 4), dtype=np.uint32)
+    off = np.empty((n_streams,), dtype=np.int32)
+    nb = np.empty((n_streams,), dtype=np.int32)
+    st = np.empty((n_streams,), dtype=np.int32)
+    _check(lib().sc2_rans_encode_host(tables._h, symbols.ctypes.data, indexes.ctypes.data if indexes is not None else None,
+                                      int(index_div), n_streams, n_sym, buf.ctypes.data, out_stride, off.ctypes.data,
+                                      nb.ctypes.data, st.ctypes.data, _host_threads(n_streams)), 'rans_encode_host')
+    raw = buf.view(np.uint8).reshape(n_streams, out_stride)
+    return [raw[i, int(off[i]):int(off[i]) + int(nb[i])].tobytes() for i in range(n_streams)], st
+
+
+def rans_decode_host(tables, strings, n_sym, indexes=None, index_div=0):
+    """strings: list[bytes] -> (int32 numpy [n_streams, n_sym] (HOST), status int32 numpy [n_streams])."""
+    import numpy as np
+    n_streams = len(strings)
+    stride = (max([len(q) for q in strings] + [8]) + 3) // 4 * 4
+    buf = np.zeros((n_streams, stride // 4), dtype=np.uint32)
+    raw = buf.view(np.uint8).reshape(n_streams, stride)
+    nb = np.empty((n_streams,), dtype=np.int32)
+    for i, q in enumerate(strings):
+        raw[i, :len(q)] = np.frombuffer(q, dtype=np.uint8)
+        nb[i] = len(q)
+    off = np.zeros((n_streams,), dtype=np.int32)
+    if indexes is not None:
+        indexes = np.ascontiguousarray(indexes, dtype=np.int32)
+        assert indexes.shape == (n_streams, n_sym)
+    sym = np.empty((n_streams, int(n_sym)), dtype=np.int32)
+    st = np.empty((n_streams,), dtype=np.int32)
+    _check(lib().sc2_rans_decode_host(tables._h, buf.ctypes.data, stride, off.ctypes.data, nb.ctypes.data,
+                                      indexes.ctypes.data if indexes is not None else None, int(index_div), n_streams,
+                                      int(n_sym), sym.ctypes.data, st.ctypes.data, _host_threads(n_streams)), 'rans_decode_host')
+    return sym, st
 
 
 def rans_encode_batch(symbols, cdfs, cdf_sizes, offsets, indexes=None, index_div=0, out_stride=None):

@@ -254,7 +254,9 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         h = self.synthesis_nhwc(y_hat_nhwc, upto_last=True)
         if not hip.conv2x2_win_tail_supported(tuple(h.shape)) or tuple(c4.padding) != (1, 1):
             return self._last_conv(h), None
-        key = (c4.weight._version, c4.weight.data_ptr(), id(head))
+        # keyed on the tensors that are packed (their storage and version), not on the identity of `head`: a rebuilt
+        # HipHead may reuse the address of a dropped one
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in (c4.weight,) + tuple(spec))
         cache = self.__dict__.setdefault('_tail_cache', {})
         if cache.get('key') != key:
             w1, b1, wds, bds = spec
@@ -333,18 +335,17 @@ class FPBasedResNetBottleneck(BaseBottleneck):
     # ---- reference API -------------------------------------------------------------------------- #
     def encode(self, x, **kwargs):
         """-> {'strings': [list of N byte strings], 'shape': latent spatial size} (layer.py:496-507)."""
-        latent = self.analysis(x)
-        latent_strings = self.entropy_bottleneck.compress(latent)
-        return {'strings': [latent_strings], 'shape': latent.size()[-2:]}
+        eb = self.entropy_bottleneck
+        eb._tables()     # "Uninitialized CDFs. Run update() first" before any device work
+        # the last encoder conv quantises its own accumulators (round(acc - median)): the coder's symbols without an f32 latent
+        sym = self.analysis(x, symbols_for=eb)
+        shape = torch.Size(sym.shape[-2:])
+        latent_strings = eb.compress_symbols(sym.reshape(sym.shape[0], -1), shape[0] * shape[1])
+        return {'strings': [latent_strings], 'shape': shape}
 
     def decode(self, strings, shape):
         """strings, shape -> decoder output (layer.py:509-521)."""
-        eb = self.entropy_bottleneck
-        dev = eb._quantized_cdf.device
-        if dev.type != 'cuda':
-            raise hip.Sc2Error('FPBasedResNetBottleneck.decode: module is on {}; HIP device required'.format(dev))
-        buf, off, nb = eb.pack_strings(strings[0], dev)
-        _, y_hat_nhwc = eb.decompress_device(buf, off, nb, tuple(shape), want_f32=False, want_nhwc=True)
+        _, y_hat_nhwc = self.entropy_bottleneck.decompress_to_device(strings[0], tuple(shape), want_f32=False, want_nhwc=True)
         return self.synthesis_nhwc(y_hat_nhwc)
 
     def encode_device(self, x):
@@ -514,14 +515,14 @@ class SHPBasedResNetBottleneck(BaseBottleneck):
         z = self.hyper_analysis(y)
         z_shape = z.size()[-2:]
         eb = self.entropy_bottleneck
-        zbuf, zoff, znb, zst = eb.compress_device(z)
-        if int(zst.max().item()) != 0:
-            raise hip.Sc2Error('rANS row overflow in the hyper-latent stream')
-        _, z_hat_nhwc = eb.decompress_device(zbuf, zoff, znb, tuple(z_shape), want_f32=False, want_nhwc=True)
+        # the coder is lossless: z_hat = dequantize(symbols) is what decompress(compress(z)) returns (layer.py:643-645), so the
+        # hyper-synthesis does not wait for the serial coder; both streams are then coded by whichever coder suits the batch
+        z_sym = eb.symbols_device(z)
+        _, z_hat_nhwc = eb.dequantize_device(z_sym, tuple(z_shape), want_f32=False, want_nhwc=True)
         scales_hat, means_hat = self._params(self.hyper_synthesis(z_hat_nhwc))
         indices = self.gaussian_conditional.build_indexes(scales_hat)
         y_strings = self.gaussian_conditional.compress(y, indices, means=means_hat)
-        z_strings = eb.unpack_strings(zbuf, zoff, znb)
+        z_strings = eb.compress_symbols(z_sym, int(z_shape[0]) * int(z_shape[1]))
         return {'strings': [y_strings, z_strings], 'shape': z_shape}
 
     def decode(self, strings, shape):
@@ -531,13 +532,11 @@ class SHPBasedResNetBottleneck(BaseBottleneck):
         dev = eb._quantized_cdf.device
         if dev.type != 'cuda':
             raise hip.Sc2Error('{}.decode: module is on {}; HIP device required'.format(type(self).__name__, dev))
-        zbuf, zoff, znb = eb.pack_strings(strings[1], dev)
-        _, z_hat_nhwc = eb.decompress_device(zbuf, zoff, znb, tuple(shape), want_f32=False, want_nhwc=True)
+        _, z_hat_nhwc = eb.decompress_to_device(strings[1], tuple(shape), want_f32=False, want_nhwc=True)
         scales_hat, means_hat = self._params(self.hyper_synthesis(z_hat_nhwc))
         indices = self.gaussian_conditional.build_indexes(scales_hat)
-        gc = self.gaussian_conditional
-        ybuf, yoff, ynb = gc.pack_strings(strings[0], dev)
-        _, y_hat_nhwc = gc.decompress_device(ybuf, yoff, ynb, indices, means_hat, want_f32=False, want_nhwc=True)
+        _, y_hat_nhwc = self.gaussian_conditional.decompress_to_device(strings[0], indices, means_hat, want_f32=False,
+                                                                       want_nhwc=True)
         return self.synthesis_nhwc(y_hat_nhwc)
 
     def _get_means(self, x):

@@ -219,3 +219,74 @@ def test_bench_torchrun_dry_run_world2():
     assert rec['config']['global_batch'] == 2 * rec['config']['batch_per_gpu']
     assert rec['ranks'] == [{'rank': 0, 'local_rank': 0, 'seed': 0}, {'rank': 1, 'local_rank': 1, 'seed': 1}]
     assert rec['scaling'] == 'weak' and rec['value'] > 0
+
+
+def test_bench_self_launch_dry_run_world2():
+    """`bench.py --gpus 2 --dry-run` with NO launcher environment: bench.py itself starts the 2 ranks as child processes
+    (torch.distributed.run, 127.0.0.1, a free port), relays rank 0's single JSON line and returns the children's code."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line from rank 0: {}'.format(r.stdout)
+    rec = json.loads(lines[0])
+    assert rec['dry_run'] and rec['n_gpus'] == 2 and rec['steps'] == 3
+    assert [q['rank'] for q in rec['ranks']] == [0, 1]
+
+
+def test_bench_refuses_gpus_world_mismatch():
+    """--gpus must equal the world size the launcher made: a line that says n_gpus 1 for `--gpus 2` is not a result."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--dry-run']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and '--gpus 2 but WORLD_SIZE 1' in r.stderr
+
+
+def _eval_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update({'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'RANK': str(rank),
+                       'WORLD_SIZE': str(world), 'LOCAL_RANK': str(rank)})
+    from sc2bench_amd import dataparallel as dp, evaluation as E
+    dp.init_distributed(backend='gloo')
+    torch.manual_seed(0)
+    model = torch.nn.Linear(8, 10)        # every rank holds the same classifier
+    g = torch.Generator().manual_seed(3)
+    xs, ys = torch.randn(10, 8, generator=g), torch.randint(0, 10, (10,), generator=g)
+    lo, hi = (0, 7) if rank == 0 else (7, 10)    # UNEQUAL shards: 7 and 3 samples
+    loader = [(xs[i:i + 1], ys[i:i + 1]) for i in range(lo, hi)]
+    res = E.evaluate(model, loader, torch.device('cpu'), log_freq=0)
+    out[rank] = (res['acc1'], res['acc5'], res['samples'], res['samples_all_ranks'])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_evaluate_world2_sums_totals_and_counts():
+    """evaluate() under a process group: the metric is total / count over ALL ranks' samples (the reference's
+    MetricLogger.synchronize_between_processes), not the mean of the per-rank averages -- the two differ when ranks
+    saw different numbers of samples; the reduction runs on the backend's device."""
+    from sc2bench_amd import evaluation as E
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_eval_worker, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=240)
+            assert p.exitcode == 0
+        res = dict(out)
+    torch.manual_seed(0)
+    model = torch.nn.Linear(8, 10)
+    g = torch.Generator().manual_seed(3)
+    xs, ys = torch.randn(10, 8, generator=g), torch.randint(0, 10, (10,), generator=g)
+    single = E.evaluate(model, [(xs[i:i + 1], ys[i:i + 1]) for i in range(10)], torch.device('cpu'), log_freq=0)
+    for r in range(world):
+        assert abs(res[r][0] - single['acc1']) < 1e-9 and abs(res[r][1] - single['acc5']) < 1e-9
+        assert res[r][3] == 10
+    assert (res[0][2], res[1][2]) == (7, 3)
