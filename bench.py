@@ -210,6 +210,69 @@ def cpu_baseline(sample_images, state_dict, dev_symbols=None, hw=None):
     return out
 
 
+def precision_check(model, x_dev, dev, n=64):
+    """Row g3: the SAME n images through (i) the oracle's f32 CPU encoder, (ii) the device's default bf16-MFMA encoder and
+    (iii) the device's reference-precision encoder (f32 operands on the f32 matrix cores, set_encoder_precision('f32')):
+    symbol mismatch rate, bpp of the streams actually coded from each, and how many images code to the identical bytes.
+    Runs after the timed region (the oracle is the checker here, never the thing measured)."""
+    ref = oracle_model(model.state_dict())
+    n = min(n, x_dev.shape[0])
+    x = x_dev[:n].float().cpu()
+    eb, reb = model.bottleneck_layer.entropy_bottleneck, ref.bottleneck_layer.entropy_bottleneck
+    with torch.no_grad():
+        ref_sym = torch.cat([reb.symbols(ref.bottleneck_layer.encoder(x[i:i + 16])) for i in range(0, n, 16)]).reshape(n, -1)
+    hw = None
+    out = {'images': n, 'what': 'same images, same weights: f32 CPU oracle encoder vs the device encoders; bpp from the '
+                                'streams each one codes (device coder == oracle coder byte for byte given the symbols)'}
+    pix = x.shape[-1] * x.shape[-2]
+    modes = {}
+    for mode in ('bf16', 'f32'):
+        model.set_encoder_precision(mode)
+        with torch.no_grad():
+            sym, hw = model.stage_front(x_dev[:n])
+            _, _, nb, st = eb.encode_symbols_device(sym, hw[0] * hw[1])
+            assert int(st.max().item()) == 0
+            # encoder-stage time for the whole resident batch
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            model.stage_front(x_dev)
+            e0.record()
+            for _ in range(3):
+                model.stage_front(x_dev)
+            e1.record()
+            torch.cuda.synchronize(dev)
+        s_h = sym.cpu().reshape(n, -1)
+        diff = (s_h != ref_sym)
+        modes[mode] = {'symbols': s_h, 'nbytes': nb.cpu(),
+                       'row': {'symbol_mismatch_rate': diff.float().mean().item(),
+                               'images_with_identical_symbols': int((~diff.any(dim=1)).sum().item()),
+                               'bpp': 8.0 * float(nb.sum().item()) / (n * pix),
+                               'encoder_stage_ms_per_batch': e0.elapsed_time(e1) / 3.0, 'batch': int(x_dev.shape[0])}}
+    model.set_encoder_precision('bf16')
+    ref_streams = oracle_streams(ref, ref_sym, hw[0] * hw[1])
+    ref_len = torch.tensor([len(q) for q in ref_streams])
+    out['reference_f32_cpu'] = {'bpp': 8.0 * float(ref_len.sum().item()) / (n * pix)}
+    for mode in ('bf16', 'f32'):
+        row = modes[mode]['row']
+        row['delta_bpp'] = row['bpp'] - out['reference_f32_cpu']['bpp']
+        row['images_with_identical_byte_count'] = int((modes[mode]['nbytes'].long() == ref_len).sum().item())
+        out[mode + '_encoder'] = row
+    # identical symbols => identical bytes: check it on the f32 encoder's exact images through the device coder
+    same = [i for i in range(n) if bool((modes['f32']['symbols'][i] == ref_sym[i]).all())][:8]
+    if same:
+        with torch.no_grad():
+            model.set_encoder_precision('f32')
+            sym, hw = model.stage_front(x_dev[:n])
+            buf, off, nbs, _ = eb.encode_symbols_device(sym, hw[0] * hw[1])
+            model.set_encoder_precision('bf16')
+            idx = torch.tensor(same, device=dev)
+            streams = eb.unpack_strings(buf[idx], off[idx], nbs[idx])
+        out['f32_encoder']['bitstreams_identical_to_reference_on_checked_images'] = \
+            all(streams[k] == ref_streams[i] for k, i in enumerate(same))
+        out['f32_encoder']['images_checked_byte_for_byte'] = len(same)
+    return out
+
+
 STAGE1 = {   # train.stage1 of configs/ilsvrc2012/supervised_compression/entropic_student/splitable_resnet50-fp-beta0.08_from_resnet50.yaml
     'teacher': {'sequential': ['conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4'],
                 'forward_hook': {'input': [], 'output': ['layer1', 'layer2', 'layer3', 'layer4']}},
@@ -751,6 +814,10 @@ def main():
                            'encode_Msym_per_s_per_stream': n_sym / ksum['rans_encode'][1] / 1e3,
                            'decode_Msym_per_s_per_stream': n_sym / ksum['rans_decode'][1] / 1e3}
         failed = None
+        if world == 1 and not args.no_cpu_baseline:
+            out['precision_check'] = precision_check(model, x, dev)
+            out['symbol_mismatch_rate'] = out['precision_check']['bf16_encoder']['symbol_mismatch_rate']
+            out['delta_bpp'] = out['precision_check']['bf16_encoder']['delta_bpp']
         if world == 1 and not args.no_bs1:
             out['bs1_eval'] = bs1_eval(model, x, dev)
         if world == 1 and not args.no_cpu_baseline:

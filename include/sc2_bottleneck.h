@@ -149,6 +149,29 @@ int sc2_conv_patch_supported(const sc2_conv_desc *d);
 int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
                    const void *ep_x, const float *ep_beta, void *stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Reference-precision analysis transform: the same convolution / GDN1 with f32 OPERANDS on the   */
+/* f32 matrix cores (v_mfma_f32_16x16x4_f32: bit for bit a k-ordered f32 fma chain), for callers   */
+/* that need the symbols -- hence the byte streams -- the reference's f32 CPU path produces        */
+/* (nn.Conv2d + compressai GDN1 in f32, sc2bench/models/layer.py:475-483, quantised at :506).      */
+/* 1/16 of the bf16 matrix rate; `FPBasedResNetBottleneck.set_encoder_precision('f32')`.           */
+/* ------------------------------------------------------------------------------------------ */
+/* x: f32 NCHW [N,C,H,W] -> y: f32 NHWC [N,H,W,Cpad], channels >= C zero, Cpad % 4 == 0. */
+int sc2_nchw_f32_to_nhwc_f32(const float *x, float *y, int N, int C, int H, int W, int Cpad, void *stream);
+/* Output channels per weight chunk for a given Cout (32, 48 or 96): the packing unit of w_frag below. */
+int sc2_conv_f32_chunk_channels(int Cout);
+/* d      : as for sc2_conv2d_fwd; Cin % 4 == 0 (the padded channel count of x), square stride / padding, no output scatter;
+ *          Kpad / Cout_pad / k_order are ignored.  a_op: NONE / ABS / SQUARE.  epilogue: NONE, BIAS, GDN (y = ep_x * (1 /
+ *          (ep_beta[c] + acc))), IGDN (y = ep_x * (ep_beta[c] + acc)) -- the operation order of compressai GDN1.forward.
+ * x      : f32 NHWC [N,H,W,Cin]
+ * w_frag : f32, [chunks][steps][NT][64 lanes][4] with cc = sc2_conv_f32_chunk_channels(Cout), NT = cc / 16, chunks =
+ *          ceil(Cout / cc), steps = ceil(KH*KW*Cin / 16); entry (ch, s, nt, lane = q*16 + r, j) =
+ *          W[ch*cc + nt*16 + r][k = 16 s + 4 q + j], k = (kh*KW + kw)*Cin + ci, zero beyond Cout / K.
+ * ep_x   : f32 NHWC [N,OH,OW,Cout] for GDN / IGDN;  ep_beta : f32 [Cout] (beta, bias, or the medians for symbols)
+ * y      : SC2_OUT_F32_NHWC [N,OH,OW,Cout] / SC2_OUT_F32_NCHW / SC2_OUT_I32_NCHW_SYM (round_half_even(acc - ep_beta[c])). */
+int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const float *w_frag, void *y, const float *ep_x,
+                       const float *ep_beta, void *stream);
+
 /* First decoder stage in ONE launch: y = GDN1_512(Conv2d(Cin -> 512, k2, s1, p1, bias=False)(x)) with the inverse
  * (multiplicative) or forward (divisive) normalisation: t = conv(x); y = t * (beta + gamma |t|) resp. t / (...).
  * Replaces decoder[0] + decoder[1] of FPBasedResNetBottleneck (sc2bench/models/layer.py:486-488); the 512-channel

@@ -207,6 +207,12 @@ class SplittableResNet(UpdatableBackbone):
             self.bottleneck_layer.output_format = 'bf16_nhwc' if dtype == 'bf16' else 'f32_nchw'
         return self
 
+    def set_encoder_precision(self, precision):
+        """'f32': the bottleneck's analysis transform with f32 operands, so that symbols / byte streams / bpp are the f32
+        reference path's (FPBasedResNetBottleneck.set_encoder_precision); 'bf16': the fast default."""
+        self.bottleneck_layer.set_encoder_precision(precision)
+        return self
+
     def _hip_head_for_eval(self):
         """Folded conv+BN(+ReLU)(+residual) head for bf16 eval; rebuilt when a parameter changes."""
         mods = [m for m in (self.layer2, self.layer3, self.layer4, self.fc) if m is not None]

@@ -1,0 +1,241 @@
+// Reference-precision convolution / GDN: f32 operands on the f32 matrix cores.
+//
+// The reference's CPU path runs the analysis transform in f32 (nn.Conv2d + CompressAI GDN1, sc2bench/models/layer.py:475-483);
+// the symbols it then codes are round(latent - median) (layer.py:506), so the byte stream of an image depends on every bit of
+// the latent that lies near a rounding boundary.  The bf16 MFMA kernels (conv_igemm*, conv0_gdn96, conv2_gdn48, conv2x2_c48)
+// move ~1-2 % of the symbols of an image across such a boundary.  This file is the encoder mode that does not:
+// `v_mfma_f32_16x16x4_f32` takes f32 A / B operands and accumulates in f32 -- bit for bit a k-ordered fmaf chain, one rounding
+// per product (cdna_hip_programming.md, "FP32-input MFMA") -- at 1/16 of the bf16 matrix rate (155 TFLOP/s).  The encoder is
+// only 1.18 GFLOP per image, so the mode costs ~2-4 ms per 256 images.  What remains against the CPU's f32 convolution is the
+// ORDER of the f32 additions (the CPU's blocked loops sum in another order): relative 1e-7 per element, symbol flips ~1e-5.
+//
+// Structure (SIMPLE on purpose: this path is bound by the f32 matrix pipe at one sixteenth of the bf16 rate, so it needs no
+// LDS staging -- 16 output pixels x 16 k values x 4 B = 1 KB per A fragment against 4 MFMAs x NT of 32 cycles each):
+//   * implicit GEMM, M = output pixels, N = output channels, K = (kh, kw, ci) with ci fastest; activations f32 NHWC with the
+//     channel count padded to a multiple of 4, so a lane's four consecutive k are ONE 16-byte load of one input pixel;
+//   * a k-step = 16 consecutive k = 4 MFMAs: lane (row r = l & 15, quarter q = l >> 4) loads k = 16 s + 4 q + j (j = 0..3) of
+//     its pixel / its output channel and MFMA j consumes element j of every lane (k = 16 s + 4 q + j for q = 0..3): the same
+//     permutation on both operands, so every product lands in the right sum;
+//   * a wave owns MT x 16 pixels x NT x 16 channels; weights are packed fragment-major ([chunk][step][nt][lane][4], 1 KB per
+//     fragment) by hip.pack_conv_f32; operands of step s + 1 are loaded while step s multiplies;
+//   * per-step tap offsets / bounds come from a small table built in LDS at the start of the workgroup;
+//   * epilogues: none, GDN1 / inverse GDN1 in the reference's operation order (norm = beta + acc; y = x * (1 / norm) resp.
+//     x * norm: compressai.layers.GDN1.forward), output f32 NHWC / f32 NCHW / int32 NCHW symbols round_half_even(acc - median).
+#include "sc2_common.h"
+
+namespace {
+
+struct F32Args {
+    const float *__restrict__ x;       // f32 NHWC [N, H, W, Cin] (Cin % 4 == 0)
+    const float *__restrict__ w;       // fragment-major weights
+    const float *__restrict__ ep_x;    // f32 NHWC [N, OH, OW, Cout] (GDN operand) or null
+    const float *__restrict__ ep_beta; // f32 [Cout]: beta (GDN) / medians (symbols) or null
+    void *__restrict__ y;
+    int N, H, W, Cin, Cout, KH, KW, stride, pad, OH, OW;
+    int a_op, epilogue, out_format;
+    int n_steps;                       // K_pad / 16
+    long long M;                       // N * OH * OW
+};
+
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
+    extern __shared__ int2 ktab[];     // [n_steps * 4]: {element offset of the lane's 4 k inside the window, kh | kw << 16}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    for (int e = tid; e < p.n_steps * 4; e += 256) {
+        const int k0 = (e >> 2) * 16 + (e & 3) * 4;
+        const int tap = k0 / p.Cin, ci = k0 - tap * p.Cin;
+        int2 v;
+        if (tap < p.KH * p.KW) {
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            v.x = (kh * p.W + kw) * p.Cin + ci;
+            v.y = kh | (kw << 16);
+        } else {            // K padding: never in bounds (its weights are zero too)
+            v.x = 0;
+            v.y = 0x7FFF | (0x7FFF << 16);
+        }
+        ktab[e] = v;
+    }
+    __syncthreads();
+
+    const long long m_base = ((long long)blockIdx.x * 4 + wave) * (MT * 16);
+    const int chunk = blockIdx.y;                                  // NT * 16 output channels per chunk
+    // the lane's A rows: pixel m_base + mt * 16 + r
+    long long a_base[MT];
+    int ih0[MT], iw0[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long long m = m_base + mt * 16 + r;
+        if (m < p.M) {
+            const long long n = m / ((long long)p.OH * p.OW);
+            const int rem = (int)(m - n * p.OH * p.OW);
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            ih0[mt] = oh * p.stride - p.pad;
+            iw0[mt] = ow * p.stride - p.pad;
+            a_base[mt] = ((n * p.H + ih0[mt]) * (long long)p.W + iw0[mt]) * p.Cin;
+        } else {
+            ih0[mt] = iw0[mt] = -(1 << 20);       // every tap out of bounds: zeros
+            a_base[mt] = 0;
+        }
+    }
+    const f4_t *wf = reinterpret_cast<const f4_t *>(p.w) + ((long long)chunk * p.n_steps * NT) * 64 + lane;
+
+    f4_t acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto load_a = [&](int s, f4_t (&a)[MT]) {
+        const int2 t = ktab[s * 4 + q];
+        const int kh = t.y & 0xFFFF, kw = t.y >> 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bool ok = (unsigned)(ih0[mt] + kh) < (unsigned)p.H && (unsigned)(iw0[mt] + kw) < (unsigned)p.W;
+            f4_t v = f4_t{0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f4_t *>(p.x + a_base[mt] + t.x);
+            if (p.a_op == SC2_AOP_ABS) v = f4_t{fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+            else if (p.a_op == SC2_AOP_SQUARE) v = v * v;
+            a[mt] = v;
+        }
+    };
+    auto load_b = [&](int s, f4_t (&b)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = wf[((long long)s * NT + nt) * 64];
+    };
+
+    f4_t a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
+    load_a(0, a_cur);
+    load_b(0, b_cur);
+    for (int s = 0; s < p.n_steps; ++s) {
+        if (s + 1 < p.n_steps) {
+            load_a(s + 1, a_nxt);
+            load_b(s + 1, b_nxt);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[mt][j], b_cur[nt][j], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
+    }
+
+    // epilogue: acc[mt][nt][i] = output (pixel m_base + mt * 16 + 4 q + i, channel (chunk * NT + nt) * 16 + r)
+    const long long ohw = (long long)p.OH * p.OW;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = (chunk * NT + nt) * 16 + r;
+        if (c >= p.Cout) continue;
+        const float bc = p.ep_beta ? p.ep_beta[c] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long long m = m_base + mt * 16 + 4 * q + i;
+                if (m >= p.M) continue;
+                float v = acc[mt][nt][i];
+                if (p.epilogue == SC2_EPI_GDN || p.epilogue == SC2_EPI_IGDN) {
+                    const float xv = p.ep_x[m * p.Cout + c];
+                    float norm = v + bc;                       // conv2d(|x|, gamma, beta): the bias joins the finished sum
+                    if (p.epilogue == SC2_EPI_GDN) norm = 1.0f / norm;   // IEEE division, then one multiply, as GDN1.forward
+                    v = xv * norm;
+                } else if (p.epilogue == SC2_EPI_BIAS) {
+                    v += bc;
+                }
+                if (p.out_format == SC2_OUT_F32_NHWC) {
+                    static_cast<float *>(p.y)[m * p.Cout + c] = v;
+                } else {
+                    const long long n = m / ohw;
+                    const long long o = (n * p.Cout + c) * ohw + (m - n * ohw);
+                    if (p.out_format == SC2_OUT_F32_NCHW) static_cast<float *>(p.y)[o] = v;
+                    else static_cast<int32_t *>(p.y)[o] = (int32_t)rintf(v - bc);   // symbols: bc = the channel's median
+                }
+            }
+        }
+    }
+}
+
+template <int NT, int MT>
+int launch_f32(const F32Args &a, int chunks, hipStream_t s) {
+    const long long tiles = (a.M + (4 * MT * 16) - 1) / (4 * MT * 16);
+    const size_t lds = (size_t)a.n_steps * 4 * sizeof(int2);
+    hipLaunchKernelGGL((conv_f32_kernel<NT, MT>), dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds, s, a);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+// f32 NCHW -> f32 NHWC with the channel count padded (zeros): the layout the f32 conv reads.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f32_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int HW,
+                                                               int Cpad, long long total_pix) {
+    const int c0 = blockIdx.y * 4;
+    for (long long gp = (long long)blockIdx.x * 256 + threadIdx.x; gp < total_pix; gp += (long long)gridDim.x * 256) {
+        const long long n = gp / HW;
+        const int pix = (int)(gp - n * HW);
+        f4_t v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = c0 + j < C ? x[(n * C + c0 + j) * HW + pix] : 0.f;
+        *reinterpret_cast<f4_t *>(y + gp * Cpad + c0) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int sc2_conv_f32_chunk_channels(int Cout) { return Cout <= 32 ? 32 : (Cout <= 48 ? 48 : 96); }
+
+extern "C" int sc2_nchw_f32_to_nhwc_f32(const float *x, float *y, int N, int C, int H, int W, int Cpad, void *stream) {
+    SC2_REQUIRE(x && y, SC2_ERR_INVALID_ARG, "nchw_to_nhwc_f32: null argument");
+    SC2_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && Cpad % 4 == 0, SC2_ERR_INVALID_ARG,
+                "nchw_to_nhwc_f32: bad dims N=%d C=%d H=%d W=%d Cpad=%d", N, C, H, W, Cpad);
+    const long long total = (long long)N * H * W;
+    const int gx = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(gx, Cpad / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, C,
+                       H * W, Cpad, total);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const float *w_frag, void *y, const float *ep_x,
+                                  const float *ep_beta, void *stream) {
+    SC2_REQUIRE(d && x && w_frag && y, SC2_ERR_INVALID_ARG, "conv2d_f32: null argument");
+    SC2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cin % 4 == 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0,
+                SC2_ERR_INVALID_ARG, "conv2d_f32: bad dims (Cin must be a multiple of 4)");
+    SC2_REQUIRE(d->stride_h == d->stride_w && d->pad_h == d->pad_w && d->stride_h > 0 && d->pad_h >= 0, SC2_ERR_UNSUPPORTED,
+                "conv2d_f32: square stride / padding only");
+    SC2_REQUIRE(d->OH == (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1 && d->OW == (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1,
+                SC2_ERR_INVALID_ARG, "conv2d_f32: OH / OW do not match the geometry");
+    SC2_REQUIRE(d->out_H == 0, SC2_ERR_UNSUPPORTED, "conv2d_f32: no output scatter");
+    SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS || d->a_op == SC2_AOP_SQUARE, SC2_ERR_INVALID_ARG, "conv2d_f32: a_op");
+    SC2_REQUIRE(d->epilogue == SC2_EPI_NONE || d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS,
+                SC2_ERR_UNSUPPORTED, "conv2d_f32: epilogue %d", d->epilogue);
+    SC2_REQUIRE(d->out_format == SC2_OUT_F32_NHWC || d->out_format == SC2_OUT_F32_NCHW || d->out_format == SC2_OUT_I32_NCHW_SYM,
+                SC2_ERR_UNSUPPORTED, "conv2d_f32: out_format %d", d->out_format);
+    const bool gdn = d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN;
+    SC2_REQUIRE(!gdn || (ep_x && ep_beta), SC2_ERR_INVALID_ARG, "conv2d_f32: GDN epilogue needs ep_x and ep_beta");
+    SC2_REQUIRE((d->epilogue != SC2_EPI_BIAS && d->out_format != SC2_OUT_I32_NCHW_SYM) || ep_beta, SC2_ERR_INVALID_ARG,
+                "conv2d_f32: ep_beta (bias / medians) missing");
+    SC2_REQUIRE(d->out_format != SC2_OUT_I32_NCHW_SYM || d->epilogue == SC2_EPI_NONE, SC2_ERR_INVALID_ARG,
+                "conv2d_f32: symbols come straight from the accumulators (epilogue NONE)");
+    F32Args a;
+    a.x = x; a.w = w_frag; a.ep_x = ep_x; a.ep_beta = ep_beta; a.y = y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+    a.stride = d->stride_h; a.pad = d->pad_h; a.OH = d->OH; a.OW = d->OW;
+    a.a_op = d->a_op; a.epilogue = d->epilogue; a.out_format = d->out_format;
+    a.n_steps = (d->KH * d->KW * d->Cin + 15) / 16;
+    a.M = (long long)d->N * d->OH * d->OW;
+    SC2_REQUIRE((long long)d->N * d->H * d->W * d->Cin < (1ll << 31) && a.M * d->Cout < (1ll << 33), SC2_ERR_UNSUPPORTED,
+                "conv2d_f32: tensor too large for this kernel's index arithmetic");
+    SC2_REQUIRE((size_t)a.n_steps * 32 <= 64 * 1024, SC2_ERR_UNSUPPORTED, "conv2d_f32: K too long for the tap table");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int cc = sc2_conv_f32_chunk_channels(d->Cout);
+    const int chunks = (d->Cout + cc - 1) / cc;
+    if (cc == 32) return launch_f32<2, 2>(a, chunks, s);
+    if (cc == 48) return launch_f32<3, 2>(a, chunks, s);
+    return launch_f32<6, 2>(a, chunks, s);
+}

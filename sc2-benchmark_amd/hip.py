@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_fc_fwd',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
-    'sc2_conv2d_fwd',
+    'sc2_conv2d_fwd', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
     'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
@@ -71,6 +71,9 @@ def lib():
     L.sc2_conv_fused_gdn_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.sc2_conv_patch_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
+    L.sc2_nchw_f32_to_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv_f32_chunk_channels.argtypes = [i32]
+    L.sc2_conv2d_f32_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     L.sc2_conv2x2_gdn512_supported.argtypes = [i32] * 6
     L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_conv0_gdn96_supported.argtypes = [i32, i32, i32]
@@ -1036,6 +1039,75 @@ def gc_dequantize(symbols, means=None, want_f32=True, want_nhwc=False):
 # --------------------------------------------------------------------------------------------- #
 # CDF + rANS
 # --------------------------------------------------------------------------------------------- #
+# --------------------------------------------------------------------------------------------- #
+# reference-precision (f32 operand) convolution / GDN1: csrc/conv_f32.hip
+# --------------------------------------------------------------------------------------------- #
+def nchw_f32_to_nhwc_f32(x, cpad=None):
+    """x: f32 [N,C,H,W] -> f32 [N,H,W,Cpad] (channels >= C zero)."""
+    _dev(x, 'x')
+    assert x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    cpad = (C + 3) // 4 * 4 if cpad is None else cpad
+    y = torch.empty((N, H, W, cpad), dtype=torch.float32, device=x.device)
+    _check(lib().sc2_nchw_f32_to_nhwc_f32(_ptr(x), _ptr(y), N, C, H, W, cpad, _stream()), 'nchw_f32_to_nhwc_f32')
+    return y
+
+
+def pack_conv_f32(weight, cin_pad=None):
+    """Conv weight [Cout, Cin, KH, KW] (any float dtype) -> the f32 fragment-major stream of sc2_conv2d_f32_fwd:
+    [chunks][steps][NT][64 lanes][4], entry (ch, s, nt, lane = q*16 + r, j) = W[ch*cc + nt*16 + r][16 s + 4 q + j] with
+    k = (kh*KW + kw)*cin_pad + ci."""
+    w = weight.detach().float()
+    Cout, Cin, KH, KW = w.shape
+    cin_pad = (Cin + 3) // 4 * 4 if cin_pad is None else cin_pad
+    cc = int(lib().sc2_conv_f32_chunk_channels(Cout))
+    chunks, NT = (Cout + cc - 1) // cc, cc // 16
+    K = KH * KW * cin_pad
+    steps = (K + 15) // 16
+    m = torch.zeros((chunks * cc, KH, KW, cin_pad), dtype=torch.float32, device=w.device)
+    m[:Cout, :, :, :Cin] = w.permute(0, 2, 3, 1)
+    m = torch.nn.functional.pad(m.reshape(chunks * cc, K), (0, steps * 16 - K))
+    m = m.reshape(chunks, NT, 16, steps, 4, 4)            # [ch, nt, r, s, q, j]
+    return m.permute(0, 3, 1, 4, 2, 5).contiguous()       # [ch, s, nt, q, r, j]
+
+
+def conv2d_f32_fwd(x_nhwc, w_frag, cout, kh, kw, stride, padding, a_op=AOP_NONE, epilogue=EPI_NONE, out_format=None,
+                   ep_x=None, ep_beta=None, out=None, tag=None):
+    """x_nhwc: f32 [N,H,W,Cin] (Cin % 4 == 0) -> per out_format: OUT_F32_NHWC [N,OH,OW,Cout] (default), OUT_F32_NCHW
+    [N,Cout,OH,OW], OUT_I32_NCHW_SYM int32 [N,Cout,OH,OW] (ep_beta = medians)."""
+    _dev(x_nhwc, 'x')
+    assert x_nhwc.dtype == torch.float32 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    assert w_frag.dtype == torch.float32 and w_frag.is_contiguous()
+    out_format = OUT_F32_NHWC if out_format is None else out_format
+    N, H, W, Cin = x_nhwc.shape
+    sh = stride[0] if isinstance(stride, (tuple, list)) else stride
+    ph = padding[0] if isinstance(padding, (tuple, list)) else padding
+    OH, OW = (H + 2 * ph - kh) // sh + 1, (W + 2 * ph - kw) // sh + 1
+    d = ConvDesc(N=N, H=H, W=W, Cin=Cin, Cout=cout, KH=kh, KW=kw, stride_h=sh, stride_w=sh, pad_h=ph, pad_w=ph, OH=OH, OW=OW,
+                 a_op=a_op, epilogue=epilogue, out_format=out_format, Kpad=0, Cout_pad=0, out_H=0, out_W=0, out_stride_h=0,
+                 out_stride_w=0, out_off_h=0, out_off_w=0, k_order=0)
+    if out_format == OUT_F32_NHWC:
+        y = torch.empty((N, OH, OW, cout), dtype=torch.float32, device=x_nhwc.device)
+    elif out_format == OUT_F32_NCHW:
+        y = torch.empty((N, cout, OH, OW), dtype=torch.float32, device=x_nhwc.device)
+    else:
+        assert out_format == OUT_I32_NCHW_SYM
+        if out is not None:
+            assert out.dtype == torch.int32 and out.is_contiguous() and out.numel() == N * cout * OH * OW
+            y = out.view(N, cout, OH, OW)
+        else:
+            y = torch.empty((N, cout, OH, OW), dtype=torch.int32, device=x_nhwc.device)
+    for t in (ep_x, ep_beta):
+        if t is not None:
+            _dev(t, 'epilogue operand')
+            assert t.dtype == torch.float32 and t.is_contiguous()
+    with _timed(tag or 'conv_f32'):
+        _check(lib().sc2_conv2d_f32_fwd(ctypes.byref(d), _ptr(x_nhwc), _ptr(w_frag), _ptr(y), _ptr(ep_x), _ptr(ep_beta),
+                                        _stream()), 'conv2d_f32_fwd')
+    return y
+
+
 def pmf_to_quantized_cdf(pmf, precision=16):
     """Host function. pmf: sequence / 1-D CPU tensor of floats -> torch.IntTensor (len+1)."""
     if isinstance(pmf, torch.Tensor):
