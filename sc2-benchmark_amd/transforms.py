@@ -236,20 +236,17 @@ class AdaptivePad(nn.Module):
         self.returns_org_patch_size = returns_org_patch_size
 
     def forward(self, x):
-        height, width = x.shape[-2:]
-        vertical_pad_size = 0 if height % self.factor == 0 else int((height // self.factor + 1) * self.factor - height)
-        horizontal_pad_size = 0 if width % self.factor == 0 else int((width // self.factor + 1) * self.factor - width)
-        padded_vertical_size = vertical_pad_size + height
-        padded_horizontal_size = horizontal_pad_size + width
-        assert padded_vertical_size % self.factor == 0 and padded_horizontal_size % self.factor == 0, \
-            'padded vertical and horizontal sizes ({}, {}) should be ' \
-            'factor of {}'.format(padded_vertical_size, padded_horizontal_size, self.factor)
-        padding = [horizontal_pad_size // 2, vertical_pad_size // 2] if self.padding_position == 'equal_side' \
-            else [0, 0, horizontal_pad_size, vertical_pad_size]
-        x = pad(x, padding, self.fill, self.padding_mode)
-        if self.returns_org_patch_size:
-            return x, (height, width)
-        return x
+        # written against the behaviour of misc.py:141-154 (not its text): each side grows by what it lacks to the next
+        # multiple of `factor`; 'equal_side' hands torchvision's two-value form HALF of that per side (so an odd remainder
+        # ends one short of a multiple -- the reference's behaviour, kept), anything else pads right and bottom only
+        org_h, org_w = (int(v) for v in x.shape[-2:])
+        lack_h, lack_w = -org_h % self.factor, -org_w % self.factor
+        if self.padding_position == 'equal_side':
+            borders = [lack_w // 2, lack_h // 2]                # left = right, top = bottom
+        else:
+            borders = [0, 0, lack_w, lack_h]                    # left, top, right, bottom
+        x = pad(x, borders, self.fill, self.padding_mode)
+        return (x, (org_h, org_w)) if self.returns_org_patch_size else x
 
 
 @register_misc_transform_module
@@ -270,6 +267,15 @@ def default_collate_w_pil(batch):
 
 
 # --------------------------------------------------------------------------------------------------------- sc2bench.codec
+def _pil_codec_round_trip(pil_img, save_kwargs, open_kwargs):
+    """image -> codec bytes in memory -> reopened image: (image, byte count of the coded file)."""
+    from PIL import Image
+    coded = BytesIO()
+    pil_img.save(coded, **save_kwargs)
+    n_bytes = coded.tell()          # before reopening: the decoder moves the position
+    return Image.open(coded, **open_kwargs), n_bytes
+
+
 @register_codec_transform_module
 class PILImageModule(nn.Module):
     """Compresses (and reopens) a PIL image with a PIL codec (codec.py:79-111)."""
@@ -281,14 +287,8 @@ class PILImageModule(nn.Module):
         self.save_kwargs = save_kwargs
 
     def forward(self, pil_img, *args):
-        from PIL import Image
-        img_buffer = BytesIO()
-        pil_img.save(img_buffer, **self.save_kwargs)
-        file_size = img_buffer.tell()
-        pil_img = Image.open(img_buffer, **self.open_kwargs)
-        if self.returns_file_size:
-            return pil_img, file_size
-        return pil_img
+        decoded, n_bytes = _pil_codec_round_trip(pil_img, self.save_kwargs, self.open_kwargs)
+        return (decoded, n_bytes) if self.returns_file_size else decoded
 
     def __repr__(self):
         return self.__class__.__name__ + '(returns_file_size={}, open_kwargs={}, save_kwargs={})'.format(
@@ -305,35 +305,35 @@ class PILTensorModule(nn.Module):
         self.open_kwargs = open_kwargs if isinstance(open_kwargs, dict) else dict()
         self.save_kwargs = save_kwargs
 
+    @staticmethod
+    def _channel_groups(x):
+        """[C,H,W] -> groups of three channels (RGB images); a remainder of one goes as a grey image, a remainder of two as
+        two grey images (a two-channel tensor has no PIL mode)."""
+        groups = list(x.split(3, dim=0))
+        if groups[-1].shape[0] == 2:
+            groups[-1:] = list(groups[-1].split(1, dim=0))
+        return groups
+
     def forward(self, x, *args):
-        from PIL import Image
-        device = x.device
-        split_features = x.split(3, dim=0)
-        if split_features[-1].shape[0] == 2:     # a trailing pair goes as two single-channel images
-            split_features = split_features[:-1] + split_features[-1].split(1, dim=0)
-        file_size = 0
-        norm_max_list, norm_min_list, reconstructed = list(), list(), list()
-        for split_feature in split_features:
-            max_value = split_feature.max()
-            min_value = split_feature.min()
-            norm_max_list.append(max_value)
-            norm_min_list.append(min_value)
-            normed_feature = (split_feature - min_value) / max_value      # the reference's normalisation, as is
-            pil_img = to_pil_image(normed_feature)
-            img_buffer = BytesIO()
-            pil_img.save(img_buffer, **self.save_kwargs)
-            file_size += img_buffer.tell()
-            pil_img = Image.open(img_buffer, **self.open_kwargs)
-            if split_feature.shape[0] == 1 and pil_img.mode != 'L':
-                pil_img = pil_img.convert('L')
-            tensor = to_tensor(pil_img)
-            reconstructed.append(tensor.to(device) * max_value + min_value)
-        reconstructed_features = torch.vstack(reconstructed)
-        # compressed channel groups + the values needed to denormalise them, measured as the reference measures them
-        file_size += get_binary_object_size(norm_min_list, unit_size=1) + get_binary_object_size(norm_max_list, unit_size=1)
-        if self.returns_file_size:
-            return reconstructed_features, file_size
-        return reconstructed_features
+        # written against the behaviour of codec.py:141-186: per channel group, scale with the group's own extrema AS THE
+        # REFERENCE DOES -- (v - min) / max on the way in, v * max + min on the way out, which is not a min-max scaling and
+        # must not be "fixed" (SURVEY appendix A) --, 8-bit image through the codec, back to a tensor on x's device.  The
+        # payload is the coded images plus the two pickled lists of 0-dim tensors the receiver needs to undo the scaling.
+        lows, highs, restored, coded_bytes = [], [], [], 0
+        for group in self._channel_groups(x):
+            high, low = group.max(), group.min()
+            decoded, n_bytes = _pil_codec_round_trip(to_pil_image((group - low) / high), self.save_kwargs, self.open_kwargs)
+            coded_bytes += n_bytes
+            if group.shape[0] == 1 and decoded.mode != 'L':     # a grey image some codecs reopen as RGB
+                decoded = decoded.convert('L')
+            restored.append(to_tensor(decoded).to(x.device) * high + low)
+            lows.append(low)
+            highs.append(high)
+        features = torch.vstack(restored)
+        if not self.returns_file_size:
+            return features
+        side_info = get_binary_object_size(lows, unit_size=1) + get_binary_object_size(highs, unit_size=1)
+        return features, coded_bytes + side_info
 
     def __repr__(self):
         return self.__class__.__name__ + '(returns_file_size={}, open_kwargs={}, save_kwargs={})'.format(
