@@ -146,3 +146,77 @@ def test_dilated_conv3x3_on_phase_grids(S, dev, d, H, W):
         ref = torch.relu(torch.nn.functional.conv2d(xr, w_f.to(torch.bfloat16).float(), padding=d, dilation=d) + b_f.view(1, -1, 1, 1))
     assert out.shape == (2, H, W, 128)
     _close(out.permute(0, 3, 1, 2).float(), ref, 2e-2)
+
+
+def _oracle_features_from_bytes(model_body, ref_bn, enc, keys):
+    """The DEVICE's byte streams through the oracle's decoder, then CPU f32 copies of the body's tail modules: isolates the
+    decoder + tail arithmetic from symbol flips of the bf16 encoder (the construction of tests/test_gpu_shapes.py)."""
+    with torch.no_grad():
+        h = ref_bn.decode(**enc)
+        out = OrderedDict()
+        for name, module in model_body.named_children():
+            if name != 'bottleneck_layer':
+                h = copy.deepcopy(module).cpu().float()(h)
+            if name in keys:
+                out[keys[name]] = h
+    return out
+
+
+def test_fpn_body_at_800x1216_bf16_vs_oracle_tail(S, R, dev):
+    """BASELINE config 4's operating shape (a typical Faster R-CNN batch element, 800 x 1216): the FrozenBatchNorm2d body in
+    bf16 -- bottleneck through encode / decode, layer2..4 on the HIP stacks at 100 x 152 / 50 x 76 / 25 x 38 -- against the
+    oracle's decoder + f32 tail ON THE DEVICE'S BYTES, 3e-2 relative L2 per returned map (sc2bench/models/backbone.py:90-172,
+    models/detection/base.py:44-129)."""
+    from sc2bench_amd import dense
+    torch.set_num_threads(32)
+    backbone, ref_bn = _build(S, R, dev, norm_layer='FrozenBatchNorm2d')
+    keys = {'bottleneck_layer': '1', 'layer2': '2', 'layer3': '3', 'layer4': '4'}
+    bf = dense.backbone_with_fpn(backbone, return_layer_dict=keys, in_channels_list=[256, 512, 1024, 2048], out_channels=256,
+                                 analyzable_layer_key='bottleneck_layer', analysis_config={'analyzes_after_compress': False})
+    bf.eval().to(dev)
+    bf.update()
+    ref_bn.update(force=True)
+    bf.body.set_compute_dtype('bf16')
+    x = torch.rand(1, 3, 800, 1216, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        feats = bf.body(x.to(dev))
+        assert set(bf.body._hip_layers) == {'layer2', 'layer3', 'layer4'}
+        assert [tuple(v.shape) for v in feats.values()] == [(1, 256, 200, 304), (1, 512, 100, 152), (1, 1024, 50, 76),
+                                                            (1, 2048, 25, 38)]
+        enc = bf.body.bottleneck_layer.encode(x.to(dev))
+        ref = _oracle_features_from_bytes(bf.body, ref_bn, enc, keys)
+        for k in ref:
+            _close(feats[k], ref[k], 3e-2)
+        pyramid = bf(x.to(dev))
+        assert pyramid['pool'].shape == (1, 256, 13, 19) and all(torch.isfinite(v.float()).all() for v in pyramid.values())
+
+
+def test_deeplab_body_at_513_bf16_vs_oracle_tail(S, R, dev):
+    """BASELINE config 5's shape (2 x 513 x 513): the dilated body in bf16 (layer2 and the dilated layer3 / layer4 on the HIP
+    head) and the DeepLabv3 classifier against the oracle's decoder + f32 tail + f32 classifier on the device's bytes
+    (sc2bench/models/segmentation/deeplabv3.py:44-104)."""
+    from sc2bench_amd import dense
+    torch.set_num_threads(32)
+    backbone, ref_bn = _build(S, R, dev, replace_stride_with_dilation=[False, True, True])
+    keys = {'layer3': 'aux', 'layer4': 'out'}
+    body = S.FeatureExtractionBackbone(backbone, keys, [], False, analyzable_layer_key='bottleneck_layer')
+    model = dense.create_deeplabv3(body, num_input_channels=2048, uses_aux=True, num_aux_channels=1024, num_classes=21)
+    model.eval().to(dev)
+    model.update()
+    ref_bn.update(force=True)
+    cls_ref = copy.deepcopy(model.classifier).cpu().float()
+    body.set_compute_dtype('bf16')
+    model.classifier.to(torch.bfloat16)
+    model.aux_classifier.to(torch.bfloat16)
+    x = torch.rand(2, 3, 513, 513, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        feats = body(x.to(dev))
+        assert set(body._hip_layers) == {'layer2', 'layer3', 'layer4'}
+        assert feats['out'].shape == (2, 2048, 65, 65) and feats['aux'].shape == (2, 1024, 65, 65)
+        enc = body.bottleneck_layer.encode(x.to(dev))
+        ref = _oracle_features_from_bytes(body, ref_bn, enc, keys)
+        for k in ref:
+            _close(feats[k], ref[k], 3e-2)
+        out = model(x.to(dev))
+        want = torch.nn.functional.interpolate(cls_ref(ref['out']), size=(513, 513), mode='bilinear', align_corners=False)
+        _close(out['out'], want, 5e-2)      # + a bf16 ASPP head (torch ops) on top of the 3e-2 features
