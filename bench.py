@@ -379,6 +379,146 @@ def dry_run(args, world, rank, local_rank):
         dist.destroy_process_group()
 
 
+def bottleneck_gflop(H, W):
+    """algorithmic GFLOP (2 * MACs) of the ten transforms of the FP bottleneck for one H x W image."""
+    def o(n, k, st, p):
+        return (n + 2 * p - k) // st + 1
+    h1, w1 = o(H, 5, 2, 2), o(W, 5, 2, 2)
+    h2, w2 = o(h1, 5, 2, 2), o(w1, 5, 2, 2)
+    h3, w3 = h2 - 1, w2 - 1
+    macs = (h1 * w1 * 96 * (75 + 96) + h2 * w2 * 48 * (2400 + 48) + h3 * w3 * 24 * 192 +
+            (h3 + 1) * (w3 + 1) * 512 * (96 + 512) + h3 * w3 * 256 * (2048 + 256) + (h3 + 1) * (w3 + 1) * 256 * 1024)
+    return 2e-9 * macs
+
+
+def _shape_backbone(S, **resnet_kwargs):
+    torch.manual_seed(0)
+    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
+    backbone = S.splittable_resnet(cfg, skips_avgpool=True, skips_fc=True, **resnet_kwargs)
+    shape_workload(backbone)
+    return backbone
+
+
+def build_workload(name, dev, bs):
+    """The other BASELINE configs as the reference's API runs them (module forward in eval mode after update(): encode ->
+    bytes -> decode inside): -> (model, input batch, description, (H, W) of the bottleneck's input or None, default bs)."""
+    import sc2bench_amd as S
+    from sc2bench_amd import dense, transforms as T
+    if name == 'seg513':      # config 5: Entropic-Student DeepLabv3-ResNet-50, PASCAL VOC2012 513 x 513 (voc yaml:132 batch 16)
+        n = bs or 16
+        backbone = _shape_backbone(S, replace_stride_with_dilation=[False, True, True])
+        body = S.FeatureExtractionBackbone(backbone, {'layer3': 'aux', 'layer4': 'out'}, [], False,
+                                           analyzable_layer_key='bottleneck_layer')
+        model = dense.create_deeplabv3(body, num_input_channels=2048, uses_aux=True, num_aux_channels=1024, num_classes=21)
+        model.eval().to(dev)
+        model.update()
+        body.set_compute_dtype('bf16')
+        model.classifier.to(torch.bfloat16)
+        model.aux_classifier.to(torch.bfloat16)
+        x = torch.rand(n, 3, 513, 513, generator=torch.Generator().manual_seed(0)).to(dev)
+        what = ('Entropic-Student DeepLabv3-ResNet-50 (FP bottleneck 24ch, dilated layer3/4 on the HIP head, ASPP head = torch '
+                'ops in bf16), 513x513, eval after update()')
+        return model, x, what, (513, 513), n
+    if name == 'det800x1216':  # config 4: the Faster R-CNN body: bottleneck + FrozenBN layer2-4 + FPN (RPN / RoI heads need torchvision)
+        n = bs or 6
+        backbone = _shape_backbone(S, norm_layer='FrozenBatchNorm2d')
+        model = dense.backbone_with_fpn(backbone, return_layer_dict={'bottleneck_layer': '1', 'layer2': '2', 'layer3': '3', 'layer4': '4'},
+                                        in_channels_list=[256, 512, 1024, 2048], out_channels=256,
+                                        analyzable_layer_key='bottleneck_layer', analysis_config={'analyzes_after_compress': False})
+        model.eval().to(dev)
+        model.update()
+        model.body.set_compute_dtype('bf16')
+        model.fpn.to(torch.bfloat16)
+        x = torch.rand(n, 3, 800, 1216, generator=torch.Generator().manual_seed(0)).to(dev)
+        what = ('Entropic-Student Faster R-CNN ResNet-50-FPN BODY (FP bottleneck 24ch + FrozenBN layer2-4 on the HIP head + FPN '
+                'in bf16 torch ops; RPN / RoI heads need torchvision: not part of this figure), 800x1216, eval after update()')
+        return model, x, what, (800, 1216), n
+    if name == 'fp_input':     # config 3: Factorized-Prior (quality 8) input compression + ResNet-50, 224 x 224
+        from sc2bench_amd.resnet import resnet50
+        n = bs or 32
+        torch.manual_seed(0)
+        codec = S.bmshj2018_factorized(8)
+        eb = codec.entropy_bottleneck
+        with torch.no_grad():
+            q = torch.zeros(eb.channels, 1, 3)
+            for c in range(eb.channels):
+                q[c, 0, 0], q[c, 0, 1], q[c, 0, 2] = -(3 + c % 5), 0.25 * (c % 3), 4 + c % 7
+            eb.quantiles.copy_(q)
+            codec.g_a[6].weight.mul_(10.0)
+        clf = resnet50(num_classes=1000).eval()
+        post = T.Compose([T.CenterCrop([224, 224]), T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
+        model = S.NeuralInputCompressionClassifier(clf, pre_transform=T.AdaptivePad(fill=0, factor=64), compression_model=codec,
+                                                   post_transform=post, analysis_config={})
+        model.eval().to(dev)
+        codec.update()
+        x = torch.rand(n, 3, 224, 224, generator=torch.Generator().manual_seed(0)).to(dev)
+        what = ('bmshj2018_factorized quality 8 (N 192, M 320) input compression on the HIP kernels (AdaptivePad 64 -> 256x256) + '
+                'ResNet-50 classifier (torch f32 ops), 224x224, eval after update()')
+        return model, x, what, None, n
+    raise SystemExit('unknown workload ' + name)
+
+
+def workload_bench(args, dev, rank, world, distributed):
+    """`--workload seg513 | det800x1216 | fp_input`: the module forward of that config, K steps after W warm-up steps, one
+    stream, bytes objects through the host API (the reference's semantics).  Secondary figures: the headline metric and the
+    pipelined device-resident path are `--workload es224` (default)."""
+    from sc2bench_amd import hip
+    model, x, what, hw, n = build_workload(args.workload, dev, args.bs if args.bs != 256 else 0)
+    sizes = []
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    for _ in range(max(1, args.warmup)):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    select = lambda tag: tag is not None and (tag.startswith(('enc.', 'dec.', 'g_a', 'g_s')) or tag.startswith('rans'))  # noqa: E731
+    with hip.KernelTimer(select) as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize(dev)
+        if distributed:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    leaves = list(out.values()) if isinstance(out, dict) else [out]
+    assert all(torch.isfinite(v.float()).all() for v in leaves)
+    if rank != 0:
+        return
+    ksum = timer.summary()
+    bn = {k: v for k, v in ksum.items() if k.startswith(('enc.', 'dec.'))}
+    roofline = None
+    if hw is not None and bn:
+        ms = sum(v[1] for v in bn.values())
+        tf = bottleneck_gflop(*hw) * n / ms
+        roofline = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_BF16_TFLOPS,
+                    'traffic': None, 'kernel': 'bottleneck forward = sum of its six fused launches', 'kernel_ms': ms,
+                    'gflop_per_image': bottleneck_gflop(*hw)}
+    # compressed size of the batch as the reference measures it
+    with torch.no_grad():
+        bl = model.compression_model if args.workload == 'fp_input' else \
+            (model.body if hasattr(model, 'body') else model.backbone).bottleneck_layer
+        obj = bl.compress(model.pre_transform(x)) if args.workload == 'fp_input' else bl.encode(x)
+    nbytes = sum(len(q) for q in obj['strings'][0])
+    pix = x.shape[-1] * x.shape[-2] * n
+    print(json.dumps({
+        'metric': 'images/s + bpp, ' + args.workload, 'value': n * args.steps * world / elapsed, 'unit': 'images/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': max(1, args.warmup), 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': what, 'batch_per_gpu': n, 'global_batch': n * world, 'pipeline': 'none: module forward, one stream',
+                   'streams': 'Python bytes through the host API (host coder up to {} streams, batched device coder above)'
+                              .format(hip.host_coder_max_streams()), 'sharding': 'images, no collective'},
+        'bpp': 8.0 * nbytes / pix, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': None,
+        'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())}}))
+
+
 def self_launch(n):
     """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <the same arguments>` as a child process (one rank per
     GPU over RCCL, rendezvous on 127.0.0.1 and a free port), relays its output and exits with its return code.  A process
@@ -425,6 +565,8 @@ def main():
     ap.add_argument('--diag-timeline', action='store_true', help='DIAGNOSTIC: HIP events around every stage of the timed run, printed to stderr (adds ~100 event records)')
     ap.add_argument('--diag-repeat', type=int, default=0, help='DIAGNOSTIC: after the timed region, time R more runs of K steps and print their wall times to stderr')
     ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
+    ap.add_argument('--workload', choices=['es224', 'fp_input', 'seg513', 'det800x1216'], default='es224',
+                    help='es224 = the headline config (default); the others are BASELINE configs 3 / 5 / 4 through the module API')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
     args = ap.parse_args()
@@ -456,6 +598,12 @@ def main():
     from sc2bench_amd import hip
     if args.mode == 'train':
         return train_bench(args, dev, rank, world, distributed)
+    if args.workload != 'es224':
+        workload_bench(args, dev, rank, world, distributed)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     model = build_model(dev)
     x = synthetic_batch(args.bs, dev, seed=rank)   # a different shard per rank, resident in HBM
     torch.cuda.synchronize(dev)

@@ -1126,7 +1126,10 @@ def rans_max_bytes(n_sym):
 # ---- host range coder (csrc/rans_host.cpp): a few streams are coded faster by CPU cores than by GPU lanes ----------------
 def host_coder_max_streams():
     """Stream count up to which compress() / decompress() use the library's HOST coder (0 = always the device coder)."""
-    return int(os.environ.get('SC2_HOST_CODER_MAX_STREAMS', '8'))
+    # measured (profiles/r03c_*): the device coder takes ~120 ns per symbol of ONE stream however few streams there are (one
+    # lane each), a host thread ~15-25 ns; with up to 32 threads the host wins far beyond a handful of streams (16 streams
+    # of 393 k symbols, the 513 x 513 batch: 85 ms on the device coder)
+    return int(os.environ.get('SC2_HOST_CODER_MAX_STREAMS', '64'))
 
 
 class HostRansTables(object):
@@ -1150,7 +1153,7 @@ class HostRansTables(object):
 
 
 def _host_threads(n_streams):
-    return max(1, min(int(n_streams), len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16))
+    return max(1, min(int(n_streams), len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 32))
 
 
 def rans_encode_host(tables, symbols, indexes=None, index_div=0, out_stride=None):
