@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 33
+#define SC2_ABI_VERSION 34
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -431,6 +431,20 @@ int sc2_rans_decode_dequantize_batch(const uint8_t *in, int64_t in_stride, const
                                      int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets, const float *medians,
                                      int32_t *symbols_out, void *y_hat_bf16_nhwc, int32_t *status, void *workspace,
                                      int64_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Element-wise pieces of the distillation step (stage 1 of the Entropic-Student recipe:          */
+/* nn.MSELoss(reduction='sum') between student and teacher feature maps, yaml:155-200; ReLU       */
+/* gradients of the frozen ResNet tail, yaml:135), bf16 tensors of n elements, n % 8 == 0.         */
+/* ------------------------------------------------------------------------------------------ */
+/* partial : f32 [sc2_mse_partial_len(n)] block sums of (x - y)^2 (f32 accumulation, fixed order); the caller adds them. */
+int sc2_mse_partial_len(long long n);
+int sc2_mse_sum_bf16(const void *x, const void *y, long long n, float *partial, void *stream);
+/* gx = bf16(2 * scale[0] * (x - y)); scale: DEVICE f32 scalar (the upstream gradient of the loss). */
+int sc2_mse_grad_bf16(const void *x, const void *y, long long n, const float *scale, void *gx, void *stream);
+/* gi = (g [+ add]) * (out > 0): gradient through a ReLU whose output was saved; `add` (nullable) = a second gradient that
+ * reaches the same tensor, summed in f32 before the mask. */
+int sc2_relu_bwd_bf16(const void *g, const void *out, const void *add, long long n, void *gi, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* HOST range coder (same bit-exact format; every pointer is HOST memory, no HIP call is made).  */

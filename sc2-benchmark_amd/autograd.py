@@ -184,13 +184,15 @@ def analysis_autograd(m, x):
 
 
 def synthesis_autograd(m, y_hat):
-    """decoder(y_hat) with gradients: f32 NCHW latent -> f32 NCHW features."""
+    """decoder(y_hat) with gradients: f32 NCHW latent -> f32 NCHW features (or a bf16 channels_last view, per output_format)."""
     c0, g1, c2, g3, c4 = m._g_s()
     h = _ToNhwcBf16.apply(y_hat, y_hat.shape[1])
     h = _conv(c0, h)
     h = _gdn(g1, h)
     h = _conv(c2, h)
     h = _gdn(g3, h)
+    if getattr(m, 'output_format', 'f32_nchw') == 'bf16_nhwc':     # a bf16 channels_last view for a bf16 tail / loss
+        return _cl(_conv(c4, h, hip.OUT_BF16_NHWC))
     return _conv(c4, h, hip.OUT_F32_NCHW)
 
 

@@ -20,7 +20,10 @@ from .resnet import Bottleneck, FrozenBatchNorm2d
 def _fold(conv, bn):
     """conv (no bias) followed by an eval-mode norm layer -> (packed bf16 weight, f32 bias)."""
     w = conv.weight.detach().float()
-    if isinstance(bn, (nn.BatchNorm2d, FrozenBatchNorm2d)):
+    if bn is None:      # a bare convolution (the data-gradient convs of frozen.py): identity scale, zero bias
+        scale = torch.ones(w.shape[0], dtype=torch.float32, device=w.device)
+        bias = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device)
+    elif isinstance(bn, (nn.BatchNorm2d, FrozenBatchNorm2d)):
         gamma = bn.weight.detach().float() if bn.weight is not None else torch.ones_like(bn.running_mean)
         beta = bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(bn.running_mean)
         scale = gamma * torch.rsqrt(bn.running_var.detach().float() + bn.eps)
@@ -49,10 +52,23 @@ def _win1_policy(cin, cout, stride):
     return (cin, cout, stride) in ((512, 128, 1), (2048, 512, 1), (512, 2048, 1), (512, 1024, 2))
 
 
+class ConvSpec(object):
+    """What `_Conv` reads of an nn.Conv2d, for convolutions that exist only as a weight tensor."""
+    bias = None
+    groups = 1
+
+    def __init__(self, weight, stride=(1, 1), padding=(0, 0), dilation=(1, 1)):
+        self.weight = weight
+        self.out_channels, self.in_channels = int(weight.shape[0]), int(weight.shape[1])
+        self.kernel_size = (int(weight.shape[2]), int(weight.shape[3]))
+        self.stride, self.padding, self.dilation = tuple(stride), tuple(padding), tuple(dilation)
+
+
 class _Conv(object):
     def __init__(self, conv, bn, tag):
         assert conv.bias is None and conv.groups == 1
         self.w, self.b, self.k_order, w_folded = _fold(conv, bn)
+        self.w_folded = w_folded       # f32 OIHW with the norm layer's scale folded in (frozen.py builds the data gradient from it)
         self.cout = conv.out_channels
         self.k = conv.kernel_size
         self.stride = conv.stride

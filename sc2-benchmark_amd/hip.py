@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch',
+    'sc2_mse_partial_len', 'sc2_mse_sum_bf16', 'sc2_mse_grad_bf16', 'sc2_relu_bwd_bf16',
     'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
 ]
 
@@ -118,6 +119,10 @@ def lib():
     L.sc2_rans_decode_batch.argtypes = [vp, i64, vp, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, i64,
                                         vp]
     L.sc2_rans_decode_dequantize_batch.argtypes = [vp, i64, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.sc2_mse_partial_len.argtypes = [ctypes.c_longlong]
+    L.sc2_mse_sum_bf16.argtypes = [vp, vp, ctypes.c_longlong, vp, vp]
+    L.sc2_mse_grad_bf16.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, vp]
+    L.sc2_relu_bwd_bf16.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
     L.sc2_rans_host_tables_create.argtypes = [vp, i32, i32, vp, vp, ctypes.POINTER(vp)]
     L.sc2_rans_host_tables_destroy.argtypes = [vp]
     L.sc2_rans_host_tables_destroy.restype = None
@@ -1039,6 +1044,48 @@ def gc_dequantize(symbols, means=None, want_f32=True, want_nhwc=False):
 # --------------------------------------------------------------------------------------------- #
 # CDF + rANS
 # --------------------------------------------------------------------------------------------- #
+# --------------------------------------------------------------------------------------------- #
+# element-wise pieces of the distillation step: csrc/loss.hip
+# --------------------------------------------------------------------------------------------- #
+def _same_dense_bf16(*ts):
+    """True if the tensors are bf16 device tensors of one shape AND one dense memory layout (element i of each is the same
+    logical element), so that an element-wise kernel may walk their storage linearly."""
+    a = ts[0]
+    if not all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.bfloat16 and t.shape == a.shape and
+               t.stride() == a.stride() for t in ts):
+        return False
+    return (a.is_contiguous() or (a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last))) and a.numel() % 8 == 0
+
+
+def mse_sum(x, y):
+    """sum((x - y)^2) as an f32 device scalar; x, y: bf16, same shape and dense layout (_same_dense_bf16)."""
+    assert _same_dense_bf16(x, y)
+    n = x.numel()
+    partial = torch.empty((int(lib().sc2_mse_partial_len(n)),), dtype=torch.float32, device=x.device)
+    with _timed('mse_sum'):
+        _check(lib().sc2_mse_sum_bf16(_ptr(x), _ptr(y), n, _ptr(partial), _stream()), 'mse_sum')
+    return partial.double().sum().float()
+
+
+def mse_grad(x, y, scale):
+    """bf16(2 * scale * (x - y)) laid out like x; scale: f32 device scalar tensor."""
+    assert _same_dense_bf16(x, y) and scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1
+    gx = torch.empty_like(x)
+    with _timed('mse_grad'):
+        _check(lib().sc2_mse_grad_bf16(_ptr(x), _ptr(y), x.numel(), _ptr(scale), _ptr(gx), _stream()), 'mse_grad')
+    return gx
+
+
+def relu_bwd(g, out, add=None):
+    """(g [+ add]) * (out > 0), bf16, laid out like g (all operands one shape and dense layout)."""
+    ops = (g, out) if add is None else (g, out, add)
+    assert _same_dense_bf16(*ops)
+    gi = torch.empty_like(g)
+    with _timed('relu_bwd'):
+        _check(lib().sc2_relu_bwd_bf16(_ptr(g), _ptr(out), _ptr(add), g.numel(), _ptr(gi), _stream()), 'relu_bwd')
+    return gi
+
+
 # --------------------------------------------------------------------------------------------- #
 # reference-precision (f32 operand) convolution / GDN1: csrc/conv_f32.hip
 # --------------------------------------------------------------------------------------------- #

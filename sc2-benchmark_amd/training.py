@@ -48,6 +48,8 @@ class ForwardHookManager(object):
         self.handles = []
         paths_in = (hook_config or {}).get('input') or []
         paths_out = (hook_config or {}).get('output') or []
+        self._paths_out = set(paths_out) - set(paths_in)     # modules whose OUTPUT alone is wanted
+        self.all_paths = set(paths_out) | set(paths_in)
         for path in sorted(set(paths_in) | set(paths_out)):
             module = get_module(model, path)
             self.handles.append(module.register_forward_hook(self._make(path, path in paths_in, path in paths_out)))
@@ -60,6 +62,10 @@ class ForwardHookManager(object):
             if want_out:
                 entry['output'] = output
         return hook
+
+    def io_dict_paths(self):
+        """paths a caller may fill in place of the module hook (output-only hooks)."""
+        return self._paths_out
 
     def pop(self):
         out, self.io_dict = self.io_dict, dict()
@@ -109,6 +115,11 @@ class SimpleLossWrapper(nn.Module):
     def forward(self, student_io_dict, teacher_io_dict, targets=None, *args, **kwargs):
         x = self._extract(self.input_cfg, student_io_dict, teacher_io_dict)
         y = self._extract(self.target_cfg, student_io_dict, teacher_io_dict)
+        if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.bfloat16:
+            from .frozen import mse_fast_path      # two bf16 feature maps: one HIP pass instead of two casts + loss + grad
+            fast = mse_fast_path(self.low_level_loss, x, y)
+            if fast is not None:
+                return fast
         return self.low_level_loss(x.float(), y.float())
 
 
@@ -192,11 +203,57 @@ class DistillationStage(object):
         self.student_full.train()
         for path in s_cfg.get('frozen_modules') or list():   # frozen BatchNorm layers keep their statistics
             get_module(student, path).eval()
+        self._frozen_stacks = dict()     # id(module) -> (parameter versions, frozen.FrozenStack)
+        self.use_hip_frozen = head_dtype == torch.bfloat16 and device.type == 'cuda'
+        if self.use_hip_frozen and hasattr(getattr(student, 'bottleneck_layer', None), 'output_format'):
+            # the decoder hands bf16 NHWC features to the frozen tail (and to the layer-1 feature-matching loss) directly
+            student.bottleneck_layer.output_format = 'bf16_nhwc'
+
+    def _frozen_stack(self, name, module):
+        """frozen.FrozenStack of a frozen, eval-mode stack of Bottleneck blocks (None if `module` is not one); rebuilt when a
+        parameter or buffer of it changed."""
+        from .frozen import FrozenStack
+        if not self.use_hip_frozen or not FrozenStack.supported(module):
+            return None
+        key = tuple(t._version for t in list(module.parameters()) + list(module.buffers()))
+        cached = self._frozen_stacks.get(id(module))
+        if cached is None or cached[0] != key:
+            cached = (key, FrozenStack(name, module))
+            self._frozen_stacks[id(module)] = cached
+        return cached[1]
+
+    def _run_sequential(self, seq, hooks, x, with_grad):
+        """`seq(x)` with every frozen Bottleneck stack on the HIP kernels (forward, and input gradient when `with_grad`); the
+        forward-hook dict is filled for those stacks as their module hooks would have."""
+        from .frozen import FrozenStackFn
+        wanted = hooks.io_dict_paths()
+        for name, module in seq.named_children():
+            path = name.replace('__', '.')
+            # a hook on the stack's INPUT, or on a module inside it, needs the torch modules to run
+            hooked_inside = any(q == path and q not in wanted or q.startswith(path + '.') for q in hooks.all_paths)
+            stack = self._frozen_stack(name, module) if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and
+                                                         not hooked_inside) else None
+            if stack is None:
+                x = module(x)
+                if self.head_dtype is not None and x.dtype != self.head_dtype and isinstance(x, torch.Tensor) and x.dim() == 4:
+                    x = x.to(self.head_dtype).contiguous(memory_format=torch.channels_last)
+                continue
+            if with_grad and x.requires_grad:
+                x = FrozenStackFn.apply(x, stack)
+            else:
+                with torch.no_grad():
+                    x = stack.forward(x.permute(0, 2, 3, 1).contiguous())[0].permute(0, 3, 1, 2)
+            if path in wanted:
+                hooks.io_dict.setdefault(path, dict())['output'] = x
+        return x
 
     def forward_process(self, batch, targets=None):
         tb = batch.to(self.head_dtype).contiguous(memory_format=torch.channels_last) if self.head_dtype else batch
         with torch.no_grad():
-            t_out = self.teacher(tb)
+            if self.use_hip_frozen and isinstance(self.teacher, nn.Sequential):
+                t_out = self._run_sequential(self.teacher, self.t_hooks, tb, with_grad=False)
+            else:
+                t_out = self.teacher(tb)
         t_io = self.t_hooks.pop()
         t_io['.'] = {'output': t_out}
         s_out = self._student_forward(batch)
@@ -207,6 +264,8 @@ class DistillationStage(object):
     def _student_forward(self, batch):
         if self.head_dtype is None or not isinstance(self.student, nn.Sequential):
             return self.student(batch)
+        if self.use_hip_frozen:
+            return self._run_sequential(self.student, self.s_hooks, batch, with_grad=True)
         x = batch
         for i, module in enumerate(self.student):   # the bottleneck speaks f32 NCHW; the frozen tail runs in head_dtype
             x = module(x)
