@@ -293,6 +293,17 @@ STAGE1 = {   # train.stage1 of configs/ilsvrc2012/supervised_compression/entropi
 }
 
 
+STAGE2 = {   # train.stage2 of the same YAML (:231-295): KD loss on the logits, decoder + layer2-4 + fc train, encoder + prior frozen
+    'teacher': {'sequential': [], 'frozen_modules': [], 'forward_hook': {'input': [], 'output': []}},
+    'student': {'sequential': [], 'frozen_modules': ['bottleneck_layer.encoder', 'bottleneck_layer.entropy_bottleneck'],
+                'forward_hook': {'input': [], 'output': []}},
+    'optimizer': {'key': 'SGD', 'kwargs': {'lr': 0.001, 'momentum': 0.9, 'weight_decay': 0.0005}},
+    'criterion': {'key': 'WeightedSumLoss', 'kwargs': {'sub_terms': {'kd': {'criterion': {'key': 'KDLoss', 'kwargs': {
+        'student_module_path': '.', 'student_module_io': 'output', 'teacher_module_path': '.', 'teacher_module_io': 'output',
+        'temperature': 1.0, 'alpha': 0.5, 'reduction': 'batchmean'}}, 'weight': 1.0}}}},
+}
+
+
 def train_bench(args, dev, rank, world, distributed):
     """Stage-1 Entropic-Student training step: frozen teacher forward, student forward (HIP bottleneck + frozen tail),
     MSE-sum + 0.08 * bits, aux loss, backward on the HIP kernels, ONE flat-bucket gradient all-reduce (RCCL), Adam."""
@@ -305,12 +316,17 @@ def train_bench(args, dev, rank, world, distributed):
     teacher = resnet50().to(dev)
     if distributed:
         dp.broadcast_parameters(student)
-    stage = T.DistillationStage(teacher, student, STAGE1, dev, head_dtype=torch.bfloat16)
+    stage2 = args.stage == 2
+    if stage2:      # the reference updates the bottleneck when stage 2 starts (epoch_to_update): round + detach in the student
+        shape_workload(student)
+        student.update()
+    stage = T.DistillationStage(teacher, student, STAGE2 if stage2 else STAGE1, dev, head_dtype=torch.bfloat16)
     x = synthetic_batch(args.bs, dev, seed=rank)
+    targets = torch.randint(0, 1000, (args.bs,), generator=torch.Generator().manual_seed(rank)).to(dev) if stage2 else None
 
     def step():
-        loss = stage.forward_process(x)
-        stage.post_forward_process(loss)
+        loss = stage.forward_process(x, targets)
+        stage.post_forward_process(loss, bottleneck_updated=stage2)
         return loss
 
     for _ in range(args.warmup):
@@ -332,11 +348,13 @@ def train_bench(args, dev, rank, world, distributed):
     assert torch.isfinite(loss)
     if rank == 0:
         print(json.dumps({
-            'metric': 'images/s, Entropic-Student ResNet-50 stage-1 training step, 224^2', 'value': args.bs * args.steps * world / elapsed,
+            'metric': 'images/s, Entropic-Student ResNet-50 stage-{} training step, 224^2'.format(args.stage), 'value': args.bs * args.steps * world / elapsed,
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'stage 1 of the Entropic-Student recipe (bottleneck trains, layer2-4 frozen, frozen teacher)',
+            'config': {'workload': 'stage 2 of the Entropic-Student recipe (KD loss; decoder + layer2-4 + fc train with batch-statistics '
+                                   'BatchNorm on torch / MIOpen ops, encoder + prior frozen, frozen teacher on the HIP stacks)' if stage2 else
+                                   'stage 1 of the Entropic-Student recipe (bottleneck trains, layer2-4 frozen, frozen teacher)',
                        'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'gradient_all_reduce_bytes': stage.reducer.nbytes(),
                        'sharding': 'images; one flat-bucket all-reduce per step'},
             'final_loss': loss.item()}))
@@ -567,6 +585,7 @@ def main():
     ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
     ap.add_argument('--workload', choices=['es224', 'fp_input', 'seg513', 'det800x1216'], default='es224',
                     help='es224 = the headline config (default); the others are BASELINE configs 3 / 5 / 4 through the module API')
+    ap.add_argument('--stage', type=int, choices=[1, 2], default=1, help='--mode train: which stage of the recipe')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
     args = ap.parse_args()

@@ -253,7 +253,10 @@ class SplittableResNet(UpdatableBackbone):
                 self.analyze(x)
             x = self.bottleneck_layer.decode(**x)
         else:
-            x = self.bottleneck_layer(x)
+            # the bottleneck chooses its own arithmetic (bf16 MFMA operands, f32 accumulation, f32 entropy model): a caller's
+            # autocast region (a training tail in reduced precision) must not re-type the torch ops between its kernels
+            with torch.autocast(device_type=x.device.type if x.device.type in ('cuda', 'cpu') else 'cuda', enabled=False):
+                x = self.bottleneck_layer(x)
         return self.head(x)
 
     def forward_device(self, x):

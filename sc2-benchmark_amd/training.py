@@ -12,8 +12,20 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from . import hip
 from .dataparallel import FlatGradAllReducer
 from .loss import MIDDLE_LEVEL_LOSS_DICT
+
+
+def hip_epi_bias_relu():
+    return hip.EPI_BIAS_RELU
+
+
+def hip_nhwc_input(x, cin_pad):
+    """NCHW batch (any float dtype / layout) -> bf16 NHWC with the channels zero-padded to `cin_pad`."""
+    if x.shape[1] == cin_pad and x.dtype == torch.bfloat16:
+        return x.permute(0, 2, 3, 1).contiguous()
+    return hip.nchw_f32_to_nhwc_bf16(x.float().contiguous(), cin_pad)
 
 
 def get_module(root, path):
@@ -176,15 +188,23 @@ class DistillationStage(object):
         for p in teacher.parameters():
             p.requires_grad_(False)
         teacher.eval()
-        if head_dtype is not None:     # bf16 channels_last task-head modules (teacher and the frozen student tail)
-            teacher.to(dtype=head_dtype, memory_format=torch.channels_last)
-            for name in ('layer2', 'layer3', 'layer4', 'avgpool', 'fc'):
-                m = getattr(student, name, None)
-                if m is not None:
-                    m.to(dtype=head_dtype, memory_format=torch.channels_last)
         self.head_dtype = head_dtype
         self.teacher = redesign_model(teacher, t_cfg.get('sequential'))
         self.student = redesign_model(student, s_cfg.get('sequential'))
+        self.autocast_student = False
+        if head_dtype is not None:     # bf16 channels_last task-head modules (teacher and the frozen student tail)
+            teacher.to(dtype=head_dtype, memory_format=torch.channels_last)
+            stepped = {id(p) for p in self.student.parameters() if p.requires_grad}     # what this stage's optimizer updates
+            for name in ('layer2', 'layer3', 'layer4', 'avgpool', 'fc'):
+                m = getattr(student, name, None)
+                if m is None:
+                    continue
+                if any(id(p) in stepped for p in m.parameters()):
+                    # a tail that TRAINS (stage 2) keeps its f32 parameters (optimizer state, weight decay, BatchNorm statistics)
+                    # and computes in head_dtype under autocast; only modules this stage does not update are converted
+                    self.autocast_student = head_dtype in (torch.bfloat16, torch.float16) and device.type == 'cuda'
+                else:
+                    m.to(dtype=head_dtype, memory_format=torch.channels_last)
         self.t_hooks = ForwardHookManager(self.teacher, t_cfg.get('forward_hook'))
         self.s_hooks = ForwardHookManager(self.student, s_cfg.get('forward_hook'))
         self.criterion = build_criterion(stage_config['criterion'])
@@ -222,13 +242,70 @@ class DistillationStage(object):
             self._frozen_stacks[id(module)] = cached
         return cached[1]
 
+    def _teacher_sequence(self):
+        """The frozen teacher as a sequence of children whose Bottleneck stacks / stem `_run_sequential` can take: the
+        redesigned nn.Sequential itself, or -- for a whole torchvision-layout ResNet (stage 2: `sequential: []`) -- its
+        children in forward order with the flatten its forward() does between avgpool and fc."""
+        from .resnet import ResNet
+        if isinstance(self.teacher, nn.Sequential):
+            return self.teacher
+        if type(self.teacher) is ResNet and not self.t_hooks.all_paths:
+            seq = self.__dict__.get('_teacher_seq')
+            if seq is None:
+                kids = OrderedDict()
+                for name, module in self.teacher.named_children():
+                    if name == 'fc':
+                        kids['flatten'] = nn.Flatten(1)
+                    kids[name] = module
+                seq = self.__dict__['_teacher_seq'] = nn.Sequential(kids)
+            return seq
+        return None
+
+    def _frozen_stem(self, triple, hooks):
+        """head._Conv of a (Conv2d without bias, frozen eval-mode BatchNorm, ReLU) run of children that nobody hooks and
+        nothing trains, else None."""
+        from .head import ConvSpec, _Conv
+        from .resnet import FrozenBatchNorm2d
+        if not self.use_hip_frozen or len(triple) < 3:
+            return None
+        (n0, conv), (n1, bn), (n2, act) = triple
+        if not (isinstance(conv, nn.Conv2d) and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1) and
+                isinstance(bn, (nn.BatchNorm2d, FrozenBatchNorm2d)) and not bn.training and type(act) is nn.ReLU):
+            return None
+        if any(p.requires_grad for p in list(conv.parameters()) + list(bn.parameters())):
+            return None
+        if any(q.split('.')[0] in (n0, n1, n2) for q in hooks.all_paths):
+            return None
+        key = tuple(t._version for t in list(conv.parameters()) + list(bn.parameters()) + list(bn.buffers()))
+        cached = self._frozen_stacks.get(id(conv))
+        if cached is None or cached[0] != key:
+            w = conv.weight.detach().float()
+            cin_pad = (w.shape[1] + 7) // 8 * 8
+            if cin_pad != w.shape[1]:      # 3 input channels -> 8 (zeros): the kernels read 16-byte channel runs
+                w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - w.shape[1], w.shape[2], w.shape[3])], 1)
+            cached = (key, _Conv(ConvSpec(w, conv.stride, conv.padding), bn, 'stem'))
+            self._frozen_stacks[id(conv)] = cached
+        return cached[1]
+
     def _run_sequential(self, seq, hooks, x, with_grad):
         """`seq(x)` with every frozen Bottleneck stack on the HIP kernels (forward, and input gradient when `with_grad`); the
         forward-hook dict is filled for those stacks as their module hooks would have."""
         from .frozen import FrozenStackFn
         wanted = hooks.io_dict_paths()
-        for name, module in seq.named_children():
+        children = list(seq.named_children())
+        skip = 0
+        for ci, (name, module) in enumerate(children):
+            if skip:
+                skip -= 1
+                continue
             path = name.replace('__', '.')
+            stem = self._frozen_stem(children[ci:ci + 3], hooks) if (x.is_cuda and x.dim() == 4) else None
+            if stem is not None:      # conv + frozen norm + ReLU at the head of a frozen network (the teacher's stem): one launch
+                with torch.no_grad():
+                    x_nhwc = hip_nhwc_input(x, stem.w_folded.shape[1])
+                    x = stem(x_nhwc, hip_epi_bias_relu()).permute(0, 3, 1, 2)
+                skip = 2
+                continue
             # a hook on the stack's INPUT, or on a module inside it, needs the torch modules to run
             hooked_inside = any(q == path and q not in wanted or q.startswith(path + '.') for q in hooks.all_paths)
             stack = self._frozen_stack(name, module) if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and
@@ -250,8 +327,9 @@ class DistillationStage(object):
     def forward_process(self, batch, targets=None):
         tb = batch.to(self.head_dtype).contiguous(memory_format=torch.channels_last) if self.head_dtype else batch
         with torch.no_grad():
-            if self.use_hip_frozen and isinstance(self.teacher, nn.Sequential):
-                t_out = self._run_sequential(self.teacher, self.t_hooks, tb, with_grad=False)
+            t_seq = self._teacher_sequence() if self.use_hip_frozen else None
+            if t_seq is not None:
+                t_out = self._run_sequential(t_seq, self.t_hooks, tb, with_grad=False)
             else:
                 t_out = self.teacher(tb)
         t_io = self.t_hooks.pop()
@@ -262,6 +340,9 @@ class DistillationStage(object):
         return self.criterion(s_io, t_io, targets)
 
     def _student_forward(self, batch):
+        if self.autocast_student:
+            with torch.autocast(device_type='cuda', dtype=self.head_dtype):
+                return self.student(batch)
         if self.head_dtype is None or not isinstance(self.student, nn.Sequential):
             return self.student(batch)
         if self.use_hip_frozen:

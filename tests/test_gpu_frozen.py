@@ -146,8 +146,38 @@ def test_stage1_step_frozen_stacks_on_hip_vs_torch_modules(S, dev):
         results.append((loss.item(), grads, len(stage._frozen_stacks)))
         stage.clean_modules()
     (loss_h, g_h, n_stacks), (loss_t, g_t, n_none) = results
-    assert n_stacks == 7 and n_none == 0          # teacher layer1-4 + student layer2-4 ran as FrozenStacks
+    assert n_stacks == 8 and n_none == 0          # teacher stem + layer1-4 and student layer2-4 ran on the HIP kernels
     assert abs(loss_h - loss_t) <= 2e-2 * abs(loss_t), (loss_h, loss_t)
     assert set(g_h) == set(g_t)
     bad = {n: _rel(g_h[n], g_t[n]) for n in g_t if g_t[n].norm() > 1e-6 and _rel(g_h[n], g_t[n]) > 0.35}
     assert not bad, bad
+
+
+def test_stage2_steps_kd_loss(S, dev):
+    """Stage 2 of the recipe (yaml:231-295) as the reference drives it: bottleneck updated, encoder + prior frozen, decoder +
+    layer2-4 + fc train under the KD loss (labels + teacher logits); the whole frozen teacher (stem, layer1-4 as HIP stacks,
+    pool, fc) runs without gradients.  A few steps on a fixed batch lower the loss; the frozen parts get no gradient."""
+    import bench
+    from sc2bench_amd import training as T
+    from sc2bench_amd.resnet import resnet50
+    torch.manual_seed(0)
+    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
+    student = S.splittable_resnet(cfg, skips_avgpool=False, skips_fc=False).to(dev)
+    teacher = resnet50().to(dev)
+    bench.shape_workload(student)
+    student.update()
+    stage = T.DistillationStage(teacher, student, bench.STAGE2, dev, head_dtype=torch.bfloat16)
+    trainable = sum(p.numel() for p in student.parameters() if p.requires_grad)
+    assert stage.reducer.nbytes() == 4 * trainable and 100e6 < stage.reducer.nbytes() < 112e6      # SURVEY C1: ~106 MB
+    x = torch.rand(8, 3, 64, 64, generator=torch.Generator().manual_seed(2)).to(dev)
+    y = torch.randint(0, 1000, (8,), generator=torch.Generator().manual_seed(3)).to(dev)
+    losses = []
+    for _ in range(5):
+        loss = stage.forward_process(x, y)
+        assert torch.isfinite(loss)
+        losses.append(loss.item())
+        stage.post_forward_process(loss, bottleneck_updated=True)
+    assert losses[-1] < losses[0], losses
+    assert all(p.grad is None or float(p.grad.abs().sum()) == 0.0 for p in student.bottleneck_layer.encoder.parameters())
+    assert len(stage._frozen_stacks) == 5          # the teacher's stem + layer1-4
+    stage.clean_modules()
