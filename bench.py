@@ -41,6 +41,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 BOTTLENECK_GFLOP_PER_IMG = 8.3418
+PEAK_F32_MATRIX_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 (f32 operands): 1/16 of the bf16 rate (MI355X_MICROARCH.md, Matrix cores)
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy achieves
 # per image, 224x224: algorithmic MFLOP (2 * MACs), bf16 activation MB read, MB written.  Weights
 # (< 2.6 MB in total, L2-resident) are not counted.
@@ -56,7 +57,7 @@ OPS = {'enc.conv0': (180.6, 0.401, 2.408), 'enc.gdn1': (231.2, 2.408, 2.408), 'e
 def launch_work(tag):
     """(MFLOP, MB) per image of one tagged launch; 'a+b' = ops a and b fused in one launch (reads a's input, writes
     b's output); an unfused GDN launch reads its input twice (GEMM operand + element-wise operand)."""
-    parts = tag.split('+')
+    parts = [q[:-4] if q.endswith('.f32') else q for q in tag.split('+')]   # '.f32': the reference-precision encoder's launches
     if any(q not in OPS for q in parts):
         return None
     mflop = sum(OPS[q][0] for q in parts)
@@ -91,7 +92,7 @@ def shape_workload(model):
     return model
 
 
-def build_model(dev, seed=0):
+def build_model(dev, seed=0, encoder_precision='bf16'):
     import sc2bench_amd as S
     torch.manual_seed(seed)
     cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
@@ -100,6 +101,7 @@ def build_model(dev, seed=0):
     model.eval().to(dev)
     model.update()
     model.set_compute_dtype('bf16')
+    model.set_encoder_precision(encoder_precision)
     if dev.type == 'cuda':
         torch.cuda.synchronize(dev)   # the casts above ran on the null stream; the pipeline streams are non-blocking
     return model
@@ -216,6 +218,7 @@ def precision_check(model, x_dev, dev, n=64):
     symbol mismatch rate, bpp of the streams actually coded from each, and how many images code to the identical bytes.
     Runs after the timed region (the oracle is the checker here, never the thing measured)."""
     ref = oracle_model(model.state_dict())
+    configured = model.bottleneck_layer.encoder_precision
     n = min(n, x_dev.shape[0])
     x = x_dev[:n].float().cpu()
     eb, reb = model.bottleneck_layer.entropy_bottleneck, ref.bottleneck_layer.entropy_bottleneck
@@ -248,7 +251,7 @@ def precision_check(model, x_dev, dev, n=64):
                                'images_with_identical_symbols': int((~diff.any(dim=1)).sum().item()),
                                'bpp': 8.0 * float(nb.sum().item()) / (n * pix),
                                'encoder_stage_ms_per_batch': e0.elapsed_time(e1) / 3.0, 'batch': int(x_dev.shape[0])}}
-    model.set_encoder_precision('bf16')
+    model.set_encoder_precision(configured)
     ref_streams = oracle_streams(ref, ref_sym, hw[0] * hw[1])
     ref_len = torch.tensor([len(q) for q in ref_streams])
     out['reference_f32_cpu'] = {'bpp': 8.0 * float(ref_len.sum().item()) / (n * pix)}
@@ -264,7 +267,7 @@ def precision_check(model, x_dev, dev, n=64):
             model.set_encoder_precision('f32')
             sym, hw = model.stage_front(x_dev[:n])
             buf, off, nbs, _ = eb.encode_symbols_device(sym, hw[0] * hw[1])
-            model.set_encoder_precision('bf16')
+            model.set_encoder_precision(configured)
             idx = torch.tensor(same, device=dev)
             streams = eb.unpack_strings(buf[idx], off[idx], nbs[idx])
         out['f32_encoder']['bitstreams_identical_to_reference_on_checked_images'] = \
@@ -585,6 +588,9 @@ def main():
     ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
     ap.add_argument('--workload', choices=['es224', 'fp_input', 'seg513', 'det800x1216'], default='es224',
                     help='es224 = the headline config (default); the others are BASELINE configs 3 / 5 / 4 through the module API')
+    ap.add_argument('--encoder-precision', choices=['bf16', 'f32'], default='bf16',
+                    help="f32: the analysis transform with f32 operands on the f32 matrix cores -- symbols, byte streams and bpp are the "
+                         "f32 reference path's (precision_check in the line shows it); bf16 (default): the fast encoder")
     ap.add_argument('--stage', type=int, choices=[1, 2], default=1, help='--mode train: which stage of the recipe')
     ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
                     help="'train' = Entropic-Student stage-1 step (secondary figure; the headline metric is 'infer')")
@@ -623,7 +629,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
-    model = build_model(dev)
+    model = build_model(dev, encoder_precision=args.encoder_precision)
     x = synthetic_batch(args.bs, dev, seed=rank)   # a different shard per rank, resident in HBM
     torch.cuda.synchronize(dev)
     # Software pipeline over HIP streams: front(i) [encoder + quantise] and back(i - lag) [dequantise + decoder +
@@ -908,12 +914,15 @@ def main():
         def roof(k, ms):
             """bound = whichever roof the launch's algorithmic intensity puts it under (ridge = 312.5 FLOP/B)"""
             mflop, mbyte = launch_work(k)
+            f32 = k.endswith('.f32')     # the reference-precision encoder: f32 activations (twice the bytes), f32 matrix peak
+            mbyte = mbyte * (2.0 if f32 else 1.0)
+            peak_tf = PEAK_F32_MATRIX_TFLOPS if f32 else PEAK_BF16_TFLOPS
             tf = mflop * 1e6 * args.bs / (ms * 1e-3) / 1e12
             gbs = mbyte * 1e6 * args.bs / (ms * 1e-3) / 1e9
-            hbm = mflop / mbyte < PEAK_BF16_TFLOPS * 1e3 / PEAK_HBM_GBS
+            hbm = mflop / mbyte < peak_tf * 1e3 / PEAK_HBM_GBS
             return {'bound': 'hbm' if hbm else 'mfma', 'achieved': gbs if hbm else tf,
-                    'peak': PEAK_HBM_GBS if hbm else PEAK_BF16_TFLOPS, 'unit': 'GB/s' if hbm else 'TFLOP/s',
-                    'frac': (gbs / PEAK_HBM_GBS) if hbm else (tf / PEAK_BF16_TFLOPS), 'tflops': tf, 'gbs': gbs,
+                    'peak': PEAK_HBM_GBS if hbm else peak_tf, 'unit': 'GB/s' if hbm else 'TFLOP/s',
+                    'frac': (gbs / PEAK_HBM_GBS) if hbm else (tf / peak_tf), 'tflops': tf, 'gbs': gbs,
                     'kernel_ms': ms}
         per_kernel = {k: roof(k, v[1]) for k, v in conv.items()}
         floor_ms = sum(max(launch_work(k)[0] * 1e6 * args.bs / (PEAK_BF16_TFLOPS * 1e12),
@@ -954,6 +963,9 @@ def main():
                        'images': 'torch.rand, per-image contrast 0.25-1, ImageNet normalisation',
                        'streams': 'device-resident in the timed region (u8 rows in HBM with offset / nbytes vectors, no Python '
                                   'bytes objects); the host-bytes encode()/decode() API of the reference is timed in bs1_eval',
+                       'encoder_precision': args.encoder_precision + (' (f32 operands on v_mfma_f32_16x16x4_f32: bitstreams of the f32 '
+                                                                      'reference path; decoder + head bf16)' if args.encoder_precision == 'f32' else
+                                                                      ' MFMA operands, f32 accumulation'),
                        'sharding': 'images, no collective'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
             'bytes_per_image_min_mean_max': [nb_f.min().item(), bytes_per_img, nb_f.max().item()],
@@ -983,8 +995,8 @@ def main():
         failed = None
         if world == 1 and not args.no_cpu_baseline:
             out['precision_check'] = precision_check(model, x, dev)
-            out['symbol_mismatch_rate'] = out['precision_check']['bf16_encoder']['symbol_mismatch_rate']
-            out['delta_bpp'] = out['precision_check']['bf16_encoder']['delta_bpp']
+            out['symbol_mismatch_rate'] = out['precision_check'][args.encoder_precision + '_encoder']['symbol_mismatch_rate']
+            out['delta_bpp'] = out['precision_check'][args.encoder_precision + '_encoder']['delta_bpp']
         if world == 1 and not args.no_bs1:
             out['bs1_eval'] = bs1_eval(model, x, dev)
         if world == 1 and not args.no_cpu_baseline:
