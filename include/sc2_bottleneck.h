@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 34
+#define SC2_ABI_VERSION 35
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -148,6 +148,19 @@ int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d);
 int sc2_conv_patch_supported(const sc2_conv_desc *d);
 int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
                    const void *ep_x, const float *ep_beta, void *stream);
+
+/* Two consecutive 1x1 layers of the ResNet tail across a block boundary in ONE launch (torchvision Bottleneck blocks b and
+ * b + 1 of layer2, eval mode, BatchNorm folded; sc2bench/models/backbone.py:235-254 runs them one after the other):
+ *     h = relu(W3 o + b3 + identity)      conv3 + bn3 + residual + ReLU of block b        (K1 -> C)
+ *     u = relu(W1 h + b1)                 conv1 + bn1 + ReLU of block b + 1               (C -> N2)
+ * h is written once (it is the next block's identity) and feeds the second GEMM from LDS instead of being read again.
+ *   o : bf16 [M][K1];  identity, h : bf16 [M][C];  u : bf16 [M][N2];  w3_frag : bf16 fragment-major [C/16][K1/32][64][8];
+ *   w1_frag : bf16 fragment-major [N2/16][C/32][64][8] (hip.pack_weight_fragments);  b3 : f32 [C];  b1 : f32 [N2].
+ * Supported: K1 = 128, C = 512, N2 = 128 (layer2 of ResNet-50).  Bit-identical to sc2_conv1x1_stream_fwd (residual, relu)
+ * followed by the 1x1 kernel of the next block. */
+int sc2_conv1x1_pair_supported(int K1, int C, int N2);
+int sc2_conv1x1_pair_fwd(const void *o, const void *w3_frag, const float *b3, const void *identity, void *h,
+                         const void *w1_frag, const float *b1, void *u, long long M, int K1, int C, int N2, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Reference-precision analysis transform: the same convolution / GDN1 with f32 OPERANDS on the   */

@@ -177,6 +177,18 @@ class HipHead(object):
                     b16[:fc.out_features] = fc.bias.detach().float()
                 self.fc_frag = (hip.pack_weight_fragments(w16), b16.contiguous())
 
+    @staticmethod
+    def _pair_ok(c3, c1n):
+        return (c3.k == (1, 1) and c1n.k == (1, 1) and c3.stride == (1, 1) and c1n.stride == (1, 1) and c3.stream and
+                c3.w2d is not None and c1n.w2d is not None and c3.w2d.shape[0] == c1n.w2d.shape[1] and
+                hip.conv1x1_pair_supported(c3.w2d.shape[1], c3.cout, c1n.cout))
+
+    @staticmethod
+    def _pair_w1(c1n):
+        if getattr(c1n, 'w_frag_pair', None) is None:
+            c1n.w_frag_pair = hip.pack_weight_fragments(c1n.w_folded.reshape(c1n.w_folded.shape[0], c1n.w_folded.shape[1]))
+        return c1n.w_frag_pair
+
     def tail_spec(self):
         """(W1 [128, 256], bias1, Wds [512, 256], bias_ds) of the first block when it is layer2.0 of a ResNet-50 tail (conv1 1x1
         256 -> 128 stride 1, downsample 1x1 256 -> 512 stride 2) -- the two layers `sc2_conv2x2_win_tail_fwd` can take along
@@ -192,16 +204,23 @@ class HipHead(object):
         """x_nhwc: bf16 [N,H,W,C] -> logits f32 [N,classes] (or pooled / feature map if the model skips them).
         pre = (conv1 output, downsample output) of the first block when the decoder's last launch produced them."""
         h = x_nhwc
+        o_next = None      # conv1 output of the coming block, when the previous block's last launch produced it
         for bi, (c1, c2, c3, ds) in enumerate(self.blocks):
             if bi == 0 and pre is not None:
                 o, identity = pre
-                o = c2(o, hip.EPI_BIAS_RELU)
-                h = c3(o, hip.EPI_BIAS_ADD_RELU, ep_x=identity)
-                continue
-            identity = h if ds is None else ds(h, hip.EPI_BIAS)
-            o = c1(h, hip.EPI_BIAS_RELU)
+            else:
+                identity = h if ds is None else ds(h, hip.EPI_BIAS)
+                o = o_next if o_next is not None else c1(h, hip.EPI_BIAS_RELU)
+            o_next = None
             o = c2(o, hip.EPI_BIAS_RELU)
-            h = c3(o, hip.EPI_BIAS_ADD_RELU, ep_x=identity)
+            nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+            if nxt is not None and nxt[3] is None and self._pair_ok(c3, nxt[0]) and o.numel() // o.shape[-1] * c3.cout * 2 < 0x7FF00000:
+                # conv3 + residual + ReLU of this block and conv1 + ReLU of the next in one launch (conv1x1_pair.hip): the
+                # block output is written once and feeds the second GEMM from LDS
+                h, o_next = hip.conv1x1_pair_fwd(o, c3.w_frag, c3.b, identity.contiguous(), self._pair_w1(nxt[0]), nxt[0].b,
+                                                 tag=c3.tag + '+' + nxt[0].tag)
+            else:
+                h = c3(o, hip.EPI_BIAS_ADD_RELU, ep_x=identity)
         if not with_pool:
             return h.permute(0, 3, 1, 2)
         if self.fc is None:                                       # [N, C] (AdaptiveAvgPool2d((1,1)) + flatten)

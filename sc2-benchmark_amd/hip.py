@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_fc_fwd',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
-    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd',
+    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv1x1_pair_supported', 'sc2_conv1x1_pair_fwd',
     'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
@@ -95,6 +95,8 @@ def lib():
     L.sc2_conv2x2_win_tail_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.sc2_conv1x1_pair_supported.argtypes = [i32, i32, i32]
+    L.sc2_conv1x1_pair_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_stream_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
@@ -765,6 +767,30 @@ def conv1x1_stream_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False
         _check(lib().sc2_conv1x1_stream_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(out), N, H, W,
                                             Cin, cout, int(stride), 1 if relu else 0, _stream()), 'conv1x1_stream_fwd')
     return out
+
+
+def conv1x1_pair_supported(k1, c, n2):
+    """True if conv3 (k1 -> c, + residual + ReLU) of one Bottleneck block and conv1 (c -> n2, + ReLU) of the next run as one
+    launch (sc2_conv1x1_pair_fwd); SC2_CONV1X1_PAIR=0: A/B switch."""
+    return os.environ.get('SC2_CONV1X1_PAIR', '1') != '0' and bool(lib().sc2_conv1x1_pair_supported(k1, c, n2))
+
+
+def conv1x1_pair_fwd(o_nhwc, w3_frag, b3, identity, w1_frag, b1, tag=None):
+    """h = relu(conv1x1(o; W3) + b3 + identity); u = relu(conv1x1(h; W1) + b1): -> (h [N,H,W,C], u [N,H,W,N2]), bf16 NHWC."""
+    for t, name in ((o_nhwc, 'o'), (w3_frag, 'w3_frag'), (b3, 'b3'), (identity, 'identity'), (w1_frag, 'w1_frag'), (b1, 'b1')):
+        _dev(t, name)
+        assert t.is_contiguous(), name
+    N, H, W, K1 = o_nhwc.shape
+    C, N2 = w3_frag.shape[0] * 16, w1_frag.shape[0] * 16
+    assert o_nhwc.dtype == torch.bfloat16 and identity.dtype == torch.bfloat16 and tuple(identity.shape) == (N, H, W, C)
+    assert tuple(w3_frag.shape) == (C // 16, K1 // 32, 64, 8) and tuple(w1_frag.shape) == (N2 // 16, C // 32, 64, 8)
+    assert b3.dtype == torch.float32 and b3.numel() == C and b1.dtype == torch.float32 and b1.numel() == N2
+    h = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=o_nhwc.device)
+    u = torch.empty((N, H, W, N2), dtype=torch.bfloat16, device=o_nhwc.device)
+    with _timed(tag or 'conv1x1_pair'):
+        _check(lib().sc2_conv1x1_pair_fwd(_ptr(o_nhwc), _ptr(w3_frag), _ptr(b3), _ptr(identity), _ptr(h), _ptr(w1_frag), _ptr(b1),
+                                          _ptr(u), N * H * W, K1, C, N2, _stream()), 'conv1x1_pair_fwd')
+    return h, u
 
 
 def conv2x2_c48_supported(x_shape, cout, kh, kw, stride, pad):

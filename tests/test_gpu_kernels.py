@@ -1183,3 +1183,33 @@ def test_rans_lut_decoder_row_widths(S, dev, n_symbols_in_row):
         assert got[i] == oracle_rans.encode_with_indexes(sym[i], imp, h, sizes, offs)
     dec, dst = S.hip.rans_decode_batch(buf, off, nb, n_sym, cdfs, d_sizes, d_offs, index_div=div)
     assert int(dst.max()) == 0 and np.array_equal(dec.cpu().numpy(), sym)
+
+
+@pytest.mark.parametrize('N,H,W', [(8, 28, 28), (3, 28, 28), (1, 5, 7), (16, 28, 28)])
+def test_conv1x1_pair_equals_two_launches(S, dev, N, H, W):
+    """conv3 + bn3 + residual + ReLU of a Bottleneck block and conv1 + bn1 + ReLU of the next one in ONE launch
+    (sc2_conv1x1_pair_fwd; layer2 of the ResNet-50 tail, sc2bench/models/backbone.py:235-254) against the two launches the head
+    otherwise makes -- same products, same accumulation order, same epilogue order: bit-identical -- and against the f32 ops on
+    the bf16-rounded operands; ragged last tile (M not a multiple of 112), several launches (persistent tile claims re-arm)."""
+    hip = S.hip
+    g = torch.Generator().manual_seed(N * 100 + H)
+    K1, C, N2 = 128, 512, 128
+    o = torch.randn(N, H, W, K1, generator=g).to(dev).to(torch.bfloat16)
+    idn = torch.randn(N, H, W, C, generator=g).to(dev).to(torch.bfloat16)
+    w3 = (torch.randn(C, K1, generator=g) / K1 ** 0.5).to(dev)
+    w1 = (torch.randn(N2, C, generator=g) / C ** 0.5).to(dev)
+    b3 = torch.randn(C, generator=g).to(dev)
+    b1 = torch.randn(N2, generator=g).to(dev)
+    w3f, w1f = hip.pack_weight_fragments(w3), hip.pack_weight_fragments(w1)
+    assert hip.conv1x1_pair_supported(K1, C, N2)
+    h_ref = hip.conv1x1_stream_fwd(o, w3f, b3, residual=idn, relu=True)
+    u_ref = hip.conv1x1_win_fwd(h_ref, hip.pack_conv_win(w1.reshape(N2, C, 1, 1)), b1, relu=True)
+    for _ in range(3):
+        h, u = hip.conv1x1_pair_fwd(o, w3f, b3, idn, w1f, b1)
+        assert torch.equal(h, h_ref), 'h differs from the streaming kernel: max {}'.format((h.float() - h_ref.float()).abs().max().item())
+        assert torch.equal(u, u_ref), 'u differs from the 1x1 kernel: max {}'.format((u.float() - u_ref.float()).abs().max().item())
+    # against f32 ops on the same bf16 operands
+    h32 = torch.relu(o.float().reshape(-1, K1) @ w3.to(torch.bfloat16).float().t() + b3 + idn.float().reshape(-1, C))
+    assert (h.float().reshape(-1, C) - h32).abs().max().item() <= 2 ** -7 * h32.abs().max().item()
+    u32 = torch.relu(h.float().reshape(-1, C) @ w1.to(torch.bfloat16).float().t() + b1)
+    assert (u.float().reshape(-1, N2) - u32).abs().max().item() <= 2 ** -7 * u32.abs().max().item()
