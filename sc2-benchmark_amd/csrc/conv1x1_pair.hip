@@ -75,6 +75,10 @@ __device__ __forceinline__ void lds_write16(uint32_t addr, u32x4_t v) {
     asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
+#ifndef SC2_PAIR_DBG
+#define SC2_PAIR_DBG 0   // timing experiments (results garbage): 1 = no identity loads, 2 = no output stores, 4 = no second GEMM
+#endif
+
 struct PairArgs {
     const uint16_t *__restrict__ o;      // bf16 [M][K1]   input of conv3 (block b's conv2 output)
     const uint16_t *__restrict__ w3;     // bf16 fragment-major [C/16][K1/32][64][8]
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int frow = lane & 15, fq = lane >> 4;
+
     constexpr uint32_t OOB = 0x80000000u;
     const buf_rsrc_t rs_idn = make_rsrc(p.idn, (uint32_t)((long long)p.M * ROWB));
     const buf_rsrc_t rs_o = make_rsrc(p.o, (uint32_t)((long long)p.M * K1 * 2));
@@ -151,15 +155,15 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
         for (int r = 0; r < P / 8; ++r) {
             const int row = wn + 8 * r;
             const long long m = (long long)tile * P + row;
-            const bool ok = tile < p.n_tiles && m < p.M;      // wave-uniform
+            const bool ok = tile < p.n_tiles && m < p.M && !(SC2_PAIR_DBG & 1);      // wave-uniform
             const uint32_t voff = ok ? (uint32_t)((lq ^ (row & 15)) << 4) : OOB;
             buf_load_lds16(rs_idn, (lds_ptr_t)(img + row * ROWB), voff, (uint32_t)(ok ? m * ROWB : 0));
         }
     };
 
     // ---- per-workgroup constants -------------------------------------------------------------------------------
-    // W3 fragments of this wave (channel tiles wn * NT1 + j, all K1): 64 registers, the same for every tile but dead weight during
-    // phase 2, so they are re-fetched (L2) per tile, issued before the previous tile's last barrier
+    // W3 fragments of this wave (channel tiles wn * NT1 + j, all K1): 64 registers, resident for the life of the workgroup (phase 2
+    // parks its sixteen W1 fragments in the accumulators' registers, which are dead by then)
     // (buffer-addressed: ONE per-lane offset register + a scalar offset per fragment; as 16 global pointers the addresses were
     //  hoisted out of the tile loop, spilled, and every reload waited vmcnt(0) -- for the identity rows just issued)
     uint4 wv[KS1][NT1];
@@ -172,10 +176,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
             for (int s = 0; s < KS1; ++s) wv[s][j] = buf_load16(rs_w3, w3_vo, (uint32_t)((j * KS1 + s) * 1024));
     };
     load_w();
-    // per-lane LDS offsets; the tile-dependent part of every address is a compile-time constant (row = 16 i + frow, so
-    // row & 15 = frow and (row >> 1) & 3 = (frow >> 1) & 3 for every row tile i)
-    const int o_lane = frow * 64 + ((fq ^ ((frow >> 1) & 3)) << 4);          // + s * SLAB + i * 1024
-    const int img_row = frow * ROWB;                                           // + i * 16 * ROWB
+    // (per-lane LDS offsets are formed inside the tile loop from an opaque copy of the lane index: the tile-dependent part of
+    //  every address is a compile-time constant -- row = 16 i + frow, so row & 15 = frow and (row >> 1) & 3 = (frow >> 1) & 3 --
+    //  and what is loop-invariant would be hoisted out of the loop and held in ~50 registers across it)
     const buf_rsrc_t rs_w1 = make_rsrc(p.w1, (uint32_t)(N2 * C * 2));
     const uint32_t w1_vo = (uint32_t)((wn * KS2 * 64 + lane) * 16);
 
@@ -198,6 +201,16 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
         // output stores)
         int tq = tid, lq = lane;
         asm volatile("" : "+v"(tq), "+v"(lq));
+        const int frow = lq & 15, fq = lq >> 4;                                  // (shadow the hoistable ones)
+        const int o_lane = frow * 64 + ((fq ^ ((frow >> 1) & 3)) << 4);          // + s * SLAB + i * 1024
+        const int img_row = frow * ROWB;                                           // + i * 16 * ROWB
+        // the claim of the tile after next: a raw instruction (the compiler's atomicAdd waits for the result, vmcnt(0), on the
+        // spot), issued here and read behind phase 2 -- 256 workgroups on one counter take 1 - 3 us to answer
+        unsigned claimed = 0;
+        if (tid == 0) {
+            const unsigned one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.tile_ctr), "v"(one) : "memory");
+        }
         // ------------------------------------------------------------------ phase 1: acc = W3 o
         f32x4_t acc[MT][NT1];
 #pragma unroll
@@ -208,18 +221,32 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
             const uint32_t o_addr = lds_base + IMG + o_lane;
 #pragma unroll
             for (int s = 0; s < KS1; ++s) {
-                u32x4_t xr[MT];
-#define SC2_PAIR_RD(i) if (i < MT) xr[i] = lds_read16_imm<(i) * 1024>(o_addr + s * SLAB);
-                SC2_PAIR_RD(0) SC2_PAIR_RD(1) SC2_PAIR_RD(2) SC2_PAIR_RD(3) SC2_PAIR_RD(4) SC2_PAIR_RD(5) SC2_PAIR_RD(6)
-#undef SC2_PAIR_RD
-                static_assert(MT == 7, "the asm wait below names seven registers");
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6])::"memory");
+                // row tiles in two batches (4 + 3): seven fragments in flight at once cost 28 registers on top of the 176 of
+                // accumulators + weights, and hipcc spilled five weight fragments
+                u32x4_t xa[4], xb[3];
+                static_assert(MT == 7, "the asm waits below name 4 + 3 registers");
+                xa[0] = lds_read16_imm<0 * 1024>(o_addr + s * SLAB);
+                xa[1] = lds_read16_imm<1 * 1024>(o_addr + s * SLAB);
+                xa[2] = lds_read16_imm<2 * 1024>(o_addr + s * SLAB);
+                xa[3] = lds_read16_imm<3 * 1024>(o_addr + s * SLAB);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3])::"memory");
+                xb[0] = lds_read16_imm<4 * 1024>(o_addr + s * SLAB);
+                xb[1] = lds_read16_imm<5 * 1024>(o_addr + s * SLAB);
+                xb[2] = lds_read16_imm<6 * 1024>(o_addr + s * SLAB);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, xr[i]);
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, xa[i]);
 #pragma unroll
                     for (int j = 0; j < NT1; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[s][j]), xf, acc[i][j], 0, 0, 0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2])::"memory");
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, xb[i]);
+#pragma unroll
+                    for (int j = 0; j < NT1; ++j)
+                        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[s][j]), xf, acc[4 + i][j], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -229,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
         // stream of the last one.  (Every store below is issued unconditionally -- masked lanes go out of range -- so the count
         // is exact.)
         if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (wn == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IQ + OQ + 1) : "memory");   // (+ this tile's claim, wave 0 only)
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IQ + OQ) : "memory");
         first = false;
         __syncthreads();                                     // ... everybody's; the o tile has been consumed
@@ -258,35 +286,31 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
         }
         __syncthreads();   // the image holds h for all C channels of the tile
         // ------------------------------------------------------------------ next tile's o rows, the claim after next
-        unsigned claimed = 0;
-        if (tid == 0) {   // raw instruction: the compiler's atomicAdd waits for the result (vmcnt(0)) on the spot
-            const unsigned one = 1u;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.tile_ctr), "v"(one) : "memory");
-        }
+        // W1 fragments of this wave, EIGHT k-steps ahead, into registers the accumulators have just left: two steps of read-ahead
+        // left every k-step of phase 2 (7 MFMAs) waiting ~600 cycles for its fragment to come from L2 (timing experiment: the
+        // phase took 10 k cycles per tile against 1.8 k of MFMA issue)
+        __builtin_amdgcn_sched_barrier(0);   // (not above the epilogue: the accumulators' registers are what they go into)
+        constexpr int GB = 8;     // fragments in flight: eight k-steps (8 x 7 MFMAs ~ 900 cycles) cover the L2 round trip
+        uint4 gb[GB];
+#pragma unroll
+        for (int ks = 0; ks < GB; ++ks) gb[ks] = buf_load16(rs_w1, w1_vo, (uint32_t)(ks * 1024));
         uint4 ov[OQ];
         load_o(next_tile, ov, tq);
         // ------------------------------------------------------------------ phase 2: acc2 = W1 h
         f32x4_t acc2[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc2[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        uint4 gb[2];
-        gb[0] = buf_load16(rs_w1, w1_vo, 0u);
-        gb[1] = buf_load16(rs_w1, w1_vo, 1024u);
-#pragma unroll 1
-        for (int d = 0; d < KS2 / 2; ++d) {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int ks = 2 * d + hh;
-                const bf16x8_t gf = __builtin_bit_cast(bf16x8_t, gb[hh]);
-                if (d + 1 < KS2 / 2) gb[hh] = buf_load16(rs_w1, w1_vo, (uint32_t)((ks + 2) * 1024));
-                const int rd_lane = img_row + (((ks * 4 + fq) ^ frow) << 4);
+        for (int ks = 0; ks < ((SC2_PAIR_DBG & 4) ? 0 : KS2); ++ks) {
+            const bf16x8_t gf = __builtin_bit_cast(bf16x8_t, gb[ks % GB]);
+            if (ks + GB < KS2) gb[ks % GB] = buf_load16(rs_w1, w1_vo, (uint32_t)((ks + GB) * 1024));
+            const int rd_lane = img_row + (((ks * 4 + fq) ^ frow) << 4);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(img + rd_lane + i * (16 * ROWB)));
-                    acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc2[i], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < MT; ++i) {
+                const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(img + rd_lane + i * (16 * ROWB)));
+                acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc2[i], 0, 0, 0);
             }
+            if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (tid == 0) {    // the claim is older than everything issued since, bar the OQ loads of the next o tile
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(claimed) : "n"(OQ) : "memory");
@@ -332,14 +356,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
         __syncthreads();   // the staging has been read by everybody: the region may take the next o tile
         // From here to the counted wait behind the next phase 1 no LDS access is visible to the compiler (see lds_read16_imm).
         issue_identity(next_tile, lq);     // the image is free: the next tile's identity rows start to arrive now ...
-        load_w();
         // ... and only then this tile's output goes out: h from the registers (the tile is contiguous in HBM), then u
         {
             const uint32_t so = (uint32_t)(m0 * ROWB);
 #pragma unroll
             for (int k = 0; k < IQ; ++k) {
                 const int q = tq + 512 * k;
-                buf_store16(rs_h, (q < P * CPR && m0 + q / CPR < p.M) ? (uint32_t)q * 16u : OOB, so, hv[k]);
+                buf_store16(rs_h, (q < P * CPR && m0 + q / CPR < p.M && !(SC2_PAIR_DBG & 2)) ? (uint32_t)q * 16u : OOB, so, hv[k]);
             }
         }
         {
@@ -347,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
 #pragma unroll
             for (int k = 0; k < OQ; ++k) {
                 const int q = tq + 512 * k;
-                buf_store16(rs_u, (q < P * (N2 / 8) && m0 + q / (N2 / 8) < p.M) ? (uint32_t)q * 16u : OOB, so, uv[k]);
+                buf_store16(rs_u, (q < P * (N2 / 8) && m0 + q / (N2 / 8) < p.M && !(SC2_PAIR_DBG & 2)) ? (uint32_t)q * 16u : OOB, so, uv[k]);
             }
         }
         store_o(ov, tq);
