@@ -175,7 +175,10 @@ int sc2_nchw_f32_to_nhwc_f32(const float *x, float *y, int N, int C, int H, int 
 int sc2_conv_f32_chunk_channels(int Cout);
 /* d      : as for sc2_conv2d_fwd; Cin % 4 == 0 (the padded channel count of x), square stride / padding, no output scatter;
  *          Kpad / Cout_pad / k_order are ignored.  a_op: NONE / ABS / SQUARE.  epilogue: NONE, BIAS, GDN (y = ep_x * (1 /
- *          (ep_beta[c] + acc))), IGDN (y = ep_x * (ep_beta[c] + acc)) -- the operation order of compressai GDN1.forward.
+ *          (ep_beta[c] + acc))), IGDN (y = ep_x * (ep_beta[c] + acc)) -- the operation order of compressai GDN1.forward;
+ *          FUSED_GDN / FUSED_IGDN (Cout <= 96): the conv followed by GDN1 over its own output in one launch, `ep_x` = the
+ *          effective gamma as the w_frag of a 1x1 conv Cout -> Cout (same packing), ep_beta = the effective beta; bit-identical
+ *          to the two launches.
  * x      : f32 NHWC [N,H,W,Cin]
  * w_frag : f32, [chunks][steps][NT][64 lanes][4] with cc = sc2_conv_f32_chunk_channels(Cout), NT = cc / 16, chunks =
  *          ceil(Cout / cc), steps = ceil(KH*KW*Cin / 16); entry (ch, s, nt, lane = q*16 + r, j) =

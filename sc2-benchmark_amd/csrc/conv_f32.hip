@@ -19,6 +19,8 @@
 //   * a wave owns MT x 16 pixels x NT x 16 channels; weights are packed fragment-major ([chunk][step][nt][lane][4], 1 KB per
 //     fragment) by hip.pack_conv_f32; operands of step s + 1 are loaded while step s multiplies;
 //   * per-step tap offsets / bounds come from a small table built in LDS at the start of the workgroup;
+//   * conv + GDN1 in one launch where a wave holds every channel of its pixels (Cout <= 96: SC2_EPI_FUSED_GDN): the accumulators
+//     are, as they stand, the operand fragments of the 1x1 GEMM over the channels;
 //   * epilogues: none, GDN1 / inverse GDN1 in the reference's operation order (norm = beta + acc; y = x * (1 / norm) resp.
 //     x * norm: compressai.layers.GDN1.forward), output f32 NHWC / f32 NCHW / int32 NCHW symbols round_half_even(acc - median).
 #include "sc2_common.h"
@@ -39,7 +41,7 @@ struct F32Args {
 
 typedef __attribute__((ext_vector_type(4))) float f4_t;
 
-template <int NT, int MT>
+template <int NT, int MT, bool FUSED>
 __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
     extern __shared__ int2 ktab[];     // [n_steps * 4]: {element offset of the lane's 4 k inside the window, kh | kw << 16}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,6 +129,34 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
         for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
     }
 
+    // conv FOLLOWED BY GDN1 in the same launch (SC2_EPI_FUSED_GDN / _IGDN; one channel chunk = every channel of a pixel in this
+    // wave).  With the weights as the first MFMA operand a lane's accumulators acc[mt][s] ARE the second-operand fragment of
+    // k-step s of the 1x1 GEMM over the channels (pixel r, channels 16 s + 4 q + j): norm = gamma |x| consumes them in place --
+    // no LDS, no HBM round trip of the f32 map (1.2 GB each way for conv0 at bs 256).  Same k order as the separate GDN launch:
+    // bit-identical to it.
+    f4_t nrm[FUSED ? MT : 1][FUSED ? NT : 1];     // (a compile-time property: as a runtime case it cost every launch 110 registers)
+    constexpr bool fused_gdn = FUSED;
+    if (FUSED) {
+        const f4_t *gf = reinterpret_cast<const f4_t *>(p.ep_x) + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) nrm[mt][nt] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            f4_t g[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) g[nt] = gf[(s * NT + nt) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        nrm[FUSED ? mt : 0][FUSED ? nt : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[nt][j], fabsf(acc[mt][s][j]), nrm[FUSED ? mt : 0][FUSED ? nt : 0], 0, 0, 0);
+        }
+    }
+
     // epilogue.  The WEIGHTS are the first MFMA operand, so the result tile is [channel][pixel]: acc[mt][nt][i] = output
     // (pixel m_base + mt * 16 + r, channel (chunk * NT + nt) * 16 + 4 q + i) -- a lane holds FOUR CONSECUTIVE CHANNELS of one
     // pixel: one 16-byte access per tile for NHWC tensors (ep_x, y), and for NCHW outputs the 16 lanes of a quarter write 16
@@ -154,7 +184,14 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
                     for (int i = 0; i < 4; ++i) bc[i] = c0 + i < p.Cout ? p.ep_beta[c0 + i] : 0.f;
                 }
             }
-            if (p.epilogue == SC2_EPI_GDN || p.epilogue == SC2_EPI_IGDN) {
+            if (fused_gdn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float norm = nrm[FUSED ? mt : 0][FUSED ? nt : 0][i] + bc[i];
+                    if (p.epilogue == SC2_EPI_FUSED_GDN) norm = 1.0f / norm;
+                    v[i] = v[i] * norm;
+                }
+            } else if (p.epilogue == SC2_EPI_GDN || p.epilogue == SC2_EPI_IGDN) {
                 float xv[4];
                 if (vec4) {
                     const f4_t t = *reinterpret_cast<const f4_t *>(p.ep_x + m * p.Cout + c0);
@@ -195,11 +232,11 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
     }
 }
 
-template <int NT, int MT>
+template <int NT, int MT, bool FUSED = false>
 int launch_f32(const F32Args &a, int chunks, hipStream_t s) {
     const long long tiles = (a.M + (4 * MT * 16) - 1) / (4 * MT * 16);
     const size_t lds = (size_t)a.n_steps * 4 * sizeof(int2);
-    hipLaunchKernelGGL((conv_f32_kernel<NT, MT>), dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((conv_f32_kernel<NT, MT, FUSED>), dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -245,8 +282,11 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
                 SC2_ERR_INVALID_ARG, "conv2d_f32: OH / OW do not match the geometry");
     SC2_REQUIRE(d->out_H == 0, SC2_ERR_UNSUPPORTED, "conv2d_f32: no output scatter");
     SC2_REQUIRE(d->a_op == SC2_AOP_NONE || d->a_op == SC2_AOP_ABS || d->a_op == SC2_AOP_SQUARE, SC2_ERR_INVALID_ARG, "conv2d_f32: a_op");
-    SC2_REQUIRE(d->epilogue == SC2_EPI_NONE || d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS,
+    const bool fused = d->epilogue == SC2_EPI_FUSED_GDN || d->epilogue == SC2_EPI_FUSED_IGDN;
+    SC2_REQUIRE(d->epilogue == SC2_EPI_NONE || d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN || d->epilogue == SC2_EPI_BIAS || fused,
                 SC2_ERR_UNSUPPORTED, "conv2d_f32: epilogue %d", d->epilogue);
+    SC2_REQUIRE(!fused || (d->Cout <= 96 && ep_x && ep_beta), SC2_ERR_UNSUPPORTED,
+                "conv2d_f32: the fused GDN needs every channel of a pixel in one chunk (Cout <= 96), gamma fragments and beta");
     SC2_REQUIRE(d->out_format == SC2_OUT_F32_NHWC || d->out_format == SC2_OUT_F32_NCHW || d->out_format == SC2_OUT_I32_NCHW_SYM,
                 SC2_ERR_UNSUPPORTED, "conv2d_f32: out_format %d", d->out_format);
     const bool gdn = d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN;
@@ -270,6 +310,11 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
     const int chunks = (d->Cout + cc - 1) / cc;
     // (measured: four row tiles per wave for the narrow chunks -- twice the MFMAs per operand load -- ran the 96 -> 48 k5 s2 conv
     //  in 2.89 ms instead of 2.38 at bs 256: fewer, fatter waves hide less of the operand latency; two row tiles everywhere)
+    if (fused) {
+        if (cc == 32) return launch_f32<2, 2, true>(a, chunks, s);
+        if (cc == 48) return launch_f32<3, 2, true>(a, chunks, s);
+        return launch_f32<6, 2, true>(a, chunks, s);
+    }
     if (cc == 32) return launch_f32<2, 2>(a, chunks, s);
     if (cc == 48) return launch_f32<3, 2>(a, chunks, s);
     return launch_f32<6, 2>(a, chunks, s);

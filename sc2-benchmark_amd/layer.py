@@ -198,8 +198,12 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         launch of sc2_conv2d_f32_fwd on f32 NHWC activations; the last conv writes the f32 NCHW latent or the symbols."""
         mods = list(self._g_a())
         h = hip.nchw_f32_to_nhwc_f32(x)
+        fused_into_previous = False
         for i, mod in enumerate(mods):
             last = i == len(mods) - 1
+            if fused_into_previous:      # this GDN1 ran inside the conv before it
+                fused_into_previous = False
+                continue
             if isinstance(mod, GDN1):
                 if type(mod) is not GDN1:
                     raise hip.Sc2Error('f32 analysis: {} is not supported'.format(type(mod).__name__))
@@ -213,6 +217,16 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                 raise hip.Sc2Error('f32 analysis: unsupported module {}'.format(mod))
             w, bias = self._f32_pack(mod)
             kh, kw = mod.kernel_size
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (self.fuse_gdn and type(nxt) is GDN1 and bias is None and nxt.in_channels == mod.out_channels <= 96 and
+                    i + 2 < len(mods)):
+                # conv + GDN1 in one launch: the wave that owns a pixel's channels applies the normalisation to its accumulators
+                gamma, beta = self._f32_pack(nxt)
+                h = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding,
+                                       epilogue=hip.EPI_FUSED_IGDN if nxt.inverse else hip.EPI_FUSED_GDN, ep_x=gamma, ep_beta=beta,
+                                       out_format=hip.OUT_F32_NHWC, tag=mod._tag + '.f32+' + nxt._tag + '.f32')
+                fused_into_previous = True
+                continue
             if last and symbols_for is not None and bias is None:
                 sym = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding, out_format=hip.OUT_I32_NCHW_SYM,
                                          ep_beta=symbols_for._median_vector(), out=out, tag=mod._tag + '.f32')

@@ -143,3 +143,34 @@ def test_f32_encoder_on_bench_images(S, R, dev):
     ref_bytes = sum(len(q) for q in bench.oracle_streams(ref, ref_sym.reshape(64, -1), hw[0] * hw[1]))
     dev_bytes = int(nb.sum().item())
     assert abs(dev_bytes - ref_bytes) <= 1e-4 * ref_bytes, (dev_bytes, ref_bytes)
+
+
+@pytest.mark.parametrize('cin,cout,k,s,p,inverse', [(3, 96, 5, 2, 2, False), (96, 48, 5, 2, 2, False), (8, 32, 3, 1, 1, True), (4, 20, 1, 1, 0, False)])
+def test_conv_f32_fused_gdn_equals_two_launches(S, R, dev, cin, cout, k, s, p, inverse):
+    """SC2_EPI_FUSED_GDN: the conv and the GDN1 over its output in one launch (the accumulators are the operand fragments of the
+    1x1 GEMM over the channels) == conv launch + GDN launch, bit for bit (same products, same k order), incl. a channel count
+    that is not a multiple of 16."""
+    hip = S.hip
+    g = torch.Generator().manual_seed(cout)
+    x = torch.randn(2, cin, 21, 18, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    ref = R.GDN1(cout, inverse=inverse)
+    with torch.no_grad():
+        ref.gamma.add_(0.02 * torch.rand(ref.gamma.shape, generator=g))
+        ref.beta.add_(0.1 * torch.rand(ref.beta.shape, generator=g))
+    gdn = S.GDN1(cout, inverse=inverse)
+    gdn.load_state_dict(ref.state_dict())
+    gdn.to(dev)
+    gdn._tag = 't'
+    gamma, beta = S.FPBasedResNetBottleneck()._f32_pack(gdn)
+    xh = hip.nchw_f32_to_nhwc_f32(x.to(dev))
+    wf = hip.pack_conv_f32(w.to(dev))
+    t = hip.conv2d_f32_fwd(xh, wf, cout, k, k, s, p)
+    two = hip.conv2d_f32_fwd(t, gamma, cout, 1, 1, 1, 0, a_op=hip.AOP_ABS, epilogue=hip.EPI_IGDN if inverse else hip.EPI_GDN,
+                             ep_x=t, ep_beta=beta)
+    one = hip.conv2d_f32_fwd(xh, wf, cout, k, k, s, p, epilogue=hip.EPI_FUSED_IGDN if inverse else hip.EPI_FUSED_GDN,
+                             ep_x=gamma, ep_beta=beta)
+    assert torch.equal(one, two)
+    with torch.no_grad():
+        want = ref(torch.nn.functional.conv2d(x, w, None, s, p))
+    _close(one.permute(0, 3, 1, 2), want, tol=4e-6)
