@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        unsigned claimed = 0;
 
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
@@ -219,16 +220,18 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             STAMP(1 + 2 * cb);
-            if (cb == 1 && tid == 0) {
-                // Claim of the unit after next.  Issue AND wait in one statement: the compiler may copy or spill an asm
-                // load's destination before the data lands (it did, once the register pressure changed: stale claims,
-                // an endless unit loop).  Here nothing else of wave 0 is in flight (slab 1's loads have just been waited
-                // for, slab 2's are not issued yet) and wave 0 has six taps in this slab where wave 3 has seven, so the
-                // atomic's round trip is mostly slack.
-                unsigned claimed;
+            // Claim of the unit after next: ISSUED behind the first slab's barrier, READ behind the second slab's `vmcnt(0)` above
+            // (which the wave executes anyway), so its round trip -- 0.3 - 1 us with 32 workgroups on an XCD's counter -- runs
+            // beside a whole slab of MFMAs instead of stalling wave 0 (and, at the next barrier, everybody).  The destination
+            // register is written when the atomic RETURNS; hipcc does not know that and once copied such a register early (stale
+            // claims, an endless unit loop): tools/audit_asm_atomic.py checks in the built ISA that its first reader is the add
+            // below, behind the wait (tests/test_abi.py runs it).
+            if (cb == 0 && tid == 0) {
                 const unsigned one = 1u;
-                asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(claimed) : "v"(my_ctr), "v"(one) : "memory");
+                asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(my_ctr), "v"(one) : "memory");
+            }
+            if (cb == 1 && tid == 0) {
+                asm volatile("" : "+v"(claimed)::"memory");
                 next_slot = (int)(claimed + 2 * wgs_x);
                 if (claimed == (unsigned)(n_local - 1)) *my_ctr = 0u;   // this XCD's last claim re-arms its counter
             }

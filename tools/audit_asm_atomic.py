@@ -1,4 +1,4 @@
-"""Audit of the raw `global_atomic_add` claims in the persistent kernels (conv0_gdn96.hip, conv1x1_stream.hip, conv1x1_kres.hip).
+"""Audit of the raw `global_atomic_add` claims in the persistent kernels (conv0_gdn96.hip, conv1x1_stream.hip, conv1x1_kres.hip, conv1x1_pair.hip).
 
 Their destination VGPR is written when the atomic RETURNS, not at the asm statement; hipcc does not know that and may
 copy or spill the register early (under register pressure it did so in conv2_gdn48.hip: stale claims, an endless unit
@@ -10,7 +10,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'sc2-benchmark_amd', 'csrc')
 bad = 0
-for f in ('conv0_gdn96.hip', 'conv1x1_stream.hip', 'conv1x1_kres.hip'):
+for f in ('conv0_gdn96.hip', 'conv1x1_stream.hip', 'conv1x1_kres.hip', 'conv1x1_pair.hip', 'conv2_gdn48.hip'):
     out = os.path.join(tempfile.gettempdir(), f + '.s')
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-x', 'hip', '-S',
                            '--cuda-device-only', os.path.join(CSRC, f), '-o', out], stderr=subprocess.DEVNULL)
