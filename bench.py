@@ -578,6 +578,7 @@ def main():
     ap.add_argument('--head-streams', type=int, default=0, help='H > 0: the task head of step j runs on head stream j %% H (the next decoder does not wait for it)')
     ap.add_argument('--head-halves', type=int, default=0, help='P > 1: the task head runs as P batch slices on P streams, the next decoder waits for all of them')
     ap.add_argument('--diag-skip-coder', type=int, default=0, help='DIAGNOSTIC (invalid as a result): 1 = reuse the first step\'s coder output, 2 = same but still run the coder')
+    ap.add_argument('--front-priority', type=int, default=0, help='HIP stream priority of the encoder stream (-1 = high)')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
     ap.add_argument('--unfused-dequantize', action='store_true', help='A/B: the coder writes int32 symbols and the decoder+head stage dequantises them (two launches more traffic)')
@@ -639,7 +640,7 @@ def main():
     # (1, 2, 4, ...) so that the first decoder stage starts after one coder latency, not after G encoder stages.
     n_coder = max(1, min(args.inflight, 13))
     G = max(1, args.coder_group)   # steps whose symbols share ONE coder launch (G * bs streams per launch)
-    mfma_stream = torch.cuda.Stream(device=dev)
+    mfma_stream = torch.cuda.Stream(device=dev, priority=args.front_priority)
     # --split-mfma: front(i) [encoder] and back(i - depth) [decoder + head] on two streams, so that the tails of one
     # stage's short launches overlap the other's (both still feed the same matrix cores)
     back_streams = [torch.cuda.Stream(device=dev, priority=args.back_priority) for _ in range(args.split_mfma)] \
