@@ -96,8 +96,9 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool ok = (unsigned)(ih0[mt] + kh) < (unsigned)p.H && (unsigned)(iw0[mt] + kw) < (unsigned)p.W;
-            f4_t v = f4_t{0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f4_t *>(p.x + a_base[mt] + t.x);
+            // branch-free: the load is always issued (from element 0 when the tap is out of the image) and zeroed by a select
+            f4_t v = *reinterpret_cast<const f4_t *>(p.x + (ok ? a_base[mt] + t.x : 0));
+            if (!ok) v = f4_t{0.f, 0.f, 0.f, 0.f};
             if (p.a_op == SC2_AOP_ABS) v = f4_t{fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
             else if (p.a_op == SC2_AOP_SQUARE) v = v * v;
             a[mt] = v;
