@@ -156,7 +156,7 @@ int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, 
  * h is written once (it is the next block's identity) and feeds the second GEMM from LDS instead of being read again.
  *   o : bf16 [M][K1];  identity, h : bf16 [M][C];  u : bf16 [M][N2];  w3_frag : bf16 fragment-major [C/16][K1/32][64][8];
  *   w1_frag : bf16 fragment-major [N2/16][C/32][64][8] (hip.pack_weight_fragments);  b3 : f32 [C];  b1 : f32 [N2].
- * Supported: K1 = 128, C = 512, N2 = 128 (layer2 of ResNet-50).  Bit-identical to sc2_conv1x1_stream_fwd (residual, relu)
+ * Supported: K1 = 128, C = 512, N2 = 128 (the block boundaries inside layer2 of ResNet-50) or 256 (layer2.3 -> layer3.0).  Bit-identical to sc2_conv1x1_stream_fwd (residual, relu)
  * followed by the 1x1 kernel of the next block. */
 int sc2_conv1x1_pair_supported(int K1, int C, int N2);
 int sc2_conv1x1_pair_fwd(const void *o, const void *w3_frag, const float *b3, const void *identity, void *h,

@@ -19,7 +19,8 @@
 //   epilogue1 h = relu((acc + b3) + identity) in place in the image (the operation order of the streaming kernel)
 //   phase 2   acc2 = W1 h: K = C from the image (every wave reads all rows), wave w owns 16 of the N2 channels, W1 fragments
 //             stream from L2 (fragment-major, two steps ahead); the image is streamed out to HBM (h) meanwhile
-//   epilogue2 u = relu(acc2 + b1) -> bf16 staging in the o-tile region -> coalesced 16-byte stores
+//   epilogue2 u = relu(acc2 + b1) -> bf16 staging in the image region (free once h sits in registers for its stores) ->
+//             coalesced 16-byte stores; N2 = 128 (conv1 of the next layer2 block) or 256 (conv1 of layer3.0 behind layer2.3)
 #include <stdlib.h>
 
 #include <atomic>
@@ -100,10 +101,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
     constexpr int ROWB = C * 2;                // image row bytes
     constexpr int CPR = ROWB / 16;             // 16-byte chunks per image row
     constexpr int IMG = P * ROWB, SLAB = P * 64, OT = KS1 * SLAB;
-    static_assert(N2 == K1, "the u staging reuses the o tile region: P * N2 * 2 == KS1 * P * 64");
-    static_assert(N2 == 128, "one 16-channel tile of u per wave");
+    constexpr int NT2 = N2 / 128;              // 16-channel tiles of u per wave (wave w owns channels [N2/8 w, N2/8 (w + 1)))
+    static_assert(N2 == 128 || N2 == 256, "one or two 16-channel tiles of u per wave");
+    static_assert(N2 <= C, "the u staging lives in the image region");
     static_assert(CPR == 64, "one image row = one LDS-DMA wave-instruction");
-    constexpr int OQ = (P * K1 * 2 / 16 + 511) / 512;     // 16-byte chunks of an o tile (or a u tile) per thread
+    constexpr int UROW = N2 * 2, UCPR = UROW / 16;        // u staging row bytes / 16-byte chunks per row
+    constexpr int OQ = (P * K1 * 2 / 16 + 511) / 512;     // 16-byte chunks of an o tile per thread
+    constexpr int UQ = (P * UCPR + 511) / 512;            // ... of a u tile
     constexpr int IQ = (P * CPR + 511) / 512;             // image chunks per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *img = smem;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
     //  every address is a compile-time constant -- row = 16 i + frow, so row & 15 = frow and (row >> 1) & 3 = (frow >> 1) & 3 --
     //  and what is loop-invariant would be hoisted out of the loop and held in ~50 registers across it)
     const buf_rsrc_t rs_w1 = make_rsrc(p.w1, (uint32_t)(N2 * C * 2));
-    const uint32_t w1_vo = (uint32_t)((wn * KS2 * 64 + lane) * 16);
+    const uint32_t w1_vo = (uint32_t)(((wn * NT2) * KS2 * 64 + lane) * 16);      // + (t * KS2 + ks) * 1024
 
     for (int k = tid; k < C + N2; k += 512) bias_lds[k] = k < C ? p.b3[k] : p.b1[k - C];
     int tile = blockIdx.x;
@@ -252,12 +256,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
             }
         }
         // this wave's identity rows have landed.  They were issued BEFORE the previous tile's output stores (vmcnt retires in
-        // issue order), so the wait leaves exactly those IQ + OQ stores outstanding: reads of this tile never wait for the write
+        // issue order), so the wait leaves exactly those IQ + UQ stores outstanding: reads of this tile never wait for the write
         // stream of the last one.  (Every store below is issued unconditionally -- masked lanes go out of range -- so the count
         // is exact.)
         if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (wn == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IQ + OQ + 1) : "memory");   // (+ this tile's claim, wave 0 only)
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IQ + OQ) : "memory");
+        else if (wn == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IQ + UQ + 1) : "memory");   // (+ this tile's claim, wave 0 only)
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IQ + UQ) : "memory");
         first = false;
         __syncthreads();                                     // ... everybody's; the o tile has been consumed
         // ------------------------------------------------------------------ epilogue 1: h = relu((acc + b3) + identity), in place
@@ -290,25 +294,34 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
         // left every k-step of phase 2 (7 MFMAs) waiting ~600 cycles for its fragment to come from L2 (timing experiment: the
         // phase took 10 k cycles per tile against 1.8 k of MFMA issue)
         __builtin_amdgcn_sched_barrier(0);   // (not above the epilogue: the accumulators' registers are what they go into)
-        constexpr int GB = 8;     // fragments in flight: eight k-steps (8 x 7 MFMAs ~ 900 cycles) cover the L2 round trip
-        uint4 gb[GB];
+        constexpr int GB = 8;     // k-steps in flight: eight (8 x 7 MFMAs per channel tile ~ 900 cycles) cover the L2 round trip
+        uint4 gb[GB][NT2];
 #pragma unroll
-        for (int ks = 0; ks < GB; ++ks) gb[ks] = buf_load16(rs_w1, w1_vo, (uint32_t)(ks * 1024));
+        for (int ks = 0; ks < GB; ++ks)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) gb[ks][t] = buf_load16(rs_w1, w1_vo, (uint32_t)((t * KS2 + ks) * 1024));
         uint4 ov[OQ];
         load_o(next_tile, ov, tq);
         // ------------------------------------------------------------------ phase 2: acc2 = W1 h
-        f32x4_t acc2[MT];
+        f32x4_t acc2[MT][NT2];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc2[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) acc2[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < ((SC2_PAIR_DBG & 4) ? 0 : KS2); ++ks) {
-            const bf16x8_t gf = __builtin_bit_cast(bf16x8_t, gb[ks % GB]);
-            if (ks + GB < KS2) gb[ks % GB] = buf_load16(rs_w1, w1_vo, (uint32_t)((ks + GB) * 1024));
+            bf16x8_t gf[NT2];
+#pragma unroll
+            for (int t = 0; t < NT2; ++t) {
+                gf[t] = __builtin_bit_cast(bf16x8_t, gb[ks % GB][t]);
+                if (ks + GB < KS2) gb[ks % GB][t] = buf_load16(rs_w1, w1_vo, (uint32_t)((t * KS2 + ks + GB) * 1024));
+            }
             const int rd_lane = img_row + (((ks * 4 + fq) ^ frow) << 4);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(img + rd_lane + i * (16 * ROWB)));
-                acc2[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf, acc2[i], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT2; ++t) acc2[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[t], xf, acc2[i][t], 0, 0, 0);
             }
             if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -316,24 +329,6 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(claimed) : "n"(OQ) : "memory");
             *next_slot = (int)(claimed + 2 * gridDim.x);
             if (claimed == (unsigned)(p.n_tiles - 1)) *p.tile_ctr = 0u;   // the launch's last claim re-arms the counter
-        }
-        // ------------------------------------------------------------------ epilogue 2: u = relu(acc2 + b1) -> staging [P][N2]
-        {
-            const float4 b1v = *reinterpret_cast<const float4 *>(bias_lds + C + wn * 16 + fq * 4);
-            const f32x2_t b01 = {b1v.x, b1v.y}, b23 = {b1v.z, b1v.w};
-            const int c16 = wn * 2 + (fq >> 1);
-            const int u_lane = frow * (N2 * 2) + ((c16 ^ frow) << 4) + (fq & 1) * 8;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                f32x2_t v01 = f32x2_t{acc2[i][0], acc2[i][1]} + b01;
-                f32x2_t v23 = f32x2_t{acc2[i][2], acc2[i][3]} + b23;
-                v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
-                v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
-                uint2 o2;
-                o2.x = pack2(v01);
-                o2.y = pack2(v23);
-                *reinterpret_cast<uint2 *>(ot + u_lane + i * (16 * N2 * 2)) = o2;
-            }
         }
         // ------------------------------------------------------------------ h: the image into registers (stored further down)
         u32x4_t hv[IQ];
@@ -343,20 +338,42 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
             const int row = q / CPR, c = q % CPR;
             hv[k] = *reinterpret_cast<const u32x4_t *>(img + row * ROWB + ((c ^ (row & 15)) << 4));
         }
-        __syncthreads();   // u staged; every wave is done with the image
-        const int tile_after_next = __builtin_amdgcn_readfirstlane(*next_slot);
-        u32x4_t uv[OQ];
+        __syncthreads();   // every wave is done with the image (its region now stages u); the o region has been free since phase 1
+        store_o(ov, tq);   // the next tile's o rows (asm ds_write: see lds_read16_imm)
+        // ------------------------------------------------------------------ epilogue 2: u = relu(acc2 + b1) -> staging [P][N2]
 #pragma unroll
-        for (int k = 0; k < OQ; ++k) {
-            const int q = tq + 512 * k;
-            const int row = q / (N2 / 8), c = q % (N2 / 8);
-            const int qq = q < P * (N2 / 8) ? row * (N2 * 2) + ((c ^ (row & 15)) << 4) : 0;
-            uv[k] = *reinterpret_cast<const u32x4_t *>(ot + qq);
+        for (int t = 0; t < NT2; ++t) {
+            const float4 b1v = *reinterpret_cast<const float4 *>(bias_lds + C + (wn * NT2 + t) * 16 + fq * 4);
+            const f32x2_t b01 = {b1v.x, b1v.y}, b23 = {b1v.z, b1v.w};
+            const int c16 = (wn * NT2 + t) * 2 + (fq >> 1);
+            const int u_lane = frow * UROW + ((c16 ^ frow) << 4) + (fq & 1) * 8;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f32x2_t v01 = f32x2_t{acc2[i][t][0], acc2[i][t][1]} + b01;
+                f32x2_t v23 = f32x2_t{acc2[i][t][2], acc2[i][t][3]} + b23;
+                v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
+                v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
+                uint2 o2;
+                o2.x = pack2(v01);
+                o2.y = pack2(v23);
+                *reinterpret_cast<uint2 *>(img + u_lane + i * (16 * UROW)) = o2;
+            }
         }
-        __syncthreads();   // the staging has been read by everybody: the region may take the next o tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the asm writes of store_o)
+        __syncthreads();   // u staged; the next o tile is visible
+        const int tile_after_next = __builtin_amdgcn_readfirstlane(*next_slot);
+        u32x4_t uv[UQ];
+#pragma unroll
+        for (int k = 0; k < UQ; ++k) {
+            const int q = tq + 512 * k;
+            const int row = q / UCPR, c = q % UCPR;
+            const int qq = q < P * UCPR ? row * UROW + ((c ^ (row & 15)) << 4) : 0;
+            uv[k] = *reinterpret_cast<const u32x4_t *>(img + qq);
+        }
+        __syncthreads();   // the staging has been read by everybody: the image may take the next tile's identity rows
         // From here to the counted wait behind the next phase 1 no LDS access is visible to the compiler (see lds_read16_imm).
-        issue_identity(next_tile, lq);     // the image is free: the next tile's identity rows start to arrive now ...
-        // ... and only then this tile's output goes out: h from the registers (the tile is contiguous in HBM), then u
+        issue_identity(next_tile, lq);     // ... which start to arrive now,
+        // and only then this tile's output goes out: h from the registers (the tile is contiguous in HBM), then u
         {
             const uint32_t so = (uint32_t)(m0 * ROWB);
 #pragma unroll
@@ -366,16 +383,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
             }
         }
         {
-            const uint32_t so = (uint32_t)(m0 * (N2 * 2));
+            const uint32_t so = (uint32_t)(m0 * UROW);
 #pragma unroll
-            for (int k = 0; k < OQ; ++k) {
+            for (int k = 0; k < UQ; ++k) {
                 const int q = tq + 512 * k;
-                buf_store16(rs_u, (q < P * (N2 / 8) && m0 + q / (N2 / 8) < p.M && !(SC2_PAIR_DBG & 2)) ? (uint32_t)q * 16u : OOB, so, uv[k]);
+                buf_store16(rs_u, (q < P * UCPR && m0 + q / UCPR < p.M && !(SC2_PAIR_DBG & 2)) ? (uint32_t)q * 16u : OOB, so, uv[k]);
             }
         }
-        store_o(ov, tq);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the asm writes above)
-        __syncthreads();   // next o tile visible
         tile = next_tile;
         next_tile = tile_after_next;
     }
@@ -429,7 +443,7 @@ int launch_pair(const PairArgs &a, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int sc2_conv1x1_pair_supported(int K1, int C, int N2) { return (K1 == 128 && C == 512 && N2 == 128) ? 1 : 0; }
+extern "C" int sc2_conv1x1_pair_supported(int K1, int C, int N2) { return (K1 == 128 && C == 512 && (N2 == 128 || N2 == 256)) ? 1 : 0; }
 
 extern "C" int sc2_conv1x1_pair_fwd(const void *o, const void *w3_frag, const float *b3, const void *identity, void *h,
                                     const void *w1_frag, const float *b1, void *u, long long M, int K1, int C, int N2,
@@ -442,5 +456,6 @@ extern "C" int sc2_conv1x1_pair_fwd(const void *o, const void *w3_frag, const fl
     a.idn = static_cast<const uint16_t *>(identity); a.h = static_cast<uint16_t *>(h);
     a.w1 = static_cast<const uint16_t *>(w1_frag); a.b1 = b1; a.u = static_cast<uint16_t *>(u);
     a.M = (int)M; a.n_tiles = 0; a.tile_ctr = nullptr;
+    if (N2 == 256) return launch_pair<512, 128, 256, 7>(a, static_cast<hipStream_t>(stream));
     return launch_pair<512, 128, 128, 7>(a, static_cast<hipStream_t>(stream));
 }

@@ -214,9 +214,10 @@ class HipHead(object):
             o_next = None
             o = c2(o, hip.EPI_BIAS_RELU)
             nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
-            if nxt is not None and nxt[3] is None and self._pair_ok(c3, nxt[0]) and o.numel() // o.shape[-1] * c3.cout * 2 < 0x7FF00000:
+            if nxt is not None and self._pair_ok(c3, nxt[0]) and o.numel() // o.shape[-1] * c3.cout * 2 < 0x7FF00000:
                 # conv3 + residual + ReLU of this block and conv1 + ReLU of the next in one launch (conv1x1_pair.hip): the
-                # block output is written once and feeds the second GEMM from LDS
+                # block output is written once and feeds the second GEMM from LDS (layer2's block boundaries, and layer2.3 ->
+                # layer3.0, whose downsample then reads the block output as any other identity path does)
                 h, o_next = hip.conv1x1_pair_fwd(o, c3.w_frag, c3.b, identity.contiguous(), self._pair_w1(nxt[0]), nxt[0].b,
                                                  tag=c3.tag + '+' + nxt[0].tag)
             else:

@@ -1185,15 +1185,17 @@ def test_rans_lut_decoder_row_widths(S, dev, n_symbols_in_row):
     assert int(dst.max()) == 0 and np.array_equal(dec.cpu().numpy(), sym)
 
 
-@pytest.mark.parametrize('N,H,W', [(8, 28, 28), (3, 28, 28), (1, 5, 7), (16, 28, 28)])
-def test_conv1x1_pair_equals_two_launches(S, dev, N, H, W):
+@pytest.mark.parametrize('N,H,W,N2', [(8, 28, 28, 128), (3, 28, 28, 128), (1, 5, 7, 128), (16, 28, 28, 128), (5, 28, 28, 256),
+                                        (1, 5, 7, 256)])
+def test_conv1x1_pair_equals_two_launches(S, dev, N, H, W, N2):
     """conv3 + bn3 + residual + ReLU of a Bottleneck block and conv1 + bn1 + ReLU of the next one in ONE launch
     (sc2_conv1x1_pair_fwd; layer2 of the ResNet-50 tail, sc2bench/models/backbone.py:235-254) against the two launches the head
     otherwise makes -- same products, same accumulation order, same epilogue order: bit-identical -- and against the f32 ops on
-    the bf16-rounded operands; ragged last tile (M not a multiple of 112), several launches (persistent tile claims re-arm)."""
+    the bf16-rounded operands; ragged last tile (M not a multiple of 112), several launches (persistent tile claims re-arm); N2 = 128
+    (the next layer2 block) and 256 (layer3.0 behind layer2.3)."""
     hip = S.hip
     g = torch.Generator().manual_seed(N * 100 + H)
-    K1, C, N2 = 128, 512, 128
+    K1, C = 128, 512
     o = torch.randn(N, H, W, K1, generator=g).to(dev).to(torch.bfloat16)
     idn = torch.randn(N, H, W, C, generator=g).to(dev).to(torch.bfloat16)
     w3 = (torch.randn(C, K1, generator=g) / K1 ** 0.5).to(dev)
