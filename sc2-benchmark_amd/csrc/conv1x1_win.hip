@@ -52,6 +52,29 @@ __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, 
 __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t, uint32_t, uint32_t) { return make_uint4(0, 0, 0, 0); }
 #endif
 
+// Weight fragments are loaded by INLINE ASM and waited for with hand-counted `s_waitcnt vmcnt(N)` (round 4; conv2x2_win.hip has
+// the full note): with the compiler's own loads the conditional window fill in front of a slab made its scoreboard merge
+// conservative -- the first k-step of every slab waited `vmcnt(9)` right behind eight freshly issued window pieces, i.e. for one of
+// THEM to land (tools/audit_vmcnt.py): ~a memory round trip per 50 MFMAs.  The rules that keep this safe are in conv2x2_win.hip: a fragment
+// register is read only by the MFMAs of its k-step, each of which consumes a pixel fragment that went through wait_lgkm behind
+// wait_vm; the load of k-step k + PF goes into the registers of k-step k behind that step's last MFMA.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t rsrc_words(const void *base, uint32_t bytes) {   // raw buffer descriptor: base, no stride, size, 32-bit raw data format
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+// ("s_nop 4": the hazard recognizer does not look into inline asm.  The scalar offset / descriptor may have been written by a
+//  VALU instruction just before -- hipcc restores spilled SGPRs with v_readlane_b32 -- and a VMEM instruction needs 5 wait states
+//  behind a VALU write of an SGPR it reads: without them the loads of the tail-mode kernel used a stale offset (wrong weights) and
+//  conv1x1_win a stale descriptor (memory fault).)
+__device__ __forceinline__ void wload16(u32x4_t &d, i32x4_t r, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen ; wfrag" : "=&v"(d) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {   // (does not name the fragment registers: conv2x2_win.hip, rule (ii))
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int OFF>
 __device__ __forceinline__ u32x4_t lds_read16_imm(uint32_t addr) {
     u32x4_t v;
@@ -100,14 +123,16 @@ __device__ __forceinline__ void mma_chain(f32x4_t (&acc)[T::MT][2], u32x4_t (&av
     }
 }
 
-template <class T, int PAR, int KS>
-__device__ __forceinline__ void k_step(f32x4_t (&acc)[T::MT][2], const uint32_t (&a_base)[T::MT], const uint4 &b0, const uint4 &b1) {
+// NVM: vmcnt budget of the wait for b0 / b1 (asm loads)
+template <class T, int PAR, int KS, int NVM>
+__device__ __forceinline__ void k_step(f32x4_t (&acc)[T::MT][2], const uint32_t (&a_base)[T::MT], u32x4_t &b0, u32x4_t &b1) {
     constexpr int MT = T::MT;
     constexpr int OFF = (PAR & 1) * T::WIN_BYTES + KS * 4 * T::PLANE;   // (a_base points at window PAR & ~1: 16-bit immediates)
     u32x4_t av[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) av[i] = lds_read16_imm<OFF>(a_base[i]);
     __builtin_amdgcn_sched_barrier(0);
+    wait_vm<NVM>();
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
     mma_chain<T, 0>(acc, av, bf0, bf1);
 }
@@ -142,8 +167,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
     const int n0 = chunk * 128 + wave * 32;
     const long long m0 = (long long)mtile * PX;
 
-    const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
-    const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    const i32x4_t rs_w = rsrc_words(p.w, p.w_bytes);
 
     // window fill: wave w fills chunk planes 2 w and 2 w + 1 (chunk c = channels [8 c, 8 c + 8) of the slab); piece j = rows
     // [64 j, 64 j + 64) = output pixels m0 + 64 j + lane.  The per-lane source offsets stay in registers.
@@ -164,7 +188,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
         }
         pw_vo[j] = vo;
     }
+    // (EVERY slab start issues its 2 NRG pieces -- the k-steps' vmcnt budgets count them: past the last slab they come from a
+    //  zero-sized descriptor, i.e. zeros into a dead buffer)
     auto issue_window = [&](int cb, int par) {
+        const buf_rsrc_t rs_x = make_rsrc(p.x, cb < NS ? p.x_bytes : 0u);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -187,10 +214,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
     const uint32_t b_step = (uint32_t)(Cout >> 4) * 1024u;
     const uint32_t KT = (uint32_t)NS * 2u;
     const uint32_t b_so0 = (uint32_t)(n0 >> 4) * 1024u;
-    auto fetch_b = [&](uint32_t kt, uint4 &b0, uint4 &b1) {   // (past the end: the last k-step again, never used)
+    auto fetch_b = [&](uint32_t kt, u32x4_t &b0, u32x4_t &b1) {   // (past the end: the last k-step again, never used)
         const uint32_t so = b_so0 + (kt < KT - 1u ? kt : KT - 1u) * b_step;
-        b0 = buf_load16(rs_w, b_vo, so);
-        b1 = buf_load16(rs_w, b_vo, so + 1024u);
+        wload16(b0, rs_w, b_vo, so);
+        wload16(b1, rs_w, b_vo, so + 1024u);
     };
 
     f32x4_t acc[MT][2];
@@ -201,28 +228,30 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
     }
 
 #pragma unroll
-    for (int d = 0; d < NBUF - 1; ++d)
-        if (d < NS) issue_window(d, d);
-    uint4 bq[PF][2];
+    for (int d = 0; d < NBUF - 1; ++d) issue_window(d, d);
+    u32x4_t bq[PF][2];
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch_b((uint32_t)s, bq[s][0], bq[s][1]);
 
+    // a k-step's fragments were fetched PF k-steps = two slabs ago: behind them the 2 (PF - 1) loads of the three steps in
+    // between and the window pieces of two slab starts; the fetch of k-step + PF goes into the same registers behind the step's
+    // last MFMA
+    constexpr int VM_STEP = 2 * (PF - 1) + 2 * (2 * NRG);
 #define SC2_P1_STEP(PAR, cb, KS, SLOT)                                                 \
     {                                                                                 \
-        const uint4 b0 = bq[SLOT][0], b1 = bq[SLOT][1];                               \
+        if constexpr ((PAR) < 2) k_step<T, PAR, KS, VM_STEP>(acc, a_base, bq[SLOT][0], bq[SLOT][1]); \
+        else k_step<T, PAR, KS, VM_STEP>(acc, a_base2, bq[SLOT][0], bq[SLOT][1]);     \
         fetch_b((uint32_t)(cb) * 2u + (KS + PF), bq[SLOT][0], bq[SLOT][1]);           \
-        if constexpr ((PAR) < 2) k_step<T, PAR, KS>(acc, a_base, b0, b1);             \
-        else k_step<T, PAR, KS>(acc, a_base2, b0, b1);                                \
     }
     // this wave's share of window cb has landed when at most the loads issued after it are outstanding: the NBUF - 2 younger
     // windows (8 pieces each) and the 2 x 2 weight fetches of each of the NBUF - 1 slabs since (fewer near the ends: a
     // conservative wait)
-    constexpr int YOUNGER = (NBUF - 2) * 8 + (NBUF - 1) * 4;
+    constexpr int YOUNGER = (NBUF - 2) * (2 * NRG) + (NBUF - 1) * 4;
 #define SC2_P1_SLAB(PAR, cb, SLOT0)                                                                     \
     {                                                                                                   \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");                                   \
         __builtin_amdgcn_s_barrier();   /* window cb complete; everybody is done with window cb - 1 */   \
-        if ((cb) + NBUF - 1 < NS) issue_window((cb) + NBUF - 1, (PAR + NBUF - 1) % NBUF);               \
+        issue_window((cb) + NBUF - 1, (PAR + NBUF - 1) % NBUF);                                          \
         SC2_P1_STEP(PAR, cb, 0, SLOT0) SC2_P1_STEP(PAR, cb, 1, SLOT0 + 1)                                \
     }
     // (the windows of the prologue have fewer weight fetches behind them than YOUNGER assumes: drain everything once)
@@ -242,6 +271,12 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
     }
 #undef SC2_P1_SLAB
 #undef SC2_P1_STEP
+    // The last PF k-steps fetched "the last k-step again" (never used): those loads are still in flight here, and the compiler
+    // regards their registers as dead -- epilogue values computed into them were overwritten when the loads landed (memory
+    // access faults at bs 256, where they land late).  The wait names the registers, which keeps them allocated up to it.
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1]), "+v"(bq[3][0]),
+                   "+v"(bq[3][1])::"memory");
 
     // epilogue: lane (frow, fq) holds, for row tile i, output channels n0 + 8 fq + [0, 4) in acc[i][0] and + [4, 8) in acc[i][1]
     // of pixel m0 + i * 16 + frow

@@ -65,6 +65,47 @@ __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t, uint32_t, uint32_t) { re
 __device__ __forceinline__ void buf_store16(buf_rsrc_t, uint32_t, uint32_t, u32x4_t) {}
 #endif
 
+// Weight fragments are loaded by INLINE ASM and waited for with hand-counted `s_waitcnt vmcnt(N)` (round 4).  With the
+// compiler's own loads the conditional window fills in front of a slab made its scoreboard merge conservative: the first
+// k-step of every other slab waited `vmcnt(2)`, i.e. for the window pieces of the NEXT slab issued a few instructions
+// earlier (a full L2 / HBM round trip with every wave of the workgroup parked; tools/audit_vmcnt.py shows such waits).
+// The asm loads are invisible to that scoreboard; vmcnt retires in issue order, so "all but the N youngest" is exact.
+// Rules that keep this safe: (i) a fragment register is written by its load and read only by the MFMAs of its k-step,
+// which sit behind wait_vm: every MFMA of a step consumes a pixel fragment that went through wait_lgkm (asm volatile, issued
+// behind wait_vm in program order), so none can be placed above it; (ii) wait_vm does NOT name the registers: as a tied
+// "+v" operand the compiler once placed a v_mov of the fragment into a fresh register IN FRONT of the wait -- a copy of a
+// register whose load is still in flight (stale weights, found by the bit-exact multi-tile test); (iii) the load of k-step
+// k + 4 goes into the registers of k-step k AFTER that step's last MFMA (no renaming); (iv) tools/audit_vmcnt.py --copies
+// checks in the built ISA that no instruction but an MFMA reads a register written by such a load (tests/test_abi.py).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t rsrc_words(const void *base, uint32_t bytes) {   // raw buffer descriptor: base, no stride, size, 32-bit raw data format
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+// ("s_nop 4": the hazard recognizer does not look into inline asm.  The scalar offset / descriptor may have been written by a
+//  VALU instruction just before -- hipcc restores spilled SGPRs with v_readlane_b32 -- and a VMEM instruction needs 5 wait states
+//  behind a VALU write of an SGPR it reads: without them the loads of the tail-mode kernel used a stale offset (wrong weights) and
+//  conv1x1_win a stale descriptor (memory fault).)
+__device__ __forceinline__ void wload16(u32x4_t &d, i32x4_t r, uint32_t voff, uint32_t soff) {   // ("; wfrag": marker for the audit)
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen ; wfrag" : "=&v"(d) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void cload16(u32x4_t &d, i32x4_t r, uint32_t voff, uint32_t soff) {   // epilogue constants (wait_vm_tied)
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(d) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+#ifndef SC2_W2_VMCAP
+#define SC2_W2_VMCAP 63   // DEBUG: -DSC2_W2_VMCAP=<n> caps every counted weight wait at n (0 = drain): bisects a wrong budget
+#endif
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < SC2_W2_VMCAP ? N : SC2_W2_VMCAP) : "memory");
+}
+// (epilogue constants only: consumed by vector ALU code, which nothing else orders behind the wait.  Their loads are at least
+//  eight k-steps old at the wait, so even a copy placed in front of it reads landed data)
+template <int N>
+__device__ __forceinline__ void wait_vm_tied(u32x4_t &a, u32x4_t &b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 template <int OFF>
 __device__ __forceinline__ u32x4_t lds_read16_imm(uint32_t addr) {
     u32x4_t v;
@@ -98,27 +139,41 @@ struct W2Args {
     unsigned x_bytes, w_bytes, y_bytes, o1_bytes, ods_bytes;
 };
 
-// OW: output width (static: the tap offsets are immediates); PAD: 0 (W = OW + 1) or 1 (W = OW - 1)
+// OW: output width (static: the tap offsets are immediates); PAD: 0 (W = OW + 1) or 1 (W = OW - 1).
+// Round 4: the window row pitch AND the pitch of the tile's pixel index are both 56, so tile pixel m reads window row
+// m + kh 56 + kw: sixteen consecutive fragment rows are sixteen consecutive 16-byte LDS rows for every row tile and tap --
+// conflict-free under the ds_read_b128 lane groups (with a 55-pixel pitch the three row tiles that straddle an output row
+// skipped a window row, rows R and R + 16 met in one group: 2.9e7 SQ_LDS_BANK_CONFLICT cycles per launch, profiles/r03f),
+// and the fourteen fragment addresses are ONE register + immediates.
+//   PAD 0 (dec.conv2, W = 56, OW = 55): pixel column 55 of a tile row is a dummy (its window column 56 is the next row's
+//     column 0; results discarded, never stored);
+//   PAD 1 (dec.conv4, W = 55, OW = 56): the window needs columns -1 .. 55 = 57; with pitch 56 the right padding column of
+//     row r IS the left padding column of row r + 1 (both zero), and (5, 0) is the zero row behind the window.
 template <int OW_, int PAD_>
 struct Geo2 {
     static constexpr int OW = OW_, PAD = PAD_, W = OW_ + 1 - 2 * PAD_;
     static constexpr int ROWS = 4;                               // output rows per tile
-    static constexpr int PWD = W + 2 * PAD;                      // window row pitch
-    static constexpr int WROWS = (ROWS + 1) * PWD;
-    static constexpr int NRG = (WROWS + 63) / 64;                // 64-row direct-to-LDS pieces per plane
+    static constexpr int PWD = 56;                               // window row pitch = pixel-index pitch
+    static constexpr int WROWS = (ROWS + 1) * PWD;               // 280 (+ the zero row (5, 0) for PAD 1: filled as out of range)
+    static constexpr int NRG = (WROWS + 1 + 63) / 64;            // 64-row direct-to-LDS pieces per plane
     static constexpr int PLANE = NRG * 64 * 16;
     static constexpr int WIN_BYTES = 4 * PLANE;
-    static constexpr int PX = ROWS * OW;
-    static constexpr int MT = (PX + 15) / 16;
+    static constexpr int PX = ROWS * PWD;                        // 224 tile pixels (PAD 0: 4 of them dummies)
+    static constexpr int MT = PX / 16;
     static constexpr int IMG0 = 2 * WIN_BYTES;                   // fused: bf16 image of the conv output, 32 planes
     static constexpr int IMG_PLANE = MT * 16 * 16;               // [224 rows][16 B]
     static constexpr int LDS_PLAIN = 2 * WIN_BYTES, LDS_FUSED = IMG0 + 32 * IMG_PLANE;
+    static_assert(W + PAD <= PWD && OW <= PWD, "a window row holds the image row (+ one shared padding column)");
     static_assert(MT == 14 && NRG == 5 && PLANE % 256 == 0 && IMG_PLANE % 256 == 0, "14 row tiles, 5 pieces per plane");
-    static_assert(WIN_BYTES + (PWD + 1) * 16 < 65536 && 16 * IMG_PLANE + 13 * 256 < 65536, "16-bit immediates");
+    static_assert(WIN_BYTES + 13 * 256 + (PWD + 1) * 16 < 65536 && 16 * IMG_PLANE + 13 * 256 < 65536, "16-bit immediates");
     static_assert(LDS_FUSED <= 160 * 1024, "LDS");
 };
 
 constexpr int PF = 4;   // weight fragments are fetched this many k-steps ahead (= taps per slab: the ring slot of a k-step is its tap)
+// vmcnt budget of a k-step's wait for its own two weight fragments (issue order, oldest first): ..., [its two loads], the six
+// loads of the three k-steps behind it, and -- always inside those four k-steps -- the window pieces of one slab start (two
+// or three per wave: two are counted).  Everything older than "the N youngest" has landed.
+constexpr int VM_STEP = 2 * (PF - 1) + 2;
 
 // One k-step: 14 pixel fragments x 2 weight fragments.  The fragment reads run seven row tiles ahead of the MFMAs through
 // seven register quads: fragment i + 7 is read into the quad of fragment i as soon as its two MFMAs have been issued (28
@@ -128,36 +183,23 @@ constexpr int PF = 4;   // weight fragments are fetched this many k-steps ahead 
     SC2_W2_MMA(0, 6) SC2_W2_MMA(1, 6) SC2_W2_MMA(2, 6) SC2_W2_MMA(3, 6) SC2_W2_MMA(4, 6) SC2_W2_MMA(5, 6) SC2_W2_MMA(6, 6) \
     SC2_W2_MMA(7, 6) SC2_W2_MMA(8, 5) SC2_W2_MMA(9, 4) SC2_W2_MMA(10, 3) SC2_W2_MMA(11, 2) SC2_W2_MMA(12, 1) SC2_W2_MMA(13, 0)
 
-template <class G, int OFF>
-__device__ __forceinline__ void mma_step(f32x4_t (&acc)[G::MT][2], const uint32_t (&a_base)[G::MT], const uint4 &b0, const uint4 &b1) {
-    static_assert(G::MT == 14, "fourteen row tiles");
+// pixel fragments of row tile i at a_base + OFF + 256 i (window planes, image planes alike); ABS: |.| on the fragment
+// (norm GEMM of the fused GDN1); NVM: vmcnt budget of the wait for b0 / b1 (NVM_AFTER: ... when `after` is set: the first slab
+// of a later tile, where the previous tile's output stores are younger than the fetch as well -- a branch around the wait
+// only, so that both cases are ONE instruction stream: two copies of the slab made the copy audit path-blind)
+template <int OFF, int NVM, bool ABS, int NVM_AFTER = NVM>
+__device__ __forceinline__ void mma_step(f32x4_t (&acc)[14][2], uint32_t a_base, u32x4_t &b0, u32x4_t &b1, bool after = false) {
     u32x4_t av[7];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) av[i] = lds_read16_imm<OFF>(a_base[i]);
-    __builtin_amdgcn_sched_barrier(0);
-    const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
-#define SC2_W2_MMA(i, NWAIT)                                                                    \
-    {                                                                                           \
-        wait_lgkm<NWAIT>(av[(i) % 7]);                                                          \
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[(i) % 7]);                          \
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        if constexpr ((i) + 7 < 14) av[(i) % 7] = lds_read16_imm<OFF>(a_base[(i) + 7 < 14 ? (i) + 7 : 0]); \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-    }
-    SC2_W2_MMA_SEQ
-#undef SC2_W2_MMA
-}
-
-// k-step of the norm GEMM: pixel fragments from the image planes [4 s, 4 s + 4) (this lane: plane 4 s + fq), |.| on the fragment
-template <class G, int OFF, bool ABS>
-__device__ __forceinline__ void norm_step(f32x4_t (&acc)[G::MT][2], uint32_t g_base, const uint4 &b0, const uint4 &b1) {
-    u32x4_t av[7];
-#define SC2_W2_RD(i) av[i] = lds_read16_imm<OFF + (i) * 256>(g_base);
+#define SC2_W2_RD(i) av[i] = lds_read16_imm<OFF + (i) * 256>(a_base);
     SC2_W2_RD(0) SC2_W2_RD(1) SC2_W2_RD(2) SC2_W2_RD(3) SC2_W2_RD(4) SC2_W2_RD(5) SC2_W2_RD(6)
 #undef SC2_W2_RD
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NVM_AFTER != NVM) {
+        if (after) wait_vm<NVM_AFTER>();
+        else wait_vm<NVM>();
+    } else {
+        wait_vm<NVM>();
+    }
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
 #define SC2_W2_MMA(i, NWAIT)                                                                    \
     {                                                                                           \
@@ -167,7 +209,7 @@ __device__ __forceinline__ void norm_step(f32x4_t (&acc)[G::MT][2], uint32_t g_b
         acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
         acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
-        if constexpr ((i) + 7 < 14) av[(i) % 7] = lds_read16_imm<OFF + ((i) + 7 < 14 ? (i) + 7 : 0) * 256>(g_base); \
+        if constexpr ((i) + 7 < 14) av[(i) % 7] = lds_read16_imm<OFF + ((i) + 7 < 14 ? (i) + 7 : 0) * 256>(a_base); \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
     SC2_W2_MMA_SEQ
@@ -177,12 +219,13 @@ __device__ __forceinline__ void norm_step(f32x4_t (&acc)[G::MT][2], uint32_t g_b
 
 // MODE 0: conv;  1: conv + (inverse) GDN1;  2: conv + the two 1x1 layers of the caller that read its output ("tail")
 // k-step of the tail's stride-2 1x1 layer: 4 row tiles = the tile's 56 pixels with even row and column (per-lane image rows)
-template <int OFF>
-__device__ __forceinline__ void ds_step(f32x4_t (&acc)[14][2], const uint32_t (&base)[4], const uint4 &b0, const uint4 &b1) {
+template <int OFF, int NVM>
+__device__ __forceinline__ void ds_step(f32x4_t (&acc)[14][2], const uint32_t (&base)[4], u32x4_t &b0, u32x4_t &b1) {
     u32x4_t av[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) av[i] = lds_read16_imm<OFF>(base[i]);
     __builtin_amdgcn_sched_barrier(0);
+    wait_vm<NVM>();
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
 #define SC2_W2_DS(i)                                                                            \
     {                                                                                           \
@@ -198,10 +241,18 @@ __device__ __forceinline__ void ds_step(f32x4_t (&acc)[14][2], const uint32_t (&
 
 template <class G, int MODE, bool INVERSE>
 __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
-    constexpr int MT = G::MT, W = G::W, OW = G::OW, PAD = G::PAD;
+    constexpr int MT = G::MT, W = G::W, OW = G::OW, PAD = G::PAD, PWD = G::PWD;
     constexpr bool FUSE = MODE == 1, TAIL = MODE == 2;
     constexpr uint32_t OOB = 0x80000000u;
-    constexpr int NSTORE = TAIL ? 2 * MT + 8 : MT;   // output stores per lane and tile (tail: o1, y, 2 x 4 ods; an upper bound when y is null)
+    // output stores per lane and tile, ALWAYS issued (masked ones out of range): the counted vmcnt waits of the next tile rely
+    // on it.  Tail: o1, y (out of range as a whole when the caller does not want y), 2 x 4 ods.
+    constexpr int NSTORE = TAIL ? 2 * MT + 8 : MT;
+    constexpr int NSTORE_LAST = TAIL ? 4 : MT;   // ... of them behind the last weight fetch of the tile
+    // The next tile's first four k-steps are fetched during the last four k-steps of this one, i.e. across the epilogue -- except
+    // in the forward-GDN1 variant, whose divisions need the registers: there the allocator SPILLED the fragments in flight
+    // (tools/audit_vmcnt.py --copies), so that variant fetches them behind its output stores (and waits for those stores'
+    // acknowledgements with them: it is not on the bottleneck's path, which uses the inverse form).
+    constexpr bool WRAP = !(FUSE && !INVERSE);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
 
@@ -221,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     if (t_first >= t_last) return;
 
     const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
-    const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    const i32x4_t rs_w = rsrc_words(p.w, p.w_bytes);
     const buf_rsrc_t rs_y = make_rsrc(p.y, p.y_bytes);
     [[maybe_unused]] const buf_rsrc_t rs_o1 = make_rsrc(TAIL ? p.o1 : p.y, TAIL ? p.o1_bytes : 0u);
     [[maybe_unused]] const buf_rsrc_t rs_ods = make_rsrc(TAIL ? p.ods : p.y, TAIL ? p.ods_bytes : 0u);
@@ -230,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     // (waves 0-3) or {3, 4} (waves 4-7)
     const int pq = wave & 3, pj0 = wave < 4 ? 0 : 3, pn = wave < 4 ? 3 : 2;
     uint32_t pw_vo[3];
-    auto window_offsets = [&](int tile) {
+    auto window_offsets = [&](int tile, bool live) {   // live = false: every lane out of range (zeros; see SC2_W2_SLAB)
         const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * G::ROWS;
         // (the lane index is re-derived here and the values below recomputed per tile: hoisted out of the tile loop they were spilled)
         int ln;   // (volatile: computed where it is used)
@@ -238,9 +289,12 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int wr = (pj0 + j) * 64 + ln;
-            const int ihp = wr / G::PWD, iwp = wr - ihp * G::PWD;
+            // wr / 56 and wr % 56 for wr < 320, by multiply-shift and shifts (a 32-bit `wr - ihp * 56` became v_mad_u64_u32 with
+            // a don't-care high addend register -- which the copy audit cannot tell from a read of a fragment in flight)
+            static_assert(PWD == 56 && G::NRG * 64 <= 320, "ihp = (wr * 1171) >> 16 is exact below 336");
+            const int ihp = (int)(((uint32_t)wr * 1171u) >> 16), iwp = wr - ((ihp << 6) - (ihp << 3));
             const int ih = oh0 - PAD + ihp, iw = iwp - PAD;
-            const bool ok = (j < pn) & (wr < G::WROWS) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
+            const bool ok = live & (j < pn) & (wr < G::WROWS) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
             pw_vo[j] = ok ? (uint32_t)((((img * H + ih) * W + iw) * Cin) * 2 + pq * 16) : OOB;
         }
     };
@@ -251,29 +305,22 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
         if (pn == 3) buf_load_lds16(rs_x, (lds_ptr_t)(dst + 2048), pw_vo[2], (uint32_t)cb * 64u);
     };
 
-    // fragment rows of this lane at tap (0, 0)
-    uint32_t a_base[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int m = i * 16 + frow;
-        m = m < G::PX ? m : G::PX - 1;   // (rows past the tile: any valid address, results discarded)
-        const int ohl = m / OW, ow = m - ohl * OW;
-        a_base[i] = lds_base + (uint32_t)(fq * G::PLANE + (ohl * G::PWD + ow) * 16);
-    }
+    // fragment row of this lane in row tile 0 at tap (0, 0); row tile i: + 256 i, tap (kh, kw): + (kh PWD + kw) 16
+    const uint32_t a_base = lds_base + (uint32_t)(fq * G::PLANE + frow * 16);
     // weights: k-step k, 16-channel tile t -> 1 KB at (k * 16 + t) * 1024; this wave's tiles are 2 w, 2 w + 1
     const uint32_t b_vo = (uint32_t)(lane * 16);
     const uint32_t b_so0 = (uint32_t)(2 * wave) * 1024u;
-    uint4 bq[PF][2];
-    auto fetch_b = [&](uint32_t k, uint4 &b0, uint4 &b1) {   // k in [0, 2 KTT): wraps to the next tile's first k-steps
+    u32x4_t bq[PF][2];
+    auto fetch_b = [&](uint32_t k, u32x4_t &b0, u32x4_t &b1) {   // k in [0, 2 KTT): wraps to the next tile's first k-steps
         const uint32_t kk = k >= KTT ? k - KTT : k;
         const uint32_t so = b_so0 + kk * 16384u;
-        b0 = buf_load16(rs_w, b_vo, so);
-        b1 = buf_load16(rs_w, b_vo, so + 1024u);
+        wload16(b0, rs_w, b_vo, so);
+        wload16(b1, rs_w, b_vo, so + 1024u);
     };
 
     f32x4_t acc[MT][2];
 
-    window_offsets(t_first);
+    window_offsets(t_first, true);
     issue_window(0, 0);
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch_b((uint32_t)s, bq[s][0], bq[s][1]);
@@ -286,46 +333,69 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
         }
         const bool first = tile == t_first;
 
-#define SC2_W2_STEP(PAR, cb, TAP)                                                                                   \
-    {                                                                                                               \
-        const uint4 b0 = bq[TAP][0], b1 = bq[TAP][1];                                                               \
-        fetch_b((uint32_t)(cb) * 4u + (TAP + PF), bq[TAP][0], bq[TAP][1]);                                           \
-        mma_step<G, PAR * G::WIN_BYTES + ((TAP / 2) * G::PWD + TAP % 2) * 16>(acc, a_base, b0, b1);                  \
+        // k-step TAP of slab cb: its fragments were fetched four k-steps ago; the fetch of k-step + 4 goes into the same
+        // registers behind the step's last MFMA.  In the first slab of a later tile (SLAB0 && !first) the previous tile's last
+        // NSTORE_LAST output stores are younger than the fetch as well.
+#define SC2_W2_STEP(PAR, cb, TAP, SLAB0)                                                                                \
+    {                                                                                                                   \
+        mma_step<PAR * G::WIN_BYTES + ((TAP / 2) * PWD + TAP % 2) * 16, VM_STEP, false,                                  \
+                 VM_STEP + (SLAB0 && WRAP && !TAIL ? NSTORE_LAST : 0)>(acc, a_base, bq[TAP][0], bq[TAP][1], !first);    \
+        fetch_b((uint32_t)(cb) * 4u + (TAP + PF), bq[TAP][0], bq[TAP][1]);                                               \
     }
-#define SC2_W2_SLAB(PAR, cb)                                                                                        \
-    {                                                                                                               \
+#define SC2_W2_SLAB(PAR, cb, SLAB0)                                                                                     \
+    {                                                                                                                   \
         /* this wave's share of the slab's window has landed: it is older than the 2 PF weight loads in flight and, in \
            the first slab of a later tile, than the previous tile's output stores */                                \
-        if ((cb) == 0 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF + NSTORE) : "memory");             \
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF) : "memory");                                          \
+        if (SLAB0 && !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF + NSTORE) : "memory");                     \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF) : "memory");                                              \
         __builtin_amdgcn_s_barrier();   /* window complete; everybody is done with the previous slab's window */    \
+        /* EVERY slab start issues this wave's two or three window pieces (VM_STEP counts two of them): the next slab's, \
+           or the next tile's first window (buffer 0: NS is even), or -- behind the workgroup's last tile -- zeros into the \
+           dead buffer 0 */                                                                                         \
         if ((cb) + 1 < NS) {                                                                                        \
             issue_window((cb) + 1, 1 - PAR);                                                                        \
-        } else if (tile + 1 < t_last) {   /* the next tile's first window (buffer 0: NS is even) */                 \
-            window_offsets(tile + 1);                                                                               \
+        } else {                                                                                                    \
+            window_offsets(tile + 1 < t_last ? tile + 1 : tile, tile + 1 < t_last);                                 \
             issue_window(0, 0);                                                                                     \
         }                                                                                                           \
-        SC2_W2_STEP(PAR, cb, 0) SC2_W2_STEP(PAR, cb, 1) SC2_W2_STEP(PAR, cb, 2) SC2_W2_STEP(PAR, cb, 3)             \
+        SC2_W2_STEP(PAR, cb, 0, SLAB0) SC2_W2_STEP(PAR, cb, 1, SLAB0) SC2_W2_STEP(PAR, cb, 2, SLAB0)                    \
+        SC2_W2_STEP(PAR, cb, 3, SLAB0)                                                                                  \
     }
-        for (int cb = 0; cb < NS; cb += 2) {
-            SC2_W2_SLAB(0, cb)
-            SC2_W2_SLAB(1, cb + 1)
+        // the first two slabs peeled (the first one's waits branch on `first`), then the steady state
+        SC2_W2_SLAB(0, 0, true)
+        SC2_W2_SLAB(1, 1, false)
+        for (int cb = 2; cb < NS; cb += 2) {
+            SC2_W2_SLAB(0, cb, false)
+            SC2_W2_SLAB(1, cb + 1, false)
         }
 #undef SC2_W2_SLAB
 #undef SC2_W2_STEP
 
         // ---- output.  Lane (frow, fq) holds, for row tile i, channels 32 w + 8 fq + [0, 4) in acc[i][0] and + [4, 8) in
-        // acc[i][1] (the packing permutes the weight rows that way) of tile pixel 16 i + frow
+        // acc[i][1] (the packing permutes the weight rows that way) of tile pixel 16 i + frow = (row ml / 56, column ml % 56)
         // Stores go through a buffer descriptor with invalid lanes sent out of range: ALWAYS 14 store instructions per tile,
         // which the counted vmcnt wait of the next tile's first slab relies on.
         const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * G::ROWS;
         const int rows_valid = OH - oh0 < G::ROWS ? OH - oh0 : G::ROWS;
-        const int px_valid = rows_valid * OW;
         const uint32_t y_so = (uint32_t)((img * OH + oh0) * OW) * 512u;            // tile base (bytes), scalar
         int ln_o;   // the lane index, computed HERE (volatile): the per-row-tile offsets and masks derived from it are then recomputed per
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln_o));   // tile, not hoisted and spilled
         const int fr = ln_o & 15, fqo = ln_o >> 4;
-        const uint32_t y_vo = (uint32_t)(fr * 512 + (32 * wave + 8 * fqo) * 2);   // + i * 8192
+        const uint32_t y_ch = (uint32_t)((32 * wave + 8 * fqo) * 2);
+        // byte offset of tile pixel ml = 16 i + fr in the tile's block of y (pixel pitch `pitch` bytes), or out of range
+        // (store groups that run behind further k-steps re-derive the lane index where they run -- lane_now(): offsets
+        //  computed from ONE copy were all formed up front and held, or spilled, across those steps)
+        auto lane_now = []() {
+            int l;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+            return l;
+        };
+        auto out_off = [&](int i, int fr_, uint32_t ch, int pitch) -> uint32_t {
+            const int ml = i * 16 + fr_;
+            const int r = (ml >= PWD) + (ml >= 2 * PWD) + (ml >= 3 * PWD), c = ml - r * PWD;
+            const bool ok = (r < rows_valid) & (c < OW);
+            return ok ? (uint32_t)((r * OW + c) * pitch) + ch : OOB;
+        };
         if constexpr (FUSE || TAIL) {
             // image slots (computed here, per tile, from the re-derived lane index: held across the K loop they were spilled).
             // Writer / read-back: plane 4 wave + fq, row 16 i + frow; second-GEMM reader: plane 4 s + fq
@@ -346,12 +416,23 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();   // the image is complete
-            // norm = gamma |x|: k-steps KT .. KT + 7 of the weight stream, ring slot = step & 3
+            // epilogue constants of this lane's eight channels (beta, or the tail's bias1): asm loads as well -- a compiler-tracked
+            // load here made its use wait vmcnt(0), i.e. for the next tile's weight fragments fetched just before.  Issued in
+            // front of the eight norm k-steps (whose budgets do not count them: two more young loads only make those waits
+            // reach one fetch further back), waited for behind them.
+            const i32x4_t rs_c0 = rsrc_words(TAIL ? p.bias1 : p.beta, TAIL ? 128u * 4u : 256u * 4u);
+            u32x4_t c0_lo, c0_hi;
+            {
+                const uint32_t co = (uint32_t)(((TAIL ? (wave < 4 ? 32 * wave : 0) : 32 * wave) + 8 * fqo) * 4);
+                cload16(c0_lo, rs_c0, co, 0u);
+                cload16(c0_hi, rs_c0, co, 16u);
+            }
+            // norm = gamma |x|: k-steps KT .. KT + 7 of the weight stream, ring slot = step & 3 (no window piece and no store
+            // is issued between such a step and its fetch: six younger loads)
 #define SC2_W2_NSTEP(S, BASE, OFF)                                                         \
     {                                                                                      \
-        const uint4 b0 = bq[(S) & 3][0], b1 = bq[(S) & 3][1];                              \
-        fetch_b(KT + (S) + PF, bq[(S) & 3][0], bq[(S) & 3][1]);                            \
-        norm_step<G, OFF, !TAIL>(acc, BASE, b0, b1);                                       \
+        mma_step<OFF, (!WRAP && (S) >= 4) ? 2 * (7 - (S)) : 2 * (PF - 1), !TAIL>(acc, BASE, bq[(S) & 3][0], bq[(S) & 3][1]); \
+        if constexpr (WRAP || (S) < 4) fetch_b(KT + (S) + PF, bq[(S) & 3][0], bq[(S) & 3][1]);                                \
     }
             SC2_W2_NSTEP(0, g_base0, 0 * G::IMG_PLANE) SC2_W2_NSTEP(1, g_base0, 4 * G::IMG_PLANE)
             SC2_W2_NSTEP(2, g_base0, 8 * G::IMG_PLANE) SC2_W2_NSTEP(3, g_base0, 12 * G::IMG_PLANE)
@@ -363,22 +444,23 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
                 // waves 4-7 issue the same 14 stores out of range (a fixed number of stores per wave and tile)
                 {
                     const bool mine = wave < 4;
-                    const float4 b_lo = *reinterpret_cast<const float4 *>(p.bias1 + (mine ? 32 * wave : 0) + 8 * fqo);
-                    const float4 b_hi = *reinterpret_cast<const float4 *>(p.bias1 + (mine ? 32 * wave : 0) + 8 * fqo + 4);
+                    wait_vm_tied<2 * PF>(c0_lo, c0_hi);   // (sixteen younger fetches)
+                    const float4 b_lo = __builtin_bit_cast(float4, c0_lo), b_hi = __builtin_bit_cast(float4, c0_hi);
                     const uint32_t o_so = (uint32_t)((img * OH + oh0) * OW) * 256u;
-                    const uint32_t o_vo = (uint32_t)(fr * 256 + (32 * wave + 8 * fqo) * 2);   // + i * 4096
+                    const int l1 = lane_now();
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         const float r[8] = {fmaxf(acc[i][0][0] + b_lo.x, 0.f), fmaxf(acc[i][0][1] + b_lo.y, 0.f), fmaxf(acc[i][0][2] + b_lo.z, 0.f),
                                             fmaxf(acc[i][0][3] + b_lo.w, 0.f), fmaxf(acc[i][1][0] + b_hi.x, 0.f), fmaxf(acc[i][1][1] + b_hi.y, 0.f),
                                             fmaxf(acc[i][1][2] + b_hi.z, 0.f), fmaxf(acc[i][1][3] + b_hi.w, 0.f)};
-                        const int ml = i * 16 + fr;
-                        buf_store16(rs_o1, (mine & (ml < px_valid)) ? o_vo + (uint32_t)i * 4096u : OOB, o_so,
-                                    u32x4_t{pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7])});
+                        const uint32_t vo = out_off(i, l1 & 15, (uint32_t)((32 * wave + 8 * (l1 >> 4)) * 2), 256);
+                        buf_store16(rs_o1, mine ? vo : OOB, o_so, u32x4_t{pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7])});
                     }
                 }
-                // ---- y itself, if the caller wants it (read back from the image: the accumulators are gone)
-                if (p.y != nullptr) {
+                // ---- y itself (read back from the image: the accumulators are gone).  A caller that does not want it passes a
+                // null y with a zero-sized descriptor: the 14 stores are issued all the same and dropped (the vmcnt budgets
+                // count them)
+                {
                     u32x4_t xr[MT];
 #define SC2_W2_RD(i) xr[i] = lds_read16_imm<(i) * 256>(img_wr);
                     SC2_W2_RD(0) SC2_W2_RD(1) SC2_W2_RD(2) SC2_W2_RD(3) SC2_W2_RD(4) SC2_W2_RD(5) SC2_W2_RD(6)
@@ -386,60 +468,67 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
 #undef SC2_W2_RD
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]),
                                  "+v"(xr[7]), "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13])::"memory");
+                    const int l2 = lane_now();
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const int ml = i * 16 + fr;
-                        buf_store16(rs_y, ml < px_valid ? y_vo + (uint32_t)i * 8192u : OOB, y_so, xr[i]);
-                    }
+                    for (int i = 0; i < MT; ++i)
+                        buf_store16(rs_y, out_off(i, l2 & 15, (uint32_t)((32 * wave + 8 * (l2 >> 4)) * 2), 512), y_so, xr[i]);
                 }
                 // ---- ods = Wds y[::2, ::2] + bias_ds: two passes of 256 output channels over the tile's 56 even pixels
                 const uint32_t d_so = (uint32_t)((img * (OH / 2) + oh0 / 2) * (OW / 2)) * 1024u;
                 uint32_t ds_lo[4], ds_hi[4];   // image rows of the even pixels (row 2 r', column 2 c'); computed here, per tile: held
-#pragma unroll                                 // across the K loop they were spilled
+                const int l3 = lane_now();             // across the K loop they were spilled
+#pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    int m = i * 16 + fr;
+                    int m = i * 16 + (l3 & 15);
                     m = m < 2 * (OW / 2) ? m : 0;
                     const int r2 = m / (OW / 2), c2 = m - r2 * (OW / 2);
-                    ds_lo[i] = lds_base + (uint32_t)(G::IMG0 + fqo * G::IMG_PLANE + (2 * r2 * OW + 2 * c2) * 16);
+                    ds_lo[i] = lds_base + (uint32_t)(G::IMG0 + (l3 >> 4) * G::IMG_PLANE + (2 * r2 * PWD + 2 * c2) * 16);
                     ds_hi[i] = ds_lo[i] + 16u * G::IMG_PLANE;
                 }
-#define SC2_W2_DSTEP(S, BASE, OFF)                                                         \
+                // vmcnt budgets: the first four k-steps of a pass were fetched in front of the stores issued since (pass 0: o1 + y,
+                // 2 MT; pass 1: the four ods stores of pass 0)
+#define SC2_W2_DSTEP(S, BASE, OFF, NVM)                                                    \
     {                                                                                      \
-        const uint4 b0 = bq[(S) & 3][0], b1 = bq[(S) & 3][1];                              \
+        ds_step<OFF, NVM>(acc, BASE, bq[(S) & 3][0], bq[(S) & 3][1]);                      \
         fetch_b(KT + (S) + PF, bq[(S) & 3][0], bq[(S) & 3][1]);                            \
-        ds_step<OFF>(acc, BASE, b0, b1);                                                   \
     }
-#define SC2_W2_DPASS(PASS)                                                                                                   \
+#define SC2_W2_DPASS(PASS, NVM0)                                                                                             \
     {                                                                                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
             acc[i][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};                                                                         \
             acc[i][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};                                                                         \
         }                                                                                                                    \
-        SC2_W2_DSTEP(8 + 8 * PASS + 0, ds_lo, 0 * G::IMG_PLANE) SC2_W2_DSTEP(8 + 8 * PASS + 1, ds_lo, 4 * G::IMG_PLANE)      \
-        SC2_W2_DSTEP(8 + 8 * PASS + 2, ds_lo, 8 * G::IMG_PLANE) SC2_W2_DSTEP(8 + 8 * PASS + 3, ds_lo, 12 * G::IMG_PLANE)     \
-        SC2_W2_DSTEP(8 + 8 * PASS + 4, ds_hi, 0 * G::IMG_PLANE) SC2_W2_DSTEP(8 + 8 * PASS + 5, ds_hi, 4 * G::IMG_PLANE)      \
-        SC2_W2_DSTEP(8 + 8 * PASS + 6, ds_hi, 8 * G::IMG_PLANE) SC2_W2_DSTEP(8 + 8 * PASS + 7, ds_hi, 12 * G::IMG_PLANE)     \
-        const float4 b_lo = *reinterpret_cast<const float4 *>(p.bias_ds + 256 * PASS + 32 * wave + 8 * fqo);                 \
-        const float4 b_hi = *reinterpret_cast<const float4 *>(p.bias_ds + 256 * PASS + 32 * wave + 8 * fqo + 4);             \
+        u32x4_t cd_lo, cd_hi;   /* bias_ds of this pass: asm loads in front of its eight k-steps, waited for behind them */          \
+        const int l4 = lane_now();                                                                                          \
+        cload16(cd_lo, rs_cd, (uint32_t)((256 * PASS + 32 * wave + 8 * (l4 >> 4)) * 4), 0u);                                      \
+        cload16(cd_hi, rs_cd, (uint32_t)((256 * PASS + 32 * wave + 8 * (l4 >> 4)) * 4), 16u);                                     \
+        SC2_W2_DSTEP(8 + 8 * PASS + 0, ds_lo, 0 * G::IMG_PLANE, NVM0) SC2_W2_DSTEP(8 + 8 * PASS + 1, ds_lo, 4 * G::IMG_PLANE, NVM0)   \
+        SC2_W2_DSTEP(8 + 8 * PASS + 2, ds_lo, 8 * G::IMG_PLANE, NVM0) SC2_W2_DSTEP(8 + 8 * PASS + 3, ds_lo, 12 * G::IMG_PLANE, NVM0)  \
+        SC2_W2_DSTEP(8 + 8 * PASS + 4, ds_hi, 0 * G::IMG_PLANE, 2 * (PF - 1)) SC2_W2_DSTEP(8 + 8 * PASS + 5, ds_hi, 4 * G::IMG_PLANE, 2 * (PF - 1))   \
+        SC2_W2_DSTEP(8 + 8 * PASS + 6, ds_hi, 8 * G::IMG_PLANE, 2 * (PF - 1)) SC2_W2_DSTEP(8 + 8 * PASS + 7, ds_hi, 12 * G::IMG_PLANE, 2 * (PF - 1)) \
+        wait_vm_tied<2 * PF>(cd_lo, cd_hi);                                                                                       \
+        const float4 b_lo = __builtin_bit_cast(float4, cd_lo), b_hi = __builtin_bit_cast(float4, cd_hi);                     \
+        const int l5 = lane_now();                                                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                      \
-            const int m2 = i * 16 + fr;                                                                                      \
+            const int m2 = i * 16 + (l5 & 15);                                                                               \
             const int r2 = m2 / (OW / 2), c2 = m2 - r2 * (OW / 2);                                                           \
             const bool ok = (m2 < 2 * (OW / 2)) & (2 * r2 < rows_valid);                                                     \
-            const uint32_t vo = (uint32_t)((r2 * (OW / 2) + c2) * 1024 + (256 * PASS + 32 * wave + 8 * fqo) * 2);            \
+            const uint32_t vo = (uint32_t)((r2 * (OW / 2) + c2) * 1024 + (256 * PASS + 32 * wave + 8 * (l5 >> 4)) * 2);      \
             buf_store16(rs_ods, ok ? vo : OOB, d_so,                                                                         \
                         u32x4_t{pack2(acc[i][0][0] + b_lo.x, acc[i][0][1] + b_lo.y), pack2(acc[i][0][2] + b_lo.z, acc[i][0][3] + b_lo.w), \
                                 pack2(acc[i][1][0] + b_hi.x, acc[i][1][1] + b_hi.y), pack2(acc[i][1][2] + b_hi.z, acc[i][1][3] + b_hi.w)}); \
         }                                                                                                                    \
     }
-                SC2_W2_DPASS(0)
-                SC2_W2_DPASS(1)
+                const i32x4_t rs_cd = rsrc_words(p.bias_ds, 512u * 4u);
+                SC2_W2_DPASS(0, 2 * (PF - 1) + 2 * MT)
+                SC2_W2_DPASS(1, 2 * (PF - 1) + 4)
 #undef SC2_W2_DPASS
 #undef SC2_W2_DSTEP
             } else {
                 // y = x * (beta + norm)  (inverse)  or  x / (beta + norm); x from this lane's own image slots.  (beta is fetched per
                 // tile: 32 bytes per lane out of L2; kept in registers across the K loop it was spilled to scratch)
-                const float4 beta_lo = *reinterpret_cast<const float4 *>(p.beta + 32 * wave + 8 * fqo);
-                const float4 beta_hi = *reinterpret_cast<const float4 *>(p.beta + 32 * wave + 8 * fqo + 4);
+                wait_vm_tied<2 * PF>(c0_lo, c0_hi);   // (sixteen younger fetches)
+                const float4 beta_lo = __builtin_bit_cast(float4, c0_lo), beta_hi = __builtin_bit_cast(float4, c0_hi);
                 // (two batches of seven row tiles: with all fourteen read-backs live the forward-GDN form, whose divisions need more
                 //  temporaries, spilled)
 #define SC2_W2_FIN(i0)                                                                                                              \
@@ -466,25 +555,28 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
             } else if (p.dbg == 2) {                                                                                                \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e) r[e] = nm[e];                                                         \
             }                                                                                                                       \
-            const int ml = i * 16 + fr;                                                                                             \
-            buf_store16(rs_y, ml < px_valid ? y_vo + (uint32_t)i * 8192u : OOB, y_so,                                               \
+            buf_store16(rs_y, out_off(i, fr, y_ch, 512), y_so,                                                                      \
                         u32x4_t{pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7])});                       \
         }                                                                                                                           \
     }
                 SC2_W2_FIN(0)
                 SC2_W2_FIN(7)
 #undef SC2_W2_FIN
+                if constexpr (!WRAP) {   // (see WRAP: the next tile's first four k-steps, as in the prologue)
+#pragma unroll
+                    for (int s4 = 0; s4 < PF; ++s4) fetch_b((uint32_t)s4, bq[s4][0], bq[s4][1]);
+                }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int ml = i * 16 + fr;
-                buf_store16(rs_y, ml < px_valid ? y_vo + (uint32_t)i * 8192u : OOB, y_so,
+                buf_store16(rs_y, out_off(i, fr, y_ch, 512), y_so,
                             u32x4_t{pack2(acc[i][0][0], acc[i][0][1]), pack2(acc[i][0][2], acc[i][0][3]),
                                     pack2(acc[i][1][0], acc[i][1][1]), pack2(acc[i][1][2], acc[i][1][3])});
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight fragments prefetched for a tile that does not exist
 }
 
 int g_cus_w2 = 0;

@@ -51,6 +51,29 @@ __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, 
 __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t, uint32_t, uint32_t) { return make_uint4(0, 0, 0, 0); }
 #endif
 
+// Weight fragments of the stride-1 kernel are loaded by INLINE ASM and waited for with hand-counted `s_waitcnt vmcnt(N)` (round 4;
+// conv2x2_win.hip has the full note): with the compiler's own loads the conditional window fill in front of a slab made its
+// scoreboard merge conservative, and the first k-step of every other slab waited `vmcnt(2)` = for the window pieces of the NEXT
+// slab issued a few instructions earlier (tools/audit_vmcnt.py).  The rules that keep this safe are in conv2x2_win.hip: a fragment
+// register is read only by the MFMAs of its k-step, each of which consumes a pixel fragment that went through wait_lgkm behind
+// wait_vm; the load of k-step k + PF goes into the registers of k-step k behind that step's last MFMA.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t rsrc_words(const void *base, uint32_t bytes) {   // raw buffer descriptor: base, no stride, size, 32-bit raw data format
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+// ("s_nop 4": the hazard recognizer does not look into inline asm.  The scalar offset / descriptor may have been written by a
+//  VALU instruction just before -- hipcc restores spilled SGPRs with v_readlane_b32 -- and a VMEM instruction needs 5 wait states
+//  behind a VALU write of an SGPR it reads: without them the loads of the tail-mode kernel used a stale offset (wrong weights) and
+//  conv1x1_win a stale descriptor (memory fault).)
+__device__ __forceinline__ void wload16(u32x4_t &d, i32x4_t r, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen ; wfrag" : "=&v"(d) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {   // (does not name the fragment registers: conv2x2_win.hip, rule (ii))
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int OFF>
 __device__ __forceinline__ u32x4_t lds_read16_imm(uint32_t addr) {
     u32x4_t v;
@@ -140,8 +163,9 @@ __device__ __forceinline__ void mma_chain(f32x4_t (&acc)[G::MT][2], u32x4_t (&av
     }
 }
 
-template <class G, int PAR, int TAP, int DBG>
-__device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t (&a_base)[G::MT], const uint4 &b0, const uint4 &b1) {
+// NVM >= 0: b0 / b1 come from asm loads (wload16): wait until at most NVM younger vector-memory operations are outstanding
+template <class G, int PAR, int TAP, int DBG, int NVM = -1, class B>
+__device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t (&a_base)[G::MT], B &b0, B &b1) {
     constexpr int MT = G::MT;
     constexpr int OFF = PAR * G::WIN_BYTES + G::tap_off(TAP);
     u32x4_t av[MT];
@@ -151,6 +175,7 @@ __device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t 
         else av[i] = lds_read16_imm<OFF>(a_base[i]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NVM >= 0) wait_vm<NVM>();
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
     mma_chain<G, DBG, 0>(acc, av, bf0, bf1);
 }
@@ -187,8 +212,7 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(co
     const int img0 = G::IMGS > 1 ? mtile * G::IMGS : mtile / G::TILES_PER_IMG;
     const int row0 = G::IMGS > 1 ? 0 : (mtile % G::TILES_PER_IMG) * G::ROWS;
 
-    const buf_rsrc_t rs_x = make_rsrc(p.x, p.x_bytes);
-    const buf_rsrc_t rs_w = make_rsrc(p.w, p.w_bytes);
+    const i32x4_t rs_w = rsrc_words(p.w, p.w_bytes);
 
     // window fill: wave w fills plane w (chunk w of every row); piece j = window rows [64 j, 64 j + 64).  The per-lane
     // source offsets stay in registers: recomputing them per slab (~25 vector instructions per piece) cost 10 - 20 % of
@@ -203,7 +227,10 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(co
         const bool ok = (wr < G::WROWS) & (img < p.N) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
         pw_vo[j] = ok ? (uint32_t)((((img * H + ih) * W + iw) * Cin) * 2 + wave * 16) : OOB;
     }
+    // (EVERY slab start issues its NRG pieces -- the k-steps' vmcnt budgets count them: behind the last slab they come from a
+    //  zero-sized descriptor, i.e. zeros into the dead buffer)
     auto issue_window = [&](int cb, int par) {
+        const buf_rsrc_t rs_x = make_rsrc(p.x, cb < NS ? p.x_bytes : 0u);
 #pragma unroll
         for (int j = 0; j < G::NRG; ++j)
             buf_load_lds16(rs_x, (lds_ptr_t)(smem + par * G::WIN_BYTES + wave * G::PLANE + j * 1024), pw_vo[j], (uint32_t)cb * 64u);
@@ -225,10 +252,10 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(co
     const uint32_t b_step = (uint32_t)(Cout >> 4) * 1024u;
     const uint32_t KT = (uint32_t)NS * 9u;
     const uint32_t b_so0 = (uint32_t)(n0 >> 4) * 1024u;
-    auto fetch_b = [&](uint32_t kt, uint4 &b0, uint4 &b1) {   // (past the end: the last k-step again, never used)
+    auto fetch_b = [&](uint32_t kt, u32x4_t &b0, u32x4_t &b1) {   // (past the end: the last k-step again, never used)
         const uint32_t so = b_so0 + (kt < KT - 1u ? kt : KT - 1u) * b_step;
-        b0 = buf_load16(rs_w, b_vo, so);
-        b1 = buf_load16(rs_w, b_vo, so + 1024u);
+        wload16(b0, rs_w, b_vo, so);
+        wload16(b1, rs_w, b_vo, so + 1024u);
     };
 
     f32x4_t acc[MT][2];
@@ -239,22 +266,24 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(co
     }
 
     issue_window(0, 0);
-    uint4 bq[PF][2];
+    u32x4_t bq[PF][2];
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch_b((uint32_t)s, bq[s][0], bq[s][1]);
 
+    // k-step TAP: its fragments were fetched PF k-steps ago, behind them the 2 (PF - 1) loads of the steps in between and -- for
+    // the first PF taps of a slab -- the NRG window pieces of this slab's start; the fetch of k-step + PF goes into the same
+    // registers behind the step's last MFMA
 #define SC2_WIN_STEP(PAR, cb, TAP, SLOT)                                              \
     {                                                                                 \
-        const uint4 b0 = bq[SLOT][0], b1 = bq[SLOT][1];                               \
+        k_step<G, PAR, TAP, DBG, (DBG & 3) ? 0 : 2 * (PF - 1) + (TAP < PF ? G::NRG : 0)>(acc, a_base, bq[SLOT][0], bq[SLOT][1]); \
         if constexpr (!(DBG & 2)) fetch_b((uint32_t)(cb) * 9u + (TAP + PF), bq[SLOT][0], bq[SLOT][1]); \
-        k_step<G, PAR, TAP, DBG>(acc, a_base, b0, b1);                                \
     }
 #define SC2_WIN_SLAB(PAR, cb)                                                                           \
     {                                                                                                   \
         /* this wave's share of window cb has landed: it is older than the 2 PF weight loads in flight */ \
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PF) : "memory");                                    \
         if constexpr (!(DBG & 8)) __builtin_amdgcn_s_barrier();   /* window cb complete; everybody is done with window cb - 1 */ \
-        if constexpr (!(DBG & 1)) { if ((cb) + 1 < NS) issue_window((cb) + 1, 1 - PAR); }                \
+        if constexpr (!(DBG & 1)) issue_window((cb) + 1, 1 - PAR);                                       \
         SC2_WIN_STEP(PAR, cb, 0, 0) SC2_WIN_STEP(PAR, cb, 1, 1) SC2_WIN_STEP(PAR, cb, 2, 2)              \
         SC2_WIN_STEP(PAR, cb, 3, 0) SC2_WIN_STEP(PAR, cb, 4, 1) SC2_WIN_STEP(PAR, cb, 5, 2)              \
         SC2_WIN_STEP(PAR, cb, 6, 0) SC2_WIN_STEP(PAR, cb, 7, 1) SC2_WIN_STEP(PAR, cb, 8, 2)              \
@@ -265,6 +294,12 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(co
     }
 #undef SC2_WIN_SLAB
 #undef SC2_WIN_STEP
+    // The last PF k-steps fetched "the last k-step again" (never used): those loads are still in flight here, and the compiler
+    // regards their registers as dead -- the epilogue's store addresses computed into them were overwritten when the loads
+    // landed (memory access faults at bs 256, where they land late).  The wait names the registers, which keeps them allocated
+    // up to it.
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(bq[0][0]), "+v"(bq[0][1]), "+v"(bq[1][0]), "+v"(bq[1][1]), "+v"(bq[2][0]), "+v"(bq[2][1])::"memory");
 
     // epilogue: lane (frow, fq) holds, for row tile i, output channels n0 + 8 fq + [0, 4) in acc[i][0] and + [4, 8) in acc[i][1]
     // (the packing permutes the weight rows that way) of pixel i * 16 + frow

@@ -40,6 +40,34 @@
 
 namespace {
 
+// gamma fragments of phase 2 are loaded by INLINE ASM into a three-step register ring and waited for with hand-counted
+// `s_waitcnt vmcnt(N)` (round 4).  Before, the ring was two steps deep on compiler-tracked loads: a step's fragments were
+// requested one step (32 MFMAs) before their use and every step drained vmcnt to 0 (tools/audit_vmcnt.py) -- the L2 round trip
+// was exposed whenever the partner wave of the SIMD was not exactly in antiphase (phase 2: 70 % MFMA-busy, tools/dec_stamps.py).
+// The loads of step k + 3 go into the registers of step k behind that step's last MFMA (two whole steps = 64 MFMAs of this
+// wave, ~2 k cycles with its partner, between request and use); vmcnt retires in issue order, so the wait for step k is "all
+// but the 8 loads of the two steps behind it".
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t rsrc_words(const void *base, uint32_t bytes) {   // raw buffer descriptor: base, no stride, size, 32-bit raw data format
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    return i32x4_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+// ("s_nop 4": the hazard recognizer does not look into inline asm.  The scalar offset / descriptor may have been written by a
+//  VALU instruction just before -- hipcc restores spilled SGPRs with v_readlane_b32 -- and a VMEM instruction needs 5 wait states
+//  behind a VALU write of an SGPR it reads: without them the loads of the tail-mode kernel used a stale offset (wrong weights) and
+//  conv1x1_win a stale descriptor (memory fault).)
+__device__ __forceinline__ void wload16(u32x4_t &d, i32x4_t r, uint32_t voff, uint32_t soff) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen ; wfrag" : "=&v"(d) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+// (the wait does not name the fragment registers -- as tied operands the compiler may copy them in front of the wait, i.e.
+//  while their loads are in flight: conv2x2_win.hip, rule (ii).  The MFMAs of a step consume |t| fragments read from LDS by
+//  ordinary loads, which the "memory" clobber keeps behind the wait.)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 struct DecArgs {
     const uint16_t *__restrict__ x;      // bf16 NHWC [N,H,W,CIN]
     const uint16_t *__restrict__ w;      // packed bf16 [512][Kpad], k = (kh*2+kw)*CIN + ci
@@ -87,8 +115,10 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
     };
 
     // this thread's share of a tile's patch: chunk (row = tid >> 2, c = tid & 3) of each of the KS1 slabs
-    const int prow = tid >> 2, pc = tid & 3;
+    const int prow = tid >> 2, pc_lane = tid & 3;
     auto load_patch = [&](int tile, uint4 (&pv)[KS1]) {
+        int pc = pc_lane;   // (opaque per call: hoisted out of the tile loop, the per-slab source pointers derived from it were spilled)
+        asm volatile("" : "+v"(pc));
         const int m = tile * BM + prow;
         const bool m_ok = (tile < p.n_tiles) & (m < p.M);
         const int mm = m_ok ? m : 0;
@@ -107,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
     };
     auto store_patch = [&](const uint4 (&pv)[KS1]) {
 #pragma unroll
-        for (int s = 0; s < KS1; ++s) *reinterpret_cast<uint4 *>(patch + s * 8192 + slab_off(prow, pc)) = pv[s];
+        for (int s = 0; s < KS1; ++s) *reinterpret_cast<uint4 *>(patch + s * 8192 + slab_off(prow, pc_lane)) = pv[s];
     };
 
     int tile = blockIdx.x;
@@ -118,21 +148,22 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
     }
     __syncthreads();
 
-    const uint16_t *wrow[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) wrow[j] = p.w + (long long)(wn * WN + j * 16 + frow) * p.Kpad + fq * 8;
-    // this lane's 16 bytes of fragment (channel tile wn*4 + j, step ks): gfrag[(j * 16 + ks) * 64]
-    const uint4 *gfrag = reinterpret_cast<const uint4 *>(p.g) + (long long)(wn * NT) * (CH / 32) * 64 + lane;
 
     // W0 fragments of this wave (its 64 channels x K): the same for every tile, but 48 registers are too many to
     // hold through phase 2, so they are re-fetched (L2) per tile - issued BEFORE the previous tile's output stores so
     // that waiting for them never waits for those stores (vmcnt retires in issue order).
     uint4 wv[KS1][NT];
     auto load_w = [&]() {
+        // (row pointers rebuilt per call from an opaque copy of the lane's fragment coordinates: eight registers of pointers
+        //  held across phase 2 pushed loop invariants of the patch loader into scratch once the gamma ring grew)
+        int fr = frow, fk = fq;
+        asm volatile("" : "+v"(fr), "+v"(fk));
 #pragma unroll
-        for (int s = 0; s < KS1; ++s)
+        for (int j = 0; j < NT; ++j) {
+            const uint16_t *wrow = p.w + (long long)(wn * WN + j * 16 + fr) * p.Kpad + fk * 8;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) wv[s][j] = *reinterpret_cast<const uint4 *>(wrow[j] + s * 32);
+            for (int s = 0; s < KS1; ++s) wv[s][j] = *reinterpret_cast<const uint4 *>(wrow + s * 32);
+        }
     };
     load_w();
 
@@ -193,42 +224,56 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
         // such load touch 16 lines for 64 bytes each, and the phase ran at the vector L1's request rate: 2.7k cycles
         // per 32-deep step against 1k of MFMA issue - tools/dec_stamps.py.)  gb[h] holds step 2d + h and is
         // re-filled for step 2d + 2 + h as soon as its MFMAs have been issued.
-        constexpr int NS = CH / 32;
-        uint4 gb[2][NT];
+        constexpr int NS = CH / 32, GR = 3;   // k-steps; depth of the gamma ring (four steps deep the kernel spilled)
+        // fragment (channel tile wn * 4 + j, step ks) of this lane: 16 bytes at ((wn * 4 + j) * NS + ks) * 1024 + lane * 16
+        const i32x4_t rs_g = rsrc_words(p.g, (uint32_t)(CH / 16) * NS * 1024u);
+        const uint32_t g_vo = (uint32_t)(lane * 16);
+        const uint32_t g_so0 = (uint32_t)(wn * NT) * NS * 1024u;
+        u32x4_t gb[GR][NT];
+        auto fetch_g = [&](int ks, u32x4_t (&g)[NT]) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < NT; ++j) wload16(g[j], rs_g, g_vo, g_so0 + (uint32_t)(j * NS + ks) * 1024u);
+        };
 #pragma unroll
-            for (int j = 0; j < NT; ++j) gb[h][j] = gfrag[(j * NS + h) * 64];
+        for (int h = 0; h < GR; ++h) fetch_g(h, gb[h]);
+        // one k-step: YOUNG = loads issued behind this step's own four (the steps still in flight behind it)
+#define SC2_DEC_STEP(ks, h, YOUNG)                                                                                           \
+    {                                                                                                                        \
+        const int kc = (ks) * 4 + fq;   /* this lane's 16-byte k chunk of the step */                                        \
+        const int rd_lane = frow * (CH * 2) + ((kc ^ frow) << 4);   /* + i*16384 */                                          \
+        const int rd_hi = hi(rd_lane);                                                                                       \
+        wait_vm<YOUNG>();                                                                                                    \
+        bf16x8_t gf[NT];                                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) gf[j] = __builtin_bit_cast(bf16x8_t, gb[h][j]);                       \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                     \
+            uint4 v = *reinterpret_cast<const uint4 *>(img + (i < 4 ? rd_lane : rd_hi) + (i & 3) * 16384);                   \
+            v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu;   /* |t| */                      \
+            const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, v);                                                             \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                   \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[j], xf, acc[i][j], 0, 0, 0);                          \
+            if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                                    \
+    }
+        static_assert(NS == 16 && GR == 3, "four trips of three steps, then steps 12 .. 15");
 #pragma unroll 1
-        for (int d = 0; d < NS / 2; ++d) {
+        for (int d = 0; d < 4; ++d) {
             // the two waves of a SIMD (w and w + 4) take turns at priority: with a fixed priority (or none: age decides)
             // one of them runs the phase at full speed and the other finishes what is left alone, at half speed
-            if (((d >> 1) ^ (wn >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+            if ((d ^ (wn >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int kc = (2 * d + h) * 4 + fq;   // this lane's 16-byte k chunk of step 2d + h
-                const int rd_lane = frow * (CH * 2) + ((kc ^ frow) << 4);   // + i*16384
-                const int rd_hi = hi(rd_lane);
-                bf16x8_t gf[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) gf[j] = __builtin_bit_cast(bf16x8_t, gb[h][j]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    uint4 v = *reinterpret_cast<const uint4 *>(img + (i < 4 ? rd_lane : rd_hi) + (i & 3) * 16384);
-                    v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu;   // |t|
-                    const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, v);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[j], xf, acc[i][j], 0, 0, 0);
-                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-                if (d + 1 < NS / 2) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) gb[h][j] = gfrag[(j * NS + 2 * d + 2 + h) * 64];
-                }
-            }
+            SC2_DEC_STEP(GR * d + 0, 0, 2 * NT) fetch_g(GR * d + GR + 0, gb[0]);
+            SC2_DEC_STEP(GR * d + 1, 1, 2 * NT) fetch_g(GR * d + GR + 1, gb[1]);
+            SC2_DEC_STEP(GR * d + 2, 2, 2 * NT) fetch_g(GR * d + GR + 2, gb[2]);
         }
+        {   // steps 12 .. 15: only step 12 still fetches (step 15)
+            if ((wn >> 2) & 1) __builtin_amdgcn_s_setprio(0);
+            else __builtin_amdgcn_s_setprio(1);
+            SC2_DEC_STEP(12, 0, 2 * NT) fetch_g(15, gb[0]);
+            SC2_DEC_STEP(13, 1, 2 * NT)
+            SC2_DEC_STEP(14, 2, 1 * NT)
+            SC2_DEC_STEP(15, 0, 0)
+        }
+#undef SC2_DEC_STEP
         __builtin_amdgcn_s_setprio(0);
         STAMP(3);
         // Loads issued here, in this order (vmcnt retires in issue order): beta for the epilogue below, then this

@@ -85,6 +85,28 @@ def test_raw_claim_atomics_are_read_behind_their_wait():
     assert r.stdout.count('ok ') >= 14 and 'BAD' not in r.stdout, r.stdout
 
 
+def test_asm_weight_loads_are_never_copied_in_flight():
+    """The window-plane kernels and the fused decoder head load their weight fragments by inline asm and wait for them
+    with hand-counted `s_waitcnt vmcnt(N)` (the compiler's scoreboard turned the prefetch into a drain of freshly issued
+    window pieces).  What the compiler does not know is that such a register is valid only behind its wait: a copy or
+    a spill placed between the load and the wait reads stale data (seen: a tied wait operand made hipcc copy the
+    fragment IN FRONT of the wait; the forward-GDN1 variant spilled fragments across its epilogue).
+    tools/audit_vmcnt.py --copies compiles the kernels to ISA and follows every marked load (`; wfrag`) through the
+    control-flow graph to its first MFMA: nothing else may read the register on the way."""
+    import os
+    import subprocess
+    import sys
+    if not os.path.exists('/opt/rocm/bin/hipcc'):
+        import pytest
+        pytest.skip('hipcc not available')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, 'sc2-benchmark_amd', 'csrc')
+    files = [os.path.join(csrc, f) for f in ('conv2x2_win.hip', 'conv3x3_win.hip', 'conv1x1_win.hip', 'conv_gdn512.hip')]
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_vmcnt.py'), '--copies'] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(': ok') == len(files) and 'COPY?' not in r.stdout, r.stdout
+
+
 def test_hot_path_kernels_use_no_scratch():
     """Read from the built library's code objects (tools/kernel_resources.py): no kernel of the default path may spill
     to scratch.  (A shared-header edit once demoted the 256-wide decoder kernels' accumulators to 528 B / lane of

@@ -1,0 +1,197 @@
+"""Development aid: lists the s_waitcnt vmcnt(N) of every loop of every kernel in a hipcc -S listing, with the number of
+MFMAs and vector-memory instructions since the previous wait.  A small N in a K loop whose operands are fetched several
+k-steps ahead means the compiler's scoreboard merge (conditional loads, loop back edges) has turned the prefetch into a
+full drain: the case found in conv2x2_win (round 4: `vmcnt(2)` at every other slab = a wait for the window pieces issued
+a few instructions earlier).
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip --cuda-device-only -S csrc/<file>.hip -o /tmp/f.s
+    python tools/audit_vmcnt.py /tmp/f.s [kernel-name substring]
+    python tools/audit_vmcnt.py --copies csrc/<file>.hip [...]     (compiles; exit status 1 on a finding)
+
+--copies: the second hazard of hand-counted waits.  A register written by an inline-asm `buffer_load_dwordx4` (between
+;;#ASMSTART / ;;#ASMEND) holds its value only once the load has landed, which the compiler does not know: any instruction
+other than an MFMA that READS such a register (a v_mov the register allocator placed to satisfy a tied operand or a phi)
+may copy it while the load is in flight.  The kernels mark their weight-fragment loads with the asm comment `; wfrag`; the
+check walks each kernel's listing in layout order, keeps a register 'hot' from a marked load until some other instruction
+writes it, and reports every instruction but a v_mfma that reads a hot register.
+"""
+import re
+import sys
+
+
+def kernels(path):
+    name, body = None, []
+    for line in open(path):
+        m = re.match(r'^(_Z\w+):', line)
+        if m:
+            if name:
+                yield name, body
+            name, body = m.group(1), []
+        elif name is not None:
+            if line.startswith('.Lfunc_end'):
+                yield name, body
+                name, body = None, []
+            else:
+                body.append(line.rstrip('\n'))
+    if name:
+        yield name, body
+
+
+def audit(body):
+    out = []
+    mfma = vmem = dma = 0
+    depth = 0
+    for i, ln in enumerate(body):
+        s = ln.strip()
+        m = re.search(r'Depth=(\d+)', ln)
+        if s.startswith('.LBB') and m:
+            depth = int(m.group(1))
+        elif s.startswith('.LBB'):
+            depth = 0
+        if s.startswith('v_mfma'):
+            mfma += 1
+        elif re.match(r'(buffer|global)_(load|store|atomic)', s):
+            if ' lds' in s:
+                dma += 1
+            else:
+                vmem += 1
+        w = re.search(r'vmcnt\((\d+)\)', s)
+        if w or s.startswith('s_barrier'):
+            out.append((i, depth, 'vmcnt(%s)' % w.group(1) if w else 'barrier', mfma, vmem, dma))
+            mfma = vmem = dma = 0
+    return out
+
+
+def regs_of(tok):
+    m = re.match(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'v(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+
+
+def audit_copies(body):
+    """-> list of (line, text) of instructions that may read a weight-fragment register while its load is in flight.
+
+    Dataflow over the kernel's control-flow graph (labels, s_branch / s_cbranch_*): a register becomes HOT at a marked asm load
+    (`; wfrag`) that writes it and stays hot until (a) another instruction writes it, or (b) a v_mfma reads it -- by the kernels'
+    discipline the first MFMA that reads a fragment sits behind the counted wait for it, so from there on the value has landed
+    and later copies are harmless.  Any other instruction that reads a hot register is reported (a v_mov or a scratch store the
+    register allocator placed between a load and its wait), and so is any instruction that WRITES one: the load overwrites the
+    new value when it lands (seen: fetches "past the end" that nothing consumes, their registers reused by the epilogue).
+    `s_waitcnt vmcnt(0)` clears every register."""
+    # ---- instructions and blocks
+    insts = []   # (line index, text, is_marked_load, in_asm)
+    inasm = False
+    for i, ln in enumerate(body):
+        s = ln.strip()
+        if s.startswith(';;#ASMSTART'):
+            inasm = True
+            continue
+        if s.startswith(';;#ASMEND'):
+            inasm = False
+            continue
+        if not s or s[0] == ';' or (s[0] == '.' and not s.startswith('.LBB')):
+            continue
+        insts.append((i, s, inasm))
+    if not any(a and t.startswith('buffer_load_dwordx4') and 'wfrag' in t for _, t, a in insts):
+        return []
+    blocks, cur, label_of = [], None, {}
+    for idx, (i, t, a) in enumerate(insts):
+        if t.startswith('.LBB'):
+            name = t.split(':')[0]
+            cur = {'name': name, 'insts': [], 'succ': []}
+            label_of[name] = len(blocks)
+            blocks.append(cur)
+            continue
+        if cur is None:
+            cur = {'name': '<entry>', 'insts': [], 'succ': []}
+            blocks.append(cur)
+        cur['insts'].append((i, t, a))
+        if t.startswith('s_cbranch') or t.startswith('s_branch') or t.startswith('s_endpgm'):
+            nxt = {'name': '<ft%d>' % len(blocks), 'insts': [], 'succ': []}
+            cur['term'] = t
+            blocks.append(nxt)
+            cur = nxt
+    for b, blk in enumerate(blocks):
+        term = blk.get('term', '')
+        if term.startswith('s_endpgm'):
+            continue
+        if term.startswith('s_branch') or term.startswith('s_cbranch'):
+            tgt = term.split()[1]
+            if tgt in label_of:
+                blk['succ'].append(label_of[tgt])
+        if not term.startswith('s_branch') and b + 1 < len(blocks):
+            blk['succ'].append(b + 1)
+
+    def step(t, a, hot, report, i):
+        toks = t.replace(',', ' ').split()
+        op, args = toks[0], toks[1:]
+        if a and op == 'buffer_load_dwordx4' and 'wfrag' in t:
+            return hot | regs_of(args[0])
+        if op == 's_waitcnt' and 'vmcnt(0)' in t:
+            return set()   # everything has landed
+        if op.startswith('s_'):
+            return hot
+        is_store = op.startswith(('buffer_store', 'global_store', 'ds_write', 'flat_store', 'scratch_store'))
+        dst = set() if is_store or op.startswith('s_') else (regs_of(args[0]) if args else set())
+        srcs = set()
+        for x in (args if is_store else args[1:]):
+            srcs |= regs_of(x)
+        if op.startswith('v_mfma'):
+            if (dst & (hot - srcs)) and report is not None:
+                report.append((i, t + '   <- overwrites a register whose load is in flight'))
+            return hot - srcs - dst
+        if ((srcs | dst) & hot) and report is not None:
+            report.append((i, t + ('   <- overwrites a register whose load is in flight' if dst & hot else '')))
+        return hot - dst
+
+    # ---- fixpoint of the hot set at block entry (union over predecessors)
+    hot_in = [set() for _ in blocks]
+    work = list(range(len(blocks)))
+    while work:
+        b = work.pop()
+        hot = set(hot_in[b])
+        for i, t, a in blocks[b]['insts']:
+            hot = step(t, a, hot, None, i)
+        for sidx in blocks[b]['succ']:
+            if not hot <= hot_in[sidx]:
+                hot_in[sidx] |= hot
+                work.append(sidx)
+    out = []
+    for b, blk in enumerate(blocks):
+        hot = set(hot_in[b])
+        for i, t, a in blk['insts']:
+            hot = step(t, a, hot, out, i)
+    return sorted(set(out))
+
+
+if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == '--copies':
+        import os
+        import subprocess
+        import tempfile
+        bad = 0
+        for src in sys.argv[2:]:
+            out = os.path.join(tempfile.gettempdir(), os.path.basename(src) + '.audit.s')
+            subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-D__HIP_PLATFORM_AMD__=1', '-x', 'hip',
+                                   '-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)
+            n_file = 0
+            for name, body in kernels(out):
+                found = audit_copies(body)
+                for i, text in found[:6]:
+                    print('COPY? %s line %d: %s' % (name[:90], i, text))
+                if len(found) > 6:
+                    print('       ... %d more in this kernel' % (len(found) - 6))
+                n_file += len(found)
+            bad += n_file
+            print('%s: %s' % (os.path.basename(src), 'ok' if not n_file else '%d findings' % n_file))
+        sys.exit(1 if bad else 0)
+    pat = sys.argv[2] if len(sys.argv) > 2 else ''
+    for name, body in kernels(sys.argv[1]):
+        if pat not in name:
+            continue
+        print('==', name)
+        for i, depth, what, mfma, vmem, dma in audit(body):
+            if depth > 0:
+                print('  line %5d depth %d %-10s after %3d mfma, %2d vmem, %2d lds-dma' % (i, depth, what, mfma, vmem, dma))

@@ -31,5 +31,6 @@ for trial in range(3):
         tot += d.shape[0]
         if d.shape[0]:
             print('trial', trial, 'rep', rep, 'diff', d.shape[0], 'tiles', sorted(set((d[:, 0] * 14 + d[:, 1] // 4).tolist())),
-                  'chans', sorted(set((d[:, 3] // 32).tolist())), 'e', sorted(set((d[:, 3] % 8).tolist())))
+                  'chans', sorted(set((d[:, 3] // 32).tolist())), 'e', sorted(set((d[:, 3] % 8).tolist())),
+                  'rows%4', sorted(set((d[:, 1] % 4).tolist())), 'cols', sorted(set(d[:, 2].tolist()))[:20])
 print('run', os.environ['SC2_W2_RUN'], 'fused', fused, 'cin', cin, 'total differing elements', tot)

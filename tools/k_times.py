@@ -1,0 +1,103 @@
+"""Development aid: stand-alone HIP-event timings of the bottleneck's launches (and optionally the head) at bs x 224 x 224,
+the few rows an A/B of two library builds needs (SC2_LIB=tools/variants/lib_<name>.so selects the build):
+
+    python tools/k_times.py [--bs 256] [--iters 20] [--head] [--only dec]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sc2bench_amd as S  # noqa: E402
+from sc2bench_amd import hip  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--bs', type=int, default=256)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--head', action='store_true')
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    m = S.FPBasedResNetBottleneck().eval().to(dev)
+    N = args.bs
+    rows = []
+
+    def row(name, fn, flops):
+        if args.only and args.only not in name:
+            return
+        rows.append((name, timeit(fn, args.iters), flops))
+
+    with torch.no_grad():
+        e0, g1, e2, g3, e4 = m.encoder
+        d0, h1, d2, h3, d4 = m.decoder
+        x = torch.rand(N, 3, 224, 224, device=dev)
+        x4 = hip.nchw_f32_to_nhwc_bf16(x, 4)
+        xp = x4.view(N, 224, 112, 8)
+        row('enc.nchw->nhwc4', lambda: hip.nchw_f32_to_nhwc_bf16(x, 4), 0)
+        beta_g1, gamma_g1 = g1.effective_fragments()
+        wf0 = m._conv0_fragments()
+        a1 = hip.conv0_gdn96_fwd(xp, wf0, gamma_g1, beta_g1)
+        row('enc.conv0+gdn96', lambda: hip.conv0_gdn96_fwd(xp, wf0, gamma_g1, beta_g1), (180.6e6 + 231.2e6) * N)
+        beta_g3, gamma_g3 = g3.effective()
+        wq48 = e2.packed_weight(hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR)
+        gf48 = hip.pack_weight_fragments(gamma_g3)
+        a3 = hip.conv2_gdn48_fwd(a1, wq48, gf48, beta_g3)
+        row('enc.conv2+gdn48', lambda: hip.conv2_gdn48_fwd(a1, wq48, gf48, beta_g3), (722.5e6 + 14.5e6) * N)
+        row('enc.conv4', lambda: e4.forward_nhwc(a3, out_format=hip.OUT_F32_NCHW), 27.9e6 * N)
+        row('enc.analysis()', lambda: m.analysis(x), 1177e6 * N)
+        yh = torch.randn(N, 55, 55, 24, device=dev).to(torch.bfloat16)
+        beta1, gamma1 = h1.effective_fragments()
+        w0t = d0.packed_weight(hip.K_TAP_MAJOR)
+        b1 = hip.conv2x2_gdn512_fwd(yh, w0t, gamma1, beta1, True)
+        row('dec.conv0+igdn512', lambda: hip.conv2x2_gdn512_fwd(yh, w0t, gamma1, beta1, True), (308.3e6 + 1644.2e6) * N)
+        beta3w, w2f = m._win_weights(d2, h3)
+        w2p = hip.pack_conv2x2_win(d2.weight)
+        row('dec.conv2 (win)', lambda: hip.conv2x2_win_fwd(b1, w2p, 0), 3171.9e6 * N)
+        b3 = hip.conv2x2_win_fwd(b1, w2f, 0, beta=beta3w, inverse=True)
+        row('dec.conv2+igdn256 (win)', lambda: hip.conv2x2_win_fwd(b1, w2f, 0, beta=beta3w, inverse=True), (3171.9e6 + 396.5e6) * N)
+        w4p = m._win_weights(d4, None)[1]
+        row('dec.conv4 (win)', lambda: hip.conv2x2_win_fwd(b3, w4p, 1), 1644.2e6 * N)
+        w1 = (torch.randn(128, 256, device=dev) / 16.0).to(torch.bfloat16)
+        wds = (torch.randn(512, 256, device=dev) / 16.0).to(torch.bfloat16)
+        bias1, biasd = torch.randn(128, device=dev), torch.randn(512, device=dev)
+        tail = hip.pack_conv2x2_win_tail(d4.weight.detach(), w1, wds)
+        row('dec.conv4+head.2.0 (tail)', lambda: hip.conv2x2_win_tail_fwd(b3, tail, bias1, biasd), (1644.2e6 + 205.5e6 + 205.5e6) * N)
+        m.output_format = 'bf16_nhwc'
+        row('dec.synthesis()', lambda: m.synthesis_nhwc(yh), 7165e6 * N)
+    if args.head:
+        import bench as B
+        full = B.build_model(dev)
+        with torch.no_grad():
+            feat = torch.randn(N, 56, 56, 256, device=dev).to(torch.bfloat16)
+            xh = feat.permute(0, 3, 1, 2)
+            row('head(hip)()', lambda: full.head(xh), 6.6e9 * N)
+    print('{:<28}{:>10}{:>12}{:>10}'.format('kernel', 'ms', 'TFLOP/s', 'of 2.5PF'))
+    for name, ms, flops in rows:
+        print('{:<28}{:>10.4f}{:>12.1f}{:>10.3f}'.format(name, ms, flops / ms / 1e9, flops / ms / 1e9 / 2500.0))
+    enc = [r for r in rows if r[0] == 'enc.analysis()']
+    dec = [r for r in rows if r[0] == 'dec.synthesis()']
+    if enc and dec:
+        t = enc[0][1] + dec[0][1]
+        print('bottleneck forward {:.4f} ms = {:.1f} TFLOP/s = {:.3f} of the bf16 peak'.format(t, 8.3418e9 * N / t / 1e9, 8.3418e9 * N / t / 1e9 / 2500.0))
+
+
+if __name__ == '__main__':
+    main()
