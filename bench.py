@@ -222,12 +222,15 @@ def precision_check(model, x_dev, dev, n=64):
     n = min(n, x_dev.shape[0])
     x = x_dev[:n].float().cpu()
     eb, reb = model.bottleneck_layer.entropy_bottleneck, ref.bottleneck_layer.entropy_bottleneck
+    pix = x.shape[-1] * x.shape[-2]
     with torch.no_grad():
-        ref_sym = torch.cat([reb.symbols(ref.bottleneck_layer.encoder(x[i:i + 16])) for i in range(0, n, 16)]).reshape(n, -1)
+        ref_lat = torch.cat([ref.bottleneck_layer.encoder(x[i:i + 16]) for i in range(0, n, 16)])
+        ref_sym = reb.symbols(ref_lat).reshape(n, -1)
+        # estimated rate = what BppLoss trains (sc2bench/loss.py:20-37), in eval mode: -sum log2 p(round(y - m) + m) / pixels
+        ref_bpp_est = float(-torch.log2(reb(ref_lat)[1]).sum().item()) / (n * pix)
     hw = None
     out = {'images': n, 'what': 'same images, same weights: f32 CPU oracle encoder vs the device encoders; bpp from the '
                                 'streams each one codes (device coder == oracle coder byte for byte given the symbols)'}
-    pix = x.shape[-1] * x.shape[-2]
     modes = {}
     for mode in ('bf16', 'f32'):
         model.set_encoder_precision(mode)
@@ -235,6 +238,9 @@ def precision_check(model, x_dev, dev, n=64):
             sym, hw = model.stage_front(x_dev[:n])
             _, _, nb, st = eb.encode_symbols_device(sym, hw[0] * hw[1])
             assert int(st.max().item()) == 0
+            # the estimated rate of the same images: eval-mode likelihoods of the f32 latent (eb_forward_kernel)
+            lik = eb(model.bottleneck_layer.analysis(x_dev[:n]))[1]
+            bpp_est = float(-torch.log2(lik.float()).sum().item()) / (n * pix)
             # encoder-stage time for the whole resident batch
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -249,12 +255,14 @@ def precision_check(model, x_dev, dev, n=64):
         modes[mode] = {'symbols': s_h, 'nbytes': nb.cpu(),
                        'row': {'symbol_mismatch_rate': diff.float().mean().item(),
                                'images_with_identical_symbols': int((~diff.any(dim=1)).sum().item()),
-                               'bpp': 8.0 * float(nb.sum().item()) / (n * pix),
+                               'bpp': 8.0 * float(nb.sum().item()) / (n * pix), 'bpp_estimated': bpp_est,
                                'encoder_stage_ms_per_batch': e0.elapsed_time(e1) / 3.0, 'batch': int(x_dev.shape[0])}}
     model.set_encoder_precision(configured)
     ref_streams = oracle_streams(ref, ref_sym, hw[0] * hw[1])
     ref_len = torch.tensor([len(q) for q in ref_streams])
-    out['reference_f32_cpu'] = {'bpp': 8.0 * float(ref_len.sum().item()) / (n * pix)}
+    out['reference_f32_cpu'] = {'bpp': 8.0 * float(ref_len.sum().item()) / (n * pix), 'bpp_estimated': ref_bpp_est}
+    out['bpp_estimated_is'] = ('-sum log2 p(y_hat) / pixels in eval mode, the quantity BppLoss trains (sc2bench/loss.py:20-37); '
+                               'bpp = 8 x bytes of the streams actually coded / pixels')
     for mode in ('bf16', 'f32'):
         row = modes[mode]['row']
         row['delta_bpp'] = row['bpp'] - out['reference_f32_cpu']['bpp']
@@ -349,6 +357,8 @@ def train_bench(args, dev, rank, world, distributed):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     assert torch.isfinite(loss)
+    # metric reduction as evaluation does it (sum of [count, total] over ranks), on the backend's device
+    g_images, g_loss = dp.all_reduce_sum_scalars([float(args.bs * args.steps), float(loss) * args.bs])
     if rank == 0:
         print(json.dumps({
             'metric': 'images/s, Entropic-Student ResNet-50 stage-{} training step, 224^2'.format(args.stage), 'value': args.bs * args.steps * world / elapsed,
@@ -359,8 +369,12 @@ def train_bench(args, dev, rank, world, distributed):
                                    'BatchNorm on torch / MIOpen ops, encoder + prior frozen, frozen teacher on the HIP stacks)' if stage2 else
                                    'stage 1 of the Entropic-Student recipe (bottleneck trains, layer2-4 frozen, frozen teacher)',
                        'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'gradient_all_reduce_bytes': stage.reducer.nbytes(),
-                       'sharding': 'images; one flat-bucket all-reduce per step'},
-            'final_loss': loss.item()}))
+                       'sharding': 'images; one flat-bucket all-reduce per step',
+                       'process_group': '{} ({} rank{})'.format(dist.get_backend(), world, '' if world == 1 else 's') if distributed else 'none',
+                       'collectives_issued': bool(dp.collectives_active()),
+                       'gradient_buckets': len(stage.reducer.buckets),
+                       'buckets_launched_from_backward_hooks_last_step': stage.reducer.launched_by_hook},
+            'final_loss': loss.item(), 'images_all_ranks': g_images, 'mean_loss_all_ranks': g_loss / max(g_images / args.steps, 1.0)}))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -479,6 +493,72 @@ def build_workload(name, dev, bs):
     raise SystemExit('unknown workload ' + name)
 
 
+def workload_cpu_baseline(name, model, x, budget_s=12.0):
+    """The oracle (CPU port, f32 torch CPU ops + the single-threaded C range coder, as upstream) on ONE image of the same
+    workload, repeated until `budget_s` seconds of CPU work have run: a reported baseline on a bounded sample (kind 'port').
+    seg513 / det800x1216: oracle bottleneck encode -> bytes -> decode, then f32 CPU copies of the model's own tail modules
+    (layer2-4 and the ASPP classifier / the FPN); fp_input: the oracle's bmshj2018_factorized + an f32 CPU copy of the classifier."""
+    import copy
+    from collections import OrderedDict
+    from oracle import cpu_ref as R
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 64))
+    torch.set_num_threads(threads)
+    x1 = x[:1].float().cpu()
+    tables = ('_offset', '_quantized_cdf', '_cdf_length')
+    with torch.no_grad():
+        if name == 'fp_input':
+            from oracle import cpu_ref_input as RI
+            codec = model.compression_model
+            ref = RI.FactorizedPrior(codec.N, codec.M)
+            ref.load_state_dict({k: v.detach().float().cpu() for k, v in codec.state_dict().items() if not k.endswith(tables)}, strict=False)
+            ref.eval()
+            ref.update(force=True)
+            clf = copy.deepcopy(model.classification_model).cpu().float().eval()
+            pre, post = model.pre_transform, model.post_transform
+
+            def run():
+                return RI.neural_input_compression_forward(pre, ref, post, clf, x1)
+            what = 'oracle bmshj2018_factorized compress -> decompress + f32 CPU classifier'
+        else:
+            body = model.body if hasattr(model, 'body') else model.backbone
+            ref_bn = R.FPBasedResNetBottleneck()
+            ref_bn.load_state_dict({k: v.detach().float().cpu() for k, v in body.bottleneck_layer.state_dict().items()
+                                    if not k.endswith(tables)}, strict=False)
+            ref_bn.eval()
+            ref_bn.update(force=True)
+            tail = [(n_, copy.deepcopy(m).cpu().float().eval()) for n_, m in body.named_children() if n_ != 'bottleneck_layer']
+            keys = {str(k): v for k, v in body.return_layer_dict.items()}
+            head = copy.deepcopy(model.classifier if name == 'seg513' else model.fpn).cpu().float().eval()
+
+            def run():
+                h = ref_bn.decode(**ref_bn.encode(x1))
+                feats = OrderedDict()
+                if 'bottleneck_layer' in keys:
+                    feats[keys['bottleneck_layer']] = h
+                for n_, m in tail:
+                    h = m(h)
+                    if n_ in keys:
+                        feats[keys[n_]] = h
+                return head(feats['out']) if name == 'seg513' else head(feats)
+            what = 'oracle bottleneck encode -> bytes -> decode + f32 CPU copies of layer2-4 and the ' + \
+                   ('ASPP classifier' if name == 'seg513' else 'FPN')
+        run()   # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            run()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or n >= 8:
+                break
+    return {'value': n / dt, 'unit': 'images/s', 'cores': threads, 'host_cpu_count': os.cpu_count(), 'kind': 'port',
+            'sample': '{} x 1 image of the same workload ({}), {:.1f} s of CPU work'.format(n, what, dt)}
+
+
 def workload_bench(args, dev, rank, world, distributed):
     """`--workload seg513 | det800x1216 | fp_input`: the module forward of that config, K steps after W warm-up steps, one
     stream, bytes objects through the host API (the reference's semantics).  Secondary figures: the headline metric and the
@@ -529,15 +609,35 @@ def workload_bench(args, dev, rank, world, distributed):
         obj = bl.compress(model.pre_transform(x)) if args.workload == 'fp_input' else bl.encode(x)
     nbytes = sum(len(q) for q in obj['strings'][0])
     pix = x.shape[-1] * x.shape[-2] * n
+    n_streams = len(obj['strings'][0])
+    sym_shape = obj.get('shape')
+    lat_c = 320 if args.workload == 'fp_input' else 24
+    sym_per_stream = lat_c * int(sym_shape[-2]) * int(sym_shape[-1]) if sym_shape is not None else None
+    on_host = n_streams <= hip.host_coder_max_streams()
+    cpu, cpu_failed = None, None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = workload_cpu_baseline(args.workload, model, x)
+        except Exception as e:   # the GPU figures are still printed, but a line without its baseline is not a result: rc != 0
+            cpu = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: {!r}'.format(e)}
+            cpu_failed = 'cpu_baseline failed: {!r}'.format(e)
     print(json.dumps({
         'metric': 'images/s + bpp, ' + args.workload, 'value': n * args.steps * world / elapsed, 'unit': 'images/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': max(1, args.warmup), 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': what, 'batch_per_gpu': n, 'global_batch': n * world, 'pipeline': 'none: module forward, one stream',
                    'streams': 'Python bytes through the host API (host coder up to {} streams, batched device coder above)'
-                              .format(hip.host_coder_max_streams()), 'sharding': 'images, no collective'},
-        'bpp': 8.0 * nbytes / pix, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': None,
+                              .format(hip.host_coder_max_streams()),
+                   'range_coder': ('HOST threads (sc2_rans_encode_host / sc2_rans_decode_host): this batch is {} streams of {} '
+                                   'symbols, a few long serial chains, which a CPU core steps faster than a GPU lane -- these are '
+                                   'NOT HIP-coder figures'.format(n_streams, sym_per_stream)) if on_host else
+                                  'batched HIP coder ({} streams per launch)'.format(n_streams),
+                   'sharding': 'images, no collective'},
+        'bpp': 8.0 * nbytes / pix, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': cpu,
         'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())}}))
+    if cpu_failed:
+        sys.stdout.flush()
+        raise SystemExit('bench.py: ' + cpu_failed)
 
 
 def self_launch(n):
@@ -612,7 +712,11 @@ def main():
         raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    distributed = world > 1
+    # one process per GPU over RCCL.  Under a launcher (torchrun exports RANK / WORLD_SIZE / MASTER_*) the process group is formed
+    # whatever the world size, so that `torch.distributed.run --nproc-per-node 1 bench.py` runs the barrier and the MAX
+    # reduction of the timing on RCCL on a one-GPU box as well (tests/test_00_rccl_gpu.py); plain `python bench.py` forms none.
+    launched = all(k in os.environ for k in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'))
+    distributed = world > 1 or launched
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
@@ -967,7 +1071,8 @@ def main():
                        'encoder_precision': args.encoder_precision + (' (f32 operands on v_mfma_f32_16x16x4_f32: bitstreams of the f32 '
                                                                       'reference path; decoder + head bf16)' if args.encoder_precision == 'f32' else
                                                                       ' MFMA operands, f32 accumulation'),
-                       'sharding': 'images, no collective'},
+                       'sharding': 'images, no collective',
+                       'process_group': '{} ({} rank{})'.format(dist.get_backend(), world, '' if world == 1 else 's') if distributed else 'none'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
             'bytes_per_image_min_mean_max': [nb_f.min().item(), bytes_per_img, nb_f.max().item()],
             'bitstream_sha256_first8': sha256_of(dev_streams),
@@ -998,6 +1103,28 @@ def main():
             out['precision_check'] = precision_check(model, x, dev)
             out['symbol_mismatch_rate'] = out['precision_check'][args.encoder_precision + '_encoder']['symbol_mismatch_rate']
             out['delta_bpp'] = out['precision_check'][args.encoder_precision + '_encoder']['delta_bpp']
+            out['bpp_estimated'] = out['precision_check'][args.encoder_precision + '_encoder']['bpp_estimated']
+        if world == 1 and not args.no_cpu_baseline and args.encoder_precision == 'bf16':
+            # the same K steps of the same pipeline with the reference-precision encoder (f32 operands on the f32 matrix cores):
+            # the mode whose bitstreams are the f32 reference path's, measured by the same command as the headline figure
+            model.set_encoder_precision('f32')
+            run_steps(warm_steps)
+            sync_all()
+            tf0 = time.perf_counter()
+            run_steps(args.steps)
+            sync_all()
+            tf1 = time.perf_counter()
+            model.set_encoder_precision('bf16')
+            _, nb32, st32 = results[0]
+            assert int(st32.max().item()) == 0, 'rANS status != 0 in an f32-mode step'
+            pc32 = out['precision_check']['f32_encoder']
+            out['f32_mode'] = {'images_per_s': args.bs * args.steps / (tf1 - tf0), 'ms_per_step': 1e3 * (tf1 - tf0) / args.steps,
+                               'steps': args.steps, 'bpp': 8.0 * nb32.float().mean().item() / (224 * 224),
+                               'bpp_estimated': pc32['bpp_estimated'], 'symbol_mismatch_rate': pc32['symbol_mismatch_rate'],
+                               'images_with_identical_symbols': '{} of {}'.format(pc32['images_with_identical_symbols'],
+                                                                                  out['precision_check']['images']),
+                               'what': 'the same pipeline with set_encoder_precision("f32"): symbols / bitstreams of the f32 reference '
+                                       'path (the residual mismatch is f32 summation order against torch CPU); decoder + head bf16'}
         if world == 1 and not args.no_bs1:
             out['bs1_eval'] = bs1_eval(model, x, dev)
         if world == 1 and not args.no_cpu_baseline:

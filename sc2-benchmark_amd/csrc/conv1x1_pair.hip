@@ -395,7 +395,6 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
     }
 }
 
-int g_cus = 0;
 constexpr int kMaxDev = 16, kRing = 256;
 unsigned *g_ring[kMaxDev] = {};
 std::atomic<unsigned> g_seq{0};
@@ -405,25 +404,27 @@ int launch_pair(const PairArgs &a, hipStream_t s) {
     constexpr int P = MT * 16;
     constexpr int lds = P * C * 2 + (K1 / 32) * P * 64 + 16 + (C + N2) * 4;
     static_assert(lds <= 160 * 1024, "image + o tile must fit the CU's LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_pair_kernel<C, K1, N2, MT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    if (g_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            n <= 0)
-            n = 256;
-        g_cus = n;
-    }
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= kMaxDev) {
         sc2_set_error("conv1x1_pair: device ordinal %d out of range", dev);
         return SC2_ERR_UNSUPPORTED;
     }
+    // per DEVICE, like the tile counters: the dynamic-LDS attribute of a function is a property of the device's code object, and
+    // a process may launch on several devices
+    static bool attr_set[kMaxDev] = {};
+    static int cus[kMaxDev] = {};
+    if (!attr_set[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_pair_kernel<C, K1, N2, MT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set[dev] = true;
+    }
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    const int g_cus = cus[dev];
     if (!g_ring[dev]) {
         void *ptr = nullptr;
         if (hipMalloc(&ptr, kRing * sizeof(unsigned)) != hipSuccess || hipMemset(ptr, 0, kRing * sizeof(unsigned)) != hipSuccess) {

@@ -187,12 +187,26 @@ constexpr int VM_STEP = 2 * (PF - 1) + 2;
 // (norm GEMM of the fused GDN1); NVM: vmcnt budget of the wait for b0 / b1 (NVM_AFTER: ... when `after` is set: the first slab
 // of a later tile, where the previous tile's output stores are younger than the fetch as well -- a branch around the wait
 // only, so that both cases are ONE instruction stream: two copies of the slab made the copy audit path-blind)
-template <int OFF, int NVM, bool ABS, int NVM_AFTER = NVM>
-__device__ __forceinline__ void mma_step(f32x4_t (&acc)[14][2], uint32_t a_base, u32x4_t &b0, u32x4_t &b1, bool after = false) {
-    u32x4_t av[7];
+//
+// Round 4: the k-steps of one slab (and the eight of the norm GEMM) are CHAINED: while row tiles 7 .. 13 are multiplied, the
+// quads they free take the NEXT step's fragments 0 .. 6 (OFF_NEXT relative to a_base_next), so that step starts with its reads
+// in flight (PRE) and every wait is lgkmcnt(6).  Before, each step began by issuing seven reads and waiting for the first:
+// with the two waves of a SIMD in lockstep behind the slab barrier nobody covered that latency (~150 - 250 cycles of every
+// ~1 500-cycle step).  The chain stops at a slab boundary: the next slab's window is complete only behind its barrier.
+#ifndef SC2_W2_CHAIN
+#define SC2_W2_CHAIN 1   // 0: every k-step reads its own first seven fragments (A/B)
+#endif
+constexpr int NO_NEXT = -1;
+template <int OFF, int NVM, bool ABS, int NVM_AFTER = NVM, bool PRE_ = false, int OFF_NEXT_ = NO_NEXT>
+__device__ __forceinline__ void mma_step(f32x4_t (&acc)[14][2], uint32_t a_base, u32x4_t &b0, u32x4_t &b1, u32x4_t (&av)[7],
+                                         bool after = false, uint32_t a_base_next = 0u) {
+    constexpr bool PRE = SC2_W2_CHAIN && PRE_;
+    constexpr int OFF_NEXT = SC2_W2_CHAIN ? OFF_NEXT_ : NO_NEXT;
+    if constexpr (!PRE) {
 #define SC2_W2_RD(i) av[i] = lds_read16_imm<OFF + (i) * 256>(a_base);
-    SC2_W2_RD(0) SC2_W2_RD(1) SC2_W2_RD(2) SC2_W2_RD(3) SC2_W2_RD(4) SC2_W2_RD(5) SC2_W2_RD(6)
+        SC2_W2_RD(0) SC2_W2_RD(1) SC2_W2_RD(2) SC2_W2_RD(3) SC2_W2_RD(4) SC2_W2_RD(5) SC2_W2_RD(6)
 #undef SC2_W2_RD
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (NVM_AFTER != NVM) {
         if (after) wait_vm<NVM_AFTER>();
@@ -203,13 +217,15 @@ __device__ __forceinline__ void mma_step(f32x4_t (&acc)[14][2], uint32_t a_base,
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
 #define SC2_W2_MMA(i, NWAIT)                                                                    \
     {                                                                                           \
-        wait_lgkm<NWAIT>(av[(i) % 7]);                                                          \
+        wait_lgkm<(OFF_NEXT != NO_NEXT) ? 6 : NWAIT>(av[(i) % 7]);                              \
         const u32x4_t m = ABS ? av[(i) % 7] & 0x7FFF7FFFu : av[(i) % 7];                        \
         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, m);                                    \
         acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[i][0], 0, 0, 0);       \
         acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[i][1], 0, 0, 0);       \
         __builtin_amdgcn_sched_barrier(0);                                                      \
         if constexpr ((i) + 7 < 14) av[(i) % 7] = lds_read16_imm<OFF + ((i) + 7 < 14 ? (i) + 7 : 0) * 256>(a_base); \
+        else if constexpr (OFF_NEXT != NO_NEXT)                                                 \
+            av[(i) % 7] = lds_read16_imm<(OFF_NEXT != NO_NEXT ? OFF_NEXT : 0) + ((i) >= 7 ? (i) - 7 : 0) * 256>(a_base_next); \
         __builtin_amdgcn_sched_barrier(0);                                                      \
     }
     SC2_W2_MMA_SEQ
@@ -319,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     };
 
     f32x4_t acc[MT][2];
+    u32x4_t av[7];   // the fragment ring (mma_step): lives across the chained k-steps
 
     window_offsets(t_first, true);
     issue_window(0, 0);
@@ -339,7 +356,9 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
 #define SC2_W2_STEP(PAR, cb, TAP, SLAB0)                                                                                \
     {                                                                                                                   \
         mma_step<PAR * G::WIN_BYTES + ((TAP / 2) * PWD + TAP % 2) * 16, VM_STEP, false,                                  \
-                 VM_STEP + (SLAB0 && WRAP && !TAIL ? NSTORE_LAST : 0)>(acc, a_base, bq[TAP][0], bq[TAP][1], !first);    \
+                 VM_STEP + (SLAB0 && WRAP && !TAIL ? NSTORE_LAST : 0), (TAP > 0),                                        \
+                 (TAP < 3 ? PAR * G::WIN_BYTES + (((TAP + 1) / 2) * PWD + (TAP + 1) % 2) * 16 : NO_NEXT)>(               \
+            acc, a_base, bq[TAP][0], bq[TAP][1], av, !first, a_base);                                                    \
         fetch_b((uint32_t)(cb) * 4u + (TAP + PF), bq[TAP][0], bq[TAP][1]);                                               \
     }
 #define SC2_W2_SLAB(PAR, cb, SLAB0)                                                                                     \
@@ -431,7 +450,9 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
             // is issued between such a step and its fetch: six younger loads)
 #define SC2_W2_NSTEP(S, BASE, OFF)                                                         \
     {                                                                                      \
-        mma_step<OFF, (!WRAP && (S) >= 4) ? 2 * (7 - (S)) : 2 * (PF - 1), !TAIL>(acc, BASE, bq[(S) & 3][0], bq[(S) & 3][1]); \
+        constexpr int nvm = (!WRAP && (S) >= 4) ? 2 * (7 - (S)) : 2 * (PF - 1);            \
+        mma_step<OFF, nvm, !TAIL, nvm, ((S) > 0), ((S) < 7 ? (((S) + 1) & 3) * 4 * G::IMG_PLANE : NO_NEXT)>(                  \
+            acc, BASE, bq[(S) & 3][0], bq[(S) & 3][1], av, false, (S) + 1 < 4 ? g_base0 : g_base1);                            \
         if constexpr (WRAP || (S) < 4) fetch_b(KT + (S) + PF, bq[(S) & 3][0], bq[(S) & 3][1]);                                \
     }
             SC2_W2_NSTEP(0, g_base0, 0 * G::IMG_PLANE) SC2_W2_NSTEP(1, g_base0, 4 * G::IMG_PLANE)

@@ -288,6 +288,11 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
                 SC2_ERR_UNSUPPORTED, "conv2d_f32: epilogue %d", d->epilogue);
     SC2_REQUIRE(!fused || (d->Cout <= 96 && ep_x && ep_beta), SC2_ERR_UNSUPPORTED,
                 "conv2d_f32: the fused GDN needs every channel of a pixel in one chunk (Cout <= 96), gamma fragments and beta");
+    // the fused norm GEMM walks chunk / 16 k-steps of gamma fragments; gamma is packed with ceil(Cout / 16) of them (a 1x1 weight
+    // of K = Cout): a narrower Cout (49 .. 80, or <= 16) would read up to 12 KB past the tensor
+    SC2_REQUIRE(!fused || (d->Cout + 15) / 16 * 16 == sc2_conv_f32_chunk_channels(d->Cout), SC2_ERR_UNSUPPORTED,
+                "conv2d_f32: the fused GDN needs ceil(Cout / 16) * 16 == the chunk width (%d channels: chunk %d); run conv and GDN1 as two launches",
+                d->Cout, sc2_conv_f32_chunk_channels(d->Cout));
     SC2_REQUIRE(d->out_format == SC2_OUT_F32_NHWC || d->out_format == SC2_OUT_F32_NCHW || d->out_format == SC2_OUT_I32_NCHW_SYM,
                 SC2_ERR_UNSUPPORTED, "conv2d_f32: out_format %d", d->out_format);
     const bool gdn = d->epilogue == SC2_EPI_GDN || d->epilogue == SC2_EPI_IGDN;

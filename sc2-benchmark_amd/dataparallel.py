@@ -19,6 +19,16 @@ import torch
 import torch.distributed as dist
 
 
+def collectives_active(process_group=None):
+    """True when this module's collectives should actually be issued: a process group exists and either has more than one
+    rank or `SC2_DP_WORLD1_COLLECTIVES=1` asks for them on a single rank too.  The second form exists for ONE purpose: a box with
+    one GPU can then run every collective of the training / evaluation path on RCCL (world 1: `init_process_group('nccl')`,
+    broadcast, the hook-launched bucket all-reduces, the metric reductions on HIP tensors) -- tests/test_00_rccl_gpu.py."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(process_group) > 1 or os.environ.get('SC2_DP_WORLD1_COLLECTIVES') == '1'
+
+
 def init_distributed(backend=None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK (torchrun) -> (distributed, rank, world, device)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -28,13 +38,14 @@ def init_distributed(backend=None):
     device = torch.device('cuda', local_rank) if use_cuda else torch.device('cpu')
     if use_cuda:
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    launched = all(k in os.environ for k in ('RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'))   # torchrun, any world size
+    if (world > 1 or (launched and os.environ.get('SC2_DP_WORLD1_COLLECTIVES') == '1')) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         backend = backend or ('nccl' if use_cuda else 'gloo')
         kwargs = {'device_id': device} if (use_cuda and backend == 'nccl') else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
-    return world > 1, rank, world, device
+    return dist.is_initialized() and collectives_active(), rank, world, device
 
 
 def shard_range(n_items, rank, world):
@@ -61,6 +72,7 @@ class FlatGradAllReducer(object):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = collectives_active(process_group)   # (world > 1, or a forced single-rank group: collectives_active)
         cap = max(1, int(bucket_mb * 1024 * 1024 / 4))
         self.buckets = []
         cur, cur_n = [], 0
@@ -88,7 +100,7 @@ class FlatGradAllReducer(object):
         self._works = [None] * len(self.buckets)
         self.launched_by_hook = 0      # buckets whose all-reduce started inside backward (last step)
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] \
-            if self.world > 1 else []
+            if self.active else []
 
     def _launch(self, b):
         self._works[b] = dist.all_reduce(self.flats[b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -111,7 +123,7 @@ class FlatGradAllReducer(object):
                 reducer._pending = [len(b) for b in reducer.buckets]
                 reducer._works = [None] * len(reducer.buckets)
                 reducer.launched_by_hook = 0
-                reducer._armed = reducer.world > 1
+                reducer._armed = reducer.active
                 return reducer
 
             def __exit__(self_inner, *exc):
@@ -125,7 +137,7 @@ class FlatGradAllReducer(object):
 
     def all_reduce(self):
         """Average gradients over ranks.  Call after backward(); a no-op on a single process."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in range(len(self.buckets)):
             if self._works[b] is None:
@@ -141,7 +153,7 @@ class FlatGradAllReducer(object):
 
 def broadcast_parameters(module, src=0, process_group=None):
     """Makes every rank start from rank `src`'s parameters and buffers (what DDP does at construction)."""
-    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+    if not collectives_active(process_group):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         if t.numel() > 0:
@@ -159,7 +171,7 @@ def collective_device(process_group=None):
 def all_reduce_mean_scalars(values, device=None, process_group=None):
     """Mean over ranks of per-rank scalars (every rank weighs the same).  `device` None = the backend's device."""
     t = torch.tensor(values, dtype=torch.float64, device=collective_device(process_group) if device is None else device)
-    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+    if collectives_active(process_group):
         dist.all_reduce(t, group=process_group)
         t /= dist.get_world_size(process_group)
     return t.tolist()
@@ -170,7 +182,7 @@ def all_reduce_sum_scalars(values, device=None, process_group=None):
     (`synchronize_between_processes`: every meter's [count, total] are summed, the global average is total / count
     afterwards), so ranks that saw different numbers of samples weigh by their samples."""
     t = torch.tensor(values, dtype=torch.float64, device=collective_device(process_group) if device is None else device)
-    if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+    if collectives_active(process_group):
         dist.all_reduce(t, group=process_group)
     return t.tolist()
 
@@ -179,7 +191,7 @@ def all_gather_picklable(data, process_group=None):
     """Every rank's picklable object, in rank order (script/task/coco/eval.py:161-200, the C3 collective of SURVEY.md 2.3:
     variable-size pickled buffers, sizes exchanged first, payloads padded to the longest).  `torch.distributed`'s object
     collective does exactly that on the backend's device (RCCL: the current HIP device; gloo: host)."""
-    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+    if not collectives_active(process_group):
         return [data]
     out = [None] * dist.get_world_size(process_group)
     dist.all_gather_object(out, data, group=process_group)

@@ -69,12 +69,23 @@ def _require_device(x, what):
                            .format(what, x.device))
 
 
+def _status_or(st):
+    """OR over the per-stream status bit masks (the max of bit masks is not their OR: 1 and 2 give 2)."""
+    if isinstance(st, torch.Tensor):
+        st = st.detach().cpu().numpy()
+    st = np.asarray(st)
+    return int(np.bitwise_or.reduce(st.astype(np.int64).reshape(-1))) if st.size else 0
+
+
 def _raise_on_status(st, what):
     """rANS status per stream: bit 0 = the row overflowed its stride, bit 1 = a symbol lies outside the codable range
-    (|symbol - offset| >= 2^30: a non-finite or diverged latent; upstream's nibble loop never terminates there)."""
-    code = int(st.max().item())
+    (|symbol - offset| >= 2^30: a non-finite or diverged latent; upstream's nibble loop never terminates there), bit 2 = a
+    CDF-row index outside the table (host coder) / a stream that ran past its end while decoding."""
+    code = _status_or(st)
     if code & 2:
         raise ValueError('{}: a symbol is outside the codable range (non-finite or diverged latent)'.format(what))
+    if code & 4:
+        raise ValueError('{}: a CDF-row index lies outside the table, or a stream is shorter than its symbols need'.format(what))
     if code:
         raise hip.Sc2Error('{}: rANS stream overflowed its maximum size'.format(what))
 
@@ -330,10 +341,34 @@ class GDN(GDN1):
                               ep_x=x_nhwc, ep_beta=beta, tag=getattr(self, '_tag', None))
 
 
+class _HostTablesMixin(object):
+    """Lifetime of the prepared host-coder tables (`_host_tables_cache`, a ctypes handle kept in the instance __dict__):
+    dropped whenever the integer tables can have changed -- update(), load_state_dict(), .to() / .cuda() / .float() -- and never
+    pickled or deep-copied (a ctypes object holding pointers cannot be)."""
+
+    def _invalidate_host_tables(self):
+        self.__dict__['_tables_epoch'] = self.__dict__.get('_tables_epoch', 0) + 1
+        self.__dict__.pop('_host_tables_cache', None)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._invalidate_host_tables()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate_host_tables()
+        return out
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_host_tables_cache', None)
+        return state
+
+
 # --------------------------------------------------------------------------------------------- #
 # EntropyBottleneck
 # --------------------------------------------------------------------------------------------- #
-class EntropyBottleneck(nn.Module):
+class EntropyBottleneck(_HostTablesMixin, nn.Module):
     """Factorised-prior entropy model with CompressAI 1.2.x semantics.
 
     forward / quantize / dequantize / compress / decompress run in the HIP library; ``update()``
@@ -534,6 +569,7 @@ class EntropyBottleneck(nn.Module):
         self._offset = offset.to(dev)
         self._quantized_cdf = quantized_cdf.to(dev)
         self._cdf_length = (pmf_length + 2).to(dev)
+        self._invalidate_host_tables()
         return True
 
     def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
@@ -636,7 +672,9 @@ class EntropyBottleneck(nn.Module):
     def _host_tables(self):
         """Prepared tables of the library's host coder (csrc/rans_host.cpp), rebuilt when update() / load_state_dict() changed
         the integer tables."""
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self._quantized_cdf, self._cdf_length, self._offset))
+        # keyed on an explicit epoch that update() / load_state_dict() / .to() bump: the buffers are REPLACED by fresh tensors there
+        # (version 0 again, and the caching allocator hands the same address out), so pointer identity can hit a stale entry
+        key = self.__dict__.get('_tables_epoch', 0)
         cached = self.__dict__.get('_host_tables_cache')
         if cached is None or cached[0] != key:
             cdf, cdf_len, offset = self._tables()
@@ -654,7 +692,7 @@ class EntropyBottleneck(nn.Module):
             tables = self._host_tables()
             sym_h = sym.cpu().numpy()
             strings, st = hip.rans_encode_host(tables, sym_h, index_div=hw)
-            if int(st.max()) & 1:      # a row overflowed 2 B/symbol: redo with the proven upper bound
+            if _status_or(st) & 1:     # a row overflowed 2 B/symbol: redo with the proven upper bound
                 strings, st = hip.rans_encode_host(tables, sym_h, index_div=hw, out_stride=hip.rans_max_bytes(n_sym))
             _raise_on_status(torch.from_numpy(st), 'EntropyBottleneck.compress')
             return strings
@@ -720,7 +758,8 @@ class EntropyBottleneck(nn.Module):
         if 0 < len(strings) <= hip.host_coder_max_streams():
             C = self._quantized_cdf.shape[0]
             hw = int(np.prod(size))
-            sym_h, _ = hip.rans_decode_host(self._host_tables(), strings, C * hw, index_div=hw)
+            sym_h, st_h = hip.rans_decode_host(self._host_tables(), strings, C * hw, index_div=hw)
+            _raise_on_status(st_h, 'EntropyBottleneck.decompress')
             sym = torch.from_numpy(sym_h).to(dev)
             return hip.eb_dequantize(sym.view(len(strings), C, *size), self._median_vector(), want_f32=want_f32,
                                      want_nhwc=want_nhwc)
@@ -740,7 +779,7 @@ def get_scale_table(min=SCALES_MIN, max=SCALES_MAX, levels=SCALES_LEVELS):
     return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
 
 
-class GaussianConditional(nn.Module):
+class GaussianConditional(_HostTablesMixin, nn.Module):
     """Gaussian conditional entropy model with CompressAI 1.2.x semantics, as the hyperprior
     bottlenecks use it (layer.py:627,646-647,665,679,691-693,702,776,785,794,811-813).  forward / quantize /
     dequantize / build_indexes / compress / decompress run in the HIP library (per-symbol CDF rows through the
@@ -825,6 +864,7 @@ class GaussianConditional(nn.Module):
         self._quantized_cdf = quantized_cdf.to(dev)
         self._offset = (-pmf_center).to(dev)
         self._cdf_length = (pmf_length + 2).to(dev)
+        self._invalidate_host_tables()
 
     # ---- quantisation (EntropyModel.quantize; reference calls layer.py:691-693,811-813)
     def quantize(self, inputs, mode, means=None):
@@ -885,7 +925,9 @@ class GaussianConditional(nn.Module):
                                      indexes=indexes.int().contiguous().view(N, -1), out_stride=out_stride)
 
     def _host_tables(self):
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self._quantized_cdf, self._cdf_length, self._offset))
+        # keyed on an explicit epoch that update() / load_state_dict() / .to() bump: the buffers are REPLACED by fresh tensors there
+        # (version 0 again, and the caching allocator hands the same address out), so pointer identity can hit a stale entry
+        key = self.__dict__.get('_tables_epoch', 0)
         cached = self.__dict__.get('_host_tables_cache')
         if cached is None or cached[0] != key:
             cdf, cdf_len, offset = self._tables()
@@ -908,7 +950,7 @@ class GaussianConditional(nn.Module):
             idx_h = indexes.int().contiguous().view(N, -1).cpu().numpy()
             tables = self._host_tables()
             strings, st = hip.rans_encode_host(tables, sym_h, indexes=idx_h)
-            if int(st.max()) & 1:
+            if _status_or(st) & 1:
                 strings, st = hip.rans_encode_host(tables, sym_h, indexes=idx_h, out_stride=hip.rans_max_bytes(sym_h.shape[1]))
             _raise_on_status(torch.from_numpy(st), 'GaussianConditional.compress')
             return strings
@@ -951,7 +993,8 @@ class GaussianConditional(nn.Module):
         if 0 < len(strings) <= hip.host_coder_max_streams():
             N = indexes.shape[0]
             idx_h = indexes.int().contiguous().view(N, -1).cpu().numpy()
-            sym_h, _ = hip.rans_decode_host(self._host_tables(), list(strings), idx_h.shape[1], indexes=idx_h)
+            sym_h, st_h = hip.rans_decode_host(self._host_tables(), list(strings), idx_h.shape[1], indexes=idx_h)
+            _raise_on_status(st_h, 'GaussianConditional.decompress')
             sym = torch.from_numpy(sym_h).to(dev)
             return hip.gc_dequantize(sym.view(indexes.shape), None if means is None else means.float(), want_f32=want_f32,
                                      want_nhwc=want_nhwc)

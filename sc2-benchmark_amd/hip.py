@@ -1127,6 +1127,13 @@ def nchw_f32_to_nhwc_f32(x, cpad=None):
     return y
 
 
+def conv_f32_fused_gdn_supported(cout):
+    """conv + GDN1 in one f32 launch needs every channel of a pixel in one wave (Cout <= 96) AND a gamma stream as long as the
+    chunk is wide: ceil(Cout / 16) * 16 == chunk width (96 / 48 / 32 / 20 ... yes; 64 or 16 no: two launches)."""
+    cout = int(cout)
+    return cout <= 96 and (cout + 15) // 16 * 16 == int(lib().sc2_conv_f32_chunk_channels(cout))
+
+
 def pack_conv_f32(weight, cin_pad=None):
     """Conv weight [Cout, Cin, KH, KW] (any float dtype) -> the f32 fragment-major stream of sc2_conv2d_f32_fwd:
     [chunks][steps][NT][64 lanes][4], entry (ch, s, nt, lane = q*16 + r, j) = W[ch*cc + nt*16 + r][16 s + 4 q + j] with

@@ -219,7 +219,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
             kh, kw = mod.kernel_size
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if (self.fuse_gdn and type(nxt) is GDN1 and bias is None and nxt.in_channels == mod.out_channels <= 96 and
-                    i + 2 < len(mods)):
+                    hip.conv_f32_fused_gdn_supported(mod.out_channels) and i + 2 < len(mods)):
                 # conv + GDN1 in one launch: the wave that owns a pixel's channels applies the normalisation to its accumulators
                 gamma, beta = self._f32_pack(nxt)
                 h = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding,

@@ -227,6 +227,7 @@ class DistillationStage(object):
         self.use_hip_frozen = head_dtype == torch.bfloat16 and device.type == 'cuda'
         if self.use_hip_frozen and hasattr(getattr(student, 'bottleneck_layer', None), 'output_format'):
             # the decoder hands bf16 NHWC features to the frozen tail (and to the layer-1 feature-matching loss) directly
+            self._restore_output_format = (student.bottleneck_layer, student.bottleneck_layer.output_format)
             student.bottleneck_layer.output_format = 'bf16_nhwc'
 
     def _frozen_stack(self, name, module):
@@ -299,7 +300,8 @@ class DistillationStage(object):
                 skip -= 1
                 continue
             path = name.replace('__', '.')
-            stem = self._frozen_stem(children[ci:ci + 3], hooks) if (x.is_cuda and x.dim() == 4) else None
+            is_map = isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4    # (a child may hand on a tuple or a dict)
+            stem = self._frozen_stem(children[ci:ci + 3], hooks) if is_map else None
             if stem is not None:      # conv + frozen norm + ReLU at the head of a frozen network (the teacher's stem): one launch
                 with torch.no_grad():
                     x_nhwc = hip_nhwc_input(x, stem.w_folded.shape[1])
@@ -308,11 +310,10 @@ class DistillationStage(object):
                 continue
             # a hook on the stack's INPUT, or on a module inside it, needs the torch modules to run
             hooked_inside = any(q == path and q not in wanted or q.startswith(path + '.') for q in hooks.all_paths)
-            stack = self._frozen_stack(name, module) if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and
-                                                         not hooked_inside) else None
+            stack = self._frozen_stack(name, module) if (is_map and x.dtype == torch.bfloat16 and not hooked_inside) else None
             if stack is None:
                 x = module(x)
-                if self.head_dtype is not None and x.dtype != self.head_dtype and isinstance(x, torch.Tensor) and x.dim() == 4:
+                if self.head_dtype is not None and isinstance(x, torch.Tensor) and x.dtype != self.head_dtype and x.dim() == 4:
                     x = x.to(self.head_dtype).contiguous(memory_format=torch.channels_last)
                 continue
             if with_grad and x.requires_grad:
@@ -370,3 +371,8 @@ class DistillationStage(object):
     def clean_modules(self):
         self.t_hooks.clear()
         self.s_hooks.clear()
+        # the decoder's output format was switched to bf16 NHWC for THIS stage's bf16 tail: a student that goes on with an f32
+        # tail must get f32 NCHW features again
+        restore = self.__dict__.pop('_restore_output_format', None)
+        if restore is not None:
+            restore[0].output_format = restore[1]

@@ -181,3 +181,24 @@ def test_rans_symbol_out_of_range_sets_status(S, dev):
     y[0, 0, 1, 1] = float('inf')
     with pytest.raises(ValueError):
         eb.compress(y)
+
+
+def test_bpp_estimated_against_the_oracle(bench_model, dev):
+    """The line's `bpp_estimated` (eval-mode -sum log2 p / pixels from eb_forward_kernel: what BppLoss trains,
+    sc2bench/loss.py:20-37) against the oracle's value on the same images: (i) the device kernel on the ORACLE'S latent equals
+    the oracle's sum to 1e-5; (ii) through the reference-precision encoder the figure is the oracle's to 1e-4, through the
+    bf16 encoder to 1e-2; (iii) the estimate and the rate actually coded agree within 3 % (16-bit tables, escapes)."""
+    bench, model = bench_model
+    x = bench.synthetic_batch(16, dev, seed=3)
+    pc = bench.precision_check(model, x, dev, n=16)
+    ref = pc['reference_f32_cpu']['bpp_estimated']
+    assert ref > 0.5
+    assert abs(pc['f32_encoder']['bpp_estimated'] - ref) <= 1e-4 * ref, (pc['f32_encoder']['bpp_estimated'], ref)
+    assert abs(pc['bf16_encoder']['bpp_estimated'] - ref) <= 1e-2 * ref, (pc['bf16_encoder']['bpp_estimated'], ref)
+    assert abs(pc['reference_f32_cpu']['bpp'] - ref) <= 3e-2 * ref, (pc['reference_f32_cpu']['bpp'], ref)
+    oracle = bench.oracle_model(model.state_dict())
+    with torch.no_grad():
+        lat = oracle.bottleneck_layer.encoder(x[:4].float().cpu())
+        want = float(-torch.log2(oracle.bottleneck_layer.entropy_bottleneck(lat)[1]).sum().item())
+        got = float(-torch.log2(model.bottleneck_layer.entropy_bottleneck(lat.to(dev))[1].float()).sum().item())
+    assert abs(got - want) <= 1e-5 * want, (got, want)

@@ -74,9 +74,24 @@ def test_modes_match_reference_semantics(S, R, dev):
         m.eval()
     assert torch.equal(out0.cpu(), out_codec.cpu()), 'lossless coder must not change y_hat'
     assert torch.equal(out0.cpu(), out_train.cpu())
-    r, mx = rel_err(out0, g['decoded_from_strings'])
-    # symbols may flip where bf16 moves a latent across a rounding boundary: compare through the oracle decoder
-    assert r < 0.1, 'end-to-end rel L2 {} max {}'.format(r, mx)
+    # Two separate statements instead of one loose end-to-end bound:
+    # (i) bf16 encoder: its symbol flips (a latent within bf16 rounding distance of a .5 boundary) are the encoder's, so the
+    #     decoder is judged ON THE DEVICE'S BYTES through the oracle's decoder;
+    ref.update(force=True)
+    with torch.no_grad():
+        enc = m.encode(xd)
+        r, mx = rel_err(out0, ref.decode(**enc))
+    assert r < 1.5e-2, 'decoder on the device bytes: rel L2 {} max {}'.format(r, mx)
+    # (ii) reference-precision encoder: the symbols are the f32 oracle's (up to summation order), so the whole path is held
+    #     against the pure-f32 golden output end to end
+    m.set_encoder_precision('f32')
+    with torch.no_grad():
+        out32 = m(xd)
+    m.set_encoder_precision('bf16')
+    r, mx = rel_err(out32, g['decoded_from_strings'])
+    assert r < 2e-2, 'f32 encoder, end to end vs the f32 golden output: rel L2 {} max {}'.format(r, mx)
+    r_bf16, _ = rel_err(out0, g['decoded_from_strings'])
+    assert r_bf16 < 0.1     # (the old bound, kept as a sanity fence only: it contains the bf16 encoder's symbol flips)
 
 
 def test_encode_decode_bitstreams(S, R, dev):
@@ -179,7 +194,18 @@ def test_splittable_resnet_logits(S, R, dev):
         post_bf16, nb, st = model.forward_device(x.to(dev))
     assert int(st.max()) == 0 and nb.shape == (2,)
     assert model._hip_head is not None, 'bf16 eval must run the fused HIP head'
-    assert (post_bf16.float().cpu() - ref_post).abs().max().item() <= 0.08 * scale + 0.08
+    # the bf16 decoder + head judged on the DEVICE'S bytes (the oracle decodes them and runs its f32 tail): no symbol flips in
+    # the comparison, hence the tight bound; then the reference-precision encoder against the pure-f32 path end to end
+    with torch.no_grad():
+        enc = model.bottleneck_layer.encode(x.to(dev))
+        h = ref.bottleneck_layer.decode(**enc)
+        ref_on_bytes = ref.fc(torch.flatten(ref.avgpool(ref.layer4(ref.layer3(ref.layer2(h)))), 1))
+        model.set_encoder_precision('f32')
+        post_f32enc, _, _ = model.forward_device(x.to(dev))
+        model.set_encoder_precision('bf16')
+    assert (post_bf16.float().cpu() - ref_on_bytes).abs().max().item() <= 0.03 * scale + 0.03
+    assert (post_f32enc.float().cpu() - ref_post).abs().max().item() <= 0.03 * scale + 0.03
+    assert (post_bf16.float().cpu() - ref_post).abs().max().item() <= 0.08 * scale + 0.08   # (sanity fence: incl. symbol flips)
     # the same head through torch modules (MIOpen) agrees with the fused folded-BN head
     model.use_hip_head = False
     with torch.no_grad():

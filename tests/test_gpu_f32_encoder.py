@@ -174,3 +174,41 @@ def test_conv_f32_fused_gdn_equals_two_launches(S, R, dev, cin, cout, k, s, p, i
     with torch.no_grad():
         want = ref(torch.nn.functional.conv2d(x, w, None, s, p))
     _close(one.permute(0, 3, 1, 2), want, tol=4e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cout', [64, 16, 80])
+def test_conv_f32_fused_gdn_refused_for_narrow_chunks(S, R, dev, cout):
+    """the fused norm GEMM walks chunk / 16 gamma k-steps, gamma is packed with ceil(Cout / 16): for Cout 49..80 or
+    <= 16 the kernel would read past the gamma tensor.  The C-ABI refuses the fusion there, `conv_f32_fused_gdn_supported` says
+    so, and the f32 analysis transform of a bottleneck with such a width runs as two launches and equals the oracle's."""
+    hip = S.hip
+    assert not hip.conv_f32_fused_gdn_supported(cout)
+    assert all(hip.conv_f32_fused_gdn_supported(c) for c in (96, 48, 32, 20))
+    g = torch.Generator().manual_seed(cout)
+    x = torch.randn(1, 4, 9, 11, generator=g)
+    w = torch.randn(cout, 4, 3, 3, generator=g) / 6.0
+    gdn = S.GDN1(cout).to(dev)
+    gdn._tag = 't'
+    gamma, beta = S.FPBasedResNetBottleneck()._f32_pack(gdn)
+    xh = hip.nchw_f32_to_nhwc_f32(x.to(dev))
+    with pytest.raises(hip.Sc2Error):
+        hip.conv2d_f32_fwd(xh, hip.pack_conv_f32(w.to(dev)), cout, 3, 3, 1, 1, epilogue=hip.EPI_FUSED_GDN, ep_x=gamma, ep_beta=beta)
+    # the module path: conv0 of a 3 -> cout -> ... encoder takes the two-launch route and stays exact
+    m = S.FPBasedResNetBottleneck()
+    ref = R.FPBasedResNetBottleneck()
+    conv = torch.nn.Conv2d(3, cout, 5, 2, 2, bias=False)
+    enc_ref = torch.nn.Sequential(conv, R.GDN1(cout), torch.nn.Conv2d(cout, 24, 2, 1, 0, bias=False))
+    enc_dev = torch.nn.Sequential(S.HipConv2d(3, cout, 5, 2, 2, bias=False), S.GDN1(cout),
+                                  S.HipConv2d(cout, 24, 2, 1, 0, bias=False))
+    enc_dev.load_state_dict(enc_ref.state_dict())
+    for i, mod in enumerate(enc_dev):
+        mod._tag = 'enc.{}'.format(i)
+    m.encoder = enc_dev
+    m.eval().to(dev)
+    m.set_encoder_precision('f32')
+    xi = torch.rand(2, 3, 32, 32, generator=g)
+    with torch.no_grad():
+        got = m._analysis_f32(xi.to(dev))     # (analysis() itself unpacks the five modules of the stock encoder)
+        want = enc_ref(xi)
+    _close(got, want, tol=4e-6)
