@@ -468,6 +468,34 @@ def build_workload(name, dev, bs):
         what = ('Entropic-Student Faster R-CNN ResNet-50-FPN BODY (FP bottleneck 24ch + FrozenBN layer2-4 on the HIP head + FPN '
                 'in bf16 torch ops; RPN / RoI heads need torchvision: not part of this figure), 800x1216, eval after update()')
         return model, x, what, (800, 1216), n
+    if name == 'mshp224':      # the mean-scale hyperprior Entropic-Student (29 of the reference's Entropic-Student configs): 224 x 224
+        n = bs or 256
+        torch.manual_seed(0)
+        cfg = {'key': 'MSHPBasedResNetBottleneck', 'kwargs': {'num_latent_channels': 16, 'num_bottleneck_channels': 24,
+                                                               'num_target_channels': 256}}
+        model = S.splittable_resnet(cfg, skips_avgpool=False, skips_fc=False, num_classes=1000)
+        bl = model.bottleneck_layer
+        with torch.no_grad():    # a non-degenerate operating point for random weights: ragged z tables, a latent of std ~1.5,
+            eb = bl.entropy_bottleneck      # hyper-synthesis outputs that spread the predicted scales over the scale table
+            q = torch.zeros(eb.channels, 1, 3)
+            for c in range(eb.channels):
+                q[c, 0, 0], q[c, 0, 1], q[c, 0, 2] = -(3 + c % 5), 0.25 * (c % 3), 4 + c % 7
+            eb.quantiles.copy_(q)
+            bl.g_a[4].weight.mul_(10.0)      # latent std ~1.3
+            bl.h_a[2].weight.mul_(4.0)
+            w = bl.h_s[4].weight             # [scales | means] halves of gaussian_params (layer.py:764-785 chunks them that way)
+            half = w.shape[0] // 2
+            w[:half].abs_().mul_(5.0)        # predicted scales ~1.3: the Gaussian model FITS the latent (~2.4 bits per symbol, a
+            #                                  few escapes) -- with an untrained h_s every scale sits at the 0.11 floor, every
+            #                                  non-zero symbol is bypass-coded and the coder is measured on its slow path only
+        model.eval().to(dev)
+        model.update()
+        model.set_compute_dtype('bf16')
+        x = synthetic_batch(n, dev, seed=0)
+        what = ('Entropic-Student ResNet-50 with the MEAN-SCALE HYPERPRIOR bottleneck (MSHPBasedResNetBottleneck 16 / 24 ch: g_a, h_a, '
+                'h_s, g_s on the HIP kernels; z on the factorised prior, y on the Gaussian conditional with per-symbol CDF rows; both '
+                'streams through the batched device coder), 224x224, eval after update(): encode -> bytes -> decode -> layer2..fc')
+        return model, x, what, (224, 224), n
     if name == 'fp_input':     # config 3: Factorized-Prior (quality 8) input compression + ResNet-50, 224 x 224
         from sc2bench_amd.resnet import resnet50
         n = bs or 32
@@ -510,7 +538,19 @@ def workload_cpu_baseline(name, model, x, budget_s=12.0):
     x1 = x[:1].float().cpu()
     tables = ('_offset', '_quantized_cdf', '_cdf_length')
     with torch.no_grad():
-        if name == 'fp_input':
+        if name == 'mshp224':
+            ref = R.SplittableResNet50(R.MSHPBasedResNetBottleneck())
+            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if not k.endswith(tables + ('scale_table',))}
+            ref.load_state_dict({k: v for k, v in sd.items() if not k.startswith('bottleneck_layer.')}, strict=False)
+            ref.bottleneck_layer.load_state_dict({k[len('bottleneck_layer.'):]: v for k, v in sd.items()
+                                                  if k.startswith('bottleneck_layer.')}, strict=False)
+            ref.eval()
+            ref.update()
+
+            def run():
+                return ref(x1)
+            what = 'oracle mean-scale hyperprior bottleneck encode -> bytes -> decode + f32 CPU layer2..fc'
+        elif name == 'fp_input':
             from oracle import cpu_ref_input as RI
             codec = model.compression_model
             ref = RI.FactorizedPrior(codec.N, codec.M)
@@ -576,7 +616,7 @@ def workload_bench(args, dev, rank, world, distributed):
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()
-    select = lambda tag: tag is not None and (tag.startswith(('enc.', 'dec.', 'g_a', 'g_s')) or tag.startswith('rans'))  # noqa: E731
+    select = lambda tag: tag is not None and (tag.startswith(('enc.', 'dec.', 'g_a', 'g_s', 'h_a', 'h_s')) or tag.startswith('rans'))  # noqa: E731
     with hip.KernelTimer(select) as timer:
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -604,15 +644,16 @@ def workload_bench(args, dev, rank, world, distributed):
                     'gflop_per_image': bottleneck_gflop(*hw)}
     # compressed size of the batch as the reference measures it
     with torch.no_grad():
-        bl = model.compression_model if args.workload == 'fp_input' else \
+        bl = model.compression_model if args.workload == 'fp_input' else model.bottleneck_layer if args.workload == 'mshp224' else \
             (model.body if hasattr(model, 'body') else model.backbone).bottleneck_layer
         obj = bl.compress(model.pre_transform(x)) if args.workload == 'fp_input' else bl.encode(x)
-    nbytes = sum(len(q) for q in obj['strings'][0])
+    nbytes = sum(len(q) for lst in obj['strings'] for q in lst)     # (the hyperprior codes two streams per image: y and z)
     pix = x.shape[-1] * x.shape[-2] * n
     n_streams = len(obj['strings'][0])
     sym_shape = obj.get('shape')
     lat_c = 320 if args.workload == 'fp_input' else 24
-    sym_per_stream = lat_c * int(sym_shape[-2]) * int(sym_shape[-1]) if sym_shape is not None else None
+    sym_per_stream = lat_c * int(sym_shape[-2]) * int(sym_shape[-1]) if (sym_shape is not None and args.workload != 'mshp224') else \
+        '24 x 55 x 55 (y, per-symbol CDF rows) + 16 x {} x {} (z)'.format(int(sym_shape[-2]), int(sym_shape[-1]))
     on_host = n_streams <= hip.host_coder_max_streams()
     cpu, cpu_failed = None, None
     if world == 1 and not args.no_cpu_baseline:
@@ -634,6 +675,8 @@ def workload_bench(args, dev, rank, world, distributed):
                                   'batched HIP coder ({} streams per launch)'.format(n_streams),
                    'sharding': 'images, no collective'},
         'bpp': 8.0 * nbytes / pix, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': cpu,
+        'rans': {k: {'ms_per_launch': round(v[1], 4), 'launches_per_step': v[0] / float(args.steps)}
+                 for k, v in sorted(ksum.items()) if k.startswith('rans')},
         'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())}}))
     if cpu_failed:
         sys.stdout.flush()
@@ -687,7 +730,7 @@ def main():
     ap.add_argument('--diag-timeline', action='store_true', help='DIAGNOSTIC: HIP events around every stage of the timed run, printed to stderr (adds ~100 event records)')
     ap.add_argument('--diag-repeat', type=int, default=0, help='DIAGNOSTIC: after the timed region, time R more runs of K steps and print their wall times to stderr')
     ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
-    ap.add_argument('--workload', choices=['es224', 'fp_input', 'seg513', 'det800x1216'], default='es224',
+    ap.add_argument('--workload', choices=['es224', 'mshp224', 'fp_input', 'seg513', 'det800x1216'], default='es224',
                     help='es224 = the headline config (default); the others are BASELINE configs 3 / 5 / 4 through the module API')
     ap.add_argument('--encoder-precision', choices=['bf16', 'f32'], default='bf16',
                     help="f32: the analysis transform with f32 operands on the f32 matrix cores -- symbols, byte streams and bpp are the "

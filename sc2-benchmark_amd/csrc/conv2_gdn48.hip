@@ -56,6 +56,36 @@ __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+// Round 4: EVERY LDS access of the unit loop is inline asm and every barrier a raw s_barrier.  hipcc knows that a direct-to-LDS
+// load writes LDS: in front of any LDS access it can see -- and of every __syncthreads() -- it drains vmcnt(0).  The next slab's
+// (or unit's) pieces are in flight all the time, so each such access waited for them (a loaded HBM round trip: the reduction
+// rounds took 4.5 - 7 k of a unit's 22 - 24 k cycles, tools/enc2_stamps.py) and the counted `vmcnt(3)` at a unit's first slab was
+// void.  Results of asm reads are consumed behind `lds_wait()` = s_waitcnt lgkmcnt(0) + a scheduling barrier.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void lds_write16(uint32_t addr, uint4 v) {
+    const u32x4_t q = {v.x, v.y, v.z, v.w};
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(q) : "memory");
+}
+__device__ __forceinline__ void lds_write8(uint32_t addr, uint2 v) {
+    const u32x2_t q = {v.x, v.y};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(q) : "memory");
+}
+__device__ __forceinline__ void lds_write4(uint32_t addr, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ uint32_t lds_read4(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wg_barrier() {   // this wave's LDS writes are done, then the workgroup meets (no vmcnt drain)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 #ifndef SC2_ENC2_STAMPS
 #define SC2_ENC2_STAMPS 0   // 1: diagnostic build that records s_memtime at the phase boundaries (tools/enc2_stamps.py)
@@ -97,12 +127,14 @@ constexpr int BETA_OFF = GAM_OFF + 6 * 1024;
 constexpr int LDS_BYTES = BETA_OFF + COUT * 4;
 static_assert(OIMG_OFF + 112 * 96 <= GAM_OFF, "images fit the reduction area");
 static_assert(LDS_BYTES + 64 <= 160 * 1024, "one workgroup per CU");
+static_assert(NW * 9 * 1024 <= PATCH_STRIDE, "pixel tiles 4 .. 6 of the four partial sums fit a dead patch buffer");
 
 template <bool INVERSE>
 __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int next_slot;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    const uint32_t next_slot_addr = (uint32_t)(uintptr_t)(lds_ptr_t)&next_slot;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -218,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             // the previous unit were issued after this slab's loads, so vmcnt(3) does not wait for their acknowledgements.)
             if (cb == 0 && g != 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            wg_barrier();
             STAMP(1 + 2 * cb);
             // Claim of the unit after next: ISSUED behind the first slab's barrier, READ behind the second slab's `vmcnt(0)` above
             // (which the wave executes anyway), so its round trip -- 0.3 - 1 us with 32 workgroups on an XCD's counter -- runs
@@ -232,19 +264,26 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             }
             if (cb == 1 && tid == 0) {
                 asm volatile("" : "+v"(claimed)::"memory");
-                next_slot = (int)(claimed + 2 * wgs_x);
+                lds_write4(next_slot_addr, claimed + 2u * (unsigned)wgs_x);
                 if (claimed == (unsigned)(n_local - 1)) *my_ctr = 0u;   // this XCD's last claim re-arms its counter
             }
             // the wave with a seventh tap in this slab fetches that fragment now (L2; older than the patch loads below)
             const int tap6 = ((wave + cb) & 3) + 4 * NQ;
-            uint4 w6[NT];
+            // (asm loads, waited for with a counted vmcnt in front of the seventh tap: as compiler-tracked loads their wait was
+            //  vmcnt(0) = for the 12 - 13 patch pieces this wave issues behind them, i.e. the wave with seven taps -- the slowest
+            //  of the slab already -- also waited for the next slab's or unit's patch)
+            u32x4_t w6[NT];
             if (tap6 < NTAP) {
                 int ln = lane;
                 asm volatile("" : "+v"(ln));   // (address rebuilt here, not carried across the unit)
                 const uint4 *w6p = reinterpret_cast<const uint4 *>(p.w) + ((cb * NTAP + tap6) * NT) * 64 + ln;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) w6[j] = w6p[j * 64];
+                for (int j = 0; j < NT; ++j)
+                    asm volatile("global_load_dwordx4 %0, %1, off ; wfrag" : "=&v"(w6[j]) : "v"(w6p + j * 64) : "memory");
             }
+            // (the slab behind the unit's last one is the NEXT unit's first: same buffer rotation, and since round 4 issued behind
+            //  the taps like every other slab -- in the reduction rounds, where it used to be issued, the 13 pieces cost more than
+            //  among MFMAs and the rounds were the longest phase of a unit: 7.4 k of 23.8 k cycles, tools/enc2_stamps.py)
             const PatchJob jb = cb + 1 < NCB ? patch_setup(unit, cb + 1, (g + 1) & 1) : patch_setup(next_unit, 0, (g + 1) & 1);
             const uint32_t pb = lds_base + (uint32_t)((g & 1) * PATCH_STRIDE);
             // one wave per SIMD: the fragments of tap q + 1 are read between the MFMAs of tap q
@@ -262,6 +301,8 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             for (int q = 0; q <= NQ; ++q) {
                 const int tap = ((wave + cb) & 3) + 4 * q;
                 if (tap < NTAP) {   // wave-uniform (q < NQ: always)
+                    // (seventh tap: its fragments are older than the >= 12 patch pieces issued behind taps 0 .. 4)
+                    if (q == NQ) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tap q's fragments
                     __builtin_amdgcn_sched_barrier(0);
                     const int ntap = tap + 4;
@@ -276,18 +317,16 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[q & 1][i]);
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {
-                            const uint4 wv = q < NQ ? wreg[cb][q < NQ ? q : 0][j] : w6[j];
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv), af, acc[i][j],
-                                                                                0, 0, 0);
+                            const bf16x8_t wv = q < NQ ? __builtin_bit_cast(bf16x8_t, wreg[cb][q < NQ ? q : 0][j])
+                                                       : __builtin_bit_cast(bf16x8_t, w6[j]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af, acc[i][j], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 // three pieces of the next slab behind each of the first taps (13 pieces over taps 0 .. 4): spread, but
                 // early enough to have landed when the slab ends
-                // (the last slab issues nothing here: the next unit's first slab is fetched from the reduction rounds
-                //  below, where this wave mostly waits)
-                if (cb + 1 < NCB) {
+                {
                     if (q < 4) {
                         issue_piece(jb, 3 * q);
                         issue_piece(jb, 3 * q + 1);
@@ -300,74 +339,95 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             STAMP(2 + 2 * cb);
             ++g;
         }
-        const PatchJob jb_next = patch_setup(next_unit, 0, g & 1);   // g = first slab of the next unit: its buffer is free
-        // ---------------------------------------------------------------- sum of the four partial tiles, two rounds
+        // ---------------------------------------------------------------- sum of the four partial tiles, ONE round
+        // Every wave parks its 21 partial tiles: pixel tiles 0 .. 3 in the round area (48 KB), 4 .. 6 in the patch buffer of the
+        // unit's LAST slab, which is dead until the next unit's second slab is issued (36 of its 52 KB) -- one write / read round
+        // and three barriers instead of two rounds and five (round 4).  Same summation order as before (wave 0 + 1 + 2 + 3).
         f32x4_t own[2][NT];   // owned pixel tiles 4 r + wave, all three channel tiles
+        wg_barrier();   // everybody is done reading the last slab
+        const uint32_t red_lo_a = lds_base + (uint32_t)RED_OFF, red_hi_a = lds_base + (uint32_t)(((g - 1) & 1) * PATCH_STRIDE);
+        int ln_r = lane;
+        asm volatile("" : "+v"(ln_r));   // (slot addresses formed here, not carried across the slabs)
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            __syncthreads();   // round r - 1 has been read
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int b = 0; b < 12; ++b) {
-                const int i = 4 * r + b / 3, j = b % 3;
-                if (i < MT)
-                    *reinterpret_cast<f32x4_t *>(smem + RED_OFF + ((wave * 12 + b) * 64 + lane) * 16) = acc[i][j];
+            for (int j = 0; j < NT; ++j)
+                lds_write16(i < 4 ? red_lo_a + (uint32_t)(((wave * 12 + i * 3 + j) * 64 + ln_r) * 16)
+                                  : red_hi_a + (uint32_t)(((wave * 9 + (i - 4) * 3 + j) * 64 + ln_r) * 16),
+                            __builtin_bit_cast(uint4, acc[i][j]));
+        wg_barrier();
+        // six batches of four partial tiles (one per wave), two batches in flight: 32 registers (all 24 reads at once spilled
+        // resident weight fragments)
+        auto red_addr = [&](int b, int w2) {
+            const int r = b / NT, j = b - r * NT;
+            return r == 0 ? red_lo_a + (uint32_t)(((w2 * 12 + wave * 3 + j) * 64 + ln_r) * 16)
+                          : red_hi_a + (uint32_t)(((w2 * 9 + (4 + wave < MT ? wave : 0) * 3 + j) * 64 + ln_r) * 16);   // (wave 3 owns no
+        };                                                                                                     // second tile: reads wave 0's)
+        uint4 pa[2][NW];
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) pa[0][w2] = lds_read16(red_addr(0, w2));
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) pa[1][w2] = lds_read16(red_addr(1, w2));
+#pragma unroll
+        for (int b = 0; b < 2 * NT; ++b) {
+            if (b + 1 < 2 * NT) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");   // batch b landed, batch b + 1 may be in flight
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (4 * (b / NT) + wave < MT) {
+#pragma unroll
+                for (int w2 = 0; w2 < NW; ++w2) sum += __builtin_bit_cast(f32x4_t, pa[b & 1][w2]);
             }
-            __syncthreads();
-            // the next unit's first slab: 7 + 6 pieces, issued while the partial tiles are being read
+            own[b / NT][b % NT] = sum;
+            __builtin_amdgcn_sched_barrier(0);
+            if (b + 2 < 2 * NT) {
 #pragma unroll
-            for (int k = 0; k < PIECES_PER_WAVE; ++k)
-                if ((k < 7) == (r == 0)) issue_piece(jb_next, k);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                if (4 * r + wave < MT) {
-#pragma unroll
-                    for (int w2 = 0; w2 < NW; ++w2)
-                        s += *reinterpret_cast<const f32x4_t *>(smem + RED_OFF + ((w2 * 12 + wave * 3 + j) * 64 + lane) * 16);
-                }
-                own[r][j] = s;
+                for (int w2 = 0; w2 < NW; ++w2) pa[b & 1][w2] = lds_read16(red_addr(b + 2, w2));
             }
         }
-        __syncthreads();   // the rounds are dead: their area becomes the |t| image and the output image
+        wg_barrier();   // the round is dead: its area becomes the |t| image and the output image
         STAMP(7);
         // ---------------------------------------------------------------- GDN1(48) on the owned pixel tiles (wave-private rows)
-        unsigned char *timg = smem + TIMG_OFF;
-        unsigned char *oimg = smem + OIMG_OFF;
+        const uint32_t timg = lds_base + (uint32_t)TIMG_OFF, oimg = lds_base + (uint32_t)OIMG_OFF;
         {
             // both owned pixel tiles side by side (their LDS round trips and MFMA chains overlap); the rows are this wave's
             // own, its LDS operations complete in order: no barrier
             const bool has1 = 4 + wave < MT;   // wave-uniform: wave 3 owns one tile only
+            // (lane coordinates from the opaque copy made in this unit: hoisted out of the unit loop, the image addresses derived
+            //  from them were spilled, and a scratch reload waits vmcnt(0))
+            const int frow = ln_r & 15, fq = ln_r >> 4;
             int px[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) px[r] = (4 * r + wave) * 16 + frow;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (r == 1 && !has1) continue;
-                if (fq < 2) *reinterpret_cast<uint4 *>(timg + px[r] * 128 + (((6 + fq) ^ (px[r] & 7)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+                if (fq < 2) lds_write16(timg + (uint32_t)(px[r] * 128 + (((6 + fq) ^ (px[r] & 7)) << 4)), make_uint4(0u, 0u, 0u, 0u));
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int c = j * 2 + (fq >> 1);
                     uint2 h;
                     h.x = pack2(f32x2_t{own[r][j][0], own[r][j][1]}) & 0x7FFF7FFFu;
                     h.y = pack2(f32x2_t{own[r][j][2], own[r][j][3]}) & 0x7FFF7FFFu;
-                    *reinterpret_cast<uint2 *>(timg + px[r] * 128 + ((c ^ (px[r] & 7)) << 4) + (fq & 1) * 8) = h;
+                    lds_write8(timg + (uint32_t)(px[r] * 128 + ((c ^ (px[r] & 7)) << 4) + (fq & 1) * 8), h);
                 }
             }
             uint4 gv[NT][2];
             float4 beta4[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                beta4[j] = *reinterpret_cast<const float4 *>(smem + BETA_OFF + (j * 16 + fq * 4) * 4);
+                beta4[j] = __builtin_bit_cast(float4, lds_read16(lds_base + (uint32_t)(BETA_OFF + (j * 16 + fq * 4) * 4)));
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    gv[j][ks] = *reinterpret_cast<const uint4 *>(smem + GAM_OFF + ((j * 2 + ks) * 64 + lane) * 16);
+                    gv[j][ks] = lds_read16(lds_base + (uint32_t)(GAM_OFF + ((j * 2 + ks) * 64 + ln_r) * 16));
             }
             uint4 xv[2][2];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    xv[r][ks] = *reinterpret_cast<const uint4 *>(timg + px[r] * 128 + (((ks * 4 + fq) ^ (px[r] & 7)) << 4));
+                    xv[r][ks] = lds_read16(timg + (uint32_t)(px[r] * 128 + (((ks * 4 + fq) ^ (px[r] & 7)) << 4)));
+            lds_wait();   // (a wave's LDS operations complete in order: its own |t| rows are written before they are read)
             f32x4_t nrm[2][NT];
 #pragma unroll
             for (int r = 0; r < 2; ++r)
@@ -395,28 +455,38 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                         o.x = pack2(t01 * f32x2_t{__builtin_amdgcn_rcpf(n01[0]), __builtin_amdgcn_rcpf(n01[1])});
                         o.y = pack2(t23 * f32x2_t{__builtin_amdgcn_rcpf(n23[0]), __builtin_amdgcn_rcpf(n23[1])});
                     }
-                    *reinterpret_cast<uint2 *>(oimg + px[r] * (COUT * 2) + (j * 16 + fq * 4) * 2) = o;
+                    lds_write8(oimg + (uint32_t)(px[r] * (COUT * 2) + (j * 16 + fq * 4) * 2), o);
                 }
             }
         }
-        __syncthreads();
+        wg_barrier();
         STAMP(8);
         // ---------------------------------------------------------------- stream the unit out (one contiguous block of y)
         {
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * COUT);
             const unsigned n_out = (unsigned)(n_rows * OW * (COUT / 8));   // 672 or 336 chunks
+            uint4 ov[3];
+            unsigned oq[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const unsigned q0 = tid + 256 * k;
-                const unsigned q = q0 < n_out ? q0 : (unsigned)tid;   // past the end: the thread's first chunk again (same data)
-                yo[q] = *reinterpret_cast<const uint4 *>(oimg + q * 16);
+                const unsigned tid_r = (unsigned)(wave * 64 + ln_r);
+                const unsigned q0 = tid_r + 256 * k;
+                oq[k] = q0 < n_out ? q0 : tid_r;   // past the end: the thread's first chunk again (same data)
+                ov[k] = lds_read16(oimg + oq[k] * 16u);
             }
+            lds_wait();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) yo[oq[k]] = ov[k];
         }
-        __syncthreads();   // also: the images are free for the next unit's rounds
+        wg_barrier();   // also: the images are free for the next unit's rounds
         STAMP(9);
         ++g_units;
         unit = next_unit;
-        next_unit = __builtin_amdgcn_readfirstlane(next_slot);
+        {
+            const uint32_t ns = lds_read4(next_slot_addr);
+            lds_wait();
+            next_unit = __builtin_amdgcn_readfirstlane((int)ns);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the patch prefetched for a unit that does not exist
 }

@@ -746,6 +746,267 @@ __global__ __launch_bounds__(64) void rans_dec_ragged_kernel(const RansArgs a) {
     a.status[s] = 0;
 }
 
+// Round 4: the same decoder (explicit per-symbol indexes over a ragged table, rows packed into LDS as u16), rebuilt around what
+// bounds a serial wave: INSTRUCTION ISSUE.  One lane per stream spent ~100 vector instructions per symbol on a search whose
+// probes are independent -- so here FOUR lanes serve a stream (a quad; 16 streams per wave), every lane keeps a copy of the state
+// and the quad splits the search:
+//   * ONE 2-byte bucket read: first candidate entry of the 256-wide cum_freq bucket;
+//   * lane q probes candidates q + 1 and q + 5 (eight candidates per symbol, two u16 reads per lane), the count of candidates
+//     <= cum_freq is a quad sum (two DPP adds);
+//   * {start, next} = ONE unaligned 4-byte read at the answer (entries lo + cnt - 1, lo + cnt);
+//   * stream words come from an LDS ring per stream, topped up 16 words at a time one batch ahead, every lane of the quad moving
+//     four of them (no global load and no pointer compare on the state's chain);
+//   * 8-symbol chunks are decoded speculatively and branch-free, and rolled back to the exact per-symbol path when any stream of
+//     the wave met an escape symbol or a bucket with more than eight candidates (EVERY row crowds its tail entries into the
+//     first and the last bucket and cum_freq is uniform: with four candidates ~0.8 % of the symbols were unresolved and
+//     practically every chunk rolled back).
+// Rows are stored as cdf[k] - 1 (the closing 65536 fits; "cdf > cum_freq" is "stored >= cum_freq") and each is followed by eight
+// 0xFFFF sentinels: probes need no clamping.  Per-symbol row metadata is read ahead of the chain with the indexes.
+// y decode of the MSHP bottleneck, 256 x 72 600 symbols: 43.5 ms (one lane per stream, global stream words) -> 26.7 (ring +
+// speculation, one lane per stream, ~97 instructions per symbol) -> 19.4 ms (quads: ~58 instructions and three dependent LDS
+// round trips per symbol -- bucket, probes, {start, next} -- which is now what a symbol costs: ~570 cycles).  One wave per
+// workgroup (each with its own copy of the tables) is the fastest arrangement measured: 19.4 / 19.5 / 20.9 / 26.0 ms at 1 / 2 /
+// 4 / 8 waves per workgroup -- the chip is otherwise idle, and waves that share a CU share its LDS pipe.
+// Same bytes in, same symbols out (tests/test_gpu_hyperprior.py, tests/test_gpu_kernels.py).
+constexpr int kRagged2Cap = 45056;   // u16 entries of packed CDF rows incl. sentinels (88 KB) beside 32 KB of buckets and the 8 KB ring
+constexpr int kRagged2Rows = 64;
+constexpr int kProbe = 8;            // candidate entries examined by the speculative path
+
+__device__ __forceinline__ int quad_sum(int v) {   // sum over the four lanes of a quad, in every lane
+    v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+    v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+    return v;
+}
+
+template <int WAVES>   // waves (of 16 streams) per workgroup, which share one copy of the tables
+__global__ __launch_bounds__(64 * WAVES) void rans_dec_ragged2_kernel(const RansArgs a) {
+    constexpr int T = 64 * WAVES, SPW = 16 * WAVES;
+    constexpr int kBuckets = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *l_cdf = reinterpret_cast<uint16_t *>(smem);                                   // [kRagged2Cap]: cdf[k] - 1 (mod 2^16)
+    uint16_t *bucket = reinterpret_cast<uint16_t *>(smem + kRagged2Cap * 2);                // [n_cdfs][257]: first candidate of a bucket
+    uint32_t *win = reinterpret_cast<uint32_t *>(smem + kRagged2Cap * 2 + ((kRagged2Rows * (kBuckets + 1) * 2 + 15) & ~15));   // [kWin][SPW]
+    int *row_start = reinterpret_cast<int *>(win + kWin * SPW);                              // [n_cdfs + 1]
+    int *l_size = row_start + kRagged2Rows + 1;                                             // [n_cdfs]
+    int *l_off = l_size + kRagged2Rows;                                                     // [n_cdfs]
+    const int tid = threadIdx.x;
+    for (int r = tid; r < a.n_cdfs; r += T) {
+        l_size[r] = a.cdf_sizes[r];
+        l_off[r] = a.offsets[r];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int r = 0; r < a.n_cdfs; ++r) {
+            row_start[r] = tot;
+            tot += l_size[r] + kProbe;
+        }
+        row_start[a.n_cdfs] = tot;
+    }
+    __syncthreads();
+    const bool in_lds = row_start[a.n_cdfs] <= kRagged2Cap;   // (otherwise every symbol takes the exact path on the global table)
+    if (in_lds) {
+        for (int r = 0; r < a.n_cdfs; ++r) {
+            const int size = l_size[r], st = row_start[r];
+            for (int k = tid; k < size + kProbe; k += T)
+                l_cdf[st + k] = k < size ? (uint16_t)((uint32_t)a.cdfs[(long long)r * a.cdf_stride + k] - 1u) : (uint16_t)0xFFFFu;
+        }
+    }
+    __syncthreads();
+    auto row_at = [&](const uint16_t *row, int k) -> unsigned { return k == 0 ? 0u : (unsigned)row[k] + 1u; };   // cdf[k]
+    if (in_lds) {
+        // bucket[r][b] = first k >= 1 with cdf[k] >= b << 8 (entries before it are < the bucket's floor <= cum_freq); bucket 256 = size - 1
+        for (int t = tid; t < a.n_cdfs * (kBuckets + 1); t += T) {
+            const int r = t / (kBuckets + 1), b = t - r * (kBuckets + 1);
+            const int size = l_size[r];
+            const uint16_t *row = l_cdf + row_start[r];
+            const unsigned target = (unsigned)b << 8;
+            int lo = 1, hi = size - 1;   // cdf[size - 1] = 65536 >= every target
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (row_at(row, mid) >= target) hi = mid; else lo = mid + 1;
+            }
+            bucket[t] = (uint16_t)lo;
+        }
+    }
+    __syncthreads();
+    const int sl = tid >> 2, q = tid & 3;        // stream of the workgroup, lane of the quad
+    const int s = blockIdx.x * SPW + sl;
+    const int blk = s >> 6;                      // 64-stream block of the transposed workspace (a wave's 16 streams share it)
+    if (blk * 64 >= a.n_streams) return;         // (a whole wave, past the last block; no workgroup barrier follows)
+    const bool active = s < a.n_streams;
+    const int sc = active ? s : a.n_streams - 1;
+    __builtin_amdgcn_s_setprio(3);
+    uint32_t *out = a.ws + (long long)blk * a.n_sym * 64 + (s & 63);   // (the workspace has all 64 columns of every block)
+    const uint32_t *idxp = out;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)sc * a.stride + a.io_offset[sc]);
+    // a column without a stream decodes an all-zero stream with index 0 (x stays 0: entry 0 of row 0 for ever): it takes part in
+    // the wave's votes without ever asking for the slow path
+    const int n_words = active ? a.io_nbytes[sc] / 4 : 0;
+    uint32_t *const wl = win + sl;
+
+    // ---- the stream-word ring of rans_dec_lut_kernel, one per stream; lane q of the quad moves words 4 q .. 4 q + 3 of a batch
+    int lp = 0, rp = 0;
+    struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
+    uint32_t pre[4];
+    auto prefetch = [&]() {   // pre[] <- words [lp + 4 q, lp + 4 q + 4)
+        const int k = lp + 4 * q;
+        Words4 t;
+        if (k + 3 < n_words) {
+            t = *reinterpret_cast<const Words4 *>(w + k);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t.v[e] = k + e < n_words ? w[k + e] : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pre[e] = t.v[e];
+    };
+    prefetch();
+    auto top_up = [&]() {   // (lp, rp are equal in the four lanes of a quad: the quad tops up or not as one)
+        if (lp - rp <= kWin - 16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wl[((lp + 4 * q + j) & (kWin - 1)) * SPW] = pre[j];
+            lp += 16;
+            prefetch();
+        }
+    };
+    auto ring = [&](int k) { return wl[(k & (kWin - 1)) * SPW]; };
+    top_up();
+    top_up();
+    unsigned long long x = (unsigned long long)ring(0) | ((unsigned long long)ring(1) << 32);
+    rp = 2;
+    uint32_t wq = ring(rp), wq1 = ring(rp + 1);
+
+    // ---- exact per-symbol path (every lane of the quad runs it on its copy of the state): escapes, buckets with more than
+    //      kProbe candidates, the ragged tail
+    auto renorm_slow = [&]() {
+        if (x < kRansL) {
+            x = (x << 32) | ring(rp);
+            rp += 1;
+        }
+    };
+    auto get_bits = [&]() {
+        const int val = (int)(x & kMaxBypassVal);
+        x >>= kBypassPrecision;
+        renorm_slow();
+        return val;
+    };
+    auto step_slow = [&](long long pos, int idx) {
+        if (__any(lp - rp < 14)) top_up();
+        const int size = l_size[idx];
+        const int max_value = size - 2;
+        const unsigned cum_freq = (unsigned)(x & 0xFFFFu);
+        unsigned start, next;
+        int lo, hi;
+        if (in_lds) {
+            const uint16_t *row = l_cdf + row_start[idx];
+            const uint16_t *bk = bucket + idx * (kBuckets + 1) + (cum_freq >> 8);
+            lo = (int)bk[0];
+            hi = (int)bk[1];            // cdf[hi] >= the next bucket's floor > cum_freq: the answer is in [lo, hi]
+            while (lo < hi) {           // first k with cdf[k] > cum_freq
+                const int mid = (lo + hi) >> 1;
+                if (row_at(row, mid) > cum_freq) hi = mid; else lo = mid + 1;
+            }
+            start = row_at(row, lo - 1);
+            next = row_at(row, lo);
+        } else {
+            const int32_t *row = a.cdfs + (long long)idx * a.cdf_stride;
+            lo = 0, hi = size;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((unsigned)row[mid] > cum_freq) hi = mid; else lo = mid + 1;
+            }
+            start = (unsigned)row[lo - 1];
+            next = (unsigned)row[lo];
+        }
+        x = (unsigned long long)(next - start) * (x >> kPrecision) + cum_freq - start;
+        renorm_slow();
+        int value = lo - 1;
+        if (value == max_value) {
+            int val = get_bits();
+            int n_bypass = val;
+            while (val == kMaxBypassVal) {
+                val = get_bits();
+                n_bypass += val;
+            }
+            int raw_val = 0;
+            for (int j = 0; j < n_bypass; ++j) {
+                val = get_bits();
+                if (j < 8) raw_val |= val << (j * kBypassPrecision);
+            }
+            value = raw_val >> 1;
+            if (raw_val & 1) value = -value - 1;
+            else value += max_value;
+        }
+        out[pos * 64] = (uint32_t)(value + l_off[idx]);   // (the four lanes store the same word)
+    };
+
+    constexpr int U = 8;
+    int nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) nxt[u] = u < a.n_sym ? (int)idxp[(long long)u * 64] : 0;
+    for (long long i0 = 0; i0 < a.n_sym; i0 += U) {
+        int cur[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cur[u] = nxt[u];
+            nxt[u] = i0 + U + u < a.n_sym ? (int)idxp[(i0 + U + u) * 64] : 0;
+        }
+        if (i0 + U > a.n_sym || !in_lds) {   // ragged tail (or tables that do not fit): exact path
+#pragma unroll 1
+            for (int u = 0; u < U; ++u)
+                if (i0 + u < a.n_sym) step_slow(i0 + u, cur[u]);
+            wq = ring(rp);
+            wq1 = ring(rp + 1);
+            continue;
+        }
+        if (__any(lp - rp < 12)) top_up();
+        // row metadata of the chunk, off the state's chain
+        int r_st[U], r_size[U], r_off[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            r_st[u] = row_start[cur[u]];
+            r_size[u] = l_size[cur[u]];
+            r_off[u] = l_off[cur[u]];
+        }
+        const unsigned long long x0 = x;
+        const int rp0 = rp;
+        uint32_t bad = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned cum_freq = (unsigned)(x & 0xFFFFu);
+            const int lo = (int)bucket[cur[u] * (kBuckets + 1) + (int)(cum_freq >> 8)];
+            const uint16_t *pr = l_cdf + r_st[u] + lo - 1;       // stored entries lo - 1 .. lo + 8 (sentinels behind the row)
+            // candidate t (entry lo - 1 + t, t = 1 .. 8) is <= cum_freq  <=>  stored < cum_freq; entries increase, so those form a
+            // prefix and their count is the answer's distance from lo.  This lane: candidates q + 1 and q + 5
+            const int local = ((unsigned)pr[q + 1] < cum_freq ? 1 : 0) + ((unsigned)pr[q + 5] < cum_freq ? 1 : 0);
+            const int cnt = quad_sum(local);
+            uint32_t pair;                                       // stored[lo - 1 + cnt] | stored[lo + cnt] << 16
+            __builtin_memcpy(&pair, pr + cnt, 4);
+            const unsigned start = (cnt == 0 && lo == 1) ? 0u : (pair & 0xFFFFu) + 1u;   // entry 0 of a row is cdf 0 (stored 0xFFFF)
+            const unsigned next = (pair >> 16) + 1u;
+            const int sidx = lo + cnt - 1;
+            bad |= (active && (cnt == kProbe || sidx == r_size[u] - 2)) ? 1u : 0u;
+            x = (unsigned long long)(next - start) * (x >> kPrecision) + cum_freq - start;
+            const bool need = (x >> 31) == 0ull;
+            x = need ? ((x << 32) | wq) : x;
+            rp += need ? 1 : 0;
+            wq = need ? wq1 : wq;
+            wq1 = ring(rp + 1);
+            out[(i0 + u) * 64] = (uint32_t)(sidx + r_off[u]);
+        }
+        if (__any(bad != 0)) {   // roll the chunk back and decode it exactly
+            x = x0;
+            rp = rp0;
+#pragma unroll 1
+            for (int u = 0; u < U; ++u) step_slow(i0 + u, cur[u]);
+            wq = ring(rp);
+            wq1 = ring(rp + 1);
+        }
+    }
+    if (active && q == 0) a.status[s] = 0;
+}
+
 int check_common(const int32_t *indexes, long long index_div, int n_streams, long long n_sym, const int32_t *cdfs,
                  int n_cdfs, int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets) {
     SC2_REQUIRE(cdfs && cdf_sizes && offsets, SC2_ERR_INVALID_ARG, "rans: Uninitialized CDFs. Run update() first");
@@ -905,6 +1166,29 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
                 hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
                 SC2_CHECK_LAUNCH();
             }
+        }
+        return SC2_OK;
+    }
+    static const bool ragged2 = [] { const char *e = getenv("SC2_RANS_RAGGED2"); return !e || atoi(e) != 0; }();   // (0: A/B)
+    if (indexes && n_entries > 12288 && n_cdfs <= kRagged2Rows && ragged2) {
+        static const int waves = [] { const char *e = getenv("SC2_RANS_RAGGED2_WAVES"); const int v = e ? atoi(e) : 1; return v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 4 : 8; }();
+        const size_t lds = (size_t)kRagged2Cap * 2 + (((size_t)kRagged2Rows * 257 * 2 + 15) & ~(size_t)15) + (size_t)kWin * 16 * waves * 4 +
+                           (size_t)(3 * kRagged2Rows + 1) * 4 + 16;
+        auto kern = waves == 1 ? rans_dec_ragged2_kernel<1> : waves == 2 ? rans_dec_ragged2_kernel<2> : waves == 4 ? rans_dec_ragged2_kernel<4> : rans_dec_ragged2_kernel<8>;
+        allow_big_lds(kern, lds);
+        if (n_sym > 0) {
+            const long long gx = (n_sym + 63) / 64;
+            SC2_REQUIRE(gx < (1ll << 31) && n_blocks <= 65535, SC2_ERR_UNSUPPORTED, "rans_decode: problem too large");
+            hipLaunchKernelGGL(rans_transpose_in_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, indexes, n_streams,
+                               (long long)n_sym, a.ws);
+            SC2_CHECK_LAUNCH();
+        }
+        hipLaunchKernelGGL(kern, dim3((n_blocks * 64 + 16 * waves - 1) / (16 * waves)), dim3(64 * waves), lds, s, a);
+        SC2_CHECK_LAUNCH();
+        if (n_sym > 0) {
+            const long long gx = (n_sym + 63) / 64;
+            hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
+            SC2_CHECK_LAUNCH();
         }
         return SC2_OK;
     }

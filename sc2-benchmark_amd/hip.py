@@ -1302,7 +1302,7 @@ def rans_encode_batch(symbols, cdfs, cdf_sizes, offsets, indexes=None, index_div
     st = torch.empty((n_streams,), dtype=torch.int32, device=dev)
     ws_bytes = int(lib().sc2_rans_workspace_bytes(n_streams, n_sym, cdfs.shape[0], cdfs.shape[1]))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    with _timed('rans_encode'):
+    with _timed('rans_encode' if indexes is None else 'rans_encode.indexed'):   # (.indexed: per-symbol CDF rows, the hyperprior's y stream)
         _check(lib().sc2_rans_encode_batch(_ptr(symbols), _ptr(indexes), int(index_div), n_streams, n_sym, _ptr(cdfs),
                                        cdfs.shape[0], cdfs.shape[1], _ptr(cdf_sizes), _ptr(offsets), _ptr(buf),
                                          out_stride, _ptr(off), _ptr(nb), _ptr(st), _ptr(ws), ws_bytes, _stream()),
@@ -1356,7 +1356,7 @@ def rans_decode_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, indexes=Non
         assert indexes.shape == sym.shape and indexes.dtype == torch.int32 and indexes.is_contiguous()
     ws_bytes = int(lib().sc2_rans_workspace_bytes(n_streams, n_sym, cdfs.shape[0], cdfs.shape[1]))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    with _timed('rans_decode'):
+    with _timed('rans_decode' if indexes is None else 'rans_decode.indexed'):
         _check(lib().sc2_rans_decode_batch(_ptr(buf), stride, _ptr(off), _ptr(nb), _ptr(indexes), int(index_div),
                                        n_streams, int(n_sym), _ptr(cdfs), cdfs.shape[0], cdfs.shape[1],
                                        _ptr(cdf_sizes), _ptr(offsets), _ptr(sym), _ptr(st), _ptr(ws), ws_bytes,

@@ -8,7 +8,7 @@ a few instructions earlier).
     python tools/audit_vmcnt.py /tmp/f.s [kernel-name substring]
     python tools/audit_vmcnt.py --copies csrc/<file>.hip [...]     (compiles; exit status 1 on a finding)
 
---copies: the second hazard of hand-counted waits.  A register written by an inline-asm `buffer_load_dwordx4` (between
+--copies: the second hazard of hand-counted waits.  A register written by an inline-asm `buffer_load_dwordx4` / `global_load_dwordx4` (between
 ;;#ASMSTART / ;;#ASMEND) holds its value only once the load has landed, which the compiler does not know: any instruction
 other than an MFMA that READS such a register (a v_mov the register allocator placed to satisfy a tied operand or a phi)
 may copy it while the load is in flight.  The kernels mark their weight-fragment loads with the asm comment `; wfrag`; the
@@ -94,7 +94,7 @@ def audit_copies(body):
         if not s or s[0] == ';' or (s[0] == '.' and not s.startswith('.LBB')):
             continue
         insts.append((i, s, inasm))
-    if not any(a and t.startswith('buffer_load_dwordx4') and 'wfrag' in t for _, t, a in insts):
+    if not any(a and t.startswith(('buffer_load_dwordx4', 'global_load_dwordx4')) and 'wfrag' in t for _, t, a in insts):
         return []
     blocks, cur, label_of = [], None, {}
     for idx, (i, t, a) in enumerate(insts):
@@ -127,7 +127,7 @@ def audit_copies(body):
     def step(t, a, hot, report, i):
         toks = t.replace(',', ' ').split()
         op, args = toks[0], toks[1:]
-        if a and op == 'buffer_load_dwordx4' and 'wfrag' in t:
+        if a and op in ('buffer_load_dwordx4', 'global_load_dwordx4') and 'wfrag' in t:
             return hot | regs_of(args[0])
         if op == 's_waitcnt' and 'vmcnt(0)' in t:
             return set()   # everything has landed
