@@ -52,7 +52,7 @@ __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_
 __device__ __forceinline__ void buf_store16(buf_rsrc_t r, uint32_t voff, uint32_t soff, u32x4_t v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7" ::: "memory");
+    asm volatile("s_nop 1" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 #else   // host pass: stand-ins

@@ -42,19 +42,21 @@ __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint
 __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
-// A 16-byte buffer store reads its data registers for several cycles after issue (the last quarter of the lanes last).  hipcc
-// (ROCm 7.2) placed a VALU write to those registers directly behind the store: lanes 12-15 of every 16 then stored the NEW
-// value (seen as garbage in the first dword of a few outputs, only from the second wave of a SIMD).  The nops keep the data
-// registers untouched until the store has read them.  The ISA rule behind it is the GCN/CDNA "VMEM store of more than 64 bits
-// followed by a write of its data VGPRs" hazard (the store streams its 128-bit data out over several cycles after issue; the
-// manual wants wait states or independent instructions in between).  hipcc's hazard recognizer inserts them when it sees
-// the producer of the data registers; here they come out of `asm volatile` LDS reads / packs, and the following VALU write
-// was scheduled into the shadow.  The wait states are therefore explicit, and the bit-exact multi-launch test
+// A 16-byte buffer store reads its data registers for a few cycles after issue (lanes 12-15 of every 16 last): the GCN / CDNA
+// hazard "VMEM store of more than 64 bits followed by a VALU write of its data VGPRs".  hipcc's hazard recogniser inserts the
+// wait states only when the store's soffset field is NOT a register (GCNHazardRecognizer exempts MUBUF stores with an SGPR
+// soffset) -- and every store here carries an SGPR soffset.  On gfx950 the hazard exists in that form too:
+// tools/micro/store_hazard.hip issues `buffer_store_dwordx4 v[10:13], voff, rsrc, sN offen` directly followed by writes of
+// v10..v13 and finds the NEW value in memory for 0.12 % of the elements, all of them in lanes 12-15 of a group of 16 (with a
+// literal soffset, the case the compiler does handle: 6 %); ONE wait state removes every error (profiles/r04_store_hazard.txt).
+// That is what round 2 saw in this kernel: hipcc scheduled a VALU write of a data register directly behind a store, and lanes
+// 12-15 of the second wave of a SIMD (the one that is delayed at the memory pipe) stored the new value.  Two wait states follow
+// every store here (what the compiler inserts for the literal-soffset form on gfx940+); the bit-exact multi-launch test
 // (tests/test_gpu_kernels.py::test_conv2x2_win) stays in the default GPU suite as the guard against a compiler update.
 __device__ __forceinline__ void buf_store16(buf_rsrc_t r, uint32_t voff, uint32_t soff, u32x4_t v) {
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7" ::: "memory");
+    asm volatile("s_nop 1" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 #else   // host pass: stand-ins (see conv_igemm_impl.h)

@@ -7,6 +7,7 @@ a few instructions earlier).
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip --cuda-device-only -S csrc/<file>.hip -o /tmp/f.s
     python tools/audit_vmcnt.py /tmp/f.s [kernel-name substring]
     python tools/audit_vmcnt.py --copies csrc/<file>.hip [...]     (compiles; exit status 1 on a finding)
+    python tools/audit_vmcnt.py --stores csrc/<file>.hip [...]     (compiles; exit status 1 on a finding)
 
 --copies: the second hazard of hand-counted waits.  A register written by an inline-asm `buffer_load_dwordx4` / `global_load_dwordx4` (between
 ;;#ASMSTART / ;;#ASMEND) holds its value only once the load has landed, which the compiler does not know: any instruction
@@ -14,6 +15,11 @@ other than an MFMA that READS such a register (a v_mov the register allocator pl
 may copy it while the load is in flight.  The kernels mark their weight-fragment loads with the asm comment `; wfrag`; the
 check walks each kernel's listing in layout order, keeps a register 'hot' from a marked load until some other instruction
 writes it, and reports every instruction but a v_mfma that reads a hot register.
+
+--stores: `buffer_store_dwordx3/x4 vData, vOff, rsrc, sN` (SGPR soffset) directly followed by a VALU write of one of its data
+registers.  hipcc's hazard recogniser exempts this form from the ">64-bit store data" hazard; gfx950 has the hazard all the same
+(tools/micro/store_hazard.hip, profiles/r04_store_hazard.txt).  The kernels that store this way put wait states behind every
+store (`buf_store16`); this mode checks the listing for any such store the compiler left unprotected.
 """
 import re
 import sys
@@ -166,16 +172,53 @@ def audit_copies(body):
     return sorted(set(out))
 
 
+def audit_stores(body):
+    """-> list of (store, next instruction) where a VALU write of the store's data registers follows it directly."""
+    ins = [ln.strip() for ln in body]
+    ins = [t for t in ins if t and t[0] not in ';.' and not t.endswith(':')]
+    out = []
+    for i, t in enumerate(ins[:-1]):
+        if not t.startswith(('buffer_store_dwordx4', 'buffer_store_dwordx3')):
+            continue
+        toks = t.replace(',', ' ').split()
+        if len(toks) < 5 or not re.match(r's\d+$', toks[4]):
+            continue
+        nx = ins[i + 1].replace(',', ' ').split()
+        if nx[0].startswith('v_') and not nx[0].startswith('v_cmp') and len(nx) > 1 and regs_of(nx[1]) & regs_of(toks[1]):
+            out.append((t, ins[i + 1]))
+    return out
+
+
+def compile_to_isa(src):
+    import os
+    import subprocess
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), os.path.basename(src) + '.audit.s')
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-D__HIP_PLATFORM_AMD__=1', '-x', 'hip',
+                           '-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)
+    return out
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == '--stores':
+        import os
+        bad = 0
+        for src in sys.argv[2:]:
+            n_file = 0
+            for name, body in kernels(compile_to_isa(src)):
+                for st, nx in audit_stores(body):
+                    print('STORE? %s: %s -> %s' % (name[:80], st, nx))
+                    n_file += 1
+            bad += n_file
+            print('%s: %s' % (os.path.basename(src), 'ok' if not n_file else '%d findings' % n_file))
+        sys.exit(1 if bad else 0)
     if len(sys.argv) > 1 and sys.argv[1] == '--copies':
         import os
         import subprocess
         import tempfile
         bad = 0
         for src in sys.argv[2:]:
-            out = os.path.join(tempfile.gettempdir(), os.path.basename(src) + '.audit.s')
-            subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-D__HIP_PLATFORM_AMD__=1', '-x', 'hip',
-                                   '-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)
+            out = compile_to_isa(src)
             n_file = 0
             for name, body in kernels(out):
                 found = audit_copies(body)
