@@ -266,7 +266,9 @@ int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const float *bias, 
 /* The two MFMA-bound decoder convolutions of the FP / SHP / MSHP bottlenecks on the window-plane structure, with the
  * inverse GDN1 that follows the first one fused in (sc2bench/models/layer.py:489-493: Conv2d(512 -> 256, k2, p0) + GDN1(256,
  * inverse) and Conv2d(256 -> 256, k2, p1)); conv2x2_win.hip.  Results bit-identical to sc2_conv2d_fwd's.
- *   x : bf16 NHWC [N,H,W,Cin], W == 56 (pad 0) or 55 (pad 1), Cin % 64 == 0;   y : bf16 NHWC [N,H+2pad-1,W+2pad-1,256]
+ *   x : bf16 NHWC [N,H,W,Cin], Cin % 64 == 0, pad 0 (H, W >= 2) or 1;   y : bf16 NHWC [N,H+2pad-1,W+2pad-1,256]
+ *       (W == 56 with pad 0 and W == 55 with pad 1 -- the 224 x 224 operating point -- run the static-geometry instantiation;
+ *        every other width runs the same kernel over column segments of 55 output pixels: BASELINE configs 4 / 5)
  *   w_frag : bf16 [Cin/32 * 4 (+ 8 when fused)][16][64][8]: conv k-step kt = slab*4 + kh*2 + kw, then (fused) the 8 k-steps of
  *            the effective gamma [256][256] as a 1x1 layer; entry (kt, tile t = 2 g + j, lane = fq*16 + frow, e) =
  *            W[32 g + 8 (frow / 4) + 4 j + frow % 4][slab*32 + fq*8 + e][kh][kw]  (row permutation as sc2_conv3x3_win_fwd)

@@ -136,6 +136,7 @@ struct W2Args {
     uint16_t *__restrict__ o1;           // bf16 NHWC [N, OH, OW, 128]     = relu(W1 y + bias1)
     uint16_t *__restrict__ ods;          // bf16 NHWC [N, OH/2, OW/2, 512] = Wds y[::2, ::2] + bias_ds
     int N, H, Cin, OH;
+    int W, OW, nseg;                     // runtime-geometry instantiations only (Geo2<.., .., true>): map widths, column segments per row block
     int n_tiles, tiles_per_img, tiles_per_wg;
     int dbg;                             // DEBUG (SC2_W2_DBG): 1 = store x instead of y, 2 = store beta + norm
     unsigned x_bytes, w_bytes, y_bytes, o1_bytes, ods_bytes;
@@ -151,8 +152,17 @@ struct W2Args {
 //     column 0; results discarded, never stored);
 //   PAD 1 (dec.conv4, W = 55, OW = 56): the window needs columns -1 .. 55 = 57; with pitch 56 the right padding column of
 //     row r IS the left padding column of row r + 1 (both zero), and (5, 0) is the zero row behind the window.
-template <int OW_, int PAD_>
+//
+// RT (round 4): the same kernel for ANY map size (BASELINE configs 4 / 5: 128 / 129 x 128 / 129 at 513 x 513, 199 / 200 x
+// 303 / 304 at 800 x 1216).  A tile is four output rows x one SEGMENT of at most 55 output columns (OW_ = the segment
+// pitch); W, OW and the segment count come from the arguments, a tile's window starts at the segment's first input column and
+// everything beyond the image is out of range (zeros) -- with segments of <= 55 columns the 56-column window row holds every
+// column both paddings need (no shared padding column).  Window pitch, tap immediates, fragment ring and epilogue are
+// the static kernel's; what changes is the tile -> (image, row block, segment) split and two multiplications by OW.
+template <int OW_, int PAD_, bool RT_ = false>
 struct Geo2 {
+    static constexpr bool RT = RT_;
+    static constexpr int SEG = 55;                               // RT: output columns per segment
     static constexpr int OW = OW_, PAD = PAD_, W = OW_ + 1 - 2 * PAD_;
     static constexpr int ROWS = 4;                               // output rows per tile
     static constexpr int PWD = 56;                               // window row pitch = pixel-index pitch
@@ -165,7 +175,7 @@ struct Geo2 {
     static constexpr int IMG0 = 2 * WIN_BYTES;                   // fused: bf16 image of the conv output, 32 planes
     static constexpr int IMG_PLANE = MT * 16 * 16;               // [224 rows][16 B]
     static constexpr int LDS_PLAIN = 2 * WIN_BYTES, LDS_FUSED = IMG0 + 32 * IMG_PLANE;
-    static_assert(W + PAD <= PWD && OW <= PWD, "a window row holds the image row (+ one shared padding column)");
+    static_assert(RT || (W + PAD <= PWD && OW <= PWD), "a window row holds the image row (+ one shared padding column)");
     static_assert(MT == 14 && NRG == 5 && PLANE % 256 == 0 && IMG_PLANE % 256 == 0, "14 row tiles, 5 pieces per plane");
     static_assert(WIN_BYTES + 13 * 256 + (PWD + 1) * 16 < 65536 && 16 * IMG_PLANE + 13 * 256 < 65536, "16-bit immediates");
     static_assert(LDS_FUSED <= 160 * 1024, "LDS");
@@ -259,8 +269,25 @@ __device__ __forceinline__ void ds_step(f32x4_t (&acc)[14][2], const uint32_t (&
 
 template <class G, int MODE, bool INVERSE>
 __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
-    constexpr int MT = G::MT, W = G::W, OW = G::OW, PAD = G::PAD, PWD = G::PWD;
-    constexpr bool FUSE = MODE == 1, TAIL = MODE == 2;
+    constexpr int MT = G::MT, PAD = G::PAD, PWD = G::PWD;
+    constexpr bool FUSE = MODE == 1, TAIL = MODE == 2, RT = G::RT;
+    static_assert(!(RT && TAIL), "the tail mode is the 224 x 224 geometry's");
+    const int W = RT ? p.W : G::W, OW = RT ? p.OW : G::OW;       // (compile-time constants unless RT)
+    // tile -> image, first output row, first output column and width of its segment
+    auto tile_origin = [&](int tile, int &img, int &oh0, int &ow0, int &sw) {
+        img = tile / p.tiles_per_img;
+        const int t_in = tile - img * p.tiles_per_img;
+        if constexpr (RT) {
+            const int rb = t_in / p.nseg, seg = t_in - rb * p.nseg;
+            oh0 = rb * G::ROWS;
+            ow0 = seg * G::SEG;
+            sw = OW - ow0 < G::SEG ? OW - ow0 : G::SEG;
+        } else {
+            oh0 = t_in * G::ROWS;
+            ow0 = 0;
+            sw = OW;
+        }
+    };
     constexpr uint32_t OOB = 0x80000000u;
     // output stores per lane and tile, ALWAYS issued (masked ones out of range): the counted vmcnt waits of the next tile rely
     // on it.  Tail: o1, y (out of range as a whole when the caller does not want y), 2 x 4 ods.
@@ -300,7 +327,8 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     const int pq = wave & 3, pj0 = wave < 4 ? 0 : 3, pn = wave < 4 ? 3 : 2;
     uint32_t pw_vo[3];
     auto window_offsets = [&](int tile, bool live) {   // live = false: every lane out of range (zeros; see SC2_W2_SLAB)
-        const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * G::ROWS;
+        int img, oh0, ow0, sw;
+        tile_origin(tile, img, oh0, ow0, sw);
         // (the lane index is re-derived here and the values below recomputed per tile: hoisted out of the tile loop they were spilled)
         int ln;   // (volatile: computed where it is used)
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
@@ -311,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
             // a don't-care high addend register -- which the copy audit cannot tell from a read of a fragment in flight)
             static_assert(PWD == 56 && G::NRG * 64 <= 320, "ihp = (wr * 1171) >> 16 is exact below 336");
             const int ihp = (int)(((uint32_t)wr * 1171u) >> 16), iwp = wr - ((ihp << 6) - (ihp << 3));
-            const int ih = oh0 - PAD + ihp, iw = iwp - PAD;
+            const int ih = oh0 - PAD + ihp, iw = ow0 + iwp - PAD;
             const bool ok = live & (j < pn) & (wr < G::WROWS) & ((unsigned)ih < (unsigned)H) & ((unsigned)iw < (unsigned)W);
             pw_vo[j] = ok ? (uint32_t)((((img * H + ih) * W + iw) * Cin) * 2 + pq * 16) : OOB;
         }
@@ -396,9 +424,10 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
         // acc[i][1] (the packing permutes the weight rows that way) of tile pixel 16 i + frow = (row ml / 56, column ml % 56)
         // Stores go through a buffer descriptor with invalid lanes sent out of range: ALWAYS 14 store instructions per tile,
         // which the counted vmcnt wait of the next tile's first slab relies on.
-        const int img = tile / p.tiles_per_img, oh0 = (tile - img * p.tiles_per_img) * G::ROWS;
+        int img, oh0, ow0, sw;
+        tile_origin(tile, img, oh0, ow0, sw);
         const int rows_valid = OH - oh0 < G::ROWS ? OH - oh0 : G::ROWS;
-        const uint32_t y_so = (uint32_t)((img * OH + oh0) * OW) * 512u;            // tile base (bytes), scalar
+        const uint32_t y_so = (uint32_t)((img * OH + oh0) * OW + ow0) * 512u;      // tile base (bytes), scalar
         int ln_o;   // the lane index, computed HERE (volatile): the per-row-tile offsets and masks derived from it are then recomputed per
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln_o));   // tile, not hoisted and spilled
         const int fr = ln_o & 15, fqo = ln_o >> 4;
@@ -414,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
         auto out_off = [&](int i, int fr_, uint32_t ch, int pitch) -> uint32_t {
             const int ml = i * 16 + fr_;
             const int r = (ml >= PWD) + (ml >= 2 * PWD) + (ml >= 3 * PWD), c = ml - r * PWD;
-            const bool ok = (r < rows_valid) & (c < OW);
+            const bool ok = (r < rows_valid) & (c < sw);
             return ok ? (uint32_t)((r * OW + c) * pitch) + ch : OOB;
         };
         if constexpr (FUSE || TAIL) {
@@ -619,7 +648,8 @@ int launch_w2(W2Args a, hipStream_t s) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         g_cus_w2 = n;
     }
-    a.tiles_per_img = (a.OH + G::ROWS - 1) / G::ROWS;
+    a.nseg = G::RT ? (a.OW + G::SEG - 1) / G::SEG : 1;
+    a.tiles_per_img = (a.OH + G::ROWS - 1) / G::ROWS * a.nseg;
     a.n_tiles = a.N * a.tiles_per_img;
     // runs of `tiles_per_wg` consecutive tiles per workgroup.  Default 2: many short workgroups that the dispatcher places on
     // whatever CUs are free -- inside the pipelined bench the serial coder's workgroups and the encoder stage of a later batch
@@ -641,13 +671,15 @@ int launch_w2(W2Args a, hipStream_t s) {
 
 typedef Geo2<55, 0> Gd2;   // dec.conv2: 56 -> 55
 typedef Geo2<56, 1> Gd4;   // dec.conv4: 55 -> 56
+typedef Geo2<55, 0, true> Gr0;   // any width, pad 0 (W -> W - 1)
+typedef Geo2<55, 1, true> Gr1;   // any width, pad 1 (W -> W + 1)
 
 }  // namespace
 
 extern "C" int sc2_conv2x2_win_supported(int H, int W, int Cin, int Cout, int pad) {
     if (Cout != 256 || Cin < 64 || Cin % 64 != 0) return 0;
-    if (pad == 0) return W == 56 && H >= 2 ? 1 : 0;
-    if (pad == 1) return W == 55 && H >= 1 ? 1 : 0;
+    if (pad == 0) return W >= 2 && H >= 2 ? 1 : 0;   // (56: the static geometry; any other width: segments of 55 columns)
+    if (pad == 1) return W >= 1 && H >= 1 ? 1 : 0;   // (55: static)
     return 0;
 }
 
@@ -656,8 +688,8 @@ extern "C" int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const floa
     SC2_REQUIRE(x && w_frag && y, SC2_ERR_INVALID_ARG, "conv2x2_win: null argument");
     SC2_REQUIRE(N > 0, SC2_ERR_INVALID_ARG, "conv2x2_win: non-positive batch");
     SC2_REQUIRE(sc2_conv2x2_win_supported(H, W, Cin, 256, pad), SC2_ERR_UNSUPPORTED,
-                "conv2x2_win: needs Cout 256, Cin %% 64 == 0 and width 56 (pad 0) or 55 (pad 1); got %d x %d, Cin %d, pad %d", H, W, Cin,
-                pad);
+                "conv2x2_win: needs Cout 256, Cin %% 64 == 0, pad 0 or 1 and a map of at least 2 x 2 (pad 0); got %d x %d, Cin %d, pad %d",
+                H, W, Cin, pad);
     SC2_REQUIRE(!fused || beta, SC2_ERR_INVALID_ARG, "conv2x2_win: the fused GDN1 needs beta");
     const int ksteps = Cin / 32 * 4 + (fused ? 8 : 0);
     const long long x_bytes = (long long)N * H * W * Cin * 2, w_bytes = (long long)ksteps * 16384;
@@ -670,6 +702,7 @@ extern "C" int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const floa
     a.beta = beta;
     a.y = static_cast<uint16_t *>(y);
     a.N = N; a.H = H; a.Cin = Cin; a.OH = H + 2 * pad - 1;
+    a.W = W; a.OW = W + 2 * pad - 1; a.nseg = 1;
     a.n_tiles = 0; a.tiles_per_img = 0; a.tiles_per_wg = 0;
     {
         const char *dbg = getenv("SC2_W2_DBG");
@@ -678,8 +711,10 @@ extern "C" int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const floa
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     a.bias1 = nullptr; a.bias_ds = nullptr; a.o1 = nullptr; a.ods = nullptr; a.o1_bytes = 0; a.ods_bytes = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (pad == 0) return !fused ? launch_w2<Gd2, 0>(a, s) : inverse ? launch_w2<Gd2, 1, true>(a, s) : launch_w2<Gd2, 1, false>(a, s);
-    return !fused ? launch_w2<Gd4, 0>(a, s) : inverse ? launch_w2<Gd4, 1, true>(a, s) : launch_w2<Gd4, 1, false>(a, s);
+    if (pad == 0 && W == 56) return !fused ? launch_w2<Gd2, 0>(a, s) : inverse ? launch_w2<Gd2, 1, true>(a, s) : launch_w2<Gd2, 1, false>(a, s);
+    if (pad == 1 && W == 55) return !fused ? launch_w2<Gd4, 0>(a, s) : inverse ? launch_w2<Gd4, 1, true>(a, s) : launch_w2<Gd4, 1, false>(a, s);
+    if (pad == 0) return !fused ? launch_w2<Gr0, 0>(a, s) : inverse ? launch_w2<Gr0, 1, true>(a, s) : launch_w2<Gr0, 1, false>(a, s);
+    return !fused ? launch_w2<Gr1, 0>(a, s) : inverse ? launch_w2<Gr1, 1, true>(a, s) : launch_w2<Gr1, 1, false>(a, s);
 }
 
 extern "C" int sc2_conv2x2_win_tail_supported(int H, int W, int Cin) {
@@ -704,6 +739,7 @@ extern "C" int sc2_conv2x2_win_tail_fwd(const void *x, const void *w_stream, con
     a.o1 = static_cast<uint16_t *>(o1);
     a.ods = static_cast<uint16_t *>(ods);
     a.N = N; a.H = H; a.Cin = Cin; a.OH = 56;
+    a.W = W; a.OW = W + 1; a.nseg = 1;
     a.n_tiles = 0; a.tiles_per_img = 0; a.tiles_per_wg = 0; a.dbg = 0;
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)((Cin / 32 * 4 + 24) * 16384); a.y_bytes = y ? (unsigned)y_bytes : 0u;
     a.o1_bytes = (unsigned)((long long)N * 56 * 56 * 256); a.ods_bytes = (unsigned)((long long)N * 28 * 28 * 1024);

@@ -726,7 +726,7 @@ def test_conv2x2_win(S, dev, monkeypatch, cin, pad, N, H, fused, inverse, run):
     x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
     assert S.hip.conv2x2_win_supported(tuple(x_nhwc.shape), 256, 2, 2, 1, pad)
     assert not S.hip.conv2x2_win_supported(tuple(x_nhwc.shape), 128, 2, 2, 1, pad)
-    assert not S.hip.conv2x2_win_supported((N, H, W + 1, cin), 256, 2, 2, 1, pad)
+    assert not S.hip.conv2x2_win_supported((N, H, W, cin + 32), 256, 2, 2, 1, pad)
     order = S.hip.preferred_k_order(cin, 2, 2)
     wp = S.hip.pack_conv_weight(w.to(dev), order)
     if fused:
@@ -750,6 +750,50 @@ def test_conv2x2_win(S, dev, monkeypatch, cin, pad, N, H, fused, inverse, run):
     assert out.shape == ref.shape
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), \
         'window-plane decoder kernel differs from the tile kernel in {} elements'.format(int((out != ref).sum()))
+
+@pytest.mark.parametrize('cin,pad,N,H,W,fused', [
+    (512, 0, 2, 17, 129, True),     # 513 x 513 input: dec.conv2 + IGDN256 at 129 x 129 -> 128 x 128 (segments 55 + 55 + 18)
+    (256, 1, 2, 9, 128, False),     # ... dec.conv4 128 -> 129 (55 + 55 + 19)
+    (512, 0, 1, 40, 304, True),     # 800 x 1216 input: 200 x 304 -> 199 x 303 (five whole segments + 28)
+    (256, 1, 1, 21, 303, False),    # ... 303 -> 304
+    (64, 0, 3, 5, 2, False),        # narrowest maps: one output column
+    (64, 1, 3, 1, 1, True),         # a 1 x 1 map with padding: 2 x 2 output
+    (128, 0, 2, 6, 56 + 55, True),  # exactly two whole segments
+    (128, 1, 2, 7, 56, False),      # pad 1 at the width whose pad-0 form is the static geometry
+])
+def test_conv2x2_win_any_width(S, dev, cin, pad, N, H, W, fused):
+    """The runtime-geometry instantiation of the window-plane decoder kernel (column segments of 55 output pixels; BASELINE
+    configs 4 / 5) against the tile kernels' launches of the same layer: BIT-IDENTICAL, repeated launches."""
+    g = torch.Generator().manual_seed(cin + 3 * H + W)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w = torch.randn(256, cin, 2, 2, generator=g) / (4 * cin) ** 0.5
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    assert S.hip.conv2x2_win_supported(tuple(x_nhwc.shape), 256, 2, 2, 1, pad)
+    order = S.hip.preferred_k_order(cin, 2, 2)
+    wp = S.hip.pack_conv_weight(w.to(dev), order)
+    if fused:
+        gdn = S.GDN1(256, inverse=True).to(dev)
+        with torch.no_grad():
+            gdn.gamma.add_(0.02 * torch.rand(256, 256, generator=g).to(dev))
+        ref = gdn.forward_nhwc(S.hip.conv2d_fwd(x_nhwc, wp, 256, 2, 2, 1, pad, k_order=order))
+        wf = S.hip.pack_conv2x2_win(w.to(dev), gdn.gamma_reparam(gdn.gamma).detach())
+        beta = gdn.beta_reparam(gdn.beta).detach().float().contiguous()
+        run = lambda: S.hip.conv2x2_win_fwd(x_nhwc, wf, pad, beta=beta, inverse=True)
+    else:
+        ref = S.hip.conv2d_fwd(x_nhwc, wp, 256, 2, 2, 1, pad, k_order=order)
+        wf = S.hip.pack_conv2x2_win(w.to(dev))
+        run = lambda: S.hip.conv2x2_win_fwd(x_nhwc, wf, pad)
+        f32 = F.conv2d(bf16_round(x), bf16_round(w), padding=pad)
+    for _ in range(2):
+        out = run()
+        assert out.shape == ref.shape == (N, H + 2 * pad - 1, W + 2 * pad - 1, 256)
+        if fused:
+            # (the two-launch reference rounds the conv output to bf16 before the GDN as the fused kernel does: same bits)
+            assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), \
+                '{} elements differ from conv -> IGDN1'.format(int((out != ref).sum()))
+        else:
+            assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), '{} elements differ'.format(int((out != ref).sum()))
+            assert_close_bf16(out.permute(0, 3, 1, 2), f32, 'window-plane 2x2 conv, runtime geometry')
 
 
 @pytest.mark.parametrize('N,run,want_y', [(3, 0, True), (2, 5, False), (5, 3, True)])
