@@ -25,6 +25,9 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_DEC_DBG
+#define SC2_DEC_DBG 0      // timing experiments (results garbage): 1 = no output stores
+#endif
 #ifndef SC2_DEC_STAMPS
 #define SC2_DEC_STAMPS 0   // 1: diagnostic build that records s_memtime at the phase boundaries (tools/dec_stamps.py)
 #endif
@@ -48,6 +51,12 @@ namespace {
 // wave, ~2 k cycles with its partner, between request and use); vmcnt retires in issue order, so the wait for step k is "all
 // but the 8 loads of the two steps behind it".
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// one v_cvt_pk_bf16_f32 on an explicit (e0, e1) pair.  With scalar element-wise code the SLP vectoriser paired the wrong
+// elements ((e0, e2), (e1, e3)) and re-interleaved them with and / shift / or_sdwa / v_mov: 870 vector instructions per wave for
+// the in-place epilogue of a tile where 350 do (round 4).
+__device__ __forceinline__ uint32_t pack2(f32x2_t v) { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); }
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ i32x4_t rsrc_words(const void *base, uint32_t bytes) {   // raw buffer descriptor: base, no stride, size, 32-bit raw data format
     const uint64_t a = (uint64_t)(uintptr_t)base;
@@ -77,6 +86,7 @@ struct DecArgs {
     int N, H, W, OH, OW, OHW, M, Kpad, n_tiles, inverse;
     unsigned long long *stamps;          // diagnostic build only (SC2_DEC_STAMPS)
     unsigned *tile_ctr;                  // claims so far (claim c = tile c + 2 * gridDim.x); zero between launches
+    int stagger;                         // start delay per workgroup of an XCD, in 64-cycle sleeps (see the launcher)
 };
 
 constexpr int BM = 128, CH = 512, WN = 64, MT = 8, NT = 4;
@@ -92,7 +102,9 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *img = smem;
     unsigned char *patch = smem + IMG_BYTES;     // KS1 slabs of [128 rows][64 B]
-    volatile int *next_slot = reinterpret_cast<volatile int *>(smem + IMG_BYTES + KS1 * 8192);
+    // (an LDS-space pointer: through a generic `volatile int *` the read was a flat_load followed by s_waitcnt vmcnt(0))
+    typedef __attribute__((address_space(3))) volatile int lds_int_t;
+    lds_int_t *next_slot = (lds_int_t *)(__attribute__((address_space(3))) unsigned char *)(smem + IMG_BYTES + KS1 * 8192);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -166,6 +178,8 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
         }
     };
     load_w();
+    // staggered start: workgroup j of its XCD begins j * stagger * 64 cycles late (launcher: why)
+    for (int n = (int)(blockIdx.x >> 3) * p.stagger; n > 0; --n) __builtin_amdgcn_s_sleep(1);
 
     // Tiles are claimed dynamically, one atomic per tile: a workgroup whose CU is shared with other kernels (the range
     // coder's serial waves), or that starts late because its CU's LDS was taken, simply processes fewer tiles.
@@ -207,8 +221,8 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 uint2 h;
-                h.x = pack_bf16x2(acc[i][j][0], acc[i][j][1]);
-                h.y = pack_bf16x2(acc[i][j][2], acc[i][j][3]);
+                h.x = pack2(f32x2_t{acc[i][j][0], acc[i][j][1]});
+                h.y = pack2(f32x2_t{acc[i][j][2], acc[i][j][3]});
                 *reinterpret_cast<uint2 *>(img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384) = h;
                 acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
@@ -293,22 +307,24 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
         // ---------------------------------------------------------------- epilogue: y = t * (beta + norm), in place
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const float b[4] = {b4v[j].x, b4v[j].y, b4v[j].z, b4v[j].w};
+            const f32x2_t b01 = {b4v[j].x, b4v[j].y}, b23 = {b4v[j].z, b4v[j].w};
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384;
                 const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
-                const float t[4] = {__builtin_bit_cast(float, xr.x << 16), __builtin_bit_cast(float, xr.x & 0xFFFF0000u),
-                                    __builtin_bit_cast(float, xr.y << 16), __builtin_bit_cast(float, xr.y & 0xFFFF0000u)};
-                float r[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float norm = b[e] + acc[i][j][e];
-                    r[e] = INVERSE ? t[e] * norm : t[e] * (1.0f / norm);
-                }
+                // explicit (e0, e1) / (e2, e3) pairs: packed add / multiply / convert, no shuffles
+                const f32x2_t t01 = {__builtin_bit_cast(float, xr.x << 16), __builtin_bit_cast(float, xr.x & 0xFFFF0000u)};
+                const f32x2_t t23 = {__builtin_bit_cast(float, xr.y << 16), __builtin_bit_cast(float, xr.y & 0xFFFF0000u)};
+                const f32x2_t n01 = b01 + f32x2_t{acc[i][j][0], acc[i][j][1]};
+                const f32x2_t n23 = b23 + f32x2_t{acc[i][j][2], acc[i][j][3]};
                 uint2 o;
-                o.x = pack_bf16x2(r[0], r[1]);
-                o.y = pack_bf16x2(r[2], r[3]);
+                if (INVERSE) {
+                    o.x = pack2(t01 * n01);
+                    o.y = pack2(t23 * n23);
+                } else {
+                    o.x = pack2(t01 * f32x2_t{1.0f / n01[0], 1.0f / n01[1]});
+                    o.y = pack2(t23 * f32x2_t{1.0f / n23[0], 1.0f / n23[1]});
+                }
                 *reinterpret_cast<uint2 *>(slot) = o;
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
@@ -327,12 +343,40 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
                 rd_base[par] = (wn + 8 * par) * (CH * 2) + ((lane ^ (wn + 8 * par)) << 4);
                 asm volatile("" : "+v"(rd_base[par]));
             }
+            if (m0 + BM <= p.M) {
+                // whole tile (every tile but possibly the last): eight reads in flight, then their eight stores.  Row by row
+                // -- read, wait, store, branch on the row bound -- the copy was a chain of sixteen LDS latencies per wave:
+                // 9.2 k of a tile's 46.7 k cycles (tools/dec_stamps.py) for 16 KB per wave
 #pragma unroll
-            for (int r = 0; r < BM / 8; ++r) {
-                const int row = wn + r * 8;
-                if (m0 + row < p.M)   // wave-uniform
-                    yo[r * 512] = *reinterpret_cast<const uint4 *>(img + rd_base[r & 1] + (r >> 1) * 16384);
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                for (int h = 0; h < 2; ++h) {
+                    // (inline asm: left to itself hipcc keeps two reads in flight and waits between the stores)
+                    u32x4_t v[8];
+                    const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(img + rd_base[0] + h * 65536);
+                    const uint32_t l1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(img + rd_base[1] + h * 65536);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                     : "=v"(v[r])
+                                     : "v"((r & 1) ? l1 : l0), "n"((r >> 1) * 16384));
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                                 :
+                                 : "memory");
+#if !(SC2_DEC_DBG & 1)   // (timing experiment: no output stores)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) yo[(8 * h + r) * 512] = __builtin_bit_cast(uint4, v[r]);
+#else
+                    asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll 1
+                for (int r = 0; r < BM / 8; ++r) {
+                    const int row = wn + r * 8;
+                    if (m0 + row < p.M)   // wave-uniform
+                        yo[r * 512] = *reinterpret_cast<const uint4 *>(img + rd_base[r & 1] + (r >> 1) * 16384);
+                }
             }
         }
         store_patch(pv);   // (the patch region was last read in phase 1)
@@ -391,6 +435,10 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
     }
     DecArgs b = a;
     b.tile_ctr = g_ctr_ring[dev] + (g_ctr_seq.fetch_add(1) % kCtrRing);
+    {
+        static const int stagger = [] { const char *e = getenv("SC2_DEC_STAGGER"); return e ? atoi(e) : 0; }();
+        b.stagger = stagger;
+    }
     b.stamps = nullptr;
 #if SC2_DEC_STAMPS
     const char *stamp_path = getenv("SC2_DEC_STAMPS");
@@ -444,7 +492,7 @@ extern "C" int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int K
     a.beta = beta;
     a.y = static_cast<uint16_t *>(y);
     a.N = N; a.H = H; a.W = W; a.OH = H + 1; a.OW = W + 1; a.OHW = a.OH * a.OW; a.M = (int)M;
-    a.Kpad = Kpad; a.n_tiles = (int)((M + BM - 1) / BM); a.inverse = inverse ? 1 : 0; a.tile_ctr = nullptr; a.stamps = nullptr;
+    a.Kpad = Kpad; a.n_tiles = (int)((M + BM - 1) / BM); a.inverse = inverse ? 1 : 0; a.tile_ctr = nullptr; a.stamps = nullptr; a.stagger = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (Cin) {
         case 8: return inverse ? launch_dec<8, true>(a, s) : launch_dec<8, false>(a, s);
