@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(wave >= 0 && wave < 4);
     const int frow = lane & 15, fq = lane >> 4;
     const int H = p.H;
 
@@ -195,13 +196,15 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         jb.row0 = 2 * oh0 - 2;
         return jb;
     };
+    // (branch-free: this wave is alone on its SIMD and a scalar branch costs it tens of cycles -- the unit loop held 109 of them.
+    //  A piece index past the end (k = 12 on the last wave) re-issues the wave's FIRST piece: same bytes to the same place.)
     auto issue_piece = [&](const PatchJob &jb, int k) {
-        const int pc = wave + NW * k;
-        if (pc < N_PIECES) {   // wave-uniform
-            const int ih = jb.row0 + (int)(pv[k] & 7u);   // patch row r rides in the offset's free low bits
-            const uint32_t vo = (jb.live & ((unsigned)ih < (unsigned)H)) ? (pv[k] & ~15u) : 0x80000000u;
-            buf_load_lds16(jb.rs, (lds_ptr_t)(jb.dst + pc * 1024), vo, jb.soff);
-        }
+        const bool real = k < PIECES_PER_WAVE - 1 || wave + NW * k < N_PIECES;   // (k < 12: compile-time true)
+        const int pc = real ? wave + NW * k : wave;
+        const uint32_t pvk = real ? pv[k] : pv[0];
+        const int ih = jb.row0 + (int)(pvk & 7u);   // patch row r rides in the offset's free low bits
+        const uint32_t vo = (jb.live & ((unsigned)ih < (unsigned)H)) ? (pvk & ~15u) : 0x80000000u;
+        buf_load_lds16(jb.rs, (lds_ptr_t)(jb.dst + pc * 1024), vo, jb.soff);
     };
     auto issue_patch = [&](int unit, int cb, int buf) {
         const PatchJob jb = patch_setup(unit, cb, buf);
@@ -273,10 +276,11 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             //  vmcnt(0) = for the 12 - 13 patch pieces this wave issues behind them, i.e. the wave with seven taps -- the slowest
             //  of the slab already -- also waited for the next slab's or unit's patch)
             u32x4_t w6[NT];
-            if (tap6 < NTAP) {
+            {   // (every wave fetches: the three without a seventh tap load tap 24 again and ignore it -- no branch, and the same
+                //  number of vector-memory operations in flight on every wave)
                 int ln = lane;
                 asm volatile("" : "+v"(ln));   // (address rebuilt here, not carried across the unit)
-                const uint4 *w6p = reinterpret_cast<const uint4 *>(p.w) + ((cb * NTAP + tap6) * NT) * 64 + ln;
+                const uint4 *w6p = reinterpret_cast<const uint4 *>(p.w) + ((cb * NTAP + (tap6 < NTAP ? tap6 : NTAP - 1)) * NT) * 64 + ln;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     asm volatile("global_load_dwordx4 %0, %1, off ; wfrag" : "=&v"(w6[j]) : "v"(w6p + j * 64) : "memory");
@@ -300,12 +304,14 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
 #pragma unroll
             for (int q = 0; q <= NQ; ++q) {
                 const int tap = ((wave + cb) & 3) + 4 * q;
+                // (seventh tap: its fragments are older than the >= 12 patch pieces issued behind taps 0 .. 4.  EVERY wave waits,
+                //  also the three that ignore what they fetched: a load that lands in a register the compiler has given to
+                //  something else is the hazard tools/audit_vmcnt.py --copies looks for; the marker tells it they have landed)
+                if (q == NQ) asm volatile("s_waitcnt vmcnt(12) ; wfrag-landed" ::: "memory");
                 if (tap < NTAP) {   // wave-uniform (q < NQ: always)
-                    // (seventh tap: its fragments are older than the >= 12 patch pieces issued behind taps 0 .. 4)
-                    if (q == NQ) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tap q's fragments
                     __builtin_amdgcn_sched_barrier(0);
-                    const int ntap = tap + 4;
+                    const int ntap = tap + 4 < NTAP ? tap + 4 : tap;   // (past the last tap: this tap's fragments again, unused)
                     const int nkh = ntap / 5, nkw = ntap - nkh * 5;
                     const int noff = (((nkw & 1) * 7 + nkh) * J + (nkw >> 1)) * 64;
                     int fqo = fq;
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
 
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-                        if (q < NQ && ntap < NTAP) av[(q + 1) & 1][i] = lds_read16(frag_addr(pb + (uint32_t)noff, i, nkw >> 1, fqo));
+                        if (q < NQ) av[(q + 1) & 1][i] = lds_read16(frag_addr(pb + (uint32_t)noff, i, nkw >> 1, fqo));
                         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[q & 1][i]);
 #pragma unroll
                         for (int j = 0; j < NT; ++j) {

@@ -138,7 +138,6 @@ struct W2Args {
     int N, H, Cin, OH;
     int W, OW, nseg;                     // runtime-geometry instantiations only (Geo2<.., .., true>): map widths, column segments per row block
     int n_tiles, tiles_per_img, tiles_per_wg;
-    int dbg;                             // DEBUG (SC2_W2_DBG): 1 = store x instead of y, 2 = store beta + norm
     unsigned x_bytes, w_bytes, y_bytes, o1_bytes, ods_bytes;
 };
 
@@ -205,6 +204,12 @@ constexpr int VM_STEP = 2 * (PF - 1) + 2;
 // in flight (PRE) and every wait is lgkmcnt(6).  Before, each step began by issuing seven reads and waiting for the first:
 // with the two waves of a SIMD in lockstep behind the slab barrier nobody covered that latency (~150 - 250 cycles of every
 // ~1 500-cycle step).  The chain stops at a slab boundary: the next slab's window is complete only behind its barrier.
+// DEBUG builds only (-DSC2_W2_DBG_OUT=1: the fused kernels store x instead of y; 2: beta + norm).  As a RUNTIME argument the
+// two tests sat in front of each of a tile's fourteen output stores: three scalar branches and sixteen register copies per row
+// tile in the shipping kernel (round 4: found in the listing).
+#ifndef SC2_W2_DBG_OUT
+#define SC2_W2_DBG_OUT 0
+#endif
 #ifndef SC2_W2_CHAIN
 #define SC2_W2_CHAIN 1   // 0: every k-step reads its own first seven fragments (A/B)
 #endif
@@ -602,9 +607,9 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
                                  beta_hi.x + acc[i][1][0], beta_hi.y + acc[i][1][1], beta_hi.z + acc[i][1][2], beta_hi.w + acc[i][1][3]}; \
             float r[8];                                                                                                             \
             _Pragma("unroll") for (int e = 0; e < 8; ++e) r[e] = INVERSE ? xv[e] * nm[e] : xv[e] * (1.0f / nm[e]);                  \
-            if (p.dbg == 1) {                                                                                                       \
+            if (SC2_W2_DBG_OUT == 1) {                                                                                              \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e) r[e] = xv[e];                                                         \
-            } else if (p.dbg == 2) {                                                                                                \
+            } else if (SC2_W2_DBG_OUT == 2) {                                                                                       \
                 _Pragma("unroll") for (int e = 0; e < 8; ++e) r[e] = nm[e];                                                         \
             }                                                                                                                       \
             buf_store16(rs_y, out_off(i, fr, y_ch, 512), y_so,                                                                      \
@@ -704,10 +709,6 @@ extern "C" int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const floa
     a.N = N; a.H = H; a.Cin = Cin; a.OH = H + 2 * pad - 1;
     a.W = W; a.OW = W + 2 * pad - 1; a.nseg = 1;
     a.n_tiles = 0; a.tiles_per_img = 0; a.tiles_per_wg = 0;
-    {
-        const char *dbg = getenv("SC2_W2_DBG");
-        a.dbg = dbg ? atoi(dbg) : 0;
-    }
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     a.bias1 = nullptr; a.bias_ds = nullptr; a.o1 = nullptr; a.ods = nullptr; a.o1_bytes = 0; a.ods_bytes = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -740,7 +741,7 @@ extern "C" int sc2_conv2x2_win_tail_fwd(const void *x, const void *w_stream, con
     a.ods = static_cast<uint16_t *>(ods);
     a.N = N; a.H = H; a.Cin = Cin; a.OH = 56;
     a.W = W; a.OW = W + 1; a.nseg = 1;
-    a.n_tiles = 0; a.tiles_per_img = 0; a.tiles_per_wg = 0; a.dbg = 0;
+    a.n_tiles = 0; a.tiles_per_img = 0; a.tiles_per_wg = 0;
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)((Cin / 32 * 4 + 24) * 16384); a.y_bytes = y ? (unsigned)y_bytes : 0u;
     a.o1_bytes = (unsigned)((long long)N * 56 * 56 * 256); a.ods_bytes = (unsigned)((long long)N * 28 * 28 * 1024);
     return launch_w2<Gd4, 2>(a, static_cast<hipStream_t>(stream));

@@ -135,8 +135,9 @@ def audit_copies(body):
         op, args = toks[0], toks[1:]
         if a and op in ('buffer_load_dwordx4', 'global_load_dwordx4') and 'wfrag' in t:
             return hot | regs_of(args[0])
-        if op == 's_waitcnt' and 'vmcnt(0)' in t:
-            return set()   # everything has landed
+        if op == 's_waitcnt' and ('vmcnt(0)' in t or 'wfrag-landed' in t):
+            return set()   # everything has landed (vmcnt(0)), or the kernel says so: a counted wait whose budget covers every marked
+            #                load still in flight carries the asm comment `; wfrag-landed` (conv2_gdn48: fetches some waves never use)
         if op.startswith('s_'):
             return hot
         is_store = op.startswith(('buffer_store', 'global_store', 'ds_write', 'flat_store', 'scratch_store'))
