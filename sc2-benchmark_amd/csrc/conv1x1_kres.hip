@@ -19,6 +19,8 @@
 
 #include <atomic>
 
+#include <type_traits>
+
 #include "sc2_common.h"
 
 namespace {
@@ -229,25 +231,32 @@ __global__ __launch_bounds__(256, 1) void conv1x1_kres_kernel(const KresArgs p) 
         {
             unsigned char *oimg = smem + S::OIMG_OFF;
             constexpr int CPI = BNC / 8;
+            // (the ReLU flag is tested once per unit: inside the loop it was two scalar branches per owned tile, on a wave that has
+            //  its SIMD to itself)
+            auto finish = [&](auto relu_c) {
+                constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-            for (int b = 0; b < NOWN; ++b) {
-                const int bb = kh * NOWN + b;
-                const int i = bb / NTW, j = bb % NTW;             // (scalar)
-                const int px = i * 16 + frow;
-                const int ch = nh * (BNC / 2) + j * 16 + fq * 4;  // channel inside the chunk
-                const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + ch);
-                f32x2_t v01 = f32x2_t{own[b][0], own[b][1]} + f32x2_t{bias4.x, bias4.y};
-                f32x2_t v23 = f32x2_t{own[b][2], own[b][3]} + f32x2_t{bias4.z, bias4.w};
-                if (p.relu) {
-                    v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
-                    v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
+                for (int b = 0; b < NOWN; ++b) {
+                    const int bb = kh * NOWN + b;
+                    const int i = bb / NTW, j = bb % NTW;             // (scalar)
+                    const int px = i * 16 + frow;
+                    const int ch = nh * (BNC / 2) + j * 16 + fq * 4;  // channel inside the chunk
+                    const float4 bias4 = *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + ch);
+                    f32x2_t v01 = f32x2_t{own[b][0], own[b][1]} + f32x2_t{bias4.x, bias4.y};
+                    f32x2_t v23 = f32x2_t{own[b][2], own[b][3]} + f32x2_t{bias4.z, bias4.w};
+                    if (RELU) {
+                        v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
+                        v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
+                    }
+                    uint2 o;
+                    o.x = pack2(v01);
+                    o.y = pack2(v23);
+                    const int c = ch >> 3;                            // 16-byte chunk of the row; swizzled by the row
+                    *reinterpret_cast<uint2 *>(oimg + px * (BNC * 2) + ((c ^ (px & (CPI - 1))) << 4) + (ch & 7) * 2) = o;
                 }
-                uint2 o;
-                o.x = pack2(v01);
-                o.y = pack2(v23);
-                const int c = ch >> 3;                            // 16-byte chunk of the row; swizzled by the row
-                *reinterpret_cast<uint2 *>(oimg + px * (BNC * 2) + ((c ^ (px & (CPI - 1))) << 4) + (ch & 7) * 2) = o;
-            }
+            };
+            if (p.relu) finish(std::true_type{});
+            else finish(std::false_type{});
         }
         __syncthreads();
         {

@@ -19,6 +19,8 @@
 
 #include <atomic>
 
+#include <type_traits>
+
 #include "sc2_common.h"
 
 namespace {
@@ -97,18 +99,27 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
             }
         }
         // A tile: chunk q = tid + 512 k  ->  (row, 16-byte chunk); the youngest loads: waiting for them covers the rest
+        // (ONE test of the stride per unit, not one per chunk: wave-uniform runtime conditions inside unrolled loops become
+        //  scalar branches, and this kernel's unit loop held 62 of them for 128 MFMAs)
+        if (p.stride != 1) {
 #pragma unroll
-        for (int k = 0; k < A_Q; ++k) {
-            const int q = tid + 512 * k;
-            const int row = q / CPR, c = q - row * CPR;
-            const int m = min(m0 + row, p.M - 1);
-            long long pix = m;
-            if (p.stride != 1) {
+            for (int k = 0; k < A_Q; ++k) {
+                const int q = tid + 512 * k;
+                const int row = q / CPR, c = q - row * CPR;
+                const int m = min(m0 + row, p.M - 1);
                 const int im = m / p.OHW, rem = m - im * p.OHW;
                 const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                pix = ((long long)im * p.H + oh * p.stride) * p.W + ow * p.stride;
+                const long long pix = ((long long)im * p.H + oh * p.stride) * p.W + ow * p.stride;
+                a_next[k] = *reinterpret_cast<const u32x4_t *>(p.x + pix * K + c * 8);
             }
-            a_next[k] = *reinterpret_cast<const u32x4_t *>(p.x + pix * K + c * 8);
+        } else {
+#pragma unroll
+            for (int k = 0; k < A_Q; ++k) {
+                const int q = tid + 512 * k;
+                const int row = q / CPR, c = q - row * CPR;
+                const long long pix = min(m0 + row, p.M - 1);
+                a_next[k] = *reinterpret_cast<const u32x4_t *>(p.x + pix * K + c * 8);
+            }
         }
     };
     auto store_a = [&](int tid) {
@@ -160,32 +171,38 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
         }
         __syncthreads();   // the A tile has been consumed by every wave; the residual image is complete
         // ---- y = act(acc + bias [+ residual]) in place in the image; explicit (e0,e1)/(e2,e3) pairs: packed ops
+        // (the ReLU flag is tested ONCE per unit: as `if (p.relu)` inside the loops it was two scalar branches per accumulator tile)
+        auto finish = [&](auto relu_c) {
+            constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = wn * (NT * 16) + j * 16 + fq * 4;            // channel inside the chunk
-            const float4 b4 = b_next[j];
-            const f32x2_t b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
+            for (int j = 0; j < NT; ++j) {
+                const int col = wn * (NT * 16) + j * 16 + fq * 4;            // channel inside the chunk
+                const float4 b4 = b_next[j];
+                const f32x2_t b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = i * 16 + frow;
-                unsigned char *slot = img + row * (BNC * 2) + (((col >> 3) ^ frow) << 4) + (col & 7) * 2;
-                f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]} + b01;
-                f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]} + b23;
-                if (RES) {
-                    const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
-                    v01 += f32x2_t{__builtin_bit_cast(float, xr.x << 16), __builtin_bit_cast(float, xr.x & 0xFFFF0000u)};
-                    v23 += f32x2_t{__builtin_bit_cast(float, xr.y << 16), __builtin_bit_cast(float, xr.y & 0xFFFF0000u)};
+                for (int i = 0; i < MT; ++i) {
+                    const int row = i * 16 + frow;
+                    unsigned char *slot = img + row * (BNC * 2) + (((col >> 3) ^ frow) << 4) + (col & 7) * 2;
+                    f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]} + b01;
+                    f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]} + b23;
+                    if (RES) {
+                        const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
+                        v01 += f32x2_t{__builtin_bit_cast(float, xr.x << 16), __builtin_bit_cast(float, xr.x & 0xFFFF0000u)};
+                        v23 += f32x2_t{__builtin_bit_cast(float, xr.y << 16), __builtin_bit_cast(float, xr.y & 0xFFFF0000u)};
+                    }
+                    if (RELU) {
+                        v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
+                        v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
+                    }
+                    uint2 o;
+                    o.x = pack2(v01);
+                    o.y = pack2(v23);
+                    *reinterpret_cast<uint2 *>(slot) = o;
                 }
-                if (p.relu) {
-                    v01 = f32x2_t{fmaxf(v01[0], 0.f), fmaxf(v01[1], 0.f)};
-                    v23 = f32x2_t{fmaxf(v23[0], 0.f), fmaxf(v23[1], 0.f)};
-                }
-                uint2 o;
-                o.x = pack2(v01);
-                o.y = pack2(v23);
-                *reinterpret_cast<uint2 *>(slot) = o;
             }
-        }
+        };
+        if (p.relu) finish(std::true_type{});
+        else finish(std::false_type{});
         __syncthreads();
         // ---- the accumulators are dead: claim a unit and fetch the next unit's operands, THEN stream this unit out
         int tq = tid;   // opaque: per-thread offsets are recomputed here, not carried (spilled) across the unit

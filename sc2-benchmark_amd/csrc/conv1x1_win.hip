@@ -20,6 +20,8 @@
 // Stride 2 (the downsample layers) only changes which input pixel a window row is filled from.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sc2_common.h"
 
 namespace {
@@ -45,11 +47,17 @@ __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint
 __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+// (masked lanes out of range instead of a branch around the store; literal soffset 0: see conv3x3_win.hip buf_store16_z)
+typedef unsigned win_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store16_z(buf_rsrc_t r, uint32_t voff, uint4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(win_u32x4_t{v.x, v.y, v.z, v.w}, r, (int)voff, 0, 0);
+}
 #else   // host pass: stand-ins (see conv_igemm_impl.h)
 typedef int buf_rsrc_t;
 __device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *, uint32_t) { return 0; }
 __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, uint32_t) {}
 __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t, uint32_t, uint32_t) { return make_uint4(0, 0, 0, 0); }
+__device__ __forceinline__ void buf_store16_z(buf_rsrc_t, uint32_t, uint4) {}
 #endif
 
 // Weight fragments are loaded by INLINE ASM and waited for with hand-counted `s_waitcnt vmcnt(N)` (round 4; conv2x2_win.hip has
@@ -95,7 +103,7 @@ struct P1Args {
     int N, H, W, OH, OW, stride, Cin, Cout, relu;
     int n_chunks;                        // Cout / 128
     long long M;
-    unsigned x_bytes, w_bytes;
+    unsigned x_bytes, w_bytes, y_bytes;
 };
 
 // MT_ MFMA row tiles per tile: 13 (208 pixels, two workgroups per CU or one with the 4-deep ring) or 7 (112 pixels, ~150 VGPRs,
@@ -172,21 +180,26 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
     // window fill: wave w fills chunk planes 2 w and 2 w + 1 (chunk c = channels [8 c, 8 c + 8) of the slab); piece j = rows
     // [64 j, 64 j + 64) = output pixels m0 + 64 j + lane.  The per-lane source offsets stay in registers.
     uint32_t pw_vo[NRG];
+    // (stride tested once, lane masks as selects: branch-free)
+    if (p.stride != 1) {
+        const int ohw = p.OH * p.OW;
 #pragma unroll
-    for (int j = 0; j < NRG; ++j) {
-        const long long m = m0 + j * 64 + lane;
-        uint32_t vo = OOB;
-        if (j * 64 + lane < PX && m < p.M) {
-            long long pix = m;
-            if (p.stride != 1) {
-                const int ohw = p.OH * p.OW;
-                const int n = (int)(m / ohw), rem = (int)(m - (long long)n * ohw);
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                pix = ((long long)n * p.H + oh * p.stride) * p.W + ow * p.stride;
-            }
-            vo = (uint32_t)(pix * Cin * 2);
+        for (int j = 0; j < NRG; ++j) {
+            const long long m = m0 + j * 64 + lane;
+            const bool ok = (j * 64 + lane < PX) & (m < p.M);
+            const long long mc = ok ? m : 0;
+            const int n = (int)(mc / ohw), rem = (int)(mc - (long long)n * ohw);
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const long long pix = ((long long)n * p.H + oh * p.stride) * p.W + ow * p.stride;
+            pw_vo[j] = ok ? (uint32_t)(pix * Cin * 2) : OOB;
         }
-        pw_vo[j] = vo;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NRG; ++j) {
+            const long long m = m0 + j * 64 + lane;
+            const bool ok = (j * 64 + lane < PX) & (m < p.M);
+            pw_vo[j] = ok ? (uint32_t)(m * Cin * 2) : OOB;
+        }
     }
     // (EVERY slab start issues its 2 NRG pieces -- the k-steps' vmcnt budgets count them: past the last slab they come from a
     //  zero-sized descriptor, i.e. zeros into a dead buffer)
@@ -282,31 +295,43 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
     // of pixel m0 + i * 16 + frow
     const float4 bias_lo = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq);
     const float4 bias_hi = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq + 4);
-    const bool relu = p.relu != 0;
-    const bool has_res = p.res != nullptr;
-    uint4 rv[MT];
-    if (has_res) {
+    // Branch-free (round 4): the flags are tested once, masked lanes load / store out of range through descriptors (a load out
+    // of range returns zeros) -- as per-row-tile `if`s the epilogue of a 3 - 6 us workgroup held ~75 scalar branches.
+    const buf_rsrc_t rs_y = make_rsrc(p.y, p.y_bytes);
+    const buf_rsrc_t rs_r = make_rsrc(p.res ? p.res : p.y, p.res ? p.y_bytes : 0u);
+    auto finish = [&](auto relu_c, auto res_c) {
+        constexpr bool RELU = decltype(relu_c)::value, HAS_RES = decltype(res_c)::value;
+        uint4 rv[MT];
+        if (HAS_RES) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const long long m = m0 + i * 16 + frow;
+                rv[i] = buf_load16(rs_r, m < p.M ? (uint32_t)((m * Cout + n0 + 8 * fq) * 2) : 0x80000000u, 0u);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const long long m = m0 + i * 16 + frow;
-            rv[i] = m < p.M ? *reinterpret_cast<const uint4 *>(p.res + m * Cout + n0 + 8 * fq) : make_uint4(0, 0, 0, 0);
-        }
-    }
+            float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
+                          acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
+            if (HAS_RES) {
+                v[0] += bf_lo(rv[i].x); v[1] += bf_hi(rv[i].x); v[2] += bf_lo(rv[i].y); v[3] += bf_hi(rv[i].y);
+                v[4] += bf_lo(rv[i].z); v[5] += bf_hi(rv[i].z); v[6] += bf_lo(rv[i].w); v[7] += bf_hi(rv[i].w);
+            }
+            if (RELU) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const long long m = m0 + i * 16 + frow;
-        float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
-                      acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
-        if (has_res) {
-            v[0] += bf_lo(rv[i].x); v[1] += bf_hi(rv[i].x); v[2] += bf_lo(rv[i].y); v[3] += bf_hi(rv[i].y);
-            v[4] += bf_lo(rv[i].z); v[5] += bf_hi(rv[i].z); v[6] += bf_lo(rv[i].w); v[7] += bf_hi(rv[i].w);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+            buf_store16_z(rs_y, m < p.M ? (uint32_t)((m * Cout + n0 + 8 * fq) * 2) : 0x80000000u, o);
         }
-        if (relu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-        if (m < p.M) *reinterpret_cast<uint4 *>(p.y + m * Cout + n0 + 8 * fq) = o;
+    };
+    if (p.res != nullptr) {
+        if (p.relu != 0) finish(std::true_type{}, std::true_type{});
+        else finish(std::false_type{}, std::true_type{});
+    } else {
+        if (p.relu != 0) finish(std::true_type{}, std::false_type{});
+        else finish(std::false_type{}, std::false_type{});
     }
 }
 
@@ -352,7 +377,7 @@ extern "C" int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const floa
     a.N = N; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.stride = stride; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
     a.n_chunks = Cout / 128;
     a.M = M;
-    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     const long long n_wg = (M + 207) / 208 * a.n_chunks;   // (workgroups of the 208-pixel tiling)
     // ring depth: four buffers (one workgroup per CU) when the launch has about one workgroup per CU anyway (layer4's conv1 at
     // bs 256: 244 workgroups, 0.050 -> 0.045 ms; every launch with more workgroups measured slower that way) and K is a

@@ -21,6 +21,8 @@
 // The two workgroups of a CU are independent: while one wave of a SIMD reads its 13 pixel fragments the other issues MFMAs.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "sc2_common.h"
 
 namespace {
@@ -44,11 +46,19 @@ __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t r, lds_ptr_t dst, uint
 __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+// 16-byte store through a descriptor, masked lanes sent out of range instead of branching around the store.  soffset is the
+// LITERAL 0: that is the form for which hipcc inserts the wait states of the ">64-bit store data" hazard itself (with an SGPR
+// soffset it does not: conv2x2_win.hip buf_store16, tools/micro/store_hazard.hip)
+typedef unsigned win_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store16_z(buf_rsrc_t r, uint32_t voff, uint4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(win_u32x4_t{v.x, v.y, v.z, v.w}, r, (int)voff, 0, 0);
+}
 #else   // host pass: stand-ins (see conv_igemm_impl.h)
 typedef int buf_rsrc_t;
 __device__ __forceinline__ buf_rsrc_t make_rsrc(const uint16_t *, uint32_t) { return 0; }
 __device__ __forceinline__ void buf_load_lds16(buf_rsrc_t, lds_ptr_t, uint32_t, uint32_t) {}
 __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t, uint32_t, uint32_t) { return make_uint4(0, 0, 0, 0); }
+__device__ __forceinline__ void buf_store16_z(buf_rsrc_t, uint32_t, uint4) {}
 #endif
 
 // Weight fragments of the stride-1 kernel are loaded by INLINE ASM and waited for with hand-counted `s_waitcnt vmcnt(N)` (round 4;
@@ -95,7 +105,7 @@ struct WinArgs {
     int N, Cin, Cout, relu;
     int n_chunks;                        // Cout / 128
     int n_mtiles;
-    unsigned x_bytes, w_bytes;
+    unsigned x_bytes, w_bytes, y_bytes;
     unsigned long long *stamps;          // DEBUG (SC2_WIN_STAMPS=1): [workgroup][start, end] of the 100 MHz wall clock, or null
 };
 
@@ -307,20 +317,29 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(co
     const float4 bias_hi = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq + 4);
     const long long m_base = G::IMGS > 1 ? (long long)img0 * (H * W) : ((long long)img0 * H + row0) * W;
     const long long M = (long long)p.N * H * W;
-    const bool relu = p.relu != 0;
+    // Branch-free (round 4): the ReLU flag is tested once (as `if (relu)` inside the unrolled loop it was two scalar branches per
+    // row tile) and masked lanes store out of range through a descriptor instead of jumping around the store -- a workgroup
+    // lives for 3 - 6 us, and its ~60 branches were a measurable part of that.
+    const buf_rsrc_t rs_y = make_rsrc(p.y, p.y_bytes);
+    auto finish = [&](auto relu_c) {
+        constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int ml = i * 16 + frow;
-        const long long m = m_base + ml;
-        float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
-                      acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
-        if (relu) {
+        for (int i = 0; i < MT; ++i) {
+            const int ml = i * 16 + frow;
+            const long long m = m_base + ml;
+            float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
+                          acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
+            if (RELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+            const bool ok = (ml < G::PX) & (m < M);
+            buf_store16_z(rs_y, ok ? (uint32_t)((m * Cout + n0 + 8 * fq) * 2) : 0x80000000u, o);
         }
-        const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-        if (ml < G::PX && m < M) *reinterpret_cast<uint4 *>(p.y + m * Cout + n0 + 8 * fq) = o;
-    }
+    };
+    if (p.relu != 0) finish(std::true_type{});
+    else finish(std::false_type{});
     if (p.stamps && tid == 0) p.stamps[2 * blockIdx.x + 1] = wall_clock64();
 }
 
@@ -469,20 +488,29 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3s2_win_kernel(
     const float4 bias_hi = *reinterpret_cast<const float4 *>(p.bias + n0 + 8 * fq + 4);
     const long long m_base = G::IMGS > 1 ? (long long)img0 * (OH * OW) : ((long long)img0 * OH + row0) * OW;
     const long long M = (long long)p.N * OH * OW;
-    const bool relu = p.relu != 0;
+    // Branch-free (round 4): the ReLU flag is tested once (as `if (relu)` inside the unrolled loop it was two scalar branches per
+    // row tile) and masked lanes store out of range through a descriptor instead of jumping around the store -- a workgroup
+    // lives for 3 - 6 us, and its ~60 branches were a measurable part of that.
+    const buf_rsrc_t rs_y = make_rsrc(p.y, p.y_bytes);
+    auto finish = [&](auto relu_c) {
+        constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int ml = i * 16 + frow;
-        const long long m = m_base + ml;
-        float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
-                      acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
-        if (relu) {
+        for (int i = 0; i < MT; ++i) {
+            const int ml = i * 16 + frow;
+            const long long m = m_base + ml;
+            float v[8] = {acc[i][0][0] + bias_lo.x, acc[i][0][1] + bias_lo.y, acc[i][0][2] + bias_lo.z, acc[i][0][3] + bias_lo.w,
+                          acc[i][1][0] + bias_hi.x, acc[i][1][1] + bias_hi.y, acc[i][1][2] + bias_hi.z, acc[i][1][3] + bias_hi.w};
+            if (RELU) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+            const bool ok = (ml < G::PX) & (m < M);
+            buf_store16_z(rs_y, ok ? (uint32_t)((m * Cout + n0 + 8 * fq) * 2) : 0x80000000u, o);
         }
-        const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-        if (ml < G::PX && m < M) *reinterpret_cast<uint4 *>(p.y + m * Cout + n0 + 8 * fq) = o;
-    }
+    };
+    if (p.relu != 0) finish(std::true_type{});
+    else finish(std::false_type{});
 }
 
 template <class G>
@@ -531,8 +559,9 @@ extern "C" int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const fl
                 "conv3x3s2_win: needs a 56 x 56, 28 x 28 or 14 x 14 input map, Cin %% 32 == 0, Cout %% 128 == 0 (got %d x %d, %d -> %d)", H,
                 W, Cin, Cout);
     const long long x_bytes = (long long)N * H * W * Cin * 2, w_bytes = (long long)Cin * 9 * Cout * 2;
-    SC2_REQUIRE(x_bytes < 0x7FF00000LL && w_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv3x3s2_win: operand of %lld bytes exceeds 2 GB",
-                x_bytes > w_bytes ? x_bytes : w_bytes);
+    const long long y_bytes = (long long)N * (H / 2) * (W / 2) * Cout * 2;
+    SC2_REQUIRE(x_bytes < 0x7FF00000LL && w_bytes < 0x7FF00000LL && y_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED,
+                "conv3x3s2_win: operand of %lld bytes exceeds 2 GB", x_bytes > w_bytes ? x_bytes : w_bytes);
     WinArgs a;
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(w_frag);
@@ -540,7 +569,7 @@ extern "C" int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const fl
     a.y = static_cast<uint16_t *>(y);
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
     a.n_chunks = Cout / 128; a.n_mtiles = 0;
-    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int half = [] { const char *e = getenv("SC2_WIN_HALF"); return e ? atoi(e) : 1; }();
@@ -567,8 +596,9 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
                 "conv3x3_win: needs a 28 x 28, 14 x 14 or 7 x 7 map, Cin %% 64 == 0, Cout %% 128 == 0 (got %d x %d, %d -> %d)", H, W, Cin,
                 Cout);
     const long long x_bytes = (long long)N * H * W * Cin * 2, w_bytes = (long long)Cin * 9 * Cout * 2;
-    SC2_REQUIRE(x_bytes < 0x7FF00000LL && w_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv3x3_win: operand of %lld bytes exceeds 2 GB",
-                x_bytes > w_bytes ? x_bytes : w_bytes);
+    const long long y_bytes = (long long)N * H * W * Cout * 2;
+    SC2_REQUIRE(x_bytes < 0x7FF00000LL && w_bytes < 0x7FF00000LL && y_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED,
+                "conv3x3_win: operand of %lld bytes exceeds 2 GB", x_bytes > w_bytes ? x_bytes : w_bytes);
     WinArgs a;
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(w_frag);
@@ -576,7 +606,7 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
     a.y = static_cast<uint16_t *>(y);
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
     a.n_chunks = Cout / 128; a.n_mtiles = 0;
-    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes;
+    a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const int half = [] { const char *e = getenv("SC2_WIN_HALF"); return e ? atoi(e) : 1; }();
