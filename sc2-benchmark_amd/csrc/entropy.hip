@@ -169,14 +169,21 @@ __global__ __launch_bounds__(EB_THREADS) void eb_backward_kernel(
     const float *P = params + c * SC2_EB_PARAM_STRIDE;
     const float med = P[58];
     const long long base = (long long)plane * HW;
+    // The workgroup blockIdx.y == 0 of a plane walks the WHOLE plane (the others only zero their partial row, which the caller
+    // sums): the 59 parameter-gradient sums per thread end in 354 cross-lane shuffles + an LDS round, which with four elements per
+    // thread cost as much as the elements themselves (round 4: 0.85 ms per 256 x 24 x 55 x 55 launch).
+    if (blockIdx.y != 0) {
+        if (threadIdx.x < SC2_EB_PARAM_STRIDE)
+            g_partial[((long long)plane * gridDim.y + blockIdx.y) * SC2_EB_PARAM_STRIDE + threadIdx.x] = 0.f;
+        return;
+    }
     float G[SC2_EB_PARAM_STRIDE];
 #pragma unroll
     for (int k = 0; k < SC2_EB_PARAM_STRIDE; ++k) G[k] = 0.f;
     float g_med = 0.f;
 #pragma unroll 1
-    for (int e = 0; e < EB_EPT; ++e) {
-        const int pix = blockIdx.y * EB_TILE + e * EB_THREADS + threadIdx.x;
-        if (pix < HW) {
+    for (int pix = threadIdx.x; pix < HW; pix += EB_THREADS) {
+        {
             const float v = y[base + pix];
             const float out = mode == SC2_EB_NOISE ? v + noise[base + pix] : rintf(v - med) + med;
             float d_total = g_yhat ? g_yhat[base + pix] : 0.f;
