@@ -202,3 +202,24 @@ def test_bpp_estimated_against_the_oracle(bench_model, dev):
         want = float(-torch.log2(oracle.bottleneck_layer.entropy_bottleneck(lat)[1]).sum().item())
         got = float(-torch.log2(model.bottleneck_layer.entropy_bottleneck(lat.to(dev))[1].float()).sum().item())
     assert abs(got - want) <= 1e-5 * want, (got, want)
+
+
+@pytest.mark.gpu
+def test_workload_line_mshp224_on_the_device_coder(dev, capsys):
+    """`bench.py --workload mshp224` in-process at 72 images (more streams than the host coder takes: both byte streams go
+    through the batched HIP coder, the y stream through the per-symbol-index decoder with four lanes per stream): line schema,
+    finite outputs (asserted inside), bpp in a plausible range, both indexed coder tags timed."""
+    import argparse
+    import json
+    import bench
+    from sc2bench_amd import hip
+    assert 72 > hip.host_coder_max_streams()
+    args = argparse.Namespace(workload='mshp224', bs=72, steps=1, warmup=1, no_cpu_baseline=True)
+    bench.workload_bench(args, dev, 0, 1, False)
+    line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('{')][-1])
+    assert line['unit'] == 'images/s' and line['value'] > 0 and line['config']['batch_per_gpu'] == 72
+    assert line['config']['range_coder'].startswith('batched HIP coder')
+    assert 1.0 < line['bpp'] < 12.0
+    for tag in ('rans_encode.indexed', 'rans_decode.indexed', 'rans_encode', 'rans_decode'):
+        assert tag in line['rans'] and line['rans'][tag]['ms_per_launch'] > 0, (tag, line['rans'])
+    assert line['roofline'] is not None and 0.0 < line['roofline']['frac'] < 1.0
