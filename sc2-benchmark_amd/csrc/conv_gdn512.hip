@@ -25,6 +25,12 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_DEC_NT
+#define SC2_DEC_NT 1       // non-temporal output stores (the 822 MB map is read by the NEXT launch, from HBM / the memory-side cache either way): - 2 %
+#endif
+#ifndef SC2_DEC_W_EARLY
+#define SC2_DEC_W_EARLY 1
+#endif
 #ifndef SC2_DEC_DBG
 #define SC2_DEC_DBG 0      // timing experiments (results garbage): 1 = no output stores
 #endif
@@ -328,12 +334,20 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
                 *reinterpret_cast<uint2 *>(slot) = o;
                 if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+#if SC2_DEC_W_EARLY
+            // the next tile's W0 fragments, fetched HALFWAY through the epilogue (half of the norm accumulators are dead: no
+            // register pressure) instead of directly in front of the read-out, whose sixteen stores per wave then queue behind
+            // twelve scattered loads: 0.527 -> 0.514 ms (round 4)
+            if (j == 1) load_w();
+#endif
         }
         STAMP(4);
         __syncthreads();
         STAMP(5);
         const int tile_after_next = __builtin_amdgcn_readfirstlane(*next_slot);
+#if !SC2_DEC_W_EARLY
         load_w();          // next tile's W0 fragments, issued ahead of the output stores
+#endif
         {
             // thread (wave wn, lane) streams chunk `lane` of rows wn, wn + 8, ...: row & 15 = wn or wn + 8
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)m0 * CH) + tid;   // the tile is contiguous in y
@@ -364,7 +378,11 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
                                  : "memory");
 #if !(SC2_DEC_DBG & 1)   // (timing experiment: no output stores)
 #pragma unroll
+#if SC2_DEC_NT
+                    for (int r = 0; r < 8; ++r) __builtin_nontemporal_store(v[r], reinterpret_cast<u32x4_t *>(yo + (8 * h + r) * 512));
+#else
                     for (int r = 0; r < 8; ++r) yo[(8 * h + r) * 512] = __builtin_bit_cast(uint4, v[r]);
+#endif
 #else
                     asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
 #endif
