@@ -25,6 +25,10 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_NT_ENC0
+#define SC2_NT_ENC0 1   // non-temporal output stores (sc2_common.h); 0: A/B
+#endif
+
 namespace {
 
 struct EncArgs {
@@ -239,7 +243,8 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
                     const unsigned q0 = tq + 256 * k;
                     const unsigned q = q0 < (unsigned)n_chunks ? q0 : (unsigned)tq;   // past the end: the thread's first chunk again
                     const unsigned px = (q * 43691u) >> 19;                           // q / 12 for q < 4096
-                    yo[q] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
+                    if (SC2_NT_ENC0) sc2_store16_nt(yo + q, *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2)));
+                    else yo[q] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
                 }
             } else {
                 // the unit's two output rows x n_cols pixels: runs of n_cols * 192 bytes at (oh0 + row, seg * OW); for the
@@ -255,7 +260,8 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
                     const unsigned q = ok ? q0 : q_safe;                               // invalid: a valid chunk again (same data)
                     const unsigned px = (q * 43691u) >> 19;
                     const unsigned row = px >= (unsigned)OW ? 1u : 0u, col = px - row * OW;
-                    yo[(row * p.WP + col) * 12 + (q - px * 12)] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
+                    if (SC2_NT_ENC0) sc2_store16_nt(yo + (row * p.WP + col) * 12 + (q - px * 12), *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2)));
+                    else yo[(row * p.WP + col) * 12 + (q - px * 12)] = *reinterpret_cast<const uint4 *>(img + q * 16 + px * (IMG_PITCH - CH * 2));
                 }
             }
         }

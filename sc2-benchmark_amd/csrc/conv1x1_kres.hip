@@ -23,6 +23,10 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_NT_KRES
+#define SC2_NT_KRES 0   // non-temporal output stores: measured SLOWER here (the consumer launch finds part of this map in L2 / the memory-side cache: head + 2.5 %, dec.conv2 + 2 %); 1: A/B
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -269,8 +273,9 @@ __global__ __launch_bounds__(256, 1) void conv1x1_kres_kernel(const KresArgs p) 
                 int row = q / CPI;
                 const int c = q % CPI;
                 row = m0 + row < p.M ? row : 0;      // past the end: row 0 of the tile again (same data, same address)
-                yo[(long long)(m0 + row) * (p.Cout / 8) + c] =
-                    *reinterpret_cast<const uint4 *>(oimg + row * (BNC * 2) + ((c ^ (row & (CPI - 1))) << 4));
+                const uint4 ov = *reinterpret_cast<const uint4 *>(oimg + row * (BNC * 2) + ((c ^ (row & (CPI - 1))) << 4));
+                if (SC2_NT_KRES) sc2_store16_nt(yo + (long long)(m0 + row) * (p.Cout / 8) + c, ov);
+                else yo[(long long)(m0 + row) * (p.Cout / 8) + c] = ov;
             }
         }
         if (tid == 0) {   // the claim is older than the A pieces whose wait opens the next unit - and than these stores

@@ -27,6 +27,10 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_NT_PAIR
+#define SC2_NT_PAIR 0   // non-temporal output stores: measured SLOWER here (the consumer launch finds part of this map in L2 / the memory-side cache: head + 2.5 %, dec.conv2 + 2 %); 1: A/B
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -50,7 +54,7 @@ __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_
 }
 // (the wait states behind a 16-byte buffer store: see buf_store16 in conv2x2_win.hip)
 __device__ __forceinline__ void buf_store16(buf_rsrc_t r, uint32_t voff, uint32_t soff, u32x4_t v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)voff, (int)soff, SC2_NT_PAIR ? SC2_BUF_AUX_NT : 0);
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 1" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -90,6 +94,7 @@ struct PairArgs {
     const float *__restrict__ b1;        // f32 [N2]
     uint16_t *__restrict__ u;            // bf16 [M][N2]   conv1 output of block b + 1
     int M, n_tiles;
+    int rev;                             // 1: tiles are walked from the END of the map (see sc2_conv1x1_pair_fwd)
     unsigned *tile_ctr;                  // claims so far (claim c = tile c + 2 * gridDim.x); zero between launches
 };
 
@@ -132,11 +137,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
         // straight-line: every load is issued, masked lanes / tiles go out of range and read zeros, so that the compiler's vmcnt
         // bookkeeping stays exact (a conditional load turned into a branch made it wait vmcnt(0) -- for the output stores)
         const bool t_ok = tile < p.n_tiles;
-        const uint32_t so = (uint32_t)(t_ok ? (long long)tile * P * (K1 * 2) : 0);
+        const int tpos = p.rev ? p.n_tiles - 1 - tile : tile;
+        const uint32_t so = (uint32_t)(t_ok ? (long long)tpos * P * (K1 * 2) : 0);
 #pragma unroll
         for (int k = 0; k < OQ; ++k) {
             const int q = tq + 512 * k;
-            const bool ok = t_ok && q < P * (K1 / 8) && (long long)tile * P + q / (K1 / 8) < p.M;
+            const bool ok = t_ok && q < P * (K1 / 8) && (long long)tpos * P + q / (K1 / 8) < p.M;
             ov[k] = buf_load16(rs_o, ok ? (uint32_t)q * 16u : OOB, so);
         }
     };
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
 #pragma unroll
         for (int r = 0; r < P / 8; ++r) {
             const int row = wn + 8 * r;
-            const long long m = (long long)tile * P + row;
+            const long long m = (long long)(p.rev ? p.n_tiles - 1 - tile : tile) * P + row;
             const bool ok = tile < p.n_tiles && m < p.M && !(SC2_PAIR_DBG & 1);      // wave-uniform
             const uint32_t voff = ok ? (uint32_t)((lq ^ (row & 15)) << 4) : OOB;
             buf_load_lds16(rs_idn, (lds_ptr_t)(img + row * ROWB), voff, (uint32_t)(ok ? m * ROWB : 0));
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
 
     bool first = true;
     while (tile < p.n_tiles) {
-        const long long m0 = (long long)tile * P;
+        const long long m0 = (long long)(p.rev ? p.n_tiles - 1 - tile : tile) * P;
         // opaque copies of the thread / lane index: the per-thread offsets of the copy loops below are recomputed inside the tile
         // loop instead of being hoisted out of it and spilled (hipcc kept ~70 of them in scratch and reloaded them between the
         // output stores)
@@ -436,6 +442,16 @@ int launch_pair(const PairArgs &a, hipStream_t s) {
     PairArgs b = a;
     b.n_tiles = (a.M + P - 1) / P;
     b.tile_ctr = g_ring[dev] + (g_seq.fetch_add(1) % kRing);
+    {
+        // Every other launch walks its tiles from the END of the map (SC2_PAIR_ALT=0: always front to back).  The block input a
+        // launch re-reads as the identity was written by the previous pair launch front to back; read front to back again, its
+        // head has been pushed out of the 256 MB memory-side cache by that very traffic (LRU, 512 MB per launch), read back to
+        // front its newest part is still there.  Small: the four launches of a step 0.549 -> 0.536 ms, head - 0.5 % (the
+        // 3x3 layer between two pair launches and the pair's own writes leave ~100 MB of the identity in the cache).
+        static const int alt = [] { const char *e = getenv("SC2_PAIR_ALT"); return e ? atoi(e) : 1; }();
+        static std::atomic<unsigned> calls{0};
+        b.rev = alt ? (int)(calls.fetch_add(1) & 1u) : 0;
+    }
     const int grid = b.n_tiles < g_cus ? b.n_tiles : g_cus;
     hipLaunchKernelGGL((conv1x1_pair_kernel<C, K1, N2, MT>), dim3(grid), dim3(512), lds, s, b);
     SC2_CHECK_LAUNCH();
@@ -456,7 +472,7 @@ extern "C" int sc2_conv1x1_pair_fwd(const void *o, const void *w3_frag, const fl
     a.o = static_cast<const uint16_t *>(o); a.w3 = static_cast<const uint16_t *>(w3_frag); a.b3 = b3;
     a.idn = static_cast<const uint16_t *>(identity); a.h = static_cast<uint16_t *>(h);
     a.w1 = static_cast<const uint16_t *>(w1_frag); a.b1 = b1; a.u = static_cast<uint16_t *>(u);
-    a.M = (int)M; a.n_tiles = 0; a.tile_ctr = nullptr;
+    a.M = (int)M; a.n_tiles = 0; a.tile_ctr = nullptr; a.rev = 0;
     if (N2 == 256) return launch_pair<512, 128, 256, 7>(a, static_cast<hipStream_t>(stream));
     return launch_pair<512, 128, 128, 7>(a, static_cast<hipStream_t>(stream));
 }

@@ -23,6 +23,10 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_NT_STREAM
+#define SC2_NT_STREAM 0   // non-temporal output stores: measured SLOWER here (the consumer launch finds part of this map in L2 / the memory-side cache: head + 2.5 %, dec.conv2 + 2 %); 1: A/B
+#endif
+
 namespace {
 
 struct StreamArgs {
@@ -221,8 +225,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
                 int row = q / CPI;
                 const int c = q % CPI;
                 row = m0 + row < p.M ? row : 0;      // past the end: row 0 of the tile again (same data, same address)
-                yo[(long long)(m0 + row) * (Cout / 8) + c] =
-                    *reinterpret_cast<const uint4 *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4));
+                const uint4 ov = *reinterpret_cast<const uint4 *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4));
+                if (SC2_NT_STREAM) sc2_store16_nt(yo + (long long)(m0 + row) * (Cout / 8) + c, ov);
+                else yo[(long long)(m0 + row) * (Cout / 8) + c] = ov;
             }
         }
         store_a(tq);       // the A tile region was last read before the first barrier of this unit

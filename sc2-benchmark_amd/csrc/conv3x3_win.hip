@@ -25,6 +25,10 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_NT_WIN3
+#define SC2_NT_WIN3 0   // non-temporal output stores: measured SLOWER here (the consumer launch finds part of this map in L2 / the memory-side cache: head + 2.5 %, dec.conv2 + 2 %); 1: A/B
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -51,7 +55,7 @@ __device__ __forceinline__ uint4 buf_load16(buf_rsrc_t r, uint32_t voff, uint32_
 // soffset it does not: conv2x2_win.hip buf_store16, tools/micro/store_hazard.hip)
 typedef unsigned win_u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void buf_store16_z(buf_rsrc_t r, uint32_t voff, uint4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(win_u32x4_t{v.x, v.y, v.z, v.w}, r, (int)voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(win_u32x4_t{v.x, v.y, v.z, v.w}, r, (int)voff, 0, SC2_NT_WIN3 ? SC2_BUF_AUX_NT : 0);
 }
 #else   // host pass: stand-ins (see conv_igemm_impl.h)
 typedef int buf_rsrc_t;

@@ -25,6 +25,16 @@ void sc2_set_error(const char *fmt, ...);
         }                                                               \
     } while (0)
 
+// Non-temporal output stores (round 4), per kernel by measurement: they pay where a launch writes a map far larger than the
+// caches while re-reading operands of its own (conv0_gdn96: 616 MB out, - 8 %; conv2x2_gdn512: 822 MB out, - 2 %) and they LOSE
+// where the next launch finds part of the map in L2 / the memory-side cache (the head's layers: + 2.5 % over the head, layer4's
+// 13 - 51 MB maps + 10 - 15 % each; conv2x2_win + 2 %).  Each kernel has its switch (-DSC2_NT_<KERNEL>=0/1).
+typedef __attribute__((ext_vector_type(4))) unsigned sc2_u32x4_t;
+__device__ __forceinline__ void sc2_store16_nt(uint4 *dst, const uint4 v) {
+    __builtin_nontemporal_store(sc2_u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<sc2_u32x4_t *>(dst));
+}
+constexpr int SC2_BUF_AUX_NT = 2;   // `aux` of __builtin_amdgcn_raw_buffer_store_*: the nt bit
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
