@@ -25,6 +25,9 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_ENC0_ROWS_EARLY
+#define SC2_ENC0_ROWS_EARLY 1
+#endif
 #ifndef SC2_NT_ENC0
 #define SC2_NT_ENC0 1   // non-temporal output stores (sc2_common.h); 0: A/B
 #endif
@@ -167,6 +170,11 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
                 *reinterpret_cast<uint2 *>(img + (px_lane + i * 16) * IMG_PITCH + col * 2) = h;
             }
         __syncthreads();   // staged rows consumed; |t| image complete (a pixel's 96 channels come from two waves)
+        // the NEXT unit's seven rows are fetched here, in front of the GDN phase, instead of directly in front of this unit's
+        // output stores (round 4: loads queued in front of a store burst delay it; conv2x2_gdn512 gained 5 % from the same move).
+        // (The segmented-row instantiations keep the late fetch: with it here the forward one spilled.)
+        constexpr bool ROWS_EARLY = SC2_ENC0_ROWS_EARLY && !SEG;
+        if constexpr (ROWS_EARLY) load_rows(next_unit, tid);
 
         // ---------------------------------------------------------------- GDN1: norm = beta + gamma |t|
         // two passes over the pixel tiles (4 + 3): half the norm accumulators live at a time, and a pass's results may
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
             const unsigned one = 1u;
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
         }
-        load_rows(next_unit, tq);
+        if constexpr (!ROWS_EARLY) load_rows(next_unit, tq);
         {
             if constexpr (!SEG) {
                 uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * CH);   // contiguous 2 rows

@@ -23,6 +23,9 @@
 
 #include "sc2_common.h"
 
+#ifndef SC2_STREAM_EARLY
+#define SC2_STREAM_EARLY 1
+#endif
 #ifndef SC2_NT_STREAM
 #define SC2_NT_STREAM 0   // non-temporal output stores: measured SLOWER here (the consumer launch finds part of this map in L2 / the memory-side cache: head + 2.5 %, dec.conv2 + 2 %); 1: A/B
 #endif
@@ -78,14 +81,20 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
     uint4 w_regs[KS][NT];
     float4 b_next[NT];
 
-    auto load_unit = [&](int unit, int tid) {
+    // PART 0: everything (prologue); 1: all but the bias (issued in front of the epilogue, see the unit loop); 2: the bias, which
+    // the epilogue of the CURRENT unit still reads from b_next
+    auto load_unit = [&](int unit, int tid, auto part_c) {
+        constexpr int PART = decltype(part_c)::value;
         const bool live = unit < p.n_units;     // a dead unit loads unit 0's operands and never uses them
         const int tile = live ? unit / p.n_chunks : 0;
         const int chunk = live ? unit - tile * p.n_chunks : 0;
         const int m0 = tile * BM;
+        if (PART != 1) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            b_next[j] = *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + wn * (NT * 16) + j * 16 + ((tid & 63) >> 4) * 4);
+            for (int j = 0; j < NT; ++j)
+                b_next[j] = *reinterpret_cast<const float4 *>(p.bias + chunk * BNC + wn * (NT * 16) + j * 16 + ((tid & 63) >> 4) * 4);
+        }
+        if (PART == 2) return;
         // weights of this wave's 32 channels of the chunk: all k-steps
         const uint4 *wf = reinterpret_cast<const uint4 *>(p.w) + ((long long)(chunk * (BNC / 16) + wn * NT) * KS) * 64 + (tid & 63);
 #pragma unroll
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
 
     int unit = blockIdx.x;
     int next_unit = unit + gridDim.x;
-    load_unit(unit, tid);
+    load_unit(unit, tid, std::integral_constant<int, 0>{});
     store_a(tid);
     __syncthreads();
 
@@ -173,6 +182,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
                 *reinterpret_cast<u32x4_t *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4)) = r_next[k];
             }
         }
+        // The NEXT unit's A tile, residual tile and weights are fetched HERE, in front of the epilogue, where they used to be
+        // issued directly in front of this unit's output stores (round 4: loads queued in front of a store burst delay it;
+        // their registers are free: a_next went to LDS at the end of the previous unit, r_next just above).
+        // (the K = 512 x 256-channel residual instantiation keeps the late fetch: with it here it spilled)
+        constexpr bool EARLY = SC2_STREAM_EARLY && !(K == 512 && BNC == 256 && RES);
+        if (EARLY) load_unit(next_unit, tid, std::integral_constant<int, 1>{});
         __syncthreads();   // the A tile has been consumed by every wave; the residual image is complete
         // ---- y = act(acc + bias [+ residual]) in place in the image; explicit (e0,e1)/(e2,e3) pairs: packed ops
         // (the ReLU flag is tested ONCE per unit: as `if (p.relu)` inside the loops it was two scalar branches per accumulator tile)
@@ -216,7 +231,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
             const unsigned one = 1u;
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
         }
-        load_unit(next_unit, tq);
+        if (EARLY) load_unit(next_unit, tq, std::integral_constant<int, 2>{});
+        else load_unit(next_unit, tq, std::integral_constant<int, 0>{});
         {
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)chunk * BNC);
 #pragma unroll
