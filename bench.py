@@ -649,6 +649,16 @@ def workload_bench(args, dev, rank, world, distributed):
         obj = bl.compress(model.pre_transform(x)) if args.workload == 'fp_input' else bl.encode(x)
     nbytes = sum(len(q) for lst in obj['strings'] for q in lst)     # (the hyperprior codes two streams per image: y and z)
     pix = x.shape[-1] * x.shape[-2] * n
+    # the entropy model's estimate of the same batch: -sum log2 p / pixels in eval mode (sc2bench/loss.py:20-37)
+    with torch.no_grad():
+        if args.workload == 'fp_input':
+            liks = list(model.compression_model(model.pre_transform(x))['likelihoods'].values())
+        elif args.workload == 'mshp224':
+            bl._forward2train(x)
+            liks = list(bl.last_likelihoods)
+        else:
+            liks = [bl.entropy_bottleneck(bl.analysis(x))[1]]
+        bpp_est = float(sum(-torch.log2(v.float()).sum().item() for v in liks)) / pix
     n_streams = len(obj['strings'][0])
     sym_shape = obj.get('shape')
     lat_c = 320 if args.workload == 'fp_input' else 24
@@ -674,7 +684,7 @@ def workload_bench(args, dev, rank, world, distributed):
                                    'NOT HIP-coder figures'.format(n_streams, sym_per_stream)) if on_host else
                                   'batched HIP coder ({} streams per launch)'.format(n_streams),
                    'sharding': 'images, no collective'},
-        'bpp': 8.0 * nbytes / pix, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': cpu,
+        'bpp': 8.0 * nbytes / pix, 'bpp_estimated': bpp_est, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': cpu,
         'rans': {k: {'ms_per_launch': round(v[1], 4), 'launches_per_step': v[0] / float(args.steps)}
                  for k, v in sorted(ksum.items()) if k.startswith('rans')},
         'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())}}))

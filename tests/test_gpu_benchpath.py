@@ -220,6 +220,7 @@ def test_workload_line_mshp224_on_the_device_coder(dev, capsys):
     assert line['unit'] == 'images/s' and line['value'] > 0 and line['config']['batch_per_gpu'] == 72
     assert line['config']['range_coder'].startswith('batched HIP coder')
     assert 1.0 < line['bpp'] < 12.0
+    assert abs(line['bpp_estimated'] - line['bpp']) < 0.25 * line['bpp']      # the entropy model's estimate of the same batch
     for tag in ('rans_encode.indexed', 'rans_decode.indexed', 'rans_encode', 'rans_decode'):
         assert tag in line['rans'] and line['rans'][tag]['ms_per_launch'] > 0, (tag, line['rans'])
     assert line['roofline'] is not None and 0.0 < line['roofline']['frac'] < 1.0
