@@ -639,8 +639,12 @@ def workload_bench(args, dev, rank, world, distributed):
     if hw is not None and bn:
         ms = sum(v[1] for v in bn.values())
         tf = bottleneck_gflop(*hw) * n / ms
+        traffic = None   # HBM bytes of the bottleneck forward of one step from the committed PMC passes (tools/pmc_workload.sh)
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic_workloads.json')
+        if os.path.exists(tpath) and args.bs in (0, 256):   # (the committed figures are for the default batch of the workload)
+            traffic = json.load(open(tpath)).get(args.workload, {}).get('hbm_bytes_per_bottleneck_forward')
         roofline = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_BF16_TFLOPS,
-                    'traffic': None, 'kernel': 'bottleneck forward = sum of its six fused launches', 'kernel_ms': ms,
+                    'traffic': traffic, 'kernel': 'bottleneck forward = sum of its six fused launches', 'kernel_ms': ms,
                     'gflop_per_image': bottleneck_gflop(*hw)}
     # compressed size of the batch as the reference measures it
     with torch.no_grad():
