@@ -106,7 +106,7 @@ def test_asm_weight_loads_are_never_copied_in_flight():
     assert r.returncode == 0, r.stdout + r.stderr
     # the second hazard the compiler does not cover: a 16-byte buffer store with an SGPR soffset directly followed by a VALU write
     # of its data registers (tools/micro/store_hazard.hip; the kernels' buf_store16 carries the wait states)
-    stores = [os.path.join(csrc, f) for f in ('conv2x2_win.hip', 'conv1x1_pair.hip')]
+    stores = [os.path.join(csrc, f) for f in ('conv2x2_win.hip', 'conv1x1_pair.hip', 'conv3x3_win.hip', 'conv1x1_win.hip')]
     r2 = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_vmcnt.py'), '--stores'] + stores, capture_output=True, text=True)
     assert r2.returncode == 0 and r2.stdout.count(': ok') == len(stores), r2.stdout + r2.stderr
     assert r.stdout.count(': ok') == len(files) and 'COPY?' not in r.stdout, r.stdout
