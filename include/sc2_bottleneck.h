@@ -290,9 +290,10 @@ int sc2_conv2x2_win_tail_supported(int H, int W, int Cin);
 int sc2_conv2x2_win_tail_fwd(const void *x, const void *w_stream, const float *bias1, const float *bias_ds, void *y, void *o1,
                              void *ods, int N, int H, int W, int Cin, void *stream);
 
-/* Second encoder stage in ONE persistent launch: y = GDN1_48(Conv2d(96 -> 48, k5, s2, p2, bias=False)(x)) for
- * 112-pixel-wide inputs (replaces encoder[2] + encoder[3], sc2bench/models/layer.py:479-481; inverse != 0: inverse GDN1).
- *   x : bf16 NHWC [N, H, 112, 96];   y : bf16 NHWC [N, (H - 1)/2 + 1, 56, 48]
+/* Second encoder stage in ONE persistent launch: y = GDN1_48(Conv2d(96 -> 48, k5, s2, p2, bias=False)(x)) (replaces
+ * encoder[2] + encoder[3], sc2bench/models/layer.py:479-481; inverse != 0: inverse GDN1).  W == 112 (the 224 x 224 operating
+ * point) runs the static geometry, any other width the same kernel over 56-column output segments.
+ *   x : bf16 NHWC [N, H, W, 96];   y : bf16 NHWC [N, (H - 1)/2 + 1, (W - 1)/2 + 1, 48]
  *   w_frag : the conv weights packed SC2_K_SLAB_MAJOR | SC2_K_B_FRAG_MAJOR ([k-step = slab*25 + tap][3][64][8] bf16)
  *   gamma_frag : bf16 fragment blocks [3][2][64][8] of the effective gamma [48][48 -> 64 zero-padded];  beta : f32 [48] */
 int sc2_conv2_gdn48_supported(int Cin, int Cout, int W);

@@ -107,6 +107,7 @@ struct Enc2Args {
     const float *__restrict__ beta;      // f32 [48]
     uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, 56, 48]
     int N, H, OH, n_units, units_per_img;
+    int W, OWT, n_seg;    // SEG instantiations (any width): input width, output width, 56-column segments per output row
     unsigned *unit_ctr;   // eight counters: one per XCD
     unsigned long long *stamps;   // diagnostic build only (SC2_ENC2_STAMPS)
 };
@@ -129,7 +130,11 @@ static_assert(OIMG_OFF + 112 * 96 <= GAM_OFF, "images fit the reduction area");
 static_assert(LDS_BYTES + 64 <= 160 * 1024, "one workgroup per CU");
 static_assert(NW * 9 * 1024 <= PATCH_STRIDE, "pixel tiles 4 .. 6 of the four partial sums fit a dead patch buffer");
 
-template <bool INVERSE>
+// SEG (round 4): any input width.  An output row is cut into segments of OW = 56 pixels (a unit = two output rows of ONE
+// segment), the patch of a segment starts 2 ow0 input columns to the right, and which of its columns exist is decided per
+// unit instead of once per workgroup; everything behind the patch fill -- tap offsets, fragment addresses, reduction, GDN1 --
+// is segment-local and unchanged.  !SEG is the 112-pixel-wide geometry of the 224 x 224 operating point (one segment).
+template <bool INVERSE, bool SEG>
 __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int next_slot;
@@ -141,6 +146,8 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     __builtin_assume(wave >= 0 && wave < 4);
     const int frow = lane & 15, fq = lane >> 4;
     const int H = p.H;
+    const int W = SEG ? p.W : W_IN;            // input width (compile-time unless SEG)
+    const int OWT = SEG ? p.OWT : OW;          // output width
 
     // ---- resident weight fragments: taps ((wave + cb) & 3) + 4 q, q < 6, of every slab (54 fragments = 216 VGPRs)
     const uint4 *wfrag = reinterpret_cast<const uint4 *>(p.w) + lane;   // [(kstep * 3 + j) * 64]
@@ -159,7 +166,10 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
 
     // ---- patch fill: piece pc = wave + 4 k of a slab = LDS chunks [64 pc, 64 pc + 64); chunk P <-> (plane, row r, half
     //      column j, physical chunk): source = input row 2 oh0 - 2 + r, column 2 j + plane - 2, logical chunk = phys ^ swz
+    // (SEG: the descriptor base also sits two COLUMNS to the left, offsets are relative to column 2 ow0 - 2 and non-negative,
+    //  and the column test is made per unit from pcol: issue_piece)
     uint32_t pv[PIECES_PER_WAVE];     // byte offset inside the image relative to row 2 oh0 - 2; low bits: r
+    [[maybe_unused]] int pcol[SEG ? PIECES_PER_WAVE : 1];   // SEG: the chunk's input column relative to 2 ow0 (-2 .. 115)
 #pragma unroll
     for (int k = 0; k < PIECES_PER_WAVE; ++k) {
         const int P = (wave + NW * k) * 64 + lane;
@@ -168,13 +178,18 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         const int plane = t2 / 7, r = t2 - plane * 7;
         const int chunk = cphys ^ ((j >> 1) & 3);
         const int iw = 2 * j + plane - 2;
-        const bool ok = (P < N_CHUNKS) & ((unsigned)iw < (unsigned)W_IN);
-        pv[k] = ok ? (uint32_t)(((r * W_IN + iw) * CIN + chunk * 8) * 2) | (uint32_t)r : 0x80000000u;
+        if constexpr (SEG) {
+            pcol[k] = iw;
+            pv[k] = P < N_CHUNKS ? (uint32_t)(((r * W + iw + 2) * CIN + chunk * 8) * 2) | (uint32_t)r : 0x80000000u;
+        } else {
+            const bool ok = (P < N_CHUNKS) & ((unsigned)iw < (unsigned)W_IN);
+            pv[k] = ok ? (uint32_t)(((r * W_IN + iw) * CIN + chunk * 8) * 2) | (uint32_t)r : 0x80000000u;
+        }
     }
     // direct-to-LDS pieces of one slab: the descriptor / scalar offset / destination are set up once (patch_setup), the
     // pieces are then issued one or two at a time BETWEEN the taps of the slab being multiplied (a burst of 13 at the
     // top of a slab cost ~2 000 cycles of this wave's only instruction stream)
-    struct PatchJob { buf_rsrc_t rs; uint32_t soff; unsigned char *dst; int row0; bool live; };
+    struct PatchJob { buf_rsrc_t rs; uint32_t soff; unsigned char *dst; int row0; int col0; bool live; };
     // Units are XCD-local: workgroup b runs on XCD b & 7 (round-robin dispatch) and only takes units of the images
     // im = xcd (mod 8), in order - neighbouring row pairs of an image (3 of their 7 input rows are shared) and the three
     // slab passes over the same 128-byte lines then meet in ONE 4 MB L2 instead of eight.
@@ -188,12 +203,15 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         jb.live = unit < n_local;
         const int im_l = jb.live ? unit / p.units_per_img : 0;
         const int im = xcd + 8 * im_l;
-        const int oh0 = jb.live ? (unit - im_l * p.units_per_img) * 2 : 0;
-        // descriptor base two rows above the image: row offsets are then non-negative for oh0 = 0
-        jb.rs = make_rsrc(p.x + ((long long)im * H - 2) * W_IN * CIN, (uint32_t)(H + 2) * W_IN * CIN * 2);
-        jb.soff = (uint32_t)((2 * oh0) * W_IN * CIN + cb * 32) * 2u;
+        const int u_in = jb.live ? unit - im_l * p.units_per_img : 0;
+        const int rp = SEG ? u_in / p.n_seg : u_in, seg = SEG ? u_in - rp * p.n_seg : 0;
+        const int oh0 = rp * 2, ow0 = seg * OW;
+        // descriptor base two rows above the image (SEG: and two columns to its left): offsets are then non-negative
+        jb.rs = make_rsrc(p.x + (((long long)im * H - 2) * W - (SEG ? 2 : 0)) * CIN, (uint32_t)((H + 2) * W + (SEG ? 2 : 0)) * CIN * 2);
+        jb.soff = (uint32_t)(((2 * oh0) * W + 2 * ow0) * CIN + cb * 32) * 2u;
         jb.dst = smem + buf * PATCH_STRIDE;
         jb.row0 = 2 * oh0 - 2;
+        jb.col0 = 2 * ow0;
         return jb;
     };
     // (branch-free: this wave is alone on its SIMD and a scalar branch costs it tens of cycles -- the unit loop held 109 of them.
@@ -203,7 +221,9 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         const int pc = real ? wave + NW * k : wave;
         const uint32_t pvk = real ? pv[k] : pv[0];
         const int ih = jb.row0 + (int)(pvk & 7u);   // patch row r rides in the offset's free low bits
-        const uint32_t vo = (jb.live & ((unsigned)ih < (unsigned)H)) ? (pvk & ~15u) : 0x80000000u;
+        bool ok = jb.live & ((unsigned)ih < (unsigned)H);
+        if constexpr (SEG) ok = ok & ((int)pvk >= 0) & ((unsigned)(jb.col0 + (real ? pcol[k] : pcol[0])) < (unsigned)W);
+        const uint32_t vo = ok ? (pvk & ~15u) : 0x80000000u;
         buf_load_lds16(jb.rs, (lds_ptr_t)(jb.dst + pc * 1024), vo, jb.soff);
     };
     auto issue_patch = [&](int unit, int cb, int buf) {
@@ -236,8 +256,12 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     while (unit < n_local) {
         const int im_l = unit / p.units_per_img;
         const int im = xcd + 8 * im_l;
-        const int oh0 = (unit - im_l * p.units_per_img) * 2;
+        const int u_in = unit - im_l * p.units_per_img;
+        const int rp = SEG ? u_in / p.n_seg : u_in, seg = SEG ? u_in - rp * p.n_seg : 0;
+        const int oh0 = rp * 2;
+        [[maybe_unused]] const int ow0 = seg * OW;
         const int n_rows = p.OH - oh0 >= 2 ? 2 : 1;
+        [[maybe_unused]] const int n_cols = OWT - ow0 >= OW ? OW : OWT - ow0;   // valid output columns of this segment
         STAMP(0);
         f32x4_t acc[MT][NT];
 #pragma unroll
@@ -468,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         wg_barrier();
         STAMP(8);
         // ---------------------------------------------------------------- stream the unit out (one contiguous block of y)
-        {
+        if constexpr (!SEG) {
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * COUT);
             const unsigned n_out = (unsigned)(n_rows * OW * (COUT / 8));   // 672 or 336 chunks
             uint4 ov[3];
@@ -483,6 +507,29 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             lds_wait();
 #pragma unroll
             for (int k = 0; k < 3; ++k) yo[oq[k]] = ov[k];
+        } else {
+            // the unit's two output rows x n_cols pixels: runs of n_cols * 96 bytes at (oh0 + row, ow0); a chunk outside them is
+            // replaced by one of row 0 that always exists (same data, same address: still three stores per thread)
+            uint4 *yo = reinterpret_cast<uint4 *>(p.y + (((long long)im * p.OH + oh0) * OWT + ow0) * COUT);
+            const unsigned tid_r = (unsigned)(wave * 64 + ln_r);
+            const unsigned q_safe = tid_r % (unsigned)(6 * n_cols);
+            uint4 ov[3];
+            unsigned oa[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned q0 = tid_r + 256 * k;
+                const unsigned px0 = (q0 * 10923u) >> 16;                         // q0 / 6 for q0 < 768
+                const unsigned row0 = px0 >= (unsigned)OW ? 1u : 0u, col0 = px0 - row0 * OW;
+                const bool ok = (q0 < (unsigned)(2 * OW * 6)) & (row0 < (unsigned)n_rows) & (col0 < (unsigned)n_cols);
+                const unsigned q = ok ? q0 : q_safe;
+                const unsigned px = (q * 10923u) >> 16;
+                const unsigned row = px >= (unsigned)OW ? 1u : 0u, col = px - row * OW;
+                oa[k] = (row * (unsigned)OWT + col) * 6u + (q - px * 6u);
+                ov[k] = lds_read16(oimg + q * 16u);
+            }
+            lds_wait();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) yo[oa[k]] = ov[k];
         }
         wg_barrier();   // also: the images are free for the next unit's rounds
         STAMP(9);
@@ -505,7 +552,7 @@ std::atomic<unsigned> g_seq2{0};
 }  // namespace
 
 extern "C" int sc2_conv2_gdn48_supported(int Cin, int Cout, int W) {
-    return Cin == CIN && Cout == COUT && W == W_IN ? 1 : 0;
+    return Cin == CIN && Cout == COUT && W >= 1 ? 1 : 0;   // (112: the static geometry; any other width: 56-column segments)
 }
 
 extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y,
@@ -513,8 +560,8 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
     SC2_REQUIRE(x && w_frag && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "conv2_gdn48: null argument");
     SC2_REQUIRE(N > 0 && H > 0, SC2_ERR_INVALID_ARG, "conv2_gdn48: non-positive dimension");
     SC2_REQUIRE(sc2_conv2_gdn48_supported(CIN, COUT, W), SC2_ERR_UNSUPPORTED,
-                "conv2_gdn48: needs a %d-pixel-wide input (got %d)", W_IN, W);
-    SC2_REQUIRE((long long)(H + 2) * W_IN * CIN * 2 < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv2_gdn48: image too tall");
+                "conv2_gdn48: needs a positive input width (got %d)", W);
+    SC2_REQUIRE(((long long)(H + 2) * W + 2) * CIN * 2 < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv2_gdn48: image too large");
     Enc2Args a;
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(w_frag);
@@ -523,16 +570,23 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
     a.y = static_cast<uint16_t *>(y);
     a.N = N; a.H = H;
     a.OH = (H + 4 - 5) / 2 + 1;
-    a.units_per_img = (a.OH + 1) / 2;
+    a.W = W; a.OWT = (W + 4 - 5) / 2 + 1;
+    const bool seg = W != W_IN;
+    a.n_seg = seg ? (a.OWT + OW - 1) / OW : 1;
+    a.units_per_img = (a.OH + 1) / 2 * a.n_seg;
     const long long units = (long long)N * a.units_per_img;
     SC2_REQUIRE(units < 0x7FFFFFFFLL - 1024, SC2_ERR_UNSUPPORTED, "conv2_gdn48: too many units");
     a.n_units = (int)units;
     hipStream_t s = static_cast<hipStream_t>(stream);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
@@ -565,8 +619,13 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
         a.stamps = static_cast<unsigned long long *>(sp);
     }
 #endif
-    if (inverse) hipLaunchKernelGGL(conv2_gdn48_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, s, a);
-    else hipLaunchKernelGGL(conv2_gdn48_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, s, a);
+    if (seg) {
+        if (inverse) hipLaunchKernelGGL((conv2_gdn48_kernel<true, true>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((conv2_gdn48_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+    } else {
+        if (inverse) hipLaunchKernelGGL((conv2_gdn48_kernel<true, false>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+        else hipLaunchKernelGGL((conv2_gdn48_kernel<false, false>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+    }
 #if SC2_ENC2_STAMPS
     if (a.stamps) {
         (void)hipStreamSynchronize(s);

@@ -526,7 +526,8 @@ def conv2_gdn48_supported(x_shape, cout, kh, kw, stride, pad):
 
 
 def conv2_gdn48_fwd(x_nhwc, w_frag, gamma_frag, beta, inverse=False, tag=None):
-    """x bf16 [N,H,112,96] -> bf16 NHWC [N,(H-1)//2+1,56,48]; w_frag: pack_conv_weight(w, K_SLAB_MAJOR | K_B_FRAG_MAJOR);
+    """x bf16 [N,H,W,96] -> bf16 NHWC [N,(H-1)//2+1,(W-1)//2+1,48] (W = 112: the static geometry of the 224 x 224 operating point;
+    any other width: 56-column output segments); w_frag: pack_conv_weight(w, K_SLAB_MAJOR | K_B_FRAG_MAJOR);
     gamma_frag: pack_weight_fragments of the effective gamma zero-padded to [48, 64]."""
     for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (gamma_frag, 'gamma_frag'), (beta, 'beta')):
         _dev(t, name)
@@ -535,7 +536,7 @@ def conv2_gdn48_fwd(x_nhwc, w_frag, gamma_frag, beta, inverse=False, tag=None):
     assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (48, weight_pitch(2400))
     assert gamma_frag.dtype == torch.bfloat16 and gamma_frag.is_contiguous() and tuple(gamma_frag.shape) == (3, 2, 64, 8)
     assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 48
-    out = torch.empty((N, (H - 1) // 2 + 1, 56, 48), dtype=torch.bfloat16, device=x_nhwc.device)
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 48), dtype=torch.bfloat16, device=x_nhwc.device)
     with _timed(tag or 'conv2_gdn48'):
         _check(lib().sc2_conv2_gdn48_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, W,
                                          1 if inverse else 0, _stream()), 'conv2_gdn48_fwd')

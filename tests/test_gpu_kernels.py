@@ -507,7 +507,7 @@ def test_conv2_gdn48_fused(S, R, dev, N, H, inverse):
     beta_d, gamma_d = m.effective()
     x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
     assert S.hip.conv2_gdn48_supported(tuple(x_nhwc.shape), 48, 5, 5, 2, 2)
-    assert not S.hip.conv2_gdn48_supported((N, H, 100, 96), 48, 5, 5, 2, 2)
+    assert not S.hip.conv2_gdn48_supported((N, H, W, 64), 48, 5, 5, 2, 2)
     order = S.hip.K_SLAB_MAJOR | S.hip.K_B_FRAG_MAJOR
     wp = S.hip.pack_conv_weight(w.to(dev), order)
     out = S.hip.conv2_gdn48_fwd(x_nhwc, wp, S.hip.pack_weight_fragments(gamma_d), beta_d, inverse)
@@ -1259,3 +1259,38 @@ def test_conv1x1_pair_equals_two_launches(S, dev, N, H, W, N2):
     assert (h.float().reshape(-1, C) - h32).abs().max().item() <= 2 ** -7 * h32.abs().max().item()
     u32 = torch.relu(h.float().reshape(-1, C) @ w1.to(torch.bfloat16).float().t() + b1)
     assert (u.float().reshape(-1, N2) - u32).abs().max().item() <= 2 ** -7 * u32.abs().max().item()
+
+
+@pytest.mark.parametrize('N,H,W,inverse', [(2, 257, 257, False),    # 513 x 513 input: 257 -> 129 = 56 + 56 + 17 columns
+                                           (1, 400, 608, False),    # 800 x 1216: 608 -> 304 = five segments + 24
+                                           (3, 23, 167, True),      # 333 x 500 -> 167 -> 84 (odd everything), inverse form
+                                           (9, 9, 7, False),        # narrower than a segment, more images than XCDs
+                                           (2, 11, 113, False)])    # one column more than the static geometry
+def test_conv2_gdn48_any_width(S, R, dev, N, H, W, inverse):
+    """The segmented instantiation of the fused second encoder stage (conv 96 -> 48, k5 s2 p2 + GDN1(48)) at widths other than
+    112, against the f32 ops on the bf16-rounded operands (as test_conv2_gdn48_fused), repeated launches."""
+    torch.manual_seed(N * 1000 + H + W)
+    x = torch.randn(N, 96, H, W)
+    w = torch.randn(48, 96, 5, 5) / 2400 ** 0.5
+    gdn = R.GDN1(48, inverse=inverse)
+    with torch.no_grad():
+        gdn.gamma.add_(0.05 * torch.rand(48, 48) / 48 ** 0.5)
+        gdn.beta.add_(0.1 * torch.rand(48))
+        conv = F.conv2d(bf16_round(x), bf16_round(w), stride=2, padding=2)
+        beta = gdn.beta_reparam(gdn.beta)
+        gamma = bf16_round(gdn.gamma_reparam(gdn.gamma))
+        norm = F.conv2d(bf16_round(conv).abs(), gamma.reshape(48, 48, 1, 1), beta)
+        ref = conv * norm if inverse else conv / norm
+    m = S.GDN1(48, inverse=inverse)
+    m.load_state_dict(gdn.state_dict())
+    m.to(dev)
+    beta_d, gamma_d = m.effective()
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    assert S.hip.conv2_gdn48_supported(tuple(x_nhwc.shape), 48, 5, 5, 2, 2)
+    wp = S.hip.pack_conv_weight(w.to(dev), S.hip.K_SLAB_MAJOR | S.hip.K_B_FRAG_MAJOR)
+    gf = S.hip.pack_weight_fragments(gamma_d)
+    for _ in range(2):
+        out = S.hip.conv2_gdn48_fwd(x_nhwc, wp, gf, beta_d, inverse)
+        assert out.shape == (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 48) == (N, ref.shape[2], ref.shape[3], 48)
+        assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'fused conv2 + gdn48, segmented', extra=2.0 ** -8)
+    torch.cuda.synchronize()
