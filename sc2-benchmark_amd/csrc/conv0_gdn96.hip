@@ -318,7 +318,8 @@ extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, cons
     a.n_units = (int)units;
     hipStream_t s = static_cast<hipStream_t>(stream);
     constexpr int lds = IN_BYTES + IMG_BYTES + GAM_BYTES + CH * 4;
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -300,7 +300,8 @@ template <class S>
 int launch_kres(KresArgs a, hipStream_t s) {
     a.n_chunks = a.Cout / S::BNC;
     a.n_tiles = (a.M + S::BM - 1) / S::BM;
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_kres_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   S::LDS_BYTES);

@@ -274,7 +274,8 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
         return SC2_ERR_UNSUPPORTED;
     }
     a.n_units = (int)units;
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, BM, BNC, RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);

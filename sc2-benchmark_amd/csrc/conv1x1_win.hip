@@ -342,7 +342,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
 template <int NBUF, class T>
 int launch_p1(const P1Args &a, hipStream_t s) {
     constexpr int LDS_BYTES = NBUF * T::WIN_BYTES;
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_win_kernel<NBUF, T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_BYTES);

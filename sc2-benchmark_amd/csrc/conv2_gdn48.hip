@@ -578,7 +578,8 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
     SC2_REQUIRE(units < 0x7FFFFFFFLL - 1024, SC2_ERR_UNSUPPORTED, "conv2_gdn48: too many units");
     a.n_units = (int)units;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

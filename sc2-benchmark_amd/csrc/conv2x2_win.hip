@@ -641,7 +641,8 @@ int g_cus_w2 = 0;
 template <class G, int MODE, bool INVERSE = true>
 int launch_w2(W2Args a, hipStream_t s) {
     constexpr int LDS = MODE != 0 ? G::LDS_FUSED : G::LDS_PLAIN;
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2x2_win_kernel<G, MODE, INVERSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS);

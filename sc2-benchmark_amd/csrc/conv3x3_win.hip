@@ -352,7 +352,8 @@ int launch_win(WinArgs a, hipStream_t s) {
     constexpr int HW = G::H * G::W;
     a.n_mtiles = G::IMGS > 1 ? (a.N + G::IMGS - 1) / G::IMGS : a.N * G::TILES_PER_IMG;
     (void)HW;
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_win_kernel<G, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   G::LDS_BYTES);
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3s2_win_kernel(
 template <class G>
 int launch_win_s2(WinArgs a, hipStream_t s) {
     a.n_mtiles = G::IMGS > 1 ? (a.N + G::IMGS - 1) / G::IMGS : a.N * G::TILES_PER_IMG;
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3s2_win_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   G::LDS_BYTES);

@@ -525,7 +525,8 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
     // 128 KB: the ring, reused as the output image.  (The per-tile kernel asks for 160 KB -- its f32-output staging -- which
     // no other workgroup fits beside; with 128 KB an encode wave of the range coder (20 KB) can share the CU.)
     constexpr int LDS_P = C::STAGES * C::STAGE_BYTES;
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     static int n_cus = 0;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8p_kernel<C, MODE>),

@@ -417,7 +417,8 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
     constexpr int KS1 = (4 * CIN + 31) / 32;
     constexpr int lds = IMG_BYTES + KS1 * 8192 + 16;   // + the next-tile slot
     static_assert(lds <= 160 * 1024, "image + patch must fit the CU's LDS");
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2x2_gdn512_kernel<CIN, INVERSE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);

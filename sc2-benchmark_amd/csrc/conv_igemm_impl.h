@@ -1666,7 +1666,8 @@ int launch4(const ConvArgs &a, hipStream_t s) {
         sc2_set_error("conv2d: grid of %lld workgroups out of range", nwg);
         return SC2_ERR_INVALID_ARG;
     }
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm4_kernel<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -1688,7 +1689,8 @@ int launch8(const ConvArgs &a, hipStream_t s) {
         sc2_set_error("conv2d: grid of %lld workgroups out of range", nwg);
         return SC2_ERR_INVALID_ARG;
     }
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8_kernel<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -1710,7 +1712,8 @@ int launch(const ConvArgs &a, hipStream_t s) {
         sc2_set_error("conv2d: grid of %lld workgroups out of range", nwg);
         return SC2_ERR_INVALID_ARG;
     }
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -1734,7 +1737,8 @@ int launch_patch(const ConvArgs &a, hipStream_t s) {
         sc2_set_error("conv2d: grid of %lld workgroups out of range", nwg);
         return SC2_ERR_INVALID_ARG;
     }
-    static bool attr_set = false;
+    static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+    bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv5s2_patch_kernel<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 7 * 66 * 64);

@@ -35,6 +35,15 @@ __device__ __forceinline__ void sc2_store16_nt(uint4 *dst, const uint4 v) {
 }
 constexpr int SC2_BUF_AUX_NT = 2;   // `aux` of __builtin_amdgcn_raw_buffer_store_*: the nt bit
 
+// Per-DEVICE once-flags of the launchers (hipFuncSetAttribute for > 64 KB of dynamic LDS is a per-device property of a function:
+// a process that launches on a second device must set it there too).  Usage: static bool f[SC2_MAX_DEVICES] = {}; bool &done = f[sc2_device_slot()];
+constexpr int SC2_MAX_DEVICES = 16;
+inline int sc2_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d < SC2_MAX_DEVICES ? d : SC2_MAX_DEVICES - 1;
+}
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
