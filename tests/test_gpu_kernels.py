@@ -1037,7 +1037,10 @@ def test_rans_overflow_flag_and_large_table(S, dev):
     assert int(st.min()) == 1
 
 
-@pytest.mark.parametrize('n_rows,max_len,label', [(200, 90, 'ragged rows packed in LDS'), (60, 1400, 'packed rows exceed LDS: global')])
+@pytest.mark.parametrize('n_rows,max_len,label', [(200, 90, 'ragged rows packed in LDS'), (60, 1400, 'packed rows exceed LDS: global'),
+                                                   (40, 600, 'four lanes per stream, rows + buckets in LDS'),
+                                                   (64, 2400, 'four lanes per stream, rows do not fit LDS: exact path on the global table'),
+                                                   (1, 20000, 'one very long row')])
 def test_rans_ragged_tables_explicit_indexes(S, dev, n_rows, max_len, label):
     """Per-symbol CDF rows over a wide ragged table (the shape of the Gaussian conditional model): encoder with the
     global entry table, decoder with the rows packed into LDS as u16 (or its in-kernel global fallback)."""
