@@ -23,6 +23,8 @@
 //     are, as they stand, the operand fragments of the 1x1 GEMM over the channels;
 //   * epilogues: none, GDN1 / inverse GDN1 in the reference's operation order (norm = beta + acc; y = x * (1 / norm) resp.
 //     x * norm: compressai.layers.GDN1.forward), output f32 NHWC / f32 NCHW / int32 NCHW symbols round_half_even(acc - median).
+#include <type_traits>
+
 #include "sc2_common.h"
 
 namespace {
@@ -37,13 +39,32 @@ struct F32Args {
     int a_op, epilogue, out_format;
     int n_steps;                       // K_pad / 16
     long long M;                       // N * OH * OW
+    unsigned x_bytes;                  // size of x (< 2 GB: the activation loads go through a buffer descriptor)
 };
 
 typedef __attribute__((ext_vector_type(4))) float f4_t;
 
+#ifndef SC2_F32_MT4
+#define SC2_F32_MT4 0   // experiment: four pixel tiles per wave for the 48-channel chunk (twice the MFMAs per weight fragment)
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t f32_rsrc_t;
+__device__ __forceinline__ f32_rsrc_t f32_make_rsrc(const float *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f4_t f32_buf_load16(f32_rsrc_t r, uint32_t voff) {   // out of range: zeros
+    return __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+#else   // host pass: stand-ins
+typedef int f32_rsrc_t;
+__device__ __forceinline__ f32_rsrc_t f32_make_rsrc(const float *, uint32_t) { return 0; }
+__device__ __forceinline__ f4_t f32_buf_load16(f32_rsrc_t, uint32_t) { return f4_t{0.f, 0.f, 0.f, 0.f}; }
+#endif
+
 template <int NT, int MT, bool FUSED>
 __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
-    extern __shared__ int2 ktab[];     // [n_steps * 4]: {element offset of the lane's 4 k inside the window, kh | kw << 16}
+    extern __shared__ int2 ktab[];     // [n_steps * 4]: {byte offset of the lane's 4 k inside the window, kh | kw << 16}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     for (int e = tid; e < p.n_steps * 4; e += 256) {
@@ -52,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
         int2 v;
         if (tap < p.KH * p.KW) {
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            v.x = (kh * p.W + kw) * p.Cin + ci;
+            v.x = ((kh * p.W + kw) * p.Cin + ci) * 4;      // BYTE offset inside the window
             v.y = kh | (kw << 16);
         } else {            // K padding: never in bounds (its weights are zero too)
             v.x = 0;
@@ -65,7 +86,9 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
     const long long m_base = ((long long)blockIdx.x * 4 + wave) * (MT * 16);
     const int chunk = blockIdx.y;                                  // NT * 16 output channels per chunk
     // the lane's A rows: pixel m_base + mt * 16 + r
-    long long a_base[MT];
+    // (byte offsets modulo 2^32: a window that starts above / left of the image has a negative base, but base + tap offset of
+    //  every tap that is INSIDE the image is a plain offset below x_bytes < 2^31)
+    uint32_t a_base[MT];
     int ih0[MT], iw0[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -76,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
             const int oh = rem / p.OW, ow = rem - oh * p.OW;
             ih0[mt] = oh * p.stride - p.pad;
             iw0[mt] = ow * p.stride - p.pad;
-            a_base[mt] = ((n * p.H + ih0[mt]) * (long long)p.W + iw0[mt]) * p.Cin;
+            a_base[mt] = (uint32_t)((((n * p.H + ih0[mt]) * (long long)p.W + iw0[mt]) * p.Cin) * 4);
         } else {
             ih0[mt] = iw0[mt] = -(1 << 20);       // every tap out of bounds: zeros
             a_base[mt] = 0;
@@ -90,45 +113,59 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto load_a = [&](int s, f4_t (&a)[MT]) {
+    // Round 4: the loop was bound by its own vector instructions, not by the f32 matrix pipe -- 237 VALU and 12 scalar branches per
+    // k-step against 8 NT MFMAs (listing): 64-bit address arithmetic per load, the runtime `a_op` tested per load, the next
+    // step's operands COPIED into the current set, a select to zero out-of-image taps.  Now: byte offsets in 32 bits through a
+    // buffer descriptor (a tap outside the image is an out-of-range offset = zeros from the hardware), `a_op` a compile-time
+    // property of the loop's copy, two operand sets that swap roles (no copies), the weight pointer advanced per step.
+    const f32_rsrc_t rs_x = f32_make_rsrc(p.x, p.x_bytes);
+    auto load_a = [&](int s, auto aop_c, f4_t (&a)[MT]) {
+        constexpr int AOP = decltype(aop_c)::value;
         const int2 t = ktab[s * 4 + q];
         const int kh = t.y & 0xFFFF, kw = t.y >> 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const bool ok = (unsigned)(ih0[mt] + kh) < (unsigned)p.H && (unsigned)(iw0[mt] + kw) < (unsigned)p.W;
-            // branch-free: the load is always issued (from element 0 when the tap is out of the image) and zeroed by a select
-            f4_t v = *reinterpret_cast<const f4_t *>(p.x + (ok ? a_base[mt] + t.x : 0));
-            if (!ok) v = f4_t{0.f, 0.f, 0.f, 0.f};
-            if (p.a_op == SC2_AOP_ABS) v = f4_t{fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
-            else if (p.a_op == SC2_AOP_SQUARE) v = v * v;
+            const bool ok = ((unsigned)(ih0[mt] + kh) < (unsigned)p.H) & ((unsigned)(iw0[mt] + kw) < (unsigned)p.W);
+            f4_t v = f32_buf_load16(rs_x, ok ? a_base[mt] + (uint32_t)t.x : 0x80000000u);
+            if (AOP == SC2_AOP_ABS) v = f4_t{fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
+            else if (AOP == SC2_AOP_SQUARE) v = v * v;
             a[mt] = v;
         }
     };
     auto load_b = [&](int s, f4_t (&b)[NT]) {
+        const f4_t *ws = wf + (long long)s * (NT * 64);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = wf[((long long)s * NT + nt) * 64];
+        for (int nt = 0; nt < NT; ++nt) b[nt] = ws[nt * 64];
     };
-
-    f4_t a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
-    load_a(0, a_cur);
-    load_b(0, b_cur);
-    for (int s = 0; s < p.n_steps; ++s) {
-        if (s + 1 < p.n_steps) {
-            load_a(s + 1, a_nxt);
-            load_b(s + 1, b_nxt);
-        }
+    auto mma = [&](const f4_t (&a)[MT], const f4_t (&b)[NT]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b_cur[nt][j], a_cur[mt][j], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a_cur[mt] = a_nxt[mt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b_cur[nt] = b_nxt[nt];
-    }
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][j], a[mt][j], acc[mt][nt], 0, 0, 0);
+    };
+    auto k_loop = [&](auto aop_c) {
+        f4_t a0[MT], b0[NT], a1[MT], b1[NT];
+        const int n = p.n_steps;
+        load_a(0, aop_c, a0);
+        load_b(0, b0);
+        int s = 0;
+        for (; s + 2 <= n; s += 2) {          // (a0, b0) hold step s
+            load_a(s + 1, aop_c, a1);
+            load_b(s + 1, b1);
+            mma(a0, b0);
+            const int s2 = s + 2 < n ? s + 2 : s + 1;   // past the end: the last step again, unused
+            load_a(s2, aop_c, a0);
+            load_b(s2, b0);
+            mma(a1, b1);
+        }
+        if (s < n) mma(a0, b0);               // odd step count
+    };
+    if (p.a_op == SC2_AOP_ABS) k_loop(std::integral_constant<int, SC2_AOP_ABS>{});
+    else if (p.a_op == SC2_AOP_SQUARE) k_loop(std::integral_constant<int, SC2_AOP_SQUARE>{});
+    else k_loop(std::integral_constant<int, SC2_AOP_NONE>{});
 
     // conv FOLLOWED BY GDN1 in the same launch (SC2_EPI_FUSED_GDN / _IGDN; one channel chunk = every channel of a pixel in this
     // wave).  With the weights as the first MFMA operand a lane's accumulators acc[mt][s] ARE the second-operand fragment of
@@ -308,6 +345,11 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
     a.a_op = d->a_op; a.epilogue = d->epilogue; a.out_format = d->out_format;
     a.n_steps = (d->KH * d->KW * d->Cin + 15) / 16;
     a.M = (long long)d->N * d->OH * d->OW;
+    {
+        const long long xb = (long long)d->N * d->H * d->W * d->Cin * 4;
+        SC2_REQUIRE(xb < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv2d_f32: input of %lld bytes exceeds 2 GB", xb);
+        a.x_bytes = (unsigned)xb;
+    }
     SC2_REQUIRE((long long)d->N * d->H * d->W * d->Cin < (1ll << 31) && a.M * d->Cout < (1ll << 33), SC2_ERR_UNSUPPORTED,
                 "conv2d_f32: tensor too large for this kernel's index arithmetic");
     SC2_REQUIRE((size_t)a.n_steps * 32 <= 64 * 1024, SC2_ERR_UNSUPPORTED, "conv2d_f32: K too long for the tap table");
@@ -318,10 +360,10 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
     //  in 2.89 ms instead of 2.38 at bs 256: fewer, fatter waves hide less of the operand latency; two row tiles everywhere)
     if (fused) {
         if (cc == 32) return launch_f32<2, 2, true>(a, chunks, s);
-        if (cc == 48) return launch_f32<3, 2, true>(a, chunks, s);
+        if (cc == 48) return SC2_F32_MT4 ? launch_f32<3, 4, true>(a, chunks, s) : launch_f32<3, 2, true>(a, chunks, s);
         return launch_f32<6, 2, true>(a, chunks, s);
     }
     if (cc == 32) return launch_f32<2, 2>(a, chunks, s);
-    if (cc == 48) return launch_f32<3, 2>(a, chunks, s);
+    if (cc == 48) return SC2_F32_MT4 ? launch_f32<3, 4>(a, chunks, s) : launch_f32<3, 2>(a, chunks, s);
     return launch_f32<6, 2>(a, chunks, s);
 }
