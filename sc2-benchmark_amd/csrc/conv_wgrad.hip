@@ -15,6 +15,8 @@
 // Bank conflicts: a fragment read touches 8 different pixel rows at one 32-byte column offset; the 16-byte chunk
 // index is XORed with f(row) = 2*((row & 3) + 4*((row >> 3) & 1)) -- applied to the SOURCE address of the
 // direct-to-LDS load and again to the read address -- so the 8 rows land on 8 different 32-byte slots.
+#include <type_traits>
+
 #include "sc2_common.h"
 
 namespace {
@@ -44,12 +46,14 @@ constexpr int WG_STAGES = 3;
 
 __device__ __forceinline__ int wg_swz(int row) { return 2 * ((row & 3) + 4 * ((row >> 3) & 1)); }
 
-__device__ __forceinline__ uint2 lds_read_tr(uint32_t addr) {
+template <int OFF>
+__device__ __forceinline__ uint2 lds_read_tr(uint32_t addr) {   // (stage base as an immediate: no address arithmetic per read)
     uint2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
 
+template <bool ABS>   // |x| as the im2col operand (d gamma of GDN1): a compile-time property (16 mask operations per slab otherwise)
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
@@ -91,27 +95,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         kw_j[j] = tap - kh_j[j] * p.KW;
     }
 
-    auto issue_slab = [&](int s, int buf) {
+    // Pixel coordinates of this lane's two slab rows, carried from slab to slab (round 4).  Slabs are issued strictly in order,
+    // each 32 pixels further; recomputing (image, oh, ow) from the pixel index cost two runtime divisions per piece and slab --
+    // 183 vector instructions per slab against its 16 MFMAs (listing): the kernel was bound by its address arithmetic.  Now a
+    // slab step adds the decomposition of 32 pixels (d_img, d_oh, d_ow) with one conditional subtract per coordinate.
+    const int d_img = WG_SLAB / p.OHW, d_rem = WG_SLAB - d_img * p.OHW;
+    const int d_oh = d_rem / p.OW, d_ow = d_rem - d_oh * p.OW;
+    int m_j[2], img_j[2], oh_j[2], ow_j[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        m_j[j] = m_begin + row_j[j];
+        const int mm = m_j[j] < p.M ? m_j[j] : 0;      // (rows past the end: coordinates of pixel 0, never used)
+        img_j[j] = mm / p.OHW;
+        const int rem = mm - img_j[j] * p.OHW;
+        oh_j[j] = rem / p.OW;
+        ow_j[j] = rem - oh_j[j] * p.OW;
+    }
+    auto issue_slab = [&](int buf) {   // the NEXT slab in order
         unsigned char *Gi = smem + buf * (2 * WG_IMG);
         unsigned char *Ai = Gi + WG_IMG;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m_begin + s * WG_SLAB + row_j[j];
-            const bool mok = (s < n_slabs) & (m < m_end);
-            const int mm = mok ? m : 0;
+            const bool mok = m_j[j] < m_end;
             // dY operand
             const bool g_ok = mok & gok_j[j];
-            const long long goff = g_ok ? (long long)mm * p.Cout + gco_j[j] : zoff_g;
+            const long long goff = g_ok ? (long long)(uint32_t)(m_j[j] * p.Cout + gco_j[j]) : zoff_g;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.gy + goff), (lds_ptr_t)(Gi + (j * 4 + wave) * 1024), 16, 0, 0);
             // im2col operand
-            const int img = mm / p.OHW;
-            const int rem = mm - img * p.OHW;
-            const int oh = rem / p.OW;
-            const int ow = rem - oh * p.OW;
-            const int ih = oh * p.SH - p.PH + kh_j[j], iw = ow * p.SW - p.PW + kw_j[j];
+            const int ih = oh_j[j] * p.SH - p.PH + kh_j[j], iw = ow_j[j] * p.SW - p.PW + kw_j[j];
             const bool a_ok = mok & kok_j[j] & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
-            const long long aoff = a_ok ? ((long long)(img * p.H + ih) * p.W + iw) * p.Cin + ci_j[j] : zoff_x;
+            const long long aoff = a_ok ? (long long)(uint32_t)(((img_j[j] * p.H + ih) * p.W + iw) * p.Cin + ci_j[j]) : zoff_x;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.x + aoff), (lds_ptr_t)(Ai + (j * 4 + wave) * 1024), 16, 0, 0);
+            // 32 pixels on
+            m_j[j] += WG_SLAB;
+            ow_j[j] += d_ow;
+            const int c1 = ow_j[j] >= p.OW ? 1 : 0;
+            ow_j[j] -= c1 ? p.OW : 0;
+            oh_j[j] += d_oh + c1;
+            const int c2 = oh_j[j] >= p.OH ? 1 : 0;
+            oh_j[j] -= c2 ? p.OH : 0;
+            img_j[j] += d_img + c2;
         }
     };
 
@@ -133,43 +156,55 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
             const int r = rrow + 4 * h;
             const int gc = wm * 64 + tt * 16 + 4 * (i16 & 3);   // column inside the 128-wide image
             const int ac = wn * 64 + tt * 16 + 4 * (i16 & 3);
-            g_rd[tt][h] = (uint32_t)(r * WG_ROWB + (((gc >> 3) ^ wg_swz(r)) << 4) + ((gc >> 2) & 1) * 8);
-            a_rd[tt][h] = (uint32_t)(WG_IMG + r * WG_ROWB + (((ac >> 3) ^ wg_swz(r)) << 4) + ((ac >> 2) & 1) * 8);
+            g_rd[tt][h] = lds_base + (uint32_t)(r * WG_ROWB + (((gc >> 3) ^ wg_swz(r)) << 4) + ((gc >> 2) & 1) * 8);
+            a_rd[tt][h] = lds_base + (uint32_t)(r * WG_ROWB + (((ac >> 3) ^ wg_swz(r)) << 4) + ((ac >> 2) & 1) * 8);
         }
 
-    const uint32_t xmask = p.x_abs ? 0x7FFF7FFFu : 0xFFFFFFFFu;
+    constexpr uint32_t xmask = 0x7FFF7FFFu;
     constexpr int S = WG_STAGES, L = 4;
+    static_assert(S == 3, "the slab loop below is unrolled by the ring depth");
 #pragma unroll
-    for (int st = 0; st < S - 1; ++st) issue_slab(st, st);
+    for (int st = 0; st < S - 1; ++st) issue_slab(st);
 
-    for (int s = 0; s < n_slabs; ++s) {
+    // one slab out of ring stage ST (compile-time: the fragment reads address the stage through an immediate offset)
+    auto slab = [&](auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        constexpr int GOFF = ST * (2 * WG_IMG), AOFF = GOFF + WG_IMG;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");
         __builtin_amdgcn_s_barrier();
-        const uint32_t sb = lds_base + (uint32_t)((s % S) * (2 * WG_IMG));
         uint2 gv[4][2], av[4][2];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                gv[tt][h] = lds_read_tr(sb + g_rd[tt][h]);
-                av[tt][h] = lds_read_tr(sb + a_rd[tt][h]);
+                gv[tt][h] = lds_read_tr<GOFF>(g_rd[tt][h]);
+                av[tt][h] = lds_read_tr<AOFF>(a_rd[tt][h]);
             }
-        issue_slab(s + S - 1, (s + S - 1) % S);
+        issue_slab((ST + S - 1) % S);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         bf16x8_t gf[4], af[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             gf[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(gv[tt][0].x, gv[tt][0].y, gv[tt][1].x, gv[tt][1].y));
-            af[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(av[tt][0].x & xmask, av[tt][0].y & xmask, av[tt][1].x & xmask,
-                                                             av[tt][1].y & xmask));
+            if (ABS) af[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(av[tt][0].x & xmask, av[tt][0].y & xmask, av[tt][1].x & xmask,
+                                                                      av[tt][1].y & xmask));
+            else af[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(av[tt][0].x, av[tt][0].y, av[tt][1].x, av[tt][1].y));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], af[j], acc[i][j], 0, 0, 0);
+    };
+    int sl = 0;
+    for (; sl + S <= n_slabs; sl += S) {
+        slab(std::integral_constant<int, 0>{});
+        slab(std::integral_constant<int, 1>{});
+        slab(std::integral_constant<int, 2>{});
     }
+    if (sl < n_slabs) slab(std::integral_constant<int, 0>{});
+    if (sl + 1 < n_slabs) slab(std::integral_constant<int, 1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // combine the pixel-range partial sums: f32 atomic adds (dW is small; arrival order varies run to run)
@@ -199,8 +234,9 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     SC2_REQUIRE(OH == d->OH && OW == d->OW && OH > 0 && OW > 0, SC2_ERR_INVALID_ARG,
                 "conv2d_wgrad: output size %dx%d does not match geometry (%dx%d)", d->OH, d->OW, OH, OW);
     const long long M = (long long)d->N * OH * OW;
-    SC2_REQUIRE(M < 0x7FFFFFFFLL && (long long)d->N * d->H < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED,
-                "conv2d_wgrad: problem too large");
+    SC2_REQUIRE(M < 0x7FFFFFFFLL - 4096 && (long long)d->N * d->H < 0x7FFFFFFFLL && M * d->Cout < 0xFFFFFFFFLL &&
+                    (long long)d->N * d->H * d->W * d->Cin < 0xFFFFFFFFLL,
+                SC2_ERR_UNSUPPORTED, "conv2d_wgrad: problem too large (32-bit element offsets)");
     WgradArgs a;
     a.x = static_cast<const uint16_t *>(x);
     a.gy = static_cast<const uint16_t *>(gy);
@@ -225,7 +261,8 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)a.Cout * a.K * sizeof(float), s);
     SC2_REQUIRE(e == hipSuccess, SC2_ERR_LAUNCH, "conv2d_wgrad: memset failed: %s", hipGetErrorString(e));
     const size_t lds = (size_t)WG_STAGES * 2 * WG_IMG;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)grid), dim3(256), lds, s, a);
+    if (a.x_abs) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
