@@ -40,14 +40,23 @@ struct F32Args {
     int n_steps;                       // K_pad / 16
     long long M;                       // N * OH * OW
     unsigned x_bytes;                  // size of x (< 2 GB: the activation loads go through a buffer descriptor)
+    unsigned w_bytes;                  // size of w
+    unsigned ring_off;                 // LDS offset of the weight ring (after the tap table, 1 KB aligned)
 };
 
 typedef __attribute__((ext_vector_type(4))) float f4_t;
 
+#ifndef SC2_F32_SYNC
+#define SC2_F32_SYNC 1   // a workgroup barrier every two k-steps: the four waves read the SAME weight fragments, and kept within two
+#endif                   // steps of each other three of the four reads are L1 hits
+#ifndef SC2_F32_WAVES
+#define SC2_F32_WAVES 4  // waves per SIMD the register allocation must allow for the narrow tiles (NT * MT <= 6)
+#endif
 #ifndef SC2_F32_MT4
 #define SC2_F32_MT4 0   // experiment: four pixel tiles per wave for the 48-channel chunk (twice the MFMAs per weight fragment)
 #endif
 
+typedef __attribute__((address_space(3))) void *f32_lds_ptr_t;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t f32_rsrc_t;
 __device__ __forceinline__ f32_rsrc_t f32_make_rsrc(const float *base, uint32_t bytes) {
@@ -56,14 +65,34 @@ __device__ __forceinline__ f32_rsrc_t f32_make_rsrc(const float *base, uint32_t 
 __device__ __forceinline__ f4_t f32_buf_load16(f32_rsrc_t r, uint32_t voff) {   // out of range: zeros
     return __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
 }
+__device__ __forceinline__ void f32_buf_load_lds16(f32_rsrc_t r, uint32_t lds_addr, uint32_t voff) {   // lane l -> LDS lds_addr + 16 l
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (f32_lds_ptr_t)(uintptr_t)lds_addr, 16, (int)voff, 0, 0, 0);
+}
 #else   // host pass: stand-ins
 typedef int f32_rsrc_t;
 __device__ __forceinline__ f32_rsrc_t f32_make_rsrc(const float *, uint32_t) { return 0; }
 __device__ __forceinline__ f4_t f32_buf_load16(f32_rsrc_t, uint32_t) { return f4_t{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void f32_buf_load_lds16(f32_rsrc_t, uint32_t, uint32_t) {}
 #endif
+// LDS reads of the k loop are inline asm (and its barriers raw s_barrier): hipcc knows that a direct-to-LDS load writes LDS and
+// drains the vector-memory counter in front of every LDS access it can see -- the operand prefetch with it (conv2_gdn48.hip).
+__device__ __forceinline__ f4_t f32_lds_read16(uint32_t addr) {
+    f4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// The wait names the registers it is for: an asm statement without a data dependence does not hold the VALU instructions that
+// consume the read's result behind it (the first build computed one row tile's addresses from a tap entry still in flight).
+__device__ __forceinline__ void f32_lds_wait(f4_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory"); }
+__device__ __forceinline__ void f32_lds_wait(int2 &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory"); }
+__device__ __forceinline__ int2 f32_lds_read8(uint32_t addr) {
+    int2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
 
 template <int NT, int MT, bool FUSED>
-__global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
+__global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_f32_kernel(F32Args p) {
     extern __shared__ int2 ktab[];     // [n_steps * 4]: {byte offset of the lane's 4 k inside the window, kh | kw << 16}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -105,7 +134,6 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
             a_base[mt] = 0;
         }
     }
-    const f4_t *wf = reinterpret_cast<const f4_t *>(p.w) + ((long long)chunk * p.n_steps * NT) * 64 + lane;
 
     f4_t acc[MT][NT];
 #pragma unroll
@@ -113,55 +141,88 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    // Round 4: the loop was bound by its own vector instructions, not by the f32 matrix pipe -- 237 VALU and 12 scalar branches per
-    // k-step against 8 NT MFMAs (listing): 64-bit address arithmetic per load, the runtime `a_op` tested per load, the next
-    // step's operands COPIED into the current set, a select to zero out-of-image taps.  Now: byte offsets in 32 bits through a
-    // buffer descriptor (a tap outside the image is an out-of-range offset = zeros from the hardware), `a_op` a compile-time
-    // property of the loop's copy, two operand sets that swap roles (no copies), the weight pointer advanced per step.
+    // The k loop.  Activations: one 16-byte load per lane, row tile and step through a buffer descriptor (a tap outside the image is
+    // an out-of-range offset = zeros from the hardware), one step ahead in registers.  Weights: the four waves of the workgroup
+    // consume the SAME fragment stream, so it goes through LDS once per workgroup -- groups of four steps, wave w fetching step w
+    // of the group direct-to-LDS one group ahead into a two-deep ring, one barrier per group.  (Before: every wave loaded its own
+    // copy, 11.5 GB per launch of the 96 -> 48 conv through the 32 KB L1s beside 7.7 GB of activations; an L1 holds less than the
+    // loads its 16 waves keep in flight, and prefetching FURTHER ahead made the launch slower.)
     const f32_rsrc_t rs_x = f32_make_rsrc(p.x, p.x_bytes);
-    auto load_a = [&](int s, auto aop_c, f4_t (&a)[MT]) {
-        constexpr int AOP = decltype(aop_c)::value;
-        const int2 t = ktab[s * 4 + q];
+    const f32_rsrc_t rs_w = f32_make_rsrc(p.w, p.w_bytes);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(f32_lds_ptr_t)ktab;
+    const uint32_t ring = lds_base + p.ring_off;
+    constexpr uint32_t GROUP_BYTES = 4u * NT * 1024u;
+    const uint32_t w_chunk = (uint32_t)chunk * (uint32_t)p.n_steps * (NT * 1024u) + (uint32_t)lane * 16u;
+    const int n = p.n_steps, n_groups = (n + 3) >> 2;
+    auto fetch_group = [&](int g) {          // this wave's step of group g (past the end: out of range = zeros, never consumed)
+        const int st = g * 4 + wave;
+        const uint32_t src = st < n ? w_chunk + (uint32_t)st * (NT * 1024u) : 0x80000000u;
+        const uint32_t dst = ring + (uint32_t)(g & 1) * GROUP_BYTES + (uint32_t)wave * (NT * 1024u);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) f32_buf_load_lds16(rs_w, dst + nt * 1024u, src + nt * 1024u);
+    };
+    auto load_a = [&](int2 t, f4_t (&a)[MT]) {
         const int kh = t.y & 0xFFFF, kw = t.y >> 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool ok = ((unsigned)(ih0[mt] + kh) < (unsigned)p.H) & ((unsigned)(iw0[mt] + kw) < (unsigned)p.W);
-            f4_t v = f32_buf_load16(rs_x, ok ? a_base[mt] + (uint32_t)t.x : 0x80000000u);
-            if (AOP == SC2_AOP_ABS) v = f4_t{fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)};
-            else if (AOP == SC2_AOP_SQUARE) v = v * v;
-            a[mt] = v;
+            a[mt] = f32_buf_load16(rs_x, ok ? a_base[mt] + (uint32_t)t.x : 0x80000000u);   // raw: |x| / x^2 where it is consumed
         }
     };
-    auto load_b = [&](int s, f4_t (&b)[NT]) {
-        const f4_t *ws = wf + (long long)s * (NT * 64);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = ws[nt * 64];
-    };
-    auto mma = [&](const f4_t (&a)[MT], const f4_t (&b)[NT]) {
+    auto mma = [&](auto aop_c, const f4_t (&a)[MT], const f4_t (&b)[NT]) {
+        constexpr int AOP = decltype(aop_c)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                const float av = AOP == SC2_AOP_ABS ? fabsf(a[mt][j]) : (AOP == SC2_AOP_SQUARE ? a[mt][j] * a[mt][j] : a[mt][j]);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][j], a[mt][j], acc[mt][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][j], av, acc[mt][nt], 0, 0, 0);
+            }
     };
     auto k_loop = [&](auto aop_c) {
-        f4_t a0[MT], b0[NT], a1[MT], b1[NT];
-        const int n = p.n_steps;
-        load_a(0, aop_c, a0);
-        load_b(0, b0);
-        int s = 0;
-        for (; s + 2 <= n; s += 2) {          // (a0, b0) hold step s
-            load_a(s + 1, aop_c, a1);
-            load_b(s + 1, b1);
-            mma(a0, b0);
-            const int s2 = s + 2 < n ? s + 2 : s + 1;   // past the end: the last step again, unused
-            load_a(s2, aop_c, a0);
-            load_b(s2, b0);
-            mma(a1, b1);
+        const uint32_t kt = lds_base + (uint32_t)q * 8u;       // tap table entry of (step, this lane's quarter): + 32 per step
+        const uint32_t last = (uint32_t)(n - 1) * 32u;
+        f4_t a0[MT], a1[MT];
+        int2 t = f32_lds_read8(kt);
+        f32_lds_wait(t);
+        load_a(t, a0);                                         // step 0
+        fetch_group(0);
+        int2 t_nxt = f32_lds_read8(kt + (1u * 32u < last ? 32u : last));
+        f32_lds_wait(t_nxt);
+        // One step: wait for the activations of step s (issued a step ago; the vector-memory counter completes in order, so the
+        // weight fetch issued during the previous step has landed too), read the weights of step s and the tap entry of step
+        // s + 2 from LDS, issue the next group's weight fetch (first step of a group) and the activations of step s + 1, multiply.
+        // The wait is the BUILTIN: hipcc's counter model sees it and adds no vmcnt of its own in front of the asm LDS reads.
+        auto step = [&](int s, int i, uint32_t gbuf, int g_fetch, f4_t (&a_cur)[MT], f4_t (&a_nxt)[MT]) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+            f4_t b[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = f32_lds_read16(gbuf + (uint32_t)(i * NT + nt) * 1024u + (uint32_t)lane * 16u);
+            const uint32_t s2 = (uint32_t)(s + 2) * 32u;
+            const int2 t_cur = t_nxt;                          // (table entry of step s + 1, read one step ago)
+            t_nxt = f32_lds_read8(kt + (s2 < last ? s2 : last));
+            load_a(t_cur, a_nxt);                              // past the end: the last step again, unused
+            if (g_fetch >= 0) fetch_group(g_fetch);
+            f32_lds_wait(t_nxt);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) f32_lds_wait(b[nt]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(aop_c, a_cur, b);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int g = 0; g < n_groups; ++g) {
+            // every wave's share of group g landed before its last vmcnt(0); the barrier makes them visible to all four waves
+            // and says that nobody reads the other half of the ring any more
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            const uint32_t gbuf = ring + (uint32_t)(g & 1) * GROUP_BYTES;
+            const int s = g * 4;
+            step(s, 0, gbuf, g + 1 < n_groups ? g + 1 : -1, a0, a1);
+            if (s + 1 < n) step(s + 1, 1, gbuf, -1, a1, a0);
+            if (s + 2 < n) step(s + 2, 2, gbuf, -1, a0, a1);
+            if (s + 3 < n) step(s + 3, 3, gbuf, -1, a1, a0);
         }
-        if (s < n) mma(a0, b0);               // odd step count
     };
     if (p.a_op == SC2_AOP_ABS) k_loop(std::integral_constant<int, SC2_AOP_ABS>{});
     else if (p.a_op == SC2_AOP_SQUARE) k_loop(std::integral_constant<int, SC2_AOP_SQUARE>{});
@@ -273,8 +334,11 @@ __global__ __launch_bounds__(256) void conv_f32_kernel(F32Args p) {
 template <int NT, int MT, bool FUSED = false>
 int launch_f32(const F32Args &a, int chunks, hipStream_t s) {
     const long long tiles = (a.M + (4 * MT * 16) - 1) / (4 * MT * 16);
-    const size_t lds = (size_t)a.n_steps * 4 * sizeof(int2);
-    hipLaunchKernelGGL((conv_f32_kernel<NT, MT, FUSED>), dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds, s, a);
+    F32Args b = a;
+    b.ring_off = (unsigned)(((size_t)a.n_steps * 4 * sizeof(int2) + 1023) / 1024 * 1024);
+    b.w_bytes = (unsigned)((size_t)chunks * a.n_steps * NT * 1024);
+    const size_t lds = (size_t)b.ring_off + 2 * 4 * NT * 1024;
+    hipLaunchKernelGGL((conv_f32_kernel<NT, MT, FUSED>), dim3((unsigned)tiles, (unsigned)chunks), dim3(256), lds, s, b);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
