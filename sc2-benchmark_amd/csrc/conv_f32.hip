@@ -42,6 +42,7 @@ struct F32Args {
     unsigned x_bytes;                  // size of x (< 2 GB: the activation loads go through a buffer descriptor)
     unsigned w_bytes;                  // size of w
     unsigned ring_off;                 // LDS offset of the weight ring (after the tap table, 1 KB aligned)
+    int skip_j3;                       // Cin == 4 carrying 3 real channels: every fourth k is a zero channel times a zero weight
 };
 
 typedef __attribute__((ext_vector_type(4))) float f4_t;
@@ -81,6 +82,24 @@ __device__ __forceinline__ f4_t f32_lds_read16(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
     return v;
 }
+// The k loop issues its vector-memory instructions itself (asm) and counts them itself: hipcc's counter model put vmcnt(0) /
+// vmcnt(1) in front of address arithmetic that reuses a dead operand register and in front of every LDS access after a
+// direct-to-LDS load it knows about -- the two-step prefetch was gone again.  ("s_nop 4": the descriptor may have been written by
+// a VALU instruction just before, e.g. v_readlane of a spilled SGPR; a VMEM instruction needs 5 wait states behind that.)
+typedef int f32_desc_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32_desc_t f32_make_desc(const void *base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    return f32_desc_t{(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void f32_aload16(f4_t &d, f32_desc_t r, uint32_t voff) {   // out of range: zeros
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen ; wfrag" : "=&v"(d) : "v"(voff), "s"(r) : "memory");
+}
+__device__ __forceinline__ void f32_dma16(f32_desc_t r, uint32_t lds_addr, uint32_t voff) {   // lane l -> LDS lds_addr + 16 l
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void f32_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void f32_tie(f4_t &v) { asm volatile("; landed %0" : "+v"(v)::"memory"); }   // (tools/audit_vmcnt.py reads it)
 // The wait names the registers it is for: an asm statement without a data dependence does not hold the VALU instructions that
 // consume the read's result behind it (the first build computed one row tile's addresses from a tap entry still in flight).
 __device__ __forceinline__ void f32_lds_wait(f4_t &v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory"); }
@@ -122,13 +141,13 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const long long m = m_base + mt * 16 + r;
-        if (m < p.M) {
-            const long long n = m / ((long long)p.OH * p.OW);
-            const int rem = (int)(m - n * p.OH * p.OW);
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        if (m < p.M) {                             // (M < 2^31, checked by the host: 32-bit divisions)
+            const uint32_t ohw_u = (uint32_t)(p.OH * p.OW), n = (uint32_t)m / ohw_u;
+            const int rem = (int)((uint32_t)m - n * ohw_u);
+            const int oh = (int)((uint32_t)rem / (uint32_t)p.OW), ow = rem - oh * p.OW;
             ih0[mt] = oh * p.stride - p.pad;
             iw0[mt] = ow * p.stride - p.pad;
-            a_base[mt] = (uint32_t)((((n * p.H + ih0[mt]) * (long long)p.W + iw0[mt]) * p.Cin) * 4);
+            a_base[mt] = (uint32_t)(((((long long)n * p.H + ih0[mt]) * (long long)p.W + iw0[mt]) * p.Cin) * 4);
         } else {
             ih0[mt] = iw0[mt] = -(1 << 20);       // every tap out of bounds: zeros
             a_base[mt] = 0;
@@ -147,8 +166,8 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
     // of the group direct-to-LDS one group ahead into a two-deep ring, one barrier per group.  (Before: every wave loaded its own
     // copy, 11.5 GB per launch of the 96 -> 48 conv through the 32 KB L1s beside 7.7 GB of activations; an L1 holds less than the
     // loads its 16 waves keep in flight, and prefetching FURTHER ahead made the launch slower.)
-    const f32_rsrc_t rs_x = f32_make_rsrc(p.x, p.x_bytes);
-    const f32_rsrc_t rs_w = f32_make_rsrc(p.w, p.w_bytes);
+    const f32_desc_t rs_x = f32_make_desc(p.x, p.x_bytes);
+    const f32_desc_t rs_w = f32_make_desc(p.w, p.w_bytes);
     const uint32_t lds_base = (uint32_t)(uintptr_t)(f32_lds_ptr_t)ktab;
     const uint32_t ring = lds_base + p.ring_off;
     constexpr uint32_t GROUP_BYTES = 4u * NT * 1024u;
@@ -157,22 +176,22 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
     auto fetch_group = [&](int g) {          // this wave's step of group g (past the end: out of range = zeros, never consumed)
         const int st = g * 4 + wave;
         const uint32_t src = st < n ? w_chunk + (uint32_t)st * (NT * 1024u) : 0x80000000u;
-        const uint32_t dst = ring + (uint32_t)(g & 1) * GROUP_BYTES + (uint32_t)wave * (NT * 1024u);
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(ring + (uint32_t)(g & 1) * GROUP_BYTES + (uint32_t)wave * (NT * 1024u));
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) f32_buf_load_lds16(rs_w, dst + nt * 1024u, src + nt * 1024u);
+        for (int nt = 0; nt < NT; ++nt) f32_dma16(rs_w, dst + nt * 1024u, src + nt * 1024u);
     };
     auto load_a = [&](int2 t, f4_t (&a)[MT]) {
         const int kh = t.y & 0xFFFF, kw = t.y >> 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool ok = ((unsigned)(ih0[mt] + kh) < (unsigned)p.H) & ((unsigned)(iw0[mt] + kw) < (unsigned)p.W);
-            a[mt] = f32_buf_load16(rs_x, ok ? a_base[mt] + (uint32_t)t.x : 0x80000000u);   // raw: |x| / x^2 where it is consumed
+            f32_aload16(a[mt], rs_x, ok ? a_base[mt] + (uint32_t)t.x : 0x80000000u);   // raw: |x| / x^2 where it is consumed
         }
     };
     auto mma = [&](auto aop_c, const f4_t (&a)[MT], const f4_t (&b)[NT]) {
-        constexpr int AOP = decltype(aop_c)::value;
+        constexpr int AOP = decltype(aop_c)::value & 0xFF, JN = (decltype(aop_c)::value >> 8) ? 3 : 4;   // (bit 8: skip_j3)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < JN; ++j)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const float av = AOP == SC2_AOP_ABS ? fabsf(a[mt][j]) : (AOP == SC2_AOP_SQUARE ? a[mt][j] * a[mt][j] : a[mt][j]);
@@ -183,48 +202,66 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
     auto k_loop = [&](auto aop_c) {
         const uint32_t kt = lds_base + (uint32_t)q * 8u;       // tap table entry of (step, this lane's quarter): + 32 per step
         const uint32_t last = (uint32_t)(n - 1) * 32u;
-        f4_t a0[MT], a1[MT];
-        int2 t = f32_lds_read8(kt);
-        f32_lds_wait(t);
-        load_a(t, a0);                                         // step 0
+        auto entry = [&](int s) { const uint32_t o = (uint32_t)s * 32u; return f32_lds_read8(kt + (o < last ? o : last)); };
+        // activations TWO steps ahead in three register sets (a[s % 3] holds step s); the weight fetch of the next group sits
+        // between the activation loads of steps s + 1 and s + 2 in the in-order counter
+        f4_t a[3][MT];
         fetch_group(0);
-        int2 t_nxt = f32_lds_read8(kt + (1u * 32u < last ? 32u : last));
+        int2 t = entry(0);
+        f32_lds_wait(t);
+        load_a(t, a[0]);
+        t = entry(1);
+        f32_lds_wait(t);
+        load_a(t, a[1]);                                       // past the end: the last step again, unused
+        int2 t_nxt = entry(2);
         f32_lds_wait(t_nxt);
-        // One step: wait for the activations of step s (issued a step ago; the vector-memory counter completes in order, so the
-        // weight fetch issued during the previous step has landed too), read the weights of step s and the tap entry of step
-        // s + 2 from LDS, issue the next group's weight fetch (first step of a group) and the activations of step s + 1, multiply.
-        // The wait is the BUILTIN: hipcc's counter model sees it and adds no vmcnt of its own in front of the asm LDS reads.
-        auto step = [&](int s, int i, uint32_t gbuf, int g_fetch, f4_t (&a_cur)[MT], f4_t (&a_nxt)[MT]) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+        f32_vm_wait<2 * MT>();                                 // the first group's fragments
+        // One step: wait for the activations of step s, read the weights of step s and the tap entry of step s + 3 from LDS,
+        // issue the next group's weight fetch (first step of a group; past the end it fetches zeros nobody reads: the counter
+        // arithmetic stays the same) and the activations of step s + 2, multiply.
+        auto step = [&](int s, auto i_c, auto ph_c, uint32_t gbuf, int g) {
+            constexpr int I = decltype(i_c)::value, PH = (decltype(ph_c)::value + I) % 3;
+            f32_vm_wait<(I == 1 ? MT + NT : MT)>();            // in order: a[PH] (and everything older) has landed
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) f32_tie(a[PH][mt]);
             f4_t b[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = f32_lds_read16(gbuf + (uint32_t)(i * NT + nt) * 1024u + (uint32_t)lane * 16u);
-            const uint32_t s2 = (uint32_t)(s + 2) * 32u;
-            const int2 t_cur = t_nxt;                          // (table entry of step s + 1, read one step ago)
-            t_nxt = f32_lds_read8(kt + (s2 < last ? s2 : last));
-            load_a(t_cur, a_nxt);                              // past the end: the last step again, unused
-            if (g_fetch >= 0) fetch_group(g_fetch);
+            for (int nt = 0; nt < NT; ++nt) b[nt] = f32_lds_read16(gbuf + (uint32_t)(I * NT + nt) * 1024u + (uint32_t)lane * 16u);
+            int2 t_cur = t_nxt;                                // (table entry of step s + 2, read one step ago)
+            t_nxt = entry(s + 3);
+            if (I == 0) fetch_group(g + 1);
+            load_a(t_cur, a[(PH + 2) % 3]);
             f32_lds_wait(t_nxt);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) f32_lds_wait(b[nt]);
             __builtin_amdgcn_sched_barrier(0);
-            mma(aop_c, a_cur, b);
+            mma(aop_c, a[PH], b);
             __builtin_amdgcn_sched_barrier(0);
         };
-        for (int g = 0; g < n_groups; ++g) {
-            // every wave's share of group g landed before its last vmcnt(0); the barrier makes them visible to all four waves
-            // and says that nobody reads the other half of the ring any more
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+        auto group = [&](int g, auto ph_c) {                   // steps 4 g ..: a[(4 g) % 3] = a[g % 3] holds the first
+            // every wave's share of group g has landed (it is older than activation loads already consumed); the barrier makes
+            // them visible to all four waves and says that nobody reads the other half of the ring any more
             __builtin_amdgcn_s_barrier();
             const uint32_t gbuf = ring + (uint32_t)(g & 1) * GROUP_BYTES;
             const int s = g * 4;
-            step(s, 0, gbuf, g + 1 < n_groups ? g + 1 : -1, a0, a1);
-            if (s + 1 < n) step(s + 1, 1, gbuf, -1, a1, a0);
-            if (s + 2 < n) step(s + 2, 2, gbuf, -1, a0, a1);
-            if (s + 3 < n) step(s + 3, 3, gbuf, -1, a1, a0);
+            step(s, std::integral_constant<int, 0>{}, ph_c, gbuf, g);
+            if (s + 1 < n) step(s + 1, std::integral_constant<int, 1>{}, ph_c, gbuf, g);
+            if (s + 2 < n) step(s + 2, std::integral_constant<int, 2>{}, ph_c, gbuf, g);
+            if (s + 3 < n) step(s + 3, std::integral_constant<int, 3>{}, ph_c, gbuf, g);
+        };
+        for (int g = 0; g < n_groups; g += 3) {
+            group(g, std::integral_constant<int, 0>{});
+            if (g + 1 < n_groups) group(g + 1, std::integral_constant<int, 1>{});
+            if (g + 2 < n_groups) group(g + 2, std::integral_constant<int, 2>{});
         }
+        f32_vm_wait<0>();                                      // (the unused loads past the end)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) f32_tie(a[i][mt]);
     };
-    if (p.a_op == SC2_AOP_ABS) k_loop(std::integral_constant<int, SC2_AOP_ABS>{});
+    if (p.skip_j3) k_loop(std::integral_constant<int, SC2_AOP_NONE | 0x100>{});
+    else if (p.a_op == SC2_AOP_ABS) k_loop(std::integral_constant<int, SC2_AOP_ABS>{});
     else if (p.a_op == SC2_AOP_SQUARE) k_loop(std::integral_constant<int, SC2_AOP_SQUARE>{});
     else k_loop(std::integral_constant<int, SC2_AOP_NONE>{});
 
@@ -266,7 +303,7 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
     for (int mt = 0; mt < MT; ++mt) {
         const long long m = m_base + mt * 16 + r;
         if (m >= p.M) continue;
-        const long long n_img = m / ohw;
+        const long long n_img = (uint32_t)m / (uint32_t)ohw;
         const long long pix = m - n_img * ohw;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -408,6 +445,9 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
     a.stride = d->stride_h; a.pad = d->pad_h; a.OH = d->OH; a.OW = d->OW;
     a.a_op = d->a_op; a.epilogue = d->epilogue; a.out_format = d->out_format;
     a.n_steps = (d->KH * d->KW * d->Cin + 15) / 16;
+    // Kpad (the bf16 kernels' weight pitch) carries the REAL channel count here: 3 of Cin == 4 means the fourth channel of x and the
+    // weights of k % 4 == 3 are zero (hip.nchw_f32_to_nhwc_f32 / hip.pack_conv_f32 make them so) and their products are skipped
+    a.skip_j3 = (d->Cin == 4 && d->Kpad == 3 && d->a_op == SC2_AOP_NONE) ? 1 : 0;
     a.M = (long long)d->N * d->OH * d->OW;
     {
         const long long xb = (long long)d->N * d->H * d->W * d->Cin * 4;

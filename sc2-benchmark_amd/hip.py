@@ -1160,9 +1160,10 @@ def pack_conv_f32(weight, cin_pad=None):
 
 
 def conv2d_f32_fwd(x_nhwc, w_frag, cout, kh, kw, stride, padding, a_op=AOP_NONE, epilogue=EPI_NONE, out_format=None,
-                   ep_x=None, ep_beta=None, out=None, tag=None):
+                   ep_x=None, ep_beta=None, out=None, tag=None, cin_real=0):
     """x_nhwc: f32 [N,H,W,Cin] (Cin % 4 == 0) -> per out_format: OUT_F32_NHWC [N,OH,OW,Cout] (default), OUT_F32_NCHW
-    [N,Cout,OH,OW], OUT_I32_NCHW_SYM int32 [N,Cout,OH,OW] (ep_beta = medians)."""
+    [N,Cout,OH,OW], OUT_I32_NCHW_SYM int32 [N,Cout,OH,OW] (ep_beta = medians).  cin_real: the module's channel count when x_nhwc
+    carries zero padding channels (3 of 4: the kernel skips the padding channel's products)."""
     _dev(x_nhwc, 'x')
     assert x_nhwc.dtype == torch.float32 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
     assert w_frag.dtype == torch.float32 and w_frag.is_contiguous()
@@ -1172,7 +1173,7 @@ def conv2d_f32_fwd(x_nhwc, w_frag, cout, kh, kw, stride, padding, a_op=AOP_NONE,
     ph = padding[0] if isinstance(padding, (tuple, list)) else padding
     OH, OW = (H + 2 * ph - kh) // sh + 1, (W + 2 * ph - kw) // sh + 1
     d = ConvDesc(N=N, H=H, W=W, Cin=Cin, Cout=cout, KH=kh, KW=kw, stride_h=sh, stride_w=sh, pad_h=ph, pad_w=ph, OH=OH, OW=OW,
-                 a_op=a_op, epilogue=epilogue, out_format=out_format, Kpad=0, Cout_pad=0, out_H=0, out_W=0, out_stride_h=0,
+                 a_op=a_op, epilogue=epilogue, out_format=out_format, Kpad=int(cin_real or 0), Cout_pad=0, out_H=0, out_W=0, out_stride_h=0,
                  out_stride_w=0, out_off_h=0, out_off_w=0, k_order=0)
     if out_format == OUT_F32_NHWC:
         y = torch.empty((N, OH, OW, cout), dtype=torch.float32, device=x_nhwc.device)

@@ -224,16 +224,16 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                 gamma, beta = self._f32_pack(nxt)
                 h = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding,
                                        epilogue=hip.EPI_FUSED_IGDN if nxt.inverse else hip.EPI_FUSED_GDN, ep_x=gamma, ep_beta=beta,
-                                       out_format=hip.OUT_F32_NHWC, tag=mod._tag + '.f32+' + nxt._tag + '.f32')
+                                       out_format=hip.OUT_F32_NHWC, tag=mod._tag + '.f32+' + nxt._tag + '.f32', cin_real=mod.in_channels)
                 fused_into_previous = True
                 continue
             if last and symbols_for is not None and bias is None:
                 sym = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding, out_format=hip.OUT_I32_NCHW_SYM,
-                                         ep_beta=symbols_for._median_vector(), out=out, tag=mod._tag + '.f32')
+                                         ep_beta=symbols_for._median_vector(), out=out, tag=mod._tag + '.f32', cin_real=mod.in_channels)
                 return sym
             h = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding,
                                    epilogue=hip.EPI_NONE if bias is None else hip.EPI_BIAS, ep_beta=bias,
-                                   out_format=hip.OUT_F32_NCHW if last else hip.OUT_F32_NHWC, tag=mod._tag + '.f32')
+                                   out_format=hip.OUT_F32_NCHW if last else hip.OUT_F32_NHWC, tag=mod._tag + '.f32', cin_real=mod.in_channels)
         if symbols_for is None:
             return h
         sym = symbols_for.quantize(h, 'symbols', self._get_means(h))

@@ -16,6 +16,9 @@ may copy it while the load is in flight.  The kernels mark their weight-fragment
 check walks each kernel's listing in layout order, keeps a register 'hot' from a marked load until some other instruction
 writes it, and reports every instruction but a v_mfma that reads a hot register.
 
+A counted wait that lands only SOME of the marked loads names them: the asm comment `; landed v[a:b]` (conv_f32.hip: an empty asm
+statement per operand register behind the s_waitcnt) takes those registers off the hot set.
+
 --stores: `buffer_store_dwordx3/x4 vData, vOff, rsrc, sN` (SGPR soffset) directly followed by a VALU write of one of its data
 registers.  hipcc's hazard recogniser exempts this form from the ">64-bit store data" hazard; gfx950 has the hazard all the same
 (tools/micro/store_hazard.hip, profiles/r04_store_hazard.txt).  The kernels that store this way put wait states behind every
@@ -97,6 +100,9 @@ def audit_copies(body):
         if s.startswith(';;#ASMEND'):
             inasm = False
             continue
+        if inasm and s.startswith('; landed'):     # asm comment of a counted wait: `; landed v[a:b]` = these registers' loads have landed
+            insts.append((i, 'landed ' + s[len('; landed'):], inasm))
+            continue
         if not s or s[0] == ';' or (s[0] == '.' and not s.startswith('.LBB')):
             continue
         insts.append((i, s, inasm))
@@ -133,6 +139,11 @@ def audit_copies(body):
     def step(t, a, hot, report, i):
         toks = t.replace(',', ' ').split()
         op, args = toks[0], toks[1:]
+        if op == 'landed':
+            out = set(hot)
+            for x in args:
+                out -= regs_of(x)
+            return out
         if a and op in ('buffer_load_dwordx4', 'global_load_dwordx4') and 'wfrag' in t:
             return hot | regs_of(args[0])
         if op == 's_waitcnt' and ('vmcnt(0)' in t or 'wfrag-landed' in t):
