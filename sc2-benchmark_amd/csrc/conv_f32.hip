@@ -6,18 +6,23 @@
 // move ~1-2 % of the symbols of an image across such a boundary.  This file is the encoder mode that does not:
 // `v_mfma_f32_16x16x4_f32` takes f32 A / B operands and accumulates in f32 -- bit for bit a k-ordered fmaf chain, one rounding
 // per product (cdna_hip_programming.md, "FP32-input MFMA") -- at 1/16 of the bf16 matrix rate (155 TFLOP/s).  The encoder is
-// only 1.18 GFLOP per image, so the mode costs ~2-4 ms per 256 images.  What remains against the CPU's f32 convolution is the
+// only 1.18 GFLOP per image, so the mode costs ~3 ms per 256 images.  What remains against the CPU's f32 convolution is the
 // ORDER of the f32 additions (the CPU's blocked loops sum in another order): relative 1e-7 per element, symbol flips ~1e-5.
 //
-// Structure (SIMPLE on purpose: this path is bound by the f32 matrix pipe at one sixteenth of the bf16 rate, so it needs no
-// LDS staging -- 16 output pixels x 16 k values x 4 B = 1 KB per A fragment against 4 MFMAs x NT of 32 cycles each):
+// Structure:
 //   * implicit GEMM, M = output pixels, N = output channels, K = (kh, kw, ci) with ci fastest; activations f32 NHWC with the
 //     channel count padded to a multiple of 4, so a lane's four consecutive k are ONE 16-byte load of one input pixel;
 //   * a k-step = 16 consecutive k = 4 MFMAs: lane (row r = l & 15, quarter q = l >> 4) loads k = 16 s + 4 q + j (j = 0..3) of
 //     its pixel / its output channel and MFMA j consumes element j of every lane (k = 16 s + 4 q + j for q = 0..3): the same
 //     permutation on both operands, so every product lands in the right sum;
 //   * a wave owns MT x 16 pixels x NT x 16 channels; weights are packed fragment-major ([chunk][step][nt][lane][4], 1 KB per
-//     fragment) by hip.pack_conv_f32; operands of step s + 1 are loaded while step s multiplies;
+//     fragment) by hip.pack_conv_f32;
+//   * round 4: the four waves of a workgroup read the SAME weight stream, so it goes through LDS once per workgroup (direct-to-LDS
+//     loads, a two-deep ring of four-step groups, one barrier per group); the activations stay per-wave register loads, two
+//     steps ahead, issued and counted by hand (asm; tools/audit_vmcnt.py --copies checks that nothing touches a register whose
+//     load is in flight).  Measured on the 96 -> 48 k5 s2 conv + GDN1 at bs 256: 1.81 -> 1.62 ms, matrix pipe 80 % busy at the
+//     2.10 GHz the board then clocks (PMC, profiles/r04_f32_*): the launch sits at the power ceiling of the f32 matrix pipe
+//     (155.7 TFLOP/s with register-only operands, tools/micro/mfma_f32_peak.hip);
 //   * per-step tap offsets / bounds come from a small table built in LDS at the start of the workgroup;
 //   * conv + GDN1 in one launch where a wave holds every channel of its pixels (Cout <= 96: SC2_EPI_FUSED_GDN): the accumulators
 //     are, as they stand, the operand fragments of the 1x1 GEMM over the channels;
@@ -238,22 +243,29 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
             mma(aop_c, a[PH], b);
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto group = [&](int g, auto ph_c) {                   // steps 4 g ..: a[(4 g) % 3] = a[g % 3] holds the first
-            // every wave's share of group g has landed (it is older than activation loads already consumed); the barrier makes
-            // them visible to all four waves and says that nobody reads the other half of the ring any more
-            __builtin_amdgcn_s_barrier();
-            const uint32_t gbuf = ring + (uint32_t)(g & 1) * GROUP_BYTES;
-            const int s = g * 4;
-            step(s, std::integral_constant<int, 0>{}, ph_c, gbuf, g);
-            if (s + 1 < n) step(s + 1, std::integral_constant<int, 1>{}, ph_c, gbuf, g);
-            if (s + 2 < n) step(s + 2, std::integral_constant<int, 2>{}, ph_c, gbuf, g);
-            if (s + 3 < n) step(s + 3, std::integral_constant<int, 3>{}, ph_c, gbuf, g);
+        // Twelve steps = three groups = one turn of the three activation sets: step s0 + K has compile-time position K % 4 in its
+        // group and set K % 3.  Whole turns first, then the rest as ONE chain that leaves at the first step past the end (a flat
+        // control flow: the copy audit of tools/audit_vmcnt.py follows it).
+        int s0 = 0;
+        auto blk = [&](auto k_c) {
+            constexpr int K = decltype(k_c)::value;
+            const int g = (s0 + K) >> 2;
+            // first step of a group: every wave's share of the group has landed (it is older than activation loads already
+            // consumed); the barrier makes them visible to all four waves and frees the other half of the ring
+            if (K % 4 == 0) __builtin_amdgcn_s_barrier();
+            step(s0 + K, std::integral_constant<int, K % 4>{}, std::integral_constant<int, (K / 4) % 3>{},
+                 ring + (uint32_t)(g & 1) * GROUP_BYTES, g);
         };
-        for (int g = 0; g < n_groups; g += 3) {
-            group(g, std::integral_constant<int, 0>{});
-            if (g + 1 < n_groups) group(g + 1, std::integral_constant<int, 1>{});
-            if (g + 2 < n_groups) group(g + 2, std::integral_constant<int, 2>{});
-        }
+        auto turn = [&](auto... k_c) { (blk(k_c), ...); };
+        auto rest = [&](auto... k_c) { (void)((s0 + decltype(k_c)::value < n && (blk(k_c), true)) && ...); };
+#define SC2_F32_K12(f)                                                                                                             \
+    f(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{},                        \
+      std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{},                        \
+      std::integral_constant<int, 6>{}, std::integral_constant<int, 7>{}, std::integral_constant<int, 8>{},                        \
+      std::integral_constant<int, 9>{}, std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{})
+        for (; s0 + 12 <= n; s0 += 12) SC2_F32_K12(turn);
+        SC2_F32_K12(rest);
+#undef SC2_F32_K12
         f32_vm_wait<0>();                                      // (the unused loads past the end)
 #pragma unroll
         for (int i = 0; i < 3; ++i)

@@ -101,7 +101,7 @@ def test_asm_weight_loads_are_never_copied_in_flight():
         pytest.skip('hipcc not available')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, 'sc2-benchmark_amd', 'csrc')
-    files = [os.path.join(csrc, f) for f in ('conv2x2_win.hip', 'conv3x3_win.hip', 'conv1x1_win.hip', 'conv_gdn512.hip', 'conv2_gdn48.hip')]
+    files = [os.path.join(csrc, f) for f in ('conv2x2_win.hip', 'conv3x3_win.hip', 'conv1x1_win.hip', 'conv_gdn512.hip', 'conv2_gdn48.hip', 'conv_f32.hip')]
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_vmcnt.py'), '--copies'] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     # the second hazard the compiler does not cover: a 16-byte buffer store with an SGPR soffset directly followed by a VALU write
