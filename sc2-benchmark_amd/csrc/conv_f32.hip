@@ -115,8 +115,11 @@ __device__ __forceinline__ int2 f32_lds_read8(uint32_t addr) {
     return v;
 }
 
+#ifndef SC2_F32_WAVES12
+#define SC2_F32_WAVES12 3
+#endif
 template <int NT, int MT, bool FUSED>
-__global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_f32_kernel(F32Args p) {
+__global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : SC2_F32_WAVES12)) void conv_f32_kernel(F32Args p) {
     extern __shared__ int2 ktab[];     // [n_steps * 4]: {byte offset of the lane's 4 k inside the window, kh | kw << 16}
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -208,34 +211,38 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
         const uint32_t kt = lds_base + (uint32_t)q * 8u;       // tap table entry of (step, this lane's quarter): + 32 per step
         const uint32_t last = (uint32_t)(n - 1) * 32u;
         auto entry = [&](int s) { const uint32_t o = (uint32_t)s * 32u; return f32_lds_read8(kt + (o < last ? o : last)); };
-        // activations TWO steps ahead in three register sets (a[s % 3] holds step s); the weight fetch of the next group sits
-        // between the activation loads of steps s + 1 and s + 2 in the in-order counter
-        f4_t a[3][MT];
+        // activations S - 1 steps ahead in S register sets (a[s % S] holds step s): two ahead for the narrow tiles, one for the
+        // 96-channel tile (its accumulators leave no room for a third set at three waves per SIMD).  The weight fetch of the
+        // next group is issued in front of its step's activation loads in the in-order counter.
+        constexpr int S = NT * MT > 6 ? 2 : 3;
+        f4_t a[S][MT];
         fetch_group(0);
         int2 t = entry(0);
         f32_lds_wait(t);
         load_a(t, a[0]);
-        t = entry(1);
-        f32_lds_wait(t);
-        load_a(t, a[1]);                                       // past the end: the last step again, unused
-        int2 t_nxt = entry(2);
+        if (S == 3) {
+            t = entry(1);
+            f32_lds_wait(t);
+            load_a(t, a[1]);                                   // past the end: the last step again, unused
+        }
+        int2 t_nxt = entry(S - 1);
         f32_lds_wait(t_nxt);
-        f32_vm_wait<2 * MT>();                                 // the first group's fragments
+        f32_vm_wait<(S - 1) * MT>();                           // the first group's fragments
         // One step: wait for the activations of step s, read the weights of step s and the tap entry of step s + 3 from LDS,
         // issue the next group's weight fetch (first step of a group; past the end it fetches zeros nobody reads: the counter
-        // arithmetic stays the same) and the activations of step s + 2, multiply.
+        // arithmetic stays the same) and the activations of step s + S - 1, multiply.
         auto step = [&](int s, auto i_c, auto ph_c, uint32_t gbuf, int g) {
-            constexpr int I = decltype(i_c)::value, PH = (decltype(ph_c)::value + I) % 3;
-            f32_vm_wait<(I == 1 ? MT + NT : MT)>();            // in order: a[PH] (and everything older) has landed
+            constexpr int I = decltype(i_c)::value, PH = decltype(ph_c)::value % S;
+            f32_vm_wait<(S - 2) * MT + (S == 3 && I == 1 ? NT : 0)>();   // in order: a[PH] (and everything older) has landed
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) f32_tie(a[PH][mt]);
             f4_t b[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) b[nt] = f32_lds_read16(gbuf + (uint32_t)(I * NT + nt) * 1024u + (uint32_t)lane * 16u);
-            int2 t_cur = t_nxt;                                // (table entry of step s + 2, read one step ago)
-            t_nxt = entry(s + 3);
+            int2 t_cur = t_nxt;                                // (table entry of step s + S - 1, read one step ago)
+            t_nxt = entry(s + S);
             if (I == 0) fetch_group(g + 1);
-            load_a(t_cur, a[(PH + 2) % 3]);
+            load_a(t_cur, a[(PH + S - 1) % S]);
             f32_lds_wait(t_nxt);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) f32_lds_wait(b[nt]);
@@ -243,8 +250,8 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
             mma(aop_c, a[PH], b);
             __builtin_amdgcn_sched_barrier(0);
         };
-        // Twelve steps = three groups = one turn of the three activation sets: step s0 + K has compile-time position K % 4 in its
-        // group and set K % 3.  Whole turns first, then the rest as ONE chain that leaves at the first step past the end (a flat
+        // Twelve steps = three groups = a whole number of turns of the activation sets: step s0 + K has compile-time position
+        // K % 4 in its group and set K % S.  Whole turns first, then the rest as ONE chain that leaves at the first step past the end (a flat
         // control flow: the copy audit of tools/audit_vmcnt.py follows it).
         int s0 = 0;
         auto blk = [&](auto k_c) {
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
             // first step of a group: every wave's share of the group has landed (it is older than activation loads already
             // consumed); the barrier makes them visible to all four waves and frees the other half of the ring
             if (K % 4 == 0) __builtin_amdgcn_s_barrier();
-            step(s0 + K, std::integral_constant<int, K % 4>{}, std::integral_constant<int, (K / 4) % 3>{},
+            step(s0 + K, std::integral_constant<int, K % 4>{}, std::integral_constant<int, K>{},
                  ring + (uint32_t)(g & 1) * GROUP_BYTES, g);
         };
         auto turn = [&](auto... k_c) { (blk(k_c), ...); };
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : 3)) void conv_
 #undef SC2_F32_K12
         f32_vm_wait<0>();                                      // (the unused loads past the end)
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < S; ++i)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) f32_tie(a[i][mt]);
     };
@@ -474,12 +481,13 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
     const int chunks = (d->Cout + cc - 1) / cc;
     // (measured: four row tiles per wave for the narrow chunks -- twice the MFMAs per operand load -- ran the 96 -> 48 k5 s2 conv
     //  in 2.89 ms instead of 2.38 at bs 256: fewer, fatter waves hide less of the operand latency; two row tiles everywhere)
+    constexpr int MT48 = SC2_F32_MT4 ? 4 : 2;
     if (fused) {
         if (cc == 32) return launch_f32<2, 2, true>(a, chunks, s);
-        if (cc == 48) return SC2_F32_MT4 ? launch_f32<3, 4, true>(a, chunks, s) : launch_f32<3, 2, true>(a, chunks, s);
+        if (cc == 48) return launch_f32<3, MT48, true>(a, chunks, s);
         return launch_f32<6, 2, true>(a, chunks, s);
     }
     if (cc == 32) return launch_f32<2, 2>(a, chunks, s);
-    if (cc == 48) return SC2_F32_MT4 ? launch_f32<3, 4>(a, chunks, s) : launch_f32<3, 2>(a, chunks, s);
+    if (cc == 48) return launch_f32<3, MT48>(a, chunks, s);
     return launch_f32<6, 2>(a, chunks, s);
 }
