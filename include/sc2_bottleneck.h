@@ -176,7 +176,8 @@ int sc2_conv_f32_chunk_channels(int Cout);
 /* d      : as for sc2_conv2d_fwd; Cin % 4 == 0 (the padded channel count of x), square stride / padding, no output scatter;
  *          Cout_pad / k_order are ignored.  Kpad: 0, or the number of REAL input channels: Cin == 4 with Kpad == 3 says that
  *          channel 3 of x is zero and zero-weighted (the layout sc2_nchw_f32_to_nhwc_f32 and the packer produce for RGB), and
- *          the kernel skips those products (same sums: they are exact zeros).  a_op: NONE / ABS / SQUARE.  epilogue: NONE, BIAS, GDN (y = ep_x * (1 /
+ *          the kernel skips those products (same sums: they are exact zeros).  With that, k_order == 1 says that x is the f32 NCHW image
+ *          [N, 3, H, W] itself (the reference's input layout): the three channel planes are read in place, no NHWC copy.  a_op: NONE / ABS / SQUARE.  epilogue: NONE, BIAS, GDN (y = ep_x * (1 /
  *          (ep_beta[c] + acc))), IGDN (y = ep_x * (ep_beta[c] + acc)) -- the operation order of compressai GDN1.forward;
  *          FUSED_GDN / FUSED_IGDN (Cout <= 96): the conv followed by GDN1 over its own output in one launch, `ep_x` = the
  *          effective gamma as the w_frag of a 1x1 conv Cout -> Cout (same packing), ep_beta = the effective beta; bit-identical

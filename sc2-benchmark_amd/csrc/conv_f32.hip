@@ -48,6 +48,7 @@ struct F32Args {
     unsigned w_bytes;                  // size of w
     unsigned ring_off;                 // LDS offset of the weight ring (after the tap table, 1 KB aligned)
     int skip_j3;                       // Cin == 4 carrying 3 real channels: every fourth k is a zero channel times a zero weight
+    int planar;                        // with skip_j3: x is f32 NCHW [N, 3, H, W] (the reference's input layout), read in place
 };
 
 typedef __attribute__((ext_vector_type(4))) float f4_t;
@@ -102,6 +103,10 @@ __device__ __forceinline__ void f32_aload16(f4_t &d, f32_desc_t r, uint32_t voff
 __device__ __forceinline__ void f32_dma16(f32_desc_t r, uint32_t lds_addr, uint32_t voff) {   // lane l -> LDS lds_addr + 16 l
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r) : "memory", "m0");
 }
+__device__ __forceinline__ void f32_aload4(float &d, f32_desc_t r, uint32_t voff, uint32_t soff) {   // one float of a channel plane
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen ; wfrag" : "=&v"(d) : "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void f32_tie(float &v) { asm volatile("; landed %0" : "+v"(v)::"memory"); }
 template <int N>
 __device__ __forceinline__ void f32_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void f32_tie(f4_t &v) { asm volatile("; landed %0" : "+v"(v)::"memory"); }   // (tools/audit_vmcnt.py reads it)
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : SC2_F32_WAVES1
         int2 v;
         if (tap < p.KH * p.KW) {
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            v.x = ((kh * p.W + kw) * p.Cin + ci) * 4;      // BYTE offset inside the window
+            v.x = p.planar ? (kh * p.W + kw) * 4 : ((kh * p.W + kw) * p.Cin + ci) * 4;      // BYTE offset inside the window
             v.y = kh | (kw << 16);
         } else {            // K padding: never in bounds (its weights are zero too)
             v.x = 0;
@@ -155,7 +160,8 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : SC2_F32_WAVES1
             const int oh = (int)((uint32_t)rem / (uint32_t)p.OW), ow = rem - oh * p.OW;
             ih0[mt] = oh * p.stride - p.pad;
             iw0[mt] = ow * p.stride - p.pad;
-            a_base[mt] = (uint32_t)(((((long long)n * p.H + ih0[mt]) * (long long)p.W + iw0[mt]) * p.Cin) * 4);
+            a_base[mt] = p.planar ? (uint32_t)(((((long long)n * 3 * p.H + ih0[mt]) * (long long)p.W + iw0[mt])) * 4)
+                                  : (uint32_t)(((((long long)n * p.H + ih0[mt]) * (long long)p.W + iw0[mt]) * p.Cin) * 4);
         } else {
             ih0[mt] = iw0[mt] = -(1 << 20);       // every tap out of bounds: zeros
             a_base[mt] = 0;
@@ -188,21 +194,51 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : SC2_F32_WAVES1
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) f32_dma16(rs_w, dst + nt * 1024u, src + nt * 1024u);
     };
-    auto load_a = [&](int2 t, f4_t (&a)[MT]) {
+    // an operand set of one step: MT pixel quads (NHWC input), or MT x 3 single floats out of the three channel planes (the RGB
+    // image read in the reference's NCHW layout: no transposed copy)
+    struct SetV { f4_t v[MT]; };
+    struct SetP { float c[MT][3]; };
+    const uint32_t plane_bytes = (uint32_t)(p.H * p.W) * 4u;
+    auto load_a = [&](int2 t, auto &a) {
+        constexpr bool PL = std::is_same<std::remove_reference_t<decltype(a)>, SetP>::value;
         const int kh = t.y & 0xFFFF, kw = t.y >> 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bool ok = ((unsigned)(ih0[mt] + kh) < (unsigned)p.H) & ((unsigned)(iw0[mt] + kw) < (unsigned)p.W);
-            f32_aload16(a[mt], rs_x, ok ? a_base[mt] + (uint32_t)t.x : 0x80000000u);   // raw: |x| / x^2 where it is consumed
+            const uint32_t vo = ok ? a_base[mt] + (uint32_t)t.x : 0x80000000u;
+            if constexpr (PL) {
+                f32_aload4(a.c[mt][0], rs_x, vo, 0u);
+                f32_aload4(a.c[mt][1], rs_x, vo, plane_bytes);
+                f32_aload4(a.c[mt][2], rs_x, vo, 2u * plane_bytes);
+            } else {
+                f32_aload16(a.v[mt], rs_x, vo);                // raw: |x| / x^2 where it is consumed
+            }
         }
     };
-    auto mma = [&](auto aop_c, const f4_t (&a)[MT], const f4_t (&b)[NT]) {
-        constexpr int AOP = decltype(aop_c)::value & 0xFF, JN = (decltype(aop_c)::value >> 8) ? 3 : 4;   // (bit 8: skip_j3)
+    auto tie_a = [&](auto &a) {
+        constexpr bool PL = std::is_same<std::remove_reference_t<decltype(a)>, SetP>::value;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if constexpr (PL) {
+                f32_tie(a.c[mt][0]);
+                f32_tie(a.c[mt][1]);
+                f32_tie(a.c[mt][2]);
+            } else {
+                f32_tie(a.v[mt]);
+            }
+        }
+    };
+    auto mma = [&](auto aop_c, const auto &a, const f4_t (&b)[NT]) {
+        constexpr bool PL = std::is_same<std::remove_cv_t<std::remove_reference_t<decltype(a)>>, SetP>::value;
+        constexpr int AOP = decltype(aop_c)::value & 0xFF, JN = ((decltype(aop_c)::value >> 8) & 1) ? 3 : 4;   // (bit 8: skip_j3)
 #pragma unroll
         for (int j = 0; j < JN; ++j)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const float av = AOP == SC2_AOP_ABS ? fabsf(a[mt][j]) : (AOP == SC2_AOP_SQUARE ? a[mt][j] * a[mt][j] : a[mt][j]);
+                float ar;
+                if constexpr (PL) ar = a.c[mt][j < 3 ? j : 0];
+                else ar = a.v[mt][j];
+                const float av = AOP == SC2_AOP_ABS ? fabsf(ar) : (AOP == SC2_AOP_SQUARE ? ar * ar : ar);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][j], av, acc[mt][nt], 0, 0, 0);
             }
@@ -215,7 +251,9 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : SC2_F32_WAVES1
         // 96-channel tile (its accumulators leave no room for a third set at three waves per SIMD).  The weight fetch of the
         // next group is issued in front of its step's activation loads in the in-order counter.
         constexpr int S = NT * MT > 6 ? 2 : 3;
-        f4_t a[S][MT];
+        constexpr bool PL = (decltype(aop_c)::value >> 9) & 1;
+        constexpr int LPS = PL ? 3 * MT : MT;                  // vector-memory instructions per step of activations
+        std::conditional_t<PL, SetP, SetV> a[S];
         fetch_group(0);
         int2 t = entry(0);
         f32_lds_wait(t);
@@ -227,15 +265,14 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : SC2_F32_WAVES1
         }
         int2 t_nxt = entry(S - 1);
         f32_lds_wait(t_nxt);
-        f32_vm_wait<(S - 1) * MT>();                           // the first group's fragments
+        f32_vm_wait<(S - 1) * LPS>();                          // the first group's fragments
         // One step: wait for the activations of step s, read the weights of step s and the tap entry of step s + 3 from LDS,
         // issue the next group's weight fetch (first step of a group; past the end it fetches zeros nobody reads: the counter
         // arithmetic stays the same) and the activations of step s + S - 1, multiply.
         auto step = [&](int s, auto i_c, auto ph_c, uint32_t gbuf, int g) {
             constexpr int I = decltype(i_c)::value, PH = decltype(ph_c)::value % S;
-            f32_vm_wait<(S - 2) * MT + (S == 3 && I == 1 ? NT : 0)>();   // in order: a[PH] (and everything older) has landed
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) f32_tie(a[PH][mt]);
+            f32_vm_wait<(S - 2) * LPS + (S == 3 && I == 1 ? NT : 0)>();   // in order: a[PH] (and everything older) has landed
+            tie_a(a[PH]);
             f4_t b[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) b[nt] = f32_lds_read16(gbuf + (uint32_t)(I * NT + nt) * 1024u + (uint32_t)lane * 16u);
@@ -275,11 +312,10 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : SC2_F32_WAVES1
 #undef SC2_F32_K12
         f32_vm_wait<0>();                                      // (the unused loads past the end)
 #pragma unroll
-        for (int i = 0; i < S; ++i)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) f32_tie(a[i][mt]);
+        for (int i = 0; i < S; ++i) tie_a(a[i]);
     };
-    if (p.skip_j3) k_loop(std::integral_constant<int, SC2_AOP_NONE | 0x100>{});
+    if (p.planar) k_loop(std::integral_constant<int, SC2_AOP_NONE | 0x300>{});
+    else if (p.skip_j3) k_loop(std::integral_constant<int, SC2_AOP_NONE | 0x100>{});
     else if (p.a_op == SC2_AOP_ABS) k_loop(std::integral_constant<int, SC2_AOP_ABS>{});
     else if (p.a_op == SC2_AOP_SQUARE) k_loop(std::integral_constant<int, SC2_AOP_SQUARE>{});
     else k_loop(std::integral_constant<int, SC2_AOP_NONE>{});
@@ -467,9 +503,12 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
     // Kpad (the bf16 kernels' weight pitch) carries the REAL channel count here: 3 of Cin == 4 means the fourth channel of x and the
     // weights of k % 4 == 3 are zero (hip.nchw_f32_to_nhwc_f32 / hip.pack_conv_f32 make them so) and their products are skipped
     a.skip_j3 = (d->Cin == 4 && d->Kpad == 3 && d->a_op == SC2_AOP_NONE) ? 1 : 0;
+    // k_order (ignored otherwise) = 1 with it: x is the f32 NCHW image [N, 3, H, W] itself, the three planes read in place
+    a.planar = d->k_order == 1 ? 1 : 0;
+    SC2_REQUIRE(!a.planar || a.skip_j3, SC2_ERR_UNSUPPORTED, "conv2d_f32: the NCHW input form needs Cin == 4 with Kpad == 3 and a_op NONE");
     a.M = (long long)d->N * d->OH * d->OW;
     {
-        const long long xb = (long long)d->N * d->H * d->W * d->Cin * 4;
+        const long long xb = (long long)d->N * d->H * d->W * (d->k_order == 1 ? 3 : d->Cin) * 4;
         SC2_REQUIRE(xb < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv2d_f32: input of %lld bytes exceeds 2 GB", xb);
         a.x_bytes = (unsigned)xb;
     }

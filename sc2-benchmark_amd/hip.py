@@ -1160,21 +1160,27 @@ def pack_conv_f32(weight, cin_pad=None):
 
 
 def conv2d_f32_fwd(x_nhwc, w_frag, cout, kh, kw, stride, padding, a_op=AOP_NONE, epilogue=EPI_NONE, out_format=None,
-                   ep_x=None, ep_beta=None, out=None, tag=None, cin_real=0):
+                   ep_x=None, ep_beta=None, out=None, tag=None, cin_real=0, x_is_nchw_rgb=False):
     """x_nhwc: f32 [N,H,W,Cin] (Cin % 4 == 0) -> per out_format: OUT_F32_NHWC [N,OH,OW,Cout] (default), OUT_F32_NCHW
     [N,Cout,OH,OW], OUT_I32_NCHW_SYM int32 [N,Cout,OH,OW] (ep_beta = medians).  cin_real: the module's channel count when x_nhwc
-    carries zero padding channels (3 of 4: the kernel skips the padding channel's products)."""
+    carries zero padding channels (3 of 4: the kernel skips the padding channel's products).  x_is_nchw_rgb: x_nhwc is the f32 NCHW
+    image [N,3,H,W] itself (w_frag packed for cin_pad 4 as always): the kernel reads the three planes in place."""
     _dev(x_nhwc, 'x')
     assert x_nhwc.dtype == torch.float32 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
     assert w_frag.dtype == torch.float32 and w_frag.is_contiguous()
     out_format = OUT_F32_NHWC if out_format is None else out_format
-    N, H, W, Cin = x_nhwc.shape
+    if x_is_nchw_rgb:
+        N, c3, H, W = x_nhwc.shape
+        assert c3 == 3
+        Cin, cin_real = 4, 3
+    else:
+        N, H, W, Cin = x_nhwc.shape
     sh = stride[0] if isinstance(stride, (tuple, list)) else stride
     ph = padding[0] if isinstance(padding, (tuple, list)) else padding
     OH, OW = (H + 2 * ph - kh) // sh + 1, (W + 2 * ph - kw) // sh + 1
     d = ConvDesc(N=N, H=H, W=W, Cin=Cin, Cout=cout, KH=kh, KW=kw, stride_h=sh, stride_w=sh, pad_h=ph, pad_w=ph, OH=OH, OW=OW,
                  a_op=a_op, epilogue=epilogue, out_format=out_format, Kpad=int(cin_real or 0), Cout_pad=0, out_H=0, out_W=0, out_stride_h=0,
-                 out_stride_w=0, out_off_h=0, out_off_w=0, k_order=0)
+                 out_stride_w=0, out_off_h=0, out_off_w=0, k_order=1 if x_is_nchw_rgb else 0)
     if out_format == OUT_F32_NHWC:
         y = torch.empty((N, OH, OW, cout), dtype=torch.float32, device=x_nhwc.device)
     elif out_format == OUT_F32_NCHW:

@@ -197,10 +197,14 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         """encoder(x) with f32 operands (set_encoder_precision('f32')): every Conv2d / GDN1 of the analysis stack as one
         launch of sc2_conv2d_f32_fwd on f32 NHWC activations; the last conv writes the f32 NCHW latent or the symbols."""
         mods = list(self._g_a())
-        h = hip.nchw_f32_to_nhwc_f32(x)
+        # an RGB image goes to the first convolution as it is (f32 NCHW, three planes read in place); anything else as f32 NHWC
+        rgb_in_place = (x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32 and x.is_contiguous() and
+                        isinstance(mods[0], nn.Conv2d) and mods[0].in_channels == 3)
+        h = x if rgb_in_place else hip.nchw_f32_to_nhwc_f32(x)
         fused_into_previous = False
         for i, mod in enumerate(mods):
             last = i == len(mods) - 1
+            first_kw = dict(x_is_nchw_rgb=True) if (i == 0 and rgb_in_place) else {}
             if fused_into_previous:      # this GDN1 ran inside the conv before it
                 fused_into_previous = False
                 continue
@@ -224,16 +228,16 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                 gamma, beta = self._f32_pack(nxt)
                 h = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding,
                                        epilogue=hip.EPI_FUSED_IGDN if nxt.inverse else hip.EPI_FUSED_GDN, ep_x=gamma, ep_beta=beta,
-                                       out_format=hip.OUT_F32_NHWC, tag=mod._tag + '.f32+' + nxt._tag + '.f32', cin_real=mod.in_channels)
+                                       out_format=hip.OUT_F32_NHWC, tag=mod._tag + '.f32+' + nxt._tag + '.f32', cin_real=mod.in_channels, **first_kw)
                 fused_into_previous = True
                 continue
             if last and symbols_for is not None and bias is None:
                 sym = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding, out_format=hip.OUT_I32_NCHW_SYM,
-                                         ep_beta=symbols_for._median_vector(), out=out, tag=mod._tag + '.f32', cin_real=mod.in_channels)
+                                         ep_beta=symbols_for._median_vector(), out=out, tag=mod._tag + '.f32', cin_real=mod.in_channels, **first_kw)
                 return sym
             h = hip.conv2d_f32_fwd(h, w, mod.out_channels, kh, kw, mod.stride, mod.padding,
                                    epilogue=hip.EPI_NONE if bias is None else hip.EPI_BIAS, ep_beta=bias,
-                                   out_format=hip.OUT_F32_NCHW if last else hip.OUT_F32_NHWC, tag=mod._tag + '.f32', cin_real=mod.in_channels)
+                                   out_format=hip.OUT_F32_NCHW if last else hip.OUT_F32_NHWC, tag=mod._tag + '.f32', cin_real=mod.in_channels, **first_kw)
         if symbols_for is None:
             return h
         sym = symbols_for.quantize(h, 'symbols', self._get_means(h))

@@ -47,6 +47,8 @@ def test_conv_f32_vs_torch_cpu(S, dev, cin, cout, k, s, p, hw):
     if cin == 3:      # the padding channel's products skipped (Kpad = 3 of Cin = 4): exact zeros left out, the same sums
         y3 = hip.conv2d_f32_fwd(xh, wf, cout, k, k, s, p, cin_real=3)
         assert torch.equal(y3.cpu(), y.cpu())
+        y4 = hip.conv2d_f32_fwd(x.to(dev).contiguous(), wf, cout, k, k, s, p, x_is_nchw_rgb=True)   # the NCHW image read in place
+        assert torch.equal(y4.cpu(), y.cpu())
     yb = hip.conv2d_f32_fwd(xh, wf, cout, k, k, s, p, epilogue=hip.EPI_BIAS, ep_beta=b.to(dev), out_format=hip.OUT_F32_NCHW)
     _close(yb, F.conv2d(x, w, b, s, p))
     med = torch.linspace(-0.4, 0.4, cout)

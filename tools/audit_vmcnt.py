@@ -106,7 +106,7 @@ def audit_copies(body):
         if not s or s[0] == ';' or (s[0] == '.' and not s.startswith('.LBB')):
             continue
         insts.append((i, s, inasm))
-    if not any(a and t.startswith(('buffer_load_dwordx4', 'global_load_dwordx4')) and 'wfrag' in t for _, t, a in insts):
+    if not any(a and t.startswith(('buffer_load_dwordx4', 'global_load_dwordx4', 'buffer_load_dword')) and 'wfrag' in t for _, t, a in insts):
         return []
     blocks, cur, label_of = [], None, {}
     for idx, (i, t, a) in enumerate(insts):
@@ -144,7 +144,7 @@ def audit_copies(body):
             for x in args:
                 out -= regs_of(x)
             return out
-        if a and op in ('buffer_load_dwordx4', 'global_load_dwordx4') and 'wfrag' in t:
+        if a and op in ('buffer_load_dwordx4', 'global_load_dwordx4', 'buffer_load_dword') and 'wfrag' in t:
             return hot | regs_of(args[0])
         if op == 's_waitcnt' and ('vmcnt(0)' in t or 'wfrag-landed' in t):
             return set()   # everything has landed (vmcnt(0)), or the kernel says so: a counted wait whose budget covers every marked
