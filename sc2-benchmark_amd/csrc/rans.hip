@@ -247,9 +247,12 @@ __global__ __launch_bounds__(64) void rans_enc_serial_kernel(const RansArgs a, c
             for (int u = 0; u < U; ++u) step_slow(e[u], i0 - u);
         } else {
             if (__any(cnt > kStage - U)) flush();
+            // (the fence: hipcc otherwise sinks each table read down to its symbol -- `ds_read2_b64; s_waitcnt lgkmcnt(0)` per
+            //  symbol in the listing -- and the serial chain pays an LDS round trip per symbol instead of one per chunk)
             EncEntry en[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) en[u] = tab[e[u]];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U; ++u) put_fast(en[u]);
         }
