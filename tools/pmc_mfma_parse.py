@@ -28,8 +28,8 @@ KERNELS = [   # (label, name pattern, algorithmic GFLOP per launch at bs 256)
     ('dec.conv0+igdn512', 'conv2x2_gdn512_kernel', 1.9525 * N),
     ('dec.conv2+igdn256 (tile kernel)', 'Cfg8<256, 2, 4, true, 512, 2, 2', 3.5684 * N),
     ('dec.conv4 (tile kernel)', 'Cfg8<256, 2, 4, true, 256, 2, 2', 1.6442 * N),
-    ('dec.conv2+igdn256 (win)', 'Geo2<55, 0>, 1,', 3.5684 * N), ('dec.conv2 (win)', 'Geo2<55, 0>, 0,', 3.1719 * N),
-    ('dec.conv4 (win)', 'Geo2<56, 1>, 0,', 1.6442 * N), ('dec.conv4 + layer2.0 conv1 / downsample (win, tail)', 'Geo2<56, 1>, 2,', 2.0552 * N)]
+    ('dec.conv2+igdn256 (win)', 'Geo2<55, 0, false>, 1,', 3.5684 * N), ('dec.conv2 (win)', 'Geo2<55, 0, false>, 0,', 3.1719 * N),
+    ('dec.conv4 (win)', 'Geo2<56, 1, false>, 0,', 1.6442 * N), ('dec.conv4 + layer2.0 conv1 / downsample (win, tail)', 'Geo2<56, 1, false>, 2,', 2.0552 * N)]
 if len(sys.argv) > 2:   # label:pattern:gflop triples replace the default list (tools/pmc_head.sh)
     KERNELS = [(a.split('|')[0], a.split('|')[1], float(a.split('|')[2])) for a in sys.argv[2:]]
 
