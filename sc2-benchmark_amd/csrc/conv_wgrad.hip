@@ -15,6 +15,8 @@
 // Bank conflicts: a fragment read touches 8 different pixel rows at one 32-byte column offset; the 16-byte chunk
 // index is XORed with f(row) = 2*((row & 3) + 4*((row >> 3) & 1)) -- applied to the SOURCE address of the
 // direct-to-LDS load and again to the read address -- so the 8 rows land on 8 different 32-byte slots.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "sc2_common.h"
@@ -101,15 +103,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     // slab step adds the decomposition of 32 pixels (d_img, d_oh, d_ow) with one conditional subtract per coordinate.
     const int d_img = WG_SLAB / p.OHW, d_rem = WG_SLAB - d_img * p.OHW;
     const int d_oh = d_rem / p.OW, d_ow = d_rem - d_oh * p.OW;
-    int m_j[2], img_j[2], oh_j[2], ow_j[2];
+    // ... and so are the input coordinates (ih, iw) of the lane's tap and the ELEMENT OFFSETS of both operands (second pass: the
+    // loop still multiplied -- oh * SH, ow * SW, ((img * H + ih) * W + iw) * Cin: ten quarter-rate instructions per slab beside
+    // sixty others against 16 MFMAs).  A slab step moves the im2col offset by cA, plus cB when the output column wraps, plus cC
+    // when the output row does (32-bit modular arithmetic; the offset is used only where the tap lies inside the image).
+    const uint32_t g_step = (uint32_t)(WG_SLAB * p.Cout);
+    const int iw_step = d_ow * p.SW, iw_wrap = p.OW * p.SW, ih_step = d_oh * p.SH, ih_wrap = p.OH * p.SH;
+    const uint32_t cA = (uint32_t)(p.Cin * (p.W * d_oh * p.SH + d_ow * p.SW) + p.Cin * p.H * p.W * d_img);
+    const uint32_t cB = (uint32_t)(p.Cin * (p.W * p.SH - p.OW * p.SW));
+    const uint32_t cC = (uint32_t)(p.Cin * (p.H * p.W - p.W * p.OH * p.SH));
+    int m_j[2], oh_j[2], ow_j[2], ih_j[2], iw_j[2];
+    uint32_t goff_j[2], aoff_j[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         m_j[j] = m_begin + row_j[j];
         const int mm = m_j[j] < p.M ? m_j[j] : 0;      // (rows past the end: coordinates of pixel 0, never used)
-        img_j[j] = mm / p.OHW;
-        const int rem = mm - img_j[j] * p.OHW;
+        const int img = mm / p.OHW;
+        const int rem = mm - img * p.OHW;
         oh_j[j] = rem / p.OW;
         ow_j[j] = rem - oh_j[j] * p.OW;
+        ih_j[j] = oh_j[j] * p.SH - p.PH + kh_j[j];
+        iw_j[j] = ow_j[j] * p.SW - p.PW + kw_j[j];
+        goff_j[j] = (uint32_t)(m_j[j] * p.Cout + gco_j[j]);
+        aoff_j[j] = (uint32_t)(((img * p.H + ih_j[j]) * p.W + iw_j[j]) * p.Cin + ci_j[j]);
     }
     auto issue_slab = [&](int buf) {   // the NEXT slab in order
         unsigned char *Gi = smem + buf * (2 * WG_IMG);
@@ -119,22 +135,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
             const bool mok = m_j[j] < m_end;
             // dY operand
             const bool g_ok = mok & gok_j[j];
-            const long long goff = g_ok ? (long long)(uint32_t)(m_j[j] * p.Cout + gco_j[j]) : zoff_g;
+            const long long goff = g_ok ? (long long)goff_j[j] : zoff_g;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.gy + goff), (lds_ptr_t)(Gi + (j * 4 + wave) * 1024), 16, 0, 0);
             // im2col operand
-            const int ih = oh_j[j] * p.SH - p.PH + kh_j[j], iw = ow_j[j] * p.SW - p.PW + kw_j[j];
-            const bool a_ok = mok & kok_j[j] & ((unsigned)ih < (unsigned)p.H) & ((unsigned)iw < (unsigned)p.W);
-            const long long aoff = a_ok ? (long long)(uint32_t)(((img_j[j] * p.H + ih) * p.W + iw) * p.Cin + ci_j[j]) : zoff_x;
+            const bool a_ok = mok & kok_j[j] & ((unsigned)ih_j[j] < (unsigned)p.H) & ((unsigned)iw_j[j] < (unsigned)p.W);
+            const long long aoff = a_ok ? (long long)aoff_j[j] : zoff_x;
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.x + aoff), (lds_ptr_t)(Ai + (j * 4 + wave) * 1024), 16, 0, 0);
             // 32 pixels on
             m_j[j] += WG_SLAB;
+            goff_j[j] += g_step;
             ow_j[j] += d_ow;
-            const int c1 = ow_j[j] >= p.OW ? 1 : 0;
+            const bool c1 = ow_j[j] >= p.OW;
             ow_j[j] -= c1 ? p.OW : 0;
-            oh_j[j] += d_oh + c1;
-            const int c2 = oh_j[j] >= p.OH ? 1 : 0;
+            iw_j[j] += iw_step - (c1 ? iw_wrap : 0);
+            oh_j[j] += d_oh + (c1 ? 1 : 0);
+            const bool c2 = oh_j[j] >= p.OH;
             oh_j[j] -= c2 ? p.OH : 0;
-            img_j[j] += d_img + c2;
+            ih_j[j] += ih_step + (c1 ? p.SH : 0) - (c2 ? ih_wrap : 0);
+            aoff_j[j] += cA + (c1 ? cB : 0u) + (c2 ? cC : 0u);
         }
     };
 
@@ -249,7 +267,12 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     a.n_ctiles = (a.Cout + WG_TILE - 1) / WG_TILE;
     // enough pixel chunks to fill the chip several times over, at least 8 slabs each
     const long long tiles = (long long)a.n_ktiles * a.n_ctiles;
-    long long chunks = (4096 + tiles - 1) / tiles;
+    // workgroups per launch = output tiles x pixel ranges.  Every workgroup ends with 128 x 128 f32 atomic adds, so the pixel split
+    // is paid in atomics: 4 096 workgroups (16 per CU) -> 1 024 (two rounds of the 512 resident ones) took the small layers'
+    // launches from 0.095 / 0.31 / 0.28 ms to 0.054 / 0.24 / 0.24 (the 512 x 512 gamma gradient stays at 0.89: it is bound by
+    // the L2 -> LDS fill of its 128 x 128 tiles, 16 KB per 64 MFMAs), the training step + 2 %.  SC2_WGRAD_WGS overrides (A/B).
+    static const int wg_target = [] { const char *e = getenv("SC2_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    long long chunks = (wg_target + tiles - 1) / tiles;
     long long rows = (M + chunks - 1) / chunks;
     rows = (rows + WG_SLAB - 1) / WG_SLAB * WG_SLAB;
     if (rows < 8 * WG_SLAB) rows = 8 * WG_SLAB;
