@@ -39,26 +39,38 @@ __global__ __launch_bounds__(256) void gdn_bwd_pre_kernel(const uint16_t *__rest
     const int pl = threadIdx.x / cpr;
     float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (pl < pix_per_iter) {
-        for (long long m = (long long)blockIdx.x * pix_per_iter + pl; m < M; m += (long long)gridDim.x * pix_per_iter) {
-            const long long o = m * C + cc * 8;
-            float g[8], xv[8], nv[8], dn[8], dd[8];
-            unpack8(*reinterpret_cast<const uint4 *>(gy + o), g);
-            unpack8(*reinterpret_cast<const uint4 *>(x + o), xv);
-            unpack8(*reinterpret_cast<const uint4 *>(norm + o), nv);
+        // two pixels per iteration: six 16-byte loads in flight per thread (the grid is a quarter of what it was, see the launcher)
+        const long long stride = (long long)gridDim.x * pix_per_iter;
+        for (long long m = (long long)blockIdx.x * pix_per_iter + pl; m < M; m += 2 * stride) {
+            const long long o0 = m * C + cc * 8;
+            const bool two = m + stride < M;
+            const long long o1 = two ? (m + stride) * C + cc * 8 : o0;
+            const uint4 rg[2] = {*reinterpret_cast<const uint4 *>(gy + o0), *reinterpret_cast<const uint4 *>(gy + o1)};
+            const uint4 rx[2] = {*reinterpret_cast<const uint4 *>(x + o0), *reinterpret_cast<const uint4 *>(x + o1)};
+            const uint4 rn[2] = {*reinterpret_cast<const uint4 *>(norm + o0), *reinterpret_cast<const uint4 *>(norm + o1)};
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                if (inverse) {
-                    dn[t] = g[t] * xv[t];
-                    dd[t] = g[t] * nv[t];
-                } else {
-                    const float r = 1.0f / nv[t];
-                    dd[t] = g[t] * r;
-                    dn[t] = -dd[t] * xv[t] * r;
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !two) break;
+                float g[8], xv[8], nv[8], dn[8], dd[8];
+                unpack8(rg[h], g);
+                unpack8(rx[h], xv);
+                unpack8(rn[h], nv);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (inverse) {
+                        dn[t] = g[t] * xv[t];
+                        dd[t] = g[t] * nv[t];
+                    } else {
+                        const float r = 1.0f / nv[t];
+                        dd[t] = g[t] * r;
+                        dn[t] = -dd[t] * xv[t] * r;
+                    }
+                    sum[t] += dn[t];
                 }
-                sum[t] += dn[t];
+                const long long o = h ? o1 : o0;
+                *reinterpret_cast<uint4 *>(d_norm + o) = pack8(dn);
+                *reinterpret_cast<uint4 *>(dx_direct + o) = pack8(dd);
             }
-            *reinterpret_cast<uint4 *>(d_norm + o) = pack8(dn);
-            *reinterpret_cast<uint4 *>(dx_direct + o) = pack8(dd);
         }
     }
     // combine the threads that share a channel chunk, then one atomic per channel per workgroup
@@ -104,7 +116,10 @@ extern "C" int sc2_gdn_bwd_pre(const void *gy, const void *x, const void *norm, 
     SC2_REQUIRE(e == hipSuccess, SC2_ERR_LAUNCH, "gdn_bwd_pre: memset failed: %s", hipGetErrorString(e));
     const int pix_per_iter = 256 / (C / 8);
     long long blocks = (M + pix_per_iter - 1) / pix_per_iter;
-    if (blocks > 4096) blocks = 4096;
+    // every workgroup ends with one f32 atomic per channel on the SAME C addresses: they serialise in L2 (~0.15 us each), so the
+    // launch cannot be shorter than (workgroups x that) -- with 4 096 workgroups the 48-channel layer (0.4 GB) took 0.61 ms, as
+    // long as layers ten times its size (kernel trace).  1 024 workgroups, two pixels per thread and iteration.
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(gdn_bwd_pre_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const uint16_t *>(gy),
                        static_cast<const uint16_t *>(x), static_cast<const uint16_t *>(norm), C, M, inverse,
                        static_cast<uint16_t *>(d_norm), static_cast<uint16_t *>(dx_direct), d_beta);
