@@ -27,6 +27,7 @@ class _Dgrad(object):
         self.stride, self.pad, self.k = conv.stride, conv.pad, conv.k
         self.w_folded = conv.w_folded
         self.as_conv = None
+        self._packed = {}      # strided layers: the packed sub-filters of hip.conv2d_dgrad, built at the first call (frozen weight)
         if conv.stride == (1, 1) and conv.dilation == (1, 1):
             wd = conv.w_folded.permute(1, 0, 2, 3).flip(2, 3).contiguous()
             self.as_conv = _Conv(ConvSpec(wd, (1, 1), (self.k[0] - 1 - self.pad[0], self.k[1] - 1 - self.pad[1])), None, tag)
@@ -34,7 +35,7 @@ class _Dgrad(object):
     def __call__(self, g, in_hw):
         if self.as_conv is not None:
             return self.as_conv(g, hip.EPI_BIAS)
-        return hip.conv2d_dgrad(g, self.w_folded, self.stride, self.pad, in_hw)
+        return hip.conv2d_dgrad(g, self.w_folded, self.stride, self.pad, in_hw, cache=self._packed)
 
 
 class FrozenStack(object):

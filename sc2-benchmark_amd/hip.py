@@ -369,13 +369,14 @@ def conv2d_wgrad(x_nhwc, gy_nhwc, kh, kw, stride, pad, x_abs=False):
     return dw.view(cout, kh, kw, Cin).permute(0, 3, 1, 2)
 
 
-def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16):
+def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16, cache=None):
     """Data gradient of y = conv2d(x, weight, stride, pad) on the forward implicit-GEMM kernel.
 
     gy_nhwc: bf16 [N,OH,OW,Cout]; weight: [Cout,Cin,KH,KW]; returns NHWC [N,H,W,Cin] (H, W = in_hw).
     A transposed convolution is, per stride-parity class (ih % s, iw % s), a stride-1 correlation of gy with the
     sub-filter of taps kh = r + s*t (r = (ih + p) % s), flipped; each class is one launch that scatters its rows
     to every s-th pixel of the gradient.  Stride 1 is the single-class case (full flip, pad k-1-p).
+    `cache`: a dict owned by the caller of a FROZEN weight -- the packed sub-filters are then built once, not per step.
     """
     cout, cin, KH, KW = weight.shape
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
@@ -403,14 +404,21 @@ def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16):
             pad_h, pad_w = len(khs) - 1 - qh, len(kws) - 1 - qw
             if pad_h < 0 or pad_w < 0:
                 raise Sc2Error('conv2d_dgrad: unsupported geometry k={} s={} p={}'.format((KH, KW), (sh, sw), (ph, pw)))
-            sub = wt[:, :, khs][:, :, :, kws].flip(2, 3).contiguous()      # taps in correlation order
-            packed = pack_conv_weight(sub)
+            win = (sh == 1 and sw == 1 and out_dtype == torch.bfloat16 and pad_h == pad_w and gy_nhwc.is_contiguous() and
+                   conv2x2_win_supported(tuple(gy_nhwc.shape), cin, len(khs), len(kws), 1, pad_h))
+            key = (ch, cw, win)
+            packed = cache.get(key) if cache is not None else None
+            if packed is None:
+                # (strided SLICES, not index lists: an index list is a host tensor copied to the device per call)
+                sub = wt[:, :, rh::sh, rw::sw].flip(2, 3).contiguous()      # taps in correlation order
+                packed = pack_conv2x2_win(sub) if win else pack_conv_weight(sub)
+                if cache is not None:
+                    cache[key] = packed
             if sh == 1 and sw == 1:
-                if (out_dtype == torch.bfloat16 and pad_h == pad_w and gy_nhwc.is_contiguous() and
-                        conv2x2_win_supported(tuple(gy_nhwc.shape), cin, len(khs), len(kws), 1, pad_h)):
+                if win:
                     # the decoder's last conv (256 -> 256, k2, p1): its data gradient is the k2 p0 conv of the first window-plane
                     # geometry (1.16 ms on the tile kernel at bs 256, 0.37 here)
-                    gx = conv2x2_win_fwd(gy_nhwc, pack_conv2x2_win(sub), pad_h, tag='dgrad')
+                    gx = conv2x2_win_fwd(gy_nhwc, packed, pad_h, tag='dgrad')
                     continue
                 conv2d_fwd(gy_nhwc, packed, cin, len(khs), len(kws), 1, (pad_h, pad_w), out_format=fmt, out=gx,
                            tag='dgrad')
