@@ -31,6 +31,15 @@ class _Dgrad(object):
         if conv.stride == (1, 1) and conv.dilation == (1, 1):
             wd = conv.w_folded.permute(1, 0, 2, 3).flip(2, 3).contiguous()
             self.as_conv = _Conv(ConvSpec(wd, (1, 1), (self.k[0] - 1 - self.pad[0], self.k[1] - 1 - self.pad[1])), None, tag)
+        # a 1x1 stride-2 layer (the downsample of a stage's first block): its input gradient lives on the even pixels only, where it
+        # is the stride-1 1x1 conv of g with the transposed weights -- `dense()`; the caller adds it into the other branch in place
+        self.as_dense = None
+        if tuple(conv.stride) == (2, 2) and tuple(self.k) == (1, 1) and tuple(self.pad) == (0, 0) and conv.dilation == (1, 1):
+            wd = conv.w_folded.permute(1, 0, 2, 3).contiguous()
+            self.as_dense = _Conv(ConvSpec(wd, (1, 1), (0, 0)), None, tag)
+
+    def dense(self, g):
+        return self.as_dense(g, hip.EPI_BIAS)
 
     def __call__(self, g, in_hw):
         if self.as_conv is not None:
@@ -88,7 +97,12 @@ class FrozenStack(object):
             g2 = hip.relu_bwd(d3(g, o2.shape[1:3]), o2)
             g1 = hip.relu_bwd(d2(g2, o1.shape[1:3]), o1)
             g_c1 = d1(g1, h.shape[1:3])
-            if dds is not None:
+            if dds is not None and dds.as_dense is not None:
+                # (was: scatter into a zero-filled map, then a full-size add -- three fills and 1.2 GB of traffic per block)
+                sub = dds.dense(g)
+                g_c1[:, ::2, ::2][:, :sub.shape[1], :sub.shape[2]].add_(sub)
+                g_a, g_b = g_c1, None
+            elif dds is not None:
                 g_a, g_b = g_c1 + dds(g, h.shape[1:3]), None
             else:
                 g_a, g_b = g_c1, g
