@@ -28,6 +28,8 @@
 //     are, as they stand, the operand fragments of the 1x1 GEMM over the channels;
 //   * epilogues: none, GDN1 / inverse GDN1 in the reference's operation order (norm = beta + acc; y = x * (1 / norm) resp.
 //     x * norm: compressai.layers.GDN1.forward), output f32 NHWC / f32 NCHW / int32 NCHW symbols round_half_even(acc - median).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "sc2_common.h"
@@ -423,6 +425,134 @@ __global__ __launch_bounds__(256, (NT * MT <= 6 ? SC2_F32_WAVES : SC2_F32_WAVES1
     }
 }
 
+// The first encoder stage of the reference-precision path as a PERSISTENT kernel: Conv2d(3 -> 96, k5, s2, p2) on the RGB planes +
+// GDN1(96), f32 NHWC out.  K is 7 steps (+ 6 of the norm GEMM): in the tile-per-workgroup form above a wave lives for 13 steps,
+// and prologue, first-load latency and epilogue of every 128 pixels leave the matrix pipe 35 % idle (PMC).  Here a workgroup
+// loads the conv's fragments (42 KB), gamma's (36 KB) and beta into LDS ONCE and its four waves walk 32-pixel tiles: the next
+// tile's 42 plane loads are issued when the conv phase has consumed the operand registers and land behind the 288 MFMAs of the
+// norm phase.  Same products in the same order as the tile form: bit-identical (`test_conv_f32_persist_equals_tile_form`).
+constexpr int P0_STEPS = 7, P0_NT = 6, P0_MT = 2;
+constexpr int P0_W_FRAGS = P0_STEPS * P0_NT * 64, P0_G_FRAGS = P0_NT * P0_NT * 64;   // 16-byte fragments
+
+template <bool INVERSE>
+__global__ __launch_bounds__(256, 2) void conv0_gdn_f32_persist_kernel(const F32Args p) {
+    extern __shared__ f4_t pl[];                     // [P0_W_FRAGS] conv, [P0_G_FRAGS] gamma, [24] beta
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    {
+        const f4_t *wsrc = reinterpret_cast<const f4_t *>(p.w), *gsrc = reinterpret_cast<const f4_t *>(p.ep_x);
+        for (int e = tid; e < P0_W_FRAGS; e += 256) pl[e] = wsrc[e];
+        for (int e = tid; e < P0_G_FRAGS; e += 256) pl[P0_W_FRAGS + e] = gsrc[e];
+        if (tid < 24) pl[P0_W_FRAGS + P0_G_FRAGS + tid] = reinterpret_cast<const f4_t *>(p.ep_beta)[tid];
+    }
+    __syncthreads();
+    const f32_desc_t rs_x = f32_make_desc(p.x, p.x_bytes);
+    const uint32_t plane_bytes = (uint32_t)(p.H * p.W) * 4u;
+    // this lane's tap of every step: k-quarter q of step s is tap 4 s + q (25 .. 27: padding, never in bounds)
+    uint32_t tap_off[P0_STEPS];
+    int tap_hw[P0_STEPS];
+#pragma unroll
+    for (int s = 0; s < P0_STEPS; ++s) {
+        const int tap = 4 * s + q, kh = tap / 5, kw = tap - kh * 5;
+        tap_off[s] = (uint32_t)((kh * p.W + kw) * 4);
+        tap_hw[s] = tap < 25 ? (kh | (kw << 16)) : (0x7FFF | (0x7FFF << 16));
+    }
+    const uint32_t ohw = (uint32_t)(p.OH * p.OW), M = (uint32_t)p.M;
+    const int n_tiles = (int)((p.M + 31) / 32), tile_step = gridDim.x * 4;
+    float a[P0_STEPS][P0_MT][3];
+    auto fetch = [&](int tile) {                     // 42 plane loads of this lane's two pixels (tile past the end: zeros)
+#pragma unroll
+        for (int mt = 0; mt < P0_MT; ++mt) {
+            const uint32_t m = (uint32_t)tile * 32u + (uint32_t)(mt * 16 + r);
+            const bool live = tile < n_tiles && m < M;
+            const uint32_t mm = live ? m : 0u;
+            const uint32_t n = mm / ohw, rem = mm - n * ohw, oh = rem / (uint32_t)p.OW, ow = rem - oh * (uint32_t)p.OW;
+            const int ih0 = live ? (int)oh * 2 - 2 : -(1 << 20), iw0 = (int)ow * 2 - 2;
+            const uint32_t base = (uint32_t)((((long long)n * 3 * p.H + ih0) * (long long)p.W + iw0) * 4);
+#pragma unroll
+            for (int s = 0; s < P0_STEPS; ++s) {
+                const int kh = tap_hw[s] & 0xFFFF, kw = tap_hw[s] >> 16;
+                const bool ok = ((unsigned)(ih0 + kh) < (unsigned)p.H) & ((unsigned)(iw0 + kw) < (unsigned)p.W);
+                const uint32_t vo = ok ? base + tap_off[s] : 0x80000000u;
+                f32_aload4(a[s][mt][0], rs_x, vo, 0u);
+                f32_aload4(a[s][mt][1], rs_x, vo, plane_bytes);
+                f32_aload4(a[s][mt][2], rs_x, vo, 2u * plane_bytes);
+            }
+        }
+    };
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;                     // (no barrier below)
+    fetch(tile);
+    for (; tile < n_tiles; tile += tile_step) {
+        f32_vm_wait<P0_MT * P0_NT>();                // in order: everything but the previous tile's stores
+#pragma unroll
+        for (int s = 0; s < P0_STEPS; ++s)
+#pragma unroll
+            for (int mt = 0; mt < P0_MT; ++mt) {
+                f32_tie(a[s][mt][0]);
+                f32_tie(a[s][mt][1]);
+                f32_tie(a[s][mt][2]);
+            }
+        f4_t acc[P0_MT][P0_NT], nrm[P0_MT][P0_NT];
+#pragma unroll
+        for (int mt = 0; mt < P0_MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < P0_NT; ++nt) acc[mt][nt] = nrm[mt][nt] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < P0_STEPS; ++s) {
+            f4_t b[P0_NT];
+#pragma unroll
+            for (int nt = 0; nt < P0_NT; ++nt) b[nt] = pl[(s * P0_NT + nt) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int mt = 0; mt < P0_MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < P0_NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt][j], a[s][mt][j], acc[mt][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(tile + tile_step);                     // the operand registers are free: the next tile's loads, behind the norm phase
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < P0_NT; ++s) {
+            f4_t g[P0_NT];
+#pragma unroll
+            for (int nt = 0; nt < P0_NT; ++nt) g[nt] = pl[P0_W_FRAGS + (s * P0_NT + nt) * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < P0_MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < P0_NT; ++nt)
+                        nrm[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[nt][j], fabsf(acc[mt][s][j]), nrm[mt][nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < P0_MT; ++mt) {
+            const uint32_t m = (uint32_t)tile * 32u + (uint32_t)(mt * 16 + r);
+#pragma unroll
+            for (int nt = 0; nt < P0_NT; ++nt) {
+                const f4_t bc = pl[P0_W_FRAGS + P0_G_FRAGS + nt * 4 + q];
+                f4_t v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float norm = nrm[mt][nt][i] + bc[i];
+                    if (!INVERSE) norm = 1.0f / norm;          // IEEE division, then one multiply, as GDN1.forward
+                    v[i] = acc[mt][nt][i] * norm;
+                }
+                float *dst = static_cast<float *>(p.y) + (long long)(m < M ? m : M - 1) * 96 + nt * 16 + 4 * q;
+                if (m < M) *reinterpret_cast<f4_t *>(dst) = v;
+            }
+        }
+    }
+    f32_vm_wait<0>();                                // (the loads of a tile past the end)
+}
+
+bool f32_persist0_enabled() {     // SC2_F32_PERSIST0=0: the tile form (A/B)
+    static const bool on = [] { const char *e = getenv("SC2_F32_PERSIST0"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int NT, int MT, bool FUSED = false>
 int launch_f32(const F32Args &a, int chunks, hipStream_t s) {
     const long long tiles = (a.M + (4 * MT * 16) - 1) / (4 * MT * 16);
@@ -521,6 +651,29 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
     // (measured: four row tiles per wave for the narrow chunks -- twice the MFMAs per operand load -- ran the 96 -> 48 k5 s2 conv
     //  in 2.89 ms instead of 2.38 at bs 256: fewer, fatter waves hide less of the operand latency; two row tiles everywhere)
     constexpr int MT48 = SC2_F32_MT4 ? 4 : 2;
+    if (fused && a.planar && d->Cout == 96 && d->KH == 5 && d->KW == 5 && d->stride_h == 2 && d->pad_h == 2 && d->out_format == SC2_OUT_F32_NHWC &&
+        f32_persist0_enabled()) {
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+        }
+        const size_t lds = (size_t)(P0_W_FRAGS + P0_G_FRAGS + 24) * 16;
+        const long long tiles = (a.M + 31) / 32;
+        int grid = n_cu * 2;
+        if ((long long)grid * 4 > tiles) grid = (int)((tiles + 3) / 4);
+        static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+        bool &attr_set = attr_set_dev[sc2_device_slot()];
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn_f32_persist_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn_f32_persist_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (d->epilogue == SC2_EPI_FUSED_IGDN) hipLaunchKernelGGL(conv0_gdn_f32_persist_kernel<true>, dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(conv0_gdn_f32_persist_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+        SC2_CHECK_LAUNCH();
+        return SC2_OK;
+    }
     if (fused) {
         if (cc == 32) return launch_f32<2, 2, true>(a, chunks, s);
         if (cc == 48) return launch_f32<3, MT48, true>(a, chunks, s);

@@ -182,6 +182,30 @@ def test_conv_f32_fused_gdn_equals_two_launches(S, R, dev, cin, cout, k, s, p, i
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('inverse', [False, True])
+@pytest.mark.parametrize('n,hw', [(3, (37, 50)), (2, (224, 224)), (1, (5, 7))])
+def test_conv_f32_persist_equals_tile_form(S, dev, n, hw, inverse):
+    """The persistent first stage (RGB planes read in place, weights + gamma + beta resident in LDS, a wave walks 32-pixel tiles:
+    `conv0_gdn_f32_persist_kernel`) against the tile-per-workgroup form on the NHWC copy of the same image: the same f32 products in
+    the same order -- BIT-IDENTICAL -- with ragged tile counts, odd map sizes and fewer tiles than waves."""
+    hip = S.hip
+    g = torch.Generator().manual_seed(n * 1000 + hw[0])
+    x = torch.randn(n, 3, hw[0], hw[1], generator=g).to(dev).contiguous()
+    w = (torch.randn(96, 3, 5, 5, generator=g) / 75 ** 0.5).to(dev)
+    gdn = S.GDN1(96, inverse=inverse).to(dev)
+    with torch.no_grad():
+        gdn.gamma.add_(0.02 * torch.rand(gdn.gamma.shape, generator=g).to(dev))
+    gdn._tag = 't'
+    gamma, beta = S.FPBasedResNetBottleneck()._f32_pack(gdn)
+    wf = hip.pack_conv_f32(w)
+    epi = hip.EPI_FUSED_IGDN if inverse else hip.EPI_FUSED_GDN
+    tile = hip.conv2d_f32_fwd(hip.nchw_f32_to_nhwc_f32(x), wf, 96, 5, 5, 2, 2, epilogue=epi, ep_x=gamma, ep_beta=beta, cin_real=3)
+    pers = hip.conv2d_f32_fwd(x, wf, 96, 5, 5, 2, 2, epilogue=epi, ep_x=gamma, ep_beta=beta, x_is_nchw_rgb=True)
+    assert pers.shape == tile.shape and torch.isfinite(pers).all()
+    assert torch.equal(pers, tile)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('cout', [64, 16, 80])
 def test_conv_f32_fused_gdn_refused_for_narrow_chunks(S, R, dev, cout):
     """the fused norm GEMM walks chunk / 16 gamma k-steps, gamma is packed with ceil(Cout / 16): for Cout 49..80 or
