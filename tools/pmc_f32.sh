@@ -9,7 +9,7 @@ for G in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_
   i=$((i+1))
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $G --output-format csv -d $ROOT/$OUT/g$i -o pmc -- python3 $ROOT/tools/f32_times.py > $ROOT/$OUT/g$i.log 2>&1)
 done
-python3 tools/pmc_mfma_parse.py $OUT 'enc.conv0+gdn1 f32|conv_f32_kernel<6, 2, true>|105.4' 'enc.conv2+gdn3 f32|conv_f32_kernel<3, 2, true>|188.7' 'enc.conv4 f32|conv_f32_kernel<2, 2, false>|7.1' > $OUT/mfma_busy.txt 2>&1
+python3 tools/pmc_mfma_parse.py $OUT 'enc.conv0+gdn1 f32 (persistent)|conv0_gdn_f32_persist_kernel|105.4' 'enc.conv0+gdn1 f32 (tile form)|conv_f32_kernel<6, 2, true>|105.4' 'enc.conv2+gdn3 f32|conv_f32_kernel<3, 2, true>|188.7' 'enc.conv4 f32|conv_f32_kernel<2, 2, false>|7.1' > $OUT/mfma_busy.txt 2>&1
 cat $OUT/mfma_busy.txt
 python3 - <<PY
 import csv,glob,collections
