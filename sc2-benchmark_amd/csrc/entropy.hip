@@ -163,26 +163,23 @@ __device__ __forceinline__ float eb_logits_bwd(float v, const float *__restrict_
 __global__ __launch_bounds__(EB_THREADS) void eb_backward_kernel(
     const float *__restrict__ y, const float *__restrict__ noise, const float *__restrict__ params, int C, int HW,
     int mode, float lik_bound, const float *__restrict__ g_yhat, const float *__restrict__ g_lik,
-    float *__restrict__ g_y, float *__restrict__ g_partial) {
-    const int plane = blockIdx.x;
-    const int c = plane % C;
+    float *__restrict__ g_y, float *__restrict__ g_partial, int planes_per_wg, int rows_per_plane) {
+    // One workgroup walks `planes_per_wg` WHOLE planes of one channel (images n0 .. n0 + planes_per_wg - 1): the 59
+    // parameter-gradient sums per thread end in 354 cross-lane shuffles + an LDS round, which with four elements per thread cost as
+    // much as the elements themselves (round 4: 0.85 ms per 256 x 24 x 55 x 55 launch with a workgroup per 1 024 elements, 0.66
+    // with one per plane).  The partial-sum rows the caller adds up keep their layout: this workgroup's sums go to the first row of
+    // its first plane, zeros to the other rows of its planes.
+    const int c = blockIdx.x % C, n0 = (blockIdx.x / C) * planes_per_wg;
     const float *P = params + c * SC2_EB_PARAM_STRIDE;
     const float med = P[58];
-    const long long base = (long long)plane * HW;
-    // The workgroup blockIdx.y == 0 of a plane walks the WHOLE plane (the others only zero their partial row, which the caller
-    // sums): the 59 parameter-gradient sums per thread end in 354 cross-lane shuffles + an LDS round, which with four elements per
-    // thread cost as much as the elements themselves (round 4: 0.85 ms per 256 x 24 x 55 x 55 launch).
-    if (blockIdx.y != 0) {
-        if (threadIdx.x < SC2_EB_PARAM_STRIDE)
-            g_partial[((long long)plane * gridDim.y + blockIdx.y) * SC2_EB_PARAM_STRIDE + threadIdx.x] = 0.f;
-        return;
-    }
     float G[SC2_EB_PARAM_STRIDE];
 #pragma unroll
     for (int k = 0; k < SC2_EB_PARAM_STRIDE; ++k) G[k] = 0.f;
     float g_med = 0.f;
 #pragma unroll 1
-    for (int pix = threadIdx.x; pix < HW; pix += EB_THREADS) {
+    for (int e = threadIdx.x; e < planes_per_wg * HW; e += EB_THREADS) {
+        const int pi = e / HW, pix = e - pi * HW;
+        const long long base = ((long long)(n0 + pi) * C + c) * HW;
         {
             const float v = y[base + pix];
             const float out = mode == SC2_EB_NOISE ? v + noise[base + pix] : rintf(v - med) + med;
@@ -222,13 +219,14 @@ __global__ __launch_bounds__(EB_THREADS) void eb_backward_kernel(
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < SC2_EB_PARAM_STRIDE) {
+    for (int q = threadIdx.x; q < planes_per_wg * rows_per_plane * SC2_EB_PARAM_STRIDE; q += EB_THREADS) {
+        const int pi = q / (rows_per_plane * SC2_EB_PARAM_STRIDE), rem = q - pi * (rows_per_plane * SC2_EB_PARAM_STRIDE);
         float s = 0.f;
-        if (threadIdx.x < 59) {
+        if (q < 59) {                        // (row 0 of the first plane: q = parameter index)
 #pragma unroll
-            for (int w = 0; w < EB_THREADS / 64; ++w) s += red[w][threadIdx.x];
+            for (int w = 0; w < EB_THREADS / 64; ++w) s += red[w][q];
         }
-        g_partial[((long long)plane * gridDim.y + blockIdx.y) * SC2_EB_PARAM_STRIDE + threadIdx.x] = s;
+        g_partial[((long long)(n0 + pi) * C + c) * rows_per_plane * SC2_EB_PARAM_STRIDE + rem] = s;
     }
 }
 
@@ -331,9 +329,11 @@ extern "C" int sc2_eb_backward(const float *y, const float *noise, const float *
     if (mode == SC2_EB_NOISE) SC2_REQUIRE(noise, SC2_ERR_INVALID_ARG, "eb_backward: noise mode needs the noise tensor");
     SC2_REQUIRE(n_partial == sc2_eb_bits_partial_len(N, C, HW), SC2_ERR_INVALID_ARG,
                 "eb_backward: n_partial %d != %d", n_partial, sc2_eb_bits_partial_len(N, C, HW));
-    dim3 grid(N * C, plane_grid_x(HW, EB_TILE));
+    int ppw = 8;                             // planes (images) per workgroup: a divisor of N that leaves >= 512 workgroups
+    while (ppw > 1 && (N % ppw != 0 || (long long)(N / ppw) * C < 512)) ppw >>= 1;
+    dim3 grid((N / ppw) * C, 1);
     hipLaunchKernelGGL(eb_backward_kernel, grid, dim3(EB_THREADS), 0, static_cast<hipStream_t>(stream), y, noise,
-                       params, C, HW, mode, lik_bound, g_yhat, g_lik, g_y, g_params_partial);
+                       params, C, HW, mode, lik_bound, g_yhat, g_lik, g_y, g_params_partial, ppw, plane_grid_x(HW, EB_TILE));
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
