@@ -91,39 +91,39 @@ __global__ __launch_bounds__(EB_THREADS) void eb_forward_kernel(
 // accumulated in registers over the thread's elements, reduced over the workgroup (wave shuffles, then LDS) and written
 // as one partial row per workgroup; the caller sums the partial rows of a channel.
 //   g_lik passes the likelihood lower bound by CompressAI's LowerBound rule (x >= bound or the gradient pushes x up).
-struct EbGrad {
-    float g[SC2_EB_PARAM_STRIDE];
+// (the forward of one evaluation with everything its backward needs: 12 tanh values, the three hidden vectors)
+struct EbEval {
+    float v, t0[3], h0[3], tl[3][3], hl[3][3];
 };
 
-__device__ __forceinline__ float eb_logits_bwd(float v, const float *__restrict__ P, float d_out, float *__restrict__ G,
-                                               bool want) {
-    // forward, keeping pre-activations and tanh values
-    float g0[3], t0[3], h0[3];
+__device__ __forceinline__ float eb_logits_keep(float v, const float *__restrict__ P, EbEval &e) {
+    e.v = v;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        g0[k] = P[k] * v + P[3 + k];
-        t0[k] = tanhf(g0[k]);
-        h0[k] = g0[k] + P[6 + k] * t0[k];
+        const float g0 = P[k] * v + P[3 + k];
+        e.t0[k] = tanhf(g0);
+        e.h0[k] = g0 + P[6 + k] * e.t0[k];
     }
-    float gl[3][3], tl[3][3], hl[3][3];
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
         const float *Q = P + 9 + 15 * l;
-        const float *hin = l == 0 ? h0 : hl[l - 1];
+        const float *hin = l == 0 ? e.h0 : e.hl[l - 1];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            gl[l][k] = Q[3 * k] * hin[0] + Q[3 * k + 1] * hin[1] + Q[3 * k + 2] * hin[2] + Q[9 + k];
-            tl[l][k] = tanhf(gl[l][k]);
-            hl[l][k] = gl[l][k] + Q[12 + k] * tl[l][k];
+            const float gl = Q[3 * k] * hin[0] + Q[3 * k + 1] * hin[1] + Q[3 * k + 2] * hin[2] + Q[9 + k];
+            e.tl[l][k] = tanhf(gl);
+            e.hl[l][k] = gl + Q[12 + k] * e.tl[l][k];
         }
     }
-    const float out = P[54] * hl[2][0] + P[55] * hl[2][1] + P[56] * hl[2][2] + P[57];
-    if (!want) return out;
-    // backward
+    return P[54] * e.hl[2][0] + P[55] * e.hl[2][1] + P[56] * e.hl[2][2] + P[57];
+}
+
+// backward of one kept evaluation: parameter gradients into G, returns d out / d v
+__device__ __forceinline__ float eb_logits_bwd_kept(const EbEval &e, const float *__restrict__ P, float d_out, float *__restrict__ G) {
     float dh[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        G[54 + j] += d_out * hl[2][j];
+        G[54 + j] += d_out * e.hl[2][j];
         dh[j] = d_out * P[54 + j];
     }
     G[57] += d_out;
@@ -131,12 +131,12 @@ __device__ __forceinline__ float eb_logits_bwd(float v, const float *__restrict_
     for (int l = 2; l >= 0; --l) {
         const float *Q = P + 9 + 15 * l;
         float *GQ = G + 9 + 15 * l;
-        const float *hin = l == 0 ? h0 : hl[l - 1];
+        const float *hin = l == 0 ? e.h0 : e.hl[l - 1];
         float dg[3], dhin[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            GQ[12 + k] += dh[k] * tl[l][k];
-            dg[k] = dh[k] * (1.0f + Q[12 + k] * (1.0f - tl[l][k] * tl[l][k]));
+            GQ[12 + k] += dh[k] * e.tl[l][k];
+            dg[k] = dh[k] * (1.0f + Q[12 + k] * (1.0f - e.tl[l][k] * e.tl[l][k]));
             GQ[9 + k] += dg[k];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -150,14 +150,13 @@ __device__ __forceinline__ float eb_logits_bwd(float v, const float *__restrict_
     float dv = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        G[6 + k] += dh[k] * t0[k];
-        const float dg = dh[k] * (1.0f + P[6 + k] * (1.0f - t0[k] * t0[k]));
+        G[6 + k] += dh[k] * e.t0[k];
+        const float dg = dh[k] * (1.0f + P[6 + k] * (1.0f - e.t0[k] * e.t0[k]));
         G[3 + k] += dg;
-        G[k] += dg * v;
+        G[k] += dg * e.v;
         dv += P[k] * dg;
     }
-    G[63] = dv;   // scratch slot: d out / d v of this evaluation
-    return out;
+    return dv;
 }
 
 __global__ __launch_bounds__(EB_THREADS) void eb_backward_kernel(
@@ -186,16 +185,16 @@ __global__ __launch_bounds__(EB_THREADS) void eb_backward_kernel(
             float d_total = g_yhat ? g_yhat[base + pix] : 0.f;
             if (g_lik) {
                 const float gl = g_lik[base + pix];
-                const float lower = eb_logits_bwd(out - 0.5f, P, 0.f, G, false);
-                const float upper = eb_logits_bwd(out + 0.5f, P, 0.f, G, false);
+                // (both evaluations are kept: their backward passes used to recompute them -- 24 of the element's 48 tanhf)
+                EbEval el, eu;
+                const float lower = eb_logits_keep(out - 0.5f, P, el);
+                const float upper = eb_logits_keep(out + 0.5f, P, eu);
                 const float su = sigmoidf_(upper), sl = sigmoidf_(lower);
                 const float raw = su - sl;
                 const float g_raw = (raw >= lik_bound || gl < 0.f) ? gl : 0.f;
                 if (g_raw != 0.f) {
-                    (void)eb_logits_bwd(out + 0.5f, P, g_raw * su * (1.0f - su), G, true);
-                    d_total += G[63];
-                    (void)eb_logits_bwd(out - 0.5f, P, -g_raw * sl * (1.0f - sl), G, true);
-                    d_total += G[63];
+                    d_total += eb_logits_bwd_kept(eu, P, g_raw * su * (1.0f - su), G);
+                    d_total += eb_logits_bwd_kept(el, P, -g_raw * sl * (1.0f - sl), G);
                 }
             }
             // noise mode: y_hat = y + u -> dy = d y_hat ; dequantize mode: y_hat = round(y - m) + m -> dy = 0, dm = d y_hat
