@@ -483,8 +483,9 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn_f32_persist_kernel(const F32
     int tile = blockIdx.x * 4 + wave;
     if (tile >= n_tiles) return;                     // (no barrier below)
     fetch(tile);
+    f32_vm_wait<0>();                                // (the first tile has no stores behind its loads: the counted wait below would let 12 LOADS stay out)
     for (; tile < n_tiles; tile += tile_step) {
-        f32_vm_wait<P0_MT * P0_NT>();                // in order: everything but the previous tile's stores
+        f32_vm_wait<P0_MT * P0_NT>();                // in order: everything but the previous tile's 12 stores, issued behind the loads
 #pragma unroll
         for (int s = 0; s < P0_STEPS; ++s)
 #pragma unroll
