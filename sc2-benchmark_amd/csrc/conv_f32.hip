@@ -541,6 +541,8 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn_f32_persist_kernel(const F32
                     if (!INVERSE) norm = 1.0f / norm;          // IEEE division, then one multiply, as GDN1.forward
                     v[i] = acc[mt][nt][i] * norm;
                 }
+                // (only the tensor's LAST tile has rows past the end, and it is its wave's last: a store the compiler branches around
+                //  there cannot make the counted wait of a following iteration too lax -- there is none)
                 float *dst = static_cast<float *>(p.y) + (long long)(m < M ? m : M - 1) * 96 + nt * 16 + 4 * q;
                 if (m < M) *reinterpret_cast<f4_t *>(dst) = v;
             }
