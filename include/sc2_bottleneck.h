@@ -182,7 +182,9 @@ int sc2_conv_f32_chunk_channels(int Cout);
  *          FUSED_GDN / FUSED_IGDN (Cout <= 96): the conv followed by GDN1 over its own output in one launch, `ep_x` = the
  *          effective gamma as the w_frag of a 1x1 conv Cout -> Cout (same packing), ep_beta = the effective beta; bit-identical
  *          to the two launches.
- * x      : f32 NHWC [N,H,W,Cin]
+ * x      : f32 NHWC [N,H,W,Cin]; addressed through a 32-bit buffer descriptor: N*H*W*Cin*4 (N*H*W*12 for the NCHW image) must be
+ *          below 0x7FF00000 bytes (SC2_ERR_UNSUPPORTED otherwise -- about 445 images of the 96-channel 112 x 112 map; the host side
+ *          runs larger batches as slices, `FPBasedResNetBottleneck._analysis_f32`)
  * w_frag : f32, [chunks][steps][NT][64 lanes][4] with cc = sc2_conv_f32_chunk_channels(Cout), NT = cc / 16, chunks =
  *          ceil(Cout / cc), steps = ceil(KH*KW*Cin / 16); entry (ch, s, nt, lane = q*16 + r, j) =
  *          W[ch*cc + nt*16 + r][k = 16 s + 4 q + j], k = (kh*KW + kw)*Cin + ci, zero beyond Cout / K.
@@ -424,7 +426,10 @@ int sc2_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *c
  *           their rows because rANS emits its words back to front)
  * out_stride must be >= sc2_rans_max_bytes(n_sym); out_stride % 4 == 0.
  * status  : i32 [n_streams] 0 ok; bit 0 = row overflow (cannot happen with sc2_rans_max_bytes); bit 1 = a symbol with
- *           |symbol - offset| >= 2^30 was clamped (non-finite / diverged latent).
+ *           |symbol - offset| >= 2^30 was clamped (non-finite / diverged latent); decoders only: bit 3 = corrupt, truncated or
+ *           hostile stream (an escape that announces more than the eight nibbles of a 32-bit value -- upstream's decoder
+ *           loops on such a count for ever -- or words read past the end of the stream, where zeros are supplied): the
+ *           decode always terminates, the symbols of a flagged stream are undefined.
  * workspace : device scratch of sc2_rans_workspace_bytes(n_streams, n_sym, n_cdfs, cdf_stride) bytes (the
  *             [position][lane] transposed intermediate of the multi-pass coder and the per-entry reciprocal
  *             table); contents undefined afterwards.

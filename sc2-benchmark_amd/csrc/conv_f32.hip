@@ -656,7 +656,8 @@ extern "C" int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const 
     constexpr int MT48 = SC2_F32_MT4 ? 4 : 2;
     if (fused && a.planar && d->Cout == 96 && d->KH == 5 && d->KW == 5 && d->stride_h == 2 && d->pad_h == 2 && d->out_format == SC2_OUT_F32_NHWC &&
         f32_persist0_enabled()) {
-        static int n_cu = 0;
+        static int n_cu_dev[SC2_MAX_DEVICES] = {};     // per device, as the function attributes below
+        int &n_cu = n_cu_dev[sc2_device_slot()];
         if (n_cu == 0) {
             int dev = 0, v = 0;
             n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;

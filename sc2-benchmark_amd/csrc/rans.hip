@@ -316,22 +316,35 @@ __device__ __forceinline__ unsigned dec_get_bits(DecState &d) {
     dec_renorm(d);
     return val;
 }
-__device__ __forceinline__ int dec_escape(DecState &d, int max_value) {
-    int val = (int)dec_get_bits(d);
-    int n_bypass = val;
-    while (val == kMaxBypassVal) {
-        val = (int)dec_get_bits(d);
-        n_bypass += val;
+// Status bit 3: a corrupt, truncated or hostile stream.  A value the encoder escapes is a 32-bit raw value, i.e. at most eight
+// nibbles, so its nibble count is ONE count digit <= 8: upstream's `while (val == 15)` continuation loop never runs on a stream
+// an encoder produced.  A decoder that trusts it spins for ever on a stream of 0xFF bytes (x = 2^64 - 1: every nibble is 0xF,
+// every renormalisation word is all ones); decompress() takes its bytes from the network in split computing, so anything but a
+// single digit <= 8 ends the escape here, flags the stream and codes the escape entry itself.  The same bit reports a stream
+// whose decoding read words past its end (zeros are supplied there).
+constexpr int kStatusCorrupt = 8;
+constexpr int kMaxEscapeNibbles = 8;
+
+template <class GetBits>
+__device__ __forceinline__ int decode_escape(GetBits &&get_bits, int max_value, int &corrupt) {
+    const int n_bypass = (int)get_bits();
+    if (n_bypass > kMaxEscapeNibbles) {
+        corrupt = kStatusCorrupt;
+        return max_value;
     }
     int raw_val = 0;
-    for (int j = 0; j < n_bypass; ++j) {
-        val = (int)dec_get_bits(d);
-        if (j < 8) raw_val |= val << (j * kBypassPrecision);   // a corrupt stream may announce more than 8 nibbles
-    }
+    for (int j = 0; j < n_bypass; ++j) raw_val |= (int)get_bits() << (j * kBypassPrecision);
     int value = raw_val >> 1;
     if (raw_val & 1) value = -value - 1;
     else value += max_value;
     return value;
+}
+__device__ __forceinline__ int dec_escape(DecState &d, int max_value, int &corrupt) {
+    return decode_escape([&]() { return dec_get_bits(d); }, max_value, corrupt);
+}
+// words of the stream consumed so far (the two look-ahead words are fetched, not consumed)
+__device__ __forceinline__ bool dec_past_end(const DecState &d, const uint32_t *w, int n_words) {
+    return (d.ptr - 2) - w > n_words;
 }
 
 constexpr int kWin = 32;   // stream words buffered per lane in LDS (ring)
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
     uint32_t *wsb = a.ws + (long long)blk * a.n_sym * 64 + lane;
     uint32_t *const wl = win + lane;
 
+    int corrupt = 0;   // kStatusCorrupt once an escape of this stream is malformed
     int lp = 0;   // words [0, lp) of this lane's stream have been copied into the ring
     int rp = 0;   // next unread word
     // every lane whose ring has >= 16 free slots takes its next 16 words (0 past the end) as four 16-byte loads: a lane's words
@@ -444,22 +458,7 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
             x = (unsigned long long)(sf >> 16) * (x >> kPrecision) + cum_freq - (sf & 0xFFFFu);
             renorm_slow();
             int value = sidx;
-            if (value == max_value) {
-                int val = get_bits();
-                int n_bypass = val;
-                while (val == kMaxBypassVal) {
-                    val = get_bits();
-                    n_bypass += val;
-                }
-                int raw_val = 0;
-                for (int j = 0; j < n_bypass; ++j) {
-                    val = get_bits();
-                    if (j < 8) raw_val |= val << (j * kBypassPrecision);   // corrupt stream: more than 8 nibbles
-                }
-                value = raw_val >> 1;
-                if (raw_val & 1) value = -value - 1;
-                else value += max_value;
-            }
+            if (value == max_value) value = decode_escape(get_bits, max_value, corrupt);
             wsb[pos * 64] = (uint32_t)(value + offset);
         };
 
@@ -501,7 +500,7 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
             i += U;
         }
     }
-    if (active) a.status[s] = 0;
+    if (active) a.status[s] = corrupt | (rp > n_words ? kStatusCorrupt : 0);
 }
 
 // parallel pass: symbols_out[s][i] = ws[blk][i][lane]
@@ -578,7 +577,9 @@ __global__ __launch_bounds__(64) void rans_dec_generic_kernel(const RansArgs a) 
     int32_t *out = a.symbols_out + (long long)s * a.n_sym;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)s * a.stride + a.io_offset[s]);
     DecState d;
-    dec_init(d, w, a.io_nbytes[s] / 4);
+    const int n_words = a.io_nbytes[s] / 4;
+    int corrupt = 0;
+    dec_init(d, w, n_words);
     for (long long i = 0; i < a.n_sym; ++i) {
         const int idx = idxp ? idxp[i] : (int)(i / a.index_div);
         const int32_t *cdf = tab + idx * a.cdf_stride;
@@ -596,10 +597,10 @@ __global__ __launch_bounds__(64) void rans_dec_generic_kernel(const RansArgs a) 
         d.x = (unsigned long long)freq * (d.x >> kPrecision) + cum_freq - start;
         dec_renorm(d);
         int value = sidx;
-        if (value == max_value) value = dec_escape(d, max_value);
+        if (value == max_value) value = dec_escape(d, max_value, corrupt);
         out[i] = value + a.offsets[idx];
     }
-    a.status[s] = 0;
+    a.status[s] = corrupt | (dec_past_end(d, w, n_words) ? kStatusCorrupt : 0);
 }
 
 // parallel pass: dst[blk][i][lane] = src[blk*64 + lane][i] (per-symbol indexes into the serial decoder's lane-contiguous
@@ -695,7 +696,9 @@ __global__ __launch_bounds__(64) void rans_dec_ragged_kernel(const RansArgs a) {
     const uint32_t *idxp = out;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)s * a.stride + a.io_offset[s]);
     DecState d;
-    dec_init(d, w, a.io_nbytes[s] / 4);
+    const int n_words = a.io_nbytes[s] / 4;
+    int corrupt = 0;
+    dec_init(d, w, n_words);
     constexpr int U = 8;
     int nxt[U];
 #pragma unroll
@@ -741,12 +744,12 @@ __global__ __launch_bounds__(64) void rans_dec_ragged_kernel(const RansArgs a) {
                 d.x = (unsigned long long)(next - start) * (d.x >> kPrecision) + cum_freq - start;
                 dec_renorm(d);
                 int value = sidx;
-                if (value == max_value) value = dec_escape(d, max_value);
+                if (value == max_value) value = dec_escape(d, max_value, corrupt);
                 out[(i0 + u) * 64] = (uint32_t)(value + l_off[idx]);
             }
         }
     }
-    a.status[s] = 0;
+    a.status[s] = corrupt | (dec_past_end(d, w, n_words) ? kStatusCorrupt : 0);
 }
 
 // Round 4: the same decoder (explicit per-symbol indexes over a ragged table, rows packed into LDS as u16), rebuilt around what
@@ -849,7 +852,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_dec_ragged2_kernel(const Rans
     uint32_t *const wl = win + sl;
 
     // ---- the stream-word ring of rans_dec_lut_kernel, one per stream; lane q of the quad moves words 4 q .. 4 q + 3 of a batch
-    int lp = 0, rp = 0;
+    int lp = 0, rp = 0, corrupt = 0;
     struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
     uint32_t pre[4];
     auto prefetch = [&]() {   // pre[] <- words [lp + 4 q, lp + 4 q + 4)
@@ -925,22 +928,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_dec_ragged2_kernel(const Rans
         x = (unsigned long long)(next - start) * (x >> kPrecision) + cum_freq - start;
         renorm_slow();
         int value = lo - 1;
-        if (value == max_value) {
-            int val = get_bits();
-            int n_bypass = val;
-            while (val == kMaxBypassVal) {
-                val = get_bits();
-                n_bypass += val;
-            }
-            int raw_val = 0;
-            for (int j = 0; j < n_bypass; ++j) {
-                val = get_bits();
-                if (j < 8) raw_val |= val << (j * kBypassPrecision);
-            }
-            value = raw_val >> 1;
-            if (raw_val & 1) value = -value - 1;
-            else value += max_value;
-        }
+        if (value == max_value) value = decode_escape(get_bits, max_value, corrupt);
         out[pos * 64] = (uint32_t)(value + l_off[idx]);   // (the four lanes store the same word)
     };
 
@@ -1007,7 +995,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_dec_ragged2_kernel(const Rans
             wq1 = ring(rp + 1);
         }
     }
-    if (active && q == 0) a.status[s] = 0;
+    if (active && q == 0) a.status[s] = corrupt | (rp > n_words ? kStatusCorrupt : 0);
 }
 
 int check_common(const int32_t *indexes, long long index_div, int n_streams, long long n_sym, const int32_t *cdfs,

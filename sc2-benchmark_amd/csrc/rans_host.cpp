@@ -128,7 +128,12 @@ void encode_stream(const sc2_rans_host_tables &t, const int32_t *sym, const int3
 struct Reader {
     const uint32_t *w, *end;
     uint64_t x;
-    inline uint32_t next() { return w < end ? *w++ : 0u; }     // a truncated stream decodes zeros, as on the device
+    bool past = false;    // a word was asked for past the end of the stream (status bit 3, as on the device)
+    inline uint32_t next() {      // a truncated stream decodes zeros, as on the device
+        if (w < end) return *w++;
+        past = true;
+        return 0u;
+    }
     // branch-free: whether a word is due is data-dependent (every ~32 / bits-per-symbol symbols) and a mispredicted branch
     // costs more than the whole step; both selects compile to conditional moves
     inline void renorm() {
@@ -137,6 +142,7 @@ struct Reader {
         const uint32_t *src = w < end ? w : &zero;
         const uint64_t refilled = (x << 32) | *src;
         x = need ? refilled : x;
+        past |= need & !(w < end);
         w += (need & (w < end)) ? 1 : 0;
     }
     inline uint32_t nibble() {
@@ -172,19 +178,20 @@ void decode_stream(const sc2_rans_host_tables &t, const uint8_t *in, int32_t nby
         rd.renorm();
         int32_t v = entry;
         if (entry == r.max_value) {
-            uint32_t d = rd.nibble();
-            int n_nib = (int)d;
-            while (d == kBypassMax && n_nib < 64) { d = rd.nibble(); n_nib += (int)d; }
-            uint32_t raw = 0;
-            for (int j = 0; j < n_nib; ++j) {
-                const uint32_t nb = rd.nibble();
-                if (j < 8) raw |= nb << (j * kBypassBits);
+            // the nibble count of a value an encoder escaped is ONE digit <= 8 (a 32-bit raw value); anything else is a corrupt
+            // or hostile stream: flagged (bit 3), coded as the escape entry itself -- the device decoders do the same
+            const int n_nib = (int)rd.nibble();
+            if (n_nib > 8) {
+                st |= 8;
+            } else {
+                uint32_t raw = 0;
+                for (int j = 0; j < n_nib; ++j) raw |= rd.nibble() << (j * kBypassBits);
+                v = (raw & 1u) ? -(int32_t)(raw >> 1) - 1 : (int32_t)(raw >> 1) + r.max_value;
             }
-            v = (raw & 1u) ? -(int32_t)(raw >> 1) - 1 : (int32_t)(raw >> 1) + r.max_value;
         }
         out[i] = v + r.offset;
     }
-    *status = st;
+    *status = st | (rd.past ? 8 : 0);
 }
 
 template <class F>

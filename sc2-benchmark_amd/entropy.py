@@ -80,12 +80,16 @@ def _status_or(st):
 def _raise_on_status(st, what):
     """rANS status per stream: bit 0 = the row overflowed its stride, bit 1 = a symbol lies outside the codable range
     (|symbol - offset| >= 2^30: a non-finite or diverged latent; upstream's nibble loop never terminates there), bit 2 = a
-    CDF-row index outside the table (host coder) / a stream that ran past its end while decoding."""
+    CDF-row index outside the table (host coder), bit 3 (decoders) = a corrupt, truncated or hostile stream: an escape that
+    announces more than eight nibbles (upstream's decoder never returns from one made of 0xFF bytes) or words read past the
+    end of the stream."""
     code = _status_or(st)
     if code & 2:
         raise ValueError('{}: a symbol is outside the codable range (non-finite or diverged latent)'.format(what))
     if code & 4:
-        raise ValueError('{}: a CDF-row index lies outside the table, or a stream is shorter than its symbols need'.format(what))
+        raise ValueError('{}: a CDF-row index lies outside the table'.format(what))
+    if code & 8:
+        raise ValueError('{}: a byte stream is corrupt or shorter than its symbols need'.format(what))
     if code:
         raise hip.Sc2Error('{}: rANS stream overflowed its maximum size'.format(what))
 
@@ -363,6 +367,21 @@ class _HostTablesMixin(object):
         state = dict(self.__dict__)
         state.pop('_host_tables_cache', None)
         return state
+
+    def _host_tables(self):
+        """Prepared tables of the library's host coder (csrc/rans_host.cpp), rebuilt when the integer tables changed."""
+        # keyed on (i) an explicit epoch that update() / load_state_dict() / .to() bump: the buffers are REPLACED by fresh tensors
+        # there (version 0 again, and the caching allocator hands the same address out), so pointer identity can hit a stale entry;
+        # (ii) the buffers' versions and shapes: an in-place write (`_quantized_cdf.copy_(...)` in a tool or a test) changes the
+        # tables without going through any of those entry points (ADVICE r4)
+        bufs = (self._quantized_cdf, self._offset, self._cdf_length)
+        key = (self.__dict__.get('_tables_epoch', 0), tuple(t._version for t in bufs), tuple(tuple(t.shape) for t in bufs))
+        cached = self.__dict__.get('_host_tables_cache')
+        if cached is None or cached[0] != key:
+            cdf, cdf_len, offset = self._tables()
+            cached = (key, hip.HostRansTables(cdf, cdf_len, offset))
+            self.__dict__['_host_tables_cache'] = cached
+        return cached[1]
 
 
 # --------------------------------------------------------------------------------------------- #
@@ -669,19 +688,6 @@ class EntropyBottleneck(_HostTablesMixin, nn.Module):
         host = buf.cpu().numpy()
         return [host[i, int(off_h[i]):int(off_h[i]) + int(nb_h[i])].tobytes() for i in range(host.shape[0])]
 
-    def _host_tables(self):
-        """Prepared tables of the library's host coder (csrc/rans_host.cpp), rebuilt when update() / load_state_dict() changed
-        the integer tables."""
-        # keyed on an explicit epoch that update() / load_state_dict() / .to() bump: the buffers are REPLACED by fresh tensors there
-        # (version 0 again, and the caching allocator hands the same address out), so pointer identity can hit a stale entry
-        key = self.__dict__.get('_tables_epoch', 0)
-        cached = self.__dict__.get('_host_tables_cache')
-        if cached is None or cached[0] != key:
-            cdf, cdf_len, offset = self._tables()
-            cached = (key, hip.HostRansTables(cdf, cdf_len, offset))
-            self.__dict__['_host_tables_cache'] = cached
-        return cached[1]
-
     def compress_symbols(self, sym, hw):
         """int32 symbols [N, C*hw] on the device -> list[bytes], one rANS stream per row.  Up to
         `hip.host_coder_max_streams()` streams (the reference's evaluation mode codes ONE per forward) go through the
@@ -738,13 +744,17 @@ class EntropyBottleneck(_HostTablesMixin, nn.Module):
         off = torch.zeros((n,), dtype=torch.int32, device=device)
         return buf, off, nb
 
-    def decompress_device(self, buf, off, nb, size, want_f32=True, want_nhwc=False):
-        """Device buffers -> (y_hat f32 NCHW or None, y_hat bf16 NHWC or None)."""
+    def decompress_device(self, buf, off, nb, size, want_f32=True, want_nhwc=False, check=False):
+        """Device buffers -> (y_hat f32 NCHW or None, y_hat bf16 NHWC or None).  `check`: read the decoder's status vector back
+        and raise on a corrupt / truncated stream (a host synchronisation: for bytes that arrived from outside, not for streams
+        this process has just encoded on the device)."""
         cdf, cdf_len, offset = self._tables()
         C = cdf.shape[0]
         hw = int(np.prod(size))
         N = buf.shape[0]
-        sym, _ = hip.rans_decode_batch(buf, off, nb, C * hw, cdf, cdf_len, offset, index_div=hw)
+        sym, st = hip.rans_decode_batch(buf, off, nb, C * hw, cdf, cdf_len, offset, index_div=hw)
+        if check:
+            _raise_on_status(st, 'EntropyBottleneck.decompress')
         return hip.eb_dequantize(sym.view(N, C, *size), self._median_vector(), want_f32=want_f32,
                                  want_nhwc=want_nhwc)
 
@@ -764,7 +774,7 @@ class EntropyBottleneck(_HostTablesMixin, nn.Module):
             return hip.eb_dequantize(sym.view(len(strings), C, *size), self._median_vector(), want_f32=want_f32,
                                      want_nhwc=want_nhwc)
         buf, off, nb = self.pack_strings(strings, dev)
-        return self.decompress_device(buf, off, nb, size, want_f32=want_f32, want_nhwc=want_nhwc)
+        return self.decompress_device(buf, off, nb, size, want_f32=want_f32, want_nhwc=want_nhwc, check=True)
 
     def decompress(self, strings, size):
         """list[bytes], spatial size -> f32 [N,C,*size] (EntropyBottleneck.decompress, layer.py:520)."""
@@ -924,17 +934,6 @@ class GaussianConditional(_HostTablesMixin, nn.Module):
         return hip.rans_encode_batch(sym.view(N, -1), cdf, cdf_len, offset,
                                      indexes=indexes.int().contiguous().view(N, -1), out_stride=out_stride)
 
-    def _host_tables(self):
-        # keyed on an explicit epoch that update() / load_state_dict() / .to() bump: the buffers are REPLACED by fresh tensors there
-        # (version 0 again, and the caching allocator hands the same address out), so pointer identity can hit a stale entry
-        key = self.__dict__.get('_tables_epoch', 0)
-        cached = self.__dict__.get('_host_tables_cache')
-        if cached is None or cached[0] != key:
-            cdf, cdf_len, offset = self._tables()
-            cached = (key, hip.HostRansTables(cdf, cdf_len, offset))
-            self.__dict__['_host_tables_cache'] = cached
-        return cached[1]
-
     def compress(self, inputs, indexes, means=None):
         """-> list[bytes], one rANS stream per batch item (EntropyModel.compress, layer.py:647,776).  A few streams go
         through the library's host coder (EntropyBottleneck.compress_symbols: why)."""
@@ -965,11 +964,14 @@ class GaussianConditional(_HostTablesMixin, nn.Module):
         tail = buf[:, stride - width:].contiguous().cpu().numpy()
         return [tail[i, width - int(nb_h[i]):].tobytes() for i in range(tail.shape[0])]
 
-    def decompress_device(self, buf, off, nb, indexes, means=None, want_f32=True, want_nhwc=False):
+    def decompress_device(self, buf, off, nb, indexes, means=None, want_f32=True, want_nhwc=False, check=False):
+        """`check`: as EntropyBottleneck.decompress_device (raise on a corrupt / truncated stream; synchronises)."""
         cdf, cdf_len, offset = self._tables()
         N = indexes.shape[0]
-        sym, _ = hip.rans_decode_batch(buf, off, nb, indexes[0].numel(), cdf, cdf_len, offset,
-                                       indexes=indexes.int().contiguous().view(N, -1))
+        sym, st = hip.rans_decode_batch(buf, off, nb, indexes[0].numel(), cdf, cdf_len, offset,
+                                        indexes=indexes.int().contiguous().view(N, -1))
+        if check:
+            _raise_on_status(st, 'GaussianConditional.decompress')
         return hip.gc_dequantize(sym.view(indexes.shape), None if means is None else means.float(), want_f32=want_f32,
                                  want_nhwc=want_nhwc)
 
@@ -999,7 +1001,7 @@ class GaussianConditional(_HostTablesMixin, nn.Module):
             return hip.gc_dequantize(sym.view(indexes.shape), None if means is None else means.float(), want_f32=want_f32,
                                      want_nhwc=want_nhwc)
         buf, off, nb = self.pack_strings(strings, dev)
-        return self.decompress_device(buf, off, nb, indexes, means, want_f32=want_f32, want_nhwc=want_nhwc)
+        return self.decompress_device(buf, off, nb, indexes, means, want_f32=want_f32, want_nhwc=want_nhwc, check=True)
 
 
 class _CpuReplica(object):

@@ -406,7 +406,9 @@ def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16, 
                 raise Sc2Error('conv2d_dgrad: unsupported geometry k={} s={} p={}'.format((KH, KW), (sh, sw), (ph, pw)))
             win = (sh == 1 and sw == 1 and out_dtype == torch.bfloat16 and pad_h == pad_w and gy_nhwc.is_contiguous() and
                    conv2x2_win_supported(tuple(gy_nhwc.shape), cin, len(khs), len(kws), 1, pad_h))
-            key = (ch, cw, win)
+            # (the packed sub-filters belong to THIS weight tensor at this version, stride and padding: a cache dict shared
+            #  between layers, or kept across an optimizer step, must miss -- ADVICE r4)
+            key = (ch, cw, win, weight.data_ptr(), weight._version, tuple(weight.shape), (sh, sw), (ph, pw))
             packed = cache.get(key) if cache is not None else None
             if packed is None:
                 # (strided SLICES, not index lists: an index list is a host tensor copied to the device per call)

@@ -197,6 +197,21 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         """encoder(x) with f32 operands (set_encoder_precision('f32')): every Conv2d / GDN1 of the analysis stack as one
         launch of sc2_conv2d_f32_fwd on f32 NHWC activations; the last conv writes the f32 NCHW latent or the symbols."""
         mods = list(self._g_a())
+        # sc2_conv2d_f32_fwd addresses activations through 32-bit buffer descriptors: every f32 tensor of a launch stays below
+        # 2 GB (include/sc2_bottleneck.h).  The widest map of the stack is the first stage's output (C0 x H/2 x W/2 floats per
+        # image: 4.8 MB at 224 x 224, i.e. ~445 images); larger batches run as slices of the batch (ADVICE r4)
+        if x.dim() == 4 and x.shape[0] > 1:
+            per_image = 4 * max(x.shape[1] * x.shape[2] * x.shape[3],
+                                max(getattr(m, 'out_channels', 0) for m in mods) * ((x.shape[2] + 1) // 2) * ((x.shape[3] + 1) // 2))
+            n_max = max(1, (0x7FF00000 - 1) // per_image)
+            if x.shape[0] > n_max:
+                parts = []
+                flat = None if out is None else out.view(x.shape[0], -1)
+                for i in range(0, x.shape[0], n_max):
+                    parts.append(self._analysis_f32(x[i:i + n_max].contiguous(), symbols_for=symbols_for,
+                                                    out=None if flat is None else flat[i:i + n_max]))
+                res = torch.cat(parts)
+                return res if out is None else out.view(res.shape)
         # an RGB image goes to the first convolution as it is (f32 NCHW, three planes read in place); anything else as f32 NHWC
         rgb_in_place = (x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32 and x.is_contiguous() and
                         isinstance(mods[0], nn.Conv2d) and mods[0].in_channels == 3)

@@ -1232,6 +1232,65 @@ def test_rans_lut_decoder_row_widths(S, dev, n_symbols_in_row):
     assert int(dst.max()) == 0 and np.array_equal(dec.cpu().numpy(), sym)
 
 
+def _hostile_rows(rng, n_rows, max_len):
+    rows, sizes, offs = [], [], []
+    for r in range(n_rows):
+        n = int(rng.randint(5, max_len))
+        p = rng.rand(n).astype(np.float32) ** 2 + 1e-4
+        p /= p.sum()
+        cdf = [int(v) for v in oracle_rans.pmf_to_quantized_cdf(p)]
+        rows.append(cdf)
+        sizes.append(len(cdf))
+        offs.append(-(n // 2))
+    return rows, sizes, offs
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize('path', ['lut (implicit indexes)', 'four lanes per stream (explicit indexes, rows in LDS)',
+                                  'explicit indexes, table too large for LDS'])
+def test_rans_decoders_terminate_on_hostile_streams(S, dev, path):
+    """decompress() takes its bytes from the network in split computing.  A stream of 0xFF bytes makes every
+    escape nibble 0xF and every renormalisation word all ones: upstream's `while (val == 15)` count loop -- and a decoder that
+    restates it -- never returns.  Every device decoder must terminate on (i) an all-0xFF stream, (ii) a valid stream cut short,
+    and report status bit 3 for both; valid streams in the same launch still decode exactly with status 0."""
+    rng = np.random.RandomState(11)
+    n_streams, n_sym = 70, 400
+    if path.startswith('lut'):
+        rows, sizes, offs = _hostile_rows(rng, 4, 30)
+        idx, div = None, 100
+    elif 'too large' in path:
+        rows, sizes, offs = _hostile_rows(rng, 64, 2400)
+        idx, div = rng.randint(0, 64, size=(n_streams, n_sym)).astype(np.int32), 0
+    else:
+        rows, sizes, offs = _hostile_rows(rng, 40, 600)
+        idx, div = rng.randint(0, 40, size=(n_streams, n_sym)).astype(np.int32), 0
+    cdfs, d_sizes, d_offs = _tables(dev, rows, sizes, offs)
+    row_of = idx if idx is not None else np.broadcast_to((np.arange(n_sym) // div).astype(np.int32), (n_streams, n_sym))
+    span = np.array(sizes)[row_of]
+    sym = ((rng.rand(n_streams, n_sym) * (span + 2) - 1).astype(np.int64) + np.array(offs)[row_of]).astype(np.int32)   # a few escapes
+    d_idx = None if idx is None else torch.from_numpy(idx).to(dev)
+    buf, off, nb, st = S.hip.rans_encode_batch(torch.from_numpy(sym).to(dev), cdfs, d_sizes, d_offs, indexes=d_idx, index_div=div,
+                                               out_stride=S.hip.rans_max_bytes(n_sym))
+    assert int(st.max()) == 0
+    buf, off, nb = buf.clone(), off.clone(), nb.clone()
+    # stream 3: every byte 0xFF (same length); stream 5: 0xFF for 4 KB (longer than any valid stream of this size);
+    # stream 9: cut to its first 16 bytes; stream 64 (second wave / block): cut to 8 bytes = the bare initial state
+    o3, n3 = int(off[3]), int(nb[3])
+    buf[3, o3:o3 + n3] = 255
+    buf[5, :] = 255
+    off[5], nb[5] = 0, buf.shape[1] // 4 * 4
+    nb[9] = 16
+    nb[64] = 8
+    dec, dst = S.hip.rans_decode_batch(buf, off, nb, n_sym, cdfs, d_sizes, d_offs, indexes=d_idx, index_div=div)
+    torch.cuda.synchronize()     # (the point of the test: this returns)
+    dst = dst.cpu().numpy()
+    bad = [3, 5, 9, 64]
+    assert all(dst[i] & 8 for i in bad), (path, dst[bad])
+    good = [i for i in range(n_streams) if i not in bad]
+    assert not dst[good].any(), path
+    assert np.array_equal(dec.cpu().numpy()[good], sym[good]), path
+
+
 @pytest.mark.parametrize('N,H,W,N2', [(8, 28, 28, 128), (3, 28, 28, 128), (1, 5, 7, 128), (16, 28, 28, 128), (5, 28, 28, 256),
                                         (1, 5, 7, 256)])
 def test_conv1x1_pair_equals_two_launches(S, dev, N, H, W, N2):

@@ -141,3 +141,19 @@ def test_many_streams_threaded(S):
     idx = (np.arange(200) // 50).astype(np.int32)
     assert all(strings[i] == oracle_rans.encode_with_indexes(sym[i], idx, cdf, sizes, offs) for i in range(13))
     assert np.array_equal(S.hip.rans_decode_host(tables, strings, 200, index_div=50)[0], sym)
+
+
+def test_host_decoder_terminates_on_hostile_streams(S):
+    """an all-0xFF stream (every escape nibble 0xF: upstream's count loop never ends) and a stream cut short both
+    decode to the end, flagged with status bit 3; the API raises on them."""
+    rng = np.random.RandomState(5)
+    cdf, sizes, offs = _random_tables(rng, 6, lo=6, hi=24)
+    tables = S.hip.HostRansTables(cdf, sizes, offs)
+    n_sym = 600
+    sym = np.round(rng.randn(3, n_sym) * 3).astype(np.int32)
+    strings, status = S.hip.rans_encode_host(tables, sym, index_div=100)
+    assert not status.any()
+    hostile = [b'\xff' * len(strings[0]), b'\xff' * 4096, strings[2][:16], strings[1]]
+    dec, status = S.hip.rans_decode_host(tables, hostile, n_sym, index_div=100)
+    assert all(int(status[i]) & 8 for i in range(3)) and int(status[3]) == 0
+    assert np.array_equal(dec[3], sym[1])
