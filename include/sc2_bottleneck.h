@@ -211,10 +211,17 @@ int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const 
  *   x_pairs : bf16 [N, H, W/2, 8] (two pixels x four channels, channel 3 zero: sc2_nchw_f32_to_nhwc_bf16 with c_pad 4)
  *   w_frag  : bf16 MFMA-fragment blocks [6][4][64][8] of the pair-packed weights W'[96][128], k = (kh*3 + t)*8 + dw*4 + c
  *   gamma_frag : bf16 fragment blocks [6][3][64][8] of the effective gamma;  beta : f32 [96]
- *   y : bf16 NHWC [N, OH, W/2, 96], OH = (H - 1)/2 + 1.   W/2 must be 112 (224-pixel-wide images). */
+ *   y : bf16 NHWC [N, OH, W/2, 96], OH = (H - 1)/2 + 1.   Any width: rows are cut into 112-pixel output segments. */
 int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs);
 int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N,
                         int H, int W_pairs, int inverse, void *stream);
+/* The same launch on the reference's own input: x_nchw = the f32 NCHW image batch [N, 3, H, W] that
+ * `FPBasedResNetBottleneck.encoder` receives (sc2bench/models/layer.py:496-498), read where it lies -- the three colour planes
+ * of a pixel pair are rounded to bf16 (round-to-nearest-even, as sc2_nchw_f32_to_nhwc_bf16 rounds) as the kernel stages them:
+ * bit-identical to sc2_nchw_f32_to_nhwc_bf16(c_pad 4) + sc2_conv0_gdn96_fwd without the layout pass.  W even (an odd width
+ * goes through the pair view, zero-padded by the caller); y : bf16 NHWC [N, OH, W/2, 96]. */
+int sc2_conv0_gdn96_nchw_fwd(const float *x_nchw, const void *w_frag, const void *gamma_frag, const float *beta, void *y,
+                             int N, int H, int W, int inverse, void *stream);
 
 /* 1x1 convolution with a long K and the weights resident in registers (conv1 + bn1 + ReLU and the stride-2 downsample of
  * the ResNet tail's layer3 / layer4 in eval mode, sc2bench/models/backbone.py:235-254): y = act(x W^T + bias).

@@ -19,14 +19,22 @@
 // width -- an output row is cut into segments of OW = 112 pixels (one segment for the 224-pixel-wide input; 513 x 513 ->
 // 257 = 112 + 112 + 33, 1216 -> 608 = 5 x 112 + 48), a unit is two output rows of one segment; an odd image width is
 // zero-padded to even by the caller (the zero column is what the convolution's own padding would read).
+// Round 5, PLANAR: the input is the reference's own f32 NCHW image batch, read where it lies -- a staged 16-byte chunk (pixel
+// pair x 4 channels) is three 8-byte loads, one per colour plane, rounded to bf16 (round-to-nearest-even, as
+// sc2_nchw_f32_to_nhwc_bf16 rounds) when the chunk is written to LDS: bit-identical to the layout pass + this kernel, without
+// the pass (0.09 ms and 257 MB per 256-image batch) and without the [N, H, W, 4] bf16 copy.  Even widths only.
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "sc2_common.h"
 
 #ifndef SC2_ENC0_ROWS_EARLY
 #define SC2_ENC0_ROWS_EARLY 1
+#endif
+#ifndef SC2_ENC0_PLANAR_EARLY
+#define SC2_ENC0_PLANAR_EARLY 2   // PLANAR: how many of a thread's IN_Q chunks are fetched in front of the GDN phase
 #endif
 #ifndef SC2_NT_ENC0
 #define SC2_NT_ENC0 1   // non-temporal output stores (sc2_common.h); 0: A/B
@@ -35,7 +43,7 @@
 namespace {
 
 struct EncArgs {
-    const uint16_t *__restrict__ x;      // bf16 [N, H, WP, 8] pixel pairs
+    const uint16_t *__restrict__ x;      // bf16 [N, H, WP, 8] pixel pairs; PLANAR: f32 [N, 3, H, 2 WP] (the NCHW image batch itself)
     const uint16_t *__restrict__ w;      // bf16 fragment-major [6][4][64][8]  (rows = 96 channels, K = 120 -> 128)
     const uint16_t *__restrict__ g;      // bf16 fragment-major gamma [6][3][64][8]
     const float *__restrict__ beta;      // f32 [96]
@@ -60,7 +68,7 @@ __device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f3
 }
 
 // SEG = false: one 112-pixel segment per row (the 224-pixel-wide geometry), the unit's output is one contiguous block
-template <bool INVERSE, bool SEG>
+template <bool INVERSE, bool SEG, bool PLANAR>
 __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *rows = smem;
@@ -77,32 +85,55 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
 
     // Global loads of the tail are written branch-free (clamped address + select) so that the compiler counts vmcnt
     // exactly: its wait for the rows is then vmcnt(<stores issued after them>) and never waits for a store.
-    uint4 in_next[IN_Q];
+    uint4 in_next[PLANAR ? 1 : IN_Q];
+    float2 in_pl[PLANAR ? IN_Q : 1][3];   // PLANAR: the chunk's pixel pair out of the three colour planes
     bool in_ok[IN_Q];
-    auto load_rows = [&](int unit, int tid) {   // the 7 input rows of `unit`, zero outside the image
+    auto load_rows = [&](int unit, int tid, auto k_lo, auto k_hi) {   // loads [k_lo, k_hi) of the 7 input rows of `unit`, zero outside the image
         const bool live = unit < p.n_units;
         const int im = live ? unit / p.units_per_img : 0;
         const int u_in = live ? unit - im * p.units_per_img : 0;
         const int rp = SEG ? u_in / p.n_seg : u_in, seg = SEG ? u_in - rp * p.n_seg : 0;
         const int oh0 = rp * 2;
         const uint16_t *ximg = p.x + (long long)im * p.H * p.WP * 8;
+        [[maybe_unused]] const float *fimg = reinterpret_cast<const float *>(p.x) + (long long)im * 3 * p.H * p.WP * 2;
+        [[maybe_unused]] const unsigned plane = (unsigned)(p.H * p.WP) * 8u;       // bytes of one colour plane
 #pragma unroll
-        for (int k = 0; k < IN_Q; ++k) {
+        for (int k = decltype(k_lo)::value; k < decltype(k_hi)::value; ++k) {
             const unsigned q = tid + 256 * k;
             const unsigned r = (q * 575u) >> 16, c = q - r * (OW + 2);      // q / 114 for q < 1100
             const int ih = 2 * oh0 - 2 + (int)r, pc = seg * OW + (int)c - 1;
             in_ok[k] = live & (q < IN_ROWS * (OW + 2)) & ((unsigned)ih < (unsigned)p.H) & ((unsigned)pc < (unsigned)p.WP);
-            const unsigned off = in_ok[k] ? (unsigned)(ih * p.WP + pc) * 16u : 0u;   // bytes within the image (< 2^31)
-            in_next[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(ximg) + off);
+            if constexpr (PLANAR) {
+                const unsigned off = in_ok[k] ? (unsigned)(ih * p.WP + pc) * 8u : 0u;   // bytes within a plane (3 planes < 2^31)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    in_pl[k][ch] = *reinterpret_cast<const float2 *>(reinterpret_cast<const unsigned char *>(fimg) + ch * plane + off);
+            } else {
+                const unsigned off = in_ok[k] ? (unsigned)(ih * p.WP + pc) * 16u : 0u;   // bytes within the image (< 2^31)
+                in_next[k] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(ximg) + off);
+            }
         }
     };
     auto store_rows = [&](int tid) {
+        // (PLANAR: the staged 16-byte chunk of a load = (pixel 0: c0 c1 c2 0)(pixel 1: c0 c1 c2 0), rounded to bf16 here)
+        uint4 ck[IN_Q];
+#pragma unroll
+        for (int k = 0; k < IN_Q; ++k) {
+            if constexpr (PLANAR) {
+                ck[k].x = pack2(f32x2_t{in_pl[k][0].x, in_pl[k][1].x});
+                ck[k].y = pack2(f32x2_t{in_pl[k][2].x, 0.f});
+                ck[k].z = pack2(f32x2_t{in_pl[k][0].y, in_pl[k][1].y});
+                ck[k].w = pack2(f32x2_t{in_pl[k][2].y, 0.f});
+            } else {
+                ck[k] = in_next[k];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < IN_Q; ++k) {
             const int q = tid + 256 * k;
             const bool inside = q < IN_ROWS * (OW + 2);       // k == IN_Q - 1: the others rewrite their previous chunk
             const int kk = k > 0 ? k - 1 : 0;
-            const uint4 v = inside ? in_next[k] : in_next[kk];
+            const uint4 v = inside ? ck[k] : ck[kk];
             const bool ok = inside ? in_ok[k] : in_ok[kk];
             *reinterpret_cast<uint4 *>(rows + (inside ? q : q - 256) * 16) = ok ? v : make_uint4(0u, 0u, 0u, 0u);
         }
@@ -123,7 +154,9 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
 
     int unit = blockIdx.x;
     int next_unit = unit + gridDim.x;
-    load_rows(unit, tid);
+    using K0 = std::integral_constant<int, 0>;
+    using KN = std::integral_constant<int, IN_Q>;
+    load_rows(unit, tid, K0{}, KN{});
     store_rows(tid);
     __syncthreads();
 
@@ -173,8 +206,11 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
         // the NEXT unit's seven rows are fetched here, in front of the GDN phase, instead of directly in front of this unit's
         // output stores (round 4: loads queued in front of a store burst delay it; conv2x2_gdn512 gained 5 % from the same move).
         // (The segmented-row instantiations keep the late fetch: with it here the forward one spilled.)
-        constexpr bool ROWS_EARLY = SC2_ENC0_ROWS_EARLY && !SEG;
-        if constexpr (ROWS_EARLY) load_rows(next_unit, tid);
+        // (PLANAR: a chunk is three 8-byte loads = 24 registers in flight instead of 16, which spilled: half of them go early,
+        //  the other half stay directly in front of the output stores)
+        constexpr int K_EARLY = (SC2_ENC0_ROWS_EARLY && !SEG) ? (PLANAR ? SC2_ENC0_PLANAR_EARLY : IN_Q) : 0;
+        using KE = std::integral_constant<int, K_EARLY>;
+        load_rows(next_unit, tid, K0{}, KE{});
 
         // ---------------------------------------------------------------- GDN1: norm = beta + gamma |t|
         // two passes over the pixel tiles (4 + 3): half the norm accumulators live at a time, and a pass's results may
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
             const unsigned one = 1u;
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(claimed) : "v"(p.unit_ctr), "v"(one) : "memory");
         }
-        if constexpr (!ROWS_EARLY) load_rows(next_unit, tq);
+        load_rows(next_unit, tq, KE{}, KN{});
         {
             if constexpr (!SEG) {
                 uint4 *yo = reinterpret_cast<uint4 *>(p.y + ((long long)(im * p.OH + oh0) * OW) * CH);   // contiguous 2 rows
@@ -285,8 +321,8 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
     }
 }
 
-int g_cus0 = 0;
 constexpr int kMaxDev0 = 16, kRing0 = 256;
+int g_cus0[kMaxDev0] = {};
 unsigned *g_ring0[kMaxDev0] = {};
 std::atomic<unsigned> g_seq0{0};
 
@@ -296,15 +332,18 @@ extern "C" int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs) {
     return Cin_pairs == 8 && Cout == 96 && W_pairs >= 1 ? 1 : 0;
 }
 
-extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta,
-                                   void *y, int N, int H, int W_pairs, int inverse, void *stream) {
-    SC2_REQUIRE(x_pairs && w_frag && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "conv0_gdn96: null argument");
+namespace {
+template <bool PLANAR>
+int launch_conv0_gdn96(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N, int H,
+                       int W_pairs, int inverse, void *stream) {
+    SC2_REQUIRE(x && w_frag && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "conv0_gdn96: null argument");
     SC2_REQUIRE(N > 0 && H > 0, SC2_ERR_INVALID_ARG, "conv0_gdn96: non-positive dimension");
     SC2_REQUIRE(sc2_conv0_gdn96_supported(8, 96, W_pairs), SC2_ERR_UNSUPPORTED,
                 "conv0_gdn96: needs at least one pixel pair per row, got %d", W_pairs);
-    SC2_REQUIRE((long long)H * W_pairs * 16 < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv0_gdn96: image too large");
+    // (per-image byte offsets are 32-bit: the pair view is 16 B per pair, the f32 planes 3 x 8 B per pair)
+    SC2_REQUIRE((long long)H * W_pairs * (PLANAR ? 24 : 16) < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv0_gdn96: image too large");
     EncArgs a;
-    a.x = static_cast<const uint16_t *>(x_pairs);
+    a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(w_frag);
     a.g = static_cast<const uint16_t *>(gamma_frag);
     a.beta = beta;
@@ -321,23 +360,23 @@ extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, cons
     static bool attr_set_dev[SC2_MAX_DEVICES] = {};
     bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, false, PLANAR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, false, PLANAR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, true, PLANAR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, true, PLANAR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     int dev = 0;
     (void)hipGetDevice(&dev);
     SC2_REQUIRE(dev >= 0 && dev < kMaxDev0, SC2_ERR_UNSUPPORTED, "conv0_gdn96: device ordinal %d out of range", dev);
-    if (g_cus0 == 0) {
+    if (g_cus0[dev] == 0) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_cus0 = n;
+        g_cus0[dev] = n;
     }
     if (!g_ring0[dev]) {
         void *ptr = nullptr;
@@ -347,13 +386,26 @@ extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, cons
                     "conv0_gdn96: cannot clear the unit counters");
         g_ring0[dev] = static_cast<unsigned *>(ptr);
     }
-    const int grid = a.n_units < 2 * g_cus0 ? a.n_units : 2 * g_cus0;   // two workgroups per CU
+    const int grid = a.n_units < 2 * g_cus0[dev] ? a.n_units : 2 * g_cus0[dev];   // two workgroups per CU
     a.unit_ctr = g_ring0[dev] + (g_seq0.fetch_add(1) % kRing0);
     const bool seg = W_pairs != OW;
-    if (inverse && seg) hipLaunchKernelGGL((conv0_gdn96_kernel<true, true>), dim3(grid), dim3(256), lds, s, a);
-    else if (inverse) hipLaunchKernelGGL((conv0_gdn96_kernel<true, false>), dim3(grid), dim3(256), lds, s, a);
-    else if (seg) hipLaunchKernelGGL((conv0_gdn96_kernel<false, true>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv0_gdn96_kernel<false, false>), dim3(grid), dim3(256), lds, s, a);
+    if (inverse && seg) hipLaunchKernelGGL((conv0_gdn96_kernel<true, true, PLANAR>), dim3(grid), dim3(256), lds, s, a);
+    else if (inverse) hipLaunchKernelGGL((conv0_gdn96_kernel<true, false, PLANAR>), dim3(grid), dim3(256), lds, s, a);
+    else if (seg) hipLaunchKernelGGL((conv0_gdn96_kernel<false, true, PLANAR>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv0_gdn96_kernel<false, false, PLANAR>), dim3(grid), dim3(256), lds, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
+}
+}  // namespace
+
+extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta,
+                                   void *y, int N, int H, int W_pairs, int inverse, void *stream) {
+    return launch_conv0_gdn96<false>(x_pairs, w_frag, gamma_frag, beta, y, N, H, W_pairs, inverse, stream);
+}
+
+extern "C" int sc2_conv0_gdn96_nchw_fwd(const float *x_nchw, const void *w_frag, const void *gamma_frag, const float *beta,
+                                        void *y, int N, int H, int W, int inverse, void *stream) {
+    SC2_REQUIRE(W > 0 && W % 2 == 0, SC2_ERR_UNSUPPORTED,
+                "conv0_gdn96_nchw: even widths only (got %d): a row of an odd-width plane does not start on a pixel pair", W);
+    return launch_conv0_gdn96<true>(x_nchw, w_frag, gamma_frag, beta, y, N, H, W / 2, inverse, stream);
 }

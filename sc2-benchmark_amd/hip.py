@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv1x1_pair_supported', 'sc2_conv1x1_pair_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv0_gdn96_nchw_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -79,6 +79,7 @@ def lib():
     L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_conv0_gdn96_supported.argtypes = [i32, i32, i32]
     L.sc2_conv0_gdn96_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.sc2_conv0_gdn96_nchw_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_kres_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3_win_supported.argtypes = [i32, i32, i32, i32]
@@ -522,6 +523,24 @@ def conv0_gdn96_fwd(x_pairs, w_frag, gamma_frag, beta, inverse=False, tag=None):
     with _timed(tag or 'conv0_gdn96'):
         _check(lib().sc2_conv0_gdn96_fwd(_ptr(x_pairs), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, WP,
                                          1 if inverse else 0, _stream()), 'conv0_gdn96_fwd')
+    return out
+
+
+def conv0_gdn96_nchw_fwd(x_nchw, w_frag, gamma_frag, beta, inverse=False, tag=None):
+    """The same launch on the f32 NCHW image batch [N,3,H,W] itself (W even): the colour planes are read in place and rounded
+    to bf16 as they are staged -- no layout pass, bit-identical to nchw_f32_to_nhwc_bf16(x, 4) + conv0_gdn96_fwd."""
+    for t, name in ((x_nchw, 'x_nchw'), (w_frag, 'w_frag'), (gamma_frag, 'gamma_frag'), (beta, 'beta')):
+        _dev(t, name)
+    assert x_nchw.dtype == torch.float32 and x_nchw.dim() == 4 and x_nchw.is_contiguous() and x_nchw.shape[1] == 3
+    N, _, H, W = x_nchw.shape
+    assert W % 2 == 0
+    assert w_frag.dtype == torch.bfloat16 and w_frag.is_contiguous() and tuple(w_frag.shape) == (6, 4, 64, 8)
+    assert gamma_frag.dtype == torch.bfloat16 and gamma_frag.is_contiguous() and tuple(gamma_frag.shape) == (6, 3, 64, 8)
+    assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 96
+    out = torch.empty((N, (H - 1) // 2 + 1, W // 2, 96), dtype=torch.bfloat16, device=x_nchw.device)
+    with _timed(tag or 'conv0_gdn96'):
+        _check(lib().sc2_conv0_gdn96_nchw_fwd(_ptr(x_nchw), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, W,
+                                              1 if inverse else 0, _stream()), 'conv0_gdn96_nchw_fwd')
     return out
 
 

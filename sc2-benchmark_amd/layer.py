@@ -129,6 +129,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         self.output_format = 'f32_nchw'
         self.fuse_gdn = True    # conv + GDN1 in one launch where one tile holds all output channels
         self.encoder_precision = 'bf16'   # 'f32': reference-precision analysis transform (set_encoder_precision)
+        self.conv0_reads_nchw = True      # bf16 encoder: the first stage reads the f32 NCHW planes in place (False: A/B, layout pass)
         self._conv0_pack = None
         self._conv0_key = None
 
@@ -274,12 +275,24 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         fuse0 = self.fuse_gdn and c0.out_channels in hip.FUSABLE_GDN_CHANNELS
         fuse2 = self.fuse_gdn and c2.out_channels in hip.FUSABLE_GDN_CHANNELS
         if self._uses_pair_conv0(x):
-            if x.shape[-1] % 2:      # odd width (513): one zero column, exactly what the conv's own padding would read
-                x = torch.nn.functional.pad(x, (0, 1))
             N, _, H, W = x.shape
-            x4 = hip.nchw_f32_to_nhwc_bf16(x, 4)                      # [N,H,W,4]
-            xp = x4.view(N, H, W // 2, 8)                             # pixel pairs
-            if fuse0 and g1.in_channels == 96 and hip.conv0_gdn96_supported(tuple(xp.shape), c0.out_channels):
+            in_place = (fuse0 and g1.in_channels == 96 and W % 2 == 0 and x.shape[1] == 3 and self.conv0_reads_nchw and
+                        hip.conv0_gdn96_supported((N, H, W // 2, 8), c0.out_channels))
+            if in_place:
+                # the RGB batch goes to the first stage as it is (f32 NCHW, the reference's input layout): the kernel rounds the
+                # three colour planes to bf16 as it stages them -- no layout launch, no [N,H,W,4] copy
+                beta, gamma_f = g1.effective_fragments()
+                h = hip.conv0_gdn96_nchw_fwd(x.contiguous(), self._conv0_fragments(), gamma_f, beta, g1.inverse,
+                                             tag=c0._tag + '+' + g1._tag)
+            else:
+                if x.shape[-1] % 2:      # odd width (513): one zero column, exactly what the conv's own padding would read
+                    x = torch.nn.functional.pad(x, (0, 1))
+                    N, _, H, W = x.shape
+                x4 = hip.nchw_f32_to_nhwc_bf16(x, 4)                      # [N,H,W,4]
+                xp = x4.view(N, H, W // 2, 8)                             # pixel pairs
+            if in_place:
+                pass
+            elif fuse0 and g1.in_channels == 96 and hip.conv0_gdn96_supported(tuple(xp.shape), c0.out_channels):
                 beta, gamma_f = g1.effective_fragments()   # conv + GDN1(96) as one persistent streaming launch
                 h = hip.conv0_gdn96_fwd(xp, self._conv0_fragments(), gamma_f, beta, g1.inverse,
                                         tag=c0._tag + '+' + g1._tag)

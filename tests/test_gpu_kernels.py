@@ -481,6 +481,12 @@ def test_conv0_gdn96_fused(S, R, dev, N, H, W, inverse):
     tile = S.hip.conv2d_fwd(xp, packed, 96, 5, 3, (2, 1), (2, 1), epilogue=S.hip.EPI_FUSED_IGDN if inverse else
                             S.hip.EPI_FUSED_GDN, ep_x=gamma_d, ep_beta=beta_d)
     assert_close_bf16(out, tile, 'persistent vs tile kernel', extra=2.0 ** -7)
+    # round 5: the same launch on the f32 NCHW batch itself (colour planes read in place, rounded to bf16 while staged): the
+    # layout pass and the pair view disappear, the result does not change by a bit
+    in_place = S.hip.conv0_gdn96_nchw_fwd(x.to(dev), S.hip.pack_weight_fragments(packed[:96]), gamma_f, beta_d, inverse)
+    assert torch.equal(in_place, out), 'planes read in place != layout pass + pair view'
+    again = S.hip.conv0_gdn96_nchw_fwd(x.to(dev), S.hip.pack_weight_fragments(packed[:96]), gamma_f, beta_d, inverse)
+    assert torch.equal(again, out)     # (the unit counter re-arms itself: a second launch claims the same units)
 
 
 @pytest.mark.parametrize('N,H,inverse', [(3, 112, False), (2, 30, False), (300, 3, False), (5, 9, True)])

@@ -56,6 +56,7 @@ def main():
         wf0 = m._conv0_fragments()
         a1 = hip.conv0_gdn96_fwd(xp, wf0, gamma_g1, beta_g1)
         row('enc.conv0+gdn96', lambda: hip.conv0_gdn96_fwd(xp, wf0, gamma_g1, beta_g1), (180.6e6 + 231.2e6) * N)
+        row('enc.conv0+gdn96 (nchw in place)', lambda: hip.conv0_gdn96_nchw_fwd(x, wf0, gamma_g1, beta_g1), (180.6e6 + 231.2e6) * N)
         beta_g3, gamma_g3 = g3.effective()
         wq48 = e2.packed_weight(hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR)
         gf48 = hip.pack_weight_fragments(gamma_g3)
