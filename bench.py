@@ -1,6 +1,6 @@
 """bench.py -- images/s + bpp of the Entropic-Student ResNet-50 (FP bottleneck 24ch) at 224x224 on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--bs 256] [--inflight D]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--bs 256]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -9,15 +9,17 @@ reference's evaluation mode after update() (sc2bench/models/backbone.py:229-233)
     encoder (3 MFMA convs + 2 GDN1) -> symbols -> rANS encode (one stream per image) -> rANS decode ->
     dequantise -> decoder (3 MFMA convs + 2 inverse GDN1) -> ResNet-50 layer2..fc -> logits.
 Nothing is skipped: the byte streams are really produced and really decoded; bpp is 8 * bytes / pixels.
-Steps are software-pipelined over HIP streams: the encoder stage on one stream, decoder + head on a second, and the serial
-range coder on four coder streams, ONE coder launch per 8 steps (8 x 256 image streams encoded, then decoded, by the same
-two serial kernels: their ~20 ms are per-stream latency, not work, and do not grow with the number of streams).  Measured:
-a long-running kernel on another hardware queue slows every MFMA launch of the pipeline, even a single-thread spin
-kernel (6.3 ms per step without the coder, 7.1 ms with spin kernels in its place, 7.9 ms with one coder chain per step,
-6.7 ms with one per 8 steps; `--diag-skip-coder`, tools/diag_coder.sh), so fewer, wider coder launches win.  Exactly K
-steps start and complete inside the timed region, bracketed by barrier + synchronize, so the region carries one fill and
-drain of that pipeline; the wall time is the max over ranks.  One process per GPU; the path shards by image, so
-N GPUs = N independent shards, no data-path collective ("weak" scaling, bs per GPU fixed).
+Steps run on the PACKAGE's stage pipeline (sc2bench_amd/pipeline.py, `StagePipeline` -- the scheduler
+`evaluation.evaluate()` uses on a data loader): the encoder stage on one HIP stream, decoder + head on a second, and the
+serial range coder on four coder streams, ONE coder launch per 8 steps (8 x 256 image streams encoded, then decoded, by the
+same two serial kernels: their ~20 ms are per-stream latency, not work, and do not grow with the number of streams).
+Measured: a long-running kernel on another hardware queue slows every MFMA launch of the pipeline, even a single-thread
+spin kernel (6.3 ms per step without the coder, 7.1 ms with spin kernels in its place, 7.9 ms with one coder chain per
+step, 6.7 ms with one per 8 steps: DESIGN.md section 6), so fewer, wider coder launches win.  Exactly K steps start and
+complete inside the timed region, bracketed by barrier + synchronize, so the region carries one fill and drain of that
+pipeline; the wall time is the max over ranks.  One process per GPU; the path shards by image, so N GPUs = N independent
+shards, no data-path collective ("weak" scaling, bs per GPU fixed).  `--workload mshp224 | seg513 | det800x1216 |
+fp_input` run the other configs' models through the same pipeline class.
 
 Prints ONE JSON line (rank 0) with the contract keys plus `roofline` (dominant MFMA kernel, HIP events on
 its own stream, inside the timed region) and `cpu_baseline` (the oracle = CPU port of the same path, timed on
@@ -45,13 +47,20 @@ PEAK_F32_MATRIX_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 (f32 operands): 1/16 of
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy achieves
 # per image, 224x224: algorithmic MFLOP (2 * MACs), bf16 activation MB read, MB written.  Weights
 # (< 2.6 MB in total, L2-resident) are not counted.
-OPS = {'enc.conv0': (180.6, 0.401, 2.408), 'enc.gdn1': (231.2, 2.408, 2.408), 'enc.conv2': (722.5, 2.408, 0.301),
+OPS = {'enc.conv0': (180.6, 0.602, 2.408), 'enc.gdn1': (231.2, 2.408, 2.408), 'enc.conv2': (722.5, 2.408, 0.301),
        'enc.gdn3': (14.5, 0.301, 0.301), 'enc.conv4': (27.9, 0.301, 0.290), 'dec.conv0': (308.3, 0.145, 3.211),
        'dec.igdn1': (1644.2, 3.211, 3.211), 'dec.conv2': (3171.9, 3.211, 1.549), 'dec.igdn3': (396.5, 1.549, 1.549),
        'dec.conv4': (1644.2, 1.549, 1.606),
        # layer2.0's conv1 (256 -> 128) and downsample (256 -> 512, stride 2) when the decoder's last launch takes them along
        # ('dec.conv4+head.2.0'): they read that launch's output tile from LDS and write 56*56*128 + 28*28*512 bf16
-       'head.2.0': (411.0, 0.0, 1.606)}
+       'head.2.0': (411.0, 0.0, 1.606),
+       # EntropyModel.dequantize (layer.py:520) = the last pass of the coder's decode launch (rans_dec_finish_dq_kernel): reads
+       # the [position][lane] int32 intermediate (72 600 x 4 B), writes the bf16 NHWC latent (72 600 x 2 B); timed by its own
+       # event pair (sc2_rans_decode_dequantize_batch_ev); one launch covers every stream of its coder group
+       'dec.dequantize': (0.0, 0.2904, 0.1452),
+       # round 4's layout pass in front of the first encoder stage (f32 NCHW -> bf16 [N,H,W,4]); since round 5 the first stage
+       # reads the f32 planes in place (enc.conv0's 0.602 MB) and this launch only exists with --conv0-layout-pass (A/B)
+       'enc.layout': (0.0, 0.602, 0.401)}
 
 
 def launch_work(tag):
@@ -394,12 +403,20 @@ def dry_run(args, world, rank, local_rank):
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    info = {'rank': rank, 'local_rank': local_rank, 'seed': rank}
+    # what rank r would process: its own synthetic shard (seed r) = images [lo, hi) of a global batch of bs * world
+    sys.path.insert(0, ROOT)
+    from sc2bench_amd.dataparallel import shard_range
+    lo, hi = shard_range(args.bs * world, rank, world)
+    info = {'rank': rank, 'local_rank': local_rank, 'seed': rank, 'shard': [lo, hi], 'own_elapsed_s': elapsed}
     ranks = [info]
+    n_ranks = None
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        one = torch.ones(1)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)     # backend-side proof of the rank count (the GPU line: `ranks_reduced`)
+        n_ranks = int(round(one.item()))
         ranks = [None] * world
         dist.all_gather_object(ranks, info)
     if rank == 0:
@@ -408,7 +425,7 @@ def dry_run(args, world, rank, local_rank):
                           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
                           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'none',
                           'config': {'workload': 'dry run: launch / rank / reduction plumbing only',
-                                     'batch_per_gpu': args.bs, 'global_batch': args.bs * world}, 'ranks': ranks}))
+                                     'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'ranks_reduced': n_ranks}, 'ranks': ranks}))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
@@ -599,60 +616,132 @@ def workload_cpu_baseline(name, model, x, budget_s=12.0):
             'sample': '{} x 1 image of the same workload ({}), {:.1f} s of CPU work'.format(n, what, dt)}
 
 
-def workload_bench(args, dev, rank, world, distributed):
-    """`--workload seg513 | det800x1216 | fp_input`: the module forward of that config, K steps after W warm-up steps, one
-    stream, bytes objects through the host API (the reference's semantics).  Secondary figures: the headline metric and the
-    pipelined device-resident path are `--workload es224` (default)."""
+WORKLOAD_PIPELINE = {   # (coder group G, coder streams) per workload, by measurement
+    'es224': (8, 4),
+    # mean-scale hyperprior: the per-symbol-index decoder holds 120 KB of LDS per 16-stream workgroup for ~19 ms -- a 2 048-stream
+    # launch would pin 128 CUs; 512 streams per launch (32 CUs), three launches in flight
+    'mshp224': (2, 3),
+    'fp_input': (8, 4),      # 32 streams per batch: 256 per launch
+    'seg513': (8, 4),        # 16 streams x 393 k symbols per batch: 128 per launch, ~85 ms of chain each way
+    'det800x1216': (8, 6),   # 6 streams x 1.45 M symbols per batch: 48 per launch (one wave), ~330 ms each way
+}
+
+
+def make_pipeline(args, model, dev):
+    import sc2bench_amd as S
+    g_default, c_default = WORKLOAD_PIPELINE[args.workload]
+    return S.StagePipeline(model, dev, coder_group=args.coder_group or g_default, coder_streams=args.inflight or c_default,
+                           max_inflight=args.max_inflight, ramp=bool(args.ramp), lag=max(0, args.lag),
+                           front_priority=args.front_priority, back_priority=args.back_priority, coder_priority=args.coder_priority,
+                           back_streams=max(1, args.split_mfma), share_buffer=not args.cat_symbols,
+                           coder_kwargs={'dequantized': False} if args.unfused_dequantize else None)
+
+
+def timed_pipeline_run(pipe, x, steps, select, distributed, timeline=False):
+    """K batches through the package's stage pipeline (sc2bench_amd/pipeline.py), bracketed as the contract says: the caller has
+    synchronised; this starts the clock, issues K batches, synchronises every stream (+ barrier) and stops it.
+    -> (elapsed s, host issue s, KernelTimer, last (output, nbytes, status), record)"""
     from sc2bench_amd import hip
+    rec = {'timeline': []} if timeline else {}
+    last = [None]
+
+    def keep(step, out, nb, st):
+        last[0] = (out, nb, st)
+
+    with hip.KernelTimer(select) as timer:
+        t0 = time.perf_counter()
+        pipe.run(x, n_steps=steps, on_output=keep, record=rec)
+        t_issued = time.perf_counter()
+        pipe.synchronize()
+        if distributed:
+            dist.barrier()
+        t1 = time.perf_counter()
+    return t1 - t0, t_issued - t0, timer, last[0], rec
+
+
+def ranks_reduced(dev, distributed):
+    """RCCL-side proof of the rank count: every rank contributes 1 to a device all-reduce on the backend (the process group's
+    world size in `config.process_group` comes from the launcher's environment)."""
+    if not distributed:
+        return None
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(one.item()))
+
+
+def workload_bench(args, dev, rank, world, distributed):
+    """`--workload mshp224 | seg513 | det800x1216 | fp_input`: that config's updated model through the package's stage pipeline
+    (the same scheduler as the headline line: front stages run ahead, the range coder of G batches shares a launch on its own
+    HIP stream, byte streams stay on the device), K steps after W warm-up steps.  `--no-pipeline`: the module forward per
+    batch (one stream, bytes objects through the host API: the reference's semantics; what rounds 3 - 4 reported)."""
+    from sc2bench_amd import hip
+    import sc2bench_amd as S
     model, x, what, hw, n = build_workload(args.workload, dev, args.bs if args.bs != 256 else 0)
-    sizes = []
+    select = lambda tag: tag is not None and (tag.startswith(('enc.', 'dec.', 'g_a', 'g_s', 'h_a', 'h_s')) or tag.startswith('rans'))  # noqa: E731
+    pipelined = not args.no_pipeline and S.supports_stages(model)
+    pipe = make_pipeline(args, model, dev) if pipelined else None
 
     def step():
         with torch.no_grad():
             return model(x)
 
-    for _ in range(max(1, args.warmup)):
-        out = step()
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    select = lambda tag: tag is not None and (tag.startswith(('enc.', 'dec.', 'g_a', 'g_s', 'h_a', 'h_s')) or tag.startswith('rans'))  # noqa: E731
-    with hip.KernelTimer(select) as timer:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+    if pipelined:
+        G = pipe.G
+        pipe.run(x, n_steps=max(1, (args.warmup + G - 1) // G * G))
+        pipe.synchronize()
+        if args.warmup > 0 and not args.no_prealloc:
+            pipe.warm(x, args.steps)
+        if distributed:
+            dist.barrier()
+        elapsed, _, timer, last, rec = timed_pipeline_run(pipe, x, args.steps, select, distributed)
+        out, nb_last, _ = last
+        from sc2bench_amd.entropy import _status_or
+        assert all(_status_or(st) == 0 for st in rec['statuses']), 'rANS status != 0 in a timed step'
+    else:
+        for _ in range(max(1, args.warmup)):
             out = step()
         torch.cuda.synchronize(dev)
         if distributed:
             dist.barrier()
-        elapsed = time.perf_counter() - t0
+        with hip.KernelTimer(select) as timer:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = step()
+            torch.cuda.synchronize(dev)
+            if distributed:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    n_ranks = ranks_reduced(dev, distributed)
     leaves = list(out.values()) if isinstance(out, dict) else [out]
     assert all(torch.isfinite(v.float()).all() for v in leaves)
     if rank != 0:
         return
     ksum = timer.summary()
-    bn = {k: v for k, v in ksum.items() if k.startswith(('enc.', 'dec.'))}
+    bn = {k: v for k, v in ksum.items() if k.startswith(('enc.', 'dec.')) and k != 'dec.dequantize'}
     roofline = None
     if hw is not None and bn:
-        ms = sum(v[1] for v in bn.values())
+        ms = sum(v[1] for v in bn.values()) + timer.total_ms('dec.dequantize') / float(args.steps)
         tf = bottleneck_gflop(*hw) * n / ms
         traffic = None   # HBM bytes of the bottleneck forward of one step from the committed PMC passes (tools/pmc_workload.sh)
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic_workloads.json')
         if os.path.exists(tpath) and args.bs in (0, 256):   # (the committed figures are for the default batch of the workload)
             traffic = json.load(open(tpath)).get(args.workload, {}).get('hbm_bytes_per_bottleneck_forward')
         roofline = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_BF16_TFLOPS,
-                    'traffic': traffic, 'kernel': 'bottleneck forward = sum of its six fused launches', 'kernel_ms': ms,
+                    'traffic': traffic, 'kernel': 'bottleneck forward = sum of its fused launches + the dequantise pass', 'kernel_ms': ms,
                     'gflop_per_image': bottleneck_gflop(*hw)}
-    # compressed size of the batch as the reference measures it
+    # compressed size of the batch as the reference measures it (host API: bytes objects)
     with torch.no_grad():
         bl = model.compression_model if args.workload == 'fp_input' else model.bottleneck_layer if args.workload == 'mshp224' else \
             (model.body if hasattr(model, 'body') else model.backbone).bottleneck_layer
         obj = bl.compress(model.pre_transform(x)) if args.workload == 'fp_input' else bl.encode(x)
     nbytes = sum(len(q) for lst in obj['strings'] for q in lst)     # (the hyperprior codes two streams per image: y and z)
     pix = x.shape[-1] * x.shape[-2] * n
+    if pipelined:    # the pipeline's device-resident streams code to the same byte count as the host API's bytes objects
+        assert int(nb_last.sum().item()) == nbytes, 'pipeline streams and encode() disagree: {} vs {} bytes'.format(int(nb_last.sum().item()), nbytes)
     # the entropy model's estimate of the same batch: -sum log2 p / pixels in eval mode (sc2bench/loss.py:20-37; SURVEY 8(d))
     with torch.no_grad():
         if args.workload == 'fp_input':
@@ -668,7 +757,7 @@ def workload_bench(args, dev, rank, world, distributed):
     lat_c = 320 if args.workload == 'fp_input' else 24
     sym_per_stream = lat_c * int(sym_shape[-2]) * int(sym_shape[-1]) if (sym_shape is not None and args.workload != 'mshp224') else \
         '24 x 55 x 55 (y, per-symbol CDF rows) + 16 x {} x {} (z)'.format(int(sym_shape[-2]), int(sym_shape[-1]))
-    on_host = n_streams <= hip.host_coder_max_streams()
+    on_host = (not pipelined) and n_streams <= hip.host_coder_max_streams()
     cpu, cpu_failed = None, None
     if world == 1 and not args.no_cpu_baseline:
         try:
@@ -676,18 +765,23 @@ def workload_bench(args, dev, rank, world, distributed):
         except Exception as e:   # the GPU figures are still printed, but a line without its baseline is not a result: rc != 0
             cpu = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: {!r}'.format(e)}
             cpu_failed = 'cpu_baseline failed: {!r}'.format(e)
+    if pipelined:
+        pl = dict(pipe.describe(), what='sc2bench_amd.pipeline.StagePipeline: front stages run ahead, back stages wait for their coder launch',
+                  streams_per_coder_launch=pipe.G * n_streams, coder_group_plan=pipe.group_plan(args.steps)[:6])
+        streams = 'device-resident in the timed region (u8 rows in HBM with offset / nbytes vectors)'
+        coder = 'batched HIP coder ({} streams of {} symbols per launch)'.format(pipe.G * n_streams, sym_per_stream)
+    else:
+        pl = 'none: module forward, one stream'
+        streams = 'Python bytes through the host API (host coder up to {} streams, batched device coder above)'.format(hip.host_coder_max_streams())
+        coder = ('HOST threads (sc2_rans_encode_host / sc2_rans_decode_host): this batch is {} streams of {} symbols, a few long '
+                 'serial chains, which a CPU core steps faster than a GPU lane -- these are NOT HIP-coder figures'.format(n_streams, sym_per_stream)) \
+            if on_host else 'batched HIP coder ({} streams per launch)'.format(n_streams)
     print(json.dumps({
         'metric': 'images/s + bpp, ' + args.workload, 'value': n * args.steps * world / elapsed, 'unit': 'images/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': max(1, args.warmup), 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': what, 'batch_per_gpu': n, 'global_batch': n * world, 'pipeline': 'none: module forward, one stream',
-                   'streams': 'Python bytes through the host API (host coder up to {} streams, batched device coder above)'
-                              .format(hip.host_coder_max_streams()),
-                   'range_coder': ('HOST threads (sc2_rans_encode_host / sc2_rans_decode_host): this batch is {} streams of {} '
-                                   'symbols, a few long serial chains, which a CPU core steps faster than a GPU lane -- these are '
-                                   'NOT HIP-coder figures'.format(n_streams, sym_per_stream)) if on_host else
-                                  'batched HIP coder ({} streams per launch)'.format(n_streams),
-                   'sharding': 'images, no collective'},
+        'config': {'workload': what, 'batch_per_gpu': n, 'global_batch': n * world, 'pipeline': pl, 'streams': streams, 'range_coder': coder,
+                   'sharding': 'images, no collective', 'ranks_reduced': n_ranks},
         'bpp': 8.0 * nbytes / pix, 'bpp_estimated': bpp_est, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': cpu,
         'rans': {k: {'ms_per_launch': round(v[1], 4), 'launches_per_step': v[0] / float(args.steps)}
                  for k, v in sorted(ksum.items()) if k.startswith('rans')},
@@ -723,29 +817,27 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--bs', type=int, default=256, help='images per GPU per step')
-    ap.add_argument('--inflight', type=int, default=4, help='coder HIP streams (coder launches that may be in flight)')
+    ap.add_argument('--inflight', type=int, default=0, help='coder HIP streams (coder launches that may be in flight); 0 = the workload\'s default')
     ap.add_argument('--max-inflight', type=int, default=24, help='encoder stage i waits for decoder+head stage i - this')
-    ap.add_argument('--lag', type=int, default=-1, help='steps between issuing encoder stage i and decoder+head stage i - lag (-1: 0 with --split-mfma, 2 coder groups without)')
-    ap.add_argument('--front-beside-head', type=int, default=0, help='1: encoder stage i waits for the decoder of the batch in flight (runs beside its head)')
+    ap.add_argument('--lag', type=int, default=0, help='steps between issuing encoder stage i and decoder+head stage i - lag in host order')
     ap.add_argument('--ramp', type=int, default=1, help='1: the first coder groups of a run hold 1, 2, 4, ... steps')
-    ap.add_argument('--coder-group', type=int, default=8, help='steps whose symbols share one range-coder launch')
+    ap.add_argument('--coder-group', type=int, default=0, help='steps whose symbols share one range-coder launch; 0 = the workload\'s default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bs1', action='store_true', help='skip the bs-1 evaluation-mode row')
-    ap.add_argument('--split-mfma', type=int, default=1, help='K > 0: decoder+head stages round-robin on K HIP streams of their own (0: one MFMA stream for everything)')
-    ap.add_argument('--head-streams', type=int, default=0, help='H > 0: the task head of step j runs on head stream j %% H (the next decoder does not wait for it)')
-    ap.add_argument('--head-halves', type=int, default=0, help='P > 1: the task head runs as P batch slices on P streams, the next decoder waits for all of them')
-    ap.add_argument('--diag-skip-coder', type=int, default=0, help='DIAGNOSTIC (invalid as a result): 1 = reuse the first step\'s coder output, 2 = same but still run the coder')
+    ap.add_argument('--split-mfma', type=int, default=1, help='decoder+head stages round-robin on K HIP streams of their own')
     ap.add_argument('--front-priority', type=int, default=0, help='HIP stream priority of the encoder stream (-1 = high)')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
     ap.add_argument('--coder-priority', type=int, default=0, help='HIP stream priority of the coder streams (-1 = high)')
     ap.add_argument('--unfused-dequantize', action='store_true', help='A/B: the coder writes int32 symbols and the decoder+head stage dequantises them (two launches more traffic)')
     ap.add_argument('--cat-symbols', action='store_true', help='A/B: the symbols of a coder group are concatenated (torch.cat) instead of being written into one buffer by the encoder stages')
+    ap.add_argument('--conv0-layout-pass', action='store_true', help='A/B: round 4\'s f32 NCHW -> bf16 NHWC4 layout launch in front of the first encoder stage (default: the stage reads the planes in place)')
     ap.add_argument('--no-prealloc', action='store_true', help='A/B: skip the coder-buffer pre-allocation pass after the warm-up steps')
+    ap.add_argument('--no-pipeline', action='store_true', help='--workload lines: the module forward per batch (one stream, host bytes) instead of the stage pipeline')
     ap.add_argument('--diag-timeline', action='store_true', help='DIAGNOSTIC: HIP events around every stage of the timed run, printed to stderr (adds ~100 event records)')
     ap.add_argument('--diag-repeat', type=int, default=0, help='DIAGNOSTIC: after the timed region, time R more runs of K steps and print their wall times to stderr')
     ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
     ap.add_argument('--workload', choices=['es224', 'mshp224', 'fp_input', 'seg513', 'det800x1216'], default='es224',
-                    help='es224 = the headline config (default); the others are BASELINE configs 3 / 5 / 4 through the module API')
+                    help='es224 = the headline config (default); the others are BASELINE configs 3 / 5 / 4 and the hyperprior bottleneck')
     ap.add_argument('--encoder-precision', choices=['bf16', 'f32'], default='bf16',
                     help="f32: the analysis transform with f32 operands on the f32 matrix cores -- symbols, byte streams and bpp are the "
                          "f32 reference path's (precision_check in the line shows it); bf16 (default): the fast encoder")
@@ -783,6 +875,7 @@ def main():
 
     import sc2bench_amd as S
     from sc2bench_amd import hip
+    from sc2bench_amd.entropy import _status_or
     if args.mode == 'train':
         return train_bench(args, dev, rank, world, distributed)
     if args.workload != 'es224':
@@ -792,261 +885,56 @@ def main():
             dist.destroy_process_group()
         return
     model = build_model(dev, encoder_precision=args.encoder_precision)
+    if args.conv0_layout_pass:
+        model.bottleneck_layer.conv0_reads_nchw = False
     x = synthetic_batch(args.bs, dev, seed=rank)   # a different shard per rank, resident in HBM
     torch.cuda.synchronize(dev)
-    # Software pipeline over HIP streams: front(i) [encoder + quantise] and back(i - lag) [dequantise + decoder +
-    # head] are issued back to back; the serial range coder (encode -> bytes -> decode) of up to `coder_group`
-    # consecutive steps runs as ONE launch on one of `n_coder` coder streams (module docstring: why grouped).  A coder
-    # launch is one wave per 64 image streams for ~25 ms: latency, not work.  The first groups of a run are smaller
-    # (1, 2, 4, ...) so that the first decoder stage starts after one coder latency, not after G encoder stages.
-    n_coder = max(1, min(args.inflight, 13))
-    G = max(1, args.coder_group)   # steps whose symbols share ONE coder launch (G * bs streams per launch)
-    mfma_stream = torch.cuda.Stream(device=dev, priority=args.front_priority)
-    # --split-mfma: front(i) [encoder] and back(i - depth) [decoder + head] on two streams, so that the tails of one
-    # stage's short launches overlap the other's (both still feed the same matrix cores)
-    back_streams = [torch.cuda.Stream(device=dev, priority=args.back_priority) for _ in range(args.split_mfma)] \
-        if args.split_mfma else [mfma_stream]
-    coder_streams = [torch.cuda.Stream(device=dev, priority=args.coder_priority) for _ in range(n_coder)]
-    head_streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.head_streams, args.head_halves))]
-    sym_cols = [None]   # symbols per image
+    # The software pipeline is the package's (sc2bench_amd/pipeline.py: StagePipeline over stage_front / stage_coder /
+    # stage_back of the model): front(i) [encoder + quantise] stages run ahead on one HIP stream, the serial range coder
+    # (encode -> bytes -> decode) of up to G consecutive steps runs as ONE launch on one of the coder streams, back(i)
+    # [dequantise + decoder + head] waits for its coder launch on a second MFMA stream.  evaluation.evaluate() runs the same
+    # class on a data loader; bench.py only feeds it the resident synthetic batch K times and reads the clock.
+    pipe = make_pipeline(args, model, dev)
+    G, n_coder = pipe.G, len(pipe.coder_streams)
     with torch.no_grad():
         # fold / pack every cached weight once on the null stream, before the side streams use them, THROUGH THE THREE STAGES the
         # pipeline runs (the staged form packs more than forward_device does: the symbol-writing last encoder conv and the
-        # decoder tail that carries layer2.0's two 1x1 layers), and learn the symbol count per image so that the very first
-        # coder group of a run already writes into its shared buffer
+        # decoder tail that carries layer2.0's two 1x1 layers)
         sym0, hw0 = model.stage_front(x[:2])
-        dec0, _, st0 = model.stage_coder(sym0, hw0, dequantized=not args.unfused_dequantize)
+        dec0, _, st0 = model.stage_coder(sym0, hw0, **pipe.coder_kwargs)
         model.stage_back(dec0, hw0)
-        sym_cols[0] = sym0.shape[1]
         assert int(st0.max().item()) == 0
         del sym0, dec0, st0
     torch.cuda.synchronize(dev)
-    results = [None]
-    cached = []
-    statuses = []     # status vectors of EVERY coder launch of the timed run (checked after the final sync)
-    latency = []      # (event at front(i) start, event at back(i) end) for a few steps
-    timeline = []     # --diag-timeline: (stage, step, start event, end event)
-
-    def tl_event(stream):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record(stream)
-        return e
-
-    def group_plan(n_steps):
-        """sizes of the coder groups of a run: 1, 2, 4, ... up to G, then G."""
-        sizes, g = [], (1 if args.ramp else G)
-        while sum(sizes) < n_steps:
-            sizes.append(min(g, G, n_steps - sum(sizes)))
-            g *= 2
-        return sizes
-
-    def run_steps(n_steps, record=False):
-        pending = {}
-        gbuf = [None]
-        group = []   # (step, symbols, (h, w), event, in the shared buffer?) of the steps waiting for their coder launch
-        plan = group_plan(n_steps)
-        back_done = {}
-        dec_done = [None]
-        end_events = []
-        # host-order lag of the decoder+head stages.  With their own stream (default) they are issued as soon as their
-        # coder launch is and wait for it ON that stream; on a single MFMA stream a waiting stage would block the encoder
-        # stages queued behind it, so it is issued only when its coder launch has had time to finish (two groups later)
-        lag = args.lag if args.lag >= 0 else (0 if args.split_mfma else 2 * G)
-        # (stage i waits for back_done[i - max_inflight], which exists only once that decoder+head stage has been issued: a lag
-        #  of max_inflight or more would switch the throttle off and let the host run the encoder stages ahead without bound)
-        lag = min(lag, max(args.max_inflight - 1, 0))
-        launches = [0]
-
-        def flush():
-            cs = coder_streams[launches[0] % n_coder]
-            launches[0] += 1
-            with torch.cuda.stream(cs):
-                for _, g_sym, _, g_ev, _ in group:
-                    cs.wait_event(g_ev)
-                    g_sym.record_stream(cs)
-                if len(group) == 1:
-                    sym = group[0][1]
-                elif gbuf[0] is not None and all(g[4] for g in group):
-                    sym = gbuf[0]                # every encoder stage wrote its row block of the one buffer: nothing to copy
-                    sym.record_stream(cs)
-                else:
-                    sym = torch.cat([g[1] for g in group])
-                gbuf[0] = None
-                hw = group[0][2]
-                if args.diag_skip_coder and cached:   # diagnostic only: how much the coder chains cost the MFMA stages
-                    dec, nb, st = cached[0]
-                    ev2 = torch.cuda.Event()
-                    ev2.record(cs)
-                    if args.diag_skip_coder == 2:     # the coder still runs (resources), nobody waits for it
-                        model.stage_coder(sym, hw)
-                    elif args.diag_skip_coder == 3:   # two long single-thread spin kernels in its place
-                        torch.cuda._sleep(int(12e-3 * 2.0e9))
-                        torch.cuda._sleep(int(11e-3 * 2.0e9))
-                else:
-                    tl0 = tl_event(cs) if (record and args.diag_timeline) else None
-                    dec, nb, st = model.stage_coder(sym, hw, dequantized=not args.unfused_dequantize)
-                    if tl0 is not None:
-                        timeline.append(('coder', group[0][0], tl0, tl_event(cs)))
-                    if args.diag_skip_coder:
-                        cached.append((dec, nb, st))
-                    ev2 = torch.cuda.Event()
-                    ev2.record(cs)
-                if record:
-                    statuses.append(st)
-            n = group[0][1].shape[0]
-            for k, (step, _, _, _, _) in enumerate(group):
-                sl = slice(k * n, (k + 1) * n) if dec.shape[0] == n * len(group) else slice(0, n)
-                pending[step] = (dec[sl], nb[sl], st[sl], hw, ev2, dec)
-            group.clear()
-
-        with torch.no_grad():
-            issued_back = 0
-            for i in range(n_steps):
-                with torch.cuda.stream(mfma_stream):
-                    if args.front_beside_head and dec_done[0] is not None:
-                        # the encoder stage runs beside the task head of the batch in flight, not beside its decoder
-                        mfma_stream.wait_event(dec_done[0])
-                    if i - args.max_inflight in back_done:
-                        # bound the run-ahead of the host and of the encoder stream: memory in flight, latency per batch,
-                        # and the caching allocator keeps recycling cross-stream blocks instead of calling hipMalloc
-                        back_done.pop(i - args.max_inflight).synchronize()
-                    if record and i % 8 == 0:
-                        e0 = torch.cuda.Event(enable_timing=True)
-                        e0.record(mfma_stream)
-                        latency.append([i, e0, None])
-                    if record and args.diag_timeline:
-                        timeline.append(('front', i, tl_event(mfma_stream), None))
-                    g_size = plan[launches[0]]
-                    out = None
-                    if g_size > 1 and sym_cols[0] is not None and not args.cat_symbols:
-                        if gbuf[0] is None:      # one buffer per coder group; encoder stage k writes row block k
-                            gbuf[0] = torch.empty((g_size * args.bs, sym_cols[0]), dtype=torch.int32, device=dev)
-                        out = gbuf[0][len(group) * args.bs:(len(group) + 1) * args.bs]
-                    sym, hw = model.stage_front(x, out=out)
-                    sym_cols[0] = sym.shape[1]
-                    if record and args.diag_timeline:
-                        timeline[-1] = timeline[-1][:3] + (tl_event(mfma_stream),)
-                    ev = torch.cuda.Event()
-                    ev.record(mfma_stream)
-                group.append((i, sym, hw, ev, out is not None))
-                if len(group) == plan[launches[0]]:
-                    flush()
-                # back stages of every step whose coder launch has been issued, oldest first: they wait for the
-                # coder's event on their own stream, the encoder stream runs ahead
-                while issued_back in pending and (i - issued_back >= lag or i == n_steps - 1):
-                    j = issued_back
-                    issued_back += 1
-                    dec, nb, st, hw, ev2, whole = pending.pop(j)
-                    back_stream = back_streams[j % len(back_streams)]
-                    with torch.cuda.stream(back_stream):
-                        back_stream.wait_event(ev2)
-                        whole.record_stream(back_stream)
-                        def mark():
-                            ev_d = torch.cuda.Event()
-                            ev_d.record(back_stream)
-                            dec_done[0] = ev_d
-                        if args.head_halves > 1:
-                            # the head as P batch slices on P streams (their launch tails overlap); the decoder of the
-                            # next step waits for all of them, so decoder launches never share the CUs with a head
-                            feats = model.stage_decoder(dec, hw)
-                            ev_f = torch.cuda.Event()
-                            ev_f.record(back_stream)
-                            P = args.head_halves
-                            n_sl = (feats.shape[0] + P - 1) // P
-                            outs = []
-                            for hs_i in range(P):
-                                hs = head_streams[hs_i]
-                                with torch.cuda.stream(hs):
-                                    hs.wait_event(ev_f)
-                                    feats.record_stream(hs)
-                                    outs.append(model.head(feats[hs_i * n_sl:(hs_i + 1) * n_sl]))
-                                    ev_h = torch.cuda.Event()
-                                    ev_h.record(hs)
-                                back_stream.wait_event(ev_h)
-                            for o in outs:
-                                o.record_stream(back_stream)
-                            logits = torch.cat(outs)
-                        elif args.head_streams > 0:
-                            feats = model.stage_decoder(dec, hw)
-                            ev_f = torch.cuda.Event()
-                            ev_f.record(back_stream)
-                            hs = head_streams[j % args.head_streams]
-                            with torch.cuda.stream(hs):
-                                hs.wait_event(ev_f)
-                                feats.record_stream(hs)
-                                logits = model.head(feats)
-                                ev_h = torch.cuda.Event()
-                                ev_h.record(hs)
-                            end_events.append(ev_h)
-                            logits.record_stream(back_stream)
-                        else:
-                            tl0 = tl_event(back_stream) if (record and args.diag_timeline) else None
-                            logits = model.stage_back(dec, hw, after_decoder=mark if args.front_beside_head else None)
-                            if tl0 is not None:
-                                timeline.append(('back', j, tl0, tl_event(back_stream)))
-                        results[0] = (logits, nb, st)
-                        back_done[j] = torch.cuda.Event()
-                        if args.head_streams > 0 and args.head_halves <= 1:
-                            back_stream.wait_event(end_events[-args.head_streams]) if len(end_events) >= args.head_streams else None
-                            back_done[j] = end_events[-1]
-                        else:
-                            back_done[j].record(back_stream)
-                        if record and j % 8 == 0:
-                            e1 = torch.cuda.Event(enable_timing=True)
-                            e1.record(head_streams[j % args.head_streams] if (args.head_streams > 0 and args.head_halves <= 1) else back_stream)
-                            [r for r in latency if r[0] == j][0][2] = e1
-            assert issued_back == n_steps and not pending and not group
 
     def sync_all():
-        mfma_stream.synchronize()
-        for bstream in back_streams:
-            bstream.synchronize()
-        for cstream in coder_streams + head_streams:
-            cstream.synchronize()
-        torch.cuda.synchronize(dev)
+        pipe.synchronize()
         if distributed:
             dist.barrier()
 
     # whole coder groups, so that the timed region meets warm allocator pools and LDS attributes (W = 0 stays 0)
     warm_steps = (args.warmup + G - 1) // G * G
-    run_steps(warm_steps)
+    if warm_steps:
+        pipe.run(x, n_steps=warm_steps)
     sync_all()
-
-    def prealloc_coder(n_steps):
-        """Resource warm-up, not a step: one range-coder launch per coder group of the timed plan, on the coder stream that group
-        will use, so that the timed region makes no first-time device allocation.  W warm-up steps only reach the group sizes
-        1, 2, 4 (W = 5: plan 1 + 2 + 4 + 1); the 8-step groups of the timed run then allocate ~2 GB of workspace, streams and
-        symbol buffers inside the timed region, and the FIRST process on a freshly booted box pays ~45 ms for that (measured:
-        174 ms vs 128 ms for the same 20 steps, tools/cold_diag.sh) -- the driver's situation."""
-        with torch.no_grad():
-            with torch.cuda.stream(mfma_stream):
-                sym1, hw = model.stage_front(x)
-            mfma_stream.synchronize()
-            for li, g in enumerate(group_plan(n_steps)):
-                cs = coder_streams[li % n_coder]
-                with torch.cuda.stream(cs):
-                    model.stage_coder(sym1 if g == 1 else torch.cat([sym1] * g), hw)
-        sync_all()
-
     if args.warmup > 0 and not args.no_prealloc:
-        prealloc_coder(args.steps)
+        # resource warm-up, not a step: one untimed range-coder launch per coder-group shape of the timed plan, so that the timed
+        # region makes no first-time device allocation (the FIRST process on a freshly booted box pays ~45 ms for them otherwise)
+        pipe.warm(x, args.steps)
+        sync_all()
 
     select = lambda tag: launch_work(tag) is not None or tag.startswith('rans')  # noqa: E731
-    with hip.KernelTimer(select) as timer:
-        t0 = time.perf_counter()
-        run_steps(args.steps, record=True)
-        t_issued = time.perf_counter()
-        sync_all()
-        t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if timeline:
-        base = timeline[0][2]
-        for kind, step, e_a, e_b in sorted(timeline, key=lambda r: base.elapsed_time(r[2])):
+    elapsed, issue_s, timer, last, rec = timed_pipeline_run(pipe, x, args.steps, select, distributed, timeline=args.diag_timeline)
+    statuses, latency = rec['statuses'], rec['latency']
+    if args.diag_timeline:
+        tl = rec['timeline']
+        base = tl[0][2]
+        for kind, step, e_a, e_b in sorted(tl, key=lambda r: base.elapsed_time(r[2])):
             print('timeline {:<6} step {:3d}  start {:8.2f} ms  end {:8.2f} ms  ({:.2f} ms)'.format(
                 kind, step, base.elapsed_time(e_a), base.elapsed_time(e_b), e_a.elapsed_time(e_b)), file=sys.stderr)
     for rep in range(args.diag_repeat):
         tr0 = time.perf_counter()
-        run_steps(args.steps)
+        pipe.run(x, n_steps=args.steps)
         sync_all()
         print('diag-repeat {}: first timed region {:.2f} ms, this one {:.2f} ms'.format(rep, elapsed * 1e3, (time.perf_counter() - tr0) * 1e3),
               file=sys.stderr)
@@ -1054,9 +942,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    n_ranks = ranks_reduced(dev, distributed)
 
-    logits, nb, st = results[0]
-    assert max(int(s.max().item()) for s in statuses) == 0, 'rANS status != 0 in a timed step'
+    logits, nb, st = last
+    assert all(_status_or(s_) == 0 for s_ in statuses), 'rANS status != 0 in a timed step'
     assert torch.isfinite(logits.float()).all()
     nb_f = nb.float()
     bytes_per_img = nb_f.mean().item()
@@ -1066,10 +955,12 @@ def main():
 
     if rank == 0:
         ksum = timer.summary()
-        conv = {k: v for k, v in ksum.items() if launch_work(k) is not None}
+        # every launch of the bottleneck forward: the fused conv / GDN launches (mean duration per launch = per step) and the
+        # coder's dequantise pass, whose launches cover 1 .. G steps each: its total over the run / steps
+        conv = {k: v for k, v in ksum.items() if launch_work(k) is not None and k != 'dec.dequantize'}
+        dq_ms = timer.total_ms('dec.dequantize') / float(args.steps)
         dom = max(conv, key=lambda k: conv[k][0] * conv[k][1])
-        dom_ms = conv[dom][1]
-        fwd_ms = sum(v[1] for v in conv.values())
+        fwd_ms = sum(v[1] for v in conv.values()) + dq_ms
         # (the last decoder launch may carry two 1x1 layers of the head: their 0.411 GFLOP per image then sit in fwd_ms too)
         fwd_gflop = BOTTLENECK_GFLOP_PER_IMG + (0.411 if any('head.2.0' in k for k in conv) else 0.0)
 
@@ -1087,19 +978,42 @@ def main():
                     'frac': (gbs / PEAK_HBM_GBS) if hbm else (tf / peak_tf), 'tflops': tf, 'gbs': gbs,
                     'kernel_ms': ms}
         per_kernel = {k: roof(k, v[1]) for k, v in conv.items()}
+        if dq_ms > 0:
+            per_kernel['dec.dequantize'] = roof('dec.dequantize', dq_ms)
         floor_ms = sum(max(launch_work(k)[0] * 1e6 * args.bs / (PEAK_BF16_TFLOPS * 1e12),
-                           launch_work(k)[1] * 1e6 * args.bs / (PEAK_HBM_GBS * 1e9)) * 1e3 for k in conv)
-        traffic = None
+                           launch_work(k)[1] * 1e6 * args.bs / (PEAK_HBM_GBS * 1e9)) * 1e3 for k in per_kernel)
+        # HBM-side bytes per launch of the dominant kernel from the committed PMC pass -- reported only while that pass still
+        # describes the library that runs (profiles/traffic.json records the hashes of the library / kernel sources it measured)
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tpath):
             try:
-                # measured at bs 256 per GPU; HBM-side bytes per launch (FETCH_SIZE doubled as the microarch guide
-                # prescribes for gfx950 + WRITE_SIZE), scaled to this run's batch
-                rec = json.load(open(tpath)).get(dom)
-                traffic = rec['hbm_bytes_per_launch'] * args.bs / 256.0 if rec else None
+                tj = json.load(open(tpath))
+                meas, now = tj.get('_measured_on') or {}, hip.library_fingerprint()
+                same = any(meas.get(k) and meas.get(k) == now.get(k) for k in ('lib_sha256', 'csrc_sha256'))
+                rec_t = tj.get(dom)
+                if rec_t and same:      # measured at bs 256 per GPU; scaled to this run's batch
+                    traffic = rec_t['hbm_bytes_per_launch'] * args.bs / 256.0
+                elif rec_t:
+                    traffic_note = 'profiles/traffic.json was measured on another build of the library: dropped'
             except Exception:
                 traffic = None
         lat_ms = [e0.elapsed_time(e1) for _, e0, e1 in latency if e1 is not None]
+        # the same launches stand-alone: one stream, nothing beside them (the in-pipeline durations above are taken while the
+        # other MFMA stream and the coder share the chip with the launch: the sum of overlapped kernel durations counts shared
+        # time twice)
+        with torch.no_grad():
+            sym_s, hw_s = model.stage_front(x)
+            dec_s, _, _ = model.stage_coder(sym_s, hw_s, **pipe.coder_kwargs)
+            torch.cuda.synchronize(dev)
+            with hip.KernelTimer(select) as solo:
+                for _ in range(5):
+                    model.stage_front(x)
+                    model.stage_back(dec_s, hw_s)
+                torch.cuda.synchronize(dev)
+            solo_sum = {k: v for k, v in solo.summary().items() if launch_work(k) is not None}
+            solo_ms = sum(v[1] for v in solo_sum.values())
+            del sym_s, dec_s
         # the device bitstreams of the first 8 images of this shard, and the symbols they were coded from
         with torch.no_grad():
             sym, hw = model.stage_front(x)
@@ -1116,9 +1030,10 @@ def main():
             'config': {'workload': 'Entropic-Student ResNet-50 (FPBasedResNetBottleneck 24ch), ILSVRC2012 shape '
                                    '224x224x3, eval after update(): encode -> rANS -> decode -> layer2..fc',
                        'batch_per_gpu': args.bs, 'global_batch': args.bs * world,
-                       'pipeline': 'event-driven: encoder stages run ahead, decoder+head stages wait for their coder launch',
-                       'hip_streams': {'encoder': 1, 'decoder+head': len(back_streams), 'range_coder': n_coder},
-                       'steps_per_coder_launch': G, 'max_inflight_steps': args.max_inflight, 'coder_group_plan': group_plan(args.steps)[:6], 'warmup_steps_run': warm_steps,
+                       'pipeline': 'sc2bench_amd.pipeline.StagePipeline (the scheduler evaluation.evaluate() uses): encoder stages run '
+                                   'ahead, decoder+head stages wait for their coder launch',
+                       'hip_streams': pipe.describe()['hip_streams'],
+                       'steps_per_coder_launch': G, 'max_inflight_steps': args.max_inflight, 'coder_group_plan': pipe.group_plan(args.steps)[:6], 'warmup_steps_run': warm_steps,
                        'prealloc': 'none' if (args.no_prealloc or args.warmup == 0) else 'one untimed range-coder launch per coder group of the timed plan (device buffers only, not a step)',
                        'weights': 'random init seed 0, operating point shaped by bench.shape_workload (ragged tables, '
                                   'peaked prior, latent std ~1, ~1e-4 escape symbols)',
@@ -1128,26 +1043,34 @@ def main():
                        'encoder_precision': args.encoder_precision + (' (f32 operands on v_mfma_f32_16x16x4_f32: bitstreams of the f32 '
                                                                       'reference path; decoder + head bf16)' if args.encoder_precision == 'f32' else
                                                                       ' MFMA operands, f32 accumulation'),
+                       'first_encoder_stage_input': 'round-4 layout pass (A/B)' if args.conv0_layout_pass else 'f32 NCHW planes read in place',
                        'sharding': 'images, no collective',
-                       'process_group': '{} ({} rank{})'.format(dist.get_backend(), world, '' if world == 1 else 's') if distributed else 'none'},
+                       'process_group': '{} ({} rank{})'.format(dist.get_backend(), world, '' if world == 1 else 's') if distributed else 'none',
+                       'ranks_reduced': n_ranks},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
             'bytes_per_image_min_mean_max': [nb_f.min().item(), bytes_per_img, nb_f.max().item()],
             'bitstream_sha256_first8': sha256_of(dev_streams),
             'latency_ms_per_batch': {'mean': sum(lat_ms) / max(1, len(lat_ms)), 'max': max(lat_ms) if lat_ms else None,
                                      'what': 'encoder stage start -> logits of the same batch'},
-            'host_issue_ms_per_step': 1e3 * (t_issued - t0) / args.steps,
+            'host_issue_ms_per_step': 1e3 * issue_s / args.steps,
             'roofline': dict(per_kernel[dom], kernel=dom, traffic=traffic, launches_timed=conv[dom][0]),
-            'bottleneck_forward': {'ms_per_batch_sum_of_mfma_kernels': fwd_ms,
+            'bottleneck_forward': {'ms_per_batch_sum_of_its_launches': fwd_ms,
+                                   'launches_counted': sorted(per_kernel),
                                    'gflop_per_image': fwd_gflop,
                                    'tflops': fwd_gflop * args.bs / fwd_ms,
                                    'frac_of_mfma_peak': fwd_gflop * args.bs / fwd_ms / PEAK_BF16_TFLOPS,
                                    'roofline_floor_ms_of_this_launch_structure': floor_ms,
-                                   'frac_of_floor': floor_ms / fwd_ms},
+                                   'frac_of_floor': floor_ms / fwd_ms,
+                                   'stand_alone': {'ms_per_batch': solo_ms, 'frac_of_mfma_peak': fwd_gflop * args.bs / solo_ms / PEAK_BF16_TFLOPS,
+                                                   'what': 'the same launches (without the dequantise pass) on one stream with nothing beside them, 5 repetitions after the timed region',
+                                                   'kernels_ms': {k: round(v[1], 4) for k, v in sorted(solo_sum.items())}}},
             'kernel_rooflines': {k: {'bound': v['bound'], 'frac': round(v['frac'], 4), 'tflops': round(v['tflops'], 1),
                                      'gbs': round(v['gbs'], 1), 'ms': round(v['kernel_ms'], 4)}
                                  for k, v in sorted(per_kernel.items())},
             'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())},
         }
+        if traffic_note:
+            out['roofline']['traffic_note'] = traffic_note
         if 'rans_encode' in ksum:
             n_sym = 24 * 55 * 55
             out['rans'] = {'encode_ms': ksum['rans_encode'][1], 'decode_ms': ksum['rans_decode'][1],
@@ -1165,17 +1088,15 @@ def main():
             # the same K steps of the same pipeline with the reference-precision encoder (f32 operands on the f32 matrix cores):
             # the mode whose bitstreams are the f32 reference path's, measured by the same command as the headline figure
             model.set_encoder_precision('f32')
-            run_steps(warm_steps)
+            if warm_steps:
+                pipe.run(x, n_steps=warm_steps)
             sync_all()
-            tf0 = time.perf_counter()
-            run_steps(args.steps)
-            sync_all()
-            tf1 = time.perf_counter()
+            el32, _, _, last32, rec32 = timed_pipeline_run(pipe, x, args.steps, lambda tag: False, distributed)
             model.set_encoder_precision('bf16')
-            _, nb32, st32 = results[0]
-            assert int(st32.max().item()) == 0, 'rANS status != 0 in an f32-mode step'
+            _, nb32, _ = last32
+            assert all(_status_or(s_) == 0 for s_ in rec32['statuses']), 'rANS status != 0 in an f32-mode step'
             pc32 = out['precision_check']['f32_encoder']
-            out['f32_mode'] = {'images_per_s': args.bs * args.steps / (tf1 - tf0), 'ms_per_step': 1e3 * (tf1 - tf0) / args.steps,
+            out['f32_mode'] = {'images_per_s': args.bs * args.steps / el32, 'ms_per_step': 1e3 * el32 / args.steps,
                                'steps': args.steps, 'bpp': 8.0 * nb32.float().mean().item() / (224 * 224),
                                'bpp_estimated': pc32['bpp_estimated'], 'symbol_mismatch_rate': pc32['symbol_mismatch_rate'],
                                'images_with_identical_symbols': '{} of {}'.format(pc32['images_with_identical_symbols'],

@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 35
+#define SC2_ABI_VERSION 36
 int sc2_abi_version(void);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
@@ -465,6 +465,15 @@ int sc2_rans_decode_dequantize_batch(const uint8_t *in, int64_t in_stride, const
                                      int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets, const float *medians,
                                      int32_t *symbols_out, void *y_hat_bf16_nhwc, int32_t *status, void *workspace,
                                      int64_t workspace_bytes, void *stream);
+
+/* The same call; additionally records the caller's two hipEvent_t (may be NULL) on `stream` directly in front of and behind its
+ * LAST pass (dequantise + transposition to NHWC = EntropyModel.dequantize, layer.py:520), so that a caller can time that pass
+ * as part of the bottleneck forward while the serial passes count as the range coder's. */
+int sc2_rans_decode_dequantize_batch_ev(const uint8_t *in, int64_t in_stride, const int32_t *in_offset, const int32_t *in_nbytes,
+                                        int64_t index_div, int n_streams, int64_t n_sym, const int32_t *cdfs, int n_cdfs,
+                                        int cdf_stride, const int32_t *cdf_sizes, const int32_t *offsets, const float *medians,
+                                        int32_t *symbols_out, void *y_hat_bf16_nhwc, int32_t *status, void *workspace,
+                                        int64_t workspace_bytes, void *stream, void *ev_dequantize_begin, void *ev_dequantize_end);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Element-wise pieces of the distillation step (stage 1 of the Entropic-Student recipe:          */

@@ -23,4 +23,6 @@ from .wrapper import (WRAPPER_CLASS_DICT, CodecFeatureCompressionClassifier, Cod
 from .dense import (DETECTION_MODEL_FUNC_DICT, SEGMENTATION_MODEL_FUNC_DICT, BaseRCNN, BaseSegmentationModel,  # noqa: F401
                     SegEvaluator, UpdatableBackboneWithFPN, backbone_with_fpn, deeplabv3_model, faster_rcnn_model)
 
-__version__ = '0.2.0'
+from .pipeline import StagePipeline, supports_stages  # noqa: F401
+
+__version__ = '0.3.0'

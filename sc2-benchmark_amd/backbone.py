@@ -14,7 +14,7 @@ from torch import nn
 
 from .analysis import AnalyzableModule
 from .entropy import CompressionModel
-from .layer import get_layer
+from .layer import FPBasedResNetBottleneck, get_layer
 from .resnet import RESNET_FUNC_DICT, FrozenBatchNorm2d
 
 BACKBONE_CLASS_DICT = dict()
@@ -131,6 +131,50 @@ class FeatureExtractionBackbone(UpdatableBackbone):
                 if self.analyzes_after_compress:
                     self.analyze(compressed)
                 x = module.decode(**compressed)
+            else:
+                x = self._run_child(name, module, x)
+            if name in self.return_layer_dict:
+                out[self.return_layer_dict[name]] = x
+        return out
+
+    # ---- the updated eval forward in stages (pipeline.StagePipeline): children in front of the bottleneck + its front stage,
+    #      the coder, then its decoder + the remaining children
+    @property
+    def stage_front_takes_out(self):
+        key = self.analyzable_layer_key
+        first = next(iter(self._modules), None)
+        return key is not None and first == key and bool(getattr(self._modules[key], 'stage_front_takes_out', False))
+
+    @property
+    def stage_coder_kwargs(self):
+        key = self.analyzable_layer_key
+        return dict(getattr(self._modules.get(key), 'stage_coder_kwargs', {})) if key is not None else {}
+
+    def stages_ready(self):
+        key = self.analyzable_layer_key
+        return (key is not None and key in self._modules and self.bottleneck_updated and not self.training and
+                hasattr(self._modules[key], 'stage_front') and next(self.parameters()).is_cuda)
+
+    def stage_front(self, x, out=None):
+        for name, module in self.named_children():
+            if name == self.analyzable_layer_key:
+                return module.stage_front(x, out=out) if out is not None else module.stage_front(x)
+            x = self._run_child(name, module, x)
+        raise KeyError('`analyzable_layer_key` ({}) does not exist'.format(self.analyzable_layer_key))
+
+    def stage_coder(self, payload, meta, **kwargs):
+        return self._modules[self.analyzable_layer_key].stage_coder(payload, meta, **kwargs)
+
+    def stage_back(self, decoded, meta):
+        out = OrderedDict()
+        seen = False
+        x = None
+        for name, module in self.named_children():
+            if name == self.analyzable_layer_key:
+                x = module.synthesis_nhwc(module.stage_decode(decoded, meta))
+                seen = True
+            elif not seen:
+                continue        # (ran in stage_front; a layer in front of the bottleneck is never a returned one in the reference's configs)
             else:
                 x = self._run_child(name, module, x)
             if name in self.return_layer_dict:
@@ -268,17 +312,29 @@ class SplittableResNet(UpdatableBackbone):
         x = self.bottleneck_layer.decode_device(buf, off, nb, shape)
         return self.head(x), nb, st
 
-    # ---- the same eval forward cut into three stages, so that a caller can run the serial range coder on its
-    #      own HIP stream(s) while the MFMA stream works on neighbouring batches (bench.py)
+    # ---- the same eval forward cut into three stages, so that a caller (pipeline.StagePipeline) can run the serial range coder
+    #      on its own HIP stream(s) while the MFMA streams work on neighbouring batches
+    @property
+    def stage_front_takes_out(self):
+        return bool(getattr(self.bottleneck_layer, 'stage_front_takes_out', False)) and hasattr(self.bottleneck_layer, 'stage_front')
+
+    @property
+    def stage_coder_kwargs(self):
+        return dict(getattr(self.bottleneck_layer, 'stage_coder_kwargs', {}))
+
+    def stages_ready(self):
+        return (self.bottleneck_updated and not self.training and hasattr(self.bottleneck_layer, 'stage_front') and
+                next(self.parameters()).is_cuda)
+
     def stage_front(self, x, out=None):
-        """encoder + quantisation: -> (symbols int32 [N, C*h*w], (h, w)).  `out`: a contiguous int32 [N, C*h*w] tensor to write
-        the symbols into (a row block of the buffer one range-coder launch will read: no concatenation afterwards)."""
+        """encoder + quantisation: -> (payload, meta) of the bottleneck's `stage_front` (FP bottleneck: symbols int32 [N, C*h*w]
+        and (h, w); `out`: a row block of the buffer one range-coder launch will read).  A bottleneck without stages: analysis +
+        its entropy bottleneck's symbols."""
         if self.pre_transform is not None:
             x = self.pre_transform(x)
         bl = self.bottleneck_layer
-        if type(bl).__name__ == 'FPBasedResNetBottleneck':      # last conv + quantisation in one launch
-            sym = bl.analysis(x, symbols_for=bl.entropy_bottleneck, out=out)
-            return sym.view(sym.shape[0], -1), tuple(sym.shape[-2:])
+        if hasattr(bl, 'stage_front'):
+            return bl.stage_front(x, out=out) if out is not None else bl.stage_front(x)
         latent = bl.analysis(x)
         sym = bl.entropy_bottleneck.symbols_device(latent)
         if out is not None:
@@ -286,19 +342,13 @@ class SplittableResNet(UpdatableBackbone):
             sym = out
         return sym, tuple(latent.shape[-2:])
 
-    def stage_coder(self, sym, hw_shape, dequantized=False):
-        """rANS encode to byte streams, then decode them: -> (decoded symbols, nbytes [N], status [N]).  `dequantized`: the
-        first item is the dequantised latent as bf16 NHWC [N, h, w, C] (decode + EntropyModel.dequantize in one coder launch,
-        the int32 symbols are never written) when the tables allow it; `stage_back` takes either."""
-        eb = self.bottleneck_layer.entropy_bottleneck
-        hw = hw_shape[0] * hw_shape[1]
-        buf, off, nb, st = eb.encode_symbols_device(sym, hw)
-        if dequantized:
-            y_hat = eb.decode_dequantize_device(buf, off, nb, sym.shape[1], hw_shape)
-            if y_hat is not None:
-                return y_hat, nb, st
-        dec = eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw)
-        return dec, nb, st
+    def stage_coder(self, payload, meta, **kwargs):
+        """rANS encode to byte streams, then decode them: -> (decoded, nbytes [N], status [N]) of the bottleneck's `stage_coder`
+        (FP bottleneck, `dequantized=True`: the dequantised latent as bf16 NHWC straight from the coder's last pass)."""
+        bl = self.bottleneck_layer
+        if hasattr(bl, 'stage_coder'):
+            return bl.stage_coder(payload, meta, **kwargs)
+        return FPBasedResNetBottleneck.stage_coder(bl, payload, meta, **kwargs)
 
     def decode_head(self, y_hat_nhwc):
         """decoder + task head on a dequantised bf16 NHWC latent.  In bf16 eval with the HIP head, the decoder's last conv takes
@@ -316,23 +366,19 @@ class SplittableResNet(UpdatableBackbone):
                 return self.head(feats)
         return self.head(bl.synthesis_nhwc(y_hat_nhwc))
 
-    def stage_decoder(self, dec_sym, hw_shape):
-        """dequantise + decoder: decoded symbols -> features (the MFMA-bound half of the back stage)."""
-        if dec_sym.dtype == torch.bfloat16:
-            return self.bottleneck_layer.synthesis_nhwc(dec_sym)
-        _, y_hat_nhwc = self.bottleneck_layer.entropy_bottleneck.dequantize_device(dec_sym, hw_shape)
-        return self.bottleneck_layer.synthesis_nhwc(y_hat_nhwc)
+    def stage_decoder(self, decoded, meta):
+        """dequantise + decoder: what the coder stage returned -> features (the MFMA-bound half of the back stage)."""
+        bl = self.bottleneck_layer
+        y_hat = bl.stage_decode(decoded, meta) if hasattr(bl, 'stage_decode') else FPBasedResNetBottleneck.stage_decode(bl, decoded, meta)
+        return bl.synthesis_nhwc(y_hat)
 
-    def stage_back(self, dec_sym, hw_shape, after_decoder=None):
-        """dequantise + decoder + task head.  `after_decoder()` is called between the two (bench.py records an event
-        there: the encoder stage of a later batch is scheduled beside the head's HBM-bound kernels, not beside the
-        decoder's MFMA-bound ones)."""
+    def stage_back(self, decoded, meta, after_decoder=None):
+        """dequantise + decoder + task head.  `after_decoder()` is called between the two."""
         if after_decoder is None:
-            if dec_sym.dtype == torch.bfloat16:      # stage_coder(..., dequantized=True): already the NHWC latent
-                return self.decode_head(dec_sym)
-            _, y_hat_nhwc = self.bottleneck_layer.entropy_bottleneck.dequantize_device(dec_sym, hw_shape)
-            return self.decode_head(y_hat_nhwc)
-        feats = self.stage_decoder(dec_sym, hw_shape)
+            bl = self.bottleneck_layer
+            y_hat = bl.stage_decode(decoded, meta) if hasattr(bl, 'stage_decode') else FPBasedResNetBottleneck.stage_decode(bl, decoded, meta)
+            return self.decode_head(y_hat)
+        feats = self.stage_decoder(decoded, meta)
         after_decoder()
         return self.head(feats)
 

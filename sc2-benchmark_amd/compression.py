@@ -114,6 +114,27 @@ class FactorizedPrior(CompressionModel):
         x_hat = self.synthesis_nhwc(y_hat_nhwc).clamp_(0, 1)
         return {'x_hat': x_hat}
 
+    # ---- compress -> decompress in stages (pipeline.StagePipeline through NeuralInputCompressionClassifier)
+    stage_front_takes_out = False
+
+    def stage_front(self, x, out=None):
+        y = self.analysis(x)
+        return self.entropy_bottleneck.symbols_device(y), tuple(y.shape[-2:])
+
+    def stage_coder(self, sym, hw_shape, dequantized=False):
+        eb = self.entropy_bottleneck
+        hw = hw_shape[0] * hw_shape[1]
+        buf, off, nb, st = eb.encode_symbols_device(sym, hw)
+        if dequantized:
+            y_hat = eb.decode_dequantize_device(buf, off, nb, sym.shape[1], hw_shape)
+            if y_hat is not None:
+                return y_hat, nb, st
+        return eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw), nb, st
+
+    def stage_back(self, decoded, hw_shape):
+        y_hat = decoded if decoded.dtype == torch.bfloat16 else self.entropy_bottleneck.dequantize_device(decoded, hw_shape)[1]
+        return self.synthesis_nhwc(y_hat).clamp_(0, 1)
+
     @classmethod
     def from_state_dict(cls, state_dict):
         N = state_dict['g_a.0.weight'].size(0)

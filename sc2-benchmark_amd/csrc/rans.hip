@@ -1103,7 +1103,7 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
                        int n_streams, int64_t n_sym, const int32_t *cdfs, int n_cdfs, int cdf_stride,
                        const int32_t *cdf_sizes, const int32_t *offsets, int32_t *symbols_out,
                        int32_t *status, void *workspace, int64_t workspace_bytes, void *stream, const float *medians,
-                       void *y_hat) {
+                       void *y_hat, void *ev_dq_begin = nullptr, void *ev_dq_end = nullptr) {
     int rc = check_common(indexes, index_div, n_streams, n_sym, cdfs, n_cdfs, cdf_stride, cdf_sizes, offsets);
     if (rc != SC2_OK) return rc;
     SC2_REQUIRE(in && in_offset && in_nbytes && (symbols_out || y_hat || n_sym == 0) && status && workspace,
@@ -1149,8 +1149,10 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
                 const int HW = (int)index_div;
                 const size_t dq_lds = (size_t)64 * (kDqP * n_cdfs * 2 + 16);
                 allow_big_lds(rans_dec_finish_dq_kernel, dq_lds);
+                if (ev_dq_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_begin), s);
                 hipLaunchKernelGGL(rans_dec_finish_dq_kernel, dim3((HW + kDqP - 1) / kDqP, n_blocks), dim3(256), dq_lds, s, a, medians,
                                    static_cast<uint16_t *>(y_hat), n_cdfs, HW);
+                if (ev_dq_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_end), s);
                 SC2_CHECK_LAUNCH();
             }
             if (symbols_out) {
@@ -1232,4 +1234,19 @@ extern "C" int sc2_rans_decode_dequantize_batch(const uint8_t *in, int64_t in_st
     SC2_REQUIRE(y_hat_bf16_nhwc, SC2_ERR_INVALID_ARG, "rans_decode_dequantize: null output");
     return decode_impl(in, in_stride, in_offset, in_nbytes, nullptr, index_div, n_streams, n_sym, cdfs, n_cdfs, cdf_stride, cdf_sizes,
                        offsets, symbols_out, status, workspace, workspace_bytes, stream, medians, y_hat_bf16_nhwc);
+}
+
+// The same call with two caller-owned hipEvent_t recorded on `stream` directly around its last pass (dequantise + NHWC
+// transposition): that pass is EntropyModel.dequantize of the reference's decode (sc2bench/models/layer.py:520) and belongs to
+// the bottleneck forward, not to the serial coder -- bench.py times it with these events.  Either may be NULL.
+extern "C" int sc2_rans_decode_dequantize_batch_ev(const uint8_t *in, int64_t in_stride, const int32_t *in_offset,
+                                                   const int32_t *in_nbytes, int64_t index_div, int n_streams, int64_t n_sym,
+                                                   const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
+                                                   const int32_t *offsets, const float *medians, int32_t *symbols_out,
+                                                   void *y_hat_bf16_nhwc, int32_t *status, void *workspace, int64_t workspace_bytes,
+                                                   void *stream, void *ev_dequantize_begin, void *ev_dequantize_end) {
+    SC2_REQUIRE(y_hat_bf16_nhwc, SC2_ERR_INVALID_ARG, "rans_decode_dequantize: null output");
+    return decode_impl(in, in_stride, in_offset, in_nbytes, nullptr, index_div, n_streams, n_sym, cdfs, n_cdfs, cdf_stride, cdf_sizes,
+                       offsets, symbols_out, status, workspace, workspace_bytes, stream, medians, y_hat_bf16_nhwc,
+                       ev_dequantize_begin, ev_dequantize_end);
 }

@@ -176,6 +176,33 @@ class _UpdatableDenseModel(AnalyzableModule):
             analyzer.clear()
         self._body().clear_analysis()
 
+    # ---- the updated eval forward in stages (pipeline.StagePipeline): the body's stages, the dense head behind its back stage.
+    #      meta = (the body's meta, input height x width): the segmentation head resizes to the input
+    @property
+    def stage_front_takes_out(self):
+        return bool(getattr(self._body(), 'stage_front_takes_out', False))
+
+    @property
+    def stage_coder_kwargs(self):
+        return dict(getattr(self._body(), 'stage_coder_kwargs', {}))
+
+    def stages_ready(self):
+        body = self._body()
+        return hasattr(body, 'stages_ready') and body.stages_ready()
+
+    def stage_front(self, x, out=None):
+        payload, meta = self._body().stage_front(x, out=out) if out is not None else self._body().stage_front(x)
+        return payload, (meta, tuple(x.shape[-2:]))
+
+    def stage_coder(self, payload, meta, **kwargs):
+        return self._body().stage_coder(payload, meta[0], **kwargs)
+
+    def stage_back(self, decoded, meta):
+        return self._finish(self._body().stage_back(decoded, meta[0]), meta[1])
+
+    def _finish(self, features, input_shape):
+        raise NotImplementedError()
+
 
 # ------------------------------------------------------------------------------------------------ detection
 class UpdatableBackboneWithFPN(_UpdatableDenseModel):
@@ -196,10 +223,12 @@ class UpdatableBackboneWithFPN(_UpdatableDenseModel):
     def _body(self):
         return self.body
 
-    def forward(self, x):
-        feats = self.body(x)
+    def _finish(self, feats, input_shape=None):
         ref_dtype = self.fpn.inner_blocks[0][0].weight.dtype
         return self.fpn(OrderedDict((k, v.to(ref_dtype)) for k, v in feats.items()))
+
+    def forward(self, x):
+        return self._finish(self.body(x))
 
     def check_if_updatable(self):
         return self.body.check_if_updatable()
@@ -299,14 +328,15 @@ class BaseSegmentationModel(_UpdatableDenseModel):
         w = next(head.parameters())
         return F.interpolate(head(feat.to(w.dtype)), size=size, mode='bilinear', align_corners=False)
 
-    def forward(self, x):
-        input_shape = x.shape[-2:]
-        features = self.backbone(x)
+    def _finish(self, features, input_shape):
         result = OrderedDict()
         result['out'] = self._head(self.classifier, features['out'], input_shape)
         if self.aux_classifier is not None:
             result['aux'] = self._head(self.aux_classifier, features['aux'], input_shape)
         return result
+
+    def forward(self, x):
+        return self._finish(self.backbone(x), x.shape[-2:])
 
 
 def create_deeplabv3(backbone, num_input_channels=2048, uses_aux=False, num_aux_channels=1024, num_classes=21):

@@ -920,6 +920,25 @@ class GaussianConditional(_HostTablesMixin, nn.Module):
         return hip.gc_symbols_indexes(None, scales.float(), None, self.scale_table.float().contiguous(),
                                       scale_bound=self._scale_bound, want_symbols=False)[1]
 
+    # ---- stage-wise device API (pipeline.StagePipeline: the serial coder on its own HIP stream)
+    def symbols_indexes_device(self, inputs, scales, means=None):
+        """quantize(inputs, 'symbols', means) and build_indexes(scales) in ONE pass: -> (symbols, indexes), int32 like `inputs`."""
+        _require_device(inputs, 'GaussianConditional.symbols_indexes')
+        if self.scale_table.numel() == 0:
+            raise ValueError('Uninitialized scale table. Run update() first')
+        return hip.gc_symbols_indexes(inputs.float().contiguous(), scales.float(), None if means is None else means.float(),
+                                      self.scale_table.float().contiguous(), scale_bound=self._scale_bound)
+
+    def encode_symbols_device(self, sym, indexes, out_stride=None):
+        """int32 symbols / indexes [N, n] -> (buf, offset, nbytes, status) on the device."""
+        cdf, cdf_len, offset = self._tables()
+        return hip.rans_encode_batch(sym, cdf, cdf_len, offset, indexes=indexes.int().contiguous(), out_stride=out_stride)
+
+    def decode_symbols_device(self, buf, off, nb, indexes):
+        """-> (int32 symbols [N, n], status [N]) on the device."""
+        cdf, cdf_len, offset = self._tables()
+        return hip.rans_decode_batch(buf, off, nb, indexes.shape[1], cdf, cdf_len, offset, indexes=indexes.int().contiguous())
+
     # ---- entropy coding on the device
     def compress_device(self, inputs, indexes, means=None, out_stride=None):
         """f32 [N,C,*spatial], int32 indexes -> (buf, offset, nbytes, status) on the device."""

@@ -45,9 +45,60 @@ class Meter(object):
         return self.total / max(1, self.count)
 
 
+def _pipelined(model, data_loader, device, pipeline):
+    """True if evaluate() should run the batches through `pipeline.StagePipeline`: an updated bottleneck model on a HIP device,
+    batches of more than one image (the reference measures data size at batch size 1, README.md:100-108: those runs keep the
+    per-batch forward, bytes objects and analyzers), and no analyzer that wants the compressed object of every batch."""
+    if pipeline is False or device.type != 'cuda':
+        return False
+    from .pipeline import supports_stages
+    if not supports_stages(model):
+        return False
+    if getattr(model, 'analyzes_after_compress', False) and getattr(model, 'analyzers', None):
+        return False
+    return pipeline is True or (getattr(data_loader, 'batch_size', None) or 1) > 1
+
+
+def _evaluate_pipelined(model, data_loader, device, max_samples, pipeline_kwargs):
+    """The loop of evaluate() on the stage pipeline: front stages run ahead, the range coder of several batches shares a
+    launch on its own HIP stream, top-1 / top-5 hits are counted on the device behind each back stage -- the host reads
+    two numbers at the end instead of two per batch.  -> (correct@1, correct@5, samples) as floats."""
+    from .pipeline import StagePipeline
+    pipe = StagePipeline(model, device, **(pipeline_kwargs or {}))
+    hits = torch.zeros(2, dtype=torch.float64, device=device)
+    targets = {}
+    seen = [0]
+
+    def batches():
+        for i, (image, target) in enumerate(data_loader):
+            if max_samples is not None and seen[0] >= max_samples:
+                return
+            targets[i] = target.to(device, non_blocking=True)
+            seen[0] += len(image)
+            yield image.to(device, non_blocking=True)
+
+    def on_output(step, output, nbytes, status):
+        target = targets.pop(step)
+        _, preds = output.float().topk(5, 1, True, True)
+        corrects = preds.t().eq(target[None])
+        hits[0] += corrects[:1].sum(dtype=torch.float64)
+        hits[1] += corrects[:5].sum(dtype=torch.float64)
+
+    record = {}
+    pipe.run(batches(), on_output=on_output, record=record)
+    pipe.synchronize()
+    from .entropy import _raise_on_status
+    for st in record['statuses']:       # every coder launch of the run, read once at the end
+        _raise_on_status(st, 'evaluate (stage pipeline)')
+    h = hits.cpu()
+    return float(h[0]), float(h[1]), seen[0]
+
+
 @torch.inference_mode()
-def evaluate(model, data_loader, device, max_samples=None, log_freq=1000, title=None):
-    """-> {'acc1', 'acc5', 'samples', 'seconds', 'analysis': [summaries]}."""
+def evaluate(model, data_loader, device, max_samples=None, log_freq=1000, title=None, pipeline=None, pipeline_kwargs=None):
+    """-> {'acc1', 'acc5', 'samples', 'seconds', 'analysis': [summaries]}.  `pipeline`: None = the stage pipeline
+    (sc2bench_amd/pipeline.py) when the model is an updated bottleneck model on a HIP device and the loader's batches hold more
+    than one image; True / False force it on / off."""
     model = model.to(device) if device.type == 'cuda' else model
     if hasattr(model, 'use_cpu4compression') and device.type != 'cuda':
         model.use_cpu4compression()
@@ -60,7 +111,12 @@ def evaluate(model, data_loader, device, max_samples=None, log_freq=1000, title=
     acc1, acc5 = Meter(), Meter()
     t0 = time.perf_counter()
     seen = 0
-    for i, (image, target) in enumerate(data_loader):
+    pipelined = _pipelined(model, data_loader, device, pipeline)
+    if pipelined:
+        c1, c5, seen = _evaluate_pipelined(model, data_loader, device, max_samples, pipeline_kwargs)
+        acc1.total, acc1.count = 100.0 * c1, seen       # (Meter: sum of percent x batch size, and the sample count)
+        acc5.total, acc5.count = 100.0 * c5, seen
+    for i, (image, target) in enumerate(() if pipelined else data_loader):
         if isinstance(image, torch.Tensor):
             image = image.to(device, non_blocking=True)
         if isinstance(target, torch.Tensor):
@@ -84,7 +140,8 @@ def evaluate(model, data_loader, device, max_samples=None, log_freq=1000, title=
     if analyzable and model.activated_analysis:
         model.summarize()
         analysis = [a.summary() for a in model.analyzers if hasattr(a, 'summary') and getattr(a, 'file_size_list', None)]
-    return {'acc1': top1, 'acc5': top5, 'samples': seen, 'samples_all_ranks': int(seen_all), 'seconds': time.perf_counter() - t0, 'analysis': analysis}
+    return {'acc1': top1, 'acc5': top5, 'samples': seen, 'samples_all_ranks': int(seen_all), 'seconds': time.perf_counter() - t0, 'analysis': analysis,
+            'pipeline': 'stage pipeline (sc2bench_amd/pipeline.py)' if pipelined else 'none: module forward per batch'}
 
 
 def build_data_loader(dataset_dict, loader_config):

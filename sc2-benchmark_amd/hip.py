@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
-    'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch',
+    'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch', 'sc2_rans_decode_dequantize_batch_ev',
     'sc2_mse_partial_len', 'sc2_mse_sum_bf16', 'sc2_mse_grad_bf16', 'sc2_relu_bwd_bf16',
     'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
 ]
@@ -47,6 +47,34 @@ class ConvDesc(ctypes.Structure):
 
 class Sc2Error(RuntimeError):
     pass
+
+
+def library_fingerprint():
+    """{'lib_sha256': hash of the libsc2amd.so this process loads, 'csrc_sha256': hash of the kernel sources beside it (csrc/*.hip,
+    *.h, *.cpp and include/sc2_bottleneck.h, names and contents in sorted order)}: what a committed measurement of the kernels
+    (profiles/traffic.json) records, so that a reader -- bench.py -- can tell whether it still describes the library that runs.
+    The source hash survives a rebuild (hipcc's output is not guaranteed to be byte-reproducible), the library hash a checkout
+    without sources."""
+    import hashlib
+    out = {'lib_sha256': None, 'csrc_sha256': None}
+    path = os.environ.get('SC2_LIB') or LIB_PATH
+    if os.path.exists(path):
+        h = hashlib.sha256()
+        with open(path, 'rb') as f:
+            for blk in iter(lambda: f.read(1 << 20), b''):
+                h.update(blk)
+        out['lib_sha256'] = h.hexdigest()
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(here, 'csrc')
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.hip', '.h', '.cpp'))) if os.path.isdir(csrc) else []
+    header = os.path.join(here, '..', 'include', 'sc2_bottleneck.h')
+    if files and os.path.exists(header):
+        h = hashlib.sha256()
+        for f in files + [header]:
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, 'rb').read())
+        out['csrc_sha256'] = h.hexdigest()
+    return out
 
 
 def lib():
@@ -122,6 +150,7 @@ def lib():
     L.sc2_rans_decode_batch.argtypes = [vp, i64, vp, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, i64,
                                         vp]
     L.sc2_rans_decode_dequantize_batch.argtypes = [vp, i64, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    L.sc2_rans_decode_dequantize_batch_ev.argtypes = [vp, i64, vp, vp, i64, i32, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     L.sc2_mse_partial_len.argtypes = [ctypes.c_longlong]
     L.sc2_mse_sum_bf16.argtypes = [vp, vp, ctypes.c_longlong, vp, vp]
     L.sc2_mse_grad_bf16.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, vp]
@@ -176,9 +205,14 @@ class KernelTimer(object):
 
     def summary(self):
         out = {}
-        for tag, e0, e1 in self.records:
-            out.setdefault(tag, []).append(e0.elapsed_time(e1))
+        for rec in self.records:
+            out.setdefault(rec[0], []).append(rec[1].elapsed_time(rec[2]))
         return {k: (len(v), sum(v) / len(v)) for k, v in out.items()}
+
+    def total_ms(self, tag):
+        """sum of the durations of every launch tagged `tag` (launches that cover different amounts of work, e.g. the coder's
+        dequantise pass over 1, 2, 4 or 8 steps' streams, have no meaningful mean)."""
+        return sum(rec[1].elapsed_time(rec[2]) for rec in self.records if rec[0] == tag)
 
 
 class _timed(object):
@@ -215,7 +249,7 @@ def _ptr(t):
 # --------------------------------------------------------------------------------------------- #
 # layout
 # --------------------------------------------------------------------------------------------- #
-def nchw_f32_to_nhwc_bf16(x, cpad=None):
+def nchw_f32_to_nhwc_bf16(x, cpad=None, tag=None):
     """x: f32 [N,C,H,W] contiguous -> bf16 tensor of shape [N,H,W,Cpad] (NHWC memory)."""
     _dev(x, 'x')
     assert x.dtype == torch.float32 and x.dim() == 4
@@ -223,7 +257,8 @@ def nchw_f32_to_nhwc_bf16(x, cpad=None):
     N, C, H, W = x.shape
     cpad = C if cpad is None else cpad
     y = torch.empty((N, H, W, cpad), dtype=torch.bfloat16, device=x.device)
-    _check(lib().sc2_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(y), N, C, H, W, cpad, _stream()), 'nchw_f32_to_nhwc_bf16')
+    with _timed(tag or 'layout.nchw_to_nhwc'):
+        _check(lib().sc2_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(y), N, C, H, W, cpad, _stream()), 'nchw_f32_to_nhwc_bf16')
     return y
 
 
@@ -1370,11 +1405,23 @@ def rans_decode_dequantize_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, 
     st = torch.empty((n_streams,), dtype=torch.int32, device=dev)
     ws_bytes = int(lib().sc2_rans_workspace_bytes(n_streams, n_sym, cdfs.shape[0], cdfs.shape[1]))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    # the last pass of the call (dequantise + NHWC transposition) is EntropyModel.dequantize of the reference's decode: an active
+    # KernelTimer that selects 'dec.dequantize' gets its own event pair around it (recorded by the library on this stream)
+    t = KernelTimer.active
+    ev = None
+    if t is not None and (t.select is None or t.select('dec.dequantize')):
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for e in ev:
+            e.record()         # creates the hipEvent_t; the library records it again where it belongs
+        t.records.append(('dec.dequantize', ev[0], ev[1], n_streams))
     with _timed('rans_decode'):
-        _check(lib().sc2_rans_decode_dequantize_batch(_ptr(buf), stride, _ptr(off), _ptr(nb), int(index_div), n_streams, int(n_sym),
-                                                      _ptr(cdfs), cdfs.shape[0], cdfs.shape[1], _ptr(cdf_sizes), _ptr(offsets),
-                                                      _ptr(medians), _ptr(sym) if want_symbols else None, _ptr(y_hat), _ptr(st),
-                                                      _ptr(ws), ws_bytes, _stream()), 'rans_decode_dequantize_batch')
+        _check(lib().sc2_rans_decode_dequantize_batch_ev(_ptr(buf), stride, _ptr(off), _ptr(nb), int(index_div), n_streams, int(n_sym),
+                                                         _ptr(cdfs), cdfs.shape[0], cdfs.shape[1], _ptr(cdf_sizes), _ptr(offsets),
+                                                         _ptr(medians), _ptr(sym) if want_symbols else None, _ptr(y_hat), _ptr(st),
+                                                         _ptr(ws), ws_bytes, _stream(),
+                                                         ctypes.c_void_p(ev[0].cuda_event) if ev else None,
+                                                         ctypes.c_void_p(ev[1].cuda_event) if ev else None),
+               'rans_decode_dequantize_batch')
     return y_hat, st, sym
 
 

@@ -288,7 +288,7 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                 if x.shape[-1] % 2:      # odd width (513): one zero column, exactly what the conv's own padding would read
                     x = torch.nn.functional.pad(x, (0, 1))
                     N, _, H, W = x.shape
-                x4 = hip.nchw_f32_to_nhwc_bf16(x, 4)                      # [N,H,W,4]
+                x4 = hip.nchw_f32_to_nhwc_bf16(x, 4, tag='enc.layout')    # [N,H,W,4]
                 xp = x4.view(N, H, W // 2, 8)                             # pixel pairs
             if in_place:
                 pass
@@ -476,6 +476,37 @@ class FPBasedResNetBottleneck(BaseBottleneck):
                                                                   want_nhwc=True)
         return self.synthesis_nhwc(y_hat_nhwc)
 
+    # ---- the eval forward (encode -> bytes -> decode) cut into stages for `pipeline.StagePipeline`: the serial range coder
+    #      of several batches then shares one launch on its own HIP stream while the MFMA streams work on neighbouring batches
+    stage_front_takes_out = True     # stage_front(x, out=): the last encoder conv writes the coder's symbols into `out` itself
+    stage_coder_kwargs = {'dequantized': True}   # what a pipeline passes to stage_coder (plain calls return the int32 symbols)
+
+    def stage_front(self, x, out=None):
+        """encoder + quantisation (layer.py:496-506 up to the coder): -> (symbols int32 [N, C*h*w], (h, w)).  `out`: a contiguous
+        int32 [N, C*h*w] tensor to write the symbols into (a row block of the buffer one range-coder launch will read)."""
+        sym = self.analysis(x, symbols_for=self.entropy_bottleneck, out=out)
+        return sym.view(sym.shape[0], -1), tuple(sym.shape[-2:])
+
+    def stage_coder(self, sym, hw_shape, dequantized=False):
+        """rANS encode to byte streams, then decode them (layer.py:506 + :520): -> (decoded, nbytes [N], status [N]).
+        `dequantized`: `decoded` is the dequantised latent as bf16 NHWC [N, h, w, C] (decode + EntropyModel.dequantize in one
+        coder launch, the int32 symbols are never written) when the tables allow it, else the int32 symbols."""
+        eb = self.entropy_bottleneck
+        hw = hw_shape[0] * hw_shape[1]
+        buf, off, nb, st = eb.encode_symbols_device(sym, hw)
+        if dequantized:
+            y_hat = eb.decode_dequantize_device(buf, off, nb, sym.shape[1], hw_shape)
+            if y_hat is not None:
+                return y_hat, nb, st
+        dec = eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw)
+        return dec, nb, st
+
+    def stage_decode(self, decoded, hw_shape):
+        """what `stage_coder` returned -> the dequantised latent, bf16 NHWC (the input of `synthesis_nhwc`)."""
+        if decoded.dtype == torch.bfloat16:
+            return decoded
+        return self.entropy_bottleneck.dequantize_device(decoded, hw_shape)[1]
+
     def _get_means(self, x):
         medians = self.entropy_bottleneck._get_medians().detach()
         spatial_dims = len(x.size()) - 2
@@ -655,6 +686,48 @@ class SHPBasedResNetBottleneck(BaseBottleneck):
         _, y_hat_nhwc = self.gaussian_conditional.decompress_to_device(strings[0], indices, means_hat, want_f32=False,
                                                                        want_nhwc=True)
         return self.synthesis_nhwc(y_hat_nhwc)
+
+    # ---- the same eval forward in stages (pipeline.StagePipeline)
+    stage_front_takes_out = False
+    stage_coder_kwargs = {}
+
+    def stage_front(self, x, out=None):
+        """encode() up to the coders (layer.py:630-647 / 765-776): g_a, h_a, the hyper-latent's symbols, the Gaussian parameters
+        from its dequantised form, and in ONE pass the latent's symbols and their CDF-row indexes:
+        -> ((y symbols [N, C*h*w], indexes [N, C*h*w], z symbols [N, L*hz*wz]), ((h, w), (hz, wz)))."""
+        y = self.analysis(x)
+        z = self.hyper_analysis(y)
+        eb, gc = self.entropy_bottleneck, self.gaussian_conditional
+        z_shape = tuple(z.shape[-2:])
+        z_sym = eb.symbols_device(z)
+        _, z_hat_nhwc = eb.dequantize_device(z_sym, z_shape, want_f32=False, want_nhwc=True)
+        scales_hat, means_hat = self._params(self.hyper_synthesis(z_hat_nhwc))
+        y_sym, idx = gc.symbols_indexes_device(y, scales_hat, means_hat)
+        N = y.shape[0]
+        return (y_sym.view(N, -1), idx.view(N, -1), z_sym), (tuple(y.shape[-2:]), z_shape)
+
+    def stage_coder(self, payload, meta):
+        """Both byte streams of every image are produced (layer.py:646-647) and then decoded as decode() decodes them
+        (layer.py:650-666 / 779-786): z from ITS bytes, the Gaussian parameters from the decoded z, the indexes from those, y
+        from its bytes with these indexes: -> (y_hat bf16 NHWC [N, h, w, C], nbytes of both streams [N], status [N])."""
+        y_sym, idx, z_sym = payload
+        (h, w), (hz, wz) = meta
+        eb, gc = self.entropy_bottleneck, self.gaussian_conditional
+        N = y_sym.shape[0]
+        zb, zo, znb, zst = eb.encode_symbols_device(z_sym, hz * wz)
+        yb, yo, ynb, yst = gc.encode_symbols_device(y_sym, idx)
+        z_dec = eb.decode_symbols_device(zb, zo, znb, z_sym.shape[1], hz * wz)
+        _, z_hat_nhwc = eb.dequantize_device(z_dec, (hz, wz), want_f32=False, want_nhwc=True)
+        scales_hat, means_hat = self._params(self.hyper_synthesis(z_hat_nhwc))
+        idx2 = gc.build_indexes(scales_hat)
+        y_dec, dst = gc.decode_symbols_device(yb, yo, ynb, idx2.view(N, -1))
+        C = y_sym.shape[1] // (h * w)
+        _, y_hat_nhwc = hip.gc_dequantize(y_dec.view(N, C, h, w), None if means_hat is None else means_hat.float(),
+                                          want_f32=False, want_nhwc=True)
+        return y_hat_nhwc, ynb + znb, yst | zst | dst
+
+    def stage_decode(self, decoded, meta):
+        return decoded
 
     def _get_means(self, x):
         medians = self.entropy_bottleneck._get_medians().detach()

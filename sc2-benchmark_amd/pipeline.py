@@ -1,0 +1,270 @@
+"""Software pipeline of the updated bottleneck's evaluation forward over HIP streams.
+
+The reference evaluates batch by batch: `output = model(image)` = encode -> bytes -> decode -> task head, one after the other
+(script/task/image_classification.py:106-145 -> sc2bench/models/backbone.py:229-233 -> layer.py:496-521).  On a GPU the range
+coder in the middle is a serial state machine per image: ~20 ms of LATENCY for a 224 x 224 latent whatever the batch size,
+during which the matrix cores idle.  This module runs the same forward cut into the three stages every updated model of
+this package exposes
+
+    stage_front(x[, out=])        encoder (+ hyper transforms) + quantisation        -> (payload, meta)
+    stage_coder(payload, meta)    rANS encode to byte streams, then decode them      -> (decoded, nbytes, status)
+    stage_back(decoded, meta)     (hyper synthesis +) dequantise + decoder + head    -> output
+
+as an event-driven pipeline: the front stages run ahead on one HIP stream, the coder stages of up to `coder_group`
+consecutive batches share ONE launch of the two serial kernels on one of `coder_streams` coder streams (a coder launch is one
+wave per 64 image streams: its duration is per-stream latency and does not grow with the stream count; fewer, wider launches
+also cost the MFMA kernels beside them less), and each back stage waits for its coder launch on the
+decoder + head stream.  Nothing is skipped and nothing is reordered inside a batch: every batch's byte streams are really
+produced and really decoded, outputs are bit-identical to the unpipelined forward (tests/test_gpu_pipeline.py).
+
+`payload` / `decoded` are a tensor or a tuple of tensors whose leading dimension is the batch: the pipeline concatenates
+the payloads of a group along it and hands each batch its slice of what the coder returns.  A model whose `stage_front`
+accepts `out=` (SplittableResNet on the FP bottleneck: the last encoder conv writes the coder's int32 symbols itself) gets a
+row block of the group's shared buffer to write into, so nothing is concatenated.  Batches of a group must agree in `meta`
+(the latent's spatial size); a change of shape closes the group early.
+"""
+import torch
+
+__all__ = ['StagePipeline', 'supports_stages']
+
+
+def supports_stages(model):
+    """True if `model` is an updated bottleneck model that exposes the three stages (and is ready to run them)."""
+    return all(callable(getattr(model, n, None)) for n in ('stage_front', 'stage_coder', 'stage_back')) and \
+        bool(getattr(model, 'stages_ready', lambda: True)())
+
+
+def _as_tuple(v):
+    return v if isinstance(v, tuple) else (v,)
+
+
+def _like(v, parts):
+    return tuple(parts) if isinstance(v, tuple) else parts[0]
+
+
+class StagePipeline(object):
+    """Event-driven front / coder-group / back scheduler over any model with `stage_front / stage_coder / stage_back`.
+
+    :param model: updated model in eval mode on `device`
+    :param coder_group: G = batches whose streams share one range-coder launch
+    :param coder_streams: HIP streams for coder launches (= coder launches that may be in flight)
+    :param max_inflight: front stage i waits for back stage i - max_inflight (bounds memory and host run-ahead)
+    :param ramp: the first groups of a run hold 1, 2, 4, ... batches, so that the first back stage starts after one coder
+                 latency instead of after G front stages
+    :param lag: batches between issuing front stage i and back stage i - lag in host order (0: as soon as its coder launch is)
+    :param coder_kwargs: keyword arguments of `stage_coder`; None = the model's `stage_coder_kwargs` (FP bottleneck:
+                         dequantized=True, the coder's last pass writes the bf16 NHWC latent the decoder reads)
+    """
+
+    def __init__(self, model, device, coder_group=8, coder_streams=4, max_inflight=24, ramp=True, lag=0,
+                 front_priority=0, back_priority=0, coder_priority=0, back_streams=1, coder_kwargs=None, share_buffer=True):
+        self.model = model
+        self.device = torch.device(device)
+        self.G = max(1, int(coder_group))
+        self.max_inflight = max(1, int(max_inflight))
+        self.ramp = bool(ramp)
+        self.lag = min(max(0, int(lag)), self.max_inflight - 1)
+        self.front_stream = torch.cuda.Stream(device=self.device, priority=front_priority)
+        self.back_streams = [torch.cuda.Stream(device=self.device, priority=back_priority) for _ in range(max(1, back_streams))]
+        self.coder_streams = [torch.cuda.Stream(device=self.device, priority=coder_priority)
+                              for _ in range(max(1, min(int(coder_streams), 13)))]
+        self.coder_kwargs = dict(getattr(model, 'stage_coder_kwargs', {}) if coder_kwargs is None else coder_kwargs)
+        self.share_buffer = bool(share_buffer) and bool(getattr(model, 'stage_front_takes_out', False))
+        self._payload_cols = None     # columns of the single-tensor payload (learned from the first front stage)
+        self._payload_dtype = None
+
+    # ---- plan ------------------------------------------------------------------------------------------------------ #
+    def group_plan(self, n_steps):
+        """sizes of the coder groups of a run of n_steps batches: 1, 2, 4, ... up to G, then G."""
+        sizes, g = [], (1 if self.ramp else self.G)
+        while sum(sizes) < n_steps:
+            sizes.append(min(g, self.G, n_steps - sum(sizes)))
+            g *= 2
+        return sizes
+
+    def describe(self):
+        return {'hip_streams': {'encoder': 1, 'decoder+head': len(self.back_streams), 'range_coder': len(self.coder_streams)},
+                'steps_per_coder_launch': self.G, 'max_inflight_steps': self.max_inflight, 'ramp': self.ramp}
+
+    def synchronize(self):
+        self.front_stream.synchronize()
+        for s in self.back_streams + self.coder_streams:
+            s.synchronize()
+        torch.cuda.synchronize(self.device)
+
+    # ---- the run --------------------------------------------------------------------------------------------------- #
+    def run(self, inputs, n_steps=None, on_output=None, record=None):
+        """Runs every batch of `inputs` (an iterable of input batches resident on the device, or ONE tensor used for each of
+        `n_steps` batches) through the three stages.  `on_output(step, output, nbytes, status)` is called in batch order,
+        INSIDE the back stage's stream context, right after that stage has been issued (device work that consumes `output`
+        there is ordered behind it; nothing has been waited for).  Returns the number of batches issued; the caller
+        synchronises (`synchronize()`).
+
+        `record`: a dict that receives 'statuses' (status vector of every coder launch), 'latency' ([step, front-start event,
+        back-end event] of every 8th batch) and, if it holds 'timeline': [], (stage, first step, start, end) event tuples."""
+        if isinstance(inputs, torch.Tensor):
+            assert n_steps is not None, 'a single input tensor needs n_steps'
+            x_single, it = inputs, None
+        else:
+            x_single, it = None, iter(inputs)
+            if n_steps is None and hasattr(inputs, '__len__'):
+                n_steps = len(inputs)
+        model, dev = self.model, self.device
+        timeline = record.get('timeline') if record is not None else None
+        statuses = record.setdefault('statuses', []) if record is not None else None
+        latency = record.setdefault('latency', []) if record is not None else None
+
+        def tl_event(stream):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            return e
+
+        plan = self.group_plan(n_steps) if n_steps is not None else None
+        pending = {}          # step -> (decoded slice, nbytes slice, status slice, meta, coder-done event, whole tensors)
+        back_done = {}        # step -> event at the end of its back stage
+        group = []            # (step, payload, meta, front-done event, written into the shared buffer?)
+        gbuf = [None]
+        launches = [0]
+        state = {'issued_back': 0}
+
+        def group_target():
+            if plan is not None:
+                return plan[launches[0]] if launches[0] < len(plan) else self.G
+            return min(self.G, 1 << launches[0]) if self.ramp else self.G      # (open-ended input: same ramp, no tail trim)
+
+        def flush():
+            cs = self.coder_streams[launches[0] % len(self.coder_streams)]
+            launches[0] += 1
+            with torch.cuda.stream(cs):
+                for _, g_pl, _, g_ev, _ in group:
+                    cs.wait_event(g_ev)
+                    for t in _as_tuple(g_pl):
+                        t.record_stream(cs)
+                first = group[0][1]
+                if len(group) == 1:
+                    payload = first
+                elif gbuf[0] is not None and all(g[4] for g in group):
+                    payload = gbuf[0][:len(group) * group[0][1].shape[0]]     # every front stage wrote its row block: nothing to copy
+                    payload.record_stream(cs)
+                else:
+                    cols = list(zip(*[_as_tuple(g[1]) for g in group]))
+                    payload = _like(first, [torch.cat(c) for c in cols])
+                gbuf[0] = None
+                meta = group[0][2]
+                tl0 = tl_event(cs) if timeline is not None else None
+                decoded, nb, st = model.stage_coder(payload, meta, **self.coder_kwargs)
+                if tl0 is not None:
+                    timeline.append(('coder', group[0][0], tl0, tl_event(cs)))
+                ev2 = torch.cuda.Event()
+                ev2.record(cs)
+                if statuses is not None:
+                    statuses.append(st)
+            sizes = [_as_tuple(g[1])[0].shape[0] for g in group]
+            o = 0
+            whole = _as_tuple(decoded)
+            for (step, _, _, _, _), n in zip(group, sizes):
+                sl = slice(o, o + n)
+                pending[step] = (_like(decoded, [t[sl] for t in whole]), nb[sl], st[sl], meta, ev2, whole)
+                o += n
+            group.clear()
+
+        def issue_backs(i, last):
+            while state['issued_back'] in pending and (i - state['issued_back'] >= self.lag or last):
+                j = state['issued_back']
+                state['issued_back'] += 1
+                dec, nb, st, meta, ev2, whole = pending.pop(j)
+                bs = self.back_streams[j % len(self.back_streams)]
+                with torch.cuda.stream(bs):
+                    bs.wait_event(ev2)
+                    for t in whole:
+                        t.record_stream(bs)
+                    nb.record_stream(bs)
+                    tl0 = tl_event(bs) if timeline is not None else None
+                    out = model.stage_back(dec, meta)
+                    if tl0 is not None:
+                        timeline.append(('back', j, tl0, tl_event(bs)))
+                    if on_output is not None:
+                        on_output(j, out, nb, st)
+                    back_done[j] = torch.cuda.Event()
+                    back_done[j].record(bs)
+                    if latency is not None and j % 8 == 0:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record(bs)
+                        for r in latency:
+                            if r[0] == j:
+                                r[2] = e1
+
+        i = 0
+        with torch.no_grad():
+            x = x_single
+            while True:
+                if it is not None:
+                    try:
+                        x = next(it)
+                    except StopIteration:
+                        break
+                    # the batch was produced (copied to the device) on the caller's current stream: the encoder stream waits for
+                    # that work and the allocator learns that the encoder stream reads the block
+                    self.front_stream.wait_stream(torch.cuda.current_stream(dev))
+                    x.record_stream(self.front_stream)
+                elif i >= n_steps:
+                    break
+                last = (n_steps is not None and i == n_steps - 1)
+                with torch.cuda.stream(self.front_stream):
+                    if i - self.max_inflight in back_done:
+                        # bound the run-ahead of the host and of the encoder stream: memory in flight, latency per batch,
+                        # and the caching allocator keeps recycling cross-stream blocks instead of calling hipMalloc
+                        back_done.pop(i - self.max_inflight).synchronize()
+                    if latency is not None and i % 8 == 0:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record(self.front_stream)
+                        latency.append([i, e0, None])
+                    tl0 = tl_event(self.front_stream) if timeline is not None else None
+                    n = x.shape[0]
+                    g_size = group_target()
+                    out = None
+                    if (self.share_buffer and g_size > 1 and self._payload_cols is not None and
+                            (gbuf[0] is None or gbuf[0].shape[0] >= (len(group) + 1) * n)):
+                        if gbuf[0] is None:      # one buffer per coder group; front stage k writes row block k
+                            gbuf[0] = torch.empty((g_size * n, self._payload_cols), dtype=self._payload_dtype, device=dev)
+                        out = gbuf[0][len(group) * n:(len(group) + 1) * n]
+                    if out is not None:
+                        payload, meta = model.stage_front(x, out=out)
+                    else:
+                        payload, meta = model.stage_front(x)
+                    if isinstance(payload, torch.Tensor) and payload.dim() == 2:
+                        self._payload_cols, self._payload_dtype = payload.shape[1], payload.dtype
+                    if tl0 is not None:
+                        timeline.append(('front', i, tl0, tl_event(self.front_stream)))
+                    ev = torch.cuda.Event()
+                    ev.record(self.front_stream)
+                if group and (group[0][2] != meta or _as_tuple(group[0][1])[0].shape[0] != n):
+                    flush()          # another latent shape (or a ragged last batch): this batch opens a new group
+                    issue_backs(i, False)
+                group.append((i, payload, meta, ev, out is not None))
+                if len(group) >= group_target() or last:
+                    flush()
+                # back stages of every batch whose coder launch has been issued, oldest first: they wait for the coder's
+                # event on their own stream, the encoder stream runs ahead
+                issue_backs(i, last)
+                i += 1
+            if group:
+                flush()
+            issue_backs(i, True)
+        assert not pending and not group and state['issued_back'] == i
+        return i
+
+    def warm(self, x, n_steps):
+        """Resource warm-up, not a step: one range-coder launch per coder group SHAPE of a run of n_steps batches like `x`, on
+        the coder stream that group will use, so that the run makes no first-time device allocation (a freshly booted box
+        pays ~45 ms for the ~2 GB of workspace / stream buffers of the 8-batch groups otherwise)."""
+        with torch.no_grad():
+            with torch.cuda.stream(self.front_stream):
+                payload, meta = self.model.stage_front(x)
+            self.front_stream.synchronize()
+            for li, g in enumerate(self.group_plan(n_steps)):
+                cs = self.coder_streams[li % len(self.coder_streams)]
+                with torch.cuda.stream(cs):
+                    pl = payload if g == 1 else _like(payload, [torch.cat([t] * g) for t in _as_tuple(payload)])
+                    self.model.stage_coder(pl, meta, **self.coder_kwargs)
+        self.synchronize()

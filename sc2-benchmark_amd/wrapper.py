@@ -96,6 +96,29 @@ class NeuralInputCompressionClassifier(AnalyzableModule):
             from . import hip
             raise hip.Sc2Error('uses_cpu4compression_model: the compression model of this build runs on a HIP device only')
 
+    # ---- the same forward in stages (pipeline.StagePipeline): the codec's serial range coder on its own HIP stream
+    stage_front_takes_out = False
+    stage_coder_kwargs = {'dequantized': True}
+
+    def stages_ready(self):
+        cm = self.compression_model
+        return (cm is not None and hasattr(cm, 'stage_front') and not self.training and next(cm.parameters()).is_cuda and
+                cm.entropy_bottleneck._quantized_cdf.numel() > 0)
+
+    def stage_front(self, x, out=None):
+        if self.pre_transform is not None:
+            x = self.pre_transform(x)
+        return self.compression_model.stage_front(x)
+
+    def stage_coder(self, payload, meta, **kwargs):
+        return self.compression_model.stage_coder(payload, meta, **kwargs)
+
+    def stage_back(self, decoded, meta):
+        x = self.compression_model.stage_back(decoded, meta)
+        if self.post_transform is not None:
+            x = self.post_transform(x)
+        return self.classification_model(x)
+
     def forward(self, x):
         if self.pre_transform is not None:
             x = self.pre_transform(x)

@@ -57,6 +57,7 @@ def test_rccl_world1_inference_and_training_as_child_processes():
     line = _torchrun_bench(['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-bs1'])
     assert line['n_gpus'] == 1 and line['steps'] == 2 and line['unit'] == 'images/s' and line['value'] > 0
     assert line['config']['process_group'].startswith('nccl'), line['config']['process_group']
+    assert line['config']['ranks_reduced'] == 1, 'the device all-reduce of 1 over the RCCL group must count this rank'
     assert line['scaling'] == 'weak' and line['config']['sharding'] == 'images, no collective'
     # ---- training step: broadcast, hook-launched bucket all-reduces, scalar reductions, all on RCCL with HIP tensors
     tr = _torchrun_bench(['--mode', 'train', '--steps', '2', '--warmup', '1', '--bs', '32'],

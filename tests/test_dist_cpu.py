@@ -217,7 +217,9 @@ def test_bench_torchrun_dry_run_world2():
     rec = json.loads(lines[0])
     assert rec['dry_run'] and rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['warmup'] == 1
     assert rec['config']['global_batch'] == 2 * rec['config']['batch_per_gpu']
-    assert rec['ranks'] == [{'rank': 0, 'local_rank': 0, 'seed': 0}, {'rank': 1, 'local_rank': 1, 'seed': 1}]
+    assert [{k: q[k] for k in ('rank', 'local_rank', 'seed')} for q in rec['ranks']] == \
+        [{'rank': 0, 'local_rank': 0, 'seed': 0}, {'rank': 1, 'local_rank': 1, 'seed': 1}]
+    assert [q['shard'] for q in rec['ranks']] == [[0, 256], [256, 512]] and rec['config']['ranks_reduced'] == 2
     assert rec['scaling'] == 'weak' and rec['value'] > 0
 
 
@@ -236,6 +238,32 @@ def test_bench_self_launch_dry_run_world2():
     rec = json.loads(lines[0])
     assert rec['dry_run'] and rec['n_gpus'] == 2 and rec['steps'] == 3
     assert [q['rank'] for q in rec['ranks']] == [0, 1]
+
+
+def test_bench_self_launch_dry_run_world8():
+    """The driver's 8-GPU launch shape on gloo (no device): `bench.py --gpus 8 --dry-run` starts eight ranks itself; the shards of
+    the global batch are disjoint and cover it, an all-reduce on the backend counts eight ranks, and the reported time is the MAX
+    over ranks (rank r sleeps (1 + r) ms per step: the line must carry rank 7's time, not rank 0's)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '5', '--warmup', '1', '--bs', '256', '--dry-run']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, 'exactly one JSON line from rank 0: {}'.format(r.stdout)
+    rec = json.loads(lines[0])
+    assert rec['dry_run'] and rec['n_gpus'] == 8 and rec['config']['global_batch'] == 2048 and rec['config']['ranks_reduced'] == 8
+    ranks = rec['ranks']
+    assert [q['rank'] for q in ranks] == list(range(8)) and sorted(q['seed'] for q in ranks) == list(range(8))
+    shards = sorted(tuple(q['shard']) for q in ranks)
+    assert shards[0][0] == 0 and shards[-1][1] == 2048
+    assert all(a[1] == b[0] for a, b in zip(shards, shards[1:])), 'shards overlap or leave a gap: {}'.format(shards)
+    slowest = max(q['own_elapsed_s'] for q in ranks)
+    assert slowest >= 5 * 0.008 and ranks[0]['own_elapsed_s'] < slowest
+    assert rec['ms_per_step'] * 5e-3 >= slowest - 1e-6, 'the line does not carry the MAX over ranks'
+    assert abs(rec['value'] - 2048 * 5 / (rec['ms_per_step'] * 5e-3)) < 1e-6 * rec['value']
 
 
 def test_bench_refuses_gpus_world_mismatch():

@@ -1,0 +1,121 @@
+"""-m gpu: sc2bench_amd/pipeline.py -- the stage pipeline (front stages ahead, the range coder of G batches in one launch on its
+own HIP stream, back stages behind it) produces, batch for batch, exactly what the unpipelined eval forward of the same model
+produces (sc2bench/models/backbone.py:229-233 / layer.py:496-521 / 764-817 run one after the other), for every model class that
+exposes the three stages: the FP bottleneck classifier, the mean-scale-hyperprior classifier, the DeepLabv3 and FPN bodies and
+the neural input-compression classifier; and evaluation.evaluate() on it counts the same hits as the per-batch loop."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _equal(a, b, what):
+    if isinstance(a, dict):
+        assert list(a.keys()) == list(b.keys()), what
+        for k in a:
+            _equal(a[k], b[k], '{}[{}]'.format(what, k))
+        return
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    assert torch.equal(a, b), '{}: pipelined output != unpipelined forward (max diff {})'.format(
+        what, (a.float() - b.float()).abs().max().item())
+
+
+def _run_both(S, model, batches, dev, **pipe_kwargs):
+    """every batch through model(x) and through the pipeline; -> (reference outputs, pipelined outputs, nbytes per batch)"""
+    assert S.supports_stages(model)
+    with torch.no_grad():
+        ref = [model(x) for x in batches]
+    torch.cuda.synchronize(dev)
+    got, nbs = {}, {}
+
+    def keep(step, out, nb, st):
+        got[step] = out
+        nbs[step] = nb
+
+    pipe = S.StagePipeline(model, dev, **pipe_kwargs)
+    rec = {}
+    n = pipe.run(list(batches), on_output=keep, record=rec)
+    pipe.synchronize()
+    assert n == len(batches) and sorted(got) == list(range(len(batches)))
+    from sc2bench_amd.entropy import _status_or
+    assert all(_status_or(st) == 0 for st in rec['statuses'])
+    return ref, [got[i] for i in range(len(batches))], [nbs[i] for i in range(len(batches))]
+
+
+@pytest.fixture(scope='module')
+def bench_mod():
+    import bench
+    return bench
+
+
+def test_fp_classifier_pipelined_equals_forward(S, dev, bench_mod):
+    """the headline model: five batches, groups of 1 + 2 + 2 (ramp, G = 2), shared symbol buffer; logits bit for bit, and the
+    streams' byte counts those of encode()."""
+    model = bench_mod.build_model(dev)
+    batches = [bench_mod.synthetic_batch(8, dev, seed=s) for s in range(5)]
+    ref, got, nbs = _run_both(S, model, batches, dev, coder_group=2, coder_streams=2)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        _equal(a, b, 'batch {}'.format(i))
+    with torch.no_grad():
+        enc = model.bottleneck_layer.encode(batches[3])
+    assert nbs[3].cpu().tolist() == [len(s) for s in enc['strings'][0]]
+    # the same through concatenated payloads (no shared buffer), no ramp, one group of five
+    ref2, got2, _ = _run_both(S, model, batches, dev, coder_group=8, coder_streams=1, ramp=False, share_buffer=False)
+    for i, (a, b) in enumerate(zip(got2, ref2)):
+        _equal(a, b, 'batch {} (cat)'.format(i))
+
+
+def test_fp_classifier_ragged_last_batch_and_shape_change(S, dev, bench_mod):
+    """a loader's last batch is smaller, and a batch of another image size closes its group early: outputs unchanged."""
+    model = bench_mod.build_model(dev)
+    g = torch.Generator().manual_seed(3)
+    batches = [bench_mod.synthetic_batch(6, dev, seed=1), bench_mod.synthetic_batch(6, dev, seed=2),
+               (torch.rand(6, 3, 160, 192, generator=g) * 2 - 1).to(dev), bench_mod.synthetic_batch(6, dev, seed=4),
+               bench_mod.synthetic_batch(3, dev, seed=5)]
+    ref, got, _ = _run_both(S, model, batches, dev, coder_group=4, coder_streams=2, ramp=False)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        _equal(a, b, 'batch {}'.format(i))
+
+
+def test_mshp_classifier_pipelined_equals_forward(S, dev, bench_mod):
+    """mean-scale hyperprior (layer.py:764-817): y with per-symbol CDF rows rebuilt from the DECODED z, both streams through
+    the batched coder, three batches in groups of 1 + 2."""
+    model, x, _, _, _ = bench_mod.build_workload('mshp224', dev, 6)
+    batches = [bench_mod.synthetic_batch(6, dev, seed=s) for s in (0, 7, 8)]
+    ref, got, nbs = _run_both(S, model, batches, dev, coder_group=2, coder_streams=2)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        _equal(a, b, 'batch {}'.format(i))
+    with torch.no_grad():
+        enc = model.bottleneck_layer.encode(batches[1])
+    assert nbs[1].cpu().tolist() == [len(y) + len(z) for y, z in zip(*enc['strings'])]
+
+
+@pytest.mark.parametrize('name,n,hw', [('seg513', 2, (513, 513)), ('det800x1216', 1, (320, 416)), ('fp_input', 4, (224, 224))])
+def test_dense_and_input_compression_pipelined_equals_forward(S, dev, bench_mod, name, n, hw):
+    """DeepLabv3 (dict of resized logits), the FPN body (dict of pyramid levels) and the neural input-compression classifier."""
+    model, _, _, _, _ = bench_mod.build_workload(name, dev, n)
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.rand(n, 3, hw[0], hw[1], generator=g).to(dev) for _ in range(3)]
+    ref, got, _ = _run_both(S, model, batches, dev, coder_group=2, coder_streams=2)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        _equal(a, b, '{} batch {}'.format(name, i))
+
+
+def test_evaluate_on_the_pipeline_counts_the_same_hits(S, dev, bench_mod):
+    """evaluation.evaluate(): pipelined (device-side hit counters, no .item() per batch) == per-batch loop, on a loader whose last
+    batch is ragged; a loader of batch size 1 keeps the per-batch forward (the reference's data-size measurement mode)."""
+    from sc2bench_amd import evaluation
+    model = bench_mod.build_model(dev)
+    x = bench_mod.synthetic_batch(22, torch.device('cpu'), seed=2)
+    with torch.no_grad():
+        labels = model(x.to(dev)).float().argmax(1).cpu()
+    labels[::3] = (labels[::3] + 1) % 1000            # two thirds of the top-1 predictions are "right"
+    ds = torch.utils.data.TensorDataset(x, labels)
+    loader = torch.utils.data.DataLoader(ds, batch_size=8)
+    a = evaluation.evaluate(model, loader, dev, pipeline=False)
+    b = evaluation.evaluate(model, loader, dev, pipeline_kwargs={'coder_group': 2, 'coder_streams': 2})
+    assert b['pipeline'].startswith('stage pipeline') and a['pipeline'].startswith('none')
+    assert a['samples'] == b['samples'] == 22
+    assert abs(a['acc1'] - b['acc1']) < 1e-9 and abs(a['acc5'] - b['acc5']) < 1e-9 and 50.0 < a['acc1'] < 80.0
+    c = evaluation.evaluate(model, torch.utils.data.DataLoader(ds, batch_size=1), dev, max_samples=4)
+    assert c['pipeline'].startswith('none') and c['samples'] == 4

@@ -42,4 +42,12 @@ for tag, pat in TAGS.items():
                          'write_bytes': v['write_bytes'], 'launches_sampled': v['launches'],
                          'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/layer_times.py --bs 256'}
             break
+# which library these counters describe: bench.py reports `roofline.traffic` from profiles/traffic.json only while one of the two
+# hashes still matches the library it runs (VERDICT r4 item 7 iii)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import sc2bench_amd
+    tags['_measured_on'] = sc2bench_amd.hip.library_fingerprint()
+except Exception as e:   # (the table is still written; bench.py then has nothing to match and drops `traffic`)
+    tags['_measured_on'] = {'error': repr(e)}
 json.dump(tags, open(os.path.join(out, 'traffic_tags.json'), 'w'), indent=1)
