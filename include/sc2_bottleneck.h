@@ -127,6 +127,11 @@ typedef struct sc2_conv_desc {
      * ow*out_stride_w + out_off_w) of an NHWC tensor [N,out_H,out_W,Cout]; pixels outside it are dropped. */
     int32_t out_H, out_W, out_stride_h, out_stride_w, out_off_h, out_off_w;
     int32_t k_order;               /* enum sc2_conv_k_order */
+    /* filter dilation (0 or 1 = none), sc2_conv2d_fwd only: tap (kh, kw) reads input pixel (oh*stride_h - pad_h + kh*dil_h, ..);
+     * OH = (H + 2 pad_h - dil_h (KH - 1) - 1) / stride_h + 1.  The atrous layers of the dense-prediction models
+     * (sc2bench/models/segmentation/deeplabv3.py ASPP rates 12 / 24 / 36; torchvision's `replace_stride_with_dilation` layer3 /
+     * layer4): Cout > 96, plain epilogues (NONE / BIAS / BIAS_RELU / BIAS_ADD_RELU / GDN / IGDN / ADD), dense output. */
+    int32_t dil_h, dil_w;
 } sc2_conv_desc;
 
 /* Rows the packed weight buffer must have for a given Cout (zero rows beyond Cout). */

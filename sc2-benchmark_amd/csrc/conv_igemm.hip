@@ -22,6 +22,7 @@ extern template int launch<G_96>(const ConvArgs &, hipStream_t);
 extern template int launch<G_64>(const ConvArgs &, hipStream_t);
 extern template int launch<G_48>(const ConvArgs &, hipStream_t);
 extern template int launch<G_32>(const ConvArgs &, hipStream_t);
+extern template int launch<Gd_128>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_128>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_96>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_64>(const ConvArgs &, hipStream_t);
@@ -105,8 +106,11 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
                 "conv2d: Cin (%d) and Cout (%d) must be multiples of 8", d->Cin, d->Cout);
     SC2_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride_h > 0 && d->stride_w > 0 && d->pad_h >= 0 && d->pad_w >= 0,
                 SC2_ERR_INVALID_ARG, "conv2d: bad filter geometry");
-    int OH = (d->H + 2 * d->pad_h - d->KH) / d->stride_h + 1;
-    int OW = (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1;
+    SC2_REQUIRE(d->dil_h >= 0 && d->dil_w >= 0, SC2_ERR_INVALID_ARG, "conv2d: negative dilation");
+    const int dil_h = d->dil_h > 0 ? d->dil_h : 1, dil_w = d->dil_w > 0 ? d->dil_w : 1;   // (0 = 1: descriptors written before the field existed)
+    const bool dilated = dil_h != 1 || dil_w != 1;
+    int OH = (d->H + 2 * d->pad_h - dil_h * (d->KH - 1) - 1) / d->stride_h + 1;
+    int OW = (d->W + 2 * d->pad_w - dil_w * (d->KW - 1) - 1) / d->stride_w + 1;
     const bool scatter = d->out_H > 0;
     if (scatter) {
         // transposed-convolution use: the caller fixes the number of output rows/cols (rows past the symmetric
@@ -182,7 +186,18 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     }
     a.o_H = scatter ? d->out_H : 0; a.o_W = d->out_W; a.o_sh = d->out_stride_h; a.o_sw = d->out_stride_w;
     a.o_h0 = d->out_off_h; a.o_w0 = d->out_off_w;
+    a.DH = dil_h; a.DW = dil_w;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dilated) {
+        // atrous convolution: the generic 128-wide tile with the dilation compiled in (every other instantiation -- static
+        // geometries, window / patch staging, the 8-wave tiles -- derives input coordinates from undilated taps)
+        SC2_REQUIRE(!fused && !scatter && d->Cout_pad % 128 == 0 && !(d->k_order & SC2_K_B_FRAG_MAJOR) &&
+                        d->a_op != SC2_AOP_SQUARE && d->epilogue != SC2_EPI_GDN2 && d->epilogue != SC2_EPI_IGDN2 &&
+                        d->out_format != SC2_OUT_I32_NCHW_SYM,
+                    SC2_ERR_UNSUPPORTED, "conv2d: a dilated convolution needs Cout > 96 (packed rows %% 128 == 0), a dense output and "
+                                         "one of the plain epilogues (got %d rows, epilogue %d)", d->Cout_pad, d->epilogue);
+        return launch<Gd_128>(a, s);
+    }
 
     const int rows = d->Cout_pad;
     if (d->k_order & SC2_K_B_FRAG_MAJOR) {

@@ -80,11 +80,15 @@ struct ConvArgs {
     int dbg;   // development switches (SC2_CONV_DEBUG): bit 0 skips the store epilogue, bit 1 the K loop
     unsigned x_bytes, w_bytes;   // sizes of x and of the packed weights when both are < 2 GB (buffer-addressed loads), else 0
     int o_H, o_W, o_sh, o_sw, o_h0, o_w0;   // NHWC output scatter (o_H == 0: dense): pixel (oh, ow) -> (oh*o_sh+o_h0, ..)
+    int DH, DW;                             // filter dilation (1 = none); read by the Cfg::DIL instantiations only
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_,
-          int PH_, int PW_, int STAGES_ = 2, bool EPX_ = false, bool SQ_ = false>
+          int PH_, int PW_, int STAGES_ = 2, bool EPX_ = false, bool SQ_ = false, bool DIL_ = false>
 struct Cfg {
+    // DIL: runtime filter dilation (ConvArgs::DH / DW): input pixel of tap (kh, kw) = (oh SH - PH + kh DH, ow SW - PW + kw DW).
+    // A compile-time property of its own instantiations (the atrous layers of the dense-prediction heads), like SQ.
+    static constexpr bool DIL = DIL_;
     // SQ: the squared-form GDN build (CompressAI GDN: SC2_AOP_SQUARE operand, SC2_EPI_GDN2 / _IGDN2 epilogues).  Its code
     // exists only in the instantiations that set it: in the shared epilogues a runtime case costs every kernel two
     // transcendental ops per element (measured +3 % on the decoder layers), so it is a compile-time property.
@@ -588,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     const int SW = C::STATIC ? C::SW : p.SW;
     const int PH = C::STATIC ? C::PH : p.PH;
     const int PW = C::STATIC ? C::PW : p.PW;
+    const int DH = C::DIL ? p.DH : 1, DW = C::DIL ? p.DW : 1;
     const int CIN8 = Cin >> 3;
     const int H = p.H, W = p.W;
 
@@ -665,14 +670,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
             int tap, cb;
             if (p.k_slab_major) { cb = kt / ntaps; tap = kt - cb * ntaps; }
             else { tap = kt / spt; cb = kt - tap * spt; }
-            t_kh = tap / KW;
-            t_kw = tap - t_kh * KW;
+            t_kh = (tap / KW) * DH;         // (input-row / -column offset of the tap: tap index x dilation)
+            t_kw = (tap - (tap / KW) * KW) * DW;
             tap_off = ((long long)t_kh * W + t_kw) * Cin + cb * 32 + kc * 8;
             tap_ok = kt < KT;
         } else {
-            t_kh = kh;
-            t_kw = kw;
-            tap_off = ((long long)kh * W + kw) * Cin + c8 * 8;
+            t_kh = kh * DH;
+            t_kw = kw * DW;
+            tap_off = ((long long)t_kh * W + t_kw) * Cin + c8 * 8;
             tap_ok = kh < KH;   // false for the K tail and for the dummy slabs past KT
         }
 #pragma unroll
@@ -1777,6 +1782,9 @@ using Gx_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, true>;
 using Gx_96 = Cfg<128, 96, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
 // squared-form GDN GEMMs (1x1 on x^2, rsqrt / sqrt epilogue): bmshj2018_factorized, N = 128 / 192 (rows 128 / 256)
 using Gq_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, false, true>;
+// dilated (atrous) convolutions: the generic 128-wide tile with the runtime dilation compiled in (DeepLab's ASPP branches,
+// sc2bench/models/segmentation/deeplabv3.py: rates 12 / 24 / 36 on the 2048-channel map; torchvision's dilated layer3 / layer4)
+using Gd_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, false, false, true>;
 using Gqx_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, true, true>;
 using Gx_64 = Cfg<128, 64, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
 using Gx_48 = Cfg<128, 48, 4, 1, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;

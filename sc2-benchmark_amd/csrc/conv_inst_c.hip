@@ -7,4 +7,5 @@ template int launch<G_96>(const ConvArgs &, hipStream_t);
 template int launch<G_64>(const ConvArgs &, hipStream_t);
 template int launch<G_48>(const ConvArgs &, hipStream_t);
 template int launch<G_32>(const ConvArgs &, hipStream_t);
+template int launch<Gd_128>(const ConvArgs &, hipStream_t);
 }  // namespace sc2conv

@@ -130,6 +130,145 @@ class FCNHead(nn.Sequential):
                          nn.Dropout(0.1), nn.Conv2d(inter, channels, 1))
 
 
+class HipDenseHead(object):
+    """A segmentation head (`DeepLabHead` / `FCNHead`) or a feature pyramid in eval mode on the library's kernels: every
+    conv (+ BatchNorm) (+ ReLU) is ONE folded `sc2_conv2d_fwd` launch on bf16 NHWC maps, the atrous branches of the ASPP
+    (sc2bench/models/segmentation/deeplabv3.py: rates 12 / 24 / 36 over the 2048-channel map) through the dilation field of the
+    descriptor.  Round 5: on torch ops these layers went to MIOpen's `naive_conv_*` kernels in bf16 (rocprofv3 of
+    `bench.py --workload seg513`: 90 % of the GPU time of a step) -- the reference leaves them to cuDNN, which has tuned
+    kernels for them; this is that role on this hardware."""
+
+    def __init__(self, module):
+        from .head import ConvSpec, _Conv
+        self._Conv, self._ConvSpec = _Conv, ConvSpec
+        self.module = module
+        self.key = self.version_key(module)
+        self.n_out = None
+        if isinstance(module, FeaturePyramidNetwork):
+            self.inner = [self._plain(b[0], 'fpn.inner{}'.format(i)) for i, b in enumerate(module.inner_blocks)]
+            self.layer = [self._plain(b[0], 'fpn.layer{}'.format(i)) for i, b in enumerate(module.layer_blocks)]
+            self.steps = None
+        else:
+            self.steps = self._sequence(list(module), 'seg')
+
+    @staticmethod
+    def version_key(module):
+        return tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+    @staticmethod
+    def supported(module):
+        if isinstance(module, FeaturePyramidNetwork):
+            return all(isinstance(b[0], nn.Conv2d) and b[0].groups == 1 for b in list(module.inner_blocks) + list(module.layer_blocks))
+        if not isinstance(module, nn.Sequential):
+            return False
+        ok = (nn.Conv2d, nn.BatchNorm2d, FrozenBatchNorm2d, nn.ReLU, nn.Dropout, ASPP)
+        return all(isinstance(m, ok) for m in module) and all(m.groups == 1 for m in module.modules() if isinstance(m, nn.Conv2d))
+
+    def _plain(self, conv, tag):
+        """a convolution with (or without) its own bias and no norm layer: -> (_Conv on Cout padded to a multiple of 8, Cout)"""
+        cout = conv.out_channels
+        cpad = (cout + 7) // 8 * 8
+        w = conv.weight.detach().float()
+        b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(cout, device=w.device)
+        if cpad != cout:
+            w = torch.cat([w, torch.zeros((cpad - cout,) + tuple(w.shape[1:]), device=w.device)])
+            b = torch.cat([b, torch.zeros(cpad - cout, device=w.device)])
+        c = self._Conv(self._ConvSpec(w, conv.stride, conv.padding, conv.dilation), None, tag)
+        c.b = b.contiguous()
+        return c, cout
+
+    def _sequence(self, mods, tag):
+        """[(kind, payload, relu)]: 'conv' (folded conv + norm), 'plain' (conv with bias), 'aspp'"""
+        from . import hip
+        steps, i = [], 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, ASPP):
+                branches = []
+                for bi, br in enumerate(m.convs):
+                    if isinstance(br, ASPPPooling):
+                        branches.append(('pool', self._Conv(br[1], br[2], '{}.aspp.pool'.format(tag))))
+                    else:
+                        branches.append(('conv', self._Conv(br[0], br[1], '{}.aspp.{}'.format(tag, bi))))
+                steps.append(('aspp', (branches, self._Conv(m.project[0], m.project[1], '{}.aspp.project'.format(tag))), True))
+                i += 1
+            elif isinstance(m, nn.Conv2d):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                if isinstance(nxt, (nn.BatchNorm2d, FrozenBatchNorm2d)) and m.bias is None:
+                    relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                    steps.append(('conv', self._Conv(m, nxt, '{}.{}'.format(tag, i)), relu))
+                    i += 3 if relu else 2
+                else:
+                    relu = isinstance(nxt, nn.ReLU)
+                    steps.append(('plain', self._plain(m, '{}.{}'.format(tag, i)), relu))
+                    i += 2 if relu else 1
+            elif isinstance(m, (nn.Dropout, nn.ReLU)):
+                i += 1
+            else:
+                raise hip.Sc2Error('HipDenseHead: unsupported module {}'.format(type(m).__name__))
+        return steps
+
+    def _aspp(self, x, branches, project):
+        from . import hip
+        N, H, W, _ = x.shape
+        outs = []
+        for kind, c in branches:
+            if kind == 'pool':     # AdaptiveAvgPool2d(1) -> 1x1 conv + norm + ReLU -> bilinear resize of a 1 x 1 map = a broadcast
+                pooled = hip.avgpool_nhwc(x, want_f32=False, want_bf16=True)[1].view(N, 1, 1, -1)
+                outs.append(c(pooled, hip.EPI_BIAS_RELU).expand(N, H, W, c.cout))
+            else:
+                outs.append(c(x, hip.EPI_BIAS_RELU))
+        return project(torch.cat(outs, dim=3), hip.EPI_BIAS_RELU)
+
+    def __call__(self, feat):
+        """feat: bf16 [N,C,H,W] (any memory format) -> bf16 logits [N,classes,H,W] (a view of NHWC memory)"""
+        from . import hip
+        x = feat.permute(0, 2, 3, 1).contiguous()      # a view when `feat` is channels_last (the HIP stacks' output)
+        n_out = x.shape[3]
+        for kind, payload, relu in self.steps:
+            if kind == 'aspp':
+                x = self._aspp(x, *payload)
+                n_out = x.shape[3]
+            elif kind == 'conv':
+                x = payload(x, hip.EPI_BIAS_RELU if relu else hip.EPI_BIAS)
+                n_out = payload.cout
+            else:
+                c, n_out = payload
+                x = c(x, hip.EPI_BIAS_RELU if relu else hip.EPI_BIAS)
+        return x[..., :n_out].permute(0, 3, 1, 2)
+
+    def fpn(self, feats):
+        """torchvision's FeaturePyramidNetwork.forward on bf16 maps: lateral 1x1 convs, top-down nearest upsampling + add,
+        3x3 output convs; -> (results, names) in the module's order (extra blocks are applied by the caller)."""
+        from . import hip
+        names = list(feats.keys())
+        xs = [v.permute(0, 2, 3, 1).contiguous() for v in feats.values()]
+        last_inner = self.inner[-1][0](xs[-1], hip.EPI_BIAS)
+        results = [self.layer[-1][0](last_inner, hip.EPI_BIAS)]
+        for idx in range(len(xs) - 2, -1, -1):
+            lateral = self.inner[idx][0](xs[idx], hip.EPI_BIAS)
+            top_down = F.interpolate(last_inner.permute(0, 3, 1, 2), size=lateral.shape[1:3], mode='nearest').permute(0, 2, 3, 1)
+            last_inner = (lateral + top_down).contiguous()
+            results.insert(0, self.layer[idx][0](last_inner, hip.EPI_BIAS))
+        return [r.permute(0, 3, 1, 2) for r in results], names
+
+
+def _hip_dense_head(owner, module, x):
+    """The cached `HipDenseHead` of `module` if this call can run on it (eval mode, bf16 parameters and bf16 features on a HIP
+    device, a supported structure), else None (the torch modules run)."""
+    import os
+    p = next(module.parameters(), None)
+    if (module.training or p is None or p.dtype != torch.bfloat16 or not x.is_cuda or x.dtype != torch.bfloat16 or
+            os.environ.get('SC2_DENSE_HEAD', '1') == '0' or not HipDenseHead.supported(module)):
+        return None
+    cache = owner.__dict__.setdefault('_hip_dense_heads', {})
+    ent = cache.get(id(module))
+    if ent is None or ent.module is not module or ent.key != HipDenseHead.version_key(module):
+        ent = HipDenseHead(module)
+        cache[id(module)] = ent
+    return ent
+
+
 # ------------------------------------------------------------------------------------------------ shared behaviour
 class _UpdatableDenseModel(AnalyzableModule):
     """Analysis / update calls reach the feature-extraction body that holds the bottleneck (`_body()`)."""
@@ -225,7 +364,14 @@ class UpdatableBackboneWithFPN(_UpdatableDenseModel):
 
     def _finish(self, feats, input_shape=None):
         ref_dtype = self.fpn.inner_blocks[0][0].weight.dtype
-        return self.fpn(OrderedDict((k, v.to(ref_dtype)) for k, v in feats.items()))
+        feats = OrderedDict((k, v.to(ref_dtype)) for k, v in feats.items())
+        hd = _hip_dense_head(self, self.fpn, next(iter(feats.values())))
+        if hd is not None:       # the pyramid's 1x1 / 3x3 convs on the library's kernels (bf16 eval)
+            results, names = hd.fpn(feats)
+            if self.fpn.extra_blocks is not None:
+                results, names = self.fpn.extra_blocks(results, list(feats.values()), names)
+            return OrderedDict(zip(names, results))
+        return self.fpn(feats)
 
     def forward(self, x):
         return self._finish(self.body(x))
@@ -326,7 +472,10 @@ class BaseSegmentationModel(_UpdatableDenseModel):
 
     def _head(self, head, feat, size):
         w = next(head.parameters())
-        return F.interpolate(head(feat.to(w.dtype)), size=size, mode='bilinear', align_corners=False)
+        feat = feat.to(w.dtype)
+        hd = _hip_dense_head(self, head, feat)
+        logits = hd(feat) if hd is not None else head(feat)
+        return F.interpolate(logits, size=size, mode='bilinear', align_corners=False)
 
     def _finish(self, features, input_shape):
         result = OrderedDict()

@@ -99,13 +99,16 @@ class _Conv(object):
         # Dilated 3x3 layers (DeepLab's layer3 / layer4, torchvision `replace_stride_with_dilation`): a stride-1 conv with
         # dilation d and padding d is d*d independent UNDILATED pad-1 convs on the phase grids x[a::d, b::d] -- the same
         # weights, the same kernels, outputs scattered back to y[a::d, b::d]
-        if self.dilation != (1, 1):
+        # (round 5: sc2_conv2d_fwd takes the dilation itself -- one launch on the generic tile with runtime dilation -- whenever the
+        #  layer has more than 96 output channels; narrower layers keep the phase-grid form below)
+        self.native_dilation = self.dilation != (1, 1) and self.k != (1, 1) and hip.weight_rows(self.cout) % 128 == 0
+        if self.dilation != (1, 1) and not self.native_dilation:
             d = self.dilation[0]
             ok = (self.k == (3, 3) and self.stride == (1, 1) and self.dilation == (d, d) and self.pad == (d, d)) or self.k == (1, 1)
             if not ok:
-                raise hip.Sc2Error('the HIP head supports dilation only on 3x3 stride-1 layers with padding == dilation '
-                                   '(got kernel {}, stride {}, padding {}, dilation {})'.format(self.k, self.stride, self.pad,
-                                                                                               self.dilation))
+                raise hip.Sc2Error('the HIP head supports dilation on layers of <= 96 output channels only as 3x3 stride-1 with '
+                                   'padding == dilation (got kernel {}, stride {}, padding {}, dilation {})'.format(
+                                       self.k, self.stride, self.pad, self.dilation))
 
     def _dilated(self, x, epilogue):
         d = self.dilation[0]
@@ -119,7 +122,10 @@ class _Conv(object):
         return y
 
     def __call__(self, x, epilogue, ep_x=None):
-        if self.dilation != (1, 1) and self.k == (3, 3):
+        if self.dilation != (1, 1) and self.k != (1, 1):
+            if self.native_dilation and os.environ.get('SC2_CONV_DILATION', '1') != '0':      # ('0': A/B, the phase grids)
+                return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,
+                                      ep_x=ep_x, ep_beta=self.b, tag=self.tag, k_order=self.k_order, dilation=self.dilation)
             assert ep_x is None
             return self._dilated(x, epilogue)
         if self.w_win1 is not None and epilogue in (hip.EPI_BIAS, hip.EPI_BIAS_RELU, hip.EPI_BIAS_ADD_RELU) and \

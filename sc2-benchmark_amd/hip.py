@@ -42,7 +42,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'N', 'H', 'W', 'Cin', 'Cout', 'KH', 'KW', 'stride_h', 'stride_w', 'pad_h', 'pad_w', 'OH', 'OW',
         'a_op', 'epilogue', 'out_format', 'Kpad', 'Cout_pad', 'out_H', 'out_W', 'out_stride_h', 'out_stride_w',
-        'out_off_h', 'out_off_w', 'k_order')]
+        'out_off_h', 'out_off_w', 'k_order', 'dil_h', 'dil_w')]
 
 
 class Sc2Error(RuntimeError):
@@ -481,11 +481,11 @@ def conv_fused_gdn_supported(x_shape, cout, kh, kw, stride, pad, out_format=OUT_
 
 def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilogue=EPI_NONE,
                out_format=OUT_BF16_NHWC, ep_x=None, ep_beta=None, out=None, tag=None, scatter=None,
-               k_order=K_TAP_MAJOR):
+               k_order=K_TAP_MAJOR, dilation=1):
     """x_nhwc: bf16 [N,H,W,Cin]; returns the output tensor.
 
     out_format OUT_BF16_NHWC -> bf16 [N,OH,OW,Cout]; OUT_F32_NCHW -> f32 [N,Cout,OH,OW];
-    OUT_F32_NHWC -> f32 [N,OH,OW,Cout].  stride / pad: int or (h, w).
+    OUT_F32_NHWC -> f32 [N,OH,OW,Cout].  stride / pad / dilation: int or (h, w) (dilation > 1: Cout > 96, plain epilogues).
     """
     _dev(x_nhwc, 'x')
     _dev(w_packed, 'w_packed')
@@ -493,9 +493,10 @@ def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilo
     assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous()
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    dh, dw = (dilation, dilation) if isinstance(dilation, int) else dilation
     N, H, W, Cin = x_nhwc.shape
-    OH = (H + 2 * ph - kh) // sh + 1
-    OW = (W + 2 * pw - kw) // sw + 1
+    OH = (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1
+    OW = (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
     sc = (0, 0, 0, 0, 0, 0)
     if scatter is not None:   # (OH, OW, out tensor [N,out_H,out_W,cout], stride_h, stride_w, off_h, off_w)
         OH, OW, out, s_h, s_w, o_h, o_w = scatter
@@ -503,7 +504,7 @@ def conv2d_fwd(x_nhwc, w_packed, cout, kh, kw, stride, pad, a_op=AOP_NONE, epilo
         assert out.shape[0] == N and out.shape[3] == cout
         sc = (out.shape[1], out.shape[2], s_h, s_w, o_h, o_w)
     d = ConvDesc(N, H, W, Cin, cout, kh, kw, sh, sw, ph, pw, OH, OW, a_op, epilogue, out_format,
-                 w_packed.shape[1], w_packed.shape[0], *(sc + (k_order,)))
+                 w_packed.shape[1], w_packed.shape[0], *(sc + (k_order, dh, dw)))
     if out is None:
         if out_format == OUT_BF16_NHWC:
             out = torch.empty((N, OH, OW, cout), dtype=torch.bfloat16, device=x_nhwc.device)

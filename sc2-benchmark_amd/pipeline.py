@@ -70,8 +70,7 @@ class StagePipeline(object):
                               for _ in range(max(1, min(int(coder_streams), 13)))]
         self.coder_kwargs = dict(getattr(model, 'stage_coder_kwargs', {}) if coder_kwargs is None else coder_kwargs)
         self.share_buffer = bool(share_buffer) and bool(getattr(model, 'stage_front_takes_out', False))
-        self._payload_cols = None     # columns of the single-tensor payload (learned from the first front stage)
-        self._payload_dtype = None
+        self._payload_shapes = {}     # input shape [C, H, W] -> (columns, dtype) of the single-tensor payload (learned per shape)
 
     # ---- plan ------------------------------------------------------------------------------------------------------ #
     def group_plan(self, n_steps):
@@ -124,6 +123,7 @@ class StagePipeline(object):
         back_done = {}        # step -> event at the end of its back stage
         group = []            # (step, payload, meta, front-done event, written into the shared buffer?)
         gbuf = [None]
+        gshape = [None]       # (rows per batch, columns) the shared buffer was made for
         launches = [0]
         state = {'issued_back': 0}
 
@@ -223,17 +223,21 @@ class StagePipeline(object):
                     n = x.shape[0]
                     g_size = group_target()
                     out = None
-                    if (self.share_buffer and g_size > 1 and self._payload_cols is not None and
-                            (gbuf[0] is None or gbuf[0].shape[0] >= (len(group) + 1) * n)):
-                        if gbuf[0] is None:      # one buffer per coder group; front stage k writes row block k
-                            gbuf[0] = torch.empty((g_size * n, self._payload_cols), dtype=self._payload_dtype, device=dev)
-                        out = gbuf[0][len(group) * n:(len(group) + 1) * n]
+                    known = self._payload_shapes.get(tuple(x.shape[1:]))     # (columns, dtype) of the payload of such an input
+                    if self.share_buffer and g_size > 1 and known is not None:
+                        if gbuf[0] is None and not group:      # one buffer per coder group; front stage k writes row block k
+                            gbuf[0] = torch.empty((g_size * n, known[0]), dtype=known[1], device=dev)
+                            gshape[0] = (n, known[0])
+                        # (a batch of another size or another image shape gets no block: it will close this group and open its own)
+                        if gbuf[0] is not None and gshape[0] == (n, known[0]) and gbuf[0].shape[0] >= (len(group) + 1) * n and \
+                                all(g[4] for g in group):
+                            out = gbuf[0][len(group) * n:(len(group) + 1) * n]
                     if out is not None:
                         payload, meta = model.stage_front(x, out=out)
                     else:
                         payload, meta = model.stage_front(x)
                     if isinstance(payload, torch.Tensor) and payload.dim() == 2:
-                        self._payload_cols, self._payload_dtype = payload.shape[1], payload.dtype
+                        self._payload_shapes[tuple(x.shape[1:])] = (payload.shape[1], payload.dtype)
                     if tl0 is not None:
                         timeline.append(('front', i, tl0, tl_event(self.front_stream)))
                     ev = torch.cuda.Event()

@@ -220,3 +220,76 @@ def test_deeplab_body_at_513_bf16_vs_oracle_tail(S, R, dev):
         out = model(x.to(dev))
         want = torch.nn.functional.interpolate(cls_ref(ref['out']), size=(513, 513), mode='bilinear', align_corners=False)
         _close(out['out'], want, 5e-2)      # + a bf16 ASPP head (torch ops) on top of the 3e-2 features
+
+
+def _randomise_norms(module):
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+            if isinstance(m, torch.nn.Conv2d) and m.bias is not None:
+                m.bias.normal_(0, 0.1)
+
+
+@pytest.mark.parametrize('N,H,W', [(2, 65, 65), (1, 33, 41)])
+def test_hip_dense_head_deeplab_and_fcn_vs_torch_f32(S, dev, N, H, W):
+    """Round 5: DeepLabHead (ASPP: 1x1, three ATROUS 3x3 convs at rates 12 / 24 / 36 through the descriptor's dilation field,
+    the pooling branch, projection; then 3x3 + classifier) and FCNHead folded onto the library's kernels, against the same
+    torch modules in f32 on the same bf16-rounded features (sc2bench/models/segmentation/deeplabv3.py:44-104): 2e-2 rel. L2."""
+    from sc2bench_amd import dense
+    torch.manual_seed(N + H)
+    for head, cin in ((dense.DeepLabHead(2048, 21), 2048), (dense.FCNHead(1024, 21), 1024)):
+        head.eval()
+        _randomise_norms(head)
+        x = (torch.randn(N, cin, H, W) * 0.5).to(torch.bfloat16)
+        with torch.no_grad():
+            ref = head.float()(x.float())
+        head = head.to(dev).to(torch.bfloat16)
+        assert dense.HipDenseHead.supported(head)
+        hd = dense.HipDenseHead(head)
+        with torch.no_grad():
+            got = hd(x.to(dev).contiguous(memory_format=torch.channels_last))
+        assert got.shape == ref.shape
+        _close(got, ref, 2e-2)
+
+
+def test_conv2d_fwd_dilation_vs_torch(S, dev):
+    """sc2_conv2d_fwd with the descriptor's dilation (the generic tile's Cfg::DIL instantiation): dilation 2 / 4 with padding ==
+    dilation (torchvision's dilated layer3 / layer4), 12 on a map smaller than the reach of its taps, unequal padding, stride 2;
+    tap-major and slab-major K; against F.conv2d on the bf16-rounded operands."""
+    import torch.nn.functional as F
+    hip = S.hip
+    torch.manual_seed(1)
+    for (cin, cout, k, stride, pad, dil, H, W, order) in [(64, 128, 3, 1, 2, 2, 19, 23, hip.K_TAP_MAJOR), (64, 256, 3, 1, 4, 4, 17, 9, hip.K_SLAB_MAJOR),
+                                                          (96, 128, 3, 1, 12, 12, 15, 20, hip.K_SLAB_MAJOR), (32, 128, 3, 2, 1, 3, 21, 21, hip.K_TAP_MAJOR),
+                                                          (40, 128, 2, 1, 0, 5, 14, 14, hip.K_TAP_MAJOR)]:
+        x = torch.randn(2, cin, H, W).to(torch.bfloat16)
+        w = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).to(torch.bfloat16)
+        ref = F.conv2d(x.float(), w.float(), stride=stride, padding=pad, dilation=dil)
+        got = hip.conv2d_fwd(x.to(dev).permute(0, 2, 3, 1).contiguous(), hip.pack_conv_weight(w.to(dev), order), cout, k, k, stride, pad,
+                             k_order=order, dilation=dil)
+        assert tuple(got.shape) == (2, ref.shape[2], ref.shape[3], cout)
+        _close(got.permute(0, 3, 1, 2), ref, 6e-3)
+
+
+def test_fpn_on_hip_kernels_vs_torch_f32(S, dev):
+    """The feature pyramid's lateral 1x1 and output 3x3 convs (with bias) on the library's kernels vs the torch module in f32."""
+    from collections import OrderedDict
+    from sc2bench_amd import dense
+    torch.manual_seed(3)
+    fpn = dense.FeaturePyramidNetwork([256, 512, 1024, 2048], 256, extra_blocks=dense.LastLevelMaxPool()).eval()
+    _randomise_norms(fpn)
+    shapes = [(256, 40, 52), (512, 20, 26), (1024, 10, 13), (2048, 5, 7)]
+    feats = OrderedDict((str(i), (torch.randn(2, c, h, w) * 0.5).to(torch.bfloat16)) for i, (c, h, w) in enumerate(shapes))
+    with torch.no_grad():
+        ref = fpn.float()(OrderedDict((k, v.float()) for k, v in feats.items()))
+    fpn = fpn.to(dev).to(torch.bfloat16)
+    hd = dense.HipDenseHead(fpn)
+    with torch.no_grad():
+        results, names = hd.fpn(OrderedDict((k, v.to(dev).contiguous(memory_format=torch.channels_last)) for k, v in feats.items()))
+    assert names == list(feats.keys())
+    for name, r in zip(names, results):
+        _close(r, ref[name], 2e-2)

