@@ -503,6 +503,199 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
     if (active) a.status[s] = corrupt | (rp > n_words ? kStatusCorrupt : 0);
 }
 
+// Round 5: ONE LDS round trip per symbol instead of two.  The chain of the decoder above is cum_freq -> symbol (lut) -> {start,
+// freq} (rowtab) -> state: two DEPENDENT LDS reads, ~80 cycles each on a wave that has its SIMD to itself.  An exact
+// one-lookup table needs 32 bits per cumulative frequency (256 KB per row); but the CDF row is wave-uniform for index_div
+// consecutive symbols, so a BUCKETED table per row can be staged in LDS: 8 192 buckets of eight cumulative frequencies, 8 bytes
+// each = 64 KB, the footprint of the byte-sized lut.  A bucket names the symbol A that owns its first value and, if A ends
+// inside the bucket, its successor B = A + 1 (symbols are consecutive, so B's start is A's end):
+//     dword 0 = start_A | (end_A - 1) << 16         dword 1 = (end_B - 1) | A << 16 | multi << 24
+// (ends are stored minus one: 65 536 fits 16 bits).  One ds_read_b64, then selects: the symbol is B iff cum_freq > end_A - 1.
+// `multi` marks a bucket that B does not finish either (two boundaries within eight values: symbols of probability < 2^-13,
+// the far tails of a trained table) -- such a symbol, like an escape, sends its 8-symbol chunk to the exact path, which finds
+// the symbol by bisection over the row's starts.  The tables are built by a parallel pre-pass into the workspace
+// (rans_build_dec_table_kernel: one thread per bucket) and copied row by row into LDS.  Rows of up to 257 entries (symbol
+// index < 256).  Same symbols out, bit for bit (tests/test_gpu_kernels.py: every decoder test runs through this kernel).
+constexpr int kBucketShift = 3, kBucketsPerRow = 65536 >> kBucketShift;      // 8 192 buckets x 8 B = 64 KB per row
+
+__global__ __launch_bounds__(256) void rans_build_dec_table_kernel(const int32_t *__restrict__ cdfs, const int32_t *__restrict__ cdf_sizes,
+                                                                   int n_rows, int cdf_stride, uint2 *__restrict__ tab) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)n_rows * kBucketsPerRow) return;
+    const int r = (int)(t / kBucketsPerRow), b = (int)(t - (long long)r * kBucketsPerRow);
+    const int32_t *cdf = cdfs + (long long)r * cdf_stride;
+    const int size = cdf_sizes[r];                  // entries; symbols 0 .. size - 2, cdf[size - 1] = 65536
+    const unsigned cf0 = (unsigned)b << kBucketShift;
+    int lo = 0, hi = size - 1;                      // A = last k with cdf[k] <= cf0
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((unsigned)cdf[mid] <= cf0) lo = mid; else hi = mid;
+    }
+    const int A = lo;
+    const unsigned start_a = (unsigned)cdf[A], end_a = (unsigned)cdf[A + 1];
+    const bool has_b = A + 2 <= size - 1;
+    const unsigned end_b = has_b ? (unsigned)cdf[A + 2] : end_a;
+    const unsigned multi = end_b < cf0 + (1u << kBucketShift) && end_b < 65536u ? 1u : 0u;
+    uint2 e;
+    e.x = (start_a & 0xFFFFu) | ((end_a - 1u) << 16);
+    e.y = ((end_b - 1u) & 0xFFFFu) | ((unsigned)A << 16) | (multi << 24);
+    tab[t] = e;
+}
+
+__global__ __launch_bounds__(64) void rans_dec_lut8_kernel(const RansArgs a, const uint2 *__restrict__ gtab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint2 *tab = reinterpret_cast<uint2 *>(smem);                                            // [8192]
+    uint32_t *win = reinterpret_cast<uint32_t *>(smem + kBucketsPerRow * 8);                 // [kWin][64]
+    uint32_t *rowtab = win + kWin * 64;                                                      // start | freq << 16 per symbol
+    const int lane = threadIdx.x;
+    const int blk = blockIdx.x;
+    const int s = blk * 64 + lane;
+    const bool active = s < a.n_streams;
+    const int sc = active ? s : a.n_streams - 1;
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)sc * a.stride + a.io_offset[sc]);
+    const int n_words = a.io_nbytes[sc] / 4;
+    uint32_t *wsb = a.ws + (long long)blk * a.n_sym * 64 + lane;
+    uint32_t *const wl = win + lane;
+
+    int corrupt = 0;
+    int lp = 0, rp = 0;
+    struct __attribute__((packed, aligned(4))) Words4 { uint32_t v[4]; };
+    uint32_t pre[16];
+    auto prefetch = [&]() {   // pre[] <- words [lp, lp + 16) of the lane's stream (zeros past its end)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lp + 4 * q;
+            Words4 t;
+            if (k + 3 < n_words) {
+                t = *reinterpret_cast<const Words4 *>(w + k);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t.v[e] = k + e < n_words ? w[k + e] : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pre[4 * q + e] = t.v[e];
+        }
+    };
+    prefetch();
+    auto top_up = [&]() {
+        const bool want = lp - rp <= kWin - 16;
+        if (want) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wl[((lp + j) & (kWin - 1)) * 64] = pre[j];
+            lp += 16;
+            prefetch();
+        }
+    };
+    auto ring = [&](int k) { return wl[(k & (kWin - 1)) * 64]; };
+    top_up();
+    top_up();
+    unsigned long long x = (unsigned long long)ring(0) | ((unsigned long long)ring(1) << 32);
+    rp = 2;
+    uint32_t wq = ring(rp), wq1 = ring(rp + 1);
+
+    const long long n_rows = a.n_sym == 0 ? 0 : (a.n_sym - 1) / a.index_div + 1;
+    for (long long row = 0; row < n_rows; ++row) {
+        const int32_t *cdf = a.cdfs + row * a.cdf_stride;
+        const int size = __builtin_amdgcn_readfirstlane(a.cdf_sizes[row]);
+        const int max_value = size - 2;
+        const int offset = __builtin_amdgcn_readfirstlane(a.offsets[row]);
+        __syncthreads();  // previous row's table reads are done
+        {   // this row's 64 KB of buckets: 64 lanes x 16 B per trip, eight trips in flight
+            const uint4 *src = reinterpret_cast<const uint4 *>(gtab + row * kBucketsPerRow) + lane;
+            uint4 *dst = reinterpret_cast<uint4 *>(tab) + lane;
+#pragma unroll 1
+            for (int it = 0; it < kBucketsPerRow * 8 / 16 / 64; it += 8) {
+                uint4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[(it + u) * 64];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dst[(it + u) * 64] = v[u];
+            }
+        }
+        for (int k = lane; k + 1 < size; k += 64) {
+            const uint32_t lo = (uint32_t)cdf[k], hi = (uint32_t)cdf[k + 1];
+            rowtab[k] = (lo & 0xFFFFu) | ((hi - lo) << 16);
+        }
+        __syncthreads();
+        const long long i_end = (row + 1) * a.index_div < a.n_sym ? (row + 1) * a.index_div : a.n_sym;
+        long long i = row * a.index_div;
+
+        // exact per-symbol path (escapes, multi-boundary buckets, ragged tails, redo of rolled-back chunks)
+        auto renorm_slow = [&]() {
+            if (x < kRansL) {
+                x = (x << 32) | ring(rp);
+                rp += 1;
+            }
+        };
+        auto get_bits = [&]() {
+            const int val = (int)(x & kMaxBypassVal);
+            x >>= kBypassPrecision;
+            renorm_slow();
+            return val;
+        };
+        auto step_slow = [&](long long pos) {
+            if (__any(lp - rp < 14)) top_up();
+            const unsigned cum_freq = (unsigned)(x & 0xFFFFu);
+            int lo = 0, hi = size - 1;        // last symbol whose start <= cum_freq (bisection over the row's starts)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((rowtab[mid] & 0xFFFFu) <= cum_freq && mid <= max_value) lo = mid; else hi = mid;
+            }
+            const int sidx = lo;
+            const uint32_t sf = rowtab[sidx];
+            x = (unsigned long long)(sf >> 16) * (x >> kPrecision) + cum_freq - (sf & 0xFFFFu);
+            renorm_slow();
+            int value = sidx;
+            if (value == max_value) value = decode_escape(get_bits, max_value, corrupt);
+            wsb[pos * 64] = (uint32_t)(value + offset);
+        };
+
+        constexpr int U = 8;
+        while (i < i_end) {
+            if (i + U > i_end) {   // ragged tail of the row
+                step_slow(i);
+                ++i;
+                wq = ring(rp);
+                wq1 = ring(rp + 1);
+                continue;
+            }
+            if (__any(lp - rp < 12)) top_up();
+            const unsigned long long x0 = x;
+            const int rp0 = rp;
+            uint32_t bad = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned cum_freq = (unsigned)(x & 0xFFFFu);
+                const uint2 e = tab[cum_freq >> kBucketShift];
+                const unsigned ea = e.x >> 16;
+                const bool sel = cum_freq > ea;
+                const unsigned start = sel ? ea + 1u : (e.x & 0xFFFFu);
+                const unsigned nm1 = sel ? (e.y & 0xFFFFu) : ea;
+                const uint32_t sidx = ((e.y >> 16) & 0xFFu) + (sel ? 1u : 0u);
+                x = (unsigned long long)(nm1 + 1u - start) * (x >> kPrecision) + cum_freq - start;
+                const bool need = (x >> 31) == 0ull;
+                x = need ? ((x << 32) | wq) : x;
+                rp += need ? 1 : 0;
+                wq = need ? wq1 : wq;
+                wq1 = ring(rp + 1);
+                bad |= (e.y >> 24) | ((sidx == (uint32_t)max_value) ? 1u : 0u);
+                wsb[(i + u) * 64] = (uint32_t)((int)sidx + offset);
+            }
+            if (__any(bad != 0)) {   // roll the chunk back and decode it exactly
+                x = x0;
+                rp = rp0;
+#pragma unroll 1
+                for (int u = 0; u < U; ++u) step_slow(i + u);
+                wq = ring(rp);
+                wq1 = ring(rp + 1);
+            }
+            i += U;
+        }
+    }
+    if (active) a.status[s] = corrupt | (rp > n_words ? kStatusCorrupt : 0);
+}
+
 // parallel pass: symbols_out[s][i] = ws[blk][i][lane]
 __global__ __launch_bounds__(256) void rans_dec_finish_kernel(const RansArgs a) {
     __shared__ uint32_t tile[64][65];
@@ -1046,9 +1239,16 @@ static int64_t ws_entries_bytes(int n_streams, int64_t n_sym) {
     return (b + 255) / 256 * 256 + 256;
 }
 
+// the bucketed one-lookup decode tables (rans_dec_lut8_kernel): 64 KB per CDF row, rows of up to 257 entries, at most 1 024 rows
+static int64_t dec_table_bytes(int n_cdfs, int cdf_stride) {
+    return (cdf_stride <= 257 && n_cdfs <= 1024) ? (int64_t)n_cdfs * kBucketsPerRow * 8 : 0;
+}
+
 extern "C" int64_t sc2_rans_workspace_bytes(int n_streams, int64_t n_sym, int n_cdfs, int cdf_stride) {
     if (n_streams <= 0 || n_sym < 0 || n_cdfs <= 0 || cdf_stride <= 0) return 0;
-    return ws_entries_bytes(n_streams, n_sym) + (int64_t)n_cdfs * cdf_stride * (int64_t)sizeof(EncEntry);
+    const int64_t tables = (int64_t)n_cdfs * cdf_stride * (int64_t)sizeof(EncEntry);
+    const int64_t dec = dec_table_bytes(n_cdfs, cdf_stride);
+    return ws_entries_bytes(n_streams, n_sym) + (tables > dec ? tables : dec);
 }
 
 extern "C" int sc2_rans_encode_batch(const int32_t *symbols, const int32_t *indexes, int64_t index_div, int n_streams,
@@ -1131,6 +1331,42 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
     const int n_blocks = (n_streams + 63) / 64;
     const int n_entries = n_cdfs * cdf_stride;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static const bool lut8 = [] { const char *e = getenv("SC2_RANS_LUT8"); return !e || atoi(e) != 0; }();   // (0: A/B, the two-lookup decoder)
+    if (!indexes && lut8 && dec_table_bytes(n_cdfs, cdf_stride) > 0) {
+        // one LDS round trip per symbol: bucketed tables built by a parallel pre-pass into the workspace (behind the [position][lane]
+        // intermediate), then the serial kernel
+        const long long n_rows = n_sym == 0 ? 0 : (n_sym - 1) / a.index_div + 1;
+        uint2 *gtab = reinterpret_cast<uint2 *>(static_cast<unsigned char *>(workspace) + ws_entries_bytes(n_streams, n_sym));
+        if (n_rows > 0) {
+            const long long threads = n_rows * kBucketsPerRow;
+            hipLaunchKernelGGL(rans_build_dec_table_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, cdfs, cdf_sizes,
+                               (int)n_rows, cdf_stride, gtab);
+            SC2_CHECK_LAUNCH();
+        }
+        const size_t lds = lds_pad((size_t)kBucketsPerRow * 8 + (size_t)kWin * 64 * 4 + (size_t)cdf_stride * 4 + 16, n_blocks);
+        allow_big_lds(rans_dec_lut8_kernel, lds);
+        hipLaunchKernelGGL(rans_dec_lut8_kernel, dim3(n_blocks), dim3(64), lds, s, a, gtab);
+        SC2_CHECK_LAUNCH();
+        if (n_sym > 0) {
+            const long long gx = (n_sym + 63) / 64;
+            SC2_REQUIRE(gx < (1ll << 31) && n_blocks <= 65535, SC2_ERR_UNSUPPORTED, "rans_decode: problem too large");
+            if (y_hat) {
+                const int HW = (int)index_div;
+                const size_t dq_lds = (size_t)64 * (kDqP * n_cdfs * 2 + 16);
+                allow_big_lds(rans_dec_finish_dq_kernel, dq_lds);
+                if (ev_dq_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_begin), s);
+                hipLaunchKernelGGL(rans_dec_finish_dq_kernel, dim3((HW + kDqP - 1) / kDqP, n_blocks), dim3(256), dq_lds, s, a, medians,
+                                   static_cast<uint16_t *>(y_hat), n_cdfs, HW);
+                if (ev_dq_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_end), s);
+                SC2_CHECK_LAUNCH();
+            }
+            if (symbols_out) {
+                hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
+                SC2_CHECK_LAUNCH();
+            }
+        }
+        return SC2_OK;
+    }
     if (!indexes && cdf_stride <= kMaxRowLds) {
         const bool small = cdf_stride <= 257;   // symbol indexes fit a byte
         const size_t lds = lds_pad((size_t)65536 * (small ? 1 : 2) + (size_t)kWin * 64 * 4 + (size_t)cdf_stride * 4 + 16, n_blocks);

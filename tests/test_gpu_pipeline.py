@@ -128,6 +128,8 @@ def test_evaluate_on_the_pipeline_counts_the_same_hits(S, dev, bench_mod):
     b = evaluation.evaluate(model, loader, dev, pipeline_kwargs={'coder_group': 2, 'coder_streams': 2})
     assert b['pipeline'].startswith('stage pipeline') and a['pipeline'].startswith('none')
     assert a['samples'] == b['samples'] == 22
-    assert abs(a['acc1'] - b['acc1']) < 1e-9 and abs(a['acc5'] - b['acc5']) < 1e-9 and 50.0 < a['acc1'] < 80.0
+    # (the per-batch loop averages float32 percentages, the pipelined one divides exact hit counts: equal to float32 rounding)
+    assert abs(a['acc1'] - b['acc1']) < 1e-4 and abs(a['acc5'] - b['acc5']) < 1e-4 and 50.0 < a['acc1'] < 80.0
+    assert abs(b['acc1'] - 100.0 * 14 / 22) < 1e-9
     c = evaluation.evaluate(model, torch.utils.data.DataLoader(ds, batch_size=1), dev, max_samples=4)
     assert c['pipeline'].startswith('none') and c['samples'] == 4
