@@ -835,6 +835,8 @@ def main():
     ap.add_argument('--no-pipeline', action='store_true', help='--workload lines: the module forward per batch (one stream, host bytes) instead of the stage pipeline')
     ap.add_argument('--diag-timeline', action='store_true', help='DIAGNOSTIC: HIP events around every stage of the timed run, printed to stderr (adds ~100 event records)')
     ap.add_argument('--diag-repeat', type=int, default=0, help='DIAGNOSTIC: after the timed region, time R more runs of K steps and print their wall times to stderr')
+    ap.add_argument('--policy', default='', help="dispatch-policy overrides, 'field=value,...' (fields of sc2_policy / hip.host_policy): A/B measurements")
+    ap.add_argument('--policy-env', action='store_true', help='tools only: also apply the SC2_* variables of the A/B scripts through tools/env_policy.py')
     ap.add_argument('--dry-run', action='store_true', help='rank / shard / barrier / reduction plumbing only (gloo), no GPU call')
     ap.add_argument('--workload', choices=['es224', 'mshp224', 'fp_input', 'seg513', 'det800x1216'], default='es224',
                     help='es224 = the headline config (default); the others are BASELINE configs 3 / 5 / 4 and the hyperprior bottleneck')
@@ -876,6 +878,13 @@ def main():
     import sc2bench_amd as S
     from sc2bench_amd import hip
     from sc2bench_amd.entropy import _status_or
+    if args.policy or args.policy_env:      # A/B runs: the package itself reads no SC2_* dispatch variable
+        from tools import env_policy
+        overrides = env_policy.apply() if args.policy_env else {}
+        overrides.update(env_policy.parse(args.policy))
+        if overrides:
+            hip.configure(**overrides)
+        print('bench.py: dispatch policy overrides {}'.format(overrides), file=sys.stderr)
     if args.mode == 'train':
         return train_bench(args, dev, rank, world, distributed)
     if args.workload != 'es224':

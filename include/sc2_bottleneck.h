@@ -39,6 +39,55 @@ extern "C" {
 /* ABI version: bumped on any signature change. */
 #define SC2_ABI_VERSION 36
 int sc2_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Dispatch policy.  Which kernel serves a launch is a function of the call's arguments and of  */
+/* THIS struct -- the library reads no environment variable (round 5; rounds 1 - 4 steered ~27    */
+/* choices through getenv).  The defaults are the measured choices; every   */
+/* field exists for an A/B measurement or a diagnostic, and `tools/env_policy.py` is the only     */
+/* place that maps SC2_* environment variables onto it.  The policy is process-wide             */
+/* configuration: set it before issuing launches (sc2_policy_set copies the struct; concurrent    */
+/* launches from other threads see either the old or the new value of each field).  The entry     */
+/* points themselves stay re-entrant: no call reads or writes anything else that outlives it,     */
+/* except per-device resource caches (unit counters, function attributes).                        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct sc2_policy {
+    int32_t struct_bytes;        /* sizeof(sc2_policy) of the caller's header (sc2_policy_default sets it; _set checks it) */
+    /* sc2_conv2d_fwd */
+    int32_t conv_patch3;         /* window staging of stride-1 slab-major layers: 0 off, 1 = 3x3 on the 128-wide tile (default), 256 = also the 256-wide tile, 2 = also the 2x2 decoder layers */
+    int32_t conv_s2;             /* static 3x3 stride-2 tile: 0 off, 1 (default) 256-wide where it wins, 128 / 256 force */
+    int32_t conv_persist;        /* persistent 8-wave decoder tile (conv_dec_persist): 0 off, 1, 2, 3 (default: one phase per slab) */
+    int32_t conv_half;           /* 1: half-width static decoder tiles (A/B; default 0) */
+    int32_t conv_big4;           /* 1: the 4-wave register-tile kernel for the 256-channel layers (A/B; default 0) */
+    int32_t conv_no_big;         /* 1: never the 8-wave 256-row tile */
+    int32_t conv_force_big;      /* 1: the 8-wave tile wherever Cout allows (tests) */
+    int32_t conv_no_epx;         /* 1: no epilogue-operand prefetch instantiations */
+    int32_t conv_touch;          /* 1: touch the epilogue operand's lines before the K loop (A/B) */
+    int32_t conv_debug;          /* development: bit 0 skips the store epilogue, bit 1 the K loop (results garbage) */
+    int32_t conv_chunk;          /* conv_dec_persist: tiles per claim (0 = default 2) */
+    /* window-plane kernels */
+    int32_t w2_run;              /* conv2x2_win: tiles per workgroup run (0 = default: min(share, 2)) */
+    int32_t win_half;            /* conv3x3_win: half tiles, two workgroups per CU (default 1) */
+    int32_t win_dbg;             /* conv3x3_win 14 x 14: timing experiments 1 / 2 / 4 (results garbage; default 0) */
+    int32_t win_stamps;          /* conv3x3_win: 1 = per-workgroup wall-clock summary on stderr (diagnostic) */
+    int32_t p1_half;             /* conv1x1_win: 112-pixel tiles (default 0) */
+    int32_t p1_nbuf;             /* conv1x1_win: LDS ring depth 2 / 4 (0 = by shape) */
+    int32_t pair_alt;            /* conv1x1_pair: alternate the traversal direction between launches (default 1) */
+    /* reference-precision encoder, decoder head, training */
+    int32_t f32_persist0;        /* conv_f32: the persistent first stage (default 1) */
+    int32_t dec_stagger;         /* conv2x2_gdn512: stagger workgroup starts (A/B; default 0) */
+    int32_t wgrad_wgs;           /* conv_wgrad: target workgroup count (0 = default 1024) */
+    /* range coder */
+    int32_t rans_lds_pad_kb;     /* small coder launches ask for this much LDS so that nothing shares their CU (default 159; 0 off) */
+    int32_t rans_pad_waves;      /* ... launches of up to this many serial waves (default 16) */
+    int32_t rans_ragged2;        /* four-lanes-per-stream decoder for per-symbol CDF rows (default 1) */
+    int32_t rans_ragged2_waves;  /* ... waves per workgroup sharing one table copy: 1 (default), 2, 4, 8 */
+    int32_t rans_lut8;           /* one-lookup bucketed decode tables for implicit CDF rows (default 1; 0 = the two-lookup decoder) */
+    int32_t reserved[8];
+} sc2_policy;
+void sc2_policy_default(sc2_policy *p);
+int sc2_policy_set(const sc2_policy *p);      /* SC2_ERR_INVALID_ARG if p is NULL or struct_bytes != sizeof(sc2_policy) */
+void sc2_policy_get(sc2_policy *p);
 const char *sc2_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box); never throws. */
 int sc2_device_count(void);

@@ -448,7 +448,7 @@ int launch_pair(const PairArgs &a, hipStream_t s) {
         // head has been pushed out of the 256 MB memory-side cache by that very traffic (LRU, 512 MB per launch), read back to
         // front its newest part is still there.  Small: the four launches of a step 0.549 -> 0.536 ms, head - 0.5 % (the
         // 3x3 layer between two pair launches and the pair's own writes leave ~100 MB of the identity in the cache).
-        static const int alt = [] { const char *e = getenv("SC2_PAIR_ALT"); return e ? atoi(e) : 1; }();
+        const int alt = sc2_pol().pair_alt;
         static std::atomic<unsigned> calls{0};
         b.rev = alt ? (int)(calls.fetch_add(1) & 1u) : 0;
     }

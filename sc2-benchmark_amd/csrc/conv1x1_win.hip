@@ -388,14 +388,13 @@ extern "C" int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const floa
     // bs 256: 244 workgroups, 0.050 -> 0.045 ms; every launch with more workgroups measured slower that way) and K is a
     // multiple of 256; SC2_P1_NBUF = 2 | 4 overrides (A/B)
     int nbuf = (Cin % 256 == 0 && n_wg <= 320) ? 4 : 2;
-    if (const char *e = getenv("SC2_P1_NBUF")) {
-        const int v = atoi(e);
+    if (const int v = sc2_pol().p1_nbuf) {
         if (v == 2 || (v == 4 && Cin % 256 == 0)) nbuf = v;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (nbuf == 4) return launch_p1<4, Tile<13>>(a, s);
     // half tiles (SC2_P1_HALF=1; off by default): 112-pixel tiles, three workgroups per CU.  Unlike the 3x3 kernels (conv3x3_win.hip)
     // this one loses with them -- conv1 of layer2 0.068 -> 0.076 ms, bench - 0.3 %: per pixel a 1x1 layer streams twice the weights
-    static const int half = [] { const char *e = getenv("SC2_P1_HALF"); return e ? atoi(e) : 0; }();
+    const int half = sc2_pol().p1_half;
     return half ? launch_p1<2, Tile<7>>(a, s) : launch_p1<2, Tile<13>>(a, s);
 }

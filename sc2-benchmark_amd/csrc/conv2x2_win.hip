@@ -665,8 +665,7 @@ int launch_w2(W2Args a, hipStream_t s) {
     const int cus8 = (g_cus_w2 / 8) * 8 > 0 ? (g_cus_w2 / 8) * 8 : 8;
     const int share = (a.n_tiles + cus8 - 1) / cus8;
     int run = share < 2 ? share : 2;
-    const char *rn = getenv("SC2_W2_RUN");
-    if (rn && atoi(rn) > 0) run = atoi(rn);
+    if (sc2_pol().w2_run > 0) run = sc2_pol().w2_run;
     a.tiles_per_wg = run;
     int grid = (a.n_tiles + run - 1) / run;
     grid = (grid + 7) / 8 * 8;

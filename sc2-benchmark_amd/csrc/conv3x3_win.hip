@@ -360,8 +360,7 @@ int launch_win(WinArgs a, hipStream_t s) {
         attr_set = true;
     }
     const int n_wg = a.n_mtiles * a.n_chunks;
-    const char *st = getenv("SC2_WIN_STAMPS");   // DEBUG: per-workgroup start / end times of this launch, summarised on stderr
-    if (st && atoi(st)) {
+    if (sc2_pol().win_stamps) {   // DEBUG: per-workgroup start / end times of this launch, summarised on stderr
         unsigned long long *d = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&d), (size_t)n_wg * 16) != hipSuccess) return SC2_ERR_INTERNAL;
         a.stamps = d;
@@ -578,7 +577,7 @@ extern "C" int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const fl
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int half = [] { const char *e = getenv("SC2_WIN_HALF"); return e ? atoi(e) : 1; }();
+    const int half = sc2_pol().win_half;
     if (half) {
         if (W == 56) return launch_win_s2<HS28>(a, s);
         if (W == 28) return launch_win_s2<HS14>(a, s);
@@ -615,7 +614,7 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const int half = [] { const char *e = getenv("SC2_WIN_HALF"); return e ? atoi(e) : 1; }();
+    const int half = sc2_pol().win_half;
     if (half) {
         if (W == 28) return launch_win<H28>(a, s);
         if (W == 14) return launch_win<H14>(a, s);
@@ -623,8 +622,7 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
     }
     if (W == 28) return launch_win<G28>(a, s);
     if (W == 14) {
-        const char *dbg = getenv("SC2_WIN_DBG");   // timing experiments on the 14 x 14 geometry (results garbage)
-        switch (dbg ? atoi(dbg) : 0) {
+        switch (sc2_pol().win_dbg) {   // timing experiments on the 14 x 14 geometry (results garbage)
             case 1: return launch_win<G14, 1>(a, s);
             case 2: return launch_win<G14, 2>(a, s);
             case 4: return launch_win<G14, 4>(a, s);

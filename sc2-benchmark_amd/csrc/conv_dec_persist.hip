@@ -538,9 +538,9 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
         attr_set = true;
     }
     // tiles per workgroup: SC2_CONV_CHUNK (0 / unset: the default below; large: one static share per CU)
-    const char *ce = getenv("SC2_CONV_CHUNK");
+    const int ce = sc2_pol().conv_chunk;
     const int per_xcd = (n_tiles + 7) / 8, cus_x = n_cus / 8 > 0 ? n_cus / 8 : 1;
-    int chunk = ce && atoi(ce) > 0 ? atoi(ce) : 2;   // measured inside the pipelined bench (tools/chunk_ab.sh): 2 - 3 best, 1 static share per CU worst
+    int chunk = ce > 0 ? ce : 2;   // measured inside the pipelined bench (tools/chunk_ab.sh): 2 - 3 best, 1 static share per CU worst
     const int full = (per_xcd + cus_x - 1) / cus_x;          // the share of one CU
     if (chunk > full) chunk = full;
     const int grid = 8 * ((per_xcd + chunk - 1) / chunk);

@@ -552,8 +552,7 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn_f32_persist_kernel(const F32
 }
 
 bool f32_persist0_enabled() {     // SC2_F32_PERSIST0=0: the tile form (A/B)
-    static const bool on = [] { const char *e = getenv("SC2_F32_PERSIST0"); return !(e && e[0] == '0'); }();
-    return on;
+    return sc2_pol().f32_persist0 != 0;
 }
 
 template <int NT, int MT, bool FUSED = false>

@@ -455,8 +455,7 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
     DecArgs b = a;
     b.tile_ctr = g_ctr_ring[dev] + (g_ctr_seq.fetch_add(1) % kCtrRing);
     {
-        static const int stagger = [] { const char *e = getenv("SC2_DEC_STAGGER"); return e ? atoi(e) : 0; }();
-        b.stagger = stagger;
+        b.stagger = sc2_pol().dec_stagger;
     }
     b.stamps = nullptr;
 #if SC2_DEC_STAMPS

@@ -75,8 +75,8 @@ bool big_tile_eligible(const sc2_conv_desc *d, long long M, int K) {
     // Measured (tools/ab_big.py, one process, MI355X): 256-wide big tile wins +27 % at K = 2048 and +13 % at K = 1024,
     // ties or loses on the HBM-bound 1x1 GDN GEMMs and on short K; the 128-wide big tile never wins.
     // (SC2_CONV_FORCE_BIG / SC2_CONV_NO_BIG: test and A/B switches)
-    const bool forced = getenv("SC2_CONV_FORCE_BIG") != nullptr;
-    return sc2_conv_weight_rows(d->Cout) % 128 == 0 && !getenv("SC2_CONV_NO_BIG") &&
+    const bool forced = sc2_pol().conv_force_big != 0;
+    return sc2_conv_weight_rows(d->Cout) % 128 == 0 && !sc2_pol().conv_no_big &&
            ((K >= 1024 && d->Cout % 256 == 0 && d->a_op == SC2_AOP_NONE && M >= 256LL * 192) || forced);
 }
 }  // namespace
@@ -175,15 +175,9 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.k_slab_major = (d->k_order & SC2_K_SLAB_MAJOR) ? 1 : 0;
     a.b_kt_stride = (d->k_order & SC2_K_B_TILE_MAJOR) ? d->Cout_pad * 32 : 32;
     a.b_row_stride = (d->k_order & SC2_K_B_TILE_MAJOR) ? 32 : d->Kpad;
-    {
-        const char *dbg = getenv("SC2_CONV_DEBUG");
-        a.dbg = dbg ? atoi(dbg) : 0;
-    }
+    a.dbg = sc2_pol().conv_debug;
     const bool needs_x_operand = epi_needs_x(d->epilogue);
-    {
-        const char *t = getenv("SC2_CONV_TOUCH");
-        a.touch = (needs_x_operand && d->out_format == SC2_OUT_BF16_NHWC && !scatter && t && atoi(t)) ? 1 : 0;
-    }
+    a.touch = (needs_x_operand && d->out_format == SC2_OUT_BF16_NHWC && !scatter && sc2_pol().conv_touch) ? 1 : 0;
     a.o_H = scatter ? d->out_H : 0; a.o_W = d->out_W; a.o_sh = d->out_stride_h; a.o_sw = d->out_stride_w;
     a.o_h0 = d->out_off_h; a.o_w0 = d->out_off_w;
     a.DH = dil_h; a.DW = dil_w;
@@ -219,8 +213,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         // tile; the 2x2 decoder layers +25 % SLOWER (their four taps re-read through L2 cheaply, the shifted reads cost
         // address arithmetic and LDS bank conflicts), so those stay on the im2col gather unless asked for.
         // SC2_CONV_PATCH3: 0 = off, 256 = the 256-wide tile for the 3x3 layers too, 2 = also the 2x2 decoder layers
-        const char *p3 = getenv("SC2_CONV_PATCH3");
-        const int mode = p3 ? atoi(p3) : 1;
+        const int mode = sc2_pol().conv_patch3;
         const bool base_ok = mode != 0 && a.x_bytes != 0 && d->stride_h == 1 && d->stride_w == 1 && d->Cin % 32 == 0 &&
                              (d->k_order & SC2_K_SLAB_MAJOR) && !scatter && d->a_op == SC2_AOP_NONE;
         // rows of the window a 256-pixel tile can need: its own pixels, the taps' reach, and the drift of g(m) - m over
@@ -245,8 +238,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         // 3x3 stride-2 pad-1 layers: static-geometry 8-wave tile with buffer-addressed gather.  Measured (bs 256): the
         // 256-wide tile wins where the runtime-geometry big tile was already in use (layer3.0 conv2: 0.127 -> 0.107 ms); the
         // 128-wide one loses to the 4-wave kernel (layer2.0 0.143 -> 0.168 ms) and is only reachable with SC2_CONV_S2=128.
-        const char *s2 = getenv("SC2_CONV_S2");
-        const int mode = s2 ? atoi(s2) : 1;
+        const int mode = sc2_pol().conv_s2;
         if (mode != 0 && a.x_bytes != 0 && d->KH == 3 && d->KW == 3 && d->stride_h == 2 && d->stride_w == 2 && d->pad_h == 1 &&
             d->pad_w == 1 && d->Cin % 32 == 0 && !scatter && d->a_op == SC2_AOP_NONE && d->Cout % 128 == 0 && !fused) {
             if (mode == 128) return launch8<S2_128>(a, s);
@@ -263,14 +255,12 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     const bool big = big_tile_eligible(d, M, K);
     if (big && d->Cout % 256 == 0 && a.x_bytes == 0) return launch8<BG_256>(a, s);   // >= 2 GB: 64-bit addressing only
     if (big && d->Cout % 256 == 0) {
-        const char *half = getenv("SC2_CONV_HALF");
-        if ((half ? atoi(half) : 0) && d->out_format == SC2_OUT_BF16_NHWC) {
+        if (sc2_pol().conv_half && d->out_format == SC2_OUT_BF16_NHWC) {
             if (matches<H_dec2>(a)) return launch8<H_dec2>(a, s);
             if (matches<H_dec4>(a)) return launch8<H_dec4>(a, s);
         }
         {
-            const char *r4 = getenv("SC2_CONV_BIG4");   // A/B switch: the 4-wave register-tile kernel
-            if (r4 && atoi(r4) && d->out_format == SC2_OUT_BF16_NHWC) {
+            if (sc2_pol().conv_big4 && d->out_format == SC2_OUT_BF16_NHWC) {   // A/B switch: the 4-wave register-tile kernel
                 if (matches<R_dec2>(a)) return launch4<R_dec2>(a, s);
                 if (matches<R_dec4>(a)) return launch4<R_dec4>(a, s);
                 return launch4<RG_256>(a, s);
@@ -278,8 +268,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
         }
         {
             // persistent form of the two decoder layers (deferred output stores, conv_dec_persist.hip); SC2_CONV_PERSIST=0/1: A/B
-            const char *pe = getenv("SC2_CONV_PERSIST");
-            const int pmode = pe ? atoi(pe) : 3;   // 0: one workgroup per tile; 1: persistent; 2: + fragment reads a phase early; 3: one phase (32 MFMAs) per slab
+            const int pmode = sc2_pol().conv_persist;   // 0: one workgroup per tile; 1: persistent; 2: + fragment reads a phase early; 3: one phase (32 MFMAs) per slab
             const bool persist = pmode && a.x_bytes != 0 && d->out_format == SC2_OUT_BF16_NHWC && !scatter &&
                                  d->Cout == 256 && d->a_op == SC2_AOP_NONE && (d->epilogue == SC2_EPI_NONE || fused);
 #ifdef SC2_EXPERIMENTS   // timing experiment with garbage results: never in the shipped library
@@ -303,7 +292,7 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     }
     if (big && d->Cout % 128 == 0) return launch8<BG_128>(a, s);
     bool epx = needs_x_operand &&
-                     d->out_format == SC2_OUT_BF16_NHWC && !scatter && !getenv("SC2_CONV_NO_EPX");
+                     d->out_format == SC2_OUT_BF16_NHWC && !scatter && !sc2_pol().conv_no_epx;
     if (a.touch) epx = false;
     if (epx) {
         if (rows == 96 && matches<Cx_gdn96>(a)) return launch<Cx_gdn96>(a, s);

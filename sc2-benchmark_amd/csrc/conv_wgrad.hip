@@ -271,7 +271,7 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     // is paid in atomics: 4 096 workgroups (16 per CU) -> 1 024 (two rounds of the 512 resident ones) took the small layers'
     // launches from 0.095 / 0.31 / 0.28 ms to 0.054 / 0.24 / 0.24 (the 512 x 512 gamma gradient stays at 0.89: it is bound by
     // the L2 -> LDS fill of its 128 x 128 tiles, 16 KB per 64 MFMAs), the training step + 2 %.  SC2_WGRAD_WGS overrides (A/B).
-    static const int wg_target = [] { const char *e = getenv("SC2_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    const int wg_target = sc2_pol().wgrad_wgs > 0 ? sc2_pol().wgrad_wgs : 1024;
     long long chunks = (wg_target + tiles - 1) / tiles;
     long long rows = (M + chunks - 1) / chunks;
     rows = (rows + WG_SLAB - 1) / WG_SLAB * WG_SLAB;

@@ -1211,8 +1211,7 @@ int check_common(const int32_t *indexes, long long index_div, int n_streams, lon
 // images/s, 3 of 3 runs; 16 CUs at most).  Larger launches keep their footprint: giving 32 - 64 CUs away costs more than it
 // gains.  SC2_RANS_LDS_PAD (KB, 0 = off) / SC2_RANS_PAD_WAVES override (A/B).
 static size_t lds_pad(size_t need, int n_wave_blocks) {
-    static const int pad_kb = [] { const char *e = getenv("SC2_RANS_LDS_PAD"); return e ? atoi(e) : 159; }();
-    static const int max_waves = [] { const char *e = getenv("SC2_RANS_PAD_WAVES"); return e ? atoi(e) : 16; }();
+    const int pad_kb = sc2_pol().rans_lds_pad_kb, max_waves = sc2_pol().rans_pad_waves;
     const size_t want = (size_t)pad_kb * 1024;
     return (n_wave_blocks <= max_waves && want > need) ? want : need;
 }
@@ -1331,7 +1330,7 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
     const int n_blocks = (n_streams + 63) / 64;
     const int n_entries = n_cdfs * cdf_stride;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    static const bool lut8 = [] { const char *e = getenv("SC2_RANS_LUT8"); return !e || atoi(e) != 0; }();   // (0: A/B, the two-lookup decoder)
+    const bool lut8 = sc2_pol().rans_lut8 != 0;   // (0: A/B, the two-lookup decoder)
     if (!indexes && lut8 && dec_table_bytes(n_cdfs, cdf_stride) > 0) {
         // one LDS round trip per symbol: bucketed tables built by a parallel pre-pass into the workspace (behind the [position][lane]
         // intermediate), then the serial kernel
@@ -1398,9 +1397,9 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
         }
         return SC2_OK;
     }
-    static const bool ragged2 = [] { const char *e = getenv("SC2_RANS_RAGGED2"); return !e || atoi(e) != 0; }();   // (0: A/B)
+    const bool ragged2 = sc2_pol().rans_ragged2 != 0;   // (0: A/B)
     if (indexes && n_entries > 12288 && n_cdfs <= kRagged2Rows && ragged2) {
-        static const int waves = [] { const char *e = getenv("SC2_RANS_RAGGED2_WAVES"); const int v = e ? atoi(e) : 1; return v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 4 : 8; }();
+        const int waves = [] { const int v = sc2_pol().rans_ragged2_waves; return v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 4 : 8; }();
         const size_t lds = (size_t)kRagged2Cap * 2 + (((size_t)kRagged2Rows * 257 * 2 + 15) & ~(size_t)15) + (size_t)kWin * 16 * waves * 4 +
                            (size_t)(3 * kRagged2Rows + 1) * 4 + 16;
         auto kern = waves == 1 ? rans_dec_ragged2_kernel<1> : waves == 2 ? rans_dec_ragged2_kernel<2> : waves == 4 ? rans_dec_ragged2_kernel<4> : rans_dec_ragged2_kernel<8>;

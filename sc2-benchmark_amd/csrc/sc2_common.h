@@ -7,6 +7,7 @@
 #include "../../include/sc2_bottleneck.h"
 
 void sc2_set_error(const char *fmt, ...);
+const sc2_policy &sc2_pol();   // the process-wide dispatch policy (abi.cpp; include/sc2_bottleneck.h): the library reads no environment variable
 
 #define SC2_REQUIRE(cond, code, ...)   \
     do {                               \

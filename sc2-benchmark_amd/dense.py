@@ -256,10 +256,10 @@ class HipDenseHead(object):
 def _hip_dense_head(owner, module, x):
     """The cached `HipDenseHead` of `module` if this call can run on it (eval mode, bf16 parameters and bf16 features on a HIP
     device, a supported structure), else None (the torch modules run)."""
-    import os
+    from . import hip
     p = next(module.parameters(), None)
     if (module.training or p is None or p.dtype != torch.bfloat16 or not x.is_cuda or x.dtype != torch.bfloat16 or
-            os.environ.get('SC2_DENSE_HEAD', '1') == '0' or not HipDenseHead.supported(module)):
+            not hip.host_policy.dense_head or not HipDenseHead.supported(module)):
         return None
     cache = owner.__dict__.setdefault('_hip_dense_heads', {})
     ent = cache.get(id(module))

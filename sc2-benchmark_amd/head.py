@@ -38,7 +38,7 @@ def _fold(conv, bn):
 def _win1_policy(cin, cout, stride):
     """Which 1x1 layers go to the window-plane 1x1 kernel (conv1x1_win.hip).  SC2_CONV1X1_WIN: '0' none, 'all' every supported
     layer (A/B, tools/head_times.py), default = the layers it measured faster on."""
-    mode = os.environ.get('SC2_CONV1X1_WIN', '1')
+    mode = str(hip.host_policy.conv1x1_win)
     if mode == '0':
         return False
     if mode == 'all':
@@ -123,7 +123,7 @@ class _Conv(object):
 
     def __call__(self, x, epilogue, ep_x=None):
         if self.dilation != (1, 1) and self.k != (1, 1):
-            if self.native_dilation and os.environ.get('SC2_CONV_DILATION', '1') != '0':      # ('0': A/B, the phase grids)
+            if self.native_dilation and hip.host_policy.conv_dilation:      # ('0': A/B, the phase grids)
                 return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,
                                       ep_x=ep_x, ep_beta=self.b, tag=self.tag, k_order=self.k_order, dilation=self.dilation)
             assert ep_x is None
@@ -174,7 +174,7 @@ class HipHead(object):
             self.fc = (hip.pack_conv_weight(w), b.contiguous(), cout_pad, fc.out_features)
             # the dedicated classifier kernel (K split over the waves of a workgroup): rows padded to a multiple of 16
             self.fc_frag = None
-            if fc.in_features % 128 == 0 and os.environ.get('SC2_FC_KERNEL', '1') != '0':
+            if fc.in_features % 128 == 0 and hip.host_policy.fc_kernel:
                 n16 = (fc.out_features + 15) // 16 * 16
                 w16 = torch.zeros(n16, fc.in_features, device=w.device)
                 w16[:fc.out_features] = fc.weight.detach().float()

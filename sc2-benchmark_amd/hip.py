@@ -23,7 +23,7 @@ EB_PARAM_STRIDE = 64
 
 # symbols the header declares; tests check each is exported
 ABI_SYMBOLS = [
-    'sc2_abi_version', 'sc2_last_error', 'sc2_device_count',
+    'sc2_abi_version', 'sc2_last_error', 'sc2_device_count', 'sc2_policy_default', 'sc2_policy_set', 'sc2_policy_get',
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_fc_fwd',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
@@ -47,6 +47,72 @@ class ConvDesc(ctypes.Structure):
 
 class Sc2Error(RuntimeError):
     pass
+
+
+# --------------------------------------------------------------------------------------------- #
+# dispatch policy: no environment variable steers a kernel choice.  `Policy` mirrors `sc2_policy` of the
+# C-ABI (the library's own choices), `HostPolicy` holds the choices made on this side of the boundary (which fused /
+# persistent kernel a layer is sent to).  Defaults = the measured choices; `configure(name=value, ...)` changes either kind;
+# tools/env_policy.py maps the SC2_* variables of the A/B scripts onto it -- the package itself never reads them.
+# --------------------------------------------------------------------------------------------- #
+POLICY_FIELDS = ('struct_bytes', 'conv_patch3', 'conv_s2', 'conv_persist', 'conv_half', 'conv_big4', 'conv_no_big', 'conv_force_big',
+                 'conv_no_epx', 'conv_touch', 'conv_debug', 'conv_chunk', 'w2_run', 'win_half', 'win_dbg', 'win_stamps', 'p1_half',
+                 'p1_nbuf', 'pair_alt', 'f32_persist0', 'dec_stagger', 'wgrad_wgs', 'rans_lds_pad_kb', 'rans_pad_waves', 'rans_ragged2',
+                 'rans_ragged2_waves', 'rans_lut8')
+
+
+class Policy(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in POLICY_FIELDS] + [('reserved', ctypes.c_int32 * 8)]
+
+
+class HostPolicy(object):
+    """Kernel choices made in Python (per layer shape); every attribute is an A/B switch with its measured default."""
+    conv_patch = True          # enc.conv2 + GDN48 on the LDS-patch tile kernel where the persistent kernel does not apply
+    k_order_tap = False        # True: tap-major K everywhere (default: slab-major where several taps re-read pixels)
+    b_tile_major = True        # weights packed [k-slab][row][32]
+    conv0_fused = True         # conv0 + GDN96 as one persistent launch
+    conv2_fused = True         # conv2 + GDN48 as one persistent launch
+    conv_kres = 1              # weights-in-registers 1x1 kernel: 0 off, 1 the K = 1024 layers, 2 also K = 2048
+    conv_win = True            # window-plane 3x3 kernel
+    conv_win_s2 = True         # ... its stride-2 form
+    conv2x2_win = True         # window-plane 2x2 decoder kernel
+    w2_tail = True             # decoder's last conv takes layer2.0's conv1 + downsample along
+    conv_stream = True         # persistent streaming 1x1 kernel
+    conv1x1_pair = True        # conv3 + next block's conv1 in one launch
+    conv_c48 = True            # streaming last encoder conv
+    conv1x1_win = '1'          # window-plane 1x1 kernel: '0' none, '1' the layers it measured faster on, 'all'
+    conv_dilation = True       # dilated layers through the descriptor's dilation (False: phase grids)
+    fc_kernel = True           # dedicated classifier kernel
+    dense_head = True          # DeepLab / FCN heads and the FPN on the library's kernels in bf16 eval
+    rans_fused_dq = True       # decode + dequantise in one coder launch
+    host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
+
+
+host_policy = HostPolicy()
+
+
+def get_policy():
+    p = Policy()
+    lib().sc2_policy_get(ctypes.byref(p))
+    return p
+
+
+def configure(**kw):
+    """Sets dispatch-policy fields by name: fields of `sc2_policy` (the library) and attributes of `host_policy` (this side).
+    -> the library policy in force.  Unknown names raise."""
+    p = get_policy()
+    touched = False
+    for k, v in kw.items():
+        if k in POLICY_FIELDS and k != 'struct_bytes':
+            setattr(p, k, int(v))
+            touched = True
+        elif hasattr(HostPolicy, k):
+            setattr(host_policy, k, v)
+        else:
+            raise Sc2Error('configure: unknown policy field {!r}'.format(k))
+    if touched:
+        _check(lib().sc2_policy_set(ctypes.byref(p)), 'policy_set')
+    return p
 
 
 def library_fingerprint():
@@ -91,6 +157,11 @@ def lib():
     L.sc2_abi_version.restype = i32
     L.sc2_last_error.restype = ctypes.c_char_p
     L.sc2_device_count.restype = i32
+    L.sc2_policy_default.argtypes = [vp]
+    L.sc2_policy_default.restype = None
+    L.sc2_policy_set.argtypes = [vp]
+    L.sc2_policy_get.argtypes = [vp]
+    L.sc2_policy_get.restype = None
     L.sc2_nchw_f32_to_nhwc_bf16.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_nhwc_bf16_to_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.sc2_avgpool_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, vp]
@@ -315,7 +386,7 @@ def pack_conv_weight(w, k_order=K_TAP_MAJOR):
 
 def conv_patch_supported(x_shape, cout, kh, kw, stride, pad, out_format=OUT_BF16_NHWC, epilogue=EPI_NONE):
     """True if this conv runs on the LDS-resident-patch kernel (weights then packed K_SLAB_MAJOR | K_B_FRAG_MAJOR)."""
-    if os.environ.get('SC2_CONV_PATCH', '1') == '0':      # A/B switch (tools/)
+    if not host_policy.conv_patch:      # A/B switch (tools/)
         return False
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
@@ -329,11 +400,11 @@ def conv_patch_supported(x_shape, cout, kh, kw, stride, pad, out_format=OUT_BF16
 
 def preferred_k_order(cin, kh, kw):
     """Slab-major pays when several taps re-read overlapping pixels and the channel count allows it."""
-    if os.environ.get('SC2_K_ORDER') == 'tap':      # A/B switch (tools/)
-        return K_TAP_MAJOR | (K_B_TILE_MAJOR if os.environ.get('SC2_B_TILE', '1') != '0' else 0)
+    if host_policy.k_order_tap:      # A/B switch (tools/)
+        return K_TAP_MAJOR | (K_B_TILE_MAJOR if host_policy.b_tile_major else 0)
     # measured (same box, tools/layer_times.py): +1.5 % on the 2x2 decoder convs, -4 % on the 25-tap stride-2 conv
     base = K_SLAB_MAJOR if (cin % 32 == 0 and 1 < kh * kw <= 9) else K_TAP_MAJOR
-    return base | (K_B_TILE_MAJOR if os.environ.get('SC2_B_TILE', '1') != '0' else 0)
+    return base | (K_B_TILE_MAJOR if host_policy.b_tile_major else 0)
 
 
 def pack_conv0_weight_pairs(w):
@@ -540,7 +611,7 @@ def conv2x2_gdn512_supported(cin, cout, kh, kw, stride, pad):
 def conv0_gdn96_supported(x_pairs_shape, cout):
     """True if the pixel-pair first conv + GDN1(96) runs as the single persistent launch (any width: 112-pixel output
     segments)."""
-    if os.environ.get('SC2_CONV0_FUSED', '1') == '0':      # A/B switch (tools/)
+    if not host_policy.conv0_fused:      # A/B switch (tools/)
         return False
     return len(x_pairs_shape) == 4 and bool(lib().sc2_conv0_gdn96_supported(x_pairs_shape[3], cout, x_pairs_shape[2]))
 
@@ -582,7 +653,7 @@ def conv0_gdn96_nchw_fwd(x_nchw, w_frag, gamma_frag, beta, inverse=False, tag=No
 
 def conv2_gdn48_supported(x_shape, cout, kh, kw, stride, pad):
     """True if this conv + GDN1(48) runs as the persistent weights-in-registers launch (96 -> 48, k5 s2 p2, W = 112)."""
-    if os.environ.get('SC2_CONV2_FUSED', '1') == '0':      # A/B switch (tools/)
+    if not host_policy.conv2_fused:      # A/B switch (tools/)
         return False
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
@@ -649,7 +720,7 @@ def conv1x1_kres_supported(cin, cout, kh, kw, stride, pad):
     """True if this 1x1 conv runs on the weights-in-registers kernel (K = 1024 or 2048, stride 1 or 2)."""
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    mode = os.environ.get('SC2_CONV_KRES', '1')          # A/B switch (tools/): 0 off, 2 = also the K = 2048 layers
+    mode = str(host_policy.conv_kres)          # A/B switch (tools/): 0 off, 2 = also the K = 2048 layers
     if mode == '0':
         return False
     if cin == 2048 and mode != '2':   # measured: layer4 conv1 (2048 -> 512, 12 544 pixels) 0.065 ms vs 0.063 ms on the tile kernel
@@ -679,12 +750,12 @@ def conv3x3_win_supported(h, w, cin, cout, kh, kw, stride, pad, dilation=(1, 1))
     56 / 28 / 14 pixel maps (h, w = the INPUT map)."""
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    if os.environ.get('SC2_CONV_WIN', '1') == '0':      # A/B switch (tools/)
+    if not host_policy.conv_win:      # A/B switch (tools/)
         return False
     if (kh, kw, ph, pw) != (3, 3, 1, 1) or tuple(dilation) != (1, 1):
         return False
     if (sh, sw) == (2, 2):
-        return os.environ.get('SC2_CONV_WIN_S2', '1') != '0' and bool(lib().sc2_conv3x3s2_win_supported(h, w, cin, cout))
+        return host_policy.conv_win_s2 and bool(lib().sc2_conv3x3s2_win_supported(h, w, cin, cout))
     return (sh, sw) == (1, 1) and \
         bool(lib().sc2_conv3x3_win_supported(h, w, cin, cout))   # (the caller checks the 2 GB operand bound: head._Conv)
 
@@ -712,7 +783,7 @@ def conv2x2_win_supported(x_shape, cout, kh, kw, stride, pad):
     """True if this conv runs on the window-plane decoder kernel (k2, s1, Cout 256, width 56 / pad 0 or 55 / pad 1)."""
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    if os.environ.get('SC2_CONV2X2_WIN', '1') == '0':      # A/B switch (tools/)
+    if not host_policy.conv2x2_win:      # A/B switch (tools/)
         return False
     N, H, W, Cin = x_shape
     if max(N * H * W * Cin, N * (H + 2 * ph - 1) * (W + 2 * pw - 1) * cout) * 2 >= 0x7FF00000:   # 32-bit buffer offsets
@@ -732,7 +803,7 @@ def pack_conv2x2_win(w, gamma=None):
 
 def conv2x2_win_tail_supported(x_shape):
     """True if the last decoder conv can take the head's first two 1x1 layers with it (55 x 55 input, sc2_conv2x2_win_tail_fwd)."""
-    if os.environ.get('SC2_CONV2X2_WIN', '1') == '0' or os.environ.get('SC2_W2_TAIL', '1') == '0':      # A/B switches (tools/)
+    if not host_policy.conv2x2_win or not host_policy.w2_tail:      # A/B switches (tools/)
         return False
     N, H, W, Cin = x_shape
     if N * 56 * 56 * 256 * 2 >= 0x7FF00000 or N * H * W * Cin * 2 >= 0x7FF00000:
@@ -815,7 +886,7 @@ def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None, stride=1):
 def conv1x1_stream_supported(cin, cout, kh, kw, stride, pad):
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    if os.environ.get('SC2_CONV_STREAM', '1') == '0':      # A/B switch (tools/)
+    if not host_policy.conv_stream:      # A/B switch (tools/)
         return False
     return kh == 1 and kw == 1 and sh == sw and ph == 0 and pw == 0 and \
         bool(lib().sc2_conv1x1_stream_supported(cin, cout, sh))
@@ -844,7 +915,7 @@ def conv1x1_stream_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False
 def conv1x1_pair_supported(k1, c, n2):
     """True if conv3 (k1 -> c, + residual + ReLU) of one Bottleneck block and conv1 (c -> n2, + ReLU) of the next run as one
     launch (sc2_conv1x1_pair_fwd); SC2_CONV1X1_PAIR=0: A/B switch."""
-    return os.environ.get('SC2_CONV1X1_PAIR', '1') != '0' and bool(lib().sc2_conv1x1_pair_supported(k1, c, n2))
+    return host_policy.conv1x1_pair and bool(lib().sc2_conv1x1_pair_supported(k1, c, n2))
 
 
 def conv1x1_pair_fwd(o_nhwc, w3_frag, b3, identity, w1_frag, b1, tag=None):
@@ -869,7 +940,7 @@ def conv2x2_c48_supported(x_shape, cout, kh, kw, stride, pad):
     """True if this conv runs on the streaming kernel of the FP encoder's last layer (Cin 48, k2, s1, p0, Cout <= 32)."""
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (pad, pad) if isinstance(pad, int) else pad
-    if os.environ.get('SC2_CONV_C48', '1') == '0':      # A/B switch (tools/)
+    if not host_policy.conv_c48:      # A/B switch (tools/)
         return False
     N, H, W, Cin = x_shape
     if N * H * W * Cin * 2 >= 0x7FF00000:
@@ -1288,7 +1359,7 @@ def host_coder_max_streams():
     # measured (profiles/r03c_*): the device coder takes ~120 ns per symbol of ONE stream however few streams there are (one
     # lane each), a host thread ~15-25 ns; with up to 32 threads the host wins far beyond a handful of streams (16 streams
     # of 393 k symbols, the 513 x 513 batch: 85 ms on the device coder)
-    return int(os.environ.get('SC2_HOST_CODER_MAX_STREAMS', '64'))
+    return int(host_policy.host_coder_max_streams)
 
 
 class HostRansTables(object):
@@ -1428,7 +1499,7 @@ def rans_decode_dequantize_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, 
 
 def rans_decode_dequantize_supported(n_cdfs, cdf_stride):
     """True if sc2_rans_decode_dequantize_batch takes these tables (channel count % 8 == 0, <= 64, rows within the LUT decoder)."""
-    return n_cdfs % 8 == 0 and n_cdfs <= 64 and cdf_stride <= 4096 and os.environ.get('SC2_RANS_FUSED_DQ', '1') != '0'
+    return n_cdfs % 8 == 0 and n_cdfs <= 64 and cdf_stride <= 4096 and host_policy.rans_fused_dq
 
 
 def rans_decode_batch(buf, off, nb, n_sym, cdfs, cdf_sizes, offsets, indexes=None, index_div=0):

@@ -4,6 +4,8 @@ import os, sys
 import torch, torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sc2bench_amd as S
+from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)
+env_policy.apply()
 hip = S.hip
 dev = torch.device('cuda:0')
 for (cin, cout, k, s, p, hw) in [(3, 96, 5, 2, 2, (37, 50)), (96, 48, 5, 2, 2, (28, 31)), (4, 5, 1, 1, 0, (7, 5)), (16, 16, 1, 1, 0, (8, 16))]:

@@ -2,6 +2,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sc2bench_amd as S
+from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)
+env_policy.apply()
 hip = S.hip
 dev = torch.device('cuda:0')
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256

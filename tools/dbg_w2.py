@@ -7,6 +7,8 @@ os.environ['SC2_W2_RUN'] = sys.argv[1] if len(sys.argv) > 1 else '5'
 fused = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 cin = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 import sc2bench_amd as S
+from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)
+env_policy.apply()
 dev = torch.device('cuda:0')
 pad, N, H = 0, 3, 56
 W = 56

@@ -5,6 +5,8 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sc2bench_amd as S
+from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)
+env_policy.apply()
 from sc2bench_amd import hip
 dev = torch.device('cuda:0')
 torch.manual_seed(0)

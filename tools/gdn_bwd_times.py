@@ -3,6 +3,8 @@ stage-1 step: norm GEMM + gamma^T GEMM + weight gradient on the round-1 tile ker
 import sys,os,torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sc2bench_amd as S
+from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)
+env_policy.apply()
 from sc2bench_amd import hip
 dev=torch.device('cuda:0')
 for C,HW in ((512,56*56),(96,112*112),(256,55*55),(48,56*56)):

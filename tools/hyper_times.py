@@ -3,6 +3,8 @@ import argparse, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sc2bench_amd as S
+from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)
+env_policy.apply()
 from sc2bench_amd import hip
 ap = argparse.ArgumentParser(); ap.add_argument('--bs', type=int, default=256); ap.add_argument('--name', default='MSHPBasedResNetBottleneck')
 args = ap.parse_args()
