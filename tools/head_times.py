@@ -4,6 +4,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as B
 from sc2bench_amd import hip
+from tools import env_policy  # (the SC2_* variables of the A/B scripts -> the dispatch policy)
+env_policy.apply()
 dev = torch.device('cuda:0')
 m = B.build_model(dev)
 N = 256
