@@ -214,9 +214,16 @@ def test_workload_line_mshp224_on_the_device_coder(dev, capsys):
     import bench
     from sc2bench_amd import hip
     assert 72 > hip.host_coder_max_streams()
-    args = argparse.Namespace(workload='mshp224', bs=72, steps=1, warmup=1, no_cpu_baseline=True)
-    bench.workload_bench(args, dev, 0, 1, False)
+    base = dict(workload='mshp224', bs=72, steps=3, warmup=1, no_cpu_baseline=True, coder_group=0, inflight=0, max_inflight=24, ramp=1,
+                lag=0, front_priority=0, back_priority=0, coder_priority=0, split_mfma=1, cat_symbols=False, unfused_dequantize=False,
+                no_prealloc=False)
+    # the module forward per batch (rounds 3 - 4) and the package's stage pipeline (round 5): the same line schema
+    bench.workload_bench(argparse.Namespace(no_pipeline=True, **base), dev, 0, 1, False)
+    plain = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('{')][-1])
+    assert plain['config']['pipeline'].startswith('none')
+    bench.workload_bench(argparse.Namespace(no_pipeline=False, **base), dev, 0, 1, False)
     line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith('{')][-1])
+    assert line['config']['pipeline']['what'].startswith('sc2bench_amd.pipeline.StagePipeline') and abs(line['bpp'] - plain['bpp']) < 1e-12
     assert line['unit'] == 'images/s' and line['value'] > 0 and line['config']['batch_per_gpu'] == 72
     assert line['config']['range_coder'].startswith('batched HIP coder')
     assert 1.0 < line['bpp'] < 12.0

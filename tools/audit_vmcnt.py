@@ -8,6 +8,11 @@ a few instructions earlier).
     python tools/audit_vmcnt.py /tmp/f.s [kernel-name substring]
     python tools/audit_vmcnt.py --copies csrc/<file>.hip [...]     (compiles; exit status 1 on a finding)
     python tools/audit_vmcnt.py --stores csrc/<file>.hip [...]     (compiles; exit status 1 on a finding)
+    python tools/audit_vmcnt.py --counts csrc/<file>.hip [...]     (compiles; exit status 1 on a finding)
+
+--counts: is every counted wait SMALL enough?  (audit_counts: every register an inline-asm load writes is followed through the
+control-flow graph with the number of vector-memory operations issued behind it; a `vmcnt(N)` with N larger than that number does
+not wait for it -- the class of commit 9bc486e, which --copies cannot see because it trusts the wait in front of the first MFMA.)
 
 --copies: the second hazard of hand-counted waits.  A register written by an inline-asm `buffer_load_dwordx4` / `global_load_dwordx4` (between
 ;;#ASMSTART / ;;#ASMEND) holds its value only once the load has landed, which the compiler does not know: any instruction
@@ -184,6 +189,135 @@ def audit_copies(body):
     return sorted(set(out))
 
 
+def _cfg(body):
+    """-> list of blocks {'insts': [(line, text, in_asm)], 'succ': [block index]} of one kernel listing."""
+    insts, inasm = [], False
+    for i, ln in enumerate(body):
+        s = ln.strip()
+        if s.startswith(';;#ASMSTART'):
+            inasm = True
+            continue
+        if s.startswith(';;#ASMEND'):
+            inasm = False
+            continue
+        if not s or s[0] == ';' or (s[0] == '.' and not s.startswith('.LBB')):
+            continue
+        insts.append((i, s, inasm))
+    blocks, cur, label_of = [], None, {}
+    for i, t, a in insts:
+        if t.startswith('.LBB'):
+            cur = {'insts': [], 'succ': []}
+            label_of[t.split(':')[0]] = len(blocks)
+            blocks.append(cur)
+            continue
+        if cur is None:
+            cur = {'insts': [], 'succ': []}
+            blocks.append(cur)
+        cur['insts'].append((i, t, a))
+        if t.startswith(('s_cbranch', 's_branch', 's_endpgm')):
+            cur['term'] = t
+            cur = {'insts': [], 'succ': []}
+            blocks.append(cur)
+    for b, blk in enumerate(blocks):
+        term = blk.get('term', '')
+        if term.startswith('s_endpgm'):
+            continue
+        if term.startswith(('s_branch', 's_cbranch')):
+            tgt = term.split()[1]
+            if tgt in label_of:
+                blk['succ'].append(label_of[tgt])
+        if not term.startswith('s_branch') and b + 1 < len(blocks):
+            blk['succ'].append(b + 1)
+    return blocks
+
+
+_VMEM = re.compile(r'(buffer|global|flat|scratch)_(load|store|atomic)')
+CAP = 64
+
+
+def audit_counts(body):
+    """-> list of (line, text): instructions that read or overwrite a register whose INLINE-ASM load (or returning atomic) the
+    counted `s_waitcnt vmcnt(N)` in front of them does not cover -- the "too large N" class (commit 9bc486e: the first tile of
+    conv0_gdn_f32_persist waited vmcnt(12) with no store behind its loads yet, i.e. for nothing).
+
+    Model = the one the kernels are written to: vector-memory operations retire in issue order, `vmcnt(N)` returns when at most N
+    are outstanding.  For every register written by an asm `global_load / buffer_load / returning global_atomic` the analysis
+    carries d = the number of vector-memory operations (loads, stores, atomics, LDS-DMA; asm or compiler-issued) issued after
+    it, the MINIMUM over all paths of the control-flow graph (fixpoint); `vmcnt(N)` retires the registers with d >= N.  A
+    register that is still outstanding when an instruction reads it, or overwrites it, is a finding.  Compiler-visible loads are
+    not tracked: hipcc's own scoreboard waits for those."""
+    blocks = _cfg(body)
+
+    def is_asm_ret(t, a):
+        if not a:
+            return False
+        op = t.split()[0]
+        if op.startswith(('global_load_dword', 'buffer_load_dword', 'global_load_ushort', 'global_load_ubyte')) and ' lds' not in t:
+            return True
+        return op.startswith('global_atomic') and (' sc0' in t or ' glc' in t)
+
+    def step(t, a, st, report, i):
+        toks = t.replace(',', ' ').split()
+        op, args = toks[0], toks[1:]
+        if op == 's_waitcnt':
+            m = re.search(r'vmcnt\((\d+)\)', t)
+            if m:
+                n = int(m.group(1))
+                st = {r: d for r, d in st.items() if d < n}
+            return st
+        if op.startswith('s_'):
+            return st
+        vm = bool(_VMEM.match(op))
+        is_store = op.startswith(('buffer_store', 'global_store', 'ds_write', 'flat_store', 'scratch_store'))
+        dst = set() if is_store else (regs_of(args[0]) if args else set())
+        srcs = set()
+        for x in (args if is_store else args[1:]):
+            srcs |= regs_of(x)
+        tracked = is_asm_ret(t, a)
+        hit = (srcs | (set() if tracked else dst)) & set(st)
+        if hit and report is not None:
+            report.append((i, t + '   <- v%s: asm load possibly in flight (vmcnt budget %d)' % (sorted(hit)[0], min(st[r] for r in hit))))
+        if vm:
+            st = {r: min(d + 1, CAP) for r, d in st.items()}
+        st = {r: d for r, d in st.items() if r not in dst}
+        if tracked:
+            for r in dst:
+                st[r] = 0
+        return st
+
+    state_in = [None] * len(blocks)
+    state_in[0] = {}
+    work = [0]
+    while work:
+        b = work.pop()
+        st = dict(state_in[b])
+        for i, t, a in blocks[b]['insts']:
+            st = step(t, a, st, None, i)
+        for sidx in blocks[b]['succ']:
+            old = state_in[sidx]
+            if old is None:
+                state_in[sidx] = dict(st)
+                work.append(sidx)
+            else:
+                merged = dict(old)
+                changed = False
+                for r, d in st.items():
+                    if r not in merged or d < merged[r]:
+                        merged[r] = d
+                        changed = True
+                if changed:
+                    state_in[sidx] = merged
+                    work.append(sidx)
+    out = []
+    for b, blk in enumerate(blocks):
+        if state_in[b] is None:
+            continue
+        st = dict(state_in[b])
+        for i, t, a in blk['insts']:
+            st = step(t, a, st, out, i)
+    return sorted(set(out))
+
+
 def audit_stores(body):
     """-> list of (store, next instruction) where a VALU write of the store's data registers follows it directly."""
     ins = [ln.strip() for ln in body]
@@ -221,6 +355,21 @@ if __name__ == '__main__':
                 for st, nx in audit_stores(body):
                     print('STORE? %s: %s -> %s' % (name[:80], st, nx))
                     n_file += 1
+            bad += n_file
+            print('%s: %s' % (os.path.basename(src), 'ok' if not n_file else '%d findings' % n_file))
+        sys.exit(1 if bad else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == '--counts':
+        import os
+        bad = 0
+        for src in sys.argv[2:]:
+            n_file = 0
+            for name, body in kernels(compile_to_isa(src)):
+                found = audit_counts(body)
+                for i, text in found[:6]:
+                    print('COUNT? %s line %d: %s' % (name[:90], i, text))
+                if len(found) > 6:
+                    print('       ... %d more in this kernel' % (len(found) - 6))
+                n_file += len(found)
             bad += n_file
             print('%s: %s' % (os.path.basename(src), 'ok' if not n_file else '%d findings' % n_file))
         sys.exit(1 if bad else 0)
