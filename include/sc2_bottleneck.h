@@ -62,13 +62,12 @@ typedef struct sc2_policy {
     int32_t conv_no_big;         /* 1: never the 8-wave 256-row tile */
     int32_t conv_force_big;      /* 1: the 8-wave tile wherever Cout allows (tests) */
     int32_t conv_no_epx;         /* 1: no epilogue-operand prefetch instantiations */
-    int32_t conv_touch;          /* 1: touch the epilogue operand's lines before the K loop (A/B) */
     int32_t conv_debug;          /* development: bit 0 skips the store epilogue, bit 1 the K loop (results garbage) */
     int32_t conv_chunk;          /* conv_dec_persist: tiles per claim (0 = default 2) */
     /* window-plane kernels */
     int32_t w2_run;              /* conv2x2_win: tiles per workgroup run (0 = default: min(share, 2)) */
     int32_t win_half;            /* conv3x3_win: half tiles, two workgroups per CU (default 1) */
-    int32_t win_dbg;             /* conv3x3_win 14 x 14: timing experiments 1 / 2 / 4 (results garbage; default 0) */
+    int32_t win_dbg;             /* conv3x3_win 14 x 14: timing experiments (results garbage; -DSC2_EXPERIMENTS builds only; default 0) */
     int32_t win_stamps;          /* conv3x3_win: 1 = per-workgroup wall-clock summary on stderr (diagnostic) */
     int32_t p1_half;             /* conv1x1_win: 112-pixel tiles (default 0) */
     int32_t p1_nbuf;             /* conv1x1_win: LDS ring depth 2 / 4 (0 = by shape) */

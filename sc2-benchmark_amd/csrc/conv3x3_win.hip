@@ -622,7 +622,8 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
     }
     if (W == 28) return launch_win<G28>(a, s);
     if (W == 14) {
-        switch (sc2_pol().win_dbg) {   // timing experiments on the 14 x 14 geometry (results garbage)
+#ifdef SC2_EXPERIMENTS   // timing experiments on the 14 x 14 geometry (results garbage): never in the shipped library
+        switch (sc2_pol().win_dbg) {
             case 1: return launch_win<G14, 1>(a, s);
             case 2: return launch_win<G14, 2>(a, s);
             case 4: return launch_win<G14, 4>(a, s);
@@ -630,8 +631,12 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
             case 3: return launch_win<G14, 3>(a, s);
             case 7: return launch_win<G14, 7>(a, s);
             case 15: return launch_win<G14, 15>(a, s);
-            default: return launch_win<G14>(a, s);
+            default: break;
         }
+#else
+        SC2_REQUIRE(sc2_pol().win_dbg == 0, SC2_ERR_UNSUPPORTED, "conv3x3_win: win_dbg timing experiments need a -DSC2_EXPERIMENTS build");
+#endif
+        return launch_win<G14>(a, s);
     }
     return launch_win<G7>(a, s);
 }

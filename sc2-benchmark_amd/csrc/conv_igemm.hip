@@ -177,7 +177,6 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.b_row_stride = (d->k_order & SC2_K_B_TILE_MAJOR) ? 32 : d->Kpad;
     a.dbg = sc2_pol().conv_debug;
     const bool needs_x_operand = epi_needs_x(d->epilogue);
-    a.touch = (needs_x_operand && d->out_format == SC2_OUT_BF16_NHWC && !scatter && sc2_pol().conv_touch) ? 1 : 0;
     a.o_H = scatter ? d->out_H : 0; a.o_W = d->out_W; a.o_sh = d->out_stride_h; a.o_sw = d->out_stride_w;
     a.o_h0 = d->out_off_h; a.o_w0 = d->out_off_w;
     a.DH = dil_h; a.DW = dil_w;
@@ -293,7 +292,6 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     if (big && d->Cout % 128 == 0) return launch8<BG_128>(a, s);
     bool epx = needs_x_operand &&
                      d->out_format == SC2_OUT_BF16_NHWC && !scatter && !sc2_pol().conv_no_epx;
-    if (a.touch) epx = false;
     if (epx) {
         if (rows == 96 && matches<Cx_gdn96>(a)) return launch<Cx_gdn96>(a, s);
         if (rows == 48 && matches<Cx_gdn48>(a)) return launch<Cx_gdn48>(a, s);

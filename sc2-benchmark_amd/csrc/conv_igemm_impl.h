@@ -76,7 +76,6 @@ struct ConvArgs {
                         // (SC2_K_B_TILE_MAJOR: [k-slab][row][32], a slab's B tile is contiguous: whole 128-byte lines per load)
     int b_row_stride;   // element stride between weight rows: Kpad or 32
     int k_slab_major;   // K ordered (channel slab of 32, tap, channel) instead of (tap, channel): needs Cin % 32 == 0
-    int touch; // 1: pull the epilogue operand's lines into L2 with one dword load per 128-byte line before the K loop
     int dbg;   // development switches (SC2_CONV_DEBUG): bit 0 skips the store epilogue, bit 1 the K loop
     unsigned x_bytes, w_bytes;   // sizes of x and of the packed weights when both are < 2 GB (buffer-addressed loads), else 0
     int o_H, o_W, o_sh, o_sw, o_h0, o_w0;   // NHWC output scatter (o_H == 0: dense): pixel (oh, ow) -> (oh*o_sh+o_h0, ..)
@@ -214,37 +213,6 @@ __device__ __forceinline__ void conv_prefetch_epx(const ConvArgs &p, int tid, in
         const bool ok = (q < Q) & (m < p.M) & (n < p.Cout);
         epx[r] = ok ? *reinterpret_cast<const uint4 *>(p.ep_x + (long long)m * p.Cout + n) : make_uint4(0u, 0u, 0u, 0u);
     }
-}
-
-// L2 prefetch of the epilogue operand tile (gfx950 has no prefetch instruction): one dword load per 128-byte line into
-// a scratch register that nothing reads; the load is the oldest entry of the wave's vmcnt queue, so the counted waits of
-// the K loop retire it with the first slab.  Costs one VGPR instead of the 32 of the register prefetch.
-template <class C, int NTHREADS>
-struct TouchGeom {
-    static constexpr int LPR = (C::BN * 2 + 127) / 128;            // lines per tile row
-    static constexpr int NL = C::BM * LPR;
-    static constexpr int TPT = (NL + NTHREADS - 1) / NTHREADS;     // touches per thread
-};
-// The destination registers must stay reserved until the loads have returned (the compiler cannot see the pending
-// writes of an asm load): the caller passes `sink` to conv_touch_done() after a vmcnt wait that covers them.
-template <class C, int NTHREADS>
-__device__ __forceinline__ void conv_touch_epx(const ConvArgs &p, int tid, int m0, int n0,
-                                               uint32_t (&sink)[TouchGeom<C, NTHREADS>::TPT]) {
-    constexpr int LPR = TouchGeom<C, NTHREADS>::LPR, NL = TouchGeom<C, NTHREADS>::NL;
-#pragma unroll
-    for (int r = 0; r < TouchGeom<C, NTHREADS>::TPT; ++r) {
-        const int q = tid + r * NTHREADS;
-        const int row = q / LPR, cl = q - row * LPR;
-        const int m = m0 + row, n = n0 + cl * 64;
-        const bool ok = (q < NL) & (m < p.M) & (n < p.Cout);
-        const uint16_t *src = ok ? p.ep_x + (long long)m * p.Cout + n : p.ep_x;
-        asm volatile("global_load_dword %0, %1, off" : "=v"(sink[r]) : "v"(src) : "memory");
-    }
-}
-template <int N>
-__device__ __forceinline__ void conv_touch_done(uint32_t (&sink)[N]) {
-#pragma unroll
-    for (int r = 0; r < N; ++r) asm volatile("" ::"v"(sink[r]));
 }
 
 __device__ __forceinline__ long long conv_out_offset(const ConvArgs &p, int m, int n, bool &ok) {
@@ -720,8 +688,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     // epilogue operand (GDN's x / residual), fetched now so that its latency hides behind the K loop
     uint4 epx[C::EPX ? EpiGeom<C, 256>::QPT : 1];
     if constexpr (C::EPX) conv_prefetch_epx<C, 256>(p, tid, m0, n0, epx);
-    uint32_t touch_sink[TouchGeom<C, 256>::TPT] = {};
-    if (!C::EPX && p.touch) conv_touch_epx<C, 256>(p, tid, m0, n0, touch_sink);
 
 #pragma unroll
     for (int st = 0; st < S - 1; ++st) issue_tile(st, st);
@@ -772,7 +738,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     }
     // drain the dummy slabs and make sure every wave is done reading before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    conv_touch_done(touch_sink);
     __builtin_amdgcn_s_barrier();
 
     // ------------------------------------------------------------------ fused GDN1 / inverse GDN1

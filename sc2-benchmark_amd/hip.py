@@ -56,7 +56,7 @@ class Sc2Error(RuntimeError):
 # tools/env_policy.py maps the SC2_* variables of the A/B scripts onto it -- the package itself never reads them.
 # --------------------------------------------------------------------------------------------- #
 POLICY_FIELDS = ('struct_bytes', 'conv_patch3', 'conv_s2', 'conv_persist', 'conv_half', 'conv_big4', 'conv_no_big', 'conv_force_big',
-                 'conv_no_epx', 'conv_touch', 'conv_debug', 'conv_chunk', 'w2_run', 'win_half', 'win_dbg', 'win_stamps', 'p1_half',
+                 'conv_no_epx', 'conv_debug', 'conv_chunk', 'w2_run', 'win_half', 'win_dbg', 'win_stamps', 'p1_half',
                  'p1_nbuf', 'pair_alt', 'f32_persist0', 'dec_stagger', 'wgrad_wgs', 'rans_lds_pad_kb', 'rans_pad_waves', 'rans_ragged2',
                  'rans_ragged2_waves', 'rans_lut8')
 

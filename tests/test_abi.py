@@ -110,6 +110,22 @@ def test_asm_weight_loads_are_never_copied_in_flight():
     r2 = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_vmcnt.py'), '--stores'] + stores, capture_output=True, text=True)
     assert r2.returncode == 0 and r2.stdout.count(': ok') == len(stores), r2.stdout + r2.stderr
     assert r.stdout.count(': ok') == len(files) and 'COPY?' not in r.stdout, r.stdout
+    # round 5, the third check: is every counted wait SMALL enough?  `--counts` follows each register an inline-asm load (or returning
+    # atomic) writes through the control-flow graph with the number of vector-memory operations issued behind it (the model the
+    # kernels are written to: in-order retirement); a `vmcnt(N)` with a larger N does not wait for it -- the class of commit 9bc486e
+    # (conv0_gdn_f32_persist's first tile), which --copies cannot see.  Every file with hand-written vector-memory asm goes through
+    # it EXCEPT conv2x2_win.hip: there a wave-uniform runtime condition selects both how many window fills a k-step issues and which
+    # wait constant it uses (correlated branches), which a path-insensitive analysis cannot pair up -- that kernel stays under
+    # --copies and its bit-identity tests (tests/test_gpu_kernels.py::test_conv2x2_win*).
+    counted = [os.path.join(csrc, f) for f in ('conv0_gdn96.hip', 'conv1x1_kres.hip', 'conv1x1_pair.hip', 'conv1x1_stream.hip', 'conv1x1_win.hip',
+                                               'conv2_gdn48.hip', 'conv3x3_win.hip', 'conv_gdn512.hip', 'conv_f32.hip', 'conv_dec_persist.hip',
+                                               'conv_wgrad.hip', 'rans.hip', 'conv_inst_a.hip', 'conv_inst_c.hip', 'conv_inst_e.hip')]
+    from concurrent.futures import ThreadPoolExecutor     # (one hipcc -S per file: six at a time)
+    tool = os.path.join(root, 'tools', 'audit_vmcnt.py')
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        runs = list(ex.map(lambda f: subprocess.run([sys.executable, tool, '--counts', f], capture_output=True, text=True), counted))
+    for f, r3 in zip(counted, runs):
+        assert r3.returncode == 0 and ': ok' in r3.stdout and 'COUNT?' not in r3.stdout, f + '\n' + r3.stdout + r3.stderr
 
 
 def test_hot_path_kernels_use_no_scratch():

@@ -18,7 +18,7 @@ ENV = {
     'SC2_CONV_PATCH3': ('conv_patch3', _INT), 'SC2_CONV_S2': ('conv_s2', _INT), 'SC2_CONV_PERSIST': ('conv_persist', _INT),
     'SC2_CONV_HALF': ('conv_half', _INT), 'SC2_CONV_BIG4': ('conv_big4', _INT), 'SC2_CONV_NO_BIG': ('conv_no_big', lambda v: 1),
     'SC2_CONV_FORCE_BIG': ('conv_force_big', lambda v: 1), 'SC2_CONV_NO_EPX': ('conv_no_epx', lambda v: 1),
-    'SC2_CONV_TOUCH': ('conv_touch', _INT), 'SC2_CONV_DEBUG': ('conv_debug', _INT), 'SC2_CONV_CHUNK': ('conv_chunk', _INT),
+    'SC2_CONV_DEBUG': ('conv_debug', _INT), 'SC2_CONV_CHUNK': ('conv_chunk', _INT),
     'SC2_W2_RUN': ('w2_run', _INT), 'SC2_WIN_HALF': ('win_half', _INT), 'SC2_WIN_DBG': ('win_dbg', _INT),
     'SC2_WIN_STAMPS': ('win_stamps', _INT), 'SC2_P1_HALF': ('p1_half', _INT), 'SC2_P1_NBUF': ('p1_nbuf', _INT),
     'SC2_PAIR_ALT': ('pair_alt', _INT), 'SC2_F32_PERSIST0': ('f32_persist0', lambda v: 0 if v.startswith('0') else 1),
