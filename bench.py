@@ -324,7 +324,7 @@ STAGE2 = {   # train.stage2 of the same YAML (:231-295): KD loss on the logits, 
 }
 
 
-def train_bench(args, dev, rank, world, distributed):
+def train_bench(args, dev, rank, world, distributed, emit=True):
     """Stage-1 Entropic-Student training step: frozen teacher forward, student forward (HIP bottleneck + frozen tail),
     MSE-sum + 0.08 * bits, aux loss, backward on the HIP kernels, ONE flat-bucket gradient all-reduce (RCCL), Adam."""
     import sc2bench_amd as S
@@ -368,8 +368,9 @@ def train_bench(args, dev, rank, world, distributed):
     assert torch.isfinite(loss)
     # metric reduction as evaluation does it (sum of [count, total] over ranks), on the backend's device
     g_images, g_loss = dp.all_reduce_sum_scalars([float(args.bs * args.steps), float(loss) * args.bs])
+    line = None
     if rank == 0:
-        print(json.dumps({
+        line = ({
             'metric': 'images/s, Entropic-Student ResNet-50 stage-{} training step, 224^2'.format(args.stage), 'value': args.bs * args.steps * world / elapsed,
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -383,10 +384,13 @@ def train_bench(args, dev, rank, world, distributed):
                        'collectives_issued': bool(dp.collectives_active()),
                        'gradient_buckets': len(stage.reducer.buckets),
                        'buckets_launched_from_backward_hooks_last_step': stage.reducer.launched_by_hook},
-            'final_loss': loss.item(), 'images_all_ranks': g_images, 'mean_loss_all_ranks': g_loss / max(g_images / args.steps, 1.0)}))
-    if distributed:
+            'final_loss': loss.item(), 'images_all_ranks': g_images, 'mean_loss_all_ranks': g_loss / max(g_images / args.steps, 1.0)})
+        if emit:
+            print(json.dumps(line))
+    if distributed and emit:
         dist.barrier()
         dist.destroy_process_group()
+    return line
 
 
 def dry_run(args, world, rank, local_rank):
@@ -669,7 +673,7 @@ def ranks_reduced(dev, distributed):
     return int(round(one.item()))
 
 
-def workload_bench(args, dev, rank, world, distributed):
+def workload_bench(args, dev, rank, world, distributed, emit=True):
     """`--workload mshp224 | seg513 | det800x1216 | fp_input`: that config's updated model through the package's stage pipeline
     (the same scheduler as the headline line: front stages run ahead, the range coder of G batches shares a launch on its own
     HIP stream, byte streams stay on the device), K steps after W warm-up steps.  `--no-pipeline`: the module forward per
@@ -719,7 +723,7 @@ def workload_bench(args, dev, rank, world, distributed):
     leaves = list(out.values()) if isinstance(out, dict) else [out]
     assert all(torch.isfinite(v.float()).all() for v in leaves)
     if rank != 0:
-        return
+        return None
     ksum = timer.summary()
     bn = {k: v for k, v in ksum.items() if k.startswith(('enc.', 'dec.')) and k != 'dec.dequantize'}
     roofline = None
@@ -776,7 +780,7 @@ def workload_bench(args, dev, rank, world, distributed):
         coder = ('HOST threads (sc2_rans_encode_host / sc2_rans_decode_host): this batch is {} streams of {} symbols, a few long '
                  'serial chains, which a CPU core steps faster than a GPU lane -- these are NOT HIP-coder figures'.format(n_streams, sym_per_stream)) \
             if on_host else 'batched HIP coder ({} streams per launch)'.format(n_streams)
-    print(json.dumps({
+    line = ({
         'metric': 'images/s + bpp, ' + args.workload, 'value': n * args.steps * world / elapsed, 'unit': 'images/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': max(1, args.warmup), 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
@@ -785,10 +789,44 @@ def workload_bench(args, dev, rank, world, distributed):
         'bpp': 8.0 * nbytes / pix, 'bpp_estimated': bpp_est, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': cpu,
         'rans': {k: {'ms_per_launch': round(v[1], 4), 'launches_per_step': v[0] / float(args.steps)}
                  for k, v in sorted(ksum.items()) if k.startswith('rans')},
-        'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())}}))
+        'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())}})
+    if emit:
+        print(json.dumps(line))
     if cpu_failed:
         sys.stdout.flush()
         raise SystemExit('bench.py: ' + cpu_failed)
+    return line
+
+
+def secondary_lines(args, dev):
+    """Compact rows of the other workloads and of the stage-1 training step, measured by the default invocation after its own
+    timed region: {name: {'value', 'unit', 'ms_per_step', 'steps', ...}}; a workload that fails leaves {'error': ...}."""
+    import copy
+    import gc
+    rows = {}
+    for name in ('mshp224', 'seg513', 'det800x1216', 'fp_input', 'train_stage1'):
+        a = copy.copy(args)
+        a.no_cpu_baseline, a.warmup, a.bs, a.coder_group, a.inflight = True, 3, 256, 0, 0
+        try:
+            if name == 'train_stage1':
+                a.mode, a.stage, a.steps, a.warmup = 'train', 1, 10, 3
+                line = train_bench(a, dev, 0, 1, False, emit=False)
+                rows[name] = {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': a.steps,
+                              'workload': line['config']['workload'], 'batch': line['config']['batch_per_gpu']}
+            else:
+                a.workload, a.steps = name, (40 if name == 'det800x1216' else 20)
+                line = workload_bench(a, dev, 0, 1, False, emit=False)
+                rows[name] = {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': a.steps,
+                              'bpp': line['bpp'], 'bpp_estimated': line['bpp_estimated'], 'batch': line['config']['batch_per_gpu'],
+                              'pipeline': line['config']['pipeline'] if isinstance(line['config']['pipeline'], str)
+                              else {k: line['config']['pipeline'][k] for k in ('steps_per_coder_launch', 'hip_streams', 'streams_per_coder_launch')},
+                              'bottleneck_forward_frac_of_mfma_peak': line['roofline']['frac'] if line.get('roofline') else None,
+                              'workload': line['config']['workload'][:120]}
+        except Exception as e:     # a secondary row never costs the headline line
+            rows[name] = {'error': repr(e)[:300]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return rows
 
 
 def self_launch(n):
@@ -824,6 +862,7 @@ def main():
     ap.add_argument('--coder-group', type=int, default=0, help='steps whose symbols share one range-coder launch; 0 = the workload\'s default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bs1', action='store_true', help='skip the bs-1 evaluation-mode row')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` rows (the other workloads + the training step, a few steps each, after the timed region)')
     ap.add_argument('--split-mfma', type=int, default=1, help='decoder+head stages round-robin on K HIP streams of their own')
     ap.add_argument('--front-priority', type=int, default=0, help='HIP stream priority of the encoder stream (-1 = high)')
     ap.add_argument('--back-priority', type=int, default=0, help='HIP stream priority of the decoder+head stream(s) (-1 = high)')
@@ -1122,6 +1161,11 @@ def main():
                 out['cpu_baseline'] = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': 'failed: {!r}'.format(e)}
                 failed = 'cpu_baseline failed: {!r}'.format(e)
+        if world == 1 and not distributed and not args.no_secondary:
+            # the other configurations through the SAME command (VERDICT r4 "builder-only numbers"): after the headline's timed
+            # region, each on the package's stage pipeline (or the training step), a few steps each, compact rows in `secondary`
+            del logits, nb, st, last
+            out['secondary'] = secondary_lines(args, dev)
         print(json.dumps(out))
         if failed:
             sys.stdout.flush()
