@@ -535,9 +535,10 @@ def build_workload(name, dev, bs):
                                                    post_transform=post, analysis_config={})
         model.eval().to(dev)
         codec.update()
+        model.set_compute_dtype('bf16')      # the ResNet-50 classifier on the library's fused conv + norm kernels (head.HipResNet)
         x = torch.rand(n, 3, 224, 224, generator=torch.Generator().manual_seed(0)).to(dev)
         what = ('bmshj2018_factorized quality 8 (N 192, M 320) input compression on the HIP kernels (AdaptivePad 64 -> 256x256) + '
-                'ResNet-50 classifier (torch f32 ops), 224x224, eval after update()')
+                'ResNet-50 classifier (bf16, the library\'s fused conv + norm kernels), 224x224, eval after update()')
         return model, x, what, None, n
     raise SystemExit('unknown workload ' + name)
 

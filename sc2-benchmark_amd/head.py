@@ -240,3 +240,42 @@ class HipHead(object):
         out = hip.conv2d_fwd(pin, w, cout_pad, 1, 1, 1, 0, epilogue=hip.EPI_BIAS, ep_beta=b,
                              out_format=hip.OUT_F32_NHWC, tag='head.fc')
         return out.reshape(out.shape[0], cout_pad)[:, :n_cls]
+
+
+class HipResNet(object):
+    """A whole torchvision-layout ResNet (`resnet.ResNet`: stem conv 7x7 + norm + ReLU, max-pool, layer1..4, avgpool, fc) in eval
+    mode on the library's kernels: the classifier behind a neural INPUT codec (sc2bench/models/wrapper.py:80-135,
+    `NeuralInputCompressionClassifier`, BASELINE config 3), which the reference leaves to cuDNN.  On torch ops in f32 that
+    classifier went to MIOpen's `naive_conv_*` kernels and took three quarters of a step (rocprofv3 of
+    `bench.py --workload fp_input`, round 5).  bf16 operands, f32 accumulation, as the Entropic-Student head."""
+
+    def __init__(self, model):
+        w = model.conv1.weight.detach().float()
+        cin_pad = (w.shape[1] + 7) // 8 * 8
+        if cin_pad != w.shape[1]:      # 3 input channels -> 8 (zeros): the kernels read 16-byte channel runs
+            w = torch.cat([w, w.new_zeros(w.shape[0], cin_pad - w.shape[1], w.shape[2], w.shape[3])], 1)
+        self.cin_pad = cin_pad
+        self.stem = _Conv(ConvSpec(w, model.conv1.stride, model.conv1.padding), model.bn1, 'clf.stem')
+        self.pool = (model.maxpool.kernel_size, model.maxpool.stride, model.maxpool.padding)
+        self.head = HipHead([(i + 1, layer) for i, layer in enumerate((model.layer1, model.layer2, model.layer3, model.layer4))], model.fc)
+        self.key = self.version_key(model)
+
+    @staticmethod
+    def version_key(model):
+        return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+
+    @staticmethod
+    def supported(model):
+        from .resnet import ResNet
+        return (isinstance(model, ResNet) and not model.training and model.conv1.bias is None and model.conv1.groups == 1 and
+                isinstance(model.bn1, (nn.BatchNorm2d, FrozenBatchNorm2d)) and isinstance(model.maxpool, nn.MaxPool2d) and
+                all(c.dilation == (1, 1) for layer in (model.layer1, model.layer2, model.layer3, model.layer4) for b in layer
+                    for c in (b.conv1, b.conv2, b.conv3)))
+
+    def forward(self, x):
+        """f32 (or bf16) NCHW image batch -> f32 logits [N, classes]"""
+        x_nhwc = hip.nchw_f32_to_nhwc_bf16(x.float().contiguous(), self.cin_pad)
+        h = self.stem(x_nhwc, hip.EPI_BIAS_RELU)
+        k, st, pd = self.pool
+        h = nn.functional.max_pool2d(h.permute(0, 3, 1, 2), k, st, pd).permute(0, 2, 3, 1).contiguous()   # channels_last: a view
+        return self.head.forward(h, with_pool=True)

@@ -117,7 +117,27 @@ class NeuralInputCompressionClassifier(AnalyzableModule):
         x = self.compression_model.stage_back(decoded, meta)
         if self.post_transform is not None:
             x = self.post_transform(x)
-        return self.classification_model(x)
+        return self._classify(x)
+
+    def set_compute_dtype(self, dtype):
+        """'f32' (the reference's dtype; default): the classifier's own torch modules.  'bf16': a torchvision-layout ResNet
+        classifier in eval mode runs on the library's fused conv + norm kernels (head.HipResNet), as the Entropic-Student
+        model's head does; any other classifier keeps its modules."""
+        assert dtype in ('f32', 'bf16')
+        self.compute_dtype = dtype
+        return self
+
+    def _classify(self, x):
+        clf = self.classification_model
+        if getattr(self, 'compute_dtype', 'f32') == 'bf16' and x.is_cuda and not self.training:
+            from .head import HipResNet
+            if HipResNet.supported(clf):
+                ent = self.__dict__.get('_hip_clf')
+                if ent is None or ent.key != HipResNet.version_key(clf):
+                    ent = HipResNet(clf)
+                    self.__dict__['_hip_clf'] = ent
+                return ent.forward(x)
+        return clf(x)
 
     def forward(self, x):
         if self.pre_transform is not None:
@@ -133,7 +153,7 @@ class NeuralInputCompressionClassifier(AnalyzableModule):
                 x = x['x_hat']
         if self.post_transform is not None:
             x = self.post_transform(x)
-        return self.classification_model(x)
+        return self._classify(x)
 
 
 @register_wrapper_class

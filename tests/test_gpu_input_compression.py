@@ -139,3 +139,12 @@ def test_neural_input_compression_classifier_config3(S, R, dev):
     sizes = wrapped.analyzers[0].file_size_list
     assert len(sizes) == 2 and all(s > 0 for s in sizes)        # one analysed object per forward call
     assert sizes[1] == R.file_size(obj)                          # the batch-of-4 object, pickled as the reference pickles it
+    # round 5: set_compute_dtype('bf16') -- the ResNet-50 classifier on the library's fused conv + norm kernels (head.HipResNet:
+    # stem conv 7x7 + layer1..4 + fc); against the f32 torch classifier on the same reconstruction, at the bf16 head's tolerance
+    with torch.no_grad():
+        f32_logits = wrapped(x.to(dev)).float().cpu()
+        wrapped.set_compute_dtype('bf16')
+        bf_logits = wrapped(x.to(dev)).float().cpu()
+    assert wrapped.__dict__.get('_hip_clf') is not None, 'the bf16 mode did not take the HIP classifier'
+    scale = f32_logits.abs().max().item()
+    assert (bf_logits - f32_logits).abs().max().item() <= 0.03 * scale + 0.03
