@@ -170,9 +170,15 @@ class Normalize(nn.Module):
         self.mean, self.std = list(mean), list(std)
 
     def forward(self, x):
-        mean = torch.as_tensor(self.mean, dtype=x.dtype, device=x.device).view(-1, 1, 1)
-        std = torch.as_tensor(self.std, dtype=x.dtype, device=x.device).view(-1, 1, 1)
-        return (x - mean) / std
+        # (the two constant vectors live on the input's device once: building them per call is a blocking host-to-device copy,
+        #  4 ms each with a busy device queue -- it was 8 of the 12 ms of a pipelined fp_input step, tools/host_prof_workload.py)
+        key = (x.dtype, x.device)
+        cached = self.__dict__.get('_consts')
+        if cached is None or cached[0] != key or cached[3] != (tuple(self.mean), tuple(self.std)):
+            cached = (key, torch.as_tensor(self.mean, dtype=x.dtype, device=x.device).view(-1, 1, 1),
+                      torch.as_tensor(self.std, dtype=x.dtype, device=x.device).view(-1, 1, 1), (tuple(self.mean), tuple(self.std)))
+            self.__dict__['_consts'] = cached
+        return (x - cached[1]) / cached[2]
 
 
 @_tv
