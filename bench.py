@@ -623,9 +623,10 @@ def workload_cpu_baseline(name, model, x, budget_s=12.0):
 
 WORKLOAD_PIPELINE = {   # (coder group G, coder streams) per workload, by measurement
     'es224': (8, 4),
-    # mean-scale hyperprior: the per-symbol-index decoder holds 120 KB of LDS per 16-stream workgroup for ~19 ms -- a 2 048-stream
-    # launch would pin 128 CUs; 512 streams per launch (32 CUs), three launches in flight
-    'mshp224': (2, 3),
+    # mean-scale hyperprior: the per-symbol-index decoder holds 120 KB of LDS per workgroup for ~20 ms; 2 048 streams per launch with
+    # two 16-stream waves per workgroup (64 CUs held, the library's choice from 1 024 streams up), three launches in flight
+    # (tools/mshp_sweep.sh, 40 steps: 35.2 k images/s at G = 2, 36.6 k at G = 8 with one wave per workgroup, 39.3 k with two)
+    'mshp224': (8, 3),
     'fp_input': (8, 4),      # 32 streams per batch: 256 per launch
     'seg513': (8, 4),        # 16 streams x 393 k symbols per batch: 128 per launch, ~85 ms of chain each way
     'det800x1216': (8, 6),   # 6 streams x 1.45 M symbols per batch: 48 per launch (one wave), ~330 ms each way

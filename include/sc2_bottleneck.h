@@ -80,7 +80,7 @@ typedef struct sc2_policy {
     int32_t rans_lds_pad_kb;     /* small coder launches ask for this much LDS so that nothing shares their CU (default 159; 0 off) */
     int32_t rans_pad_waves;      /* ... launches of up to this many serial waves (default 16) */
     int32_t rans_ragged2;        /* four-lanes-per-stream decoder for per-symbol CDF rows (default 1) */
-    int32_t rans_ragged2_waves;  /* ... waves per workgroup sharing one table copy: 1 (default), 2, 4, 8 */
+    int32_t rans_ragged2_waves;  /* ... waves per workgroup sharing one table copy: 0 (default) = 1 below 1 024 streams per launch, 2 from there; 1, 2, 4, 8 force */
     int32_t rans_lut8;           /* 1: one-lookup bucketed decode tables for implicit CDF rows (default 0: measured 6 % SLOWER than the two-lookup decoder) */
     int32_t reserved[8];
 } sc2_policy;
