@@ -135,7 +135,12 @@ enum sc2_conv_epilogue {
     /* CompressAI GDN (squared form; bmshj2018_factorized g_a / g_s, reached from sc2bench/models/registry.py:73-80): with
      * a_op = SC2_AOP_SQUARE and the 1x1 gamma GEMM, acc = gamma x^2 */
     SC2_EPI_GDN2 = 9,  /* y = ep_x * rsqrt(ep_beta[c] + acc)   (GDN, inverse=False) */
-    SC2_EPI_IGDN2 = 10 /* y = ep_x * sqrt(ep_beta[c] + acc)    (GDN, inverse=True)  */
+    SC2_EPI_IGDN2 = 10, /* y = ep_x * sqrt(ep_beta[c] + acc)    (GDN, inverse=True)  */
+    /* sc2_gdn1_bwd_gemm only (round 5): the two GEMMs of the GDN1 backward with its element-wise halves in their epilogues.
+     * n = ep_beta[c] + acc (acc = gamma |x|, a_op ABS), g = the gradient at the GDN's output, x = its input: */
+    SC2_EPI_GDN1_BWD_PRE = 11,   /* ep_x = g, ep_x2 = x:  y2 = g / n (direct term),  y = -y2 * x / n  (d_norm) */
+    SC2_EPI_IGDN1_BWD_PRE = 12,  /* ep_x = g, ep_x2 = x:  y2 = g * n,                y = g * x         (d_norm) */
+    SC2_EPI_GDN1_BWD_POST = 13   /* acc = gamma^T d_norm, ep_x = direct term, ep_x2 = x:  y = ep_x + sign(x) * acc  (= dL/dx) */
 };
 enum sc2_conv_out { SC2_OUT_BF16_NHWC = 0, SC2_OUT_F32_NCHW = 1, SC2_OUT_F32_NHWC = 2,
                     /* int32 NCHW symbols round_half_even(acc - ep_beta[c]) (ep_beta = the entropy bottleneck's medians,
@@ -178,7 +183,7 @@ typedef struct sc2_conv_desc {
     /* filter dilation (0 or 1 = none), sc2_conv2d_fwd only: tap (kh, kw) reads input pixel (oh*stride_h - pad_h + kh*dil_h, ..);
      * OH = (H + 2 pad_h - dil_h (KH - 1) - 1) / stride_h + 1.  The atrous layers of the dense-prediction models
      * (sc2bench/models/segmentation/deeplabv3.py ASPP rates 12 / 24 / 36; torchvision's `replace_stride_with_dilation` layer3 /
-     * layer4): Cout > 96, plain epilogues (NONE / BIAS / BIAS_RELU / BIAS_ADD_RELU / GDN / IGDN / ADD), dense output. */
+     * layer4): Cout > 96, plain epilogues (NONE / BIAS / BIAS_RELU / BIAS_ADD_RELU / GDN / IGDN), dense output. */
     int32_t dil_h, dil_w;
 } sc2_conv_desc;
 
@@ -201,6 +206,19 @@ int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d);
 int sc2_conv_patch_supported(const sc2_conv_desc *d);
 int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y,
                    const void *ep_x, const float *ep_beta, void *stream);
+
+/* The two channel-mixing GEMMs of the GDN1 / inverse-GDN1 BACKWARD (CompressAI GDN1 under autograd, reached by loss.backward() for
+ * sc2bench/models/layer.py:478,481,488,491) with the element-wise halves of that backward fused into their epilogues
+ * (SC2_EPI_GDN1_BWD_PRE / SC2_EPI_IGDN1_BWD_PRE / SC2_EPI_GDN1_BWD_POST): a 1x1 "conv" (d: KH = KW = 1, stride 1, no padding,
+ * Cin == Cout == C in {96, 256, 512, ...: packed rows 96 or a multiple of 128}, bf16 NHWC output) that reads TWO per-element
+ * operands and, for the PRE forms, writes TWO outputs.  Replaces, per GDN layer, the norm GEMM + sc2_gdn_bwd_pre and the
+ * gamma^T GEMM + sc2_gdn_bwd_post (nine passes over [pixels x C] tensors instead of fifteen).
+ *   x : bf16 [M, C] the GEMM's operand (PRE: the GDN input, a_op ABS; POST: d_norm);  w_packed : gamma resp. gamma^T, packed as for
+ *   sc2_conv2d_fwd;  ep_x, ep_x2 : bf16 [M, C];  ep_beta : f32 [C] (PRE; ignored by POST);  y, y2 : bf16 [M, C] (y2: PRE only). */
+int sc2_gdn1_bwd_gemm(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, void *y2, const void *ep_x,
+                      const void *ep_x2, const float *ep_beta, void *stream);
+/* column sums of a bf16 [M, C] tensor in f32 (d_beta = sum over pixels of d_norm): out f32 [C], C % 8 == 0, C <= 2048. */
+int sc2_colsum_bf16(const void *x, long long M, int C, float *out, void *stream);
 
 /* Two consecutive 1x1 layers of the ResNet tail across a block boundary in ONE launch (torchvision Bottleneck blocks b and
  * b + 1 of layer2, eval mode, BatchNorm folded; sc2bench/models/backbone.py:235-254 runs them one after the other):

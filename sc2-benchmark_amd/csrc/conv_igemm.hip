@@ -23,6 +23,8 @@ extern template int launch<G_64>(const ConvArgs &, hipStream_t);
 extern template int launch<G_48>(const ConvArgs &, hipStream_t);
 extern template int launch<G_32>(const ConvArgs &, hipStream_t);
 extern template int launch<Gd_128>(const ConvArgs &, hipStream_t);
+extern template int launch<Gb_128>(const ConvArgs &, hipStream_t);
+extern template int launch<Gb_96>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_128>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_96>(const ConvArgs &, hipStream_t);
 extern template int launch<Gx_64>(const ConvArgs &, hipStream_t);
@@ -97,8 +99,33 @@ extern "C" int sc2_conv_fused_gdn_supported(const sc2_conv_desc *d) {
            big_tile_eligible(d, M, d->KH * d->KW * d->Cin) ? 2 : 0;
 }
 
+namespace {
+int conv2d_fwd_impl(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, const void *ep_x, const float *ep_beta,
+                    void *stream, const void *ep_x2, void *y2);
+}
 extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, const void *ep_x,
                               const float *ep_beta, void *stream) {
+    SC2_REQUIRE(d && d->epilogue <= SC2_EPI_IGDN2, SC2_ERR_INVALID_ARG, "conv2d: bad epilogue (the GDN1-backward forms go through sc2_gdn1_bwd_gemm)");
+    return conv2d_fwd_impl(d, x, w_packed, y, ep_x, ep_beta, stream, nullptr, nullptr);
+}
+extern "C" int sc2_gdn1_bwd_gemm(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, void *y2, const void *ep_x,
+                                 const void *ep_x2, const float *ep_beta, void *stream) {
+    SC2_REQUIRE(d && d->epilogue >= SC2_EPI_GDN1_BWD_PRE && d->epilogue <= SC2_EPI_GDN1_BWD_POST, SC2_ERR_INVALID_ARG,
+                "gdn1_bwd_gemm: epilogue must be one of SC2_EPI_GDN1_BWD_PRE / IGDN1_BWD_PRE / GDN1_BWD_POST");
+    const bool post = d->epilogue == SC2_EPI_GDN1_BWD_POST;
+    SC2_REQUIRE(ep_x && ep_x2 && (post || (ep_beta && y2)), SC2_ERR_INVALID_ARG, "gdn1_bwd_gemm: null operand");
+    SC2_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride_h == 1 && d->stride_w == 1 && d->pad_h == 0 && d->pad_w == 0 && d->Cin == d->Cout &&
+                    d->out_format == SC2_OUT_BF16_NHWC && d->out_H == 0 && d->dil_h <= 1 && d->dil_w <= 1 &&
+                    !(d->k_order & SC2_K_B_FRAG_MAJOR) && (d->Cout_pad % 128 == 0 || d->Cout_pad == 96) &&
+                    d->a_op == (post ? SC2_AOP_NONE : SC2_AOP_ABS),
+                SC2_ERR_UNSUPPORTED, "gdn1_bwd_gemm: a 1x1 C x C GEMM on bf16 NHWC with 96 or a multiple of 128 packed rows (got %d -> %d, %d rows)",
+                d->Cin, d->Cout, d->Cout_pad);
+    static const float one = 1.0f;    // (the shared argument checks want a non-null ep_beta for any epilogue; POST reads none)
+    return conv2d_fwd_impl(d, x, w_packed, y, ep_x, post ? &one : ep_beta, stream, ep_x2, y2);
+}
+namespace {
+int conv2d_fwd_impl(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, const void *ep_x, const float *ep_beta,
+                    void *stream, const void *ep_x2, void *y2) {
     SC2_REQUIRE(d && x && w_packed && y, SC2_ERR_INVALID_ARG, "conv2d: null argument");
     SC2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, SC2_ERR_INVALID_ARG,
                 "conv2d: non-positive dimension");
@@ -134,8 +161,9 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
                     (!(d->k_order & SC2_K_B_FRAG_MAJOR) ||
                      ((d->k_order & SC2_K_SLAB_MAJOR) && !(d->k_order & SC2_K_B_TILE_MAJOR))),
                 SC2_ERR_INVALID_ARG, "conv2d: slab-major K order needs Cin %% 32 == 0 (Cin = %d)", d->Cin);
-    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_IGDN2, SC2_ERR_INVALID_ARG,
+    SC2_REQUIRE(d->epilogue >= SC2_EPI_NONE && d->epilogue <= SC2_EPI_GDN1_BWD_POST, SC2_ERR_INVALID_ARG,
                 "conv2d: bad epilogue");
+    const bool gdn_bwd = d->epilogue >= SC2_EPI_GDN1_BWD_PRE;
     const bool fused = d->epilogue == SC2_EPI_FUSED_GDN || d->epilogue == SC2_EPI_FUSED_IGDN;
     if (fused)
         SC2_REQUIRE(d->Cout == d->Cout_pad && sc2_conv_fused_gdn_supported(d), SC2_ERR_UNSUPPORTED,
@@ -180,7 +208,10 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     a.o_H = scatter ? d->out_H : 0; a.o_W = d->out_W; a.o_sh = d->out_stride_h; a.o_sw = d->out_stride_w;
     a.o_h0 = d->out_off_h; a.o_w0 = d->out_off_w;
     a.DH = dil_h; a.DW = dil_w;
+    a.ep_x2 = static_cast<const uint16_t *>(ep_x2);
+    a.y2 = y2;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gdn_bwd) return d->Cout_pad == 96 ? launch<Gb_96>(a, s) : launch<Gb_128>(a, s);   // (geometry checked by sc2_gdn1_bwd_gemm)
     if (dilated) {
         // atrous convolution: the generic 128-wide tile with the dilation compiled in (every other instantiation -- static
         // geometries, window / patch staging, the 8-wave tiles -- derives input coordinates from undilated taps)
@@ -320,3 +351,4 @@ extern "C" int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void 
     sc2_set_error("conv2d: unsupported packed row count %d", rows);
     return SC2_ERR_UNSUPPORTED;
 }
+}  // namespace

@@ -80,11 +80,15 @@ struct ConvArgs {
     unsigned x_bytes, w_bytes;   // sizes of x and of the packed weights when both are < 2 GB (buffer-addressed loads), else 0
     int o_H, o_W, o_sh, o_sw, o_h0, o_w0;   // NHWC output scatter (o_H == 0: dense): pixel (oh, ow) -> (oh*o_sh+o_h0, ..)
     int DH, DW;                             // filter dilation (1 = none); read by the Cfg::DIL instantiations only
+    const uint16_t *__restrict__ ep_x2;     // Cfg::BWD: the second per-element operand (the GDN's input x)
+    void *__restrict__ y2;                  // Cfg::BWD, PRE epilogues: the second output (the direct term)
 };
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, bool STATIC_, int CIN_, int KH_, int KW_, int SH_, int SW_,
-          int PH_, int PW_, int STAGES_ = 2, bool EPX_ = false, bool SQ_ = false, bool DIL_ = false>
+          int PH_, int PW_, int STAGES_ = 2, bool EPX_ = false, bool SQ_ = false, bool DIL_ = false, bool BWD_ = false>
 struct Cfg {
+    // BWD: the GDN1-backward epilogues (SC2_EPI_*GDN1_BWD_*: two per-element operands, two outputs; conv_store_tile_gdn_bwd).
+    static constexpr bool BWD = BWD_;
     // DIL: runtime filter dilation (ConvArgs::DH / DW): input pixel of tap (kh, kw) = (oh SH - PH + kh DH, ow SW - PW + kw DW).
     // A compile-time property of its own instantiations (the atrous layers of the dense-prediction heads), like SQ.
     static constexpr bool DIL = DIL_;
@@ -126,7 +130,8 @@ struct Cfg {
     static constexpr int IMG_LDS = BM * (BN * 2 + 16);     // bf16 store image (ImgPad)
     static constexpr int LDS0 = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
     static constexpr int LDS1 = LDS0 > FUSE_LDS ? LDS0 : FUSE_LDS;
-    static constexpr int LDS_BYTES = LDS1 > IMG_LDS ? LDS1 : IMG_LDS;
+    static constexpr int LDS2 = LDS1 > IMG_LDS ? LDS1 : IMG_LDS;
+    static constexpr int LDS_BYTES = (BWD_ && 2 * IMG_LDS > LDS2) ? 2 * IMG_LDS : LDS2;   // BWD: two operand images side by side
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(BM % (WAVES_M * 16) == 0 && BN % (WAVES_N * 16) == 0, "wave tiling");
     static_assert(BM % 64 == 0, "A rows per wave-instruction");
@@ -315,6 +320,100 @@ __device__ __forceinline__ void conv_store_tile_bf16(const ConvArgs &p, unsigned
             bool ok;
             const long long o = conv_out_offset(p, m, n, ok);
             if (ok) *reinterpret_cast<uint4 *>(y + o) = *reinterpret_cast<const uint4 *>(img + Img::off(row, cc));
+        }
+    }
+}
+
+// GDN1 backward (Cfg::BWD, round 5): the element-wise halves of the backward in the epilogues of its two GEMMs.  Both per-element
+// operands are parked in LDS images with coalesced 16-byte accesses (ep_x -> img, ep_x2 -> img2), every lane updates its 8-byte
+// slots in place from its accumulators, and the images are streamed out in whole channel runs (img -> y, img2 -> y2).
+//   PRE  (acc = gamma |x|, img = g, img2 = x):  n = beta + acc;  GDN: dd = g / n, dn = -dd x / n;  inverse: dd = g n, dn = g x
+//        img <- dn (d_norm), img2 <- dd (the direct term of dL/dx)
+//   POST (acc = gamma^T d_norm, img = dd, img2 = x):  img <- dd + sign(x) acc  (sign(0) = 0, as torch.abs differentiates)
+// Same arithmetic, in f32, as gdn_bwd_pre_kernel / gdn_bwd_post_kernel -- except that n is the f32 accumulator here where the
+// two-launch form read it back rounded to bf16.
+template <class C, class Img, int NTHREADS>
+__device__ __forceinline__ void conv_store_tile_gdn_bwd(const ConvArgs &p, unsigned char *smem, f32x4_t (&acc)[C::MT][C::NT],
+                                                        int tid, int wm, int wn, int frow, int fq, int m0, int n0) {
+    constexpr int MT = C::MT, NT = C::NT;
+    constexpr int CPR = EpiGeom<C, NTHREADS>::CPR, QPT = EpiGeom<C, NTHREADS>::QPT, Q = EpiGeom<C, NTHREADS>::Q;
+    unsigned char *img = smem, *img2 = smem + Img::BYTES;
+    const int Cout = p.Cout;
+    const int epi = p.epi;
+    const bool post = epi == SC2_EPI_GDN1_BWD_POST;
+    const bool inverse = epi == SC2_EPI_IGDN1_BWD_PRE;
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int q = tid + r * NTHREADS;
+        const int row = q / CPR, cc = q - row * CPR;
+        if (q < Q) {
+            const int m = m0 + row, n = n0 + cc * 8;
+            const bool ok = (m < p.M) & (n < Cout);
+            const long long o = ok ? (long long)m * Cout + n : 0;
+            const uint4 a = *reinterpret_cast<const uint4 *>(p.ep_x + o), b = *reinterpret_cast<const uint4 *>(p.ep_x2 + o);
+            *reinterpret_cast<uint4 *>(img + Img::off(row, cc)) = ok ? a : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(img2 + Img::off(row, cc)) = ok ? b : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __syncthreads();
+    float4 bj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * C::WN + j * 16 + fq * 4;
+        bj[j] = (!post && n < Cout) ? *reinterpret_cast<const float4 *>(p.ep_beta + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = wm * C::WM + i * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = wn * C::WN + j * 16 + fq * 4;
+            const int so = Img::off(row, col >> 3) + (col & 7) * 2;
+            const uint2 ar = *reinterpret_cast<const uint2 *>(img + so), br = *reinterpret_cast<const uint2 *>(img2 + so);
+            const float av[4] = {__builtin_bit_cast(float, ar.x << 16), __builtin_bit_cast(float, ar.x & 0xFFFF0000u),
+                                 __builtin_bit_cast(float, ar.y << 16), __builtin_bit_cast(float, ar.y & 0xFFFF0000u)};
+            const float xv[4] = {__builtin_bit_cast(float, br.x << 16), __builtin_bit_cast(float, br.x & 0xFFFF0000u),
+                                 __builtin_bit_cast(float, br.y << 16), __builtin_bit_cast(float, br.y & 0xFFFF0000u)};
+            const float b[4] = {bj[j].x, bj[j].y, bj[j].z, bj[j].w};
+            float o1[4], o2[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (post) {
+                    const float sgn = xv[t] > 0.f ? 1.0f : (xv[t] < 0.f ? -1.0f : 0.f);
+                    o1[t] = av[t] + sgn * acc[i][j][t];
+                    o2[t] = 0.f;
+                } else {
+                    const float norm = b[t] + acc[i][j][t];
+                    if (inverse) {
+                        o1[t] = av[t] * xv[t];
+                        o2[t] = av[t] * norm;
+                    } else {
+                        const float rn = 1.0f / norm;
+                        o2[t] = av[t] * rn;
+                        o1[t] = -o2[t] * xv[t] * rn;
+                    }
+                }
+            }
+            uint2 w1, w2;
+            w1.x = pack_bf16x2(o1[0], o1[1]);
+            w1.y = pack_bf16x2(o1[2], o1[3]);
+            w2.x = pack_bf16x2(o2[0], o2[1]);
+            w2.y = pack_bf16x2(o2[2], o2[3]);
+            *reinterpret_cast<uint2 *>(img + so) = w1;
+            if (!post) *reinterpret_cast<uint2 *>(img2 + so) = w2;
+        }
+    }
+    __syncthreads();
+    uint16_t *y = reinterpret_cast<uint16_t *>(p.y), *y2 = reinterpret_cast<uint16_t *>(p.y2);
+#pragma unroll
+    for (int r = 0; r < QPT; ++r) {
+        const int q = tid + r * NTHREADS;
+        const int row = q / CPR, cc = q - row * CPR;
+        const int m = m0 + row, n = n0 + cc * 8;
+        if ((q < Q) & (m < p.M) & (n < Cout)) {
+            const long long o = (long long)m * Cout + n;
+            *reinterpret_cast<uint4 *>(y + o) = *reinterpret_cast<const uint4 *>(img + Img::off(row, cc));
+            if (!post) *reinterpret_cast<uint4 *>(y2 + o) = *reinterpret_cast<const uint4 *>(img2 + Img::off(row, cc));
         }
     }
 }
@@ -753,6 +852,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
         return;
     }
 
+    if constexpr (C::BWD) {
+        conv_store_tile_gdn_bwd<C, ImgPad<C>, 256>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0);
+        return;
+    }
     if (p.out == SC2_OUT_BF16_NHWC)
         conv_store_tile_bf16<C, ImgPad<C>, 256, C::EPX>(p, smem, acc, tid, wm, wn, frow, fq, m0, n0, epi, epx, false);
     else
@@ -1750,6 +1853,9 @@ using Gq_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, false, true>;
 // dilated (atrous) convolutions: the generic 128-wide tile with the runtime dilation compiled in (DeepLab's ASPP branches,
 // sc2bench/models/segmentation/deeplabv3.py: rates 12 / 24 / 36 on the 2048-channel map; torchvision's dilated layer3 / layer4)
 using Gd_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, false, false, true>;
+// the two GEMMs of the GDN1 backward with its element-wise halves in their epilogues (sc2_gdn1_bwd_gemm): C = 256 / 512, C = 96
+using Gb_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, false, false, false, true>;
+using Gb_96 = Cfg<128, 96, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 2, false, false, false, true>;
 using Gqx_128 = Cfg<128, 128, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 3, true, true>;
 using Gx_64 = Cfg<128, 64, 2, 2, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;
 using Gx_48 = Cfg<128, 48, 4, 1, false, 0, 0, 0, 0, 0, 0, 0, 2, true>;

@@ -9,4 +9,6 @@ template int launch<Gx_48>(const ConvArgs &, hipStream_t);
 template int launch<Gx_32>(const ConvArgs &, hipStream_t);
 template int launch<Gq_128>(const ConvArgs &, hipStream_t);
 template int launch<Gqx_128>(const ConvArgs &, hipStream_t);
+template int launch<Gb_128>(const ConvArgs &, hipStream_t);
+template int launch<Gb_96>(const ConvArgs &, hipStream_t);
 }  // namespace sc2conv

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count', 'sc2_policy_default', 'sc2_policy_set', 'sc2_policy_get',
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_fc_fwd',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
-    'sc2_conv2d_fwd', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
+    'sc2_conv2d_fwd', 'sc2_gdn1_bwd_gemm', 'sc2_colsum_bf16', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv1x1_pair_supported', 'sc2_conv1x1_pair_fwd',
     'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv0_gdn96_nchw_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
@@ -85,6 +85,7 @@ class HostPolicy(object):
     fc_kernel = True           # dedicated classifier kernel
     dense_head = True          # DeepLab / FCN heads and the FPN on the library's kernels in bf16 eval
     rans_fused_dq = True       # decode + dequantise in one coder launch
+    gdn_bwd_fused = True       # GDN1 backward: element-wise halves in the epilogues of its two GEMMs (sc2_gdn1_bwd_gemm)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
 
 
@@ -171,6 +172,8 @@ def lib():
     L.sc2_conv_fused_gdn_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.sc2_conv_patch_supported.argtypes = [ctypes.POINTER(ConvDesc)]
     L.sc2_conv2d_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
+    L.sc2_gdn1_bwd_gemm.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    L.sc2_colsum_bf16.argtypes = [vp, ctypes.c_longlong, i32, vp, vp]
     L.sc2_nchw_f32_to_nhwc_f32.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_conv_f32_chunk_channels.argtypes = [i32]
     L.sc2_conv2d_f32_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
@@ -431,14 +434,59 @@ def pack_conv0_weight_pairs(w):
     return packed
 
 
+EPI_GDN1_BWD_PRE, EPI_IGDN1_BWD_PRE, EPI_GDN1_BWD_POST = 11, 12, 13
+
+
+def gdn1_bwd_gemm(x_nhwc, w_packed, epilogue, ep_x, ep_x2, beta=None, tag=None):
+    """One of the two GEMMs of the GDN1 backward with the element-wise half of that backward in its epilogue
+    (sc2_gdn1_bwd_gemm): -> (y, y2 or None)."""
+    for t, name in ((x_nhwc, 'x'), (w_packed, 'w'), (ep_x, 'ep_x'), (ep_x2, 'ep_x2')):
+        _dev(t, name)
+        assert t.dtype == torch.bfloat16 and t.is_contiguous(), name
+    C = x_nhwc.shape[-1]
+    M = x_nhwc.numel() // C
+    assert ep_x.numel() == M * C and ep_x2.numel() == M * C
+    post = epilogue == EPI_GDN1_BWD_POST
+    if not post:
+        _dev(beta, 'beta')
+        assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == C
+    d = ConvDesc(M, 1, 1, C, C, 1, 1, 1, 1, 0, 0, 1, 1, AOP_NONE if post else AOP_ABS, epilogue, OUT_BF16_NHWC, w_packed.shape[1],
+                 w_packed.shape[0], 0, 0, 0, 0, 0, 0, K_TAP_MAJOR, 1, 1)
+    y = torch.empty_like(x_nhwc)
+    y2 = None if post else torch.empty_like(x_nhwc)
+    with _timed(tag or 'gdn.bwd.gemm'):
+        _check(lib().sc2_gdn1_bwd_gemm(ctypes.byref(d), _ptr(x_nhwc), _ptr(w_packed), _ptr(y), _ptr(y2), _ptr(ep_x), _ptr(ep_x2),
+                                       _ptr(beta), _stream()), 'gdn1_bwd_gemm')
+    return y, y2
+
+
+def colsum_bf16(x, C):
+    """bf16 [..., C] -> f32 [C] column sums."""
+    _dev(x, 'x')
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] == C
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    _check(lib().sc2_colsum_bf16(_ptr(x), x.numel() // C, C, _ptr(out), _stream()), 'colsum_bf16')
+    return out
+
+
 def gdn1_backward(gy_nhwc, x_nhwc, beta, gamma, inverse):
     """Backward of GDN1 / inverse GDN1 on the HIP kernels: returns (dx bf16 NHWC, d_beta f32 [C], d_gamma f32 [C,C]).
 
-    beta [C] / gamma [C,C] are the effective (reparametrised) f32 tensors."""
+    beta [C] / gamma [C,C] are the effective (reparametrised) f32 tensors.  Round 5: for C = 96 and C a multiple of 128 the two
+    element-wise halves ride in the epilogues of the two GEMMs (norm GEMM -> d_norm + direct term; gamma^T GEMM -> dx): nine
+    passes over the [pixels, C] tensors instead of fifteen (`host_policy.gdn_bwd_fused = False`: the five-launch form, A/B)."""
     C = beta.numel()
     M = x_nhwc.numel() // C
     gy_nhwc = gy_nhwc.contiguous()
     beta = beta.detach().float().contiguous()
+    if host_policy.gdn_bwd_fused and (weight_rows(C) % 128 == 0 or weight_rows(C) == 96) and M < (1 << 31):
+        g = gamma.detach()
+        d_norm, dxd = gdn1_bwd_gemm(x_nhwc, pack_conv_weight(g.reshape(C, C, 1, 1)), EPI_IGDN1_BWD_PRE if inverse else EPI_GDN1_BWD_PRE,
+                                    gy_nhwc, x_nhwc, beta, tag='gdn.bwd.pre')
+        dx, _ = gdn1_bwd_gemm(d_norm, pack_conv_weight(g.t().reshape(C, C, 1, 1)), EPI_GDN1_BWD_POST, dxd, x_nhwc, tag='gdn.bwd.post')
+        d_beta = colsum_bf16(d_norm, C)
+        d_gamma = conv2d_wgrad(x_nhwc, d_norm, 1, 1, 1, 0, x_abs=True).reshape(C, C)
+        return dx, d_beta, d_gamma
     norm = conv2d_fwd(x_nhwc, pack_conv_weight(gamma.detach().reshape(C, C, 1, 1)), C, 1, 1, 1, 0, a_op=AOP_ABS,
                       epilogue=EPI_BIAS, ep_beta=beta, tag='gdn.bwd.norm')
     d_norm = torch.empty_like(x_nhwc)

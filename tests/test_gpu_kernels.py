@@ -1121,9 +1121,12 @@ def test_conv_wgrad(S, dev, cin, cout, k, stride, pad, H, W, N):
     torch.testing.assert_close(dw.cpu(), ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item())
 
 
-@pytest.mark.parametrize('C,inverse', [(96, False), (48, False), (256, True), (40, True)])
+@pytest.mark.parametrize('C,inverse', [(96, False), (48, False), (256, True), (40, True), (512, True), (96, True), (256, False)])
 def test_gdn1_backward(S, R, dev, C, inverse):
-    """GDN1 backward on the HIP kernels (element-wise pre/post + gamma^T GEMM + wgrad) vs the oracle's autograd."""
+    """GDN1 backward on the HIP kernels vs the oracle's autograd.  C = 96 and multiples of 128: the element-wise halves in the
+    epilogues of the two GEMMs (sc2_gdn1_bwd_gemm, round 5) + column sums + wgrad; other widths: element-wise pre / post kernels
+    around a gamma^T GEMM.  The fused form is also compared with the five-launch form it replaces (same arithmetic, the norm in f32
+    instead of rounded to bf16 in between)."""
     torch.manual_seed(C + 1)
     ref_m = R.GDN1(C, inverse=inverse)
     with torch.no_grad():
@@ -1145,6 +1148,14 @@ def test_gdn1_backward(S, R, dev, C, inverse):
     assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 1.5e-2      # norm, d_norm and t pass through bf16
     assert rel(d_beta, beta.grad) < 1.5e-2
     assert rel(d_gamma, gamma.grad) < 1.5e-2
+    if S.hip.weight_rows(C) % 128 == 0 or S.hip.weight_rows(C) == 96:
+        S.hip.configure(gdn_bwd_fused=False)
+        try:
+            dx5, d_beta5, d_gamma5 = S.hip.gdn1_backward(S.hip.nchw_f32_to_nhwc_bf16(gy.to(dev)), S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)),
+                                                         beta.detach().to(dev), gamma.detach().to(dev), inverse)
+        finally:
+            S.hip.configure(gdn_bwd_fused=True)
+        assert rel(dx, dx5.float().cpu()) < 1e-2 and rel(d_beta, d_beta5.cpu()) < 1e-2 and rel(d_gamma, d_gamma5.cpu()) < 1e-2
 
 
 @pytest.mark.parametrize('N', [3, 40, 131])
