@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 36
+#define SC2_ABI_VERSION 38
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -217,6 +217,22 @@ int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, 
  *   sc2_conv2d_fwd;  ep_x, ep_x2 : bf16 [M, C];  ep_beta : f32 [C] (PRE; ignored by POST);  y, y2 : bf16 [M, C] (y2: PRE only). */
 int sc2_gdn1_bwd_gemm(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, void *y2, const void *ep_x,
                       const void *ep_x2, const float *ep_beta, void *stream);
+
+/* GDN1 / inverse GDN1 over 512 channels with the whole channel row of a 128-pixel tile resident in LDS (gdn512_rows.hip) -- the
+ * training-time forms of the decoder's first normalisation (sc2bench/models/layer.py:486-488; forward in train mode keeps its input for
+ * the backward, which loss.backward() of script/task/image_classification.py:79 reaches):
+ *   sc2_gdn1_rows_fwd : y = x * (beta + gamma |x|)  (inverse != 0)  or  x / (...);  x, y bf16 [M, 512]
+ *   sc2_gdn1_rows_bwd : given x and the gradient gy of y, BOTH GEMMs of the backward and its element-wise halves in one launch:
+ *                       d_norm (bf16 [M, 512]: its column sums are d_beta, d_norm^T |x| is d_gamma) and dx (bf16 [M, 512]).
+ *                       Same quantities as SC2_EPI_(I)GDN1_BWD_PRE + SC2_EPI_GDN1_BWD_POST of sc2_gdn1_bwd_gemm, the direct term kept
+ *                       in f32 in the accumulators instead of rounded to bf16 in between; sign(0) = 0 as torch.abs's gradient.
+ *   gamma_frag / gamma_t_frag : the effective gamma [512, 512] and its transpose as MFMA fragments, bf16 [32][16][64][8]: entry
+ *                       (jt, ks, lane = fq*16 + frow, e) = W[jt*16 + frow][ks*32 + fq*8 + e];  beta f32 [512];  M * 1024 < 2 GB. */
+int sc2_gdn1_rows_supported(int C);
+int sc2_gdn1_rows_fwd(const void *x, const void *gamma_frag, const float *beta, void *y, long long M, int C, int inverse,
+                      void *stream);
+int sc2_gdn1_rows_bwd(const void *x, const void *gy, const void *gamma_frag, const void *gamma_t_frag, const float *beta,
+                      void *d_norm, void *dx, long long M, int C, int inverse, void *stream);
 /* column sums of a bf16 [M, C] tensor in f32 (d_beta = sum over pixels of d_norm): out f32 [C], C % 8 == 0, C <= 2048. */
 int sc2_colsum_bf16(const void *x, long long M, int C, float *out, void *stream);
 
@@ -355,10 +371,13 @@ int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const float *bias, 
  *   w_frag : bf16 [Cin/32 * 4 (+ 8 when fused)][16][64][8]: conv k-step kt = slab*4 + kh*2 + kw, then (fused) the 8 k-steps of
  *            the effective gamma [256][256] as a 1x1 layer; entry (kt, tile t = 2 g + j, lane = fq*16 + frow, e) =
  *            W[32 g + 8 (frow / 4) + 4 j + frow % 4][slab*32 + fq*8 + e][kh][kw]  (row permutation as sc2_conv3x3_win_fwd)
- *   fused != 0: y = GDN1(conv(x)) with beta f32 [256]; inverse != 0: x * (beta + gamma |x|), else x / (...). */
+ *   fused != 0: y = GDN1(conv(x)) with beta f32 [256]; inverse != 0: x * (beta + gamma |x|), else x / (...).
+ *   y_channels 256, y_channel0 0: y as above.  y_channels 512 (plain pad-1 convs only): y is bf16 NHWC [N,H+1,W+1,512] and this
+ *   launch writes its channels [y_channel0, y_channel0 + 256), y_channel0 in {0, 256} -- the data gradient of the 512 -> 256 layer
+ *   (loss.backward() of script/task/image_classification.py:79 through layer.py:489) is two such launches. */
 int sc2_conv2x2_win_supported(int H, int W, int Cin, int Cout, int pad);
 int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const float *beta, void *y, int N, int H, int W, int Cin, int pad,
-                        int fused, int inverse, void *stream);
+                        int fused, int inverse, int y_channels, int y_channel0, void *stream);
 
 /* The last decoder convolution (256 -> 256, k2, p1: 55 -> 56) with the two 1x1 layers of the caller that consume its output
  * fused behind it: conv1 + bn1 + ReLU (256 -> 128) and downsample conv + bn (256 -> 512, stride 2) of layer2.0 of the ResNet

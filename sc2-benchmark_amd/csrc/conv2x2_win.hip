@@ -158,9 +158,11 @@ struct W2Args {
 // everything beyond the image is out of range (zeros) -- with segments of <= 55 columns the 56-column window row holds every
 // column both paddings need (no shared padding column).  Window pitch, tap immediates, fragment ring and epilogue are
 // the static kernel's; what changes is the tile -> (image, row block, segment) split and two multiplications by OW.
-template <int OW_, int PAD_, bool RT_ = false>
+template <int OW_, int PAD_, bool RT_ = false, int YP_ = 512>
 struct Geo2 {
     static constexpr bool RT = RT_;
+    static constexpr int YP = YP_;                               // bytes between output pixels: 512 = a 256-channel tensor of its own;
+                                                                 // 1024: a 256-channel half of a 512-channel tensor (plain conv only)
     static constexpr int SEG = 55;                               // RT: output columns per segment
     static constexpr int OW = OW_, PAD = PAD_, W = OW_ + 1 - 2 * PAD_;
     static constexpr int ROWS = 4;                               // output rows per tile
@@ -274,6 +276,7 @@ __device__ __forceinline__ void ds_step(f32x4_t (&acc)[14][2], const uint32_t (&
 
 template <class G, int MODE, bool INVERSE>
 __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
+    static_assert(MODE == 0 || G::YP == 512, "the fused / tail forms write 256-channel tensors of their own");
     constexpr int MT = G::MT, PAD = G::PAD, PWD = G::PWD;
     constexpr bool FUSE = MODE == 1, TAIL = MODE == 2, RT = G::RT;
     static_assert(!(RT && TAIL), "the tail mode is the 224 x 224 geometry's");
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
         int img, oh0, ow0, sw;
         tile_origin(tile, img, oh0, ow0, sw);
         const int rows_valid = OH - oh0 < G::ROWS ? OH - oh0 : G::ROWS;
-        const uint32_t y_so = (uint32_t)((img * OH + oh0) * OW + ow0) * 512u;      // tile base (bytes), scalar
+        const uint32_t y_so = (uint32_t)((img * OH + oh0) * OW + ow0) * (uint32_t)G::YP;   // tile base (bytes), scalar
         int ln_o;   // the lane index, computed HERE (volatile): the per-row-tile offsets and masks derived from it are then recomputed per
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln_o));   // tile, not hoisted and spilled
         const int fr = ln_o & 15, fqo = ln_o >> 4;
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
         } else {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                buf_store16(rs_y, out_off(i, fr, y_ch, 512), y_so,
+                buf_store16(rs_y, out_off(i, fr, y_ch, G::YP), y_so,
                             u32x4_t{pack2(acc[i][0][0], acc[i][0][1]), pack2(acc[i][0][2], acc[i][0][3]),
                                     pack2(acc[i][1][0], acc[i][1][1]), pack2(acc[i][1][2], acc[i][1][3])});
             }
@@ -678,6 +681,8 @@ typedef Geo2<55, 0> Gd2;   // dec.conv2: 56 -> 55
 typedef Geo2<56, 1> Gd4;   // dec.conv4: 55 -> 56
 typedef Geo2<55, 0, true> Gr0;   // any width, pad 0 (W -> W - 1)
 typedef Geo2<55, 1, true> Gr1;   // any width, pad 1 (W -> W + 1)
+typedef Geo2<56, 1, false, 1024> Gd4w;   // 55 -> 56 into one 256-channel half of a 512-channel tensor (data gradient of dec.conv2)
+typedef Geo2<55, 1, true, 1024> Gr1w;
 
 }  // namespace
 
@@ -689,7 +694,7 @@ extern "C" int sc2_conv2x2_win_supported(int H, int W, int Cin, int Cout, int pa
 }
 
 extern "C" int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const float *beta, void *y, int N, int H, int W, int Cin,
-                                   int pad, int fused, int inverse, void *stream) {
+                                   int pad, int fused, int inverse, int y_channels, int y_channel0, void *stream) {
     SC2_REQUIRE(x && w_frag && y, SC2_ERR_INVALID_ARG, "conv2x2_win: null argument");
     SC2_REQUIRE(N > 0, SC2_ERR_INVALID_ARG, "conv2x2_win: non-positive batch");
     SC2_REQUIRE(sc2_conv2x2_win_supported(H, W, Cin, 256, pad), SC2_ERR_UNSUPPORTED,
@@ -698,20 +703,27 @@ extern "C" int sc2_conv2x2_win_fwd(const void *x, const void *w_frag, const floa
     SC2_REQUIRE(!fused || beta, SC2_ERR_INVALID_ARG, "conv2x2_win: the fused GDN1 needs beta");
     const int ksteps = Cin / 32 * 4 + (fused ? 8 : 0);
     const long long x_bytes = (long long)N * H * W * Cin * 2, w_bytes = (long long)ksteps * 16384;
-    const long long y_bytes = (long long)N * (H + 2 * pad - 1) * (W + 2 * pad - 1) * 512;
+    // y_channels 512: this launch's 256 output channels are channels [y_channel0, y_channel0 + 256) of a 512-channel tensor (the
+    // data gradient of a 512 -> 256 layer is two such launches); plain pad-1 convolutions only
+    const bool wide = y_channels == 512;
+    SC2_REQUIRE(y_channels == 256 ? y_channel0 == 0 : (wide && (y_channel0 == 0 || y_channel0 == 256) && !fused && pad == 1),
+                SC2_ERR_UNSUPPORTED, "conv2x2_win: output channels %d at offset %d (256 at 0, or a half of 512 for a plain pad-1 conv)",
+                y_channels, y_channel0);
+    const long long y_bytes = (long long)N * (H + 2 * pad - 1) * (W + 2 * pad - 1) * (wide ? 1024 : 512) - y_channel0 * 2;
     SC2_REQUIRE(x_bytes < 0x7FF00000LL && y_bytes < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "conv2x2_win: tensor of %lld bytes exceeds 2 GB",
                 x_bytes > y_bytes ? x_bytes : y_bytes);
     W2Args a;
     a.x = static_cast<const uint16_t *>(x);
     a.w = static_cast<const uint16_t *>(w_frag);
     a.beta = beta;
-    a.y = static_cast<uint16_t *>(y);
+    a.y = static_cast<uint16_t *>(y) + y_channel0;
     a.N = N; a.H = H; a.Cin = Cin; a.OH = H + 2 * pad - 1;
     a.W = W; a.OW = W + 2 * pad - 1; a.nseg = 1;
     a.n_tiles = 0; a.tiles_per_img = 0; a.tiles_per_wg = 0;
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     a.bias1 = nullptr; a.bias_ds = nullptr; a.o1 = nullptr; a.ods = nullptr; a.o1_bytes = 0; a.ods_bytes = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (wide) return W == 55 ? launch_w2<Gd4w, 0>(a, s) : launch_w2<Gr1w, 0>(a, s);
     if (pad == 0 && W == 56) return !fused ? launch_w2<Gd2, 0>(a, s) : inverse ? launch_w2<Gd2, 1, true>(a, s) : launch_w2<Gd2, 1, false>(a, s);
     if (pad == 1 && W == 55) return !fused ? launch_w2<Gd4, 0>(a, s) : inverse ? launch_w2<Gd4, 1, true>(a, s) : launch_w2<Gd4, 1, false>(a, s);
     if (pad == 0) return !fused ? launch_w2<Gr0, 0>(a, s) : inverse ? launch_w2<Gr0, 1, true>(a, s) : launch_w2<Gr0, 1, false>(a, s);

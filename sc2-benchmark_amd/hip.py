@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd', 'sc2_gdn1_bwd_gemm', 'sc2_colsum_bf16', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv1x1_pair_supported', 'sc2_conv1x1_pair_fwd',
-    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv0_gdn96_nchw_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post',
+    'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv0_gdn96_nchw_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post', 'sc2_gdn1_rows_supported', 'sc2_gdn1_rows_fwd', 'sc2_gdn1_rows_bwd',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
@@ -85,7 +85,10 @@ class HostPolicy(object):
     fc_kernel = True           # dedicated classifier kernel
     dense_head = True          # DeepLab / FCN heads and the FPN on the library's kernels in bf16 eval
     rans_fused_dq = True       # decode + dequantise in one coder launch
+    gdn_rows = True            # 512-channel GDN1 in training: forward and the whole backward on the resident-row kernel (gdn512_rows.hip)
     gdn_bwd_fused = True       # GDN1 backward: element-wise halves in the epilogues of its two GEMMs (sc2_gdn1_bwd_gemm)
+    dgrad_win_halves = True    # data gradient of dec.conv2 as two 256-channel launches of the window-plane 2x2 kernel
+    teacher_stream = False     # distillation step: the frozen teacher's forward on a stream of its own beside the student's (A/B)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
 
 
@@ -193,7 +196,7 @@ def lib():
     L.sc2_conv1x1_win_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3s2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2x2_win_supported.argtypes = [i32, i32, i32, i32, i32]
-    L.sc2_conv2x2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv2x2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2x2_win_tail_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2x2_win_tail_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
@@ -203,6 +206,9 @@ def lib():
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_stream_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
+    L.sc2_gdn1_rows_supported.argtypes = [i32]
+    L.sc2_gdn1_rows_fwd.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, i32, i32, vp]
+    L.sc2_gdn1_rows_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, i32, i32, vp]
     L.sc2_gdn_bwd_pre.argtypes = [vp, vp, vp, ctypes.c_longlong, i32, i32, vp, vp, vp, vp]
     L.sc2_gdn_bwd_post.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
     L.sc2_eb_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
@@ -460,6 +466,44 @@ def gdn1_bwd_gemm(x_nhwc, w_packed, epilogue, ep_x, ep_x2, beta=None, tag=None):
     return y, y2
 
 
+def gdn1_rows_supported(x_nhwc, C):
+    """True if GDN1 over C channels of this bf16 [..., C] tensor runs on the resident-row kernel (C = 512, < 2 GB)."""
+    return bool(host_policy.gdn_rows) and x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_cuda and x_nhwc.is_contiguous() and \
+        x_nhwc.shape[-1] == C and x_nhwc.numel() * 2 < 0x7FF00000 and bool(lib().sc2_gdn1_rows_supported(C))
+
+
+def gdn1_rows_fwd(x_nhwc, gamma_frag, beta, inverse, tag=None):
+    """y = GDN1(x) / inverse GDN1(x) for a bf16 [..., 512] tensor; gamma_frag = pack_weight_fragments(effective gamma)."""
+    for t, name in ((x_nhwc, 'x'), (gamma_frag, 'gamma_frag'), (beta, 'beta')):
+        _dev(t, name)
+    C = x_nhwc.shape[-1]
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous()
+    assert gamma_frag.dtype == torch.bfloat16 and gamma_frag.is_contiguous() and tuple(gamma_frag.shape) == (C // 16, C // 32, 64, 8)
+    assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == C
+    y = torch.empty_like(x_nhwc)
+    with _timed(tag or 'gdn.rows.fwd'):
+        _check(lib().sc2_gdn1_rows_fwd(_ptr(x_nhwc), _ptr(gamma_frag), _ptr(beta), _ptr(y), x_nhwc.numel() // C, C, 1 if inverse else 0,
+                                       _stream()), 'gdn1_rows_fwd')
+    return y
+
+
+def gdn1_rows_bwd(x_nhwc, gy_nhwc, gamma_frag, gamma_t_frag, beta, inverse, tag=None):
+    """-> (d_norm, dx), both bf16 like x: the two GEMMs of the GDN1 backward and its element-wise halves in one launch."""
+    for t, name in ((x_nhwc, 'x'), (gy_nhwc, 'gy'), (gamma_frag, 'gamma_frag'), (gamma_t_frag, 'gamma_t_frag'), (beta, 'beta')):
+        _dev(t, name)
+    C = x_nhwc.shape[-1]
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and gy_nhwc.dtype == torch.bfloat16 and gy_nhwc.is_contiguous()
+    assert gy_nhwc.numel() == x_nhwc.numel()
+    for g in (gamma_frag, gamma_t_frag):
+        assert g.dtype == torch.bfloat16 and g.is_contiguous() and tuple(g.shape) == (C // 16, C // 32, 64, 8)
+    assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == C
+    d_norm, dx = torch.empty_like(x_nhwc), torch.empty_like(x_nhwc)
+    with _timed(tag or 'gdn.rows.bwd'):
+        _check(lib().sc2_gdn1_rows_bwd(_ptr(x_nhwc), _ptr(gy_nhwc), _ptr(gamma_frag), _ptr(gamma_t_frag), _ptr(beta), _ptr(d_norm),
+                                       _ptr(dx), x_nhwc.numel() // C, C, 1 if inverse else 0, _stream()), 'gdn1_rows_bwd')
+    return d_norm, dx
+
+
 def colsum_bf16(x, C):
     """bf16 [..., C] -> f32 [C] column sums."""
     _dev(x, 'x')
@@ -479,6 +523,14 @@ def gdn1_backward(gy_nhwc, x_nhwc, beta, gamma, inverse):
     M = x_nhwc.numel() // C
     gy_nhwc = gy_nhwc.contiguous()
     beta = beta.detach().float().contiguous()
+    if gdn1_rows_supported(x_nhwc, C):
+        # C = 512: both GEMMs and both element-wise halves in ONE launch with the pixel tile's whole channel row in LDS (four passes
+        # over the [pixels, C] tensors: x, g in; d_norm, dx out)
+        g = gamma.detach()
+        d_norm, dx = gdn1_rows_bwd(x_nhwc, gy_nhwc, pack_weight_fragments(g), pack_weight_fragments(g.t()), beta, inverse)
+        d_beta = colsum_bf16(d_norm, C)
+        d_gamma = conv2d_wgrad(x_nhwc, d_norm, 1, 1, 1, 0, x_abs=True).reshape(C, C)
+        return dx, d_beta, d_gamma
     if host_policy.gdn_bwd_fused and (weight_rows(C) % 128 == 0 or weight_rows(C) == 96) and M < (1 << 31):
         g = gamma.detach()
         d_norm, dxd = gdn1_bwd_gemm(x_nhwc, pack_conv_weight(g.reshape(C, C, 1, 1)), EPI_IGDN1_BWD_PRE if inverse else EPI_GDN1_BWD_PRE,
@@ -561,17 +613,28 @@ def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16, 
                 raise Sc2Error('conv2d_dgrad: unsupported geometry k={} s={} p={}'.format((KH, KW), (sh, sw), (ph, pw)))
             win = (sh == 1 and sw == 1 and out_dtype == torch.bfloat16 and pad_h == pad_w and gy_nhwc.is_contiguous() and
                    conv2x2_win_supported(tuple(gy_nhwc.shape), cin, len(khs), len(kws), 1, pad_h))
+            # ... and a 512-channel gradient (dec.conv2: 512 -> 256, k2, p0) as two 256-channel halves of that kernel (pad 1)
+            win2 = (not win and cin == 512 and pad_h == 1 and sh == 1 and sw == 1 and out_dtype == torch.bfloat16 and pad_w == 1 and
+                    gy_nhwc.is_contiguous() and host_policy.dgrad_win_halves and gx.numel() * 2 < 0x7FF00000 and
+                    conv2x2_win_supported(tuple(gy_nhwc.shape), 256, len(khs), len(kws), 1, 1))
             # (the packed sub-filters belong to THIS weight tensor at this version, stride and padding: a cache dict shared
             #  between layers, or kept across an optimizer step, must miss -- ADVICE r4)
-            key = (ch, cw, win, weight.data_ptr(), weight._version, tuple(weight.shape), (sh, sw), (ph, pw))
+            key = (ch, cw, win, win2, weight.data_ptr(), weight._version, tuple(weight.shape), (sh, sw), (ph, pw))
             packed = cache.get(key) if cache is not None else None
             if packed is None:
                 # (strided SLICES, not index lists: an index list is a host tensor copied to the device per call)
                 sub = wt[:, :, rh::sh, rw::sw].flip(2, 3).contiguous()      # taps in correlation order
-                packed = pack_conv2x2_win(sub) if win else pack_conv_weight(sub)
+                if win2:
+                    packed = (pack_conv2x2_win(sub[:256]), pack_conv2x2_win(sub[256:]))
+                else:
+                    packed = pack_conv2x2_win(sub) if win else pack_conv_weight(sub)
                 if cache is not None:
                     cache[key] = packed
             if sh == 1 and sw == 1:
+                if win2:     # (1.07 ms on the 256-row tile kernel at bs 256)
+                    conv2x2_win_fwd(gy_nhwc, packed[0], 1, tag='dgrad', out=gx, channel0=0)
+                    conv2x2_win_fwd(gy_nhwc, packed[1], 1, tag='dgrad', out=gx, channel0=256)
+                    continue
                 if win:
                     # the decoder's last conv (256 -> 256, k2, p1): its data gradient is the k2 p0 conv of the first window-plane
                     # geometry (1.16 ms on the tile kernel at bs 256, 0.37 here)
@@ -887,8 +950,10 @@ def conv2x2_win_tail_fwd(x_nhwc, w_stream, bias1, bias_ds, want_y=False, tag=Non
     return o1, ods, y
 
 
-def conv2x2_win_fwd(x_nhwc, w_frag, pad, beta=None, inverse=True, tag=None):
-    """y = conv2x2(x, stride 1, pad) [-> GDN1 / inverse GDN1 when beta is given]; bf16 NHWC in / out, Cout 256."""
+def conv2x2_win_fwd(x_nhwc, w_frag, pad, beta=None, inverse=True, tag=None, out=None, channel0=0):
+    """y = conv2x2(x, stride 1, pad) [-> GDN1 / inverse GDN1 when beta is given]; bf16 NHWC in / out, Cout 256.
+    `out` [N, OH, OW, 512] with `channel0` 0 or 256: this launch's 256 channels go into that half of a 512-channel tensor (plain
+    pad-1 convs only: the data gradient of a 512 -> 256 k2 layer is two such launches)."""
     for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag')):
         _dev(t, name)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
@@ -900,10 +965,17 @@ def conv2x2_win_fwd(x_nhwc, w_frag, pad, beta=None, inverse=True, tag=None):
         _dev(beta, 'beta')
         assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 256
     pad = int(pad)
-    out = torch.empty((N, H + 2 * pad - 1, W + 2 * pad - 1, 256), dtype=torch.bfloat16, device=x_nhwc.device)
+    if out is None:
+        assert channel0 == 0
+        out = torch.empty((N, H + 2 * pad - 1, W + 2 * pad - 1, 256), dtype=torch.bfloat16, device=x_nhwc.device)
+    else:
+        _dev(out, 'out')
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and \
+            tuple(out.shape) == (N, H + 2 * pad - 1, W + 2 * pad - 1, 512) and channel0 in (0, 256)
     with _timed(tag or 'conv2x2_win'):
         _check(lib().sc2_conv2x2_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(beta) if fused else None, _ptr(out), N, H, W, Cin, pad,
-                                         1 if fused else 0, 1 if inverse else 0, _stream()), 'conv2x2_win_fwd')
+                                         1 if fused else 0, 1 if inverse else 0, int(out.shape[3]), int(channel0), _stream()),
+               'conv2x2_win_fwd')
     return out
 
 

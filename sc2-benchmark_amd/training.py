@@ -325,20 +325,44 @@ class DistillationStage(object):
                 hooks.io_dict.setdefault(path, dict())['output'] = x
         return x
 
-    def forward_process(self, batch, targets=None):
+    def _teacher_forward(self, batch):
         tb = batch.to(self.head_dtype).contiguous(memory_format=torch.channels_last) if self.head_dtype else batch
         with torch.no_grad():
             t_seq = self._teacher_sequence() if self.use_hip_frozen else None
             if t_seq is not None:
-                t_out = self._run_sequential(t_seq, self.t_hooks, tb, with_grad=False)
-            else:
-                t_out = self.teacher(tb)
+                return self._run_sequential(t_seq, self.t_hooks, tb, with_grad=False)
+            return self.teacher(tb)
+
+    def forward_process(self, batch, targets=None):
+        side = self._teacher_side_stream(batch)
+        if side is None:
+            t_out = self._teacher_forward(batch)
+        else:
+            # The frozen teacher shares nothing with the student's forward but the batch: it runs on a stream of its own beside it
+            # (its launches are 50 - 100 us kernels of 250 - 1000 workgroups, whose tails leave compute units idle).  The side
+            # stream first waits for everything issued so far -- the previous step's backward still reads the previous teacher
+            # features, whose blocks this stream's allocator pool is about to hand out again.
+            main = torch.cuda.current_stream(batch.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                t_out = self._teacher_forward(batch)
         t_io = self.t_hooks.pop()
         t_io['.'] = {'output': t_out}
         s_out = self._student_forward(batch)
+        if side is not None:
+            main.wait_stream(side)
         s_io = self.s_hooks.pop()
         s_io['.'] = {'output': s_out}
         return self.criterion(s_io, t_io, targets)
+
+    def _teacher_side_stream(self, batch):
+        from . import hip
+        if not (self.use_hip_frozen and hip.host_policy.teacher_stream and batch.is_cuda):
+            return None
+        st = self.__dict__.get('_teacher_stream')
+        if st is None:
+            st = self.__dict__['_teacher_stream'] = torch.cuda.Stream(device=batch.device)
+        return st
 
     def _student_forward(self, batch):
         if self.autocast_student:

@@ -52,7 +52,8 @@ CONV_CASES = [
     (96, 48, 5, 2, 2, 20, 24, 2),
     (48, 24, 2, 1, 0, 9, 11, 3),
     (24, 512, 2, 1, 1, 7, 9, 2),
-    (512, 256, 2, 1, 0, 8, 8, 2),
+    (512, 256, 2, 1, 0, 8, 8, 2),      # bf16: two 256-channel halves on the window-plane kernel (runtime geometry)
+    (512, 256, 2, 1, 0, 56, 56, 2),    # ... the static 55 -> 56 geometry of the 224 x 224 operating point
     (256, 256, 2, 1, 1, 7, 7, 3),
     (16, 40, 3, 1, 1, 13, 9, 2),     # generic, Cout 40 -> 48-row tile
     (64, 64, 3, 2, 1, 15, 15, 2),    # generic 64
@@ -1083,7 +1084,8 @@ DGRAD_CASES = [
     (96, 48, 5, 2, 2, 20, 24, 2),      # enc.conv2 geometry: 4 stride-parity classes (3x3, 3x2, 2x3, 2x2 sub-filters)
     (48, 24, 2, 1, 0, 9, 11, 3),
     (24, 512, 2, 1, 1, 7, 9, 2),
-    (512, 256, 2, 1, 0, 8, 8, 2),
+    (512, 256, 2, 1, 0, 8, 8, 2),      # bf16: two 256-channel halves on the window-plane kernel (runtime geometry)
+    (512, 256, 2, 1, 0, 56, 56, 2),    # ... the static 55 -> 56 geometry of the 224 x 224 operating point
     (256, 256, 2, 1, 1, 7, 7, 3),
     (64, 64, 3, 2, 1, 15, 15, 2),      # odd input size with stride 2
     (128, 32, 1, 2, 0, 9, 9, 2),       # 1x1 stride 2: three of four parity classes receive no tap
@@ -1149,13 +1151,70 @@ def test_gdn1_backward(S, R, dev, C, inverse):
     assert rel(d_beta, beta.grad) < 1.5e-2
     assert rel(d_gamma, gamma.grad) < 1.5e-2
     if S.hip.weight_rows(C) % 128 == 0 or S.hip.weight_rows(C) == 96:
-        S.hip.configure(gdn_bwd_fused=False)
+        # C = 512 ran on the resident-row kernel (gdn512_rows.hip): its other form is the pair of GEMMs with fused epilogues; the
+        # other fused widths: theirs is the five-launch form
+        off = dict(gdn_rows=False) if C == 512 else dict(gdn_bwd_fused=False)
+        S.hip.configure(**off)
         try:
             dx5, d_beta5, d_gamma5 = S.hip.gdn1_backward(S.hip.nchw_f32_to_nhwc_bf16(gy.to(dev)), S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)),
                                                          beta.detach().to(dev), gamma.detach().to(dev), inverse)
         finally:
-            S.hip.configure(gdn_bwd_fused=True)
+            S.hip.configure(**{k: True for k in off})
         assert rel(dx, dx5.float().cpu()) < 1e-2 and rel(d_beta, d_beta5.cpu()) < 1e-2 and rel(d_gamma, d_gamma5.cpu()) < 1e-2
+
+
+@pytest.mark.parametrize('inverse', [True, False])
+@pytest.mark.parametrize('shape', [(3, 16, 24), (2, 11, 9), (1, 1, 5)])
+def test_gdn512_rows(S, dev, shape, inverse):
+    """gdn512_rows.hip: GDN1 / inverse GDN1 over 512 channels, forward and the whole backward in one launch each, against f32
+    autograd on the bf16-rounded operands.  1 152 pixels = nine full 128-pixel tiles; 198 and 5 pixels: a partial last tile.  x holds
+    exact zeros -- single elements, a whole pixel, a whole channel: sign(0) = 0, such an element's gradient is its direct term alone
+    (the kernel parks it in dx in front of the second GEMM and fetches it back behind it)."""
+    C = 512
+    N, H, W = shape
+    torch.manual_seed(N * 7 + H)
+    x = bf16_round(torch.randn(N, H, W, C))
+    x[0, 0, 1, :] = 0.0                      # a whole pixel
+    x[:, :, :, 37] = 0.0                     # a whole channel
+    x.view(-1)[torch.randperm(x.numel())[:200]] = 0.0
+    x[0, 0, 2, 5] = -0.0
+    gy = bf16_round(torch.randn(N, H, W, C))
+    gamma = bf16_round(0.3 * torch.rand(C, C) / C ** 0.5 + 0.1 * torch.eye(C))      # (a second term as large as the direct one)
+    beta = 1.0 + 0.1 * torch.rand(C)
+    xr = x.clone().requires_grad_(True)
+    norm = xr.abs().reshape(-1, C) @ gamma.t() + beta
+    y_ref = xr.reshape(-1, C) * norm if inverse else xr.reshape(-1, C) / norm
+    y_ref.backward(gy.reshape(-1, C))
+    n = norm.detach()
+    g2, x2 = gy.reshape(-1, C), x.reshape(-1, C)
+    dn_ref = g2 * x2 if inverse else -(g2 / n) * x2 / n
+    dd_ref = g2 * n if inverse else g2 / n
+    xd, gd = x.to(torch.bfloat16).to(dev), gy.to(torch.bfloat16).to(dev)
+    gf, gtf = S.hip.pack_weight_fragments(gamma.to(dev)), S.hip.pack_weight_fragments(gamma.t().contiguous().to(dev))
+    bd = beta.to(dev)
+    y = S.hip.gdn1_rows_fwd(xd, gf, bd, inverse)
+    torch.cuda.synchronize()
+    assert_close_bf16(y.reshape(-1, C), y_ref.detach(), 'gdn512 rows forward')
+    # ... and the tile kernel's fused epilogue: the same products in the same order
+    y_tile = S.hip.conv2d_fwd(xd, S.hip.pack_conv_weight(gamma.reshape(C, C, 1, 1).to(dev)), C, 1, 1, 1, 0, a_op=S.hip.AOP_ABS,
+                              epilogue=S.hip.EPI_IGDN if inverse else S.hip.EPI_GDN, ep_x=xd, ep_beta=bd)
+    assert torch.equal(y, y_tile)
+    d_norm, dx = S.hip.gdn1_rows_bwd(xd, gd, gf, gtf, bd, inverse)
+    torch.cuda.synchronize()
+    assert_close_bf16(d_norm.reshape(-1, C), dn_ref, 'gdn512 rows d_norm')
+
+    def rel(a, b):
+        return ((a.float().cpu() - b).norm() / (b.norm() + 1e-20)).item()
+    dx_ref = xr.grad.reshape(-1, C)
+    assert rel(dx.reshape(-1, C), dx_ref) < 1e-2
+    zero = x2 == 0
+    assert int(zero.sum()) > 200
+    # where x == 0 the gradient is the direct term alone, to bf16 rounding (the second term there is of the same size: adding it
+    # would be a gross error)
+    got0, want0 = dx.reshape(-1, C).float().cpu()[zero], dd_ref[zero]
+    assert torch.allclose(dx_ref[zero], want0, rtol=1e-6, atol=1e-7)
+    assert (got0 - want0).abs().max().item() <= 2.0 ** -7 * want0.abs().max().item()
+    assert ((got0 - want0).abs() <= 2.0 ** -7 * want0.abs() + 1e-6).all()
 
 
 @pytest.mark.parametrize('N', [3, 40, 131])
