@@ -218,16 +218,16 @@ int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, 
 int sc2_gdn1_bwd_gemm(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, void *y2, const void *ep_x,
                       const void *ep_x2, const float *ep_beta, void *stream);
 
-/* GDN1 / inverse GDN1 over 512 channels with the whole channel row of a 128-pixel tile resident in LDS (gdn512_rows.hip) -- the
- * training-time forms of the decoder's first normalisation (sc2bench/models/layer.py:486-488; forward in train mode keeps its input for
- * the backward, which loss.backward() of script/task/image_classification.py:79 reaches):
- *   sc2_gdn1_rows_fwd : y = x * (beta + gamma |x|)  (inverse != 0)  or  x / (...);  x, y bf16 [M, 512]
+/* GDN1 / inverse GDN1 over C = 256 or 512 channels with the whole channel row of a 128-pixel tile resident in LDS (gdn512_rows.hip) --
+ * the training-time forms of the decoder's two normalisations (sc2bench/models/layer.py:486-491; forward in train mode keeps its input
+ * for the backward, which loss.backward() of script/task/image_classification.py:79 reaches):
+ *   sc2_gdn1_rows_fwd : y = x * (beta + gamma |x|)  (inverse != 0)  or  x / (...);  x, y bf16 [M, C]
  *   sc2_gdn1_rows_bwd : given x and the gradient gy of y, BOTH GEMMs of the backward and its element-wise halves in one launch:
- *                       d_norm (bf16 [M, 512]: its column sums are d_beta, d_norm^T |x| is d_gamma) and dx (bf16 [M, 512]).
+ *                       d_norm (bf16 [M, C]: its column sums are d_beta, d_norm^T |x| is d_gamma) and dx (bf16 [M, C]).
  *                       Same quantities as SC2_EPI_(I)GDN1_BWD_PRE + SC2_EPI_GDN1_BWD_POST of sc2_gdn1_bwd_gemm, the direct term kept
  *                       in f32 in the accumulators instead of rounded to bf16 in between; sign(0) = 0 as torch.abs's gradient.
- *   gamma_frag / gamma_t_frag : the effective gamma [512, 512] and its transpose as MFMA fragments, bf16 [32][16][64][8]: entry
- *                       (jt, ks, lane = fq*16 + frow, e) = W[jt*16 + frow][ks*32 + fq*8 + e];  beta f32 [512];  M * 1024 < 2 GB. */
+ *   gamma_frag / gamma_t_frag : the effective gamma [C, C] and its transpose as MFMA fragments, bf16 [C/16][C/32][64][8]: entry
+ *                       (jt, ks, lane = fq*16 + frow, e) = W[jt*16 + frow][ks*32 + fq*8 + e];  beta f32 [C];  M * C * 2 < 2 GB. */
 int sc2_gdn1_rows_supported(int C);
 int sc2_gdn1_rows_fwd(const void *x, const void *gamma_frag, const float *beta, void *y, long long M, int C, int inverse,
                       void *stream);

@@ -106,7 +106,7 @@ class _GdnFn(torch.autograd.Function):
         C = beta.numel()
         ctx.save_for_backward(x_nhwc, beta, gamma)
         ctx.inverse = inverse
-        if hip.gdn1_rows_supported(x_nhwc, C):      # C = 512: the resident-row kernel (gdn512_rows.hip)
+        if hip.gdn1_rows_supported(x_nhwc, C):      # C = 256 / 512: the resident-row kernel (gdn512_rows.hip)
             return hip.gdn1_rows_fwd(x_nhwc, hip.pack_weight_fragments(gamma.detach()), beta.detach().float().contiguous(), inverse, tag=tag)
         packed = hip.pack_conv_weight(gamma.reshape(C, C, 1, 1))
         y = hip.conv2d_fwd(x_nhwc, packed, C, 1, 1, 1, 0, a_op=hip.AOP_ABS,

@@ -101,21 +101,40 @@ struct RowsArgs {
     unsigned bytes;                      // M * 1024
 };
 
-constexpr int BM = 128, CH = 512, WN = 64, MT = 8, NT = 4, NS = CH / 32, GR = SC2_ROWS_GR;
-constexpr int IMG_BYTES = BM * CH * 2;
-constexpr int MASK_OFF = IMG_BYTES + CH * 4;   // backward: [512 threads][2 x 16 B] bit masks
-constexpr int LDS_BYTES = MASK_OFF + 512 * 32;
+constexpr int BM = 128, MT = 8, GR = SC2_ROWS_GR;
 constexpr uint32_t OOB = 0x80000000u;
 
-// vmcnt budget of k-step ks: the fragment loads issued behind its own four -- the steps the ring holds beyond it -- plus, for the
-// entry fetches, whatever else was issued between them and the GEMM (y0)
-constexpr int rows_young(int ks, int y0) {
-    return ks < GR ? (GR - 1) * NT + y0 : ((NS - 1 - ks) < (GR - 1) ? (NS - 1 - ks) : (GR - 1)) * NT;
-}
+// Geometry of a channel count (512: the first decoder GDN; 256: the second).  A tile is always 128 pixels x all channels, eight waves
+// with CH / 8 channels each.
+template <int CH_>
+struct RowsGeo {
+    static constexpr int CH = CH_;
+    static constexpr int WN = CH / 8, NT = WN / 16, NS = CH / 32;    // channels / accumulator column tiles per wave; k-steps
+    static constexpr int ROWB = CH * 2;                              // bytes per image row
+    static constexpr int I16 = 16 * ROWB;                            // bytes per 16-row block (16 384 / 8 192)
+    static constexpr bool SPLIT = 8 * I16 > 65536;                   // ds offsets are 16 bits: rows 64 .. 127 need a second base
+    static constexpr int CPR = CH / 8;                               // 16-byte chunks per row (64 / 32)
+    static constexpr int RPP = 64 / CPR;                             // rows per 1 KB wave-instruction (1 / 2)
+    static constexpr int PIECES = BM / RPP / 8;                      // direct-to-LDS instructions per wave and tile (16 / 8)
+    static constexpr int STORES = BM * ROWB / 16 / 512;              // 16-byte output stores per thread and tile (16 / 8)
+    static constexpr int MW = MT * NT / 8;                           // 32-bit words of a per-lane element bit mask (4 / 2)
+    static constexpr int IMG_BYTES = BM * ROWB;
+    static constexpr int MASK_OFF = IMG_BYTES + CH * 4;              // backward: [512 threads][2 masks x MW words]
+    static constexpr int LDS_BYTES = MASK_OFF + 512 * 2 * MW * 4;
+    static_assert(NT >= 2 && NT % 2 == 0 && CPR >= 16 && 64 % CPR == 0 && NS <= 16, "256 or 512 channels");
+    // vmcnt budget of k-step ks: the fragment loads issued behind its own NT -- the steps the ring holds beyond it -- plus, for the
+    // entry fetches, whatever else was issued between them and the GEMM (y0)
+    static constexpr int young(int ks, int y0) {
+        return ks < GR ? (GR - 1) * NT + y0 : ((NS - 1 - ks) < (GR - 1) ? (NS - 1 - ks) : (GR - 1)) * NT;
+    }
+};
 
 // MODE 0: forward; 1: backward
-template <int MODE, bool INVERSE>
+template <int CH_, int MODE, bool INVERSE>
 __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
+    typedef RowsGeo<CH_> G;
+    constexpr int CH = G::CH, WN = G::WN, NT = G::NT, NS = G::NS, ROWB = G::ROWB, I16 = G::I16, IMG_BYTES = G::IMG_BYTES, MASK_OFF = G::MASK_OFF,
+                  MW = G::MW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *img = smem;                                              // [128 px][512 ch] bf16, 16-byte chunks XORed with row & 15
     float *beta_s = reinterpret_cast<float *>(smem + IMG_BYTES);            // [512]
@@ -124,12 +143,12 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
     const int lane = tid & 63;
     const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 15, fq = lane >> 4;
-    beta_s[tid] = p.beta[tid];
+    if (tid < CH) beta_s[tid] = p.beta[tid];
 
-    // image slot of this lane's 4 channels of accumulator tile (i, j): + i * 16384
+    // image slot of this lane's 4 channels of accumulator tile (i, j): + i * I16
     int slot_lane[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) slot_lane[j] = frow * (CH * 2) + (((wn * 8 + j * 2 + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8;
+    for (int j = 0; j < NT; ++j) slot_lane[j] = frow * ROWB + (((wn * (WN / 8) + j * 2 + (fq >> 1)) ^ frow) << 4) + (fq & 1) * 8;
 
     auto hi = [](int base) {   // base + 65536 as a value the compiler cannot fold back into a 17-bit offset (ds offsets are 16 bits)
         int v = base + 65536;
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
     const i32x4_t rs_dn = rsrc_words(MODE == 1 ? p.dn : p.out, p.bytes);
     const i32x4_t rs_g1 = rsrc_words(p.g1, (uint32_t)(CH / 16) * NS * 1024u);
     const i32x4_t rs_g2 = rsrc_words(MODE == 1 ? p.g2 : p.g1, (uint32_t)(CH / 16) * NS * 1024u);
-    // fragment (channel tile wn * 4 + j, step ks) of this lane: 16 bytes at ((wn * 4 + j) * NS + ks) * 1024 + lane * 16.  The tile
+    // fragment (channel tile wn * NT + j, step ks) of this lane: 16 bytes at ((wn * NT + j) * NS + ks) * 1024 + lane * 16.  The tile
     // index goes into the VECTOR offset (rebuilt per fetch from an opaque lane index: one v_lshl_add), the step into the scalar one:
     // as 64 different scalar offsets per GEMM the fully unrolled steps' offsets were all formed up front and spilled to VGPR lanes
     const uint32_t g_so0 = (uint32_t)(wn * NT) * NS * 1024u;
@@ -163,13 +182,13 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         int fq_s = fq, fr_s = frow;   /* opaque: the sixteen steps' read offsets are rebuilt per step, not hoisted and spilled */ \
         asm volatile("" : "+v"(fq_s), "+v"(fr_s));                                                                           \
         const int kc = (ks) * 4 + fq_s;                                                                                      \
-        const int rd_lane = fr_s * (CH * 2) + ((kc ^ fr_s) << 4);   /* + i * 16384 */                                        \
-        const int rd_hi = hi(rd_lane);                                                                                       \
+        const int rd_lane = fr_s * ROWB + ((kc ^ fr_s) << 4);   /* + i * I16 */                                              \
+        const int rd_hi = G::SPLIT ? hi(rd_lane) : rd_lane + 4 * I16;                                                        \
         wait_vm<YOUNG>();                                                                                                    \
         bf16x8_t gf[NT];                                                                                                     \
         _Pragma("unroll") for (int j = 0; j < NT; ++j) gf[j] = __builtin_bit_cast(bf16x8_t, gb[h][j]);                       \
         _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                     \
-            uint4 v = *reinterpret_cast<const uint4 *>(img + (i < 4 ? rd_lane : rd_hi) + (i & 3) * 16384);                   \
+            uint4 v = *reinterpret_cast<const uint4 *>(img + (i < 4 ? rd_lane : rd_hi) + (i & 3) * I16);                     \
             if (ABS) { v.x &= 0x7FFF7FFFu; v.y &= 0x7FFF7FFFu; v.z &= 0x7FFF7FFFu; v.w &= 0x7FFF7FFFu; }                     \
             const bf16x8_t xf = __builtin_bit_cast(bf16x8_t, v);                                                             \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                   \
@@ -182,17 +201,17 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
     // against the waits of steps 0 .. GR - 1 only: every later fragment is fetched behind them).
     // The two waves of a SIMD (w and w + 4) take turns at priority every three steps (conv_gdn512.hip).
 #define SC2_ROWS_ONE(rs, ks, ABS, Y0)                                                                                        \
-    {                                                                                                                        \
+    if constexpr ((ks) < NS) {                                                                                               \
         if ((ks) % 3 == 0) {                                                                                                 \
             if ((((ks) / 3) ^ (wn >> 2)) & 1) __builtin_amdgcn_s_setprio(1);                                                 \
             else __builtin_amdgcn_s_setprio(0);                                                                              \
         }                                                                                                                    \
-        SC2_ROWS_STEP(ks, (ks) % GR, rows_young(ks, Y0), ABS)                                                                \
+        SC2_ROWS_STEP(ks, (ks) % GR, G::young(ks, Y0), ABS)                                                                  \
         if constexpr ((ks) + GR < NS) fetch_g(rs, (ks) + GR, gb[(ks) % GR]);                                                 \
     }
 #define SC2_ROWS_GEMM(rs, ABS, Y0)                                                                                           \
     {                                                                                                                        \
-        static_assert(NS == 16, "sixteen steps");                                                                            \
+        static_assert(NS <= 16, "at most sixteen steps");                                                                    \
         SC2_ROWS_ONE(rs, 0, ABS, Y0) SC2_ROWS_ONE(rs, 1, ABS, Y0) SC2_ROWS_ONE(rs, 2, ABS, Y0) SC2_ROWS_ONE(rs, 3, ABS, Y0)    \
         SC2_ROWS_ONE(rs, 4, ABS, Y0) SC2_ROWS_ONE(rs, 5, ABS, Y0) SC2_ROWS_ONE(rs, 6, ABS, Y0) SC2_ROWS_ONE(rs, 7, ABS, Y0)    \
         SC2_ROWS_ONE(rs, 8, ABS, Y0) SC2_ROWS_ONE(rs, 9, ABS, Y0) SC2_ROWS_ONE(rs, 10, ABS, Y0) SC2_ROWS_ONE(rs, 11, ABS, Y0)  \
@@ -200,36 +219,41 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         __builtin_amdgcn_s_setprio(0);                                                                                       \
     }
 
-    // the image -> global, ALWAYS 16 sixteen-byte stores per thread, every one of them IN RANGE (GEMM 2's first waits count them as
-    // younger operations, and a store sent out of the descriptor's range does not keep its place in the return order): thread
-    // (wave wn, lane) streams chunk `lane` of rows wn + 8 r; a row past the end of the tensor stores row 0 of the tile again (same
-    // data, same address).  Branch-free and four rows at a time: this pass runs with the accumulators AND the next GEMM's fragment
-    // ring live -- with eight rows in flight and a separate loop for the last tile the compiler spilled ring registers right behind
-    // their (asm) loads, i.e. before the data had arrived (tools/audit_inflight.py).
+    // the image -> global, ALWAYS G::STORES sixteen-byte stores per thread, every one of them IN RANGE (GEMM 2's first waits count
+    // them as younger operations, and a store sent out of the descriptor's range does not keep its place in the return order): a
+    // wave-instruction covers 1 KB = RPP rows; thread (wave wn, lane) streams chunk lane % CPR of rows RPP (wn + 8 r) + lane / CPR; a
+    // row past the end of the tensor stores row 0 of the tile again (same data, same address).  Branch-free and four rows at a time:
+    // this pass runs with the accumulators AND the next GEMM's fragment ring live -- with eight rows in flight and a separate loop
+    // for the last tile the compiler spilled ring registers right behind their (asm) loads, i.e. before the data had arrived
+    // (tools/audit_inflight.py).
     auto stream_out = [&](const i32x4_t &rs_dst, int m0) {
+        constexpr int CPR = G::CPR, RPP = G::RPP;
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const uint32_t lz = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(img + (ln << 4));   // row 0
-        const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(img + wn * (CH * 2) + ((ln ^ wn) << 4));
-        const uint32_t l1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(img + (wn + 8) * (CH * 2) + ((ln ^ (wn + 8)) << 4));
-        const uint32_t gz = (uint32_t)m0 * (uint32_t)(CH * 2) + (uint32_t)(ln * 16);          // row m0
-        const uint32_t g0 = gz + (uint32_t)(wn * CH * 2);                                      // row m0 + wn (+ 8 r)
-        const int rows_left = p.M - m0 - wn;                                                   // row wn + 8 r exists iff 8 r < rows_left
+        const int sub = ln / CPR, ch = ln % CPR;                 // row inside the instruction's RPP rows, chunk of the row
+        const int ra = RPP * wn + sub, rb = RPP * (wn + 8) + sub;   // rows of r = 0 and r = 1; r + 2: 16 RPP rows further
+        const uint32_t lz = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(img + (ch << 4));   // row 0
+        const uint32_t l0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(img + ra * ROWB + ((ch ^ (ra & 15)) << 4));
+        const uint32_t l1 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)(img + rb * ROWB + ((ch ^ (rb & 15)) << 4));
+        const uint32_t gz = (uint32_t)m0 * (uint32_t)ROWB + (uint32_t)(ch * 16);              // row m0
+        const uint32_t g0 = gz + (uint32_t)(ra * ROWB);                                        // row m0 + ra (+ 8 RPP r)
+        const int rows_left = p.M - m0 - ra;                                                   // row ra + 8 RPP r exists iff 8 RPP r < rows_left
+        static_assert((16 * RPP) % 16 == 0, "r + 2 keeps row & 15");
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < G::STORES / 4; ++q) {
             u32x4_t v[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int r = 4 * q + k;   // row wn + 8 r: (r & 1) picks the base, (r >> 1) * 16 rows further
-                const uint32_t la = ((r & 1) ? l1 : l0) + (uint32_t)((r >> 1) * 16384);
-                const uint32_t a = 8 * r < rows_left ? la : lz;
+                const int r = 4 * q + k;   // (r & 1) picks the base, (r >> 1) * 16 RPP rows further
+                const uint32_t la = ((r & 1) ? l1 : l0) + (uint32_t)((r >> 1) * 16 * RPP * ROWB);
+                const uint32_t a = 8 * RPP * r < rows_left ? la : lz;
                 asm volatile("ds_read_b128 %0, %1" : "=v"(v[k]) : "v"(a));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = 4 * q + k;
-                store16_nt(v[k], rs_dst, 8 * r < rows_left ? g0 + (uint32_t)(8 * r * CH * 2) : gz);
+                store16_nt(v[k], rs_dst, 8 * RPP * r < rows_left ? g0 + (uint32_t)(8 * RPP * r * ROWB) : gz);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -242,11 +266,12 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         int ln = lane;              // (opaque per tile: per-lane offsets are rebuilt where they are used -- hoisted out of the tile loop
         asm volatile("" : "+v"(ln));   //  they were held in scratch and reloaded with vmcnt(0) waits inside the counted pipeline)
 #pragma unroll
-        for (int k = 0; k < BM / 8; ++k) {
-            const int row = wn + 8 * k;
+        for (int k = 0; k < G::PIECES; ++k) {
+            // piece wn + 8 k = rows RPP (wn + 8 k) .. + RPP - 1: lane -> (row, chunk position); position c of row r holds logical chunk c ^ (r & 15)
+            const int row = G::RPP * (wn + 8 * k) + ln / G::CPR;
             const int m = m0 + row;
-            const uint32_t vo = m < p.M ? (uint32_t)m * (uint32_t)(CH * 2) + (uint32_t)((ln ^ (row & 15)) << 4) : OOB;
-            buf_load_lds16(rs_x, (lds_ptr_t)(smem + row * (CH * 2)), vo, 0u);
+            const uint32_t vo = m < p.M ? (uint32_t)m * (uint32_t)ROWB + (uint32_t)(((ln % G::CPR) ^ (row & 15)) << 4) : OOB;
+            buf_load_lds16(rs_x, (lds_ptr_t)(smem + (wn + 8 * k) * 1024), vo, 0u);
         }
 #pragma unroll
         for (int h = 0; h < GR; ++h) fetch_g(rs_g1, h, gb[h]);
@@ -263,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         __syncthreads();        // every wave has read its last |x| fragment: the image may be rewritten in place
         int slot_hi[NT];        // (built here, not at the top of the tile: four registers less across the GEMM)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) slot_hi[j] = hi(slot_lane[j]);
+        for (int j = 0; j < NT; ++j) slot_hi[j] = G::SPLIT ? hi(slot_lane[j]) : slot_lane[j] + 4 * I16;
 
         if (MODE == 0) {
             // ------------------------------------------------------------ forward epilogue: y = x * (beta + norm), in place
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
                 const f32x2_t b01 = {b4.x, b4.y}, b23 = {b4.z, b4.w};
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384;
+                    unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * I16;
                     const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
                     const f32x2_t t01 = {__builtin_bit_cast(float, xr.x << 16), __builtin_bit_cast(float, xr.x & 0xFFFF0000u)};
                     const f32x2_t t23 = {__builtin_bit_cast(float, xr.y << 16), __builtin_bit_cast(float, xr.y & 0xFFFF0000u)};
@@ -299,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
 
         // ---------------------------------------------------------------- backward, first half: dn -> image, sign(x) dd -> acc
         // VMEM order from here: g in four column groups of eight 8-byte loads, each group requested one group ahead of its use
-        uint32_t zmask[4] = {0u, 0u, 0u, 0u}, smask[4] = {0u, 0u, 0u, 0u};   // bit (i * NT + j) * 4 + e: x == 0 / x < 0
+        uint32_t zmask[MW] = {}, smask[MW] = {};   // bit (i * NT + j) * 4 + e: x == 0 / x < 0
         u32x2_t gq[2][MT];
         auto load_gy = [&](int j, u32x2_t (&q)[MT]) {
             int fr = frow, fk = fq;
@@ -307,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int m = m0 + i * 16 + fr;
-                gload8(q[i], rs_gy, m < p.M ? (uint32_t)m * (uint32_t)(CH * 2) + (uint32_t)((wn * WN + j * 16 + fk * 4) * 2) : OOB);
+                gload8(q[i], rs_gy, m < p.M ? (uint32_t)m * (uint32_t)ROWB + (uint32_t)((wn * WN + j * 16 + fk * 4) * 2) : OOB);
             }
         };
         load_gy(0, gq[0]);
@@ -326,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
             asm volatile("" : "+v"(fr_o), "+v"(fq_o));
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384;
+                unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * I16;
                 const uint2 xr = *reinterpret_cast<const uint2 *>(slot);
                 const uint32_t xb[4] = {xr.x << 16, xr.x & 0xFFFF0000u, xr.y << 16, xr.y & 0xFFFF0000u};
                 const u32x2_t gr = gq[j & 1][i];
@@ -366,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
                 // Branch-free: ALWAYS one 8-byte store per slot, sent out of range unless the slot holds a zero (the counted waits
                 // below include these stores; rows past the end of the tensor are out of the descriptor's range by themselves).
                 {
-                    const uint32_t po = (uint32_t)(m0 + i * 16 + fr_o) * (uint32_t)(CH * 2) + (uint32_t)((wn * WN + j * 16 + fq_o * 4) * 2);
+                    const uint32_t po = (uint32_t)(m0 + i * 16 + fr_o) * (uint32_t)ROWB + (uint32_t)((wn * WN + j * 16 + fq_o * 4) * 2);
                     park8(u32x2_t{pack2(f32x2_t{ddv[0], ddv[1]}), pack2(f32x2_t{ddv[2], ddv[3]})}, rs_out, zm4 != 0u ? po : OOB);
                 }
                 uint2 o;
@@ -385,31 +410,36 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         // the two masks sit out GEMM 2 in LDS (eight registers the GEMM does not have: with them live across it the accumulators
         // were spilled)
         {
-            uint4 *mk = reinterpret_cast<uint4 *>(smem + MASK_OFF) + 2 * tid;
-            mk[0] = make_uint4(zmask[0], zmask[1], zmask[2], zmask[3]);
-            mk[1] = make_uint4(smask[0], smask[1], smask[2], smask[3]);
+            uint32_t *mk = reinterpret_cast<uint32_t *>(smem + MASK_OFF) + 2 * MW * tid;
+#pragma unroll
+            for (int w = 0; w < MW; ++w) {
+                mk[w] = zmask[w];
+                mk[MW + w] = smask[w];
+            }
         }
         __syncthreads();        // the image holds dn
         stream_out(rs_dn, m0);   // sixteen stores, younger than the three gamma^T steps in the ring
 
         // ---------------------------------------------------------------- GEMM 2 on top: acc = sign(x) dd + gamma^T dn
-        SC2_ROWS_GEMM(rs_g2, false, 16)   /* younger than the ring's three steps: the sixteen dn stores */
+        SC2_ROWS_GEMM(rs_g2, false, G::STORES)   /* younger than the ring's three steps: the dn stores */
         __syncthreads();        // every wave has read its last dn fragment
 
         // ---------------------------------------------------------------- dx = sign(x) * acc, in place
         {
-            const uint4 *mk = reinterpret_cast<const uint4 *>(smem + MASK_OFF) + 2 * tid;
-            const uint4 z = mk[0], sg = mk[1];
-            zmask[0] = z.x; zmask[1] = z.y; zmask[2] = z.z; zmask[3] = z.w;
-            smask[0] = sg.x; smask[1] = sg.y; smask[2] = sg.z; smask[3] = sg.w;
+            const uint32_t *mk = reinterpret_cast<const uint32_t *>(smem + MASK_OFF) + 2 * MW * tid;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) slot_hi[j] = hi(slot_lane[j]);
+            for (int w = 0; w < MW; ++w) {
+                zmask[w] = mk[w];
+                smask[w] = mk[MW + w];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) slot_hi[j] = G::SPLIT ? hi(slot_lane[j]) : slot_lane[j] + 4 * I16;
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384;
+                unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * I16;
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -425,7 +455,10 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
             }
         }
         // elements with x == 0: dx = the dd parked in front of GEMM 2
-        if (__builtin_amdgcn_ballot_w64((zmask[0] | zmask[1] | zmask[2] | zmask[3]) != 0u) != 0ull) {
+        uint32_t zany = 0u;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) zany |= zmask[w];
+        if (__builtin_amdgcn_ballot_w64(zany != 0u) != 0ull) {
             wait_vm<0>();   // the parking stores have completed (vmcnt counts stores on gfx9)
             int fr_o = frow, fq_o = fq;
             asm volatile("" : "+v"(fr_o), "+v"(fq_o));
@@ -436,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
                     const uint32_t zm4 = (zmask[(i * NT + j) >> 3] >> (((i * NT + j) & 7) * 4)) & 15u;
                     if (zm4 != 0u && m0 + i * 16 + fr_o < p.M) {   // (rows past the end of the tensor read zeros: flagged, never stored)
                         const volatile uint16_t *park = p.out + (long long)(m0 + i * 16 + fr_o) * CH + wn * WN + j * 16 + fq_o * 4;
-                        unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * 16384;
+                        unsigned char *slot = img + (i < 4 ? slot_lane[j] : slot_hi[j]) + (i & 3) * I16;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if ((zm4 >> e) & 1u) *reinterpret_cast<uint16_t *>(slot + e * 2) = park[e];
@@ -455,14 +488,14 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
 
 int g_cus_rows = 0;
 
-template <int MODE, bool INVERSE>
+template <int CH, int MODE, bool INVERSE>
 int launch_rows(const RowsArgs &a, hipStream_t s) {
-    constexpr int lds = LDS_BYTES;
+    constexpr int lds = RowsGeo<CH>::LDS_BYTES;
     static_assert(lds <= 160 * 1024, "LDS");
     static bool attr_set_dev[SC2_MAX_DEVICES] = {};
     bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gdn512_rows_kernel<MODE, INVERSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gdn512_rows_kernel<CH, MODE, INVERSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   lds);
         attr_set = true;
     }
@@ -473,15 +506,21 @@ int launch_rows(const RowsArgs &a, hipStream_t s) {
         g_cus_rows = n;
     }
     const int grid = a.n_tiles < g_cus_rows ? a.n_tiles : g_cus_rows;
-    hipLaunchKernelGGL((gdn512_rows_kernel<MODE, INVERSE>), dim3(grid), dim3(512), lds, s, a);
+    hipLaunchKernelGGL((gdn512_rows_kernel<CH, MODE, INVERSE>), dim3(grid), dim3(512), lds, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
 
+template <int MODE>
+int launch_rows_c(const RowsArgs &a, int C, int inverse, hipStream_t s) {
+    if (C == 512) return inverse ? launch_rows<512, MODE, true>(a, s) : launch_rows<512, MODE, false>(a, s);
+    return inverse ? launch_rows<256, MODE, true>(a, s) : launch_rows<256, MODE, false>(a, s);
+}
+
 int rows_args(RowsArgs &a, const void *x, const void *gy, const void *g1, const void *g2, const float *beta, void *out, void *dn,
-              long long M, const char *who) {
-    SC2_REQUIRE(M > 0 && M * (CH * 2) < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "%s: %lld pixels x 512 channels exceed 2 GB (32-bit buffer offsets)",
-                who, M);
+              long long M, int C, const char *who) {
+    SC2_REQUIRE(M > 0 && M * (C * 2) < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "%s: %lld pixels x %d channels exceed 2 GB (32-bit buffer offsets)",
+                who, M, C);
     a.x = static_cast<const uint16_t *>(x);
     a.gy = static_cast<const uint16_t *>(gy);
     a.g1 = static_cast<const uint16_t *>(g1);
@@ -491,30 +530,28 @@ int rows_args(RowsArgs &a, const void *x, const void *gy, const void *g1, const 
     a.dn = static_cast<uint16_t *>(dn);
     a.M = (int)M;
     a.n_tiles = (int)((M + BM - 1) / BM);
-    a.bytes = (unsigned)(M * (CH * 2));
+    a.bytes = (unsigned)(M * (C * 2));
     return SC2_OK;
 }
 
 }  // namespace
 
-extern "C" int sc2_gdn1_rows_supported(int C) { return C == 512 ? 1 : 0; }
+extern "C" int sc2_gdn1_rows_supported(int C) { return C == 512 || C == 256 ? 1 : 0; }
 
 extern "C" int sc2_gdn1_rows_fwd(const void *x, const void *gamma_frag, const float *beta, void *y, long long M, int C, int inverse,
                                  void *stream) {
     SC2_REQUIRE(x && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "gdn1_rows_fwd: null argument");
-    SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_fwd: C = %d (512 only)", C);
+    SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_fwd: C = %d (256 or 512)", C);
     RowsArgs a;
-    if (const int rc = rows_args(a, x, nullptr, gamma_frag, nullptr, beta, y, nullptr, M, "gdn1_rows_fwd")) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return inverse ? launch_rows<0, true>(a, s) : launch_rows<0, false>(a, s);
+    if (const int rc = rows_args(a, x, nullptr, gamma_frag, nullptr, beta, y, nullptr, M, C, "gdn1_rows_fwd")) return rc;
+    return launch_rows_c<0>(a, C, inverse, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int sc2_gdn1_rows_bwd(const void *x, const void *gy, const void *gamma_frag, const void *gamma_t_frag, const float *beta,
                                  void *d_norm, void *dx, long long M, int C, int inverse, void *stream) {
     SC2_REQUIRE(x && gy && gamma_frag && gamma_t_frag && beta && d_norm && dx, SC2_ERR_INVALID_ARG, "gdn1_rows_bwd: null argument");
-    SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_bwd: C = %d (512 only)", C);
+    SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_bwd: C = %d (256 or 512)", C);
     RowsArgs a;
-    if (const int rc = rows_args(a, x, gy, gamma_frag, gamma_t_frag, beta, dx, d_norm, M, "gdn1_rows_bwd")) return rc;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return inverse ? launch_rows<1, true>(a, s) : launch_rows<1, false>(a, s);
+    if (const int rc = rows_args(a, x, gy, gamma_frag, gamma_t_frag, beta, dx, d_norm, M, C, "gdn1_rows_bwd")) return rc;
+    return launch_rows_c<1>(a, C, inverse, static_cast<hipStream_t>(stream));
 }

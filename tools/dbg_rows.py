@@ -9,7 +9,8 @@ from sc2bench_amd import hip  # noqa: E402
 
 dev = torch.device('cuda:0')
 torch.manual_seed(1)
-C, M = 512, int(sys.argv[1]) if len(sys.argv) > 1 else 128
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+C = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 inverse = True
 x = torch.randn(M, C).to(torch.bfloat16).float()
 gy = torch.randn(M, C).to(torch.bfloat16).float()
