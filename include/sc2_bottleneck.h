@@ -218,8 +218,9 @@ int sc2_conv2d_fwd(const sc2_conv_desc *d, const void *x, const void *w_packed, 
 int sc2_gdn1_bwd_gemm(const sc2_conv_desc *d, const void *x, const void *w_packed, void *y, void *y2, const void *ep_x,
                       const void *ep_x2, const float *ep_beta, void *stream);
 
-/* GDN1 / inverse GDN1 over C = 256 or 512 channels with the whole channel row of a 128-pixel tile resident in LDS (gdn512_rows.hip) --
- * the training-time forms of the decoder's two normalisations (sc2bench/models/layer.py:486-491; forward in train mode keeps its input
+/* GDN1 / inverse GDN1 over C = 96, 256 or 512 channels with the whole channel row of a pixel tile resident in LDS (gdn512_rows.hip: 128-pixel
+ * tiles, C = 256 / 512; gdn96_strips.hip: 32-pixel strips per wave, C = 96) -- the training-time forms of the first encoder normalisation
+ * and the decoder's two (sc2bench/models/layer.py:476-477, 486-491; forward in train mode keeps its input
  * for the backward, which loss.backward() of script/task/image_classification.py:79 reaches):
  *   sc2_gdn1_rows_fwd : y = x * (beta + gamma |x|)  (inverse != 0)  or  x / (...);  x, y bf16 [M, C]
  *   sc2_gdn1_rows_bwd : given x and the gradient gy of y, BOTH GEMMs of the backward and its element-wise halves in one launch:

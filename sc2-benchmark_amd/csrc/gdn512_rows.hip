@@ -536,12 +536,17 @@ int rows_args(RowsArgs &a, const void *x, const void *gy, const void *g1, const 
 
 }  // namespace
 
-extern "C" int sc2_gdn1_rows_supported(int C) { return C == 512 || C == 256 ? 1 : 0; }
+// C = 96: every wave an independent worker on 32-pixel strips (gdn96_strips.hip)
+int sc2_gdn96_strips(int mode, const void *x, const void *gy, const void *g1, const void *g2, const float *beta, void *out, void *dn,
+                     long long M, int inverse, hipStream_t s);
+
+extern "C" int sc2_gdn1_rows_supported(int C) { return C == 512 || C == 256 || C == 96 ? 1 : 0; }
 
 extern "C" int sc2_gdn1_rows_fwd(const void *x, const void *gamma_frag, const float *beta, void *y, long long M, int C, int inverse,
                                  void *stream) {
     SC2_REQUIRE(x && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "gdn1_rows_fwd: null argument");
-    SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_fwd: C = %d (256 or 512)", C);
+    SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_fwd: C = %d (96, 256 or 512)", C);
+    if (C == 96) return sc2_gdn96_strips(0, x, nullptr, gamma_frag, nullptr, beta, y, nullptr, M, inverse, static_cast<hipStream_t>(stream));
     RowsArgs a;
     if (const int rc = rows_args(a, x, nullptr, gamma_frag, nullptr, beta, y, nullptr, M, C, "gdn1_rows_fwd")) return rc;
     return launch_rows_c<0>(a, C, inverse, static_cast<hipStream_t>(stream));
@@ -550,7 +555,9 @@ extern "C" int sc2_gdn1_rows_fwd(const void *x, const void *gamma_frag, const fl
 extern "C" int sc2_gdn1_rows_bwd(const void *x, const void *gy, const void *gamma_frag, const void *gamma_t_frag, const float *beta,
                                  void *d_norm, void *dx, long long M, int C, int inverse, void *stream) {
     SC2_REQUIRE(x && gy && gamma_frag && gamma_t_frag && beta && d_norm && dx, SC2_ERR_INVALID_ARG, "gdn1_rows_bwd: null argument");
-    SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_bwd: C = %d (256 or 512)", C);
+    SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_bwd: C = %d (96, 256 or 512)", C);
+    if (C == 96)
+        return sc2_gdn96_strips(1, x, gy, gamma_frag, gamma_t_frag, beta, dx, d_norm, M, inverse, static_cast<hipStream_t>(stream));
     RowsArgs a;
     if (const int rc = rows_args(a, x, gy, gamma_frag, gamma_t_frag, beta, dx, d_norm, M, C, "gdn1_rows_bwd")) return rc;
     return launch_rows_c<1>(a, C, inverse, static_cast<hipStream_t>(stream));

@@ -85,7 +85,7 @@ class HostPolicy(object):
     fc_kernel = True           # dedicated classifier kernel
     dense_head = True          # DeepLab / FCN heads and the FPN on the library's kernels in bf16 eval
     rans_fused_dq = True       # decode + dequantise in one coder launch
-    gdn_rows = True            # 256- / 512-channel GDN1 in training: forward and the whole backward on the resident-row kernel (gdn512_rows.hip)
+    gdn_rows = True            # 96- / 256- / 512-channel GDN1 in training: forward and the whole backward on the resident-row kernel (gdn512_rows.hip)
     gdn_bwd_fused = True       # GDN1 backward: element-wise halves in the epilogues of its two GEMMs (sc2_gdn1_bwd_gemm)
     dgrad_win_halves = True    # data gradient of dec.conv2 as two 256-channel launches of the window-plane 2x2 kernel
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
@@ -467,7 +467,7 @@ def gdn1_bwd_gemm(x_nhwc, w_packed, epilogue, ep_x, ep_x2, beta=None, tag=None):
 
 
 def gdn1_rows_supported(x_nhwc, C):
-    """True if GDN1 over C channels of this bf16 [..., C] tensor runs on the resident-row kernel (C = 256 or 512, < 2 GB)."""
+    """True if GDN1 over C channels of this bf16 [..., C] tensor runs on the resident-row kernel (C = 96, 256 or 512, < 2 GB)."""
     return bool(host_policy.gdn_rows) and x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_cuda and x_nhwc.is_contiguous() and \
         x_nhwc.shape[-1] == C and x_nhwc.numel() * 2 < 0x7FF00000 and bool(lib().sc2_gdn1_rows_supported(C))
 

@@ -1151,9 +1151,9 @@ def test_gdn1_backward(S, R, dev, C, inverse):
     assert rel(d_beta, beta.grad) < 1.5e-2
     assert rel(d_gamma, gamma.grad) < 1.5e-2
     if S.hip.weight_rows(C) % 128 == 0 or S.hip.weight_rows(C) == 96:
-        # C = 256 / 512 ran on the resident-row kernel (gdn512_rows.hip): its other form is the pair of GEMMs with fused epilogues; the
+        # C = 96 / 256 / 512 ran on the resident-row kernels (gdn512_rows.hip, gdn96_strips.hip): its other form is the pair of GEMMs with fused epilogues; the
         # other fused widths: theirs is the five-launch form
-        off = dict(gdn_rows=False) if C in (256, 512) else dict(gdn_bwd_fused=False)
+        off = dict(gdn_rows=False) if C in (96, 256, 512) else dict(gdn_bwd_fused=False)
         S.hip.configure(**off)
         try:
             dx5, d_beta5, d_gamma5 = S.hip.gdn1_backward(S.hip.nchw_f32_to_nhwc_bf16(gy.to(dev)), S.hip.nchw_f32_to_nhwc_bf16(x.to(dev)),
@@ -1165,13 +1165,14 @@ def test_gdn1_backward(S, R, dev, C, inverse):
 
 @pytest.mark.parametrize('inverse', [True, False])
 @pytest.mark.parametrize('shape', [(3, 16, 24), (2, 11, 9), (1, 1, 5)])
-@pytest.mark.parametrize('C', [512, 256])
+@pytest.mark.parametrize('C', [512, 256, 96])
 def test_gdn512_rows(S, dev, C, shape, inverse):
     """gdn512_rows.hip: GDN1 / inverse GDN1 over 512 channels, forward and the whole backward in one launch each, against f32
     autograd on the bf16-rounded operands.  1 152 pixels = nine full 128-pixel tiles; 198 and 5 pixels: a partial last tile.  x holds
     exact zeros -- single elements, a whole pixel, a whole channel: sign(0) = 0, such an element's gradient is its direct term alone
     (the kernel parks it in dx in front of the second GEMM and fetches it back behind it).  C = 256: the second decoder GDN's
-    geometry (two image rows per 1 KB direct-to-LDS / store instruction, eight k-steps, two accumulator columns per wave)."""
+    geometry (two image rows per 1 KB direct-to-LDS / store instruction, eight k-steps, two accumulator columns per wave); C = 96:
+    gdn96_strips.hip (every wave an independent worker on 32-pixel strips, the first encoder GDN)."""
     N, H, W = shape
     torch.manual_seed(N * 7 + H)
     x = bf16_round(torch.randn(N, H, W, C))
