@@ -64,10 +64,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    int bid = blockIdx.x;
+    // Workgroup b runs on XCD b & 7 (round-robin dispatch).  The `tiles` workgroups that reduce the SAME pixel range -- each reads the
+    // range's dY slab for its 128 output channels and the im2col slab for its 128 k-columns -- are consecutive workgroups of ONE XCD:
+    // the range's rows of x and dY then come from HBM once, into that XCD's L2, instead of once per XCD (round 5: with the ranges dealt
+    // out in launch order a range's 16 - 32 tiles were spread over all eight L2s).  The launcher makes the number of ranges a multiple
+    // of 8; range c belongs to XCD c & 7.
     const int tiles = p.n_ktiles * p.n_ctiles;
-    const int chunk = bid / tiles;
-    const int t = bid - chunk * tiles;
+    const int xcd = (int)(blockIdx.x & 7), local = (int)(blockIdx.x >> 3);
+    const int chunk = (local / tiles) * 8 + xcd;
+    const int t = local % tiles;
+    if (chunk * p.rows_per_block >= p.M) return;   // (a range past the end, from rounding the range count up)
     const int ctile = t / p.n_ktiles, ktile = t - ctile * p.n_ktiles;
     const int co0 = ctile * WG_TILE, k0 = ktile * WG_TILE;
     const int m_begin = chunk * p.rows_per_block;
@@ -277,6 +283,7 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     rows = (rows + WG_SLAB - 1) / WG_SLAB * WG_SLAB;
     if (rows < 8 * WG_SLAB) rows = 8 * WG_SLAB;
     chunks = (M + rows - 1) / rows;
+    chunks = (chunks + 7) / 8 * 8;      // the kernel deals the ranges to the eight XCDs
     a.rows_per_block = (int)rows;
     const long long grid = tiles * chunks;
     SC2_REQUIRE(grid > 0 && grid < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv2d_wgrad: grid out of range");
