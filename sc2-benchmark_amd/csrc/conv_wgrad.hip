@@ -277,7 +277,11 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     // is paid in atomics: 4 096 workgroups (16 per CU) -> 1 024 (two rounds of the 512 resident ones) took the small layers'
     // launches from 0.095 / 0.31 / 0.28 ms to 0.054 / 0.24 / 0.24 (the 512 x 512 gamma gradient stays at 0.89: it is bound by
     // the L2 -> LDS fill of its 128 x 128 tiles, 16 KB per 64 MFMAs), the training step + 2 %.  SC2_WGRAD_WGS overrides (A/B).
-    const int wg_target = sc2_pol().wgrad_wgs > 0 ? sc2_pol().wgrad_wgs : 1024;
+    // (round 5, ranges XCD-local -- tools/wgrad_times.py: four output tiles or fewer want 512 workgroups (igdn3's gamma 0.177 -> 0.152
+    //  ms), a single 128-channel tile row with a long K -- enc.conv2, 19 k-tiles -- wants 4 096 (0.63 -> 0.53); the rest is flat
+    //  between 1 024 and 2 048)
+    const int wg_auto = tiles <= 4 ? 512 : (a.n_ctiles == 1 ? 4096 : 1024);
+    const int wg_target = sc2_pol().wgrad_wgs > 0 ? sc2_pol().wgrad_wgs : wg_auto;
     long long chunks = (wg_target + tiles - 1) / tiles;
     long long rows = (M + chunks - 1) / chunks;
     rows = (rows + WG_SLAB - 1) / WG_SLAB * WG_SLAB;
