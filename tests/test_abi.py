@@ -151,7 +151,12 @@ def test_hot_path_kernels_use_no_scratch():
     ks = kr.kernels(os.path.join(root, 'sc2-benchmark_amd', 'libsc2amd.so'))
     assert len(ks) > 60
     opt_in = ('conv_igemm4_kernel',                   # SC2_CONV_BIG4 experiment (4-wave register tile)
-              'ELi128ELi3ELb0ELi64EEEEEvNS_8ConvArgsE')   # SC2_CONV_HALF experiment (128-row tile, 128-register cap)
+              'ELi128ELi3ELb0ELi64EEEEEvNS_8ConvArgsE',   # SC2_CONV_HALF experiment (128-row tile, 128-register cap)
+              # the training-step GDN1 kernels (round 5) sit at the 256-register cap of two waves per SIMD: 9 - 31 dwords of loop
+              # invariants and one accumulator tile go to scratch (36 - 124 B / lane; measured with them: 512-channel backward
+              # 2.45 -> 1.22 ms).  What may NOT happen there -- a spill of a register an asm load is still filling -- is checked by
+              # tools/audit_inflight.py and audit_vmcnt.py --copies (test above).
+              'gdn512_rows_kernelILi512E', 'gdn96_strips_kernelILi1E')
     bad = [(k['name'], k['scratch']) for k in ks if k['scratch'] and not any(o in k['name'] for o in opt_in)]
     assert not bad, 'kernels with scratch: {}'.format(bad)
     big = [k for k in ks if 'conv_igemm8_kernel' in k['name'] and 'ELi256ELi4ELb0ELi64' in k['name']]
