@@ -31,6 +31,9 @@
 #ifndef SC2_DEC_W_EARLY
 #define SC2_DEC_W_EARLY 1
 #endif
+#ifndef SC2_DEC_EPI_BARRIER
+#define SC2_DEC_EPI_BARRIER 1
+#endif
 #ifndef SC2_DEC_DBG
 #define SC2_DEC_DBG 0      // timing experiments (results garbage): 1 = no output stores
 #endif
@@ -310,6 +313,11 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
             if (c == (unsigned)(p.n_tiles - 1)) *p.tile_ctr = 0u;   // the launch's last claim re-arms the counter
         }
 
+        // (round 5: every wave has read its last |t| fragment before any wave rewrites its slots.  The phase has no barrier inside and
+        //  the in-place epilogue below used to start as soon as a wave's own last MFMA was issued: a wave more than ~2 k cycles ahead of
+        //  the slowest one would have replaced t by y under that wave's last k-steps.  Never observed -- the beta loads above sit in
+        //  between -- but nothing ruled it out.  SC2_DEC_EPI_BARRIER=0: A/B.)
+        if (SC2_DEC_EPI_BARRIER) __builtin_amdgcn_s_barrier();
         // ---------------------------------------------------------------- epilogue: y = t * (beta + norm), in place
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
