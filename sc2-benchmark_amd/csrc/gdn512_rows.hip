@@ -1,28 +1,36 @@
-// GDN1 / inverse GDN1 over 512 channels with the WHOLE channel row of a pixel tile resident in LDS (gfx950) -- the training-time
-// counterparts of conv_gdn512.hip's second phase:
+// GDN1 / inverse GDN1 over 512 or 256 channels with the WHOLE channel row of a pixel tile resident in LDS (gfx950) -- the training-time
+// counterparts of conv_gdn512.hip's second phase (96 channels: gdn96_strips.hip):
 //
 //   forward   y = x * (beta + gamma |x|)            (inverse)      |  x / (beta + gamma |x|)
 //   backward  n  = beta + gamma |x|
 //             dd = g * n,  dn = g * x               (inverse)      |  dd = g / n,  dn = -dd * x / n
 //             dx = dd + sign(x) * (gamma^T dn)                      d_norm = dn is written out (d_gamma = dn^T |x|, d_beta = colsum dn)
 //
-// (sc2bench/models/layer.py:486-488: the 512-channel inverse GDN1 behind the first decoder conv; its backward is reached through
-//  loss.backward() in script/task/image_classification.py:79.)
+// (sc2bench/models/layer.py:486-491: the 512- and 256-channel inverse GDN1 behind the first two decoder convs; their backward is reached
+//  through loss.backward() in script/task/image_classification.py:79.)
 //
-// Why: as launches of the 128 x 128 tile kernel (sc2_gdn1_bwd_gemm) the two C x C GEMMs of the backward run at 0.32 - 0.36 PFLOP/s
-// and move the 822 MB tensors nine times (1.30 + 1.16 ms at 256 x 56 x 56; the plain GEMM without any epilogue already takes 0.83 ms:
-// K = 512 is sixteen slabs through a three-deep LDS ring per tile, re-read by four channel tiles).  Here a workgroup owns 128 pixels x
-// all 512 channels: x lands in the LDS image once (direct-to-LDS, 128 KB), gamma streams L2 -> registers as MFMA fragments (hand-counted
-// vmcnt ring, as conv_gdn512.hip), the element-wise halves run on the accumulators in place, and -- backward -- the second GEMM
-// accumulates ON TOP of sign(x) * dd in the same accumulators (dx = sign(x) * (sign(x) dd + gamma^T dn)), so neither n nor dd ever
-// exists in memory: four tensor passes (x, g in; dn, dx out) and both GEMMs at the resident-image rate.
+// Why: as launches of the 128 x 128 tile kernel (sc2_gdn1_bwd_gemm) the two C x C GEMMs of the 512-channel backward run at 0.32 - 0.36
+// PFLOP/s and move the 822 MB tensors nine times (1.30 + 1.16 ms at 256 x 56 x 56; the plain GEMM without any epilogue already takes
+// 0.83 ms: K = 512 is sixteen slabs through a three-deep LDS ring per tile, re-read by four channel tiles).  Here a workgroup owns 128
+// pixels x all channels: x lands in the LDS image once (direct-to-LDS, 128 / 64 KB), gamma streams L2 -> registers as MFMA fragments
+// (hand-counted vmcnt ring, as conv_gdn512.hip), the element-wise halves run on the accumulators in place, and -- backward -- the second
+// GEMM accumulates ON TOP of sign(x) * dd in the same accumulators (dx = sign(x) * (sign(x) dd + gamma^T dn)), so neither n nor dd ever
+// exists in memory: four tensor passes (x, g in; dn, dx out).  Measured at bs 256 (tools/gdn_gemm_times.py): 512 channels forward
+// 0.88 -> 0.60 ms, backward 2.45 -> 1.22 ms; 256 channels 0.35 -> 0.22 and 0.92 -> 0.45 ms.
 //
 // sign(0) = 0 (torch.abs's gradient): an element with x == 0 contributes dn = 0 and must come out as dx = dd alone.  Its accumulator
-// starts at 0 and a per-lane bit mask remembers it; after the second GEMM the (rare) flagged elements recompute their norm with a
-// scalar dot product from global memory.
+// starts at 0, a per-lane bit mask remembers it, its dd is parked in its own place in dx (one 8-byte store per slot, sent out of
+// range unless the slot holds a zero) and fetched back behind the second GEMM.
 //
-// Eight waves; wave w owns channels [64 w, 64 w + 64) of every pixel (8 x 4 accumulator tiles, weights as the MFMA A operand: a lane
-// holds 4 consecutive channels of one pixel).  Persistent workgroups, one per CU, tiles dealt round-robin.
+// Eight waves; wave w owns channels [CH/8 w, CH/8 (w + 1)) of every pixel (8 x 4 / 8 x 2 accumulator tiles, weights as the MFMA A
+// operand: a lane holds 4 consecutive channels of one pixel).  Persistent workgroups, one per CU, tiles dealt round-robin.
+//
+// Three things this kernel taught (round 5), each now checked where it can be:
+//   * a register an asm load is filling must never be under spilling pressure -- the compiler spills it right behind the load, i.e.
+//     stores what the register held BEFORE (tools/audit_inflight.py; audit_vmcnt.py --copies);
+//   * a VMEM store of more than 64 bits written in asm needs its own wait states before a VALU instruction overwrites the data
+//     registers (store16_nt; audit_vmcnt.py --stores);
+//   * __builtin_bit_cast(uint32_t, vec[e]) on an ext_vector element LVALUE reads element 0, whatever e is (copy the element first).
 #include <stdlib.h>
 
 #include "sc2_common.h"
@@ -219,13 +227,13 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         __builtin_amdgcn_s_setprio(0);                                                                                       \
     }
 
-    // the image -> global, ALWAYS G::STORES sixteen-byte stores per thread, every one of them IN RANGE (GEMM 2's first waits count
-    // them as younger operations, and a store sent out of the descriptor's range does not keep its place in the return order): a
-    // wave-instruction covers 1 KB = RPP rows; thread (wave wn, lane) streams chunk lane % CPR of rows RPP (wn + 8 r) + lane / CPR; a
-    // row past the end of the tensor stores row 0 of the tile again (same data, same address).  Branch-free and four rows at a time:
-    // this pass runs with the accumulators AND the next GEMM's fragment ring live -- with eight rows in flight and a separate loop
-    // for the last tile the compiler spilled ring registers right behind their (asm) loads, i.e. before the data had arrived
-    // (tools/audit_inflight.py).
+    // the image -> global, ALWAYS G::STORES sixteen-byte stores per thread, every one of them IN RANGE: GEMM 2's first waits count
+    // them as younger operations, and whether a store that is dropped by the descriptor's range check keeps its place in the return
+    // order was not established -- so none is sent there.  A wave-instruction covers 1 KB = RPP rows; thread (wave wn, lane) streams
+    // chunk lane % CPR of rows RPP (wn + 8 r) + lane / CPR; a row past the end of the tensor stores row 0 of the tile again (same data,
+    // same address).  Branch-free and four rows at a time: this pass runs with the accumulators AND the next GEMM's fragment ring
+    // live -- with eight rows in flight and a separate loop for the last tile the compiler spilled ring registers right behind
+    // their (asm) loads, i.e. before the data had arrived (tools/audit_inflight.py).
     auto stream_out = [&](const i32x4_t &rs_dst, int m0) {
         constexpr int CPR = G::CPR, RPP = G::RPP;
         int ln = lane;
@@ -340,9 +348,9 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             // issue order: L0 L1 | C0 (8 parking stores) L2 | C1 (8) L3 | C2 (8) | C3 (8) | F (12 gamma^T fragments).  The parking
-            // stores are NOT counted as younger operations: a store sent out of the descriptor's range is dropped without taking its
-            // turn in the return order (measured: with them counted -- vmcnt(16) -- groups 2 and 3 were read half-landed), so a
-            // wait may only rely on the LOADS behind the group it waits for
+            // stores are NOT counted as younger operations -- nearly all of them are sent out of the descriptor's range, and whether
+            // such a store keeps its place in the return order was not established: a wait relies only on the LOADS behind the
+            // group it waits for (the conservative choice: if the stores do keep their place, the wait also retires them)
             if (j < NT - 1) wait_vm_q<MT>(gq[j & 1]);             // group j has landed: group j + 1 is younger
             else wait_vm_q<0>(gq[j & 1]);
             const float4 b4 = *reinterpret_cast<const float4 *>(beta_s + wn * WN + j * 16 + fq * 4);
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
                 // sign(0) = 0: such an element's gradient is dd alone.  The slot's four dd are parked in their own place in dx (which
                 // the tile's final store pass overwrites -- with the same value where x == 0) and fetched back behind the second GEMM.
                 // Branch-free: ALWAYS one 8-byte store per slot, sent out of range unless the slot holds a zero (the counted waits
-                // below include these stores; rows past the end of the tensor are out of the descriptor's range by themselves).
+                // below do not rely on these stores; rows past the end of the tensor are out of the descriptor's range by themselves).
                 {
                     const uint32_t po = (uint32_t)(m0 + i * 16 + fr_o) * (uint32_t)ROWB + (uint32_t)((wn * WN + j * 16 + fq_o * 4) * 2);
                     park8(u32x2_t{pack2(f32x2_t{ddv[0], ddv[1]}), pack2(f32x2_t{ddv[2], ddv[3]})}, rs_out, zm4 != 0u ? po : OOB);
