@@ -383,7 +383,9 @@ def train_bench(args, dev, rank, world, distributed, emit=True):
                        'process_group': '{} ({} rank{})'.format(dist.get_backend(), world, '' if world == 1 else 's') if distributed else 'none',
                        'collectives_issued': bool(dp.collectives_active()),
                        'gradient_buckets': len(stage.reducer.buckets),
-                       'buckets_launched_from_backward_hooks_last_step': stage.reducer.launched_by_hook},
+                       'buckets_launched_from_backward_hooks_last_step': stage.reducer.launched_by_hook,
+                       'teacher_on_side_stream': bool(S.hip.host_policy.teacher_stream),
+                       'gdn_kernels': 'resident-row (gdn512_rows / gdn96_strips)' if S.hip.host_policy.gdn_rows else 'tile GEMMs'},
             'final_loss': loss.item(), 'images_all_ranks': g_images, 'mean_loss_all_ranks': g_loss / max(g_images / args.steps, 1.0)})
         if emit:
             print(json.dumps(line))
