@@ -227,9 +227,10 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         __builtin_amdgcn_s_setprio(0);                                                                                       \
     }
 
-    // the image -> global, ALWAYS G::STORES sixteen-byte stores per thread, every one of them IN RANGE: GEMM 2's first waits count
-    // them as younger operations, and whether a store that is dropped by the descriptor's range check keeps its place in the return
-    // order was not established -- so none is sent there.  A wave-instruction covers 1 KB = RPP rows; thread (wave wn, lane) streams
+    // the image -> global, ALWAYS G::STORES sixteen-byte stores per thread (GEMM 2's first waits count them as younger operations),
+    // every one of them in range.  (A store dropped by the descriptor's range check DOES keep its place in vmcnt's return order --
+    // tools/micro/oob_store_order.hip, 5e8 probes -- so masking by range would have been safe too; this form dates from before that
+    // was measured.)  A wave-instruction covers 1 KB = RPP rows; thread (wave wn, lane) streams
     // chunk lane % CPR of rows RPP (wn + 8 r) + lane / CPR; a row past the end of the tensor stores row 0 of the tile again (same data,
     // same address).  Branch-free and four rows at a time: this pass runs with the accumulators AND the next GEMM's fragment ring
     // live -- with eight rows in flight and a separate loop for the last tile the compiler spilled ring registers right behind
@@ -347,10 +348,10 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         load_gy(1, gq[1]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            // issue order: L0 L1 | C0 (8 parking stores) L2 | C1 (8) L3 | C2 (8) | C3 (8) | F (12 gamma^T fragments).  The parking
-            // stores are NOT counted as younger operations -- nearly all of them are sent out of the descriptor's range, and whether
-            // such a store keeps its place in the return order was not established: a wait relies only on the LOADS behind the
-            // group it waits for (the conservative choice: if the stores do keep their place, the wait also retires them)
+            // issue order: L0 L1 | C0 (8 parking stores) L2 | C1 (8) L3 | C2 (8) | C3 (8) | F (12 gamma^T fragments).  The waits rely
+            // only on the LOADS behind the group they wait for, i.e. they also retire the previous group's parking stores (which are
+            // nearly all dropped by the range check and cost nothing; such stores do keep their place in the return order --
+            // tools/micro/oob_store_order.hip -- so counting them would be correct as well)
             if (j < NT - 1) wait_vm_q<MT>(gq[j & 1]);             // group j has landed: group j + 1 is younger
             else wait_vm_q<0>(gq[j & 1]);
             const float4 b4 = *reinterpret_cast<const float4 *>(beta_s + wn * WN + j * 16 + fq * 4);
