@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 38
+#define SC2_ABI_VERSION 39
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -82,7 +82,8 @@ typedef struct sc2_policy {
     int32_t rans_ragged2;        /* four-lanes-per-stream decoder for per-symbol CDF rows (default 1) */
     int32_t rans_ragged2_waves;  /* ... waves per workgroup sharing one table copy: 0 (default) = 1 below 1 024 streams per launch, 2 from there; 1, 2, 4, 8 force */
     int32_t rans_lut8;           /* 1: one-lookup bucketed decode tables for implicit CDF rows (default 0: measured 6 % SLOWER than the two-lookup decoder) */
-    int32_t reserved[8];
+    int32_t rans_dq_lds;         /* 1: the dequantising last pass of a decode launch through LDS for every channel count (default 0: <= 32 channels transpose in registers, no LDS: fits beside the persistent kernels) */
+    int32_t reserved[7];
 } sc2_policy;
 void sc2_policy_default(sc2_policy *p);
 int sc2_policy_set(const sc2_policy *p);      /* SC2_ERR_INVALID_ARG if p is NULL or struct_bytes != sizeof(sc2_policy) */

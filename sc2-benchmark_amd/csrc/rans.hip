@@ -752,6 +752,48 @@ __global__ __launch_bounds__(256) void rans_dec_finish_dq_kernel(const RansArgs 
     }
 }
 
+// The same pass WITHOUT LDS (round 5), for channel counts of at most 32 (the FP bottleneck's 24): one wave = 64 streams x two pixels,
+// lane = stream.  A lane reads its stream's 2 C symbols of the pixel pair (for a fixed position the 64 lanes' words are 256
+// contiguous bytes of the intermediate: every load is coalesced, 2 C of them independent and in flight together) and writes them as
+// one contiguous run of 2 C bf16 (96 bytes at C = 24) of the NHWC latent.  Why: the form above needs 50 KB of LDS per workgroup, and
+// inside the pipelined bench the CUs' LDS is held by the persistent convolution kernels of the neighbouring steps (conv2x2_gdn512:
+// 152 KB): its 6 080 workgroups per coder launch trickled in behind them -- 3.3 ms per launch of 8 batches for 0.9 GB of traffic
+// (0.41 ms per step in `bottleneck_forward`), 0.03 ms per batch alone.  A kernel without LDS fits beside anything.
+template <int C>
+__global__ __launch_bounds__(256) void rans_dec_finish_dq_reg_kernel(const RansArgs a, const float *__restrict__ medians,
+                                                                     uint16_t *__restrict__ y_hat, int HW) {
+    static_assert(C % 8 == 0 && C <= 32, "8-channel groups, at most 32 channels");
+    const int blk = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int pix0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (pix0 >= HW) return;
+    const int s = blk * 64 + lane;
+    const bool two = pix0 + 1 < HW;
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(a.ws) + ((long long)blk * a.n_sym + pix0) * 64 + lane;   // + (c HW + p) * 64
+    int32_t v[2][C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        v[0][c] = (int32_t)w[(long long)c * HW * 64];
+        v[1][c] = two ? (int32_t)w[((long long)c * HW + 1) * 64] : 0;
+    }
+    if (s >= a.n_streams) return;
+    uint4 *out = reinterpret_cast<uint4 *>(y_hat + ((long long)s * HW + pix0) * C);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p == 1 && !two) break;
+#pragma unroll
+        for (int g = 0; g < C / 8; ++g) {
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = g * 8 + 2 * e;
+                o[e] = (uint32_t)f32_to_bf16_bits((float)v[p][c] + medians[c]) | ((uint32_t)f32_to_bf16_bits((float)v[p][c + 1] + medians[c + 1]) << 16);
+            }
+            out[p * (C / 8) + g] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // generic decoder: explicit per-symbol indexes (or rows too long for the LUT path); upper-bound binary search,
 // identical in result to upstream's linear find_if over the strictly increasing CDF row.
 template <bool LDS_TABLES>
@@ -1223,6 +1265,32 @@ void allow_big_lds(K kernel, size_t bytes) {
                                   (int)bytes);
 }
 
+// the dequantising last pass of a decode launch: the register form where it applies, else the LDS form
+int launch_finish_dq(const RansArgs &a, const float *medians, void *y_hat, int n_cdfs, int HW, int n_blocks, hipStream_t s,
+                            void *ev_dq_begin, void *ev_dq_end) {
+    if (ev_dq_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_begin), s);
+    const bool reg = (n_cdfs == 24 || n_cdfs == 16 || n_cdfs == 8 || n_cdfs == 32) && !sc2_pol().rans_dq_lds;   // (rans_dq_lds = 1: A/B)
+    if (reg) {
+        const dim3 grid((unsigned)((HW + 7) / 8), (unsigned)n_blocks);
+        uint16_t *y = static_cast<uint16_t *>(y_hat);
+        switch (n_cdfs) {
+            case 8: hipLaunchKernelGGL(rans_dec_finish_dq_reg_kernel<8>, grid, dim3(256), 0, s, a, medians, y, HW); break;
+            case 16: hipLaunchKernelGGL(rans_dec_finish_dq_reg_kernel<16>, grid, dim3(256), 0, s, a, medians, y, HW); break;
+            case 24: hipLaunchKernelGGL(rans_dec_finish_dq_reg_kernel<24>, grid, dim3(256), 0, s, a, medians, y, HW); break;
+            default: hipLaunchKernelGGL(rans_dec_finish_dq_reg_kernel<32>, grid, dim3(256), 0, s, a, medians, y, HW); break;
+        }
+    } else {
+        const size_t dq_lds = (size_t)64 * (kDqP * n_cdfs * 2 + 16);
+        allow_big_lds(rans_dec_finish_dq_kernel, dq_lds);
+        hipLaunchKernelGGL(rans_dec_finish_dq_kernel, dim3((HW + kDqP - 1) / kDqP, n_blocks), dim3(256), dq_lds, s, a, medians,
+                           static_cast<uint16_t *>(y_hat), n_cdfs, HW);
+    }
+    if (ev_dq_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_end), s);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
+
 }  // namespace
 
 extern "C" int64_t sc2_rans_max_bytes(int64_t n_sym) {
@@ -1350,14 +1418,7 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
             const long long gx = (n_sym + 63) / 64;
             SC2_REQUIRE(gx < (1ll << 31) && n_blocks <= 65535, SC2_ERR_UNSUPPORTED, "rans_decode: problem too large");
             if (y_hat) {
-                const int HW = (int)index_div;
-                const size_t dq_lds = (size_t)64 * (kDqP * n_cdfs * 2 + 16);
-                allow_big_lds(rans_dec_finish_dq_kernel, dq_lds);
-                if (ev_dq_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_begin), s);
-                hipLaunchKernelGGL(rans_dec_finish_dq_kernel, dim3((HW + kDqP - 1) / kDqP, n_blocks), dim3(256), dq_lds, s, a, medians,
-                                   static_cast<uint16_t *>(y_hat), n_cdfs, HW);
-                if (ev_dq_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_end), s);
-                SC2_CHECK_LAUNCH();
+                if (const int rc = launch_finish_dq(a, medians, y_hat, n_cdfs, (int)index_div, n_blocks, s, ev_dq_begin, ev_dq_end)) return rc;
             }
             if (symbols_out) {
                 hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
@@ -1381,14 +1442,7 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
             const long long gx = (n_sym + 63) / 64;
             SC2_REQUIRE(gx < (1ll << 31) && n_blocks <= 65535, SC2_ERR_UNSUPPORTED, "rans_decode: problem too large");
             if (y_hat) {
-                const int HW = (int)index_div;
-                const size_t dq_lds = (size_t)64 * (kDqP * n_cdfs * 2 + 16);
-                allow_big_lds(rans_dec_finish_dq_kernel, dq_lds);
-                if (ev_dq_begin) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_begin), s);
-                hipLaunchKernelGGL(rans_dec_finish_dq_kernel, dim3((HW + kDqP - 1) / kDqP, n_blocks), dim3(256), dq_lds, s, a, medians,
-                                   static_cast<uint16_t *>(y_hat), n_cdfs, HW);
-                if (ev_dq_end) (void)hipEventRecord(static_cast<hipEvent_t>(ev_dq_end), s);
-                SC2_CHECK_LAUNCH();
+                if (const int rc = launch_finish_dq(a, medians, y_hat, n_cdfs, (int)index_div, n_blocks, s, ev_dq_begin, ev_dq_end)) return rc;
             }
             if (symbols_out) {
                 hipLaunchKernelGGL(rans_dec_finish_kernel, dim3((unsigned)gx, n_blocks), dim3(256), 0, s, a);
