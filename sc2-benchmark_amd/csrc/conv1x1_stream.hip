@@ -65,6 +65,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
     constexpr int CPR = K / 8;                 // 16-byte chunks per A row
     constexpr int A_Q = BM * CPR / 512;        // A chunks per thread
     constexpr int IMG_Q = BM * CPI / 512;      // image chunks per thread
+    constexpr int ASW = CPR >= 16 ? 15 : CPR - 1;   // chunk XOR mask of the A tile (K = 64: eight chunks per row)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int next_slot;
     unsigned char *At = smem;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
         for (int k = 0; k < A_Q; ++k) {
             const int q = tid + 512 * k;
             const int row = q / CPR, c = q - row * CPR;
-            *reinterpret_cast<u32x4_t *>(At + row * (K * 2) + ((c ^ (row & 15)) << 4)) = a_next[k];
+            *reinterpret_cast<u32x4_t *>(At + row * (K * 2) + ((c ^ (row & ASW)) << 4)) = a_next[k];
         }
     };
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int a_lane = frow * (K * 2) + (((ks * 4 + fq) ^ frow) << 4);
+            const int a_lane = frow * (K * 2) + (((ks * 4 + fq) ^ (frow & ASW)) << 4);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const bf16x8_t af = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(At + a_lane + i * 16 * K * 2));
@@ -324,7 +325,7 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
 }  // namespace
 
 extern "C" int sc2_conv1x1_stream_supported(int Cin, int Cout, int stride) {
-    return (Cin == 128 || Cin == 256 || Cin == 512) && Cout >= 128 && Cout % 128 == 0 && (stride == 1 || stride == 2) ? 1 : 0;
+    return (Cin == 64 || Cin == 128 || Cin == 256 || Cin == 512) && Cout >= 128 && Cout % 128 == 0 && (stride == 1 || stride == 2) ? 1 : 0;
 }
 
 extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y,
@@ -332,7 +333,7 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
     SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv1x1_stream: null argument");
     SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv1x1_stream: non-positive dimension");
     SC2_REQUIRE(sc2_conv1x1_stream_supported(Cin, Cout, stride), SC2_ERR_UNSUPPORTED,
-                "conv1x1_stream: needs Cin in {128, 256, 512}, Cout %% 128 == 0, stride 1 or 2 (got %d -> %d, stride %d)", Cin,
+                "conv1x1_stream: needs Cin in {64, 128, 256, 512}, Cout %% 128 == 0, stride 1 or 2 (got %d -> %d, stride %d)", Cin,
                 Cout, stride);
     StreamArgs a;
     a.x = static_cast<const uint16_t *>(x);
@@ -354,6 +355,9 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
 #define SC2_STREAM_GO(KK, BMM, BNN) return a.res ? launch_stream<KK, BMM, BNN, true>(a, s) : launch_stream<KK, BMM, BNN, false>(a, s)
     if (Cin == 512 && Cout % 256 == 0) SC2_STREAM_GO(512, 64, 256);   // (half the A re-reads of the 128-wide unit)
     if (Cin == 512) SC2_STREAM_GO(512, 64, 128);
+    // K = 64: conv3 / downsample of layer1 (64 -> 256 at 56 x 56; only a frozen TEACHER runs them: the student's layer1 is the bottleneck)
+    if (Cin == 64 && Cout % 256 == 0) SC2_STREAM_GO(64, 128, 256);
+    if (Cin == 64) SC2_STREAM_GO(64, 128, 128);
     if (Cout % 256 == 0) {   // (64-pixel units, two workgroups per CU: measured the same for K = 128, 5 - 15 % slower for K = 256)
         if (Cin == 128) SC2_STREAM_GO(128, 128, 256);
         SC2_STREAM_GO(256, 128, 256);

@@ -417,7 +417,9 @@ def test_conv5s2_patch_kernel(S, R, dev, N, H, W, fused):
                                                            (512, 128, 1, 5, 17, 9, False, True),      # 64 x 128 units, K = 512
                                                            (512, 256, 2, 3, 15, 15, True, True),      # two 128-channel chunks
                                                            (256, 128, 1, 7, 12, 12, False, True),     # 128 x 128 units
-                                                           (128, 384, 1, 2, 10, 10, True, True)])     # Cout % 256 != 0
+                                                           (128, 384, 1, 2, 10, 10, True, True),      # Cout % 256 != 0
+                                                           (64, 256, 1, 5, 13, 9, True, True),        # K = 64 (layer1's conv3 / downsample)
+                                                           (64, 128, 1, 3, 9, 9, False, False)])
 def test_conv1x1_stream(S, dev, cin, cout, stride, N, H, W, res, relu):
     """Persistent streaming 1x1 conv (+ bias, residual, ReLU) against the f32 op on the bf16-rounded operands and
     against the generic tile kernel; several units per workgroup, ragged last pixel tile, stride-2 gather."""
@@ -432,7 +434,7 @@ def test_conv1x1_stream(S, dev, cin, cout, stride, N, H, W, res, relu):
     if relu:
         ref = F.relu(ref)
     assert S.hip.conv1x1_stream_supported(cin, cout, 1, 1, stride, 0)
-    assert not S.hip.conv1x1_stream_supported(64, cout, 1, 1, stride, 0)
+    assert not S.hip.conv1x1_stream_supported(32, cout, 1, 1, stride, 0)
     assert not S.hip.conv1x1_stream_supported(cin, cout, 3, 3, stride, 1)
     x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
     r_nhwc = S.hip.nchw_f32_to_nhwc_bf16(r.to(dev)) if res else None

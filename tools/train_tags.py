@@ -89,5 +89,5 @@ for t, (ms, n) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
 # the individual launches of the coarse tags, in issue order, for the last profiled step
 per = len(kt.records) // args.steps
 for tag, e0, e1 in kt.records[-per:]:
-    if tag in ('wgrad', 'dgrad', 'gdn.bwd.pre', 'gdn.bwd.post') or tag.startswith(('enc.', 'dec.')):
+    if tag in ('wgrad', 'dgrad', 'gdn.bwd.pre', 'gdn.bwd.post', 'stem') or tag.startswith(('enc.', 'dec.', 'layer1', 'gdn.rows')):
         print('    {:<20}{:8.3f}'.format(tag, e0.elapsed_time(e1)))
