@@ -86,14 +86,19 @@ class FrozenStack(object):
             self._dgrads = [tuple(None if c is None else _Dgrad(c, c.tag + '.dgrad') for c in blk) for blk in self.blocks]
         return self._dgrads
 
-    def backward(self, g_out, saved):
-        """gradient with respect to the stack's input, given the gradient at its output (bf16 NHWC, contiguous)."""
+    def backward(self, g_out, saved, mse=None):
+        """gradient with respect to the stack's input, given the gradient at its output (bf16 NHWC, contiguous; None: no gradient
+        but the MSE term's reaches it).  `mse` = (teacher features laid out like the output, f32 device scale): a feature-matching
+        MSE term on the stack's OUTPUT whose gradient 2 scale (out - t) is formed inside the first ReLU-gradient pass."""
         dgs = self._dg()
         g_a, g_b = g_out, None          # the two branches that meet at the current block's output
         for bi in range(len(self.blocks) - 1, -1, -1):
             h, o1, o2, out = saved[bi]
             d1, d2, d3, dds = dgs[bi]
-            g = hip.relu_bwd(g_a, out, add=g_b)
+            if mse is not None and bi == len(self.blocks) - 1:
+                g = hip.relu_bwd_mse(g_a, out, mse[0], mse[1])
+            else:
+                g = hip.relu_bwd(g_a, out, add=g_b)
             g2 = hip.relu_bwd(d3(g, o2.shape[1:3]), o2)
             g1 = hip.relu_bwd(d2(g2, o1.shape[1:3]), o1)
             g_c1 = d1(g1, h.shape[1:3])
@@ -119,14 +124,35 @@ class FrozenStackFn(torch.autograd.Function):
             x_nhwc = x_nhwc.contiguous()
         out, saved = stack.forward(x_nhwc, save=x.requires_grad)
         ctx.stack, ctx.saved = stack, saved
-        return out.permute(0, 3, 1, 2)
+        # MSE terms on this output hand their (target, scale) to this node instead of a gradient tensor (MseSumFn.backward; autograd
+        # runs every consumer's backward before the producer's): the sink travels on the output tensor
+        ctx.mse_sink = []
+        ctx.set_materialize_grads(False)       # no other gradient: None, not a zero-filled map
+        res = out.permute(0, 3, 1, 2)
+        res._sc2_mse_sink = ctx.mse_sink
+        return res
 
     @staticmethod
     def backward(ctx, gy):
-        g = gy.permute(0, 2, 3, 1)
-        if g.dtype != torch.bfloat16 or not g.is_contiguous():
-            g = g.to(torch.bfloat16).contiguous()
-        gx = ctx.stack.backward(g, ctx.saved)
+        sink, ctx.mse_sink = ctx.mse_sink, None
+        if gy is None and not sink:
+            ctx.saved = None
+            return None, None
+        g = None
+        if gy is not None:
+            g = gy.permute(0, 2, 3, 1)
+            if g.dtype != torch.bfloat16 or not g.is_contiguous():
+                g = g.to(torch.bfloat16).contiguous()
+        mse = None
+        out = ctx.saved[-1][3]
+        for y, scale in sink:            # (one term per output in the recipes; further ones as gradient tensors)
+            t = y.permute(0, 2, 3, 1)
+            if mse is None and hip._same_dense_bf16(out, t):
+                mse = (t, scale)
+            else:
+                extra = hip.mse_grad(out, t.contiguous(), scale)
+                g = extra if g is None else g + extra
+        gx = ctx.stack.backward(g, ctx.saved, mse=mse)
         ctx.saved = None
         return gx.permute(0, 3, 1, 2), None
 
@@ -136,16 +162,22 @@ class MseSumFn(torch.autograd.Function):
     one pass backward; y is a target (no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, y, mean):
+    def forward(ctx, x, y, mean, sink=None):
         ctx.save_for_backward(x, y)
         ctx.div = float(x.numel()) if mean else 1.0
+        ctx.sink = sink
         return hip.mse_sum(x, y) / ctx.div
 
     @staticmethod
     def backward(ctx, g):
         x, y = ctx.saved_tensors
         scale = (g.float() / ctx.div).reshape(1).contiguous()
-        return hip.mse_grad(x, y, scale), None, None
+        if ctx.sink is not None:
+            # x is the output of a frozen stack (FrozenStackFn): its backward forms 2 scale (x - y) inside its first ReLU-gradient pass
+            # (sc2_relu_bwd_mse_bf16) -- no gradient tensor, no add
+            ctx.sink.append((y, scale))
+            return None, None, None, None
+        return hip.mse_grad(x, y, scale), None, None, None
 
 
 def mse_fast_path(loss_module, x, y):
@@ -155,4 +187,5 @@ def mse_fast_path(loss_module, x, y):
         return None
     if not hip._same_dense_bf16(x, y) or y.requires_grad:
         return None
-    return MseSumFn.apply(x, y.detach(), loss_module.reduction == 'mean')
+    sink = getattr(x, '_sc2_mse_sink', None) if hip.host_policy.mse_fused and x.requires_grad else None
+    return MseSumFn.apply(x, y.detach(), loss_module.reduction == 'mean', sink)

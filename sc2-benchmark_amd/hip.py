@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch', 'sc2_rans_decode_dequantize_batch_ev',
-    'sc2_mse_partial_len', 'sc2_mse_sum_bf16', 'sc2_mse_grad_bf16', 'sc2_relu_bwd_bf16',
+    'sc2_mse_partial_len', 'sc2_mse_sum_bf16', 'sc2_mse_grad_bf16', 'sc2_relu_bwd_bf16', 'sc2_relu_bwd_mse_bf16',
     'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
 ]
 
@@ -88,6 +88,7 @@ class HostPolicy(object):
     gdn_rows = True            # 96- / 256- / 512-channel GDN1 in training: forward and the whole backward on the resident-row kernel (gdn512_rows.hip)
     gdn_bwd_fused = True       # GDN1 backward: element-wise halves in the epilogues of its two GEMMs (sc2_gdn1_bwd_gemm)
     dgrad_win_halves = True    # data gradient of dec.conv2 as two 256-channel launches of the window-plane 2x2 kernel
+    mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
 
@@ -235,6 +236,7 @@ def lib():
     L.sc2_mse_sum_bf16.argtypes = [vp, vp, ctypes.c_longlong, vp, vp]
     L.sc2_mse_grad_bf16.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, vp]
     L.sc2_relu_bwd_bf16.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
+    L.sc2_relu_bwd_mse_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, vp, vp]
     L.sc2_rans_host_tables_create.argtypes = [vp, i32, i32, vp, vp, ctypes.POINTER(vp)]
     L.sc2_rans_host_tables_destroy.argtypes = [vp]
     L.sc2_rans_host_tables_destroy.restype = None
@@ -1372,6 +1374,16 @@ def relu_bwd(g, out, add=None):
     gi = torch.empty_like(g)
     with _timed('relu_bwd'):
         _check(lib().sc2_relu_bwd_bf16(_ptr(g), _ptr(out), _ptr(add), g.numel(), _ptr(gi), _stream()), 'relu_bwd')
+    return gi
+
+
+def relu_bwd_mse(g, out, t, scale):
+    """([g] + 2 * scale * (out - t)) * (out > 0), bf16 like out; g may be None; scale: f32 device scalar tensor."""
+    ops = (out, t) if g is None else (g, out, t)
+    assert _same_dense_bf16(*ops) and scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1
+    gi = torch.empty_like(out)
+    with _timed('relu_bwd'):
+        _check(lib().sc2_relu_bwd_mse_bf16(_ptr(g), _ptr(out), _ptr(t), _ptr(scale), out.numel(), _ptr(gi), _stream()), 'relu_bwd_mse')
     return gi
 
 

@@ -189,3 +189,41 @@ def test_stage2_steps_kd_loss(S, dev):
     assert all(p.grad is None or float(p.grad.abs().sum()) == 0.0 for p in student.bottleneck_layer.encoder.parameters())
     assert len(stage._frozen_stacks) == 5          # the teacher's stem + layer1-4
     stage.clean_modules()
+
+@pytest.mark.parametrize('with_downstream', [True, False])
+def test_mse_term_inside_the_stack_backward(S, dev, with_downstream):
+    """A feature-matching MSE term on a frozen stack's output hands (target, scale) to the stack's autograd node instead of a gradient
+    tensor (frozen.MseSumFn -> FrozenStackFn: sc2_relu_bwd_mse_bf16): the input gradient equals the three-pass form's (mse_grad, add,
+    relu_bwd) up to the roundings it saves -- with and without another gradient reaching the same output."""
+    from sc2bench_amd.frozen import FrozenStack, FrozenStackFn, mse_fast_path
+    from sc2bench_amd.resnet import resnet50
+    torch.manual_seed(11)
+    layer = resnet50().layer3
+    _randomise_bn(layer)
+    layer.eval()
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    layer.to(dev)
+    stack = FrozenStack('layer3', layer)
+    x = torch.randn(2, 512, 28, 28)
+    t = (torch.randn(2, 1024, 14, 14) * 0.5).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(2, 1024, 14, 14).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    grads = {}
+    for fused in (True, False):
+        S.hip.configure(mse_fused=fused)
+        try:
+            xd = x.to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            out = FrozenStackFn.apply(xd, stack)
+            loss = 0.37 * mse_fast_path(torch.nn.MSELoss(reduction='sum'), out, t)
+            assert loss is not None
+            if with_downstream:
+                loss = loss + (out.float() * w.float()).sum()
+            loss.backward()
+            grads[fused] = xd.grad.float()
+        finally:
+            S.hip.configure(mse_fused=True)
+    scale = grads[False].abs().max().item()
+    assert scale > 0
+    err = (grads[True] - grads[False]).abs().max().item()
+    assert err <= 3e-2 * scale, (err, scale)
+    assert _rel(grads[True], grads[False].cpu()) < 1e-2
