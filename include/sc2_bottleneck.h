@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 40
+#define SC2_ABI_VERSION 41
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -583,8 +583,9 @@ int sc2_relu_bwd_bf16(const void *g, const void *out, const void *add, long long
 /* ... with the feature-matching MSE term that sits on the same tensor folded in: g_in = ([g] + 2 * scale[0] * (out - t)) * (out > 0),
  * g may be NULL (no other gradient reaches the tensor).  `out` = the student's stack output the criterion compares with the teacher's
  * `t` (yaml:155-200: MSELoss(reduction='sum') per layer), scale = loss weight x upstream gradient [/ numel for 'mean'] as an f32 device
- * scalar.  Replaces sc2_mse_grad_bf16 + the add + sc2_relu_bwd_bf16 at the output of a frozen stack. */
-int sc2_relu_bwd_mse_bf16(const void *g, const void *out, const void *t, const float *scale, long long n, void *gi, void *stream);
+ * scalar; relu = 0: no activation behind the tensor (the bottleneck's own output: [g] + 2 scale (out - t)).  Replaces sc2_mse_grad_bf16 +
+ * the add + sc2_relu_bwd_bf16 at the output of a frozen stack. */
+int sc2_relu_bwd_mse_bf16(const void *g, const void *out, const void *t, const float *scale, long long n, int relu, void *gi, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 /* HOST range coder (same bit-exact format; every pointer is HOST memory, no HIP call is made).  */

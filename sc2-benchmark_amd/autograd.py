@@ -51,14 +51,26 @@ class _ConvFn(torch.autograd.Function):
                                k_order=k_order)
         ctx.save_for_backward(x_nhwc, weight)
         ctx.cfg = (stride, pad, out_format, w_view)
+        # a feature-matching MSE term on this output may hand (its operands, scale) over instead of a gradient tensor
+        # (frozen.MseSumFn.backward): the sink travels on the output (and on the channels_last view synthesis_autograd returns)
+        ctx.mse_sink = []
+        if out_format == hip.OUT_BF16_NHWC:
+            y._sc2_mse_sink = ctx.mse_sink
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x_nhwc, weight = ctx.saved_tensors
         stride, pad, out_format, w_view = ctx.cfg
+        sink, ctx.mse_sink = ctx.mse_sink, None
         if out_format == hip.OUT_BF16_NHWC:
             g = gy.contiguous()
+            for xs, ts, scale in sink:           # 2 scale (y - t) added in one pass (no gradient tensor, no separate add)
+                ys, tt = xs.permute(0, 2, 3, 1), ts.permute(0, 2, 3, 1)
+                if hip._same_dense_bf16(g, ys, tt):
+                    g = hip.relu_bwd_mse(g, ys, tt, scale, relu=False)
+                else:
+                    g = g + hip.mse_grad(xs, ts, scale).permute(0, 2, 3, 1)
         elif out_format == hip.OUT_F32_NCHW:
             g = hip.nchw_f32_to_nhwc_bf16(gy.float().contiguous())
         else:
@@ -209,7 +221,13 @@ def synthesis_autograd(m, y_hat):
     h = _conv(c2, h)
     h = _gdn(g3, h)
     if getattr(m, 'output_format', 'f32_nchw') == 'bf16_nhwc':     # a bf16 channels_last view for a bf16 tail / loss
-        return _cl(_conv(c4, h, hip.OUT_BF16_NHWC))
+        y = _conv(c4, h, hip.OUT_BF16_NHWC)
+        res = _cl(y)
+        sink = getattr(y, '_sc2_mse_sink', None)
+        if sink is not None:
+            res._sc2_mse_sink = sink           # (entries for THIS producer carry the MSE's own operands: MseSumFn appends (x, y, scale))
+            res._sc2_mse_sink_wants_x = True
+        return res
     return _conv(c4, h, hip.OUT_F32_NCHW)
 
 

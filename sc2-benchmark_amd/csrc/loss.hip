@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const uint4 *__restrict__
 // stack output that the feature-matching loss compares with the teacher's t, so the loss gradient needs no operand of its own: the
 // three passes mse_grad (x, y -> g_mse), add (g, g_mse -> sum), relu_bwd (sum, out -> g_in) = nine tensor reads / writes become four.
 // One rounding instead of three.
+template <bool RELU>   // false: no activation behind the tensor (the bottleneck's own output): g_in = [g] + 2 scale (out - t)
 __global__ __launch_bounds__(256) void relu_bwd_mse_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ out,
                                                            const uint4 *__restrict__ t, const float *__restrict__ scale, long long n8,
                                                            uint4 *__restrict__ gi) {
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(256) void relu_bwd_mse_kernel(const uint4 *__restri
         uint32_t o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            o[k] = pack_bf16x2(lo(mw[k]) > 0.f ? lo(aw[k]) + s * (lo(mw[k]) - lo(bw[k])) : 0.f,
-                               hi(mw[k]) > 0.f ? hi(aw[k]) + s * (hi(mw[k]) - hi(bw[k])) : 0.f);
+            o[k] = pack_bf16x2((!RELU || lo(mw[k]) > 0.f) ? lo(aw[k]) + s * (lo(mw[k]) - lo(bw[k])) : 0.f,
+                               (!RELU || hi(mw[k]) > 0.f) ? hi(aw[k]) + s * (hi(mw[k]) - hi(bw[k])) : 0.f);
         gi[i] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -127,12 +128,18 @@ extern "C" int sc2_relu_bwd_bf16(const void *g, const void *out, const void *add
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
-extern "C" int sc2_relu_bwd_mse_bf16(const void *g, const void *out, const void *t, const float *scale, long long n, void *gi, void *stream) {
+extern "C" int sc2_relu_bwd_mse_bf16(const void *g, const void *out, const void *t, const float *scale, long long n, int relu, void *gi,
+                                     void *stream) {
     SC2_REQUIRE(out && t && scale && gi, SC2_ERR_INVALID_ARG, "relu_bwd_mse: null argument");
     SC2_REQUIRE(n > 0 && n % 8 == 0, SC2_ERR_INVALID_ARG, "relu_bwd_mse: element count %lld must be a positive multiple of 8", n);
-    hipLaunchKernelGGL(relu_bwd_mse_kernel, dim3(grid_for(n / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const uint4 *>(g), static_cast<const uint4 *>(out), static_cast<const uint4 *>(t), scale, n / 8,
-                       static_cast<uint4 *>(gi));
+    if (relu)
+        hipLaunchKernelGGL(relu_bwd_mse_kernel<true>, dim3(grid_for(n / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint4 *>(g), static_cast<const uint4 *>(out), static_cast<const uint4 *>(t), scale, n / 8,
+                           static_cast<uint4 *>(gi));
+    else
+        hipLaunchKernelGGL(relu_bwd_mse_kernel<false>, dim3(grid_for(n / 8)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const uint4 *>(g), static_cast<const uint4 *>(out), static_cast<const uint4 *>(t), scale, n / 8,
+                           static_cast<uint4 *>(gi));
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }

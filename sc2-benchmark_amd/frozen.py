@@ -162,10 +162,10 @@ class MseSumFn(torch.autograd.Function):
     one pass backward; y is a target (no gradient)."""
 
     @staticmethod
-    def forward(ctx, x, y, mean, sink=None):
+    def forward(ctx, x, y, mean, sink=None, wants_x=False):
         ctx.save_for_backward(x, y)
         ctx.div = float(x.numel()) if mean else 1.0
-        ctx.sink = sink
+        ctx.sink, ctx.wants_x = sink, wants_x
         return hip.mse_sum(x, y) / ctx.div
 
     @staticmethod
@@ -175,9 +175,9 @@ class MseSumFn(torch.autograd.Function):
         if ctx.sink is not None:
             # x is the output of a frozen stack (FrozenStackFn): its backward forms 2 scale (x - y) inside its first ReLU-gradient pass
             # (sc2_relu_bwd_mse_bf16) -- no gradient tensor, no add
-            ctx.sink.append((y, scale))
-            return None, None, None, None
-        return hip.mse_grad(x, y, scale), None, None, None
+            ctx.sink.append((x, y, scale) if ctx.wants_x else (y, scale))      # (a conv node does not keep its output: it gets x too)
+            return None, None, None, None, None
+        return hip.mse_grad(x, y, scale), None, None, None, None
 
 
 def mse_fast_path(loss_module, x, y):
@@ -188,4 +188,4 @@ def mse_fast_path(loss_module, x, y):
     if not hip._same_dense_bf16(x, y) or y.requires_grad:
         return None
     sink = getattr(x, '_sc2_mse_sink', None) if hip.host_policy.mse_fused and x.requires_grad else None
-    return MseSumFn.apply(x, y.detach(), loss_module.reduction == 'mean', sink)
+    return MseSumFn.apply(x, y.detach(), loss_module.reduction == 'mean', sink, bool(getattr(x, '_sc2_mse_sink_wants_x', False)))

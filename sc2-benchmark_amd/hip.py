@@ -236,7 +236,7 @@ def lib():
     L.sc2_mse_sum_bf16.argtypes = [vp, vp, ctypes.c_longlong, vp, vp]
     L.sc2_mse_grad_bf16.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, vp]
     L.sc2_relu_bwd_bf16.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
-    L.sc2_relu_bwd_mse_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, vp, vp]
+    L.sc2_relu_bwd_mse_bf16.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, i32, vp, vp]
     L.sc2_rans_host_tables_create.argtypes = [vp, i32, i32, vp, vp, ctypes.POINTER(vp)]
     L.sc2_rans_host_tables_destroy.argtypes = [vp]
     L.sc2_rans_host_tables_destroy.restype = None
@@ -1377,13 +1377,14 @@ def relu_bwd(g, out, add=None):
     return gi
 
 
-def relu_bwd_mse(g, out, t, scale):
-    """([g] + 2 * scale * (out - t)) * (out > 0), bf16 like out; g may be None; scale: f32 device scalar tensor."""
+def relu_bwd_mse(g, out, t, scale, relu=True):
+    """([g] + 2 * scale * (out - t)) [* (out > 0)], bf16 like out; g may be None; scale: f32 device scalar tensor."""
     ops = (out, t) if g is None else (g, out, t)
     assert _same_dense_bf16(*ops) and scale.is_cuda and scale.dtype == torch.float32 and scale.numel() == 1
     gi = torch.empty_like(out)
     with _timed('relu_bwd'):
-        _check(lib().sc2_relu_bwd_mse_bf16(_ptr(g), _ptr(out), _ptr(t), _ptr(scale), out.numel(), _ptr(gi), _stream()), 'relu_bwd_mse')
+        _check(lib().sc2_relu_bwd_mse_bf16(_ptr(g), _ptr(out), _ptr(t), _ptr(scale), out.numel(), 1 if relu else 0, _ptr(gi), _stream()),
+               'relu_bwd_mse')
     return gi
 
 

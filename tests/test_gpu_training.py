@@ -151,3 +151,34 @@ def test_stage1_training_steps_reduce_the_loss(S, dev):
     stage.clean_modules()
     assert losses[-1] < losses[0], losses
     assert float(student.bottleneck_layer.encoder[0].weight.grad.abs().sum()) == 0.0   # zeroed after the step
+
+
+def test_mse_term_on_the_bottleneck_output_inside_the_conv_backward(S, dev):
+    """The layer-1 feature-matching MSE term sits on the decoder's last conv output: with `host_policy.mse_fused` it hands (its operands,
+    scale) to that conv's autograd node, which adds 2 scale (y - t) to the incoming gradient in one pass (sc2_relu_bwd_mse_bf16, relu =
+    0) -- the parameter gradients equal the gradient-tensor form's up to the roundings it saves."""
+    from sc2bench_amd.frozen import mse_fast_path
+    torch.manual_seed(5)
+    x = torch.rand(4, 3, 64, 64, device=dev)
+    grads = {}
+    for fused in (True, False):
+        torch.manual_seed(7)
+        m = S.FPBasedResNetBottleneck().to(dev).train()
+        m.output_format = 'bf16_nhwc'
+        S.hip.configure(mse_fused=fused)
+        try:
+            torch.manual_seed(9)                      # the same noise draw in both runs
+            out = m(x)
+            assert out.dtype == torch.bfloat16 and (hasattr(out, '_sc2_mse_sink') or not fused)
+            torch.manual_seed(13)
+            t = (torch.randn(out.shape, device=dev) * 0.3).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            w = torch.randn(out.shape, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            loss = 0.41 * mse_fast_path(torch.nn.MSELoss(reduction='sum'), out, t) + (out.float() * w.float()).sum()
+            loss.backward()
+            grads[fused] = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            S.hip.configure(mse_fused=True)
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) >= 10
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert ((a - b).norm() / (b.norm() + 1e-12)).item() < 2e-2, n
