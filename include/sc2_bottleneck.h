@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 41
+#define SC2_ABI_VERSION 42
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -340,8 +340,8 @@ int sc2_conv2x2_c48_fwd(const void *x, const void *w_frag, const float *medians,
  *   w_frag : bf16 [Cin/32][Cout/16][64][8] (BN folded), the k-step stream of sc2_conv3x3_win_fwd for a 1 x 1 kernel (same row
  *            permutation);   bias : f32 [Cout];   residual : bf16 [N,OH,OW,Cout] or NULL (added before the ReLU);   relu != 0: ReLU. */
 int sc2_conv1x1_win_supported(int Cin, int Cout, int stride);
-int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y, int N, int H, int W,
-                        int Cin, int Cout, int stride, int relu, void *stream);
+int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, const void *mask, void *y, int N,
+                        int H, int W, int Cin, int Cout, int stride, int relu, void *stream);
 
 /* 3x3 stride-1 pad-1 convolution + bias (+ ReLU) on 28 x 28 / 14 x 14 / 7 x 7 maps: conv2 + bn2 + ReLU of the torchvision
  * Bottleneck blocks of layer2 / layer3 / layer4 behind the bottleneck (sc2bench/models/backbone.py:235-254 runs them) at the
@@ -352,8 +352,8 @@ int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const float *bias, co
  *            frow, e) = W[32 g + 8 (frow / 4) + 4 j + frow % 4][slab*32 + fq*8 + e][kh][kw]   (the row permutation leaves
  *            every lane with eight consecutive output channels of a pixel);   bias : f32 [Cout];   relu != 0: ReLU. */
 int sc2_conv3x3_win_supported(int H, int W, int Cin, int Cout);
-int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin, int Cout,
-                        int relu, void *stream);
+int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, const void *mask, void *y, int N, int H, int W, int Cin,
+                        int Cout, int relu, void *stream);
 
 /* The stride-2 form of the same kernel: conv2 + bn2 + ReLU of layer2.0 / layer3.0 / layer4.0 (3x3, stride 2, pad 1; torchvision
  * puts the stride on conv2), 56 -> 28, 28 -> 14, 14 -> 7 at the 224 x 224 operating point (sc2bench/models/backbone.py:235-254).

@@ -103,6 +103,7 @@ struct P1Args {
     const uint16_t *__restrict__ w;      // bf16 [Cin/32][Cout/16][64][8]  (hip.pack_conv_win of the [Cout, Cin, 1, 1] weight)
     const float *__restrict__ bias;      // f32 [Cout]
     const uint16_t *__restrict__ res;    // bf16 [M, Cout] or null
+    const uint16_t *__restrict__ mask;   // bf16 [M, Cout] or null: y = mask > 0 ? acc + bias [+ res] : 0 (gradient through a ReLU whose OUTPUT is `mask`)
     uint16_t *__restrict__ y;            // bf16 [M, Cout], M = N * OH * OW
     int N, H, W, OH, OW, stride, Cin, Cout, relu;
     int n_chunks;                        // Cout / 128
@@ -303,8 +304,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
     // of range returns zeros) -- as per-row-tile `if`s the epilogue of a 3 - 6 us workgroup held ~75 scalar branches.
     const buf_rsrc_t rs_y = make_rsrc(p.y, p.y_bytes);
     const buf_rsrc_t rs_r = make_rsrc(p.res ? p.res : p.y, p.res ? p.y_bytes : 0u);
-    auto finish = [&](auto relu_c, auto res_c) {
-        constexpr bool RELU = decltype(relu_c)::value, HAS_RES = decltype(res_c)::value;
+    const buf_rsrc_t rs_m = make_rsrc(p.mask ? p.mask : p.y, p.mask ? p.y_bytes : 0u);
+    auto finish = [&](auto relu_c, auto res_c, auto mask_c) {
+        constexpr bool RELU = decltype(relu_c)::value, HAS_RES = decltype(res_c)::value, MASK = decltype(mask_c)::value;
         uint4 rv[MT];
         if (HAS_RES) {
 #pragma unroll
@@ -326,16 +328,28 @@ __global__ __launch_bounds__(256, NBUF == 2 ? (T::MT == 7 ? 3 : 2) : 1) void con
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+            if (MASK) {   // (round 5: the ReLU-gradient pass over this tensor folded in; loaded per row tile behind the arithmetic)
+                const uint4 mq = buf_load16(rs_m, m < p.M ? (uint32_t)((m * Cout + n0 + 8 * fq) * 2) : 0x80000000u, 0u);
+                const uint32_t mw[4] = {mq.x, mq.y, mq.z, mq.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = bf_lo(mw[e]) > 0.f ? v[2 * e] : 0.f;
+                    v[2 * e + 1] = bf_hi(mw[e]) > 0.f ? v[2 * e + 1] : 0.f;
+                }
+            }
             const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
             buf_store16_z(rs_y, m < p.M ? (uint32_t)((m * Cout + n0 + 8 * fq) * 2) : 0x80000000u, o);
         }
     };
-    if (p.res != nullptr) {
-        if (p.relu != 0) finish(std::true_type{}, std::true_type{});
-        else finish(std::false_type{}, std::true_type{});
+    if (p.mask != nullptr) {
+        if (p.res != nullptr) finish(std::false_type{}, std::true_type{}, std::true_type{});
+        else finish(std::false_type{}, std::false_type{}, std::true_type{});
+    } else if (p.res != nullptr) {
+        if (p.relu != 0) finish(std::true_type{}, std::true_type{}, std::false_type{});
+        else finish(std::false_type{}, std::true_type{}, std::false_type{});
     } else {
-        if (p.relu != 0) finish(std::true_type{}, std::false_type{});
-        else finish(std::false_type{}, std::false_type{});
+        if (p.relu != 0) finish(std::true_type{}, std::false_type{}, std::false_type{});
+        else finish(std::false_type{}, std::false_type{}, std::false_type{});
     }
 }
 
@@ -362,9 +376,10 @@ extern "C" int sc2_conv1x1_win_supported(int Cin, int Cout, int stride) {
     return (stride == 1 || stride == 2) && Cin >= 128 && Cin % 128 == 0 && Cout >= 128 && Cout % 128 == 0 ? 1 : 0;
 }
 
-extern "C" int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y, int N, int H,
-                                   int W, int Cin, int Cout, int stride, int relu, void *stream) {
+extern "C" int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, const void *mask, void *y,
+                                   int N, int H, int W, int Cin, int Cout, int stride, int relu, void *stream) {
     SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv1x1_win: null argument");
+    SC2_REQUIRE(!(mask && relu), SC2_ERR_INVALID_ARG, "conv1x1_win: mask and relu are exclusive");
     SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv1x1_win: non-positive shape");
     SC2_REQUIRE(sc2_conv1x1_win_supported(Cin, Cout, stride), SC2_ERR_UNSUPPORTED,
                 "conv1x1_win: needs Cin %% 128 == 0, Cout %% 128 == 0, stride 1 or 2 (got %d -> %d, stride %d)", Cin, Cout, stride);
@@ -378,6 +393,7 @@ extern "C" int sc2_conv1x1_win_fwd(const void *x, const void *w_frag, const floa
     a.w = static_cast<const uint16_t *>(w_frag);
     a.bias = bias;
     a.res = static_cast<const uint16_t *>(residual);
+    a.mask = static_cast<const uint16_t *>(mask);
     a.y = static_cast<uint16_t *>(y);
     a.N = N; a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.stride = stride; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
     a.n_chunks = Cout / 128;

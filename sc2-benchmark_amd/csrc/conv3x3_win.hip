@@ -106,6 +106,7 @@ struct WinArgs {
     const uint16_t *__restrict__ w;      // bf16 [Cin/32 * 9][Cout/16][64][8]  (sc2_conv3x3_win_fwd's packing)
     const float *__restrict__ bias;      // f32 [Cout]
     uint16_t *__restrict__ y;            // bf16 NHWC [N, H, W, Cout]
+    const uint16_t *__restrict__ mask;   // bf16 like y or null: y = mask > 0 ? acc + bias : 0 (the gradient through a ReLU whose OUTPUT is `mask`)
     int N, Cin, Cout, relu;
     int n_chunks;                        // Cout / 128
     int n_mtiles;
@@ -195,7 +196,9 @@ __device__ __forceinline__ void k_step(f32x4_t (&acc)[G::MT][2], const uint32_t 
 }
 
 // DBG (timing experiments, results garbage): 1 no window refills, 2 no weight fetches in the loop, 4 no fragment reads, 8 no barriers
-template <class G, int DBG = 0>
+// MASK_: the epilogue's ReLU-gradient form (y = mask > 0 ? value : 0) is an instantiation of its own -- as a runtime case it cost the
+// half-tile kernels of the inference head ten registers (128 -> 138: one workgroup per CU less)
+template <class G, int DBG = 0, bool MASK_ = false>
 __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(const WinArgs p) {
     constexpr int MT = G::MT, W = G::W, H = G::H;
     constexpr uint32_t OOB = 0x80000000u;
@@ -325,8 +328,20 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(co
     // row tile) and masked lanes store out of range through a descriptor instead of jumping around the store -- a workgroup
     // lives for 3 - 6 us, and its ~60 branches were a measurable part of that.
     const buf_rsrc_t rs_y = make_rsrc(p.y, p.y_bytes);
-    auto finish = [&](auto relu_c) {
-        constexpr bool RELU = decltype(relu_c)::value;
+    [[maybe_unused]] const buf_rsrc_t rs_m = make_rsrc(MASK_ ? p.mask : p.y, MASK_ ? p.y_bytes : 0u);
+    // MASK (round 5): the layer is the data gradient of a conv whose INPUT was a fused ReLU's output: y = mask > 0 ? value : 0 -- the
+    // separate ReLU-gradient pass over this tensor (read, read, write) becomes one extra 16-byte load per row tile here
+    auto finish = [&](auto relu_c, auto mask_c) {
+        constexpr bool RELU = decltype(relu_c)::value, MASK = decltype(mask_c)::value;
+        uint4 mv[MT];
+        if (MASK) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int ml = i * 16 + frow;
+                const long long m = m_base + ml;
+                mv[i] = buf_load16(rs_m, ((ml < G::PX) & (m < M)) ? (uint32_t)((m * Cout + n0 + 8 * fq) * 2) : 0x80000000u, 0u);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int ml = i * 16 + frow;
@@ -337,17 +352,26 @@ __global__ __launch_bounds__(256, G::MT == 7 ? 3 : 2) void conv3x3_win_kernel(co
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+            if (MASK) {
+                const uint32_t mw[4] = {mv[i].x, mv[i].y, mv[i].z, mv[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = __builtin_bit_cast(float, mw[e] << 16) > 0.f ? v[2 * e] : 0.f;
+                    v[2 * e + 1] = __builtin_bit_cast(float, mw[e] & 0xFFFF0000u) > 0.f ? v[2 * e + 1] : 0.f;
+                }
+            }
             const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
             const bool ok = (ml < G::PX) & (m < M);
             buf_store16_z(rs_y, ok ? (uint32_t)((m * Cout + n0 + 8 * fq) * 2) : 0x80000000u, o);
         }
     };
-    if (p.relu != 0) finish(std::true_type{});
-    else finish(std::false_type{});
+    if constexpr (MASK_) finish(std::false_type{}, std::true_type{});
+    else if (p.relu != 0) finish(std::true_type{}, std::false_type{});
+    else finish(std::false_type{}, std::false_type{});
     if (p.stamps && tid == 0) p.stamps[2 * blockIdx.x + 1] = wall_clock64();
 }
 
-template <class G, int DBG = 0>
+template <class G, int DBG = 0, bool MASK_ = false>
 int launch_win(WinArgs a, hipStream_t s) {
     constexpr int HW = G::H * G::W;
     a.n_mtiles = G::IMGS > 1 ? (a.N + G::IMGS - 1) / G::IMGS : a.N * G::TILES_PER_IMG;
@@ -355,7 +379,7 @@ int launch_win(WinArgs a, hipStream_t s) {
     static bool attr_set_dev[SC2_MAX_DEVICES] = {};
     bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_win_kernel<G, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_win_kernel<G, DBG, MASK_>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   G::LDS_BYTES);
         attr_set = true;
     }
@@ -364,7 +388,7 @@ int launch_win(WinArgs a, hipStream_t s) {
         unsigned long long *d = nullptr;
         if (hipMalloc(reinterpret_cast<void **>(&d), (size_t)n_wg * 16) != hipSuccess) return SC2_ERR_INTERNAL;
         a.stamps = d;
-        hipLaunchKernelGGL((conv3x3_win_kernel<G, DBG>), dim3(n_wg), dim3(256), G::LDS_BYTES, s, a);
+        hipLaunchKernelGGL((conv3x3_win_kernel<G, DBG, MASK_>), dim3(n_wg), dim3(256), G::LDS_BYTES, s, a);
         (void)hipStreamSynchronize(s);
         unsigned long long *h = static_cast<unsigned long long *>(malloc((size_t)n_wg * 16));
         (void)hipMemcpy(h, d, (size_t)n_wg * 16, hipMemcpyDeviceToHost);
@@ -382,7 +406,7 @@ int launch_win(WinArgs a, hipStream_t s) {
         SC2_CHECK_LAUNCH();
         return SC2_OK;
     }
-    hipLaunchKernelGGL((conv3x3_win_kernel<G, DBG>), dim3(n_wg), dim3(256), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv3x3_win_kernel<G, DBG, MASK_>), dim3(n_wg), dim3(256), G::LDS_BYTES, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -572,6 +596,7 @@ extern "C" int sc2_conv3x3s2_win_fwd(const void *x, const void *w_frag, const fl
     a.w = static_cast<const uint16_t *>(w_frag);
     a.bias = bias;
     a.y = static_cast<uint16_t *>(y);
+    a.mask = nullptr;
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
     a.n_chunks = Cout / 128; a.n_mtiles = 0;
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
@@ -593,9 +618,10 @@ extern "C" int sc2_conv3x3_win_supported(int H, int W, int Cin, int Cout) {
     return Cin >= 64 && Cin % 64 == 0 && Cout >= 128 && Cout % 128 == 0 ? 1 : 0;
 }
 
-extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, void *y, int N, int H, int W, int Cin,
-                                   int Cout, int relu, void *stream) {
+extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const float *bias, const void *mask, void *y, int N, int H, int W,
+                                   int Cin, int Cout, int relu, void *stream) {
     SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv3x3_win: null argument");
+    SC2_REQUIRE(!(mask && relu), SC2_ERR_INVALID_ARG, "conv3x3_win: mask and relu are exclusive");
     SC2_REQUIRE(N > 0, SC2_ERR_INVALID_ARG, "conv3x3_win: non-positive batch");
     SC2_REQUIRE(sc2_conv3x3_win_supported(H, W, Cin, Cout), SC2_ERR_UNSUPPORTED,
                 "conv3x3_win: needs a 28 x 28, 14 x 14 or 7 x 7 map, Cin %% 64 == 0, Cout %% 128 == 0 (got %d x %d, %d -> %d)", H, W, Cin,
@@ -609,12 +635,23 @@ extern "C" int sc2_conv3x3_win_fwd(const void *x, const void *w_frag, const floa
     a.w = static_cast<const uint16_t *>(w_frag);
     a.bias = bias;
     a.y = static_cast<uint16_t *>(y);
+    a.mask = static_cast<const uint16_t *>(mask);
     a.N = N; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0;
     a.n_chunks = Cout / 128; a.n_mtiles = 0;
     a.x_bytes = (unsigned)x_bytes; a.w_bytes = (unsigned)w_bytes; a.y_bytes = (unsigned)y_bytes;
     a.stamps = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int half = sc2_pol().win_half;
+    if (a.mask) {   // the ReLU-gradient epilogue (training: data gradient of a frozen block's conv2)
+        if (half) {
+            if (W == 28) return launch_win<H28, 0, true>(a, s);
+            if (W == 14) return launch_win<H14, 0, true>(a, s);
+            return launch_win<H7, 0, true>(a, s);
+        }
+        if (W == 28) return launch_win<G28, 0, true>(a, s);
+        if (W == 14) return launch_win<G14, 0, true>(a, s);
+        return launch_win<G7, 0, true>(a, s);
+    }
     if (half) {
         if (W == 28) return launch_win<H28>(a, s);
         if (W == 14) return launch_win<H14>(a, s);

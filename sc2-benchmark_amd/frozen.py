@@ -41,10 +41,12 @@ class _Dgrad(object):
     def dense(self, g):
         return self.as_dense(g, hip.EPI_BIAS)
 
-    def __call__(self, g, in_hw):
+    def __call__(self, g, in_hw, mask=None):
+        """mask: the saved output of the ReLU in front of this layer's input -- the result is the gradient IN FRONT of that ReLU."""
         if self.as_conv is not None:
-            return self.as_conv(g, hip.EPI_BIAS)
-        return hip.conv2d_dgrad(g, self.w_folded, self.stride, self.pad, in_hw, cache=self._packed)
+            return self.as_conv(g, hip.EPI_BIAS, ep_mask=mask)
+        gx = hip.conv2d_dgrad(g, self.w_folded, self.stride, self.pad, in_hw, cache=self._packed)
+        return gx if mask is None else hip.relu_bwd(gx, mask)
 
 
 class FrozenStack(object):
@@ -99,8 +101,8 @@ class FrozenStack(object):
                 g = hip.relu_bwd_mse(g_a, out, mse[0], mse[1])
             else:
                 g = hip.relu_bwd(g_a, out, add=g_b)
-            g2 = hip.relu_bwd(d3(g, o2.shape[1:3]), o2)
-            g1 = hip.relu_bwd(d2(g2, o1.shape[1:3]), o1)
+            g2 = d3(g, o2.shape[1:3], mask=o2)       # (the ReLU gradients ride in the data-gradient launches' epilogues where
+            g1 = d2(g2, o1.shape[1:3], mask=o1)      #  the layer runs on a window-plane kernel: head._Conv, ep_mask)
             g_c1 = d1(g1, h.shape[1:3])
             if dds is not None and dds.as_dense is not None:
                 # (was: scatter into a zero-filled map, then a full-size add -- three fills and 1.2 GB of traffic per block)

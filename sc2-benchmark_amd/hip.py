@@ -88,6 +88,7 @@ class HostPolicy(object):
     gdn_rows = True            # 96- / 256- / 512-channel GDN1 in training: forward and the whole backward on the resident-row kernel (gdn512_rows.hip)
     gdn_bwd_fused = True       # GDN1 backward: element-wise halves in the epilogues of its two GEMMs (sc2_gdn1_bwd_gemm)
     dgrad_win_halves = True    # data gradient of dec.conv2 as two 256-channel launches of the window-plane 2x2 kernel
+    relu_mask_fused = True     # the ReLU gradient behind a frozen block's conv2 / conv3 data gradient inside that launch's epilogue (window-plane kernels)
     mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
@@ -189,12 +190,12 @@ def lib():
     L.sc2_conv1x1_kres_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3_win_supported.argtypes = [i32, i32, i32, i32]
-    L.sc2_conv3x3_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv3x3_win_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3s2_win_supported.argtypes = [i32, i32, i32, i32]
     L.sc2_conv1x1_win_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2x2_c48_supported.argtypes = [i32, i32, i32, i32]
     L.sc2_conv2x2_c48_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
-    L.sc2_conv1x1_win_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv1x1_win_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv3x3s2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     L.sc2_conv2x2_win_supported.argtypes = [i32, i32, i32, i32, i32]
     L.sc2_conv2x2_win_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -981,8 +982,9 @@ def conv2x2_win_fwd(x_nhwc, w_frag, pad, beta=None, inverse=True, tag=None, out=
     return out
 
 
-def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None, stride=1):
-    """y = act(conv3x3(x, stride 1 or 2, pad 1) + bias); bf16 NHWC in / out; w_frag = pack_conv3x3_win(w)."""
+def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None, stride=1, mask=None):
+    """y = act(conv3x3(x, stride 1 or 2, pad 1) + bias); bf16 NHWC in / out; w_frag = pack_conv3x3_win(w).
+    mask (stride 1, bf16 like y, no relu): y = mask > 0 ? conv + bias : 0 -- the gradient through a ReLU whose output is `mask`."""
     for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
         _dev(t, name)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
@@ -999,8 +1001,11 @@ def conv3x3_win_fwd(x_nhwc, w_frag, bias, relu=False, tag=None, stride=1):
         return out
     assert stride == 1
     out = torch.empty((N, H, W, cout), dtype=torch.bfloat16, device=x_nhwc.device)
+    if mask is not None:
+        _dev(mask, 'mask')
+        assert not relu and mask.dtype == torch.bfloat16 and mask.is_contiguous() and tuple(mask.shape) == tuple(out.shape)
     with _timed(tag or 'conv3x3_win'):
-        _check(lib().sc2_conv3x3_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(out), N, H, W, Cin, cout,
+        _check(lib().sc2_conv3x3_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(mask), _ptr(out), N, H, W, Cin, cout,
                                          1 if relu else 0, _stream()), 'conv3x3_win_fwd')
     return out
 
@@ -1112,9 +1117,9 @@ def conv1x1_win_supported(cin, cout, kh, kw, stride, pad):
     return (kh, kw, ph, pw) == (1, 1, 0, 0) and sh == sw and bool(lib().sc2_conv1x1_win_supported(cin, cout, sh))
 
 
-def conv1x1_win_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False, tag=None):
+def conv1x1_win_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False, tag=None, mask=None):
     """y = act(conv1x1(x) + bias [+ residual]) on the window-plane 1x1 kernel; bf16 NHWC in / out;
-    w_frag = pack_conv_win(w.reshape(Cout, Cin, 1, 1))."""
+    w_frag = pack_conv_win(w.reshape(Cout, Cin, 1, 1)).  mask (bf16 like y, no relu): y = mask > 0 ? value : 0."""
     for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
         _dev(t, name)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
@@ -1127,9 +1132,12 @@ def conv1x1_win_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False, t
     if residual is not None:
         _dev(residual, 'residual')
         assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and tuple(residual.shape) == tuple(out.shape)
+    if mask is not None:
+        _dev(mask, 'mask')
+        assert not relu and mask.dtype == torch.bfloat16 and mask.is_contiguous() and tuple(mask.shape) == tuple(out.shape)
     with _timed(tag or 'conv1x1_win'):
-        _check(lib().sc2_conv1x1_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(out), N, H, W, Cin, cout,
-                                         stride, 1 if relu else 0, _stream()), 'conv1x1_win_fwd')
+        _check(lib().sc2_conv1x1_win_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(mask), _ptr(out), N, H, W, Cin,
+                                         cout, stride, 1 if relu else 0, _stream()), 'conv1x1_win_fwd')
     return out
 
 

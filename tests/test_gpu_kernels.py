@@ -1436,3 +1436,34 @@ def test_conv2_gdn48_any_width(S, R, dev, N, H, W, inverse):
         assert out.shape == (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 48) == (N, ref.shape[2], ref.shape[3], 48)
         assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'fused conv2 + gdn48, segmented', extra=2.0 ** -8)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('hw,cin,cout,N', [(28, 128, 128, 3), (14, 256, 256, 5), (7, 512, 512, 9)])
+def test_conv3x3_win_relu_gradient_epilogue(S, dev, hw, cin, cout, N):
+    """sc2_conv3x3_win_fwd with `mask`: y = mask > 0 ? conv + bias : 0 -- bit-identical to the plain launch followed by relu_bwd."""
+    torch.manual_seed(hw + N)
+    x = torch.randn(N, hw, hw, cin, device=dev).to(torch.bfloat16)
+    w = S.hip.pack_conv3x3_win((torch.randn(cout, cin, 3, 3) / (9 * cin) ** 0.5).to(dev))
+    b = torch.zeros(cout, device=dev)
+    mask = torch.randn(N, hw, hw, cout, device=dev).to(torch.bfloat16)
+    mask[0, 0, :, :8] = 0.0           # zeros and negative zeros count as "not positive"
+    mask[0, 1, :, :8] = -0.0
+    plain = S.hip.conv3x3_win_fwd(x, w, b)
+    want = S.hip.relu_bwd(plain, mask)
+    got = S.hip.conv3x3_win_fwd(x, w, b, mask=mask)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('cin,cout,hw,N,res', [(512, 128, 28, 3, False), (2048, 512, 7, 9, False), (512, 2048, 7, 5, True)])
+def test_conv1x1_win_relu_gradient_epilogue(S, dev, cin, cout, hw, N, res):
+    """sc2_conv1x1_win_fwd with `mask` (and with mask + residual): bit-identical to the plain launch followed by relu_bwd."""
+    torch.manual_seed(cin + N)
+    x = torch.randn(N, hw, hw, cin, device=dev).to(torch.bfloat16)
+    w = S.hip.pack_conv_win((torch.randn(cout, cin, 1, 1) / cin ** 0.5).to(dev))
+    b = torch.zeros(cout, device=dev)
+    mask = torch.randn(N, hw, hw, cout, device=dev).to(torch.bfloat16)
+    r = torch.randn(N, hw, hw, cout, device=dev).to(torch.bfloat16) if res else None
+    plain = S.hip.conv1x1_win_fwd(x, w, b, residual=r)
+    want = S.hip.relu_bwd(plain, mask)
+    got = S.hip.conv1x1_win_fwd(x, w, b, residual=r, mask=mask)
+    assert torch.equal(got, want)
