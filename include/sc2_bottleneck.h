@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 42
+#define SC2_ABI_VERSION 43
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -409,9 +409,14 @@ int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void *gamma_fra
  * Bottleneck block with its residual add + ReLU, stride-2 downsample).
  *   x : bf16 NHWC [N,H,W,Cin], Cin in {128, 256};  w_frag : bf16 MFMA-fragment blocks [Cout/16][Cin/32][64][8], entry
  *   (jt, ks, lane = fq*16 + frow, e) = W[jt*16 + frow][ks*32 + fq*8 + e];  bias : f32 [Cout];  residual : bf16 NHWC
- *   [N,OH,OW,Cout] or NULL;  y : bf16 NHWC [N,OH,OW,Cout], OH = (H-1)/stride + 1;  Cout % 256 == 0; stride 1 or 2. */
+ *   [N,OH,OW,Cout] or NULL;  y : bf16 NHWC [N,OH,OW,Cout], OH = (H-1)/stride + 1;  Cout % 256 == 0; stride 1 or 2.
+ *   (round 5: Cin also 64 and 512, Cout % 128 == 0.)  mask : NULL, or bf16 like y (sc2_conv1x1_stream_mask_supported: Cin 128 / 256,
+ *   Cout % 256 == 0, stride 1, relu 0): y = mask > 0 ? x W^T + bias [+ residual] : 0 -- the layer is the data gradient of a Bottleneck
+ *   block's conv1 and `mask` the previous block's output, whose ReLU gradient then needs no pass of its own (as sc2_conv1x1_win_fwd /
+ *   sc2_conv3x3_win_fwd take it). */
 int sc2_conv1x1_stream_supported(int Cin, int Cout, int stride);
-int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y, int N,
+int sc2_conv1x1_stream_mask_supported(int Cin, int Cout, int stride);
+int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, const void *mask, void *y, int N,
                            int H, int W, int Cin, int Cout, int stride, int relu, void *stream);
 
 /* Weight gradient of sc2_conv2d_fwd: dw[co][(kh*KW+kw)*Cin+ci] = sum over output pixels of gy * im2col(x).

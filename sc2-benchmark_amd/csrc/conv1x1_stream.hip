@@ -38,6 +38,7 @@ struct StreamArgs {
     const float *__restrict__ bias;       // f32 [Cout]
     const uint16_t *__restrict__ res;     // bf16 NHWC [N,OH,OW,Cout] or null
     uint16_t *__restrict__ y;             // bf16 NHWC [N,OH,OW,Cout]
+    const uint16_t *__restrict__ mask;    // bf16 like y or null (MASK instantiations): y = mask > 0 ? value : 0
     int H, W, OH, OW, OHW, M, Cout, stride, relu;
     int n_chunks, n_units;                // 256-channel chunks per pixel tile; units = pixel tiles x chunks
     unsigned *unit_ctr;                   // claims so far (claim c = unit c + 2 * gridDim.x); zero between launches
@@ -56,7 +57,10 @@ __device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f3
 // The tail of a unit (next unit's loads, this unit's stores) is straight-line code: addresses are clamped instead of
 // guarded, so the compiler's vmcnt bookkeeping stays exact and its wait for the loads is vmcnt(<stores issued after
 // them>) -- never a wait for a store acknowledgement.
-template <int K, int BM, int BNC, bool RES>
+// MASK (round 5): the ReLU gradient behind a data gradient rides in the store pass -- y = mask > 0 ? acc + bias [+ residual] : 0 with
+// `mask` = the saved output of that ReLU (frozen.py: conv1's data gradient of a Bottleneck block + the skip path's gradient, masked
+// by the previous block's output: the separate relu_bwd pass over the 4C-wide tensor disappears).  An instantiation of its own.
+template <int K, int BM, int BNC, bool RES, bool MASK = false>
 __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs p) {
     constexpr int MT = BM / 16, NT = BNC / 16 / 8;   // per wave: all pixel tiles x its 16 NT channels
     constexpr int CPI = BNC / 8;               // 16-byte chunks per image row
@@ -236,13 +240,34 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
         else load_unit(next_unit, tq, std::integral_constant<int, 0>{});
         {
             uint4 *yo = reinterpret_cast<uint4 *>(p.y + (long long)chunk * BNC);
+            [[maybe_unused]] uint4 mq[MASK ? IMG_Q : 1];
+            if constexpr (MASK) {
+                const uint4 *mo = reinterpret_cast<const uint4 *>(p.mask + (long long)chunk * BNC);
+#pragma unroll
+                for (int k = 0; k < IMG_Q; ++k) {
+                    const int q = tq + 512 * k;
+                    int row = q / CPI;
+                    const int c = q % CPI;
+                    row = m0 + row < p.M ? row : 0;
+                    mq[k] = mo[(long long)(m0 + row) * (Cout / 8) + c];
+                }
+            }
 #pragma unroll
             for (int k = 0; k < IMG_Q; ++k) {
                 const int q = tq + 512 * k;
                 int row = q / CPI;
                 const int c = q % CPI;
                 row = m0 + row < p.M ? row : 0;      // past the end: row 0 of the tile again (same data, same address)
-                const uint4 ov = *reinterpret_cast<const uint4 *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4));
+                uint4 ov = *reinterpret_cast<const uint4 *>(img + row * (BNC * 2) + ((c ^ (row & 15)) << 4));
+                if constexpr (MASK) {
+                    const uint32_t mw[4] = {mq[k].x, mq[k].y, mq[k].z, mq[k].w};
+                    uint32_t ow[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        ow[e] = (__builtin_bit_cast(float, mw[e] << 16) > 0.f ? ow[e] & 0xFFFFu : 0u) |
+                                (__builtin_bit_cast(float, mw[e] & 0xFFFF0000u) > 0.f ? ow[e] & 0xFFFF0000u : 0u);
+                    ov = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                }
                 if (SC2_NT_STREAM) sc2_store16_nt(yo + (long long)(m0 + row) * (Cout / 8) + c, ov);
                 else yo[(long long)(m0 + row) * (Cout / 8) + c] = ov;
             }
@@ -264,7 +289,7 @@ constexpr int kMaxDev = 16, kRing = 256;
 unsigned *g_ring[kMaxDev] = {};
 std::atomic<unsigned> g_seq{0};
 
-template <int K, int BM, int BNC, bool RES>
+template <int K, int BM, int BNC, bool RES, bool MASK = false>
 int launch_stream(const StreamArgs &a0, hipStream_t s) {
     constexpr int lds = BM * K * 2 + BM * BNC * 2;
     StreamArgs a = a0;
@@ -278,7 +303,7 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
     static bool attr_set_dev[SC2_MAX_DEVICES] = {};
     bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, BM, BNC, RES>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, BM, BNC, RES, MASK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -308,7 +333,7 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
     static int per_cu = 0;   // resident workgroups per CU of this instantiation (LDS and registers decide)
     if (per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, BM, BNC, RES>), 512,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, BM, BNC, RES, MASK>), 512,
                                                          lds) != hipSuccess || n < 1)
             n = 1;
         per_cu = n > 2 ? 2 : n;
@@ -317,7 +342,7 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
     const int grid = a.n_units < slots ? a.n_units : slots;
     StreamArgs b = a;
     b.unit_ctr = g_ring[dev] + (g_seq.fetch_add(1) % kRing);
-    hipLaunchKernelGGL((conv1x1_stream_kernel<K, BM, BNC, RES>), dim3(grid), dim3(512), lds, s, b);
+    hipLaunchKernelGGL((conv1x1_stream_kernel<K, BM, BNC, RES, MASK>), dim3(grid), dim3(512), lds, s, b);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
@@ -328,9 +353,16 @@ extern "C" int sc2_conv1x1_stream_supported(int Cin, int Cout, int stride) {
     return (Cin == 64 || Cin == 128 || Cin == 256 || Cin == 512) && Cout >= 128 && Cout % 128 == 0 && (stride == 1 || stride == 2) ? 1 : 0;
 }
 
-extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, void *y,
-                                      int N, int H, int W, int Cin, int Cout, int stride, int relu, void *stream) {
+extern "C" int sc2_conv1x1_stream_mask_supported(int Cin, int Cout, int stride) {
+    return (Cin == 128 || Cin == 256) && Cout % 256 == 0 && Cout >= 256 && stride == 1 ? 1 : 0;
+}
+
+extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const float *bias, const void *residual, const void *mask,
+                                      void *y, int N, int H, int W, int Cin, int Cout, int stride, int relu, void *stream) {
     SC2_REQUIRE(x && w_frag && bias && y, SC2_ERR_INVALID_ARG, "conv1x1_stream: null argument");
+    SC2_REQUIRE(!mask || (!relu && sc2_conv1x1_stream_mask_supported(Cin, Cout, stride)), SC2_ERR_UNSUPPORTED,
+                "conv1x1_stream: the mask form needs Cin 128 / 256, Cout %% 256 == 0, stride 1, no relu (got %d -> %d, stride %d)", Cin, Cout,
+                stride);
     SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv1x1_stream: non-positive dimension");
     SC2_REQUIRE(sc2_conv1x1_stream_supported(Cin, Cout, stride), SC2_ERR_UNSUPPORTED,
                 "conv1x1_stream: needs Cin in {64, 128, 256, 512}, Cout %% 128 == 0, stride 1 or 2 (got %d -> %d, stride %d)", Cin,
@@ -340,6 +372,7 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
     a.w = static_cast<const uint16_t *>(w_frag);
     a.bias = bias;
     a.res = static_cast<const uint16_t *>(residual);
+    a.mask = static_cast<const uint16_t *>(mask);
     a.y = static_cast<uint16_t *>(y);
     a.H = H; a.W = W;
     a.OH = (H - 1) / stride + 1;
@@ -352,6 +385,10 @@ extern "C" int sc2_conv1x1_stream_fwd(const void *x, const void *w_frag, const f
     a.unit_ctr = nullptr;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // unit shape: K = 512 -> 64 x 256 (or 64 x 128); otherwise 128 x 256 if it divides Cout, else 128 x 128
+    if (a.mask) {   // (data gradient of a block's conv1: 128 -> 512 / 256 -> 1024, with or without the skip path's gradient)
+        if (Cin == 128) return a.res ? launch_stream<128, 128, 256, true, true>(a, s) : launch_stream<128, 128, 256, false, true>(a, s);
+        return a.res ? launch_stream<256, 128, 256, true, true>(a, s) : launch_stream<256, 128, 256, false, true>(a, s);
+    }
 #define SC2_STREAM_GO(KK, BMM, BNN) return a.res ? launch_stream<KK, BMM, BNN, true>(a, s) : launch_stream<KK, BMM, BNN, false>(a, s)
     if (Cin == 512 && Cout % 256 == 0) SC2_STREAM_GO(512, 64, 256);   // (half the A re-reads of the 128-wide unit)
     if (Cin == 512) SC2_STREAM_GO(512, 64, 128);

@@ -41,12 +41,14 @@ class _Dgrad(object):
     def dense(self, g):
         return self.as_dense(g, hip.EPI_BIAS)
 
-    def __call__(self, g, in_hw, mask=None):
-        """mask: the saved output of the ReLU in front of this layer's input -- the result is the gradient IN FRONT of that ReLU."""
+    def __call__(self, g, in_hw, mask=None, add=None):
+        """mask: the saved output of the ReLU in front of this layer's input -- the result is the gradient IN FRONT of that ReLU;
+        add (with mask): a second gradient reaching the same tensor (the block's skip path), summed in front of the mask."""
+        assert add is None or mask is not None
         if self.as_conv is not None:
-            return self.as_conv(g, hip.EPI_BIAS, ep_mask=mask)
+            return self.as_conv(g, hip.EPI_BIAS, ep_x=add, ep_mask=mask) if mask is not None else self.as_conv(g, hip.EPI_BIAS)
         gx = hip.conv2d_dgrad(g, self.w_folded, self.stride, self.pad, in_hw, cache=self._packed)
-        return gx if mask is None else hip.relu_bwd(gx, mask)
+        return gx if mask is None else hip.relu_bwd(gx, mask, add=add)
 
 
 class FrozenStack(object):
@@ -94,15 +96,24 @@ class FrozenStack(object):
         MSE term on the stack's OUTPUT whose gradient 2 scale (out - t) is formed inside the first ReLU-gradient pass."""
         dgs = self._dg()
         g_a, g_b = g_out, None          # the two branches that meet at the current block's output
+        masked = False                  # g_a already IS the gradient in front of this block's output ReLU
         for bi in range(len(self.blocks) - 1, -1, -1):
             h, o1, o2, out = saved[bi]
             d1, d2, d3, dds = dgs[bi]
-            if mse is not None and bi == len(self.blocks) - 1:
+            if masked:
+                g = g_a
+            elif mse is not None and bi == len(self.blocks) - 1:
                 g = hip.relu_bwd_mse(g_a, out, mse[0], mse[1])
             else:
                 g = hip.relu_bwd(g_a, out, add=g_b)
             g2 = d3(g, o2.shape[1:3], mask=o2)       # (the ReLU gradients ride in the data-gradient launches' epilogues where
-            g1 = d2(g2, o1.shape[1:3], mask=o1)      #  the layer runs on a window-plane kernel: head._Conv, ep_mask)
+            g1 = d2(g2, o1.shape[1:3], mask=o1)      #  the layer runs on a kernel that takes a mask: head._Conv, ep_mask)
+            masked = False
+            if dds is None and bi > 0 and d1.as_conv is not None:
+                # no downsample: this block's input IS the previous block's output h (saved[bi - 1][3]).  Its gradient in front of
+                # that block's ReLU = (conv1's data gradient + g over the skip path) * (h > 0): sum and mask in the launch
+                g_a, g_b, masked = d1(g1, h.shape[1:3], mask=h, add=g), None, True
+                continue
             g_c1 = d1(g1, h.shape[1:3])
             if dds is not None and dds.as_dense is not None:
                 # (was: scatter into a zero-filled map, then a full-size add -- three fills and 1.2 GB of traffic per block)

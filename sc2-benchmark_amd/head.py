@@ -125,15 +125,18 @@ class _Conv(object):
         """ep_mask (bf16 like the output, epilogue EPI_BIAS): y = ep_mask > 0 ? conv + bias : 0 -- the ReLU gradient behind a data
         gradient (frozen.py); in the launch's epilogue on the window-plane kernels, else as a `relu_bwd` pass behind it."""
         if ep_mask is not None:
-            assert epilogue == hip.EPI_BIAS and ep_x is None
+            # (ep_x with ep_mask: a second gradient that reaches the same tensor, added in front of the mask -- the skip path's)
+            assert epilogue == hip.EPI_BIAS
             fits = max(x.numel(), x.shape[0] * x.shape[1] * x.shape[2] * self.cout) * 2 < 0x7FF00000
             if hip.host_policy.relu_mask_fused and self.dilation == (1, 1) and fits:
                 if self.w_win1 is not None:
-                    return hip.conv1x1_win_fwd(x, self.w_win1, self.b, stride=self.stride[0], mask=ep_mask, tag=self.tag)
-                if not (self.stream or self.kres) and self.w_win is not None and self.stride == (1, 1) and \
+                    return hip.conv1x1_win_fwd(x, self.w_win1, self.b, stride=self.stride[0], residual=ep_x, mask=ep_mask, tag=self.tag)
+                if self.stream and hip.conv1x1_stream_mask_supported(x.shape[3], self.cout, self.stride[0]):
+                    return hip.conv1x1_stream_fwd(x, self.w_frag, self.b, stride=self.stride[0], residual=ep_x, mask=ep_mask, tag=self.tag)
+                if ep_x is None and not (self.stream or self.kres) and self.w_win is not None and self.stride == (1, 1) and \
                         hip.conv3x3_win_supported(x.shape[1], x.shape[2], x.shape[3], self.cout, self.k[0], self.k[1], self.stride, self.pad):
                     return hip.conv3x3_win_fwd(x, self.w_win, self.b, tag=self.tag, stride=1, mask=ep_mask)
-            return hip.relu_bwd(self(x, epilogue), ep_mask)
+            return hip.relu_bwd(self(x, epilogue), ep_mask, add=ep_x)
         if self.dilation != (1, 1) and self.k != (1, 1):
             if self.native_dilation and hip.host_policy.conv_dilation:      # ('0': A/B, the phase grids)
                 return hip.conv2d_fwd(x, self.w, self.cout, self.k[0], self.k[1], self.stride, self.pad, epilogue=epilogue,

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_fc_fwd',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd', 'sc2_gdn1_bwd_gemm', 'sc2_colsum_bf16', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
-    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv1x1_pair_supported', 'sc2_conv1x1_pair_fwd',
+    'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_mask_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv1x1_pair_supported', 'sc2_conv1x1_pair_fwd',
     'sc2_conv0_gdn96_supported', 'sc2_conv0_gdn96_fwd', 'sc2_conv0_gdn96_nchw_fwd', 'sc2_conv2_gdn48_supported', 'sc2_conv2_gdn48_fwd', 'sc2_conv2x2_c48_supported', 'sc2_conv2x2_c48_fwd', 'sc2_conv1x1_kres_supported', 'sc2_conv1x1_kres_fwd', 'sc2_conv1x1_win_supported', 'sc2_conv1x1_win_fwd', 'sc2_conv3x3_win_supported', 'sc2_conv3x3_win_fwd', 'sc2_conv3x3s2_win_supported', 'sc2_conv3x3s2_win_fwd', 'sc2_conv2x2_win_supported', 'sc2_conv2x2_win_fwd', 'sc2_conv2x2_win_tail_supported', 'sc2_conv2x2_win_tail_fwd', 'sc2_conv2d_wgrad', 'sc2_gdn_bwd_pre', 'sc2_gdn_bwd_post', 'sc2_gdn1_rows_supported', 'sc2_gdn1_rows_fwd', 'sc2_gdn1_rows_bwd',
     'sc2_eb_forward', 'sc2_eb_backward', 'sc2_eb_bits_partial_len', 'sc2_eb_symbols', 'sc2_eb_dequantize',
     'sc2_gc_forward', 'sc2_gc_backward', 'sc2_gc_symbols_indexes', 'sc2_gc_dequantize',
@@ -206,7 +206,8 @@ def lib():
     L.sc2_conv1x1_pair_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_pair_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
-    L.sc2_conv1x1_stream_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv1x1_stream_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv1x1_stream_mask_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
     L.sc2_gdn1_rows_supported.argtypes = [i32]
     L.sc2_gdn1_rows_fwd.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, i32, i32, vp]
@@ -1019,7 +1020,11 @@ def conv1x1_stream_supported(cin, cout, kh, kw, stride, pad):
         bool(lib().sc2_conv1x1_stream_supported(cin, cout, sh))
 
 
-def conv1x1_stream_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False, tag=None):
+def conv1x1_stream_mask_supported(cin, cout, stride):
+    return host_policy.conv_stream and bool(lib().sc2_conv1x1_stream_mask_supported(cin, cout, int(stride)))
+
+
+def conv1x1_stream_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False, tag=None, mask=None):
     """y = act(conv1x1(x) + bias [+ residual]) on the persistent streaming kernel; bf16 NHWC in / out."""
     for t, name in ((x_nhwc, 'x'), (w_frag, 'w_frag'), (bias, 'bias')):
         _dev(t, name)
@@ -1033,8 +1038,11 @@ def conv1x1_stream_fwd(x_nhwc, w_frag, bias, stride=1, residual=None, relu=False
     if residual is not None:
         _dev(residual, 'residual')
         assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and tuple(residual.shape) == tuple(out.shape)
+    if mask is not None:
+        _dev(mask, 'mask')
+        assert not relu and mask.dtype == torch.bfloat16 and mask.is_contiguous() and tuple(mask.shape) == tuple(out.shape)
     with _timed(tag or 'conv1x1_stream'):
-        _check(lib().sc2_conv1x1_stream_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(out), N, H, W,
+        _check(lib().sc2_conv1x1_stream_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(bias), _ptr(residual), _ptr(mask), _ptr(out), N, H, W,
                                             Cin, cout, int(stride), 1 if relu else 0, _stream()), 'conv1x1_stream_fwd')
     return out
 

@@ -1467,3 +1467,21 @@ def test_conv1x1_win_relu_gradient_epilogue(S, dev, cin, cout, hw, N, res):
     want = S.hip.relu_bwd(plain, mask)
     got = S.hip.conv1x1_win_fwd(x, w, b, residual=r, mask=mask)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('cin,cout,hw,N,res', [(128, 512, 28, 3, True), (256, 1024, 14, 5, True), (128, 512, 9, 2, False)])
+def test_conv1x1_stream_relu_gradient_store_pass(S, dev, cin, cout, hw, N, res):
+    """sc2_conv1x1_stream_fwd with `mask` (the data gradient of a block's conv1 + the skip path's gradient, masked by the previous
+    block's output): bit-identical to the plain launch followed by relu_bwd; several units per workgroup, ragged last tile."""
+    torch.manual_seed(cin + hw)
+    assert S.hip.conv1x1_stream_mask_supported(cin, cout, 1) and not S.hip.conv1x1_stream_mask_supported(512, cout, 1)
+    x = torch.randn(N, hw, hw, cin, device=dev).to(torch.bfloat16)
+    w = S.hip.pack_weight_fragments((torch.randn(cout, cin) / cin ** 0.5).to(dev))
+    b = torch.zeros(cout, device=dev)
+    mask = torch.randn(N, hw, hw, cout, device=dev).to(torch.bfloat16)
+    mask[0, 0, :, :16] = 0.0
+    r = torch.randn(N, hw, hw, cout, device=dev).to(torch.bfloat16) if res else None
+    plain = S.hip.conv1x1_stream_fwd(x, w, b, residual=r)
+    want = S.hip.relu_bwd(plain, mask)
+    got = S.hip.conv1x1_stream_fwd(x, w, b, residual=r, mask=mask)
+    assert torch.equal(got, want)
