@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 43
+#define SC2_ABI_VERSION 44
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -228,13 +228,15 @@ int sc2_gdn1_bwd_gemm(const sc2_conv_desc *d, const void *x, const void *w_packe
  *                       d_norm (bf16 [M, C]: its column sums are d_beta, d_norm^T |x| is d_gamma) and dx (bf16 [M, C]).
  *                       Same quantities as SC2_EPI_(I)GDN1_BWD_PRE + SC2_EPI_GDN1_BWD_POST of sc2_gdn1_bwd_gemm, the direct term kept
  *                       in f32 in the accumulators instead of rounded to bf16 in between; sign(0) = 0 as torch.abs's gradient.
+ *                       d_beta (f32 [C] or NULL): the column sums of d_norm -- accumulated inside the launch for C = 96 / 256 (from
+ *                       the f32 values, before their rounding to bf16), by sc2_colsum_bf16 behind it for C = 512.
  *   gamma_frag / gamma_t_frag : the effective gamma [C, C] and its transpose as MFMA fragments, bf16 [C/16][C/32][64][8]: entry
  *                       (jt, ks, lane = fq*16 + frow, e) = W[jt*16 + frow][ks*32 + fq*8 + e];  beta f32 [C];  M * C * 2 < 2 GB. */
 int sc2_gdn1_rows_supported(int C);
 int sc2_gdn1_rows_fwd(const void *x, const void *gamma_frag, const float *beta, void *y, long long M, int C, int inverse,
                       void *stream);
 int sc2_gdn1_rows_bwd(const void *x, const void *gy, const void *gamma_frag, const void *gamma_t_frag, const float *beta,
-                      void *d_norm, void *dx, long long M, int C, int inverse, void *stream);
+                      void *d_norm, void *dx, float *d_beta, long long M, int C, int inverse, void *stream);
 /* column sums of a bf16 [M, C] tensor in f32 (d_beta = sum over pixels of d_norm): out f32 [C], C % 8 == 0, C <= 2048. */
 int sc2_colsum_bf16(const void *x, long long M, int C, float *out, void *stream);
 

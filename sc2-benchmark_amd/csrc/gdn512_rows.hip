@@ -105,6 +105,7 @@ struct RowsArgs {
     const float *__restrict__ beta;      // f32 [512]
     uint16_t *__restrict__ out;          // forward: y; backward: dx
     uint16_t *__restrict__ dn;           // backward: d_norm
+    float *__restrict__ d_beta;          // backward, CH == 256: column sums of d_norm, accumulated here (zeroed by the launcher); else null
     int M, n_tiles;
     unsigned bytes;                      // M * 1024
 };
@@ -268,6 +269,16 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         }
     };
 
+    // d_beta = column sums of d_norm: with two accumulator columns per wave (CH == 256) a lane keeps the running sums of its 2 x 4
+    // channels over all of the workgroup's tiles; the 512-channel form has no registers for sixteen (sc2_colsum_bf16 runs behind it)
+    constexpr bool BSUM = MODE == 1 && NT <= 2;
+    [[maybe_unused]] float bsum[NT][4];
+    if constexpr (BSUM) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[j][e] = 0.f;
+    }
     for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const int m0 = tile * BM;
         // ---------------------------------------------------------------- x tile -> image: row r = one 1 KB wave-instruction;
@@ -392,6 +403,10 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
                 // (pin the four values HERE: left alone, the compiler sinks these selects to their use in GEMM 2 and keeps dd, x and the
                 //  masks of all 128 elements alive until then -- a kilobyte of scratch per lane.  Four scalar operands: with the
                 //  f32x4 tile as ONE "+v" operand the compiler took all four elements to be element 0 afterwards)
+                if constexpr (BSUM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bsum[j][e] += dnv[e];
+                }
                 asm volatile("" : "+v"(sdd[0]), "+v"(sdd[1]), "+v"(sdd[2]), "+v"(sdd[3]));
                 acc[i][j] = f32x4_t{sdd[0], sdd[1], sdd[2], sdd[3]};
                 zmask[(i * NT + j) >> 3] |= zm4 << (((i * NT + j) & 7) * 4);
@@ -490,6 +505,19 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
         stream_out(rs_out, m0);
         __syncthreads();        // the image is free for the next tile's x
     }
+    if constexpr (BSUM) {
+        if (p.d_beta) {   // the sixteen pixel lanes of a channel quad, then one atomic per channel and wave
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = bsum[j][e];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+                    if (frow == 0) atomicAdd(p.d_beta + wn * WN + j * 16 + fq * 4 + e, v);
+                }
+        }
+    }
 #undef SC2_ROWS_GEMM
 #undef SC2_ROWS_ONE
 #undef SC2_ROWS_STEP
@@ -528,6 +556,7 @@ int launch_rows_c(const RowsArgs &a, int C, int inverse, hipStream_t s) {
 
 int rows_args(RowsArgs &a, const void *x, const void *gy, const void *g1, const void *g2, const float *beta, void *out, void *dn,
               long long M, int C, const char *who) {
+    a.d_beta = nullptr;
     SC2_REQUIRE(M > 0 && M * (C * 2) < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "%s: %lld pixels x %d channels exceed 2 GB (32-bit buffer offsets)",
                 who, M, C);
     a.x = static_cast<const uint16_t *>(x);
@@ -547,7 +576,8 @@ int rows_args(RowsArgs &a, const void *x, const void *gy, const void *g1, const 
 
 // C = 96: every wave an independent worker on 32-pixel strips (gdn96_strips.hip)
 int sc2_gdn96_strips(int mode, const void *x, const void *gy, const void *g1, const void *g2, const float *beta, void *out, void *dn,
-                     long long M, int inverse, hipStream_t s);
+                     float *d_beta, long long M, int inverse, hipStream_t s);
+extern "C" int sc2_colsum_bf16(const void *x, long long M, int C, float *out, void *stream);
 
 extern "C" int sc2_gdn1_rows_supported(int C) { return C == 512 || C == 256 || C == 96 ? 1 : 0; }
 
@@ -555,19 +585,26 @@ extern "C" int sc2_gdn1_rows_fwd(const void *x, const void *gamma_frag, const fl
                                  void *stream) {
     SC2_REQUIRE(x && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "gdn1_rows_fwd: null argument");
     SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_fwd: C = %d (96, 256 or 512)", C);
-    if (C == 96) return sc2_gdn96_strips(0, x, nullptr, gamma_frag, nullptr, beta, y, nullptr, M, inverse, static_cast<hipStream_t>(stream));
+    if (C == 96) return sc2_gdn96_strips(0, x, nullptr, gamma_frag, nullptr, beta, y, nullptr, nullptr, M, inverse, static_cast<hipStream_t>(stream));
     RowsArgs a;
     if (const int rc = rows_args(a, x, nullptr, gamma_frag, nullptr, beta, y, nullptr, M, C, "gdn1_rows_fwd")) return rc;
     return launch_rows_c<0>(a, C, inverse, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int sc2_gdn1_rows_bwd(const void *x, const void *gy, const void *gamma_frag, const void *gamma_t_frag, const float *beta,
-                                 void *d_norm, void *dx, long long M, int C, int inverse, void *stream) {
+                                 void *d_norm, void *dx, float *d_beta, long long M, int C, int inverse, void *stream) {
     SC2_REQUIRE(x && gy && gamma_frag && gamma_t_frag && beta && d_norm && dx, SC2_ERR_INVALID_ARG, "gdn1_rows_bwd: null argument");
     SC2_REQUIRE(sc2_gdn1_rows_supported(C), SC2_ERR_UNSUPPORTED, "gdn1_rows_bwd: C = %d (96, 256 or 512)", C);
-    if (C == 96)
-        return sc2_gdn96_strips(1, x, gy, gamma_frag, gamma_t_frag, beta, dx, d_norm, M, inverse, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (d_beta && C != 512) {   // accumulated by the kernels (atomics)
+        hipError_t e = hipMemsetAsync(d_beta, 0, (size_t)C * sizeof(float), s);
+        SC2_REQUIRE(e == hipSuccess, SC2_ERR_LAUNCH, "gdn1_rows_bwd: memset failed: %s", hipGetErrorString(e));
+    }
+    if (C == 96) return sc2_gdn96_strips(1, x, gy, gamma_frag, gamma_t_frag, beta, dx, d_norm, d_beta, M, inverse, s);
     RowsArgs a;
     if (const int rc = rows_args(a, x, gy, gamma_frag, gamma_t_frag, beta, dx, d_norm, M, C, "gdn1_rows_bwd")) return rc;
-    return launch_rows_c<1>(a, C, inverse, static_cast<hipStream_t>(stream));
+    a.d_beta = C == 256 ? d_beta : nullptr;
+    if (const int rc = launch_rows_c<1>(a, C, inverse, s)) return rc;
+    if (d_beta && C == 512) return sc2_colsum_bf16(d_norm, M, C, d_beta, stream);   // (no registers for the running sums there)
+    return SC2_OK;
 }

@@ -61,6 +61,7 @@ struct StripArgs {
     const float *__restrict__ beta;      // f32 [96]
     uint16_t *__restrict__ out;          // forward: y; backward: dx
     uint16_t *__restrict__ dn;           // backward: d_norm
+    float *__restrict__ d_beta;          // backward: column sums of d_norm, accumulated here (zeroed by the caller), or null
     int M, n_strips;
     unsigned bytes;                      // M * 192
 };
@@ -69,7 +70,7 @@ constexpr int CH = 96, NT = CH / 16, KS = CH / 32, SP = 32, MT = SP / 16, WAVES 
 constexpr int ROWB = CH * 2, PITCH = 208, CPR = 13, PIECES = 7;          // 32 rows x 13 chunks = 416 positions <= 7 x 64
 constexpr int AREA = PIECES * 1024;                                       // one strip image
 constexpr int GAMMA_BYTES = NT * KS * 1024;                               // 18 KB of fragments
-constexpr int BETA_OFF = 2 * GAMMA_BYTES, AREAS_OFF = BETA_OFF + 512;     // gamma | gamma^T | beta | per wave: x area, g area
+constexpr int BETA_OFF = 2 * GAMMA_BYTES, BSUM_OFF = BETA_OFF + 512, AREAS_OFF = BSUM_OFF + 512;   // gamma | gamma^T | beta | d_beta sums | per wave: x area, g area
 constexpr int LDS_BYTES = AREAS_OFF + WAVES * 2 * AREA;
 constexpr uint32_t OOB = 0x80000000u;
 static_assert(SP * CPR <= PIECES * 64 && LDS_BYTES <= 160 * 1024, "strip image, LDS");
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gdn96_strips_kernel(const Strip
         if (MODE == 1) reinterpret_cast<uint4 *>(smem + GAMMA_BYTES)[q] = reinterpret_cast<const uint4 *>(p.g2)[q];
     }
     if (tid < CH) reinterpret_cast<float *>(smem + BETA_OFF)[tid] = p.beta[tid];
+    if (tid < CH) reinterpret_cast<float *>(smem + BSUM_OFF)[tid] = 0.f;
     __syncthreads();   // the only barrier: from here on every wave works alone
     const float *beta_s = reinterpret_cast<const float *>(smem + BETA_OFF);
     unsigned char *xs = smem + AREAS_OFF + wave * (2 * AREA);
@@ -139,6 +141,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gdn96_strips_kernel(const Strip
         }
     };
 
+    [[maybe_unused]] float bsum[NT][4];   // backward: this lane's running column sums of d_norm (d_beta)
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[j][e] = 0.f;
+    }
     const int stride = (int)gridDim.x * WAVES;
     for (int strip = (int)blockIdx.x * WAVES + wave; strip < p.n_strips; strip += stride) {
         const int pix0 = strip * SP;
@@ -224,6 +233,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gdn96_strips_kernel(const Strip
                     sdd[e] = __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, ddv[e]) ^ (xb[e] & 0x80000000u)) & nz);
                 }
                 acc[i][j] = f32x4_t{sdd[0], sdd[1], sdd[2], sdd[3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[j][e] += dnv[e];
                 *reinterpret_cast<uint2 *>(xs + so) = make_uint2(pack2(f32x2_t{dnv[0], dnv[1]}), pack2(f32x2_t{dnv[2], dnv[3]}));
                 *reinterpret_cast<uint2 *>(gs + so) = make_uint2(pack2(f32x2_t{ddv[0], ddv[1]}), pack2(f32x2_t{ddv[2], ddv[3]}));
             }
@@ -253,6 +264,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gdn96_strips_kernel(const Strip
             }
         }
         stream_out(gs, rs_out, base, rows_valid);           // dx
+    }
+    if (MODE == 1 && p.d_beta) {
+        // d_beta: the sixteen pixel lanes of a channel quad, the workgroup's waves through LDS, then one atomic per channel
+        float *bs = reinterpret_cast<float *>(smem + BSUM_OFF);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = bsum[j][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+                if (frow == 0) atomicAdd(bs + j * 16 + fq * 4 + e, v);
+            }
+        __syncthreads();
+        if (tid < CH) atomicAdd(p.d_beta + tid, bs[tid]);
     }
 }
 
@@ -284,7 +310,7 @@ int launch_strips(const StripArgs &a, hipStream_t s) {
 
 // (called by sc2_gdn1_rows_fwd / _bwd of gdn512_rows.hip for C == 96: one entry point per operation, whatever the channel count)
 int sc2_gdn96_strips(int mode, const void *x, const void *gy, const void *g1, const void *g2, const float *beta, void *out, void *dn,
-                     long long M, int inverse, hipStream_t s) {
+                     float *d_beta, long long M, int inverse, hipStream_t s) {
     SC2_REQUIRE(M > 0 && M * ROWB < 0x7FF00000LL, SC2_ERR_UNSUPPORTED, "gdn1_rows: %lld pixels x 96 channels exceed 2 GB (32-bit buffer offsets)", M);
     StripArgs a;
     a.x = static_cast<const uint16_t *>(x);
@@ -294,6 +320,7 @@ int sc2_gdn96_strips(int mode, const void *x, const void *gy, const void *g1, co
     a.beta = beta;
     a.out = static_cast<uint16_t *>(out);
     a.dn = static_cast<uint16_t *>(dn);
+    a.d_beta = d_beta;
     a.M = (int)M;
     a.n_strips = (int)((M + SP - 1) / SP);
     a.bytes = (unsigned)(M * ROWB);

@@ -211,7 +211,7 @@ def lib():
     L.sc2_conv2d_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp]
     L.sc2_gdn1_rows_supported.argtypes = [i32]
     L.sc2_gdn1_rows_fwd.argtypes = [vp, vp, vp, vp, ctypes.c_longlong, i32, i32, vp]
-    L.sc2_gdn1_rows_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, i32, i32, vp]
+    L.sc2_gdn1_rows_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, i32, i32, vp]
     L.sc2_gdn_bwd_pre.argtypes = [vp, vp, vp, ctypes.c_longlong, i32, i32, vp, vp, vp, vp]
     L.sc2_gdn_bwd_post.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, vp]
     L.sc2_eb_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp, vp, i32, vp]
@@ -491,8 +491,9 @@ def gdn1_rows_fwd(x_nhwc, gamma_frag, beta, inverse, tag=None):
     return y
 
 
-def gdn1_rows_bwd(x_nhwc, gy_nhwc, gamma_frag, gamma_t_frag, beta, inverse, tag=None):
-    """-> (d_norm, dx), both bf16 like x: the two GEMMs of the GDN1 backward and its element-wise halves in one launch."""
+def gdn1_rows_bwd(x_nhwc, gy_nhwc, gamma_frag, gamma_t_frag, beta, inverse, tag=None, want_d_beta=False):
+    """-> (d_norm, dx[, d_beta]), d_norm / dx bf16 like x: the two GEMMs of the GDN1 backward and its element-wise halves in one launch;
+    want_d_beta: also the column sums of d_norm (f32 [C]; inside the launch for C = 96 / 256, a column-sum launch behind it for 512)."""
     for t, name in ((x_nhwc, 'x'), (gy_nhwc, 'gy'), (gamma_frag, 'gamma_frag'), (gamma_t_frag, 'gamma_t_frag'), (beta, 'beta')):
         _dev(t, name)
     C = x_nhwc.shape[-1]
@@ -502,10 +503,11 @@ def gdn1_rows_bwd(x_nhwc, gy_nhwc, gamma_frag, gamma_t_frag, beta, inverse, tag=
         assert g.dtype == torch.bfloat16 and g.is_contiguous() and tuple(g.shape) == (C // 16, C // 32, 64, 8)
     assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == C
     d_norm, dx = torch.empty_like(x_nhwc), torch.empty_like(x_nhwc)
+    d_beta = torch.empty((C,), dtype=torch.float32, device=x_nhwc.device) if want_d_beta else None
     with _timed(tag or 'gdn.rows.bwd'):
         _check(lib().sc2_gdn1_rows_bwd(_ptr(x_nhwc), _ptr(gy_nhwc), _ptr(gamma_frag), _ptr(gamma_t_frag), _ptr(beta), _ptr(d_norm),
-                                       _ptr(dx), x_nhwc.numel() // C, C, 1 if inverse else 0, _stream()), 'gdn1_rows_bwd')
-    return d_norm, dx
+                                       _ptr(dx), _ptr(d_beta), x_nhwc.numel() // C, C, 1 if inverse else 0, _stream()), 'gdn1_rows_bwd')
+    return (d_norm, dx, d_beta) if want_d_beta else (d_norm, dx)
 
 
 def colsum_bf16(x, C):
@@ -531,8 +533,8 @@ def gdn1_backward(gy_nhwc, x_nhwc, beta, gamma, inverse):
         # C = 256 / 512: both GEMMs and both element-wise halves in ONE launch with the pixel tile's whole channel row in LDS (four passes
         # over the [pixels, C] tensors: x, g in; d_norm, dx out)
         g = gamma.detach()
-        d_norm, dx = gdn1_rows_bwd(x_nhwc, gy_nhwc, pack_weight_fragments(g), pack_weight_fragments(g.t()), beta, inverse)
-        d_beta = colsum_bf16(d_norm, C)
+        d_norm, dx, d_beta = gdn1_rows_bwd(x_nhwc, gy_nhwc, pack_weight_fragments(g), pack_weight_fragments(g.t()), beta, inverse,
+                                           want_d_beta=True)
         d_gamma = conv2d_wgrad(x_nhwc, d_norm, 1, 1, 1, 0, x_abs=True).reshape(C, C)
         return dx, d_beta, d_gamma
     if host_policy.gdn_bwd_fused and (weight_rows(C) % 128 == 0 or weight_rows(C) == 96) and M < (1 << 31):

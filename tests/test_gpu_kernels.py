@@ -1203,9 +1203,12 @@ def test_gdn512_rows(S, dev, C, shape, inverse):
     y_tile = S.hip.conv2d_fwd(xd, S.hip.pack_conv_weight(gamma.reshape(C, C, 1, 1).to(dev)), C, 1, 1, 1, 0, a_op=S.hip.AOP_ABS,
                               epilogue=S.hip.EPI_IGDN if inverse else S.hip.EPI_GDN, ep_x=xd, ep_beta=bd)
     assert torch.equal(y, y_tile)
-    d_norm, dx = S.hip.gdn1_rows_bwd(xd, gd, gf, gtf, bd, inverse)
+    d_norm, dx, d_beta = S.hip.gdn1_rows_bwd(xd, gd, gf, gtf, bd, inverse, want_d_beta=True)
     torch.cuda.synchronize()
     assert_close_bf16(d_norm.reshape(-1, C), dn_ref, 'gdn512 rows d_norm')
+    # d_beta = the column sums of d_norm (inside the launch for C = 96 / 256, a column-sum launch behind it for 512)
+    want_db = dn_ref.sum(0)
+    assert ((d_beta.cpu() - want_db).norm() / (want_db.norm() + 1e-12)).item() < 1e-2
 
     def rel(a, b):
         return ((a.float().cpu() - b).norm() / (b.norm() + 1e-20)).item()
