@@ -62,7 +62,8 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         x_nhwc, weight = ctx.saved_tensors
         stride, pad, out_format, w_view = ctx.cfg
-        sink, ctx.mse_sink = ctx.mse_sink, None
+        sink = list(ctx.mse_sink)        # (the MSE nodes keep the list itself: emptied, not replaced -- a retained graph may run again)
+        ctx.mse_sink.clear()
         if out_format == hip.OUT_BF16_NHWC:
             g = gy.contiguous()
             for xs, ts, scale in sink:           # 2 scale (y - t) added in one pass (no gradient tensor, no separate add)

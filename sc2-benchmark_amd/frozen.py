@@ -147,7 +147,8 @@ class FrozenStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        sink, ctx.mse_sink = ctx.mse_sink, None
+        sink = list(ctx.mse_sink)        # (the MSE nodes keep the list itself: emptied, not replaced)
+        ctx.mse_sink.clear()
         if gy is None and not sink:
             ctx.saved = None
             return None, None
