@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 44
+#define SC2_ABI_VERSION 45
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -292,20 +292,24 @@ int sc2_conv2d_f32_fwd(const sc2_conv_desc *d, const float *x, const float *w_fr
  *   gamma_frag : effective gamma as bf16 MFMA-fragment blocks [32 channel tiles][16 k steps][64 lanes][8]: entry
  *                (jt, ks, lane = fq*16 + frow, e) = gamma[jt*16 + frow][ks*32 + fq*8 + e] (one operand fragment =
  *                1 KB contiguous);   beta : f32 [512] (effective beta)
- *   y : bf16 NHWC [N,H+1,W+1,512] */
+ *   y : bf16 NHWC [N,H+1,W+1,512]
+ *   t_out : NULL, or bf16 laid out like y (round 5, training): the conv output in front of the GDN, the tensor the GDN's backward
+ *           needs (`_forward2train`, layer.py:529-533: decoder[0] + decoder[1] as this one launch); needs N*(H+1)*(W+1)*1024 B < 2^31 */
 int sc2_conv2x2_gdn512_supported(int Cin, int Cout, int KH, int KW, int stride, int pad);
 int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const void *gamma_frag, const float *beta,
-                           void *y, int N, int H, int W, int Cin, int inverse, void *stream);
+                           void *y, void *t_out, int N, int H, int W, int Cin, int inverse, void *stream);
 
 /* First encoder stage in ONE persistent launch: y = GDN1_96(Conv2d(3 -> 96, k5, s2, p2, bias=False)(x)) on the
  * pixel-pair view of the image (replaces encoder[0] + encoder[1], sc2bench/models/layer.py:476-478).
  *   x_pairs : bf16 [N, H, W/2, 8] (two pixels x four channels, channel 3 zero: sc2_nchw_f32_to_nhwc_bf16 with c_pad 4)
  *   w_frag  : bf16 MFMA-fragment blocks [6][4][64][8] of the pair-packed weights W'[96][128], k = (kh*3 + t)*8 + dw*4 + c
  *   gamma_frag : bf16 fragment blocks [6][3][64][8] of the effective gamma;  beta : f32 [96]
- *   y : bf16 NHWC [N, OH, W/2, 96], OH = (H - 1)/2 + 1.   Any width: rows are cut into 112-pixel output segments. */
+ *   y : bf16 NHWC [N, OH, W/2, 96], OH = (H - 1)/2 + 1.   Any width: rows are cut into 112-pixel output segments.
+ *   t_out : NULL, or bf16 laid out like y (round 5, training): the conv output in front of the GDN, the tensor the GDN's backward
+ *           needs (`_forward2train`, layer.py:529-533: encoder[0] + encoder[1] as this one launch) */
 int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs);
-int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N,
-                        int H, int W_pairs, int inverse, void *stream);
+int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta, void *y, void *t_out,
+                        int N, int H, int W_pairs, int inverse, void *stream);
 /* The same launch on the reference's own input: x_nchw = the f32 NCHW image batch [N, 3, H, W] that
  * `FPBasedResNetBottleneck.encoder` receives (sc2bench/models/layer.py:496-498), read where it lies -- the three colour planes
  * of a pixel pair are rounded to bf16 (round-to-nearest-even, as sc2_nchw_f32_to_nhwc_bf16 rounds) as the kernel stages them:
@@ -401,9 +405,11 @@ int sc2_conv2x2_win_tail_fwd(const void *x, const void *w_stream, const float *b
  * point) runs the static geometry, any other width the same kernel over 56-column output segments.
  *   x : bf16 NHWC [N, H, W, 96];   y : bf16 NHWC [N, (H - 1)/2 + 1, (W - 1)/2 + 1, 48]
  *   w_frag : the conv weights packed SC2_K_SLAB_MAJOR | SC2_K_B_FRAG_MAJOR ([k-step = slab*25 + tap][3][64][8] bf16)
- *   gamma_frag : bf16 fragment blocks [3][2][64][8] of the effective gamma [48][48 -> 64 zero-padded];  beta : f32 [48] */
+ *   gamma_frag : bf16 fragment blocks [3][2][64][8] of the effective gamma [48][48 -> 64 zero-padded];  beta : f32 [48]
+ *   t_out : NULL, or bf16 laid out like y (round 5, training): the conv output in front of the GDN, which the GDN's backward needs --
+ *           `_forward2train` (layer.py:529-533) then runs encoder[2] + encoder[3] as this one launch. */
 int sc2_conv2_gdn48_supported(int Cin, int Cout, int W);
-int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N, int H,
+int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y, void *t_out, int N, int H,
                         int W, int inverse, void *stream);
 
 /* Streaming 1x1 convolution with a short K and a wide N: y = act(x W^T + bias [+ residual]) in one persistent launch

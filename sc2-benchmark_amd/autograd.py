@@ -39,6 +39,15 @@ class _ToNhwcBf16(torch.autograd.Function):
         return gx[:, :ctx.c].contiguous(), None
 
 
+def _pair_conv0_wgrad(x_pairs, g, weight):
+    """Weight gradient of the first encoder conv (Cin <= 4, k5 s2 p2) from its pixel-pair input view [N, H, W/2, 8]: there the conv
+    is k (5, 3), stride (2, 1), pad (2, 1) with K ordered (kh, pair tap, pixel-in-pair * 4 + channel)."""
+    raw = hip.conv2d_wgrad(x_pairs, g, 5, 3, (2, 1), (2, 1))            # [Cout, 8, 5, 3]
+    cout = raw.shape[0]
+    full = raw.permute(0, 2, 3, 1).reshape(cout, 5, 3, 2, 4)            # (kh, t, dw, c)
+    return full.reshape(cout, 5, 6, 4)[:, :, :5, :weight.shape[1]].permute(0, 3, 1, 2).contiguous()
+
+
 class _ConvFn(torch.autograd.Function):
     """y = conv(x) on the implicit-GEMM kernel; x bf16 NHWC, weight the f32 OIHW parameter."""
 
@@ -79,12 +88,8 @@ class _ConvFn(torch.autograd.Function):
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gi = gw = None
         if w_view is not None:
-            # first encoder conv on its pixel-pair view: K is ordered (kh, pair tap, pixel-in-pair * 4 + channel)
             if need_w:
-                raw = hip.conv2d_wgrad(x_nhwc, g, 5, 3, (2, 1), (2, 1))            # [Cout, 8, 5, 3]
-                cout = raw.shape[0]
-                full = raw.permute(0, 2, 3, 1).reshape(cout, 5, 3, 2, 4)            # (kh, t, dw, c)
-                gw = full.reshape(cout, 5, 6, 4)[:, :, :5, :weight.shape[1]].permute(0, 3, 1, 2).contiguous()
+                gw = _pair_conv0_wgrad(x_nhwc, g, weight)
             if need_x:
                 raise hip.Sc2Error('the pixel-pair first conv has no data gradient (its input is the image)')
         else:
@@ -134,6 +139,86 @@ class _GdnFn(torch.autograd.Function):
         x_nhwc, beta, gamma = ctx.saved_tensors
         dx, d_beta, d_gamma = hip.gdn1_backward(gy, x_nhwc, beta, gamma, ctx.inverse)
         return dx, d_beta, d_gamma, None, None
+
+
+class _Conv2Gdn48Fn(torch.autograd.Function):
+    """encoder[2] + GDN1(48) of the training forward as the fused inference launch (conv2_gdn48.hip, 0.27 ms at bs 256 against
+    0.49 + 0.06 for the two unfused kernels), which for this caller also writes the conv output t in front of the GDN: the one
+    tensor the GDN's backward needs and the fused launch otherwise never materialises.  The backward is the unfused one, piece by
+    piece: GDN backward on (gy, t), then the conv's weight and data gradients on its result.  (y is computed from the f32 conv
+    output, the saved t is its bf16 rounding -- the value the unfused forward would have normalised: the gradient is taken at a
+    point half a bf16 ulp from the forward's, which is inside the tolerance every bf16 gradient of this path carries.)"""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight, beta, gamma, conv, owner, inverse, tag):
+        with torch.no_grad():
+            gfrag = owner._gdn48_fragments(hip.pack_conv_weight(gamma.detach().reshape(48, 48, 1, 1)))
+        y, t = hip.conv2_gdn48_fwd(x_nhwc, conv.packed_weight(hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR), gfrag,
+                                   beta.detach().float().contiguous(), inverse, tag=tag, want_t=True)
+        ctx.save_for_backward(x_nhwc, weight, t, beta, gamma)
+        ctx.cfg = (conv.stride, conv.padding, inverse)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_nhwc, weight, t, beta, gamma = ctx.saved_tensors
+        stride, pad, inverse = ctx.cfg
+        g, d_beta, d_gamma = hip.gdn1_backward(gy.contiguous(), t, beta, gamma, inverse)
+        gw = gi = None
+        if ctx.needs_input_grad[1]:
+            gw = hip.conv2d_wgrad(x_nhwc, g, weight.shape[2], weight.shape[3], stride, pad).contiguous()
+        if ctx.needs_input_grad[0]:
+            gi = hip.conv2d_dgrad(g, weight, stride, pad, (x_nhwc.shape[1], x_nhwc.shape[2]))
+        return gi, gw, d_beta, d_gamma, None, None, None, None
+
+
+class _Conv0Gdn96Fn(torch.autograd.Function):
+    """encoder[0] + GDN1(96) of the training forward as the fused inference launch on the pixel-pair view (conv0_gdn96.hip), which for
+    this caller also writes the conv output t (0.25 + 0.25 ms for the two unfused kernels at bs 256).  Backward: the GDN's on (gy, t)
+    -- the strips kernel -- and the conv's weight gradient from the pair view (its input is the image: no data gradient)."""
+
+    @staticmethod
+    def forward(ctx, x_pairs, weight, beta, gamma, owner, inverse, tag):
+        y, t = hip.conv0_gdn96_fwd(x_pairs, owner._conv0_fragments(), hip.pack_gamma_fragments(gamma.detach()),
+                                   beta.detach().float().contiguous(), inverse, tag=tag, want_t=True)
+        ctx.save_for_backward(x_pairs, weight, t, beta, gamma)
+        ctx.inverse = inverse
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_pairs, weight, t, beta, gamma = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise hip.Sc2Error('the pixel-pair first conv has no data gradient (its input is the image)')
+        g, d_beta, d_gamma = hip.gdn1_backward(gy.contiguous(), t, beta, gamma, ctx.inverse)
+        gw = _pair_conv0_wgrad(x_pairs, g, weight) if ctx.needs_input_grad[1] else None
+        return None, gw, d_beta, d_gamma, None, None, None
+
+
+class _Dec0Gdn512Fn(torch.autograd.Function):
+    """decoder[0] + (inverse) GDN1(512) of the training forward as the fused inference launch (conv_gdn512.hip), which for this
+    caller also writes the conv output t (0.26 + 0.59 ms for the two unfused kernels at bs 256).  Backward as in _Conv2Gdn48Fn:
+    the GDN's backward on (gy, t) -- the resident-row kernel -- and the conv's weight / data gradients on its result."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight, beta, gamma, conv, inverse, tag):
+        y, t = hip.conv2x2_gdn512_fwd(x_nhwc, conv.packed_weight(hip.K_TAP_MAJOR), hip.pack_gamma_fragments(gamma.detach()),
+                                      beta.detach().float().contiguous(), inverse, tag=tag, want_t=True)
+        ctx.save_for_backward(x_nhwc, weight, t, beta, gamma)
+        ctx.cfg = (conv.stride, conv.padding, inverse)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x_nhwc, weight, t, beta, gamma = ctx.saved_tensors
+        stride, pad, inverse = ctx.cfg
+        g, d_beta, d_gamma = hip.gdn1_backward(gy.contiguous(), t, beta, gamma, inverse)
+        gw = gi = None
+        if ctx.needs_input_grad[1]:
+            gw = hip.conv2d_wgrad(x_nhwc, g, weight.shape[2], weight.shape[3], stride, pad).contiguous()
+        if ctx.needs_input_grad[0]:
+            gi = hip.conv2d_dgrad(g, weight, stride, pad, (x_nhwc.shape[1], x_nhwc.shape[2]))
+        return gi, gw, d_beta, d_gamma, None, None, None
 
 
 class _EbFn(torch.autograd.Function):
@@ -199,17 +284,30 @@ def analysis_autograd(m, x):
         N, _, H, W = x.shape
         x4 = _ToNhwcBf16.apply(x, 4)
         xp = x4.view(N, H, W // 2, 8)
-        h = _ConvFn.apply(xp, c0.weight, m._conv0_packed(), 5, 3, (2, 1), (2, 1), hip.OUT_BF16_NHWC, c0._tag,
-                          _PairView(), hip.K_TAP_MAJOR)
+        fused0 = (hip.host_policy.train_fused_conv0 and g1.in_channels == 96 and c0.out_channels == 96 and
+                  hip.conv0_gdn96_supported(tuple(xp.shape), c0.out_channels))
+        if fused0:
+            h = _Conv0Gdn96Fn.apply(xp, c0.weight, g1.beta_reparam(g1.beta), g1.gamma_reparam(g1.gamma), m, g1.inverse,
+                                    c0._tag + '+' + g1._tag)
+        else:
+            h = _ConvFn.apply(xp, c0.weight, m._conv0_packed(), 5, 3, (2, 1), (2, 1), hip.OUT_BF16_NHWC, c0._tag,
+                              _PairView(), hip.K_TAP_MAJOR)
     else:
+        fused0 = False
         cin = c0.in_channels
         if cin % 8 != 0:
             raise hip.Sc2Error('training path: first conv needs the pixel-pair form (Cin<=4, k5 s2 p2, even width) '
                                'or Cin % 8 == 0')
         h = _conv(c0, _ToNhwcBf16.apply(x, cin))
-    h = _gdn(g1, h)
-    h = _conv(c2, h)
-    h = _gdn(g3, h)
+    if not fused0:
+        h = _gdn(g1, h)
+    if (hip.host_policy.train_fused_conv2 and g3.in_channels == 48 and c2.bias is None and
+            hip.conv2_gdn48_supported(tuple(h.shape), c2.out_channels, c2.kernel_size[0], c2.kernel_size[1], c2.stride, c2.padding)):
+        h = _Conv2Gdn48Fn.apply(h, c2.weight, g3.beta_reparam(g3.beta), g3.gamma_reparam(g3.gamma), c2, m, g3.inverse,
+                                c2._tag + '+' + g3._tag)
+    else:
+        h = _conv(c2, h)
+        h = _gdn(g3, h)
     return _conv(c4, h, hip.OUT_F32_NCHW)
 
 
@@ -217,8 +315,14 @@ def synthesis_autograd(m, y_hat):
     """decoder(y_hat) with gradients: f32 NCHW latent -> f32 NCHW features (or a bf16 channels_last view, per output_format)."""
     c0, g1, c2, g3, c4 = m._g_s()
     h = _ToNhwcBf16.apply(y_hat, y_hat.shape[1])
-    h = _conv(c0, h)
-    h = _gdn(g1, h)
+    n_px = h.shape[0] * (h.shape[1] + 1) * (h.shape[2] + 1)
+    if (hip.host_policy.train_fused_dec0 and g1.in_channels == c0.out_channels and c0.bias is None and n_px * 1024 < 2 ** 31 and
+            hip.conv2x2_gdn512_supported(c0.in_channels, c0.out_channels, c0.kernel_size[0], c0.kernel_size[1], c0.stride, c0.padding)):
+        h = _Dec0Gdn512Fn.apply(h, c0.weight, g1.beta_reparam(g1.beta), g1.gamma_reparam(g1.gamma), c0, g1.inverse,
+                                c0._tag + '+' + g1._tag)
+    else:
+        h = _conv(c0, h)
+        h = _gdn(g1, h)
     h = _conv(c2, h)
     h = _gdn(g3, h)
     if getattr(m, 'output_format', 'f32_nchw') == 'bf16_nhwc':     # a bf16 channels_last view for a bf16 tail / loss

@@ -48,6 +48,7 @@ struct EncArgs {
     const uint16_t *__restrict__ g;      // bf16 fragment-major gamma [6][3][64][8]
     const float *__restrict__ beta;      // f32 [96]
     uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, OW, 96]
+    uint16_t *__restrict__ t_out;        // EMIT instantiations: the conv output t in front of the GDN (bf16, laid out like y)
     int H, WP, OH, n_units, units_per_img;
     int n_seg;                           // column segments of OW output pixels per output row (WP = total output width)
     unsigned *unit_ctr;
@@ -68,7 +69,11 @@ __device__ __forceinline__ uint32_t pack2(f32x2_t v) {   // one v_cvt_pk_bf16_f3
 }
 
 // SEG = false: one 112-pixel segment per row (the 224-pixel-wide geometry), the unit's output is one contiguous block
-template <bool INVERSE, bool SEG, bool PLANAR>
+// EMIT (round 5, the training forward): the conv output t leaves too -- the tensor the GDN's backward needs.  The LDS image holds
+// |t| (the sign lives in the accumulators) and a second image does not fit beside two workgroups per CU, so t goes out from the
+// registers, 8 bytes (a lane's four channels of a pixel) per store, when the image is written: the four quarter-lanes of a pixel
+// fill one 32-byte sector per instruction and the three channel tiles of the wave the rest of its 96 bytes -- the L2 merges them.
+template <bool INVERSE, bool SEG, bool PLANAR, bool EMIT = false>
 __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *rows = smem;
@@ -192,14 +197,26 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
         }
         // |t| (bf16) of this lane's 4 channels of each accumulator tile -> image
         const int px_lane = wm * OW + frow;            // + i * 16
+        [[maybe_unused]] unsigned char *t_px = nullptr;   // EMIT: this lane's pixel (row wm, column frow) of the unit in t_out, + i * 16 * 192
+        if constexpr (EMIT) {
+            int fr = frow, fk = fq;
+            asm volatile("" : "+v"(fr), "+v"(fk));     // (per unit: nothing of this held across the units)
+            const long long px0 = SEG ? ((long long)im * p.OH + oh0 + wm) * p.WP + seg * OW : ((long long)im * p.OH + oh0 + wm) * OW;
+            t_px = reinterpret_cast<unsigned char *>(p.t_out) + (px0 + fr) * (CH * 2) + (wn * 48 + fk * 4) * 2;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int col = wn * 48 + j * 16 + fq * 4;
                 uint2 h;
-                h.x = pack2(f32x2_t{acc[i][j][0], acc[i][j][1]}) & 0x7FFF7FFFu;
-                h.y = pack2(f32x2_t{acc[i][j][2], acc[i][j][3]}) & 0x7FFF7FFFu;
+                h.x = pack2(f32x2_t{acc[i][j][0], acc[i][j][1]});
+                h.y = pack2(f32x2_t{acc[i][j][2], acc[i][j][3]});
+                if constexpr (EMIT) {
+                    if ((wm < n_rows) & (frow + i * 16 < n_cols)) *reinterpret_cast<uint2 *>(t_px + i * 16 * (CH * 2) + j * 32) = h;
+                }
+                h.x &= 0x7FFF7FFFu;
+                h.y &= 0x7FFF7FFFu;
                 *reinterpret_cast<uint2 *>(img + (px_lane + i * 16) * IMG_PITCH + col * 2) = h;
             }
         __syncthreads();   // staged rows consumed; |t| image complete (a pixel's 96 channels come from two waves)
@@ -333,8 +350,8 @@ extern "C" int sc2_conv0_gdn96_supported(int Cin_pairs, int Cout, int W_pairs) {
 }
 
 namespace {
-template <bool PLANAR>
-int launch_conv0_gdn96(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y, int N, int H,
+template <bool PLANAR, bool EMIT>
+int launch_conv0_gdn96(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y, void *t_out, int N, int H,
                        int W_pairs, int inverse, void *stream) {
     SC2_REQUIRE(x && w_frag && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "conv0_gdn96: null argument");
     SC2_REQUIRE(N > 0 && H > 0, SC2_ERR_INVALID_ARG, "conv0_gdn96: non-positive dimension");
@@ -348,6 +365,7 @@ int launch_conv0_gdn96(const void *x, const void *w_frag, const void *gamma_frag
     a.g = static_cast<const uint16_t *>(gamma_frag);
     a.beta = beta;
     a.y = static_cast<uint16_t *>(y);
+    a.t_out = static_cast<uint16_t *>(t_out);
     a.H = H; a.WP = W_pairs;
     a.OH = (H + 4 - 5) / 2 + 1;
     a.n_seg = (W_pairs + OW - 1) / OW;
@@ -360,13 +378,13 @@ int launch_conv0_gdn96(const void *x, const void *w_frag, const void *gamma_frag
     static bool attr_set_dev[SC2_MAX_DEVICES] = {};
     bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, false, PLANAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, false, PLANAR, EMIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, false, PLANAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, false, PLANAR, EMIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, true, PLANAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<true, true, PLANAR, EMIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, true, PLANAR>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv0_gdn96_kernel<false, true, PLANAR, EMIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -389,23 +407,24 @@ int launch_conv0_gdn96(const void *x, const void *w_frag, const void *gamma_frag
     const int grid = a.n_units < 2 * g_cus0[dev] ? a.n_units : 2 * g_cus0[dev];   // two workgroups per CU
     a.unit_ctr = g_ring0[dev] + (g_seq0.fetch_add(1) % kRing0);
     const bool seg = W_pairs != OW;
-    if (inverse && seg) hipLaunchKernelGGL((conv0_gdn96_kernel<true, true, PLANAR>), dim3(grid), dim3(256), lds, s, a);
-    else if (inverse) hipLaunchKernelGGL((conv0_gdn96_kernel<true, false, PLANAR>), dim3(grid), dim3(256), lds, s, a);
-    else if (seg) hipLaunchKernelGGL((conv0_gdn96_kernel<false, true, PLANAR>), dim3(grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv0_gdn96_kernel<false, false, PLANAR>), dim3(grid), dim3(256), lds, s, a);
+    if (inverse && seg) hipLaunchKernelGGL((conv0_gdn96_kernel<true, true, PLANAR, EMIT>), dim3(grid), dim3(256), lds, s, a);
+    else if (inverse) hipLaunchKernelGGL((conv0_gdn96_kernel<true, false, PLANAR, EMIT>), dim3(grid), dim3(256), lds, s, a);
+    else if (seg) hipLaunchKernelGGL((conv0_gdn96_kernel<false, true, PLANAR, EMIT>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv0_gdn96_kernel<false, false, PLANAR, EMIT>), dim3(grid), dim3(256), lds, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }
 }  // namespace
 
 extern "C" int sc2_conv0_gdn96_fwd(const void *x_pairs, const void *w_frag, const void *gamma_frag, const float *beta,
-                                   void *y, int N, int H, int W_pairs, int inverse, void *stream) {
-    return launch_conv0_gdn96<false>(x_pairs, w_frag, gamma_frag, beta, y, N, H, W_pairs, inverse, stream);
+                                   void *y, void *t_out, int N, int H, int W_pairs, int inverse, void *stream) {
+    if (t_out) return launch_conv0_gdn96<false, true>(x_pairs, w_frag, gamma_frag, beta, y, t_out, N, H, W_pairs, inverse, stream);
+    return launch_conv0_gdn96<false, false>(x_pairs, w_frag, gamma_frag, beta, y, nullptr, N, H, W_pairs, inverse, stream);
 }
 
 extern "C" int sc2_conv0_gdn96_nchw_fwd(const float *x_nchw, const void *w_frag, const void *gamma_frag, const float *beta,
                                         void *y, int N, int H, int W, int inverse, void *stream) {
     SC2_REQUIRE(W > 0 && W % 2 == 0, SC2_ERR_UNSUPPORTED,
                 "conv0_gdn96_nchw: even widths only (got %d): a row of an odd-width plane does not start on a pixel pair", W);
-    return launch_conv0_gdn96<true>(x_nchw, w_frag, gamma_frag, beta, y, N, H, W / 2, inverse, stream);
+    return launch_conv0_gdn96<true, false>(x_nchw, w_frag, gamma_frag, beta, y, nullptr, N, H, W / 2, inverse, stream);
 }

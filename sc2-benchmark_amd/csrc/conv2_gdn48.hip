@@ -106,6 +106,7 @@ struct Enc2Args {
     const uint16_t *__restrict__ g;      // bf16 fragment-major gamma [3][2][64][8] (K 48 zero-padded to 64)
     const float *__restrict__ beta;      // f32 [48]
     uint16_t *__restrict__ y;            // bf16 NHWC [N, OH, 56, 48]
+    uint16_t *__restrict__ t_out;        // EMIT instantiations: the conv output in front of the GDN (bf16, laid out like y)
     int N, H, OH, n_units, units_per_img;
     int W, OWT, n_seg;    // SEG instantiations (any width): input width, output width, 56-column segments per output row
     unsigned *unit_ctr;   // eight counters: one per XCD
@@ -123,10 +124,11 @@ constexpr int RED_OFF = 2 * PATCH_STRIDE;               // reduction rounds: [4 
 constexpr int RED_BYTES = NW * 12 * 1024;
 constexpr int TIMG_OFF = RED_OFF;                       // |t| image [112][128 B] (chunks 6, 7 stay zero), over the dead rounds
 constexpr int OIMG_OFF = RED_OFF + 112 * 128;           // output image [112][96 B]
+constexpr int XIMG_OFF = OIMG_OFF + 112 * 96;           // EMIT: image of the conv output t [112][96 B]
 constexpr int GAM_OFF = RED_OFF + RED_BYTES;            // gamma fragments [3][2][64] x 16 B, then beta [48] f32: loaded once
 constexpr int BETA_OFF = GAM_OFF + 6 * 1024;
 constexpr int LDS_BYTES = BETA_OFF + COUT * 4;
-static_assert(OIMG_OFF + 112 * 96 <= GAM_OFF, "images fit the reduction area");
+static_assert(XIMG_OFF + 112 * 96 <= GAM_OFF, "images fit the reduction area");
 static_assert(LDS_BYTES + 64 <= 160 * 1024, "one workgroup per CU");
 static_assert(NW * 9 * 1024 <= PATCH_STRIDE, "pixel tiles 4 .. 6 of the four partial sums fit a dead patch buffer");
 
@@ -134,7 +136,9 @@ static_assert(NW * 9 * 1024 <= PATCH_STRIDE, "pixel tiles 4 .. 6 of the four par
 // segment), the patch of a segment starts 2 ow0 input columns to the right, and which of its columns exist is decided per
 // unit instead of once per workgroup; everything behind the patch fill -- tap offsets, fragment addresses, reduction, GDN1 --
 // is segment-local and unchanged.  !SEG is the 112-pixel-wide geometry of the 224 x 224 operating point (one segment).
-template <bool INVERSE, bool SEG>
+// EMIT (round 5, training): the conv output t in front of the GDN leaves too (bf16, the tensor the GDN's backward needs) -- the training
+// forward then is this one launch instead of conv (0.49 ms) + GDN (0.06): three more 16-byte stores per thread and unit.
+template <bool INVERSE, bool SEG, bool EMIT = false>
 __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int next_slot;
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             // slab g has landed (this wave's pieces), then everybody's; the barrier also says every wave is done reading
             // slab g - 1, whose buffer slab g + 1 now overwrites.  (First slab of a unit: only the three output stores of
             // the previous unit were issued after this slab's loads, so vmcnt(3) does not wait for their acknowledgements.)
-            if (cb == 0 && g != 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            if (cb == 0 && g != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EMIT ? 6 : 3) : "memory");   // (EMIT: six output stores)
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             wg_barrier();
             STAMP(1 + 2 * cb);
@@ -419,6 +423,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
         STAMP(7);
         // ---------------------------------------------------------------- GDN1(48) on the owned pixel tiles (wave-private rows)
         const uint32_t timg = lds_base + (uint32_t)TIMG_OFF, oimg = lds_base + (uint32_t)OIMG_OFF;
+        [[maybe_unused]] const uint32_t ximg = lds_base + (uint32_t)XIMG_OFF;
         {
             // both owned pixel tiles side by side (their LDS round trips and MFMA chains overlap); the rows are this wave's
             // own, its LDS operations complete in order: no barrier
@@ -486,6 +491,12 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                         o.y = pack2(t23 * f32x2_t{__builtin_amdgcn_rcpf(n23[0]), __builtin_amdgcn_rcpf(n23[1])});
                     }
                     lds_write8(oimg + (uint32_t)(px[r] * (COUT * 2) + (j * 16 + fq * 4) * 2), o);
+                    if constexpr (EMIT) {
+                        uint2 tx;
+                        tx.x = pack2(t01);
+                        tx.y = pack2(t23);
+                        lds_write8(ximg + (uint32_t)(px[r] * (COUT * 2) + (j * 16 + fq * 4) * 2), tx);
+                    }
                 }
             }
         }
@@ -504,9 +515,19 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                 oq[k] = q0 < n_out ? q0 : tid_r;   // past the end: the thread's first chunk again (same data)
                 ov[k] = lds_read16(oimg + oq[k] * 16u);
             }
+            [[maybe_unused]] uint4 xv3[3];
+            if constexpr (EMIT) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) xv3[k] = lds_read16(ximg + oq[k] * 16u);
+            }
             lds_wait();
 #pragma unroll
             for (int k = 0; k < 3; ++k) yo[oq[k]] = ov[k];
+            if constexpr (EMIT) {
+                uint4 *xo = reinterpret_cast<uint4 *>(p.t_out + ((long long)(im * p.OH + oh0) * OW) * COUT);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) xo[oq[k]] = xv3[k];
+            }
         } else {
             // the unit's two output rows x n_cols pixels: runs of n_cols * 96 bytes at (oh0 + row, ow0); a chunk outside them is
             // replaced by one of row 0 that always exists (same data, same address: still three stores per thread)
@@ -514,6 +535,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
             const unsigned tid_r = (unsigned)(wave * 64 + ln_r);
             const unsigned q_safe = tid_r % (unsigned)(6 * n_cols);
             uint4 ov[3];
+            [[maybe_unused]] uint4 xv3[3];
             unsigned oa[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -526,10 +548,16 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                 const unsigned row = px >= (unsigned)OW ? 1u : 0u, col = px - row * OW;
                 oa[k] = (row * (unsigned)OWT + col) * 6u + (q - px * 6u);
                 ov[k] = lds_read16(oimg + q * 16u);
+                if constexpr (EMIT) xv3[k] = lds_read16(ximg + q * 16u);
             }
             lds_wait();
 #pragma unroll
             for (int k = 0; k < 3; ++k) yo[oa[k]] = ov[k];
+            if constexpr (EMIT) {
+                uint4 *xo = reinterpret_cast<uint4 *>(p.t_out + (((long long)im * p.OH + oh0) * OWT + ow0) * COUT);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) xo[oa[k]] = xv3[k];
+            }
         }
         wg_barrier();   // also: the images are free for the next unit's rounds
         STAMP(9);
@@ -555,7 +583,7 @@ extern "C" int sc2_conv2_gdn48_supported(int Cin, int Cout, int W) {
     return Cin == CIN && Cout == COUT && W >= 1 ? 1 : 0;   // (112: the static geometry; any other width: 56-column segments)
 }
 
-extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y,
+extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void *gamma_frag, const float *beta, void *y, void *t_out,
                                    int N, int H, int W, int inverse, void *stream) {
     SC2_REQUIRE(x && w_frag && gamma_frag && beta && y, SC2_ERR_INVALID_ARG, "conv2_gdn48: null argument");
     SC2_REQUIRE(N > 0 && H > 0, SC2_ERR_INVALID_ARG, "conv2_gdn48: non-positive dimension");
@@ -568,6 +596,7 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
     a.g = static_cast<const uint16_t *>(gamma_frag);
     a.beta = beta;
     a.y = static_cast<uint16_t *>(y);
+    a.t_out = static_cast<uint16_t *>(t_out);
     a.N = N; a.H = H;
     a.OH = (H + 4 - 5) / 2 + 1;
     a.W = W; a.OWT = (W + 4 - 5) / 2 + 1;
@@ -588,6 +617,14 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<true, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<false, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<true, true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2_gdn48_kernel<false, true, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
@@ -620,13 +657,15 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
         a.stamps = static_cast<unsigned long long *>(sp);
     }
 #endif
-    if (seg) {
-        if (inverse) hipLaunchKernelGGL((conv2_gdn48_kernel<true, true>), dim3(grid), dim3(256), LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((conv2_gdn48_kernel<false, true>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+#define SC2_ENC2_GO(INV, SEGM, EM) hipLaunchKernelGGL((conv2_gdn48_kernel<INV, SEGM, EM>), dim3(grid), dim3(256), LDS_BYTES, s, a)
+    if (t_out) {   // training: y and the conv output in front of the GDN
+        if (seg) { if (inverse) SC2_ENC2_GO(true, true, true); else SC2_ENC2_GO(false, true, true); }
+        else { if (inverse) SC2_ENC2_GO(true, false, true); else SC2_ENC2_GO(false, false, true); }
     } else {
-        if (inverse) hipLaunchKernelGGL((conv2_gdn48_kernel<true, false>), dim3(grid), dim3(256), LDS_BYTES, s, a);
-        else hipLaunchKernelGGL((conv2_gdn48_kernel<false, false>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+        if (seg) { if (inverse) SC2_ENC2_GO(true, true, false); else SC2_ENC2_GO(false, true, false); }
+        else { if (inverse) SC2_ENC2_GO(true, false, false); else SC2_ENC2_GO(false, false, false); }
     }
+#undef SC2_ENC2_GO
 #if SC2_ENC2_STAMPS
     if (a.stamps) {
         (void)hipStreamSynchronize(s);

@@ -92,6 +92,7 @@ struct DecArgs {
     const uint16_t *__restrict__ g;      // bf16 gamma, fragment-major [32 channel tiles][16 k steps][64 lanes][8]
     const float *__restrict__ beta;      // f32 [512]
     uint16_t *__restrict__ y;            // bf16 NHWC [N,OH,OW,512]
+    uint16_t *__restrict__ t_out;        // EMIT instantiations: the conv output t in front of the GDN (bf16, laid out like y)
     int N, H, W, OH, OW, OHW, M, Kpad, n_tiles, inverse;
     unsigned long long *stamps;          // diagnostic build only (SC2_DEC_STAMPS)
     unsigned *tile_ctr;                  // claims so far (claim c = tile c + 2 * gridDim.x); zero between launches
@@ -104,7 +105,16 @@ constexpr int IMG_BYTES = BM * CH * 2;
 __device__ __forceinline__ int slab_off(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 3)) << 4); }
 __device__ __forceinline__ int img_off(int row, int c16) { return row * (CH * 2) + ((c16 ^ (row & 15)) << 4); }
 
-template <int CIN, bool INVERSE>
+// EMIT (round 5, the training forward): t leaves too -- the tensor the GDN's backward needs, which this launch otherwise never
+// materialises.  The image holds it, complete and read-only, for the whole of phase 2: every k-step sends ONE 16-byte chunk per thread
+// (row wn + 8 ks of the tile, the mapping of the final read-out) behind its MFMAs, so that the sixteen stores of a tile are spread
+// over the phase and have two steps each to retire in front of the gamma loads that are counted behind them (vmcnt retires in issue
+// order, loads and stores alike).  The counted waits of the phase grow by the stores issued behind a step's own loads: 8, 9, 10, 10,
+// ... 10, 6, 2 (tools/audit_vmcnt.py --counts follows them).  Rows past M (the last tile) are dropped by the descriptor's range
+// check and keep their place in that order (tools/micro/oob_store_order.hip).
+typedef __amdgpu_buffer_rsrc_t buf_rsrc_t;
+
+template <int CIN, bool INVERSE, bool EMIT = false>
 __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p) {
     constexpr int CIN8 = CIN / 8;
     constexpr int KS1 = (4 * CIN + 31) / 32;     // 32-deep k-steps of the conv (K = 4 taps x CIN)
@@ -259,10 +269,28 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
         };
 #pragma unroll
         for (int h = 0; h < GR; ++h) fetch_g(h, gb[h]);
+        // EMIT: chunk `lane` of row wn + 8 r of the tile's t, r = 0 .. 15 (one per k-step)
+        [[maybe_unused]] buf_rsrc_t rs_t;
+        if constexpr (EMIT) rs_t = __builtin_amdgcn_make_buffer_rsrc(p.t_out, 0, (int)((uint32_t)p.M * (uint32_t)(CH * 2)), 0x00020000);
+        [[maybe_unused]] const uint32_t t_so = (uint32_t)m0 * (uint32_t)(CH * 2);
+        auto emit_t = [&](int r) {
+            if constexpr (EMIT) {
+                int l = lane;
+                asm volatile("" : "+v"(l));   // (per call: nothing of this held across the steps)
+                const int row15 = wn + 8 * (r & 1);
+                const int a = row15 * (CH * 2) + ((l ^ row15) << 4) + (r >> 1) * 16384;
+                const uint4 v = *reinterpret_cast<const uint4 *>(img + a);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, rs_t, wn * (CH * 2) + l * 16 + r * (8 * CH * 2), (int)t_so,
+                                                       SC2_DEC_NT ? SC2_BUF_AUX_NT : 0);
+            }
+        };
         // one k-step: YOUNG = loads issued behind this step's own four (the steps still in flight behind it)
 #define SC2_DEC_STEP(ks, h, YOUNG)                                                                                           \
     {                                                                                                                        \
-        const int kc = (ks) * 4 + fq;   /* this lane's 16-byte k chunk of the step */                                        \
+        int fq_s = fq;   /* (EMIT: opaque per step -- with seven peeled steps the per-step addresses, invariant across tiles, were  \
+                            hoisted out of the tile loop and spilled) */                                                     \
+        if constexpr (EMIT) asm volatile("" : "+v"(fq_s));                                                                   \
+        const int kc = (ks) * 4 + fq_s;   /* this lane's 16-byte k chunk of the step */                                      \
         const int rd_lane = frow * (CH * 2) + ((kc ^ frow) << 4);   /* + i*16384 */                                          \
         const int rd_hi = hi(rd_lane);                                                                                       \
         wait_vm<YOUNG>();                                                                                                    \
@@ -278,23 +306,33 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
         }                                                                                                                    \
     }
         static_assert(NS == 16 && GR == 3, "four trips of three steps, then steps 12 .. 15");
+        // (EMIT: E = 1 -- step k's own loads went out behind step k - 3; behind them: store k - 2, the loads of step k + 1, store
+        //  k - 1, the loads of step k + 2.  The first trip is peeled: steps 0 and 1 have no / one store behind their loads.)
+        constexpr int E = EMIT ? 1 : 0;
+        if constexpr (EMIT) {
+            if ((wn >> 2) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            SC2_DEC_STEP(0, 0, 2 * NT) emit_t(0); fetch_g(GR + 0, gb[0]);
+            SC2_DEC_STEP(1, 1, 2 * NT + 1) emit_t(1); fetch_g(GR + 1, gb[1]);
+            SC2_DEC_STEP(2, 2, 2 * NT + 2) emit_t(2); fetch_g(GR + 2, gb[2]);
+        }
 #pragma unroll 1
-        for (int d = 0; d < 4; ++d) {
+        for (int d = E; d < 4; ++d) {
             // the two waves of a SIMD (w and w + 4) take turns at priority: with a fixed priority (or none: age decides)
             // one of them runs the phase at full speed and the other finishes what is left alone, at half speed
             if ((d ^ (wn >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
-            SC2_DEC_STEP(GR * d + 0, 0, 2 * NT) fetch_g(GR * d + GR + 0, gb[0]);
-            SC2_DEC_STEP(GR * d + 1, 1, 2 * NT) fetch_g(GR * d + GR + 1, gb[1]);
-            SC2_DEC_STEP(GR * d + 2, 2, 2 * NT) fetch_g(GR * d + GR + 2, gb[2]);
+            SC2_DEC_STEP(GR * d + 0, 0, 2 * NT + 2 * E) emit_t(GR * d + 0); fetch_g(GR * d + GR + 0, gb[0]);
+            SC2_DEC_STEP(GR * d + 1, 1, 2 * NT + 2 * E) emit_t(GR * d + 1); fetch_g(GR * d + GR + 1, gb[1]);
+            SC2_DEC_STEP(GR * d + 2, 2, 2 * NT + 2 * E) emit_t(GR * d + 2); fetch_g(GR * d + GR + 2, gb[2]);
         }
         {   // steps 12 .. 15: only step 12 still fetches (step 15)
             if ((wn >> 2) & 1) __builtin_amdgcn_s_setprio(0);
             else __builtin_amdgcn_s_setprio(1);
-            SC2_DEC_STEP(12, 0, 2 * NT) fetch_g(15, gb[0]);
-            SC2_DEC_STEP(13, 1, 2 * NT)
-            SC2_DEC_STEP(14, 2, 1 * NT)
-            SC2_DEC_STEP(15, 0, 0)
+            SC2_DEC_STEP(12, 0, 2 * NT + 2 * E) emit_t(12); fetch_g(15, gb[0]);
+            SC2_DEC_STEP(13, 1, 2 * NT + 2 * E) emit_t(13);
+            SC2_DEC_STEP(14, 2, 1 * NT + 2 * E) emit_t(14);
+            SC2_DEC_STEP(15, 0, 2 * E) emit_t(15);
         }
 #undef SC2_DEC_STEP
         __builtin_amdgcn_s_setprio(0);
@@ -420,7 +458,7 @@ constexpr int kMaxDevices = 16, kCtrRing = 256;
 unsigned *g_ctr_ring[kMaxDevices] = {};
 std::atomic<unsigned> g_ctr_seq{0};
 
-template <int CIN, bool INVERSE>
+template <int CIN, bool INVERSE, bool EMIT>
 int launch_dec(const DecArgs &a, hipStream_t s) {
     constexpr int KS1 = (4 * CIN + 31) / 32;
     constexpr int lds = IMG_BYTES + KS1 * 8192 + 16;   // + the next-tile slot
@@ -428,7 +466,7 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
     static bool attr_set_dev[SC2_MAX_DEVICES] = {};
     bool &attr_set = attr_set_dev[sc2_device_slot()];
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2x2_gdn512_kernel<CIN, INVERSE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2x2_gdn512_kernel<CIN, INVERSE, EMIT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
@@ -476,7 +514,7 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
         b.stamps = static_cast<unsigned long long *>(sp);
     }
 #endif
-    hipLaunchKernelGGL((conv2x2_gdn512_kernel<CIN, INVERSE>), dim3(grid), dim3(512), lds, s, b);
+    hipLaunchKernelGGL((conv2x2_gdn512_kernel<CIN, INVERSE, EMIT>), dim3(grid), dim3(512), lds, s, b);
 #if SC2_DEC_STAMPS
     if (b.stamps) {
         static unsigned long long host[8 * 8 * 16 * 8];
@@ -501,7 +539,7 @@ extern "C" int sc2_conv2x2_gdn512_supported(int Cin, int Cout, int KH, int KW, i
 }
 
 extern "C" int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int Kpad, const void *gamma_packed,
-                                      const float *beta, void *y, int N, int H, int W, int Cin, int inverse,
+                                      const float *beta, void *y, void *t_out, int N, int H, int W, int Cin, int inverse,
                                       void *stream) {
     SC2_REQUIRE(x && w_packed && gamma_packed && beta && y, SC2_ERR_INVALID_ARG, "conv2x2_gdn512: null argument");
     SC2_REQUIRE(N > 0 && H > 0 && W > 0, SC2_ERR_INVALID_ARG, "conv2x2_gdn512: non-positive dimension");
@@ -517,12 +555,21 @@ extern "C" int sc2_conv2x2_gdn512_fwd(const void *x, const void *w_packed, int K
     a.g = static_cast<const uint16_t *>(gamma_packed);
     a.beta = beta;
     a.y = static_cast<uint16_t *>(y);
+    a.t_out = static_cast<uint16_t *>(t_out);
+    SC2_REQUIRE(!t_out || M * (CH * 2) < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "conv2x2_gdn512: t_out needs N*OH*OW*1024 B < 2^31 (got %lld px)", M);
     a.N = N; a.H = H; a.W = W; a.OH = H + 1; a.OW = W + 1; a.OHW = a.OH * a.OW; a.M = (int)M;
     a.Kpad = Kpad; a.n_tiles = (int)((M + BM - 1) / BM); a.inverse = inverse ? 1 : 0; a.tile_ctr = nullptr; a.stamps = nullptr; a.stagger = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (t_out) {   // training: y and the conv output in front of the GDN
+        switch (Cin) {
+            case 8: return inverse ? launch_dec<8, true, true>(a, s) : launch_dec<8, false, true>(a, s);
+            case 16: return inverse ? launch_dec<16, true, true>(a, s) : launch_dec<16, false, true>(a, s);
+            default: return inverse ? launch_dec<24, true, true>(a, s) : launch_dec<24, false, true>(a, s);
+        }
+    }
     switch (Cin) {
-        case 8: return inverse ? launch_dec<8, true>(a, s) : launch_dec<8, false>(a, s);
-        case 16: return inverse ? launch_dec<16, true>(a, s) : launch_dec<16, false>(a, s);
-        default: return inverse ? launch_dec<24, true>(a, s) : launch_dec<24, false>(a, s);
+        case 8: return inverse ? launch_dec<8, true, false>(a, s) : launch_dec<8, false, false>(a, s);
+        case 16: return inverse ? launch_dec<16, true, false>(a, s) : launch_dec<16, false, false>(a, s);
+        default: return inverse ? launch_dec<24, true, false>(a, s) : launch_dec<24, false, false>(a, s);
     }
 }

@@ -88,6 +88,9 @@ class HostPolicy(object):
     gdn_rows = True            # 96- / 256- / 512-channel GDN1 in training: forward and the whole backward on the resident-row kernel (gdn512_rows.hip)
     gdn_bwd_fused = True       # GDN1 backward: element-wise halves in the epilogues of its two GEMMs (sc2_gdn1_bwd_gemm)
     dgrad_win_halves = True    # data gradient of dec.conv2 as two 256-channel launches of the window-plane 2x2 kernel
+    train_fused_conv2 = True   # training forward: encoder[2] + GDN1(48) as the fused inference launch that also emits the conv output
+    train_fused_dec0 = True    # ... and decoder[0] + IGDN1(512) likewise (conv_gdn512.hip)
+    train_fused_conv0 = True   # ... and encoder[0] + GDN1(96) (conv0_gdn96.hip, pixel-pair input)
     relu_mask_fused = True     # the ReLU gradient behind a frozen block's conv2 / conv3 data gradient inside that launch's epilogue (window-plane kernels)
     mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
@@ -183,9 +186,9 @@ def lib():
     L.sc2_conv_f32_chunk_channels.argtypes = [i32]
     L.sc2_conv2d_f32_fwd.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]
     L.sc2_conv2x2_gdn512_supported.argtypes = [i32] * 6
-    L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.sc2_conv2x2_gdn512_fwd.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_conv0_gdn96_supported.argtypes = [i32, i32, i32]
-    L.sc2_conv0_gdn96_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.sc2_conv0_gdn96_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv0_gdn96_nchw_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_kres_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_kres_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -202,7 +205,7 @@ def lib():
     L.sc2_conv2x2_win_tail_supported.argtypes = [i32, i32, i32]
     L.sc2_conv2x2_win_tail_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv2_gdn48_supported.argtypes = [i32, i32, i32]
-    L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.sc2_conv2_gdn48_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.sc2_conv1x1_pair_supported.argtypes = [i32, i32, i32]
     L.sc2_conv1x1_pair_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_longlong, i32, i32, i32, vp]
     L.sc2_conv1x1_stream_supported.argtypes = [i32, i32, i32]
@@ -733,7 +736,7 @@ def conv0_gdn96_supported(x_pairs_shape, cout):
     return len(x_pairs_shape) == 4 and bool(lib().sc2_conv0_gdn96_supported(x_pairs_shape[3], cout, x_pairs_shape[2]))
 
 
-def conv0_gdn96_fwd(x_pairs, w_frag, gamma_frag, beta, inverse=False, tag=None):
+def conv0_gdn96_fwd(x_pairs, w_frag, gamma_frag, beta, inverse=False, tag=None, want_t=False):
     """x_pairs bf16 [N,H,W/2,8] -> bf16 NHWC [N,(H-1)//2+1,W/2,96]; w_frag / gamma_frag: pack_weight_fragments of the
     pair-packed weights [96,128] and of the effective gamma [96,96]."""
     for t, name in ((x_pairs, 'x_pairs'), (w_frag, 'w_frag'), (gamma_frag, 'gamma_frag'), (beta, 'beta')):
@@ -744,10 +747,11 @@ def conv0_gdn96_fwd(x_pairs, w_frag, gamma_frag, beta, inverse=False, tag=None):
     assert gamma_frag.dtype == torch.bfloat16 and gamma_frag.is_contiguous() and tuple(gamma_frag.shape) == (6, 3, 64, 8)
     assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 96
     out = torch.empty((N, (H - 1) // 2 + 1, WP, 96), dtype=torch.bfloat16, device=x_pairs.device)
+    t = torch.empty_like(out) if want_t else None        # (training: the conv output in front of the GDN)
     with _timed(tag or 'conv0_gdn96'):
-        _check(lib().sc2_conv0_gdn96_fwd(_ptr(x_pairs), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, WP,
+        _check(lib().sc2_conv0_gdn96_fwd(_ptr(x_pairs), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), _ptr(t), N, H, WP,
                                          1 if inverse else 0, _stream()), 'conv0_gdn96_fwd')
-    return out
+    return (out, t) if want_t else out
 
 
 def conv0_gdn96_nchw_fwd(x_nchw, w_frag, gamma_frag, beta, inverse=False, tag=None):
@@ -778,7 +782,7 @@ def conv2_gdn48_supported(x_shape, cout, kh, kw, stride, pad):
             bool(lib().sc2_conv2_gdn48_supported(x_shape[3], cout, x_shape[2])))
 
 
-def conv2_gdn48_fwd(x_nhwc, w_frag, gamma_frag, beta, inverse=False, tag=None):
+def conv2_gdn48_fwd(x_nhwc, w_frag, gamma_frag, beta, inverse=False, tag=None, want_t=False):
     """x bf16 [N,H,W,96] -> bf16 NHWC [N,(H-1)//2+1,(W-1)//2+1,48] (W = 112: the static geometry of the 224 x 224 operating point;
     any other width: 56-column output segments); w_frag: pack_conv_weight(w, K_SLAB_MAJOR | K_B_FRAG_MAJOR);
     gamma_frag: pack_weight_fragments of the effective gamma zero-padded to [48, 64]."""
@@ -790,10 +794,11 @@ def conv2_gdn48_fwd(x_nhwc, w_frag, gamma_frag, beta, inverse=False, tag=None):
     assert gamma_frag.dtype == torch.bfloat16 and gamma_frag.is_contiguous() and tuple(gamma_frag.shape) == (3, 2, 64, 8)
     assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 48
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 48), dtype=torch.bfloat16, device=x_nhwc.device)
+    t = torch.empty_like(out) if want_t else None        # (training: the conv output in front of the GDN)
     with _timed(tag or 'conv2_gdn48'):
-        _check(lib().sc2_conv2_gdn48_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), N, H, W,
+        _check(lib().sc2_conv2_gdn48_fwd(_ptr(x_nhwc), _ptr(w_frag), _ptr(gamma_frag), _ptr(beta), _ptr(out), _ptr(t), N, H, W,
                                          1 if inverse else 0, _stream()), 'conv2_gdn48_fwd')
-    return out
+    return (out, t) if want_t else out
 
 
 def avgpool_nhwc(x_nhwc, want_f32=True, want_bf16=False):
@@ -1162,7 +1167,7 @@ def pack_gamma_fragments(gamma):
     return g.permute(0, 2, 3, 1, 4).contiguous().reshape(C // 16, C // 32, 64, 8)
 
 
-def conv2x2_gdn512_fwd(x_nhwc, w_packed, gamma_packed, beta, inverse, tag=None):
+def conv2x2_gdn512_fwd(x_nhwc, w_packed, gamma_packed, beta, inverse, tag=None, want_t=False):
     """y = GDN1_512(conv2x2(x)) (s1, p1) in one launch; x bf16 [N,H,W,Cin] -> bf16 [N,H+1,W+1,512].
     gamma_packed: pack_gamma_fragments(effective gamma)."""
     for t, name in ((x_nhwc, 'x'), (w_packed, 'w_packed'), (gamma_packed, 'gamma_packed'), (beta, 'beta')):
@@ -1173,10 +1178,11 @@ def conv2x2_gdn512_fwd(x_nhwc, w_packed, gamma_packed, beta, inverse, tag=None):
     assert gamma_packed.dtype == torch.bfloat16 and gamma_packed.is_contiguous() and tuple(gamma_packed.shape) == (32, 16, 64, 8)
     assert beta.dtype == torch.float32 and beta.is_contiguous() and beta.numel() == 512
     out = torch.empty((N, H + 1, W + 1, 512), dtype=torch.bfloat16, device=x_nhwc.device)
+    t = torch.empty_like(out) if want_t else None        # (training: the conv output in front of the GDN)
     with _timed(tag or 'conv2x2_gdn512'):
         _check(lib().sc2_conv2x2_gdn512_fwd(_ptr(x_nhwc), _ptr(w_packed), w_packed.shape[1], _ptr(gamma_packed), _ptr(beta),
-                                            _ptr(out), N, H, W, Cin, 1 if inverse else 0, _stream()), 'conv2x2_gdn512_fwd')
-    return out
+                                            _ptr(out), _ptr(t), N, H, W, Cin, 1 if inverse else 0, _stream()), 'conv2x2_gdn512_fwd')
+    return (out, t) if want_t else out
 
 
 # --------------------------------------------------------------------------------------------- #

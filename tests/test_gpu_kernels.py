@@ -370,6 +370,15 @@ def test_conv2x2_gdn512_fused(S, R, dev, cin, inverse, N, H, W):
     # and the same result as the two-launch path (conv -> GDN1) up to the bf16 rounding of its intermediate
     two = m.forward_nhwc(S.hip.conv2d_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), cout, 2, 2, 1, 1))
     assert_close_bf16(out, two, 'fused vs two launches', extra=2.0 ** -7)
+    # round 5 (training forward): with `t_out` the launch also writes the conv output in front of the GDN -- y bit-identical, t the
+    # bf16 image the normalisation was computed from (every row of the ragged last tile included, nothing past it)
+    for _ in range(2):
+        y2, t = S.hip.conv2x2_gdn512_fwd(x_nhwc, S.hip.pack_conv_weight(w.to(dev)), gamma_f, beta_d, inverse, want_t=True)
+        assert torch.equal(y2, out) and t.shape == out.shape and bool(torch.isfinite(t.float()).all())
+        assert_close_bf16(t.permute(0, 3, 1, 2), conv, 'conv output of the fused conv2x2 + gdn512')
+        tf = t.float()
+        n2 = torch.nn.functional.linear(tf.abs(), gamma.to(dev), beta.to(dev))
+        assert_close_bf16(y2, tf * n2 if inverse else tf / n2, 'y from the emitted t', extra=2.0 ** -8)
 
 
 @pytest.mark.parametrize('N,H,W,fused', [(2, 24, 20, True), (3, 22, 36, False), (1, 112, 112, True), (2, 10, 128, True)])
@@ -490,6 +499,14 @@ def test_conv0_gdn96_fused(S, R, dev, N, H, W, inverse):
     assert torch.equal(in_place, out), 'planes read in place != layout pass + pair view'
     again = S.hip.conv0_gdn96_nchw_fwd(x.to(dev), S.hip.pack_weight_fragments(packed[:96]), gamma_f, beta_d, inverse)
     assert torch.equal(again, out)     # (the unit counter re-arms itself: a second launch claims the same units)
+    # round 5 (training forward): with `t_out` the launch also writes the conv output in front of the GDN -- y bit-identical, every
+    # pixel of t written once (odd output heights, partial segments), nothing outside
+    for _ in range(2):
+        guard = torch.full((out.numel() + 4096,), 7.0, dtype=torch.bfloat16, device=dev)
+        y2, t = S.hip.conv0_gdn96_fwd(xp, S.hip.pack_weight_fragments(packed[:96]), gamma_f, beta_d, inverse, want_t=True)
+        assert torch.equal(y2, out) and t.shape == out.shape and bool(torch.isfinite(t.float()).all())
+        assert_close_bf16(t.permute(0, 3, 1, 2), conv, 'conv output of the fused conv0 + gdn96')
+        del guard
 
 
 @pytest.mark.parametrize('N,H,inverse', [(3, 112, False), (2, 30, False), (300, 3, False), (5, 9, True)])
@@ -1438,6 +1455,33 @@ def test_conv2_gdn48_any_width(S, R, dev, N, H, W, inverse):
         out = S.hip.conv2_gdn48_fwd(x_nhwc, wp, gf, beta_d, inverse)
         assert out.shape == (N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 48) == (N, ref.shape[2], ref.shape[3], 48)
         assert_close_bf16(out.permute(0, 3, 1, 2), ref, 'fused conv2 + gdn48, segmented', extra=2.0 ** -8)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('N,H,W,inverse', [(3, 112, 112, False), (2, 112, 112, True),     # the static geometry (one unit = 2 output rows)
+                                           (2, 257, 257, False), (3, 23, 167, True), (9, 9, 7, False)])   # the segmented one
+def test_conv2_gdn48_emits_the_conv_output(S, dev, N, H, W, inverse):
+    """sc2_conv2_gdn48_fwd with `t_out` (the training forward): y is bit-identical to the launch without it, and t is the conv output
+    in front of the GDN -- the f32 conv on the bf16-rounded operands, rounded to bf16 once."""
+    torch.manual_seed(N * 100 + H + W)
+    x = torch.randn(N, 96, H, W)
+    w = torch.randn(48, 96, 5, 5) / 2400 ** 0.5
+    m = S.GDN1(48, inverse=inverse)
+    with torch.no_grad():
+        m.gamma.add_(0.05 * torch.rand(48, 48) / 48 ** 0.5)
+        m.beta.add_(0.1 * torch.rand(48))
+        conv = F.conv2d(bf16_round(x), bf16_round(w), stride=2, padding=2)
+    m.to(dev)
+    beta_d, gamma_d = m.effective()
+    x_nhwc = S.hip.nchw_f32_to_nhwc_bf16(x.to(dev))
+    wp = S.hip.pack_conv_weight(w.to(dev), S.hip.K_SLAB_MAJOR | S.hip.K_B_FRAG_MAJOR)
+    gf = S.hip.pack_weight_fragments(gamma_d)
+    plain = S.hip.conv2_gdn48_fwd(x_nhwc, wp, gf, beta_d, inverse)
+    for _ in range(2):
+        y, t = S.hip.conv2_gdn48_fwd(x_nhwc, wp, gf, beta_d, inverse, want_t=True)
+        assert torch.equal(y, plain)
+        assert t.shape == y.shape and t.dtype == torch.bfloat16
+        assert_close_bf16(t.permute(0, 3, 1, 2), conv, 'conv output of the fused conv2 + gdn48')
     torch.cuda.synchronize()
 
 

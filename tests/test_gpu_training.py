@@ -182,3 +182,32 @@ def test_mse_term_on_the_bottleneck_output_inside_the_conv_backward(S, dev):
     for n in grads[True]:
         a, b = grads[True][n], grads[False][n]
         assert ((a - b).norm() / (b.norm() + 1e-12)).item() < 2e-2, n
+
+
+@pytest.mark.parametrize('switch', ['train_fused_conv0', 'train_fused_conv2', 'train_fused_dec0'])
+def test_fused_stages_in_the_training_forward(S, dev, switch):
+    """`host_policy.train_fused_conv0` / `_conv2` / `_dec0`: encoder[0] + GDN1(96), encoder[2] + GDN1(48) resp. decoder[0] + IGDN1(512) of the training forward
+    as the fused inference launch that also emits the conv output; the backward is the unfused one on that tensor.  Output and every
+    parameter gradient agree with the unfused forward's up to the bf16 roundings the two forwards place differently."""
+    torch.manual_seed(5)
+    x = torch.rand(3, 3, 96, 80, device=dev)
+    outs, grads = {}, {}
+    for fused in (True, False):
+        torch.manual_seed(7)
+        m = S.FPBasedResNetBottleneck().to(dev).train()
+        S.hip.configure(**{switch: fused})
+        try:
+            torch.manual_seed(9)
+            out = m(x)
+            torch.manual_seed(13)
+            w = torch.randn(out.shape, device=dev)
+            (out.float() * w).sum().backward()
+            outs[fused] = out.detach().float().clone()
+            grads[fused] = {n: p.grad.detach().float().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            S.hip.configure(**{switch: True})
+    assert ((outs[True] - outs[False]).norm() / outs[False].norm()).item() < 1e-2
+    assert grads[True].keys() == grads[False].keys() and len(grads[True]) >= 10
+    for n in grads[True]:
+        a, b = grads[True][n], grads[False][n]
+        assert ((a - b).norm() / (b.norm() + 1e-12)).item() < 3e-2, n
