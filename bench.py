@@ -385,7 +385,10 @@ def train_bench(args, dev, rank, world, distributed, emit=True):
                        'gradient_buckets': len(stage.reducer.buckets),
                        'buckets_launched_from_backward_hooks_last_step': stage.reducer.launched_by_hook,
                        'teacher_on_side_stream': bool(S.hip.host_policy.teacher_stream),
-                       'gdn_kernels': 'resident-row (gdn512_rows / gdn96_strips)' if S.hip.host_policy.gdn_rows else 'tile GEMMs'},
+                       'gdn_kernels': 'resident-row (gdn512_rows / gdn96_strips)' if S.hip.host_policy.gdn_rows else 'tile GEMMs',
+                       'fused_forward_stages': [n for n, on in (('enc.conv0+gdn96', S.hip.host_policy.train_fused_conv0),
+                                                                ('enc.conv2+gdn48', S.hip.host_policy.train_fused_conv2),
+                                                                ('dec.conv0+igdn512', S.hip.host_policy.train_fused_dec0)) if on]},
             'final_loss': loss.item(), 'images_all_ranks': g_images, 'mean_loss_all_ranks': g_loss / max(g_images / args.steps, 1.0)})
         if emit:
             print(json.dumps(line))
