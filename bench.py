@@ -409,6 +409,7 @@ def dry_run(args, world, rank, local_rank):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.001 * (1 + rank))      # stands in for a step; ranks differ so that MAX is exercised
+    own_work = time.perf_counter() - t0     # (in front of the closing barrier: what THIS rank took)
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -416,7 +417,7 @@ def dry_run(args, world, rank, local_rank):
     sys.path.insert(0, ROOT)
     from sc2bench_amd.dataparallel import shard_range
     lo, hi = shard_range(args.bs * world, rank, world)
-    info = {'rank': rank, 'local_rank': local_rank, 'seed': rank, 'shard': [lo, hi], 'own_elapsed_s': elapsed}
+    info = {'rank': rank, 'local_rank': local_rank, 'seed': rank, 'shard': [lo, hi], 'own_elapsed_s': elapsed, 'own_work_s': own_work}
     ranks = [info]
     n_ranks = None
     if distributed:

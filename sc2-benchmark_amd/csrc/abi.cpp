@@ -42,6 +42,7 @@ sc2_policy make_default_policy() {
     p.rans_ragged2_waves = 0;   // by stream count (rans.hip)
     p.rans_lut8 = 0;   // measured (round 5, K = 20 / 100 on one box): decode 12.1 -> 12.9 ms / 12.6 -> 13.4 ms with the one-lookup table
     p.rans_dq_lds = 0;
+    p.wgrad_ct = 0;
     return p;
 }
 sc2_policy g_policy = make_default_policy();

@@ -10,7 +10,11 @@
 // read ds_read_b64_tr_b16 (4 rows x 16 columns -> column-major), two reads per 16x16x32 operand fragment.
 //
 // Tile: 128 output channels x 128 k-columns per workgroup (4 waves, 64 x 64 each), reduction in slabs of 32 pixels
-// through a 3-deep LDS ring (same counted-vmcnt / one-barrier-per-slab pipeline as conv_igemm.hip).  The pixel range
+// through a 4-deep LDS ring (counted vmcnt, one barrier per slab; a slab's fragments are read one slab ahead of its MFMAs).
+// Round 5, CT = 256: layers with more than 128 output channels take a 256-channel x 128-column tile (8 waves, one workgroup per CU).
+// The 128 x 128 tile moves 16 KB from L2 into LDS per 64 MFMAs = 64 flop / B: at the ~17 - 19 TB/s the eight L2s deliver into LDS
+// (MI355X_MICROARCH.md, "Indexed rows: gather into LDS") that alone caps the launch at 1.1 - 1.2 PFLOP/s, beside the matrix pipe's own
+// limit (measured 0.78 - 0.87).  256 x 128 moves 24 KB per 128 MFMAs = 85 flop / B.  The pixel range
 // is split over workgroups; partial sums are combined with f32 atomic adds into the (small, pre-zeroed) dW.
 // Bank conflicts: a fragment read touches 8 different pixel rows at one 32-byte column offset; the 16-byte chunk
 // index is XORed with f(row) = 2*((row & 3) + 4*((row >> 3) & 1)) -- applied to the SOURCE address of the
@@ -40,11 +44,27 @@ struct WgradArgs {
     int n_ktiles, n_ctiles;
 };
 
-constexpr int WG_TILE = 128;              // channels / k-columns per tile
-constexpr int WG_ROWB = WG_TILE * 2;      // bytes per pixel row of a slab image
+constexpr int WG_TILE = 128;              // k-columns per tile (and channels per tile of the CT = 128 form)
+constexpr int WG_ROWB = WG_TILE * 2;      // bytes per pixel row of the im2col slab image
 constexpr int WG_SLAB = 32;               // pixels per slab
-constexpr int WG_IMG = WG_SLAB * WG_ROWB; // 8 KB
-constexpr int WG_STAGES = 3;
+constexpr int WG_IMG = WG_SLAB * WG_ROWB; // 8 KB: the im2col image of a slab
+constexpr int WG_STAGES = 4;            // (round 5: four, since a slab's fragments are read one slab ahead of its MFMAs)
+template <int CT>
+struct WgGeo {                            // CT = output channels per tile: 128 (4 waves, two workgroups per CU) or 256 (8 waves, one)
+    static constexpr int NW = CT / 32;                    // waves: (CT / 64) x 2, 64 x 64 each
+    static constexpr int G_ROWB = CT * 2;                 // bytes per pixel row of the dY slab image
+    static constexpr int G_IMG = WG_SLAB * G_ROWB;        // 8 / 16 KB
+    static constexpr int STAGE = WG_IMG + G_IMG;          // a ring stage: [im2col image][dY image]
+    static constexpr int G_RPI = 1024 / G_ROWB;           // dY rows per 1 KB direct-to-LDS instruction (4 / 2)
+    static constexpr int G_CPR = G_ROWB / 16;             // 16-byte chunks per dY row (16 / 32)
+    static constexpr int GJ = G_IMG / (NW * 1024);        // dY instructions per wave and slab (2)
+    static constexpr int AJ = WG_IMG / (NW * 1024);       // im2col instructions per wave and slab (2 / 1)
+    static constexpr int L = GJ + AJ;                     // vector-memory operations per wave and slab
+    static_assert(GJ == 2 && (AJ == 2 || AJ == 1) && (WG_STAGES - 1) * STAGE + WG_IMG + G_IMG <= 160 * 1024, "geometry");
+    // stage bases are ds immediates (16 bits): stages whose images end above 64 KB are addressed from a second base (HI_FROM)
+    static constexpr int HI_FROM = 2;
+    static_assert((HI_FROM - 1) * STAGE + WG_IMG + G_IMG <= 65536 && (WG_STAGES - 1 - HI_FROM) * STAGE + WG_IMG + G_IMG <= 65536, "immediates");
+};
 
 __device__ __forceinline__ int wg_swz(int row) { return 2 * ((row & 3) + 4 * ((row >> 3) & 1)); }
 
@@ -55,8 +75,9 @@ __device__ __forceinline__ uint2 lds_read_tr(uint32_t addr) {   // (stage base a
     return v;
 }
 
-template <bool ABS>   // |x| as the im2col operand (d gamma of GDN1): a compile-time property (16 mask operations per slab otherwise)
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
+template <bool ABS, int CT>   // |x| as the im2col operand (d gamma of GDN1): a compile-time property (16 mask operations per slab otherwise)
+__global__ __launch_bounds__(64 * WgGeo<CT>::NW, CT == 128 ? 2 : 1) void conv_wgrad_kernel(const WgradArgs p) {
+    using G = WgGeo<CT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     const int tid = threadIdx.x;
@@ -75,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const int t = local % tiles;
     if (chunk * p.rows_per_block >= p.M) return;   // (a range past the end, from rounding the range count up)
     const int ctile = t / p.n_ktiles, ktile = t - ctile * p.n_ktiles;
-    const int co0 = ctile * WG_TILE, k0 = ktile * WG_TILE;
+    const int co0 = ctile * CT, k0 = ktile * WG_TILE;
     const int m_begin = chunk * p.rows_per_block;
     const int m_end = min(p.M, m_begin + p.rows_per_block);
     const int n_slabs = (m_end - m_begin + WG_SLAB - 1) / WG_SLAB;
@@ -83,17 +104,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const uint16_t *zero = reinterpret_cast<const uint16_t *>(&g_wzero16);
     const long long zoff_x = zero - p.x, zoff_g = zero - p.gy;
 
-    // direct-to-LDS assignment: wave-instruction q = j*4 + wave covers slab rows [4q, 4q+4); lane l -> row 4q + (l >> 4),
-    // stored chunk l & 15, which holds logical chunk (l & 15) ^ swz(row)
-    int row_j[2], gco_j[2], kh_j[2], kw_j[2], ci_j[2];
-    bool gok_j[2], kok_j[2];
+    // direct-to-LDS assignment.  im2col image (256-byte rows): wave-instruction q = j * NW + wave (j < AJ) covers slab rows
+    // [4q, 4q + 4); lane l -> row 4q + (l >> 4), stored chunk l & 15, which holds logical chunk (l & 15) ^ swz(row).  dY image
+    // (CT * 2-byte rows): instruction q = j * NW + wave (j < 2) covers rows [G_RPI q, G_RPI (q + 1)); lane l -> row G_RPI q +
+    // l / G_CPR, stored chunk l % G_CPR, logical chunk (that) ^ swz(row) (the XOR stays inside a 256-byte half of the row).
+    int arow_j[G::AJ], kh_j[G::AJ], kw_j[G::AJ], ci_j[G::AJ];
+    bool kok_j[G::AJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (j * 4 + wave) * 4 + (lane >> 4);
+    for (int j = 0; j < G::AJ; ++j) {
+        const int row = (j * G::NW + wave) * 4 + (lane >> 4);
         const int c = (lane & 15) ^ wg_swz(row);
-        row_j[j] = row;
-        gco_j[j] = co0 + 8 * c;
-        gok_j[j] = gco_j[j] < p.Cout;
+        arow_j[j] = row;
         const int k = k0 + 8 * c;
         kok_j[j] = k < p.K;
         const int kk = kok_j[j] ? k : 0;
@@ -101,6 +122,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         ci_j[j] = kk - tap * p.Cin;
         kh_j[j] = tap / p.KW;
         kw_j[j] = tap - kh_j[j] * p.KW;
+    }
+    int grow_j[G::GJ], gco_j[G::GJ];
+    bool gok_j[G::GJ];
+#pragma unroll
+    for (int j = 0; j < G::GJ; ++j) {
+        const int row = (j * G::NW + wave) * G::G_RPI + lane / G::G_CPR;
+        const int c = (lane % G::G_CPR) ^ wg_swz(row);
+        grow_j[j] = row;
+        gco_j[j] = co0 + 8 * c;
+        gok_j[j] = gco_j[j] < p.Cout;
     }
 
     // Pixel coordinates of this lane's two slab rows, carried from slab to slab (round 4).  Slabs are issued strictly in order,
@@ -118,11 +149,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     const uint32_t cA = (uint32_t)(p.Cin * (p.W * d_oh * p.SH + d_ow * p.SW) + p.Cin * p.H * p.W * d_img);
     const uint32_t cB = (uint32_t)(p.Cin * (p.W * p.SH - p.OW * p.SW));
     const uint32_t cC = (uint32_t)(p.Cin * (p.H * p.W - p.W * p.OH * p.SH));
-    int m_j[2], oh_j[2], ow_j[2], ih_j[2], iw_j[2];
-    uint32_t goff_j[2], aoff_j[2];
+    int m_j[G::AJ], oh_j[G::AJ], ow_j[G::AJ], ih_j[G::AJ], iw_j[G::AJ];
+    uint32_t aoff_j[G::AJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        m_j[j] = m_begin + row_j[j];
+    for (int j = 0; j < G::AJ; ++j) {
+        m_j[j] = m_begin + arow_j[j];
         const int mm = m_j[j] < p.M ? m_j[j] : 0;      // (rows past the end: coordinates of pixel 0, never used)
         const int img = mm / p.OHW;
         const int rem = mm - img * p.OHW;
@@ -130,26 +161,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
         ow_j[j] = rem - oh_j[j] * p.OW;
         ih_j[j] = oh_j[j] * p.SH - p.PH + kh_j[j];
         iw_j[j] = ow_j[j] * p.SW - p.PW + kw_j[j];
-        goff_j[j] = (uint32_t)(m_j[j] * p.Cout + gco_j[j]);
         aoff_j[j] = (uint32_t)(((img * p.H + ih_j[j]) * p.W + iw_j[j]) * p.Cin + ci_j[j]);
     }
-    auto issue_slab = [&](int buf) {   // the NEXT slab in order
-        unsigned char *Gi = smem + buf * (2 * WG_IMG);
-        unsigned char *Ai = Gi + WG_IMG;
+    int mg_j[G::GJ];
+    uint32_t goff_j[G::GJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool mok = m_j[j] < m_end;
+    for (int j = 0; j < G::GJ; ++j) {
+        mg_j[j] = m_begin + grow_j[j];
+        goff_j[j] = (uint32_t)(mg_j[j] * p.Cout + gco_j[j]);
+    }
+    auto issue_slab = [&](int buf) {   // the NEXT slab in order
+        unsigned char *Ai = smem + buf * G::STAGE;
+        unsigned char *Gi = Ai + WG_IMG;
+#pragma unroll
+        for (int j = 0; j < G::GJ; ++j) {
             // dY operand
-            const bool g_ok = mok & gok_j[j];
+            const bool g_ok = (mg_j[j] < m_end) & gok_j[j];
             const long long goff = g_ok ? (long long)goff_j[j] : zoff_g;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.gy + goff), (lds_ptr_t)(Gi + (j * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.gy + goff), (lds_ptr_t)(Gi + (j * G::NW + wave) * 1024), 16, 0, 0);
+            mg_j[j] += WG_SLAB;
+            goff_j[j] += g_step;
+        }
+#pragma unroll
+        for (int j = 0; j < G::AJ; ++j) {
+            const bool mok = m_j[j] < m_end;
             // im2col operand
             const bool a_ok = mok & kok_j[j] & ((unsigned)ih_j[j] < (unsigned)p.H) & ((unsigned)iw_j[j] < (unsigned)p.W);
             const long long aoff = a_ok ? (long long)aoff_j[j] : zoff_x;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.x + aoff), (lds_ptr_t)(Ai + (j * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.x + aoff), (lds_ptr_t)(Ai + (j * G::NW + wave) * 1024), 16, 0, 0);
             // 32 pixels on
             m_j[j] += WG_SLAB;
-            goff_j[j] += g_step;
             ow_j[j] += d_ow;
             const bool c1 = ow_j[j] >= p.OW;
             ow_j[j] -= c1 ? p.OW : 0;
@@ -178,57 +219,83 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int r = rrow + 4 * h;
-            const int gc = wm * 64 + tt * 16 + 4 * (i16 & 3);   // column inside the 128-wide image
-            const int ac = wn * 64 + tt * 16 + 4 * (i16 & 3);
-            g_rd[tt][h] = lds_base + (uint32_t)(r * WG_ROWB + (((gc >> 3) ^ wg_swz(r)) << 4) + ((gc >> 2) & 1) * 8);
+            const int gc = wm * 64 + tt * 16 + 4 * (i16 & 3);   // column inside the CT-wide dY image
+            const int ac = wn * 64 + tt * 16 + 4 * (i16 & 3);   // ... the 128-wide im2col image
+            g_rd[tt][h] = lds_base + (uint32_t)(r * G::G_ROWB + (((gc >> 3) ^ wg_swz(r)) << 4) + ((gc >> 2) & 1) * 8);
             a_rd[tt][h] = lds_base + (uint32_t)(r * WG_ROWB + (((ac >> 3) ^ wg_swz(r)) << 4) + ((ac >> 2) & 1) * 8);
         }
 
     constexpr uint32_t xmask = 0x7FFF7FFFu;
-    constexpr int S = WG_STAGES, L = 4;
-    static_assert(S == 3, "the slab loop below is unrolled by the ring depth");
-#pragma unroll
-    for (int st = 0; st < S - 1; ++st) issue_slab(st);
-
-    // one slab out of ring stage ST (compile-time: the fragment reads address the stage through an immediate offset)
-    auto slab = [&](auto stage_c) {
-        constexpr int ST = decltype(stage_c)::value;
-        constexpr int GOFF = ST * (2 * WG_IMG), AOFF = GOFF + WG_IMG;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");
-        __builtin_amdgcn_s_barrier();
-        uint2 gv[4][2], av[4][2];
+    constexpr int S = WG_STAGES, L = G::L;
+    static_assert(S == 4, "the slab loop below is unrolled by the ring depth (and by two fragment sets)");
+    // Round 5: a slab's fragments are read from LDS ONE SLAB AHEAD, behind the barrier that publishes it and in front of the previous
+    // slab's MFMAs (two fragment sets): before, a wave read its sixteen fragments, waited for them, and only then issued its sixteen
+    // MFMAs -- the LDS round trip of every slab sat in front of its matrix work, hidden only by whatever the SIMD's other wave was
+    // doing.  Order of a step (slab s in set P, ring stage ST):
+    //     loads of slab s + 3 -> stage (ST + 3) % 4   (last read -- slab s - 1 -- before the previous step's barrier)
+    //     vmcnt(2 L): slab s + 1 has landed;  lgkmcnt(0): the fragments of slab s are in their registers
+    //     barrier:  every wave's part of slab s + 1 is in LDS, and every wave has finished READING slab s
+    //     fragment reads of slab s + 1 -> set P ^ 1;   16 MFMAs on set P
+    // (the fragment registers are written by asm reads the compiler does not track: nothing may touch a set between its reads and
+    //  the lgkmcnt(0) of the next step -- tools/audit_lds_inflight.py follows them through the listing)
+    uint2 gv[2][4][2], av[2][4][2];
+    auto read_frags = [&](auto stage_c, auto set_c) {
+        constexpr int ST = decltype(stage_c)::value, P = decltype(set_c)::value;
+        constexpr int BASE = (ST >= G::HI_FROM ? ST - G::HI_FROM : ST) * G::STAGE;
+        constexpr int AOFF = BASE, GOFF = BASE + WG_IMG;
+        constexpr uint32_t HI = ST >= G::HI_FROM ? (uint32_t)(G::HI_FROM * G::STAGE) : 0u;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                gv[tt][h] = lds_read_tr<GOFF>(g_rd[tt][h]);
-                av[tt][h] = lds_read_tr<AOFF>(a_rd[tt][h]);
+                gv[P][tt][h] = lds_read_tr<GOFF>(g_rd[tt][h] + HI);
+                av[P][tt][h] = lds_read_tr<AOFF>(a_rd[tt][h] + HI);
             }
+    };
+#pragma unroll
+    for (int st = 0; st < S - 1; ++st) issue_slab(st);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");   // slab 0 has landed
+    __builtin_amdgcn_s_barrier();
+    read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+
+    // one slab out of ring stage ST, fragments in set P (compile-time: stage bases are immediates, sets are registers)
+    auto slab = [&](auto stage_c, auto set_c) {
+        constexpr int ST = decltype(stage_c)::value, P = decltype(set_c)::value;
         issue_slab((ST + S - 1) % S);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"((S - 2) * L) : "memory");
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         bf16x8_t gf[4], af[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            gf[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(gv[tt][0].x, gv[tt][0].y, gv[tt][1].x, gv[tt][1].y));
-            if (ABS) af[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(av[tt][0].x & xmask, av[tt][0].y & xmask, av[tt][1].x & xmask,
-                                                                      av[tt][1].y & xmask));
-            else af[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(av[tt][0].x, av[tt][0].y, av[tt][1].x, av[tt][1].y));
+            gf[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(gv[P][tt][0].x, gv[P][tt][0].y, gv[P][tt][1].x, gv[P][tt][1].y));
+            if (ABS) af[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(av[P][tt][0].x & xmask, av[P][tt][0].y & xmask, av[P][tt][1].x & xmask,
+                                                                      av[P][tt][1].y & xmask));
+            else af[tt] = __builtin_bit_cast(bf16x8_t, make_uint4(av[P][tt][0].x, av[P][tt][0].y, av[P][tt][1].x, av[P][tt][1].y));
         }
+        read_frags(std::integral_constant<int, (ST + 1) % S>{}, std::integral_constant<int, P ^ 1>{});
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], af[j], acc[i][j], 0, 0, 0);
     };
-    int sl = 0;
-    for (; sl + S <= n_slabs; sl += S) {
-        slab(std::integral_constant<int, 0>{});
-        slab(std::integral_constant<int, 1>{});
-        slab(std::integral_constant<int, 2>{});
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // whole trips of four slabs, no tail code (a fragment set written in one conditional block and consumed in the next would be a
+    // value the compiler may copy at the join -- in flight): the launcher makes a range a multiple of 128 pixels, and slabs past the
+    // end of the LAST range read the zero line
+#pragma unroll 1
+    for (int sl = 0; sl < n_slabs; sl += S) {
+        slab(I0{}, I0{});
+        slab(I1{}, I1{});
+        slab(I2{}, I0{});
+        slab(I3{}, I1{});
     }
-    if (sl < n_slabs) slab(std::integral_constant<int, 0>{});
-    if (sl + 1 < n_slabs) slab(std::integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the fragment reads of the slab past the last one)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // combine the pixel-range partial sums: f32 atomic adds (dW is small; arrival order varies run to run)
@@ -270,7 +337,9 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     a.OH = OH; a.OW = OW; a.OHW = OH * OW; a.M = (int)M; a.K = d->KH * d->KW * d->Cin;
     a.x_abs = d->a_op == SC2_AOP_ABS;
     a.n_ktiles = (a.K + WG_TILE - 1) / WG_TILE;
-    a.n_ctiles = (a.Cout + WG_TILE - 1) / WG_TILE;
+    // (round 5) more than 128 output channels: the 256-channel tile, 8 waves, one workgroup per CU (policy wgrad_ct: 0 auto, 128: A/B)
+    const int ct = (a.Cout > 128 && sc2_pol().wgrad_ct != 128) ? 256 : 128;
+    a.n_ctiles = (a.Cout + ct - 1) / ct;
     // enough pixel chunks to fill the chip several times over, at least 8 slabs each
     const long long tiles = (long long)a.n_ktiles * a.n_ctiles;
     // workgroups per launch = output tiles x pixel ranges.  Every workgroup ends with 128 x 128 f32 atomic adds, so the pixel split
@@ -280,11 +349,13 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     // (round 5, ranges XCD-local -- tools/wgrad_times.py: four output tiles or fewer want 512 workgroups (igdn3's gamma 0.177 -> 0.152
     //  ms), a single 128-channel tile row with a long K -- enc.conv2, 19 k-tiles -- wants 4 096 (0.63 -> 0.53); the rest is flat
     //  between 1 024 and 2 048)
-    const int wg_auto = tiles <= 4 ? 512 : (a.n_ctiles == 1 ? 4096 : 1024);
+    // (256-channel tiles: one workgroup per CU; a single row of channel tiles -- dec.conv2 / dec.conv4 / igdn3's gamma -- wants one
+    //  round of 256, the 512 x 512 gamma gradient 1 024: profiles/r05k_wgrad_times.txt)
+    const int wg_auto = ct == 256 ? ((tiles <= 2 || a.n_ctiles == 1) ? 256 : 1024) : tiles <= 4 ? 512 : (a.n_ctiles == 1 ? 4096 : 1024);
     const int wg_target = sc2_pol().wgrad_wgs > 0 ? sc2_pol().wgrad_wgs : wg_auto;
     long long chunks = (wg_target + tiles - 1) / tiles;
     long long rows = (M + chunks - 1) / chunks;
-    rows = (rows + WG_SLAB - 1) / WG_SLAB * WG_SLAB;
+    rows = (rows + WG_STAGES * WG_SLAB - 1) / (WG_STAGES * WG_SLAB) * (WG_STAGES * WG_SLAB);   // whole trips of the kernel's slab loop
     if (rows < 8 * WG_SLAB) rows = 8 * WG_SLAB;
     chunks = (M + rows - 1) / rows;
     chunks = (chunks + 7) / 8 * 8;      // the kernel deals the ranges to the eight XCDs
@@ -294,9 +365,29 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)a.Cout * a.K * sizeof(float), s);
     SC2_REQUIRE(e == hipSuccess, SC2_ERR_LAUNCH, "conv2d_wgrad: memset failed: %s", hipGetErrorString(e));
-    const size_t lds = (size_t)WG_STAGES * 2 * WG_IMG;
-    if (a.x_abs) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3((unsigned)grid), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3((unsigned)grid), dim3(256), lds, s, a);
+    if (ct == 256) {
+        constexpr size_t lds = (size_t)WG_STAGES * WgGeo<256>::STAGE;   // 96 KB
+        static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+        bool &attr_set = attr_set_dev[sc2_device_slot()];
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_kernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_kernel<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (a.x_abs) hipLaunchKernelGGL((conv_wgrad_kernel<true, 256>), dim3((unsigned)grid), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<false, 256>), dim3((unsigned)grid), dim3(512), lds, s, a);
+    } else {
+        constexpr size_t lds = (size_t)WG_STAGES * WgGeo<128>::STAGE;   // 64 KB
+        static bool attr_set_dev[SC2_MAX_DEVICES] = {};
+        bool &attr_set = attr_set_dev[sc2_device_slot()];
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_kernel<true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wgrad_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (a.x_abs) hipLaunchKernelGGL((conv_wgrad_kernel<true, 128>), dim3((unsigned)grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<false, 128>), dim3((unsigned)grid), dim3(256), lds, s, a);
+    }
     SC2_CHECK_LAUNCH();
     return SC2_OK;
 }

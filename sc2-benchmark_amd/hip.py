@@ -58,11 +58,11 @@ class Sc2Error(RuntimeError):
 POLICY_FIELDS = ('struct_bytes', 'conv_patch3', 'conv_s2', 'conv_persist', 'conv_half', 'conv_big4', 'conv_no_big', 'conv_force_big',
                  'conv_no_epx', 'conv_debug', 'conv_chunk', 'w2_run', 'win_half', 'win_dbg', 'win_stamps', 'p1_half',
                  'p1_nbuf', 'pair_alt', 'f32_persist0', 'dec_stagger', 'wgrad_wgs', 'rans_lds_pad_kb', 'rans_pad_waves', 'rans_ragged2',
-                 'rans_ragged2_waves', 'rans_lut8', 'rans_dq_lds')
+                 'rans_ragged2_waves', 'rans_lut8', 'rans_dq_lds', 'wgrad_ct')
 
 
 class Policy(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in POLICY_FIELDS] + [('reserved', ctypes.c_int32 * 7)]
+    _fields_ = [(n, ctypes.c_int32) for n in POLICY_FIELDS] + [('reserved', ctypes.c_int32 * 6)]
 
 
 class HostPolicy(object):

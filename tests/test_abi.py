@@ -136,6 +136,11 @@ def test_asm_weight_loads_are_never_copied_in_flight():
                                '--cuda-device-only', '-S', os.path.join(csrc, 'gdn512_rows.hip'), '-o', lst], stderr=subprocess.DEVNULL)
         r4 = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_inflight.py'), lst], capture_output=True, text=True)
     assert r4.returncode == 0 and '0 finding(s)' in r4.stdout, r4.stdout + r4.stderr
+    # the fifth (round 5): conv_wgrad.hip reads a slab's fragments from LDS by asm one slab AHEAD of its MFMAs; the wait is the
+    # `lgkmcnt(0)` of the next step -- nothing may read, copy or overwrite those registers on the way (tools/audit_lds_inflight.py)
+    r5 = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_lds_inflight.py'), os.path.join(csrc, 'conv_wgrad.hip')],
+                        capture_output=True, text=True)
+    assert r5.returncode == 0 and '4 kernel(s)' in r5.stdout and ' 0 finding(s)' in r5.stdout, r5.stdout + r5.stderr
 
 
 def test_hot_path_kernels_use_no_scratch():

@@ -5,12 +5,13 @@ import subprocess
 import sys
 
 SWITCH = sys.argv[1] if len(sys.argv) > 1 else 'train_fused_conv2'
+VALUES = {True: sys.argv[2], False: sys.argv[3]} if len(sys.argv) > 3 else {True: 'True', False: 'False'}   # (e.g. wgrad_ct 0 128)
 res = {True: [], False: []}
 for rep in range(3):
     for fused in (True, False):
         code = ("import sys; sys.argv = ['bench.py', '--mode', 'train', '--steps', '20', '--warmup', '5'];"
                 "import importlib; S = importlib.import_module('sc2bench_amd');"
-                "S.hip.configure({}={}); import runpy; runpy.run_path('bench.py', run_name='__main__')".format(SWITCH, fused))
+                "S.hip.configure({}={}); import runpy; runpy.run_path('bench.py', run_name='__main__')".format(SWITCH, VALUES[fused]))
         out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith('{')]
         if not line:
@@ -18,7 +19,7 @@ for rep in range(3):
             continue
         d = json.loads(line[-1])
         res[fused].append(d['ms_per_step'])
-        print('fused' if fused else 'unfused', round(d['ms_per_step'], 3), 'ms/step', round(d['value']), 'images/s', flush=True)
+        print('{}={}'.format(SWITCH, VALUES[fused]), round(d['ms_per_step'], 3), 'ms/step', round(d['value']), 'images/s', flush=True)
 for k, v in res.items():
     if v:
         print(SWITCH, '=', k, ': min', round(min(v), 3), 'median', round(sorted(v)[len(v) // 2], 3), 'ms per 256-image step')
