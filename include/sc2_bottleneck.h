@@ -83,7 +83,7 @@ typedef struct sc2_policy {
     int32_t rans_ragged2_waves;  /* ... waves per workgroup sharing one table copy: 0 (default) = 1 below 1 024 streams per launch, 2 from there; 1, 2, 4, 8 force */
     int32_t rans_lut8;           /* 1: one-lookup bucketed decode tables for implicit CDF rows (default 0: measured 6 % SLOWER than the two-lookup decoder) */
     int32_t rans_dq_lds;         /* 1: the dequantising last pass of a decode launch through LDS for every channel count (default 0: <= 32 channels transpose in registers, no LDS: fits beside the persistent kernels) */
-    int32_t wgrad_ct;            /* conv_wgrad: 0 (default) = 256-channel tiles for layers with more than 128 output channels; 128 = always the 128 x 128 tile (A/B) */
+    int32_t wgrad_ct;            /* conv_wgrad: 0 (default) = 256-channel tiles for layers with more than 128 output channels, 64-channel tiles for 64 or fewer; 128 = always the 128 x 128 tile (A/B) */
     int32_t reserved[6];
 } sc2_policy;
 void sc2_policy_default(sc2_policy *p);

@@ -49,8 +49,12 @@ constexpr int WG_ROWB = WG_TILE * 2;      // bytes per pixel row of the im2col s
 constexpr int WG_SLAB = 32;               // pixels per slab
 constexpr int WG_IMG = WG_SLAB * WG_ROWB; // 8 KB: the im2col image of a slab
 constexpr int WG_STAGES = 4;            // (round 5: four, since a slab's fragments are read one slab ahead of its MFMAs)
+__device__ __forceinline__ int wg_swz(int row) { return 2 * ((row & 3) + 4 * ((row >> 3) & 1)); }
+// ... of a 128-byte row (the 64-channel dY image, 8 chunks): two rows per 256 bytes of banks, so row parity already separates two of
+// the eight rows a fragment read touches; the XOR spreads the other four: 32-byte slot = (4 row + ((chunk ^ f) >> 1)) mod 8
+__device__ __forceinline__ int wg_swz128(int row) { return 2 * (((row >> 1) & 1) + 2 * ((row >> 3) & 1)); }
 template <int CT>
-struct WgGeo {                            // CT = output channels per tile: 128 (4 waves, two workgroups per CU) or 256 (8 waves, one)
+struct WgGeo {                            // CT = output channels per tile: 64 (2 waves, three workgroups per CU), 128 (4 waves, two) or 256 (8 waves, one)
     static constexpr int NW = CT / 32;                    // waves: (CT / 64) x 2, 64 x 64 each
     static constexpr int G_ROWB = CT * 2;                 // bytes per pixel row of the dY slab image
     static constexpr int G_IMG = WG_SLAB * G_ROWB;        // 8 / 16 KB
@@ -58,15 +62,15 @@ struct WgGeo {                            // CT = output channels per tile: 128 
     static constexpr int G_RPI = 1024 / G_ROWB;           // dY rows per 1 KB direct-to-LDS instruction (4 / 2)
     static constexpr int G_CPR = G_ROWB / 16;             // 16-byte chunks per dY row (16 / 32)
     static constexpr int GJ = G_IMG / (NW * 1024);        // dY instructions per wave and slab (2)
-    static constexpr int AJ = WG_IMG / (NW * 1024);       // im2col instructions per wave and slab (2 / 1)
+    static constexpr int AJ = WG_IMG / (NW * 1024);       // im2col instructions per wave and slab (4 / 2 / 1)
+    static __device__ __forceinline__ int gswz(int row) { return CT == 64 ? wg_swz128(row) : wg_swz(row); }
     static constexpr int L = GJ + AJ;                     // vector-memory operations per wave and slab
-    static_assert(GJ == 2 && (AJ == 2 || AJ == 1) && (WG_STAGES - 1) * STAGE + WG_IMG + G_IMG <= 160 * 1024, "geometry");
+    static_assert(GJ == 2 && (AJ == 4 || AJ == 2 || AJ == 1) && (WG_STAGES - 1) * STAGE + WG_IMG + G_IMG <= 160 * 1024, "geometry");
     // stage bases are ds immediates (16 bits): stages whose images end above 64 KB are addressed from a second base (HI_FROM)
     static constexpr int HI_FROM = 2;
     static_assert((HI_FROM - 1) * STAGE + WG_IMG + G_IMG <= 65536 && (WG_STAGES - 1 - HI_FROM) * STAGE + WG_IMG + G_IMG <= 65536, "immediates");
 };
 
-__device__ __forceinline__ int wg_swz(int row) { return 2 * ((row & 3) + 4 * ((row >> 3) & 1)); }
 
 template <int OFF>
 __device__ __forceinline__ uint2 lds_read_tr(uint32_t addr) {   // (stage base as an immediate: no address arithmetic per read)
@@ -76,7 +80,7 @@ __device__ __forceinline__ uint2 lds_read_tr(uint32_t addr) {   // (stage base a
 }
 
 template <bool ABS, int CT>   // |x| as the im2col operand (d gamma of GDN1): a compile-time property (16 mask operations per slab otherwise)
-__global__ __launch_bounds__(64 * WgGeo<CT>::NW, CT == 128 ? 2 : 1) void conv_wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(64 * WgGeo<CT>::NW, CT == 256 ? 1 : 2) void conv_wgrad_kernel(const WgradArgs p) {
     using G = WgGeo<CT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(64 * WgGeo<CT>::NW, CT == 128 ? 2 : 1) void conv_wg
 #pragma unroll
     for (int j = 0; j < G::GJ; ++j) {
         const int row = (j * G::NW + wave) * G::G_RPI + lane / G::G_CPR;
-        const int c = (lane % G::G_CPR) ^ wg_swz(row);
+        const int c = (lane % G::G_CPR) ^ G::gswz(row);
         grow_j[j] = row;
         gco_j[j] = co0 + 8 * c;
         gok_j[j] = gco_j[j] < p.Cout;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(64 * WgGeo<CT>::NW, CT == 128 ? 2 : 1) void conv_wg
             const int r = rrow + 4 * h;
             const int gc = wm * 64 + tt * 16 + 4 * (i16 & 3);   // column inside the CT-wide dY image
             const int ac = wn * 64 + tt * 16 + 4 * (i16 & 3);   // ... the 128-wide im2col image
-            g_rd[tt][h] = lds_base + (uint32_t)(r * G::G_ROWB + (((gc >> 3) ^ wg_swz(r)) << 4) + ((gc >> 2) & 1) * 8);
+            g_rd[tt][h] = lds_base + (uint32_t)(r * G::G_ROWB + (((gc >> 3) ^ G::gswz(r)) << 4) + ((gc >> 2) & 1) * 8);
             a_rd[tt][h] = lds_base + (uint32_t)(r * WG_ROWB + (((ac >> 3) ^ wg_swz(r)) << 4) + ((ac >> 2) & 1) * 8);
         }
 
@@ -338,7 +342,8 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     a.x_abs = d->a_op == SC2_AOP_ABS;
     a.n_ktiles = (a.K + WG_TILE - 1) / WG_TILE;
     // (round 5) more than 128 output channels: the 256-channel tile, 8 waves, one workgroup per CU (policy wgrad_ct: 0 auto, 128: A/B)
-    const int ct = (a.Cout > 128 && sc2_pol().wgrad_ct != 128) ? 256 : 128;
+    // ... 64 or fewer (enc.conv2: 48 of a 128-channel tile's rows used): the 64-channel tile, 2 waves, three workgroups per CU
+    const int ct = sc2_pol().wgrad_ct == 128 ? 128 : a.Cout > 128 ? 256 : a.Cout <= 64 ? 64 : 128;
     a.n_ctiles = (a.Cout + ct - 1) / ct;
     // enough pixel chunks to fill the chip several times over, at least 8 slabs each
     const long long tiles = (long long)a.n_ktiles * a.n_ctiles;
@@ -351,7 +356,7 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     //  between 1 024 and 2 048)
     // (256-channel tiles: one workgroup per CU; a single row of channel tiles -- dec.conv2 / dec.conv4 / igdn3's gamma -- wants one
     //  round of 256, the 512 x 512 gamma gradient 1 024: profiles/r05k_wgrad_times.txt)
-    const int wg_auto = ct == 256 ? ((tiles <= 2 || a.n_ctiles == 1) ? 256 : 1024) : tiles <= 4 ? 512 : (a.n_ctiles == 1 ? 4096 : 1024);
+    const int wg_auto = ct == 256 ? ((tiles <= 2 || a.n_ctiles == 1) ? 256 : 1024) : ct == 64 ? 4096 : tiles <= 4 ? 512 : (a.n_ctiles == 1 ? 4096 : 1024);
     const int wg_target = sc2_pol().wgrad_wgs > 0 ? sc2_pol().wgrad_wgs : wg_auto;
     long long chunks = (wg_target + tiles - 1) / tiles;
     long long rows = (M + chunks - 1) / chunks;
@@ -376,6 +381,10 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
         }
         if (a.x_abs) hipLaunchKernelGGL((conv_wgrad_kernel<true, 256>), dim3((unsigned)grid), dim3(512), lds, s, a);
         else hipLaunchKernelGGL((conv_wgrad_kernel<false, 256>), dim3((unsigned)grid), dim3(512), lds, s, a);
+    } else if (ct == 64) {
+        constexpr size_t lds = (size_t)WG_STAGES * WgGeo<64>::STAGE;   // 48 KB
+        if (a.x_abs) hipLaunchKernelGGL((conv_wgrad_kernel<true, 64>), dim3((unsigned)grid), dim3(128), lds, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<false, 64>), dim3((unsigned)grid), dim3(128), lds, s, a);
     } else {
         constexpr size_t lds = (size_t)WG_STAGES * WgGeo<128>::STAGE;   // 64 KB
         static bool attr_set_dev[SC2_MAX_DEVICES] = {};

@@ -140,7 +140,7 @@ def test_asm_weight_loads_are_never_copied_in_flight():
     # `lgkmcnt(0)` of the next step -- nothing may read, copy or overwrite those registers on the way (tools/audit_lds_inflight.py)
     r5 = subprocess.run([sys.executable, os.path.join(root, 'tools', 'audit_lds_inflight.py'), os.path.join(csrc, 'conv_wgrad.hip')],
                         capture_output=True, text=True)
-    assert r5.returncode == 0 and '4 kernel(s)' in r5.stdout and ' 0 finding(s)' in r5.stdout, r5.stdout + r5.stderr
+    assert r5.returncode == 0 and '6 kernel(s)' in r5.stdout and ' 0 finding(s)' in r5.stdout, r5.stdout + r5.stderr
 
 
 def test_hot_path_kernels_use_no_scratch():

@@ -32,11 +32,11 @@ for name, cin, cout, k, pad, hw, xabs in cases:
     x = torch.randn(N, hw, hw, cin, device=dev).to(torch.bfloat16)
     g = torch.randn(N, oh, oh, cout, device=dev).to(torch.bfloat16)
     tf = 2.0 * N * oh * oh * cout * cin * k * k / 1e12
-    for ct in ((0, 128) if cout > 128 else (128,)):     # (0: the 256-channel tile where it applies; 128: always 128 x 128)
+    for ct in ((0, 128) if (cout > 128 or cout <= 64) else (128,)):     # (0: the 256- / 64-channel tile where it applies; 128: always 128 x 128)
         row = []
         for wgs in (0, 256, 512, 768, 1024, 1536, 2048, 4096):   # (0: the launcher's own choice)
             hip.configure(wgrad_wgs=wgs, wgrad_ct=ct)
             ms = timeit(lambda: hip.conv2d_wgrad(x, g, k, k, stride, pad, x_abs=xabs))
             row.append('{}: {:.3f}'.format(wgs or 'auto', ms))
-        print('{:<32}{:.3f} TFLOP  tile {:<4}'.format(name, tf, 256 if ct == 0 else 128) + '  '.join(row))
+        print('{:<32}{:.3f} TFLOP  tile {:<4}'.format(name, tf, (256 if cout > 128 else 64) if ct == 0 else 128) + '  '.join(row))
 hip.configure(wgrad_wgs=0, wgrad_ct=0)
