@@ -127,12 +127,9 @@ class _GdnFn(torch.autograd.Function):
         if hip.gdn1_rows_supported(x_nhwc, C):      # C = 256 / 512: the resident-row kernel (gdn512_rows.hip)
             return hip.gdn1_rows_fwd(x_nhwc, hip.pack_weight_fragments(gamma.detach()), beta.detach().float().contiguous(), inverse, tag=tag)
         packed = hip.pack_conv_weight(gamma.reshape(C, C, 1, 1))
-        y = hip.conv2d_fwd(x_nhwc, packed, C, 1, 1, 1, 0, a_op=hip.AOP_ABS,
-                           epilogue=hip.EPI_IGDN if inverse else hip.EPI_GDN, ep_x=x_nhwc,
-                           ep_beta=beta.float().contiguous(), tag=tag)
-        ctx.save_for_backward(x_nhwc, beta, gamma)
-        ctx.inverse = inverse
-        return y
+        return hip.conv2d_fwd(x_nhwc, packed, C, 1, 1, 1, 0, a_op=hip.AOP_ABS,
+                              epilogue=hip.EPI_IGDN if inverse else hip.EPI_GDN, ep_x=x_nhwc,
+                              ep_beta=beta.float().contiguous(), tag=tag)
 
     @staticmethod
     def backward(ctx, gy):
