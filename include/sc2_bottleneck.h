@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 45
+#define SC2_ABI_VERSION 46
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -105,6 +105,12 @@ int sc2_nhwc_bf16_to_nchw_f32(const void *x, float *y, int N, int C, int H, int 
 /* AdaptiveAvgPool2d((1,1)) + flatten of a bf16 NHWC feature map [N, HW, C] (torchvision ResNet.avgpool,
  * sc2bench/models/backbone.py:250-252): mean over HW in f32 -> y_f32 [N, C] and / or y_bf16 [N, C] (either may be NULL). */
 int sc2_avgpool_nhwc(const void *x, float *y_f32, void *y_bf16, int N, int HW, int C, void *stream);
+
+/* nn.MaxPool2d (floor mode, no dilation) on a bf16 NHWC map: x [N,H,W,C] -> y [N,OH,OW,C], C % 8 == 0 (torchvision ResNet.maxpool
+ * behind the stem, sc2bench/models/backbone.py:235-254 via torchvision's resnet forward; the teacher of the training step and the
+ * input-compression classifier run it).  Bit-identical to torch's kernel: same update rule, NaN propagates. */
+int sc2_maxpool_nhwc(const void *x, void *y, int N, int H, int W, int C, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w,
+                     void *stream);
 
 /* Classifier on the pooled features: out[m][n] = sum_k a[m][k] w[n][k] + bias[n] (torchvision ResNet.fc behind the pool,
  * sc2bench/models/backbone.py:247-253).  K split over the four waves of a workgroup, operands straight from L2.

@@ -181,6 +181,69 @@ __global__ __launch_bounds__(256) void fc_kernel(const uint16_t *__restrict__ a,
 }
 }  // namespace
 
+namespace {
+// MaxPool2d on a bf16 NHWC map (torchvision ResNet.maxpool behind the stem: k3 s2 p1 on [N, 112, 112, 64]; the teacher's forward
+// of the training step and the input-compression classifier run it).  One thread = one output pixel x 8 channels: KH x KW 16-byte
+// loads (neighbouring windows overlap in L1 / L2; HBM sees the map once), one 16-byte store.  The update rule is torch's --
+// `if (v > m || isnan(v)) m = v` over the window in row-major order, from -inf -- so the result is bit-identical to
+// nn.functional.max_pool2d including NaN propagation and the sign of zero.
+__global__ __launch_bounds__(256) void maxpool_nhwc_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y, int H, int W, int C8,
+                                                           int OH, int OW, int KH, int KW, int SH, int SW, int PH, int PW, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int c8 = (int)(t % C8);
+    long long px = t / C8;
+    const int ow = (int)(px % OW);
+    px /= OW;
+    const int oh = (int)(px % OH);
+    const long long n = px / OH;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -__builtin_inff();
+    const uint4 *xi = reinterpret_cast<const uint4 *>(x) + n * H * W * C8 + c8;
+    for (int kh = 0; kh < KH; ++kh) {
+        const int ih = oh * SH - PH + kh;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        for (int kw = 0; kw < KW; ++kw) {
+            const int iw = ow * SW - PW + kw;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            const uint4 v = xi[((long long)ih * W + iw) * C8];
+            const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float lo = __builtin_bit_cast(float, w4[q] << 16), hi = __builtin_bit_cast(float, w4[q] & 0xFFFF0000u);
+                if (lo > m[2 * q] || lo != lo) m[2 * q] = lo;
+                if (hi > m[2 * q + 1] || hi != hi) m[2 * q + 1] = hi;
+            }
+        }
+    }
+    uint4 o;
+    uint32_t *ow4 = reinterpret_cast<uint32_t *>(&o);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        ow4[q] = (__builtin_bit_cast(uint32_t, m[2 * q]) >> 16) | (__builtin_bit_cast(uint32_t, m[2 * q + 1]) & 0xFFFF0000u);
+    reinterpret_cast<uint4 *>(y)[t] = o;
+}
+}  // namespace
+
+extern "C" int sc2_maxpool_nhwc(const void *x, void *y, int N, int H, int W, int C, int KH, int KW, int stride_h, int stride_w, int pad_h,
+                                int pad_w, void *stream) {
+    SC2_REQUIRE(x && y, SC2_ERR_INVALID_ARG, "maxpool_nhwc: null argument");
+    SC2_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, SC2_ERR_INVALID_ARG, "maxpool_nhwc: bad dims N=%d H=%d W=%d C=%d (C %% 8 == 0)", N,
+                H, W, C);
+    SC2_REQUIRE(KH > 0 && KW > 0 && stride_h > 0 && stride_w > 0 && pad_h >= 0 && pad_w >= 0 && 2 * pad_h <= KH && 2 * pad_w <= KW,
+                SC2_ERR_INVALID_ARG, "maxpool_nhwc: bad window (padding at most half the kernel, as nn.MaxPool2d requires)");
+    const int OH = (H + 2 * pad_h - KH) / stride_h + 1, OW = (W + 2 * pad_w - KW) / stride_w + 1;
+    SC2_REQUIRE(OH > 0 && OW > 0, SC2_ERR_INVALID_ARG, "maxpool_nhwc: window larger than the padded map");
+    const long long total = (long long)N * OH * OW * (C / 8);
+    SC2_REQUIRE((total + 255) / 256 < 0x7FFFFFFFLL, SC2_ERR_UNSUPPORTED, "maxpool_nhwc: problem too large");
+    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint16_t *>(x), static_cast<uint16_t *>(y), H, W, C / 8, OH, OW, KH, KW, stride_h, stride_w, pad_h,
+                       pad_w, total);
+    SC2_CHECK_LAUNCH();
+    return SC2_OK;
+}
+
 extern "C" int sc2_avgpool_nhwc(const void *x, float *y_f32, void *y_bf16, int N, int HW, int C, void *stream) {
     SC2_REQUIRE(x && (y_f32 || y_bf16), SC2_ERR_INVALID_ARG, "avgpool_nhwc: null argument");
     SC2_REQUIRE(N > 0 && HW > 0 && C > 0 && C % 8 == 0 && N <= 65535, SC2_ERR_INVALID_ARG,

@@ -24,7 +24,7 @@ EB_PARAM_STRIDE = 64
 # symbols the header declares; tests check each is exported
 ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count', 'sc2_policy_default', 'sc2_policy_set', 'sc2_policy_get',
-    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_fc_fwd',
+    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_maxpool_nhwc', 'sc2_fc_fwd',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd', 'sc2_gdn1_bwd_gemm', 'sc2_colsum_bf16', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_mask_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv1x1_pair_supported', 'sc2_conv1x1_pair_fwd',
@@ -91,6 +91,7 @@ class HostPolicy(object):
     train_fused_conv2 = True   # training forward: encoder[2] + GDN1(48) as the fused inference launch that also emits the conv output
     train_fused_dec0 = True    # ... and decoder[0] + IGDN1(512) likewise (conv_gdn512.hip)
     train_fused_conv0 = True   # ... and encoder[0] + GDN1(96) (conv0_gdn96.hip, pixel-pair input)
+    maxpool_hip = True         # nn.MaxPool2d behind a frozen stem (teacher, input-compression classifier) on sc2_maxpool_nhwc (False: torch's)
     relu_mask_fused = True     # the ReLU gradient behind a frozen block's conv2 / conv3 data gradient inside that launch's epilogue (window-plane kernels)
     mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
@@ -174,6 +175,7 @@ def lib():
     L.sc2_nchw_f32_to_nhwc_bf16.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp]
     L.sc2_nhwc_bf16_to_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.sc2_avgpool_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.sc2_maxpool_nhwc.argtypes = [vp, vp] + [i32] * 10 + [vp]
     L.sc2_fc_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.sc2_conv_weight_rows.argtypes = [i32]
     L.sc2_conv_weight_pitch.argtypes = [i32]
@@ -811,6 +813,18 @@ def avgpool_nhwc(x_nhwc, want_f32=True, want_bf16=False):
     with _timed('avgpool'):
         _check(lib().sc2_avgpool_nhwc(_ptr(x_nhwc), _ptr(f32), _ptr(b16), N, H * W, C, _stream()), 'avgpool_nhwc')
     return f32, b16
+
+
+def maxpool_nhwc(x_nhwc, kernel, stride, pad, tag=None):
+    """nn.MaxPool2d (floor mode) on a bf16 NHWC map [N,H,W,C], C % 8 == 0 -> [N,OH,OW,C]; bit-identical to torch's."""
+    _dev(x_nhwc, 'x')
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    N, H, W, C = x_nhwc.shape
+    (kh, kw), (sh, sw), (ph, pw) = [(v, v) if isinstance(v, int) else tuple(v) for v in (kernel, stride, pad)]
+    out = torch.empty((N, (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1, C), dtype=torch.bfloat16, device=x_nhwc.device)
+    with _timed(tag or 'maxpool'):
+        _check(lib().sc2_maxpool_nhwc(_ptr(x_nhwc), _ptr(out), N, H, W, C, kh, kw, sh, sw, ph, pw, _stream()), 'maxpool_nhwc')
+    return out
 
 
 def fc_fwd(a, w_frag, bias, tag=None):

@@ -308,6 +308,13 @@ class DistillationStage(object):
                     x = stem(x_nhwc, hip_epi_bias_relu()).permute(0, 3, 1, 2)
                 skip = 2
                 continue
+            if (is_map and self.use_hip_frozen and hip.host_policy.maxpool_hip and type(module) is nn.MaxPool2d and x.dtype == torch.bfloat16 and not x.requires_grad and
+                    module.dilation in (1, (1, 1)) and not module.ceil_mode and not module.return_indices and x.shape[1] % 8 == 0 and
+                    x.is_contiguous(memory_format=torch.channels_last) and not any(q.split('.')[0] == name for q in hooks.all_paths)):
+                # the max-pool behind a frozen stem (the teacher's): the library's kernel on the NHWC map (bit-identical to torch's)
+                x = hip.maxpool_nhwc(x.permute(0, 2, 3, 1), module.kernel_size, module.stride, module.padding,
+                                     tag='maxpool').permute(0, 3, 1, 2)
+                continue
             # a hook on the stack's INPUT, or on a module inside it, needs the torch modules to run
             hooked_inside = any(q == path and q not in wanted or q.startswith(path + '.') for q in hooks.all_paths)
             stack = self._frozen_stack(name, module) if (is_map and x.dtype == torch.bfloat16 and not hooked_inside) else None

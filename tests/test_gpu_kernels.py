@@ -1532,3 +1532,20 @@ def test_conv1x1_stream_relu_gradient_store_pass(S, dev, cin, cout, hw, N, res):
     want = S.hip.relu_bwd(plain, mask)
     got = S.hip.conv1x1_stream_fwd(x, w, b, residual=r, mask=mask)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('N,H,W,C,k,st,pd', [(3, 112, 112, 64, 3, 2, 1), (2, 17, 23, 8, 3, 2, 1), (2, 9, 9, 72, 2, 2, 0), (1, 5, 7, 16, 3, 1, 1),
+                                             (2, 8, 6, 24, (3, 2), (2, 1), (1, 0))])
+def test_maxpool_nhwc(S, dev, N, H, W, C, k, st, pd):
+    """sc2_maxpool_nhwc against nn.functional.max_pool2d on the same bf16 map: bit for bit, NaN and the sign of zero included (the
+    update rule is torch's); odd sizes, windows hanging over every border, non-square windows."""
+    torch.manual_seed(H * W + C)
+    x = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
+    x[0, 0, 0, :4] = float('nan')
+    x[0, 1, :, 4:8] = -0.0
+    x[0, 2, :, 4:8] = 0.0
+    x[N - 1, H - 1, W - 1, :] = float('-inf')
+    want = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), k, st, pd).permute(0, 2, 3, 1).contiguous()
+    got = S.hip.maxpool_nhwc(x, k, st, pd)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
