@@ -1128,7 +1128,12 @@ def test_conv_dgrad(S, dev, cin, cout, k, stride, pad, H, W, N):
     assert_close_bf16(gxb.permute(0, 3, 1, 2), ref, 'dgrad bf16')
 
 
-@pytest.mark.parametrize('cin,cout,k,stride,pad,H,W,N', DGRAD_CASES + [(8, 96, 3, 1, 1, 30, 30, 4), (256, 136, 1, 1, 0, 40, 40, 3)])
+@pytest.mark.parametrize('cin,cout,k,stride,pad,H,W,N', DGRAD_CASES + [(8, 96, 3, 1, 1, 30, 30, 4), (256, 136, 1, 1, 0, 40, 40, 3),
+                                                                        # round 5, the three tile forms (64 / 128 / 256 output channels) with
+                                                                        # partial channel tiles, partial k tiles and ranges of one trip
+                                                                        (16, 520, 1, 1, 0, 33, 31, 2), (40, 200, 3, 1, 1, 19, 21, 3),
+                                                                        (8, 8, 3, 2, 1, 37, 41, 5), (72, 64, 1, 1, 0, 11, 13, 2),
+                                                                        (136, 264, 2, 1, 1, 9, 10, 2)])
 def test_conv_wgrad(S, dev, cin, cout, k, stride, pad, H, W, N):
     """Weight gradient kernel (transposing LDS fragment reads, f32 atomic combine of pixel-range partials)."""
     g = torch.Generator().manual_seed(cin * 3 + cout)
