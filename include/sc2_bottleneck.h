@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 46
+#define SC2_ABI_VERSION 47
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -105,6 +105,22 @@ int sc2_nhwc_bf16_to_nchw_f32(const void *x, float *y, int N, int C, int H, int 
 /* AdaptiveAvgPool2d((1,1)) + flatten of a bf16 NHWC feature map [N, HW, C] (torchvision ResNet.avgpool,
  * sc2bench/models/backbone.py:250-252): mean over HW in f32 -> y_f32 [N, C] and / or y_bf16 [N, C] (either may be NULL). */
 int sc2_avgpool_nhwc(const void *x, float *y_f32, void *y_bf16, int N, int HW, int C, void *stream);
+
+/* nn.BatchNorm2d in TRAINING mode (batch statistics) on a bf16 NHWC map x [M = N H W][C], with the ReLU and the residual add of a
+ * torchvision Bottleneck block folded in (stage 2 of the Entropic-Student recipe fine-tunes layer2 .. layer4 with their norm layers
+ * training: configs/.../splitable_resnet50-fp-beta0.08_from_resnet50.yaml:231-295; sc2bench/models/backbone.py:235-254 runs the blocks).
+ *   forward : y = relu?((x - mean) rstd gamma + beta (+ residual)); mean / biased variance over the M rows; running_mean / running_var
+ *             (may both be NULL) take the momentum update with the UNBIASED variance, as torch; save_mean / save_rstd [C] for backward
+ *   backward: dz = y ? dy * (y > 0) : dy (y = the forward's output when it applied the ReLU, else NULL); dgamma = sum dz xhat, dbeta =
+ *             sum dz; dx = gamma rstd (dz - dbeta / M - xhat dgamma / M); dz (NULL, or bf16 like dx) = the residual operand's gradient
+ *   gamma, beta, running_*, save_*, dgamma, dbeta : f32 [C];  ws : f32 scratch of sc2_bn_ws_floats(M, C) floats (per-workgroup partial
+ *   sums + coefficient rows; either direction);  C % 8 == 0, C <= 2048 */
+long long sc2_bn_ws_floats(long long M, int C);
+int sc2_bn_train_fwd(const void *x, const void *residual, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                     float momentum, float eps, int relu, void *y, float *save_mean, float *save_rstd, float *ws, long long M, int C,
+                     void *stream);
+int sc2_bn_train_bwd(const void *dy, const void *x, const void *y, const float *gamma, const float *save_mean, const float *save_rstd,
+                     void *dx, void *dz, float *dgamma, float *dbeta, float *ws, long long M, int C, void *stream);
 
 /* nn.MaxPool2d (floor mode, no dilation) on a bf16 NHWC map: x [N,H,W,C] -> y [N,OH,OW,C], C % 8 == 0 (torchvision ResNet.maxpool
  * behind the stem, sc2bench/models/backbone.py:235-254 via torchvision's resnet forward; the teacher of the training step and the

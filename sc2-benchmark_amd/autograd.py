@@ -496,3 +496,59 @@ def hyperprior_forward2train_autograd(m, x, noise_z=None, noise_y=None):
     y_hat, y_lik = m.gaussian_conditional(y, scales_hat, means=means_hat, noise=noise_y)
     m.last_likelihoods = (y_lik, z_lik)
     return synthesis_autograd(m, y_hat)
+
+
+# --------------------------------------------------------------------------------------------- #
+# trainable Bottleneck blocks (stage 2): BatchNorm2d in training mode + ReLU + residual add
+# --------------------------------------------------------------------------------------------- #
+class _BnActFn(torch.autograd.Function):
+    """y = relu?(batch_norm(x; batch statistics) (+ residual)) on bf16 NHWC maps (bn.hip): two passes forward, two backward; the
+    ReLU gradient, the gradient of the residual operand and d gamma / d beta come out of the same two passes.  Running statistics
+    are updated in place as nn.BatchNorm2d does (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, gamma, beta, residual, running_mean, running_var, momentum, eps, relu):
+        y, mean, rstd = hip.bn_train_fwd(x_nhwc, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, relu,
+                                         residual=residual)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
+        ctx.save_for_backward(x_nhwc, y if relu else None, gamma, mean, rstd)
+        return y            # (running_mean / running_var: buffers, updated in place by the kernel, not part of the graph)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_nhwc, y, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx, dz, dgamma, dbeta = hip.bn_train_bwd(dy, x_nhwc, y, gamma.detach(), mean, rstd, want_dz=ctx.has_res and ctx.relu)
+        if ctx.has_res and not ctx.relu:
+            dz = dy                                  # (no ReLU: the residual operand's gradient is the incoming one)
+        return (dx if ctx.needs_input_grad[0] else None, dgamma.to(gamma.dtype) if ctx.needs_input_grad[1] else None,
+                dbeta.to(gamma.dtype) if ctx.needs_input_grad[2] else None, dz if (ctx.has_res and ctx.needs_input_grad[3]) else None,
+                None, None, None, None, None)
+
+
+def bn_module_ok(bn):
+    """True if `bn` can take the HIP path: a training-mode nn.BatchNorm2d with f32 affine parameters and running statistics, a
+    fixed momentum, C % 8 == 0 and C <= 2048 (decided from the module alone, before anything runs)."""
+    return (hip.host_policy.bn_train_hip and type(bn) is torch.nn.BatchNorm2d and bn.training and bn.affine and bn.track_running_stats and
+            bn.momentum is not None and bn.weight.dtype == torch.float32 and bn.weight.is_cuda and bn.running_mean is not None and
+            bn.running_mean.dtype == torch.float32 and bn.num_features % 8 == 0 and bn.num_features <= 2048)
+
+
+def _nhwc_bf16(t):
+    """NCHW-shaped tensor -> contiguous bf16 NHWC view (a copy only if it is not bf16 channels_last already)."""
+    if t.dtype != torch.bfloat16:
+        t = t.to(torch.bfloat16)
+    return t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+
+def bn_act(bn, x, relu, residual=None):
+    """relu?(bn(x) (+ residual)) for a training-mode nn.BatchNorm2d (bn_module_ok) on NCHW-shaped device tensors; bf16 channels_last
+    in (anything else is converted), a bf16 channels_last view out."""
+    with torch.no_grad():
+        bn.num_batches_tracked.add_(1)
+    res = _nhwc_bf16(residual) if residual is not None else None
+    y = _BnActFn.apply(_nhwc_bf16(x), bn.weight, bn.bias, res, bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps),
+                       bool(relu))
+    return y.permute(0, 3, 1, 2)

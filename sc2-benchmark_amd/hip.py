@@ -24,7 +24,7 @@ EB_PARAM_STRIDE = 64
 # symbols the header declares; tests check each is exported
 ABI_SYMBOLS = [
     'sc2_abi_version', 'sc2_last_error', 'sc2_device_count', 'sc2_policy_default', 'sc2_policy_set', 'sc2_policy_get',
-    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_maxpool_nhwc', 'sc2_fc_fwd',
+    'sc2_nchw_f32_to_nhwc_bf16', 'sc2_nhwc_bf16_to_nchw_f32', 'sc2_avgpool_nhwc', 'sc2_maxpool_nhwc', 'sc2_bn_ws_floats', 'sc2_bn_train_fwd', 'sc2_bn_train_bwd', 'sc2_fc_fwd',
     'sc2_conv_weight_rows', 'sc2_conv_weight_pitch', 'sc2_conv_fused_gdn_supported', 'sc2_conv_patch_supported',
     'sc2_conv2d_fwd', 'sc2_gdn1_bwd_gemm', 'sc2_colsum_bf16', 'sc2_nchw_f32_to_nhwc_f32', 'sc2_conv_f32_chunk_channels', 'sc2_conv2d_f32_fwd',
     'sc2_conv2x2_gdn512_supported', 'sc2_conv2x2_gdn512_fwd', 'sc2_conv1x1_stream_supported', 'sc2_conv1x1_stream_mask_supported', 'sc2_conv1x1_stream_fwd', 'sc2_conv1x1_pair_supported', 'sc2_conv1x1_pair_fwd',
@@ -91,6 +91,7 @@ class HostPolicy(object):
     train_fused_conv2 = True   # training forward: encoder[2] + GDN1(48) as the fused inference launch that also emits the conv output
     train_fused_dec0 = True    # ... and decoder[0] + IGDN1(512) likewise (conv_gdn512.hip)
     train_fused_conv0 = True   # ... and encoder[0] + GDN1(96) (conv0_gdn96.hip, pixel-pair input)
+    bn_train_hip = True        # BatchNorm2d (training mode) + ReLU + residual add of trainable Bottleneck blocks on sc2_bn_train_* (stage 2)
     maxpool_hip = True         # nn.MaxPool2d behind a frozen stem (teacher, input-compression classifier) on sc2_maxpool_nhwc (False: torch's)
     relu_mask_fused = True     # the ReLU gradient behind a frozen block's conv2 / conv3 data gradient inside that launch's epilogue (window-plane kernels)
     mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass
@@ -176,6 +177,10 @@ def lib():
     L.sc2_nhwc_bf16_to_nchw_f32.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.sc2_avgpool_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.sc2_maxpool_nhwc.argtypes = [vp, vp] + [i32] * 10 + [vp]
+    L.sc2_bn_ws_floats.argtypes = [ctypes.c_longlong, i32]
+    L.sc2_bn_ws_floats.restype = ctypes.c_longlong
+    L.sc2_bn_train_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, i32, vp, vp, vp, vp, ctypes.c_longlong, i32, vp]
+    L.sc2_bn_train_bwd.argtypes = [vp] * 11 + [ctypes.c_longlong, i32, vp]
     L.sc2_fc_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
     L.sc2_conv_weight_rows.argtypes = [i32]
     L.sc2_conv_weight_pitch.argtypes = [i32]
@@ -825,6 +830,43 @@ def maxpool_nhwc(x_nhwc, kernel, stride, pad, tag=None):
     with _timed(tag or 'maxpool'):
         _check(lib().sc2_maxpool_nhwc(_ptr(x_nhwc), _ptr(out), N, H, W, C, kh, kw, sh, sw, ph, pw, _stream()), 'maxpool_nhwc')
     return out
+
+
+def bn_train_fwd(x_nhwc, gamma, beta, running_mean, running_var, momentum, eps, relu, residual=None, tag=None):
+    """BatchNorm2d with batch statistics on a bf16 NHWC map (+ residual, ReLU): -> (y, save_mean, save_rstd).  gamma / beta /
+    running_* : f32 [C] (running_* may be None); running statistics are updated in place as nn.BatchNorm2d does."""
+    _dev(x_nhwc, 'x')
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    C = x_nhwc.shape[3]
+    M = x_nhwc.numel() // C
+    for t in (gamma, beta, running_mean, running_var):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == C and t.device == x_nhwc.device)
+    assert residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x_nhwc.shape and residual.is_contiguous())
+    y = torch.empty_like(x_nhwc)
+    stats = torch.empty((2, C), dtype=torch.float32, device=x_nhwc.device)      # save_mean, save_rstd
+    ws = torch.empty((int(lib().sc2_bn_ws_floats(M, C)),), dtype=torch.float32, device=x_nhwc.device)
+    with _timed(tag or 'bn.fwd'):
+        _check(lib().sc2_bn_train_fwd(_ptr(x_nhwc), _ptr(residual), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                      float(momentum), float(eps), 1 if relu else 0, _ptr(y), stats[0].data_ptr(), stats[1].data_ptr(),
+                                      _ptr(ws), M, C, _stream()), 'bn_train_fwd')
+    return y, stats[0], stats[1]
+
+
+def bn_train_bwd(dy, x_nhwc, y_or_none, gamma, save_mean, save_rstd, want_dz=False, tag=None):
+    """-> (dx bf16, dz bf16 or None, dgamma f32 [C], dbeta f32 [C]); y_or_none: the forward's output if it applied the ReLU."""
+    _dev(dy, 'dy')
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and dy.shape == x_nhwc.shape and x_nhwc.is_contiguous()
+    assert y_or_none is None or (y_or_none.is_contiguous() and y_or_none.shape == x_nhwc.shape)
+    C = x_nhwc.shape[3]
+    M = x_nhwc.numel() // C
+    dx = torch.empty_like(x_nhwc)
+    dz = torch.empty_like(x_nhwc) if want_dz else None
+    out = torch.empty((2, C), dtype=torch.float32, device=dy.device)           # dgamma, dbeta
+    ws = torch.empty((int(lib().sc2_bn_ws_floats(M, C)),), dtype=torch.float32, device=dy.device)
+    with _timed(tag or 'bn.bwd'):
+        _check(lib().sc2_bn_train_bwd(_ptr(dy), _ptr(x_nhwc), _ptr(y_or_none), _ptr(gamma), _ptr(save_mean), _ptr(save_rstd), _ptr(dx),
+                                      _ptr(dz), out[0].data_ptr(), out[1].data_ptr(), _ptr(ws), M, C, _stream()), 'bn_train_bwd')
+    return dx, dz, out[0], out[1]
 
 
 def fc_fwd(a, w_frag, bias, tag=None):

@@ -57,6 +57,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if self.training and x.is_cuda and x.dtype == torch.bfloat16:
+            out = self._forward_train_hip(x)
+            if out is not None:
+                return out
         identity = x
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
@@ -65,6 +69,20 @@ class Bottleneck(nn.Module):
             identity = self.downsample(x)
         out += identity
         return self.relu(out)
+
+    def _forward_train_hip(self, x):
+        """A block that TRAINS (stage 2, bf16 autocast, channels_last): the convs stay where they are; each norm layer with its ReLU --
+        and, for the third, the residual add -- is two passes of bn.hip forward and two backward (autograd._BnActFn).  None: not
+        applicable (decided before anything runs; the torch modules run then)."""
+        from . import autograd as A
+        ds = self.downsample
+        ds_ok = ds is None or (isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d))
+        if not (ds_ok and all(A.bn_module_ok(b) for b in (self.bn1, self.bn2, self.bn3) + ((ds[1],) if ds is not None else ()))):
+            return None
+        out = A.bn_act(self.bn1, self.conv1(x), relu=True)
+        out = A.bn_act(self.bn2, self.conv2(out), relu=True)
+        identity = x if ds is None else A.bn_act(ds[1], ds[0](x), relu=False)
+        return A.bn_act(self.bn3, self.conv3(out), relu=True, residual=identity)
 
 
 class ResNet(nn.Module):

@@ -1554,3 +1554,40 @@ def test_maxpool_nhwc(S, dev, N, H, W, C, k, st, pd):
     got = S.hip.maxpool_nhwc(x, k, st, pd)
     assert got.shape == want.shape and got.dtype == torch.bfloat16
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize('N,H,C,relu,res', [(4, 14, 64, True, False), (3, 7, 2048, True, True), (5, 9, 16, False, False), (6, 14, 512, True, True),
+                                            (2, 28, 128, False, True), (64, 28, 512, True, True)])
+def test_bn_train_kernels(S, dev, N, H, C, relu, res):
+    """sc2_bn_train_fwd / _bwd (BatchNorm2d with batch statistics + residual + ReLU on a bf16 NHWC map) against torch's f32
+    batch_norm + autograd on the same bf16 operands: y and dx to bf16 rounding (one rounding each), d gamma / d beta / running
+    statistics to f32 accumulation order, the residual operand's gradient exactly."""
+    torch.manual_seed(C + H)
+    x = (torch.randn(N, H, H, C, device=dev) * 1.3 + 0.4).to(torch.bfloat16)
+    r = torch.randn(N, H, H, C, device=dev).to(torch.bfloat16) if res else None
+    g = (torch.rand(C, device=dev) + 0.5).requires_grad_(True)
+    b = (torch.rand(C, device=dev) - 0.5).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    rm2, rv2 = rm.clone(), rv.clone()
+    y, mean, rstd = S.hip.bn_train_fwd(x, g.detach(), b.detach(), rm, rv, 0.1, 1e-5, relu, residual=r)
+    xf = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    rf = r.float().permute(0, 3, 1, 2).requires_grad_(True) if res else None
+    z = F.batch_norm(xf, rm2, rv2, g, b, True, 0.1, 1e-5)
+    if res:
+        z = z + rf
+    if relu:
+        z = z.relu()
+
+    def rel(a, want):
+        return ((a.float() - want.float()).norm() / (want.float().norm() + 1e-12)).item()
+    assert rel(y, z.permute(0, 2, 3, 1)) < 3e-3
+    if N * H * H > 1:
+        assert rel(rm, rm2) < 1e-5 and rel(rv, rv2) < 1e-5
+    dy = torch.randn_like(x)
+    z.backward(dy.float().permute(0, 3, 1, 2))
+    dx, dz, dg, db = S.hip.bn_train_bwd(dy, x, y if relu else None, g.detach(), mean, rstd, want_dz=res and relu)
+    # (the reference's ReLU mask comes from ITS output; where the bf16 output rounds to zero the two masks could differ: none here)
+    assert rel(dx, xf.grad.permute(0, 2, 3, 1)) < 3e-3 or N * H * H == 1
+    assert rel(dg, g.grad) < 1e-4 and rel(db, b.grad) < 1e-4
+    if dz is not None:
+        assert torch.equal(dz.float(), rf.grad.permute(0, 2, 3, 1).to(torch.bfloat16).float())

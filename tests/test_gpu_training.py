@@ -211,3 +211,54 @@ def test_fused_stages_in_the_training_forward(S, dev, switch):
     for n in grads[True]:
         a, b = grads[True][n], grads[False][n]
         assert ((a - b).norm() / (b.norm() + 1e-12)).item() < 3e-2, n
+
+
+@pytest.mark.parametrize('inplanes,planes,stride,hw,N', [(256, 128, 2, 28, 4), (512, 128, 1, 14, 6), (1024, 512, 2, 14, 8), (64, 16, 1, 10, 6)])
+def test_trainable_bottleneck_block_on_the_bn_kernels(S, dev, inplanes, planes, stride, hw, N):
+    """A torchvision-layout Bottleneck block in TRAINING mode under bf16 autocast (stage 2's student tail): `host_policy.bn_train_hip`
+    sends its norm layers + ReLUs + residual add through sc2_bn_train_fwd / _bwd.  Both forms are compared with the SAME block run in
+    f32: the HIP form (one bf16 rounding per norm layer) must be about as close to it as the torch / MIOpen bf16 modules (which
+    round behind the norm, behind the add and behind the ReLU; within 2x: the exact check of the kernels is tests/test_gpu_kernels.py::
+    test_bn_train_kernels) -- output, input gradient, every parameter gradient; the running
+    statistics agree with the f32 run's."""
+    import copy
+    from sc2bench_amd.resnet import Bottleneck
+    torch.manual_seed(inplanes + hw)
+    ds = None
+    if stride != 1 or inplanes != planes * 4:
+        ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(planes * 4))
+    ref = Bottleneck(inplanes, planes, stride=stride, downsample=ds).to(dev).train()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    x0 = (torch.randn(N, inplanes, hw, hw, device=dev) + 0.2).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(N, planes * 4, (hw - 1) // stride + 1, (hw - 1) // stride + 1, device=dev)
+    res = {}
+    for name, on in (('f32', False), ('torch', False), ('hip', True)):
+        blk = copy.deepcopy(ref)
+        S.hip.configure(bn_train_hip=on)
+        try:
+            x = (x0.float() if name == 'f32' else x0.clone()).requires_grad_(True)
+            with torch.autocast(device_type='cuda', dtype=torch.bfloat16, enabled=name != 'f32'):
+                y = blk(x)
+            assert y.dtype == (torch.float32 if name == 'f32' else torch.bfloat16)
+            (y.float() * w).sum().backward()
+            res[name] = (y.detach().float(), x.grad.detach().float(), {n: p.grad.detach().float().clone() for n, p in blk.named_parameters()},
+                         {n: b.detach().float().clone() for n, b in blk.named_buffers()})
+        finally:
+            S.hip.configure(bn_train_hip=True)
+
+    def rel(a, b):
+        return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+    def closer(a_hip, a_torch, a_ref, what):
+        eh, et = rel(a_hip, a_ref), rel(a_torch, a_ref)
+        assert eh <= 2.0 * et + 5e-3, '{}: hip {:.4f} torch {:.4f} (relative to the f32 block)'.format(what, eh, et)
+    closer(res['hip'][0], res['torch'][0], res['f32'][0], 'output')
+    closer(res['hip'][1], res['torch'][1], res['f32'][1], 'input gradient')
+    for n in res['f32'][2]:
+        closer(res['hip'][2][n], res['torch'][2][n], res['f32'][2][n], n)
+    for n in res['f32'][3]:
+        assert rel(res['hip'][3][n], res['f32'][3][n]) < 1e-2, n
