@@ -552,3 +552,23 @@ def bn_act(bn, x, relu, residual=None):
     y = _BnActFn.apply(_nhwc_bf16(x), bn.weight, bn.bias, res, bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps),
                        bool(relu))
     return y.permute(0, 3, 1, 2)
+
+
+def conv_module_ok(conv):
+    """True if a TRAINABLE nn.Conv2d can run forward and backward on the library's kernels (`_ConvFn`: implicit-GEMM forward, data
+    gradient on the same kernel, weight gradient on conv_wgrad.hip): no bias, no groups, no dilation, channel counts % 8 == 0."""
+    return (hip.host_policy.conv_train_hip and type(conv) is torch.nn.Conv2d and conv.bias is None and conv.groups == 1 and
+            conv.dilation == (1, 1) and conv.padding_mode == 'zeros' and conv.weight.is_cuda and conv.weight.dtype == torch.float32 and
+            conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and not isinstance(conv.padding, str))
+
+
+def conv_train(conv, x):
+    """conv(x) for a trainable nn.Conv2d (conv_module_ok) on an NCHW-shaped device tensor: bf16 operands, f32 accumulation, the f32
+    parameter packed to bf16 per call (it changes every step); a bf16 channels_last view out."""
+    kh, kw = conv.kernel_size
+    order = hip.preferred_k_order(conv.in_channels, kh, kw)
+    with torch.no_grad():
+        packed = hip.pack_conv_weight(conv.weight, order)
+    y = _ConvFn.apply(_nhwc_bf16(x), conv.weight, packed, kh, kw, tuple(conv.stride), tuple(conv.padding), hip.OUT_BF16_NHWC, None, None, order)
+    return y.permute(0, 3, 1, 2)
+

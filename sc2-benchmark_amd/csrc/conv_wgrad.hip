@@ -356,7 +356,12 @@ extern "C" int sc2_conv2d_wgrad(const sc2_conv_desc *d, const void *x, const voi
     //  between 1 024 and 2 048)
     // (256-channel tiles: one workgroup per CU; a single row of channel tiles -- dec.conv2 / dec.conv4 / igdn3's gamma -- wants one
     //  round of 256, the 512 x 512 gamma gradient 1 024: profiles/r05k_wgrad_times.txt)
-    const int wg_auto = ct == 256 ? ((tiles <= 2 || a.n_ctiles == 1) ? 256 : 1024) : ct == 64 ? 4096 : tiles <= 4 ? 512 : (a.n_ctiles == 1 ? 4096 : 1024);
+    // (maps of a ResNet tail -- stage 2's trainable layer2 .. layer4, at most 2e5 pixels per batch of 256 -- want ONE round of
+    //  workgroups: every workgroup pays its 128 x 128 / 256 x 128 atomic adds whatever its share of the pixels, and with 1 024 of them
+    //  layer3's 256 -> 1024 gradient took 0.115 ms where 256 take 0.054: profiles/r05s_wgrad_head_times.txt)
+    const bool small_m = M <= 262144;
+    const int wg_auto = small_m ? (ct == 256 ? (tiles > 64 ? 512 : 256) : 512)
+                        : ct == 256 ? ((tiles <= 2 || a.n_ctiles == 1) ? 256 : 1024) : ct == 64 ? 4096 : tiles <= 4 ? 512 : (a.n_ctiles == 1 ? 4096 : 1024);
     const int wg_target = sc2_pol().wgrad_wgs > 0 ? sc2_pol().wgrad_wgs : wg_auto;
     long long chunks = (wg_target + tiles - 1) / tiles;
     long long rows = (M + chunks - 1) / chunks;

@@ -92,6 +92,7 @@ class HostPolicy(object):
     train_fused_dec0 = True    # ... and decoder[0] + IGDN1(512) likewise (conv_gdn512.hip)
     train_fused_conv0 = True   # ... and encoder[0] + GDN1(96) (conv0_gdn96.hip, pixel-pair input)
     bn_train_hip = True        # BatchNorm2d (training mode) + ReLU + residual add of trainable Bottleneck blocks on sc2_bn_train_* (stage 2)
+    conv_train_hip = True      # ... and their convolutions on autograd._ConvFn (forward, data and weight gradient on the library's kernels)
     maxpool_hip = True         # nn.MaxPool2d behind a frozen stem (teacher, input-compression classifier) on sc2_maxpool_nhwc (False: torch's)
     relu_mask_fused = True     # the ReLU gradient behind a frozen block's conv2 / conv3 data gradient inside that launch's epilogue (window-plane kernels)
     mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass

@@ -79,10 +79,12 @@ class Bottleneck(nn.Module):
         ds_ok = ds is None or (isinstance(ds, nn.Sequential) and len(ds) == 2 and isinstance(ds[0], nn.Conv2d))
         if not (ds_ok and all(A.bn_module_ok(b) for b in (self.bn1, self.bn2, self.bn3) + ((ds[1],) if ds is not None else ()))):
             return None
-        out = A.bn_act(self.bn1, self.conv1(x), relu=True)
-        out = A.bn_act(self.bn2, self.conv2(out), relu=True)
-        identity = x if ds is None else A.bn_act(ds[1], ds[0](x), relu=False)
-        return A.bn_act(self.bn3, self.conv3(out), relu=True, residual=identity)
+        def conv(m, t):     # (the library's conv kernels under autograd where the layer allows, else the module)
+            return A.conv_train(m, t) if A.conv_module_ok(m) else m(t)
+        out = A.bn_act(self.bn1, conv(self.conv1, x), relu=True)
+        out = A.bn_act(self.bn2, conv(self.conv2, out), relu=True)
+        identity = x if ds is None else A.bn_act(ds[1], conv(ds[0], x), relu=False)
+        return A.bn_act(self.bn3, conv(self.conv3, out), relu=True, residual=identity)
 
 
 class ResNet(nn.Module):
