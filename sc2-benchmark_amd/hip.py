@@ -93,6 +93,7 @@ class HostPolicy(object):
     train_fused_conv0 = True   # ... and encoder[0] + GDN1(96) (conv0_gdn96.hip, pixel-pair input)
     bn_train_hip = True        # BatchNorm2d (training mode) + ReLU + residual add of trainable Bottleneck blocks on sc2_bn_train_* (stage 2)
     conv_train_hip = True      # ... and their convolutions on autograd._ConvFn (forward, data and weight gradient on the library's kernels)
+    pack_gather = True         # pack_conv_weight as one cast + one gather through a cached index map (False: the chain of layout ops)
     maxpool_hip = True         # nn.MaxPool2d behind a frozen stem (teacher, input-compression classifier) on sc2_maxpool_nhwc (False: torch's)
     relu_mask_fused = True     # the ReLU gradient behind a frozen block's conv2 / conv3 data gradient inside that launch's epilogue (window-plane kernels)
     mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass
@@ -381,23 +382,22 @@ def weight_pitch(k):
 K_TAP_MAJOR, K_SLAB_MAJOR, K_B_TILE_MAJOR, K_B_FRAG_MAJOR = 0, 1, 2, 4   # the last two: flags OR-ed into the k order
 
 
-def pack_conv_weight(w, k_order=K_TAP_MAJOR):
-    """w: [Cout, Cin, KH, KW] (any float dtype, device) -> bf16 [Cout_pad, Kpad].
-
+def _pack_layout(t, k_order, fill):
+    """The packed-weight LAYOUT on any tensor t [Cout, Cin, KH, KW] (any dtype): -> [Cout_pad, Kpad], padding = `fill`.
     K_TAP_MAJOR: k = (kh*KW+kw)*Cin+ci.  K_SLAB_MAJOR (Cin % 32 == 0): k = ((ci//32)*KH*KW + kh*KW+kw)*32 + ci%32."""
-    cout, cin, kh, kw = w.shape
+    cout, cin, kh, kw = t.shape
     k = cin * kh * kw
     rows, pitch = weight_rows(cout), weight_pitch(k)
-    packed = torch.zeros((rows, pitch), dtype=torch.bfloat16, device=w.device)
+    packed = torch.full((rows, pitch), fill, dtype=t.dtype, device=t.device)
     tile_major = bool(k_order & K_B_TILE_MAJOR)
     frag_major = bool(k_order & K_B_FRAG_MAJOR)
     k_order = k_order & 1
     if k_order == K_SLAB_MAJOR:
         assert cin % 32 == 0
-        flat = w.detach().reshape(cout, cin // 32, 32, kh * kw).permute(0, 1, 3, 2).reshape(cout, k)
+        flat = t.reshape(cout, cin // 32, 32, kh * kw).permute(0, 1, 3, 2).reshape(cout, k)
     else:
-        flat = w.detach().permute(0, 2, 3, 1).reshape(cout, k)
-    packed[:cout, :k] = flat.to(torch.bfloat16)
+        flat = t.permute(0, 2, 3, 1).reshape(cout, k)
+    packed[:cout, :k] = flat
     if frag_major:   # [k-step][16-row tile][lane = fq*16 + frow][8]: one MFMA operand fragment = 1 KB contiguous
         rows, kpad = packed.shape
         assert rows % 16 == 0 and not tile_major
@@ -406,6 +406,54 @@ def pack_conv_weight(w, k_order=K_TAP_MAJOR):
         rows, kpad = packed.shape
         packed = packed.reshape(rows, kpad // 32, 32).permute(1, 0, 2).contiguous().reshape(rows, kpad)
     return packed
+
+
+def _pack_conv_weight_reference(w, k_order=K_TAP_MAJOR):
+    """pack_conv_weight as the chain of layout ops it was written as (tests compare the gather form with it)."""
+    return _pack_layout(w.detach().to(torch.bfloat16), k_order, 0.0)
+
+
+_PACK_INDEX = {}      # (Cout, Cin, KH, KW, k_order, sub-filter key, device) -> (int32 gather map into the flat weight + one zero, shape)
+
+
+def _pack_index(shape, k_order, device, sub=None):
+    """Gather map of the packed layout: entry -> element of the flat [Cout, Cin, KH, KW] parameter it holds, or n (an appended zero)
+    for padding.  `sub` = (rh, sh, rw, sw): the map of the DATA GRADIENT's sub-filter of one stride-parity class -- the weight seen as
+    [Cin, Cout, KH, KW], taps kh = rh + sh t, kw = rw + sw u, both flipped (hip.conv2d_dgrad) -- packed straight from the parameter."""
+    key = (tuple(shape), k_order, sub, str(device))
+    hit = _PACK_INDEX.get(key)
+    if hit is None:
+        n = 1
+        for v in shape:
+            n *= int(v)
+        idx = torch.arange(n, dtype=torch.int64, device=device).reshape(tuple(shape))
+        if sub is not None:
+            rh, sh, rw, sw = sub
+            idx = idx.permute(1, 0, 2, 3)[:, :, rh::sh, rw::sw].flip(2, 3).contiguous()
+        lay = _pack_layout(idx, k_order, n)
+        hit = (lay.reshape(-1).to(torch.int32), tuple(lay.shape), bool((lay == n).any().item()))
+        if len(_PACK_INDEX) > 512:
+            _PACK_INDEX.clear()
+        _PACK_INDEX[key] = hit
+    return hit
+
+
+def pack_conv_weight(w, k_order=K_TAP_MAJOR, _sub=None):
+    """w: [Cout, Cin, KH, KW] (any float dtype, device) -> bf16 [Cout_pad, Kpad].
+
+    K_TAP_MAJOR: k = (kh*KW+kw)*Cin+ci.  K_SLAB_MAJOR (Cin % 32 == 0): k = ((ci//32)*KH*KW + kh*KW+kw)*32 + ci%32.
+    One cast and ONE gather through a cached index map (round 5: the chain of layout ops this replaces was five small launches per
+    call, and a training step packs every trainable conv -- and every sub-filter of its data gradient -- anew)."""
+    if not host_policy.pack_gather:      # A/B: the chain of layout ops
+        if _sub is not None:
+            rh, sh, rw, sw = _sub
+            w = w.detach().permute(1, 0, 2, 3)[:, :, rh::sh, rw::sw].flip(2, 3).contiguous()
+        return _pack_conv_weight_reference(w, k_order)
+    idx, shape, padded = _pack_index(w.shape, k_order, w.device, _sub)
+    flat = w.detach().reshape(-1).to(torch.bfloat16)
+    if padded:
+        flat = torch.cat([flat, flat.new_zeros(1)])
+    return torch.index_select(flat, 0, idx).reshape(shape)
 
 
 def conv_patch_supported(x_shape, cout, kh, kw, stride, pad, out_format=OUT_BF16_NHWC, epilogue=EPI_NONE):
@@ -640,11 +688,11 @@ def conv2d_dgrad(gy_nhwc, weight, stride, pad, in_hw, out_dtype=torch.bfloat16, 
             packed = cache.get(key) if cache is not None else None
             if packed is None:
                 # (strided SLICES, not index lists: an index list is a host tensor copied to the device per call)
-                sub = wt[:, :, rh::sh, rw::sw].flip(2, 3).contiguous()      # taps in correlation order
-                if win2:
-                    packed = (pack_conv2x2_win(sub[:256]), pack_conv2x2_win(sub[256:]))
-                else:
-                    packed = pack_conv2x2_win(sub) if win else pack_conv_weight(sub)
+                if win or win2:
+                    sub = wt[:, :, rh::sh, rw::sw].flip(2, 3).contiguous()      # taps in correlation order
+                    packed = (pack_conv2x2_win(sub[:256]), pack_conv2x2_win(sub[256:])) if win2 else pack_conv2x2_win(sub)
+                else:   # (one gather from the parameter itself: sub-filter, flip and packed layout folded into the index map)
+                    packed = pack_conv_weight(weight, K_TAP_MAJOR, _sub=(rh, sh, rw, sw))
                 if cache is not None:
                     cache[key] = packed
             if sh == 1 and sw == 1:

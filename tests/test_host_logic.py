@@ -144,3 +144,35 @@ def test_bpp_loss_and_file_size(S, R, golden):
     acc = S.FileSizeAccumulator(unit='KB')
     acc.analyze(2048)
     assert acc.file_size_list == [2.0] and acc.summary()['count'] == 1
+
+
+def test_pack_conv_weight_gather_equals_the_layout_chain(S):
+    """hip.pack_conv_weight packs through a cached gather map (one cast + one index_select); the chain of layout ops it replaced stays as
+    `_pack_conv_weight_reference`: the two are bit-identical for every k order / tile / fragment layout, for padded and unpadded
+    shapes, and for the data gradient's sub-filters packed straight from the parameter (`_sub`)."""
+    import torch
+    hip = S.hip
+    torch.manual_seed(0)
+    for shape in [(96, 3, 5, 5), (48, 96, 5, 5), (24, 48, 2, 2), (512, 24, 2, 2), (256, 512, 2, 2), (128, 128, 3, 3), (1024, 256, 1, 1),
+                  (40, 72, 3, 3), (8, 8, 3, 3), (136, 264, 2, 2)]:
+        w = torch.randn(shape)
+        for order in (hip.K_TAP_MAJOR, hip.K_SLAB_MAJOR, hip.K_TAP_MAJOR | hip.K_B_TILE_MAJOR, hip.K_SLAB_MAJOR | hip.K_B_TILE_MAJOR,
+                      hip.K_SLAB_MAJOR | hip.K_B_FRAG_MAJOR, hip.K_TAP_MAJOR | hip.K_B_FRAG_MAJOR):
+            if (order & 1) == hip.K_SLAB_MAJOR and shape[1] % 32:
+                continue
+            if (order & hip.K_B_FRAG_MAJOR) and hip.weight_rows(shape[0]) % 16:
+                continue
+            a, b = hip.pack_conv_weight(w, order), hip._pack_conv_weight_reference(w, order)
+            assert a.shape == b.shape and torch.equal(a.view(torch.int16), b.view(torch.int16)), (shape, order)
+        wt = w.permute(1, 0, 2, 3)
+        for st, pd in ((1, 0), (1, 1), (2, 1), (2, 2)):
+            for ch in range(st):
+                for cw in range(st):
+                    rh, rw = (ch + pd) % st, (cw + pd) % st
+                    if rh >= shape[2] or rw >= shape[3]:
+                        continue
+                    sub = wt[:, :, rh::st, rw::st].flip(2, 3).contiguous()
+                    a = hip.pack_conv_weight(w, hip.K_TAP_MAJOR, _sub=(rh, st, rw, st))
+                    b = hip._pack_conv_weight_reference(sub)
+                    assert a.shape == b.shape and torch.equal(a.view(torch.int16), b.view(torch.int16)), (shape, st, pd, ch, cw)
+
