@@ -375,8 +375,12 @@ def train_bench(args, dev, rank, world, distributed, emit=True):
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'stage 2 of the Entropic-Student recipe (KD loss; decoder + layer2-4 + fc train with batch-statistics '
-                                   'BatchNorm on torch / MIOpen ops, encoder + prior frozen, frozen teacher on the HIP stacks)' if stage2 else
+            'config': {'workload': ('stage 2 of the Entropic-Student recipe (KD loss; decoder + layer2-4 + fc train with batch-statistics '
+                                    'BatchNorm: {}; encoder + prior frozen, frozen teacher on the HIP stacks)'.format(
+                                        'norm layers + ReLU + residual add on bn.hip, the blocks\' convs on the library\'s kernels under autograd'
+                                        if (S.hip.host_policy.bn_train_hip and S.hip.host_policy.conv_train_hip) else
+                                        'norm layers on bn.hip, convs on torch / MIOpen' if S.hip.host_policy.bn_train_hip else
+                                        'on torch / MIOpen ops under bf16 autocast')) if stage2 else
                                    'stage 1 of the Entropic-Student recipe (bottleneck trains, layer2-4 frozen, frozen teacher)',
                        'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'gradient_all_reduce_bytes': stage.reducer.nbytes(),
                        'sharding': 'images; one flat-bucket all-reduce per step',
