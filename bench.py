@@ -826,7 +826,7 @@ def secondary_lines(args, dev):
                 rows[name] = {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': a.steps,
                               'workload': line['config']['workload'], 'batch': line['config']['batch_per_gpu']}
             else:
-                a.workload, a.steps = name, (40 if name == 'det800x1216' else 20)
+                a.workload, a.steps = name, 40      # (40 steps, as the stand-alone `--workload` lines: at 20 the coder chains' ramp is a third of the region)
                 line = workload_bench(a, dev, 0, 1, False, emit=False)
                 rows[name] = {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': a.steps,
                               'bpp': line['bpp'], 'bpp_estimated': line['bpp_estimated'], 'batch': line['config']['batch_per_gpu'],
