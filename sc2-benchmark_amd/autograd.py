@@ -16,6 +16,31 @@ import torch
 from . import hip
 
 
+def _backward_pass_id():
+    """id of the autograd graph task the caller's backward() runs in (-1 outside a backward pass)."""
+    return torch._C._current_graph_task_id()
+
+
+class MseSink(list):
+    """Hand-over list between the MSE nodes on a producer's output and the producer's own backward.  Every entry is tagged with
+    the backward pass (autograd graph task) that wrote it: the producer applies the entries of ITS pass only and drops the rest,
+    so an entry left behind by a pass in which the producer's backward never ran (`torch.autograd.grad(loss, inputs=[feature])`,
+    an exception mid-backward) is neither applied later nor applied twice on a retained graph.
+
+    Restriction (documented in DESIGN.md section 7): with the sink in use the tensor-level gradient of the producer's output does
+    not carry the MSE term -- `mse_fast_path` therefore hands no sink to an output that retains its gradient or carries tensor
+    hooks AT THE TIME THE LOSS IS BUILT; register such hooks before computing the loss, or switch `host_policy.mse_fused` off."""
+
+    def put(self, entry):
+        self.append((_backward_pass_id(), entry))
+
+    def drain(self):
+        now = _backward_pass_id()
+        mine = [e for pid, e in self if pid == now]
+        self.clear()
+        return mine
+
+
 def _cl(t_nhwc):
     """bf16 [N,H,W,C] -> logical [N,C,H,W] view with channels_last strides (no copy)."""
     return t_nhwc.permute(0, 3, 1, 2)
@@ -62,7 +87,7 @@ class _ConvFn(torch.autograd.Function):
         ctx.cfg = (stride, pad, out_format, w_view)
         # a feature-matching MSE term on this output may hand (its operands, scale) over instead of a gradient tensor
         # (frozen.MseSumFn.backward): the sink travels on the output (and on the channels_last view synthesis_autograd returns)
-        ctx.mse_sink = []
+        ctx.mse_sink = MseSink()
         if out_format == hip.OUT_BF16_NHWC:
             y._sc2_mse_sink = ctx.mse_sink
         return y
@@ -71,8 +96,8 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         x_nhwc, weight = ctx.saved_tensors
         stride, pad, out_format, w_view = ctx.cfg
-        sink = list(ctx.mse_sink)        # (the MSE nodes keep the list itself: emptied, not replaced -- a retained graph may run again)
-        ctx.mse_sink.clear()
+        sink = ctx.mse_sink.drain()      # (the MSE nodes keep the list itself: emptied, not replaced -- a retained graph may run
+                                         #  again; entries of another backward pass are dropped, frozen.MseSink)
         if out_format == hip.OUT_BF16_NHWC:
             g = gy.contiguous()
             for xs, ts, scale in sink:           # 2 scale (y - t) added in one pass (no gradient tensor, no separate add)
@@ -546,6 +571,8 @@ def _nhwc_bf16(t):
 def bn_act(bn, x, relu, residual=None):
     """relu?(bn(x) (+ residual)) for a training-mode nn.BatchNorm2d (bn_module_ok) on NCHW-shaped device tensors; bf16 channels_last
     in (anything else is converted), a bf16 channels_last view out."""
+    if x.numel() // x.shape[1] <= 1:      # nn.BatchNorm2d's own refusal (torch.nn.functional._verify_batch_size): variance of one value
+        raise ValueError('Expected more than 1 value per channel when training, got input size {}'.format(x.size()))
     with torch.no_grad():
         bn.num_batches_tracked.add_(1)
     res = _nhwc_bf16(residual) if residual is not None else None

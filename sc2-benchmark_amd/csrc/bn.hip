@@ -280,6 +280,8 @@ extern "C" int sc2_bn_train_fwd(const void *x, const void *residual, const float
     SC2_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && ws, SC2_ERR_INVALID_ARG, "bn_train_fwd: null argument");
     SC2_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SC2_ERR_INVALID_ARG, "bn_train_fwd: running_mean and running_var go together");
     SC2_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C / 8 <= 256, SC2_ERR_INVALID_ARG, "bn_train_fwd: bad dims M=%lld C=%d (C %% 8 == 0, C <= 2048)", M, C);
+    // one value per channel has no variance: nn.BatchNorm2d refuses it in training mode ("Expected more than 1 value per channel"), so does this
+    SC2_REQUIRE(M > 1, SC2_ERR_INVALID_ARG, "bn_train_fwd: expected more than 1 value per channel when training (M=%lld)", M);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned nb = bn_reduce_blocks(M, C);
     float *coef = ws + (size_t)nb * 2 * C;          // scale, shift behind the partial sums

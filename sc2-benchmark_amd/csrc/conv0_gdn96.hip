@@ -338,9 +338,8 @@ __global__ __launch_bounds__(256, 2) void conv0_gdn96_kernel(const EncArgs p) {
     }
 }
 
-constexpr int kMaxDev0 = 16, kRing0 = 256;
-int g_cus0[kMaxDev0] = {};
-unsigned *g_ring0[kMaxDev0] = {};
+constexpr int kRing0 = 256;
+sc2_counter_ring g_ring0;
 std::atomic<unsigned> g_seq0{0};
 
 }  // namespace
@@ -388,24 +387,11 @@ int launch_conv0_gdn96(const void *x, const void *w_frag, const void *gamma_frag
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    SC2_REQUIRE(dev >= 0 && dev < kMaxDev0, SC2_ERR_UNSUPPORTED, "conv0_gdn96: device ordinal %d out of range", dev);
-    if (g_cus0[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_cus0[dev] = n;
-    }
-    if (!g_ring0[dev]) {
-        void *ptr = nullptr;
-        SC2_REQUIRE(hipMalloc(&ptr, kRing0 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
-                    "conv0_gdn96: cannot allocate the unit counters");
-        SC2_REQUIRE(hipMemset(ptr, 0, kRing0 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
-                    "conv0_gdn96: cannot clear the unit counters");
-        g_ring0[dev] = static_cast<unsigned *>(ptr);
-    }
-    const int grid = a.n_units < 2 * g_cus0[dev] ? a.n_units : 2 * g_cus0[dev];   // two workgroups per CU
-    a.unit_ctr = g_ring0[dev] + (g_seq0.fetch_add(1) % kRing0);
+    const int cus0 = sc2_device_cus();
+    unsigned *ring = g_ring0.get(kRing0);
+    if (!ring) return SC2_ERR_INTERNAL;
+    const int grid = a.n_units < 2 * cus0 ? a.n_units : 2 * cus0;   // two workgroups per CU
+    a.unit_ctr = ring + (g_seq0.fetch_add(1) % kRing0);
     const bool seg = W_pairs != OW;
     if (inverse && seg) hipLaunchKernelGGL((conv0_gdn96_kernel<true, true, PLANAR, EMIT>), dim3(grid), dim3(256), lds, s, a);
     else if (inverse) hipLaunchKernelGGL((conv0_gdn96_kernel<true, false, PLANAR, EMIT>), dim3(grid), dim3(256), lds, s, a);

@@ -291,9 +291,8 @@ __global__ __launch_bounds__(256, 1) void conv1x1_kres_kernel(const KresArgs p) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile prefetched for a unit that does not exist
 }
 
-int g_cus_k = 0;
-constexpr int kMaxDevK = 16, kRingK = 1024;
-unsigned *g_ring_k[kMaxDevK] = {};
+constexpr int kRingK = 1024;
+sc2_counter_ring g_ring_k;
 std::atomic<unsigned> g_seq_k{0};
 
 template <class S>
@@ -307,29 +306,13 @@ int launch_kres(KresArgs a, hipStream_t s) {
                                   S::LDS_BYTES);
         attr_set = true;
     }
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= kMaxDevK) {
-        sc2_set_error("conv1x1_kres: device ordinal %d out of range", dev);
-        return SC2_ERR_UNSUPPORTED;
-    }
-    if (g_cus_k == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_cus_k = n;
-    }
-    if (!g_ring_k[dev]) {
-        void *ptr = nullptr;
-        if (hipMalloc(&ptr, kRingK * sizeof(unsigned)) != hipSuccess || hipMemset(ptr, 0, kRingK * sizeof(unsigned)) != hipSuccess) {
-            sc2_set_error("conv1x1_kres: cannot allocate the unit counters");
-            return SC2_ERR_INTERNAL;
-        }
-        g_ring_k[dev] = static_cast<unsigned *>(ptr);
-    }
+    const int g_cus_k = sc2_device_cus();
+    unsigned *ring = g_ring_k.get(kRingK);
+    if (!ring) return SC2_ERR_INTERNAL;
     const long long units = (long long)a.n_tiles * a.n_chunks;
     int grid = units < g_cus_k ? (int)units : g_cus_k;          // one 4-wave workgroup per CU
     if (grid < 8 * a.n_chunks) grid = 8 * a.n_chunks;           // every (XCD, chunk) needs a workgroup
-    a.unit_ctr = g_ring_k[dev] + 128 * (g_seq_k.fetch_add(1) % (kRingK / 128));   // [8 XCDs][16 chunks] counters per launch
+    a.unit_ctr = ring + 128 * (g_seq_k.fetch_add(1) % (kRingK / 128));   // [8 XCDs][16 chunks] counters per launch
     hipLaunchKernelGGL(conv1x1_kres_kernel<S>, dim3(grid), dim3(256), S::LDS_BYTES, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;

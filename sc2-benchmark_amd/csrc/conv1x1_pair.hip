@@ -401,8 +401,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_pair_kernel(const PairArgs p) 
     }
 }
 
-constexpr int kMaxDev = 16, kRing = 256;
-unsigned *g_ring[kMaxDev] = {};
+constexpr int kRing = 256;
+sc2_counter_ring g_ring;
 std::atomic<unsigned> g_seq{0};
 
 template <int C, int K1, int N2, int MT>
@@ -410,38 +410,21 @@ int launch_pair(const PairArgs &a, hipStream_t s) {
     constexpr int P = MT * 16;
     constexpr int lds = P * C * 2 + (K1 / 32) * P * 64 + 16 + (C + N2) * 4;
     static_assert(lds <= 160 * 1024, "image + o tile must fit the CU's LDS");
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= kMaxDev) {
-        sc2_set_error("conv1x1_pair: device ordinal %d out of range", dev);
-        return SC2_ERR_UNSUPPORTED;
-    }
     // per DEVICE, like the tile counters: the dynamic-LDS attribute of a function is a property of the device's code object, and
     // a process may launch on several devices
-    static bool attr_set[kMaxDev] = {};
-    static int cus[kMaxDev] = {};
+    static bool attr_set[SC2_MAX_DEVICES] = {};
+    const int dev = sc2_device_slot();
     if (!attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv1x1_pair_kernel<C, K1, N2, MT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set[dev] = true;
     }
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    const int g_cus = cus[dev];
-    if (!g_ring[dev]) {
-        void *ptr = nullptr;
-        if (hipMalloc(&ptr, kRing * sizeof(unsigned)) != hipSuccess || hipMemset(ptr, 0, kRing * sizeof(unsigned)) != hipSuccess) {
-            sc2_set_error("conv1x1_pair: cannot allocate the tile counters");
-            return SC2_ERR_INTERNAL;
-        }
-        g_ring[dev] = static_cast<unsigned *>(ptr);
-    }
+    const int g_cus = sc2_device_cus();
+    unsigned *ring = g_ring.get(kRing);
+    if (!ring) return SC2_ERR_INTERNAL;
     PairArgs b = a;
     b.n_tiles = (a.M + P - 1) / P;
-    b.tile_ctr = g_ring[dev] + (g_seq.fetch_add(1) % kRing);
+    b.tile_ctr = ring + (g_seq.fetch_add(1) % kRing);
     {
         // Every other launch walks its tiles from the END of the map (SC2_PAIR_ALT=0: always front to back).  The block input a
         // launch re-reads as the identity was written by the previous pair launch front to back; read front to back again, its

@@ -284,9 +284,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_stream_kernel(const StreamArgs
     }
 }
 
-int g_cus = 0;
-constexpr int kMaxDev = 16, kRing = 256;
-unsigned *g_ring[kMaxDev] = {};
+constexpr int kRing = 256;
+sc2_counter_ring g_ring;
 std::atomic<unsigned> g_seq{0};
 
 template <int K, int BM, int BNC, bool RES, bool MASK = false>
@@ -307,41 +306,23 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= kMaxDev) {
-        sc2_set_error("conv1x1_stream: device ordinal %d out of range", dev);
-        return SC2_ERR_UNSUPPORTED;
-    }
-    if (g_cus == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_cus = n;
-    }
-    if (!g_ring[dev]) {
-        void *ptr = nullptr;
-        if (hipMalloc(&ptr, kRing * sizeof(unsigned)) != hipSuccess) {
-            sc2_set_error("conv1x1_stream: cannot allocate the unit counters");
-            return SC2_ERR_INTERNAL;
-        }
-        if (hipMemset(ptr, 0, kRing * sizeof(unsigned)) != hipSuccess) {
-            sc2_set_error("conv1x1_stream: cannot clear the unit counters");
-            return SC2_ERR_INTERNAL;
-        }
-        g_ring[dev] = static_cast<unsigned *>(ptr);
-    }
-    static int per_cu = 0;   // resident workgroups per CU of this instantiation (LDS and registers decide)
+    const int g_cus = sc2_device_cus();
+    unsigned *ring = g_ring.get(kRing);
+    if (!ring) return SC2_ERR_INTERNAL;
+    static sc2_per_device_int per_cu_dev;   // resident workgroups per CU of this instantiation (LDS and registers decide), per device
+    int per_cu = per_cu_dev.here().load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&conv1x1_stream_kernel<K, BM, BNC, RES, MASK>), 512,
                                                          lds) != hipSuccess || n < 1)
             n = 1;
         per_cu = n > 2 ? 2 : n;
+        per_cu_dev.here().store(per_cu, std::memory_order_relaxed);
     }
     const int slots = g_cus * per_cu;
     const int grid = a.n_units < slots ? a.n_units : slots;
     StreamArgs b = a;
-    b.unit_ctr = g_ring[dev] + (g_seq.fetch_add(1) % kRing);
+    b.unit_ctr = ring + (g_seq.fetch_add(1) % kRing);
     hipLaunchKernelGGL((conv1x1_stream_kernel<K, BM, BNC, RES, MASK>), dim3(grid), dim3(512), lds, s, b);
     SC2_CHECK_LAUNCH();
     return SC2_OK;

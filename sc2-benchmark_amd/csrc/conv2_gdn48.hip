@@ -572,9 +572,8 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the patch prefetched for a unit that does not exist
 }
 
-int g_cus2 = 0;
-constexpr int kMaxDev2 = 16, kRing2 = 256;
-unsigned *g_ring2[kMaxDev2] = {};
+constexpr int kRing2 = 256;
+sc2_counter_ring g_ring2;
 std::atomic<unsigned> g_seq2{0};
 
 }  // namespace
@@ -628,24 +627,11 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    SC2_REQUIRE(dev >= 0 && dev < kMaxDev2, SC2_ERR_UNSUPPORTED, "conv2_gdn48: device ordinal %d out of range", dev);
-    if (g_cus2 == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_cus2 = n;
-    }
-    if (!g_ring2[dev]) {
-        void *ptr = nullptr;
-        SC2_REQUIRE(hipMalloc(&ptr, kRing2 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
-                    "conv2_gdn48: cannot allocate the unit counters");
-        SC2_REQUIRE(hipMemset(ptr, 0, kRing2 * sizeof(unsigned)) == hipSuccess, SC2_ERR_INTERNAL,
-                    "conv2_gdn48: cannot clear the unit counters");
-        g_ring2[dev] = static_cast<unsigned *>(ptr);
-    }
+    const int g_cus2 = sc2_device_cus();
+    unsigned *ring = g_ring2.get(kRing2);
+    if (!ring) return SC2_ERR_INTERNAL;
     const int grid = a.n_units < g_cus2 ? a.n_units : g_cus2;   // one 4-wave workgroup per CU
-    a.unit_ctr = g_ring2[dev] + 8 * (g_seq2.fetch_add(1) % (kRing2 / 8));   // eight counters per launch
+    a.unit_ctr = ring + 8 * (g_seq2.fetch_add(1) % (kRing2 / 8));   // eight counters per launch
     a.stamps = nullptr;
 #if SC2_ENC2_STAMPS
     const char *stamp_path = getenv("SC2_ENC2_STAMPS");

@@ -151,14 +151,7 @@ extern "C" int sc2_conv2x2_c48_fwd(const void *x, const void *w_frag, const floa
     a.n_tiles = (int)((M + 15) / 16);
     a.x_bytes = (unsigned)x_bytes;
     // four workgroups of four waves per CU, never more waves than tiles
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n_cu = v;
-        else
-            n_cu = 256;
-    }
+    const int n_cu = sc2_device_cus();
     int grid = n_cu * 4;
     if ((long long)grid * 4 > a.n_tiles) grid = (a.n_tiles + 3) / 4;
     hipLaunchKernelGGL(conv2x2_c48_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);

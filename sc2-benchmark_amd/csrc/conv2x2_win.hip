@@ -639,8 +639,6 @@ __global__ __launch_bounds__(512, 2) void conv2x2_win_kernel(const W2Args p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weight fragments prefetched for a tile that does not exist
 }
 
-int g_cus_w2 = 0;
-
 template <class G, int MODE, bool INVERSE = true>
 int launch_w2(W2Args a, hipStream_t s) {
     constexpr int LDS = MODE != 0 ? G::LDS_FUSED : G::LDS_PLAIN;
@@ -651,12 +649,7 @@ int launch_w2(W2Args a, hipStream_t s) {
                                   LDS);
         attr_set = true;
     }
-    if (g_cus_w2 == 0) {
-        int dev = 0, n = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        g_cus_w2 = n;
-    }
+    const int g_cus_w2 = sc2_device_cus();
     a.nseg = G::RT ? (a.OW + G::SEG - 1) / G::SEG : 1;
     a.tiles_per_img = (a.OH + G::ROWS - 1) / G::ROWS * a.nseg;
     a.n_tiles = a.N * a.tiles_per_img;

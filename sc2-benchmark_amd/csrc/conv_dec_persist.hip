@@ -527,14 +527,10 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
     constexpr int LDS_P = C::STAGES * C::STAGE_BYTES;
     static bool attr_set_dev[SC2_MAX_DEVICES] = {};
     bool &attr_set = attr_set_dev[sc2_device_slot()];
-    static int n_cus = 0;
+    const int n_cus = sc2_device_cus();
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm8p_kernel<C, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_P);
-        int dev = 0, n = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        n_cus = n;
         attr_set = true;
     }
     // tiles per workgroup: SC2_CONV_CHUNK (0 / unset: the default below; large: one static share per CU)

@@ -453,9 +453,8 @@ __global__ __launch_bounds__(512, 2) void conv2x2_gdn512_kernel(const DecArgs p)
     }
 }
 
-int g_num_cus = 0;
-constexpr int kMaxDevices = 16, kCtrRing = 256;
-unsigned *g_ctr_ring[kMaxDevices] = {};
+constexpr int kCtrRing = 256;
+sc2_counter_ring g_ctr_ring;
 std::atomic<unsigned> g_ctr_seq{0};
 
 template <int CIN, bool INVERSE, bool EMIT>
@@ -470,36 +469,14 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (g_num_cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        g_num_cus = n;
-    }
+    const int g_num_cus = sc2_device_cus();
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
     // tile counter: one of a ring of device words (launches in flight on different streams must not share one),
     // preset on the stream to the first unclaimed tile
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= kMaxDevices) {
-        sc2_set_error("conv2x2_gdn512: device ordinal %d out of range", dev);
-        return SC2_ERR_UNSUPPORTED;
-    }
-    if (!g_ctr_ring[dev]) {
-        void *ptr = nullptr;
-        if (hipMalloc(&ptr, kCtrRing * sizeof(unsigned)) != hipSuccess) {
-            sc2_set_error("conv2x2_gdn512: cannot allocate the tile counters");
-            return SC2_ERR_INTERNAL;
-        }
-        if (hipMemset(ptr, 0, kCtrRing * sizeof(unsigned)) != hipSuccess) {
-            sc2_set_error("conv2x2_gdn512: cannot clear the tile counters");
-            return SC2_ERR_INTERNAL;
-        }
-        g_ctr_ring[dev] = static_cast<unsigned *>(ptr);
-    }
+    unsigned *ring = g_ctr_ring.get(kCtrRing);
+    if (!ring) return SC2_ERR_INTERNAL;
     DecArgs b = a;
-    b.tile_ctr = g_ctr_ring[dev] + (g_ctr_seq.fetch_add(1) % kCtrRing);
+    b.tile_ctr = ring + (g_ctr_seq.fetch_add(1) % kCtrRing);
     {
         b.stagger = sc2_pol().dec_stagger;
     }

@@ -523,8 +523,6 @@ __global__ __launch_bounds__(512, 2) void gdn512_rows_kernel(const RowsArgs p) {
 #undef SC2_ROWS_STEP
 }
 
-int g_cus_rows = 0;
-
 template <int CH, int MODE, bool INVERSE>
 int launch_rows(const RowsArgs &a, hipStream_t s) {
     constexpr int lds = RowsGeo<CH>::LDS_BYTES;
@@ -536,12 +534,7 @@ int launch_rows(const RowsArgs &a, hipStream_t s) {
                                   lds);
         attr_set = true;
     }
-    if (g_cus_rows == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        g_cus_rows = n;
-    }
+    const int g_cus_rows = sc2_device_cus();
     const int grid = a.n_tiles < g_cus_rows ? a.n_tiles : g_cus_rows;
     hipLaunchKernelGGL((gdn512_rows_kernel<CH, MODE, INVERSE>), dim3(grid), dim3(512), lds, s, a);
     SC2_CHECK_LAUNCH();

@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/sc2_bottleneck.h"
 
 void sc2_set_error(const char *fmt, ...);
@@ -44,6 +47,50 @@ inline int sc2_device_slot() {
     if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
     return d < SC2_MAX_DEVICES ? d : SC2_MAX_DEVICES - 1;
 }
+
+// CU count of the CURRENT device, cached per device (a launcher may be called from one host thread per GPU: ADVICE r5).
+inline int sc2_device_cus() {
+    static std::atomic<int> cus[SC2_MAX_DEVICES];
+    std::atomic<int> &c = cus[sc2_device_slot()];
+    int n = c.load(std::memory_order_relaxed);
+    if (n == 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        c.store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// Zero-filled device words for a persistent launcher's work counters: ONE allocation per (ring object, device), made once
+// under the ring's mutex and visible to the other host threads through the acquire / release pair.
+struct sc2_counter_ring {
+    std::mutex mu;
+    std::atomic<unsigned *> base[SC2_MAX_DEVICES];
+    unsigned *get(size_t words) {   // nullptr: the allocation failed (sc2_set_error holds the reason)
+        const int d = sc2_device_slot();
+        unsigned *p = base[d].load(std::memory_order_acquire);
+        if (p) return p;
+        std::lock_guard<std::mutex> lock(mu);
+        p = base[d].load(std::memory_order_relaxed);
+        if (p) return p;
+        void *ptr = nullptr;
+        if (hipMalloc(&ptr, words * sizeof(unsigned)) != hipSuccess || hipMemset(ptr, 0, words * sizeof(unsigned)) != hipSuccess ||
+            hipStreamSynchronize(nullptr) != hipSuccess) {   // (the fill runs on the null stream; launches go to non-blocking streams)
+            sc2_set_error("cannot allocate / clear %zu work-counter words on device %d", words, d);
+            return nullptr;
+        }
+        p = static_cast<unsigned *>(ptr);
+        base[d].store(p, std::memory_order_release);
+        return p;
+    }
+};
+
+// "resident workgroups per CU" of one kernel instantiation, cached per device
+struct sc2_per_device_int {
+    std::atomic<int> v[SC2_MAX_DEVICES];
+    std::atomic<int> &here() { return v[sc2_device_slot()]; }
+};
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;

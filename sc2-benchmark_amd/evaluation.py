@@ -65,7 +65,10 @@ def _evaluate_pipelined(model, data_loader, device, max_samples, pipeline_kwargs
     two numbers at the end instead of two per batch.  -> (correct@1, correct@5, samples) as floats."""
     from .pipeline import StagePipeline
     pipe = StagePipeline(model, device, **(pipeline_kwargs or {}))
-    hits = torch.zeros(2, dtype=torch.float64, device=device)
+    # one row of hit counters per back stream: back stage j runs on back stream j % len(back_streams), and two streams adding
+    # into the same two addresses would race
+    n_back = len(pipe.back_streams)
+    hits = torch.zeros(n_back, 2, dtype=torch.float64, device=device)
     targets = {}
     seen = [0]
 
@@ -78,11 +81,18 @@ def _evaluate_pipelined(model, data_loader, device, max_samples, pipeline_kwargs
             yield image.to(device, non_blocking=True)
 
     def on_output(step, output, nbytes, status):
+        # called inside the back stream's context.  The labels were copied on the caller's stream (ordered before this point
+        # through the front stage's wait on it -> coder event -> back stream), but the caching allocator only knows the stream a
+        # block was ALLOCATED on: without record_stream it would hand the block to a later batch's `target.to(device)` as soon as
+        # `target` dies here, while the back stream's eq / topk kernels -- queued milliseconds behind the coder -- still read it
         target = targets.pop(step)
+        bs = torch.cuda.current_stream(device)
+        target.record_stream(bs)
+        row = hits[step % n_back]
         _, preds = output.float().topk(5, 1, True, True)
         corrects = preds.t().eq(target[None])
-        hits[0] += corrects[:1].sum(dtype=torch.float64)
-        hits[1] += corrects[:5].sum(dtype=torch.float64)
+        row[0] += corrects[:1].sum(dtype=torch.float64)
+        row[1] += corrects[:5].sum(dtype=torch.float64)
 
     record = {}
     pipe.run(batches(), on_output=on_output, record=record)
@@ -90,7 +100,7 @@ def _evaluate_pipelined(model, data_loader, device, max_samples, pipeline_kwargs
     from .entropy import _raise_on_status
     for st in record['statuses']:       # every coder launch of the run, read once at the end
         _raise_on_status(st, 'evaluate (stage pipeline)')
-    h = hits.cpu()
+    h = hits.sum(0).cpu()
     return float(h[0]), float(h[1]), seen[0]
 
 

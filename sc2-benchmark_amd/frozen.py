@@ -16,6 +16,7 @@ stack's output (the per-layer MSE terms of the recipe) before calling its backwa
 import torch
 
 from . import hip
+from .autograd import MseSink
 from .head import ConvSpec, _Conv
 from .resnet import Bottleneck
 
@@ -139,7 +140,7 @@ class FrozenStackFn(torch.autograd.Function):
         ctx.stack, ctx.saved = stack, saved
         # MSE terms on this output hand their (target, scale) to this node instead of a gradient tensor (MseSumFn.backward; autograd
         # runs every consumer's backward before the producer's): the sink travels on the output tensor
-        ctx.mse_sink = []
+        ctx.mse_sink = MseSink()
         ctx.set_materialize_grads(False)       # no other gradient: None, not a zero-filled map
         res = out.permute(0, 3, 1, 2)
         res._sc2_mse_sink = ctx.mse_sink
@@ -147,8 +148,7 @@ class FrozenStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        sink = list(ctx.mse_sink)        # (the MSE nodes keep the list itself: emptied, not replaced)
-        ctx.mse_sink.clear()
+        sink = ctx.mse_sink.drain()      # (the MSE nodes keep the list itself: emptied, not replaced; this pass's entries only)
         if gy is None and not sink:
             ctx.saved = None
             return None, None
@@ -189,7 +189,7 @@ class MseSumFn(torch.autograd.Function):
         if ctx.sink is not None:
             # x is the output of a frozen stack (FrozenStackFn): its backward forms 2 scale (x - y) inside its first ReLU-gradient pass
             # (sc2_relu_bwd_mse_bf16) -- no gradient tensor, no add
-            ctx.sink.append((x, y, scale) if ctx.wants_x else (y, scale))      # (a conv node does not keep its output: it gets x too)
+            ctx.sink.put((x, y, scale) if ctx.wants_x else (y, scale))      # (a conv node does not keep its output: it gets x too)
             return None, None, None, None, None
         return hip.mse_grad(x, y, scale), None, None, None, None
 
@@ -202,4 +202,6 @@ def mse_fast_path(loss_module, x, y):
     if not hip._same_dense_bf16(x, y) or y.requires_grad:
         return None
     sink = getattr(x, '_sc2_mse_sink', None) if hip.host_policy.mse_fused and x.requires_grad else None
+    if sink is not None and (x.retains_grad or getattr(x, '_backward_hooks', None)):
+        sink = None       # someone reads d loss / d x off the tensor itself: it must carry the MSE term (MseSink's restriction)
     return MseSumFn.apply(x, y.detach(), loss_module.reduction == 'mean', sink, bool(getattr(x, '_sc2_mse_sink_wants_x', False)))

@@ -888,6 +888,8 @@ def bn_train_fwd(x_nhwc, gamma, beta, running_mean, running_var, momentum, eps, 
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
     C = x_nhwc.shape[3]
     M = x_nhwc.numel() // C
+    if M <= 1:
+        raise ValueError('Expected more than 1 value per channel when training, got input size {}'.format(tuple(x_nhwc.shape)))
     for t in (gamma, beta, running_mean, running_var):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == C and t.device == x_nhwc.device)
     assert residual is None or (residual.dtype == torch.bfloat16 and residual.shape == x_nhwc.shape and residual.is_contiguous())

@@ -175,10 +175,19 @@ class Normalize(nn.Module):
         key = (x.dtype, x.device)
         cached = self.__dict__.get('_consts')
         if cached is None or cached[0] != key or cached[3] != (tuple(self.mean), tuple(self.std)):
-            cached = (key, torch.as_tensor(self.mean, dtype=x.dtype, device=x.device).view(-1, 1, 1),
-                      torch.as_tensor(self.std, dtype=x.dtype, device=x.device).view(-1, 1, 1), (tuple(self.mean), tuple(self.std)))
+            # built OUTSIDE inference mode whatever the caller's mode: evaluate() runs under torch.inference_mode, and an inference
+            # tensor cached there cannot be saved for backward by a later grad-mode call (codec training through
+            # NeuralInputCompressionClassifier's post_transform)
+            with torch.inference_mode(False):
+                cached = (key, torch.as_tensor(self.mean, dtype=x.dtype, device=x.device).view(-1, 1, 1),
+                          torch.as_tensor(self.std, dtype=x.dtype, device=x.device).view(-1, 1, 1), (tuple(self.mean), tuple(self.std)))
             self.__dict__['_consts'] = cached
         return (x - cached[1]) / cached[2]
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_consts', None)          # device tensors of a cache do not belong in a pickle
+        return state
 
 
 @_tv

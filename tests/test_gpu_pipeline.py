@@ -133,3 +133,26 @@ def test_evaluate_on_the_pipeline_counts_the_same_hits(S, dev, bench_mod):
     assert abs(b['acc1'] - 100.0 * 14 / 22) < 1e-9
     c = evaluation.evaluate(model, torch.utils.data.DataLoader(ds, batch_size=1), dev, max_samples=4)
     assert c['pipeline'].startswith('none') and c['samples'] == 4
+
+
+def test_evaluate_pipeline_keeps_each_batch_with_its_own_labels(S, dev, bench_mod):
+    """72 batches with DISTINCT label patterns per batch: the caching allocator is in steady state after the first
+    few batches, so a label block handed back too early (no record_stream for the back stream that scores it) would be
+    overwritten by a later batch's host-to-device copy and batch j scored against other labels.  The per-batch right / wrong
+    pattern differs for every batch, so any such mix-up changes the count."""
+    from sc2bench_amd import evaluation
+    model = bench_mod.build_model(dev)
+    n_batches, bs = 72, 2
+    x = bench_mod.synthetic_batch(8, torch.device('cpu'), seed=5)
+    x = x.repeat(n_batches * bs // 8, 1, 1, 1)
+    with torch.no_grad():
+        top = torch.cat([model(x[i:i + bs].to(dev)).float().argmax(1).cpu() for i in range(0, len(x), bs)])
+    g = torch.Generator().manual_seed(11)
+    wrong = torch.rand(len(x), generator=g) < 0.5                      # which images are labelled wrongly: random per image
+    labels = torch.where(wrong, (top + 1 + torch.arange(len(x))) % 1000, top)
+    expect = 100.0 * float((~wrong).sum()) / len(x)
+    ds = torch.utils.data.TensorDataset(x, labels)
+    for kw in ({'coder_group': 4, 'coder_streams': 2}, {'coder_group': 8, 'coder_streams': 4, 'back_streams': 2}):
+        r = evaluation.evaluate(model, torch.utils.data.DataLoader(ds, batch_size=bs), dev, pipeline=True, pipeline_kwargs=kw)
+        assert r['samples'] == len(x) and r['pipeline'].startswith('stage pipeline')
+        assert abs(r['acc1'] - expect) < 1e-9, (r['acc1'], expect, kw)

@@ -176,3 +176,55 @@ def test_pack_conv_weight_gather_equals_the_layout_chain(S):
                     b = hip._pack_conv_weight_reference(sub)
                     assert a.shape == b.shape and torch.equal(a.view(torch.int16), b.view(torch.int16)), (shape, st, pd, ch, cw)
 
+
+
+def test_mse_sink_entries_belong_to_one_backward_pass(S):
+    """autograd.MseSink: a consumer hands (operands) to its producer through the sink instead of returning a gradient.
+    An entry written in a backward pass in which the producer's backward never runs must not be applied by a later pass, and a
+    retained graph run twice applies each pass's entry once -- on CPU stand-ins with the very hand-over protocol of
+    frozen.MseSumFn / FrozenStackFn."""
+    from sc2bench_amd.autograd import MseSink
+    applied = []
+
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            ctx.sink = MseSink()
+            ctx.set_materialize_grads(False)
+            y = x * 2.0
+            y._sink = ctx.sink
+            return y
+
+        @staticmethod
+        def backward(ctx, gy):
+            entries = ctx.sink.drain()
+            applied.append(len(entries))
+            g = gy if gy is not None else 0.0
+            for (t,) in entries:
+                g = g + t
+            return g * 2.0
+
+    class Consumer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, y, sink):
+            ctx.sink = sink
+            return y.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.sink.put((torch.ones(3) * g,))
+            return None, None
+
+    x = torch.zeros(3, requires_grad=True)
+    y = Producer.apply(x)
+    loss = Consumer.apply(y, y._sink)
+    # pass 1 stops at the feature: the producer's backward does not run, the entry stays behind (and the tensor-level gradient
+    # is None -- the documented restriction)
+    assert torch.autograd.grad(loss, inputs=[y], retain_graph=True, allow_unused=True)[0] is None
+    assert len(y._sink) == 1 and applied == []
+    # pass 2 runs the whole graph: only ITS entry is applied
+    loss.backward(retain_graph=True)
+    assert applied == [1] and torch.equal(x.grad, torch.full((3,), 2.0)) and len(y._sink) == 0
+    # pass 3 on the retained graph: again exactly one
+    loss.backward()
+    assert applied == [1, 1] and torch.equal(x.grad, torch.full((3,), 4.0))
