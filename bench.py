@@ -402,6 +402,26 @@ def train_bench(args, dev, rank, world, distributed, emit=True):
     return line
 
 
+def dry_run_streams(rank):
+    """The per-rank fields of a multi-GPU line (`per_rank`: bpp and the digest of the rank's first 8 byte streams) without a
+    device: 8 streams of rank-seeded symbols through the library's HOST range coder (csrc/rans_host.cpp, product code) on the
+    known-answer table of tests/golden/rans_kat.json."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from sc2bench_amd import hip
+    t = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'rans_kat.json')))['table']
+    width = max(len(r) for r in t['cdfs'])
+    cdf = np.zeros((len(t['cdfs']), width), np.int32)
+    for i, r in enumerate(t['cdfs']):
+        cdf[i, :len(r)] = r
+    tables = hip.HostRansTables(cdf, t['cdf_sizes'], t['offsets'])
+    rng = np.random.RandomState(1000 + rank)
+    sym = rng.randint(-3, 4, size=(8, 24 * 55 * 55)).astype(np.int32)
+    strings, status = hip.rans_encode_host(tables, sym, index_div=sym.shape[1])      # (every symbol of a stream on table row 0)
+    return {'bpp': 8.0 * sum(len(q) for q in strings) / (8 * 224 * 224), 'rans_status': int(status.max()),
+            'bitstream_sha256_first8': sha256_of(strings)}
+
+
 def dry_run(args, world, rank, local_rank):
     """The launch contract without a device: process group (gloo), per-rank shard seed, barrier-bracketed timed region,
     max over ranks, ONE JSON line from rank 0.  No HIP call is made (torch.cuda is not touched)."""
@@ -422,6 +442,7 @@ def dry_run(args, world, rank, local_rank):
     from sc2bench_amd.dataparallel import shard_range
     lo, hi = shard_range(args.bs * world, rank, world)
     info = {'rank': rank, 'local_rank': local_rank, 'seed': rank, 'shard': [lo, hi], 'own_elapsed_s': elapsed, 'own_work_s': own_work}
+    info.update(dry_run_streams(rank))
     ranks = [info]
     n_ranks = None
     if distributed:
@@ -910,6 +931,11 @@ def main():
         if args.gpus != world:
             raise SystemExit('bench.py: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
         return dry_run(args, world, rank, local_rank)
+    numa = None
+    if world > 1:       # (before the first HIP call; one rank alone keeps the whole machine)
+        sys.path.insert(0, ROOT)
+        from sc2bench_amd.dataparallel import bind_rank_to_gpu_numa
+        numa = bind_rank_to_gpu_numa(local_rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -1013,6 +1039,24 @@ def main():
     images = args.bs * args.steps * world
     value = images / elapsed
 
+    per_rank = None
+    if distributed:
+        # every rank's own bpp and the digest of the byte streams of the first 8 images of ITS shard travel to rank 0 as device
+        # tensors on the backend (RCCL cannot gather host objects): a multi-GPU line can be judged for bitstream / bpp parity
+        # rank by rank, not only through rank 0's shard
+        with torch.no_grad():
+            sym_r, hw_r = model.stage_front(x)
+            eb_r = model.bottleneck_layer.entropy_bottleneck
+            buf_r, off_r, nbs_r, sts_r = eb_r.encode_symbols_device(sym_r[:8], hw_r[0] * hw_r[1])
+            digest = sha256_of(eb_r.unpack_strings(buf_r, off_r, nbs_r))
+            del sym_r, buf_r
+        mine = torch.cat([torch.tensor(list(bytes.fromhex(digest)), dtype=torch.float64, device=dev),
+                          torch.tensor([bpp, float(rank), float(int(sts_r.max().item()))], dtype=torch.float64, device=dev)])
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        per_rank = [{'rank': int(r[33].item()), 'bpp': r[32].item(), 'rans_status': int(r[34].item()),
+                     'bitstream_sha256_first8': bytes(int(v) for v in r[:32].tolist()).hex()} for r in rows]
+
     if rank == 0:
         ksum = timer.summary()
         # every launch of the bottleneck forward: the fused conv / GDN launches (mean duration per launch = per step) and the
@@ -1073,7 +1117,25 @@ def main():
                 torch.cuda.synchronize(dev)
             solo_sum = {k: v for k, v in solo.summary().items() if launch_work(k) is not None}
             solo_ms = sum(v[1] for v in solo_sum.values())
+            # ... and on SURVEY 8(d)'s own basis: the ten layers of the bottleneck and nothing else (8.3418 GFLOP per image), i.e.
+            # with the decoder's last conv as a launch of its own instead of the form that carries layer2.0's two 1x1 layers
+            with hip.KernelTimer(select) as solo_p:
+                for _ in range(5):
+                    model.stage_front(x)
+                    model.stage_decoder(dec_s, hw_s)
+                torch.cuda.synchronize(dev)
+            plain_sum = {k: v for k, v in solo_p.summary().items() if launch_work(k) is not None}
+            plain_ms = sum(v[1] for v in plain_sum.values())
             del sym_s, dec_s
+        # steady state of the dominant kernel: a tail run of >= 60 steps after the timed region, the first 8
+        # launches dropped -- with the pipeline full the encoder stage of later steps and the coder share the CUs with it, which a
+        # 20-step region barely reaches
+        steady_steps = max(60, args.steps)
+        with hip.KernelTimer(lambda tag: tag == dom) as steady_t:
+            pipe.run(x, n_steps=steady_steps)
+            sync_all()
+        steady = [r[1].elapsed_time(r[2]) for r in steady_t.records if r[0] == dom][8:]
+        steady_ms = sum(steady) / max(1, len(steady))
         # the device bitstreams of the first 8 images of this shard, and the symbols they were coded from
         with torch.no_grad():
             sym, hw = model.stage_front(x)
@@ -1106,24 +1168,40 @@ def main():
                        'first_encoder_stage_input': 'round-4 layout pass (A/B)' if args.conv0_layout_pass else 'f32 NCHW planes read in place',
                        'sharding': 'images, no collective',
                        'process_group': '{} ({} rank{})'.format(dist.get_backend(), world, '' if world == 1 else 's') if distributed else 'none',
-                       'ranks_reduced': n_ranks},
+                       'ranks_reduced': n_ranks,
+                       'numa_binding': numa if world > 1 else 'none (one rank)'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
             'bytes_per_image_min_mean_max': [nb_f.min().item(), bytes_per_img, nb_f.max().item()],
             'bitstream_sha256_first8': sha256_of(dev_streams),
             'latency_ms_per_batch': {'mean': sum(lat_ms) / max(1, len(lat_ms)), 'max': max(lat_ms) if lat_ms else None,
                                      'what': 'encoder stage start -> logits of the same batch'},
             'host_issue_ms_per_step': 1e3 * issue_s / args.steps,
-            'roofline': dict(per_kernel[dom], kernel=dom, traffic=traffic, launches_timed=conv[dom][0]),
+            'roofline': dict(per_kernel[dom], kernel=dom, traffic=traffic, launches_timed=conv[dom][0],
+                             frac_steady=roof(dom, steady_ms)['frac'],
+                             steady={'kernel_ms': steady_ms, 'launches_averaged': len(steady), 'launches_dropped': 8,
+                                     'what': 'the same kernel in a tail run of {} steps of the same pipeline after the timed region '
+                                             '(pipeline full: the encoder stages of later steps and the coder share the CUs)'.format(steady_steps)}),
             'bottleneck_forward': {'ms_per_batch_sum_of_its_launches': fwd_ms,
                                    'launches_counted': sorted(per_kernel),
                                    'gflop_per_image': fwd_gflop,
                                    'tflops': fwd_gflop * args.bs / fwd_ms,
                                    'frac_of_mfma_peak': fwd_gflop * args.bs / fwd_ms / PEAK_BF16_TFLOPS,
+                                   # SURVEY 8(d)'s numerator only: the rider's FLOPs left out, its time left IN (a lower bound)
+                                   'frac_8p3418': BOTTLENECK_GFLOP_PER_IMG * args.bs / fwd_ms / PEAK_BF16_TFLOPS,
+                                   'head_2_0_rider': {'gflop_per_image': fwd_gflop - BOTTLENECK_GFLOP_PER_IMG,
+                                                      'stand_alone_ms': solo_ms - plain_ms,
+                                                      'what': 'layer2.0 conv1 + downsample of the task head, carried by the decoder\'s last launch '
+                                                              '(dec.conv4+head.2.0); stand_alone_ms = that launch minus dec.conv4 as a launch of its own'},
                                    'roofline_floor_ms_of_this_launch_structure': floor_ms,
                                    'frac_of_floor': floor_ms / fwd_ms,
                                    'stand_alone': {'ms_per_batch': solo_ms, 'frac_of_mfma_peak': fwd_gflop * args.bs / solo_ms / PEAK_BF16_TFLOPS,
                                                    'what': 'the same launches (without the dequantise pass) on one stream with nothing beside them, 5 repetitions after the timed region',
-                                                   'kernels_ms': {k: round(v[1], 4) for k, v in sorted(solo_sum.items())}}},
+                                                   'kernels_ms': {k: round(v[1], 4) for k, v in sorted(solo_sum.items())},
+                                                   'frac_8p3418': BOTTLENECK_GFLOP_PER_IMG * args.bs / plain_ms / PEAK_BF16_TFLOPS,
+                                                   'ms_per_batch_8p3418': plain_ms,
+                                                   'kernels_ms_8p3418': {k: round(v[1], 4) for k, v in sorted(plain_sum.items())},
+                                                   'what_8p3418': 'SURVEY 8(d) basis: the bottleneck\'s ten layers alone (dec.conv4 as a launch of its '
+                                                                  'own, no head layer inside), 8.3418 GFLOP per image'}},
             'kernel_rooflines': {k: {'bound': v['bound'], 'frac': round(v['frac'], 4), 'tflops': round(v['tflops'], 1),
                                      'gbs': round(v['gbs'], 1), 'ms': round(v['kernel_ms'], 4)}
                                  for k, v in sorted(per_kernel.items())},
@@ -1131,6 +1209,9 @@ def main():
         }
         if traffic_note:
             out['roofline']['traffic_note'] = traffic_note
+        if per_rank is not None:
+            out['per_rank'] = sorted(per_rank, key=lambda r: r['rank'])
+            out['config']['ranks_gathered'] = len(per_rank)
         if 'rans_encode' in ksum:
             n_sym = 24 * 55 * 55
             out['rans'] = {'encode_ms': ksum['rans_encode'][1], 'decode_ms': ksum['rans_decode'][1],

@@ -48,6 +48,72 @@ def init_distributed(backend=None):
     return dist.is_initialized() and collectives_active(), rank, world, device
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(local_rank, sysfs_root='/sys'):
+    """NUMA node of the `local_rank`-th GPU, read from sysfs -- NO HIP call (a rank binds itself before it touches the device).
+    GPUs are the KFD topology nodes with SIMDs, in node order = the runtime's device order unless HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES re-map it (then the n-th VISIBLE index is looked up); a node's `location_id` and `domain` give its PCI
+    address, whose `numa_node` file is the answer.  -> int >= 0, or None (unknown, one node, not a bare-metal topology)."""
+    import os
+    try:
+        nodes_dir = os.path.join(sysfs_root, 'class', 'kfd', 'kfd', 'topology', 'nodes')
+        gpus = []
+        for name in sorted(os.listdir(nodes_dir), key=int):
+            props = {}
+            with open(os.path.join(nodes_dir, name, 'properties')) as f:
+                for ln in f:
+                    k, _, v = ln.strip().partition(' ')
+                    props[k] = v
+            if int(props.get('simd_count', '0')) > 0:
+                gpus.append(props)
+        visible = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')
+        index = local_rank
+        if visible:
+            ids = [v.strip() for v in visible.split(',') if v.strip()]
+            if local_rank < len(ids) and ids[local_rank].isdigit():
+                index = int(ids[local_rank])
+        if not 0 <= index < len(gpus):
+            return None
+        loc, dom = int(gpus[index]['location_id']), int(gpus[index].get('domain', '0'))
+        bdf = '{:04x}:{:02x}:{:02x}.{:x}'.format(dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 0x7)
+        with open(os.path.join(sysfs_root, 'bus', 'pci', 'devices', bdf, 'numa_node')) as f:
+            node = int(f.read().strip())
+        return node if node >= 0 else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def bind_rank_to_gpu_numa(local_rank, sysfs_root='/sys'):
+    """Pins the calling process (every thread it starts later inherits the mask: the host coder's pool, the data-loader workers, the
+    launch thread) to the CPUs of the NUMA node its GPU hangs off.  Eight ranks on a two-socket node otherwise share whatever
+    cores the scheduler picks, and a rank whose launch thread sits on the far socket pays the inter-socket hop on every
+    doorbell and every pinned-buffer copy.  Call BEFORE the first HIP call.  -> {'numa_node', 'cpus'} or None (nothing bound:
+    unknown topology, a single node, or an affinity mask the launcher already narrowed to other CPUs -- that one is respected)."""
+    import os
+    node = gpu_numa_node(local_rank, sysfs_root)
+    if node is None or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        with open(os.path.join(sysfs_root, 'devices', 'system', 'node', 'node{}'.format(node), 'cpulist')) as f:
+            cpus = _parse_cpulist(f.read())
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return {'numa_node': node, 'cpus': len(allowed)}
+    except (OSError, ValueError):
+        return None
+
+
 def shard_range(n_items, rank, world):
     """Contiguous [start, end) slice of n_items for this rank (remainder spread over the first ranks)."""
     base, rem = divmod(n_items, world)

@@ -62,3 +62,9 @@ def build_oracle_factorized_prior(RI, R, quality=8):
     m.eval()
     x = torch.rand(2, 3, 64, 128)
     return m, x
+
+
+# Which backend of tests/golden/make_golden.py the COMMITTED fixtures are expected to come from: 'oracle' (the build container:
+# parity unpinned) or 'compressai' (regenerated where the reference's dependencies run: a pin).  Regenerating with the other
+# backend without changing this line -- or changing this line without regenerating -- fails tests/test_golden_backends.py.
+PINNED_BY = 'oracle'

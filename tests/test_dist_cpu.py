@@ -265,6 +265,25 @@ def test_bench_self_launch_dry_run_world8():
     assert slowest >= 5 * 0.008 and ranks[0]['own_work_s'] < ranks[7]['own_work_s'] <= slowest
     assert rec['ms_per_step'] * 5e-3 >= slowest - 1e-6, 'the line does not carry the MAX over ranks'
     assert abs(rec['value'] - 2048 * 5 / (rec['ms_per_step'] * 5e-3)) < 1e-6 * rec['value']
+    # the per-rank fields a multi-GPU line keeps: every rank's own bpp and the digest of its first 8 byte
+    # streams -- in the dry run from the library's host range coder on rank-seeded symbols, so eight DIFFERENT digests
+    digests = [q['bitstream_sha256_first8'] for q in ranks]
+    assert all(len(d) == 64 and int(d, 16) >= 0 for d in digests) and len(set(digests)) == 8
+    assert all(q['rans_status'] == 0 and 0.5 < q['bpp'] < 20.0 for q in ranks)
+    import numpy as np
+    from oracle import rans as oracle_rans
+    import bench as bench_mod
+    # rank 3's streams again, here, through the ORACLE's coder: the digest the rank reported is that of the reference algorithm's bytes
+    t = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'rans_kat.json')))['table']
+    width = max(len(r) for r in t['cdfs'])
+    cdf = np.zeros((len(t['cdfs']), width), np.int32)
+    for i, r in enumerate(t['cdfs']):
+        cdf[i, :len(r)] = r
+    sym = np.random.RandomState(1003).randint(-3, 4, size=(8, 24 * 55 * 55)).astype(np.int32)
+    idx = np.zeros(sym.shape[1], np.int32)
+    ref = [oracle_rans.encode_with_indexes(sym[i], idx, cdf, np.array(t['cdf_sizes'], np.int32), np.array(t['offsets'], np.int32))
+           for i in range(8)]
+    assert bench_mod.sha256_of(ref) == ranks[3]['bitstream_sha256_first8']
 
 
 def test_bench_refuses_gpus_world_mismatch():
@@ -319,3 +338,40 @@ def test_evaluate_world2_sums_totals_and_counts():
         assert abs(res[r][0] - single['acc1']) < 1e-9 and abs(res[r][1] - single['acc5']) < 1e-9
         assert res[r][3] == 10
     assert (res[0][2], res[1][2]) == (7, 3)
+
+
+def test_rank_binds_to_its_gpus_numa_node(tmp_path, monkeypatch):
+    """dataparallel.bind_rank_to_gpu_numa on a fake sysfs tree (two CPU nodes + four GPUs, two per socket): rank r lands on the CPUs
+    of the socket its GPU hangs off, HIP_VISIBLE_DEVICES re-maps the index, an unknown topology binds nothing; no HIP call."""
+    import sc2bench_amd.dataparallel as dp
+    root = tmp_path
+    nodes = root / 'class' / 'kfd' / 'kfd' / 'topology' / 'nodes'
+    cpus_all = sorted(os.sched_getaffinity(0))
+    half = max(1, len(cpus_all) // 2)
+    cpu_sets = [cpus_all[:half], cpus_all[half:] or cpus_all[:half]]
+    for n in (0, 1):          # CPU nodes: no SIMDs
+        (nodes / str(n)).mkdir(parents=True)
+        (nodes / str(n) / 'properties').write_text('cpu_cores_count 4\nsimd_count 0\nlocation_id 0\ndomain 0\n')
+        nd = root / 'devices' / 'system' / 'node' / 'node{}'.format(n)
+        nd.mkdir(parents=True)
+        nd.joinpath('cpulist').write_text(','.join(str(c) for c in cpu_sets[n]) + '\n')
+    for g in range(4):        # GPU g at bus 0x10 * (g + 1), device 0, function 0; GPUs 0, 1 on socket 0, GPUs 2, 3 on socket 1
+        bus = 0x10 * (g + 1)
+        (nodes / str(2 + g)).mkdir()
+        (nodes / str(2 + g) / 'properties').write_text('cpu_cores_count 0\nsimd_count 1024\nlocation_id {}\ndomain 0\n'.format(bus << 8))
+        pd = root / 'bus' / 'pci' / 'devices' / '0000:{:02x}:00.0'.format(bus)
+        pd.mkdir(parents=True)
+        pd.joinpath('numa_node').write_text('{}\n'.format(g // 2))
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES', raising=False)
+    monkeypatch.delenv('ROCR_VISIBLE_DEVICES', raising=False)
+    assert [dp.gpu_numa_node(r, str(root)) for r in range(4)] == [0, 0, 1, 1] and dp.gpu_numa_node(4, str(root)) is None
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '3,0')
+    assert dp.gpu_numa_node(0, str(root)) == 1 and dp.gpu_numa_node(1, str(root)) == 0
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    before = os.sched_getaffinity(0)
+    try:
+        got = dp.bind_rank_to_gpu_numa(2, str(root))
+        assert got == {'numa_node': 1, 'cpus': len(set(cpu_sets[1]))} and os.sched_getaffinity(0) == set(cpu_sets[1])
+    finally:
+        os.sched_setaffinity(0, before)
+    assert dp.bind_rank_to_gpu_numa(0, str(tmp_path / 'nowhere')) is None and os.sched_getaffinity(0) == before
