@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 47
+#define SC2_ABI_VERSION 48
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -638,6 +638,9 @@ typedef struct sc2_rans_host_tables sc2_rans_host_tables;
 int sc2_rans_host_tables_create(const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
                                 const int32_t *offsets, sc2_rans_host_tables **out);
 void sc2_rans_host_tables_destroy(sc2_rans_host_tables *tables);
+/* floor(x / freq) as the host ENCODER forms it (a multiplication by freq's precomputed reciprocal, exact for x < 2^63: the
+ * coder's state never leaves [2^31, 2^63)); exported so that a test can sweep it against the division (1 <= freq <= 65 536). */
+uint64_t sc2_rans_host_rcp_div(uint64_t x, uint32_t freq);
 /* Same arguments, row layout (END-aligned streams, out_offset / out_nbytes) and status bits as sc2_rans_encode_batch /
  * sc2_rans_decode_batch (additionally bit 2 = a CDF-row index outside the table); `out` / `in` 4-byte aligned;
  * streams are spread over n_threads host threads (<= 1: the calling thread). */

@@ -24,5 +24,6 @@ from .dense import (DETECTION_MODEL_FUNC_DICT, SEGMENTATION_MODEL_FUNC_DICT, Bas
                     SegEvaluator, UpdatableBackboneWithFPN, backbone_with_fpn, deeplabv3_model, faster_rcnn_model)
 
 from .pipeline import StagePipeline, supports_stages  # noqa: F401
+from . import graphs  # noqa: F401
 
 __version__ = '0.3.0'

@@ -12,6 +12,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from . import hip
 from .analysis import AnalyzableModule
 from .entropy import CompressionModel
 from .layer import FPBasedResNetBottleneck, get_layer
@@ -50,6 +51,10 @@ class UpdatableBackbone(AnalyzableModule):
     def get_aux_module(self, **kwargs):
         raise NotImplementedError()
 
+    def _drop_eval_graphs(self):
+        """forget captured HIP graphs of the eval forward (graphs.py): their baked-in addresses die with a change of storage / mode"""
+        self.__dict__.pop('_eval_graphs', None)
+
 
 def check_if_updatable(model):
     return isinstance(model, UpdatableBackbone)
@@ -87,6 +92,7 @@ class FeatureExtractionBackbone(UpdatableBackbone):
 
     def set_compute_dtype(self, dtype):
         assert dtype in ('f32', 'bf16')
+        self._drop_eval_graphs()
         self.compute_dtype = dtype
         for name, module in self.named_children():
             if name == self.analyzable_layer_key:
@@ -240,6 +246,7 @@ class SplittableResNet(UpdatableBackbone):
     def set_compute_dtype(self, dtype):
         """'f32' (reference dtype) or 'bf16' (task head in bf16 channels_last, decoder output zero-copy)."""
         assert dtype in ('f32', 'bf16')
+        self._drop_eval_graphs()
         self.compute_dtype = dtype
         head = [m for m in (self.layer2, self.layer3, self.layer4, self.avgpool, self.fc) if m is not None]
         for m in head:
@@ -254,6 +261,7 @@ class SplittableResNet(UpdatableBackbone):
     def set_encoder_precision(self, precision):
         """'f32': the bottleneck's analysis transform with f32 operands, so that symbols / byte streams / bpp are the f32
         reference path's (FPBasedResNetBottleneck.set_encoder_precision); 'bf16': the fast default."""
+        self._drop_eval_graphs()
         self.bottleneck_layer.set_encoder_precision(precision)
         return self
 
@@ -288,10 +296,56 @@ class SplittableResNet(UpdatableBackbone):
         x = torch.flatten(x, 1)
         return self.fc(x)
 
+    # ---- HIP-graph replay of the updated eval forward at the reference's evaluation batch size (graphs.py)
+    def _apply(self, fn, *args, **kwargs):      # .to() / .cuda() / .half(): storage moves, captured addresses die
+        self._drop_eval_graphs()
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode=True):
+        if bool(mode) != self.training:
+            self._drop_eval_graphs()
+        return super().train(mode)
+
+    def _eval_graphs_for(self, x):
+        """graphs.EvalGraphs for this input, or None: bf16 eval on the HIP head, an FP bottleneck on the bf16 encoder whose
+        tables are built, a batch the host range coder takes (`host_policy.eval_graph_max_batch`, default: batch size 1 only)."""
+        if not (hip.host_policy.eval_graphs and isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4 and
+                0 < x.shape[0] <= min(hip.host_policy.eval_graph_max_batch, hip.host_coder_max_streams()) and
+                self.compute_dtype == 'bf16' and self.use_hip_head and self.layer2 is not None and not torch.is_grad_enabled() and
+                type(self.bottleneck_layer) is FPBasedResNetBottleneck and
+                getattr(self.bottleneck_layer, 'encoder_precision', 'bf16') == 'bf16' and
+                getattr(self.bottleneck_layer, 'output_format', '') == 'bf16_nhwc' and x.dtype == torch.float32 and
+                not torch.cuda.is_current_stream_capturing()):
+            return None
+        from .graphs import graphs_for
+        return graphs_for(self, x)
+
+    def _forward_graphed(self, g, x):
+        """forward() of the updated eval model on captured graphs: the same encode -> {'strings', 'shape'} -> analyzers -> decode ->
+        head sequence, the device halves replayed instead of launched kernel by kernel."""
+        eb = self.bottleneck_layer.entropy_bottleneck
+        tables = eb._host_tables()
+        sym_h = g.symbols(x)
+        hw = g.latent_shape[0] * g.latent_shape[1]
+        strings, st = hip.rans_encode_host(tables, sym_h, index_div=hw)
+        from .entropy import _raise_on_status, _status_or
+        if _status_or(st) & 1:     # a row overflowed 2 B / symbol: redo with the proven upper bound (compress_symbols does the same)
+            strings, st = hip.rans_encode_host(tables, sym_h, index_div=hw, out_stride=hip.rans_max_bytes(sym_h.shape[1]))
+        _raise_on_status(torch.from_numpy(st), 'EntropyBottleneck.compress')
+        compressed = {'strings': [strings], 'shape': torch.Size(g.latent_shape)}
+        if self.analyzes_after_compress:
+            self.analyze(compressed)
+        dec_h, st_h = hip.rans_decode_host(tables, compressed['strings'][0], sym_h.shape[1], index_div=hw)
+        _raise_on_status(st_h, 'EntropyBottleneck.decompress')
+        return g.decode_head(dec_h)
+
     def forward(self, x):
         if self.pre_transform is not None:
             x = self.pre_transform(x)
         if self.bottleneck_updated and not self.training:
+            g = self._eval_graphs_for(x)
+            if g is not None:
+                return self._forward_graphed(g, x)
             x = self.bottleneck_layer.encode(x)
             if self.analyzes_after_compress:
                 self.analyze(x)
@@ -383,12 +437,14 @@ class SplittableResNet(UpdatableBackbone):
         return self.head(feats)
 
     def update(self):
+        self._drop_eval_graphs()
         self.bottleneck_layer.update()
         self.bottleneck_updated = True
 
     def load_state_dict(self, state_dict, **kwargs):
         """Loads everything but `bottleneck_layer.*` non-strictly, then the bottleneck through its own loader
         (which resizes the CDF buffers).  Like the reference, this pops the bottleneck keys from the passed dict."""
+        self._drop_eval_graphs()
         entropy_bottleneck_state_dict = OrderedDict()
         for key in list(state_dict.keys()):
             if key.startswith('bottleneck_layer.'):

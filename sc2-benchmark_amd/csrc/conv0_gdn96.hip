@@ -388,10 +388,10 @@ int launch_conv0_gdn96(const void *x, const void *w_frag, const void *gamma_frag
         attr_set = true;
     }
     const int cus0 = sc2_device_cus();
-    unsigned *ring = g_ring0.get(kRing0);
-    if (!ring) return SC2_ERR_INTERNAL;
+    unsigned *slot = g_ring0.launch_slot(static_cast<hipStream_t>(stream), kRing0, 1, g_seq0);
+    if (!slot) return SC2_ERR_INTERNAL;
     const int grid = a.n_units < 2 * cus0 ? a.n_units : 2 * cus0;   // two workgroups per CU
-    a.unit_ctr = ring + (g_seq0.fetch_add(1) % kRing0);
+    a.unit_ctr = slot;
     const bool seg = W_pairs != OW;
     if (inverse && seg) hipLaunchKernelGGL((conv0_gdn96_kernel<true, true, PLANAR, EMIT>), dim3(grid), dim3(256), lds, s, a);
     else if (inverse) hipLaunchKernelGGL((conv0_gdn96_kernel<true, false, PLANAR, EMIT>), dim3(grid), dim3(256), lds, s, a);

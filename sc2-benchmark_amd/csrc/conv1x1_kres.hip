@@ -307,12 +307,12 @@ int launch_kres(KresArgs a, hipStream_t s) {
         attr_set = true;
     }
     const int g_cus_k = sc2_device_cus();
-    unsigned *ring = g_ring_k.get(kRingK);
-    if (!ring) return SC2_ERR_INTERNAL;
+    unsigned *slot = g_ring_k.launch_slot(s, kRingK, 128, g_seq_k);   // [8 XCDs][16 chunks] counters per launch
+    if (!slot) return SC2_ERR_INTERNAL;
     const long long units = (long long)a.n_tiles * a.n_chunks;
     int grid = units < g_cus_k ? (int)units : g_cus_k;          // one 4-wave workgroup per CU
     if (grid < 8 * a.n_chunks) grid = 8 * a.n_chunks;           // every (XCD, chunk) needs a workgroup
-    a.unit_ctr = ring + 128 * (g_seq_k.fetch_add(1) % (kRingK / 128));   // [8 XCDs][16 chunks] counters per launch
+    a.unit_ctr = slot;
     hipLaunchKernelGGL(conv1x1_kres_kernel<S>, dim3(grid), dim3(256), S::LDS_BYTES, s, a);
     SC2_CHECK_LAUNCH();
     return SC2_OK;

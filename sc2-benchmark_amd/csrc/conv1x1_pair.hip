@@ -420,11 +420,11 @@ int launch_pair(const PairArgs &a, hipStream_t s) {
         attr_set[dev] = true;
     }
     const int g_cus = sc2_device_cus();
-    unsigned *ring = g_ring.get(kRing);
-    if (!ring) return SC2_ERR_INTERNAL;
+    unsigned *slot = g_ring.launch_slot(s, kRing, 1, g_seq);
+    if (!slot) return SC2_ERR_INTERNAL;
     PairArgs b = a;
     b.n_tiles = (a.M + P - 1) / P;
-    b.tile_ctr = ring + (g_seq.fetch_add(1) % kRing);
+    b.tile_ctr = slot;
     {
         // Every other launch walks its tiles from the END of the map (SC2_PAIR_ALT=0: always front to back).  The block input a
         // launch re-reads as the identity was written by the previous pair launch front to back; read front to back again, its

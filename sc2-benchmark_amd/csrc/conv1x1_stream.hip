@@ -307,8 +307,8 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
         attr_set = true;
     }
     const int g_cus = sc2_device_cus();
-    unsigned *ring = g_ring.get(kRing);
-    if (!ring) return SC2_ERR_INTERNAL;
+    unsigned *slot = g_ring.launch_slot(s, kRing, 1, g_seq);
+    if (!slot) return SC2_ERR_INTERNAL;
     static sc2_per_device_int per_cu_dev;   // resident workgroups per CU of this instantiation (LDS and registers decide), per device
     int per_cu = per_cu_dev.here().load(std::memory_order_relaxed);
     if (per_cu == 0) {
@@ -322,7 +322,7 @@ int launch_stream(const StreamArgs &a0, hipStream_t s) {
     const int slots = g_cus * per_cu;
     const int grid = a.n_units < slots ? a.n_units : slots;
     StreamArgs b = a;
-    b.unit_ctr = ring + (g_seq.fetch_add(1) % kRing);
+    b.unit_ctr = slot;
     hipLaunchKernelGGL((conv1x1_stream_kernel<K, BM, BNC, RES, MASK>), dim3(grid), dim3(512), lds, s, b);
     SC2_CHECK_LAUNCH();
     return SC2_OK;

@@ -628,10 +628,10 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
         attr_set = true;
     }
     const int g_cus2 = sc2_device_cus();
-    unsigned *ring = g_ring2.get(kRing2);
-    if (!ring) return SC2_ERR_INTERNAL;
+    unsigned *slot = g_ring2.launch_slot(s, kRing2, 8, g_seq2);   // eight counters per launch
+    if (!slot) return SC2_ERR_INTERNAL;
     const int grid = a.n_units < g_cus2 ? a.n_units : g_cus2;   // one 4-wave workgroup per CU
-    a.unit_ctr = ring + 8 * (g_seq2.fetch_add(1) % (kRing2 / 8));   // eight counters per launch
+    a.unit_ctr = slot;
     a.stamps = nullptr;
 #if SC2_ENC2_STAMPS
     const char *stamp_path = getenv("SC2_ENC2_STAMPS");

@@ -473,10 +473,10 @@ int launch_dec(const DecArgs &a, hipStream_t s) {
     const int grid = a.n_tiles < g_num_cus ? a.n_tiles : g_num_cus;
     // tile counter: one of a ring of device words (launches in flight on different streams must not share one),
     // preset on the stream to the first unclaimed tile
-    unsigned *ring = g_ctr_ring.get(kCtrRing);
-    if (!ring) return SC2_ERR_INTERNAL;
+    unsigned *slot = g_ctr_ring.launch_slot(s, kCtrRing, 1, g_ctr_seq);
+    if (!slot) return SC2_ERR_INTERNAL;
     DecArgs b = a;
-    b.tile_ctr = ring + (g_ctr_seq.fetch_add(1) % kCtrRing);
+    b.tile_ctr = slot;
     {
         b.stagger = sc2_pol().dec_stagger;
     }

@@ -35,13 +35,55 @@ constexpr uint64_t kLower = 1ull << 31;          // rANS64 lower bound of the no
 constexpr int kBypassBits = 4;
 constexpr uint32_t kBypassMax = (1u << kBypassBits) - 1;
 
+// What the ENCODER needs of one table entry (round 6).  The rANS step x' = floor(x / f) 2^16 + x mod f + start is a dependent
+// chain through a 64-bit division (25 - 40 cycles on the host cores; 7 ns per symbol measured, 0.51 ms for the 72 600 symbols of
+// one 224 x 224 image = a quarter of a bs-1 evaluation forward).  f is a table constant, so the quotient comes from a
+// multiplication by its reciprocal (Alverson, "Integer division using reciprocals"): with s = ceil(log2 f) and
+// m = ceil(2^(63 + s) / f) < 2^64,  floor(x / f) = mulhi64(x, m) >> (s - 1)  EXACTLY for every x < 2^63 -- the error term
+// x (m f - 2^(63 + s)) / (f 2^(63 + s)) is below x 2^s / (f 2^(63 + s)) < 1 / f -- and the coder's state never leaves
+// [2^31, 2^63).  f = 1 (s = 0) has no such form: rcp = 0 marks it and the step is x' = x 2^16 + start.
+// tests/test_host_coder.py::test_reciprocal_division_is_exact checks the quotient against `/` over every f and edge-case x.
+struct EncEntry {
+    uint64_t rcp;        // m, or 0 for f = 1
+    uint32_t start;
+    uint32_t freq_shift; // f in bits 0 .. 16, s - 1 in bits 24 .. 28
+};
+
 struct Row {
     int32_t n_entries = 0;   // cdf_size - 1 coded entries; the last one (index max_value) is the escape entry
     int32_t max_value = 0;   // cdf_size - 2
     int32_t offset = 0;
     const uint32_t *cum = nullptr;    // the row's cumulative frequencies: entry k covers [cum[k], cum[k + 1])
     const uint16_t *bucket = nullptr; // [256]: first entry that reaches into cumulative frequencies [256 b, 256 b + 256)
+    const EncEntry *enc = nullptr;    // [n_entries], or null when the table is too large to expand (division path)
+    const struct FastBucket *fast = nullptr;   // [2048]: one-load decode index for streams coded in whole runs of one row
 };
+
+// Decode index at 32-count resolution (round 6): the entry, its start and its frequency in ONE 8-byte load when the bucket
+// [32 b, 32 b + 32) lies inside a single entry -- the chain of a step is then load, multiply, add, renormalise; a bucket that an
+// entry boundary cuts (a few per cent of the probability mass of a peaked prior) is flagged and searched as before.  16 KB per
+// row: L1-resident for the run of symbols that share the row (implicit indexes: 3 025 per row at 224 x 224).
+struct FastBucket {
+    uint32_t start_entry;   // start in bits 0 .. 15, entry in bits 16 .. 31
+    uint32_t freq;          // bit 31: ambiguous (entry = the first candidate)
+};
+
+inline EncEntry make_enc_entry(uint32_t start, uint32_t freq) {
+    EncEntry e;
+    e.start = start;
+    if (freq <= 1u) {
+        e.rcp = 0;
+        e.freq_shift = 1u;
+        return e;
+    }
+    uint32_t s = 0;
+    while (freq > (1u << s)) ++s;                                  // s = ceil(log2 f) >= 1
+    const unsigned __int128 num = (unsigned __int128)1 << (63 + s);
+    const unsigned __int128 m = (num + freq - 1) / freq;           // ceil; < 2^64 because f > 2^(s - 1)
+    e.rcp = (uint64_t)m;
+    e.freq_shift = freq | ((s - 1) << 24);
+    return e;
+}
 
 }  // namespace
 
@@ -49,6 +91,8 @@ struct sc2_rans_host_tables {
     std::vector<Row> rows;
     std::vector<uint32_t> cum;
     std::vector<uint16_t> bucket;
+    std::vector<EncEntry> enc;
+    std::vector<FastBucket> fast;
 };
 
 namespace {
@@ -70,6 +114,24 @@ struct Emitter {
         if (x >= x_max) { word((uint32_t)x); x >>= 32; }
         x = ((x / freq) << kPrecision) + (x % freq) + start;
     }
+    // the same step with the entry's reciprocal (EncEntry): no division, and the renormalisation -- due every 32 / bits-per-symbol
+    // symbols, i.e. unpredictably -- without a branch: the word is stored speculatively below the cursor (ptr >= limit = row + 2,
+    // so ptr[-1] is inside the row) and the cursor moves only if it was due
+    inline void put(const EncEntry &en) {
+        const uint32_t freq = en.freq_shift & 0x1FFFFu;
+        const uint64_t x_max = (uint64_t)freq << (31 - kPrecision + 32);
+        const bool need = x >= x_max, room = ptr > limit;
+        ptr[-1] = (uint32_t)x;
+        ptr -= (need & room) ? 1 : 0;
+        overflow |= (need & !room) ? 1 : 0;
+        x = need ? x >> 32 : x;
+        if (en.rcp == 0) {      // f = 1 (rare in data: the quantiser's floor frequency)
+            x = (x << kPrecision) + en.start;
+            return;
+        }
+        const uint64_t q = (uint64_t)(((unsigned __int128)x * en.rcp) >> 64) >> (en.freq_shift >> 24);
+        x = (q << kPrecision) + (x - q * freq) + en.start;
+    }
     // one raw nibble: a uniform 4-bit symbol (freq = 2^12 of 2^16)
     inline void put_nibble(uint32_t v) {
         const uint64_t x_max = ((kLower >> kPrecision) << 32) << (kPrecision - kBypassBits);
@@ -86,14 +148,9 @@ void encode_stream(const sc2_rans_host_tables &t, const int32_t *sym, const int3
     e.ptr = row + row_words;
     e.limit = row + 2;
     const int n_rows = (int)t.rows.size();
-    // implicit indexes (row = position / index_div): the row changes every index_div positions, tracked without a division
-    int64_t run_row = (!idx && n_sym > 0) ? (n_sym - 1) / index_div : 0, run_lo = run_row * index_div;
-    for (int64_t i = n_sym - 1; i >= 0; --i) {
-        if (!idx && i < run_lo) { --run_row; run_lo -= index_div; }
-        const int64_t r64 = idx ? (int64_t)idx[i] : run_row;
-        if (r64 < 0 || r64 >= n_rows) { e.overflow |= 4; continue; }      // index outside the table: reported, not coded
-        const Row &r = t.rows[(size_t)r64];
-        long long v = (long long)sym[i] - (long long)r.offset;
+    // one symbol with its row's constants
+    auto put_symbol = [&e](const Row &r, int32_t s) {
+        long long v = (long long)s - (long long)r.offset;
         int entry;
         if (v >= 0 && v < r.max_value) {
             entry = (int)v;
@@ -112,8 +169,28 @@ void encode_stream(const sc2_rans_host_tables &t, const int32_t *sym, const int3
             for (int j = 0; j < n15; ++j) e.put_nibble(kBypassMax);
             entry = r.max_value;
         }
-        const uint32_t start = r.cum[entry];
-        e.put(start, r.cum[entry + 1] - start);
+        if (r.enc) {
+            e.put(r.enc[entry]);
+        } else {
+            const uint32_t start = r.cum[entry];
+            e.put(start, r.cum[entry + 1] - start);
+        }
+    };
+    if (idx) {
+        for (int64_t i = n_sym - 1; i >= 0; --i) {
+            const int64_t r64 = (int64_t)idx[i];
+            if (r64 < 0 || r64 >= n_rows) { e.overflow |= 4; continue; }      // index outside the table: reported, not coded
+            put_symbol(t.rows[(size_t)r64], sym[i]);
+        }
+    } else if (n_sym > 0) {
+        // implicit indexes (row = position / index_div): whole runs of one row, last run first (rANS codes in reverse); the row's
+        // constants stay in registers for the run
+        for (int64_t run = (n_sym - 1) / index_div; run >= 0; --run) {
+            const int64_t lo = run * index_div, hi = lo + index_div < n_sym ? lo + index_div : n_sym;
+            if (run >= n_rows) { e.overflow |= 4; continue; }
+            const Row r = t.rows[(size_t)run];
+            for (int64_t i = hi - 1; i >= lo; --i) put_symbol(r, sym[i]);
+        }
     }
     // flush: the state's two halves in front of everything (low word first in memory)
     e.ptr -= 2;
@@ -162,18 +239,31 @@ void decode_stream(const sc2_rans_host_tables &t, const uint8_t *in, int32_t nby
     rd.x = lo | (hi << 32);
     const int n_rows = (int)t.rows.size();
     int st = 0;
-    int64_t run_row = 0, run_hi = index_div;
-    for (int64_t i = 0; i < n_sym; ++i) {
-        if (!idx && i >= run_hi) { ++run_row; run_hi += index_div; }
-        const int64_t r64 = idx ? (int64_t)idx[i] : run_row;
-        if (r64 < 0 || r64 >= n_rows) { st |= 4; out[i] = 0; continue; }
-        const Row &r = t.rows[(size_t)r64];
+    auto get_symbol = [&rd, &st](const Row &r, const bool fine) -> int32_t {
         const uint32_t cf = (uint32_t)rd.x & 0xFFFFu;
         // symbol search: a 256-bucket table per row (the 24 x 512 B of a factorised prior stay in L1; an exact 65 536-entry
-        // table per row -- 3 MB for 24 rows -- missed L2 on nearly every symbol, 60 cycles per step) + a short forward scan
-        int entry = r.bucket[cf >> 8];
-        while (r.cum[entry + 1] <= cf) ++entry;
-        const uint32_t start = r.cum[entry], freq = r.cum[entry + 1] - start;
+        // table per row -- 3 MB for 24 rows -- missed L2 on nearly every symbol, 60 cycles per step) + a short forward scan.
+        // Round 6: a stream coded in whole runs of one row (implicit indexes: 3 025 symbols per row at 224 x 224) looks at ONE
+        // row for a whole run, so that row's 4 096-bucket index (8 KB) is L1-resident for the run and the scan behind it almost
+        // never steps (an entry narrower than 16 counts): a predictable branch instead of a coin flip per symbol
+        int entry;
+        uint32_t start, freq;
+        if (fine) {
+            const FastBucket b = r.fast[cf >> 5];
+            entry = (int)(b.start_entry >> 16);
+            start = b.start_entry & 0xFFFFu;
+            freq = b.freq;
+            if (__builtin_expect((b.freq >> 31) != 0, 0)) {
+                while (r.cum[entry + 1] <= cf) ++entry;
+                start = r.cum[entry];
+                freq = r.cum[entry + 1] - start;
+            }
+        } else {
+            entry = r.bucket[cf >> 8];
+            while (r.cum[entry + 1] <= cf) ++entry;
+            start = r.cum[entry];
+            freq = r.cum[entry + 1] - start;
+        }
         rd.x = (uint64_t)freq * (rd.x >> kPrecision) + cf - start;
         rd.renorm();
         int32_t v = entry;
@@ -189,7 +279,29 @@ void decode_stream(const sc2_rans_host_tables &t, const uint8_t *in, int32_t nby
                 v = (raw & 1u) ? -(int32_t)(raw >> 1) - 1 : (int32_t)(raw >> 1) + r.max_value;
             }
         }
-        out[i] = v + r.offset;
+        return v + r.offset;
+    };
+    if (idx) {
+        for (int64_t i = 0; i < n_sym; ++i) {
+            const int64_t r64 = (int64_t)idx[i];
+            if (r64 < 0 || r64 >= n_rows) { st |= 4; out[i] = 0; continue; }
+            out[i] = get_symbol(t.rows[(size_t)r64], false);
+        }
+    } else {
+        for (int64_t lo = 0, run = 0; lo < n_sym; lo += index_div, ++run) {      // whole runs of one row
+            const int64_t hi = lo + index_div < n_sym ? lo + index_div : n_sym;
+            if (run >= n_rows) {
+                st |= 4;
+                for (int64_t i = lo; i < hi; ++i) out[i] = 0;
+                continue;
+            }
+            const Row r = t.rows[(size_t)run];
+            if (r.fast) {
+                for (int64_t i = lo; i < hi; ++i) out[i] = get_symbol(r, true);
+            } else {
+                for (int64_t i = lo; i < hi; ++i) out[i] = get_symbol(r, false);
+            }
+        }
     }
     *status = st | (rd.past ? 8 : 0);
 }
@@ -228,6 +340,11 @@ extern "C" int sc2_rans_host_tables_create(const int32_t *cdfs, int n_cdfs, int 
     t->rows.resize((size_t)n_cdfs);
     t->cum.assign((size_t)n_cdfs * (size_t)cdf_stride, 0u);
     t->bucket.assign((size_t)n_cdfs * 256u, 0);
+    // encoder entries (16 B each) for tables up to 4 M entries (64 MB); beyond that the division path
+    const bool expand = (size_t)n_cdfs * (size_t)cdf_stride <= ((size_t)1 << 22);
+    if (expand) t->enc.assign((size_t)n_cdfs * (size_t)cdf_stride, EncEntry{0, 0, 1u});
+    const bool fine = n_cdfs <= 4096 && cdf_stride <= 65536;      // 16 KB per row; entry indexes fit 16 bits
+    if (fine) t->fast.assign((size_t)n_cdfs * 2048u, FastBucket{0u, 0u});
     for (int r = 0; r < n_cdfs; ++r) {
         const int32_t *c = cdfs + (size_t)r * cdf_stride;
         const int size = cdf_sizes[r];
@@ -251,9 +368,31 @@ extern "C" int sc2_rans_host_tables_create(const int32_t *cdfs, int n_cdfs, int 
         }
         row.cum = cum;
         row.bucket = bucket;
+        if (fine) {
+            FastBucket *fb = t->fast.data() + (size_t)r * 2048u;
+            for (int b = 0, k = 0; b < 2048; ++b) {
+                while (cum[k + 1] <= (uint32_t)b * 32u) ++k;        // entry k is the first with cum[k + 1] > 32 b
+                const bool whole = cum[k + 1] >= (uint32_t)b * 32u + 32u;   // ... and it covers the whole bucket
+                fb[b].start_entry = (cum[k] & 0xFFFFu) | ((uint32_t)k << 16);
+                fb[b].freq = whole ? cum[k + 1] - cum[k] : 0x80000000u;
+            }
+            row.fast = fb;
+        }
+        if (expand) {
+            EncEntry *enc = t->enc.data() + (size_t)r * cdf_stride;
+            for (int k = 0; k + 1 < size; ++k) enc[k] = make_enc_entry(cum[k], cum[k + 1] - cum[k]);
+            row.enc = enc;
+        }
     }
     *out = t;
     return SC2_OK;
+}
+
+// floor(x / freq) by the encoder's reciprocal form (test hook: tests/test_host_coder.py sweeps every freq against `/`)
+extern "C" uint64_t sc2_rans_host_rcp_div(uint64_t x, uint32_t freq) {
+    const EncEntry en = make_enc_entry(0u, freq);
+    if (en.rcp == 0) return x;
+    return (uint64_t)(((unsigned __int128)x * en.rcp) >> 64) >> (en.freq_shift >> 24);
 }
 
 extern "C" void sc2_rans_host_tables_destroy(sc2_rans_host_tables *t) { delete t; }

@@ -64,10 +64,42 @@ inline int sc2_device_cus() {
 
 // Zero-filled device words for a persistent launcher's work counters: ONE allocation per (ring object, device), made once
 // under the ring's mutex and visible to the other host threads through the acquire / release pair.
+// A launch that is being CAPTURED into a HIP graph (round 6: the bs-1 evaluation forward replays graphs) keeps its counter
+// address for the life of the graph, while eager launches rotate through the ring: a replay on one stream and an eager launch
+// on another could meet on one counter.  Captured launches therefore take their counters from a second region behind the ring,
+// handed out once and never reused (sc2_counter_ring::launch_slot); 4 096 words per device and kernel family.
+constexpr size_t SC2_CAPTURE_WORDS = 4096;
+inline bool sc2_stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+
 struct sc2_counter_ring {
     std::mutex mu;
     std::atomic<unsigned *> base[SC2_MAX_DEVICES];
-    unsigned *get(size_t words) {   // nullptr: the allocation failed (sc2_set_error holds the reason)
+    std::atomic<unsigned> captured[SC2_MAX_DEVICES];
+    // the counters of ONE launch on stream s: `per_launch` consecutive zeroed words.  Eager: slot seq mod (ring_words / per_launch)
+    // of the ring; captured: the next unused words of the capture region.  nullptr: allocation failed / capture region exhausted /
+    // first use of this kernel family inside a capture (hipMalloc is not capturable: run the launch once eagerly first).
+    unsigned *launch_slot(hipStream_t s, size_t ring_words, unsigned per_launch, std::atomic<unsigned> &seq) {
+        const bool cap = sc2_stream_capturing(s);
+        const int d = sc2_device_slot();
+        if (cap && !base[d].load(std::memory_order_acquire)) {
+            sc2_set_error("a persistent kernel's first launch on this device cannot be captured into a graph: warm it up eagerly");
+            return nullptr;
+        }
+        unsigned *ring = get(ring_words);
+        if (!ring) return nullptr;
+        if (!cap) return ring + (size_t)per_launch * (seq.fetch_add(1) % (unsigned)(ring_words / per_launch));
+        const unsigned at = captured[d].fetch_add(per_launch);
+        if (at + per_launch > SC2_CAPTURE_WORDS) {
+            sc2_set_error("more than %zu work-counter words captured into HIP graphs on device %d", SC2_CAPTURE_WORDS, d);
+            return nullptr;
+        }
+        return ring + ring_words + at;
+    }
+    unsigned *get(size_t ring_words) {   // nullptr: the allocation failed (sc2_set_error holds the reason)
+        const size_t words = ring_words + SC2_CAPTURE_WORDS;
         const int d = sc2_device_slot();
         unsigned *p = base[d].load(std::memory_order_acquire);
         if (p) return p;

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch', 'sc2_rans_decode_dequantize_batch_ev',
     'sc2_mse_partial_len', 'sc2_mse_sum_bf16', 'sc2_mse_grad_bf16', 'sc2_relu_bwd_bf16', 'sc2_relu_bwd_mse_bf16',
-    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
+    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_host_rcp_div', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
 ]
 
 
@@ -99,6 +99,8 @@ class HostPolicy(object):
     mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
+    eval_graphs = True         # the updated eval forward of SplittableResNet at small batch replays HIP graphs of its device halves (graphs.py)
+    eval_graph_max_batch = 1   # ... for batches up to this size (the reference evaluates at batch size 1)
 
 
 host_policy = HostPolicy()
@@ -254,6 +256,8 @@ def lib():
     L.sc2_rans_host_tables_create.argtypes = [vp, i32, i32, vp, vp, ctypes.POINTER(vp)]
     L.sc2_rans_host_tables_destroy.argtypes = [vp]
     L.sc2_rans_host_tables_destroy.restype = None
+    L.sc2_rans_host_rcp_div.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
+    L.sc2_rans_host_rcp_div.restype = ctypes.c_uint64
     L.sc2_rans_encode_host.argtypes = [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp, i32]
     L.sc2_rans_decode_host.argtypes = [vp, vp, i64, vp, vp, vp, i64, i32, i64, vp, vp, i32]
     for name in ABI_SYMBOLS:

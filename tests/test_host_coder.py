@@ -157,3 +157,50 @@ def test_host_decoder_terminates_on_hostile_streams(S):
     dec, status = S.hip.rans_decode_host(tables, hostile, n_sym, index_div=100)
     assert all(int(status[i]) & 8 for i in range(3)) and int(status[3]) == 0
     assert np.array_equal(dec[3], sym[1])
+
+
+def test_reciprocal_division_is_exact(S):
+    """The host encoder's quotient (multiplication by the entry's reciprocal, csrc/rans_host.cpp EncEntry) == floor(x / f) for EVERY
+    frequency 1 .. 65 536 at the edges of the coder's state range [2^31, 2^63) and around multiples of f, plus random states."""
+    L = S.hip.lib()
+    rng = random.Random(7)
+    edge = [1 << 31, (1 << 31) + 1, (1 << 47) - 1, 1 << 47, (1 << 62) + 12345, (1 << 63) - 1, (1 << 63) - 65536]
+    for f in list(range(1, 65537, 1 if os.environ.get('SC2_SLOW_TESTS') else 37)) + [1, 2, 3, 255, 256, 257, 32767, 32768, 32769, 65535, 65536]:
+        xs = edge + [rng.randrange(1 << 31, 1 << 63) for _ in range(3)]
+        k = rng.randrange(1 << 31, 1 << 63) // f
+        xs += [k * f, k * f + f - 1, max(1 << 31, k * f - 1)]
+        for x in xs:
+            assert L.sc2_rans_host_rcp_div(x, f) == x // f, (x, f)
+
+
+@settings(max_examples=30, deadline=None)
+@given(st.integers(0, 2 ** 31 - 1), st.integers(1, 97), st.integers(0, 400))
+def test_run_wise_paths_match_oracle(S, seed, index_div, n_sym):
+    """The round-6 fast paths of the implicit-index layout -- reciprocal division in the encoder, the one-load 2 048-bucket decode
+    index, whole runs of one row -- on PEAKED tables full of frequency-1 entries (the quantiser's floor: the f = 1 special case)
+    with a ragged last run: bytes equal to the oracle's, exact round trip; a stream longer than rows x index_div reports bit 2."""
+    rng = np.random.RandomState(seed)
+    n_rows = 5
+    rows, sizes, offs = [], [], []
+    for _ in range(n_rows):
+        n = rng.randint(3, 60)
+        p = np.full(n, 1e-9, np.float64)
+        p[rng.randint(0, n)] = 0.9
+        p[rng.randint(0, n)] += 0.1
+        c = [int(v) for v in oracle_rans.pmf_to_quantized_cdf((p / p.sum()).astype(np.float32))]
+        rows.append(c); sizes.append(len(c)); offs.append(-(n // 2))
+    cdf, sizes, offs = _pad(rows), np.array(sizes, np.int32), np.array(offs, np.int32)
+    tables = S.hip.HostRansTables(cdf, sizes, offs)
+    n_sym = min(n_sym, n_rows * index_div)
+    sym = rng.randint(-35, 36, size=(2, n_sym)).astype(np.int32)
+    idx = (np.arange(n_sym) // index_div).astype(np.int32)
+    strings, status = S.hip.rans_encode_host(tables, sym, index_div=index_div, out_stride=S.hip.rans_max_bytes(max(1, n_sym)))
+    for i in range(2):
+        assert strings[i] == oracle_rans.encode_with_indexes(sym[i], idx, cdf, sizes, offs)
+    dec, st2 = S.hip.rans_decode_host(tables, strings, n_sym, index_div=index_div)
+    assert np.array_equal(dec, sym) and not status.any() and not st2.any()
+    too_long = np.zeros((1, n_rows * index_div + 3), np.int32)
+    s3, st3 = S.hip.rans_encode_host(tables, too_long, index_div=index_div)
+    assert int(st3[0]) & 4
+    _, st4 = S.hip.rans_decode_host(tables, s3, too_long.shape[1], index_div=index_div)
+    assert int(st4[0]) & 4
