@@ -651,6 +651,16 @@ int sc2_rans_decode_host(const sc2_rans_host_tables *tables, const uint8_t *in, 
                          const int32_t *in_offset, const int32_t *in_nbytes, const int32_t *indexes, int64_t index_div,
                          int n_streams, int64_t n_sym, int32_t *symbols_out, int32_t *status, int n_threads);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Diagnostics (csrc/diag.hip; no product path calls these).                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* The shader clock the chip holds while OTHER kernels run: `n_workgroups` probe waves (one per workgroup; launch >= 8 so that
+ * every XCD gets one) each write n_samples triples (s_memtime, s_memrealtime, XCC id) as u64 into samples[wg][sample][3], one
+ * every period_ticks ticks of the constant 100 MHz counter.  clock = delta s_memtime / delta s_memrealtime x 100 MHz between two
+ * samples of one workgroup (MI355X_MICROARCH.md, DVFS item 6).  Launch it on a stream of its own BEFORE the kernels under study
+ * so that it is resident while they run (tools/clock_probe.py). */
+int sc2_clock_probe(unsigned long long *samples, int n_workgroups, int n_samples, unsigned period_ticks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

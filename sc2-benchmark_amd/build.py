@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, 'libsc2amd.so')
 #  parallel: the slowest ones first)
 SOURCES = ['conv_inst_e.hip', 'conv_inst_f.hip', 'conv_inst_g.hip', 'conv_inst_h.hip', 'conv_inst_a.hip', 'conv_inst_b.hip',
            'conv_inst_c.hip', 'conv_inst_d.hip', 'conv_dec_persist.hip', 'conv_igemm.hip', 'conv_gdn512.hip', 'gdn512_rows.hip', 'bn.hip', 'gdn96_strips.hip', 'conv0_gdn96.hip', 'conv2_gdn48.hip', 'conv2x2_c48.hip', 'conv1x1_stream.hip', 'conv1x1_pair.hip', 'conv1x1_kres.hip', 'conv3x3_win.hip', 'conv1x1_win.hip', 'conv2x2_win.hip',
-           'conv_f32.hip', 'loss.hip', 'conv_wgrad.hip', 'gdn_bwd.hip', 'entropy.hip', 'gaussian.hip', 'rans.hip', 'layout.hip', 'abi.cpp', 'cdf_host.cpp', 'rans_host.cpp']
+           'conv_f32.hip', 'loss.hip', 'conv_wgrad.hip', 'gdn_bwd.hip', 'entropy.hip', 'gaussian.hip', 'rans.hip', 'layout.hip', 'diag.hip', 'abi.cpp', 'cdf_host.cpp', 'rans_host.cpp']
 HEADERS = [os.path.join(CSRC, 'sc2_common.h'), os.path.join(CSRC, 'conv_igemm_impl.h'),
            os.path.join(HERE, '..', 'include', 'sc2_bottleneck.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

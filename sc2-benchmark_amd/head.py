@@ -221,19 +221,51 @@ class HipHead(object):
             return None
         return c1.w2d, c1.b, ds.w2d, ds.b
 
+    def _side_stream(self, t):
+        """the side stream that belongs to the caller's current stream (one per current stream: two pipelines' back stages do not
+        meet on one side stream); None while the current stream is being captured into a graph"""
+        if not t.is_cuda or torch.cuda.is_current_stream_capturing():
+            return None
+        cur = torch.cuda.current_stream(t.device)
+        pool = self.__dict__.setdefault('_side_streams', {})
+        s = pool.get(cur.cuda_stream)
+        if s is None:
+            s = pool[cur.cuda_stream] = torch.cuda.Stream(device=t.device)
+        return s
+
     def forward(self, x_nhwc, with_pool=True, pre=None):
         """x_nhwc: bf16 [N,H,W,C] -> logits f32 [N,classes] (or pooled / feature map if the model skips them).
         pre = (conv1 output, downsample output) of the first block when the decoder's last launch produced them."""
         h = x_nhwc
         o_next = None      # conv1 output of the coming block, when the previous block's last launch produced it
+        # Round 6 A/B, default OFF: a block's downsample (layer3.0 / layer4.0: a long-K strided 1x1 layer, 0.09 - 0.11 ms at 40 - 50 %
+        # of its floor rate) has no consumer until conv3, so it can run on a side stream beside conv1 -> conv2 of the same block
+        # (`host_policy.head_ds_side_stream`; fork / join by events).  Measured: the two launches take each other's CUs and the
+        # head gets SLOWER, 2.60 -> 2.67 ms (profiles/r06e_ab_ds_side.txt)
+        side = self._side_stream(h if h is not None else pre[0]) if hip.host_policy.head_ds_side_stream else None
         for bi, (c1, c2, c3, ds) in enumerate(self.blocks):
+            join = None
             if bi == 0 and pre is not None:
                 o, identity = pre
             else:
-                identity = h if ds is None else ds(h, hip.EPI_BIAS)
+                if ds is not None and side is not None:
+                    cur = torch.cuda.current_stream(h.device)
+                    fork = torch.cuda.Event()
+                    fork.record(cur)
+                    side.wait_event(fork)
+                    h.record_stream(side)
+                    with torch.cuda.stream(side):
+                        identity = ds(h, hip.EPI_BIAS)
+                        join = torch.cuda.Event()
+                        join.record(side)
+                    identity.record_stream(cur)
+                else:
+                    identity = h if ds is None else ds(h, hip.EPI_BIAS)
                 o = o_next if o_next is not None else c1(h, hip.EPI_BIAS_RELU)
             o_next = None
             o = c2(o, hip.EPI_BIAS_RELU)
+            if join is not None:
+                torch.cuda.current_stream(h.device).wait_event(join)
             nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
             if nxt is not None and self._pair_ok(c3, nxt[0]) and o.numel() // o.shape[-1] * c3.cout * 2 < 0x7FF00000:
                 # conv3 + residual + ReLU of this block and conv1 + ReLU of the next in one launch (conv1x1_pair.hip): the

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch', 'sc2_rans_decode_dequantize_batch_ev',
     'sc2_mse_partial_len', 'sc2_mse_sum_bf16', 'sc2_mse_grad_bf16', 'sc2_relu_bwd_bf16', 'sc2_relu_bwd_mse_bf16',
-    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_host_rcp_div', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
+    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_host_rcp_div', 'sc2_clock_probe', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
 ]
 
 
@@ -99,6 +99,7 @@ class HostPolicy(object):
     mse_fused = True           # a feature-matching MSE term on a frozen stack's output: its gradient inside the stack's first ReLU-gradient pass
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
+    head_ds_side_stream = False  # the head's downsample layers on a side stream beside conv1 -> conv2 of their block: measured SLOWER (head 2.60 -> 2.67 ms, bench - 1 %: profiles/r06e_ab_ds_side.txt)
     eval_graphs = True         # the updated eval forward of SplittableResNet at small batch replays HIP graphs of its device halves (graphs.py)
     eval_graph_max_batch = 1   # ... for batches up to this size (the reference evaluates at batch size 1)
 
@@ -258,6 +259,7 @@ def lib():
     L.sc2_rans_host_tables_destroy.restype = None
     L.sc2_rans_host_rcp_div.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
     L.sc2_rans_host_rcp_div.restype = ctypes.c_uint64
+    L.sc2_clock_probe.argtypes = [vp, i32, i32, ctypes.c_uint32, vp]
     L.sc2_rans_encode_host.argtypes = [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp, i32]
     L.sc2_rans_decode_host.argtypes = [vp, vp, i64, vp, vp, vp, i64, i32, i64, vp, vp, i32]
     for name in ABI_SYMBOLS:
@@ -1652,6 +1654,15 @@ class HostRansTables(object):
 
 def _host_threads(n_streams):
     return max(1, min(int(n_streams), len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 32))
+
+
+def clock_probe(n_workgroups=16, n_samples=64, period_us=20.0, stream=None):
+    """DIAGNOSTIC (csrc/diag.hip): launches the clock probe on `stream` (default: the current one) and returns the int64 tensor
+    [n_workgroups, n_samples, 3] = (s_memtime, s_memrealtime, XCC id) it fills; read it after a synchronize."""
+    out = torch.zeros((n_workgroups, n_samples, 3), dtype=torch.int64, device='cuda')
+    s = ctypes.c_void_p(stream.cuda_stream) if stream is not None else _stream()
+    _check(lib().sc2_clock_probe(_ptr(out), n_workgroups, n_samples, int(round(period_us * 100.0)), s), 'clock_probe')
+    return out
 
 
 def rans_encode_host(tables, symbols, indexes=None, index_div=0, out_stride=None):

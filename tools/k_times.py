@@ -29,23 +29,19 @@ def timeit(fn, iters=20, warmup=3):
     return t0.elapsed_time(t1) / iters
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--bs', type=int, default=256)
-    ap.add_argument('--iters', type=int, default=20)
-    ap.add_argument('--head', action='store_true')
-    ap.add_argument('--only', default='')
-    args = ap.parse_args()
+def build_rows(bs=256, only='', head=False, f32=False):
+    """-> [(name, fn, flops)]: one callable per launch of the bottleneck forward (and optionally the head / the f32 encoder)."""
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     m = S.FPBasedResNetBottleneck().eval().to(dev)
-    N = args.bs
+    N = bs
     rows = []
+    keep = []      # (tensors the callables close over stay alive with the list)
 
     def row(name, fn, flops):
-        if args.only and args.only not in name:
+        if only and only not in name:
             return
-        rows.append((name, timeit(fn, args.iters), flops))
+        rows.append((name, fn, flops))
 
     with torch.no_grad():
         e0, g1, e2, g3, e4 = m.encoder
@@ -85,13 +81,31 @@ def main():
         row('dec.conv4+head.2.0 (tail)', lambda: hip.conv2x2_win_tail_fwd(b3, tail, bias1, biasd), (1644.2e6 + 205.5e6 + 205.5e6) * N)
         m.output_format = 'bf16_nhwc'
         row('dec.synthesis()', lambda: m.synthesis_nhwc(yh), 7165e6 * N)
-    if args.head:
+    if f32:
+        m32 = S.FPBasedResNetBottleneck().eval().to(dev)
+        m32.set_encoder_precision('f32')
+        with torch.no_grad():
+            x32 = torch.rand(N, 3, 224, 224, device=dev)
+            row('enc.analysis() f32 operands', lambda: m32.analysis(x32), 1177e6 * N)
+    if head:
         import bench as B
         full = B.build_model(dev)
         with torch.no_grad():
             feat = torch.randn(N, 56, 56, 256, device=dev).to(torch.bfloat16)
             xh = feat.permute(0, 3, 1, 2)
             row('head(hip)()', lambda: full.head(xh), 6.6e9 * N)
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--bs', type=int, default=256)
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--head', action='store_true')
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    N = args.bs
+    rows = [(name, timeit(fn, args.iters), flops) for name, fn, flops in build_rows(N, args.only, args.head)]
     print('{:<28}{:>10}{:>12}{:>10}'.format('kernel', 'ms', 'TFLOP/s', 'of 2.5PF'))
     for name, ms, flops in rows:
         print('{:<28}{:>10.4f}{:>12.1f}{:>10.3f}'.format(name, ms, flops / ms / 1e9, flops / ms / 1e9 / 2500.0))
