@@ -41,91 +41,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
-BOTTLENECK_GFLOP_PER_IMG = 8.3418
-PEAK_F32_MATRIX_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 (f32 operands): 1/16 of the bf16 rate (MI355X_MICROARCH.md, Matrix cores)
-PEAK_HBM_GBS = 8000.0          # HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a streaming copy achieves
-# per image, 224x224: algorithmic MFLOP (2 * MACs), bf16 activation MB read, MB written.  Weights
-# (< 2.6 MB in total, L2-resident) are not counted.
-OPS = {'enc.conv0': (180.6, 0.602, 2.408), 'enc.gdn1': (231.2, 2.408, 2.408), 'enc.conv2': (722.5, 2.408, 0.301),
-       'enc.gdn3': (14.5, 0.301, 0.301), 'enc.conv4': (27.9, 0.301, 0.290), 'dec.conv0': (308.3, 0.145, 3.211),
-       'dec.igdn1': (1644.2, 3.211, 3.211), 'dec.conv2': (3171.9, 3.211, 1.549), 'dec.igdn3': (396.5, 1.549, 1.549),
-       'dec.conv4': (1644.2, 1.549, 1.606),
-       # layer2.0's conv1 (256 -> 128) and downsample (256 -> 512, stride 2) when the decoder's last launch takes them along
-       # ('dec.conv4+head.2.0'): they read that launch's output tile from LDS and write 56*56*128 + 28*28*512 bf16
-       'head.2.0': (411.0, 0.0, 1.606),
-       # EntropyModel.dequantize (layer.py:520) = the last pass of the coder's decode launch (rans_dec_finish_dq_kernel): reads
-       # the [position][lane] int32 intermediate (72 600 x 4 B), writes the bf16 NHWC latent (72 600 x 2 B); timed by its own
-       # event pair (sc2_rans_decode_dequantize_batch_ev); one launch covers every stream of its coder group
-       'dec.dequantize': (0.0, 0.2904, 0.1452),
-       # round 4's layout pass in front of the first encoder stage (f32 NCHW -> bf16 [N,H,W,4]); since round 5 the first stage
-       # reads the f32 planes in place (enc.conv0's 0.602 MB) and this launch only exists with --conv0-layout-pass (A/B)
-       'enc.layout': (0.0, 0.602, 0.401)}
-
-
-def launch_work(tag):
-    """(MFLOP, MB) per image of one tagged launch; 'a+b' = ops a and b fused in one launch (reads a's input, writes
-    b's output); an unfused GDN launch reads its input twice (GEMM operand + element-wise operand)."""
-    parts = [q[:-4] if q.endswith('.f32') else q for q in tag.split('+')]   # '.f32': the reference-precision encoder's launches
-    if any(q not in OPS for q in parts):
-        return None
-    mflop = sum(OPS[q][0] for q in parts)
-    rd = OPS[parts[0]][1] * (2 if len(parts) == 1 and 'gdn' in parts[0] else 1)
-    return mflop, rd + OPS[parts[-1]][2]
-
-
-def shape_workload(model):
-    """Deterministic, non-degenerate operating point for a random-init model (there are no trained checkpoints
-    offline).  With the default init the factorised prior is flat over every table row and the latent rounds to
-    {-1, 0, 1}: every image then codes to the same byte count and no escape symbol is ever produced.  Here:
-      * quantiles [-(3+c%5), 0.25*(c%3), 4+c%7] per channel c (SURVEY.md 8(d)) -> ragged tables of 10-19 entries;
-      * the first matrix of the cumulative-logit MLP is sharpened per channel (softplus(M0) * 5*(1+0.25*(c%4))): a peaked
-        prior, as a trained model has;
-      * the last encoder conv is scaled x7: latent std ~1, symbols in about [-6, 6], ~1e-4 escape (bypass) symbols: a
-        few per image (0 - 50), as an operating point whose tables fit the latent has (x10 gives 0.7 %).
-    Byte counts then depend on the image (synthetic_batch gives every image its own contrast)."""
-    import torch.nn.functional as F
-    bl = model.bottleneck_layer
-    eb = bl.entropy_bottleneck
-    with torch.no_grad():
-        C = eb.channels
-        q = torch.zeros(C, 1, 3)
-        k = torch.zeros(C, 1, 1)
-        for c in range(C):
-            q[c, 0, 0], q[c, 0, 1], q[c, 0, 2] = -(3 + c % 5), 0.25 * (c % 3), 4 + c % 7
-            k[c, 0, 0] = 5.0 * (1.0 + 0.25 * (c % 4))
-        eb.quantiles.copy_(q.to(eb.quantiles.device))
-        m0 = eb.matrices[0]
-        m0.copy_(torch.log(torch.expm1(k.to(m0.device) * F.softplus(m0))))
-        bl.encoder[4].weight.mul_(7.0)
-    return model
-
-
-def build_model(dev, seed=0, encoder_precision='bf16'):
-    import sc2bench_amd as S
-    torch.manual_seed(seed)
-    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
-    model = S.splittable_resnet(cfg, resnet_name='resnet50', skips_avgpool=False, skips_fc=False, num_classes=1000)
-    shape_workload(model)
-    model.eval().to(dev)
-    model.update()
-    model.set_compute_dtype('bf16')
-    model.set_encoder_precision(encoder_precision)
-    if dev.type == 'cuda':
-        torch.cuda.synchronize(dev)   # the casts above ran on the null stream; the pipeline streams are non-blocking
-    return model
-
-
-def synthetic_batch(bs, dev, seed=0):
-    """torch.rand images, each with its own contrast in [0.25, 1] around mid-grey so that the
-    compressed size depends on the image, then the ImageNet normalisation of the reference's transform."""
-    g = torch.Generator(device='cpu').manual_seed(seed)
-    x = torch.rand(bs, 3, 224, 224, generator=g)
-    c = (0.25 + 0.75 * ((torch.arange(bs) * 37) % 64).float() / 63.0).view(bs, 1, 1, 1)
-    x = 0.5 + (x - 0.5) * c
-    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
-    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
-    return ((x - mean) / std).to(dev)
+# Round 6: the harness is split by concern (benchlib/); this file keeps the argument parser, the headline line and the
+# CPU-baseline leg -- the only code outside tests/ and __graft_entry__.smoke() that touches oracle/.  The names below are
+# re-exported: the tests and tools/ import them from `bench`.
+from benchlib.model import (BOTTLENECK_GFLOP_PER_IMG, OPS, PEAK_BF16_TFLOPS, PEAK_F32_MATRIX_TFLOPS, PEAK_HBM_GBS,  # noqa: E402,F401
+                            build_model, launch_work, sha256_of, shape_workload, synthetic_batch)
+from benchlib.timing import WORKLOAD_PIPELINE, make_pipeline, ranks_reduced, timed_pipeline_run  # noqa: E402,F401
+from benchlib.train import STAGE1, STAGE2, train_bench  # noqa: E402,F401
+from benchlib.workloads import bottleneck_gflop, build_workload, secondary_lines, workload_bench  # noqa: E402,F401
+from benchlib.launch import dry_run, dry_run_streams, self_launch  # noqa: E402,F401
+from benchlib.eval_mode import bs1_eval  # noqa: E402,F401
 
 
 def oracle_model(state_dict):
@@ -150,15 +75,6 @@ def oracle_streams(ref, sym_rows, hw):
     idx = (torch.arange(n_sym) // hw).int().numpy()
     cdf, ln, off = eb._quantized_cdf.numpy(), eb._cdf_length.reshape(-1).numpy(), eb._offset.reshape(-1).numpy()
     return [oracle_rans.encode_with_indexes(sym_rows[i].numpy(), idx, cdf, ln, off) for i in range(sym_rows.shape[0])]
-
-
-def sha256_of(streams):
-    import hashlib
-    h = hashlib.sha256()
-    for s in streams:
-        h.update(len(s).to_bytes(4, 'little'))
-        h.update(s)
-    return h.hexdigest()
 
 
 def cpu_baseline(sample_images, state_dict, dev_symbols=None, hw=None):
@@ -293,287 +209,6 @@ def precision_check(model, x_dev, dev, n=64):
     return out
 
 
-STAGE1 = {   # train.stage1 of configs/ilsvrc2012/supervised_compression/entropic_student/splitable_resnet50-fp-beta0.08_from_resnet50.yaml
-    'teacher': {'sequential': ['conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4'],
-                'forward_hook': {'input': [], 'output': ['layer1', 'layer2', 'layer3', 'layer4']}},
-    'student': {'sequential': ['bottleneck_layer', 'layer2', 'layer3', 'layer4'],
-                'frozen_modules': ['layer2', 'layer3', 'layer4'],
-                'forward_hook': {'input': [], 'output': ['bottleneck_layer', 'layer2', 'layer3', 'layer4',
-                                                         'bottleneck_layer.entropy_bottleneck']}},
-    'optimizer': {'key': 'Adam', 'kwargs': {'lr': 0.001}},
-    'criterion': {'key': 'WeightedSumLoss', 'kwargs': {'sub_terms': dict(
-        [('layer{}'.format(i), {'criterion': {'key': 'MSELoss', 'kwargs': {'reduction': 'sum'}},
-                                'criterion_wrapper': {'key': 'SimpleLossWrapper', 'kwargs': {
-                                    'input': {'is_from_teacher': False,
-                                              'module_path': 'bottleneck_layer' if i == 1 else 'layer{}'.format(i), 'io': 'output'},
-                                    'target': {'is_from_teacher': True, 'module_path': 'layer{}'.format(i), 'io': 'output'}}},
-                                'weight': 1.0}) for i in (1, 2, 3, 4)] +
-        [('bpp', {'criterion': {'key': 'BppLoss', 'kwargs': {'entropy_module_path': 'bottleneck_layer.entropy_bottleneck',
-                                                             'reduction': 'sum'}}, 'weight': 0.08})])}},
-}
-
-
-STAGE2 = {   # train.stage2 of the same YAML (:231-295): KD loss on the logits, decoder + layer2-4 + fc train, encoder + prior frozen
-    'teacher': {'sequential': [], 'frozen_modules': [], 'forward_hook': {'input': [], 'output': []}},
-    'student': {'sequential': [], 'frozen_modules': ['bottleneck_layer.encoder', 'bottleneck_layer.entropy_bottleneck'],
-                'forward_hook': {'input': [], 'output': []}},
-    'optimizer': {'key': 'SGD', 'kwargs': {'lr': 0.001, 'momentum': 0.9, 'weight_decay': 0.0005}},
-    'criterion': {'key': 'WeightedSumLoss', 'kwargs': {'sub_terms': {'kd': {'criterion': {'key': 'KDLoss', 'kwargs': {
-        'student_module_path': '.', 'student_module_io': 'output', 'teacher_module_path': '.', 'teacher_module_io': 'output',
-        'temperature': 1.0, 'alpha': 0.5, 'reduction': 'batchmean'}}, 'weight': 1.0}}}},
-}
-
-
-def train_bench(args, dev, rank, world, distributed, emit=True):
-    """Stage-1 Entropic-Student training step: frozen teacher forward, student forward (HIP bottleneck + frozen tail),
-    MSE-sum + 0.08 * bits, aux loss, backward on the HIP kernels, ONE flat-bucket gradient all-reduce (RCCL), Adam."""
-    import sc2bench_amd as S
-    from sc2bench_amd import training as T, dataparallel as dp
-    from sc2bench_amd.resnet import resnet50
-    torch.manual_seed(0)
-    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
-    student = S.splittable_resnet(cfg, skips_avgpool=False, skips_fc=False).to(dev)
-    teacher = resnet50().to(dev)
-    if distributed:
-        dp.broadcast_parameters(student)
-    stage2 = args.stage == 2
-    if stage2:      # the reference updates the bottleneck when stage 2 starts (epoch_to_update): round + detach in the student
-        shape_workload(student)
-        student.update()
-    stage = T.DistillationStage(teacher, student, STAGE2 if stage2 else STAGE1, dev, head_dtype=torch.bfloat16)
-    x = synthetic_batch(args.bs, dev, seed=rank)
-    targets = torch.randint(0, 1000, (args.bs,), generator=torch.Generator().manual_seed(rank)).to(dev) if stage2 else None
-
-    def step():
-        loss = stage.forward_process(x, targets)
-        stage.post_forward_process(loss, bottleneck_updated=stage2)
-        return loss
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize(dev)
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    assert torch.isfinite(loss)
-    # metric reduction as evaluation does it (sum of [count, total] over ranks), on the backend's device
-    g_images, g_loss = dp.all_reduce_sum_scalars([float(args.bs * args.steps), float(loss) * args.bs])
-    line = None
-    if rank == 0:
-        line = ({
-            'metric': 'images/s, Entropic-Student ResNet-50 stage-{} training step, 224^2'.format(args.stage), 'value': args.bs * args.steps * world / elapsed,
-            'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': ('stage 2 of the Entropic-Student recipe (KD loss; decoder + layer2-4 + fc train with batch-statistics '
-                                    'BatchNorm: {}; encoder + prior frozen, frozen teacher on the HIP stacks)'.format(
-                                        'norm layers + ReLU + residual add on bn.hip, the blocks\' convs on the library\'s kernels under autograd'
-                                        if (S.hip.host_policy.bn_train_hip and S.hip.host_policy.conv_train_hip) else
-                                        'norm layers on bn.hip, convs on torch / MIOpen' if S.hip.host_policy.bn_train_hip else
-                                        'on torch / MIOpen ops under bf16 autocast')) if stage2 else
-                                   'stage 1 of the Entropic-Student recipe (bottleneck trains, layer2-4 frozen, frozen teacher)',
-                       'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'gradient_all_reduce_bytes': stage.reducer.nbytes(),
-                       'sharding': 'images; one flat-bucket all-reduce per step',
-                       'process_group': '{} ({} rank{})'.format(dist.get_backend(), world, '' if world == 1 else 's') if distributed else 'none',
-                       'collectives_issued': bool(dp.collectives_active()),
-                       'gradient_buckets': len(stage.reducer.buckets),
-                       'buckets_launched_from_backward_hooks_last_step': stage.reducer.launched_by_hook,
-                       'teacher_on_side_stream': bool(S.hip.host_policy.teacher_stream),
-                       'gdn_kernels': 'resident-row (gdn512_rows / gdn96_strips)' if S.hip.host_policy.gdn_rows else 'tile GEMMs',
-                       'fused_forward_stages': [n for n, on in (('enc.conv0+gdn96', S.hip.host_policy.train_fused_conv0),
-                                                                ('enc.conv2+gdn48', S.hip.host_policy.train_fused_conv2),
-                                                                ('dec.conv0+igdn512', S.hip.host_policy.train_fused_dec0)) if on]},
-            'final_loss': loss.item(), 'images_all_ranks': g_images, 'mean_loss_all_ranks': g_loss / max(g_images / args.steps, 1.0)})
-        if emit:
-            print(json.dumps(line))
-    if distributed and emit:
-        dist.barrier()
-        dist.destroy_process_group()
-    return line
-
-
-def dry_run_streams(rank):
-    """The per-rank fields of a multi-GPU line (`per_rank`: bpp and the digest of the rank's first 8 byte streams) without a
-    device: 8 streams of rank-seeded symbols through the library's HOST range coder (csrc/rans_host.cpp, product code) on the
-    known-answer table of tests/golden/rans_kat.json."""
-    import numpy as np
-    sys.path.insert(0, ROOT)
-    from sc2bench_amd import hip
-    t = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'rans_kat.json')))['table']
-    width = max(len(r) for r in t['cdfs'])
-    cdf = np.zeros((len(t['cdfs']), width), np.int32)
-    for i, r in enumerate(t['cdfs']):
-        cdf[i, :len(r)] = r
-    tables = hip.HostRansTables(cdf, t['cdf_sizes'], t['offsets'])
-    rng = np.random.RandomState(1000 + rank)
-    sym = rng.randint(-3, 4, size=(8, 24 * 55 * 55)).astype(np.int32)
-    strings, status = hip.rans_encode_host(tables, sym, index_div=sym.shape[1])      # (every symbol of a stream on table row 0)
-    return {'bpp': 8.0 * sum(len(q) for q in strings) / (8 * 224 * 224), 'rans_status': int(status.max()),
-            'bitstream_sha256_first8': sha256_of(strings)}
-
-
-def dry_run(args, world, rank, local_rank):
-    """The launch contract without a device: process group (gloo), per-rank shard seed, barrier-bracketed timed region,
-    max over ranks, ONE JSON line from rank 0.  No HIP call is made (torch.cuda is not touched)."""
-    distributed = world > 1
-    if distributed:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo')
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        time.sleep(0.001 * (1 + rank))      # stands in for a step; ranks differ so that MAX is exercised
-    own_work = time.perf_counter() - t0     # (in front of the closing barrier: what THIS rank took)
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # what rank r would process: its own synthetic shard (seed r) = images [lo, hi) of a global batch of bs * world
-    sys.path.insert(0, ROOT)
-    from sc2bench_amd.dataparallel import shard_range
-    lo, hi = shard_range(args.bs * world, rank, world)
-    info = {'rank': rank, 'local_rank': local_rank, 'seed': rank, 'shard': [lo, hi], 'own_elapsed_s': elapsed, 'own_work_s': own_work}
-    info.update(dry_run_streams(rank))
-    ranks = [info]
-    n_ranks = None
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-        one = torch.ones(1)
-        dist.all_reduce(one, op=dist.ReduceOp.SUM)     # backend-side proof of the rank count (the GPU line: `ranks_reduced`)
-        n_ranks = int(round(one.item()))
-        ranks = [None] * world
-        dist.all_gather_object(ranks, info)
-    if rank == 0:
-        print(json.dumps({'metric': 'images/s + bpp, Entropic-Student ResNet-50 224^2', 'dry_run': True,
-                          'value': args.bs * args.steps * world / elapsed, 'unit': 'images/s', 'n_gpus': world,
-                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'none',
-                          'config': {'workload': 'dry run: launch / rank / reduction plumbing only',
-                                     'batch_per_gpu': args.bs, 'global_batch': args.bs * world, 'ranks_reduced': n_ranks}, 'ranks': ranks}))
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def bottleneck_gflop(H, W):
-    """algorithmic GFLOP (2 * MACs) of the ten transforms of the FP bottleneck for one H x W image."""
-    def o(n, k, st, p):
-        return (n + 2 * p - k) // st + 1
-    h1, w1 = o(H, 5, 2, 2), o(W, 5, 2, 2)
-    h2, w2 = o(h1, 5, 2, 2), o(w1, 5, 2, 2)
-    h3, w3 = h2 - 1, w2 - 1
-    macs = (h1 * w1 * 96 * (75 + 96) + h2 * w2 * 48 * (2400 + 48) + h3 * w3 * 24 * 192 +
-            (h3 + 1) * (w3 + 1) * 512 * (96 + 512) + h3 * w3 * 256 * (2048 + 256) + (h3 + 1) * (w3 + 1) * 256 * 1024)
-    return 2e-9 * macs
-
-
-def _shape_backbone(S, **resnet_kwargs):
-    torch.manual_seed(0)
-    cfg = {'key': 'FPBasedResNetBottleneck', 'kwargs': {'num_bottleneck_channels': 24, 'num_target_channels': 256}}
-    backbone = S.splittable_resnet(cfg, skips_avgpool=True, skips_fc=True, **resnet_kwargs)
-    shape_workload(backbone)
-    return backbone
-
-
-def build_workload(name, dev, bs):
-    """The other BASELINE configs as the reference's API runs them (module forward in eval mode after update(): encode ->
-    bytes -> decode inside): -> (model, input batch, description, (H, W) of the bottleneck's input or None, default bs)."""
-    import sc2bench_amd as S
-    from sc2bench_amd import dense, transforms as T
-    if name == 'seg513':      # config 5: Entropic-Student DeepLabv3-ResNet-50, PASCAL VOC2012 513 x 513 (voc yaml:132 batch 16)
-        n = bs or 16
-        backbone = _shape_backbone(S, replace_stride_with_dilation=[False, True, True])
-        body = S.FeatureExtractionBackbone(backbone, {'layer3': 'aux', 'layer4': 'out'}, [], False,
-                                           analyzable_layer_key='bottleneck_layer')
-        model = dense.create_deeplabv3(body, num_input_channels=2048, uses_aux=True, num_aux_channels=1024, num_classes=21)
-        model.eval().to(dev)
-        model.update()
-        body.set_compute_dtype('bf16')
-        model.classifier.to(torch.bfloat16)
-        model.aux_classifier.to(torch.bfloat16)
-        x = torch.rand(n, 3, 513, 513, generator=torch.Generator().manual_seed(0)).to(dev)
-        what = ('Entropic-Student DeepLabv3-ResNet-50 (FP bottleneck 24ch, dilated layer3/4 on the HIP head, ASPP head = torch '
-                'ops in bf16), 513x513, eval after update()')
-        return model, x, what, (513, 513), n
-    if name == 'det800x1216':  # config 4: the Faster R-CNN body: bottleneck + FrozenBN layer2-4 + FPN (RPN / RoI heads need torchvision)
-        n = bs or 6
-        backbone = _shape_backbone(S, norm_layer='FrozenBatchNorm2d')
-        model = dense.backbone_with_fpn(backbone, return_layer_dict={'bottleneck_layer': '1', 'layer2': '2', 'layer3': '3', 'layer4': '4'},
-                                        in_channels_list=[256, 512, 1024, 2048], out_channels=256,
-                                        analyzable_layer_key='bottleneck_layer', analysis_config={'analyzes_after_compress': False})
-        model.eval().to(dev)
-        model.update()
-        model.body.set_compute_dtype('bf16')
-        model.fpn.to(torch.bfloat16)
-        x = torch.rand(n, 3, 800, 1216, generator=torch.Generator().manual_seed(0)).to(dev)
-        what = ('Entropic-Student Faster R-CNN ResNet-50-FPN BODY (FP bottleneck 24ch + FrozenBN layer2-4 on the HIP head + FPN '
-                'in bf16 torch ops; RPN / RoI heads need torchvision: not part of this figure), 800x1216, eval after update()')
-        return model, x, what, (800, 1216), n
-    if name == 'mshp224':      # the mean-scale hyperprior Entropic-Student (29 of the reference's Entropic-Student configs): 224 x 224
-        n = bs or 256
-        torch.manual_seed(0)
-        cfg = {'key': 'MSHPBasedResNetBottleneck', 'kwargs': {'num_latent_channels': 16, 'num_bottleneck_channels': 24,
-                                                               'num_target_channels': 256}}
-        model = S.splittable_resnet(cfg, skips_avgpool=False, skips_fc=False, num_classes=1000)
-        bl = model.bottleneck_layer
-        with torch.no_grad():    # a non-degenerate operating point for random weights: ragged z tables, a latent of std ~1.5,
-            eb = bl.entropy_bottleneck      # hyper-synthesis outputs that spread the predicted scales over the scale table
-            q = torch.zeros(eb.channels, 1, 3)
-            for c in range(eb.channels):
-                q[c, 0, 0], q[c, 0, 1], q[c, 0, 2] = -(3 + c % 5), 0.25 * (c % 3), 4 + c % 7
-            eb.quantiles.copy_(q)
-            bl.g_a[4].weight.mul_(10.0)      # latent std ~1.3
-            bl.h_a[2].weight.mul_(4.0)
-            w = bl.h_s[4].weight             # [scales | means] halves of gaussian_params (layer.py:764-785 chunks them that way)
-            half = w.shape[0] // 2
-            w[:half].abs_().mul_(5.0)        # predicted scales ~1.3: the Gaussian model FITS the latent (~2.4 bits per symbol, a
-            #                                  few escapes) -- with an untrained h_s every scale sits at the 0.11 floor, every
-            #                                  non-zero symbol is bypass-coded and the coder is measured on its slow path only
-        model.eval().to(dev)
-        model.update()
-        model.set_compute_dtype('bf16')
-        x = synthetic_batch(n, dev, seed=0)
-        what = ('Entropic-Student ResNet-50 with the MEAN-SCALE HYPERPRIOR bottleneck (MSHPBasedResNetBottleneck 16 / 24 ch: g_a, h_a, '
-                'h_s, g_s on the HIP kernels; z on the factorised prior, y on the Gaussian conditional with per-symbol CDF rows; both '
-                'streams through the batched device coder), 224x224, eval after update(): encode -> bytes -> decode -> layer2..fc')
-        return model, x, what, (224, 224), n
-    if name == 'fp_input':     # config 3: Factorized-Prior (quality 8) input compression + ResNet-50, 224 x 224
-        from sc2bench_amd.resnet import resnet50
-        n = bs or 32
-        torch.manual_seed(0)
-        codec = S.bmshj2018_factorized(8)
-        eb = codec.entropy_bottleneck
-        with torch.no_grad():
-            q = torch.zeros(eb.channels, 1, 3)
-            for c in range(eb.channels):
-                q[c, 0, 0], q[c, 0, 1], q[c, 0, 2] = -(3 + c % 5), 0.25 * (c % 3), 4 + c % 7
-            eb.quantiles.copy_(q)
-            codec.g_a[6].weight.mul_(10.0)
-        clf = resnet50(num_classes=1000).eval()
-        post = T.Compose([T.CenterCrop([224, 224]), T.Normalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])])
-        model = S.NeuralInputCompressionClassifier(clf, pre_transform=T.AdaptivePad(fill=0, factor=64), compression_model=codec,
-                                                   post_transform=post, analysis_config={})
-        model.eval().to(dev)
-        codec.update()
-        model.set_compute_dtype('bf16')      # the ResNet-50 classifier on the library's fused conv + norm kernels (head.HipResNet)
-        x = torch.rand(n, 3, 224, 224, generator=torch.Generator().manual_seed(0)).to(dev)
-        what = ('bmshj2018_factorized quality 8 (N 192, M 320) input compression on the HIP kernels (AdaptivePad 64 -> 256x256) + '
-                'ResNet-50 classifier (bf16, the library\'s fused conv + norm kernels), 224x224, eval after update()')
-        return model, x, what, None, n
-    raise SystemExit('unknown workload ' + name)
-
-
 def workload_cpu_baseline(name, model, x, budget_s=12.0):
     """The oracle (CPU port, f32 torch CPU ops + the single-threaded C range coder, as upstream) on ONE image of the same
     workload, repeated until `budget_s` seconds of CPU work have run: a reported baseline on a bounded sample (kind 'port').
@@ -650,236 +285,6 @@ def workload_cpu_baseline(name, model, x, budget_s=12.0):
                 break
     return {'value': n / dt, 'unit': 'images/s', 'cores': threads, 'host_cpu_count': os.cpu_count(), 'kind': 'port',
             'sample': '{} x 1 image of the same workload ({}), {:.1f} s of CPU work'.format(n, what, dt)}
-
-
-WORKLOAD_PIPELINE = {   # (coder group G, coder streams) per workload, by measurement
-    'es224': (8, 4),
-    # mean-scale hyperprior: the per-symbol-index decoder holds 120 KB of LDS per workgroup for ~20 ms; 2 048 streams per launch with
-    # two 16-stream waves per workgroup (64 CUs held, the library's choice from 1 024 streams up), three launches in flight
-    # (tools/mshp_sweep.sh, 40 steps: 35.2 k images/s at G = 2, 36.6 k at G = 8 with one wave per workgroup, 39.3 k with two)
-    'mshp224': (8, 3),
-    'fp_input': (8, 4),      # 32 streams per batch: 256 per launch
-    'seg513': (8, 4),        # 16 streams x 393 k symbols per batch: 128 per launch, ~85 ms of chain each way
-    'det800x1216': (8, 6),   # 6 streams x 1.45 M symbols per batch: 48 per launch (one wave), ~330 ms each way
-}
-
-
-def make_pipeline(args, model, dev):
-    import sc2bench_amd as S
-    g_default, c_default = WORKLOAD_PIPELINE[args.workload]
-    return S.StagePipeline(model, dev, coder_group=args.coder_group or g_default, coder_streams=args.inflight or c_default,
-                           max_inflight=args.max_inflight, ramp=bool(args.ramp), lag=max(0, args.lag),
-                           front_priority=args.front_priority, back_priority=args.back_priority, coder_priority=args.coder_priority,
-                           back_streams=max(1, args.split_mfma), share_buffer=not args.cat_symbols,
-                           coder_kwargs={'dequantized': False} if args.unfused_dequantize else None)
-
-
-def timed_pipeline_run(pipe, x, steps, select, distributed, timeline=False):
-    """K batches through the package's stage pipeline (sc2bench_amd/pipeline.py), bracketed as the contract says: the caller has
-    synchronised; this starts the clock, issues K batches, synchronises every stream (+ barrier) and stops it.
-    -> (elapsed s, host issue s, KernelTimer, last (output, nbytes, status), record)"""
-    from sc2bench_amd import hip
-    rec = {'timeline': []} if timeline else {}
-    last = [None]
-
-    def keep(step, out, nb, st):
-        last[0] = (out, nb, st)
-
-    with hip.KernelTimer(select) as timer:
-        t0 = time.perf_counter()
-        pipe.run(x, n_steps=steps, on_output=keep, record=rec)
-        t_issued = time.perf_counter()
-        pipe.synchronize()
-        if distributed:
-            dist.barrier()
-        t1 = time.perf_counter()
-    return t1 - t0, t_issued - t0, timer, last[0], rec
-
-
-def ranks_reduced(dev, distributed):
-    """RCCL-side proof of the rank count: every rank contributes 1 to a device all-reduce on the backend (the process group's
-    world size in `config.process_group` comes from the launcher's environment)."""
-    if not distributed:
-        return None
-    one = torch.ones(1, dtype=torch.float32, device=dev)
-    dist.all_reduce(one, op=dist.ReduceOp.SUM)
-    return int(round(one.item()))
-
-
-def workload_bench(args, dev, rank, world, distributed, emit=True):
-    """`--workload mshp224 | seg513 | det800x1216 | fp_input`: that config's updated model through the package's stage pipeline
-    (the same scheduler as the headline line: front stages run ahead, the range coder of G batches shares a launch on its own
-    HIP stream, byte streams stay on the device), K steps after W warm-up steps.  `--no-pipeline`: the module forward per
-    batch (one stream, bytes objects through the host API: the reference's semantics; what rounds 3 - 4 reported)."""
-    from sc2bench_amd import hip
-    import sc2bench_amd as S
-    model, x, what, hw, n = build_workload(args.workload, dev, args.bs if args.bs != 256 else 0)
-    select = lambda tag: tag is not None and (tag.startswith(('enc.', 'dec.', 'g_a', 'g_s', 'h_a', 'h_s')) or tag.startswith('rans'))  # noqa: E731
-    pipelined = not args.no_pipeline and S.supports_stages(model)
-    pipe = make_pipeline(args, model, dev) if pipelined else None
-
-    def step():
-        with torch.no_grad():
-            return model(x)
-
-    if pipelined:
-        G = pipe.G
-        pipe.run(x, n_steps=max(1, (args.warmup + G - 1) // G * G))
-        pipe.synchronize()
-        if args.warmup > 0 and not args.no_prealloc:
-            pipe.warm(x, args.steps)
-        if distributed:
-            dist.barrier()
-        elapsed, _, timer, last, rec = timed_pipeline_run(pipe, x, args.steps, select, distributed)
-        out, nb_last, _ = last
-        from sc2bench_amd.entropy import _status_or
-        assert all(_status_or(st) == 0 for st in rec['statuses']), 'rANS status != 0 in a timed step'
-    else:
-        for _ in range(max(1, args.warmup)):
-            out = step()
-        torch.cuda.synchronize(dev)
-        if distributed:
-            dist.barrier()
-        with hip.KernelTimer(select) as timer:
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                out = step()
-            torch.cuda.synchronize(dev)
-            if distributed:
-                dist.barrier()
-            elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-    n_ranks = ranks_reduced(dev, distributed)
-    leaves = list(out.values()) if isinstance(out, dict) else [out]
-    assert all(torch.isfinite(v.float()).all() for v in leaves)
-    if rank != 0:
-        return None
-    ksum = timer.summary()
-    bn = {k: v for k, v in ksum.items() if k.startswith(('enc.', 'dec.')) and k != 'dec.dequantize'}
-    roofline = None
-    if hw is not None and bn:
-        ms = sum(v[1] for v in bn.values()) + timer.total_ms('dec.dequantize') / float(args.steps)
-        tf = bottleneck_gflop(*hw) * n / ms
-        traffic = None   # HBM bytes of the bottleneck forward of one step from the committed PMC passes (tools/pmc_workload.sh)
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'traffic_workloads.json')
-        if os.path.exists(tpath) and args.bs in (0, 256):   # (the committed figures are for the default batch of the workload)
-            traffic = json.load(open(tpath)).get(args.workload, {}).get('hbm_bytes_per_bottleneck_forward')
-        roofline = {'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / PEAK_BF16_TFLOPS,
-                    'traffic': traffic, 'kernel': 'bottleneck forward = sum of its fused launches + the dequantise pass', 'kernel_ms': ms,
-                    'gflop_per_image': bottleneck_gflop(*hw)}
-    # compressed size of the batch as the reference measures it (host API: bytes objects)
-    with torch.no_grad():
-        bl = model.compression_model if args.workload == 'fp_input' else model.bottleneck_layer if args.workload == 'mshp224' else \
-            (model.body if hasattr(model, 'body') else model.backbone).bottleneck_layer
-        obj = bl.compress(model.pre_transform(x)) if args.workload == 'fp_input' else bl.encode(x)
-    nbytes = sum(len(q) for lst in obj['strings'] for q in lst)     # (the hyperprior codes two streams per image: y and z)
-    pix = x.shape[-1] * x.shape[-2] * n
-    if pipelined:    # the pipeline's device-resident streams code to the same byte count as the host API's bytes objects
-        assert int(nb_last.sum().item()) == nbytes, 'pipeline streams and encode() disagree: {} vs {} bytes'.format(int(nb_last.sum().item()), nbytes)
-    # the entropy model's estimate of the same batch: -sum log2 p / pixels in eval mode (sc2bench/loss.py:20-37; SURVEY 8(d))
-    with torch.no_grad():
-        if args.workload == 'fp_input':
-            liks = list(model.compression_model(model.pre_transform(x))['likelihoods'].values())
-        elif args.workload == 'mshp224':
-            bl._forward2train(x)
-            liks = list(bl.last_likelihoods)
-        else:
-            liks = [bl.entropy_bottleneck(bl.analysis(x))[1]]
-        bpp_est = float(sum(-torch.log2(v.float()).sum().item() for v in liks)) / pix
-    n_streams = len(obj['strings'][0])
-    sym_shape = obj.get('shape')
-    lat_c = 320 if args.workload == 'fp_input' else 24
-    sym_per_stream = lat_c * int(sym_shape[-2]) * int(sym_shape[-1]) if (sym_shape is not None and args.workload != 'mshp224') else \
-        '24 x 55 x 55 (y, per-symbol CDF rows) + 16 x {} x {} (z)'.format(int(sym_shape[-2]), int(sym_shape[-1]))
-    on_host = (not pipelined) and n_streams <= hip.host_coder_max_streams()
-    cpu, cpu_failed = None, None
-    if world == 1 and not args.no_cpu_baseline:
-        try:
-            cpu = workload_cpu_baseline(args.workload, model, x)
-        except Exception as e:   # the GPU figures are still printed, but a line without its baseline is not a result: rc != 0
-            cpu = {'value': None, 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: {!r}'.format(e)}
-            cpu_failed = 'cpu_baseline failed: {!r}'.format(e)
-    if pipelined:
-        pl = dict(pipe.describe(), what='sc2bench_amd.pipeline.StagePipeline: front stages run ahead, back stages wait for their coder launch',
-                  streams_per_coder_launch=pipe.G * n_streams, coder_group_plan=pipe.group_plan(args.steps)[:6])
-        streams = 'device-resident in the timed region (u8 rows in HBM with offset / nbytes vectors)'
-        coder = 'batched HIP coder ({} streams of {} symbols per launch)'.format(pipe.G * n_streams, sym_per_stream)
-    else:
-        pl = 'none: module forward, one stream'
-        streams = 'Python bytes through the host API (host coder up to {} streams, batched device coder above)'.format(hip.host_coder_max_streams())
-        coder = ('HOST threads (sc2_rans_encode_host / sc2_rans_decode_host): this batch is {} streams of {} symbols, a few long '
-                 'serial chains, which a CPU core steps faster than a GPU lane -- these are NOT HIP-coder figures'.format(n_streams, sym_per_stream)) \
-            if on_host else 'batched HIP coder ({} streams per launch)'.format(n_streams)
-    line = ({
-        'metric': 'images/s + bpp, ' + args.workload, 'value': n * args.steps * world / elapsed, 'unit': 'images/s', 'n_gpus': world,
-        'steps': args.steps, 'warmup': max(1, args.warmup), 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': what, 'batch_per_gpu': n, 'global_batch': n * world, 'pipeline': pl, 'streams': streams, 'range_coder': coder,
-                   'sharding': 'images, no collective', 'ranks_reduced': n_ranks},
-        'bpp': 8.0 * nbytes / pix, 'bpp_estimated': bpp_est, 'bytes_per_image': nbytes / n, 'roofline': roofline, 'cpu_baseline': cpu,
-        'rans': {k: {'ms_per_launch': round(v[1], 4), 'launches_per_step': v[0] / float(args.steps)}
-                 for k, v in sorted(ksum.items()) if k.startswith('rans')},
-        'kernels_ms': {k: round(v[1], 4) for k, v in sorted(ksum.items())}})
-    if emit:
-        print(json.dumps(line))
-    if cpu_failed:
-        sys.stdout.flush()
-        raise SystemExit('bench.py: ' + cpu_failed)
-    return line
-
-
-def secondary_lines(args, dev):
-    """Compact rows of the other workloads and of the stage-1 training step, measured by the default invocation after its own
-    timed region: {name: {'value', 'unit', 'ms_per_step', 'steps', ...}}; a workload that fails leaves {'error': ...}."""
-    import copy
-    import gc
-    rows = {}
-    for name in ('mshp224', 'seg513', 'det800x1216', 'fp_input', 'train_stage1'):
-        a = copy.copy(args)
-        a.no_cpu_baseline, a.warmup, a.bs, a.coder_group, a.inflight = True, 3, 256, 0, 0
-        try:
-            if name == 'train_stage1':
-                a.mode, a.stage, a.steps, a.warmup = 'train', 1, 10, 3
-                line = train_bench(a, dev, 0, 1, False, emit=False)
-                rows[name] = {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': a.steps,
-                              'workload': line['config']['workload'], 'batch': line['config']['batch_per_gpu']}
-            else:
-                a.workload, a.steps = name, 40      # (40 steps, as the stand-alone `--workload` lines: at 20 the coder chains' ramp is a third of the region)
-                line = workload_bench(a, dev, 0, 1, False, emit=False)
-                rows[name] = {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': a.steps,
-                              'bpp': line['bpp'], 'bpp_estimated': line['bpp_estimated'], 'batch': line['config']['batch_per_gpu'],
-                              'pipeline': line['config']['pipeline'] if isinstance(line['config']['pipeline'], str)
-                              else {k: line['config']['pipeline'][k] for k in ('steps_per_coder_launch', 'hip_streams', 'streams_per_coder_launch')},
-                              'bottleneck_forward_frac_of_mfma_peak': line['roofline']['frac'] if line.get('roofline') else None,
-                              'workload': line['config']['workload'][:120]}
-        except Exception as e:     # a secondary row never costs the headline line
-            rows[name] = {'error': repr(e)[:300]}
-        gc.collect()
-        torch.cuda.empty_cache()
-    return rows
-
-
-def self_launch(n):
-    """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <the same arguments>` as a child process (one rank per
-    GPU over RCCL, rendezvous on 127.0.0.1 and a free port), relays its output and exits with its return code.  A process
-    that has initialised the GPU must never be replaced or forked into ranks: this one has not touched it."""
-    import socket
-    import subprocess
-    with socket.socket() as sock:
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC only on this pool (RCCL needs it)
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    rc = subprocess.call(cmd, env=env)
-    if rc != 0:
-        print('bench.py: the {}-rank launch failed with return code {}'.format(n, rc), file=sys.stderr)
-    sys.exit(rc)
 
 
 def main():
@@ -965,7 +370,7 @@ def main():
     if args.mode == 'train':
         return train_bench(args, dev, rank, world, distributed)
     if args.workload != 'es224':
-        workload_bench(args, dev, rank, world, distributed)
+        workload_bench(args, dev, rank, world, distributed, cpu_baseline_fn=workload_cpu_baseline)
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -1266,62 +671,6 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def bs1_eval(model, x, dev, n=64):
-    """The reference's evaluation mode (script/task/image_classification.py:106-145, test batch size 1): per image
-    forward() = encode -> FileSizeAnalyzer on the pickled {'strings','shape'} -> decode -> head, through the host API
-    (bytes objects cross to the host and back, as in the reference).  Round 6: the two device halves of that forward replay HIP
-    graphs (sc2bench_amd/graphs.py) around the host range coder; the row also carries the eager figure, the launch count of an
-    eager forward and per-image latency percentiles (one synchronize per image)."""
-    import sc2bench_amd as S
-    from sc2bench_amd import hip
-    model.analyzes_after_compress = True
-    model.analyzers = [S.FileSizeAnalyzer(unit='KB')]
-    model.activate_analysis()
-
-    def loop(count):
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(count):
-            model(x[i % x.shape[0]:i % x.shape[0] + 1])
-        torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0
-
-    with torch.no_grad():
-        graphs_on = bool(hip.host_policy.eval_graphs)
-        hip.configure(eval_graphs=False)
-        for i in range(3):
-            model(x[i:i + 1])
-        with hip.KernelTimer() as kt:           # every tagged launch of ONE eager forward
-            model(x[0:1])
-            torch.cuda.synchronize(dev)
-        launches = len(kt.records)
-        dt_eager = loop(n)
-        hip.configure(eval_graphs=graphs_on)
-        for i in range(3):
-            model(x[i:i + 1])
-        used = model.__dict__.get('_eval_graphs') is not None and any(isinstance(v, S.graphs.EvalGraphs) for v in model.__dict__['_eval_graphs'].values())
-        model.clear_analysis()
-        dt = loop(n)
-        sizes = model.analyzers[0].file_size_list[-n:]
-        lat = []
-        for i in range(n):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            model(x[i % x.shape[0]:i % x.shape[0] + 1])
-            torch.cuda.synchronize(dev)
-            lat.append(1e3 * (time.perf_counter() - t0))
-        lat.sort()
-    model.deactivate_analysis()
-    return {'images_per_s': n / dt, 'ms_per_image': 1e3 * dt / n, 'images': n,
-            'data_size_kb_mean': sum(sizes) / len(sizes),
-            'latency_ms': {'p50': lat[len(lat) // 2], 'p99': lat[min(len(lat) - 1, int(0.99 * len(lat)))], 'what': 'one synchronize per image'},
-            'hip_graphs': ('2 graph replays per image (encoder | dequantise + decoder + layer2..fc) around the host range coder, '
-                           'captured once per input shape in this process' if used else
-                           'off: ' + str(model.__dict__.get('_eval_graphs_error') or 'policy')),
-            'eager': {'ms_per_image': 1e3 * dt_eager / n, 'launches_per_image': launches},
-            'what': 'bs 1, forward() with host bytes (encode -> pickle size -> decode -> layer2..fc), one stream'}
 
 
 if __name__ == '__main__':

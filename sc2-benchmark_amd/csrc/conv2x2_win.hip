@@ -657,7 +657,7 @@ int launch_w2(W2Args a, hipStream_t s) {
     // whatever CUs are free -- inside the pipelined bench the serial coder's workgroups and the encoder stage of a later batch
     // hold CUs for milliseconds, and with one static share per CU (14 tiles at bs 256) the launch waited for the workgroups
     // that could not start (measured in the pipeline, K = 20: 0.85 ms with the whole share, 0.79 ms with runs of 2 or 1;
-    // stand-alone the same).  SC2_W2_RUN=<tiles> overrides (tools/w2_run_ab.sh).
+    // stand-alone the same).  SC2_W2_RUN=<tiles> overrides (tools/attic/w2_run_ab.sh).
     const int cus8 = (g_cus_w2 / 8) * 8 > 0 ? (g_cus_w2 / 8) * 8 : 8;
     const int share = (a.n_tiles + cus8 - 1) / cus8;
     int run = share < 2 ? share : 2;

@@ -7,7 +7,7 @@
 // slabs in a 4-deep direct-to-LDS ring, buffer-addressed loads).  What changes is everything AROUND it.  As one workgroup
 // per tile, a CU spends per tile: ~2 us until the first slab lands, the K loop, the store epilogue (accumulators -> bf16
 // LDS image -> 128 KB of global stores) and its drain -- and with one 160 KB workgroup per CU nothing overlaps any of it
-// (measured, tools/epi_share.sh: dec.conv2 0.915 ms in all, 0.72 - 0.77 ms with the store epilogue switched off).
+// (measured, tools/attic/epi_share.sh: dec.conv2 0.915 ms in all, 0.72 - 0.77 ms with the store epilogue switched off).
 // Here a workgroup walks the tiles of its XCD's share of the output and
 //   * parks the finished tile's 128 KB in REGISTERS (16 x 16 bytes per thread) once the image is complete,
 //   * computes the next tile's gather state and issues its first three slabs,
@@ -16,7 +16,7 @@
 //     (~1 us later) they have retired,
 // so the stores drain and the first slabs arrive while the matrix pipes already work on the next tile.
 //
-// Measured on one MI355X, bs 256, same process (tools/ab_env.sh SC2_CONV_PERSIST "0 1 2 3"):
+// Measured on one MI355X, bs 256, same process (tools/attic/ab_env.sh SC2_CONV_PERSIST "0 1 2 3"):
 //                                     dec.conv2   dec.conv2 + IGDN256   dec.conv4
 //   0  one workgroup per tile           0.92 ms        1.02 ms           0.52 ms
 //   1  persistent, deferred stores      0.79           0.90              0.45
@@ -536,7 +536,7 @@ int launch8p(const ConvArgs &a, hipStream_t s) {
     // tiles per workgroup: SC2_CONV_CHUNK (0 / unset: the default below; large: one static share per CU)
     const int ce = sc2_pol().conv_chunk;
     const int per_xcd = (n_tiles + 7) / 8, cus_x = n_cus / 8 > 0 ? n_cus / 8 : 1;
-    int chunk = ce > 0 ? ce : 2;   // measured inside the pipelined bench (tools/chunk_ab.sh): 2 - 3 best, 1 static share per CU worst
+    int chunk = ce > 0 ? ce : 2;   // measured inside the pipelined bench (tools/attic/chunk_ab.sh): 2 - 3 best, 1 static share per CU worst
     const int full = (per_xcd + cus_x - 1) / cus_x;          // the share of one CU
     if (chunk > full) chunk = full;
     const int grid = 8 * ((per_xcd + chunk - 1) / chunk);

@@ -74,7 +74,7 @@ extern "C" int sc2_conv_weight_pitch(int K) { return K <= 0 ? 0 : (K + 63) / 64 
 namespace {
 // the 8-wave 256-row tile is used when ...
 bool big_tile_eligible(const sc2_conv_desc *d, long long M, int K) {
-    // Measured (tools/ab_big.py, one process, MI355X): 256-wide big tile wins +27 % at K = 2048 and +13 % at K = 1024,
+    // Measured (tools/attic/ab_big.py, one process, MI355X): 256-wide big tile wins +27 % at K = 2048 and +13 % at K = 1024,
     // ties or loses on the HBM-bound 1x1 GDN GEMMs and on short K; the 128-wide big tile never wins.
     // (SC2_CONV_FORCE_BIG / SC2_CONV_NO_BIG: test and A/B switches)
     const bool forced = sc2_pol().conv_force_big != 0;

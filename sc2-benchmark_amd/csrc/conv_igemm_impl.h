@@ -181,7 +181,7 @@ __device__ __forceinline__ uint4 lds_read16(uint32_t addr) {
 // (rows padded by 16 B, or chunk-XOR-swizzled for the 8-wave tiles): the epilogue operand x (GDN / residual) is
 // parked in the image with coalesced 16-byte accesses, every lane updates its 8-byte slots in place in f32
 // (x -> y), and the image is streamed out in whole 16-byte channel runs.  Measured before this layout
-// (tools/epi_share.sh): the 4-pass f32 staging cost as much as the whole K loop on the K <= 512 layers.
+// (tools/attic/epi_share.sh): the 4-pass f32 staging cost as much as the whole K loop on the K <= 512 layers.
 // f32 outputs (latent, module-level API, fc): MT passes through an f32 staging buffer, as before.
 template <class C>
 struct ImgPad {   // 4-wave tiles: row pitch BN*2 + 16 bytes (ds_write_b64 of 16 rows: 2-way conflicts at worst)

@@ -1456,7 +1456,7 @@ static int decode_impl(const uint8_t *in, int64_t in_stride, const int32_t *in_o
         // waves (of 16 streams) per workgroup behind one copy of the tables: 1 is the fastest for a launch that runs alone (19.4 /
         // 19.5 / 20.9 / 26.0 ms at 1 / 2 / 4 / 8, round 4); a wide launch inside a pipeline pins 120 KB of LDS per workgroup
         // for ~20 ms, and there two waves per workgroup win (half the CUs held: `bench.py --workload mshp224` 36.6 -> 39.3 k
-        // images/s at 2 048 streams per launch, tools/mshp_sweep.sh).  Policy 0 = by stream count.
+        // images/s at 2 048 streams per launch, tools/attic/mshp_sweep.sh).  Policy 0 = by stream count.
         const int waves = [n_streams] { const int v = sc2_pol().rans_ragged2_waves; return v <= 0 ? (n_streams >= 1024 ? 2 : 1) : v <= 1 ? 1 : v <= 2 ? 2 : v <= 4 ? 4 : 8; }();
         const size_t lds = (size_t)kRagged2Cap * 2 + (((size_t)kRagged2Rows * 257 * 2 + 15) & ~(size_t)15) + (size_t)kWin * 16 * waves * 4 +
                            (size_t)(3 * kRagged2Rows + 1) * 4 + 16;

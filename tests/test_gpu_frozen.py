@@ -58,7 +58,7 @@ def test_frozen_stack_forward_and_input_gradient(S, dev, name, cin, hw):
     # Reference for the input gradient: the same chain rule in f32 with the ReLU masks OF THE DEVICE'S FORWARD.  (Against a
     # pure-f32 forward the masks differ wherever bf16 rounding moves a pre-activation across zero; ~1 % flipped mask bits per
     # ReLU are each a full-magnitude error of that element: 10-20 % relative L2 after twelve ReLUs, which says nothing about
-    # the backward kernels.  tools/debug_dgrad.py checks every single data-gradient launch against torch autograd: 1.7e-3.)
+    # the backward kernels.  tools/attic/debug_dgrad.py checks every single data-gradient launch against torch autograd: 1.7e-3.)
     import torch.nn.functional as F
     with torch.no_grad():
         _, saved = stack.forward(xd.detach().permute(0, 2, 3, 1).contiguous(), save=True)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of an environment switch on the bench line, ONE box, interleaved rounds:
-#   tools/ab_bench_env.sh VAR "<values>" [rounds]
+#   tools/attic/ab_bench_env.sh VAR "<values>" [rounds]
 VAR=$1; VALS=$2; R=${3:-2}
 export GPU_MAX_HW_QUEUES=8
 mkdir -p gpurun_out/abenv

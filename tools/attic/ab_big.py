@@ -1,7 +1,7 @@
 """A/B in ONE process: 4-wave 128-row kernel vs 8-wave staggered 256-row kernel on the MFMA-bound layer shapes."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sc2bench_amd import hip
 
 dev = torch.device('cuda:0')

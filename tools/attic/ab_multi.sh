@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of several library builds on ONE box: tools/ab_multi.sh "<grep pattern>" <rounds> <variant names...>  ("cur" = the in-tree build)
+# A/B of several library builds on ONE box: tools/attic/ab_multi.sh "<grep pattern>" <rounds> <variant names...>  ("cur" = the in-tree build)
 PAT=$1; R=$2; shift; shift
 for r in $(seq $R); do
   for V in "$@"; do

@@ -1,8 +1,8 @@
 """Development aid: the f32 conv kernel against torch CPU on a few shapes, reporting WHICH 16-pixel row tiles differ (found the
-asm wait without a data dependence in round 4: only the first row tile of some waves was wrong).   python tools/dbg_f32.py"""
+asm wait without a data dependence in round 4: only the first row tile of some waves was wrong).   python tools/attic/dbg_f32.py"""
 import os, sys
 import torch, torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sc2bench_amd as S
 from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)
 env_policy.apply()

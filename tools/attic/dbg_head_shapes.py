@@ -1,6 +1,6 @@
 """Debug driver (round 4): the window-plane head kernels at the bs-256 shapes of the head, one launch at a time."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sc2bench_amd as S
 from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)
 env_policy.apply()

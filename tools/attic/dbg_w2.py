@@ -2,7 +2,7 @@
 (SC2_W2_DBG=1 in the environment: the library under test was built with -DSC2_W2_DBG_OUT=1 -- bash tools/build_variant.sh dbgx
 -DSC2_W2_DBG_OUT=1, SC2_LIB=tools/variants/lib_dbgx.so -- and stores the conv output instead of the GDN1 output.)"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ['SC2_W2_RUN'] = sys.argv[1] if len(sys.argv) > 1 else '5'
 fused = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 cin = int(sys.argv[3]) if len(sys.argv) > 3 else 512

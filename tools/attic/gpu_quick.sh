@@ -1,6 +1,6 @@
 #!/bin/bash
 # Quick GPU iteration: selected tests + head / layer timings + the two bench lines.
-# Usage: bash tools/gpu_quick.sh <tag> "<pytest -k expression or empty>" [steps: test head layers bench20 bench100]
+# Usage: bash tools/attic/gpu_quick.sh <tag> "<pytest -k expression or empty>" [steps: test head layers bench20 bench100]
 TAG=${1:-q}; KEXPR=${2:-}; shift; shift
 STEPS=${@:-test head}
 OUT=gpurun_out/$TAG

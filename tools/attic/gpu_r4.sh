@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 GPU sessions.  Usage (repo root, on the GPU box): bash tools/gpu_r4.sh <tag> <step> [<step> ...]
+# Round-4 GPU sessions.  Usage (repo root, on the GPU box): bash tools/attic/gpu_r4.sh <tag> <step> [<step> ...]
 #   steps: w2tests | ab:<variant>[:<k_times args>] | tests | smoke | bench20 | bench100 | ktimes | layers | head | prof | pmc | kt:<k_times args>
 TAG=${1:-r04a}; shift
 OUT=gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench line, rocprofv3 kernel trace of the same bench command.
-# Usage (from repo root, on the GPU box): bash tools/gpu_round.sh <tag> [bench args]
+# Usage (from repo root, on the GPU box): bash tools/attic/gpu_round.sh <tag> [bench args]
 TAG=${1:-r01}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 GPU session: parity tests, smoke, the driver's bench line (K=20) and the K=100 line, layer timings.
-# Usage (from repo root, on the GPU box): bash tools/gpu_round2.sh <tag> [steps: tests smoke bench20 bench100 layers prof]
+# Usage (from repo root, on the GPU box): bash tools/attic/gpu_round2.sh <tag> [steps: tests smoke bench20 bench100 layers prof]
 TAG=${1:-r02a}; shift
 STEPS=${@:-tests smoke bench20 bench100 layers}
 OUT=gpurun_out/$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 GPU session: parity tests, smoke, the driver's bench line (K=20) and the K=100 line, layer / head timings, rocprofv3
-# kernel stats, PMC passes.  Usage (from repo root, on the GPU box): bash tools/gpu_round3.sh <tag> [steps...]
+# kernel stats, PMC passes.  Usage (from repo root, on the GPU box): bash tools/attic/gpu_round3.sh <tag> [steps...]
 TAG=${1:-r03f}; shift
 STEPS=${@:-tests smoke bench20 bench100 layers head prof}
 OUT=gpurun_out/$TAG

@@ -1,7 +1,7 @@
 """LDS bank-conflict arithmetic for the access patterns of the fused encoder / decoder kernels (MI355X_MICROARCH.md, LDS: lane
 groups and bank modulus per instruction; an N-way conflict inside a group costs N LDS-array cycles instead of 1).
 
-    python tools/lds_conflicts.py
+    python tools/attic/lds_conflicts.py
 
 Prints, per access of conv0_gdn96's unit loop, the LDS-array cycles per wave-instruction without and with its conflicts, the
 number of such instructions per wave and unit, and the share of conflict cycles in the unit's LDS cycles -- the figure

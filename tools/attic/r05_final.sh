@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-5 evidence session (repo root, on the GPU box): bash tools/r05_final.sh [tag]
+# Round-5 evidence session (repo root, on the GPU box): bash tools/attic/r05_final.sh [tag]
 TAG=${1:-r05f}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=8 TMPDIR=/tmp
 t0=$(date +%s)
-bash tools/gpu_r4.sh $TAG smoke bench20 bench100 ktimes layers head prof
+bash tools/attic/gpu_r4.sh $TAG smoke bench20 bench100 ktimes layers head prof
 echo "== $(( $(date +%s) - t0 )) s: workloads"
 for W in mshp224 seg513 det800x1216 fp_input; do
   timeout 600 python bench.py --workload $W --steps 40 --no-cpu-baseline > $OUT/bench_$W.json 2> $OUT/bench_$W.err
@@ -29,6 +29,6 @@ timeout 300 python tools/gdn_gemm_times.py > $OUT/gdn_gemm_times.txt 2>&1; grep 
 timeout 300 python tools/wgrad_times.py > $OUT/wgrad_times.txt 2>&1; tail -6 $OUT/wgrad_times.txt
 bash tools/train_prof.sh $TAG > $OUT/train_prof.log 2>&1; tail -12 $OUT/train_prof.log
 echo "== $(( $(date +%s) - t0 )) s: PMC"
-bash tools/gpu_r4.sh $TAG pmc
+bash tools/attic/gpu_r4.sh $TAG pmc
 bash tools/pmc_workload.sh $TAG mshp224 seg513 det800x1216 2>&1 | tail -12
 echo "== $(( $(date +%s) - t0 )) s: done"

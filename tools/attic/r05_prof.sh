@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats of one bench.py invocation: bash tools/r05_prof.sh <tag> <name> <bench args...>
+# rocprofv3 kernel stats of one bench.py invocation: bash tools/attic/r05_prof.sh <tag> <name> <bench args...>
 TAG=$1; NAME=$2; shift 2
 OUT=gpurun_out/$TAG
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 """Development aid: torch.profiler view of the stage-1 training step (which aten ops the step still launches around the HIP
-kernels, and the host time per step):  python tools/train_profile.py [--steps 3]"""
+kernels, and the host time per step):  python tools/attic/train_profile.py [--steps 3]"""
 import argparse
 import os
 import sys
@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench as B  # noqa: E402
 import sc2bench_amd as S  # noqa: E402
 from sc2bench_amd import training as T  # noqa: E402

@@ -1,12 +1,12 @@
 """Experiment: the stage-1 training step captured in ONE HIP graph (torch.cuda.CUDAGraph) and replayed -- does capture go through
-the ctypes launches of the library, and what do 825 launches per step cost the host?   python tools/try_train_graph.py"""
+the ctypes launches of the library, and what do 825 launches per step cost the host?   python tools/attic/try_train_graph.py"""
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 import sc2bench_amd as S  # noqa: E402
 from tools import env_policy  # noqa: E402  (the SC2_* variables of the A/B scripts -> the dispatch policy)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copies the outputs of `bash tools/r05_final.sh <tag>` (merged back under gpurun_out/) into profiles/ and installs the PMC traffic files.
+# Copies the outputs of `bash tools/attic/r05_final.sh <tag>` (merged back under gpurun_out/) into profiles/ and installs the PMC traffic files.
 # usage (repo root): bash tools/install_evidence.sh r05k
 T=$1; O=gpurun_out/$T
 for f in bench20.json bench100.json bench_kernel_stats.csv prof_bench.json k_times.txt layer_times.txt head_times.txt train_stage1.json \
