@@ -67,8 +67,11 @@ inline int sc2_device_cus() {
 // A launch that is being CAPTURED into a HIP graph (round 6: the bs-1 evaluation forward replays graphs) keeps its counter
 // address for the life of the graph, while eager launches rotate through the ring: a replay on one stream and an eager launch
 // on another could meet on one counter.  Captured launches therefore take their counters from a second region behind the ring,
-// handed out once and never reused (sc2_counter_ring::launch_slot); 4 096 words per device and kernel family.
-constexpr size_t SC2_CAPTURE_WORDS = 4096;
+// handed out in order (sc2_counter_ring::launch_slot): 2^18 words (1 MB) per device and kernel family, i.e. 2 048 captured launches
+// of the hungriest family (128 words: conv1x1_kres) = some 250 captures of the whole evaluation forward before the region wraps
+// around and the OLDEST captures' words are handed out again (graphs that old are dropped ones in any workload of this package: a
+// model re-captures only when its parameters change).
+constexpr size_t SC2_CAPTURE_WORDS = (size_t)1 << 18;
 inline bool sc2_stream_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
@@ -79,7 +82,7 @@ struct sc2_counter_ring {
     std::atomic<unsigned *> base[SC2_MAX_DEVICES];
     std::atomic<unsigned> captured[SC2_MAX_DEVICES];
     // the counters of ONE launch on stream s: `per_launch` consecutive zeroed words.  Eager: slot seq mod (ring_words / per_launch)
-    // of the ring; captured: the next unused words of the capture region.  nullptr: allocation failed / capture region exhausted /
+    // of the ring; captured: the next unused words of the capture region.  nullptr: allocation failed /
     // first use of this kernel family inside a capture (hipMalloc is not capturable: run the launch once eagerly first).
     unsigned *launch_slot(hipStream_t s, size_t ring_words, unsigned per_launch, std::atomic<unsigned> &seq) {
         const bool cap = sc2_stream_capturing(s);
@@ -91,11 +94,8 @@ struct sc2_counter_ring {
         unsigned *ring = get(ring_words);
         if (!ring) return nullptr;
         if (!cap) return ring + (size_t)per_launch * (seq.fetch_add(1) % (unsigned)(ring_words / per_launch));
-        const unsigned at = captured[d].fetch_add(per_launch);
-        if (at + per_launch > SC2_CAPTURE_WORDS) {
-            sc2_set_error("more than %zu work-counter words captured into HIP graphs on device %d", SC2_CAPTURE_WORDS, d);
-            return nullptr;
-        }
+        // (per_launch divides the region: 1, 8 or 128 words; the modulo wraps to the oldest words)
+        const unsigned at = (captured[d].fetch_add(per_launch)) % (unsigned)SC2_CAPTURE_WORDS;
         return ring + ring_words + at;
     }
     unsigned *get(size_t ring_words) {   // nullptr: the allocation failed (sc2_set_error holds the reason)
