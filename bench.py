@@ -32,7 +32,7 @@ import sys
 import time
 
 # one hardware queue per HIP stream of the software pipeline (the runtime default is 4); must precede HIP init
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '10')   # encoder, decoder + head, 4 coder streams, the host-coder stream, the null stream, spare
 
 import torch
 import torch.distributed as dist
@@ -298,6 +298,7 @@ def main():
     ap.add_argument('--lag', type=int, default=0, help='steps between issuing encoder stage i and decoder+head stage i - lag in host order')
     ap.add_argument('--ramp', type=int, default=1, help='1: the first coder groups of a run hold 1, 2, 4, ... steps')
     ap.add_argument('--coder-group', type=int, default=0, help='steps whose symbols share one range-coder launch; 0 = the workload\'s default')
+    ap.add_argument('--host-steps', type=int, default=-1, help='leading steps whose streams the HOST coder codes (sc2bench_amd/pipeline.py); -1 = auto from the core count, 0 = none')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bs1', action='store_true', help='skip the bs-1 evaluation-mode row')
     ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` rows (the other workloads + the training step, a few steps each, after the timed region)')
@@ -415,9 +416,13 @@ def main():
         sync_all()
 
     select = lambda tag: launch_work(tag) is not None or tag.startswith('rans')  # noqa: E731
+    if args.diag_timeline:
+        pipe._host_staging['_trace'] = []
     elapsed, issue_s, timer, last, rec = timed_pipeline_run(pipe, x, args.steps, select, distributed, timeline=args.diag_timeline)
     statuses, latency = rec['statuses'], rec['latency']
     if args.diag_timeline:
+        for tr in pipe._host_staging.get('_trace', []):
+            print('host coder job {}'.format(tr), file=sys.stderr)
         tl = rec['timeline']
         base = tl[0][2]
         for kind, step, e_a, e_b in sorted(tl, key=lambda r: base.elapsed_time(r[2])):
@@ -560,7 +565,9 @@ def main():
                        'pipeline': 'sc2bench_amd.pipeline.StagePipeline (the scheduler evaluation.evaluate() uses): encoder stages run '
                                    'ahead, decoder+head stages wait for their coder launch',
                        'hip_streams': pipe.describe()['hip_streams'],
-                       'steps_per_coder_launch': G, 'max_inflight_steps': args.max_inflight, 'coder_group_plan': pipe.group_plan(args.steps)[:6], 'warmup_steps_run': warm_steps,
+                       'steps_per_coder_launch': G, 'max_inflight_steps': args.max_inflight, 'coder_group_plan': pipe.group_plan(args.steps, pipe.resolve_host_steps(x))[:8],
+                       'host_coder_steps': {'steps': pipe.resolve_host_steps(x), 'host_cores': hip.host_cores(),
+                                            'what': 'the first batches of the run are rANS-coded (encode + decode, the same bytes) by the library\'s host coder on the CPU cores while the device coder\'s first group is under way: sc2bench_amd/pipeline.py'}, 'warmup_steps_run': warm_steps,
                        'prealloc': 'none' if (args.no_prealloc or args.warmup == 0) else 'one untimed range-coder launch per coder group of the timed plan (device buffers only, not a step)',
                        'weights': 'random init seed 0, operating point shaped by bench.shape_workload (ragged tables, '
                                   'peaked prior, latent std ~1, ~1e-4 escape symbols)',

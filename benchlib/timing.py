@@ -25,7 +25,8 @@ def make_pipeline(args, model, dev):
                            max_inflight=args.max_inflight, ramp=bool(args.ramp), lag=max(0, args.lag),
                            front_priority=args.front_priority, back_priority=args.back_priority, coder_priority=args.coder_priority,
                            back_streams=max(1, args.split_mfma), share_buffer=not args.cat_symbols,
-                           coder_kwargs={'dequantized': False} if args.unfused_dequantize else None)
+                           coder_kwargs={'dequantized': False} if args.unfused_dequantize else None,
+                           host_steps=None if getattr(args, 'host_steps', -1) < 0 else args.host_steps)
 
 
 def timed_pipeline_run(pipe, x, steps, select, distributed, timeline=False):

@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 48
+#define SC2_ABI_VERSION 50
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -638,6 +638,11 @@ typedef struct sc2_rans_host_tables sc2_rans_host_tables;
 int sc2_rans_host_tables_create(const int32_t *cdfs, int n_cdfs, int cdf_stride, const int32_t *cdf_sizes,
                                 const int32_t *offsets, sc2_rans_host_tables **out);
 void sc2_rans_host_tables_destroy(sc2_rans_host_tables *tables);
+/* Both passes in one call: every stream is encoded into its row of `out` and that row decoded into symbols_out by the same host
+ * thread (the first coder groups of a pipelined run: sc2bench_amd/pipeline.py `host_steps`); status = encode | decode bits. */
+int sc2_rans_code_host(const sc2_rans_host_tables *tables, const int32_t *symbols, const int32_t *indexes, int64_t index_div,
+                       int n_streams, int64_t n_sym, uint8_t *out, int64_t out_stride, int32_t *out_offset, int32_t *out_nbytes,
+                       int32_t *symbols_out, int32_t *status, int n_threads);
 /* floor(x / freq) as the host ENCODER forms it (a multiplication by freq's precomputed reciprocal, exact for x < 2^63: the
  * coder's state never leaves [2^31, 2^63)); exported so that a test can sweep it against the division (1 <= freq <= 65 536). */
 uint64_t sc2_rans_host_rcp_div(uint64_t x, uint32_t freq);
@@ -659,6 +664,11 @@ int sc2_rans_decode_host(const sc2_rans_host_tables *tables, const uint8_t *in, 
  * every period_ticks ticks of the constant 100 MHz counter.  clock = delta s_memtime / delta s_memrealtime x 100 MHz between two
  * samples of one workgroup (MI355X_MICROARCH.md, DVFS item 6).  Launch it on a stream of its own BEFORE the kernels under study
  * so that it is resident while they run (tools/clock_probe.py). */
+/* dst[0 .. n_bytes) = src[0 .. n_bytes) by a kernel on `stream`: either side may be device memory or pinned, device-mapped host
+ * memory (hipHostMalloc); 16-byte aligned, n_bytes % 16 == 0.  Used where a copy must never block its caller (pipeline.py
+ * host-coder batches): a launch is asynchronous whatever else is in flight. */
+int sc2_copy_bytes(void *dst, const void *src, long long n_bytes, void *stream);
+
 int sc2_clock_probe(unsigned long long *samples, int n_workgroups, int n_samples, unsigned period_ticks, void *stream);
 
 #ifdef __cplusplus

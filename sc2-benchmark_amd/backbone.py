@@ -404,6 +404,17 @@ class SplittableResNet(UpdatableBackbone):
             return bl.stage_coder(payload, meta, **kwargs)
         return FPBasedResNetBottleneck.stage_coder(bl, payload, meta, **kwargs)
 
+    def stage_coder_host(self, payload, meta, **kwargs):
+        """the coder stage on the host thread pool, where the bottleneck offers it (FP bottleneck: `stage_coder_host`)"""
+        return self.bottleneck_layer.stage_coder_host(payload, meta, **kwargs)
+
+    def stage_coder_host_begin(self, payload, meta, staging, slot=0):
+        return self.bottleneck_layer.stage_coder_host_begin(payload, meta, staging, slot)
+
+    @property
+    def has_stage_coder_host(self):
+        return type(self.bottleneck_layer) is FPBasedResNetBottleneck
+
     def decode_head(self, y_hat_nhwc):
         """decoder + task head on a dequantised bf16 NHWC latent.  In bf16 eval with the HIP head, the decoder's last conv takes
         layer2.0's conv1 and downsample with it (one launch, `FPBasedResNetBottleneck.synthesis_nhwc_tail`): the 256-channel

@@ -429,3 +429,27 @@ extern "C" int sc2_rans_decode_host(const sc2_rans_host_tables *t, const uint8_t
     });
     return SC2_OK;
 }
+
+// Encode AND decode every stream on the host in one call (round 6: the first coder groups of a pipelined run, pipeline.py): a
+// thread codes a stream into its row and decodes that row straight away -- the row is still in the core's cache, and the two passes
+// share one thread start.  Arguments as the two calls above; status = encode status | decode status.
+extern "C" int sc2_rans_code_host(const sc2_rans_host_tables *t, const int32_t *symbols, const int32_t *indexes, int64_t index_div,
+                                  int n_streams, int64_t n_sym, uint8_t *out, int64_t out_stride, int32_t *out_offset,
+                                  int32_t *out_nbytes, int32_t *symbols_out, int32_t *status, int n_threads) {
+    HOST_REQUIRE(t && out && out_offset && out_nbytes && status && ((symbols && symbols_out) || n_sym == 0), "sc2_rans_code_host: null argument");
+    HOST_REQUIRE(n_streams >= 0 && n_sym >= 0, "sc2_rans_code_host: negative size");
+    HOST_REQUIRE(out_stride >= 8 && out_stride % 4 == 0, "sc2_rans_code_host: out_stride must be a multiple of 4, >= 8");
+    HOST_REQUIRE(indexes || index_div > 0 || n_sym == 0, "sc2_rans_code_host: need indexes or index_div");
+    HOST_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3u) == 0, "sc2_rans_code_host: out must be 4-byte aligned");
+    for_streams(n_streams, n_threads, [&](int s) {
+        const int32_t *idx = indexes ? indexes + (size_t)s * n_sym : nullptr;
+        int32_t st_enc = 0, st_dec = 0;
+        encode_stream(*t, symbols + (size_t)s * n_sym, idx, index_div, n_sym, out + (size_t)s * out_stride, out_stride, out_offset + s,
+                      out_nbytes + s, &st_enc);
+        decode_stream(*t, out + (size_t)s * out_stride + out_offset[s], out_nbytes[s], idx, index_div, n_sym,
+                      symbols_out + (size_t)s * n_sym, &st_dec);
+        status[s] = st_enc | st_dec;
+    });
+    return SC2_OK;
+}
+

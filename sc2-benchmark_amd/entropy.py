@@ -681,6 +681,86 @@ class EntropyBottleneck(_HostTablesMixin, nn.Module):
                                  want_nhwc=want_nhwc)
 
     @staticmethod
+    def _host_staging(staging, slot, N, n_sym):
+        """the two pinned buffers of one host-coder slot (symbols out, decoded symbols in) + the event that guards their reuse;
+        kept between calls: cudaHostAlloc of 2 x 74 MB costs tens of milliseconds"""
+        key = (slot, N, n_sym)
+        bufs = staging.get(key)
+        if bufs is None:
+            # (outside inference mode whatever the caller's: evaluate() runs under torch.inference_mode, the pipeline's worker thread
+            #  does not -- inference mode is per thread -- and it writes these buffers)
+            with torch.inference_mode(False):
+                bufs = staging[key] = [torch.empty((N, n_sym), dtype=torch.int32, pin_memory=True),
+                                       torch.empty((N, n_sym), dtype=torch.int32, pin_memory=True), None,
+                                       torch.empty((2, N), dtype=torch.int32, pin_memory=True)]
+        return bufs
+
+    def host_copy_begin(self, sym, staging, slot=0):
+        """First half of `code_on_host`, for a caller that wants the device-to-host copy under way before a worker thread picks the
+        batch up: enqueues symbols -> pinned host memory on the CURRENT stream, -> the event that marks its end."""
+        import time
+        t0 = time.perf_counter()
+        bufs = self._host_staging(staging, slot, sym.shape[0], sym.shape[1])
+        t1 = time.perf_counter()
+        if bufs[2] is not None:
+            bufs[2].synchronize()          # the previous batch's host-to-device copy out of this slot
+        t2 = time.perf_counter()
+        hip.copy_kernel(bufs[0], sym.contiguous())      # (a kernel, not the copy engine: its submission never blocks this thread)
+        t3 = time.perf_counter()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(sym.device))
+        if '_trace' in staging:
+            staging['_trace'].append({'copy_begin slot': slot, 'staging_ms': 1e3 * (t1 - t0), 'event_sync_ms': 1e3 * (t2 - t1), 'copy_call_ms': 1e3 * (t3 - t2),
+                                      'record_ms': 1e3 * (time.perf_counter() - t3)})
+        return ev
+
+    def code_on_host(self, sym, size, staging=None, slot=0, d2h_event=None):
+        """The coder stage of a whole batch on the HOST thread pool (round 6; pipeline.py `host_steps`): int32 symbols [N, C*hw]
+        on the device -> (y_hat bf16 NHWC on the device, nbytes int32 [N], status int32 [N], both on the device): the symbols cross
+        to pinned host memory (`d2h_event`: already under way, host_copy_begin), every stream is rANS-encoded into its byte row and
+        decoded from it again by the library's host coder (sc2_rans_code_host: one thread per group of streams; the same bytes as
+        the batched device coder, tests/test_gpu_host_coder.py), the decoded symbols cross back and are dequantised by the launch
+        the device path ends with.  Device work goes to the CURRENT stream; the call blocks its thread while the host codes."""
+        dev = sym.device
+        N, n_sym = sym.shape
+        hw = int(np.prod(size))
+        stream = torch.cuda.current_stream(dev)
+        staging = staging if staging is not None else {}
+        if d2h_event is None:
+            d2h_event = self.host_copy_begin(sym, staging, slot)
+        bufs = self._host_staging(staging, slot, N, n_sym)
+        sym_h, dec_h = bufs[0], bufs[1]
+        import time
+        t0 = time.perf_counter()
+        d2h_event.synchronize()
+        t1 = time.perf_counter()
+        tables = self._host_tables()
+        scratch = staging.setdefault(('scratch', slot), {})       # the byte rows, kept between calls (hip.rans_code_host)
+        _, _, nb, st = hip.rans_code_host(tables, sym_h.numpy(), hw, dec_h.numpy(), scratch=scratch)
+        if _status_or(st) & 1:     # a row overflowed 2 B / symbol: redo with the proven upper bound
+            _, _, nb, st = hip.rans_code_host(tables, sym_h.numpy(), hw, dec_h.numpy(), out_stride=hip.rans_max_bytes(n_sym))
+        t2 = time.perf_counter()
+        sym_back = torch.empty((N, n_sym), dtype=torch.int32, device=dev)
+        hip.copy_kernel(sym_back, dec_h)
+        # byte counts and status words ride in pinned memory too: a pageable copy would block this thread until the 74 MB in front
+        # of it on the stream have crossed
+        small = bufs[3]
+        small_np = small.numpy()
+        small_np[0], small_np[1] = nb, st
+        small_d = torch.empty((2, N), dtype=torch.int32, device=dev)
+        if (2 * N * 4) % 16 == 0:
+            hip.copy_kernel(small_d, small)
+        else:
+            small_d.copy_(small, non_blocking=True)
+        bufs[2] = torch.cuda.Event()
+        bufs[2].record(stream)
+        y_hat = self.dequantize_device(sym_back, tuple(size))[1]
+        if '_trace' in staging:
+            staging['_trace'].append({'slot': slot, 'wait_d2h_ms': 1e3 * (t1 - t0), 'host_code_ms': 1e3 * (t2 - t1),
+                                      'enqueue_ms': 1e3 * (time.perf_counter() - t2)})
+        return y_hat, small_d[0], small_d[1]
+
+    @staticmethod
     def unpack_strings(buf, off, nb):
         """Device streams (end-aligned rows of an encode) -> list[bytes]."""
         nb_h = nb.cpu().numpy()

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch', 'sc2_rans_decode_dequantize_batch_ev',
     'sc2_mse_partial_len', 'sc2_mse_sum_bf16', 'sc2_mse_grad_bf16', 'sc2_relu_bwd_bf16', 'sc2_relu_bwd_mse_bf16',
-    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_host_rcp_div', 'sc2_clock_probe', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
+    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_host_rcp_div', 'sc2_rans_code_host', 'sc2_clock_probe', 'sc2_copy_bytes', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
 ]
 
 
@@ -100,6 +100,7 @@ class HostPolicy(object):
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
     head_ds_side_stream = False  # the head's downsample layers on a side stream beside conv1 -> conv2 of their block: measured SLOWER (head 2.60 -> 2.67 ms, bench - 1 %: profiles/r06e_ab_ds_side.txt)
+    pipeline_host_steps = False  # StagePipeline(host_steps=None): True = the first batches of a run are coded by the host thread pool while the device coder's first group is under way (first logits of a run after ~11 ms instead of ~26); throughput of a 20-batch run unchanged (profiles/r06l_host_steps_ab.txt), so off by default
     eval_graphs = True         # the updated eval forward of SplittableResNet at small batch replays HIP graphs of its device halves (graphs.py)
     eval_graph_max_batch = 1   # ... for batches up to this size (the reference evaluates at batch size 1)
 
@@ -260,6 +261,8 @@ def lib():
     L.sc2_rans_host_rcp_div.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
     L.sc2_rans_host_rcp_div.restype = ctypes.c_uint64
     L.sc2_clock_probe.argtypes = [vp, i32, i32, ctypes.c_uint32, vp]
+    L.sc2_copy_bytes.argtypes = [vp, vp, ctypes.c_longlong, vp]
+    L.sc2_rans_code_host.argtypes = [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp, vp, i32]
     L.sc2_rans_encode_host.argtypes = [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp, i32]
     L.sc2_rans_decode_host.argtypes = [vp, vp, i64, vp, vp, vp, i64, i32, i64, vp, vp, i32]
     for name in ABI_SYMBOLS:
@@ -1652,8 +1655,54 @@ class HostRansTables(object):
             _lib.sc2_rans_host_tables_destroy(h)
 
 
-def _host_threads(n_streams):
-    return max(1, min(int(n_streams), len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 32))
+def host_cores():
+    """CPUs this process may run on (the affinity mask: a rank bound to its GPU's NUMA node counts that node's cores)."""
+    return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+
+
+def _host_threads(n_streams, cap=32):
+    return max(1, min(int(n_streams), host_cores(), cap))
+
+
+def rans_code_host(tables, symbols, index_div, dec_out, out_stride=None, threads=None, scratch=None):
+    """HOST encode + decode of every row of `symbols` (int32 numpy [n_streams, n_sym], implicit indexes) in one library call;
+    the decoded symbols land in `dec_out` (int32 numpy of the same shape, e.g. a view of a pinned tensor).
+    -> (buf uint8 [n_streams, stride], offset, nbytes, status) numpy; status = encode | decode bits.
+    `scratch`: a dict that keeps the 37 MB of byte rows between calls -- a fresh allocation is first touched by the coder's threads,
+    one page fault per 4 KB under the process's memory-map lock: 3 - 4 ms of a 5 ms call on a 128-core host."""
+    import numpy as np
+    n_streams, n_sym = symbols.shape
+    assert symbols.dtype == np.int32 and symbols.flags['C_CONTIGUOUS'] and dec_out.dtype == np.int32 and dec_out.flags['C_CONTIGUOUS']
+    assert dec_out.shape == symbols.shape
+    if out_stride is None:
+        out_stride = 2 * n_sym + 64
+    out_stride = (int(out_stride) + 3) // 4 * 4
+    key = ('rows', n_streams, out_stride)
+    if scratch is not None and key in scratch:
+        buf = scratch[key]
+    else:
+        buf = np.empty((n_streams, out_stride // 4), dtype=np.uint32)
+        if scratch is not None:
+            buf.fill(0)         # (touch the pages once, here)
+            scratch[key] = buf
+    off = np.empty((n_streams,), dtype=np.int32)
+    nb = np.empty((n_streams,), dtype=np.int32)
+    st = np.empty((n_streams,), dtype=np.int32)
+    n_thr = int(threads) if threads else _host_threads(n_streams, cap=64)
+    _check(lib().sc2_rans_code_host(tables._h, symbols.ctypes.data, None, int(index_div), n_streams, n_sym, buf.ctypes.data, out_stride,
+                                    off.ctypes.data, nb.ctypes.data, dec_out.ctypes.data, st.ctypes.data, n_thr), 'rans_code_host')
+    return buf.view(np.uint8).reshape(n_streams, out_stride), off, nb, st
+
+
+def copy_kernel(dst, src):
+    """dst.copy_(src) by a KERNEL on the current stream; either tensor may live in device memory or in pinned host memory (which the
+    device maps): same dtype, contiguous, a multiple of 16 bytes.  Never blocks the caller (sc2_copy_bytes)."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
+    for t in (dst, src):
+        assert t.is_cuda or t.is_pinned(), 'copy_kernel: device or pinned host tensors only'
+    n = dst.numel() * dst.element_size()
+    _check(lib().sc2_copy_bytes(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), n, _stream()), 'copy_bytes')
+    return dst
 
 
 def clock_probe(n_workgroups=16, n_samples=64, period_us=20.0, stream=None):

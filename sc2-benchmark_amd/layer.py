@@ -501,6 +501,16 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         dec = eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw)
         return dec, nb, st
 
+    def stage_coder_host_begin(self, sym, hw_shape, staging, slot=0):
+        """the device-to-host copy of `stage_coder_host`, enqueued on the current stream: -> its end event"""
+        return self.entropy_bottleneck.host_copy_begin(sym, staging, slot)
+
+    def stage_coder_host(self, sym, hw_shape, dequantized=False, staging=None, slot=0, d2h_event=None):
+        """`stage_coder` on the host thread pool (EntropyBottleneck.code_on_host): the same streams, coded by CPU cores -- a batch of
+        256 serial chains takes 64 cores ~3 ms where the device's lanes take ~21 ms, which is what the FIRST batches of a pipelined
+        run wait for (pipeline.StagePipeline `host_steps`).  Returns what `stage_coder(..., dequantized=True)` returns."""
+        return self.entropy_bottleneck.code_on_host(sym, hw_shape, staging=staging, slot=slot, d2h_event=d2h_event)
+
     def stage_decode(self, decoded, hw_shape):
         """what `stage_coder` returned -> the dequantised latent, bf16 NHWC (the input of `synthesis_nhwc`)."""
         if decoded.dtype == torch.bfloat16:

@@ -17,6 +17,19 @@ also cost the MFMA kernels beside them less), and each back
 decoder + head stream.  Nothing is skipped and nothing is reordered inside a batch: every batch's byte streams are really
 produced and really decoded, outputs are bit-identical to the unpipelined forward (tests/test_gpu_pipeline.py).
 
+Round 6, `host_steps`: the FIRST back stage of a run can start no earlier than one coder latency after the first front stage --
+~21 ms for a 224 x 224 latent on the device, whatever the batch, during which the run has only front stages to do (a 20-batch run
+spent a tenth of its time there).  A model that offers `stage_coder_host` (the FP bottleneck: the same streams coded by the
+library's host coder on the CPU cores, ~3 ms for 256 streams on 64 cores plus the two PCIe crossings) gets its first `host_steps`
+batches coded there, one batch per group, by one worker thread -- device-to-host copy enqueued at once on a stream of its own, host
+encode + decode, host-to-device copy and the dequantising launch on a second stream -- while the device coder takes every later
+batch with the usual 1, 2, 4, ... ramp.  Every stream is still really encoded and really decoded, to the same bytes.  Default
+(`host_steps=None`): as many batches as the host finishes before the device's first group would (`auto_host_steps`), 0 on a
+machine with few cores.  Measured (bs 256, 20 batches, 256 host threads): the first logits leave at ~11 ms instead of ~26, the
+run's throughput does not change (47.7 k vs 48.6 k images/s, profiles/r06l_host_steps_ab.txt) -- the window in which the all-device
+run has "nothing to do" is where its front stages run alone, at full efficiency; overlapped with back stages and coder launches the
+same work costs ~10 % more (tools/concurrency_probe.py).  So the default policy (`hip.host_policy.pipeline_host_steps`) is OFF.
+
 `payload` / `decoded` are a tensor or a tuple of tensors whose leading dimension is the batch: the pipeline concatenates
 the payloads of a group along it and hands each batch its slice of what the coder returns.  A model whose `stage_front`
 accepts `out=` (SplittableResNet on the FP bottleneck: the last encoder conv writes the coder's int32 symbols itself) gets a
@@ -57,7 +70,8 @@ class StagePipeline(object):
     """
 
     def __init__(self, model, device, coder_group=8, coder_streams=4, max_inflight=24, ramp=True, lag=0,
-                 front_priority=0, back_priority=0, coder_priority=0, back_streams=1, coder_kwargs=None, share_buffer=True):
+                 front_priority=0, back_priority=0, coder_priority=0, back_streams=1, coder_kwargs=None, share_buffer=True,
+                 host_steps=None):
         self.model = model
         self.device = torch.device(device)
         self.G = max(1, int(coder_group))
@@ -71,23 +85,79 @@ class StagePipeline(object):
         self.coder_kwargs = dict(getattr(model, 'stage_coder_kwargs', {}) if coder_kwargs is None else coder_kwargs)
         self.share_buffer = bool(share_buffer) and bool(getattr(model, 'stage_front_takes_out', False))
         self._payload_shapes = {}     # input shape [C, H, W] -> (columns, dtype) of the single-tensor payload (learned per shape)
+        # leading batches whose coder stage runs on the host thread pool (None: auto_host_steps at run time; 0: none)
+        self.host_steps = host_steps if bool(getattr(model, 'has_stage_coder_host', False)) else 0
+        # ONE more stream for those batches: their device-to-host copies (enqueued as the front stages finish), then the
+        # host-to-device copies + dequantising launches (enqueued by the worker, later).  One, not two: the runtime maps streams
+        # onto GPU_MAX_HW_QUEUES hardware queues, and two streams that share a queue wait for each other -- a back stage once sat
+        # 20 ms behind a coder launch of another stream that way (profiles/r06j_timeline_alias.txt)
+        self.host_in = self.host_out = torch.cuda.Stream(device=self.device)
+        self._host_staging = {}       # pinned buffers per slot (kept between runs)
+        self._worker = None
 
     # ---- plan ------------------------------------------------------------------------------------------------------ #
-    def group_plan(self, n_steps):
-        """sizes of the coder groups of a run of n_steps batches: 1, 2, 4, ... up to G, then G."""
-        sizes, g = [], (1 if self.ramp else self.G)
+    @staticmethod
+    def auto_host_steps(n_streams, cores=None, device_first_ms=21.0, pcie_ms_per_batch=3.0, ms_per_stream=0.65, limit=3):
+        """How many leading batches the host coder should take: batch k leaves the host path at about
+        front + copy out + (k + 1) x max(copy, host coding) + copy back; it is worth taking while that is earlier than the device
+        coder's first result (one device coder latency).  Host coding of a batch = streams / cores x ~0.65 ms (encode + decode of
+        72 600 symbols on one core, csrc/rans_host.cpp); a PCIe crossing of a 256-stream batch ~3 ms.  Few cores (a rank of an
+        8-GPU job bound to its NUMA node's share, a small VM): 0."""
+        from . import hip
+        cores = hip.host_cores() if cores is None else cores
+        if cores < 8 or n_streams <= 0:
+            return 0
+        scale = n_streams / 256.0
+        code = n_streams / float(min(cores, 128)) * ms_per_stream
+        per_batch = max(code, pcie_ms_per_batch * scale)
+        n = 0
+        while n < limit and 0.5 + pcie_ms_per_batch * scale * 2 + code + n * per_batch < device_first_ms - 2.0:
+            n += 1
+        return n
+
+    def group_plan(self, n_steps, host_steps=0):
+        """sizes of the coder groups of a run of n_steps batches: `host_steps` single batches for the host coder, then 1, 2, 4, ...
+        up to G, then G."""
+        sizes = [1] * min(int(host_steps), n_steps)
+        g = (1 if self.ramp else self.G)
         while sum(sizes) < n_steps:
             sizes.append(min(g, self.G, n_steps - sum(sizes)))
             g *= 2
         return sizes
 
+    def resolve_host_steps(self, x):
+        if self.host_steps is not None:
+            return int(self.host_steps)
+        from . import hip
+        if not hip.host_policy.pipeline_host_steps:
+            return 0
+        return self.auto_host_steps(int(x.shape[0]))
+
+    def _host_job(self, payload, meta, slot, d2h_event, timeline, step):
+        """worker thread: host coding of one batch; device work on `host_out`.  -> (decoded, nbytes, status, done event)"""
+        torch.cuda.set_device(self.device)
+        with torch.no_grad(), torch.cuda.stream(self.host_out):
+            tl0 = None
+            if timeline is not None:
+                tl0 = torch.cuda.Event(enable_timing=True)
+                tl0.record(self.host_out)
+            decoded, nb, st = self.model.stage_coder_host(payload, meta, staging=self._host_staging, slot=slot, d2h_event=d2h_event)
+            ev = torch.cuda.Event()
+            ev.record(self.host_out)
+            if tl0 is not None:
+                tl1 = torch.cuda.Event(enable_timing=True)
+                tl1.record(self.host_out)
+                timeline.append(('coder-host', step, tl0, tl1))
+        return decoded, nb, st, ev
+
     def describe(self):
         return {'hip_streams': {'encoder': 1, 'decoder+head': len(self.back_streams), 'range_coder': len(self.coder_streams)},
-                'steps_per_coder_launch': self.G, 'max_inflight_steps': self.max_inflight, 'ramp': self.ramp}
+                'steps_per_coder_launch': self.G, 'max_inflight_steps': self.max_inflight, 'ramp': self.ramp,
+                'host_coder_steps': self.__dict__.get('_last_host_steps', self.host_steps)}
 
     def synchronize(self):
         self.front_stream.synchronize()
-        for s in self.back_streams + self.coder_streams:
+        for s in self.back_streams + self.coder_streams + [self.host_out]:
             s.synchronize()
         torch.cuda.synchronize(self.device)
 
@@ -118,7 +188,8 @@ class StagePipeline(object):
             e.record(stream)
             return e
 
-        plan = self.group_plan(n_steps) if n_steps is not None else None
+        host_steps = [None]           # resolved at the first batch (auto: from its stream count)
+        plan = [None]
         pending = {}          # step -> (decoded slice, nbytes slice, status slice, meta, coder-done event, whole tensors)
         back_done = {}        # step -> event at the end of its back stage
         group = []            # (step, payload, meta, front-done event, written into the shared buffer?)
@@ -128,11 +199,33 @@ class StagePipeline(object):
         state = {'issued_back': 0}
 
         def group_target():
-            if plan is not None:
-                return plan[launches[0]] if launches[0] < len(plan) else self.G
-            return min(self.G, 1 << launches[0]) if self.ramp else self.G      # (open-ended input: same ramp, no tail trim)
+            if launches[0] < host_steps[0]:
+                return 1
+            if plan[0] is not None:
+                return plan[0][launches[0]] if launches[0] < len(plan[0]) else self.G
+            return min(self.G, 1 << (launches[0] - host_steps[0])) if self.ramp else self.G      # (open-ended input: same ramp, no tail trim)
+
+        def flush_host():
+            # one batch for the host coder: its device-to-host copy goes out now, the worker thread does the rest
+            slot = launches[0]
+            launches[0] += 1
+            step, g_pl, meta, g_ev, _ = group[0]
+            with torch.cuda.stream(self.host_in):
+                self.host_in.wait_event(g_ev)
+                for t in _as_tuple(g_pl):
+                    t.record_stream(self.host_in)
+                    t.record_stream(self.host_out)
+                d2h = model.stage_coder_host_begin(g_pl, meta, self._host_staging, slot)
+            if self._worker is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix='sc2-host-coder')
+            pending[step] = ('host', self._worker.submit(self._host_job, g_pl, meta, slot, d2h, timeline, step), meta)
+            gbuf[0] = None
+            group.clear()
 
         def flush():
+            if launches[0] < host_steps[0] and len(group) == 1:
+                return flush_host()
             cs = self.coder_streams[launches[0] % len(self.coder_streams)]
             launches[0] += 1
             with torch.cuda.stream(cs):
@@ -171,6 +264,16 @@ class StagePipeline(object):
         def issue_backs(i, last):
             while state['issued_back'] in pending and (i - state['issued_back'] >= self.lag or last):
                 j = state['issued_back']
+                if isinstance(pending[j][0], str):
+                    # a batch at the host coder: its back stage is issued once the worker has enqueued its result (checked again
+                    # after every front stage; the run's end waits for it -- by then there is nothing else to issue)
+                    fut = pending[j][1]
+                    if not (last or fut.done()):
+                        return
+                    dec, nb, st, ev2 = fut.result()
+                    if statuses is not None:
+                        statuses.append(st)
+                    pending[j] = (dec, nb, st, pending[j][2], ev2, _as_tuple(dec))
                 state['issued_back'] += 1
                 dec, nb, st, meta, ev2, whole = pending.pop(j)
                 bs = self.back_streams[j % len(self.back_streams)]
@@ -209,7 +312,13 @@ class StagePipeline(object):
                     x.record_stream(self.front_stream)
                 elif i >= n_steps:
                     break
+                if host_steps[0] is None:
+                    host_steps[0] = self.resolve_host_steps(x)
+                    self.__dict__['_last_host_steps'] = host_steps[0]
+                    plan[0] = self.group_plan(n_steps, host_steps[0]) if n_steps is not None else None
                 last = (n_steps is not None and i == n_steps - 1)
+                if i - self.max_inflight >= state['issued_back']:
+                    issue_backs(i, True)      # the run-ahead bound holds for batches at the host coder too: wait for their worker
                 with torch.cuda.stream(self.front_stream):
                     if i - self.max_inflight in back_done:
                         # bound the run-ahead of the host and of the encoder stream: memory in flight, latency per batch,
@@ -224,7 +333,7 @@ class StagePipeline(object):
                     g_size = group_target()
                     out = None
                     known = self._payload_shapes.get(tuple(x.shape[1:]))     # (columns, dtype) of the payload of such an input
-                    if self.share_buffer and g_size > 1 and known is not None:
+                    if self.share_buffer and g_size > 1 and known is not None:  # (host batches are groups of one: no shared buffer)
                         if gbuf[0] is None and not group:      # one buffer per coder group; front stage k writes row block k
                             gbuf[0] = torch.empty((g_size * n, known[0]), dtype=known[1], device=dev)
                             gshape[0] = (n, known[0])
@@ -248,6 +357,7 @@ class StagePipeline(object):
                 group.append((i, payload, meta, ev, out is not None))
                 if len(group) >= group_target() or last:
                     flush()
+
                 # back stages of every batch whose coder launch has been issued, oldest first: they wait for the coder's
                 # event on their own stream, the encoder stream runs ahead
                 issue_backs(i, last)
@@ -266,7 +376,13 @@ class StagePipeline(object):
             with torch.cuda.stream(self.front_stream):
                 payload, meta = self.model.stage_front(x)
             self.front_stream.synchronize()
-            for li, g in enumerate(self.group_plan(n_steps)):
+            hs = self.resolve_host_steps(x)
+            for li, g in enumerate(self.group_plan(n_steps, hs)):
+                if li < hs:
+                    # the host path's resources: pinned staging of this slot, the worker thread, the host tables
+                    with torch.cuda.stream(self.host_out):
+                        self.model.stage_coder_host(payload, meta, staging=self._host_staging, slot=li)
+                    continue
                 cs = self.coder_streams[li % len(self.coder_streams)]
                 with torch.cuda.stream(cs):
                     pl = payload if g == 1 else _like(payload, [torch.cat([t] * g) for t in _as_tuple(payload)])

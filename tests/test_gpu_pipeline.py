@@ -156,3 +156,52 @@ def test_evaluate_pipeline_keeps_each_batch_with_its_own_labels(S, dev, bench_mo
         r = evaluation.evaluate(model, torch.utils.data.DataLoader(ds, batch_size=bs), dev, pipeline=True, pipeline_kwargs=kw)
         assert r['samples'] == len(x) and r['pipeline'].startswith('stage pipeline')
         assert abs(r['acc1'] - expect) < 1e-9, (r['acc1'], expect, kw)
+
+
+def test_host_coder_steps_give_the_same_outputs(S, dev, bench_mod):
+    """StagePipeline(host_steps=k): the first k batches are coded by the host coder on a worker thread, the rest by the device
+    coder -- logits, byte counts and statuses equal those of the all-device pipeline bit for bit, in batch order, for a run
+    shorter than, equal to and longer than k; auto_host_steps stays within its limits."""
+    from sc2bench_amd.pipeline import StagePipeline
+    model = bench_mod.build_model(dev)
+    xs = [bench_mod.synthetic_batch(16, dev, seed=20 + i) for i in range(7)]
+
+    def run(host_steps, n):
+        pipe = StagePipeline(model, dev, coder_group=4, coder_streams=2, host_steps=host_steps)
+        outs, rec = [], {}
+        pipe.run(iter(xs[:n]), on_output=lambda j, o, nb, st: outs.append((j, o.clone(), nb.clone(), st.clone())), record=rec)
+        pipe.synchronize()
+        return outs, rec, pipe
+
+    for n in (1, 3, 7):
+        ref, _, _ = run(0, n)
+        got, rec, pipe = run(3, n)
+        assert [j for j, _, _, _ in got] == list(range(n)) and pipe.describe()['host_coder_steps'] == 3
+        for (_, a, na, sa), (_, b, nb_, sb) in zip(ref, got):
+            assert torch.equal(a, b) and torch.equal(na, nb_) and int(sb.max().item()) == 0 and int(sa.max().item()) == 0
+        assert len(rec['statuses']) >= min(n, 3)
+    # a tensor input with n_steps (the bench's form) and the warm-up pass
+    pipe = StagePipeline(model, dev, coder_group=4, coder_streams=2, host_steps=2)
+    pipe.warm(xs[0], 6)
+    last = []
+    pipe.run(xs[0], n_steps=6, on_output=lambda j, o, nb, st: last.append(o))
+    pipe.synchronize()
+    assert len(last) == 6 and all(torch.equal(o, last[0]) for o in last)
+    assert pipe.group_plan(6, 2) == [1, 1, 1, 2, 1]
+    assert StagePipeline.auto_host_steps(256, cores=64) in (1, 2, 3) and StagePipeline.auto_host_steps(256, cores=4) == 0
+    assert StagePipeline.auto_host_steps(2048, cores=64) == 0
+
+
+def test_evaluate_with_host_coder_steps_under_inference_mode(S, dev, bench_mod):
+    """evaluation.evaluate() runs under torch.inference_mode; the pipeline's host-coder worker thread does not (the mode is per
+    thread) and writes the pinned staging buffers: they must not be inference tensors.  Same accuracy as the device-only pipeline."""
+    from sc2bench_amd import evaluation
+    model = bench_mod.build_model(dev)
+    x = bench_mod.synthetic_batch(22, torch.device('cpu'), seed=2)
+    with torch.no_grad():
+        labels = model(x.to(dev)).float().argmax(1).cpu()
+    labels[::3] = (labels[::3] + 1) % 1000
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(x, labels), batch_size=8)
+    a = evaluation.evaluate(model, loader, dev, pipeline_kwargs={'coder_group': 2, 'coder_streams': 2, 'host_steps': 0})
+    b = evaluation.evaluate(model, loader, dev, pipeline_kwargs={'coder_group': 2, 'coder_streams': 2, 'host_steps': 2})
+    assert a['pipeline'].startswith('stage pipeline') and abs(a['acc1'] - b['acc1']) < 1e-9 and a['samples'] == b['samples'] == 22

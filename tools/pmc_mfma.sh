@@ -3,7 +3,7 @@
 #   bash tools/pmc_mfma.sh <tag>     ->  gpurun_out/<tag>/mfma_busy.txt  (copy to profiles/)
 TAG=${1:-r02_pmc}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=10
 export TMPDIR=/tmp; ROOT=$(pwd)
 i=0
 for G in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA" "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU"; do

@@ -4,7 +4,7 @@
 TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-export GPU_MAX_HW_QUEUES=8   # bench.py sets it in-process, but under rocprofv3 the runtime may initialise before Python runs
+export GPU_MAX_HW_QUEUES=10   # bench.py sets it in-process, but under rocprofv3 the runtime may initialise before Python runs
 export TMPDIR=/tmp
 ROOT=$(pwd)
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the bottleneck forward of a --workload step (PMC, separate passes).  Usage on the GPU box: bash tools/pmc_workload.sh <tag> <workload> [...]
 TAG=${1:-r04w}; shift
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=10
 export TMPDIR=/tmp
 ROOT=$(pwd)
 for W in "$@"; do

@@ -5,7 +5,7 @@ TAG=${1:-r06f}; shift
 STEPS=${@:-tests smoke bench20 bench100 ktimes head clock prof workloads train pmc}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-export GPU_MAX_HW_QUEUES=8 TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=10 TMPDIR=/tmp
 ROOT=$(pwd)
 t0=$(date +%s)
 brief() { python - "$1" "$2" <<'PY'
