@@ -37,7 +37,7 @@ extern "C" {
 #define SC2_ERR_INTERNAL (-7)
 
 /* ABI version: bumped on any signature change. */
-#define SC2_ABI_VERSION 50
+#define SC2_ABI_VERSION 51
 int sc2_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------ */
@@ -664,11 +664,6 @@ int sc2_rans_decode_host(const sc2_rans_host_tables *tables, const uint8_t *in, 
  * every period_ticks ticks of the constant 100 MHz counter.  clock = delta s_memtime / delta s_memrealtime x 100 MHz between two
  * samples of one workgroup (MI355X_MICROARCH.md, DVFS item 6).  Launch it on a stream of its own BEFORE the kernels under study
  * so that it is resident while they run (tools/clock_probe.py). */
-/* dst[0 .. n_bytes) = src[0 .. n_bytes) by a kernel on `stream`: either side may be device memory or pinned, device-mapped host
- * memory (hipHostMalloc); 16-byte aligned, n_bytes % 16 == 0.  Used where a copy must never block its caller (pipeline.py
- * host-coder batches): a launch is asynchronous whatever else is in flight. */
-int sc2_copy_bytes(void *dst, const void *src, long long n_bytes, void *stream);
-
 int sc2_clock_probe(unsigned long long *samples, int n_workgroups, int n_samples, unsigned period_ticks, void *stream);
 
 #ifdef __cplusplus

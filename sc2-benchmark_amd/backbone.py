@@ -408,9 +408,6 @@ class SplittableResNet(UpdatableBackbone):
         """the coder stage on the host thread pool, where the bottleneck offers it (FP bottleneck: `stage_coder_host`)"""
         return self.bottleneck_layer.stage_coder_host(payload, meta, **kwargs)
 
-    def stage_coder_host_begin(self, payload, meta, staging, slot=0):
-        return self.bottleneck_layer.stage_coder_host_begin(payload, meta, staging, slot)
-
     @property
     def has_stage_coder_host(self):
         return type(self.bottleneck_layer) is FPBasedResNetBottleneck

@@ -705,7 +705,7 @@ class EntropyBottleneck(_HostTablesMixin, nn.Module):
         if bufs[2] is not None:
             bufs[2].synchronize()          # the previous batch's host-to-device copy out of this slot
         t2 = time.perf_counter()
-        hip.copy_kernel(bufs[0], sym.contiguous())      # (a kernel, not the copy engine: its submission never blocks this thread)
+        bufs[0].copy_(sym, non_blocking=True)      # (copy engine; may block THIS thread for milliseconds while another transfer is in flight)
         t3 = time.perf_counter()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(sym.device))
@@ -741,17 +741,14 @@ class EntropyBottleneck(_HostTablesMixin, nn.Module):
             _, _, nb, st = hip.rans_code_host(tables, sym_h.numpy(), hw, dec_h.numpy(), out_stride=hip.rans_max_bytes(n_sym))
         t2 = time.perf_counter()
         sym_back = torch.empty((N, n_sym), dtype=torch.int32, device=dev)
-        hip.copy_kernel(sym_back, dec_h)
+        sym_back.copy_(dec_h, non_blocking=True)
         # byte counts and status words ride in pinned memory too: a pageable copy would block this thread until the 74 MB in front
         # of it on the stream have crossed
         small = bufs[3]
         small_np = small.numpy()
         small_np[0], small_np[1] = nb, st
         small_d = torch.empty((2, N), dtype=torch.int32, device=dev)
-        if (2 * N * 4) % 16 == 0:
-            hip.copy_kernel(small_d, small)
-        else:
-            small_d.copy_(small, non_blocking=True)
+        small_d.copy_(small, non_blocking=True)
         bufs[2] = torch.cuda.Event()
         bufs[2].record(stream)
         y_hat = self.dequantize_device(sym_back, tuple(size))[1]

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     'sc2_pmf_to_quantized_cdf',
     'sc2_rans_max_bytes', 'sc2_rans_workspace_bytes', 'sc2_rans_encode_batch', 'sc2_rans_decode_batch', 'sc2_rans_decode_dequantize_batch', 'sc2_rans_decode_dequantize_batch_ev',
     'sc2_mse_partial_len', 'sc2_mse_sum_bf16', 'sc2_mse_grad_bf16', 'sc2_relu_bwd_bf16', 'sc2_relu_bwd_mse_bf16',
-    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_host_rcp_div', 'sc2_rans_code_host', 'sc2_clock_probe', 'sc2_copy_bytes', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
+    'sc2_rans_host_tables_create', 'sc2_rans_host_tables_destroy', 'sc2_rans_host_rcp_div', 'sc2_rans_code_host', 'sc2_clock_probe', 'sc2_rans_encode_host', 'sc2_rans_decode_host',
 ]
 
 
@@ -100,7 +100,7 @@ class HostPolicy(object):
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
     head_ds_side_stream = False  # the head's downsample layers on a side stream beside conv1 -> conv2 of their block: measured SLOWER (head 2.60 -> 2.67 ms, bench - 1 %: profiles/r06e_ab_ds_side.txt)
-    pipeline_host_steps = False  # StagePipeline(host_steps=None): True = the first batches of a run are coded by the host thread pool while the device coder's first group is under way (first logits of a run after ~11 ms instead of ~26); throughput of a 20-batch run unchanged (profiles/r06l_host_steps_ab.txt), so off by default
+    pipeline_host_steps = True   # StagePipeline(host_steps=None): the first batches of a run (up to 3, by the host's core count) are coded by the host thread pool while the device coder's first group is under way, their back stages gated behind the opening burst of front stages: + 1.5 - 2.5 % at K = 20 and K = 100 (profiles/r06o_host_steps_ab.txt); False: device coder only
     eval_graphs = True         # the updated eval forward of SplittableResNet at small batch replays HIP graphs of its device halves (graphs.py)
     eval_graph_max_batch = 1   # ... for batches up to this size (the reference evaluates at batch size 1)
 
@@ -261,7 +261,6 @@ def lib():
     L.sc2_rans_host_rcp_div.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
     L.sc2_rans_host_rcp_div.restype = ctypes.c_uint64
     L.sc2_clock_probe.argtypes = [vp, i32, i32, ctypes.c_uint32, vp]
-    L.sc2_copy_bytes.argtypes = [vp, vp, ctypes.c_longlong, vp]
     L.sc2_rans_code_host.argtypes = [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp, vp, i32]
     L.sc2_rans_encode_host.argtypes = [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp, i32]
     L.sc2_rans_decode_host.argtypes = [vp, vp, i64, vp, vp, vp, i64, i32, i64, vp, vp, i32]
@@ -1656,8 +1655,15 @@ class HostRansTables(object):
 
 
 def host_cores():
-    """CPUs this process may run on (the affinity mask: a rank bound to its GPU's NUMA node counts that node's cores)."""
-    return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    """CPUs this process may reasonably load: its affinity mask, and -- under a launcher that starts several ranks on the node
+    (LOCAL_WORLD_SIZE) -- no more than its share of the machine (eight ranks each spawning a coder thread per CPU of the node would
+    oversubscribe it eightfold)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))
+    except ValueError:
+        ranks = 1
+    return max(1, min(n, (os.cpu_count() or n) // ranks))
 
 
 def _host_threads(n_streams, cap=32):
@@ -1692,17 +1698,6 @@ def rans_code_host(tables, symbols, index_div, dec_out, out_stride=None, threads
     _check(lib().sc2_rans_code_host(tables._h, symbols.ctypes.data, None, int(index_div), n_streams, n_sym, buf.ctypes.data, out_stride,
                                     off.ctypes.data, nb.ctypes.data, dec_out.ctypes.data, st.ctypes.data, n_thr), 'rans_code_host')
     return buf.view(np.uint8).reshape(n_streams, out_stride), off, nb, st
-
-
-def copy_kernel(dst, src):
-    """dst.copy_(src) by a KERNEL on the current stream; either tensor may live in device memory or in pinned host memory (which the
-    device maps): same dtype, contiguous, a multiple of 16 bytes.  Never blocks the caller (sc2_copy_bytes)."""
-    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
-    for t in (dst, src):
-        assert t.is_cuda or t.is_pinned(), 'copy_kernel: device or pinned host tensors only'
-    n = dst.numel() * dst.element_size()
-    _check(lib().sc2_copy_bytes(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), n, _stream()), 'copy_bytes')
-    return dst
 
 
 def clock_probe(n_workgroups=16, n_samples=64, period_us=20.0, stream=None):

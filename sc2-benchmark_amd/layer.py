@@ -501,10 +501,6 @@ class FPBasedResNetBottleneck(BaseBottleneck):
         dec = eb.decode_symbols_device(buf, off, nb, sym.shape[1], hw)
         return dec, nb, st
 
-    def stage_coder_host_begin(self, sym, hw_shape, staging, slot=0):
-        """the device-to-host copy of `stage_coder_host`, enqueued on the current stream: -> its end event"""
-        return self.entropy_bottleneck.host_copy_begin(sym, staging, slot)
-
     def stage_coder_host(self, sym, hw_shape, dequantized=False, staging=None, slot=0, d2h_event=None):
         """`stage_coder` on the host thread pool (EntropyBottleneck.code_on_host): the same streams, coded by CPU cores -- a batch of
         256 serial chains takes 64 cores ~3 ms where the device's lanes take ~21 ms, which is what the FIRST batches of a pipelined

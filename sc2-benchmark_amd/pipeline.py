@@ -25,10 +25,13 @@ batches coded there, one batch per group, by one worker thread -- device-to-host
 encode + decode, host-to-device copy and the dequantising launch on a second stream -- while the device coder takes every later
 batch with the usual 1, 2, 4, ... ramp.  Every stream is still really encoded and really decoded, to the same bytes.  Default
 (`host_steps=None`): as many batches as the host finishes before the device's first group would (`auto_host_steps`), 0 on a
-machine with few cores.  Measured (bs 256, 20 batches, 256 host threads): the first logits leave at ~11 ms instead of ~26, the
-run's throughput does not change (47.7 k vs 48.6 k images/s, profiles/r06l_host_steps_ab.txt) -- the window in which the all-device
-run has "nothing to do" is where its front stages run alone, at full efficiency; overlapped with back stages and coder launches the
-same work costs ~10 % more (tools/concurrency_probe.py).  So the default policy (`hip.host_policy.pipeline_host_steps`) is OFF.
+machine with few cores.  What it took to make that a gain (bs 256, 20 batches, a 2 x 64-core host; profiles/r06l - r06o):
+(i) every transfer of those batches is issued by the WORKER thread through the copy engine -- submitted from the thread that issues
+the front stages, the second transfer blocked it for 5.7 ms; done by a kernel instead, the copies slowed the front stages beside
+them 2 - 3x; (ii) the first early back stage waits, on the device, for the last front stage of the run's opening burst: front stages
+that run alone take 0.55 ms, overlapped with a back stage both stretch 2 - 3x, and a run that started its back stages inside the
+burst finished no earlier than the all-device run (whose "idle" first 21 ms are where its front stages run alone).  With both:
+48.6 -> 49.6 k images/s at K = 20, 51.3 -> 52.3 k at K = 100 (policy `hip.host_policy.pipeline_host_steps`, on).
 
 `payload` / `decoded` are a tensor or a tuple of tensors whose leading dimension is the batch: the pipeline concatenates
 the payloads of a group along it and hands each batch its slice of what the coder returns.  A model whose `stage_front`
@@ -133,15 +136,16 @@ class StagePipeline(object):
             return 0
         return self.auto_host_steps(int(x.shape[0]))
 
-    def _host_job(self, payload, meta, slot, d2h_event, timeline, step):
+    def _host_job(self, payload, meta, slot, front_event, timeline, step):
         """worker thread: host coding of one batch; device work on `host_out`.  -> (decoded, nbytes, status, done event)"""
         torch.cuda.set_device(self.device)
         with torch.no_grad(), torch.cuda.stream(self.host_out):
+            self.host_out.wait_event(front_event)
             tl0 = None
             if timeline is not None:
                 tl0 = torch.cuda.Event(enable_timing=True)
                 tl0.record(self.host_out)
-            decoded, nb, st = self.model.stage_coder_host(payload, meta, staging=self._host_staging, slot=slot, d2h_event=d2h_event)
+            decoded, nb, st = self.model.stage_coder_host(payload, meta, staging=self._host_staging, slot=slot)
             ev = torch.cuda.Event()
             ev.record(self.host_out)
             if tl0 is not None:
@@ -206,20 +210,19 @@ class StagePipeline(object):
             return min(self.G, 1 << (launches[0] - host_steps[0])) if self.ramp else self.G      # (open-ended input: same ramp, no tail trim)
 
         def flush_host():
-            # one batch for the host coder: its device-to-host copy goes out now, the worker thread does the rest
+            # one batch for the host coder: everything about it -- copy out, host coding, copy back, the dequantising launch --
+            # is the worker thread's (a copy-engine transfer submitted while another is in flight can block its caller for
+            # milliseconds on this runtime, profiles/r06k_copy_call_stall.txt: that caller must not be the thread that issues the
+            # front stages; and copies by a KERNEL slowed the front stages beside them 2 - 3x, profiles/r06n_host_steps_ab.txt)
             slot = launches[0]
             launches[0] += 1
             step, g_pl, meta, g_ev, _ = group[0]
-            with torch.cuda.stream(self.host_in):
-                self.host_in.wait_event(g_ev)
-                for t in _as_tuple(g_pl):
-                    t.record_stream(self.host_in)
-                    t.record_stream(self.host_out)
-                d2h = model.stage_coder_host_begin(g_pl, meta, self._host_staging, slot)
+            for t in _as_tuple(g_pl):
+                t.record_stream(self.host_out)
             if self._worker is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix='sc2-host-coder')
-            pending[step] = ('host', self._worker.submit(self._host_job, g_pl, meta, slot, d2h, timeline, step), meta)
+            pending[step] = ('host', self._worker.submit(self._host_job, g_pl, meta, slot, g_ev, timeline, step), meta)
             gbuf[0] = None
             group.clear()
 
@@ -268,9 +271,17 @@ class StagePipeline(object):
                     # a batch at the host coder: its back stage is issued once the worker has enqueued its result (checked again
                     # after every front stage; the run's end waits for it -- by then there is nothing else to issue)
                     fut = pending[j][1]
-                    if not (last or fut.done()):
+                    # ... and, for the first of them, once the run's opening burst of front stages has been issued: that back
+                    # stage waits for the burst's last front stage on the device.  Front stages that run ALONE take 0.55 ms each;
+                    # overlapped with a back stage and coder launches both stretch 2 - 3x, and a run that starts its back stages
+                    # in the middle of the burst finishes no earlier than one that starts them a coder latency later
+                    # (profiles/r06l_host_steps_ab.txt).  Behind the burst the early back stages run beside coder launches only.
+                    burst_last = (min(n_steps, self.max_inflight) if n_steps is not None else self.max_inflight) - 1
+                    if not last and (not fut.done() or (j == 0 and i < burst_last)):
                         return
                     dec, nb, st, ev2 = fut.result()
+                    if j == 0 and state.get('front_ev') is not None:
+                        self.back_streams[0].wait_event(state['front_ev'][1])
                     if statuses is not None:
                         statuses.append(st)
                     pending[j] = (dec, nb, st, pending[j][2], ev2, _as_tuple(dec))
@@ -351,6 +362,7 @@ class StagePipeline(object):
                         timeline.append(('front', i, tl0, tl_event(self.front_stream)))
                     ev = torch.cuda.Event()
                     ev.record(self.front_stream)
+                    state['front_ev'] = (i, ev)
                 if group and (group[0][2] != meta or _as_tuple(group[0][1])[0].shape[0] != n):
                     flush()          # another latent shape (or a ragged last batch): this batch opens a new group
                     issue_backs(i, False)

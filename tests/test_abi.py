@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(S):
     for name in declared:
         assert hasattr(lib, name), 'libsc2amd.so does not export {}'.format(name)
     assert sorted(S.hip.ABI_SYMBOLS) == declared
-    assert lib.sc2_abi_version() == 50
+    assert lib.sc2_abi_version() == 51
 
 
 def test_missing_library_fails_loudly(S, monkeypatch):
