@@ -22,6 +22,10 @@
 //   Per-symbol explicit `indexes` (no common row per position) use the generic kernels at the bottom.
 #include "sc2_common.h"
 
+#ifndef SC2_RANS_PRIO
+#define SC2_RANS_PRIO 3   // wave priority of the serial coder kernels (A/B: -DSC2_RANS_PRIO=0, tools/build_variant.sh)
+#endif
+
 namespace {
 
 constexpr int kPrecision = 16;
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(64) void rans_enc_serial_kernel(const RansArgs a, c
     EncEntry *ltab = reinterpret_cast<EncEntry *>(smem + (kStage + 1) * 64 * 4);
     const int n_entries = a.n_cdfs * a.cdf_stride;
     const int lane = threadIdx.x;
-    __builtin_amdgcn_s_setprio(3);   // a lone serial wave must not queue behind co-resident MFMA workgroups
+    __builtin_amdgcn_s_setprio(SC2_RANS_PRIO);   // a lone serial wave must not queue behind co-resident MFMA workgroups
     if (LDS_TABLES) {
         for (int i = lane; i < n_entries; i += 64) ltab[i] = gtab[i];
         __syncthreads();
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(64) void rans_dec_lut_kernel(const RansArgs a) {
     const int s = blk * 64 + lane;
     const bool active = s < a.n_streams;
     const int sc = active ? s : a.n_streams - 1;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(SC2_RANS_PRIO);
     const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)sc * a.stride + a.io_offset[sc]);
     const int n_words = a.io_nbytes[sc] / 4;
     uint32_t *wsb = a.ws + (long long)blk * a.n_sym * 64 + lane;
@@ -552,7 +556,7 @@ __global__ __launch_bounds__(64) void rans_dec_lut8_kernel(const RansArgs a, con
     const int s = blk * 64 + lane;
     const bool active = s < a.n_streams;
     const int sc = active ? s : a.n_streams - 1;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(SC2_RANS_PRIO);
     const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)sc * a.stride + a.io_offset[sc]);
     const int n_words = a.io_nbytes[sc] / 4;
     uint32_t *wsb = a.ws + (long long)blk * a.n_sym * 64 + lane;
@@ -923,7 +927,7 @@ __global__ __launch_bounds__(64) void rans_dec_ragged_kernel(const RansArgs a) {
     __syncthreads();
     const int s = blockIdx.x * 64 + lane;
     if (s >= a.n_streams) return;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(SC2_RANS_PRIO);
     // indexes arrive transposed to [position][lane] in the workspace; each slot is overwritten IN PLACE by the decoded
     // value of its position (an index is fetched >= 8 positions before its slot is written), and the finish pass
     // transposes the workspace into symbols_out
@@ -1077,7 +1081,7 @@ __global__ __launch_bounds__(64 * WAVES) void rans_dec_ragged2_kernel(const Rans
     if (blk * 64 >= a.n_streams) return;         // (a whole wave, past the last block; no workgroup barrier follows)
     const bool active = s < a.n_streams;
     const int sc = active ? s : a.n_streams - 1;
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(SC2_RANS_PRIO);
     uint32_t *out = a.ws + (long long)blk * a.n_sym * 64 + (s & 63);   // (the workspace has all 64 columns of every block)
     const uint32_t *idxp = out;
     const uint32_t *w = reinterpret_cast<const uint32_t *>(a.buf + (long long)sc * a.stride + a.io_offset[sc]);
