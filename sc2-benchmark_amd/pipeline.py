@@ -276,11 +276,13 @@ class StagePipeline(object):
                     # overlapped with a back stage and coder launches both stretch 2 - 3x, and a run that starts its back stages
                     # in the middle of the burst finishes no earlier than one that starts them a coder latency later
                     # (profiles/r06l_host_steps_ab.txt).  Behind the burst the early back stages run beside coder launches only.
-                    burst_last = (min(n_steps, self.max_inflight) if n_steps is not None else self.max_inflight) - 1
+                    # (a run of known length only: behind a data loader the "burst" is as slow as the loader, and a first result held
+                    #  back for 24 batches of JPEG decoding would be a stall, not a saving)
+                    burst_last = min(n_steps, self.max_inflight) - 1 if n_steps is not None else 0
                     if not last and (not fut.done() or (j == 0 and i < burst_last)):
                         return
                     dec, nb, st, ev2 = fut.result()
-                    if j == 0 and state.get('front_ev') is not None:
+                    if j == 0 and n_steps is not None and state.get('front_ev') is not None:
                         self.back_streams[0].wait_event(state['front_ev'][1])
                     if statuses is not None:
                         statuses.append(st)
