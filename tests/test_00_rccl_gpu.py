@@ -59,6 +59,12 @@ def test_rccl_world1_inference_and_training_as_child_processes():
     assert line['config']['process_group'].startswith('nccl'), line['config']['process_group']
     assert line['config']['ranks_reduced'] == 1, 'the device all-reduce of 1 over the RCCL group must count this rank'
     assert line['scaling'] == 'weak' and line['config']['sharding'] == 'images, no collective'
+    # every rank's own bpp and stream digest, gathered as device tensors on the backend: here one rank, whose
+    # row must be the line's own figures
+    assert line['config']['ranks_gathered'] == 1 and len(line['per_rank']) == 1
+    row = line['per_rank'][0]
+    assert row['rank'] == 0 and row['rans_status'] == 0 and abs(row['bpp'] - line['bpp']) < 1e-9
+    assert row['bitstream_sha256_first8'] == line['bitstream_sha256_first8'] and len(row['bitstream_sha256_first8']) == 64
     # ---- training step: broadcast, hook-launched bucket all-reduces, scalar reductions, all on RCCL with HIP tensors
     tr = _torchrun_bench(['--mode', 'train', '--steps', '2', '--warmup', '1', '--bs', '32'],
                          env_extra={'SC2_DP_WORLD1_COLLECTIVES': '1'})
