@@ -31,7 +31,7 @@ for k, v in sorted(table.items(), key=lambda kv: -kv[1]['hbm_bytes']):
 json.dump(table, open(os.path.join(out, 'traffic_raw.json'), 'w'), indent=1)
 
 # bench.py tags of the bottleneck launches -> HBM-side bytes per launch at the profiled batch (profiles/traffic.json)
-TAGS = {'enc.conv0+enc.gdn1': ('conv0_gdn96_kernel<false, false, true>',), 'enc.conv2+enc.gdn3': ('conv2_gdn48_kernel',),
+TAGS = {'enc.conv0+enc.gdn1': ('conv0_gdn96_kernel<false, false, true',), 'enc.conv2+enc.gdn3': ('conv2_gdn48_kernel',),
         'enc.conv4': ('conv2x2_c48_kernel',), 'dec.conv0+dec.igdn1': ('conv2x2_gdn512_kernel',),
         'dec.conv2+dec.igdn3': ('conv2x2_win_kernel<Geo2<55, 0', ', 1, true'), 'dec.conv4': ('conv2x2_win_kernel<Geo2<56, 1', ', 0, true')}
 tags = {}
