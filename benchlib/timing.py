@@ -26,7 +26,9 @@ def make_pipeline(args, model, dev):
                            front_priority=args.front_priority, back_priority=args.back_priority, coder_priority=args.coder_priority,
                            back_streams=max(1, args.split_mfma), share_buffer=not args.cat_symbols,
                            coder_kwargs={'dequantized': False} if args.unfused_dequantize else None,
-                           host_steps=None if getattr(args, 'host_steps', -1) < 0 else args.host_steps)
+                           # (auto only behind a warm-up: the host path's pinned staging -- 450 MB of cudaHostAlloc -- must not be
+                           #  allocated inside a timed region that starts cold)
+                           host_steps=(None if getattr(args, 'warmup', 1) > 0 else 0) if getattr(args, 'host_steps', -1) < 0 else args.host_steps)
 
 
 def timed_pipeline_run(pipe, x, steps, select, distributed, timeline=False):

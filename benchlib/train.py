@@ -82,7 +82,7 @@ def train_bench(args, dev, rank, world, distributed, emit=True):
         elapsed = t.item()
     assert torch.isfinite(loss)
     # metric reduction as evaluation does it (sum of [count, total] over ranks), on the backend's device
-    g_images, g_loss = dp.all_reduce_sum_scalars([float(args.bs * args.steps), float(loss) * args.bs])
+    g_images, g_loss = dp.all_reduce_sum_scalars([float(args.bs * args.steps), float(loss.detach()) * args.bs])
     line = None
     if rank == 0:
         line = ({

@@ -1,0 +1,11 @@
+export TMPDIR=/tmp
+run() { echo "== $*"; timeout 300 python bench.py --no-cpu-baseline --no-bs1 --no-secondary "$@" 2>/dev/null | python tools/bench_brief.py /dev/stdin | head -1 | cut -c1-60; }
+for rep in 1 2 3; do
+run --steps 100
+run --steps 100 --max-inflight 40
+run --steps 100 --inflight 6
+run --steps 100 --inflight 6 --max-inflight 40
+run --steps 100 --max-inflight 64
+run --steps 20
+run --steps 20 --inflight 6 --max-inflight 40
+done
