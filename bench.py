@@ -600,6 +600,9 @@ def main():
                                    'frac_of_mfma_peak': fwd_gflop * args.bs / fwd_ms / PEAK_BF16_TFLOPS,
                                    # SURVEY 8(d)'s numerator only: the rider's FLOPs left out, its time left IN (a lower bound)
                                    'frac_8p3418': BOTTLENECK_GFLOP_PER_IMG * args.bs / fwd_ms / PEAK_BF16_TFLOPS,
+                                   # ... and with the rider's time taken out too, by its stand-alone cost (an estimate: inside the
+                                   # pipeline the launch that carries it stretches like every other)
+                                   'frac_8p3418_rider_time_removed': BOTTLENECK_GFLOP_PER_IMG * args.bs / max(1e-9, fwd_ms - max(0.0, solo_ms - plain_ms)) / PEAK_BF16_TFLOPS,
                                    'head_2_0_rider': {'gflop_per_image': fwd_gflop - BOTTLENECK_GFLOP_PER_IMG,
                                                       'stand_alone_ms': solo_ms - plain_ms,
                                                       'what': 'layer2.0 conv1 + downsample of the task head, carried by the decoder\'s last launch '
