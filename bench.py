@@ -299,6 +299,7 @@ def main():
     ap.add_argument('--ramp', type=int, default=1, help='1: the first coder groups of a run hold 1, 2, 4, ... steps')
     ap.add_argument('--coder-group', type=int, default=0, help='steps whose symbols share one range-coder launch; 0 = the workload\'s default')
     ap.add_argument('--host-steps', type=int, default=-1, help='leading steps whose streams the HOST coder codes (sc2bench_amd/pipeline.py); -1 = auto from the core count, 0 = none')
+    ap.add_argument('--numa-bind', choices=['auto', 'on', 'off'], default='auto', help="bind this process to the CPUs of its GPU's NUMA node before the first HIP call (auto: when there is more than one rank)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bs1', action='store_true', help='skip the bs-1 evaluation-mode row')
     ap.add_argument('--no-secondary', action='store_true', help='skip the `secondary` rows (the other workloads + the training step, a few steps each, after the timed region)')
@@ -338,7 +339,7 @@ def main():
             raise SystemExit('bench.py: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
         return dry_run(args, world, rank, local_rank)
     numa = None
-    if world > 1:       # (before the first HIP call; one rank alone keeps the whole machine)
+    if args.numa_bind == 'on' or (args.numa_bind == 'auto' and world > 1):       # (before the first HIP call; by default one rank alone keeps the whole machine)
         sys.path.insert(0, ROOT)
         from sc2bench_amd.dataparallel import bind_rank_to_gpu_numa
         numa = bind_rank_to_gpu_numa(local_rank)
@@ -581,7 +582,7 @@ def main():
                        'sharding': 'images, no collective',
                        'process_group': '{} ({} rank{})'.format(dist.get_backend(), world, '' if world == 1 else 's') if distributed else 'none',
                        'ranks_reduced': n_ranks,
-                       'numa_binding': numa if world > 1 else 'none (one rank)'},
+                       'numa_binding': numa if (world > 1 or args.numa_bind == 'on') else 'none (one rank)'},
             'bpp': bpp, 'bytes_per_image': bytes_per_img,
             'bytes_per_image_min_mean_max': [nb_f.min().item(), bytes_per_img, nb_f.max().item()],
             'bitstream_sha256_first8': sha256_of(dev_streams),

@@ -58,12 +58,29 @@ def _parse_cpulist(text):
     return cpus
 
 
-def gpu_numa_node(local_rank, sysfs_root='/sys'):
+def _visible_index(local_rank):
+    visible = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')
+    if visible:
+        ids = [v.strip() for v in visible.split(',') if v.strip()]
+        if local_rank < len(ids) and ids[local_rank].isdigit():
+            return int(ids[local_rank])
+    return local_rank
+
+
+def _numa_of_pci(sysfs_root, bdf):
+    with open(os.path.join(sysfs_root, 'bus', 'pci', 'devices', bdf, 'numa_node')) as f:
+        node = int(f.read().strip())
+    return node if node >= 0 else None
+
+
+def gpu_numa_node(local_rank, sysfs_root='/sys', dev_root='/dev'):
     """NUMA node of the `local_rank`-th GPU, read from sysfs -- NO HIP call (a rank binds itself before it touches the device).
-    GPUs are the KFD topology nodes with SIMDs, in node order = the runtime's device order unless HIP_VISIBLE_DEVICES /
-    ROCR_VISIBLE_DEVICES re-map it (then the n-th VISIBLE index is looked up); a node's `location_id` and `domain` give its PCI
-    address, whose `numa_node` file is the answer.  -> int >= 0, or None (unknown, one node, not a bare-metal topology)."""
-    import os
+    Two sources, the first that answers: (i) the KFD topology: GPUs are its nodes with SIMDs, in node order = the runtime's device
+    order, `location_id` + `domain` = the PCI address (readable by root only on some kernels: on this pool's boxes it is not);
+    (ii) the render nodes this process can open (`/dev/dri/renderD*`: in a container only the GPUs it was given), each resolved
+    through `/sys/class/drm/<node>/device` to its PCI address, AMD devices only, in PCI order.  HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES re-map the index.  -> int >= 0, or None (unknown, one node, not a bare-metal topology)."""
+    index = _visible_index(local_rank)
     try:
         nodes_dir = os.path.join(sysfs_root, 'class', 'kfd', 'kfd', 'topology', 'nodes')
         gpus = []
@@ -75,31 +92,38 @@ def gpu_numa_node(local_rank, sysfs_root='/sys'):
                     props[k] = v
             if int(props.get('simd_count', '0')) > 0:
                 gpus.append(props)
-        visible = os.environ.get('HIP_VISIBLE_DEVICES') or os.environ.get('ROCR_VISIBLE_DEVICES')
-        index = local_rank
-        if visible:
-            ids = [v.strip() for v in visible.split(',') if v.strip()]
-            if local_rank < len(ids) and ids[local_rank].isdigit():
-                index = int(ids[local_rank])
-        if not 0 <= index < len(gpus):
-            return None
-        loc, dom = int(gpus[index]['location_id']), int(gpus[index].get('domain', '0'))
-        bdf = '{:04x}:{:02x}:{:02x}.{:x}'.format(dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 0x7)
-        with open(os.path.join(sysfs_root, 'bus', 'pci', 'devices', bdf, 'numa_node')) as f:
-            node = int(f.read().strip())
-        return node if node >= 0 else None
+        if 0 <= index < len(gpus):
+            loc, dom = int(gpus[index]['location_id']), int(gpus[index].get('domain', '0'))
+            return _numa_of_pci(sysfs_root, '{:04x}:{:02x}:{:02x}.{:x}'.format(dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 0x7))
     except (OSError, ValueError, KeyError):
-        return None
+        pass
+    try:
+        bdfs = []
+        for name in os.listdir(os.path.join(dev_root, 'dri')):
+            if not name.startswith('renderD'):
+                continue
+            link = os.path.join(sysfs_root, 'class', 'drm', name, 'device')
+            bdf = os.path.basename(os.path.realpath(link))
+            with open(os.path.join(sysfs_root, 'bus', 'pci', 'devices', bdf, 'vendor')) as f:
+                if f.read().strip().lower() != '0x1002':
+                    continue
+            bdfs.append(bdf)
+        bdfs.sort()
+        if 0 <= index < len(bdfs):
+            return _numa_of_pci(sysfs_root, bdfs[index])
+    except (OSError, ValueError):
+        pass
+    return None
 
 
-def bind_rank_to_gpu_numa(local_rank, sysfs_root='/sys'):
+def bind_rank_to_gpu_numa(local_rank, sysfs_root='/sys', dev_root='/dev'):
     """Pins the calling process (every thread it starts later inherits the mask: the host coder's pool, the data-loader workers, the
     launch thread) to the CPUs of the NUMA node its GPU hangs off.  Eight ranks on a two-socket node otherwise share whatever
     cores the scheduler picks, and a rank whose launch thread sits on the far socket pays the inter-socket hop on every
     doorbell and every pinned-buffer copy.  Call BEFORE the first HIP call.  -> {'numa_node', 'cpus'} or None (nothing bound:
     unknown topology, a single node, or an affinity mask the launcher already narrowed to other CPUs -- that one is respected)."""
     import os
-    node = gpu_numa_node(local_rank, sysfs_root)
+    node = gpu_numa_node(local_rank, sysfs_root, dev_root)
     if node is None or not hasattr(os, 'sched_setaffinity'):
         return None
     try:

@@ -374,4 +374,19 @@ def test_rank_binds_to_its_gpus_numa_node(tmp_path, monkeypatch):
         assert got == {'numa_node': 1, 'cpus': len(set(cpu_sets[1]))} and os.sched_getaffinity(0) == set(cpu_sets[1])
     finally:
         os.sched_setaffinity(0, before)
-    assert dp.bind_rank_to_gpu_numa(0, str(tmp_path / 'nowhere')) is None and os.sched_getaffinity(0) == before
+    assert dp.bind_rank_to_gpu_numa(0, str(tmp_path / 'nowhere'), str(tmp_path / 'nodev')) is None and os.sched_getaffinity(0) == before
+    # second source: the KFD properties are unreadable (as for a non-root user on the pool's boxes) -- the render nodes this process
+    # can open, resolved to PCI addresses: a container that was given GPUs 2 and 3 only
+    import shutil
+    shutil.rmtree(str(nodes))
+    dri = tmp_path / 'dev' / 'dri'
+    dri.mkdir(parents=True)
+    for g in (2, 3):
+        bus = 0x10 * (g + 1)
+        (dri / 'renderD{}'.format(128 + g)).write_text('')
+        link = root / 'class' / 'drm' / 'renderD{}'.format(128 + g)
+        link.mkdir(parents=True)
+        (root / 'bus' / 'pci' / 'devices' / '0000:{:02x}:00.0'.format(bus) / 'vendor').write_text('0x1002\n')
+        os.symlink(str(root / 'bus' / 'pci' / 'devices' / '0000:{:02x}:00.0'.format(bus)), str(link / 'device'))
+    (dri / 'card0').write_text('')
+    assert [dp.gpu_numa_node(r, str(root), str(tmp_path / 'dev')) for r in range(3)] == [1, 1, None]
