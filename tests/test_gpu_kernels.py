@@ -1591,3 +1591,18 @@ def test_bn_train_kernels(S, dev, N, H, C, relu, res):
     assert rel(dg, g.grad) < 1e-4 and rel(db, b.grad) < 1e-4
     if dz is not None:
         assert torch.equal(dz.float(), rf.grad.permute(0, 2, 3, 1).to(torch.bfloat16).float())
+
+
+def test_clock_probe_reads_a_plausible_shader_clock(S, dev):
+    """The diagnostic probe (csrc/diag.hip, tools/clock_probe.py): every probe wave reports a monotone s_memtime / s_memrealtime
+    series, an XCC id below 8, and delta s_memtime / delta s_memrealtime x 100 MHz lands between 0.5 and 3 GHz on an idle chip."""
+    s = S.hip.clock_probe(16, 32, 20.0)
+    torch.cuda.synchronize()
+    s = s.cpu()
+    assert s.shape == (16, 32, 3) and int(s[:, :, 2].max()) < 8 and int(s[:, :, 2].min()) >= 0
+    for w in range(16):
+        t, r = s[w, :, 0], s[w, :, 1]
+        assert bool((t[1:] > t[:-1]).all()) and bool((r[1:] > r[:-1]).all())
+        mhz = 100.0 * float(t[-1] - t[2]) / float(r[-1] - r[2])
+        assert 500.0 < mhz < 3000.0, mhz
+        assert 0.9 * 29 * 2000 <= float(r[-1] - r[2]) <= 3.0 * 29 * 2000      # 29 periods of 20 us at 100 MHz

@@ -204,3 +204,26 @@ def test_run_wise_paths_match_oracle(S, seed, index_div, n_sym):
     assert int(st3[0]) & 4
     _, st4 = S.hip.rans_decode_host(tables, s3, too_long.shape[1], index_div=index_div)
     assert int(st4[0]) & 4
+
+
+def test_code_host_is_encode_then_decode(S):
+    """sc2_rans_code_host (both passes per stream in one call: the pipeline's host batches) == sc2_rans_encode_host followed by
+    sc2_rans_decode_host: same byte rows, offsets, sizes, decoded symbols and status bits, with and without kept scratch rows,
+    including a row too small for its stream (bit 0) and a saturated symbol (bit 1)."""
+    rng = np.random.RandomState(21)
+    cdf, sizes, offs = _random_tables(rng, 6, lo=5, hi=30)
+    tables = S.hip.HostRansTables(cdf, sizes, offs)
+    hw = 37
+    sym = np.ascontiguousarray(np.round(rng.randn(9, 6 * hw) * 4).astype(np.int32))
+    sym[2, 11] = 2 ** 31 - 1
+    strings, st_enc = S.hip.rans_encode_host(tables, sym, index_div=hw)
+    dec_ref, st_dec = S.hip.rans_decode_host(tables, strings, sym.shape[1], index_div=hw)
+    scratch = {}
+    for _ in range(2):      # second call: the kept rows
+        dec = np.empty_like(sym)
+        buf, off, nb, st = S.hip.rans_code_host(tables, sym, hw, dec, scratch=scratch, threads=3)
+        assert [buf[i, int(off[i]):int(off[i]) + int(nb[i])].tobytes() for i in range(9)] == strings
+        assert np.array_equal(dec, dec_ref) and np.array_equal(st, st_enc | st_dec) and int(st[2]) == 2
+    dec = np.empty_like(sym)
+    _, _, _, st_small = S.hip.rans_code_host(tables, sym, hw, dec, out_stride=32)
+    assert all(int(v) & 1 for v in st_small)
