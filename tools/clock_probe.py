@@ -72,8 +72,16 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--f32', action='store_true')
     ap.add_argument('--head', action='store_true')
+    ap.add_argument('--zero-data', action='store_true', help='all-zero activations (torch.rand / randn patched to zeros while the inputs are built): the clock the chip holds when the operands do not toggle -- the power test of the sustained-rate reading')
     args = ap.parse_args()
+    if args.zero_data:
+        _rand, _randn = torch.rand, torch.randn
+        torch.rand = lambda *a, **k: torch.zeros(*a, **{q: v for q, v in k.items() if q != 'generator'})
+        torch.randn = lambda *a, **k: torch.zeros(*a, **{q: v for q, v in k.items() if q != 'generator'})
     rows = k_times.build_rows(args.bs, args.only, args.head, args.f32)
+    if args.zero_data:
+        torch.rand, torch.randn = _rand, _randn
+        print('ALL-ZERO activations')
     # idle chip: the probe alone
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
