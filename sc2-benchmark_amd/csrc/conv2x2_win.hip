@@ -212,6 +212,9 @@ constexpr int VM_STEP = 2 * (PF - 1) + 2;
 #ifndef SC2_W2_DBG_OUT
 #define SC2_W2_DBG_OUT 0
 #endif
+#ifndef SC2_W2_ORDER
+#define SC2_W2_ORDER 1   // 1: operand-stationary MFMA order inside a k-step (default since round 6); 0: b0 / b1 alternate on every MFMA (A/B)
+#endif
 #ifndef SC2_W2_CHAIN
 #define SC2_W2_CHAIN 1   // 0: every k-step reads its own first seven fragments (A/B)
 #endif
@@ -234,6 +237,38 @@ __device__ __forceinline__ void mma_step(f32x4_t (&acc)[14][2], uint32_t a_base,
         wait_vm<NVM>();
     }
     const bf16x8_t bf0 = __builtin_bit_cast(bf16x8_t, b0), bf1 = __builtin_bit_cast(bf16x8_t, b1);
+#if SC2_W2_ORDER
+    // Operand-stationary order (round 6): seven MFMAs in a row share ONE weight fragment -- tiles 0 .. 6 with b0, the
+    // same tiles with b1 (their quads are reloaded with tiles 7 .. 13 behind that second pass), then tiles 7 .. 13 likewise -- instead of
+    // alternating b0 / b1 on every MFMA.  Same products into the same accumulators in the same k order: bit-identical results.  These
+    // launches are POWER-limited on real data (tools/clock_probe.py --zero-data: 1.85 -> 2.33 GHz at the same pipe share on zeros), and an
+    // operand that does not change between MFMAs toggles less: dec.conv2 + IGDN256 0.715 -> 0.706 ms, dec.conv2 0.644 -> 0.639, alternating
+    // A/B on one box (profiles/r06y_mfma_order_ab.txt); dec.conv4 and the tail form unchanged.
+#define SC2_W2_PASS_A(i, NWAIT)                                                                 \
+    {                                                                                           \
+        wait_lgkm<NWAIT>(av[(i) % 7]);                                                          \
+        const u32x4_t m = ABS ? av[(i) % 7] & 0x7FFF7FFFu : av[(i) % 7];                        \
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, __builtin_bit_cast(bf16x8_t, m), acc[i][0], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+#define SC2_W2_PASS_B(i)                                                                        \
+    {                                                                                           \
+        const u32x4_t m = ABS ? av[(i) % 7] & 0x7FFF7FFFu : av[(i) % 7];                        \
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, __builtin_bit_cast(bf16x8_t, m), acc[i][1], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if constexpr ((i) + 7 < 14) av[(i) % 7] = lds_read16_imm<OFF + ((i) + 7 < 14 ? (i) + 7 : 0) * 256>(a_base); \
+        else if constexpr (OFF_NEXT != NO_NEXT)                                                 \
+            av[(i) % 7] = lds_read16_imm<(OFF_NEXT != NO_NEXT ? OFF_NEXT : 0) + ((i) >= 7 ? (i) - 7 : 0) * 256>(a_base_next); \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+    // (waits: nothing is read during a pass A, so tile i's wait leaves the 6 - i / 13 - i younger reads of its half outstanding)
+    SC2_W2_PASS_A(0, 6) SC2_W2_PASS_A(1, 5) SC2_W2_PASS_A(2, 4) SC2_W2_PASS_A(3, 3) SC2_W2_PASS_A(4, 2) SC2_W2_PASS_A(5, 1) SC2_W2_PASS_A(6, 0)
+    SC2_W2_PASS_B(0) SC2_W2_PASS_B(1) SC2_W2_PASS_B(2) SC2_W2_PASS_B(3) SC2_W2_PASS_B(4) SC2_W2_PASS_B(5) SC2_W2_PASS_B(6)
+    SC2_W2_PASS_A(7, 6) SC2_W2_PASS_A(8, 5) SC2_W2_PASS_A(9, 4) SC2_W2_PASS_A(10, 3) SC2_W2_PASS_A(11, 2) SC2_W2_PASS_A(12, 1) SC2_W2_PASS_A(13, 0)
+    SC2_W2_PASS_B(7) SC2_W2_PASS_B(8) SC2_W2_PASS_B(9) SC2_W2_PASS_B(10) SC2_W2_PASS_B(11) SC2_W2_PASS_B(12) SC2_W2_PASS_B(13)
+#undef SC2_W2_PASS_A
+#undef SC2_W2_PASS_B
+#else
 #define SC2_W2_MMA(i, NWAIT)                                                                    \
     {                                                                                           \
         wait_lgkm<(OFF_NEXT != NO_NEXT) ? 6 : NWAIT>(av[(i) % 7]);                              \
@@ -249,6 +284,7 @@ __device__ __forceinline__ void mma_step(f32x4_t (&acc)[14][2], uint32_t a_base,
     }
     SC2_W2_MMA_SEQ
 #undef SC2_W2_MMA
+#endif
 }
 #undef SC2_W2_MMA_SEQ
 

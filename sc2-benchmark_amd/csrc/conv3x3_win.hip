@@ -165,9 +165,27 @@ struct GeoS2 {
 
 constexpr int PF = 3;   // weight fragments are fetched this many k-steps ahead (18 k-steps per loop trip: 18 % PF == 0)
 
-// MFMAs of one k-step, row tile I onwards: each waits for its own fragment read only (MT - 1 - I younger reads may be in flight)
-template <class G, int DBG, int I>
+#ifndef SC2_W3_ORDER
+#define SC2_W3_ORDER 0   // 1: operand-stationary MFMA order inside a k-step (every row tile with b0, then every row tile with b1): measured 1.3 % SLOWER here (the five 3x3 shapes 0.3255 - 0.3303 -> 0.3298 - 0.3387 ms, profiles/r06y_mfma_order_ab.txt) although it gains 1 % in conv2x2_win; 0 (default): b0 / b1 alternate
+#endif
+// MFMAs of one k-step, row tile I onwards: each waits for its own fragment read only (MT - 1 - I younger reads may be in flight).
+// Round 6 A/B (SC2_W3_ORDER = 1, off): one weight fragment for MT MFMAs in a row, then the other -- the same products into the same accumulators in
+// the same k order (bit-identical); an operand that does not change between MFMAs toggles less, and these launches are power-limited
+// (conv2x2_win.hip, mma_step; tools/clock_probe.py --zero-data).
+template <class G, int DBG, int I, int PASS = 0>
 __device__ __forceinline__ void mma_chain(f32x4_t (&acc)[G::MT][2], u32x4_t (&av)[G::MT], const bf16x8_t &bf0, const bf16x8_t &bf1) {
+#if SC2_W3_ORDER
+    if constexpr (I < G::MT) {
+        if constexpr (PASS == 0 && !(DBG & 4)) wait_lgkm<G::MT - 1 - I>(av[I]);
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[I]);
+        if constexpr (PASS == 0) acc[I][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf0, af, acc[I][0], 0, 0, 0);
+        else acc[I][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf1, af, acc[I][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chain<G, DBG, I + 1, PASS>(acc, av, bf0, bf1);
+    } else if constexpr (PASS == 0) {
+        mma_chain<G, DBG, 0, 1>(acc, av, bf0, bf1);
+    }
+#else
     if constexpr (I < G::MT) {
         if constexpr (!(DBG & 4)) wait_lgkm<G::MT - 1 - I>(av[I]);
         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[I]);
@@ -176,6 +194,7 @@ __device__ __forceinline__ void mma_chain(f32x4_t (&acc)[G::MT][2], u32x4_t (&av
         __builtin_amdgcn_sched_barrier(0);
         mma_chain<G, DBG, I + 1>(acc, av, bf0, bf1);
     }
+#endif
 }
 
 // NVM >= 0: b0 / b1 come from asm loads (wload16): wait until at most NVM younger vector-memory operations are outstanding
