@@ -72,13 +72,16 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--f32', action='store_true')
     ap.add_argument('--head', action='store_true')
+    ap.add_argument('--head-layers', action='store_true', help='one representative launch per layer kind of the task head instead of the bottleneck rows')
     ap.add_argument('--zero-data', action='store_true', help='all-zero activations (torch.rand / randn patched to zeros while the inputs are built): the clock the chip holds when the operands do not toggle -- the power test of the sustained-rate reading')
     args = ap.parse_args()
     if args.zero_data:
         _rand, _randn = torch.rand, torch.randn
         torch.rand = lambda *a, **k: torch.zeros(*a, **{q: v for q, v in k.items() if q != 'generator'})
         torch.randn = lambda *a, **k: torch.zeros(*a, **{q: v for q, v in k.items() if q != 'generator'})
-    rows = k_times.build_rows(args.bs, args.only, args.head, args.f32)
+    rows = k_times.head_layer_rows(args.bs) if args.head_layers else k_times.build_rows(args.bs, args.only, args.head, args.f32)
+    if args.head_layers and args.only:
+        rows = [r for r in rows if args.only in r[0]]
     if args.zero_data:
         torch.rand, torch.randn = _rand, _randn
         print('ALL-ZERO activations')

@@ -29,6 +29,40 @@ def timeit(fn, iters=20, warmup=3):
     return t0.elapsed_time(t1) / iters
 
 
+def head_layer_rows(bs=256):
+    """-> [(name, fn, flops)]: one representative launch per layer KIND of the task head (layer2..4 at bs x 224 x 224), each on an input of
+    its own shape: conv1 / conv2 / conv3 (+ residual) of a middle block, the first block's strided layers."""
+    import bench as B
+    dev = torch.device('cuda:0')
+    full = B.build_model(dev)
+    hd = full._hip_head_for_eval()
+    rows = []
+
+    def t(n, h, w, c):
+        return torch.randn(n, h, w, c, device=dev).to(torch.bfloat16)
+
+    def add(name, fn, flops):
+        rows.append((name, fn, flops))
+    N = bs
+    # block indices: layer2 = 0..3, layer3 = 4..9, layer4 = 10..12
+    for li, bi, hw, cmid in (('2', 1, 28, 128), ('3', 5, 14, 256), ('4', 11, 7, 512)):
+        c1, c2, c3, ds = hd.blocks[bi]
+        x_in, x_mid = t(N, hw, hw, 4 * cmid), t(N, hw, hw, cmid)
+        m = N * hw * hw
+        add('head.{}.x.c1 (1x1 {}->{})'.format(li, 4 * cmid, cmid), lambda c1=c1, x=x_in: c1(x, hip.EPI_BIAS_RELU), 2.0 * m * 4 * cmid * cmid)
+        add('head.{}.x.c2 (3x3 {})'.format(li, cmid), lambda c2=c2, x=x_mid: c2(x, hip.EPI_BIAS_RELU), 2.0 * m * 9 * cmid * cmid)
+        add('head.{}.x.c3 (1x1 {}->{} + res)'.format(li, cmid, 4 * cmid), lambda c3=c3, x=x_mid, r=x_in: c3(x, hip.EPI_BIAS_ADD_RELU, ep_x=r), 2.0 * m * 4 * cmid * cmid)
+    for li, bi, hw, cin, cmid in (('3', 4, 28, 512, 256), ('4', 10, 14, 1024, 512)):
+        c1, c2, c3, ds = hd.blocks[bi]
+        x_in = t(N, hw, hw, cin)
+        x_mid = t(N, hw, hw, cmid)
+        mo = N * (hw // 2) * (hw // 2)
+        add('head.{}.0.ds (1x1 s2 {}->{})'.format(li, cin, 4 * cmid), lambda ds=ds, x=x_in: ds(x, hip.EPI_BIAS), 2.0 * mo * cin * 4 * cmid)
+        add('head.{}.0.c1 (1x1 {}->{})'.format(li, cin, cmid), lambda c1=c1, x=x_in: c1(x, hip.EPI_BIAS_RELU), 2.0 * N * hw * hw * cin * cmid)
+        add('head.{}.0.c2 (3x3 s2 {})'.format(li, cmid), lambda c2=c2, x=x_mid: c2(x, hip.EPI_BIAS_RELU), 2.0 * mo * 9 * cmid * cmid)
+    return rows
+
+
 def build_rows(bs=256, only='', head=False, f32=False):
     """-> [(name, fn, flops)]: one callable per launch of the bottleneck forward (and optionally the head / the f32 encoder)."""
     dev = torch.device('cuda:0')
