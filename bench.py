@@ -299,6 +299,7 @@ def main():
     ap.add_argument('--ramp', type=int, default=1, help='1: the first coder groups of a run hold 1, 2, 4, ... steps')
     ap.add_argument('--coder-group', type=int, default=0, help='steps whose symbols share one range-coder launch; 0 = the workload\'s default')
     ap.add_argument('--host-steps', type=int, default=-1, help='leading steps whose streams the HOST coder codes (sc2bench_amd/pipeline.py); -1 = auto from the core count, 0 = none')
+    ap.add_argument('--host-ramp-skip', type=int, default=1, help='A/B: 1 = behind host-coded steps the device coder ramp starts at 2^host_steps steps per launch; 0 = at 1')
     ap.add_argument('--numa-bind', choices=['auto', 'on', 'off'], default='auto', help="bind this process to the CPUs of its GPU's NUMA node before the first HIP call (auto: when there is more than one rank)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bs1', action='store_true', help='skip the bs-1 evaluation-mode row')

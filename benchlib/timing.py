@@ -20,6 +20,12 @@ WORKLOAD_PIPELINE = {   # (coder group G, coder streams) per workload, by measur
 
 def make_pipeline(args, model, dev):
     import sc2bench_amd as S
+    pipe = _make_pipeline(args, model, dev, S)
+    pipe.host_ramp_skip = bool(getattr(args, 'host_ramp_skip', 1))
+    return pipe
+
+
+def _make_pipeline(args, model, dev, S):
     g_default, c_default = WORKLOAD_PIPELINE[args.workload]
     return S.StagePipeline(model, dev, coder_group=args.coder_group or g_default, coder_streams=args.inflight or c_default,
                            max_inflight=args.max_inflight, ramp=bool(args.ramp), lag=max(0, args.lag),

@@ -31,7 +31,11 @@ the front stages, the second transfer blocked it for 5.7 ms; done by a kernel in
 them 2 - 3x; (ii) the first early back stage waits, on the device, for the last front stage of the run's opening burst: front stages
 that run alone take 0.55 ms, overlapped with a back stage both stretch 2 - 3x, and a run that started its back stages inside the
 burst finished no earlier than the all-device run (whose "idle" first 21 ms are where its front stages run alone).  With both:
-48.6 -> 49.6 k images/s at K = 20, 51.3 -> 52.3 k at K = 100 (policy `hip.host_policy.pipeline_host_steps`, on).
+48.6 -> 49.6 k images/s at K = 20, 51.3 -> 52.3 k at K = 100 (policy `hip.host_policy.pipeline_host_steps`, on).  (iii) Behind h host batches
+the back stages are busy for h x 4.3 ms past the burst, so the device coder's first result is not needed one coder latency into the run but
+that much later: its ramp starts at 2^h batches per launch instead of 1 (`host_ramp_skip`), i.e. two or three coder launches fewer alive while
+the early back stages run: 48.9 - 49.4 -> 50.5 - 51.2 k at K = 20 with three host batches, 51.5 - 51.7 k with four (the default on a host
+with >= 64 cores) -- within 2 - 3 % of the 100-batch rate (profiles/r06zz_host_ramp_ab.txt).
 
 `payload` / `decoded` are a tensor or a tuple of tensors whose leading dimension is the batch: the pipeline concatenates
 the payloads of a group along it and hands each batch its slice of what the coder returns.  A model whose `stage_front`
@@ -97,10 +101,11 @@ class StagePipeline(object):
         self.host_in = self.host_out = torch.cuda.Stream(device=self.device)
         self._host_staging = {}       # pinned buffers per slot (kept between runs)
         self._worker = None
+        self.host_ramp_skip = True
 
     # ---- plan ------------------------------------------------------------------------------------------------------ #
     @staticmethod
-    def auto_host_steps(n_streams, cores=None, device_first_ms=21.0, pcie_ms_per_batch=3.0, ms_per_stream=0.65, limit=3):
+    def auto_host_steps(n_streams, cores=None, device_first_ms=21.0, pcie_ms_per_batch=3.0, ms_per_stream=0.65, limit=4):
         """How many leading batches the host coder should take: batch k leaves the host path at about
         front + copy out + (k + 1) x max(copy, host coding) + copy back; it is worth taking while that is earlier than the device
         coder's first result (one device coder latency).  Host coding of a batch = streams / cores x ~0.65 ms (encode + decode of
@@ -123,6 +128,11 @@ class StagePipeline(object):
         up to G, then G."""
         sizes = [1] * min(int(host_steps), n_steps)
         g = (1 if self.ramp else self.G)
+        if self.ramp and host_steps and self.host_ramp_skip:
+            # the host's batches keep the back stages busy for host_steps x ~4.3 ms behind the opening burst: the device coder's
+            # first result is not needed after ONE coder latency but after that much more, so its ramp starts wider (fewer
+            # coder launches alive while the early back stages run)
+            g = min(self.G, 1 << int(host_steps))
         while sum(sizes) < n_steps:
             sizes.append(min(g, self.G, n_steps - sum(sizes)))
             g *= 2
@@ -207,7 +217,8 @@ class StagePipeline(object):
                 return 1
             if plan[0] is not None:
                 return plan[0][launches[0]] if launches[0] < len(plan[0]) else self.G
-            return min(self.G, 1 << (launches[0] - host_steps[0])) if self.ramp else self.G      # (open-ended input: same ramp, no tail trim)
+            shift = (launches[0] - host_steps[0]) + (host_steps[0] if self.host_ramp_skip else 0)
+            return min(self.G, 1 << min(shift, 16)) if self.ramp else self.G      # (open-ended input: same ramp, no tail trim)
 
         def flush_host():
             # one batch for the host coder: everything about it -- copy out, host coding, copy back, the dequantising launch --

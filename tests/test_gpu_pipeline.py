@@ -187,8 +187,8 @@ def test_host_coder_steps_give_the_same_outputs(S, dev, bench_mod):
     pipe.run(xs[0], n_steps=6, on_output=lambda j, o, nb, st: last.append(o))
     pipe.synchronize()
     assert len(last) == 6 and all(torch.equal(o, last[0]) for o in last)
-    assert pipe.group_plan(6, 2) == [1, 1, 1, 2, 1]
-    assert StagePipeline.auto_host_steps(256, cores=64) in (1, 2, 3) and StagePipeline.auto_host_steps(256, cores=4) == 0
+    assert pipe.group_plan(6, 2) == [1, 1, 4] and pipe.group_plan(20, 3) == [1, 1, 1, 4, 4, 4, 4, 1] and pipe.group_plan(5, 0) == [1, 2, 2]
+    assert StagePipeline.auto_host_steps(256, cores=64) in (1, 2, 3, 4) and StagePipeline.auto_host_steps(256, cores=4) == 0
     assert StagePipeline.auto_host_steps(2048, cores=64) == 0
 
 
