@@ -11,7 +11,7 @@ reference's evaluation mode after update() (sc2bench/models/backbone.py:229-233)
 Nothing is skipped: the byte streams are really produced and really decoded; bpp is 8 * bytes / pixels.
 Steps run on the PACKAGE's stage pipeline (sc2bench_amd/pipeline.py, `StagePipeline` -- the scheduler
 `evaluation.evaluate()` uses on a data loader): the encoder stage on one HIP stream, decoder + head on a second, and the
-serial range coder on four coder streams, ONE coder launch per 8 steps (8 x 256 image streams encoded, then decoded, by the
+serial range coder on three coder streams, ONE coder launch per 8 steps (8 x 256 image streams encoded, then decoded, by the
 same two serial kernels: their ~20 ms are per-stream latency, not work, and do not grow with the number of streams).
 Measured: a long-running kernel on another hardware queue slows every MFMA launch of the pipeline, even a single-thread
 spin kernel (6.3 ms per step without the coder, 7.1 ms with spin kernels in its place, 7.9 ms with one coder chain per
@@ -32,7 +32,7 @@ import sys
 import time
 
 # one hardware queue per HIP stream of the software pipeline (the runtime default is 4); must precede HIP init
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '10')   # encoder, decoder + head, 4 coder streams, the host-coder stream, the null stream, spare
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '10')   # encoder, decoder + head, 3 coder streams, the host-coder stream, the null stream, spare
 
 import torch
 import torch.distributed as dist

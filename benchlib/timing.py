@@ -7,7 +7,9 @@ import torch.distributed as dist
 
 
 WORKLOAD_PIPELINE = {   # (coder group G, coder streams) per workload, by measurement
-    'es224': (8, 4),
+    # (3 coder streams, not 4: tools/attic/r06_pipeline_sweep6.sh, 7 alternating runs each -- K = 20 median 52.1 k against 51.1 k images/s, and
+    #  the 4-stream runs dropped to 49 k at K = 100 on one box where the 3-stream runs held 52.5 k)
+    'es224': (8, 3),
     # mean-scale hyperprior: the per-symbol-index decoder holds 120 KB of LDS per workgroup for ~20 ms; 2 048 streams per launch with
     # two 16-stream waves per workgroup (64 CUs held, the library's choice from 1 024 streams up), three launches in flight
     # (tools/attic/mshp_sweep.sh, 40 steps: 35.2 k images/s at G = 2, 36.6 k at G = 8 with one wave per workgroup, 39.3 k with two)

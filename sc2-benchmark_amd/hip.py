@@ -100,7 +100,7 @@ class HostPolicy(object):
     teacher_stream = True      # distillation step: the frozen teacher's forward on a stream of its own beside the student's (+ 2 %)
     host_coder_max_streams = 64   # batches of up to this many streams go to the HOST range coder (bs-1 evaluation)
     head_ds_side_stream = False  # the head's downsample layers on a side stream beside conv1 -> conv2 of their block: measured SLOWER (head 2.60 -> 2.67 ms, bench - 1 %: profiles/r06e_ab_ds_side.txt)
-    pipeline_host_steps = True   # StagePipeline(host_steps=None): the first batches of a run (up to 3, by the host's core count) are coded by the host thread pool while the device coder's first group is under way, their back stages gated behind the opening burst of front stages: + 1.5 - 2.5 % at K = 20 and K = 100 (profiles/r06o_host_steps_ab.txt); False: device coder only
+    pipeline_host_steps = True   # StagePipeline(host_steps=None): the first batches of a run (up to 4, by the host's core count) are coded by the host thread pool while the device coder's first group is under way, their back stages gated behind the opening burst of front stages: + 1.5 - 2.5 % at K = 20 and K = 100 (profiles/r06o_host_steps_ab.txt); False: device coder only
     eval_graphs = True         # the updated eval forward of SplittableResNet at small batch replays HIP graphs of its device halves (graphs.py)
     eval_graph_max_batch = 1   # ... for batches up to this size (the reference evaluates at batch size 1)
 

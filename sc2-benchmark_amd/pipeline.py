@@ -76,7 +76,7 @@ class StagePipeline(object):
                          dequantized=True, the coder's last pass writes the bf16 NHWC latent the decoder reads)
     """
 
-    def __init__(self, model, device, coder_group=8, coder_streams=4, max_inflight=24, ramp=True, lag=0,
+    def __init__(self, model, device, coder_group=8, coder_streams=3, max_inflight=24, ramp=True, lag=0,
                  front_priority=0, back_priority=0, coder_priority=0, back_streams=1, coder_kwargs=None, share_buffer=True,
                  host_steps=None):
         self.model = model

@@ -1,0 +1,13 @@
+export TMPDIR=/tmp
+run() { echo "== $*"; timeout 300 python bench.py --no-cpu-baseline --no-bs1 --no-secondary "$@" 2>/dev/null | python tools/bench_brief.py /dev/stdin | head -1 | cut -c1-50; }
+for rep in 1 2; do
+run --steps 100
+run --steps 100 --inflight 3
+run --steps 100 --inflight 2
+run --steps 100 --coder-group 16 --max-inflight 48 --inflight 3
+run --steps 100 --coder-group 16 --max-inflight 48 --inflight 2
+run --steps 100 --coder-group 12 --max-inflight 36 --inflight 3
+run --steps 100 --coder-group 16 --max-inflight 64 --inflight 3
+run --steps 20 --inflight 3
+run --steps 20
+done
