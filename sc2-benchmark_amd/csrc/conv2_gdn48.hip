@@ -87,17 +87,36 @@ __device__ __forceinline__ void wg_barrier() {   // this wave's LDS writes are d
     __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifndef SC2_ENC2_SCHED
+#define SC2_ENC2_SCHED 1   // 1 (round 6): the slab loop with the patch pieces, the per-unit piece offsets and the next tap's fragment reads placed
+#endif                     //    BESIDE the MFMAs of a tap instead of between two taps; 0: the round-5 loop (A/B: tools/build_variant.sh)
+#ifndef SC2_ENC2_W6
+#define SC2_ENC2_W6 1   // 1 (round 6): the seventh tap's fragments are resident; 0: fetched per slab
+#endif
+#ifndef SC2_ENC2_DBG
+#define SC2_ENC2_DBG 0   // timing experiment only (WRONG results): 8 = every unit fetches the rows of unit 0, i.e. every patch piece hits L2
+#endif
 #ifndef SC2_ENC2_STAMPS
 #define SC2_ENC2_STAMPS 0   // 1: diagnostic build that records s_memtime at the phase boundaries (tools/enc2_stamps.py)
 #endif
 #if SC2_ENC2_STAMPS
-#define STAMP(k)                                                                                                \
+// (mode 2: 40 slots per unit -- the phase boundaries in slots 30 .. 39, slot 10 cb + t inside slab cb: t = 0 first fragments issued, 1 + q behind tap q)
+constexpr int N_STAMP = SC2_ENC2_STAMPS == 2 ? 40 : 12;
+#define STAMP_AT(k)                                                                                             \
     do {                                                                                                        \
         if (p.stamps && lane == 0 && blockIdx.x < 8 && g_units < 16)                                            \
-            p.stamps[((blockIdx.x * 4 + wave) * 16 + g_units) * 12 + (k)] = __builtin_amdgcn_s_memtime();       \
+            p.stamps[((blockIdx.x * 4 + wave) * 16 + g_units) * N_STAMP + (k)] = __builtin_amdgcn_s_memtime();  \
     } while (0)
+#define STAMP(k) STAMP_AT((SC2_ENC2_STAMPS == 2 ? 30 : 0) + (k))
+#if SC2_ENC2_STAMPS == 2
+#define FSTAMP(cb, t) STAMP_AT(10 * (cb) + (t))
 #else
+#define FSTAMP(cb, t)
+#endif
+#else
+constexpr int N_STAMP = 12;
 #define STAMP(k)
+#define FSTAMP(cb, t)
 #endif
 
 struct Enc2Args {
@@ -164,6 +183,16 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) wreg[cb][q][j] = wfrag[((cb * NTAP + tap) * NT + j) * 64];
         }
+    // Round 6: tap 24 is the seventh tap of exactly one (wave, slab) pair per wave -- slab (4 - wave) & 3; wave 1 has none -- so its three fragments
+    // stay in registers too (the 12 the per-slab copy occupied anyway) instead of being fetched in every slab of every unit.  What that removes
+    // is 9 loads per unit and the counted wait in front of the seventh tap: - 1.5 % on the launch (profiles/r06_enc2_taps.txt).
+    constexpr bool W6_RESIDENT = SC2_ENC2_W6 && !SEG;
+    [[maybe_unused]] uint4 w6res[NT];
+    if constexpr (W6_RESIDENT) {
+        const int cb6 = (4 - wave) & 3;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) w6res[j] = wfrag[(((cb6 < NCB ? cb6 : 0) * NTAP + (NTAP - 1)) * NT + j) * 64];
+    }
     if (tid < 384 - 256) reinterpret_cast<uint4 *>(smem + GAM_OFF)[tid + 256] = reinterpret_cast<const uint4 *>(p.g)[tid + 256];
     reinterpret_cast<uint4 *>(smem + GAM_OFF)[tid] = reinterpret_cast<const uint4 *>(p.g)[tid];
     if (tid < COUT) reinterpret_cast<float *>(smem + BETA_OFF)[tid] = p.beta[tid];
@@ -205,9 +234,9 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     auto patch_setup = [&](int unit, int cb, int buf) {
         PatchJob jb;
         jb.live = unit < n_local;
-        const int im_l = jb.live ? unit / p.units_per_img : 0;
+        const int im_l = jb.live && !(SC2_ENC2_DBG & 8) ? unit / p.units_per_img : 0;   // (DBG 8: every unit fetches the rows of unit 0 -- L2 hits)
         const int im = xcd + 8 * im_l;
-        const int u_in = jb.live ? unit - im_l * p.units_per_img : 0;
+        const int u_in = jb.live && !(SC2_ENC2_DBG & 8) ? unit - im_l * p.units_per_img : 0;
         const int rp = SEG ? u_in / p.n_seg : u_in, seg = SEG ? u_in - rp * p.n_seg : 0;
         const int oh0 = rp * 2, ow0 = seg * OW;
         // descriptor base two rows above the image (SEG: and two columns to its left): offsets are then non-negative
@@ -235,6 +264,34 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
 #pragma unroll
         for (int k = 0; k < PIECES_PER_WAVE; ++k) issue_piece(jb, k);
     };
+    constexpr bool SCHED = SC2_ENC2_SCHED && !SEG;   // (the SEG instantiations hold 465 registers in the round-5 loop: this one spills there)
+    // Round 6: what a piece's offset depends on beside the lane -- which patch rows (SEG: and columns) exist -- is a property of the UNIT, the
+    // same for its three slabs.  pvo[k] holds it for the unit whose patch is being fetched: computed once per unit (in slab 1, entry by entry
+    // behind the piece that used the old value, for the unit slab 2 starts fetching), so that issuing a piece is an LDS address and a load.
+    // What the per-tap stamps of the round-5 loop showed (`tools/enc2_stamps.py` on a -DSC2_ENC2_STAMPS=2 build, profiles/r06_enc2_taps.txt):
+    // 515 cycles per tap in slab 1, 650 - 950 in slabs 0 and 2, against 336 of MFMAs.  ~180 of them were the instructions BETWEEN two taps (piece
+    // offsets, piece issue, the wait for the last fragment read): those now ride beside the MFMAs, - 2 % on the launch.  The rest is not
+    // instruction count: slab 1 fetches slab 2 of the same rows, whose lines slabs 0 and 1 have already pulled into L2; slabs 0 and 2 fetch
+    // lines that come from HBM, and a wave whose piece waits for a place in the CU's vector-memory queue issues no MFMA either (one wave per SIMD).
+    // With every row in L2 (`-DSC2_ENC2_DBG=8`: each unit fetches the rows of unit 0) the launch takes 0.227 instead of 0.286 ms on the same box.
+    // Tried against that and NOT kept: an L2 prefetch of the unit after next (one dword per line, direct-to-LDS into a junk area: + 12 %, the
+    // prefetch loads stall the wave just the same and two units ahead do not fit 4 MB of L2 beside 32 workgroups' patches), the pieces of a slab
+    // issued hit / miss alternately or misses last (+ 0.7 %), the first slab's pieces one tap late (+ 1 %), the images walked backwards (the
+    // producer's latest output first: no difference), the encoder in slices of 64 images that fit the memory-side cache (slower).
+    uint32_t pvo[PIECES_PER_WAVE];
+    auto piece_vo = [&](const PatchJob &jb, int k) {
+        const bool real = k < PIECES_PER_WAVE - 1 || wave + NW * k < N_PIECES;
+        const uint32_t pvk = real ? pv[k] : pv[0];
+        const int ih = jb.row0 + (int)(pvk & 7u);
+        bool ok = jb.live & ((unsigned)ih < (unsigned)H);
+        if constexpr (SEG) ok = ok & ((int)pvk >= 0) & ((unsigned)(jb.col0 + (real ? pcol[k] : pcol[0])) < (unsigned)W);
+        return ok ? (pvk & ~15u) : 0x80000000u;
+    };
+    auto issue_piece_vo = [&](const PatchJob &jb, int k) {
+        const bool real = k < PIECES_PER_WAVE - 1 || wave + NW * k < N_PIECES;
+        const int pc = real ? wave + NW * k : wave;
+        buf_load_lds16(jb.rs, (lds_ptr_t)(jb.dst + pc * 1024), pvo[k], jb.soff);
+    };
     // fragment address of (pixel tile i, this lane) at tap offset tap_off / half-column shift d inside patch buffer pb:
     // the pixel part is a constant of the lane (14 registers); per read only the shift's swizzle is rebuilt - the ~10
     // instructions of the full form per read did not fit beside the MFMAs of this wave's only instruction stream
@@ -254,6 +311,11 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     int unit = wg_l;
     int next_unit = unit + wgs_x;
     issue_patch(unit, 0, 0);
+    if constexpr (SCHED) {
+        const PatchJob jb0 = patch_setup(unit, 0, 0);
+#pragma unroll
+        for (int k = 0; k < PIECES_PER_WAVE; ++k) pvo[k] = piece_vo(jb0, k);
+    }
     int g = 0;   // global slab counter of this workgroup: slab g lives in patch buffer g & 1
     [[maybe_unused]] int g_units = 0;
 
@@ -298,13 +360,16 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                 lds_write4(next_slot_addr, claimed + 2u * (unsigned)wgs_x);
                 if (claimed == (unsigned)(n_local - 1)) *my_ctr = 0u;   // this XCD's last claim re-arms its counter
             }
-            // the wave with a seventh tap in this slab fetches that fragment now (L2; older than the patch loads below)
-            const int tap6 = ((wave + cb) & 3) + 4 * NQ;
+            // (SC2_ENC2_W6 = 0, round 5: the wave with a seventh tap in this slab fetches that fragment now -- L2; older than the patch loads below)
+            [[maybe_unused]] const int tap6 = ((wave + cb) & 3) + 4 * NQ;
             // (asm loads, waited for with a counted vmcnt in front of the seventh tap: as compiler-tracked loads their wait was
             //  vmcnt(0) = for the 12 - 13 patch pieces this wave issues behind them, i.e. the wave with seven taps -- the slowest
             //  of the slab already -- also waited for the next slab's or unit's patch)
             u32x4_t w6[NT];
-            {   // (every wave fetches: the three without a seventh tap load tap 24 again and ignore it -- no branch, and the same
+            if constexpr (W6_RESIDENT) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) w6[j] = u32x4_t{w6res[j].x, w6res[j].y, w6res[j].z, w6res[j].w};
+            } else {   // (every wave fetches: the three without a seventh tap load tap 24 again and ignore it -- no branch, and the same
                 //  number of vector-memory operations in flight on every wave)
                 int ln = lane;
                 asm volatile("" : "+v"(ln));   // (address rebuilt here, not carried across the unit)
@@ -329,13 +394,63 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                 for (int i = 0; i < MT; ++i)
                     av[0][i] = lds_read16(frag_addr(pb + (uint32_t)((((kw & 1) * 7 + kh) * J + (kw >> 1)) * 64), i, kw >> 1, fqo));
             }
+            FSTAMP(cb, 0);
+            if constexpr (SCHED) {
+            // (for slab 1: the unit whose first slab the NEXT slab starts fetching -- its piece offsets replace this unit's one by one)
+            [[maybe_unused]] const PatchJob jbn = patch_setup(next_unit, 0, 0);
+#pragma unroll
+            for (int q = 0; q <= NQ; ++q) {
+                const int tap = ((wave + cb) & 3) + 4 * q;
+                // (seventh tap: its fragments are older than the >= 12 patch pieces issued beside taps 0 .. 4.  EVERY wave waits,
+                //  also the three that ignore what they fetched: a load that lands in a register the compiler has given to
+                //  something else is the hazard tools/audit_vmcnt.py --copies looks for; the marker tells it they have landed)
+                if (q == NQ && !W6_RESIDENT) asm volatile("s_waitcnt vmcnt(12) ; wfrag-landed" ::: "memory");
+                if (tap < NTAP) {   // wave-uniform (q < NQ: always)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tap q's fragments
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ntap = tap + 4 < NTAP ? tap + 4 : tap;   // (past the last tap: this tap's fragments again, unused)
+                    const int nkh = ntap / 5, nkw = ntap - nkh * 5;
+                    const int noff = (((nkw & 1) * 7 + nkh) * J + (nkw >> 1)) * 64;
+                    int fqo = fq;
+                    asm volatile("" : "+v"(fqo));
+                    // A tap = seven groups of three MFMAs (48 cycles of the matrix pipe), and everything else the wave has to do rides in
+                    // them, a few instructions per group: the next tap's fragment reads in groups 0 .. 3 (two each: the last one then has
+                    // nine MFMAs to land behind, not two), a patch piece in groups 1, 3, 5 of taps 0 .. 3 (the thirteenth in tap 4), and in
+                    // slab 1 the next unit's offset for that piece one group later.
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        if (q < NQ) {
+                            if (i < 3) {
+                                av[(q + 1) & 1][2 * i] = lds_read16(frag_addr(pb + (uint32_t)noff, 2 * i, nkw >> 1, fqo));
+                                av[(q + 1) & 1][2 * i + 1] = lds_read16(frag_addr(pb + (uint32_t)noff, 2 * i + 1, nkw >> 1, fqo));
+                            } else if (i == 3) {
+                                av[(q + 1) & 1][6] = lds_read16(frag_addr(pb + (uint32_t)noff, 6, nkw >> 1, fqo));
+                            }
+                        }
+                        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, av[q & 1][i]);
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const bf16x8_t wv = q < NQ ? __builtin_bit_cast(bf16x8_t, wreg[cb][q < NQ ? q : 0][j])
+                                                       : __builtin_bit_cast(bf16x8_t, w6[j]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, af, acc[i][j], 0, 0, 0);
+                        }
+                        const int k_issue = q < 4 ? ((i & 1) && i < 6 ? 3 * q + (i >> 1) : -1) : (q == 4 && i == 1 ? 12 : -1);
+                        const int k_next = q < 4 ? (!(i & 1) && i >= 2 ? 3 * q + (i >> 1) - 1 : -1) : (q == 4 && i == 2 ? 12 : -1);
+                        if (k_issue >= 0) issue_piece_vo(jb, k_issue);
+                        if (cb == 1 && k_next >= 0) pvo[k_next] = piece_vo(jbn, k_next);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                FSTAMP(cb, 1 + q);
+            }
+            } else {
 #pragma unroll
             for (int q = 0; q <= NQ; ++q) {
                 const int tap = ((wave + cb) & 3) + 4 * q;
                 // (seventh tap: its fragments are older than the >= 12 patch pieces issued behind taps 0 .. 4.  EVERY wave waits,
                 //  also the three that ignore what they fetched: a load that lands in a register the compiler has given to
                 //  something else is the hazard tools/audit_vmcnt.py --copies looks for; the marker tells it they have landed)
-                if (q == NQ) asm volatile("s_waitcnt vmcnt(12) ; wfrag-landed" ::: "memory");
+                if (q == NQ && !W6_RESIDENT) asm volatile("s_waitcnt vmcnt(12) ; wfrag-landed" ::: "memory");
                 if (tap < NTAP) {   // wave-uniform (q < NQ: always)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // tap q's fragments
                     __builtin_amdgcn_sched_barrier(0);
@@ -369,6 +484,8 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
                         issue_piece(jb, 12);
                     }
                 }
+                FSTAMP(cb, 1 + q);
+            }
             }
             STAMP(2 + 2 * cb);
             ++g;
@@ -635,7 +752,7 @@ extern "C" int sc2_conv2_gdn48_fwd(const void *x, const void *w_frag, const void
     a.stamps = nullptr;
 #if SC2_ENC2_STAMPS
     const char *stamp_path = getenv("SC2_ENC2_STAMPS");
-    const size_t stamp_bytes = 8 * 4 * 16 * 12 * sizeof(unsigned long long);
+    const size_t stamp_bytes = 8 * 4 * 16 * N_STAMP * sizeof(unsigned long long);
     if (stamp_path) {
         void *sp = nullptr;
         (void)hipMalloc(&sp, stamp_bytes);

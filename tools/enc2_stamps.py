@@ -18,7 +18,24 @@ path = os.environ['SC2_ENC2_STAMPS']
 for _ in range(3):
     hip.conv2_gdn48_fwd(x, wp, gp, beta)
 torch.cuda.synchronize()
-st = np.fromfile(path, dtype=np.uint64).reshape(8, 4, 16, 12).astype(np.int64)   # [wg][wave][unit][stamp]
+raw = np.fromfile(path, dtype=np.uint64).astype(np.int64)
+if raw.size == 8 * 4 * 16 * 40:   # -DSC2_ENC2_STAMPS=2: slots 10 cb + t inside slab cb (t = 0: first fragments issued, 1 + q: behind tap q), phases in 30 .. 39
+    fine = raw.reshape(8, 4, 16, 40)
+    for wg in (0, 3):
+        for wave in range(4):
+            t = fine[wg, wave, 2:10]
+            for cb in range(3):
+                top = t[:, 30 + 1 + 2 * cb]
+                row = [(t[:, 10 * cb] - top).mean()] + [(t[:, 10 * cb + 1 + q] - t[:, 10 * cb + q]).mean() for q in range(7)]
+                if cb == 0 and t[:, 8].any():   # -DSC2_ENC2_STAMPS=3: the groups of tap 0 of one slab (slots 8, 9, 18, 19, 28, 29)
+                    gs = [8, 9, 18, 19, 28, 29]
+                    print('   groups of tap 0:', ' '.join('{:.0f}'.format((t[:, b] - t[:, a]).mean()) for a, b in zip(gs[:-1], gs[1:])))
+                print('wg', wg, 'wave', wave, 'slab', cb, 'first reads {:.0f} | taps '.format(row[0]) + ' '.join('{:.0f}'.format(v) for v in row[1:]),
+                      '| slab {:.0f}'.format((t[:, 30 + 2 + 2 * cb] - top).mean()))
+    st = fine[..., 30:]
+    st = np.concatenate([st, np.zeros(st.shape[:-1] + (2,), np.int64)], -1)
+else:
+    st = raw.reshape(8, 4, 16, 12)   # [wg][wave][unit][stamp]
 names = ['wait0+bar', 'slab0', 'wait1+bar', 'slab1', 'wait2+bar', 'slab2', 'reduce', 'gdn', 'store+bar', 'loop']
 for wg in (0, 3):
     for wave in range(4):
