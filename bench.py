@@ -661,8 +661,6 @@ def main():
                                                                                   out['precision_check']['images']),
                                'what': 'the same pipeline with set_encoder_precision("f32"): symbols / bitstreams of the f32 reference '
                                        'path (the residual mismatch is f32 summation order against torch CPU); decoder + head bf16'}
-        if world == 1 and not args.no_bs1:
-            out['bs1_eval'] = bs1_eval(model, x, dev)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(8, model.state_dict(), dev_symbols=sym8, hw=hw[0] * hw[1])
@@ -676,6 +674,8 @@ def main():
             # region, each on the package's stage pipeline (or the training step), a few steps each, compact rows in `secondary`
             del logits, nb, st, last
             out['secondary'] = secondary_lines(args, dev)
+        if world == 1 and not args.no_bs1:   # (behind the secondary rows: its graphs make streams of their own -- pipeline.pooled_stream)
+            out['bs1_eval'] = bs1_eval(model, x, dev)
         print(json.dumps(out))
         if failed:
             sys.stdout.flush()

@@ -62,6 +62,30 @@ def _like(v, parts):
     return tuple(parts) if isinstance(v, tuple) else parts[0]
 
 
+_STREAMS = {}
+
+
+def pooled_stream(device, role, index, priority=0):
+    """The HIP stream a pipeline of this process uses for (role, index, priority) on `device`: created at the first request, handed to
+    every StagePipeline that asks later.  The runtime binds streams to GPU_MAX_HW_QUEUES hardware queues in the order they are first USED,
+    and two streams on one queue wait for each other; with fresh streams per pipeline, which of a later pipeline's streams shared a queue
+    depended on how many streams the process had made before -- the mean-scale-hyperprior row measured behind the headline run read 35.3 k
+    images/s with three coder streams in the headline pipeline, 39.5 k with four, 30.2 k without the bs-1 graphs in between, and 39.6 k
+    in a process of its own (`tools/attic/r06_mshp_secondary_ab.sh`).  With the pool a later pipeline runs on the queues the first one
+    ran on and only adds what it needs beyond them (bench.py measures the bs-1 graphs, which make streams of their own, behind the
+    secondary rows for that reason: the detection row's fourth to sixth coder stream read 258 against 333 images/s behind them).
+    Binding the whole pool up front gave every row its stand-alone value too, and took 0.7 % off the headline pipeline (nine bound
+    streams + the null stream leave no free queue for anything else the process starts).  Pipelines that are alive at the same time
+    share these streams, i.e. their stages queue behind each other: still ordered, and not what one process is meant to do."""
+    device = torch.device(device)
+    dev_i = device.index if device.index is not None else torch.cuda.current_device()
+    key = (dev_i, role, int(index), int(priority))
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=device, priority=priority)
+    return st
+
+
 class StagePipeline(object):
     """Event-driven front / coder-group / back scheduler over any model with `stage_front / stage_coder / stage_back`.
 
@@ -85,10 +109,9 @@ class StagePipeline(object):
         self.max_inflight = max(1, int(max_inflight))
         self.ramp = bool(ramp)
         self.lag = min(max(0, int(lag)), self.max_inflight - 1)
-        self.front_stream = torch.cuda.Stream(device=self.device, priority=front_priority)
-        self.back_streams = [torch.cuda.Stream(device=self.device, priority=back_priority) for _ in range(max(1, back_streams))]
-        self.coder_streams = [torch.cuda.Stream(device=self.device, priority=coder_priority)
-                              for _ in range(max(1, min(int(coder_streams), 13)))]
+        self.front_stream = pooled_stream(self.device, 'front', 0, front_priority)
+        self.back_streams = [pooled_stream(self.device, 'back', i, back_priority) for i in range(max(1, back_streams))]
+        self.coder_streams = [pooled_stream(self.device, 'coder', i, coder_priority) for i in range(max(1, min(int(coder_streams), 13)))]
         self.coder_kwargs = dict(getattr(model, 'stage_coder_kwargs', {}) if coder_kwargs is None else coder_kwargs)
         self.share_buffer = bool(share_buffer) and bool(getattr(model, 'stage_front_takes_out', False))
         self._payload_shapes = {}     # input shape [C, H, W] -> (columns, dtype) of the single-tensor payload (learned per shape)
@@ -98,7 +121,7 @@ class StagePipeline(object):
         # host-to-device copies + dequantising launches (enqueued by the worker, later).  One, not two: the runtime maps streams
         # onto GPU_MAX_HW_QUEUES hardware queues, and two streams that share a queue wait for each other -- a back stage once sat
         # 20 ms behind a coder launch of another stream that way (profiles/r06j_timeline_alias.txt)
-        self.host_in = self.host_out = torch.cuda.Stream(device=self.device)
+        self.host_in = self.host_out = pooled_stream(self.device, 'host', 0, 0)
         self._host_staging = {}       # pinned buffers per slot (kept between runs)
         self._worker = None
         self.host_ramp_skip = True
