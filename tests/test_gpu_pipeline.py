@@ -205,3 +205,28 @@ def test_evaluate_with_host_coder_steps_under_inference_mode(S, dev, bench_mod):
     a = evaluation.evaluate(model, loader, dev, pipeline_kwargs={'coder_group': 2, 'coder_streams': 2, 'host_steps': 0})
     b = evaluation.evaluate(model, loader, dev, pipeline_kwargs={'coder_group': 2, 'coder_streams': 2, 'host_steps': 2})
     assert a['pipeline'].startswith('stage pipeline') and abs(a['acc1'] - b['acc1']) < 1e-9 and a['samples'] == b['samples'] == 22
+
+
+def test_pipelines_of_a_process_share_one_pool_of_streams(S, dev, bench_mod):
+    """pipeline.pooled_stream: a second StagePipeline of the process runs on the HIP streams the first one ran on (the runtime binds streams
+    to hardware queues in the order they are first used -- fresh streams per pipeline made the rows bench.py measures behind its headline run
+    depend on how many streams the process had made before), a wider one adds only what it needs beyond them, and two pipelines used one after the
+    other on the shared streams still produce the unpipelined forward's outputs."""
+    from sc2bench_amd.pipeline import pooled_stream
+    model = bench_mod.build_model(dev)
+    a = S.StagePipeline(model, dev, coder_group=2, coder_streams=2)
+    b = S.StagePipeline(model, dev, coder_group=4, coder_streams=3)
+    assert a.front_stream is b.front_stream and a.back_streams[0] is b.back_streams[0] and a.host_out is b.host_out
+    assert a.coder_streams[0] is b.coder_streams[0] and a.coder_streams[1] is b.coder_streams[1] and len(b.coder_streams) == 3
+    assert pooled_stream(dev, 'coder', 2) is b.coder_streams[2]
+    assert pooled_stream(dev, 'coder', 0, priority=-1) is not a.coder_streams[0]       # another priority is another stream
+    assert len({s.cuda_stream for s in [b.front_stream, b.host_out] + b.back_streams + b.coder_streams}) == 6
+    batches = [bench_mod.synthetic_batch(8, dev, seed=40 + s) for s in range(6)]
+    with torch.no_grad():
+        ref = [model(x) for x in batches]
+    for pipe in (a, b, a):
+        got = {}
+        pipe.run(list(batches), on_output=lambda step, out, nb, st: got.__setitem__(step, out))
+        pipe.synchronize()
+        for i in range(len(batches)):
+            _equal(got[i], ref[i], 'batch {}'.format(i))
