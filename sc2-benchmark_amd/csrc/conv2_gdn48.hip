@@ -7,9 +7,10 @@
 // weights never move again after the prologue:
 //   * a workgroup is 4 waves - one per SIMD, each with the whole 512-entry register file - one workgroup per CU,
 //     persistent; K is split over the waves BY (slab, tap): wave w owns taps ((w + cb) & 3) + 4q of channel slab cb -
-//     18 or 19 of the 75 k-steps - and keeps their fragments in REGISTERS (54 resident fragments = 216 VGPRs; the one
-//     wave per slab that has a seventh tap fetches that fragment per unit); no partner wave hides latency, so the
-//     fragments of the next tap are read between the MFMAs of the current one;
+//     18 or 19 of the 75 k-steps - and keeps their fragments in REGISTERS (54 resident fragments = 216 VGPRs, + the three of tap 24
+//     for the one slab in which this wave has a seventh tap: round 6, they were fetched per slab before); no partner wave hides
+//     latency, so the fragments of the next tap are read -- and the next slab's patch pieces issued -- between the MFMAs of the
+//     current one (round 6: inside its seven groups of three MFMAs, not between two taps);
 //   * a unit = two output rows of one image (112 pixels = exactly seven 16-row MFMA tiles x three channel tiles); its
 //     input patch (7 rows x 116 columns) is staged per 32-channel slab by direct-to-LDS loads into a double buffer,
 //     slab g + 1 in flight while slab g is multiplied (buffer descriptors: per-lane offsets are constants of the
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv2_gdn48_kernel(const Enc2Args p) {
     // Round 6: tap 24 is the seventh tap of exactly one (wave, slab) pair per wave -- slab (4 - wave) & 3; wave 1 has none -- so its three fragments
     // stay in registers too (the 12 the per-slab copy occupied anyway) instead of being fetched in every slab of every unit.  What that removes
     // is 9 loads per unit and the counted wait in front of the seventh tap: - 1.5 % on the launch (profiles/r06_enc2_taps.txt).
-    constexpr bool W6_RESIDENT = SC2_ENC2_W6 && !SEG;
+    constexpr bool W6_RESIDENT = SC2_ENC2_W6 != 0;   // (every instantiation: 475 registers in the SEG ones, 506 / 510 in the others)
     [[maybe_unused]] uint4 w6res[NT];
     if constexpr (W6_RESIDENT) {
         const int cb6 = (4 - wave) & 3;
