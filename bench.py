@@ -568,7 +568,7 @@ def main():
                                    'ahead, decoder+head stages wait for their coder launch',
                        'hip_streams': pipe.describe()['hip_streams'],
                        'steps_per_coder_launch': G, 'max_inflight_steps': args.max_inflight, 'coder_group_plan': pipe.group_plan(args.steps, pipe.resolve_host_steps(x))[:8],
-                       'host_coder_steps': {'steps': pipe.resolve_host_steps(x), 'host_cores': hip.host_cores(),
+                       'host_coder_steps': {'steps': pipe.resolve_host_steps(x), 'host_cores': hip.host_cores(), 'host_ms_per_batch_measured': pipe.__dict__.get('_host_ms', {}).get(int(x.shape[0])),
                                             'what': 'the first batches of the run are rANS-coded (encode + decode, the same bytes) by the library\'s host coder on the CPU cores while the device coder\'s first group is under way: sc2bench_amd/pipeline.py'}, 'warmup_steps_run': warm_steps,
                        'prealloc': 'none' if (args.no_prealloc or args.warmup == 0) else 'one untimed range-coder launch per coder group of the timed plan (device buffers only, not a step)',
                        'weights': 'random init seed 0, operating point shaped by bench.shape_workload (ragged tables, '

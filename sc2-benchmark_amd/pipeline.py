@@ -43,6 +43,8 @@ accepts `out=` (SplittableResNet on the FP bottleneck: the last encoder conv wri
 row block of the group's shared buffer to write into, so nothing is concatenated.  Batches of a group must agree in `meta`
 (the latent's spatial size); a change of shape closes the group early.
 """
+import time
+
 import torch
 
 __all__ = ['StagePipeline', 'supports_stages']
@@ -161,13 +163,27 @@ class StagePipeline(object):
             g *= 2
         return sizes
 
+    @staticmethod
+    def host_steps_from_measurement(host_ms_per_batch, device_first_ms=21.0, limit=4):
+        """The same question as auto_host_steps, answered with what warm() measured on THIS host at this moment (copy out + host coding +
+        copy back of one batch, one after the other on the worker): batch k leaves the host path after about (k + 1) x that, and is worth
+        taking while this is earlier than the device coder's first result.  A host whose cores are busy with something else, or slower than
+        the model assumes, takes fewer batches or none instead of holding the first back stages up."""
+        if not host_ms_per_batch or host_ms_per_batch <= 0:
+            return limit
+        # (warm() times copy out, coding and copy back END TO END; in the run the copies of batch k + 1 ride beside the coding of batch k --
+        #  6 - 8 ms measured on the boxes of round 6 where a batch leaves the worker every ~3.5 ms: 0.55 of the measurement)
+        return max(0, min(limit, int((device_first_ms - 2.5) // (0.55 * host_ms_per_batch))))
+
     def resolve_host_steps(self, x):
         if self.host_steps is not None:
             return int(self.host_steps)
         from . import hip
         if not hip.host_policy.pipeline_host_steps:
             return 0
-        return self.auto_host_steps(int(x.shape[0]))
+        n = self.auto_host_steps(int(x.shape[0]))
+        measured = self.__dict__.get('_host_ms', {}).get(int(x.shape[0]))
+        return min(n, self.host_steps_from_measurement(measured)) if measured else n
 
     def _host_job(self, payload, meta, slot, front_event, timeline, step):
         """worker thread: host coding of one batch; device work on `host_out`.  -> (decoded, nbytes, status, done event)"""
@@ -436,3 +452,10 @@ class StagePipeline(object):
                     pl = payload if g == 1 else _like(payload, [torch.cat([t] * g) for t in _as_tuple(payload)])
                     self.model.stage_coder(pl, meta, **self.coder_kwargs)
         self.synchronize()
+        if hs > 0 and self.host_steps is None:
+            # ... and how long THIS host takes for a batch right now, on a slot that has its buffers (host_steps_from_measurement)
+            t0 = time.perf_counter()
+            with torch.no_grad(), torch.cuda.stream(self.host_out):
+                self.model.stage_coder_host(payload, meta, staging=self._host_staging, slot=0)
+            self.host_out.synchronize()
+            self.__dict__.setdefault('_host_ms', {})[int(x.shape[0])] = 1e3 * (time.perf_counter() - t0)

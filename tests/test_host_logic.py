@@ -228,3 +228,17 @@ def test_mse_sink_entries_belong_to_one_backward_pass(S):
     # pass 3 on the retained graph: again exactly one
     loss.backward()
     assert applied == [1, 1] and torch.equal(x.grad, torch.full((3,), 4.0))
+
+
+def test_host_steps_follow_the_measured_host_speed():
+    """StagePipeline.host_steps_from_measurement: the number of leading batches given to the host coder is bounded by what warm() measured
+    on this host -- a batch leaves the host path after about (k + 1) x the measured time, and is worth taking only while that is earlier
+    than the device coder's first result (~21 ms)."""
+    from sc2bench_amd.pipeline import StagePipeline as P
+    assert P.host_steps_from_measurement(None) == 4 and P.host_steps_from_measurement(0.0) == 4      # nothing measured: the model's answer stands
+    assert P.host_steps_from_measurement(6.2) == 4 and P.host_steps_from_measurement(8.0) == 4      # the boxes of the round: 6 - 8 ms end to end
+    assert P.host_steps_from_measurement(10.0) == 3
+    assert P.host_steps_from_measurement(14.0) == 2
+    assert P.host_steps_from_measurement(20.0) == 1
+    assert P.host_steps_from_measurement(40.0) == 0       # a host that busy takes none
+    assert P.host_steps_from_measurement(6.2, limit=2) == 2
