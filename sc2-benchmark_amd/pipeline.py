@@ -441,6 +441,19 @@ class StagePipeline(object):
                 payload, meta = self.model.stage_front(x)
             self.front_stream.synchronize()
             hs = self.resolve_host_steps(x)
+            if self.share_buffer and isinstance(payload, torch.Tensor) and payload.dim() == 2:
+                # the shared row blocks of the groups that are in flight at once are allocated on the FRONT stream in a run (the caching
+                # allocator keeps freed blocks per stream: the coder-stream launches below do not warm them): the first timed region of a
+                # process made 2 - 6 hipMalloc calls of 0.6 GB otherwise (torch.cuda.memory_stats, `segment.all.allocated` around the region;
+                # none with this -- and no measurable difference in images/s: `tools/attic/r06_warm_blocks_ab.sh`, 5 alternating runs)
+                self._payload_shapes[tuple(x.shape[1:])] = (payload.shape[1], payload.dtype)
+                sizes = [g for li, g in enumerate(self.group_plan(n_steps, hs)) if li >= hs and g > 1]
+                live = sorted(sizes, reverse=True)[:self.max_inflight // max(1, self.G) + 1]
+                with torch.cuda.stream(self.front_stream):
+                    blocks = [torch.empty((g * payload.shape[0], payload.shape[1]), dtype=payload.dtype, device=payload.device) for g in live]
+                    self.model.stage_front(x)      # (... and, while they are held, a front stage's own intermediates: as in the run)
+                self.front_stream.synchronize()
+                del blocks
             for li, g in enumerate(self.group_plan(n_steps, hs)):
                 if li < hs:
                     # the host path's resources: pinned staging of this slot, the worker thread, the host tables
